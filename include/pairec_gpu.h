@@ -1,0 +1,182 @@
+/*
+ * pairec_gpu.h — C ABI of libpairec_gpu.so, the MI355X (gfx950) engine behind pairec's
+ * rank + recall hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one network hop of the reference
+ * (alibaba/pairec, Go).  A cgo shim implements algorithm.IAlgorithm,
+ * recall.Recall and sort.ISort on top of these calls.  Signatures use plain pointers and sizes;
+ * no C++ or torch types cross the boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pg_status on failure; pg_last_error()
+ *     returns a thread-local message.  Nothing throws or aborts across the ABI (the reference's
+ *     rank goroutines have no recover(), service/rank/rank_service.go:265-288).
+ *   - all entry points are re-entrant: the reference calls IAlgorithm.Run concurrently from one
+ *     goroutine per batch × per algo (rank_service.go:264-289).  Calls on one pg_ctx are serialised
+ *     on that context's HIP stream.
+ *   - "_dev" variants take device pointers (HBM-resident inputs/outputs, used to chain stages and
+ *     by bench.py); the plain variants take host pointers (what the cgo shim passes) and copy.
+ *   - row ids are uint32 table row indices (+ a uint64 per-table row_offset for sharded tables);
+ *     item-id strings stay on the host side (module.ItemId is a string, module/item.go:13).
+ */
+#ifndef PAIREC_GPU_H
+#define PAIREC_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pg_ctx pg_ctx;
+typedef struct pg_table pg_table;      /* HBM-resident embedding table  (module.VectorDao backend) */
+typedef struct pg_model pg_model;      /* rank model weights            (algorithm/eas model)      */
+typedef struct pg_expr pg_expr;        /* compiled RankScore expression (utils/ast)                */
+
+typedef enum {
+    PG_OK = 0,
+    PG_ERR_INVALID = -1,     /* bad argument */
+    PG_ERR_DEVICE = -2,      /* HIP runtime error (message carries hipGetErrorString) */
+    PG_ERR_NOMEM = -3,
+    PG_ERR_UNSUPPORTED = -4, /* shape outside what the kernels are built for */
+    PG_ERR_ARITH = -5,       /* expression: division by zero / modulo by zero (reference panics) */
+    PG_ERR_PARSE = -6        /* expression: lexer "symbol error" (utils/ast/parse.go:125-133) */
+} pg_status;
+
+typedef enum { PG_PREC_F32 = 0, PG_PREC_BF16 = 1 } pg_prec;
+typedef enum { PG_MODEL_DNN3 = 1, PG_MODEL_FM_TWOTOWER = 2 } pg_model_kind;
+
+const char* pg_last_error(void);
+const char* pg_version(void);
+
+/* ---- context --------------------------------------------------------------------------------
+ * One context = one GPU + one HIP stream.  `stream` may be an existing hipStream_t (e.g. the
+ * stream torch.distributed's collectives are ordered on) or NULL to create a private one. */
+int pg_init(int device, void* stream, pg_ctx** out);
+int pg_shutdown(pg_ctx* ctx);
+int pg_synchronize(pg_ctx* ctx);
+int pg_device_malloc(pg_ctx* ctx, size_t bytes, void** out);
+int pg_device_free(pg_ctx* ctx, void* p);
+int pg_memcpy_h2d(pg_ctx* ctx, void* dst, const void* src, size_t bytes);
+int pg_memcpy_d2h(pg_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* ---- embedding tables -----------------------------------------------------------------------
+ * Replaces module.VectorDao.VectorString (module/vector_dao.go:13-15) and its six remote
+ * back-ends: rows live in HBM as row-major fp32 [rows][dim].  dim must be a multiple of 64. */
+int pg_table_create(pg_ctx* ctx, uint64_t rows, uint32_t dim, uint64_t row_offset, pg_table** out);
+int pg_table_destroy(pg_ctx* ctx, pg_table* t);
+/* deterministic synthetic fill: global row = row_offset + local row */
+int pg_table_fill_synthetic(pg_ctx* ctx, pg_table* t, uint64_t seed, int normalize);
+int pg_table_upload(pg_ctx* ctx, pg_table* t, uint64_t row0, uint64_t nrows, const float* host_rows);
+int pg_table_download(pg_ctx* ctx, const pg_table* t, uint64_t row0, uint64_t nrows, float* host_rows);
+/* atomically exchange the contents of two tables of equal shape (the analogue of the Hologres
+ * partition hot-swap, module/vector_hologres_dao.go:40-61) */
+int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b);
+int pg_table_info(const pg_table* t, uint64_t* rows, uint32_t* dim, uint64_t* row_offset);
+/* embedding lookup by row (the VectorString analogue): out[n][dim] fp32 */
+int pg_table_gather(pg_ctx* ctx, const pg_table* t, const uint32_t* rows, uint32_t n, float* out);
+
+/* ---- recall: exact inner-product top-K ------------------------------------------------------
+ * Replaces FaissModel.Run → VectorClient.Search (algorithm/faiss/model.go:29-31,
+ * vector_client.go:32-41; VectorRequest{k, vector} → VectorReply{retval, scores},
+ * vectorretrieval.proto:11-20) and the Hologres pm_approx_inner_product_distance ORDER BY desc
+ * LIMIT n query (service/recall/hologres_vector_recall.go:23).
+ *   score(row) = chain_k fmaf(x[row][k], q[k], acc)  (k ascending, fp32) — independent of nq.
+ *   order: score descending (IEEE totalOrder, NaN last), then row ascending.
+ * queries: [nq][dim] fp32, nq <= 32 per call.  out_rows: [nq][k] global row ids (row_offset +
+ * local), out_scores: [nq][k].  If the table has fewer than k rows the tail is filled with
+ * row = UINT64_MAX, score = -inf and *out_count (optional) receives the valid count. */
+int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_t nq, uint32_t k,
+                   uint64_t* out_rows, float* out_scores, uint32_t* out_count);
+int pg_recall_topk_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq,
+                       uint32_t k, uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count);
+/* merge `nlists` sorted/unsorted (row,score) lists of `per_list` entries per query into the global
+ * top-k (multi-GPU: the lists are the all-gathered per-shard results).  Layout [nq][nlists][per_list]. */
+int pg_topk_merge_dev(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq,
+                      uint32_t nlists, uint32_t per_list, uint32_t k, uint64_t* d_out_rows,
+                      float* d_out_scores);
+
+/* ---- rank: model predict --------------------------------------------------------------------
+ * Replaces EasModel.Run / TFservingModel.Run (algorithm/eas/model.go:197-222,
+ * algorithm/tfserving/model.go:30-55): the DNN / FM forward that the reference ships to a
+ * remote PAI-EAS / TF-Serving process, one call per batch of BatchCount=100 items
+ * (service/rank/rank_service.go:163-166).  Here one call scores any number of requests.
+ *
+ * PG_MODEL_DNN3 blob (little-endian fp32 unless noted):
+ *   u32 d_user, d_item, h1, h2;  w1[(d_user+d_item)][h1]; b1[h1]; w2[h1][h2]; b2[h2]; w3[h2]; b3
+ *   score = sigmoid( w3 · relu( W2ᵀ relu( W1ᵀ [user ‖ item_row] + b1 ) + b2 ) + b3 )
+ * PG_MODEL_FM_TWOTOWER blob:
+ *   u32 n_user_fields, n_item_fields, k, d_user, t_h1, t_out, vocab; f32 fm_b;
+ *   uw1[d_user][t_h1]; ub1; uw2[t_h1][t_out]; ub2; iw1[nif*k][t_h1]; ib1; iw2[t_h1][t_out]; ib2;
+ *   then per field f (user fields first): emb_f[vocab][k], lin_f[vocab]
+ *   score = sigmoid( y_fm + <user_tower(user), item_tower(concat item field embeddings)> )
+ * Summation orders are specified in DESIGN.md §5 (they are what makes PG_PREC_F32 bit-reproducible).
+ */
+int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blob, size_t len,
+                  pg_model** out);
+int pg_model_destroy(pg_ctx* ctx, pg_model* m);
+
+/* DNN3: R requests; request r has user vector user_vecs[r][d_user] and candidates
+ * cand_rows[req_offsets[r] .. req_offsets[r+1]) (local row indices into `t`).  out_scores is fp32
+ * per candidate, request order preserved (response.AlgoResponse order contract,
+ * rank_service.go:312-335). */
+int pg_rank_dnn3(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float* user_vecs,
+                 const uint32_t* cand_rows, const uint32_t* req_offsets, uint32_t n_req,
+                 float* out_scores);
+int pg_rank_dnn3_dev(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float* d_user_vecs,
+                     const uint32_t* d_cand_rows, const uint32_t* d_req_offsets, uint32_t n_req,
+                     uint32_t n_items, float* d_out_scores);
+/* FM + two-tower: user_field_ids [n_req][n_user_fields], item_field_ids [n_items][n_item_fields] */
+int pg_rank_fm2t(pg_ctx* ctx, const pg_model* m, const float* user_vecs,
+                 const int32_t* user_field_ids, const int32_t* item_field_ids,
+                 const uint32_t* req_offsets, uint32_t n_req, float* out_scores);
+int pg_rank_fm2t_dev(pg_ctx* ctx, const pg_model* m, const float* d_user_vecs,
+                     const int32_t* d_user_field_ids, const int32_t* d_item_field_ids,
+                     const uint32_t* d_req_offsets, uint32_t n_req, uint32_t n_items,
+                     float* d_out_scores);
+
+/* ---- rank: score fusion (RankConfig.RankScore) ----------------------------------------------
+ * Replaces ast.GetExpAST + ExprASTResult (utils/ast/ast.go:215-268,368-389): compile once,
+ * evaluate per item in fp64 on the device.  Variables are bound by position: pg_expr_var_name(i)
+ * names column i of `vars` ([n_vars][n_items] fp64, column-major per variable). */
+int pg_expr_compile(const char* source, pg_expr** out);
+int pg_expr_free(pg_expr* e);
+int pg_expr_num_vars(const pg_expr* e);
+const char* pg_expr_var_name(const pg_expr* e, int i);
+int pg_expr_eval(pg_ctx* ctx, const pg_expr* e, const double* vars, uint32_t n_items,
+                 double* out_scores);
+int pg_expr_eval_dev(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items,
+                     double* d_out_scores);
+
+/* ---- sort -----------------------------------------------------------------------------------
+ * Replaces ItemRankScoreSort (descending, sort/item_rank_score.go:26-32) and ItemScoreSort
+ * (ascending, sort/item_score.go:36-41): out_order[i] = index of the i-th item.  Segmented:
+ * seg_offsets[n_seg+1] delimits independent requests.  Ties keep input order; NaN last. */
+int pg_sort_scores(pg_ctx* ctx, const double* scores, const uint32_t* seg_offsets, uint32_t n_seg,
+                   int descending, uint32_t* out_order);
+int pg_sort_scores_dev(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg_offsets,
+                       uint32_t n_seg, uint32_t n_items, int descending, uint32_t* d_out_order);
+
+/* ---- DPP diversity re-rank ------------------------------------------------------------------
+ * Replaces DPPSort.KernelMatrix + DPPWithWindow (sort/dpp_sort.go:372-551).  Candidates are rows
+ * of `t` (embeddings are L2-normalised in fp64 when normalize_emb != 0), rel = relevance scores
+ * (Item.Score).  out_idx receives min(topn, n) indices into the candidate list. */
+int pg_dpp(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const double* rel, uint32_t n,
+           double alpha, uint32_t topn, uint32_t window, int normalize_emb, uint32_t* out_idx,
+           uint32_t* out_count);
+
+/* ---- stats ----------------------------------------------------------------------------------*/
+typedef struct {
+    uint64_t recall_calls, recall_rows_scanned, recall_rescans;
+    uint64_t rank_calls, rank_items;
+    uint64_t sort_calls, sort_items;
+    double   last_recall_ms, last_rank_ms, last_sort_ms;   /* hipEvent-timed, device side */
+} pg_stats_t;
+int pg_stats(pg_ctx* ctx, pg_stats_t* out);
+/* time (ms) of the dominant kernel of the last pg_recall_* call, measured with HIP events on the
+ * context's stream around the scan launches only (bench.py's roofline figure) */
+int pg_last_scan_kernel_ms(pg_ctx* ctx, double* out_ms, uint64_t* out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAIREC_GPU_H */

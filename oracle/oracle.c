@@ -1,0 +1,494 @@
+/*
+ * oracle.c — CPU restatement of pairec's rank+recall hot path.  TEST INFRASTRUCTURE ONLY
+ * (see oracle.h for who may load this and for the parity status of each stage).
+ *
+ * Every numeric stage below fixes a *summation order* so that the HIP kernels can be compared
+ * bit-for-bit where the arithmetic allows it:
+ *   chain(c; a_k*b_k, k asc)  :=  acc=c; for k: acc = fmaf(a_k, b_k, acc)      (one rounding/step)
+ * which is exactly what gfx950's f32-input MFMA computes (k-ordered fmaf chain).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp).
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* synthetic data: SURVEY.md §8(d).  u = splitmix64(seed ^ (row*D + col));                      */
+/* value = (u>>40) * 2^-24 * 2 - 1  (uniform fp32 in [-1,1)); rows L2-normalised in fp32.       */
+/* ------------------------------------------------------------------------------------------ */
+uint64_t orc_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+float orc_synth_value(uint64_t seed, uint64_t row, uint32_t col, uint32_t dim) {
+    uint64_t u = orc_splitmix64(seed ^ (row * (uint64_t)dim + col));
+    /* (u>>40) < 2^24 is exact in fp32; *2^-23 exact; -1 exact (result is a multiple of 2^-23) */
+    return (float)(u >> 40) * (1.0f / 8388608.0f) - 1.0f;
+}
+
+void orc_synth_rows(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, int normalize,
+                    float* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < (int64_t)nrows; ++r) {
+        float* o = out + (size_t)r * dim;
+        float ss = 0.0f;
+        for (uint32_t c = 0; c < dim; ++c) {
+            float v = orc_synth_value(seed, row0 + (uint64_t)r, c, dim);
+            o[c] = v;
+            ss = fmaf(v, v, ss);                 /* chain over c asc */
+        }
+        if (normalize) {
+            float inv = 1.0f / sqrtf(ss);        /* IEEE sqrt then IEEE divide */
+            for (uint32_t c = 0; c < dim; ++c) o[c] = o[c] * inv;
+        }
+    }
+}
+
+void orc_synth_uniform(uint64_t seed, uint64_t n, float scale, float* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t u = orc_splitmix64(seed ^ i);
+        out[i] = ((float)(u >> 40) * (1.0f / 8388608.0f) - 1.0f) * scale;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* recall: score = <row, query> (inner product, descending — hologres_vector_recall.go:23),     */
+/* fp32 query/table/score (vectorretrieval.proto:11-20), widened to f64 by the caller           */
+/* (vector_recall.go:98).  Order: IEEE-754 totalOrder on the score, then row ascending.         */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint32_t f32_ordered_bits(float f) {
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    if (f != f) return 0u;                       /* NaN sorts below everything */
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+uint64_t orc_topk_key(float score, uint32_t row) {
+    return ((uint64_t)f32_ordered_bits(score) << 32) | (uint64_t)(0xFFFFFFFFu - row);
+}
+
+void orc_dot_scores(const float* table, uint64_t nrows, uint32_t dim, const float* queries,
+                    uint32_t nq, float* out, int threads) {
+    /* transpose queries to [dim][nq] so the q loop vectorises; each (row,q) is still its own
+     * k-ascending fmaf chain. */
+    float* qt = (float*)malloc((size_t)dim * nq * sizeof(float));
+    for (uint32_t q = 0; q < nq; ++q)
+        for (uint32_t k = 0; k < dim; ++k) qt[(size_t)k * nq + q] = queries[(size_t)q * dim + k];
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+    {
+        float* acc = (float*)malloc(nq * sizeof(float));
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < (int64_t)nrows; ++r) {
+            const float* x = table + (size_t)r * dim;
+            for (uint32_t q = 0; q < nq; ++q) acc[q] = 0.0f;
+            for (uint32_t k = 0; k < dim; ++k) {
+                const float xv = x[k];
+                const float* qk = qt + (size_t)k * nq;
+                for (uint32_t q = 0; q < nq; ++q) acc[q] = fmaf(xv, qk[q], acc[q]);
+            }
+            for (uint32_t q = 0; q < nq; ++q) out[(size_t)q * nrows + r] = acc[q];
+        }
+        free(acc);
+    }
+    free(qt);
+}
+
+static int cmp_key_desc(const void* a, const void* b) {
+    uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return (x < y) - (x > y);
+}
+
+/* min-heap of keys, size k */
+static void heap_sift_down(uint64_t* h, uint32_t n, uint32_t i) {
+    for (;;) {
+        uint32_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && h[l] < h[m]) m = l;
+        if (r < n && h[r] < h[m]) m = r;
+        if (m == i) return;
+        uint64_t t = h[i]; h[i] = h[m]; h[m] = t;
+        i = m;
+    }
+}
+
+static void emit_sorted(uint64_t* keys, uint32_t n, uint64_t row_offset, uint64_t* out_rows,
+                        float* out_scores, const float* score_of_local /* may be NULL */) {
+    (void)score_of_local;
+    qsort(keys, n, sizeof(uint64_t), cmp_key_desc);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t ob = (uint32_t)(keys[i] >> 32);
+        uint32_t row = 0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFu);
+        uint32_t b = (ob & 0x80000000u) ? (ob & 0x7FFFFFFFu) : ~ob;
+        float s;
+        memcpy(&s, &b, 4);
+        if (ob == 0u) s = NAN;
+        out_rows[i] = row_offset + row;
+        out_scores[i] = s;
+    }
+}
+
+uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint64_t row_offset,
+                         const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
+                         float* out_scores, int threads) {
+    uint32_t kk = (nrows < k) ? (uint32_t)nrows : k;
+    if (kk == 0) return 0;
+    /* scan in row blocks so the score matrix stays small */
+    const uint64_t BLK = 1u << 16;
+    uint64_t* heaps = (uint64_t*)malloc((size_t)nq * kk * sizeof(uint64_t));
+    uint32_t* hn = (uint32_t*)calloc(nq, sizeof(uint32_t));
+    float* sc = (float*)malloc((size_t)nq * BLK * sizeof(float));
+    for (uint64_t r0 = 0; r0 < nrows; r0 += BLK) {
+        uint64_t nb = (nrows - r0 < BLK) ? nrows - r0 : BLK;
+        orc_dot_scores(table + (size_t)r0 * dim, nb, dim, queries, nq, sc, threads);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int32_t q = 0; q < (int32_t)nq; ++q) {
+            uint64_t* h = heaps + (size_t)q * kk;
+            uint32_t n = hn[q];
+            const float* s = sc + (size_t)q * nb;
+            for (uint64_t r = 0; r < nb; ++r) {
+                uint64_t key = orc_topk_key(s[r], (uint32_t)(r0 + r));
+                if (n < kk) {
+                    h[n++] = key;
+                    if (n == kk)
+                        for (int32_t i = (int32_t)kk / 2 - 1; i >= 0; --i) heap_sift_down(h, kk, (uint32_t)i);
+                } else if (key > h[0]) {
+                    h[0] = key;
+                    heap_sift_down(h, kk, 0);
+                }
+            }
+            hn[q] = n;
+        }
+    }
+    for (uint32_t q = 0; q < nq; ++q)
+        emit_sorted(heaps + (size_t)q * kk, kk, row_offset, out_rows + (size_t)q * k,
+                    out_scores + (size_t)q * k, NULL);
+    free(sc); free(hn); free(heaps);
+    return kk;
+}
+
+uint32_t orc_topk_merge(const uint64_t* rows, const float* scores, uint32_t nlists,
+                        uint32_t per_list, uint32_t k, uint64_t* out_rows, float* out_scores) {
+    uint32_t n = nlists * per_list;
+    uint64_t* keys = (uint64_t*)malloc((size_t)n * sizeof(uint64_t));
+    for (uint32_t i = 0; i < n; ++i) keys[i] = orc_topk_key(scores[i], (uint32_t)rows[i]);
+    qsort(keys, n, sizeof(uint64_t), cmp_key_desc);
+    uint32_t kk = n < k ? n : k;
+    emit_sorted(keys, kk, 0, out_rows, out_scores, NULL);
+    free(keys);
+    return kk;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* bf16 helpers: round-to-nearest-even from fp32 (integer formula; NaN stays NaN)              */
+/* ------------------------------------------------------------------------------------------ */
+uint16_t orc_f32_to_bf16(float x) {
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((b >> 16) | 0x0040u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
+float orc_bf16_to_f32(uint16_t x) {
+    uint32_t b = (uint32_t)x << 16;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+static inline float rbf(float x) { return orc_bf16_to_f32(orc_f32_to_bf16(x)); }
+static inline float op_round(float x, int prec) { return prec ? rbf(x) : x; }
+
+static inline float sigmoidf_spec(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* generic fused 2-layer MLP + dot head (the shape of both the DNN3 rank model and the item   */
+/* tower of the two-tower model):                                                              */
+/*   z1_j = chain(c1_j; x_k * W1[k][j], k asc)         h1 = P(relu(z1))                        */
+/*   z2_m = chain(b2_m; h1_j * W2[j][m], j asc)        h2 = act2 ? relu(z2) : z2  (fp32, kept) */
+/*   z3   = chain(bias3; h2_m*w3_m, m < H2/2) + chain(0; h2_m*w3_m, m >= H2/2)                 */
+/*   out  = 1/(1+expf(-z3))                                                                    */
+/* P() = bf16 rounding in prec 1 (operands x, W1, W2 are then bf16-rounded too), identity in   */
+/* prec 0.  In prec 1 the device accumulates z1/z2 in fp32 inside the bf16 MFMA in an          */
+/* unspecified order, so prec 1 is compared with a tolerance; prec 0 is bit-defined.           */
+/* ------------------------------------------------------------------------------------------ */
+static void mlp2_dot_row(int prec, uint32_t din, uint32_t h1n, uint32_t h2n, const float* x,
+                         const float* c1, const float* w1 /* [din][h1n], pre-rounded */,
+                         const float* w2 /* [h1n][h2n], pre-rounded */, const float* b2, int act2,
+                         const float* w3, float bias3, float* h1buf, float* h2buf, float* out) {
+    for (uint32_t j = 0; j < h1n; ++j) h1buf[j] = c1[j];
+    for (uint32_t k = 0; k < din; ++k) {
+        const float xv = op_round(x[k], prec);
+        const float* wr = w1 + (size_t)k * h1n;
+        for (uint32_t j = 0; j < h1n; ++j) h1buf[j] = fmaf(xv, wr[j], h1buf[j]);
+    }
+    for (uint32_t j = 0; j < h1n; ++j) h1buf[j] = op_round(h1buf[j] > 0.0f ? h1buf[j] : 0.0f, prec);
+    for (uint32_t m = 0; m < h2n; ++m) h2buf[m] = b2[m];
+    for (uint32_t j = 0; j < h1n; ++j) {
+        const float hv = h1buf[j];
+        const float* wr = w2 + (size_t)j * h2n;
+        for (uint32_t m = 0; m < h2n; ++m) h2buf[m] = fmaf(hv, wr[m], h2buf[m]);
+    }
+    if (act2)
+        for (uint32_t m = 0; m < h2n; ++m) h2buf[m] = h2buf[m] > 0.0f ? h2buf[m] : 0.0f;
+    float p0 = bias3, p1 = 0.0f;
+    const uint32_t half = h2n / 2;
+    for (uint32_t m = 0; m < half; ++m) p0 = fmaf(h2buf[m], w3[m], p0);
+    for (uint32_t m = half; m < h2n; ++m) p1 = fmaf(h2buf[m], w3[m], p1);
+    *out = sigmoidf_spec(p0 + p1);
+}
+
+static float* round_copy(const float* w, size_t n, int prec) {
+    float* o = (float*)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) o[i] = op_round(w[i], prec);
+    return o;
+}
+
+/* DNN3 (cfg 3): input = [user_vec ‖ item_row]; the user half of layer 1 is request-constant:   */
+/*   c1_j = chain(b1_j; P(u_k) * P(W1[k][j]), k asc over the user half)                         */
+/* and the item half continues the same chain (k asc), so z1 is one 256-long k-ordered chain.   */
+void orc_dnn3_forward(const orc_dnn3* m, int prec, const float* user_vec, const float* item_rows,
+                      uint64_t n, float* out_scores, int threads) {
+    const uint32_t du = m->d_user, di = m->d_item, h1 = m->h1, h2 = m->h2;
+    float* w1 = round_copy(m->w1, (size_t)(du + di) * h1, prec);
+    float* w2 = round_copy(m->w2, (size_t)h1 * h2, prec);
+    float* c1 = (float*)malloc(h1 * sizeof(float));
+    for (uint32_t j = 0; j < h1; ++j) c1[j] = m->b1[j];
+    for (uint32_t k = 0; k < du; ++k) {
+        const float uv = op_round(user_vec[k], prec);
+        for (uint32_t j = 0; j < h1; ++j) c1[j] = fmaf(uv, w1[(size_t)k * h1 + j], c1[j]);
+    }
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+    {
+        float* hb1 = (float*)malloc(h1 * sizeof(float));
+        float* hb2 = (float*)malloc(h2 * sizeof(float));
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < (int64_t)n; ++i)
+            mlp2_dot_row(prec, di, h1, h2, item_rows + (size_t)i * di, c1, w1 + (size_t)du * h1, w2,
+                         m->b2, 1, m->w3, m->b3, hb1, hb2, out_scores + i);
+        free(hb1); free(hb2);
+    }
+    free(c1); free(w2); free(w1);
+}
+
+/* FM + two-tower (cfg 4), SURVEY.md §8(d):                                                     */
+/*   y_fm = b + Σ_f lin_f[id_f] + ½ Σ_k [ (Σ_f v_fk)² − Σ_f v_fk² ]   over 8 user + 8 item      */
+/*   fields (user fields first), all fp32:                                                      */
+/*     lin: sequential adds, fields in order;  s_k: sequential adds;  q_k = chain(0; v*v);      */
+/*     t_k = fmaf(s_k, s_k, -q_k);  cross = balanced pairwise tree over k (xor 1,2,4,8);        */
+/*     y_fm = lin + 0.5f*cross.                                                                 */
+/*   user tower: u1 = P(relu(chain(ub1; P(u)*P(uw1)))), uo = chain(ub2; u1*P(uw2))  (no act)    */
+/*   item tower: x = concat_f v_f (item fields), same shape via mlp2 (act2 = 0),                */
+/*   score = σ( y_fm + <uo, io> )  with the dot split in two half-chains (see mlp2_dot_row).    */
+void orc_fm2t_forward(const orc_fm2t* m, int prec, const float* const* field_emb,
+                      const float* const* field_lin, const float* user_vec,
+                      const int32_t* user_field_ids, const int32_t* item_field_ids, uint64_t n,
+                      float* out_scores, int threads) {
+    const uint32_t nuf = m->n_user_fields, nif = m->n_item_fields, K = m->k;
+    const uint32_t du = m->d_user, th = m->t_h1, to = m->t_out, din = nif * K;
+    /* user tower */
+    float* uw1 = round_copy(m->uw1, (size_t)du * th, prec);
+    float* uw2 = round_copy(m->uw2, (size_t)th * to, prec);
+    float* iw1 = round_copy(m->iw1, (size_t)din * th, prec);
+    float* iw2 = round_copy(m->iw2, (size_t)th * to, prec);
+    float* u1 = (float*)malloc(th * sizeof(float));
+    float* uo = (float*)malloc(to * sizeof(float));
+    for (uint32_t j = 0; j < th; ++j) u1[j] = m->ub1[j];
+    for (uint32_t k = 0; k < du; ++k) {
+        const float uv = op_round(user_vec[k], prec);
+        for (uint32_t j = 0; j < th; ++j) u1[j] = fmaf(uv, uw1[(size_t)k * th + j], u1[j]);
+    }
+    for (uint32_t j = 0; j < th; ++j) u1[j] = op_round(u1[j] > 0.0f ? u1[j] : 0.0f, prec);
+    for (uint32_t o = 0; o < to; ++o) uo[o] = m->ub2[o];
+    for (uint32_t j = 0; j < th; ++j)
+        for (uint32_t o = 0; o < to; ++o) uo[o] = fmaf(u1[j], uw2[(size_t)j * to + o], uo[o]);
+    /* user prefix of the FM sums */
+    float linU = m->fm_b;
+    float* sU = (float*)calloc(K, sizeof(float));
+    float* qU = (float*)calloc(K, sizeof(float));
+    for (uint32_t f = 0; f < nuf; ++f) {
+        const int32_t id = user_field_ids[f];
+        linU = linU + field_lin[f][id];
+        const float* v = field_emb[f] + (size_t)id * K;
+        for (uint32_t k = 0; k < K; ++k) { sU[k] = sU[k] + v[k]; qU[k] = fmaf(v[k], v[k], qU[k]); }
+    }
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+    {
+        float* x = (float*)malloc(din * sizeof(float));
+        float* hb1 = (float*)malloc(th * sizeof(float));
+        float* hb2 = (float*)malloc(to * sizeof(float));
+        float* s = (float*)malloc(K * sizeof(float));
+        float* q = (float*)malloc(K * sizeof(float));
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < (int64_t)n; ++i) {
+            float lin = linU;
+            for (uint32_t k = 0; k < K; ++k) { s[k] = sU[k]; q[k] = qU[k]; }
+            for (uint32_t f = 0; f < nif; ++f) {
+                const int32_t id = item_field_ids[(size_t)i * nif + f];
+                lin = lin + field_lin[nuf + f][id];
+                const float* v = field_emb[nuf + f] + (size_t)id * K;
+                for (uint32_t k = 0; k < K; ++k) {
+                    s[k] = s[k] + v[k];
+                    q[k] = fmaf(v[k], v[k], q[k]);
+                    x[f * K + k] = v[k];
+                }
+            }
+            for (uint32_t k = 0; k < K; ++k) s[k] = fmaf(s[k], s[k], -q[k]);
+            for (uint32_t off = 1; off < K; off <<= 1)           /* butterfly: all lanes equal */
+                for (uint32_t k = 0; k < K; k += 2 * off) s[k] = s[k] + s[k + off];
+            const float yfm = lin + 0.5f * s[0];
+            mlp2_dot_row(prec, din, th, to, x, m->ib1, iw1, iw2, m->ib2, 0, uo, yfm, hb1, hb2,
+                         out_scores + i);
+        }
+        free(q); free(s); free(hb2); free(hb1); free(x);
+    }
+    free(qU); free(sU); free(uo); free(u1); free(iw2); free(iw1); free(uw2); free(uw1);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* sorts: sort/item_score.go:15-18 (Less = a.Score < b.Score), ItemScoreSort ascending (:36-41) */
+/* ItemRankScoreSort = sort.Reverse → descending (item_rank_score.go:26-32).  Go's sort.Sort is */
+/* unstable, so the reference leaves tie order undefined; this restatement fixes it to input    */
+/* index ascending, and NaN last.                                                               */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { double s; uint32_t i; } sort_ent;
+static int g_sort_desc;
+static int cmp_sort_ent(const void* a, const void* b) {
+    const sort_ent* x = (const sort_ent*)a; const sort_ent* y = (const sort_ent*)b;
+    const int xn = x->s != x->s, yn = y->s != y->s;
+    if (xn || yn) { if (xn != yn) return xn - yn; return (x->i > y->i) - (x->i < y->i); }
+    if (x->s < y->s) return g_sort_desc ? 1 : -1;
+    if (x->s > y->s) return g_sort_desc ? -1 : 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+void orc_sort_scores(const double* scores, uint32_t n, int desc, uint32_t* out_order) {
+    sort_ent* e = (sort_ent*)malloc((size_t)n * sizeof(sort_ent));
+    for (uint32_t i = 0; i < n; ++i) { e[i].s = scores[i]; e[i].i = i; }
+    g_sort_desc = desc;
+    qsort(e, n, sizeof(sort_ent), cmp_sort_ent);
+    for (uint32_t i = 0; i < n; ++i) out_order[i] = e[i].i;
+    free(e);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* DPP: sort/dpp_sort.go:372-551.                                                              */
+/*   f_i = [e_i, 1] * (1/√2)                       (:428-430; e_i already L2-normalised)        */
+/*   S   = F·Fᵀ                                    (:463-464)  — gonum Dgemm order is unknown   */
+/*         here (un-vendored gonum v0.12.0): this restatement uses chain(0; f_ik*f_jk, k asc).  */
+/*   L   = (r_i * S_ij) * r_j,  r = exp(alpha*rel) (:466-472; the two dense-diagonal Mul calls  */
+/*         reduce to exactly these two roundings in that association).                          */
+/*   greedy MAP with windows (:477-551), fp64, NaN-masked argmax (first max wins), ss summed    */
+/*   sequentially over earlier picks with separate multiply and add.                            */
+/* ------------------------------------------------------------------------------------------ */
+void orc_l2_normalize_f64(double* v, uint32_t d) {
+    /* floats.Norm(v,2) then floats.Scale(1/norm, v)  (dpp_sort.go:235-236) */
+    double ss = 0.0;
+    for (uint32_t k = 0; k < d; ++k) ss = fma(v[k], v[k], ss);
+    const double inv = 1.0 / sqrt(ss);
+    for (uint32_t k = 0; k < d; ++k) v[k] = inv * v[k];
+}
+
+void orc_dpp_kernel_matrix(const double* emb, uint32_t n, uint32_t d, const double* rel,
+                           double alpha, double* L) {
+    const double isq2 = 0.70710678118654757;      /* Go constant 1/math.Sqrt2, rounded to f64 */
+    double* F = (double*)malloc((size_t)n * (d + 1) * sizeof(double));
+    double* r = (double*)malloc((size_t)n * sizeof(double));
+    for (uint32_t i = 0; i < n; ++i) {
+        for (uint32_t k = 0; k < d; ++k) F[(size_t)i * (d + 1) + k] = isq2 * emb[(size_t)i * d + k];
+        F[(size_t)i * (d + 1) + d] = isq2 * 1.0;
+        r[i] = exp(alpha * rel[i]);
+    }
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < (int32_t)n; ++i)
+        for (uint32_t j = 0; j < n; ++j) {
+            double s = 0.0;
+            const double* a = F + (size_t)i * (d + 1);
+            const double* b = F + (size_t)j * (d + 1);
+            for (uint32_t k = 0; k <= d; ++k) s = fma(a[k], b[k], s);
+            L[(size_t)i * n + j] = (r[i] * s) * r[j];
+        }
+    free(r); free(F);
+}
+
+static int idx_in(const uint32_t* a, uint32_t n, uint32_t e) {
+    for (uint32_t i = 0; i < n; ++i) if (a[i] == e) return 1;
+    return 0;
+}
+static uint32_t max_idx_nan_skip(const double* v, uint32_t n) {   /* gonum floats.MaxIdx */
+    double mx = NAN; uint32_t ind = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (v[i] != v[i]) continue;
+        if (v[i] > mx || mx != mx) { mx = v[i]; ind = i; }
+    }
+    return ind;
+}
+
+static uint32_t dpp_once(const double* L, uint32_t N, uint32_t topn, const uint32_t* existed,
+                         uint32_t n_existed, uint32_t* Y) {
+    const double epsilon = 1e-10;
+    if (topn > N) topn = N;
+    if (topn == 0) return 0;
+    double* d2 = (double*)malloc((size_t)N * sizeof(double));
+    double* c = (double*)calloc((size_t)topn * N, sizeof(double));
+    double* e = (double*)malloc((size_t)N * sizeof(double));
+    uint32_t ny = 0;
+    for (uint32_t i = 0; i < N; ++i) d2[i] = idx_in(existed, n_existed, i) ? NAN : L[(size_t)i * N + i];
+    uint32_t j = max_idx_nan_skip(d2, N);
+    Y[ny++] = j;
+    while (ny < topn) {
+        double dj = d2[j];
+        if (dj < epsilon) break;
+        dj = sqrt(dj);
+        const uint32_t k = ny - 1;
+        const double inv = 1.0 / dj;
+        for (uint32_t n = 0; n < N; ++n) {
+            double lj = L[(size_t)j * N + n];
+            if (k > 0) {
+                double ss = 0.0;
+                for (uint32_t i = 0; i < k; ++i) {
+                    volatile double p = c[(size_t)i * N + j] * c[(size_t)i * N + n];  /* no FMA */
+                    ss = ss + p;
+                }
+                lj = lj - ss;
+            }
+            e[n] = inv * lj;
+        }
+        for (uint32_t n = 0; n < N; ++n) {
+            c[(size_t)k * N + n] = e[n];
+            volatile double e2 = e[n] * e[n];
+            d2[n] = d2[n] - e2;
+        }
+        d2[j] = NAN;
+        j = max_idx_nan_skip(d2, N);
+        Y[ny++] = j;
+    }
+    if (ny < topn)
+        for (uint32_t i = 0; i < N && ny < topn; ++i)
+            if (!idx_in(existed, n_existed, i) && !idx_in(Y, ny, i)) Y[ny++] = i;
+    free(e); free(c); free(d2);
+    return ny;
+}
+
+uint32_t orc_dpp_with_window(const double* L, uint32_t n, uint32_t topn, uint32_t window,
+                             uint32_t* out_idx) {
+    /* DPPWithWindow, dpp_sort.go:477-491 */
+    if (topn <= window) return dpp_once(L, n, topn, NULL, 0, out_idx);
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < topn / window; ++i) cnt += dpp_once(L, n, window, out_idx, cnt, out_idx + cnt);
+    if (topn % window) cnt += dpp_once(L, n, topn % window, out_idx, cnt, out_idx + cnt);
+    return cnt;
+}

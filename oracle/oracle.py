@@ -1,0 +1,637 @@
+"""ctypes front-end for the CPU oracle (oracle/oracle.c) + pure-Python restatements of the
+host-side pieces of pairec's rank+recall path.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under pairec_amd/ imports this module.
+
+Parity status: expression fusion / sort order / decoder widening are pinned by the reference's own
+known-answer tests (tests/golden/reference_known_answers.json); top-K, DNN/FM predict and DPP are
+**parity unpinned** (no reference-side golden data exists).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+            os.path.join(_HERE, "oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u64, u32, i32, f32p = C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_float)
+        L.orc_splitmix64.restype = u64
+        L.orc_splitmix64.argtypes = [u64]
+        L.orc_synth_value.restype = C.c_float
+        L.orc_synth_value.argtypes = [u64, u64, u32, u32]
+        L.orc_synth_rows.argtypes = [u64, u64, u64, u32, i32, f32p]
+        L.orc_synth_uniform.argtypes = [u64, u64, C.c_float, f32p]
+        L.orc_topk_key.restype = u64
+        L.orc_topk_key.argtypes = [C.c_float, u32]
+        L.orc_dot_scores.argtypes = [f32p, u64, u32, f32p, u32, f32p, i32]
+        L.orc_recall_topk.restype = u32
+        L.orc_recall_topk.argtypes = [f32p, u64, u32, u64, f32p, u32, u32, C.POINTER(u64), f32p, i32]
+        L.orc_topk_merge.restype = u32
+        L.orc_topk_merge.argtypes = [C.POINTER(u64), f32p, u32, u32, u32, C.POINTER(u64), f32p]
+        L.orc_dnn3_forward.argtypes = [C.c_void_p, i32, f32p, f32p, u64, f32p, i32]
+        L.orc_fm2t_forward.argtypes = [C.c_void_p, i32, C.c_void_p, C.c_void_p, f32p,
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64, f32p, i32]
+        L.orc_f32_to_bf16.restype = C.c_uint16
+        L.orc_f32_to_bf16.argtypes = [C.c_float]
+        L.orc_bf16_to_f32.restype = C.c_float
+        L.orc_bf16_to_f32.argtypes = [C.c_uint16]
+        L.orc_sort_scores.argtypes = [C.POINTER(C.c_double), u32, i32, C.POINTER(u32)]
+        L.orc_dpp_kernel_matrix.argtypes = [C.POINTER(C.c_double), u32, u32, C.POINTER(C.c_double),
+                                            C.c_double, C.POINTER(C.c_double)]
+        L.orc_dpp_with_window.restype = u32
+        L.orc_dpp_with_window.argtypes = [C.POINTER(C.c_double), u32, u32, u32, C.POINTER(u32)]
+        L.orc_l2_normalize_f64.argtypes = [C.POINTER(C.c_double), u32]
+        _lib = L
+    return _lib
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic data
+# ---------------------------------------------------------------------------------------------
+SEED_TABLE, SEED_QUERY, SEED_WEIGHTS, SEED_FIELDS, SEED_CANDS = (
+    0x5EED0001, 0x5EED0002, 0x5EED0003, 0x5EED0004, 0x5EED0005)
+
+
+def synth_rows(seed: int, row0: int, nrows: int, dim: int, normalize: bool = True) -> np.ndarray:
+    out = np.empty((nrows, dim), dtype=np.float32)
+    lib().orc_synth_rows(seed, row0, nrows, dim, int(normalize), _f32p(out))
+    return out
+
+
+def synth_uniform(seed: int, n: int, scale: float = 1.0) -> np.ndarray:
+    out = np.empty(n, dtype=np.float32)
+    lib().orc_synth_uniform(seed, n, scale, _f32p(out))
+    return out
+
+
+def splitmix64(x: int) -> int:
+    return int(lib().orc_splitmix64(x & 0xFFFFFFFFFFFFFFFF))
+
+
+# ---------------------------------------------------------------------------------------------
+# recall
+# ---------------------------------------------------------------------------------------------
+def dot_scores(table: np.ndarray, queries: np.ndarray, threads: int = 0) -> np.ndarray:
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    queries = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, table.shape[1])
+    out = np.empty((queries.shape[0], table.shape[0]), dtype=np.float32)
+    lib().orc_dot_scores(_f32p(table), table.shape[0], table.shape[1], _f32p(queries),
+                         queries.shape[0], _f32p(out), threads)
+    return out
+
+
+def recall_topk(table: np.ndarray, queries: np.ndarray, k: int, row_offset: int = 0,
+                threads: int = 0):
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    queries = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, table.shape[1])
+    nq = queries.shape[0]
+    rows = np.zeros((nq, k), dtype=np.uint64)
+    scores = np.zeros((nq, k), dtype=np.float32)
+    n = lib().orc_recall_topk(_f32p(table), table.shape[0], table.shape[1], row_offset,
+                              _f32p(queries), nq, k, rows.ctypes.data_as(C.POINTER(C.c_uint64)),
+                              _f32p(scores), threads)
+    return rows[:, :n], scores[:, :n]
+
+
+def topk_merge(rows: np.ndarray, scores: np.ndarray, k: int):
+    """rows/scores: [nlists, per_list] → global top-k (score desc, row asc)."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    orow = np.zeros(k, dtype=np.uint64)
+    osc = np.zeros(k, dtype=np.float32)
+    n = lib().orc_topk_merge(rows.ctypes.data_as(C.POINTER(C.c_uint64)), _f32p(scores),
+                             rows.shape[0], rows.shape[1], k,
+                             orow.ctypes.data_as(C.POINTER(C.c_uint64)), _f32p(osc))
+    return orow[:n], osc[:n]
+
+
+def topk_key(score: float, row: int) -> int:
+    return int(lib().orc_topk_key(score, row))
+
+
+# ---------------------------------------------------------------------------------------------
+# rank models
+# ---------------------------------------------------------------------------------------------
+class _Dnn3(C.Structure):
+    _fields_ = [("d_user", C.c_uint32), ("d_item", C.c_uint32), ("h1", C.c_uint32),
+                ("h2", C.c_uint32), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
+                ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_float)]
+
+
+class Dnn3Weights:
+    """3-layer MLP [user‖item] -> h1 (ReLU) -> h2 (ReLU) -> 1 (sigmoid).  cfg 3: 256->512->256->1."""
+
+    def __init__(self, d_user=128, d_item=128, h1=512, h2=256, seed=SEED_WEIGHTS):
+        self.d_user, self.d_item, self.h1, self.h2 = d_user, d_item, h1, h2
+        din = d_user + d_item
+        # uniform ±1/sqrt(fan_in); independent streams per tensor
+        self.w1 = synth_uniform(seed ^ 0x101, din * h1, 1.0 / math.sqrt(din)).reshape(din, h1)
+        self.b1 = synth_uniform(seed ^ 0x102, h1, 1.0 / math.sqrt(din))
+        self.w2 = synth_uniform(seed ^ 0x103, h1 * h2, 1.0 / math.sqrt(h1)).reshape(h1, h2)
+        self.b2 = synth_uniform(seed ^ 0x104, h2, 1.0 / math.sqrt(h1))
+        self.w3 = synth_uniform(seed ^ 0x105, h2, 1.0 / math.sqrt(h2))
+        self.b3 = float(synth_uniform(seed ^ 0x106, 1, 1.0 / math.sqrt(h2))[0])
+
+    def _struct(self):
+        s = _Dnn3(self.d_user, self.d_item, self.h1, self.h2, self.w1.ctypes.data,
+                  self.b1.ctypes.data, self.w2.ctypes.data, self.b2.ctypes.data,
+                  self.w3.ctypes.data, self.b3)
+        return s
+
+
+def dnn3_forward(w: Dnn3Weights, prec: int, user_vec: np.ndarray, item_rows: np.ndarray,
+                 threads: int = 0) -> np.ndarray:
+    item_rows = np.ascontiguousarray(item_rows, dtype=np.float32)
+    user_vec = np.ascontiguousarray(user_vec, dtype=np.float32)
+    out = np.empty(item_rows.shape[0], dtype=np.float32)
+    s = w._struct()
+    lib().orc_dnn3_forward(C.byref(s), prec, _f32p(user_vec), _f32p(item_rows),
+                           item_rows.shape[0], _f32p(out), threads)
+    return out
+
+
+class _Fm2t(C.Structure):
+    _fields_ = [("n_user_fields", C.c_uint32), ("n_item_fields", C.c_uint32), ("k", C.c_uint32),
+                ("d_user", C.c_uint32), ("t_h1", C.c_uint32), ("t_out", C.c_uint32),
+                ("fm_w", C.c_void_p), ("fm_b", C.c_float),
+                ("uw1", C.c_void_p), ("ub1", C.c_void_p), ("uw2", C.c_void_p), ("ub2", C.c_void_p),
+                ("iw1", C.c_void_p), ("ib1", C.c_void_p), ("iw2", C.c_void_p), ("ib2", C.c_void_p)]
+
+
+class Fm2tWeights:
+    """FM (16 fields × k=16) + two-tower (128->256->64 each side), SURVEY.md §8(d) cfg 4."""
+
+    def __init__(self, n_user_fields=8, n_item_fields=8, k=16, d_user=128, t_h1=256, t_out=64,
+                 vocab=1_000_000, seed=SEED_WEIGHTS, field_seed=SEED_FIELDS):
+        self.nuf, self.nif, self.k = n_user_fields, n_item_fields, k
+        self.d_user, self.t_h1, self.t_out, self.vocab = d_user, t_h1, t_out, vocab
+        din = n_item_fields * k
+        self.fm_b = float(synth_uniform(seed ^ 0x200, 1, 0.1)[0])
+        self.uw1 = synth_uniform(seed ^ 0x201, d_user * t_h1, 1 / math.sqrt(d_user)).reshape(d_user, t_h1)
+        self.ub1 = synth_uniform(seed ^ 0x202, t_h1, 1 / math.sqrt(d_user))
+        self.uw2 = synth_uniform(seed ^ 0x203, t_h1 * t_out, 1 / math.sqrt(t_h1)).reshape(t_h1, t_out)
+        self.ub2 = synth_uniform(seed ^ 0x204, t_out, 1 / math.sqrt(t_h1))
+        self.iw1 = synth_uniform(seed ^ 0x205, din * t_h1, 1 / math.sqrt(din)).reshape(din, t_h1)
+        self.ib1 = synth_uniform(seed ^ 0x206, t_h1, 1 / math.sqrt(din))
+        self.iw2 = synth_uniform(seed ^ 0x207, t_h1 * t_out, 1 / math.sqrt(t_h1)).reshape(t_h1, t_out)
+        self.ib2 = synth_uniform(seed ^ 0x208, t_out, 1 / math.sqrt(t_h1))
+        nf = n_user_fields + n_item_fields
+        # field embedding tables: unnormalised uniform ±0.25; linear tables ±0.1
+        self.field_emb = [synth_rows(field_seed + 16 * f, 0, vocab, k, normalize=False) * np.float32(0.25)
+                          for f in range(nf)]
+        self.field_lin = [synth_uniform((field_seed + 16 * f) ^ 0xABCD, vocab, 0.1) for f in range(nf)]
+
+    def _struct(self):
+        return _Fm2t(self.nuf, self.nif, self.k, self.d_user, self.t_h1, self.t_out, None, self.fm_b,
+                     self.uw1.ctypes.data, self.ub1.ctypes.data, self.uw2.ctypes.data,
+                     self.ub2.ctypes.data, self.iw1.ctypes.data, self.ib1.ctypes.data,
+                     self.iw2.ctypes.data, self.ib2.ctypes.data)
+
+
+def fm2t_forward(w: Fm2tWeights, prec: int, user_vec, user_field_ids, item_field_ids,
+                 threads: int = 0) -> np.ndarray:
+    user_vec = np.ascontiguousarray(user_vec, dtype=np.float32)
+    uf = np.ascontiguousarray(user_field_ids, dtype=np.int32)
+    itf = np.ascontiguousarray(item_field_ids, dtype=np.int32).reshape(-1, w.nif)
+    nf = w.nuf + w.nif
+    emb_ptrs = (C.c_void_p * nf)(*[a.ctypes.data for a in w.field_emb])
+    lin_ptrs = (C.c_void_p * nf)(*[a.ctypes.data for a in w.field_lin])
+    out = np.empty(itf.shape[0], dtype=np.float32)
+    s = w._struct()
+    lib().orc_fm2t_forward(C.byref(s), prec, emb_ptrs, lin_ptrs, _f32p(user_vec),
+                           uf.ctypes.data_as(C.POINTER(C.c_int32)),
+                           itf.ctypes.data_as(C.POINTER(C.c_int32)), itf.shape[0], _f32p(out),
+                           threads)
+    return out
+
+
+def f32_to_bf16_round(a: np.ndarray) -> np.ndarray:
+    """RNE bf16 rounding, returned as fp32 (vectorised twin of orc_f32_to_bf16)."""
+    b = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    nan = (b & 0x7FFFFFFF) > 0x7F800000
+    r = ((b + 0x7FFF + ((b >> 16) & 1)) >> 16) << 16
+    r = np.where(nan, ((b >> 16) | 0x40) << 16, r)
+    return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+# ---------------------------------------------------------------------------------------------
+# sorts  (sort/item_score.go:15-18, :36-41; sort/item_rank_score.go:26-32)
+# ---------------------------------------------------------------------------------------------
+def sort_scores(scores: Sequence[float], desc: bool) -> np.ndarray:
+    s = np.ascontiguousarray(scores, dtype=np.float64)
+    out = np.empty(s.shape[0], dtype=np.uint32)
+    if s.shape[0]:
+        lib().orc_sort_scores(_f64p(s), s.shape[0], int(desc), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# DPP  (sort/dpp_sort.go:372-551)
+# ---------------------------------------------------------------------------------------------
+def l2_normalize_f64(v: np.ndarray) -> np.ndarray:
+    v = np.array(v, dtype=np.float64, copy=True)
+    for row in v.reshape(-1, v.shape[-1]):
+        lib().orc_l2_normalize_f64(_f64p(row), row.shape[0])
+    return v
+
+
+def dpp_kernel_matrix(emb: np.ndarray, rel: np.ndarray, alpha: float) -> np.ndarray:
+    emb = np.ascontiguousarray(emb, dtype=np.float64)
+    rel = np.ascontiguousarray(rel, dtype=np.float64)
+    n, d = emb.shape
+    L = np.empty((n, n), dtype=np.float64)
+    lib().orc_dpp_kernel_matrix(_f64p(emb), n, d, _f64p(rel), alpha, _f64p(L))
+    return L
+
+
+def dpp_with_window(L: np.ndarray, topn: int, window: int) -> np.ndarray:
+    L = np.ascontiguousarray(L, dtype=np.float64)
+    out = np.zeros(max(topn, 1), dtype=np.uint32)
+    n = lib().orc_dpp_with_window(_f64p(L), L.shape[0], topn, window,
+                                  out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out[:n]
+
+
+# ---------------------------------------------------------------------------------------------
+# score-fusion expression language  (utils/ast/parse.go:57-158, utils/ast/ast.go:81-268)
+# ---------------------------------------------------------------------------------------------
+LITERAL, OPERATOR, PARAMETER = 0, 1, 2
+_PRECEDENCE = {"+": 20, "-": 20, "*": 40, "/": 40, "%": 40, "^": 60, "#": 80}   # ast.go:81
+
+
+class ExprError(Exception):
+    pass
+
+
+def expr_tokenize(src: str):
+    """Lexer restating parse.go:40-158: operators `# ( ) + - * / ^ %`; literals start with a digit
+    and extend over [0-9._e] (underscores stripped); `${name}` parameters; any other character is
+    a "symbol error".  Quirks kept: a `$` not followed by `{` silently ends lexing; trailing
+    whitespace is fine only if the last whitespace character is a plain space (the reference
+    re-examines its stale `ch` after running off the end, parse.go:66-72,125-133)."""
+    if src == "":
+        raise ExprError("empty source")      # the reference indexes s[0] (parse.go:176)
+    toks = []
+    n = len(src)
+    off = 0
+    ws = " \t\n\v\f\r"
+    while off < n:
+        last_ws = None
+        while off < n and src[off] in ws:
+            last_ws = src[off]
+            off += 1
+        if off >= n:
+            if last_ws is not None and last_ws != " ":
+                raise ExprError("symbol error: unknown %r" % (last_ws,))
+            break
+        ch = src[off]
+        start = off
+        if ch in "#()+-*/^%":
+            toks.append((ch, OPERATOR, start))
+            off += 1
+        elif "0" <= ch <= "9":
+            while off < n and ("0" <= src[off] <= "9" or src[off] in "._e"):
+                off += 1
+            toks.append((src[start:off].replace("_", ""), LITERAL, start))
+        elif ch == "$":
+            off += 1
+            if off < n and src[off] == "{":
+                while off < n and src[off] != "}":
+                    off += 1
+                toks.append((src[start + 2:off], PARAMETER, start + 2))
+                off += 1
+            else:
+                break
+        else:
+            raise ExprError("symbol error: unknown %r, pos [%d:]" % (ch, start))
+    return toks
+
+
+def _go_parse_float(tok: str) -> Optional[float]:
+    """strconv.ParseFloat(tok, 64) over the literal alphabet [0-9.e]; None where Go returns an
+    error (syntax error, or ErrRange for overflow to ±Inf)."""
+    import re
+    if not re.fullmatch(r"(\d+\.?\d*)(e\d+)?", tok):
+        return None
+    v = float(tok)
+    if math.isinf(v):
+        return None
+    return v
+
+
+class _Parser:
+    """Precedence-climbing parser restating ast.go:84-197, including its error quirks: a malformed
+    literal (or an operator in primary position, e.g. unary minus) yields Number(0) *without
+    consuming the token* and records Err, which GetExpAST ignores (ast.go:368-389) — so "-5"
+    evaluates as 0-5 and "2*1e-5" as 2*0.  After the last token is consumed `currTok` stays on it
+    (getNextToken returns nil without moving currTok, ast.go:90-97)."""
+
+    def __init__(self, toks):
+        if not toks:
+            raise ExprError("empty token")
+        self.toks = toks
+        self.i = 0
+        self.err = None
+
+    def cur(self):
+        return self.toks[min(self.i, len(self.toks) - 1)]
+
+    def next(self):
+        self.i = min(self.i + 1, len(self.toks))
+        return self.toks[self.i] if self.i < len(self.toks) else None
+
+    def prec(self):
+        return _PRECEDENCE.get(self.cur()[0], -1)    # keyed on the token text only (ast.go:100-105)
+
+    def parse_number(self):
+        t = self.cur()
+        v = _go_parse_float(t[0])
+        if v is None:
+            self.err = "want '(' or '0-9' but get %r" % (t[0],)
+            return ("num", 0.0)
+        self.next()
+        return ("num", v)
+
+    def parse_primary(self):
+        t = self.cur()
+        if t[1] == LITERAL:
+            return self.parse_number()
+        if t[1] == PARAMETER:
+            self.next()
+            return ("param", t[0])
+        if t[0] == "(":
+            self.next()
+            e = self.parse_expression()
+            if e is None:
+                return None
+            if self.cur()[0] != ")":
+                self.err = "want ')' but get %s" % (self.cur()[0],)
+                return None
+            self.next()
+            return e
+        return self.parse_number()
+
+    def parse_expression(self):
+        return self.parse_binop_rhs(0, self.parse_primary())
+
+    def parse_binop_rhs(self, exec_prec, lhs):
+        while True:
+            tp = self.prec()
+            if tp < exec_prec:
+                return lhs
+            op = self.cur()[0]
+            if self.next() is None:
+                return lhs
+            rhs = self.parse_primary()
+            if rhs is None:
+                return None
+            if tp < self.prec():
+                rhs = self.parse_binop_rhs(tp + 1, rhs)
+                if rhs is None:
+                    return None
+            lhs = ("bin", op, lhs, rhs)
+
+
+def expr_parse(src: str):
+    """GetExpAST (ast.go:368-389): '' → None; otherwise the (possibly truncated) AST."""
+    if src == "":
+        return None
+    return _Parser(expr_tokenize(src)).parse_expression()
+
+
+def _go_int(x: float) -> int:
+    # Go float64→int truncates toward zero; out-of-range/NaN is implementation-defined
+    # (amd64 CVTTSD2SQ yields MinInt64)
+    if x != x or abs(x) >= 2.0 ** 63:
+        return -(2 ** 63)
+    return int(x)
+
+
+def expr_eval(ast, lookup) -> float:
+    """ExprASTResult (ast.go:215-268).  lookup(name) → float or None (not found → 0.0).
+    Raises ExprError on division by zero / integer modulo by zero (the reference panics)."""
+    if ast is None:
+        return 0.0
+    kind = ast[0]
+    if kind == "num":
+        return ast[1]
+    if kind == "param":
+        v = lookup(ast[1])
+        return 0.0 if v is None else float(v)
+    _, op, lhs, rhs = ast
+    l = expr_eval(lhs, lookup)
+    r = expr_eval(rhs, lookup)
+    if op == "#":
+        return l if l != 0.0 else r
+    if op == "^":
+        return go_pow(l, r)
+    if op == "+":
+        return l + r
+    if op == "-":
+        return l - r
+    if op == "*":
+        return l * r
+    if op == "/":
+        if r == 0:
+            raise ExprError("division by zero [%g/%g]" % (l, r))
+        return l / r
+    if op == "%":
+        li, ri = _go_int(l), _go_int(r)
+        if ri == 0:
+            raise ExprError("integer divide by zero")
+        m = abs(li) % abs(ri)                  # Go's % truncates toward zero
+        return float(-m if li < 0 else m)
+    return 0.0
+
+
+def go_pow(x: float, y: float) -> float:
+    """math.Pow special cases (Go stdlib `math/pow.go`, go 1.24 per reference go.mod:3) mapped onto
+    C pow().  Values agree with Go to within 1 ulp (Go's Pow is not correctly rounded and uses a
+    platform-specific Exp on amd64), so fused scores are compared with rel 1e-14."""
+    try:
+        return math.pow(x, y)
+    except OverflowError:
+        return math.inf if (x > 0 or float(y).is_integer() and int(y) % 2 == 0) else -math.inf
+    except ValueError:
+        if x == 0 and y < 0:
+            return math.copysign(math.inf, x) if float(y).is_integer() and int(y) % 2 == 1 else math.inf
+        return math.nan
+
+
+class OracleItem:
+    """module.Item restated (module/item.go:15-27,168-212): only what the hot path touches."""
+
+    def __init__(self, item_id: str, score: float = 0.0, retrieve_id: str = ""):
+        self.id = item_id
+        self.score = float(score)
+        self.retrieve_id = retrieve_id
+        self.item_type = ""
+        self.properties: Dict[str, object] = {}
+        self.algo_scores: Dict[str, float] = {}
+        self.recall_scores: Optional[Dict[str, float]] = None
+
+    def add_algo_score(self, name, score):
+        self.algo_scores[name] = float(score)
+
+    def add_property(self, name, v):
+        self.properties[name] = v
+
+    def float_expr_data(self, name):
+        """Item.FloatExprData (module/item.go:189-212)."""
+        if name == "current_score":
+            self.algo_scores["recall_score"] = self.score
+            return self.score
+        if name in self.algo_scores:
+            return self.algo_scores[name]
+        if name in self.properties:
+            return to_float(self.properties[name], 0.0)
+        return None
+
+
+def to_float(v, default: float) -> float:
+    """utils.ToFloat (utils/type.go:43-69)."""
+    if isinstance(v, bool):
+        return default
+    if isinstance(v, (int, float, np.integer, np.floating)):
+        return float(v)
+    if isinstance(v, str):
+        try:
+            return float(v)
+        except ValueError:
+            return default
+    return default
+
+
+def fuse_scores(expr: str, items: List[OracleItem], ctx_params: Optional[Dict[str, float]] = None):
+    """rank_service.go:339-363: item.Score = ExprASTResult(ast, AstParameterData{ctx,item});
+    AB params win when non-zero (service/rank/ast_parameter_data.go:30-40)."""
+    ast = expr_parse(expr)
+    if ast is None:
+        return
+    ctx_params = ctx_params or {}
+    for it in items:
+        def lookup(name, it=it):
+            v = ctx_params.get(name, 0.0)
+            if v != 0:
+                return v
+            return it.float_expr_data(name)
+        it.score = expr_eval(ast, lookup)
+
+
+# ---------------------------------------------------------------------------------------------
+# dedup (filter/unique_filter.go:26-49) and response decoders
+# ---------------------------------------------------------------------------------------------
+def unique_filter(items: List[OracleItem]) -> List[OracleItem]:
+    out, seen = [], {}
+    for it in items:
+        ex = seen.get(it.id)
+        if ex is None:
+            seen[it.id] = it
+            out.append(it)
+        else:
+            for n, s in it.algo_scores.items():
+                ex.add_algo_score(n, s)
+            if ex.recall_scores is None:
+                ex.recall_scores = {ex.retrieve_id: ex.score}
+            ex.recall_scores[it.retrieve_id] = it.score
+    return out
+
+
+def alink_fm_score(prediction_result: float, prediction_score: float) -> float:
+    """alinkFMResponse.GetScore (algorithm/eas/fm_response.go:28-34): label 0 → 1 − score."""
+    return 1 - prediction_score if prediction_result == 0.0 else prediction_score
+
+
+def widen_f32(scores_f32: np.ndarray) -> np.ndarray:
+    """float32 model outputs widened to float64 AlgoResponse scores
+    (algorithm/eas/easyrec_response.go:479-483, tfserving/response.go:51-64)."""
+    return np.asarray(scores_f32, dtype=np.float32).astype(np.float64)
+
+
+def parse_vector_string(s: str) -> np.ndarray:
+    """vector_recall.go:70-82: split ' ', keep "i:v" pairs, ParseFloat(v, 32)."""
+    out = []
+    for vc in s.split(" "):
+        if ":" not in vc:
+            continue
+        vals = vc.split(":")
+        if len(vals) == 2:
+            try:
+                out.append(np.float32(float(vals[1])))
+            except ValueError:
+                out.append(np.float32(0.0))       # `value, _ :=` ignores the error → 0
+    return np.asarray(out, dtype=np.float32)
+
+
+def recall_cache_string(items: List[OracleItem], recall_name: str) -> str:
+    """vector_recall.go:105-110: "id:name:score,..." with Go %v float formatting (shortest repr)."""
+    return ",".join("%s:%s:%s" % (it.id, recall_name, go_fmt_float(it.score)) for it in items)
+
+
+def go_fmt_float(x: float) -> str:
+    """fmt %v for float64 = strconv 'g' with shortest repr, exponent for exp < -4 || exp >= 21."""
+    if x != x:
+        return "NaN"
+    if math.isinf(x):
+        return "+Inf" if x > 0 else "-Inf"
+    if x == 0:
+        return "-0" if math.copysign(1, x) < 0 else "0"
+    r = repr(float(x))
+    m, _, e = r.partition("e")
+    if e:
+        exp = int(e)
+    else:
+        exp = None
+    # derive decimal exponent
+    digits = m.replace("-", "").replace(".", "").lstrip("0") or "0"
+    if exp is None:
+        ip = m.lstrip("-").split(".")[0]
+        if ip.strip("0") == "":
+            frac = m.split(".")[1] if "." in m else ""
+            dexp = -(len(frac) - len(frac.lstrip("0"))) - 1
+        else:
+            dexp = len(ip.lstrip("0")) - 1
+    else:
+        ip = m.lstrip("-").split(".")[0]
+        dexp = exp + (len(ip) - 1)
+    digits = digits.rstrip("0") or "0"
+    sign = "-" if x < 0 else ""
+    if dexp < -4 or dexp >= 21:
+        mant = digits[0] + ("." + digits[1:] if len(digits) > 1 else "")
+        return "%s%se%s%02d" % (sign, mant, "+" if dexp >= 0 else "-", abs(dexp))
+    if dexp >= 0:
+        if len(digits) <= dexp + 1:
+            return sign + digits + "0" * (dexp + 1 - len(digits))
+        return sign + digits[:dexp + 1] + "." + digits[dexp + 1:]
+    return sign + "0." + "0" * (-dexp - 1) + digits

@@ -1,0 +1,106 @@
+"""ctypes binding of libpairec_gpu.so (include/pairec_gpu.h).
+
+The library is the product: there is no CPU fallback.  Importing this module without the built
+extension, or calling it without a gfx950 GPU, fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpairec_gpu.so")
+
+# every symbol include/pairec_gpu.h declares (tests/test_abi.py checks the two stay in sync)
+EXPORTS = [
+    "pg_last_error", "pg_version", "pg_init", "pg_shutdown", "pg_synchronize", "pg_device_malloc",
+    "pg_device_free", "pg_memcpy_h2d", "pg_memcpy_d2h", "pg_table_create", "pg_table_destroy",
+    "pg_table_fill_synthetic", "pg_table_upload", "pg_table_download", "pg_table_swap",
+    "pg_table_info", "pg_table_gather", "pg_recall_topk", "pg_recall_topk_dev",
+    "pg_topk_merge_dev", "pg_model_load", "pg_model_destroy", "pg_rank_dnn3", "pg_rank_dnn3_dev",
+    "pg_rank_fm2t", "pg_rank_fm2t_dev", "pg_expr_compile", "pg_expr_free", "pg_expr_num_vars",
+    "pg_expr_var_name", "pg_expr_eval", "pg_expr_eval_dev", "pg_sort_scores", "pg_sort_scores_dev",
+    "pg_dpp", "pg_stats", "pg_last_scan_kernel_ms",
+]
+
+
+class PgStats(C.Structure):
+    _fields_ = [("recall_calls", C.c_uint64), ("recall_rows_scanned", C.c_uint64),
+                ("recall_rescans", C.c_uint64), ("rank_calls", C.c_uint64),
+                ("rank_items", C.c_uint64), ("sort_calls", C.c_uint64), ("sort_items", C.c_uint64),
+                ("last_recall_ms", C.c_double), ("last_rank_ms", C.c_double),
+                ("last_sort_ms", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load libpairec_gpu.so; raise with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pairec_amd: %s not found — build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_size_t
+    P = C.POINTER
+    L.pg_last_error.restype = C.c_char_p
+    L.pg_version.restype = C.c_char_p
+    sig = {
+        "pg_init": [i32, vp, P(vp)],
+        "pg_shutdown": [vp],
+        "pg_synchronize": [vp],
+        "pg_device_malloc": [vp, sz, P(vp)],
+        "pg_device_free": [vp, vp],
+        "pg_memcpy_h2d": [vp, vp, vp, sz],
+        "pg_memcpy_d2h": [vp, vp, vp, sz],
+        "pg_table_create": [vp, u64, u32, u64, P(vp)],
+        "pg_table_destroy": [vp, vp],
+        "pg_table_fill_synthetic": [vp, vp, u64, i32],
+        "pg_table_upload": [vp, vp, u64, u64, vp],
+        "pg_table_download": [vp, vp, u64, u64, vp],
+        "pg_table_swap": [vp, vp, vp],
+        "pg_table_info": [vp, P(u64), P(u32), P(u64)],
+        "pg_table_gather": [vp, vp, vp, u32, vp],
+        "pg_recall_topk": [vp, vp, vp, u32, u32, vp, vp, vp],
+        "pg_recall_topk_dev": [vp, vp, vp, u32, u32, vp, vp, vp],
+        "pg_topk_merge_dev": [vp, vp, vp, u32, u32, u32, u32, vp, vp],
+        "pg_model_load": [vp, i32, i32, vp, sz, P(vp)],
+        "pg_model_destroy": [vp, vp],
+        "pg_rank_dnn3": [vp, vp, vp, vp, vp, vp, u32, vp],
+        "pg_rank_dnn3_dev": [vp, vp, vp, vp, vp, vp, u32, u32, vp],
+        "pg_rank_fm2t": [vp, vp, vp, vp, vp, vp, u32, vp],
+        "pg_rank_fm2t_dev": [vp, vp, vp, vp, vp, vp, u32, u32, vp],
+        "pg_expr_compile": [C.c_char_p, P(vp)],
+        "pg_expr_free": [vp],
+        "pg_expr_num_vars": [vp],
+        "pg_expr_eval": [vp, vp, vp, u32, vp],
+        "pg_expr_eval_dev": [vp, vp, vp, u32, vp],
+        "pg_sort_scores": [vp, vp, vp, u32, i32, vp],
+        "pg_sort_scores_dev": [vp, vp, vp, u32, u32, i32, vp],
+        "pg_dpp": [vp, vp, vp, vp, u32, C.c_double, u32, u32, i32, vp, vp],
+        "pg_stats": [vp, P(PgStats)],
+        "pg_last_scan_kernel_ms": [vp, P(C.c_double), P(u64)],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = i32
+    L.pg_expr_var_name.argtypes = [vp, i32]
+    L.pg_expr_var_name.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+class PgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("pairec_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(rc: int):
+    if rc != 0:
+        raise PgError(rc, load().pg_last_error().decode("utf-8", "replace"))

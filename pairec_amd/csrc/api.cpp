@@ -1,0 +1,141 @@
+// api.cpp — context lifecycle, error convention, memory helpers of libpairec_gpu.so.
+#include "common.hpp"
+
+namespace pg {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int scratch_reserve(pg_ctx* ctx, int slot, size_t bytes, void** out) {
+    Scratch& s = ctx->scratch[slot];
+    if (s.cap < bytes) {
+        if (s.p) {
+            PG_HIP(hipStreamSynchronize(ctx->stream));
+            PG_HIP(hipFree(s.p));
+            s.p = nullptr;
+            s.cap = 0;
+        }
+        size_t cap = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+        PG_HIP(hipMalloc(&s.p, cap));
+        s.cap = cap;
+    }
+    *out = s.p;
+    return PG_OK;
+}
+
+}  // namespace pg
+
+extern "C" {
+
+const char* pg_last_error(void) { return pg::g_err.c_str(); }
+const char* pg_version(void) { return "pairec_gpu 0.1 (gfx950)"; }
+
+int pg_init(int device, void* stream, pg_ctx** out) {
+    PG_REQUIRE(out != nullptr, "pg_init: out is NULL");
+    int n = 0;
+    PG_HIP(hipGetDeviceCount(&n));
+    PG_REQUIRE(device >= 0 && device < n, "pg_init: device %d out of range (%d visible)", device, n);
+    PG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PG_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        pg::set_error("pg_init: device %d is %s; this library is built for gfx950 (MI355X) only",
+                      device, prop.gcnArchName);
+        return PG_ERR_UNSUPPORTED;
+    }
+    pg_ctx* c = new pg_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        PG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    for (auto& e : c->ev) PG_HIP(hipEventCreate(&e));
+    PG_HIP(hipHostMalloc((void**)&c->h_status, 4096));
+    *out = c;
+    return PG_OK;
+}
+
+int pg_shutdown(pg_ctx* ctx) {
+    if (!ctx) return PG_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->scratch)
+        if (s.p) hipFree(s.p);
+    for (auto& e : ctx->ev)
+        if (e) hipEventDestroy(e);
+    for (auto& e : ctx->ev_pool) hipEventDestroy(e);
+    if (ctx->h_status) hipHostFree(ctx->h_status);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PG_OK;
+}
+
+int pg_synchronize(pg_ctx* ctx) {
+    PG_REQUIRE(ctx, "pg_synchronize: ctx is NULL");
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+int pg_device_malloc(pg_ctx* ctx, size_t bytes, void** out) {
+    PG_REQUIRE(ctx && out, "pg_device_malloc: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        pg::set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? PG_ERR_NOMEM : PG_ERR_DEVICE;
+    }
+    return PG_OK;
+}
+
+int pg_device_free(pg_ctx* ctx, void* p) {
+    PG_REQUIRE(ctx, "pg_device_free: ctx is NULL");
+    if (p) {
+        PG_HIP(hipStreamSynchronize(ctx->stream));
+        PG_HIP(hipFree(p));
+    }
+    return PG_OK;
+}
+
+int pg_memcpy_h2d(pg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    PG_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pg_memcpy_h2d: NULL argument");
+    if (bytes == 0) return PG_OK;
+    PG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+int pg_memcpy_d2h(pg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    PG_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pg_memcpy_d2h: NULL argument");
+    if (bytes == 0) return PG_OK;
+    PG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+int pg_stats(pg_ctx* ctx, pg_stats_t* out) {
+    PG_REQUIRE(ctx && out, "pg_stats: NULL argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = ctx->stats;
+    return PG_OK;
+}
+
+int pg_last_scan_kernel_ms(pg_ctx* ctx, double* out_ms, uint64_t* out_bytes) {
+    PG_REQUIRE(ctx, "pg_last_scan_kernel_ms: ctx is NULL");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (out_ms) *out_ms = ctx->last_scan_ms;
+    if (out_bytes) *out_bytes = ctx->last_scan_bytes;
+    return PG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// common.hpp — shared host-side plumbing of libpairec_gpu.so (context, error convention).
+// gfx950 (MI355X) only: wave = 64 lanes, 256 CUs, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pairec_gpu.h"
+
+namespace pg {
+
+void set_error(const char* fmt, ...);
+
+#define PG_HIP(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            ::pg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,  \
+                            __LINE__);                                                         \
+            return PG_ERR_DEVICE;                                                              \
+        }                                                                                      \
+    } while (0)
+
+#define PG_REQUIRE(cond, ...)                    \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::pg::set_error(__VA_ARGS__);        \
+            return PG_ERR_INVALID;               \
+        }                                        \
+    } while (0)
+
+constexpr int kWave = 64;
+constexpr int kMaxQueries = 32;   // queries per table pass (one 32x32x2 f32 MFMA column block)
+
+// Scratch arena: grows on demand, never shrinks; owned by the context, used by one call at a time
+// (calls on a context are serialised by ctx->mu).
+struct Scratch {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace pg
+
+struct pg_table {
+    float* d = nullptr;          // [rows][dim] fp32 row-major
+    uint64_t rows = 0;
+    uint32_t dim = 0;
+    uint64_t row_offset = 0;     // global row id of local row 0 (sharded tables)
+};
+
+struct pg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    std::mutex mu;               // serialises calls on this context
+    pg::Scratch scratch[8];      // named scratch slots (see users)
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_pool;   // per-launch timing events (scan kernel roofline figure)
+    uint32_t last_scan_launches = 0;
+    pg_stats_t stats{};
+    double last_scan_ms = 0.0;
+    uint64_t last_scan_bytes = 0;
+    // pinned host staging for small status words
+    uint32_t* h_status = nullptr;
+};
+
+namespace pg {
+int scratch_reserve(pg_ctx* ctx, int slot, size_t bytes, void** out);
+}

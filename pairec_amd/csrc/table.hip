@@ -1,0 +1,191 @@
+// table.hip — HBM-resident embedding tables: the device-side replacement for pairec's
+// module.VectorDao back-ends (module/vector_dao.go:13-15; redis/hologres/mysql/clickhouse/hbase/be
+// implementations fetch one embedding per network round trip).  Rows are fp32, row-major,
+// [rows][dim], 512 B per row at dim=128, so a recall scan streams them as full 128-B lines.
+#include "common.hpp"
+#include "synth.hpp"
+
+namespace pg {
+
+// One block = 256 rows.  Phase 1: thread-per-row computes the row's squared norm as the
+// specification's k-ascending fmaf chain (must be sequential to be bit-reproducible).
+// Phase 2: the block rewrites the same rows with coalesced 16-B stores.
+template <int DIM>
+__global__ __launch_bounds__(256) void table_fill_synth_kernel(float* __restrict__ out,
+                                                              uint64_t rows, uint64_t row_offset,
+                                                              uint64_t seed, int normalize) {
+    __shared__ float inv_s[256];
+    const uint64_t r0 = (uint64_t)blockIdx.x * 256;
+    const uint64_t r = r0 + threadIdx.x;
+    float inv = 1.0f;
+    if (normalize && r < rows) {
+        const uint64_t g = row_offset + r;
+        float ss = 0.0f;
+        for (int c = 0; c < DIM; ++c) {
+            const float v = synth_value(seed, g, c, DIM);
+            ss = __fmaf_rn(v, v, ss);
+        }
+        inv = __fdiv_rn(1.0f, __fsqrt_rn(ss));
+    }
+    inv_s[threadIdx.x] = inv;
+    __syncthreads();
+    constexpr int QPR = DIM / 4;                  // quads per row
+    constexpr int RPI = 256 / QPR;                // rows per iteration
+    const int q = threadIdx.x % QPR;
+    for (int rr = threadIdx.x / QPR; rr < 256; rr += RPI) {
+        const uint64_t row = r0 + rr;
+        if (row >= rows) break;
+        const uint64_t g = row_offset + row;
+        const float s = inv_s[rr];
+        float4 v;
+        v.x = synth_value(seed, g, 4 * q + 0, DIM) * s;
+        v.y = synth_value(seed, g, 4 * q + 1, DIM) * s;
+        v.z = synth_value(seed, g, 4 * q + 2, DIM) * s;
+        v.w = synth_value(seed, g, 4 * q + 3, DIM) * s;
+        *reinterpret_cast<float4*>(out + row * DIM + 4 * q) = v;
+    }
+}
+
+// one wave-half (32 lanes x 16 B = 512 B) per gathered row at dim=128
+__global__ void table_gather_kernel(const float* __restrict__ tab, uint32_t dim,
+                                    const uint32_t* __restrict__ rows, uint32_t n,
+                                    float* __restrict__ out) {
+    const uint32_t qpr = dim / 4;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = gid / qpr;
+    const uint32_t q = gid % qpr;
+    if (i >= n) return;
+    const float4 v = *reinterpret_cast<const float4*>(tab + (uint64_t)rows[i] * dim + 4 * q);
+    *reinterpret_cast<float4*>(out + i * dim + 4 * q) = v;
+}
+
+}  // namespace pg
+
+extern "C" {
+
+int pg_table_create(pg_ctx* ctx, uint64_t rows, uint32_t dim, uint64_t row_offset, pg_table** out) {
+    PG_REQUIRE(ctx && out, "pg_table_create: NULL argument");
+    PG_REQUIRE(dim >= 64 && dim % 64 == 0 && dim <= 256,
+               "pg_table_create: dim=%u unsupported (multiple of 64, <= 256)", dim);
+    PG_REQUIRE(rows > 0 && rows < (1ull << 32), "pg_table_create: rows=%llu must be in [1, 2^32)",
+               (unsigned long long)rows);
+    PG_REQUIRE(row_offset + rows < (1ull << 32),
+               "pg_table_create: global row ids must fit in 32 bits (offset %llu + rows %llu)",
+               (unsigned long long)row_offset, (unsigned long long)rows);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    PG_HIP(hipSetDevice(ctx->device));
+    pg_table* t = new pg_table();
+    t->rows = rows;
+    t->dim = dim;
+    t->row_offset = row_offset;
+    // +64 rows of slack so tile loaders may read (never use) a few rows past the end
+    hipError_t e = hipMalloc((void**)&t->d, (rows + 64) * (size_t)dim * sizeof(float));
+    if (e != hipSuccess) {
+        pg::set_error("pg_table_create: hipMalloc(%.1f GB) failed: %s",
+                      (double)(rows * dim * 4) / 1e9, hipGetErrorString(e));
+        delete t;
+        return PG_ERR_NOMEM;
+    }
+    PG_HIP(hipMemsetAsync(t->d + rows * (size_t)dim, 0, 64 * (size_t)dim * sizeof(float), ctx->stream));
+    *out = t;
+    return PG_OK;
+}
+
+int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
+    PG_REQUIRE(ctx, "pg_table_destroy: ctx is NULL");
+    if (!t) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    if (t->d) PG_HIP(hipFree(t->d));
+    delete t;
+    return PG_OK;
+}
+
+int pg_table_fill_synthetic(pg_ctx* ctx, pg_table* t, uint64_t seed, int normalize) {
+    PG_REQUIRE(ctx && t, "pg_table_fill_synthetic: NULL argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    const uint32_t blocks = (uint32_t)((t->rows + 255) / 256);
+    switch (t->dim) {
+        case 64:
+            pg::table_fill_synth_kernel<64><<<blocks, 256, 0, ctx->stream>>>(t->d, t->rows, t->row_offset, seed, normalize);
+            break;
+        case 128:
+            pg::table_fill_synth_kernel<128><<<blocks, 256, 0, ctx->stream>>>(t->d, t->rows, t->row_offset, seed, normalize);
+            break;
+        case 192:
+            pg::table_fill_synth_kernel<192><<<blocks, 256, 0, ctx->stream>>>(t->d, t->rows, t->row_offset, seed, normalize);
+            break;
+        case 256:
+            pg::table_fill_synth_kernel<256><<<blocks, 256, 0, ctx->stream>>>(t->d, t->rows, t->row_offset, seed, normalize);
+            break;
+        default:
+            pg::set_error("pg_table_fill_synthetic: dim=%u unsupported", t->dim);
+            return PG_ERR_UNSUPPORTED;
+    }
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+int pg_table_upload(pg_ctx* ctx, pg_table* t, uint64_t row0, uint64_t nrows, const float* host_rows) {
+    PG_REQUIRE(ctx && t && (nrows == 0 || host_rows), "pg_table_upload: NULL argument");
+    PG_REQUIRE(row0 + nrows <= t->rows, "pg_table_upload: rows [%llu,%llu) outside table of %llu",
+               (unsigned long long)row0, (unsigned long long)(row0 + nrows), (unsigned long long)t->rows);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (nrows == 0) return PG_OK;
+    PG_HIP(hipMemcpyAsync(t->d + row0 * t->dim, host_rows, nrows * (size_t)t->dim * sizeof(float),
+                          hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+int pg_table_download(pg_ctx* ctx, const pg_table* t, uint64_t row0, uint64_t nrows, float* host_rows) {
+    PG_REQUIRE(ctx && t && (nrows == 0 || host_rows), "pg_table_download: NULL argument");
+    PG_REQUIRE(row0 + nrows <= t->rows, "pg_table_download: rows out of range");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (nrows == 0) return PG_OK;
+    PG_HIP(hipMemcpyAsync(host_rows, t->d + row0 * t->dim, nrows * (size_t)t->dim * sizeof(float),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
+    PG_REQUIRE(ctx && a && b, "pg_table_swap: NULL argument");
+    PG_REQUIRE(a->rows == b->rows && a->dim == b->dim, "pg_table_swap: shapes differ");
+    std::lock_guard<std::mutex> g(ctx->mu);          // no call on this context is mid-flight
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    std::swap(a->d, b->d);
+    std::swap(a->row_offset, b->row_offset);
+    return PG_OK;
+}
+
+int pg_table_info(const pg_table* t, uint64_t* rows, uint32_t* dim, uint64_t* row_offset) {
+    PG_REQUIRE(t, "pg_table_info: table is NULL");
+    if (rows) *rows = t->rows;
+    if (dim) *dim = t->dim;
+    if (row_offset) *row_offset = t->row_offset;
+    return PG_OK;
+}
+
+int pg_table_gather(pg_ctx* ctx, const pg_table* t, const uint32_t* rows, uint32_t n, float* out) {
+    PG_REQUIRE(ctx && t && (n == 0 || (rows && out)), "pg_table_gather: NULL argument");
+    if (n == 0) return PG_OK;
+    for (uint32_t i = 0; i < n; ++i)
+        PG_REQUIRE(rows[i] < t->rows, "pg_table_gather: row %u out of range", rows[i]);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void *d_rows, *d_out;
+    int rc;
+    if ((rc = pg::scratch_reserve(ctx, 0, (size_t)n * 4, &d_rows))) return rc;
+    if ((rc = pg::scratch_reserve(ctx, 1, (size_t)n * t->dim * 4, &d_out))) return rc;
+    PG_HIP(hipMemcpyAsync(d_rows, rows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t threads = (uint64_t)n * (t->dim / 4);
+    pg::table_gather_kernel<<<(uint32_t)((threads + 255) / 256), 256, 0, ctx->stream>>>(
+        t->d, t->dim, (const uint32_t*)d_rows, n, (float*)d_out);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipMemcpyAsync(out, d_out, (size_t)n * t->dim * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+}  // extern "C"

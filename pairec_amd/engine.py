@@ -1,0 +1,249 @@
+"""Thin object layer over the C ABI (include/pairec_gpu.h): Context, Table, RankModel, Expr.
+
+Host arrays are numpy; "dev" methods take raw device addresses (ints), e.g. torch tensors'
+`.data_ptr()` — torch is used by callers only as plumbing for device memory and RCCL.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+PREC_F32, PREC_BF16 = 0, 1
+MODEL_DNN3, MODEL_FM_TWOTOWER = 1, 2
+MAX_QUERIES = 32
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.L.pg_init(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.pg_shutdown(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        _lib.check(self.L.pg_synchronize(self.h))
+
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        _lib.check(self.L.pg_device_malloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, p: int):
+        _lib.check(self.L.pg_device_free(self.h, C.c_void_p(p)))
+
+    def h2d(self, dst: int, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        _lib.check(self.L.pg_memcpy_h2d(self.h, C.c_void_p(dst), _ptr(a), a.nbytes))
+
+    def d2h(self, a: np.ndarray, src: int):
+        assert a.flags.c_contiguous
+        _lib.check(self.L.pg_memcpy_d2h(self.h, _ptr(a), C.c_void_p(src), a.nbytes))
+
+    def to_device(self, a: np.ndarray) -> int:
+        a = np.ascontiguousarray(a)
+        p = self.malloc(max(a.nbytes, 16))
+        self.h2d(p, a)
+        return p
+
+    def stats(self) -> _lib.PgStats:
+        s = _lib.PgStats()
+        _lib.check(self.L.pg_stats(self.h, C.byref(s)))
+        return s
+
+    def last_scan_kernel(self) -> Tuple[float, int]:
+        ms, b = C.c_double(), C.c_uint64()
+        _lib.check(self.L.pg_last_scan_kernel_ms(self.h, C.byref(ms), C.byref(b)))
+        return ms.value, b.value
+
+    # ---- sort / expr (context-level ops) ----------------------------------------------------
+    def sort_scores(self, scores: np.ndarray, seg_offsets: Optional[Sequence[int]] = None,
+                    descending: bool = True) -> np.ndarray:
+        s = np.ascontiguousarray(scores, dtype=np.float64)
+        if seg_offsets is None:
+            seg_offsets = [0, s.shape[0]]
+        so = np.ascontiguousarray(seg_offsets, dtype=np.uint32)
+        out = np.zeros(s.shape[0], dtype=np.uint32)
+        _lib.check(self.L.pg_sort_scores(self.h, _ptr(s), _ptr(so), so.shape[0] - 1,
+                                         int(descending), _ptr(out)))
+        return out
+
+
+class Table:
+    """HBM-resident embedding table (module.VectorDao replacement)."""
+
+    def __init__(self, ctx: Context, rows: int, dim: int, row_offset: int = 0):
+        self.ctx, self.rows, self.dim, self.row_offset = ctx, rows, dim, row_offset
+        h = C.c_void_p()
+        _lib.check(ctx.L.pg_table_create(ctx.h, rows, dim, row_offset, C.byref(h)))
+        self.h = h
+
+    def destroy(self):
+        if self.h:
+            _lib.check(self.ctx.L.pg_table_destroy(self.ctx.h, self.h))
+            self.h = None
+
+    def fill_synthetic(self, seed: int, normalize: bool = True):
+        _lib.check(self.ctx.L.pg_table_fill_synthetic(self.ctx.h, self.h, seed, int(normalize)))
+
+    def upload(self, rows: np.ndarray, row0: int = 0):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        assert rows.ndim == 2 and rows.shape[1] == self.dim
+        _lib.check(self.ctx.L.pg_table_upload(self.ctx.h, self.h, row0, rows.shape[0], _ptr(rows)))
+
+    def download(self, row0: int, nrows: int) -> np.ndarray:
+        out = np.empty((nrows, self.dim), dtype=np.float32)
+        _lib.check(self.ctx.L.pg_table_download(self.ctx.h, self.h, row0, nrows, _ptr(out)))
+        return out
+
+    def gather(self, rows: Sequence[int]) -> np.ndarray:
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.empty((r.shape[0], self.dim), dtype=np.float32)
+        _lib.check(self.ctx.L.pg_table_gather(self.ctx.h, self.h, _ptr(r), r.shape[0], _ptr(out)))
+        return out
+
+    def swap(self, other: "Table"):
+        _lib.check(self.ctx.L.pg_table_swap(self.ctx.h, self.h, other.h))
+        self.row_offset, other.row_offset = other.row_offset, self.row_offset
+
+    def recall_topk(self, queries: np.ndarray, k: int):
+        """queries [nq][dim] → (rows [nq][k] uint64 global ids, scores [nq][k] f32, counts [nq])."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        rows = np.empty((nq, k), dtype=np.uint64)
+        scores = np.empty((nq, k), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        for s in range(0, nq, MAX_QUERIES):          # one table pass per 32 queries
+            e = min(nq, s + MAX_QUERIES)
+            r_, s_, c_ = rows[s:e], scores[s:e], counts[s:e]
+            _lib.check(self.ctx.L.pg_recall_topk(self.ctx.h, self.h, _ptr(q[s:e]), e - s, k,
+                                                 _ptr(r_), _ptr(s_), _ptr(c_)))
+        return rows, scores, counts
+
+    def recall_topk_dev(self, d_queries: int, nq: int, k: int, d_out_rows: int, d_out_scores: int):
+        counts = np.zeros(nq, dtype=np.uint32)
+        _lib.check(self.ctx.L.pg_recall_topk_dev(self.ctx.h, self.h, C.c_void_p(d_queries), nq, k,
+                                                 C.c_void_p(d_out_rows), C.c_void_p(d_out_scores),
+                                                 _ptr(counts)))
+        return counts
+
+
+def pack_dnn3(w1, b1, w2, b2, w3, b3, d_user: int) -> bytes:
+    w1 = np.ascontiguousarray(w1, dtype=np.float32)
+    w2 = np.ascontiguousarray(w2, dtype=np.float32)
+    din, h1 = w1.shape
+    h2 = w2.shape[1]
+    return (struct.pack("<4I", d_user, din - d_user, h1, h2) + w1.tobytes() +
+            np.ascontiguousarray(b1, dtype=np.float32).tobytes() + w2.tobytes() +
+            np.ascontiguousarray(b2, dtype=np.float32).tobytes() +
+            np.ascontiguousarray(w3, dtype=np.float32).tobytes() + struct.pack("<f", float(b3)))
+
+
+def pack_fm2t(w) -> bytes:
+    """w: object with the attributes of oracle.Fm2tWeights (duck-typed; no oracle import here)."""
+    parts = [struct.pack("<7If", w.nuf, w.nif, w.k, w.d_user, w.t_h1, w.t_out, w.vocab, w.fm_b)]
+    for a in (w.uw1, w.ub1, w.uw2, w.ub2, w.iw1, w.ib1, w.iw2, w.ib2):
+        parts.append(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+    for f in range(w.nuf + w.nif):
+        parts.append(np.ascontiguousarray(w.field_emb[f], dtype=np.float32).tobytes())
+        parts.append(np.ascontiguousarray(w.field_lin[f], dtype=np.float32).tobytes())
+    return b"".join(parts)
+
+
+class RankModel:
+    """Rank model resident in HBM (algorithm/eas | tfserving predict replacement)."""
+
+    def __init__(self, ctx: Context, kind: int, prec: int, blob: bytes):
+        self.ctx, self.kind, self.prec = ctx, kind, prec
+        h = C.c_void_p()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        _lib.check(ctx.L.pg_model_load(ctx.h, kind, prec, buf, len(blob), C.byref(h)))
+        self.h = h
+
+    def destroy(self):
+        if self.h:
+            _lib.check(self.ctx.L.pg_model_destroy(self.ctx.h, self.h))
+            self.h = None
+
+    def rank_dnn3(self, table: Table, user_vecs: np.ndarray, cand_rows: np.ndarray,
+                  req_offsets: Sequence[int]) -> np.ndarray:
+        u = np.ascontiguousarray(user_vecs, dtype=np.float32)
+        c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+        ro = np.ascontiguousarray(req_offsets, dtype=np.uint32)
+        out = np.empty(c.shape[0], dtype=np.float32)
+        _lib.check(self.ctx.L.pg_rank_dnn3(self.ctx.h, self.h, table.h, _ptr(u), _ptr(c), _ptr(ro),
+                                           ro.shape[0] - 1, _ptr(out)))
+        return out
+
+    def rank_dnn3_dev(self, table: Table, d_user_vecs: int, d_cand_rows: int, d_req_offsets: int,
+                      n_req: int, n_items: int, d_out: int):
+        _lib.check(self.ctx.L.pg_rank_dnn3_dev(self.ctx.h, self.h, table.h, C.c_void_p(d_user_vecs),
+                                               C.c_void_p(d_cand_rows), C.c_void_p(d_req_offsets),
+                                               n_req, n_items, C.c_void_p(d_out)))
+
+    def rank_fm2t(self, user_vecs, user_field_ids, item_field_ids, req_offsets) -> np.ndarray:
+        u = np.ascontiguousarray(user_vecs, dtype=np.float32)
+        uf = np.ascontiguousarray(user_field_ids, dtype=np.int32)
+        itf = np.ascontiguousarray(item_field_ids, dtype=np.int32)
+        ro = np.ascontiguousarray(req_offsets, dtype=np.uint32)
+        out = np.empty(int(ro[-1]), dtype=np.float32)
+        _lib.check(self.ctx.L.pg_rank_fm2t(self.ctx.h, self.h, _ptr(u), _ptr(uf), _ptr(itf),
+                                           _ptr(ro), ro.shape[0] - 1, _ptr(out)))
+        return out
+
+
+class Expr:
+    """Compiled RankConfig.RankScore expression (utils/ast replacement)."""
+
+    def __init__(self, source: str):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.L.pg_expr_compile(source.encode("utf-8"), C.byref(h)))
+        self.h = h
+        n = self.L.pg_expr_num_vars(h)
+        self.var_names = [self.L.pg_expr_var_name(h, i).decode("utf-8") for i in range(n)]
+
+    def free(self):
+        if self.h:
+            self.L.pg_expr_free(self.h)
+            self.h = None
+
+    def eval(self, ctx: Context, vars_: np.ndarray) -> np.ndarray:
+        """vars_: [n_vars][n_items] fp64 in var_names order → fused scores [n_items] fp64."""
+        v = np.ascontiguousarray(vars_, dtype=np.float64).reshape(len(self.var_names), -1) \
+            if len(self.var_names) else np.zeros((0, int(np.shape(vars_)[-1])), dtype=np.float64)
+        n = v.shape[1]
+        out = np.empty(n, dtype=np.float64)
+        _lib.check(self.L.pg_expr_eval(ctx.h, self.h, _ptr(v) if v.size else None, n, _ptr(out)))
+        return out
+
+
+def dpp(ctx: Context, table: Table, cand_rows, rel, alpha: float, topn: int, window: int,
+        normalize_emb: bool = True) -> np.ndarray:
+    c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+    r = np.ascontiguousarray(rel, dtype=np.float64)
+    out = np.zeros(max(topn, 1), dtype=np.uint32)
+    cnt = C.c_uint32()
+    _lib.check(ctx.L.pg_dpp(ctx.h, table.h, _ptr(c), _ptr(r), c.shape[0], alpha, topn, window,
+                            int(normalize_emb), _ptr(out), C.byref(cnt)))
+    return out[:cnt.value]
