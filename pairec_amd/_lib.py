@@ -85,6 +85,10 @@ def load():
         "pg_stats": [vp, P(PgStats)],
         "pg_last_scan_kernel_ms": [vp, P(C.c_double), P(u64)],
     }
+    missing = [n for n in EXPORTS if not hasattr(L, n)]
+    if missing:
+        raise ImportError("pairec_amd: %s lacks symbols %s declared in include/pairec_gpu.h "
+                          "(stale build?)" % (LIB_PATH, missing))
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args

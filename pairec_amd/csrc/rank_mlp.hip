@@ -1,0 +1,872 @@
+// rank_mlp.hip — the rank stage's model predict on MFMA.
+//
+// Replaces the DNN / FM forward that the reference ships to a remote model server:
+// EasModel.Run (algorithm/eas/model.go:197-222), TFservingModel.Run
+// (algorithm/tfserving/model.go:30-55), called once per batch of 100 items from
+// RankService.Rank (service/rank/rank_service.go:163-166,264-289).  Here one launch scores every
+// candidate of every request in the call; candidate features are gathered straight from HBM.
+//
+// One fused kernel serves both model families:
+//     z1 = c1[req] + x · W1        h1 = P(relu(z1))           x = 128 gathered fp32 values / item
+//     z2 = b2 + h1 · W2            h2 = act2(z2)   (kept fp32)
+//     z3 = bias3[item] + <h2, w3[req]>  (two half chains)      score = 1/(1+expf(-z3))
+//   DNN3      : x = table row, c1 = b1 + user·W1[user half] (request constant), w3 shared, bias3=b3
+//   two-tower : x = concat of 8 item-field embeddings, c1 = ib1, w3 = user-tower output, bias3=y_fm
+// PG_PREC_BF16: operands bf16, fp32 accumulate on v_mfma_f32_32x32x16_bf16.
+// PG_PREC_F32 : v_mfma_f32_32x32x2_f32, which is a k-ordered fmaf chain → bit-reproducible.
+//
+// Tiling: workgroup = 4 waves = 128 items; layer 1 is produced in chunks of 128 hidden columns
+// that go through LDS (as the A operand of layer 2) and are consumed immediately, so h1 never
+// leaves the CU; weights are pre-packed in MFMA-fragment order so each B fragment is one
+// coalesced 1 KiB load shared by all of a wave's row blocks.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace pg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
+    uint32_t b;
+#ifdef __HIP_DEVICE_COMPILE__
+    b = __float_as_uint(x);
+#else
+    memcpy(&b, &x, 4);
+#endif
+    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((b >> 16) | 0x0040u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
+__host__ __device__ __forceinline__ float bf16_to_f32(uint16_t v) {
+    uint32_t b = (uint32_t)v << 16;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(b);
+#else
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+#endif
+}
+__host__ __device__ __forceinline__ float round_prec(float x, int prec) {
+    return prec ? bf16_to_f32(f32_to_bf16_rne(x)) : x;
+}
+
+constexpr int kBM = 128;       // items per workgroup tile
+constexpr int kDIN = 128;      // gathered input width
+constexpr int kCH = 128;       // layer-1 chunk (hidden columns)
+constexpr int kFmK = 16;       // FM embedding width
+constexpr int kFmFields = 8;   // item fields (= user fields)
+
+struct MlpArgs {
+    const uint32_t* tile_req;
+    const uint32_t* tile_item0;
+    const uint32_t* tile_cnt;
+    const uint32_t* n_tiles;
+    // DNN3 gather
+    const float* tab;
+    uint32_t tab_rows;
+    const uint32_t* cand_rows;
+    // two-tower gather
+    const float* const* field_emb;   // device array [16] of [vocab][16]
+    const float* const* field_lin;   // device array [16] of [vocab]
+    const int32_t* item_field_ids;   // [n_items][8]
+    uint32_t vocab;
+    const float* fm_user;            // [n_req][33]: linU, sU[16], qU[16]
+    // per request / shared vectors
+    const float* c1;
+    uint32_t c1_stride;
+    const float* w3;
+    uint32_t w3_stride;
+    float b3;
+    const float* b2;
+    // pre-packed weights
+    const void* w1p;
+    const void* w2p;
+    float* out;
+};
+
+template <int PREC>
+__device__ __forceinline__ void store_x_quad(char* tile, int row, int c, float4 v) {
+    if constexpr (PREC == 1) {
+        // 4 bf16 = 8 B at element 4c: 16-B quad index c/2, XOR-swizzled by row
+        uint2 p;
+        p.x = (uint32_t)f32_to_bf16_rne(v.x) | ((uint32_t)f32_to_bf16_rne(v.y) << 16);
+        p.y = (uint32_t)f32_to_bf16_rne(v.z) | ((uint32_t)f32_to_bf16_rne(v.w) << 16);
+        *reinterpret_cast<uint2*>(tile + row * 256 + ((((c >> 1) ^ (row & 15))) << 4) + (c & 1) * 8) = p;
+    } else {
+        *reinterpret_cast<float4*>(tile + row * 512 + ((c ^ (row & 15)) << 4)) = v;
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ void store_h_elem(char* tile, int row, int col, float v) {
+    if constexpr (PREC == 1) {
+        *reinterpret_cast<uint16_t*>(tile + row * 256 + ((((col >> 3) ^ (row & 15))) << 4) + (col & 7) * 2) =
+            f32_to_bf16_rne(v);
+    } else {
+        *reinterpret_cast<float*>(tile + row * 512 + ((((col >> 2) ^ (row & 15))) << 4) + (col & 3) * 4) = v;
+    }
+}
+
+// C[rows of this wave][n-blocks] += A(tile in LDS)[rows][K=128] · B(pre-packed fragments)
+// frag(nb, step) returns the byte offset of the 1-KiB fragment for n-block nb and k-group `step`.
+template <int PREC, int MB, int NB, typename FragOff>
+__device__ __forceinline__ void gemm_k128(f32x16 (&acc)[MB][NB], const char* tile, int mrow0,
+                                          const char* wpk, FragOff frag, int lane) {
+    const int i32 = lane & 31, h = lane >> 5;
+    if constexpr (PREC == 1) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {           // 8 k-steps of 16
+            bf16x8 bf[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                bf[nb] = *reinterpret_cast<const bf16x8*>(wpk + frag(nb, ks) + lane * 16);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int row = mrow0 + mb * 32 + i32;
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(
+                    tile + row * 256 + ((((ks * 2 + h) ^ (row & 15))) << 4));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nb], acc[mb][nb], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int g8 = 0; g8 < 16; ++g8) {          // 16 groups of 8 k (4 MFMA steps each)
+            f32x4 bf[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                bf[nb] = *reinterpret_cast<const f32x4*>(wpk + frag(nb, g8) + lane * 16);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int row = mrow0 + mb * 32 + i32;
+#pragma unroll
+                for (int qd = 0; qd < 2; ++qd) {
+                    const f32x4 aq = *reinterpret_cast<const f32x4*>(
+                        tile + row * 512 + ((((g8 * 2 + qd) ^ (row & 15))) << 4));
+                    const float a0 = h ? aq.y : aq.x;
+                    const float a1 = h ? aq.w : aq.z;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[nb][2 * qd], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[nb][2 * qd + 1], acc[mb][nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+constexpr size_t mlp_lds_bytes(int prec, int h2) {
+    const size_t tiles = (size_t)2 * kBM * kDIN * (prec ? 2 : 4);
+    const size_t h2t = (size_t)kBM * (h2 + 1) * 4;
+    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)kBM * 4;
+}
+
+// MODEL 1 = DNN3, 2 = two-tower item side
+template <int PREC, int H1, int H2, bool ACT2, int WM, int WN, int MODEL>
+__global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
+    constexpr int MB = 4 / WM;
+    constexpr int L1NB = kCH / 32 / WN;
+    constexpr int L2NB = H2 / 32 / WN;
+    constexpr int ES = PREC ? 2 : 4;
+    constexpr int TILE_B = kBM * kDIN * ES;
+    constexpr int NCHUNK = H1 / kCH;
+    constexpr int KG1 = PREC ? 8 : 16;             // k-groups (fragments) per 128-deep GEMM
+    constexpr size_t REGION = (size_t)2 * TILE_B > (size_t)kBM * (H2 + 1) * 4 ? (size_t)2 * TILE_B
+                                                                            : (size_t)kBM * (H2 + 1) * 4;
+    static_assert(L1NB >= 1 && L2NB >= 1 && MB >= 1, "bad wave layout");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const XT = smem;
+    char* const H1T = smem + TILE_B;
+    float* const H2T = reinterpret_cast<float*>(smem);      // aliases XT/H1T after the GEMMs
+    float* const w3s = reinterpret_cast<float*>(smem + REGION);
+    float* const b3s = w3s + H2;
+
+    const uint32_t tile = blockIdx.x;
+    if (tile >= *a.n_tiles) return;
+    const uint32_t req = a.tile_req[tile];
+    const uint32_t item0 = a.tile_item0[tile];
+    const uint32_t cnt = a.tile_cnt[tile];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int i32 = lane & 31, h = lane >> 5;
+
+    // ---------------- gather prologue: 32 lanes x 16 B per item, 8 items per pass ------------
+    {
+        const int c = tid & 31;
+        if (tid < H2) w3s[tid] = a.w3[(size_t)req * a.w3_stride + tid];
+        if constexpr (MODEL == 1) {
+            if (tid < kBM) b3s[tid] = a.b3;
+            float4 v[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const uint32_t r = p * 8 + (tid >> 5);
+                const uint32_t idx = item0 + (r < cnt ? r : cnt - 1);
+                uint32_t row = a.cand_rows[idx];
+                row = row < a.tab_rows ? row : a.tab_rows - 1;
+                v[p] = *reinterpret_cast<const float4*>(a.tab + (size_t)row * kDIN + 4 * c);
+            }
+#pragma unroll
+            for (int p = 0; p < 16; ++p) store_x_quad<PREC>(XT, p * 8 + (tid >> 5), c, v[p]);
+        } else {
+            // two-tower: field f = c/4, quad qd = c%4 of that field's 16-wide embedding; the FM
+            // sums ride along in registers (fields accumulate sequentially, f ascending).
+            const int f = c >> 2, qd = c & 3;
+            const float* fu = a.fm_user + (size_t)req * 33;
+            const float* emb = a.field_emb[kFmFields + f];
+            const float* lin_t[1] = {nullptr};
+            (void)lin_t;
+#pragma unroll 1
+            for (int p = 0; p < 16; ++p) {
+                const uint32_t r = p * 8 + (tid >> 5);
+                const uint32_t idx = item0 + (r < cnt ? r : cnt - 1);
+                int32_t id = a.item_field_ids[(size_t)idx * kFmFields + f];
+                id = id < 0 ? 0 : (id >= (int32_t)a.vocab ? (int32_t)a.vocab - 1 : id);
+                const float4 v = *reinterpret_cast<const float4*>(emb + (size_t)id * kFmK + 4 * qd);
+                store_x_quad<PREC>(XT, r, c, v);
+                float s[4], q[4];
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[e] = fu[1 + 4 * qd + e] + vv[e];
+                    q[e] = __fmaf_rn(vv[e], vv[e], fu[17 + 4 * qd + e]);
+                }
+#pragma unroll
+                for (int ff = 1; ff < kFmFields; ++ff) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sp = __shfl_up(s[e], 4, 32);
+                        const float qp = __shfl_up(q[e], 4, 32);
+                        if (f == ff) {
+                            s[e] = sp + vv[e];
+                            q[e] = __fmaf_rn(vv[e], vv[e], qp);
+                        }
+                    }
+                }
+                // lanes with f == 7 hold the finished sums for k = 4*qd + e
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __fmaf_rn(s[e], s[e], -q[e]);
+                float cr = (t[0] + t[1]) + (t[2] + t[3]);
+                cr = cr + __shfl_xor(cr, 1, 32);
+                cr = cr + __shfl_xor(cr, 2, 32);
+                if (c == 31) {
+                    float lin = fu[0];
+#pragma unroll
+                    for (int ff = 0; ff < kFmFields; ++ff) {
+                        int32_t idf = a.item_field_ids[(size_t)idx * kFmFields + ff];
+                        idf = idf < 0 ? 0 : (idf >= (int32_t)a.vocab ? (int32_t)a.vocab - 1 : idf);
+                        lin = lin + a.field_lin[kFmFields + ff][idf];
+                    }
+                    b3s[r] = lin + 0.5f * cr;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int mrow0 = wm * MB * 32;
+    f32x16 acc2[MB][L2NB];
+#pragma unroll
+    for (int nb = 0; nb < L2NB; ++nb) {
+        const float bv = a.b2[(wn * L2NB + nb) * 32 + i32];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mb][nb][r] = bv;
+    }
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        // ---- layer 1, columns [chunk*128, +128): wave owns L1NB n-blocks
+        f32x16 acc1[MB][L1NB];
+#pragma unroll
+        for (int nb = 0; nb < L1NB; ++nb) {
+            const float cv = a.c1[(size_t)req * a.c1_stride + chunk * kCH + (wn * L1NB + nb) * 32 + i32];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[mb][nb][r] = cv;
+        }
+        {
+            const int nbg0 = chunk * (kCH / 32) + wn * L1NB;
+            gemm_k128<PREC, MB, L1NB>(
+                acc1, XT, mrow0, reinterpret_cast<const char*>(a.w1p),
+                [&](int nb, int step) { return (size_t)((nbg0 + nb) * KG1 + step) * 1024; }, lane);
+        }
+        // relu → P() → H1 chunk tile (A operand of layer 2)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < L1NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mrow0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int col = (wn * L1NB + nb) * 32 + i32;
+                    const float v = acc1[mb][nb][r];
+                    store_h_elem<PREC>(H1T, row, col, v > 0.0f ? v : 0.0f);
+                }
+        __syncthreads();
+        // ---- layer 2 partial: acc2 += H1chunk · W2[chunk*128 .. +128, :]
+        {
+            const int nbg0 = wn * L2NB;
+            constexpr int KG2 = (H1 / kCH) * KG1;      // k-groups over the full H1 depth
+            gemm_k128<PREC, MB, L2NB>(
+                acc2, H1T, mrow0, reinterpret_cast<const char*>(a.w2p),
+                [&](int nb, int step) { return (size_t)((nbg0 + nb) * KG2 + chunk * KG1 + step) * 1024; },
+                lane);
+        }
+        __syncthreads();
+    }
+
+    // ---- layer-2 activation → H2 tile (fp32, padded rows), then the dot head
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < L2NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = (wn * L2NB + nb) * 32 + i32;
+                float v = acc2[mb][nb][r];
+                if (ACT2) v = v > 0.0f ? v : 0.0f;
+                H2T[row * (H2 + 1) + col] = v;
+            }
+    __syncthreads();
+    {
+        const int row = tid >> 1, half = tid & 1;
+        const float* hr = H2T + row * (H2 + 1) + half * (H2 / 2);
+        const float* wr = w3s + half * (H2 / 2);
+        float p = half ? 0.0f : b3s[row];
+#pragma unroll 8
+        for (int m = 0; m < H2 / 2; ++m) p = __fmaf_rn(hr[m], wr[m], p);
+        const float o = __shfl_xor(p, 1);
+        const float z = half ? (o + p) : (p + o);
+        if (half == 0 && (uint32_t)row < cnt) a.out[item0 + row] = 1.0f / (1.0f + expf(-z));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// request → tile table.  One block; requests <= 65535 per call.
+// ---------------------------------------------------------------------------------------------
+__global__ void build_tiles_kernel(const uint32_t* __restrict__ req_offsets, uint32_t n_req,
+                                   uint32_t* __restrict__ tile_req, uint32_t* __restrict__ tile_item0,
+                                   uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ n_tiles,
+                                   uint32_t* __restrict__ req_tile0) {
+    // pass 1: per-request tile counts → exclusive prefix in req_tile0 (serial, n_req is small)
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t r = 0; r < n_req; ++r) {
+            req_tile0[r] = acc;
+            acc += (req_offsets[r + 1] - req_offsets[r] + kBM - 1) / kBM;
+        }
+        *n_tiles = acc;
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < n_req; r += blockDim.x) {
+        const uint32_t b = req_offsets[r], e = req_offsets[r + 1];
+        uint32_t t = req_tile0[r];
+        for (uint32_t i = b; i < e; i += kBM, ++t) {
+            tile_req[t] = r;
+            tile_item0[t] = i;
+            tile_cnt[t] = (e - i < (uint32_t)kBM) ? e - i : (uint32_t)kBM;
+        }
+    }
+}
+
+// DNN3 request-constant half of layer 1: c1[r][j] = chain(b1[j]; P(u[r][k]) * W1u[k][j], k asc)
+// (W1u is stored already rounded to the model's operand precision)
+__global__ void dnn3_user_partial_kernel(const float* __restrict__ user, uint32_t du,
+                                         const float* __restrict__ w1u, const float* __restrict__ b1,
+                                         uint32_t h1, int prec, float* __restrict__ c1) {
+    const uint32_t r = blockIdx.x;
+    const uint32_t j = blockIdx.y * blockDim.x + threadIdx.x;
+    if (j >= h1) return;
+    float acc = b1[j];
+    for (uint32_t k = 0; k < du; ++k)
+        acc = __fmaf_rn(round_prec(user[(size_t)r * du + k], prec), w1u[(size_t)k * h1 + j], acc);
+    c1[(size_t)r * h1 + j] = acc;
+}
+
+// two-tower request side: user tower output uo[r][t_out] and the user prefix of the FM sums.
+__global__ __launch_bounds__(256) void fm2t_user_kernel(
+    const float* __restrict__ user, uint32_t du, const float* __restrict__ uw1,
+    const float* __restrict__ ub1, const float* __restrict__ uw2, const float* __restrict__ ub2,
+    uint32_t th, uint32_t to, int prec, const float* const* __restrict__ field_emb,
+    const float* const* __restrict__ field_lin, const int32_t* __restrict__ user_field_ids,
+    uint32_t vocab, float fm_b, float* __restrict__ uo, float* __restrict__ fm_user) {
+    __shared__ float u1[1024];
+    const uint32_t r = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t j = tid; j < th; j += blockDim.x) {
+        float acc = ub1[j];
+        for (uint32_t k = 0; k < du; ++k)
+            acc = __fmaf_rn(round_prec(user[(size_t)r * du + k], prec), uw1[(size_t)k * th + j], acc);
+        u1[j] = round_prec(acc > 0.0f ? acc : 0.0f, prec);
+    }
+    __syncthreads();
+    for (uint32_t o = tid; o < to; o += blockDim.x) {
+        float acc = ub2[o];
+        for (uint32_t j = 0; j < th; ++j) acc = __fmaf_rn(u1[j], uw2[(size_t)j * to + o], acc);
+        uo[(size_t)r * to + o] = acc;
+    }
+    if (tid < kFmK) {
+        float s = 0.0f, q = 0.0f;
+        for (int f = 0; f < kFmFields; ++f) {
+            int32_t id = user_field_ids[(size_t)r * kFmFields + f];
+            id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
+            const float v = field_emb[f][(size_t)id * kFmK + tid];
+            s = s + v;
+            q = __fmaf_rn(v, v, q);
+        }
+        fm_user[(size_t)r * 33 + 1 + tid] = s;
+        fm_user[(size_t)r * 33 + 17 + tid] = q;
+    }
+    if (tid == 32) {
+        float lin = fm_b;
+        for (int f = 0; f < kFmFields; ++f) {
+            int32_t id = user_field_ids[(size_t)r * kFmFields + f];
+            id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
+            lin = lin + field_lin[f][id];
+        }
+        fm_user[(size_t)r * 33] = lin;
+    }
+}
+
+}  // namespace pg
+
+// ---------------------------------------------------------------------------------------------
+// host side: model blobs, weight pre-packing, launches
+// ---------------------------------------------------------------------------------------------
+struct pg_model {
+    pg_model_kind kind;
+    int prec;
+    uint32_t d_user = 0, d_item = 0, h1 = 0, h2 = 0;           // DNN3
+    uint32_t nuf = 0, nif = 0, k = 0, th = 0, to = 0, vocab = 0;  // two-tower
+    float b3 = 0.f, fm_b = 0.f;
+    // device buffers
+    float* w1u = nullptr;   // [d_user][h1] (DNN3) / uw1 (two-tower), operand-rounded fp32
+    float* b1 = nullptr;    // b1 / ub1
+    float* uw2 = nullptr;   // two-tower user layer 2
+    float* ub2 = nullptr;
+    void* w1p = nullptr;    // packed item-side layer 1
+    void* w2p = nullptr;    // packed layer 2
+    float* c1_shared = nullptr;   // two-tower: ib1
+    float* b2 = nullptr;
+    float* w3 = nullptr;    // DNN3 head
+    float* fields = nullptr;          // two-tower: all field tables, one allocation
+    const float** d_field_emb = nullptr;
+    const float** d_field_lin = nullptr;
+    std::vector<void*> allocs;
+};
+
+namespace pg {
+
+// Pack W[K][N] (row-major, k major) into MFMA B-fragment order, 1 KiB per (n-block, k-group).
+//   bf16: fragment (nbg, ks): lane (j,hk) holds W[ks*16 + 8*hk + e][nbg*32 + j], e = 0..7
+//   f32 : fragment (nbg, g8): lane (j,h)  holds W[g8*8 + 2*st + h][nbg*32 + j], st = 0..3
+static std::vector<uint8_t> pack_weights(const float* w, uint32_t K, uint32_t N, int prec) {
+    const uint32_t kg = prec ? K / 16 : K / 8;
+    std::vector<uint8_t> out((size_t)(N / 32) * kg * 1024);
+    for (uint32_t nbg = 0; nbg < N / 32; ++nbg)
+        for (uint32_t g = 0; g < kg; ++g) {
+            uint8_t* frag = out.data() + ((size_t)nbg * kg + g) * 1024;
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                const uint32_t j = lane & 31, hh = lane >> 5;
+                if (prec) {
+                    uint16_t* d = reinterpret_cast<uint16_t*>(frag + lane * 16);
+                    for (uint32_t e = 0; e < 8; ++e)
+                        d[e] = f32_to_bf16_rne(w[(size_t)(g * 16 + 8 * hh + e) * N + nbg * 32 + j]);
+                } else {
+                    float* d = reinterpret_cast<float*>(frag + lane * 16);
+                    for (uint32_t st = 0; st < 4; ++st)
+                        d[st] = w[(size_t)(g * 8 + 2 * st + hh) * N + nbg * 32 + j];
+                }
+            }
+        }
+    return out;
+}
+
+static int upload(pg_ctx* ctx, pg_model* m, const void* src, size_t bytes, void** dst) {
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        set_error("pg_model_load: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return PG_ERR_NOMEM;
+    }
+    m->allocs.push_back(d);
+    if (bytes) PG_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    *dst = d;
+    return PG_OK;
+}
+
+static std::vector<float> rounded(const float* w, size_t n, int prec) {
+    std::vector<float> o(n);
+    for (size_t i = 0; i < n; ++i) o[i] = round_prec(w[i], prec);
+    return o;
+}
+
+template <typename K>
+static int set_lds_attr(K kernel, size_t bytes) {
+    PG_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PG_OK;
+}
+
+struct RankScratch {
+    uint32_t *tile_req, *tile_item0, *tile_cnt, *n_tiles, *req_tile0;
+    float* c1;       // [n_req][h1]  (DNN3) or uo [n_req][to] (two-tower)
+    float* fm_user;  // [n_req][33]
+};
+
+static int rank_scratch(pg_ctx* ctx, uint32_t n_req, uint32_t max_tiles, uint32_t per_req_floats,
+                        RankScratch* rs) {
+    void* p;
+    int rc;
+    const size_t ints = (size_t)3 * max_tiles + 64 + n_req;
+    const size_t bytes = ints * 4 + ((size_t)n_req * per_req_floats + (size_t)n_req * 33) * 4 + 256;
+    if ((rc = scratch_reserve(ctx, 6, bytes, &p))) return rc;
+    uint32_t* u = (uint32_t*)p;
+    rs->tile_req = u;
+    rs->tile_item0 = u + max_tiles;
+    rs->tile_cnt = u + 2 * (size_t)max_tiles;
+    rs->n_tiles = u + 3 * (size_t)max_tiles;
+    rs->req_tile0 = rs->n_tiles + 64;
+    rs->c1 = (float*)(rs->req_tile0 + n_req);
+    rs->fm_user = rs->c1 + (size_t)n_req * per_req_floats;
+    return PG_OK;
+}
+
+static int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
+                                const float* d_user, const uint32_t* d_cand, const uint32_t* d_off,
+                                uint32_t n_req, uint32_t n_items, float* d_out) {
+    if (n_items == 0 || n_req == 0) return PG_OK;
+    const uint32_t max_tiles = n_items / kBM + n_req;
+    RankScratch rs;
+    int rc;
+    if ((rc = rank_scratch(ctx, n_req, max_tiles, m->h1, &rs))) return rc;
+    PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    build_tiles_kernel<<<1, 256, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
+                                                   rs.n_tiles, rs.req_tile0);
+    dnn3_user_partial_kernel<<<dim3(n_req, (m->h1 + 255) / 256), 256, 0, ctx->stream>>>(
+        d_user, m->d_user, m->w1u, m->b1, m->h1, m->prec, rs.c1);
+    MlpArgs a{};
+    a.tile_req = rs.tile_req;
+    a.tile_item0 = rs.tile_item0;
+    a.tile_cnt = rs.tile_cnt;
+    a.n_tiles = rs.n_tiles;
+    a.tab = t->d;
+    a.tab_rows = (uint32_t)t->rows;
+    a.cand_rows = d_cand;
+    a.c1 = rs.c1;
+    a.c1_stride = m->h1;
+    a.w3 = m->w3;
+    a.w3_stride = 0;
+    a.b3 = m->b3;
+    a.b2 = m->b2;
+    a.w1p = m->w1p;
+    a.w2p = m->w2p;
+    a.out = d_out;
+    if (m->prec) {
+        constexpr size_t lds = mlp_lds_bytes(1, 256);
+        static bool once = false;
+        if (!once) { if ((rc = set_lds_attr(mlp_kernel<1, 512, 256, true, 1, 4, 1>, lds))) return rc; once = true; }
+        mlp_kernel<1, 512, 256, true, 1, 4, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
+    } else {
+        constexpr size_t lds = mlp_lds_bytes(0, 256);
+        static bool once = false;
+        if (!once) { if ((rc = set_lds_attr(mlp_kernel<0, 512, 256, true, 1, 4, 1>, lds))) return rc; once = true; }
+        mlp_kernel<0, 512, 256, true, 1, 4, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
+    }
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->stats.rank_calls++;
+    ctx->stats.rank_items += n_items;
+    return PG_OK;
+}
+
+static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_user,
+                                const int32_t* d_ufids, const int32_t* d_ifids, const uint32_t* d_off,
+                                uint32_t n_req, uint32_t n_items, float* d_out) {
+    if (n_items == 0 || n_req == 0) return PG_OK;
+    const uint32_t max_tiles = n_items / kBM + n_req;
+    RankScratch rs;
+    int rc;
+    if ((rc = rank_scratch(ctx, n_req, max_tiles, m->to, &rs))) return rc;
+    PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    build_tiles_kernel<<<1, 256, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
+                                                   rs.n_tiles, rs.req_tile0);
+    fm2t_user_kernel<<<n_req, 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th,
+                                                     m->to, m->prec, m->d_field_emb, m->d_field_lin, d_ufids,
+                                                     m->vocab, m->fm_b, rs.c1, rs.fm_user);
+    MlpArgs a{};
+    a.tile_req = rs.tile_req;
+    a.tile_item0 = rs.tile_item0;
+    a.tile_cnt = rs.tile_cnt;
+    a.n_tiles = rs.n_tiles;
+    a.field_emb = m->d_field_emb;
+    a.field_lin = m->d_field_lin;
+    a.item_field_ids = d_ifids;
+    a.vocab = m->vocab;
+    a.fm_user = rs.fm_user;
+    a.c1 = m->c1_shared;
+    a.c1_stride = 0;
+    a.w3 = rs.c1;            // user-tower output per request
+    a.w3_stride = m->to;
+    a.b2 = m->b2;
+    a.w1p = m->w1p;
+    a.w2p = m->w2p;
+    a.out = d_out;
+    if (m->prec) {
+        constexpr size_t lds = mlp_lds_bytes(1, 64);
+        static bool once = false;
+        if (!once) { if ((rc = set_lds_attr(mlp_kernel<1, 256, 64, false, 2, 2, 2>, lds))) return rc; once = true; }
+        mlp_kernel<1, 256, 64, false, 2, 2, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
+    } else {
+        constexpr size_t lds = mlp_lds_bytes(0, 64);
+        static bool once = false;
+        if (!once) { if ((rc = set_lds_attr(mlp_kernel<0, 256, 64, false, 2, 2, 2>, lds))) return rc; once = true; }
+        mlp_kernel<0, 256, 64, false, 2, 2, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
+    }
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->stats.rank_calls++;
+    ctx->stats.rank_items += n_items;
+    return PG_OK;
+}
+
+static int finish_rank_timing(pg_ctx* ctx) {
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    PG_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    ctx->stats.last_rank_ms = ms;
+    return PG_OK;
+}
+
+}  // namespace pg
+
+extern "C" {
+
+int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blob, size_t len,
+                  pg_model** out) {
+    PG_REQUIRE(ctx && blob && out, "pg_model_load: NULL argument");
+    PG_REQUIRE(prec == PG_PREC_F32 || prec == PG_PREC_BF16, "pg_model_load: bad precision %d", (int)prec);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    PG_HIP(hipSetDevice(ctx->device));
+    const uint8_t* p = (const uint8_t*)blob;
+    pg_model* m = new pg_model();
+    m->kind = kind;
+    m->prec = (int)prec;
+    int rc = PG_OK;
+    auto fail = [&](int code) {
+        for (void* a : m->allocs) hipFree(a);
+        delete m;
+        return code;
+    };
+    if (kind == PG_MODEL_DNN3) {
+        if (len < 16) { pg::set_error("pg_model_load: blob too short"); return fail(PG_ERR_INVALID); }
+        uint32_t hdr[4];
+        memcpy(hdr, p, 16);
+        m->d_user = hdr[0]; m->d_item = hdr[1]; m->h1 = hdr[2]; m->h2 = hdr[3];
+        if (m->d_item != 128 || m->h1 != 512 || m->h2 != 256 || m->d_user == 0 || m->d_user > 4096) {
+            pg::set_error("pg_model_load: DNN3 shape [%u+%u]->%u->%u->1 unsupported (kernels are built for "
+                          "[d_user+128]->512->256->1)", m->d_user, m->d_item, m->h1, m->h2);
+            return fail(PG_ERR_UNSUPPORTED);
+        }
+        const size_t din = (size_t)m->d_user + m->d_item;
+        const size_t need = 16 + (din * m->h1 + m->h1 + (size_t)m->h1 * m->h2 + m->h2 + m->h2 + 1) * 4;
+        if (len != need) { pg::set_error("pg_model_load: DNN3 blob is %zu bytes, expected %zu", len, need); return fail(PG_ERR_INVALID); }
+        const float* w1 = (const float*)(p + 16);
+        const float* b1 = w1 + din * m->h1;
+        const float* w2 = b1 + m->h1;
+        const float* b2 = w2 + (size_t)m->h1 * m->h2;
+        const float* w3 = b2 + m->h2;
+        m->b3 = w3[m->h2];
+        auto w1u = pg::rounded(w1, (size_t)m->d_user * m->h1, m->prec);
+        auto w1p = pg::pack_weights(w1 + (size_t)m->d_user * m->h1, m->d_item, m->h1, m->prec);
+        auto w2p = pg::pack_weights(w2, m->h1, m->h2, m->prec);
+        if ((rc = pg::upload(ctx, m, w1u.data(), w1u.size() * 4, (void**)&m->w1u))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, b1, m->h1 * 4, (void**)&m->b1))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, w1p.data(), w1p.size(), &m->w1p))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, w2p.data(), w2p.size(), &m->w2p))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, b2, m->h2 * 4, (void**)&m->b2))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, w3, m->h2 * 4, (void**)&m->w3))) return fail(rc);
+    } else if (kind == PG_MODEL_FM_TWOTOWER) {
+        if (len < 32) { pg::set_error("pg_model_load: blob too short"); return fail(PG_ERR_INVALID); }
+        uint32_t hdr[7];
+        memcpy(hdr, p, 28);
+        memcpy(&m->fm_b, p + 28, 4);
+        m->nuf = hdr[0]; m->nif = hdr[1]; m->k = hdr[2]; m->d_user = hdr[3];
+        m->th = hdr[4]; m->to = hdr[5]; m->vocab = hdr[6];
+        if (m->nuf != 8 || m->nif != 8 || m->k != 16 || m->th != 256 || m->to != 64 || m->d_user == 0 ||
+            m->d_user > 4096 || m->vocab == 0) {
+            pg::set_error("pg_model_load: two-tower shape unsupported (kernels are built for 8+8 fields, k=16, "
+                          "towers ->256->64)");
+            return fail(PG_ERR_UNSUPPORTED);
+        }
+        const size_t din = (size_t)m->nif * m->k;
+        const size_t nf = m->nuf + m->nif;
+        const size_t wfl = (size_t)m->d_user * m->th + m->th + (size_t)m->th * m->to + m->to + din * m->th +
+                           m->th + (size_t)m->th * m->to + m->to;
+        const size_t field_fl = nf * ((size_t)m->vocab * m->k + m->vocab);
+        const size_t need = 32 + (wfl + field_fl) * 4;
+        if (len != need) { pg::set_error("pg_model_load: two-tower blob is %zu bytes, expected %zu", len, need); return fail(PG_ERR_INVALID); }
+        const float* uw1 = (const float*)(p + 32);
+        const float* ub1 = uw1 + (size_t)m->d_user * m->th;
+        const float* uw2 = ub1 + m->th;
+        const float* ub2 = uw2 + (size_t)m->th * m->to;
+        const float* iw1 = ub2 + m->to;
+        const float* ib1 = iw1 + din * m->th;
+        const float* iw2 = ib1 + m->th;
+        const float* ib2 = iw2 + (size_t)m->th * m->to;
+        const float* fields = ib2 + m->to;
+        auto ruw1 = pg::rounded(uw1, (size_t)m->d_user * m->th, m->prec);
+        auto ruw2 = pg::rounded(uw2, (size_t)m->th * m->to, m->prec);
+        auto iw1p = pg::pack_weights(iw1, (uint32_t)din, m->th, m->prec);
+        auto iw2p = pg::pack_weights(iw2, m->th, m->to, m->prec);
+        if ((rc = pg::upload(ctx, m, ruw1.data(), ruw1.size() * 4, (void**)&m->w1u))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, ub1, m->th * 4, (void**)&m->b1))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, ruw2.data(), ruw2.size() * 4, (void**)&m->uw2))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, ub2, m->to * 4, (void**)&m->ub2))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, iw1p.data(), iw1p.size(), &m->w1p))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, ib1, m->th * 4, (void**)&m->c1_shared))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, iw2p.data(), iw2p.size(), &m->w2p))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, ib2, m->to * 4, (void**)&m->b2))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, fields, field_fl * 4, (void**)&m->fields))) return fail(rc);
+        std::vector<const float*> pe(nf), pl(nf);
+        for (size_t f = 0; f < nf; ++f) {
+            pe[f] = m->fields + f * ((size_t)m->vocab * m->k + m->vocab);
+            pl[f] = pe[f] + (size_t)m->vocab * m->k;
+        }
+        if ((rc = pg::upload(ctx, m, pe.data(), nf * sizeof(float*), (void**)&m->d_field_emb))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, pl.data(), nf * sizeof(float*), (void**)&m->d_field_lin))) return fail(rc);
+    } else {
+        pg::set_error("pg_model_load: unknown model kind %d", (int)kind);
+        return fail(PG_ERR_INVALID);
+    }
+    *out = m;
+    return PG_OK;
+}
+
+int pg_model_destroy(pg_ctx* ctx, pg_model* m) {
+    PG_REQUIRE(ctx, "pg_model_destroy: ctx is NULL");
+    if (!m) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    for (void* a : m->allocs) PG_HIP(hipFree(a));
+    delete m;
+    return PG_OK;
+}
+
+int pg_rank_dnn3_dev(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float* d_user_vecs,
+                     const uint32_t* d_cand_rows, const uint32_t* d_req_offsets, uint32_t n_req,
+                     uint32_t n_items, float* d_out_scores) {
+    PG_REQUIRE(ctx && m && t && d_user_vecs && d_cand_rows && d_req_offsets && d_out_scores,
+               "pg_rank_dnn3_dev: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_DNN3, "pg_rank_dnn3_dev: model is not DNN3");
+    PG_REQUIRE(t->dim == m->d_item, "pg_rank_dnn3_dev: table dim %u != model d_item %u", t->dim, m->d_item);
+    PG_REQUIRE(n_req <= 65535, "pg_rank_dnn3_dev: at most 65535 requests per call");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return pg::rank_dnn3_dev_locked(ctx, m, t, d_user_vecs, d_cand_rows, d_req_offsets, n_req, n_items,
+                                    d_out_scores);
+}
+
+int pg_rank_dnn3(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float* user_vecs,
+                 const uint32_t* cand_rows, const uint32_t* req_offsets, uint32_t n_req,
+                 float* out_scores) {
+    PG_REQUIRE(ctx && m && t && req_offsets, "pg_rank_dnn3: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_DNN3, "pg_rank_dnn3: model is not DNN3");
+    PG_REQUIRE(t->dim == m->d_item, "pg_rank_dnn3: table dim %u != model d_item %u", t->dim, m->d_item);
+    PG_REQUIRE(n_req <= 65535, "pg_rank_dnn3: at most 65535 requests per call");
+    if (n_req == 0) return PG_OK;
+    PG_REQUIRE(req_offsets[0] == 0, "pg_rank_dnn3: req_offsets[0] must be 0");
+    for (uint32_t r = 0; r < n_req; ++r)
+        PG_REQUIRE(req_offsets[r + 1] >= req_offsets[r], "pg_rank_dnn3: req_offsets not monotone at %u", r);
+    const uint32_t n_items = req_offsets[n_req];
+    if (n_items == 0) return PG_OK;
+    PG_REQUIRE(user_vecs && cand_rows && out_scores, "pg_rank_dnn3: NULL argument");
+    for (uint32_t i = 0; i < n_items; ++i)
+        PG_REQUIRE(cand_rows[i] < t->rows, "pg_rank_dnn3: candidate %u row %u outside table of %llu rows", i,
+                   cand_rows[i], (unsigned long long)t->rows);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    int rc;
+    const size_t ub = (size_t)n_req * m->d_user * 4, cb = (size_t)n_items * 4, ob = (size_t)(n_req + 1) * 4;
+    const size_t sb = (size_t)n_items * 4;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    if ((rc = pg::scratch_reserve(ctx, 5, al(ub) + al(cb) + al(ob) + al(sb), &buf))) return rc;
+    char* b = (char*)buf;
+    float* d_u = (float*)b;
+    uint32_t* d_c = (uint32_t*)(b + al(ub));
+    uint32_t* d_o = (uint32_t*)(b + al(ub) + al(cb));
+    float* d_s = (float*)(b + al(ub) + al(cb) + al(ob));
+    PG_HIP(hipMemcpyAsync(d_u, user_vecs, ub, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_c, cand_rows, cb, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_o, req_offsets, ob, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pg::rank_dnn3_dev_locked(ctx, m, t, d_u, d_c, d_o, n_req, n_items, d_s))) return rc;
+    PG_HIP(hipMemcpyAsync(out_scores, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
+    return pg::finish_rank_timing(ctx);
+}
+
+int pg_rank_fm2t_dev(pg_ctx* ctx, const pg_model* m, const float* d_user_vecs,
+                     const int32_t* d_user_field_ids, const int32_t* d_item_field_ids,
+                     const uint32_t* d_req_offsets, uint32_t n_req, uint32_t n_items,
+                     float* d_out_scores) {
+    PG_REQUIRE(ctx && m && d_user_vecs && d_user_field_ids && d_item_field_ids && d_req_offsets && d_out_scores,
+               "pg_rank_fm2t_dev: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER, "pg_rank_fm2t_dev: model is not FM_TWOTOWER");
+    PG_REQUIRE(n_req <= 65535, "pg_rank_fm2t_dev: at most 65535 requests per call");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return pg::rank_fm2t_dev_locked(ctx, m, d_user_vecs, d_user_field_ids, d_item_field_ids, d_req_offsets,
+                                    n_req, n_items, d_out_scores);
+}
+
+int pg_rank_fm2t(pg_ctx* ctx, const pg_model* m, const float* user_vecs, const int32_t* user_field_ids,
+                 const int32_t* item_field_ids, const uint32_t* req_offsets, uint32_t n_req,
+                 float* out_scores) {
+    PG_REQUIRE(ctx && m && req_offsets, "pg_rank_fm2t: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER, "pg_rank_fm2t: model is not FM_TWOTOWER");
+    PG_REQUIRE(n_req <= 65535, "pg_rank_fm2t: at most 65535 requests per call");
+    if (n_req == 0) return PG_OK;
+    PG_REQUIRE(req_offsets[0] == 0, "pg_rank_fm2t: req_offsets[0] must be 0");
+    for (uint32_t r = 0; r < n_req; ++r)
+        PG_REQUIRE(req_offsets[r + 1] >= req_offsets[r], "pg_rank_fm2t: req_offsets not monotone at %u", r);
+    const uint32_t n_items = req_offsets[n_req];
+    if (n_items == 0) return PG_OK;
+    PG_REQUIRE(user_vecs && user_field_ids && item_field_ids && out_scores, "pg_rank_fm2t: NULL argument");
+    for (size_t i = 0; i < (size_t)n_req * m->nuf; ++i)
+        PG_REQUIRE(user_field_ids[i] >= 0 && (uint32_t)user_field_ids[i] < m->vocab,
+                   "pg_rank_fm2t: user field id %d outside vocab %u", user_field_ids[i], m->vocab);
+    for (size_t i = 0; i < (size_t)n_items * m->nif; ++i)
+        PG_REQUIRE(item_field_ids[i] >= 0 && (uint32_t)item_field_ids[i] < m->vocab,
+                   "pg_rank_fm2t: item field id %d outside vocab %u", item_field_ids[i], m->vocab);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    int rc;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t ub = (size_t)n_req * m->d_user * 4, ufb = (size_t)n_req * m->nuf * 4;
+    const size_t ifb = (size_t)n_items * m->nif * 4, ob = (size_t)(n_req + 1) * 4, sb = (size_t)n_items * 4;
+    if ((rc = pg::scratch_reserve(ctx, 5, al(ub) + al(ufb) + al(ifb) + al(ob) + al(sb), &buf))) return rc;
+    char* b = (char*)buf;
+    float* d_u = (float*)b; b += al(ub);
+    int32_t* d_uf = (int32_t*)b; b += al(ufb);
+    int32_t* d_if = (int32_t*)b; b += al(ifb);
+    uint32_t* d_o = (uint32_t*)b; b += al(ob);
+    float* d_s = (float*)b;
+    PG_HIP(hipMemcpyAsync(d_u, user_vecs, ub, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_uf, user_field_ids, ufb, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_if, item_field_ids, ifb, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_o, req_offsets, ob, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pg::rank_fm2t_dev_locked(ctx, m, d_u, d_uf, d_if, d_o, n_req, n_items, d_s))) return rc;
+    PG_HIP(hipMemcpyAsync(out_scores, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
+    return pg::finish_rank_timing(ctx);
+}
+
+}  // extern "C"

@@ -71,9 +71,9 @@ struct ScanArgs {
 };
 
 // Issue the 8 LDS-DMA instructions of one piece.  `base` is the wave-uniform byte address of the
-// piece's first row (column 0), voff[n] the per-lane byte offsets, IMM the column-half offset.
+// piece's first row at the piece's first column, voff[n] the per-lane byte offsets.  (The
+// instruction's immediate offset is NOT used: on an LDS-DMA it is added to the LDS address too.)
 // M0 carries the LDS destination; it is saved/restored because hipcc owns it outside this asm.
-template <int IMM>
 __device__ __forceinline__ void dma_piece(const char* base, uint32_t lds_addr, const uint32_t (&voff)[8]) {
     uint32_t keep;
     asm volatile(
@@ -81,32 +81,32 @@ __device__ __forceinline__ void dma_piece(const char* base, uint32_t lds_addr, c
         "s_waitcnt lgkmcnt(0)\n\t"
         "s_mov_b32 m0, %10\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %9 offset:%11\n\t"
+        "global_load_lds_dwordx4 %1, %9\n\t"
         "s_add_u32 m0, m0, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %9 offset:%11\n\t"
+        "global_load_lds_dwordx4 %2, %9\n\t"
         "s_add_u32 m0, m0, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %9 offset:%11\n\t"
+        "global_load_lds_dwordx4 %3, %9\n\t"
         "s_add_u32 m0, m0, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, %9 offset:%11\n\t"
+        "global_load_lds_dwordx4 %4, %9\n\t"
         "s_add_u32 m0, m0, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %5, %9 offset:%11\n\t"
+        "global_load_lds_dwordx4 %5, %9\n\t"
         "s_add_u32 m0, m0, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %6, %9 offset:%11\n\t"
+        "global_load_lds_dwordx4 %6, %9\n\t"
         "s_add_u32 m0, m0, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %7, %9 offset:%11\n\t"
+        "global_load_lds_dwordx4 %7, %9\n\t"
         "s_add_u32 m0, m0, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %8, %9 offset:%11\n\t"
+        "global_load_lds_dwordx4 %8, %9\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]),
-          "v"(voff[6]), "v"(voff[7]), "s"(base), "s"(lds_addr), "i"(IMM)
+          "v"(voff[6]), "v"(voff[7]), "s"(base), "s"(lds_addr)
         : "memory");
 }
 
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a) {
         uint32_t b = t / PPB;
         if (b >= nblk) b = nblk - 1;                       // tail: harmless re-read
         const uint64_t rb = (uint64_t)a.rb_begin + gw + (uint64_t)b * W;
-        return (const char*)a.tab + rb * (uint64_t)(kPieceRows * DIM * 4);
+        return (const char*)a.tab + rb * (uint64_t)(kPieceRows * DIM * 4) + (t % PPB) * (kPieceCols * 4);
     };
     auto issue = [&](uint32_t t) {
         const char* base = piece_base(t);
@@ -172,14 +172,7 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a) {
         const char* ub = (const char*)(((uint64_t)hi << 32) | lo);
         const uint32_t slot = __builtin_amdgcn_readfirstlane(t % NS);
         const uint32_t dst = lds_wave_u + slot * kPieceBytes;
-        const uint32_t half = t % PPB;
-        // column half selects the immediate (0, 256, 512, 768 bytes)
-        switch (half) {
-            case 0: dma_piece<0>(ub, dst, voff); break;
-            case 1: dma_piece<256>(ub, dst, voff); break;
-            case 2: dma_piece<512>(ub, dst, voff); break;
-            default: dma_piece<768>(ub, dst, voff); break;
-        }
+        dma_piece(ub, dst, voff);
     };
 
     // wave-private staging list for threshold hits (keys + query ids)

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void table_fill_synth_kernel(float* __restrict
             const float v = synth_value(seed, g, c, DIM);
             ss = __fmaf_rn(v, v, ss);
         }
-        inv = __fdiv_rn(1.0f, __fsqrt_rn(ss));
+        inv = 1.0f / sqrtf(ss);   // IEEE-rounded sqrt and divide (hipcc default for fp32)
     }
     inv_s[threadIdx.x] = inv;
     __syncthreads();
