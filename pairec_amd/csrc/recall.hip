@@ -107,7 +107,7 @@ __device__ __forceinline__ void dma_piece(const char* base, uint32_t lds_addr, c
         : "=&s"(keep)
         : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]),
           "v"(voff[6]), "v"(voff[7]), "s"(base), "s"(lds_addr)
-        : "memory");
+        : "memory", "scc");      // s_add_u32 writes SCC
 }
 
 template <int N>
