@@ -1,0 +1,415 @@
+// expr.hip — RankConfig.RankScore score fusion: compile on the host, evaluate per item on device.
+//
+// Replaces ast.GetExpAST / ExprASTResult (utils/ast/ast.go:215-268,368-389; lexer
+// utils/ast/parse.go:40-158), evaluated once per candidate in RankService.Rank
+// (service/rank/rank_service.go:339-363).  Grammar and quirks follow the reference:
+//   operators  # ( ) + - * / ^ %   with precedence {+,-:20  *,/,%:40  ^:60  #:80} (ast.go:81),
+//   all binary operators left-associative (parseBinOpRHS, ast.go:169-197);
+//   literals start with a digit and extend over [0-9._e] ('_' removed); `${name}` parameters;
+//   a malformed literal or an operator in operand position yields the number 0 WITHOUT consuming
+//   the token (parseNumber, ast.go:108-124) and the recorded error is ignored by GetExpAST — so
+//   "-5" is 0-5 and "2*1e-5" is 2*0;  `#` = first non-zero, `^` = math.Pow, `%` = int(l) % int(r);
+//   `/` by zero and `%` by zero panic in the reference → PG_ERR_ARITH here.
+// The antlr evaluator (ASTType "antlr", go-antlr-valuate, not vendored) is out of scope.
+#include "common.hpp"
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+namespace pg {
+
+enum OpCode : uint32_t { OP_CONST = 0, OP_VAR, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD, OP_POW, OP_FNZ };
+
+struct Instr {
+    uint32_t op;
+    uint32_t arg;     // variable index
+    double val;       // constant
+};
+
+constexpr int kMaxStack = 32;
+constexpr int kMaxProg = 128;
+
+}  // namespace pg
+
+struct pg_expr {
+    std::string source;
+    std::vector<pg::Instr> prog;
+    std::vector<std::string> vars;
+    int max_depth = 0;
+    bool empty = false;       // "" → no expression (GetExpAST returns nil)
+};
+
+namespace pg {
+
+// ---- lexer (parse.go:40-158) -----------------------------------------------------------------
+enum TokType { T_LITERAL = 0, T_OPERATOR = 1, T_PARAMETER = 2 };
+struct Token {
+    std::string tok;
+    TokType type;
+};
+
+static bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; }
+static bool is_lit(char c) { return (c >= '0' && c <= '9') || c == '.' || c == '_' || c == 'e'; }
+
+static int tokenize(const std::string& s, std::vector<Token>* out) {
+    size_t off = 0;
+    const size_t n = s.size();
+    while (off < n) {
+        char last_ws = 0;
+        while (off < n && is_ws(s[off])) last_ws = s[off++];
+        if (off >= n) {
+            // the reference re-examines its stale `ch`: only a plain space is tolerated
+            if (last_ws != 0 && last_ws != ' ') {
+                set_error("pg_expr_compile: symbol error: unknown trailing whitespace 0x%02x", last_ws);
+                return PG_ERR_PARSE;
+            }
+            break;
+        }
+        const char ch = s[off];
+        const size_t start = off;
+        if (ch == '#' || ch == '(' || ch == ')' || ch == '+' || ch == '-' || ch == '*' || ch == '/' ||
+            ch == '^' || ch == '%') {
+            out->push_back({std::string(1, ch), T_OPERATOR});
+            ++off;
+        } else if (ch >= '0' && ch <= '9') {
+            while (off < n && is_lit(s[off])) ++off;
+            std::string t;
+            for (size_t i = start; i < off; ++i)
+                if (s[i] != '_') t.push_back(s[i]);
+            out->push_back({t, T_LITERAL});
+        } else if (ch == '$') {
+            ++off;
+            if (off < n && s[off] == '{') {
+                while (off < n && s[off] != '}') ++off;
+                out->push_back({s.substr(start + 2, off - (start + 2)), T_PARAMETER});
+                ++off;
+            } else {
+                break;       // nil token: lexing stops silently (parse.go:112-124)
+            }
+        } else {
+            set_error("pg_expr_compile: symbol error: unknown '%c', pos [%zu:]", ch, start);
+            return PG_ERR_PARSE;
+        }
+    }
+    return PG_OK;
+}
+
+// strconv.ParseFloat over the literal alphabet; false where Go reports an error
+static bool go_parse_float(const std::string& t, double* v) {
+    size_t i = 0;
+    const size_t n = t.size();
+    size_t nd = 0;
+    while (i < n && t[i] >= '0' && t[i] <= '9') { ++i; ++nd; }
+    if (nd == 0) return false;
+    if (i < n && t[i] == '.') {
+        ++i;
+        while (i < n && t[i] >= '0' && t[i] <= '9') ++i;
+    }
+    if (i < n && t[i] == 'e') {
+        ++i;
+        size_t ne = 0;
+        while (i < n && t[i] >= '0' && t[i] <= '9') { ++i; ++ne; }
+        if (ne == 0) return false;
+    }
+    if (i != n) return false;
+    const double d = strtod(t.c_str(), nullptr);
+    if (std::isinf(d)) return false;        // ErrRange
+    *v = d;
+    return true;
+}
+
+// ---- parser (ast.go:84-197) → postfix program ------------------------------------------------
+struct Node {
+    int kind;            // 0 number, 1 parameter, 2 binary
+    double val = 0;
+    std::string name;
+    char op = 0;
+    int lhs = -1, rhs = -1;
+};
+
+struct Parser {
+    const std::vector<Token>& toks;
+    size_t i = 0;
+    std::vector<Node> nodes;
+    explicit Parser(const std::vector<Token>& t) : toks(t) {}
+    const Token& cur() const { return toks[i < toks.size() ? i : toks.size() - 1]; }   // stale currTok
+    bool next() {
+        i = i + 1 < toks.size() + 1 ? i + 1 : toks.size();
+        return i < toks.size();
+    }
+    int prec() const {
+        const std::string& t = cur().tok;          // keyed on the text only (ast.go:100-105)
+        if (t == "+" || t == "-") return 20;
+        if (t == "*" || t == "/" || t == "%") return 40;
+        if (t == "^") return 60;
+        if (t == "#") return 80;
+        return -1;
+    }
+    int add(Node n) {
+        nodes.push_back(std::move(n));
+        return (int)nodes.size() - 1;
+    }
+    int parse_number() {
+        double v;
+        if (!go_parse_float(cur().tok, &v)) {
+            Node n;
+            n.kind = 0;
+            n.val = 0.0;
+            return add(n);                          // error recorded and ignored; token NOT consumed
+        }
+        next();
+        Node n;
+        n.kind = 0;
+        n.val = v;
+        return add(n);
+    }
+    int parse_primary() {
+        const Token t = cur();
+        if (t.type == T_LITERAL) return parse_number();
+        if (t.type == T_PARAMETER) {
+            next();
+            Node n;
+            n.kind = 1;
+            n.name = t.tok;
+            return add(n);
+        }
+        if (t.tok == "(") {
+            next();
+            const int e = parse_expression();
+            if (e < 0) return -1;
+            if (cur().tok != ")") return -1;        // "want ')'" → nil
+            next();
+            return e;
+        }
+        return parse_number();
+    }
+    int parse_expression() {
+        const int lhs = parse_primary();
+        return parse_binop_rhs(0, lhs);
+    }
+    int parse_binop_rhs(int exec_prec, int lhs) {
+        // NOTE the reference calls parseBinOpRHS(0, nil) when parsePrimary fails; lhs<0 propagates
+        for (;;) {
+            const int tp = prec();
+            if (tp < exec_prec) return lhs;
+            const char op = cur().tok[0];
+            if (!next()) return lhs;
+            int rhs = parse_primary();
+            if (rhs < 0) return -1;
+            if (tp < prec()) {
+                rhs = parse_binop_rhs(tp + 1, rhs);
+                if (rhs < 0) return -1;
+            }
+            Node n;
+            n.kind = 2;
+            n.op = op;
+            n.lhs = lhs;
+            n.rhs = rhs;
+            lhs = add(n);
+        }
+    }
+};
+
+static int emit(const Parser& p, int node, pg_expr* e, int depth, int* max_depth) {
+    if (node < 0) {
+        // nil sub-tree: ExprASTResult falls through to `return 0.0`
+        e->prog.push_back({OP_CONST, 0, 0.0});
+        *max_depth = std::max(*max_depth, depth + 1);
+        return PG_OK;
+    }
+    const Node& n = p.nodes[node];
+    if (n.kind == 0) {
+        e->prog.push_back({OP_CONST, 0, n.val});
+        *max_depth = std::max(*max_depth, depth + 1);
+    } else if (n.kind == 1) {
+        uint32_t idx = 0;
+        for (; idx < e->vars.size(); ++idx)
+            if (e->vars[idx] == n.name) break;
+        if (idx == e->vars.size()) e->vars.push_back(n.name);
+        e->prog.push_back({OP_VAR, idx, 0.0});
+        *max_depth = std::max(*max_depth, depth + 1);
+    } else {
+        int rc;
+        const size_t mark = e->prog.size();
+        if ((rc = emit(p, n.lhs, e, depth, max_depth))) return rc;
+        if ((rc = emit(p, n.rhs, e, depth + 1, max_depth))) return rc;
+        uint32_t op;
+        switch (n.op) {
+            case '+': op = OP_ADD; break;
+            case '-': op = OP_SUB; break;
+            case '*': op = OP_MUL; break;
+            case '/': op = OP_DIV; break;
+            case '%': op = OP_MOD; break;
+            case '^': op = OP_POW; break;
+            case '#': op = OP_FNZ; break;
+            default:
+                // unknown operator: ExprASTResult's default branch → 0.0 (operands have no side
+                // effects, so the whole sub-tree collapses to the constant)
+                e->prog.resize(mark);
+                e->prog.push_back({OP_CONST, 0, 0.0});
+                return PG_OK;
+        }
+        e->prog.push_back({op, 0, 0.0});
+    }
+    return PG_OK;
+}
+
+struct ExprDev {
+    Instr prog[kMaxProg];
+    uint32_t n;
+};
+
+__global__ void expr_eval_kernel(ExprDev e, const double* __restrict__ vars, uint32_t n_items,
+                                 double* __restrict__ out, uint32_t* __restrict__ err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    double st[kMaxStack];
+    int sp = 0;
+    bool bad = false;
+    for (uint32_t pc = 0; pc < e.n; ++pc) {
+        const Instr in = e.prog[pc];
+        if (in.op == OP_CONST) {
+            st[sp++] = in.val;
+        } else if (in.op == OP_VAR) {
+            st[sp++] = vars[(size_t)in.arg * n_items + i];
+        } else {
+            const double r = st[--sp];
+            const double l = st[--sp];
+            double v = 0.0;
+            switch (in.op) {
+                case OP_ADD: v = l + r; break;
+                case OP_SUB: v = l - r; break;
+                case OP_MUL: v = l * r; break;
+                case OP_DIV:
+                    if (r == 0.0) bad = true; else v = l / r;
+                    break;
+                case OP_MOD: {
+                    // float64(int(l) % int(r)); Go's float→int of NaN/out-of-range gives MinInt64 on amd64
+                    const long long li = (l == l && fabs(l) < 9223372036854775808.0) ? (long long)l : (long long)0x8000000000000000ull;
+                    const long long ri = (r == r && fabs(r) < 9223372036854775808.0) ? (long long)r : (long long)0x8000000000000000ull;
+                    if (ri == 0) bad = true;
+                    else if (ri == -1) v = 0.0;
+                    else v = (double)(li % ri);
+                    break;
+                }
+                case OP_POW: v = pow(l, r); break;
+                case OP_FNZ: v = (l != 0.0) ? l : r; break;
+            }
+            st[sp++] = v;
+        }
+    }
+    out[i] = sp > 0 ? st[sp - 1] : 0.0;
+    if (bad) atomicOr(err, 1u);
+}
+
+static int expr_eval_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items,
+                            double* d_out) {
+    void* p;
+    int rc;
+    if ((rc = scratch_reserve(ctx, 4, 256, &p))) return rc;
+    uint32_t* d_err = (uint32_t*)p + 32;
+    PG_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    if (e->empty) {
+        // GetExpAST("") == nil: the caller leaves Item.Score untouched; evaluate to 0 like
+        // ExprASTResult on a nil tree would
+        PG_HIP(hipMemsetAsync(d_out, 0, (size_t)n_items * 8, ctx->stream));
+    } else {
+        ExprDev dev;
+        dev.n = (uint32_t)e->prog.size();
+        for (size_t i = 0; i < e->prog.size(); ++i) dev.prog[i] = e->prog[i];
+        expr_eval_kernel<<<(n_items + 255) / 256, 256, 0, ctx->stream>>>(dev, d_vars, n_items, d_out, d_err);
+        PG_HIP(hipGetLastError());
+    }
+    PG_HIP(hipMemcpyAsync(ctx->h_status + 64, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_status[64] != 0) {
+        set_error("pg_expr_eval: violation of arithmetic specification: a division by zero in '%s' "
+                  "(the reference panics in ExprASTResult, utils/ast/ast.go:243-249)", e->source.c_str());
+        return PG_ERR_ARITH;
+    }
+    return PG_OK;
+}
+
+}  // namespace pg
+
+extern "C" {
+
+int pg_expr_compile(const char* source, pg_expr** out) {
+    PG_REQUIRE(source && out, "pg_expr_compile: NULL argument");
+    pg_expr* e = new pg_expr();
+    e->source = source;
+    if (e->source.empty()) {
+        e->empty = true;
+        *out = e;
+        return PG_OK;
+    }
+    std::vector<pg::Token> toks;
+    int rc = pg::tokenize(e->source, &toks);
+    if (rc) {
+        delete e;
+        return rc;
+    }
+    if (toks.empty()) {
+        // NewAST records "empty token"; ParseExpression then dereferences a nil currTok (panic)
+        pg::set_error("pg_expr_compile: empty token stream for '%s'", source);
+        delete e;
+        return PG_ERR_PARSE;
+    }
+    pg::Parser p(toks);
+    const int root = p.parse_expression();
+    int depth = 0;
+    rc = pg::emit(p, root, e, 0, &depth);
+    if (rc == PG_OK && ((int)e->prog.size() > pg::kMaxProg || depth > pg::kMaxStack)) {
+        pg::set_error("pg_expr_compile: expression too large (%zu ops, depth %d)", e->prog.size(), depth);
+        rc = PG_ERR_UNSUPPORTED;
+    }
+    if (rc) {
+        delete e;
+        return rc;
+    }
+    e->max_depth = depth;
+    *out = e;
+    return PG_OK;
+}
+
+int pg_expr_free(pg_expr* e) {
+    delete e;
+    return PG_OK;
+}
+
+int pg_expr_num_vars(const pg_expr* e) { return e ? (int)e->vars.size() : 0; }
+
+const char* pg_expr_var_name(const pg_expr* e, int i) {
+    if (!e || i < 0 || i >= (int)e->vars.size()) return "";
+    return e->vars[i].c_str();
+}
+
+int pg_expr_eval_dev(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items,
+                     double* d_out_scores) {
+    PG_REQUIRE(ctx && e && d_out_scores, "pg_expr_eval_dev: NULL argument");
+    PG_REQUIRE(e->vars.empty() || d_vars, "pg_expr_eval_dev: vars is NULL but the expression has parameters");
+    if (n_items == 0) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return pg::expr_eval_locked(ctx, e, d_vars, n_items, d_out_scores);
+}
+
+int pg_expr_eval(pg_ctx* ctx, const pg_expr* e, const double* vars, uint32_t n_items, double* out_scores) {
+    PG_REQUIRE(ctx && e && out_scores, "pg_expr_eval: NULL argument");
+    PG_REQUIRE(e->vars.empty() || vars, "pg_expr_eval: vars is NULL but the expression has parameters");
+    if (n_items == 0) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    int rc;
+    const size_t vb = e->vars.size() * (size_t)n_items * 8, ob = (size_t)n_items * 8;
+    if ((rc = pg::scratch_reserve(ctx, 5, vb + ob + 256, &buf))) return rc;
+    double* d_v = (double*)buf;
+    double* d_o = (double*)((char*)buf + ((vb + 255) & ~(size_t)255));
+    if (vb) PG_HIP(hipMemcpyAsync(d_v, vars, vb, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pg::expr_eval_locked(ctx, e, d_v, n_items, d_o))) return rc;     // scores untouched on error
+    PG_HIP(hipMemcpyAsync(out_scores, d_o, ob, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+}  // extern "C"

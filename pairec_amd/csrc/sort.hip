@@ -1,0 +1,156 @@
+// sort.hip — segmented score sort on the device.
+//
+// Replaces ItemRankScoreSort (descending; sort/item_rank_score.go:26-32, the default sort,
+// sort/sort.go:103-107) and ItemScoreSort (ascending; sort/item_score.go:36-41); both order
+// []*module.Item by the float64 Item.Score with Go's unstable sort.Sort.  Here the order is total:
+// score (±0 equal, NaN last in both directions), then input index ascending.
+// One workgroup per request; bitonic network over (ordered-u64 key, u32 index) pairs held in LDS
+// for segments up to 8192 items, in a global scratch slab beyond that.
+#include "common.hpp"
+
+namespace pg {
+
+__device__ __forceinline__ uint64_t f64_ordered_bits(double d) {
+    if (d == 0.0) d = 0.0;                        // -0 → +0 (Go's < treats them equal)
+    const uint64_t b = (uint64_t)__double_as_longlong(d);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// "a sorts before b"
+__device__ __forceinline__ bool before(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib, bool desc) {
+    if (ka != kb) return desc ? (ka > kb) : (ka < kb);
+    return ia < ib;
+}
+
+constexpr uint32_t kSortLdsMax = 8192;
+
+__global__ __launch_bounds__(1024) void sort_kernel(const double* __restrict__ scores,
+                                                    const uint32_t* __restrict__ seg_offsets,
+                                                    int desc, uint64_t* __restrict__ g_keys,
+                                                    uint32_t* __restrict__ g_idx, uint32_t g_stride,
+                                                    uint32_t* __restrict__ out_order) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t b = seg_offsets[seg], e = seg_offsets[seg + 1];
+    const uint32_t n = e - b;
+    if (n == 0) return;
+    uint32_t P = 2;
+    while (P < n) P <<= 1;
+    uint64_t* keys;
+    uint32_t* idx;
+    if (P <= kSortLdsMax) {
+        keys = reinterpret_cast<uint64_t*>(smem_raw);
+        idx = reinterpret_cast<uint32_t*>(smem_raw + (size_t)kSortLdsMax * 8);
+    } else {
+        keys = g_keys + (size_t)seg * g_stride;
+        idx = g_idx + (size_t)seg * g_stride;
+    }
+    const uint64_t pad_key = desc ? 0ull : ~0ull;       // NaN and padding sort last
+    for (uint32_t i = tid; i < P; i += 1024) {
+        if (i < n) {
+            const double s = scores[b + i];
+            keys[i] = (s != s) ? pad_key : f64_ordered_bits(s);
+            idx[i] = i;
+        } else {
+            keys[i] = pad_key;
+            idx[i] = 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < P; i += 1024) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t ka = keys[i], kb = keys[ixj];
+                    const uint32_t ia = idx[i], ib = idx[ixj];
+                    const bool fwd = (i & k) == 0;          // this sub-sequence sorts "before"-first
+                    const bool a_first = before(ka, ia, kb, ib, desc != 0);
+                    if (a_first != fwd) {
+                        keys[i] = kb; keys[ixj] = ka;
+                        idx[i] = ib; idx[ixj] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < n; i += 1024) out_order[b + i] = idx[i];
+}
+
+static int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg,
+                           uint32_t n_items, uint32_t max_seg, int desc, uint32_t* d_out) {
+    if (n_seg == 0 || n_items == 0) return PG_OK;
+    static bool attr = false;
+    constexpr size_t lds = (size_t)kSortLdsMax * 12;
+    if (!attr) {
+        PG_HIP(hipFuncSetAttribute((const void*)sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    uint64_t* g_keys = nullptr;
+    uint32_t* g_idx = nullptr;
+    uint32_t stride = 0;
+    if (max_seg > kSortLdsMax) {
+        stride = 2;
+        while (stride < max_seg) stride <<= 1;
+        void* p;
+        int rc;
+        if ((rc = scratch_reserve(ctx, 7, (size_t)n_seg * stride * 12, &p))) return rc;
+        g_keys = (uint64_t*)p;
+        g_idx = (uint32_t*)(g_keys + (size_t)n_seg * stride);
+    }
+    sort_kernel<<<n_seg, 1024, lds, ctx->stream>>>(d_scores, d_seg, desc, g_keys, g_idx, stride, d_out);
+    PG_HIP(hipGetLastError());
+    ctx->stats.sort_calls++;
+    ctx->stats.sort_items += n_items;
+    return PG_OK;
+}
+
+}  // namespace pg
+
+extern "C" {
+
+int pg_sort_scores_dev(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg_offsets, uint32_t n_seg,
+                       uint32_t n_items, int descending, uint32_t* d_out_order) {
+    PG_REQUIRE(ctx && d_scores && d_seg_offsets && d_out_order, "pg_sort_scores_dev: NULL argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    // segment sizes are not known on the host here: assume the worst case (one segment)
+    return pg::sort_dev_locked(ctx, d_scores, d_seg_offsets, n_seg, n_items, n_items, descending, d_out_order);
+}
+
+int pg_sort_scores(pg_ctx* ctx, const double* scores, const uint32_t* seg_offsets, uint32_t n_seg,
+                   int descending, uint32_t* out_order) {
+    PG_REQUIRE(ctx && seg_offsets, "pg_sort_scores: NULL argument");
+    if (n_seg == 0) return PG_OK;
+    PG_REQUIRE(seg_offsets[0] == 0, "pg_sort_scores: seg_offsets[0] must be 0");
+    uint32_t max_seg = 0;
+    for (uint32_t s = 0; s < n_seg; ++s) {
+        PG_REQUIRE(seg_offsets[s + 1] >= seg_offsets[s], "pg_sort_scores: seg_offsets not monotone at %u", s);
+        max_seg = std::max(max_seg, seg_offsets[s + 1] - seg_offsets[s]);
+    }
+    const uint32_t n = seg_offsets[n_seg];
+    if (n == 0) return PG_OK;
+    PG_REQUIRE(scores && out_order, "pg_sort_scores: NULL argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    int rc;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    if ((rc = pg::scratch_reserve(ctx, 5, al((size_t)n * 8) + al((size_t)(n_seg + 1) * 4) + al((size_t)n * 4), &buf)))
+        return rc;
+    double* d_s = (double*)buf;
+    uint32_t* d_o = (uint32_t*)((char*)buf + al((size_t)n * 8));
+    uint32_t* d_r = (uint32_t*)((char*)d_o + al((size_t)(n_seg + 1) * 4));
+    PG_HIP(hipMemcpyAsync(d_s, scores, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_o, seg_offsets, (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    if ((rc = pg::sort_dev_locked(ctx, d_s, d_o, n_seg, n, max_seg, descending, d_r))) return rc;
+    PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    PG_HIP(hipMemcpyAsync(out_order, d_r, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    PG_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    ctx->stats.last_sort_ms = ms;
+    return PG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,335 @@
+"""GPU parity tests: every stage of the hot path, through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact for row ids / ordering / fp32 recall scores / PG_PREC_F32
+pre-activations; the stated tolerance where a transcendental (expf, exp, pow) or the bf16 MFMA's
+internal accumulation order is involved."""
+import math
+
+import numpy as np
+import pytest
+
+import pairec_amd as pa
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+# ---------------------------------------------------------------------------------------------
+# tables
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d", [(1, 64), (1000, 64), (70001, 128), (5000, 256)])
+def test_table_fill_bitexact(ctx, n, d):
+    t = pa.Table(ctx, n, d, row_offset=12345)
+    t.fill_synthetic(o.SEED_TABLE)
+    ref = o.synth_rows(o.SEED_TABLE, 12345, n, d)
+    assert np.array_equal(bits(t.download(0, n)), bits(ref))
+    t.fill_synthetic(o.SEED_TABLE, normalize=False)
+    assert np.array_equal(bits(t.download(0, n)), bits(o.synth_rows(o.SEED_TABLE, 12345, n, d, normalize=False)))
+    t.destroy()
+
+
+def test_table_upload_gather_swap(ctx):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((300, 64)).astype(np.float32)
+    b = rng.standard_normal((300, 64)).astype(np.float32)
+    ta, tb = pa.Table(ctx, 300, 64), pa.Table(ctx, 300, 64)
+    ta.upload(a)
+    tb.upload(b)
+    idx = [0, 299, 17, 17, 5]
+    assert np.array_equal(ta.gather(idx), a[idx])            # VectorDao lookup analogue
+    ta.swap(tb)                                              # hot swap (hologres partition switch)
+    assert np.array_equal(ta.gather(idx), b[idx]) and np.array_equal(tb.download(0, 300), a)
+    with pytest.raises(pa._lib.PgError):
+        ta.gather([300])
+    ta.destroy()
+    tb.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# recall
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,k,nq", [
+    (1000, 64, 200, 1),          # cfg 1 shape in miniature (dot-product top-200)
+    (40000, 128, 200, 3),        # two chunks, one block per wave
+    (140000, 128, 500, 32),      # three chunks, several blocks per wave, full query batch
+    (300017, 64, 5000, 7),       # ragged row count, K=5000
+    (123457, 192, 16384, 2),     # maximum K, dim 192
+    (90000, 256, 50, 5),
+])
+def test_recall_matches_oracle_bitexact(ctx, n, d, k, nq):
+    t = pa.Table(ctx, n, d, row_offset=7)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 7, n, d)
+    q = o.synth_rows(o.SEED_QUERY, 0, nq, d)
+    rows, scores, cnt = t.recall_topk(q, k)
+    orow, osc = o.recall_topk(tab, q, k, row_offset=7)
+    assert cnt.tolist() == [min(k, n)] * nq
+    assert np.array_equal(rows, orow)                        # ids and order: exact
+    assert np.array_equal(bits(scores), bits(osc))           # scores: bit-exact
+    t.destroy()
+
+
+def test_recall_batching_invariance(ctx):
+    """A request's result must not depend on what it is batched with (k-ordered chain spec)."""
+    n, d, k = 60000, 128, 300
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    q = o.synth_rows(o.SEED_QUERY, 0, 40, d)                 # 40 → two table passes (32 + 8)
+    rows, scores, _ = t.recall_topk(q, k)
+    for i in (0, 13, 31, 32, 39):
+        r1, s1, _ = t.recall_topk(q[i:i + 1], k)
+        assert np.array_equal(r1[0], rows[i]) and np.array_equal(bits(s1[0]), bits(scores[i]))
+    t.destroy()
+
+
+def test_recall_edge_cases(ctx):
+    d = 64
+    # k > rows: tail padded with row=UINT64_MAX, score=-inf
+    tab = o.synth_rows(o.SEED_TABLE, 0, 10, d)
+    t = pa.Table(ctx, 10, d)
+    t.upload(tab)
+    q = o.synth_rows(o.SEED_QUERY, 0, 2, d)
+    rows, scores, cnt = t.recall_topk(q, 16)
+    orow, osc = o.recall_topk(tab, q, 16)
+    assert cnt.tolist() == [10, 10]
+    assert np.array_equal(rows[:, :10], orow) and np.array_equal(bits(scores[:, :10]), bits(osc))
+    assert np.all(rows[:, 10:] == np.uint64(2 ** 64 - 1)) and np.all(np.isneginf(scores[:, 10:]))
+    t.destroy()
+    # heavy ties + signed zeros + a NaN row: order = score desc (totalOrder, NaN last), row asc
+    n = 50000
+    tab = np.zeros((n, d), dtype=np.float32)
+    tab[:, 0] = (np.arange(n) % 7).astype(np.float32)
+    tab[100, 0] = np.nan
+    tab[200, 0] = -0.0
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    q = np.zeros((1, d), dtype=np.float32)
+    q[0, 0] = 1.0
+    for k in (10, 8000):
+        rows, scores, _ = t.recall_topk(q, k)
+        orow, osc = o.recall_topk(tab, q, k)
+        assert np.array_equal(rows, orow)
+        assert np.array_equal(bits(scores), bits(osc))
+    t.destroy()
+
+
+def test_recall_adversarial_order_forces_safe_rescan(ctx):
+    """Scores ascending with the row index defeat the running threshold: every row is a
+    candidate, the fast path overflows its list and the bounded-chunk path must take over."""
+    n, d, k = 2_200_000, 64, 100
+    tab = np.zeros((n, d), dtype=np.float32)
+    tab[:, 3] = np.arange(n, dtype=np.float32)
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    q = np.zeros((1, d), dtype=np.float32)
+    q[0, 3] = 1.0
+    before = ctx.stats().recall_rescans
+    rows, scores, _ = t.recall_topk(q, k)
+    assert rows[0].tolist() == list(range(n - 1, n - 1 - k, -1))
+    assert ctx.stats().recall_rescans == before + 1
+    t.destroy()
+
+
+def test_topk_merge_matches_oracle(ctx):
+    """The multi-GPU exchange step: G per-shard lists → global top-K (here on one device)."""
+    n, d, k, G, nq = 80000, 64, 1000, 4, 3
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    q = o.synth_rows(o.SEED_QUERY, 0, nq, d)
+    per = n // G
+    lists_r = np.zeros((nq, G, k), dtype=np.uint64)
+    lists_s = np.zeros((nq, G, k), dtype=np.float32)
+    for g in range(G):
+        t = pa.Table(ctx, per, d, row_offset=g * per)
+        t.upload(tab[g * per:(g + 1) * per])
+        r, s, _ = t.recall_topk(q, k)
+        lists_r[:, g], lists_s[:, g] = r, s
+        t.destroy()
+    d_r, d_s = ctx.to_device(lists_r), ctx.to_device(lists_s)
+    d_or, d_os = ctx.malloc(nq * k * 8), ctx.malloc(nq * k * 4)
+    pa._lib.check(ctx.L.pg_topk_merge_dev(ctx.h, d_r, d_s, nq, G, k, k, d_or, d_os))
+    out_r, out_s = np.zeros((nq, k), np.uint64), np.zeros((nq, k), np.float32)
+    ctx.d2h(out_r, d_or)
+    ctx.d2h(out_s, d_os)
+    g_rows, g_scores = o.recall_topk(tab, q, k)
+    assert np.array_equal(out_r, g_rows) and np.array_equal(bits(out_s), bits(g_scores))
+    for p in (d_r, d_s, d_or, d_os):
+        ctx.free(p)
+
+
+# ---------------------------------------------------------------------------------------------
+# rank
+# ---------------------------------------------------------------------------------------------
+def _dnn3_case(ctx, n_rows=30000):
+    t = pa.Table(ctx, n_rows, 128)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 0, n_rows, 128)
+    w = o.Dnn3Weights()
+    blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+    return t, tab, w, blob
+
+
+def test_rank_dnn3_f32_parity(ctx):
+    """PG_PREC_F32: pre-activations are bit-defined chains; only expf may differ (≤ 1 ulp of the
+    fp32 sigmoid) → tolerance 2e-7 absolute, far inside the 1e-5 the north star allows."""
+    t, tab, w, blob = _dnn3_case(ctx)
+    rng = np.random.default_rng(1)
+    sizes = [5000, 1, 0, 333, 128, 129]                      # ragged, empty, tile-boundary requests
+    users = o.synth_rows(o.SEED_QUERY, 0, len(sizes), 128)
+    cands = [rng.integers(0, 30000, s).astype(np.uint32) for s in sizes]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, blob)
+    got = m.rank_dnn3(t, users, np.concatenate(cands), off)
+    ref = np.concatenate([o.dnn3_forward(w, 0, users[r], tab[cands[r]]) for r in range(len(sizes))])
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got.astype(np.float64) - ref)) <= 2e-7
+    m.destroy()
+    t.destroy()
+
+
+def test_rank_dnn3_bf16_parity(ctx):
+    """PG_PREC_BF16: the oracle mirrors every rounding point; the MFMA's fp32 accumulation order is
+    unspecified, so scores are compared at the north star's 1e-5 (observed max ≈ 1e-6)."""
+    t, tab, w, blob = _dnn3_case(ctx)
+    rng = np.random.default_rng(2)
+    sizes = [5000, 700]
+    users = o.synth_rows(o.SEED_QUERY, 5, 2, 128)
+    cands = [rng.integers(0, 30000, s).astype(np.uint32) for s in sizes]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16, blob)
+    got = m.rank_dnn3(t, users, np.concatenate(cands), off)
+    ref = np.concatenate([o.dnn3_forward(w, 1, users[r], tab[cands[r]]) for r in range(2)])
+    diff = np.abs(got.astype(np.float64) - ref)
+    assert diff.max() <= 1e-5
+    # and the bf16 model stays close to the fp32 model (sanity of the rounding points)
+    ref32 = np.concatenate([o.dnn3_forward(w, 0, users[r], tab[cands[r]]) for r in range(2)])
+    assert np.max(np.abs(got - ref32)) < 5e-3
+    m.destroy()
+    t.destroy()
+
+
+def test_rank_dnn3_rejects_bad_input(ctx):
+    t, tab, w, blob = _dnn3_case(ctx, 1000)
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, blob)
+    users = o.synth_rows(o.SEED_QUERY, 0, 1, 128)
+    with pytest.raises(pa._lib.PgError):                      # row outside the table
+        m.rank_dnn3(t, users, np.array([5, 1000], np.uint32), [0, 2])
+    with pytest.raises(pa._lib.PgError):                      # wrong blob length
+        pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, blob[:-4])
+    assert m.rank_dnn3(t, users, np.zeros(0, np.uint32), [0, 0]).shape == (0,)
+    m.destroy()
+    t.destroy()
+
+
+@pytest.mark.parametrize("prec,tol", [(0, 3e-7), (1, 1e-5)])
+def test_rank_fm_twotower_parity(ctx, prec, tol):
+    fw = o.Fm2tWeights(vocab=3000)
+    m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, prec, pa.pack_fm2t(fw))
+    rng = np.random.default_rng(4)
+    sizes = [5000, 77, 1]
+    users = o.synth_rows(o.SEED_QUERY, 9, 3, 128)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    ufids = rng.integers(0, 3000, (3, 8)).astype(np.int32)
+    ifids = rng.integers(0, 3000, (int(off[-1]), 8)).astype(np.int32)
+    got = m.rank_fm2t(users, ufids, ifids, off)
+    ref = np.concatenate([o.fm2t_forward(fw, prec, users[r], ufids[r], ifids[off[r]:off[r + 1]])
+                          for r in range(3)])
+    assert np.max(np.abs(got.astype(np.float64) - ref)) <= tol
+    m.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# score fusion
+# ---------------------------------------------------------------------------------------------
+def test_expr_reference_known_answers_on_device(ctx, golden):
+    for c in golden["expr"]:
+        e = pa.Expr(c["expr"])
+        vals = {**c["algo_scores"], **c["properties"]}
+        v = np.array([[vals[n]] for n in e.var_names], dtype=np.float64)
+        got = e.eval(ctx, v)[0]
+        it = o.OracleItem("x")
+        for k_, v_ in vals.items():
+            it.add_algo_score(k_, v_)
+        want = o.expr_eval(o.expr_parse(c["expr"]), it.float_expr_data)
+        if "expect" in c:
+            assert got == c["expect"], c["ref"]
+        else:                                                 # `^` = pow: device pow within 2 ulp of libm
+            assert abs(got - want) <= 4e-16 * abs(want), c["ref"]
+        e.free()
+
+
+def test_expr_matches_oracle_on_5000_items(ctx):
+    rng = np.random.default_rng(6)
+    n = 5000
+    src = "(${ctr}+2*${cvr})*${price}^0.1 + ${boost}#0.5 - ${n}%7/3"
+    e = pa.Expr(src)
+    cols = {"ctr": rng.random(n), "cvr": rng.random(n) * 0.1, "price": rng.random(n) * 100 + 1,
+            "boost": np.where(rng.random(n) < 0.5, 0.0, rng.random(n)), "n": np.floor(rng.random(n) * 1000)}
+    v = np.stack([cols[name] for name in e.var_names])
+    got = e.eval(ctx, v)
+    ast = o.expr_parse(src)
+    want = np.array([o.expr_eval(ast, lambda name, i=i: cols[name][i]) for i in range(n)])
+    # device pow() is within 2 ulp of libm; the subtraction amplifies that relative to the result,
+    # so the bound is absolute against the operands' magnitude (~5)
+    assert np.max(np.abs(got - want)) <= 5e-15 * 5
+    # division by zero: the reference panics; here the call fails and reports it
+    z = pa.Expr("1/${x}")
+    with pytest.raises(pa._lib.PgError) as ei:
+        z.eval(ctx, np.array([[1.0, 0.0, 2.0]]))
+    assert ei.value.code == -5
+    # quirks survive the trip to the device
+    for s, want1 in (("-5", -5.0), ("2*1e-5", 0.0), ("2^3^2", 64.0), ("7%3", 1.0), ("0#4*2", 8.0)):
+        q = pa.Expr(s)
+        assert q.eval(ctx, np.zeros((0, 3)))[0] == want1
+        q.free()
+    e.free()
+    z.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# sort
+# ---------------------------------------------------------------------------------------------
+def test_sort_reference_known_answers_on_device(ctx, golden):
+    for c in golden["sort"]:
+        got = ctx.sort_scores(np.array(c["scores"]), descending=c["descending"]).tolist()
+        assert got == c["expect_order"], c["ref"]
+
+
+def test_sort_matches_oracle_segmented(ctx):
+    rng = np.random.default_rng(7)
+    sizes = [5000, 0, 1, 2, 8192, 777, 20000]                # 20000 > LDS capacity → global path
+    segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    s = rng.random(int(segs[-1]))
+    s[::97] = s[1::97][: len(s[::97])]                       # ties
+    s[5] = np.nan
+    s[11] = -0.0
+    s[12] = 0.0
+    for desc in (True, False):
+        got = ctx.sort_scores(s, segs, descending=desc)
+        for i in range(len(sizes)):
+            a, b = int(segs[i]), int(segs[i + 1])
+            assert np.array_equal(got[a:b], o.sort_scores(s[a:b], desc)), (desc, i)
+
+
+# ---------------------------------------------------------------------------------------------
+# DPP
+# ---------------------------------------------------------------------------------------------
+def test_dpp_matches_oracle(ctx):
+    rng = np.random.default_rng(8)
+    n_tab, d, n = 4000, 128, 500
+    centers = rng.standard_normal((12, d)).astype(np.float32)
+    tab = (centers[rng.integers(0, 12, n_tab)] + 0.2 * rng.standard_normal((n_tab, d))).astype(np.float32)
+    t = pa.Table(ctx, n_tab, d)
+    t.upload(tab)
+    cand = rng.choice(n_tab, n, replace=False).astype(np.uint32)
+    rel = np.sort(rng.random(n))[::-1].copy()
+    emb = o.l2_normalize_f64(tab[cand].astype(np.float64))
+    L = o.dpp_kernel_matrix(emb, rel, 1.0)
+    for topn, window in ((100, 10), (10, 10), (37, 5), (500, 10)):
+        want = o.dpp_with_window(L, topn, window)
+        got = pa.dpp(ctx, t, cand, rel, 1.0, topn, window, True)
+        assert np.array_equal(got, want), (topn, window)
+    assert not np.array_equal(pa.dpp(ctx, t, cand, rel, 1.0, 100, 10, True), np.arange(100))
+    t.destroy()

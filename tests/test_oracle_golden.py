@@ -1,0 +1,292 @@
+"""CPU tests: the oracle against the reference's own known-answer tests (tests/golden/) and against
+independent numpy restatements.  No GPU, no product code."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-pinned: expression fusion, sort order, decoder widening
+# ---------------------------------------------------------------------------------------------
+def _item_from_case(c):
+    it = o.OracleItem("item_1")
+    for k, v in c["algo_scores"].items():
+        it.add_algo_score(k, v)
+    for k, v in c["properties"].items():
+        it.add_property(k, v)
+    return it
+
+
+def test_expr_reference_known_answers(golden):
+    for c in golden["expr"]:
+        it = _item_from_case(c)
+        got = o.expr_eval(o.expr_parse(c["expr"]), it.float_expr_data)
+        if "expect" in c:
+            assert got == c["expect"], c["ref"]
+        else:
+            vals = {**c["algo_scores"], **c["properties"]}
+            a, b, cc = (vals[n] for n in c["formula_args"])
+            # the reference asserts result == (a+2*b)*math.Pow(c,0.1) on its own machine
+            assert got == (a + 2 * b) * math.pow(cc, 0.1), c["ref"]
+
+
+def test_fuse_scores_mutates_item_score(golden):
+    c = golden["expr"][0]
+    it = _item_from_case(c)
+    o.fuse_scores(c["expr"], [it])
+    assert it.score == 0.5
+    # AB params override when non-zero (service/rank/ast_parameter_data.go:30-40)
+    it2 = _item_from_case(c)
+    o.fuse_scores(c["expr"], [it2], {"ctr": 1.0})
+    assert it2.score == 1.0 + 0.3 + 0.1
+
+
+def test_current_score_side_effect():
+    it = o.OracleItem("x", score=0.25)
+    assert it.float_expr_data("current_score") == 0.25
+    assert it.algo_scores["recall_score"] == 0.25      # module/item.go:190-197
+
+
+def test_sort_reference_known_answers(golden):
+    for c in golden["sort"]:
+        got = o.sort_scores(c["scores"], c["descending"]).tolist()
+        assert got == c["expect_order"], c["ref"]
+
+
+def test_decode_reference_known_answers(golden):
+    d = golden["decode"][0]
+    arr = np.asarray(d["float_val"], dtype=np.float32).reshape(-1, d["dim1"])
+    wide = o.widen_f32(arr)
+    assert wide.dtype == np.float64
+    assert np.float32(wide[d["item"], d["index"]]) == np.float32(d["expect_f32"])
+    f = golden["decode"][1]
+    assert o.alink_fm_score(f["label"], f["score"]) == 1 - f["score"]
+    assert o.alink_fm_score(1.0, f["score"]) == f["score"]
+
+
+# ---------------------------------------------------------------------------------------------
+# expression language quirks (utils/ast/parse.go, ast.go)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("src,expect", [
+    ("1+2*3", 7.0), ("(1+2)*3", 9.0), ("2^3^2", 64.0),       # '^' is left-associative here
+    ("7%3", 1.0), ("0-7%3", -1.0), ("10/4", 2.5), ("0#4*2", 8.0), ("3#4", 3.0),
+    ("-5", -5.0), ("2*1e-5", 0.0), ("1_000+1", 1001.0), ("1e3", 1000.0), ("2*", 2.0),
+    ("1.5.2+1", 0.0), ("${missing}+1", 1.0), ("  4 + 4 ", 8.0),
+])
+def test_expr_quirks(src, expect):
+    assert o.expr_eval(o.expr_parse(src), lambda n: None) == expect
+
+
+def test_expr_errors():
+    with pytest.raises(o.ExprError):
+        o.expr_parse("abc")                         # symbol error
+    with pytest.raises(o.ExprError):
+        o.expr_parse("1 +\t")                       # stale trailing tab (parse.go:125-133)
+    with pytest.raises(o.ExprError):
+        o.expr_eval(o.expr_parse("1/0"), lambda n: None)
+    with pytest.raises(o.ExprError):
+        o.expr_eval(o.expr_parse("1%0"), lambda n: None)
+    assert o.expr_parse("") is None
+
+
+# ---------------------------------------------------------------------------------------------
+# dedup, vector text formats
+# ---------------------------------------------------------------------------------------------
+def test_unique_filter_first_wins_and_merges():
+    a = o.OracleItem("1", 0.5, "r1")
+    b = o.OracleItem("2", 0.4, "r1")
+    c = o.OracleItem("1", 0.9, "r2")
+    c.add_algo_score("m", 0.7)
+    out = o.unique_filter([a, b, c])
+    assert [x.id for x in out] == ["1", "2"]
+    assert out[0].score == 0.5 and out[0].recall_scores == {"r1": 0.5, "r2": 0.9}
+    assert out[0].algo_scores["m"] == 0.7
+
+
+def test_vector_string_and_cache_format():
+    v = o.parse_vector_string("1:0.12 2:-0.3 junk 3:1e-2 4:x")
+    assert v.dtype == np.float32 and v.tolist() == [np.float32(0.12), np.float32(-0.3), np.float32(0.01), 0.0]
+    items = [o.OracleItem("a", 0.5), o.OracleItem("b", 1e-7), o.OracleItem("c", 3.0)]
+    assert o.recall_cache_string(items, "vec") == "a:vec:0.5,b:vec:1e-07,c:vec:3"
+
+
+# ---------------------------------------------------------------------------------------------
+# numeric oracle vs independent numpy
+# ---------------------------------------------------------------------------------------------
+def test_synth_rows_definition():
+    t = o.synth_rows(o.SEED_TABLE, 5, 4, 64, normalize=False)
+    for r in range(4):
+        for c in (0, 1, 63):
+            u = o.splitmix64(o.SEED_TABLE ^ ((5 + r) * 64 + c))
+            assert t[r, c] == np.float32((u >> 40) * 2.0 ** -23 - 1.0)
+    tn = o.synth_rows(o.SEED_TABLE, 5, 4, 64, normalize=True)
+    assert np.allclose(np.linalg.norm(tn.astype(np.float64), axis=1), 1.0, atol=1e-6)
+    # any row is reproducible independently of the block it was generated in
+    assert np.array_equal(o.synth_rows(o.SEED_TABLE, 7, 1, 64), tn[2:3])
+
+
+def test_dot_scores_is_k_ordered_fma_chain():
+    rng = np.random.default_rng(0)
+    tab = rng.standard_normal((50, 64)).astype(np.float32)
+    q = rng.standard_normal((3, 64)).astype(np.float32)
+    got = o.dot_scores(tab, q)
+    for qi in range(3):
+        for r in (0, 17, 49):
+            acc = np.float32(0)
+            for k in range(64):   # fma in float64 is exact enough to emulate one fp32 rounding here
+                acc = np.float32(np.float64(tab[r, k]) * np.float64(q[qi, k]) + np.float64(acc))
+            assert got[qi, r] == acc
+
+
+def test_recall_topk_order_and_ties():
+    tab = np.zeros((300, 64), dtype=np.float32)
+    tab[:, 0] = np.repeat(np.arange(100, dtype=np.float32), 3)      # triple ties
+    q = np.zeros((1, 64), dtype=np.float32)
+    q[0, 0] = 1.0
+    rows, scores = o.recall_topk(tab, q, 7, row_offset=1000)
+    assert rows[0].tolist() == [1297, 1298, 1299, 1294, 1295, 1296, 1291]   # score desc, row asc
+    assert scores[0].tolist() == [99, 99, 99, 98, 98, 98, 97]
+    # k > rows
+    rows, scores = o.recall_topk(tab[:5], q, 9)
+    assert rows.shape == (1, 5)
+
+
+def test_topk_merge_equals_global():
+    tab = o.synth_rows(o.SEED_TABLE, 0, 4000, 64)
+    q = o.synth_rows(o.SEED_QUERY, 0, 1, 64)
+    g_rows, g_scores = o.recall_topk(tab, q, 100)
+    parts = [o.recall_topk(tab[s:s + 1000], q, 100, row_offset=s) for s in range(0, 4000, 1000)]
+    m_rows, m_scores = o.topk_merge(np.stack([p[0][0] for p in parts]), np.stack([p[1][0] for p in parts]), 100)
+    assert np.array_equal(m_rows, g_rows[0]) and np.array_equal(m_scores, g_scores[0])
+
+
+def test_bf16_rounding_rne():
+    x = np.array([1.0, 1.00390625, 1.005859375, -2.5, 3.0e38, 1e-40, np.inf], dtype=np.float32)
+    r = o.f32_to_bf16_round(x)
+    assert r[0] == 1.0 and r[1] == 1.0 and r[2] == np.float32(1.0078125)   # tie → even, above tie → up
+    for v in x:
+        assert o.lib().orc_bf16_to_f32(o.lib().orc_f32_to_bf16(float(v))) == o.f32_to_bf16_round(np.array([v]))[0]
+
+
+def test_dnn3_matches_float64_numpy():
+    w = o.Dnn3Weights(16, 128, 512, 256)
+    user = o.synth_rows(o.SEED_QUERY, 0, 1, 16)[0]
+    items = o.synth_rows(o.SEED_TABLE, 0, 20, 128)
+    got = o.dnn3_forward(w, 0, user, items)
+    x = np.concatenate([np.tile(user, (20, 1)), items], axis=1).astype(np.float64)
+    h1 = np.maximum(x @ w.w1.astype(np.float64) + w.b1, 0)
+    h2 = np.maximum(h1 @ w.w2.astype(np.float64) + w.b2, 0)
+    ref = 1 / (1 + np.exp(-(h2 @ w.w3.astype(np.float64) + w.b3)))
+    assert np.max(np.abs(got - ref)) < 2e-6
+    got16 = o.dnn3_forward(w, 1, user, items)
+    assert np.max(np.abs(got16 - ref)) < 5e-3 and np.max(np.abs(got16 - got)) > 0
+
+
+def test_fm2t_matches_float64_numpy():
+    w = o.Fm2tWeights(vocab=50)
+    rng = np.random.default_rng(3)
+    user = o.synth_rows(o.SEED_QUERY, 0, 1, 128)[0]
+    uf = rng.integers(0, 50, 8)
+    itf = rng.integers(0, 50, (10, 8))
+    got = o.fm2t_forward(w, 0, user, uf, itf)
+    f64 = np.float64
+    u1 = np.maximum(user.astype(f64) @ w.uw1.astype(f64) + w.ub1, 0)
+    uo = u1 @ w.uw2.astype(f64) + w.ub2
+    ref = []
+    for i in range(10):
+        vs = [w.field_emb[f][uf[f]].astype(f64) for f in range(8)] + \
+             [w.field_emb[8 + f][itf[i, f]].astype(f64) for f in range(8)]
+        lin = w.fm_b + sum(f64(w.field_lin[f][uf[f]]) for f in range(8)) + \
+            sum(f64(w.field_lin[8 + f][itf[i, f]]) for f in range(8))
+        s = np.sum(vs, axis=0)
+        cross = 0.5 * np.sum(s * s - np.sum([v * v for v in vs], axis=0))
+        x = np.concatenate(vs[8:])
+        io = np.maximum(x @ w.iw1.astype(f64) + w.ib1, 0) @ w.iw2.astype(f64) + w.ib2
+        ref.append(1 / (1 + math.exp(-(lin + cross + float(uo @ io)))))
+    assert np.max(np.abs(got - np.array(ref))) < 2e-6
+
+
+def test_sort_ties_nan_and_signed_zero():
+    s = [1.0, float("nan"), -0.0, 0.0, 1.0, -1.0]
+    assert o.sort_scores(s, True).tolist() == [0, 4, 2, 3, 5, 1]
+    assert o.sort_scores(s, False).tolist() == [5, 2, 3, 0, 4, 1]
+    assert o.sort_scores([], True).tolist() == []
+
+
+def _np_dpp(L, topn, window):
+    """Independent restatement of DPPWithWindow/DPP (dpp_sort.go:477-551) in numpy."""
+    def once(topn, existed):
+        N = L.shape[0]
+        topn = min(topn, N)
+        d2 = np.array([np.nan if i in existed else L[i, i] for i in range(N)])
+        def maxidx(v):
+            best, ind = np.nan, 0
+            for i, x in enumerate(v):
+                if x != x:
+                    continue
+                if best != best or x > best:
+                    best, ind = x, i
+            return ind
+        j = maxidx(d2)
+        Y = [j]
+        c = np.zeros((topn, N))
+        while len(Y) < topn:
+            dj = d2[j]
+            if dj < 1e-10:
+                break
+            dj = math.sqrt(dj)
+            k = len(Y) - 1
+            e = L[j].copy()
+            if k > 0:
+                ss = np.zeros(N)
+                for i in range(k):
+                    ss = ss + c[i, j] * c[i]
+                e = e - ss
+            e = (1 / dj) * e
+            c[k] = e
+            d2 = d2 - e * e
+            d2[j] = np.nan
+            j = maxidx(d2)
+            Y.append(j)
+        if len(Y) < topn:
+            for i in range(N):
+                if i not in existed and i not in Y:
+                    Y.append(i)
+                    if len(Y) == topn:
+                        break
+        return Y
+    res = []
+    if topn <= window:
+        return once(topn, res)
+    for _ in range(topn // window):
+        res = res + once(window, res)
+    if topn % window:
+        res = res + once(topn % window, res)
+    return res
+
+
+def test_dpp_matches_numpy_restatement():
+    rng = np.random.default_rng(5)
+    # clustered embeddings so diversity actually reorders things
+    centers = rng.standard_normal((6, 32))
+    emb = centers[rng.integers(0, 6, 80)] + 0.15 * rng.standard_normal((80, 32))
+    emb = o.l2_normalize_f64(emb)
+    rel = np.sort(rng.random(80))[::-1].copy()
+    L = o.dpp_kernel_matrix(emb, rel, 1.0)
+    F = np.concatenate([emb, np.ones((80, 1))], axis=1) * 0.70710678118654757
+    r = np.exp(rel)
+    Lref = (r[:, None] * (F @ F.T)) * r[None, :]
+    assert np.allclose(L, Lref, rtol=1e-13, atol=0)
+    for topn, window in ((10, 10), (25, 10), (7, 3), (80, 10)):
+        got = o.dpp_with_window(L, topn, window).tolist()
+        assert got == _np_dpp(L, topn, window), (topn, window)
+        assert len(set(got)) == len(got)
+    assert o.dpp_with_window(L, 25, 10).tolist() != list(range(25))    # diversity changed the order
+
+
+def test_go_float_format():
+    assert [o.go_fmt_float(x) for x in (0.5, 1e21, 1.5e-7, 123456.0, 0.000123, 1e20, 100.0)] == \
+        ["0.5", "1e+21", "1.5e-07", "123456", "0.000123", "100000000000000000000", "100"]
