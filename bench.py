@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py — ranked items/sec of pairec's recall → rank → sort hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the config the metric is quoted on): a batch of R=32 requests;
+each request = exact inner-product recall of the top 5000 of a 100M x 128 fp32 item table resident
+in HBM → 3-layer DNN rank (256→512→256→1, bf16 MFMA) of those 5000 candidates → RankScore fusion
+in fp64 → ItemRankScore (descending) sort.  A "step" is one such batch; value = ranked items / s
+(R*5000 per step), inputs resident in HBM when the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the same 100M-row table is
+sharded by contiguous row range over the ranks (strong scaling), with an all_gather of the
+per-shard top-K lists and an all_reduce of the score slab per step (pairec_amd/dist.py).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+FLOPS_PER_ITEM = 524800        # SURVEY.md §8(d) cfg 3: 2*(256*512+512*256+256)
+RANK_EXPR = "${rank}*(1+${recall})^0.1"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=100_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--k", type=int, default=5000)
+    ap.add_argument("--batch", type=int, default=32, help="requests per step (<= 32 = one table pass)")
+    ap.add_argument("--prec", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-reqs", type=int, default=20, help="single-request latency samples (N=1)")
+    return ap.parse_args()
+
+
+def make_queries(o, step, R, dim):
+    # 1000 distinct users cycle through the run
+    return o.synth_rows(o.SEED_QUERY, (step * R) % 1000, R, dim)
+
+
+# ------------------------------------------------------------------------------------------------
+# single-GPU pipeline on raw device pointers (no torch on this path)
+# ------------------------------------------------------------------------------------------------
+class Pipeline1:
+    def __init__(self, pa, ctx, table, model, expr, R, K):
+        self.pa, self.ctx, self.table, self.model, self.expr, self.R, self.K = pa, ctx, table, model, expr, R, K
+        n = R * K
+        m = ctx.malloc
+        self.d_rows, self.d_scores = m(n * 8), m(n * 4)
+        self.d_local, self.d_rank = m(n * 4), m(n * 4)
+        self.d_vars, self.d_fused, self.d_order = m(2 * n * 8), m(n * 8), m(n * 4)
+        self.d_off = ctx.to_device((np.arange(R + 1) * K).astype(np.uint32))
+
+    def step(self, d_q, R=None):
+        from pairec_amd import _lib
+        import ctypes as C
+        R = R or self.R
+        ctx, L, h, K = self.ctx, self.ctx.L, self.ctx.h, self.K
+        n = R * K
+        self.table.recall_topk_dev(d_q, R, K, self.d_rows, self.d_scores)
+        _lib.check(L.pg_rows_to_local_dev(h, self.table.h, self.d_rows, n, self.d_local, None))
+        self.model.rank_dnn3_dev(self.table, d_q, self.d_local, self.d_off, R, n, self.d_rank)
+        _lib.check(L.pg_widen_f32_dev(h, self.d_rank, n, self.d_vars))
+        _lib.check(L.pg_widen_f32_dev(h, self.d_scores, n, self.d_vars + n * 8))
+        _lib.check(L.pg_expr_eval_dev(h, self.expr.h, self.d_vars, n, self.d_fused))
+        _lib.check(L.pg_sort_scores_dev(h, self.d_fused, self.d_off, R, n, K, 1, self.d_order))
+
+
+def cpu_baseline(o, args, R, K):
+    """The oracle (a C port of the reference-shaped CPU path) on a bounded sample of the same
+    workload, all host cores: recall scan of a table slice (scaled to the full table by row count)
+    + DNN rank of a candidate sample (scaled to R*K items) + sort.  kind = "port": the reference is
+    Go with its arithmetic in remote services; nothing of it can run here."""
+    cores = os.cpu_count() or 1
+    slice_rows = 1_000_000
+    tab = o.synth_rows(o.SEED_TABLE, 0, slice_rows, args.dim)
+    q = make_queries(o, 0, R, args.dim)
+    t0 = time.time()
+    rows, scores = o.recall_topk(tab, q, K, threads=cores)
+    t_recall_slice = time.time() - t0
+    t_recall = t_recall_slice * (args.rows / slice_rows)
+    w = o.Dnn3Weights()
+    n_sample = 20000
+    cand = tab[rows[0][:K].astype(np.int64) % slice_rows]
+    items = np.tile(cand, (n_sample // K + 1, 1))[:n_sample]
+    t0 = time.time()
+    sc = o.dnn3_forward(w, 1 if args.prec == "bf16" else 0, q[0], items, threads=cores)
+    t_rank = (time.time() - t0) * (R * K / n_sample)
+    t0 = time.time()
+    for r in range(R):
+        o.sort_scores(sc[:K].astype(np.float64), True)
+    t_sort = time.time() - t0
+    total = t_recall + t_rank + t_sort
+    return {
+        "value": R * K / total, "unit": "ranked items/s", "cores": cores, "kind": "port",
+        "sample": "recall: %d-row slice x %d queries (%.2f s) scaled x%d by rows; rank: %d items "
+                  "(scaled to %d); sort: %d x %d" % (slice_rows, R, t_recall_slice, args.rows // slice_rows,
+                                                     n_sample, R * K, R, K),
+        "stage_seconds_per_step": {"recall": t_recall, "rank": t_rank, "sort": t_sort},
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    R, K = args.batch, args.k
+    assert 1 <= R <= 32
+
+    import pairec_amd as pa
+    from oracle import oracle as o       # synthetic-data spec + cpu_baseline leg only
+
+    torch = dist = None
+    stream = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        stream = torch.cuda.current_stream().cuda_stream
+
+    ctx = pa.Context(local_rank, stream)
+    from pairec_amd.dist import shard_range, sharded_step, GpuShardEngine
+    begin, end = shard_range(args.rows, world, rank)
+    table = pa.Table(ctx, end - begin, args.dim, row_offset=begin)
+    table.fill_synthetic(o.SEED_TABLE)
+    w = o.Dnn3Weights()
+    prec = pa.PREC_BF16 if args.prec == "bf16" else pa.PREC_F32
+    model = pa.RankModel(ctx, pa.MODEL_DNN3, prec, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    expr = pa.Expr(RANK_EXPR)
+
+    total_steps = args.warmup + args.steps
+    qs = [make_queries(o, s, R, args.dim) for s in range(total_steps)]
+
+    if world == 1:
+        pipe = Pipeline1(pa, ctx, table, model, expr, R, K)
+        d_qs = [ctx.to_device(q) for q in qs]
+
+        def run(s):
+            pipe.step(d_qs[s])
+
+        def sync():
+            ctx.synchronize()
+    else:
+        eng = GpuShardEngine(torch, ctx, table, model, expr, K, R)
+        dev = torch.device("cuda", local_rank)
+        t_qs = [torch.from_numpy(q).to(dev) for q in qs]
+
+        def run(s):
+            sharded_step(eng, dist, torch, t_qs[s], R, K)
+
+        def sync():
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        run(s)
+    sync()
+    scan_ms, scan_launches, stage = [], 0, {"recall": [], "rank": []}
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        run(s)
+        ms, nbytes = ctx.last_scan_kernel()          # HIP events around the scan launches (this step)
+        scan_ms.append(ms)
+    sync()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = R * K * args.steps / elapsed
+    shard_bytes = (end - begin) * args.dim * 4
+    scan_avg_ms = float(np.mean(scan_ms))
+    achieved = shard_bytes / (scan_avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "ranked items/sec, 5k-cand DNN rank (recall top-5000 of 100M x 128 -> DNN3 -> fuse -> sort)",
+        "value": value, "unit": "ranked items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+        "config": {"workload": "configs[2]: recall 5k of %dx%d fp32 table in HBM -> 3-layer DNN rank "
+                               "(256-512-256-1, %s MFMA) -> RankScore fusion (fp64) -> ItemRankScore sort"
+                               % (args.rows, args.dim, args.prec),
+                   "requests_per_step": R, "candidates_per_request": K, "table_rows": args.rows,
+                   "dim": args.dim, "parallelism": "table row-range shards x%d, all_gather top-K merge" % world
+                   if world > 1 else "1 GPU"},
+        "roofline": {"bound": "hbm", "kernel": "pg::scan_kernel<128>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_pass": shard_bytes, "ms_per_pass": scan_avg_ms,
+                     "note": "algorithmic bytes = shard rows x dim x 4 per table pass (one pass serves %d requests); "
+                             "duration = sum of the pass's scan launches, HIP events on the launch stream" % R},
+        "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},
+        "rank_roofline": {"bound": "mfma", "kernel": "pg::mlp_kernel<bf16,512,256>",
+                          "achieved": (R * K / world) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
+                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": (R * K / world) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS}
+        if args.prec == "bf16" and st.last_rank_ms > 0 else None,
+    }
+
+    if world == 1 and args.latency_reqs > 0:
+        # p50 single-request latency (R=1), same pipeline, inputs resident
+        lat = []
+        for i in range(args.latency_reqs):
+            dq = d_qs[i % len(d_qs)]
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            pipe.step(dq, R=1)
+            ctx.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        out["p50_request_latency_ms"] = float(np.median(lat))
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(o, args, R, K)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

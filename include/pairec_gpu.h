@@ -95,6 +95,12 @@ int pg_topk_merge_dev(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores
                       uint32_t nlists, uint32_t per_list, uint32_t k, uint64_t* d_out_rows,
                       float* d_out_scores);
 
+/* global row ids (as returned by recall/merge) → local row indices of table `t` for the rank stage;
+ * d_owned (optional, uint8 per entry) receives 1 where the row lives in this shard, else 0 and
+ * the local index is written as 0.  UINT64_MAX padding is "not owned". */
+int pg_rows_to_local_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t n,
+                         uint32_t* d_local, uint8_t* d_owned);
+
 /* ---- rank: model predict --------------------------------------------------------------------
  * Replaces EasModel.Run / TFservingModel.Run (algorithm/eas/model.go:197-222,
  * algorithm/tfserving/model.go:30-55): the DNN / FM forward that the reference ships to a
@@ -147,14 +153,22 @@ int pg_expr_eval(pg_ctx* ctx, const pg_expr* e, const double* vars, uint32_t n_i
 int pg_expr_eval_dev(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items,
                      double* d_out_scores);
 
+/* float32 model outputs → float64 AlgoResponse scores, the widening every response decoder of
+ * the reference performs (algorithm/eas/easyrec_response.go:479-483, eas/tf_response.go:55-59,
+ * tfserving/response.go:51-64; recall: vector_recall.go:98). */
+int pg_widen_f32_dev(pg_ctx* ctx, const float* d_in, uint32_t n, double* d_out);
+
 /* ---- sort -----------------------------------------------------------------------------------
  * Replaces ItemRankScoreSort (descending, sort/item_rank_score.go:26-32) and ItemScoreSort
  * (ascending, sort/item_score.go:36-41): out_order[i] = index of the i-th item.  Segmented:
  * seg_offsets[n_seg+1] delimits independent requests.  Ties keep input order; NaN last. */
 int pg_sort_scores(pg_ctx* ctx, const double* scores, const uint32_t* seg_offsets, uint32_t n_seg,
                    int descending, uint32_t* out_order);
+/* max_segment: upper bound on a segment's length (sizes the scratch of the > 8192-item path);
+ * 0 = unknown (n_items is assumed). */
 int pg_sort_scores_dev(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg_offsets,
-                       uint32_t n_seg, uint32_t n_items, int descending, uint32_t* d_out_order);
+                       uint32_t n_seg, uint32_t n_items, uint32_t max_segment, int descending,
+                       uint32_t* d_out_order);
 
 /* ---- DPP diversity re-rank ------------------------------------------------------------------
  * Replaces DPPSort.KernelMatrix + DPPWithWindow (sort/dpp_sort.go:372-551).  Candidates are rows

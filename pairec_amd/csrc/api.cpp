@@ -126,6 +126,13 @@ int pg_memcpy_d2h(pg_ctx* ctx, void* dst, const void* src, size_t bytes) {
 int pg_stats(pg_ctx* ctx, pg_stats_t* out) {
     PG_REQUIRE(ctx && out, "pg_stats: NULL argument");
     std::lock_guard<std::mutex> g(ctx->mu);
+    if (ctx->rank_timing_pending) {                  // _dev rank calls only record their events
+        PG_HIP(hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        PG_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+        ctx->stats.last_rank_ms = ms;
+        ctx->rank_timing_pending = false;
+    }
     *out = ctx->stats;
     return PG_OK;
 }

@@ -64,6 +64,7 @@ struct pg_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;   // per-launch timing events (scan kernel roofline figure)
     uint32_t last_scan_launches = 0;
+    bool rank_timing_pending = false;
     pg_stats_t stats{};
     double last_scan_ms = 0.0;
     uint64_t last_scan_bytes = 0;

@@ -587,6 +587,7 @@ static int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* 
     }
     PG_HIP(hipGetLastError());
     PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->rank_timing_pending = true;
     ctx->stats.rank_calls++;
     ctx->stats.rank_items += n_items;
     return PG_OK;
@@ -637,6 +638,7 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     }
     PG_HIP(hipGetLastError());
     PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->rank_timing_pending = true;
     ctx->stats.rank_calls++;
     ctx->stats.rank_items += n_items;
     return PG_OK;
@@ -647,6 +649,7 @@ static int finish_rank_timing(pg_ctx* ctx) {
     float ms = 0.f;
     PG_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
     ctx->stats.last_rank_ms = ms;
+    ctx->rank_timing_pending = false;
     return PG_OK;
 }
 

@@ -111,11 +111,12 @@ static int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* 
 extern "C" {
 
 int pg_sort_scores_dev(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg_offsets, uint32_t n_seg,
-                       uint32_t n_items, int descending, uint32_t* d_out_order) {
+                       uint32_t n_items, uint32_t max_segment, int descending, uint32_t* d_out_order) {
     PG_REQUIRE(ctx && d_scores && d_seg_offsets && d_out_order, "pg_sort_scores_dev: NULL argument");
     std::lock_guard<std::mutex> g(ctx->mu);
-    // segment sizes are not known on the host here: assume the worst case (one segment)
-    return pg::sort_dev_locked(ctx, d_scores, d_seg_offsets, n_seg, n_items, n_items, descending, d_out_order);
+    // segment sizes live on the device: the caller's bound (or the worst case) sizes the scratch
+    const uint32_t bound = (max_segment == 0 || max_segment > n_items) ? n_items : max_segment;
+    return pg::sort_dev_locked(ctx, d_scores, d_seg_offsets, n_seg, n_items, bound, descending, d_out_order);
 }
 
 int pg_sort_scores(pg_ctx* ctx, const double* scores, const uint32_t* seg_offsets, uint32_t n_seg,
