@@ -85,7 +85,7 @@ def cpu_baseline(o, args, R, K):
     + DNN rank of a candidate sample (scaled to R*K items) + sort.  kind = "port": the reference is
     Go with its arithmetic in remote services; nothing of it can run here."""
     cores = os.cpu_count() or 1
-    slice_rows = 1_000_000
+    slice_rows = 8_000_000 if cores >= 32 else 1_000_000
     tab = o.synth_rows(o.SEED_TABLE, 0, slice_rows, args.dim)
     q = make_queries(o, 0, R, args.dim)
     t0 = time.time()

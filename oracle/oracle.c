@@ -140,25 +140,47 @@ static void emit_sorted(uint64_t* keys, uint32_t n, uint64_t row_offset, uint64_
 uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint64_t row_offset,
                          const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
                          float* out_scores, int threads) {
+    /* The reference-shaped CPU path: each worker scans a contiguous row range,
+     * scores a row against all queries (k-ascending fmaf chains, vectorised across queries) and
+     * keeps one min-heap of K keys per query; the per-worker heaps are merged at the end. */
     uint32_t kk = (nrows < k) ? (uint32_t)nrows : k;
     if (kk == 0) return 0;
-    /* scan in row blocks so the score matrix stays small */
-    const uint64_t BLK = 1u << 16;
-    uint64_t* heaps = (uint64_t*)malloc((size_t)nq * kk * sizeof(uint64_t));
-    uint32_t* hn = (uint32_t*)calloc(nq, sizeof(uint32_t));
-    float* sc = (float*)malloc((size_t)nq * BLK * sizeof(float));
-    for (uint64_t r0 = 0; r0 < nrows; r0 += BLK) {
-        uint64_t nb = (nrows - r0 < BLK) ? nrows - r0 : BLK;
-        orc_dot_scores(table + (size_t)r0 * dim, nb, dim, queries, nq, sc, threads);
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int32_t q = 0; q < (int32_t)nq; ++q) {
-            uint64_t* h = heaps + (size_t)q * kk;
-            uint32_t n = hn[q];
-            const float* s = sc + (size_t)q * nb;
-            for (uint64_t r = 0; r < nb; ++r) {
-                uint64_t key = orc_topk_key(s[r], (uint32_t)(r0 + r));
+    float* qt = (float*)malloc((size_t)dim * nq * sizeof(float));
+    for (uint32_t q = 0; q < nq; ++q)
+        for (uint32_t c = 0; c < dim; ++c) qt[(size_t)c * nq + q] = queries[(size_t)q * dim + c];
+    int nth = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    nth = omp_get_max_threads();
+#endif
+    if ((uint64_t)nth > nrows) nth = (int)nrows;
+    uint64_t* heaps = (uint64_t*)malloc((size_t)nth * nq * kk * sizeof(uint64_t));
+    uint32_t* hn = (uint32_t*)calloc((size_t)nth * nq, sizeof(uint32_t));
+#pragma omp parallel num_threads(nth)
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        const uint64_t r0 = nrows * (uint64_t)tid / nth, r1 = nrows * (uint64_t)(tid + 1) / nth;
+        float* acc = (float*)malloc(nq * sizeof(float));
+        uint64_t* myh = heaps + (size_t)tid * nq * kk;
+        uint32_t* myn = hn + (size_t)tid * nq;
+        for (uint64_t r = r0; r < r1; ++r) {
+            const float* x = table + (size_t)r * dim;
+            for (uint32_t q = 0; q < nq; ++q) acc[q] = 0.0f;
+            for (uint32_t c = 0; c < dim; ++c) {
+                const float xv = x[c];
+                const float* qk = qt + (size_t)c * nq;
+                for (uint32_t q = 0; q < nq; ++q) acc[q] = fmaf(xv, qk[q], acc[q]);
+            }
+            for (uint32_t q = 0; q < nq; ++q) {
+                uint64_t* h = myh + (size_t)q * kk;
+                const uint64_t key = orc_topk_key(acc[q], (uint32_t)r);
+                uint32_t n = myn[q];
                 if (n < kk) {
                     h[n++] = key;
+                    myn[q] = n;
                     if (n == kk)
                         for (int32_t i = (int32_t)kk / 2 - 1; i >= 0; --i) heap_sift_down(h, kk, (uint32_t)i);
                 } else if (key > h[0]) {
@@ -166,13 +188,23 @@ uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint6
                     heap_sift_down(h, kk, 0);
                 }
             }
-            hn[q] = n;
         }
+        free(acc);
     }
-    for (uint32_t q = 0; q < nq; ++q)
-        emit_sorted(heaps + (size_t)q * kk, kk, row_offset, out_rows + (size_t)q * k,
-                    out_scores + (size_t)q * k, NULL);
-    free(sc); free(hn); free(heaps);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int32_t q = 0; q < (int32_t)nq; ++q) {
+        uint64_t* all = (uint64_t*)malloc((size_t)nth * kk * sizeof(uint64_t));
+        uint32_t n = 0;
+        for (int t = 0; t < nth; ++t) {
+            const uint32_t c = hn[(size_t)t * nq + q];
+            memcpy(all + n, heaps + ((size_t)t * nq + q) * kk, (size_t)c * sizeof(uint64_t));
+            n += c;
+        }
+        qsort(all, n, sizeof(uint64_t), cmp_key_desc);
+        emit_sorted(all, kk, row_offset, out_rows + (size_t)q * k, out_scores + (size_t)q * k, NULL);
+        free(all);
+    }
+    free(hn); free(heaps); free(qt);
     return kk;
 }
 

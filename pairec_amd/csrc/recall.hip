@@ -34,8 +34,8 @@ constexpr int kPieceBytes = kPieceRows * kPieceCols * 4;   // 8 KiB
 constexpr int kRingSlots = 4;                              // per wave: 1 consumed + 3 in flight
 constexpr int kScanWaves = 4;                              // waves per workgroup (1 per SIMD)
 constexpr int kScanLdsRing = kScanWaves * kRingSlots * kPieceBytes;   // 128 KiB
-constexpr int kStageCap = 256;                             // staged hits per wave
-constexpr int kStageBytes = kStageCap * 12;
+constexpr int kStageCap = 640;                             // staged hits per wave (fills the LDS left by the ring)
+constexpr int kStageBytes = kStageCap * 12 + 256;          // keys + query ids + 32 counters + 32 bases
 constexpr int kScanLds = kScanLdsRing + kScanWaves * kStageBytes;
 
 __device__ __forceinline__ uint32_t f32_ordered_bits(float f) {
@@ -179,14 +179,27 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a) {
     uint64_t* const st_key = reinterpret_cast<uint64_t*>(smem + kScanLdsRing + wave * kStageBytes);
     uint32_t* const st_q = reinterpret_cast<uint32_t*>(st_key + kStageCap);
     uint32_t st_n = 0;
+    uint32_t* const st_cnt = st_q + kStageCap;            // [32] per-query counts / running offsets
+    uint32_t* const st_base = st_cnt + 32;                // [32] reserved base per query
+    // Flush: reserve space per QUERY (<= 32 returning global atomics per flush instead of one per
+    // hit — the 32 list counters are the hottest words of the launch), then scatter.
     auto flush = [&]() {
+        if (lane < 32) st_cnt[lane] = 0;
+        for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            if (e < st_n) atomicAdd(&st_cnt[st_q[e]], 1u);
+        }
+        if (lane < 32) {
+            const uint32_t c = st_cnt[lane];
+            st_base[lane] = c ? atomicAdd(&a.cnt[lane], c) : 0u;
+            st_cnt[lane] = 0;
+        }
         for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
             const uint32_t e = e0 + lane;
             if (e < st_n) {
-                const uint64_t key = st_key[e];
                 const uint32_t q = st_q[e];
-                const uint32_t pos = atomicAdd(&a.cnt[q], 1u);
-                if (pos < a.cap) a.cand[(uint64_t)q * a.cap + pos] = key;
+                const uint32_t pos = st_base[q] + atomicAdd(&st_cnt[q], 1u);
+                if (pos < a.cap) a.cand[(uint64_t)q * a.cap + pos] = st_key[e];
                 else *a.overflow = 1u;
             }
         }
