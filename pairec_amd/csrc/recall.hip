@@ -29,12 +29,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPieceRows = 32;
-constexpr int kPieceCols = 64;
-constexpr int kPieceBytes = kPieceRows * kPieceCols * 4;   // 8 KiB
+constexpr int kPieceCols = 32;                             // one 128-B line per row
+constexpr int kPieceBytes = kPieceRows * kPieceCols * 4;   // 4 KiB
+constexpr int kPieceDmas = kPieceBytes / 1024;             // LDS-DMA instructions per piece
+constexpr int kPieceQuads = kPieceCols / 4;                // 16-B quads per row of a piece
 constexpr int kRingSlots = 4;                              // per wave: 1 consumed + 3 in flight
-constexpr int kScanWaves = 4;                              // waves per workgroup (1 per SIMD)
+constexpr int kScanWaves = 8;                              // waves per workgroup (2 per SIMD: one wave's
+                                                           // waits/epilogues hide behind the other's MFMAs)
 constexpr int kScanLdsRing = kScanWaves * kRingSlots * kPieceBytes;   // 128 KiB
-constexpr int kStageCap = 640;                             // staged hits per wave (fills the LDS left by the ring)
+constexpr int kStageCap = 300;                             // staged hits per wave (fills the LDS left by the ring)
 constexpr int kStageBytes = kStageCap * 12 + 256;          // keys + query ids + 32 counters + 32 bases
 constexpr int kScanLds = kScanLdsRing + kScanWaves * kStageBytes;
 
@@ -70,44 +73,29 @@ struct ScanArgs {
     uint32_t row_end;        // rows >= row_end are ignored (table end)
 };
 
-// Issue the 8 LDS-DMA instructions of one piece.  `base` is the wave-uniform byte address of the
-// piece's first row at the piece's first column, voff[n] the per-lane byte offsets.  (The
-// instruction's immediate offset is NOT used: on an LDS-DMA it is added to the LDS address too.)
-// M0 carries the LDS destination; it is saved/restored because hipcc owns it outside this asm.
-__device__ __forceinline__ void dma_piece(const char* base, uint32_t lds_addr, const uint32_t (&voff)[8]) {
+// One LDS-DMA instruction (64 lanes x 16 B = 1 KiB): global → LDS without touching VGPRs.
+// `base` is the wave-uniform byte address of the piece (first row, first column of the piece),
+// `voff` the lane's byte offset, `lds_addr` the wave-uniform LDS destination (the hardware adds
+// lane*16).  M0 carries the LDS address; it is saved/restored because hipcc owns it outside this
+// asm.  (The instruction's immediate offset is NOT used: on an LDS-DMA it is added to the LDS
+// address too.)  `nt`: the table is streamed once, keep it out of the way of L2-resident data.
+//
+// WAR guard: `after` must be a value returned by a ds_read of the piece CURRENTLY being computed.
+// It is an (unused) input of the asm, so hipcc waits for that read before the DMA issues; LDS
+// returns in order, hence every read of the previous piece — whose slot this DMA overwrites — has
+// completed too.  Without it a DMA served from L2/MALL was observed to land before a still-queued
+// ds_read of the old piece (1 lost candidate in ~10 % of small-table runs).
+__device__ __forceinline__ void dma_one(const char* base, uint32_t lds_addr, uint32_t voff, float after) {
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b32 m0, %10\n\t"
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %5, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %6, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %7, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %8, %9\n\t"
+        "global_load_lds_dwordx4 %1, %2 nt\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]),
-          "v"(voff[6]), "v"(voff[7]), "s"(base), "s"(lds_addr)
-        : "memory", "scc");      // s_add_u32 writes SCC
+        : "v"(voff), "s"(base), "s"(lds_addr), "v"(after)
+        : "memory");
 }
 
 template <int N>
@@ -115,11 +103,14 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-template <int DIM>
-__global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a) {
+// VAR: developer ablations (0 = product; 1 = no threshold test; 2 = no MFMA; 3 = no DMA)
+template <int DIM, int VAR = 0>
+__global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PPB = DIM / kPieceCols;       // pieces per 32-row block
     constexpr int NS = kRingSlots;
+    constexpr int ND = kPieceDmas;              // 4
+    constexpr int NQ = kPieceQuads;             // 8
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * kScanWaves + wave;
@@ -139,48 +130,48 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a) {
     for (int s = 0; s < DIM / 2; ++s) asm volatile("" : "+v"(bq[s]));
     asm volatile("" : "+v"(thr));
 
-    // DMA lane offsets: LDS slot S = n*64 + lane ↔ (row i = S/16, quad p = S%16) holds
-    // global quad (p + i) % 16 of that row (rotation makes the fragment reads conflict-free).
-    uint32_t voff[8];
+    // DMA lane offsets.  A piece is 32 rows x 32 columns (one 128-B line per row); DMA n covers
+    // LDS quad slots S = n*64 + lane ↔ (row i = S/8, quad p = S%8), which receive global quad
+    // (p + i/2) % 8 of that row: the rotation makes the A-fragment ds_read_b128 conflict-free.
+    uint32_t voff[ND];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
+    for (int n = 0; n < ND; ++n) {
         const int S = n * 64 + lane;
-        const int i = S >> 4, p = S & 15;
-        voff[n] = (uint32_t)(i * DIM + 4 * ((p + i) & 15)) * 4u;
+        const int i = S >> 3, p = S & 7;
+        voff[n] = (uint32_t)(i * DIM + 4 * ((p + (i >> 1)) & 7)) * 4u;
     }
-    const uint32_t lds_wave = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem) +
-                              wave * (NS * kPieceBytes);
-    const uint32_t lds_wave_u = __builtin_amdgcn_readfirstlane(lds_wave);
+    const uint32_t lds_wave_u = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + wave * (NS * kPieceBytes));
     char* const lds_ptr = smem + wave * (NS * kPieceBytes);
-    const int rd_row = i32 * 256;
-    const int rd_i16 = i32 * 16;
+    const int rd_row = i32 * 128;
+    const int rd_rot = (i32 >> 1) * 16;
 
+    // each wave walks a CONTIGUOUS run of row blocks (sequential 16 KiB reads), runs are spread
+    // evenly over the launch's waves
     const uint32_t total = a.rb_end - a.rb_begin;
-    const uint32_t nblk = (gw < total) ? (total - gw + W - 1) / W : 0;
+    const uint32_t bpw = (total + W - 1) / W;
+    const uint32_t first = gw * bpw;
+    const uint32_t nblk = first < total ? (total - first < bpw ? total - first : bpw) : 0;
     if (nblk == 0) return;
 
-    auto piece_base = [&](uint32_t t) -> const char* {
+    // wave-uniform source base and LDS destination of piece t (tail pieces re-read the last block)
+    auto piece_addr = [&](uint32_t t, const char*& ub, uint32_t& dst) {
         uint32_t b = t / PPB;
-        if (b >= nblk) b = nblk - 1;                       // tail: harmless re-read
-        const uint64_t rb = (uint64_t)a.rb_begin + gw + (uint64_t)b * W;
-        return (const char*)a.tab + rb * (uint64_t)(kPieceRows * DIM * 4) + (t % PPB) * (kPieceCols * 4);
-    };
-    auto issue = [&](uint32_t t) {
-        const char* base = piece_base(t);
+        if (b >= nblk) b = nblk - 1;
+        const uint64_t rb = (uint64_t)a.rb_begin + first + b;
+        const char* base = (const char*)a.tab + rb * (uint64_t)(kPieceRows * DIM * 4) + (t % PPB) * (kPieceCols * 4);
         const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)base >> 32));
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
-        const char* ub = (const char*)(((uint64_t)hi << 32) | lo);
-        const uint32_t slot = __builtin_amdgcn_readfirstlane(t % NS);
-        const uint32_t dst = lds_wave_u + slot * kPieceBytes;
-        dma_piece(ub, dst, voff);
+        ub = (const char*)(((uint64_t)hi << 32) | lo);
+        dst = lds_wave_u + __builtin_amdgcn_readfirstlane(t % NS) * kPieceBytes;
     };
 
     // wave-private staging list for threshold hits (keys + query ids)
     uint64_t* const st_key = reinterpret_cast<uint64_t*>(smem + kScanLdsRing + wave * kStageBytes);
     uint32_t* const st_q = reinterpret_cast<uint32_t*>(st_key + kStageCap);
-    uint32_t st_n = 0;
     uint32_t* const st_cnt = st_q + kStageCap;            // [32] per-query counts / running offsets
     uint32_t* const st_base = st_cnt + 32;                // [32] reserved base per query
+    uint32_t st_n = 0;
     // Flush: reserve space per QUERY (<= 32 returning global atomics per flush instead of one per
     // hit — the 32 list counters are the hottest words of the launch), then scatter.
     auto flush = [&]() {
@@ -207,48 +198,69 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(ScanArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), visible to hipcc's bookkeeping
     };
 
+    // prologue: pieces 0..NS-2 in flight
 #pragma unroll
-    for (int t = 0; t < NS - 1; ++t) issue(t);
+    for (int t = 0; t < NS - 1; ++t) {
+        const char* src;
+        uint32_t dst;
+        piece_addr(t, src, dst);
+#pragma unroll
+        for (int n = 0; n < ND; ++n) dma_one(src, dst + n * 1024, voff[n], 0.0f);
+    }
 
     for (uint32_t b = 0; b < nblk; ++b) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int half = 0; half < PPB; ++half) {
-            const uint32_t t = b * PPB + half;
-            issue(t + NS - 1);
-            wait_vmcnt<8 * (NS - 1)>();                     // piece t has landed
+        for (int pc = 0; pc < PPB; ++pc) {
+            const uint32_t t = b * PPB + pc;
+            // pieces t..t+NS-2 are in flight (ND DMAs each); piece t+NS-1 is issued below, one DMA
+            // every other quad, into the slot that piece t-1 just vacated
+            if (VAR != 3) wait_vmcnt<ND * (NS - 2)>();      // piece t has landed
+            const char* nb_src;
+            uint32_t nb_dst;
+            piece_addr(t + NS - 1, nb_src, nb_dst);
             const char* slot = lds_ptr + (t % NS) * kPieceBytes + rd_row;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(slot + ((g * 16 - rd_i16) & 240));
+            for (int g = 0; g < NQ; ++g) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(slot + ((g * 16 - rd_rot) & 112));
+                if (g < ND && VAR != 3) dma_one(nb_src, nb_dst + g * 1024, voff[g], q.x);
                 const float a0 = h ? q.y : q.x;
                 const float a1 = h ? q.w : q.z;
-                const int s = half * 32 + 2 * g;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[s + 1], acc, 0, 0, 0);
+                const int s = pc * (kPieceCols / 2) + 2 * g;
+                if (VAR == 2) {
+                    acc[g] += a0 + a1;
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[s + 1], acc, 0, 0, 0);
+                }
             }
         }
-        // ---- threshold test: C layout col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*h
-        const uint32_t row0 = (a.rb_begin + gw + b * W) * kPieceRows;
-        uint32_t pass = 0;
+        if (VAR == 1 || VAR == 3) { asm volatile("" ::"v"(acc)); continue; }
+        // ---- threshold test: C layout col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*h.
+        // Fast path: one not-less-than compare per accumulator register, OR-reduced.
+        bool any = false;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool p = active && !(acc[r] < thr) && row < a.row_end;
-            pass |= (p ? 1u : 0u) << r;
-        }
-        if (__builtin_amdgcn_ballot_w64(pass != 0) != 0) {
+        for (int r = 0; r < 16; ++r) any |= !(acc[r] < thr);
+        if (__builtin_amdgcn_ballot_w64(any && active) != 0) {
             // Hits are rare (≈ K/rows_seen per row·query), so they are parked in a wave-private LDS
             // staging list and flushed in bulk: a returning atomic costs a full vmcnt drain of the
             // DMA ring, which must not happen once per block.
-            uint32_t total = 0;
+            const uint32_t row0 = (a.rb_begin + first + b) * kPieceRows;
+            uint32_t pass = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool p = active && !(acc[r] < thr) && row < a.row_end;
+                pass |= (p ? 1u : 0u) << r;
+            }
+            uint32_t total_hits = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                total += __popcll(__builtin_amdgcn_ballot_w64((pass >> r) & 1u));
-            if (st_n + total > (uint32_t)kStageCap) flush();
-            if (total > (uint32_t)kStageCap) {
+                total_hits += __popcll(__builtin_amdgcn_ballot_w64((pass >> r) & 1u));
+            if (st_n + total_hits > (uint32_t)kStageCap) flush();
+            if (total_hits > (uint32_t)kStageCap) {
                 // dense case (first chunk: threshold still -inf): straight to global memory
                 if (pass != 0) {
                     uint32_t pos = atomicAdd(&a.cnt[i32], (uint32_t)__popc(pass));
@@ -435,11 +447,11 @@ static uint32_t next_pow2(uint32_t x) {
     return p;
 }
 
-template <int DIM>
+template <int DIM, int VAR = 0>
 static int launch_scan(pg_ctx* ctx, const ScanArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        PG_HIP(hipFuncSetAttribute((const void*)scan_kernel<DIM>,
+        PG_HIP(hipFuncSetAttribute((const void*)scan_kernel<DIM, VAR>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds));
         attr_set = true;
     }
@@ -447,7 +459,7 @@ static int launch_scan(pg_ctx* ctx, const ScanArgs& a) {
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total + kScanWaves - 1) / kScanWaves;
     if (grid > need) grid = need;
-    scan_kernel<DIM><<<grid, 64 * kScanWaves, kScanLds, ctx->stream>>>(a);
+    scan_kernel<DIM, VAR><<<grid, 64 * kScanWaves, kScanLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
@@ -455,7 +467,15 @@ static int launch_scan(pg_ctx* ctx, const ScanArgs& a) {
 static int dispatch_scan(pg_ctx* ctx, uint32_t dim, const ScanArgs& a) {
     switch (dim) {
         case 64: return launch_scan<64>(ctx, a);
-        case 128: return launch_scan<128>(ctx, a);
+        case 128: {
+#ifdef PG_SCAN_VARIANTS
+            const char* v = getenv("PG_SCAN_VAR");     // developer ablation builds only
+            if (v && v[0] == '1') return launch_scan<128, 1>(ctx, a);
+            if (v && v[0] == '2') return launch_scan<128, 2>(ctx, a);
+            if (v && v[0] == '3') return launch_scan<128, 3>(ctx, a);
+#endif
+            return launch_scan<128>(ctx, a);
+        }
         case 192: return launch_scan<192>(ctx, a);
         case 256: return launch_scan<256>(ctx, a);
     }
@@ -552,7 +572,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             a.cand = rs.cand[cur];
             a.overflow = rs.overflow;
             a.cap = rs.cap;
-            a.nq = nq;
+            a.nq = (getenv("PG_DEBUG_NOHITS") && rb > 0) ? 0 : nq;
             a.rb_begin = rb;
             a.rb_end = rb + cb;
             a.row_end = rows;
@@ -585,6 +605,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
         for (uint32_t i = 0; i < n_ev; ++i) {
             PG_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]));
             scan_ms += ms;
+            if (getenv("PG_DEBUG_SCAN")) fprintf(stderr, "[pg] scan launch %u: %.3f ms\n", i, ms);
         }
         scan_launches += n_ev;
         scanned_rows += rows;
