@@ -222,9 +222,16 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
             uint32_t nb_dst;
             piece_addr(t + NS - 1, nb_src, nb_dst);
             const char* slot = lds_ptr + (t % NS) * kPieceBytes + rd_row;
+            // all of the piece's A-fragment reads are issued up front (8 x ds_read_b128 in flight),
+            // so LDS latency is paid once per piece instead of once per quad
+            f32x4 qv[NQ];
+#pragma unroll
+            for (int g = 0; g < NQ; ++g)
+                qv[g] = *reinterpret_cast<const f32x4*>(slot + ((g * 16 - rd_rot) & 112));
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads up here (hipcc would sink them to their uses)
 #pragma unroll
             for (int g = 0; g < NQ; ++g) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(slot + ((g * 16 - rd_rot) & 112));
+                const f32x4 q = qv[g];
                 if (g < ND && VAR != 3) dma_one(nb_src, nb_dst + g * 1024, voff[g], q.x);
                 const float a0 = h ? q.y : q.x;
                 const float a1 = h ? q.w : q.z;
