@@ -39,13 +39,14 @@ def sharded_step(engine, dist, torch, queries, nq: int, k: int):
     world = dist.get_world_size() if dist is not None else 1
     rows, scores = engine.recall_local(queries, nq, k)                       # [nq,k] i64 / f32
     if world > 1:
-        g_rows = torch.empty((world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
-        g_scores = torch.empty((world,) + tuple(scores.shape), dtype=scores.dtype, device=scores.device)
-        dist.all_gather_into_tensor(g_rows, rows)
-        dist.all_gather_into_tensor(g_scores, scores)
+        # concatenation along dim 0 (the layout every backend accepts), viewed as [G, nq, k]
+        g_rows = torch.empty((world * nq, k), dtype=rows.dtype, device=rows.device)
+        g_scores = torch.empty((world * nq, k), dtype=scores.dtype, device=scores.device)
+        dist.all_gather_into_tensor(g_rows, rows.contiguous())
+        dist.all_gather_into_tensor(g_scores, scores.contiguous())
         # [G,nq,k] → [nq,G,k]: the merge wants all of a request's lists contiguous
-        rows, scores = engine.merge(g_rows.permute(1, 0, 2).contiguous(),
-                                    g_scores.permute(1, 0, 2).contiguous(), k)
+        rows, scores = engine.merge(g_rows.view(world, nq, k).permute(1, 0, 2).contiguous(),
+                                    g_scores.view(world, nq, k).permute(1, 0, 2).contiguous(), k)
     local, owned = engine.rows_to_local(rows)                                # [nq,k] i32 / bool
     counts = owned.sum(dim=1, dtype=torch.int32)
     req_offsets = torch.zeros(nq + 1, dtype=torch.int32, device=rows.device)

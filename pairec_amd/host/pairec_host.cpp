@@ -1,0 +1,653 @@
+// pairec_host.cpp — implementation of the C++ host mirror (see pairec_host.hpp) and the small C
+// driver API (ph_*) that the Python tests use to exercise it.
+#include "pairec_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace pairec {
+
+// ---- utils ---------------------------------------------------------------------------------------
+double ToFloat(const json::Value& v, double def) {          // utils/type.go:43-69
+    if (v.type == json::Value::Number) return v.num;
+    if (v.type == json::Value::String) {
+        char* e = nullptr;
+        const double d = strtod(v.str.c_str(), &e);
+        if (e != v.str.c_str() && *e == '\0') return d;
+        return def;
+    }
+    return def;
+}
+
+namespace module {
+bool Item::FloatExprData(const std::string& name, double* out) {
+    if (name == "current_score") {                          // item.go:190-197
+        algoScores["recall_score"] = Score;
+        *out = Score;
+        return true;
+    }
+    auto a = algoScores.find(name);
+    if (a != algoScores.end()) { *out = a->second; return true; }
+    auto p = Properties.find(name);
+    if (p != Properties.end()) { *out = ToFloat(p->second, 0.0); return true; }
+    return false;
+}
+bool InMemoryVectorDao::VectorString(const std::string& id, std::string* out, std::string* err) {
+    auto it = vectors.find(id);
+    if (it == vectors.end() || it->second.empty()) {
+        if (err) *err = "vector empty";                     // module.VectoryEmptyError
+        return false;
+    }
+    *out = it->second;
+    return true;
+}
+}  // namespace module
+
+namespace context {
+std::string RecommendContext::GetParameter(const std::string& k) const {
+    auto it = Param.find(k);
+    return (it != Param.end() && it->second.type == json::Value::String) ? it->second.str : "";
+}
+}  // namespace context
+
+// ---- recconf -------------------------------------------------------------------------------------
+namespace recconf {
+static std::vector<std::string> str_list(const json::Value& v) {
+    std::vector<std::string> out;
+    if (v.type == json::Value::Array)
+        for (const auto& e : v.arr)
+            if (e.type == json::Value::String) out.push_back(e.str);
+    return out;
+}
+bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::string* err) {
+    json::Value root;
+    if (!json::Parser(text).Parse(&root, err)) return false;
+    if (root.type != json::Value::Object) { if (err) *err = "recconf: root is not an object"; return false; }
+    for (const auto& a : root.at("AlgoConfs").arr) out->AlgoConfs.push_back({a.s("Name"), a.s("Type"), a});
+    for (const auto& r : root.at("RecallConfs").arr) {
+        RecallConfig c;
+        c.Name = r.s("Name"); c.RecallType = r.s("RecallType"); c.RecallAlgo = r.s("RecallAlgo");
+        c.ItemType = r.s("ItemType"); c.CachePrefix = r.s("CachePrefix");
+        c.RecallCount = (int)r.n("RecallCount"); c.CacheTime = (int)r.n("CacheTime");
+        out->RecallConfs.push_back(c);
+    }
+    for (const auto& kv : root.at("RankConf").obj) {
+        RankConfig c;
+        c.RankAlgoList = str_list(kv.second.at("RankAlgoList"));
+        c.RankScore = kv.second.s("RankScore"); c.Processor = kv.second.s("Processor");
+        c.ASTType = kv.second.s("ASTType"); c.BatchCount = (int)kv.second.n("BatchCount");
+        out->RankConf[kv.first] = c;
+    }
+    for (const auto& kv : root.at("SortNames").obj) out->SortNames[kv.first] = str_list(kv.second);
+    for (const auto& sc : root.at("SceneConfs").obj)
+        for (const auto& cat : sc.second.obj)
+            out->SceneRecallNames[sc.first][cat.first] = str_list(cat.second.at("RecallNames"));
+    for (const auto& d : root.at("DPPConf").arr) {
+        DPPSortConfig c;
+        c.Name = d.s("Name"); c.Alpha = d.d("Alpha", 1.0); c.WindowSize = (int)d.n("WindowSize");
+        c.CandidateCount = (int)d.n("CandidateCount"); c.MinScorePercent = d.d("MinScorePercent");
+        std::string ne = d.s("NormalizeEmb");
+        std::transform(ne.begin(), ne.end(), ne.begin(), ::tolower);
+        c.NormalizeEmb = ne != "false";                     // dpp_sort.go:95-97
+        out->DPPConf.push_back(c);
+    }
+    out->UserDefineConfs = root.at("UserDefineConfs");
+    return true;
+}
+}  // namespace recconf
+
+// ---- algorithm -----------------------------------------------------------------------------------
+namespace algorithm {
+void AlgorithmFactory::RegisterAlgorithm(const std::string& name, std::shared_ptr<IAlgorithm> a) {
+    std::lock_guard<std::mutex> g(mu_);
+    algos_[name] = std::move(a);                            // overwrites (algorithm.go:164-168)
+}
+bool AlgorithmFactory::Run(const std::string& name, const AlgoData& data, AlgoResult* out, std::string* err) {
+    std::shared_ptr<IAlgorithm> a;
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = algos_.find(name);
+        if (it == algos_.end()) {
+            if (err) *err = "not find algorithm, name:" + name;     // algorithm.go:113-115
+            return false;
+        }
+        a = it->second;
+    }
+    return a->Run(data, out, err);
+}
+}  // namespace algorithm
+
+// ---- recall --------------------------------------------------------------------------------------
+namespace recall {
+std::shared_ptr<Recall> Registry::GetRecall(const std::string& name, std::string* err) {
+    auto it = recalls_.find(name);
+    if (it == recalls_.end()) {
+        if (err) *err = "recall:not found, name:" + name;
+        return nullptr;
+    }
+    return it->second;
+}
+std::vector<float> ParseVectorString(const std::string& s) {     // vector_recall.go:70-82
+    std::vector<float> out;
+    size_t p = 0;
+    while (p <= s.size()) {
+        size_t e = s.find(' ', p);
+        if (e == std::string::npos) e = s.size();
+        const std::string vc = s.substr(p, e - p);
+        p = e + 1;
+        const size_t c = vc.find(':');
+        if (c == std::string::npos) continue;
+        if (vc.find(':', c + 1) != std::string::npos) continue;       // len(vals) != 2
+        const std::string val = vc.substr(c + 1);
+        char* end = nullptr;
+        const double d = strtod(val.c_str(), &end);
+        // `value, _ := strconv.ParseFloat(vals[1], 32)`: a malformed number yields 0
+        out.push_back((end != val.c_str() && *end == '\0') ? (float)d : 0.0f);
+    }
+    return out;
+}
+}  // namespace recall
+
+// ---- filter --------------------------------------------------------------------------------------
+namespace filter {
+std::vector<module::ItemPtr> UniqueFilter(const std::vector<module::ItemPtr>& items) {
+    std::vector<module::ItemPtr> out;
+    std::map<module::ItemId, module::ItemPtr> uniq;
+    for (const auto& item : items) {
+        auto it = uniq.find(item->Id);
+        if (it == uniq.end()) {
+            uniq[item->Id] = item;
+            out.push_back(item);
+        } else {
+            auto& exist = it->second;
+            for (const auto& kv : item->algoScores) exist->AddAlgoScore(kv.first, kv.second);
+            if (!exist->hasRecallScores) {
+                exist->RecallScores = {{exist->RetrieveId, exist->Score}};
+                exist->hasRecallScores = true;
+            }
+            exist->RecallScores[item->RetrieveId] = item->Score;
+        }
+    }
+    return out;
+}
+}  // namespace filter
+
+// ---- sort ----------------------------------------------------------------------------------------
+namespace sort {
+bool Registry::RegisterSort(const std::string& name, std::shared_ptr<ISort> s, std::string* err) {
+    if (!s) { if (err) *err = "Sort is nil, name:" + name; return false; }      // sort.go:144-146 panics
+    if (sorts_.count(name) == 0) sorts_[name] = std::move(s);                   // first registration wins
+    return true;
+}
+std::shared_ptr<ISort> Registry::Get(const std::string& name) {
+    auto it = sorts_.find(name);
+    return it == sorts_.end() ? nullptr : it->second;
+}
+}  // namespace sort
+
+// ---- GPU-backed plugins --------------------------------------------------------------------------
+namespace {
+
+std::string pg_err(const char* what) { return std::string(what) + ": " + pg_last_error(); }
+
+// algorithm.IAlgorithm replacing FaissModel (algorithm/faiss/model.go:29-31)
+struct GpuFaissAlgorithm : algorithm::IAlgorithm {
+    Engine* e;
+    explicit GpuFaissAlgorithm(Engine* eng) : e(eng) {}
+    bool Init(const recconf::AlgoConfig&, std::string*) override { return true; }
+    bool Run(const algorithm::AlgoData& data, algorithm::AlgoResult* out, std::string* err) override {
+        if (data.kind != algorithm::AlgoData::kVector) { if (err) *err = "faiss: invalid request type"; return false; }
+        const auto& req = data.vec;
+        if (req.Vector.size() != e->dim) { if (err) *err = "faiss: vector dimension mismatch"; return false; }
+        if (req.K == 0) return true;
+        std::vector<uint64_t> rows(req.K);
+        std::vector<float> scores(req.K);
+        uint32_t cnt = 0;
+        if (pg_recall_topk(e->ctx, e->table, req.Vector.data(), 1, req.K, rows.data(), scores.data(), &cnt) != PG_OK) {
+            if (err) *err = pg_err("pg_recall_topk");
+            return false;
+        }
+        for (uint32_t i = 0; i < cnt; ++i) {
+            out->reply.Retval.push_back(rows[i]);
+            out->reply.Scores.push_back(scores[i]);
+            out->reply.Labels.push_back(e->IdOfRow(rows[i]));
+        }
+        return true;
+    }
+};
+
+// algorithm.IAlgorithm replacing EasModel / TFservingModel for the DNN rank model
+struct GpuDnnAlgorithm : algorithm::IAlgorithm {
+    Engine* e;
+    explicit GpuDnnAlgorithm(Engine* eng) : e(eng) {}
+    bool Init(const recconf::AlgoConfig&, std::string*) override { return true; }
+    bool Run(const algorithm::AlgoData& data, algorithm::AlgoResult* out, std::string* err) override {
+        if (data.kind != algorithm::AlgoData::kRank) { if (err) *err = "dnn: invalid request type"; return false; }
+        const auto& req = data.rank;
+        const uint32_t n = (uint32_t)req.ItemIds.size();
+        std::vector<uint32_t> rows(n);
+        for (uint32_t i = 0; i < n; ++i)
+            if (!e->RowOfId(req.ItemIds[i], &rows[i])) { if (err) *err = "dnn: unknown item id " + req.ItemIds[i]; return false; }
+        const uint32_t off[2] = {0, n};
+        std::vector<float> scores(n);
+        if (pg_rank_dnn3(e->ctx, e->model, e->table, req.UserVector.data(), rows.data(), off, 1, scores.data()) != PG_OK) {
+            if (err) *err = pg_err("pg_rank_dnn3");
+            return false;
+        }
+        out->responses.resize(n);
+        for (uint32_t i = 0; i < n; ++i) out->responses[i].score = (double)scores[i];   // float32 → float64 widening
+        return true;
+    }
+};
+
+// recall.Recall with the body of VectorRecall.GetCandidateItems (vector_recall.go:32-123, cache omitted)
+struct GpuVectorRecall : recall::Recall {
+    Engine* e;
+    recconf::RecallConfig conf;
+    GpuVectorRecall(Engine* eng, recconf::RecallConfig c) : e(eng), conf(std::move(c)) {}
+    std::vector<module::ItemPtr> GetCandidateItems(module::User* user, context::RecommendContext*) override {
+        std::vector<module::ItemPtr> ret;
+        std::string value, err;
+        if (!e->user_vectors.VectorString(user->Id, &value, &err)) return ret;        // logged, empty result
+        algorithm::AlgoData data;
+        data.kind = algorithm::AlgoData::kVector;
+        data.vec.K = (uint32_t)conf.RecallCount;
+        data.vec.Vector = recall::ParseVectorString(value);
+        if (data.vec.Vector.empty()) return ret;                                       // "user Vector empty"
+        algorithm::AlgoResult result;
+        if (!e->algorithms.Run(conf.RecallAlgo, data, &result, &err)) return ret;      // logged, empty result
+        for (size_t i = 0; i < result.reply.Labels.size(); ++i) {
+            auto item = std::make_shared<module::Item>(result.reply.Labels[i]);
+            item->RetrieveId = conf.Name;
+            item->ItemType = conf.ItemType;
+            item->Score = (double)result.reply.Scores[i];
+            ret.push_back(item);
+        }
+        return ret;
+    }
+};
+
+bool sort_items(Engine* e, sort::SortData* d, bool desc, std::string* err) {
+    const uint32_t n = (uint32_t)d->Data.size();
+    if (n == 0) return true;
+    std::vector<double> s(n);
+    for (uint32_t i = 0; i < n; ++i) s[i] = d->Data[i]->Score;
+    const uint32_t seg[2] = {0, n};
+    std::vector<uint32_t> order(n);
+    if (pg_sort_scores(e->ctx, s.data(), seg, 1, desc ? 1 : 0, order.data()) != PG_OK) {
+        if (err) *err = pg_err("pg_sort_scores");
+        return false;                                   // caller ignores the error; Data left untouched
+    }
+    std::vector<module::ItemPtr> out(n);
+    for (uint32_t i = 0; i < n; ++i) out[i] = d->Data[order[i]];
+    d->Data.swap(out);
+    return true;
+}
+struct GpuItemRankScoreSort : sort::ISort {              // sort/item_rank_score.go:26-32 (descending)
+    Engine* e;
+    explicit GpuItemRankScoreSort(Engine* eng) : e(eng) {}
+    bool Sort(sort::SortData* d, std::string* err) override { return sort_items(e, d, true, err); }
+};
+struct GpuItemScoreSort : sort::ISort {                  // sort/item_score.go:36-41 (ascending)
+    Engine* e;
+    explicit GpuItemScoreSort(Engine* eng) : e(eng) {}
+    bool Sort(sort::SortData* d, std::string* err) override { return sort_items(e, d, false, err); }
+};
+struct GpuDPPSort : sort::ISort {                        // sort/dpp_sort.go:108-351 (embedding table = item table)
+    Engine* e;
+    recconf::DPPSortConfig conf;
+    GpuDPPSort(Engine* eng, recconf::DPPSortConfig c) : e(eng), conf(std::move(c)) {}
+    bool Sort(sort::SortData* d, std::string* err) override {
+        auto& items = d->Data;
+        if (items.empty()) return true;
+        const int size = d->Context ? d->Context->Size : 10;
+        const int window = conf.WindowSize > 0 ? conf.WindowSize : 10;
+        if ((conf.CandidateCount > 0 || conf.MinScorePercent > 0) && (int)items.size() > size) {   // :280-300
+            sort::SortData tmp = *d;
+            if (!sort_items(e, &tmp, true, err)) return false;
+            items.swap(tmp.Data);
+            if (conf.CandidateCount > 0) {
+                const size_t cnt = (size_t)std::max(size, conf.CandidateCount);
+                if (cnt < items.size()) items.resize(cnt);
+            }
+            if (conf.MinScorePercent > 0 && (int)items.size() > size) {
+                size_t idx = (size_t)size;
+                const double mx = items[0]->Score;
+                for (; idx < items.size(); ++idx)
+                    if (items[idx]->Score / mx < conf.MinScorePercent) break;
+                items.resize(idx);
+            }
+        }
+        const uint32_t n = (uint32_t)items.size();
+        std::vector<uint32_t> rows(n);
+        std::vector<double> rel(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!e->RowOfId(items[i]->Id, &rows[i])) { if (err) *err = "dpp: unknown item id"; return false; }
+            rel[i] = items[i]->Score;
+        }
+        std::vector<uint32_t> idx((size_t)std::max(size, 1));
+        uint32_t cnt = 0;
+        if (pg_dpp(e->ctx, e->table, rows.data(), rel.data(), n, conf.Alpha, (uint32_t)size, (uint32_t)window,
+                   conf.NormalizeEmb ? 1 : 0, idx.data(), &cnt) != PG_OK) {
+            if (err) *err = pg_err("pg_dpp");
+            return false;
+        }
+        std::vector<module::ItemPtr> out;
+        for (uint32_t i = 0; i < cnt; ++i) out.push_back(items[idx[i]]);
+        items.swap(out);
+        return true;
+    }
+};
+
+}  // namespace
+
+// ---- rank service --------------------------------------------------------------------------------
+namespace rank {
+bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, context::RecommendContext* ctx,
+          std::string* err) {
+    const std::string scene = ctx->GetParameter("scene");
+    auto rc = e->config.RankConf.find(scene);
+    if (rc == e->config.RankConf.end()) return true;                         // no rank config: no rank
+    const recconf::RankConfig& conf = rc->second;
+    if (conf.RankAlgoList.empty() && conf.RankScore.empty()) return true;    // :168-171
+    const int batch = conf.BatchCount > 0 ? conf.BatchCount : 100;           // :163-166
+    std::string uv, verr;
+    std::vector<float> user_vec;
+    if (e->user_vectors.VectorString(user->Id, &uv, &verr)) user_vec = recall::ParseVectorString(uv);
+    // batches × algos; a failing batch keeps its previous scores (:274-276,311)
+    for (size_t b0 = 0; b0 < items.size(); b0 += (size_t)batch) {
+        const size_t b1 = std::min(items.size(), b0 + (size_t)batch);
+        for (const auto& algo : conf.RankAlgoList) {
+            algorithm::AlgoData data;
+            data.kind = algorithm::AlgoData::kRank;
+            data.rank.UserVector = user_vec;
+            for (size_t i = b0; i < b1; ++i) data.rank.ItemIds.push_back(items[i]->Id);
+            algorithm::AlgoResult res;
+            std::string aerr;
+            if (!e->algorithms.Run(algo, data, &res, &aerr)) continue;       // logged; batch skipped
+            for (size_t j = 0; j < res.responses.size() && b0 + j < b1; ++j)
+                items[b0 + j]->AddAlgoScore(algo, res.responses[j].GetScore());
+        }
+    }
+    if (!conf.RankScore.empty()) {                                           // :339-363
+        pg_expr* ex = nullptr;
+        if (pg_expr_compile(conf.RankScore.c_str(), &ex) != PG_OK) { if (err) *err = pg_err("pg_expr_compile"); return false; }
+        const int nv = pg_expr_num_vars(ex);
+        const uint32_t n = (uint32_t)items.size();
+        std::vector<double> vars((size_t)nv * n, 0.0), out(n);
+        for (int v = 0; v < nv; ++v) {
+            const std::string name = pg_expr_var_name(ex, v);
+            auto ab = ctx->ExperimentParams.find(name);                     // ast_parameter_data.go:30-40
+            for (uint32_t i = 0; i < n; ++i) {
+                double x = 0.0;
+                if (ab != ctx->ExperimentParams.end() && ab->second != 0.0) x = ab->second;
+                else items[i]->FloatExprData(name, &x);
+                vars[(size_t)v * n + i] = x;
+            }
+        }
+        const int rcode = n ? pg_expr_eval(e->ctx, ex, nv ? vars.data() : nullptr, n, out.data()) : PG_OK;
+        pg_expr_free(ex);
+        if (rcode != PG_OK) { if (err) *err = pg_err("pg_expr_eval"); return false; }
+        for (uint32_t i = 0; i < n; ++i) items[i]->Score = out[i];
+    }
+    return true;
+}
+}  // namespace rank
+
+// ---- engine --------------------------------------------------------------------------------------
+Engine::~Engine() {
+    if (ctx) {
+        if (model) pg_model_destroy(ctx, model);
+        if (table) pg_table_destroy(ctx, table);
+        pg_shutdown(ctx);
+    }
+}
+
+bool Engine::RowOfId(const std::string& id, uint32_t* row) const {
+    if (id.compare(0, id_prefix.size(), id_prefix) != 0) return false;
+    char* e = nullptr;
+    const unsigned long long r = strtoull(id.c_str() + id_prefix.size(), &e, 10);
+    if (e == id.c_str() + id_prefix.size() || *e != '\0' || r >= table_rows) return false;
+    *row = (uint32_t)r;
+    return true;
+}
+
+Engine* Engine::Create(const std::string& config_json, std::string* err) {
+    std::unique_ptr<Engine> e(new Engine());
+    if (!recconf::RecommendConfig::Parse(config_json, &e->config, err)) return nullptr;
+    // GPU plugin settings live in UserDefineConfs["pairec_gpu"]: unknown RecallType / SortType values
+    // in RecallConfs / SortConfs would panic the reference's factories (recall.go:99-101, sort.go:196-198)
+    const json::Value& g = e->config.UserDefineConfs.at("pairec_gpu");
+    if (g.type != json::Value::Object) { if (err) *err = "UserDefineConfs.pairec_gpu missing"; return nullptr; }
+    const json::Value& tb = g.at("Table");
+    e->table_rows = (uint64_t)tb.n("Rows");
+    e->dim = (uint32_t)tb.n("Dim", 128);
+    e->id_prefix = tb.s("IdPrefix", "item_");
+    if (pg_init((int)g.n("Device", 0), nullptr, &e->ctx) != PG_OK) { if (err) *err = pg_err("pg_init"); return nullptr; }
+    if (pg_table_create(e->ctx, e->table_rows, e->dim, 0, &e->table) != PG_OK) { if (err) *err = pg_err("pg_table_create"); return nullptr; }
+    if (pg_table_fill_synthetic(e->ctx, e->table, (uint64_t)tb.n("SyntheticSeed", 0x5EED0001), 1) != PG_OK) {
+        if (err) *err = pg_err("pg_table_fill_synthetic");
+        return nullptr;
+    }
+    // built-in sorts (sort.go init(): "ItemRankScore" is registered by default)
+    e->sorts.RegisterSort("ItemRankScore", std::make_shared<GpuItemRankScoreSort>(e.get()), nullptr);
+    e->sorts.RegisterSort("ItemScore", std::make_shared<GpuItemScoreSort>(e.get()), nullptr);
+    for (const auto& d : e->config.DPPConf) e->sorts.RegisterSort(d.Name, std::make_shared<GpuDPPSort>(e.get(), d), nullptr);
+    // algorithms by name (the shim's start hook does the same with algorithm.RegisterAlgorithm)
+    for (const auto& a : g.at("Algorithms").arr) {
+        const std::string name = a.s("Name"), kind = a.s("Kind");
+        if (kind == "faiss") e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuFaissAlgorithm>(e.get()));
+        else if (kind == "dnn3") e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuDnnAlgorithm>(e.get()));
+    }
+    for (const auto& r : e->config.RecallConfs)
+        e->recalls.RegisterRecall(r.Name, std::make_shared<GpuVectorRecall>(e.get(), r));
+    return e.release();
+}
+
+bool Engine::Recommend(const std::string& uid, int size, const std::string& scene,
+                       std::vector<module::ItemPtr>* out, std::string* err) {
+    module::User user(uid);
+    context::RecommendContext ctx;
+    ctx.Size = size;
+    ctx.Param["scene"] = json::Value::Str(scene);
+    // RecallService.GetItems (service/recall.go:53-153): scene → category → recall names, concatenated
+    std::vector<module::ItemPtr> items;
+    auto sc = config.SceneRecallNames.find(scene);
+    if (sc != config.SceneRecallNames.end())
+        for (const auto& cat : sc->second)
+            for (const auto& name : cat.second) {
+                std::string rerr;
+                auto r = recalls.GetRecall(name, &rerr);
+                if (!r) continue;
+                auto got = r->GetCandidateItems(&user, &ctx);
+                items.insert(items.end(), got.begin(), got.end());
+            }
+    items = filter::UniqueFilter(items);
+    if (!rank::Rank(this, &user, items, &ctx, err)) return false;
+    // SortService.Sort (sort/sort.go:65-125): SortNames[scene] else the default ItemRankScore
+    std::vector<std::string> names;
+    auto sn = config.SortNames.find(scene);
+    if (sn != config.SortNames.end()) names = sn->second;
+    if (names.empty()) names.push_back("ItemRankScore");
+    sort::SortData sd;
+    sd.Data = items;
+    sd.Context = &ctx;
+    sd.User = &user;
+    for (const auto& n : names) {
+        auto s = sorts.Get(n);
+        std::string serr;
+        if (s) s->Sort(&sd, &serr);                                   // error ignored (sort.go:123)
+    }
+    if ((int)sd.Data.size() > size) sd.Data.resize((size_t)size);     // items[:size]
+    *out = sd.Data;
+    return true;
+}
+
+}  // namespace pairec
+
+// ---- C driver API for the tests ---------------------------------------------------------------------
+using namespace pairec;
+static thread_local std::string g_ph_err;
+static thread_local std::string g_ph_out;
+
+extern "C" {
+
+const char* ph_last_error(void) { return g_ph_err.c_str(); }
+
+void* ph_engine_create(const char* config_json) {
+    std::string err;
+    Engine* e = Engine::Create(config_json ? config_json : "", &err);
+    if (!e) g_ph_err = err;
+    return e;
+}
+void ph_engine_destroy(void* h) { delete (Engine*)h; }
+
+// load the DNN3 rank model (blob format of pg_model_load) into the engine
+int ph_engine_load_dnn3(void* h, int prec, const char* blob, size_t len) {
+    Engine* e = (Engine*)h;
+    if (!e || !blob) return -1;
+    if (e->model) { pg_model_destroy(e->ctx, e->model); e->model = nullptr; }
+    const int rc = pg_model_load(e->ctx, PG_MODEL_DNN3, (pg_prec)prec, blob, len, &e->model);
+    if (rc != PG_OK) g_ph_err = pg_last_error();
+    return rc;
+}
+
+int ph_set_user_vector(void* h, const char* uid, const char* vec) {
+    if (!h || !uid || !vec) return -1;
+    ((Engine*)h)->user_vectors.vectors[uid] = vec;
+    return 0;
+}
+
+// → JSON {"items":[{"item_id":..,"score":..,"retrieve_id":..,"algo_scores":{..}}]}
+const char* ph_recommend(void* h, const char* uid, int size, const char* scene) {
+    if (!h) return nullptr;
+    std::vector<module::ItemPtr> items;
+    std::string err;
+    if (!((Engine*)h)->Recommend(uid ? uid : "", size, scene ? scene : "", &items, &err)) {
+        g_ph_err = err;
+        return nullptr;
+    }
+    std::string& o = g_ph_out;
+    o = "{\"items\":[";
+    for (size_t i = 0; i < items.size(); ++i) {
+        if (i) o += ",";
+        o += "{\"item_id\":";
+        json::Escape(items[i]->Id, &o);
+        o += ",\"score\":" + json::NumToString(items[i]->Score) + ",\"retrieve_id\":";
+        json::Escape(items[i]->RetrieveId, &o);
+        o += ",\"algo_scores\":{";
+        bool first = true;
+        for (const auto& kv : items[i]->algoScores) {
+            if (!first) o += ",";
+            first = false;
+            json::Escape(kv.first, &o);
+            o += ":" + json::NumToString(kv.second);
+        }
+        o += "}}";
+    }
+    o += "]}";
+    return o.c_str();
+}
+
+// host-only helpers (no GPU): used by the CPU tests of the mirror
+int ph_parse_vector_string(const char* s, float* out, int cap) {
+    const auto v = recall::ParseVectorString(s ? s : "");
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+// in: JSON [{"id":..,"score":..,"retrieve_id":..,"algo_scores":{..}}] → UniqueFilter → same shape + recall_scores
+const char* ph_unique_filter(const char* items_json) {
+    json::Value root;
+    std::string err;
+    if (!json::Parser(items_json ? items_json : "").Parse(&root, &err)) { g_ph_err = err; return nullptr; }
+    std::vector<module::ItemPtr> items;
+    for (const auto& v : root.arr) {
+        auto it = std::make_shared<module::Item>(v.s("id"));
+        it->Score = v.d("score");
+        it->RetrieveId = v.s("retrieve_id");
+        for (const auto& kv : v.at("algo_scores").obj) it->AddAlgoScore(kv.first, kv.second.num);
+        items.push_back(it);
+    }
+    const auto out = filter::UniqueFilter(items);
+    std::string& o = g_ph_out;
+    o = "[";
+    for (size_t i = 0; i < out.size(); ++i) {
+        if (i) o += ",";
+        o += "{\"id\":";
+        json::Escape(out[i]->Id, &o);
+        o += ",\"score\":" + json::NumToString(out[i]->Score) + ",\"algo_scores\":{";
+        bool first = true;
+        for (const auto& kv : out[i]->algoScores) {
+            if (!first) o += ",";
+            first = false;
+            json::Escape(kv.first, &o);
+            o += ":" + json::NumToString(kv.second);
+        }
+        o += "},\"recall_scores\":{";
+        first = true;
+        for (const auto& kv : out[i]->RecallScores) {
+            if (!first) o += ",";
+            first = false;
+            json::Escape(kv.first, &o);
+            o += ":" + json::NumToString(kv.second);
+        }
+        o += "}}";
+    }
+    o += "]";
+    return o.c_str();
+}
+
+// registry semantics: returns a bitmask of checks that hold (all 5 bits set = 31)
+int ph_registry_semantics(void) {
+    struct DummySort : sort::ISort { int id; explicit DummySort(int i) : id(i) {} bool Sort(sort::SortData*, std::string*) override { return true; } };
+    struct DummyAlgo : algorithm::IAlgorithm {
+        double v; explicit DummyAlgo(double x) : v(x) {}
+        bool Init(const recconf::AlgoConfig&, std::string*) override { return true; }
+        bool Run(const algorithm::AlgoData&, algorithm::AlgoResult* out, std::string*) override { out->responses.assign(1, algorithm::AlgoResponse{v}); return true; }
+    };
+    int ok = 0;
+    sort::Registry sr;
+    std::string err;
+    auto s1 = std::make_shared<DummySort>(1), s2 = std::make_shared<DummySort>(2);
+    sr.RegisterSort("x", s1, &err);
+    sr.RegisterSort("x", s2, &err);
+    if (sr.Get("x") == s1) ok |= 1;                                   // first registration wins
+    if (!sr.RegisterSort("nil", nullptr, &err)) ok |= 2;              // nil rejected (reference panics)
+    algorithm::AlgorithmFactory f;
+    f.RegisterAlgorithm("a", std::make_shared<DummyAlgo>(1.0));
+    f.RegisterAlgorithm("a", std::make_shared<DummyAlgo>(2.0));
+    algorithm::AlgoResult res;
+    if (f.Run("a", algorithm::AlgoData{}, &res, &err) && res.responses[0].GetScore() == 2.0) ok |= 4;   // overwrite
+    if (!f.Run("missing", algorithm::AlgoData{}, &res, &err) && err.find("not find algorithm") != std::string::npos) ok |= 8;
+    recall::Registry rr;
+    if (!rr.GetRecall("nope", &err)) ok |= 16;
+    return ok;
+}
+
+// parse a recconf JSON and echo the subset the engine honours (for config tests)
+const char* ph_parse_recconf(const char* text) {
+    recconf::RecommendConfig c;
+    std::string err;
+    if (!recconf::RecommendConfig::Parse(text ? text : "", &c, &err)) { g_ph_err = err; return nullptr; }
+    std::string& o = g_ph_out;
+    o = "{\"recalls\":" + std::to_string(c.RecallConfs.size()) + ",\"algos\":" + std::to_string(c.AlgoConfs.size()) +
+        ",\"rank_scenes\":" + std::to_string(c.RankConf.size()) + ",\"dpp\":" + std::to_string(c.DPPConf.size());
+    if (!c.RecallConfs.empty()) {
+        o += ",\"recall0\":{\"name\":";
+        json::Escape(c.RecallConfs[0].Name, &o);
+        o += ",\"count\":" + std::to_string(c.RecallConfs[0].RecallCount) + ",\"algo\":";
+        json::Escape(c.RecallConfs[0].RecallAlgo, &o);
+        o += "}";
+    }
+    for (const auto& kv : c.RankConf) {
+        o += ",\"rank_" + kv.first + "\":{\"batch\":" + std::to_string(kv.second.BatchCount) + ",\"score\":";
+        json::Escape(kv.second.RankScore, &o);
+        o += ",\"algos\":" + std::to_string(kv.second.RankAlgoList.size()) + "}";
+    }
+    o += "}";
+    return o.c_str();
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+// pairec_host.hpp — C++ mirror of pairec's plugin surfaces for the rank + recall hot path.
+//
+// The reference is Go and this image has no Go toolchain, so the host side above the C ABI
+// (include/pairec_gpu.h) is written in C++ with the reference's names, argument meaning and error
+// behaviour, so that the tests read like the reference's own:
+//   module::Item / User            module/item.go:15-27, module/user.go:16-25
+//   context::RecommendContext      context/recommend_context.go:18-34
+//   algorithm::IAlgorithm + factory algorithm/algorithm.go:28-31,107-120,164-168
+//   recall::Recall + registry      service/recall/recall.go:18-20,32-45
+//   sort::ISort + registry         sort/sort.go:33-35,143-150
+//   filter::UniqueFilter           filter/unique_filter.go:26-49
+//   rank::RankService              service/rank/rank_service.go:102-372
+//   recconf subset                 recconf/recconf.go:48-93,267-276,330-367,736-745,960-979
+// The GPU-backed plugins (GpuFaissAlgorithm, GpuDnnAlgorithm, GpuVectorRecall, Gpu*Sort) are what
+// the cgo shim of INTEGRATION.md registers under the same registries in a real pairec process.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pairec_gpu.h"
+#include "json.hpp"
+
+namespace pairec {
+
+// ---- module -------------------------------------------------------------------------------------
+namespace module {
+using ItemId = std::string;
+
+struct Item {
+    ItemId Id;
+    double Score = 0.0;
+    std::string RetrieveId;
+    std::string ItemType;
+    std::vector<double> Embedding;
+    std::map<std::string, json::Value> Properties;
+    std::map<std::string, double> algoScores;
+    std::map<std::string, double> RecallScores;
+    bool hasRecallScores = false;
+
+    explicit Item(ItemId id = "") : Id(std::move(id)) {}
+    void AddAlgoScore(const std::string& name, double score) { algoScores[name] = score; }   // item.go:168-176
+    void AddProperty(const std::string& k, json::Value v) { Properties[k] = std::move(v); }
+    // Item.FloatExprData (item.go:189-212): "current_score" has the recall_score side effect
+    bool FloatExprData(const std::string& name, double* out);
+};
+using ItemPtr = std::shared_ptr<Item>;
+
+struct User {
+    std::string Id;
+    std::map<std::string, json::Value> Properties;
+    explicit User(std::string id = "") : Id(std::move(id)) {}
+};
+
+// module.VectorDao (vector_dao.go:13-15): returns "1:v1 2:v2 …"; empty → VectoryEmptyError
+struct VectorDao {
+    virtual ~VectorDao() = default;
+    virtual bool VectorString(const std::string& id, std::string* out, std::string* err) = 0;
+};
+struct InMemoryVectorDao : VectorDao {
+    std::map<std::string, std::string> vectors;
+    bool VectorString(const std::string& id, std::string* out, std::string* err) override;
+};
+}  // namespace module
+
+// utils.ToFloat (utils/type.go:43-69)
+double ToFloat(const json::Value& v, double def);
+
+namespace context {
+struct RecommendContext {
+    int Size = 10;
+    bool Debug = false;
+    std::string RecommendId;
+    std::map<std::string, json::Value> Param;               // GetParameter("scene") etc.
+    std::map<std::string, double> ExperimentParams;         // AB overrides (float view)
+    std::string GetParameter(const std::string& k) const;
+};
+}  // namespace context
+
+// ---- recconf (subset) ---------------------------------------------------------------------------
+namespace recconf {
+struct AlgoConfig { std::string Name, Type; json::Value raw; };
+struct RecallConfig {
+    std::string Name, RecallType, RecallAlgo, ItemType, CachePrefix;
+    int RecallCount = 0, CacheTime = 0;
+};
+struct RankConfig {
+    std::vector<std::string> RankAlgoList;
+    std::string RankScore, Processor, ASTType;
+    int BatchCount = 0;
+};
+struct DPPSortConfig {
+    std::string Name;
+    double Alpha = 1.0;
+    int WindowSize = 0, CandidateCount = 0;
+    double MinScorePercent = 0.0;
+    bool NormalizeEmb = true;
+};
+struct RecommendConfig {
+    std::vector<AlgoConfig> AlgoConfs;
+    std::vector<RecallConfig> RecallConfs;
+    std::map<std::string, RankConfig> RankConf;                               // by scene
+    std::map<std::string, std::vector<std::string>> SortNames;                // by scene
+    std::map<std::string, std::map<std::string, std::vector<std::string>>> SceneRecallNames;  // scene → category → RecallNames
+    std::vector<DPPSortConfig> DPPConf;
+    json::Value UserDefineConfs;                                              // recconf.go:92
+    static bool Parse(const std::string& text, RecommendConfig* out, std::string* err);
+};
+}  // namespace recconf
+
+// ---- algorithm ----------------------------------------------------------------------------------
+namespace algorithm {
+// what IAlgorithm.Run receives / returns on the hot path (algoData is interface{} in Go)
+struct VectorRequest { uint32_t K = 0; std::vector<float> Vector; };                 // pai_web.VectorRequest
+struct VectorReply { std::vector<uint64_t> Retval; std::vector<float> Scores; std::vector<std::string> Labels; };
+struct RankRequest {                        // the GPU flavour of []map[string]interface{} / PBRequest:
+    std::vector<float> UserVector;          // user features already reduced to the model's user vector
+    std::vector<std::string> ItemIds;       // request order = response order (rank_service.go:312-335)
+};
+struct AlgoResponse {                       // response.AlgoResponse (algorithm/response/resonse.go:3-7)
+    double score = 0.0;
+    double GetScore() const { return score; }
+    bool GetModuleType() const { return false; }
+};
+struct AlgoData {
+    enum Kind { kVector, kRank } kind = kVector;
+    VectorRequest vec;
+    RankRequest rank;
+};
+struct AlgoResult {
+    VectorReply reply;
+    std::vector<AlgoResponse> responses;
+};
+
+struct IAlgorithm {
+    virtual ~IAlgorithm() = default;
+    virtual bool Init(const recconf::AlgoConfig& conf, std::string* err) = 0;
+    virtual bool Run(const AlgoData& data, AlgoResult* out, std::string* err) = 0;   // (interface{}, error)
+};
+
+// AlgorithmFactory (algorithm.go:33-120): RWMutex-guarded map, RegisterAlgorithm overwrites
+class AlgorithmFactory {
+public:
+    void RegisterAlgorithm(const std::string& name, std::shared_ptr<IAlgorithm> a);
+    bool Run(const std::string& name, const AlgoData& data, AlgoResult* out, std::string* err);
+private:
+    std::mutex mu_;
+    std::map<std::string, std::shared_ptr<IAlgorithm>> algos_;
+};
+}  // namespace algorithm
+
+// ---- recall -------------------------------------------------------------------------------------
+namespace recall {
+struct Recall {
+    virtual ~Recall() = default;
+    virtual std::vector<module::ItemPtr> GetCandidateItems(module::User* user, context::RecommendContext* ctx) = 0;
+};
+class Registry {                      // recalls map (recall.go:29-45): unguarded, overwrites
+public:
+    void RegisterRecall(const std::string& name, std::shared_ptr<Recall> r) { recalls_[name] = std::move(r); }
+    std::shared_ptr<Recall> GetRecall(const std::string& name, std::string* err);
+private:
+    std::map<std::string, std::shared_ptr<Recall>> recalls_;
+};
+// vector_recall.go:70-82
+std::vector<float> ParseVectorString(const std::string& s);
+}  // namespace recall
+
+// ---- filter -------------------------------------------------------------------------------------
+namespace filter {
+std::vector<module::ItemPtr> UniqueFilter(const std::vector<module::ItemPtr>& items);   // unique_filter.go:26-49
+}
+
+// ---- sort ---------------------------------------------------------------------------------------
+namespace sort {
+struct SortData {
+    std::vector<module::ItemPtr> Data;
+    context::RecommendContext* Context = nullptr;
+    module::User* User = nullptr;
+};
+struct ISort {
+    virtual ~ISort() = default;
+    virtual bool Sort(SortData* data, std::string* err) = 0;
+};
+class Registry {                      // sort.go:143-150: first registration wins; nil panics
+public:
+    bool RegisterSort(const std::string& name, std::shared_ptr<ISort> s, std::string* err);
+    std::shared_ptr<ISort> Get(const std::string& name);
+private:
+    std::map<std::string, std::shared_ptr<ISort>> sorts_;
+};
+}  // namespace sort
+
+// ---- the engine: GPU-backed plugins wired under the registries -------------------------------------
+class Engine {
+public:
+    ~Engine();
+    static Engine* Create(const std::string& config_json, std::string* err);
+    // Recommend (service/user_recommend.go:46-183 restricted to the hot path):
+    // recall → UniqueFilter → rank → sort → items[:size]
+    bool Recommend(const std::string& uid, int size, const std::string& scene,
+                   std::vector<module::ItemPtr>* out, std::string* err);
+
+    module::InMemoryVectorDao user_vectors;
+    algorithm::AlgorithmFactory algorithms;
+    recall::Registry recalls;
+    sort::Registry sorts;
+    recconf::RecommendConfig config;
+
+    pg_ctx* ctx = nullptr;
+    pg_table* table = nullptr;
+    pg_model* model = nullptr;
+    uint64_t table_rows = 0;
+    uint32_t dim = 0;
+    std::string id_prefix = "item_";          // row ↔ id dictionary: "<prefix><row>"
+    bool RowOfId(const std::string& id, uint32_t* row) const;
+    std::string IdOfRow(uint64_t row) const { return id_prefix + std::to_string(row); }
+};
+
+namespace rank {
+// RankService.Rank (rank_service.go:102-372): batches of BatchCount, one algorithm.Run per batch
+// and algo, scores written back with AddAlgoScore, Item.Score = RankScore expression.
+bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, context::RecommendContext* ctx,
+          std::string* err);
+}
+
+}  // namespace pairec

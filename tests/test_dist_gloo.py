@@ -6,6 +6,8 @@ the all_gather layout handed to the merge, ownership bookkeeping, request-order 
 the owner-computes rank, the all_reduce'd score slab, and that every rank ends with the same,
 oracle-identical answer."""
 import os
+
+os.environ.setdefault("OMP_NUM_THREADS", "2")     # two ranks share this box's cores
 import socket
 import sys
 
@@ -74,7 +76,8 @@ class CpuEngine:
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         tab = o.synth_rows(o.SEED_TABLE, 0, N_ROWS, DIM)

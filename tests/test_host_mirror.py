@@ -1,0 +1,122 @@
+"""Tests of the C++ host mirror (pairec_amd/host): registries, recconf subset, UniqueFilter and the
+vector text format on CPU; the config-driven recall → rank → sort pipeline on the GPU."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H():
+    L = C.CDLL(os.path.join(ROOT, "pairec_amd", "libpairec_host.so"))
+    L.ph_last_error.restype = C.c_char_p
+    L.ph_engine_create.restype = C.c_void_p
+    L.ph_engine_create.argtypes = [C.c_char_p]
+    L.ph_engine_destroy.argtypes = [C.c_void_p]
+    L.ph_engine_load_dnn3.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.ph_set_user_vector.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.ph_recommend.restype = C.c_char_p
+    L.ph_recommend.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p]
+    L.ph_parse_vector_string.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int]
+    L.ph_unique_filter.restype = C.c_char_p
+    L.ph_unique_filter.argtypes = [C.c_char_p]
+    L.ph_parse_recconf.restype = C.c_char_p
+    L.ph_parse_recconf.argtypes = [C.c_char_p]
+    return L
+
+
+RANK_SCORE = "${gpu_dnn}*(1+${current_score})^0.1"
+CONFIG = {
+    "RunMode": "product",
+    "AlgoConfs": [],
+    "RecallConfs": [{"Name": "gpu_vector_recall", "RecallType": "UserCustomRecall", "RecallCount": 300,
+                     "RecallAlgo": "gpu_faiss", "ItemType": "video"}],
+    "SceneConfs": {"home_feed": {"default": {"RecallNames": ["gpu_vector_recall"]}}},
+    "RankConf": {"home_feed": {"RankAlgoList": ["gpu_dnn"], "RankScore": RANK_SCORE, "BatchCount": 100}},
+    "SortNames": {"home_feed": ["ItemRankScore"]},
+    "UserDefineConfs": {"pairec_gpu": {"Device": 0,
+                                       "Table": {"Rows": 20000, "Dim": 128, "IdPrefix": "item_",
+                                                 "SyntheticSeed": o.SEED_TABLE},
+                                       "Algorithms": [{"Name": "gpu_faiss", "Kind": "faiss"},
+                                                      {"Name": "gpu_dnn", "Kind": "dnn3"}]}},
+}
+
+
+def test_registry_semantics(H):
+    # sort: first registration wins / nil rejected; algorithm: overwrite / unknown name errors;
+    # recall: unknown name errors  (sort.go:143-150, algorithm.go:107-120,164-168, recall.go:35-45)
+    assert H.ph_registry_semantics() == 31
+
+
+def test_parse_vector_string(H):
+    buf = (C.c_float * 16)()
+    text = "1:0.12 2:-0.3 junk 3:1e-2 4:x 5:1:2"
+    n = H.ph_parse_vector_string(text.encode(), buf, 16)
+    want = o.parse_vector_string(text)
+    assert n == len(want) and list(buf)[:n] == want.tolist()
+
+
+def test_unique_filter_matches_reference_semantics(H):
+    items = [{"id": "1", "score": 0.5, "retrieve_id": "r1", "algo_scores": {}},
+             {"id": "2", "score": 0.4, "retrieve_id": "r1", "algo_scores": {}},
+             {"id": "1", "score": 0.9, "retrieve_id": "r2", "algo_scores": {"m": 0.7}}]
+    out = json.loads(H.ph_unique_filter(json.dumps(items).encode()))
+    oi = [o.OracleItem(i["id"], i["score"], i["retrieve_id"]) for i in items]
+    oi[2].add_algo_score("m", 0.7)
+    want = o.unique_filter(oi)
+    assert [x["id"] for x in out] == [x.id for x in want]
+    assert out[0]["recall_scores"] == want[0].recall_scores and out[0]["algo_scores"] == want[0].algo_scores
+
+
+def test_recconf_subset(H):
+    got = json.loads(H.ph_parse_recconf(json.dumps(CONFIG).encode()))
+    assert got["recalls"] == 1 and got["recall0"] == {"name": "gpu_vector_recall", "count": 300, "algo": "gpu_faiss"}
+    assert got["rank_home_feed"] == {"batch": 100, "score": RANK_SCORE, "algos": 1}
+    assert H.ph_parse_recconf(b"{not json") is None and b"json" in H.ph_last_error()
+
+
+@pytest.mark.gpu
+def test_config_driven_pipeline_matches_oracle(H):
+    """recconf JSON → recall (VectorRecall shape) → UniqueFilter → RankService (batches of 100) →
+    RankScore fusion → ItemRankScore sort → items[:size], against the oracle end to end."""
+    import pairec_amd as pa
+    h = H.ph_engine_create(json.dumps(CONFIG).encode())
+    assert h, H.ph_last_error()
+    n, d = 20000, 128
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    w = o.Dnn3Weights()
+    user = o.synth_rows(o.SEED_QUERY, 3, 1, d)[0]
+    vec = " ".join("%d:%s" % (i + 1, repr(float(v))) for i, v in enumerate(user))
+    H.ph_set_user_vector(h, b"u1", vec.encode())
+    blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+    assert H.ph_engine_load_dnn3(h, pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+    out = json.loads(H.ph_recommend(h, b"u1", 50, b"home_feed"))
+    # the same request through the oracle
+    rows, scores = o.recall_topk(tab, user[None], 300)
+    items = [o.OracleItem("item_%d" % r, float(s), "gpu_vector_recall") for r, s in zip(rows[0], scores[0])]
+    items = o.unique_filter(items)
+    dnn = o.dnn3_forward(w, 0, user, tab[rows[0].astype(np.int64)])
+    for it, s in zip(items, dnn):
+        it.add_algo_score("gpu_dnn", float(np.float32(s)))
+    o.fuse_scores(RANK_SCORE, items)
+    order = o.sort_scores([it.score for it in items], True)[:50]
+    want = [items[i] for i in order]
+    got_ids = [x["item_id"] for x in out["items"]]
+    assert len(got_ids) == 50
+    # ids/order exact wherever the oracle's own scores are separated by more than the sigmoid tolerance
+    for g, w_ in zip(out["items"], want):
+        assert abs(g["score"] - w_.score) <= 1e-6
+    sep = np.abs(np.diff([w_.score for w_ in want])) > 1e-6
+    for i, (g, w_) in enumerate(zip(out["items"], want)):
+        if (i == 0 or sep[i - 1]) and (i == len(want) - 1 or sep[i]):
+            assert g["item_id"] == w_.id and g["retrieve_id"] == "gpu_vector_recall"
+            assert abs(g["algo_scores"]["gpu_dnn"] - w_.algo_scores["gpu_dnn"]) <= 2e-7
+            assert g["algo_scores"]["recall_score"] == w_.algo_scores["recall_score"]   # current_score side effect
+    assert sorted(got_ids) == sorted(w_.id for w_ in want) or sep.all() is False
+    H.ph_engine_destroy(h)
