@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 constexpr int kWave = 64;
-constexpr int kMaxQueries = 32;   // queries per table pass (one 32x32x2 f32 MFMA column block)
+constexpr int kMaxQueries = 64;   // queries per table pass (one or two 32-column blocks of the 32x32x2 f32 MFMA)
 
 // Scratch arena: grows on demand, never shrinks; owned by the context, used by one call at a time
 // (calls on a context are serialised by ctx->mu).

@@ -37,8 +37,8 @@ constexpr int kRingSlots = 4;                              // per wave: 1 consum
 constexpr int kScanWaves = 8;                              // waves per workgroup (2 per SIMD: one wave's
                                                            // waits/epilogues hide behind the other's MFMAs)
 constexpr int kScanLdsRing = kScanWaves * kRingSlots * kPieceBytes;   // 128 KiB
-constexpr int kStageCap = 300;                             // staged hits per wave (fills the LDS left by the ring)
-constexpr int kStageBytes = kStageCap * 12 + 256;          // keys + query ids + 32 counters + 32 bases
+constexpr int kStageCap = 280;                             // staged hits per wave (fills the LDS left by the ring)
+constexpr int kStageBytes = kStageCap * 12 + 512;          // keys + query ids + 64 counters + 64 bases
 constexpr int kScanLds = kScanLdsRing + kScanWaves * kStageBytes;
 
 __device__ __forceinline__ uint32_t f32_ordered_bits(float f) {
@@ -68,6 +68,7 @@ struct ScanArgs {
     uint32_t* overflow;      // set to 1 if any list overflowed
     uint32_t cap;
     uint32_t nq;
+    uint32_t nq_launch;      // queries of the call (selects the 32- or 64-query kernel)
     uint32_t rb_begin;       // first 32-row block of this launch
     uint32_t rb_end;         // one past the last block
     uint32_t row_end;        // rows >= row_end are ignored (table end)
@@ -104,7 +105,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // VAR: developer ablations (0 = product; 1 = no threshold test; 2 = no MFMA; 3 = no DMA)
-template <int DIM, int VAR = 0>
+// NQB = number of 32-query column blocks riding in the B operand (1: up to 32 queries, 2: up to 64).
+// With two blocks every A fragment feeds two independent accumulator chains and the kernel becomes
+// fp32-MFMA-bound instead of HBM-bound (2 x 64 cycles per 32 B of table per SIMD).
+template <int DIM, int NQB = 1, int VAR = 0>
 __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PPB = DIM / kPieceCols;       // pieces per 32-row block
@@ -119,16 +123,24 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
     const int h = lane >> 5;         // k parity (A, B); row half (C)
 
     // B operand: bq[s] = Q[query = lane&31][k = 2s + h]
-    float bq[DIM / 2];
+    float bq[NQB][DIM / 2];
+    float thr[NQB];
+    bool active[NQB];
 #pragma unroll
-    for (int s = 0; s < DIM / 2; ++s) bq[s] = a.qpad[i32 * DIM + 2 * s + h];
-    float thr = a.thr[i32];
-    const bool active = (uint32_t)i32 < a.nq;
+    for (int c = 0; c < NQB; ++c) {
+#pragma unroll
+        for (int s = 0; s < DIM / 2; ++s) bq[c][s] = a.qpad[(c * 32 + i32) * DIM + 2 * s + h];
+        thr[c] = a.thr[c * 32 + i32];
+        active[c] = (uint32_t)(c * 32 + i32) < a.nq;
+    }
     // Pin the operand loads' completion HERE: hipcc places a load's s_waitcnt at its first use,
     // which would otherwise land inside the streaming loop as vmcnt(0) and drain the DMA ring.
 #pragma unroll
-    for (int s = 0; s < DIM / 2; ++s) asm volatile("" : "+v"(bq[s]));
-    asm volatile("" : "+v"(thr));
+    for (int c = 0; c < NQB; ++c) {
+#pragma unroll
+        for (int s = 0; s < DIM / 2; ++s) asm volatile("" : "+v"(bq[c][s]));
+        asm volatile("" : "+v"(thr[c]));
+    }
 
     // DMA lane offsets.  A piece is 32 rows x 32 columns (one 128-B line per row); DMA n covers
     // LDS quad slots S = n*64 + lane ↔ (row i = S/8, quad p = S%8), which receive global quad
@@ -169,18 +181,18 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
     // wave-private staging list for threshold hits (keys + query ids)
     uint64_t* const st_key = reinterpret_cast<uint64_t*>(smem + kScanLdsRing + wave * kStageBytes);
     uint32_t* const st_q = reinterpret_cast<uint32_t*>(st_key + kStageCap);
-    uint32_t* const st_cnt = st_q + kStageCap;            // [32] per-query counts / running offsets
-    uint32_t* const st_base = st_cnt + 32;                // [32] reserved base per query
+    uint32_t* const st_cnt = st_q + kStageCap;            // [64] per-query counts / running offsets
+    uint32_t* const st_base = st_cnt + 64;                // [64] reserved base per query
     uint32_t st_n = 0;
-    // Flush: reserve space per QUERY (<= 32 returning global atomics per flush instead of one per
-    // hit — the 32 list counters are the hottest words of the launch), then scatter.
+    // Flush: reserve space per QUERY (<= 64 returning global atomics per flush instead of one per
+    // hit — the list counters are the hottest words of the launch), then scatter.
     auto flush = [&]() {
-        if (lane < 32) st_cnt[lane] = 0;
+        st_cnt[lane] = 0;
         for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
             const uint32_t e = e0 + lane;
             if (e < st_n) atomicAdd(&st_cnt[st_q[e]], 1u);
         }
-        if (lane < 32) {
+        {
             const uint32_t c = st_cnt[lane];
             st_base[lane] = c ? atomicAdd(&a.cnt[lane], c) : 0u;
             st_cnt[lane] = 0;
@@ -209,9 +221,11 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
     }
 
     for (uint32_t b = 0; b < nblk; ++b) {
-        f32x16 acc;
+        f32x16 acc[NQB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int c = 0; c < NQB; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 #pragma unroll
         for (int pc = 0; pc < PPB; ++pc) {
             const uint32_t t = b * PPB + pc;
@@ -237,66 +251,82 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
                 const float a1 = h ? q.w : q.z;
                 const int s = pc * (kPieceCols / 2) + 2 * g;
                 if (VAR == 2) {
-                    acc[g] += a0 + a1;
+                    acc[0][g] += a0 + a1;
                 } else {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[s + 1], acc, 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < NQB; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[c][s], acc[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < NQB; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[c][s + 1], acc[c], 0, 0, 0);
                 }
             }
         }
-        if (VAR == 1 || VAR == 3) { asm volatile("" ::"v"(acc)); continue; }
-        // ---- threshold test: C layout col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*h.
+        if (VAR == 1 || VAR == 3) {
+#pragma unroll
+            for (int c = 0; c < NQB; ++c) asm volatile("" ::"v"(acc[c][0]), "v"(acc[c][15]));   // keep the chain live
+            continue;
+        }
+        // ---- threshold test: C layout col = lane&31 (query within its block), row = (r&3)+8*(r>>2)+4*h.
         // Fast path: one not-less-than compare per accumulator register, OR-reduced.
         bool any = false;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) any |= !(acc[r] < thr);
-        if (__builtin_amdgcn_ballot_w64(any && active) != 0) {
+        for (int c = 0; c < NQB; ++c) {
+            bool anyc = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) anyc |= !(acc[c][r] < thr[c]);
+            any |= anyc && active[c];
+        }
+        if (__builtin_amdgcn_ballot_w64(any) != 0) {
             // Hits are rare (≈ K/rows_seen per row·query), so they are parked in a wave-private LDS
             // staging list and flushed in bulk: a returning atomic costs a full vmcnt drain of the
             // DMA ring, which must not happen once per block.
             const uint32_t row0 = (a.rb_begin + first + b) * kPieceRows;
-            uint32_t pass = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const bool p = active && !(acc[r] < thr) && row < a.row_end;
-                pass |= (p ? 1u : 0u) << r;
-            }
-            uint32_t total_hits = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                total_hits += __popcll(__builtin_amdgcn_ballot_w64((pass >> r) & 1u));
-            if (st_n + total_hits > (uint32_t)kStageCap) flush();
-            if (total_hits > (uint32_t)kStageCap) {
-                // dense case (first chunk: threshold still -inf): straight to global memory
-                if (pass != 0) {
-                    uint32_t pos = atomicAdd(&a.cnt[i32], (uint32_t)__popc(pass));
-                    uint64_t* dst = a.cand + (uint64_t)i32 * a.cap;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (pass & (1u << r)) {
-                            const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            if (pos < a.cap) dst[pos] = topk_key(acc[r], row);
-                            else *a.overflow = 1u;
-                            ++pos;
-                        }
-                    }
-                }
-                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), visible to hipcc's bookkeeping
-            } else {
+            for (int c = 0; c < NQB; ++c) {
+                const uint32_t qid = (uint32_t)(c * 32 + i32);
+                uint32_t pass = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool p = (pass >> r) & 1u;
-                    const uint64_t m = __builtin_amdgcn_ballot_w64(p);
-                    if (m != 0) {
-                        if (p) {
-                            const uint32_t pos = st_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            st_key[pos] = topk_key(acc[r], row);
-                            st_q[pos] = (uint32_t)i32;
+                    const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const bool p = active[c] && !(acc[c][r] < thr[c]) && row < a.row_end;
+                    pass |= (p ? 1u : 0u) << r;
+                }
+                if (__builtin_amdgcn_ballot_w64(pass != 0) == 0) continue;
+                uint32_t total_hits = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    total_hits += __popcll(__builtin_amdgcn_ballot_w64((pass >> r) & 1u));
+                if (st_n + total_hits > (uint32_t)kStageCap) flush();
+                if (total_hits > (uint32_t)kStageCap) {
+                    // dense case (first chunk: threshold still -inf): straight to global memory
+                    if (pass != 0) {
+                        uint32_t pos = atomicAdd(&a.cnt[qid], (uint32_t)__popc(pass));
+                        uint64_t* dst = a.cand + (uint64_t)qid * a.cap;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if (pass & (1u << r)) {
+                                const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                if (pos < a.cap) dst[pos] = topk_key(acc[c][r], row);
+                                else *a.overflow = 1u;
+                                ++pos;
+                            }
                         }
-                        st_n += __popcll(m);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to hipcc's bookkeeping
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool p = (pass >> r) & 1u;
+                        const uint64_t m = __builtin_amdgcn_ballot_w64(p);
+                        if (m != 0) {
+                            if (p) {
+                                const uint32_t pos = st_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                                const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                st_key[pos] = topk_key(acc[c][r], row);
+                                st_q[pos] = qid;
+                            }
+                            st_n += __popcll(m);
+                        }
                     }
                 }
             }
@@ -454,11 +484,11 @@ static uint32_t next_pow2(uint32_t x) {
     return p;
 }
 
-template <int DIM, int VAR = 0>
+template <int DIM, int NQB = 1, int VAR = 0>
 static int launch_scan(pg_ctx* ctx, const ScanArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        PG_HIP(hipFuncSetAttribute((const void*)scan_kernel<DIM, VAR>,
+        PG_HIP(hipFuncSetAttribute((const void*)scan_kernel<DIM, NQB, VAR>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds));
         attr_set = true;
     }
@@ -466,25 +496,31 @@ static int launch_scan(pg_ctx* ctx, const ScanArgs& a) {
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total + kScanWaves - 1) / kScanWaves;
     if (grid > need) grid = need;
-    scan_kernel<DIM, VAR><<<grid, 64 * kScanWaves, kScanLds, ctx->stream>>>(a);
+    scan_kernel<DIM, NQB, VAR><<<grid, 64 * kScanWaves, kScanLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
 
 static int dispatch_scan(pg_ctx* ctx, uint32_t dim, const ScanArgs& a) {
+    const bool wide = a.nq_launch > 32;          // two 32-query column blocks
     switch (dim) {
-        case 64: return launch_scan<64>(ctx, a);
+        case 64: return wide ? launch_scan<64, 2>(ctx, a) : launch_scan<64, 1>(ctx, a);
         case 128: {
 #ifdef PG_SCAN_VARIANTS
             const char* v = getenv("PG_SCAN_VAR");     // developer ablation builds only
-            if (v && v[0] == '1') return launch_scan<128, 1>(ctx, a);
-            if (v && v[0] == '2') return launch_scan<128, 2>(ctx, a);
-            if (v && v[0] == '3') return launch_scan<128, 3>(ctx, a);
+            if (v && v[0] == '1') return launch_scan<128, 1, 1>(ctx, a);
+            if (v && v[0] == '2') return launch_scan<128, 1, 2>(ctx, a);
+            if (v && v[0] == '3') return launch_scan<128, 1, 3>(ctx, a);
 #endif
-            return launch_scan<128>(ctx, a);
+            return wide ? launch_scan<128, 2>(ctx, a) : launch_scan<128, 1>(ctx, a);
         }
-        case 192: return launch_scan<192>(ctx, a);
-        case 256: return launch_scan<256>(ctx, a);
+        case 192:
+        case 256:
+            if (wide) {      // 2 x dim/2 B-operand registers no longer fit 2 waves per SIMD
+                set_error("recall: dim=%u supports at most 32 queries per pass (64 up to dim 128)", dim);
+                return PG_ERR_UNSUPPORTED;
+            }
+            return dim == 192 ? launch_scan<192, 1>(ctx, a) : launch_scan<256, 1>(ctx, a);
     }
     set_error("recall: dim=%u unsupported", dim);
     return PG_ERR_UNSUPPORTED;
@@ -579,7 +615,8 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             a.cand = rs.cand[cur];
             a.overflow = rs.overflow;
             a.cap = rs.cap;
-            a.nq = (getenv("PG_DEBUG_NOHITS") && rb > 0) ? 0 : nq;
+            a.nq = nq;
+            a.nq_launch = nq;
             a.rb_begin = rb;
             a.rb_end = rb + cb;
             a.row_end = rows;

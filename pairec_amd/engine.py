@@ -15,7 +15,7 @@ from . import _lib
 
 PREC_F32, PREC_BF16 = 0, 1
 MODEL_DNN3, MODEL_FM_TWOTOWER = 1, 2
-MAX_QUERIES = 32
+MAX_QUERIES = 64          # per table pass (32 when dim > 128)
 
 
 def _ptr(a: np.ndarray):
@@ -133,8 +133,9 @@ class Table:
         rows = np.empty((nq, k), dtype=np.uint64)
         scores = np.empty((nq, k), dtype=np.float32)
         counts = np.zeros(nq, dtype=np.uint32)
-        for s in range(0, nq, MAX_QUERIES):          # one table pass per 32 queries
-            e = min(nq, s + MAX_QUERIES)
+        per_pass = MAX_QUERIES if self.dim <= 128 else 32
+        for s in range(0, nq, per_pass):             # one table pass per batch of queries
+            e = min(nq, s + per_pass)
             r_, s_, c_ = rows[s:e], scores[s:e], counts[s:e]
             _lib.check(self.ctx.L.pg_recall_topk(self.ctx.h, self.h, _ptr(q[s:e]), e - s, k,
                                                  _ptr(r_), _ptr(s_), _ptr(c_)))

@@ -54,7 +54,9 @@ def test_table_upload_gather_swap(ctx):
 @pytest.mark.parametrize("n,d,k,nq", [
     (1000, 64, 200, 1),          # cfg 1 shape in miniature (dot-product top-200)
     (40000, 128, 200, 3),        # two chunks, one block per wave
-    (140000, 128, 500, 32),      # three chunks, several blocks per wave, full query batch
+    (140000, 128, 500, 32),      # three chunks, several blocks per wave, full 32-query block
+    (140000, 128, 300, 64),      # two 32-query column blocks per A fragment
+    (70000, 64, 100, 45),
     (300017, 64, 5000, 7),       # ragged row count, K=5000
     (123457, 192, 16384, 2),     # maximum K, dim 192
     (90000, 256, 50, 5),
@@ -77,9 +79,9 @@ def test_recall_batching_invariance(ctx):
     n, d, k = 60000, 128, 300
     t = pa.Table(ctx, n, d)
     t.fill_synthetic(o.SEED_TABLE)
-    q = o.synth_rows(o.SEED_QUERY, 0, 40, d)                 # 40 → two table passes (32 + 8)
+    q = o.synth_rows(o.SEED_QUERY, 0, 100, d)                # 100 → two table passes (64 + 36)
     rows, scores, _ = t.recall_topk(q, k)
-    for i in (0, 13, 31, 32, 39):
+    for i in (0, 13, 31, 32, 63, 64, 99):
         r1, s1, _ = t.recall_topk(q[i:i + 1], k)
         assert np.array_equal(r1[0], rows[i]) and np.array_equal(bits(s1[0]), bits(scores[i]))
     t.destroy()
