@@ -36,7 +36,8 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 constexpr int kWave = 64;
-constexpr int kMaxQueries = 64;   // queries per table pass (one or two 32-column blocks of the 32x32x2 f32 MFMA)
+constexpr int kMaxQueriesExact = 64;   // exact fp32-MFMA scan: one or two 32-query column blocks
+constexpr int kMaxQueries = 128;       // screened scan (bf16 filter + exact rescoring): four blocks
 
 // Scratch arena: grows on demand, never shrinks; owned by the context, used by one call at a time
 // (calls on a context are serialised by ctx->mu).
@@ -52,6 +53,10 @@ struct pg_table {
     uint64_t rows = 0;
     uint32_t dim = 0;
     uint64_t row_offset = 0;     // global row id of local row 0 (sharded tables)
+    // lazily computed statistics for the screened recall (invalidated by upload / fill / swap)
+    bool stats_valid = false;
+    bool all_finite = false;
+    float max_norm = 0.0f;       // upper bound of the rows' L2 norms
 };
 
 struct pg_ctx {

@@ -307,8 +307,8 @@ static int expr_eval_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars,
                             double* d_out) {
     void* p;
     int rc;
-    if ((rc = scratch_reserve(ctx, 4, 256, &p))) return rc;
-    uint32_t* d_err = (uint32_t*)p + 32;
+    if ((rc = scratch_reserve(ctx, 4, 1024, &p))) return rc;
+    uint32_t* d_err = (uint32_t*)p + 220;
     PG_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
     if (e->empty) {
         // GetExpAST("") == nil: the caller leaves Item.Score untouched; evaluate to 0 like

@@ -337,6 +337,319 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Screened scan: the same stream, but the per-row scores are first *bounded* with bf16 MFMA and
+// only rows that could beat the threshold are re-scored exactly.
+//
+//   s~ = sum_k bf16(x_k) * bf16(q_k)   (v_mfma_f32_32x32x16_bf16, 16x cheaper than the fp32 MFMA)
+//   |s~ - s| <= eps_q = 0.008 * max_row_norm * ||q||          (s = the specification's fmaf chain)
+//     [2*2^-8 + 2^-16 operand rounding (any rounding mode) + 2 * 128 * 2^-24 accumulation, times
+//      sum|x_k q_k| <= ||x||*||q||]
+// A row is staged when !(s~ < thr_q - eps_q); at flush time every staged (row, query) pair gets the
+// exact k-ascending fmaf chain from the fp32 table and is kept only if !(s < thr_q).  Any member of
+// the final top-K has s >= thr_q at every moment (thr is a lower bound of the final K-th score), so
+// s~ >= thr_q - eps_q and it is staged: the result is identical, bit for bit, to the exact scan.
+// With 128 queries (4 column blocks) per pass the MFMA work is 1/4 of the 32-query exact kernel's
+// and the kernel stays HBM-bound.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kScreenNQB = 4;                   // 4 x 32 = 128 queries per pass
+constexpr int kScreenStageCap = 256;
+constexpr int kScreenStageBytes = kScreenStageCap * 12 + 1024;     // keys, query ids, 128 counters, 128 bases
+constexpr int kScreenLds = kScanLdsRing + kScanWaves * kScreenStageBytes;
+constexpr float kScreenEps = 0.008f;
+
+struct ScreenArgs {
+    const float* tab;
+    const uint4* qb16;        // [NQB][DIM/16][64] bf16x8 B fragments
+    const float* qpad;        // [128][DIM] fp32 queries (exact re-scoring)
+    const float* thr;         // [128] exact running thresholds
+    const float* thr_screen;  // [128] thr - eps, rounded down
+    uint32_t* cnt;
+    uint64_t* cand;
+    uint32_t* overflow;
+    uint32_t cap, nq, rb_begin, rb_end, row_end;
+};
+
+template <int DIM>
+__global__ __launch_bounds__(64 * kScanWaves, 2) void screen_kernel(ScreenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PPB = DIM / kPieceCols;
+    constexpr int NS = kRingSlots;
+    constexpr int ND = kPieceDmas;
+    constexpr int NQB = kScreenNQB;
+    constexpr int KS = DIM / 16;                 // bf16 k-steps
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gw = blockIdx.x * kScanWaves + wave;
+    const uint32_t W = gridDim.x * kScanWaves;
+    const int i32 = lane & 31;
+    const int h = lane >> 5;
+
+    // B operand: bfrag[c][ks] = Q[c*32 + (lane&31)][ks*16 + 8h .. +7] as bf16
+    uint4 bfrag[NQB][KS];
+    float thr_s[NQB];
+    bool active[NQB];
+#pragma unroll
+    for (int c = 0; c < NQB; ++c) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bfrag[c][ks] = a.qb16[(c * KS + ks) * 64 + lane];
+        thr_s[c] = a.thr_screen[c * 32 + i32];
+        active[c] = (uint32_t)(c * 32 + i32) < a.nq;
+    }
+#pragma unroll
+    for (int c = 0; c < NQB; ++c) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bfrag[c][ks].x), "+v"(bfrag[c][ks].y), "+v"(bfrag[c][ks].z), "+v"(bfrag[c][ks].w));
+        asm volatile("" : "+v"(thr_s[c]));
+    }
+
+    uint32_t voff[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+        const int S = n * 64 + lane;
+        const int i = S >> 3, p = S & 7;
+        voff[n] = (uint32_t)(i * DIM + 4 * ((p + (i >> 1)) & 7)) * 4u;
+    }
+    const uint32_t lds_wave_u = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + wave * (NS * kPieceBytes));
+    char* const lds_ptr = smem + wave * (NS * kPieceBytes);
+    const int rd_row = i32 * 128;
+    const int rd_rot = (i32 >> 1) * 16;
+
+    const uint32_t total = a.rb_end - a.rb_begin;
+    const uint32_t bpw = (total + W - 1) / W;
+    const uint32_t first = gw * bpw;
+    const uint32_t nblk = first < total ? (total - first < bpw ? total - first : bpw) : 0;
+    if (nblk == 0) return;
+
+    auto piece_addr = [&](uint32_t t, const char*& ub, uint32_t& dst) {
+        uint32_t b = t / PPB;
+        if (b >= nblk) b = nblk - 1;
+        const uint64_t rb = (uint64_t)a.rb_begin + first + b;
+        const char* base = (const char*)a.tab + rb * (uint64_t)(kPieceRows * DIM * 4) + (t % PPB) * (kPieceCols * 4);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)base >> 32));
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
+        ub = (const char*)(((uint64_t)hi << 32) | lo);
+        dst = lds_wave_u + __builtin_amdgcn_readfirstlane(t % NS) * kPieceBytes;
+    };
+
+    // staging: (row, query) pairs that passed the bf16 screen
+    uint64_t* const st_key = reinterpret_cast<uint64_t*>(smem + kScanLdsRing + wave * kScreenStageBytes);
+    uint32_t* const st_q = reinterpret_cast<uint32_t*>(st_key + kScreenStageCap);
+    uint32_t* const st_cnt = st_q + kScreenStageCap;      // [128]
+    uint32_t* const st_base = st_cnt + 128;               // [128]
+    uint32_t st_n = 0;
+    auto flush = [&]() {
+        // phase A: exact re-scoring (the specification's k-ascending fmaf chain, fp32 table + query)
+        for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            if (e < st_n) {
+                const uint32_t row = (uint32_t)st_key[e];
+                const uint32_t q = st_q[e];
+                const float4* xr = reinterpret_cast<const float4*>(a.tab + (size_t)row * DIM);
+                const float4* qr = reinterpret_cast<const float4*>(a.qpad + (size_t)q * DIM);
+                float s = 0.0f;
+#pragma unroll 8
+                for (int j = 0; j < DIM / 4; ++j) {
+                    const float4 x = xr[j], y = qr[j];
+                    s = __fmaf_rn(x.x, y.x, s);
+                    s = __fmaf_rn(x.y, y.y, s);
+                    s = __fmaf_rn(x.z, y.z, s);
+                    s = __fmaf_rn(x.w, y.w, s);
+                }
+                const bool keep = !(s < a.thr[q]);
+                st_key[e] = keep ? topk_key(s, row) : 0ull;
+                if (!keep) st_q[e] = 0xFFFFFFFFu;
+            }
+        }
+        // phase B: per-query reservation (<= 128 returning atomics), then scatter
+        st_cnt[lane] = 0;
+        st_cnt[lane + 64] = 0;
+        for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            if (e < st_n && st_q[e] != 0xFFFFFFFFu) atomicAdd(&st_cnt[st_q[e]], 1u);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int q = lane + 64 * half;
+            const uint32_t c = st_cnt[q];
+            st_base[q] = c ? atomicAdd(&a.cnt[q], c) : 0u;
+            st_cnt[q] = 0;
+        }
+        for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            if (e < st_n && st_q[e] != 0xFFFFFFFFu) {
+                const uint32_t q = st_q[e];
+                const uint32_t pos = st_base[q] + atomicAdd(&st_cnt[q], 1u);
+                if (pos < a.cap) a.cand[(uint64_t)q * a.cap + pos] = st_key[e];
+                else *a.overflow = 1u;
+            }
+        }
+        st_n = 0;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    };
+
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) {
+        const char* src;
+        uint32_t dst;
+        piece_addr(t, src, dst);
+#pragma unroll
+        for (int n = 0; n < ND; ++n) dma_one(src, dst + n * 1024, voff[n], 0.0f);
+    }
+
+    for (uint32_t b = 0; b < nblk; ++b) {
+        f32x16 acc[NQB];
+#pragma unroll
+        for (int c = 0; c < NQB; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+#pragma unroll
+        for (int pc = 0; pc < PPB; ++pc) {
+            const uint32_t t = b * PPB + pc;
+            wait_vmcnt<ND * (NS - 2)>();
+            const char* nb_src;
+            uint32_t nb_dst;
+            piece_addr(t + NS - 1, nb_src, nb_dst);
+            const char* slot = lds_ptr + (t % NS) * kPieceBytes + rd_row;
+            // A fragment of k-step ksl (16 columns of the piece): this lane's 8 columns = quads
+            // ksl*4 + 2h and ksl*4 + 2h + 1 of its row
+            f32x4 q4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int quad = (j >> 1) * 4 + 2 * h + (j & 1);
+                q4[j] = *reinterpret_cast<const f32x4*>(slot + ((quad * 16 - rd_rot) & 112));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < ND; ++n) dma_one(nb_src, nb_dst + n * 1024, voff[n], q4[n].x);
+#pragma unroll
+            for (int ksl = 0; ksl < 2; ++ksl) {
+                const f32x4 lo = q4[2 * ksl], hi = q4[2 * ksl + 1];
+                const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const bf16x8 af = __builtin_convertvector(v, bf16x8);
+                const int ks = pc * 2 + ksl;
+#pragma unroll
+                for (int c = 0; c < NQB; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfrag[c][ks]), acc[c], 0, 0, 0);
+            }
+        }
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < NQB; ++c) {
+            bool anyc = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) anyc |= !(acc[c][r] < thr_s[c]);
+            any |= anyc && active[c];
+        }
+        if (__builtin_amdgcn_ballot_w64(any) != 0) {
+            const uint32_t row0 = (a.rb_begin + first + b) * kPieceRows;
+#pragma unroll
+            for (int c = 0; c < NQB; ++c) {
+                const uint32_t qid = (uint32_t)(c * 32 + i32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const bool p = active[c] && !(acc[c][r] < thr_s[c]) && row < a.row_end;
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(p);
+                    if (m != 0) {
+                        const uint32_t n = __popcll(m);
+                        if (st_n + n > (uint32_t)kScreenStageCap) flush();
+                        if (p) {
+                            const uint32_t pos = st_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            st_key[pos] = row;
+                            st_q[pos] = qid;
+                        }
+                        st_n += n;
+                    }
+                }
+            }
+        }
+    }
+    flush();
+    wait_vmcnt<0>();
+}
+
+// per call: bf16 B fragments of the (zero-padded) queries and eps_q = kScreenEps * max_norm * ||q||
+__global__ void screen_prep_kernel(const float* __restrict__ qpad, uint32_t dim, float max_norm,
+                                   uint4* __restrict__ qb16, float* __restrict__ eps) {
+    const uint32_t KS = dim / 16;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (uint32_t)kScreenNQB * KS * 64) {
+        const uint32_t lane = i & 63, ks = (i >> 6) % KS, c = (i >> 6) / KS;
+        const float* q = qpad + (size_t)(c * 32 + (lane & 31)) * dim + ks * 16 + 8 * (lane >> 5);
+        uint32_t w[4];
+        for (int e = 0; e < 4; ++e) {
+            auto rne = [](float x) -> uint32_t {
+                uint32_t b = __float_as_uint(x);
+                if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (b >> 16) | 0x40u;
+                b += 0x7FFFu + ((b >> 16) & 1u);
+                return b >> 16;
+            };
+            w[e] = rne(q[2 * e]) | (rne(q[2 * e + 1]) << 16);
+        }
+        qb16[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (i < (uint32_t)kMaxQueries) {
+        double ss = 0.0;
+        for (uint32_t k = 0; k < dim; ++k) {
+            const double v = (double)qpad[(size_t)i * dim + k];
+            ss += v * v;
+        }
+        // inflated so that it is an upper bound in fp32
+        eps[i] = (float)(sqrt(ss) * (double)max_norm * (double)kScreenEps * 1.0001) + 1e-30f;
+    }
+}
+
+// thr_screen = thr - eps, rounded toward -inf
+__global__ void screen_thr_kernel(const float* __restrict__ thr, const float* __restrict__ eps,
+                                  float* __restrict__ thr_screen) {
+    const uint32_t q = threadIdx.x;
+    if (q >= (uint32_t)kMaxQueries) return;
+    const float t = thr[q], e = eps[q];
+    float v = t - e;                                   // -inf stays -inf; inf/NaN eps → -inf/NaN
+    if (v == v && v > -__builtin_inff()) v = v - fabsf(v) * 1.2e-7f - 1e-37f;
+    if (!(e == e) || e == __builtin_inff()) v = -__builtin_inff();
+    thr_screen[q] = v;
+}
+
+// table statistics for the screen: max row L2 norm (upper bound) and finiteness
+__global__ void table_stats_kernel(const float* __restrict__ tab, uint64_t rows, uint32_t dim,
+                                   float* __restrict__ out_max, uint32_t* __restrict__ out_nonfinite) {
+    __shared__ float smax[256];
+    __shared__ uint32_t sbad[256];
+    float mx = 0.0f;
+    uint32_t bad = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        const float4* x = reinterpret_cast<const float4*>(tab + r * dim);
+        float ss = 0.0f;
+        for (uint32_t j = 0; j < dim / 4; ++j) {
+            const float4 v = x[j];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        if (!(ss < 3.0e38f)) bad = 1;                  // NaN, inf or overflow
+        mx = fmaxf(mx, ss);
+    }
+    smax[threadIdx.x] = mx;
+    sbad[threadIdx.x] = bad;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+            sbad[threadIdx.x] |= sbad[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(reinterpret_cast<uint32_t*>(out_max), __float_as_uint(smax[0]));   // non-negative floats order as uints
+        if (sbad[0]) atomicOr(out_nonfinite, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // select: keep the K largest keys of cand_in[q][0..M) in cand_out[q][0..min(M,K)), set cnt, thr.
 // One 1024-thread workgroup per query; 8 radix passes (one byte each) over L2-resident keys.
 // ---------------------------------------------------------------------------------------------
@@ -533,6 +846,10 @@ struct RecallScratch {
     uint32_t* overflow;
     uint64_t* cand[2];
     uint32_t cap;
+    // screened scan only
+    uint4* qb16;
+    float* eps;
+    float* thr_screen;
 };
 
 constexpr uint32_t kFirstChunkRows = 32768;
@@ -542,11 +859,15 @@ static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* 
     const uint32_t cap = k + kCandSlack;
     void* small;
     int rc;
-    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + 1024;
+    const size_t qb16_bytes = (size_t)kScreenNQB * (dim / 16) * 64 * 16;
+    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 16 + 1024;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
-    rs->thr = (float*)((char*)small + (size_t)kMaxQueries * dim * 4);
-    rs->cnt = (uint32_t*)(rs->thr + kMaxQueries);
+    rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
+    rs->thr = (float*)((char*)rs->qb16 + qb16_bytes);
+    rs->eps = rs->thr + kMaxQueries;
+    rs->thr_screen = rs->eps + kMaxQueries;
+    rs->cnt = (uint32_t*)(rs->thr_screen + kMaxQueries);
     rs->overflow = rs->cnt + kMaxQueries;
     void* c;
     if ((rc = scratch_reserve(ctx, 3, (size_t)2 * kMaxQueries * cap * 8, &c))) return rc;
@@ -572,7 +893,44 @@ static int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, 
     return PG_OK;
 }
 
-// the whole recall for <= 32 queries; all pointers are device pointers
+static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
+    pg_table* t = const_cast<pg_table*>(tc);          // lazily computed cache
+    if (t->stats_valid) return PG_OK;
+    void* p;
+    int rc;
+    if ((rc = scratch_reserve(ctx, 4, 1024, &p))) return rc;
+    float* d_max = (float*)p + 200;
+    uint32_t* d_bad = (uint32_t*)p + 201;
+    PG_HIP(hipMemsetAsync(d_max, 0, 8, ctx->stream));
+    table_stats_kernel<<<2048, 256, 0, ctx->stream>>>(t->d, t->rows, t->dim, d_max, d_bad);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipMemcpyAsync(ctx->h_status + 200, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    float mx;
+    memcpy(&mx, ctx->h_status + 200, 4);
+    t->all_finite = ctx->h_status[201] == 0;
+    t->max_norm = sqrtf(mx) * 1.0001f;
+    t->stats_valid = true;
+    return PG_OK;
+}
+
+template <int DIM>
+static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        PG_HIP(hipFuncSetAttribute((const void*)screen_kernel<DIM>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+        attr_set = true;
+    }
+    const uint32_t total = a.rb_end - a.rb_begin;
+    uint32_t grid = (uint32_t)ctx->num_cus;
+    const uint32_t need = (total + kScanWaves - 1) / kScanWaves;
+    if (grid > need) grid = need;
+    screen_kernel<DIM><<<grid, 64 * kScanWaves, kScreenLds, ctx->stream>>>(a);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+// the whole recall for one batch of queries (one table pass); all pointers are device pointers
 static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq,
                              uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
                              uint32_t* out_count) {
@@ -580,7 +938,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
     int rc;
     if ((rc = recall_scratch(ctx, t->dim, k, &rs))) return rc;
     void* d_count;
-    if ((rc = scratch_reserve(ctx, 4, 256, &d_count))) return rc;
+    if ((rc = scratch_reserve(ctx, 4, 1024, &d_count))) return rc;
 
     const uint32_t rows = (uint32_t)t->rows;
     const uint32_t nblocks = (rows + kPieceRows - 1) / kPieceRows;
@@ -588,11 +946,29 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
     uint64_t scanned_rows = 0;
     uint32_t scan_launches = 0;
 
+    // Policy: up to 32 queries ride the exact fp32-MFMA scan (HBM-bound).  Larger batches use the
+    // screened scan (bf16 filter + exact re-scoring), which stays HBM-bound up to 128 queries; it
+    // needs a finite table and dim <= 128, otherwise the 64-query exact kernel is used.
+    bool screen = nq > 32 && t->dim <= 128 && !getenv("PG_RECALL_EXACT");
+    if (screen) {
+        if ((rc = ensure_table_stats(ctx, t))) return rc;
+        if (!t->all_finite) screen = false;
+    }
+    if (!screen && nq > (uint32_t)kMaxQueriesExact) {
+        set_error("recall: %u queries need the screened scan (finite table, dim <= 128); at most %d otherwise",
+                  nq, kMaxQueriesExact);
+        return PG_ERR_UNSUPPORTED;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool safe = attempt == 1;           // bounded chunks: can never overflow
         recall_init_kernel<<<(kMaxQueries * t->dim + 255) / 256, 256, 0, ctx->stream>>>(
             d_queries, nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
         PG_HIP(hipGetLastError());
+        if (screen) {
+            screen_prep_kernel<<<(kScreenNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
+                rs.qpad, t->dim, t->max_norm, rs.qb16, rs.eps);
+            PG_HIP(hipGetLastError());
+        }
         int cur = 0;
         uint32_t rb = 0, n_ev = 0;
         PG_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -604,22 +980,9 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
                 const uint64_t grow = seen * 3;
                 chunk_rows = grow > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (uint32_t)grow;
             }
-            if (safe && chunk_rows > kCandSlack) chunk_rows = kCandSlack;
+            if (safe && chunk_rows > kCandSlack / 4) chunk_rows = kCandSlack / 4;
             uint32_t cb = chunk_rows / kPieceRows;
             if (cb > nblocks - rb) cb = nblocks - rb;
-            ScanArgs a;
-            a.tab = t->d;
-            a.qpad = rs.qpad;
-            a.thr = rs.thr;
-            a.cnt = rs.cnt;
-            a.cand = rs.cand[cur];
-            a.overflow = rs.overflow;
-            a.cap = rs.cap;
-            a.nq = nq;
-            a.nq_launch = nq;
-            a.rb_begin = rb;
-            a.rb_end = rb + cb;
-            a.row_end = rows;
             // HIP events bracket the scan launch only: their sum is the per-pass duration of the
             // dominant kernel that bench.py prices against the HBM roofline
             while (ctx->ev_pool.size() < 2 * (size_t)(n_ev + 1)) {
@@ -628,12 +991,53 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
                 ctx->ev_pool.push_back(e);
             }
             PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev], ctx->stream));
-            if ((rc = dispatch_scan(ctx, t->dim, a))) return rc;
+            if (screen && rb > 0) {
+                ScreenArgs sa;
+                sa.tab = t->d;
+                sa.qb16 = rs.qb16;
+                sa.qpad = rs.qpad;
+                sa.thr = rs.thr;
+                sa.thr_screen = rs.thr_screen;
+                sa.cnt = rs.cnt;
+                sa.cand = rs.cand[cur];
+                sa.overflow = rs.overflow;
+                sa.cap = rs.cap;
+                sa.nq = nq;
+                sa.rb_begin = rb;
+                sa.rb_end = rb + cb;
+                sa.row_end = rows;
+                rc = t->dim == 64 ? launch_screen<64>(ctx, sa) : launch_screen<128>(ctx, sa);
+                if (rc) return rc;
+            } else {
+                // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
+                // every row is a candidate and there is nothing to screen) in groups of <= 64 queries
+                const uint32_t gsz = screen ? (uint32_t)kMaxQueriesExact : nq;
+                for (uint32_t g0 = 0; g0 < nq; g0 += gsz) {
+                    ScanArgs a;
+                    a.tab = t->d;
+                    a.qpad = rs.qpad + (size_t)g0 * t->dim;
+                    a.thr = rs.thr + g0;
+                    a.cnt = rs.cnt + g0;
+                    a.cand = rs.cand[cur] + (size_t)g0 * rs.cap;
+                    a.overflow = rs.overflow;
+                    a.cap = rs.cap;
+                    a.nq = nq - g0 < gsz ? nq - g0 : gsz;
+                    a.nq_launch = a.nq;
+                    a.rb_begin = rb;
+                    a.rb_end = rb + cb;
+                    a.row_end = rows;
+                    if ((rc = dispatch_scan(ctx, t->dim, a))) return rc;
+                }
+            }
             PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], ctx->stream));
             ++n_ev;
             rb += cb;
             select_kernel<<<nq, 1024, 0, ctx->stream>>>(rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, k);
             PG_HIP(hipGetLastError());
+            if (screen) {
+                screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.thr_screen);
+                PG_HIP(hipGetLastError());
+            }
             cur ^= 1;
         }
         PG_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -679,6 +1083,7 @@ int pg_recall_topk_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, u
                        uint32_t k, uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count) {
     PG_REQUIRE(ctx && t && d_queries && d_out_rows && d_out_scores, "pg_recall_topk_dev: NULL argument");
     PG_REQUIRE(nq >= 1 && nq <= (uint32_t)pg::kMaxQueries, "pg_recall_topk_dev: nq=%u must be in [1,%d]", nq, pg::kMaxQueries);
+    PG_REQUIRE(t->dim <= 128 || nq <= 32, "pg_recall_topk_dev: dim %u supports at most 32 queries per call", t->dim);
     if (k < 1 || k > 16384) {
         pg::set_error("pg_recall_topk_dev: k=%u unsupported (1..16384)", k);
         return PG_ERR_UNSUPPORTED;
@@ -691,6 +1096,7 @@ int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_
                    uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
     PG_REQUIRE(ctx && t && queries && out_rows && out_scores, "pg_recall_topk: NULL argument");
     PG_REQUIRE(nq >= 1 && nq <= (uint32_t)pg::kMaxQueries, "pg_recall_topk: nq=%u must be in [1,%d]", nq, pg::kMaxQueries);
+    PG_REQUIRE(t->dim <= 128 || nq <= 32, "pg_recall_topk: dim %u supports at most 32 queries per call", t->dim);
     if (k < 1 || k > 16384) {
         pg::set_error("pg_recall_topk: k=%u unsupported (1..16384)", k);
         return PG_ERR_UNSUPPORTED;

@@ -124,6 +124,7 @@ int pg_table_fill_synthetic(pg_ctx* ctx, pg_table* t, uint64_t seed, int normali
     }
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(ctx->stream));
+    t->stats_valid = false;
     return PG_OK;
 }
 
@@ -136,6 +137,7 @@ int pg_table_upload(pg_ctx* ctx, pg_table* t, uint64_t row0, uint64_t nrows, con
     PG_HIP(hipMemcpyAsync(t->d + row0 * t->dim, host_rows, nrows * (size_t)t->dim * sizeof(float),
                           hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
+    t->stats_valid = false;
     return PG_OK;
 }
 
@@ -157,6 +159,9 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     PG_HIP(hipStreamSynchronize(ctx->stream));
     std::swap(a->d, b->d);
     std::swap(a->row_offset, b->row_offset);
+    std::swap(a->stats_valid, b->stats_valid);
+    std::swap(a->all_finite, b->all_finite);
+    std::swap(a->max_norm, b->max_norm);
     return PG_OK;
 }
 

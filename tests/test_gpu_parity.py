@@ -55,8 +55,10 @@ def test_table_upload_gather_swap(ctx):
     (1000, 64, 200, 1),          # cfg 1 shape in miniature (dot-product top-200)
     (40000, 128, 200, 3),        # two chunks, one block per wave
     (140000, 128, 500, 32),      # three chunks, several blocks per wave, full 32-query block
-    (140000, 128, 300, 64),      # two 32-query column blocks per A fragment
+    (140000, 128, 300, 64),      # > 32 queries: bf16 screen + exact re-scoring
     (70000, 64, 100, 45),
+    (250000, 128, 5000, 128),    # full 128-query pass, K=5000
+    (100003, 128, 1000, 100),
     (300017, 64, 5000, 7),       # ragged row count, K=5000
     (123457, 192, 16384, 2),     # maximum K, dim 192
     (90000, 256, 50, 5),
@@ -79,9 +81,9 @@ def test_recall_batching_invariance(ctx):
     n, d, k = 60000, 128, 300
     t = pa.Table(ctx, n, d)
     t.fill_synthetic(o.SEED_TABLE)
-    q = o.synth_rows(o.SEED_QUERY, 0, 100, d)                # 100 → two table passes (64 + 36)
+    q = o.synth_rows(o.SEED_QUERY, 0, 200, d)                # 200 → two table passes (128 + 72)
     rows, scores, _ = t.recall_topk(q, k)
-    for i in (0, 13, 31, 32, 63, 64, 99):
+    for i in (0, 13, 31, 32, 63, 64, 127, 128, 199):
         r1, s1, _ = t.recall_topk(q[i:i + 1], k)
         assert np.array_equal(r1[0], rows[i]) and np.array_equal(bits(s1[0]), bits(scores[i]))
     t.destroy()
@@ -115,6 +117,32 @@ def test_recall_edge_cases(ctx):
         orow, osc = o.recall_topk(tab, q, k)
         assert np.array_equal(rows, orow)
         assert np.array_equal(bits(scores), bits(osc))
+    t.destroy()
+
+
+def test_recall_screen_is_exact_on_hostile_data(ctx):
+    """The bf16 screen must never lose a true top-K member: unnormalised rows with a wide range of
+    norms, clustered near-duplicates (scores that differ only below bf16 resolution), heavy ties and
+    negative scores, scanned with 48 queries (screened path) — ids, order and score bits exact."""
+    rng = np.random.default_rng(11)
+    n, d, k, nq = 180_000, 128, 800, 48
+    base = rng.standard_normal((64, d)).astype(np.float32)
+    tab = base[rng.integers(0, 64, n)] * (1 + 1e-4 * rng.standard_normal((n, 1))).astype(np.float32)
+    tab *= (10.0 ** rng.uniform(-2, 2, (n, 1))).astype(np.float32)      # norms over 4 decades
+    tab[::1000] = tab[1::1000][: len(tab[::1000])]                         # exact duplicates → ties
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    q = (base[rng.integers(0, 64, nq)] + 0.01 * rng.standard_normal((nq, d))).astype(np.float32)
+    q[::3] *= -1.0                                                          # negative best scores too
+    rows, scores, _ = t.recall_topk(q, k)
+    orow, osc = o.recall_topk(tab, q, k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+    # a non-finite table cannot be screened: the call falls back to the exact 64-query kernel
+    tab[5, 7] = np.inf
+    t.upload(tab)
+    rows, scores, _ = t.recall_topk(q, k)
+    orow, osc = o.recall_topk(tab, q, k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
     t.destroy()
 
 
