@@ -8,9 +8,12 @@ in fp64 → ItemRankScore (descending) sort.  A "step" is one such batch; value 
 (R*5000 per step), inputs resident in HBM when the timed region starts.
 
   python bench.py --gpus N --steps K --warmup W
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the same 100M-row table is
-sharded by contiguous row range over the ranks (strong scaling), with an all_gather of the
-per-shard top-K lists and an all_reduce of the score slab per step (pairec_amd/dist.py).
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL), two modes:
+  --mode replica (default): the 51.2 GB table fits one GPU, so it is replicated and the *requests*
+      are sharded — every rank runs its own batches, no data-path collective, weak scaling.
+  --mode shard: cfg-5 style — every rank holds --rows rows of one N x --rows table (contiguous row
+      ranges), all_gather of the per-shard top-K lists + all_reduce of the score slab per step
+      (pairec_amd/dist.py); value counts each request once.
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,9 +44,22 @@ def parse_args():
     ap.add_argument("--k", type=int, default=5000)
     ap.add_argument("--batch", type=int, default=128, help="requests per step (<= 128 = one table pass)")
     ap.add_argument("--prec", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-reqs", type=int, default=20, help="single-request latency samples (N=1)")
     return ap.parse_args()
+
+
+def pmc_traffic(R):
+    """HBM bytes per table pass of the dominant kernel from the committed rocprofv3 PMC pass of this
+    same command (profiles/r1_scan_traffic.json; FETCH_SIZE x2 per the gfx950 correction of
+    MI355X_MICROARCH.md §HBM, + WRITE_SIZE).  None if that profile does not cover this batch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_scan_traffic.json")) as f:
+            d = json.load(f)
+        return d.get(str(R), {}).get("hbm_bytes_per_pass")
+    except Exception:
+        return None
 
 
 def make_queries(o, step, R, dim):
@@ -135,9 +151,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         stream = torch.cuda.current_stream().cuda_stream
 
-    ctx = pa.Context(local_rank, stream)
+    shard = world > 1 and args.mode == "shard"
+    ctx = pa.Context(local_rank, stream if shard else None)
     from pairec_amd.dist import shard_range, sharded_step, GpuShardEngine
-    begin, end = shard_range(args.rows, world, rank)
+    if shard:
+        begin, end = shard_range(args.rows * world, world, rank)       # N x rows table, one range per rank
+    else:
+        begin, end = 0, args.rows                                      # full replica
     table = pa.Table(ctx, end - begin, args.dim, row_offset=begin)
     table.fill_synthetic(o.SEED_TABLE)
     w = o.Dnn3Weights()
@@ -146,9 +166,10 @@ def main():
     expr = pa.Expr(RANK_EXPR)
 
     total_steps = args.warmup + args.steps
-    qs = [make_queries(o, s, R, args.dim) for s in range(total_steps)]
+    # replica mode: every rank serves different users
+    qs = [make_queries(o, s * (1 if shard else world) + (0 if shard else rank), R, args.dim) for s in range(total_steps)]
 
-    if world == 1:
+    if not shard:
         pipe = Pipeline1(pa, ctx, table, model, expr, R, K)
         d_qs = [ctx.to_device(q) for q in qs]
 
@@ -157,6 +178,9 @@ def main():
 
         def sync():
             ctx.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
     else:
         eng = GpuShardEngine(torch, ctx, table, model, expr, K, R)
         dev = torch.device("cuda", local_rank)
@@ -182,12 +206,13 @@ def main():
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
     if world > 1:
+        dev = torch.device("cuda", local_rank)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = R * K * args.steps / elapsed
+    value = R * K * args.steps / elapsed * (1 if shard else world)
     shard_bytes = (end - begin) * args.dim * 4
     scan_avg_ms = float(np.mean(scan_ms))
     achieved = shard_bytes / (scan_avg_ms * 1e-3) / 1e9
@@ -195,28 +220,31 @@ def main():
         "metric": "ranked items/sec, 5k-cand DNN rank (recall top-5000 of 100M x 128 -> DNN3 -> fuse -> sort)",
         "value": value, "unit": "ranked items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "weak",
         "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
         "config": {"workload": "configs[2]: recall 5k of %dx%d fp32 table in HBM -> 3-layer DNN rank "
                                "(256-512-256-1, %s MFMA) -> RankScore fusion (fp64) -> ItemRankScore sort"
                                % (args.rows, args.dim, args.prec),
                    "requests_per_step": R, "candidates_per_request": K, "table_rows": args.rows,
-                   "dim": args.dim, "parallelism": "table row-range shards x%d, all_gather top-K merge" % world
-                   if world > 1 else "1 GPU"},
-        "roofline": {"bound": "hbm", "kernel": "pg::scan_kernel<128>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                   "dim": args.dim,
+                   "parallelism": ("table row-range shards x%d (%d rows total), all_gather top-K merge + all_reduce scores"
+                                   % (world, args.rows * world)) if shard else
+                                  ("request-parallel x%d, table replicated per GPU, no data-path collective" % world
+                                   if world > 1 else "1 GPU")},
+        "roofline": {"bound": "hbm", "kernel": "pg::screen_kernel<128>" if R > 32 else "pg::scan_kernel<128,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R),
                      "bytes_per_pass": shard_bytes, "ms_per_pass": scan_avg_ms,
                      "note": "algorithmic bytes = shard rows x dim x 4 per table pass (one pass serves %d requests); "
                              "duration = sum of the pass's scan launches, HIP events on the launch stream" % R},
         "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},
         "rank_roofline": {"bound": "mfma", "kernel": "pg::mlp_kernel<bf16,512,256>",
-                          "achieved": (R * K / world) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
+                          "achieved": (R * K / (world if shard else 1)) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
                           "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": (R * K / world) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS}
+                          "frac": (R * K / (world if shard else 1)) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS}
         if args.prec == "bf16" and st.last_rank_ms > 0 else None,
     }
 
-    if world == 1 and args.latency_reqs > 0:
+    if world == 1 and args.latency_reqs > 0:  # noqa: E129
         # p50 single-request latency (R=1), same pipeline, inputs resident
         lat = []
         for i in range(args.latency_reqs):

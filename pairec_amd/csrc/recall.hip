@@ -977,7 +977,11 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             if (rb == 0) chunk_rows = kFirstChunkRows;
             else {
                 const uint64_t seen = (uint64_t)rb * kPieceRows;
-                const uint64_t grow = seen * 3;
+                // chunk = (growth-1) x rows seen: every chunk stages ≈ (growth-1)*K candidates per query
+                // (measured: 4 is best for the exact scan, 2 for the screened scan whose re-scoring
+                // gathers 512 B per staged candidate)
+                const double growth = getenv("PG_CHUNK_GROWTH") ? atof(getenv("PG_CHUNK_GROWTH")) : (screen ? 2.0 : 4.0);
+                const uint64_t grow = (uint64_t)((double)seen * (growth - 1.0));
                 chunk_rows = grow > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (uint32_t)grow;
             }
             if (safe && chunk_rows > kCandSlack / 4) chunk_rows = kCandSlack / 4;
