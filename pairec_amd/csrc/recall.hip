@@ -653,68 +653,108 @@ __global__ void table_stats_kernel(const float* __restrict__ tab, uint64_t rows,
 // select: keep the K largest keys of cand_in[q][0..M) in cand_out[q][0..min(M,K)), set cnt, thr.
 // One 1024-thread workgroup per query; 8 radix passes (one byte each) over L2-resident keys.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSelLdsKeys = 16384;          // candidate lists up to this size are selected in LDS
+
+// Block-wide radix-select helper state lives in LDS; keys come from `src` (LDS or global).
 __global__ __launch_bounds__(1024) void select_kernel(const uint64_t* __restrict__ cand_in,
                                                       uint64_t* __restrict__ cand_out,
                                                       uint32_t* __restrict__ cnt,
                                                       float* __restrict__ thr, uint32_t cap,
                                                       uint32_t K) {
+    extern __shared__ __attribute__((aligned(16))) char sel_smem[];
+    uint64_t* const lkeys = reinterpret_cast<uint64_t*>(sel_smem);          // [kSelLdsKeys] when used
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_digit, s_need, s_out;
+    __shared__ uint32_t s_digit, s_need, s_out, s_cnt;
+    __shared__ unsigned long long s_min, s_max;
     const uint32_t q = blockIdx.x;
     const uint64_t* in = cand_in + (uint64_t)q * cap;
     uint64_t* out = cand_out + (uint64_t)q * cap;
     uint32_t M = cnt[q];
     if (M > cap) M = cap;
     const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_min = ~0ull; s_max = 0ull; }
+    __syncthreads();
+    const bool in_lds = M <= kSelLdsKeys;
+    // pass 0: stage the keys in LDS (when they fit) and find their range
+    unsigned long long mn = ~0ull, mx = 0ull;
+    for (uint32_t i = tid; i < M; i += 1024) {
+        const uint64_t k = in[i];
+        if (in_lds) lkeys[i] = k;
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+    }
+    // wave-level reduce, then one LDS atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long omn = __shfl_xor(mn, off), omx = __shfl_xor(mx, off);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+    }
+    if ((tid & 63) == 0) {
+        atomicMin(&s_min, mn);
+        atomicMax(&s_max, mx);
+    }
+    __syncthreads();
+    const uint64_t kmin = s_min, kmax = s_max;
+    const uint64_t* src = in_lds ? lkeys : in;
     if (M <= K) {
-        uint64_t mn = ~0ull;
-        for (uint32_t i = tid; i < M; i += 1024) {
-            const uint64_t k = in[i];
-            out[i] = k;
-            mn = k < mn ? k : mn;
+        for (uint32_t i = tid; i < M; i += 1024) out[i] = src[i];
+        if (tid == 0) {
+            cnt[q] = M;
+            if (M == K && K > 0) thr[q] = key_score(kmin);     // threshold = score of the smallest key
         }
-        if (M == K && K > 0) {
-            // threshold = score of the smallest key
-            __shared__ unsigned long long s_min;
-            if (tid == 0) s_min = ~0ull;
-            __syncthreads();
-            atomicMin(&s_min, (unsigned long long)mn);
-            __syncthreads();
-            if (tid == 0) thr[q] = key_score((uint64_t)s_min);
-        }
-        if (tid == 0) cnt[q] = M;
         return;
     }
-    uint64_t prefix = 0, mask = 0;
+    // radix select of the K-th largest of (key - kmin): only the bits below the span's top bit vary,
+    // so the first digit is already well spread (no single hot histogram bin)
+    const uint64_t span = kmax - kmin;
+    int shift = span ? (63 - __clzll((long long)span)) - 7 : 0;
+    if (shift < 0) shift = 0;
+    uint64_t prefix = 0, mask = 0;              // over (key - kmin)
     uint32_t need = K;
-    for (int shift = 56; shift >= 0; shift -= 8) {
+    uint32_t bucket = M;
+    while (true) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < M; i += 1024) {
-            const uint64_t k = in[i];
+            const uint64_t k = src[i] - kmin;
             if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
         }
         __syncthreads();
         if (tid < 256) {
-            // bin `tid` holds the need-th largest iff  above < need <= above + hist[tid]
             uint32_t above = 0;
             for (int d = 255; d > (int)tid; --d) above += hist[d];
             if (above < need && need <= above + hist[tid]) {
                 s_digit = tid;
                 s_need = need - above;
+                s_cnt = hist[tid];
             }
         }
         __syncthreads();
         prefix |= (uint64_t)s_digit << shift;
         mask |= 255ull << shift;
         need = s_need;
+        bucket = s_cnt;
         __syncthreads();
+        if (shift == 0 || bucket == 1) break;
+        shift = shift >= 8 ? shift - 8 : 0;
     }
-    const uint64_t kth = prefix;           // keys are distinct → exactly K keys are >= kth
+    // keys are distinct.  If the selected bucket holds one key, that key is the K-th; otherwise all
+    // digits down to bit 0 were fixed and prefix is the full (key - kmin) of the K-th.
+    if (shift != 0) {
+        if (tid == 0) s_min = 0ull;
+        __syncthreads();
+        for (uint32_t i = tid; i < M; i += 1024) {
+            const uint64_t k = src[i] - kmin;
+            if ((k & mask) == prefix) s_min = k;            // exactly one thread writes
+        }
+        __syncthreads();
+        prefix = s_min;
+    }
+    const uint64_t kth = prefix + kmin;          // exactly K keys are >= kth
     if (tid == 0) s_out = 0;
     __syncthreads();
     for (uint32_t i = tid; i < M; i += 1024) {
-        const uint64_t k = in[i];
+        const uint64_t k = src[i];
         if (k >= kth) out[atomicAdd(&s_out, 1u)] = k;
     }
     if (tid == 0) {
@@ -789,6 +829,19 @@ __global__ void merge_keys_kernel(const uint64_t* __restrict__ rows, const float
         cand[(uint64_t)q * cap + i] = (r == ~0ull) ? 0ull : topk_key(scores[(uint64_t)q * per_q + i], (uint32_t)r);
     }
     if (i == 0) cnt[q] = per_q;
+}
+
+static int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
+                         uint32_t cap, uint32_t k) {
+    constexpr size_t lds = (size_t)kSelLdsKeys * 8;
+    static bool attr = false;
+    if (!attr) {
+        PG_HIP(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    select_kernel<<<nq, 1024, lds, ctx->stream>>>(in, out, cnt, thr, cap, k);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
 }
 
 static uint32_t next_pow2(uint32_t x) {
@@ -1036,7 +1089,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], ctx->stream));
             ++n_ev;
             rb += cb;
-            select_kernel<<<nq, 1024, 0, ctx->stream>>>(rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, k);
+            if ((rc = launch_select(ctx, nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, k))) return rc;
             PG_HIP(hipGetLastError());
             if (screen) {
                 screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.thr_screen);
@@ -1138,8 +1191,7 @@ int pg_topk_merge_dev(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores
     dim3 grid((uint32_t)((per_q + 255) / 256), nq);
     pg::merge_keys_kernel<<<grid, 256, 0, ctx->stream>>>(d_rows, d_scores, (uint32_t)per_q, rs.cap, rs.cand[0], rs.cnt);
     PG_HIP(hipGetLastError());
-    pg::select_kernel<<<nq, 1024, 0, ctx->stream>>>(rs.cand[0], rs.cand[1], rs.cnt, rs.thr, rs.cap, k);
-    PG_HIP(hipGetLastError());
+    if ((rc = pg::launch_select(ctx, nq, rs.cand[0], rs.cand[1], rs.cnt, rs.thr, rs.cap, k))) return rc;
     return pg::final_launch(ctx, rs.cand[1], rs.cnt, rs.cap, nq, k, 0, d_out_rows, d_out_scores, nullptr);
 }
 
