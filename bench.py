@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — ranked items/sec of pairec's recall → rank → sort hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the config the metric is quoted on): a batch of R=128 requests;
+Workload (BASELINE.json configs[2], the config the metric is quoted on): a batch of R=256 requests;
 each request = exact inner-product recall of the top 5000 of a 100M x 128 fp32 item table resident
 in HBM → 3-layer DNN rank (256→512→256→1, bf16 MFMA) of those 5000 candidates → RankScore fusion
 in fp64 → ItemRankScore (descending) sort.  A "step" is one such batch; value = ranked items / s
@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=100_000_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=5000)
-    ap.add_argument("--batch", type=int, default=128, help="requests per step (<= 128 = one table pass)")
+    ap.add_argument("--batch", type=int, default=256, help="requests per step (<= 256 = one table pass)")
     ap.add_argument("--prec", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,7 +137,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     R, K = args.batch, args.k
-    assert 1 <= R <= 128
+    assert 1 <= R <= 256
 
     import pairec_amd as pa
     from oracle import oracle as o       # synthetic-data spec + cpu_baseline leg only

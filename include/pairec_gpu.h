@@ -82,7 +82,7 @@ int pg_table_gather(pg_ctx* ctx, const pg_table* t, const uint32_t* rows, uint32
  * LIMIT n query (service/recall/hologres_vector_recall.go:23).
  *   score(row) = chain_k fmaf(x[row][k], q[k], acc)  (k ascending, fp32) — independent of nq.
  *   order: score descending (IEEE totalOrder, NaN last), then row ascending.
- * queries: [nq][dim] fp32, nq <= 128 per call (<= 32 when dim > 128); one call = one table pass.
+ * queries: [nq][dim] fp32, nq <= 256 per call (<= 32 when dim > 128); one call = one table pass.
  * Up to 32 queries use the exact fp32-MFMA scan; larger batches use a bf16-MFMA screen followed by
  * exact re-scoring of the survivors — results are identical bit for bit.  out_rows: [nq][k] global row ids (row_offset +
  * local), out_scores: [nq][k].  If the table has fewer than k rows the tail is filled with

@@ -219,9 +219,9 @@ int pg_dpp(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const doub
     pg::dpp_kernel_matrix_kernel<<<dim3((n + 255) / 256, n), 256, 0, ctx->stream>>>(F, R, n, d1, L);
     pg::dpp_greedy_kernel<<<1, 1024, 0, ctx->stream>>>(L, n, topn, window, D2, Cm, d_out, d_cnt);
     PG_HIP(hipGetLastError());
-    PG_HIP(hipMemcpyAsync(ctx->h_status + 128, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(ctx->h_status + 330, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
-    const uint32_t cnt = ctx->h_status[128];
+    const uint32_t cnt = ctx->h_status[330];
     PG_HIP(hipMemcpyAsync(out_idx, d_out, (size_t)cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
     *out_count = cnt;

@@ -307,8 +307,8 @@ static int expr_eval_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars,
                             double* d_out) {
     void* p;
     int rc;
-    if ((rc = scratch_reserve(ctx, 4, 1024, &p))) return rc;
-    uint32_t* d_err = (uint32_t*)p + 220;
+    if ((rc = scratch_reserve(ctx, 4, 4096, &p))) return rc;
+    uint32_t* d_err = (uint32_t*)p + 320;
     PG_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
     if (e->empty) {
         // GetExpAST("") == nil: the caller leaves Item.Score untouched; evaluate to 0 like
@@ -321,9 +321,9 @@ static int expr_eval_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars,
         expr_eval_kernel<<<(n_items + 255) / 256, 256, 0, ctx->stream>>>(dev, d_vars, n_items, d_out, d_err);
         PG_HIP(hipGetLastError());
     }
-    PG_HIP(hipMemcpyAsync(ctx->h_status + 64, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(ctx->h_status + 320, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->h_status[64] != 0) {
+    if (ctx->h_status[320] != 0) {
         set_error("pg_expr_eval: violation of arithmetic specification: a division by zero in '%s' "
                   "(the reference panics in ExprASTResult, utils/ast/ast.go:243-249)", e->source.c_str());
         return PG_ERR_ARITH;

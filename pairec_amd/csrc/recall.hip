@@ -354,10 +354,8 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kScreenNQB = 4;                   // 4 x 32 = 128 queries per pass
-constexpr int kScreenStageCap = 256;
-constexpr int kScreenStageBytes = kScreenStageCap * 12 + 1024;     // keys, query ids, 128 counters, 128 bases
-constexpr int kScreenLds = kScanLdsRing + kScanWaves * kScreenStageBytes;
+constexpr int kScreenMaxNQB = 8;                // 8 x 32 = 256 queries per pass at most
+constexpr int kScreenLds = 163840;              // the whole LDS of a CU: ring (128 KiB) + staging (32 KiB)
 constexpr float kScreenEps = 0.008f;
 
 struct ScreenArgs {
@@ -372,14 +370,19 @@ struct ScreenArgs {
     uint32_t cap, nq, rb_begin, rb_end, row_end;
 };
 
-template <int DIM>
-__global__ __launch_bounds__(64 * kScanWaves, 2) void screen_kernel(ScreenArgs a) {
+// NQB query blocks of 32; WAVES waves per workgroup.  <=128 queries: 8 waves (2 per SIMD), ring of 4
+// pieces per wave; 256 queries: the 256 B-operand registers leave room for one wave per SIMD only, so
+// 4 waves with a ring of 8 pieces each.
+template <int DIM, int NQB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PPB = DIM / kPieceCols;
-    constexpr int NS = kRingSlots;
+    constexpr int NS = kScanLdsRing / (WAVES * kPieceBytes);        // ring slots per wave
     constexpr int ND = kPieceDmas;
-    constexpr int NQB = kScreenNQB;
     constexpr int KS = DIM / 16;                 // bf16 k-steps
+    constexpr int kStageBytesW = (kScreenLds - kScanLdsRing) / WAVES;
+    constexpr int kCap = (kStageBytesW - NQB * 256 - 16) / 12;      // staged pairs per wave
+    constexpr int kScanWaves = WAVES;            // (shadows the exact kernel's constant in this scope)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * kScanWaves + wave;
@@ -436,10 +439,11 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void screen_kernel(ScreenArgs a
     };
 
     // staging: (row, query) pairs that passed the bf16 screen
-    uint64_t* const st_key = reinterpret_cast<uint64_t*>(smem + kScanLdsRing + wave * kScreenStageBytes);
-    uint32_t* const st_q = reinterpret_cast<uint32_t*>(st_key + kScreenStageCap);
-    uint32_t* const st_cnt = st_q + kScreenStageCap;      // [128]
-    uint32_t* const st_base = st_cnt + 128;               // [128]
+    uint64_t* const st_key = reinterpret_cast<uint64_t*>(smem + kScanLdsRing + wave * kStageBytesW);
+    uint32_t* const st_q = reinterpret_cast<uint32_t*>(st_key + kCap);
+    uint32_t* const st_cnt = st_q + kCap;                 // [NQB*32]
+    uint32_t* const st_base = st_cnt + NQB * 32;          // [NQB*32]
+    uint32_t* const st_tmp = st_base + NQB * 32;          // [2] wave total / fill cursor
     uint32_t st_n = 0;
     auto flush = [&]() {
         // phase A: exact re-scoring (the specification's k-ascending fmaf chain, fp32 table + query)
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void screen_kernel(ScreenArgs a
                 const float4* xr = reinterpret_cast<const float4*>(a.tab + (size_t)row * DIM);
                 const float4* qr = reinterpret_cast<const float4*>(a.qpad + (size_t)q * DIM);
                 float s = 0.0f;
-#pragma unroll 8
+#pragma unroll 2
                 for (int j = 0; j < DIM / 4; ++j) {
                     const float4 x = xr[j], y = qr[j];
                     s = __fmaf_rn(x.x, y.x, s);
@@ -464,16 +468,16 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void screen_kernel(ScreenArgs a
                 if (!keep) st_q[e] = 0xFFFFFFFFu;
             }
         }
-        // phase B: per-query reservation (<= 128 returning atomics), then scatter
-        st_cnt[lane] = 0;
-        st_cnt[lane + 64] = 0;
+        // phase B: per-query reservation (one returning atomic per query present), then scatter
+#pragma unroll
+        for (int part = 0; part < NQB / 2; ++part) st_cnt[lane + 64 * part] = 0;
         for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
             const uint32_t e = e0 + lane;
             if (e < st_n && st_q[e] != 0xFFFFFFFFu) atomicAdd(&st_cnt[st_q[e]], 1u);
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int q = lane + 64 * half;
+        for (int part = 0; part < NQB / 2; ++part) {
+            const int q = lane + 64 * part;
             const uint32_t c = st_cnt[q];
             st_base[q] = c ? atomicAdd(&a.cnt[q], c) : 0u;
             st_cnt[q] = 0;
@@ -536,36 +540,75 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void screen_kernel(ScreenArgs a
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfrag[c][ks]), acc[c], 0, 0, 0);
             }
         }
+        // ---- screen test.  Each lane packs its hits into a bit set (bit c*16+r ↔ accumulator c,
+        // register r); the slow path below only needs (row, query) — both follow from the bit index —
+        // so the accumulators are never indexed dynamically.
+        uint64_t bits[(NQB + 3) / 4];
+#pragma unroll
+        for (int w = 0; w < (NQB + 3) / 4; ++w) bits[w] = 0;
         bool any = false;
 #pragma unroll
         for (int c = 0; c < NQB; ++c) {
-            bool anyc = false;
+            uint32_t m16 = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) anyc |= !(acc[c][r] < thr_s[c]);
-            any |= anyc && active[c];
+            for (int r = 0; r < 16; ++r) m16 |= (!(acc[c][r] < thr_s[c]) ? 1u : 0u) << r;
+            if (!active[c]) m16 = 0;
+            any |= m16 != 0;
+            bits[c >> 2] |= (uint64_t)m16 << (16 * (c & 3));
         }
         if (__builtin_amdgcn_ballot_w64(any) != 0) {
             const uint32_t row0 = (a.rb_begin + first + b) * kPieceRows;
+            // rows past the table end (last block only) are dropped here
 #pragma unroll
-            for (int c = 0; c < NQB; ++c) {
-                const uint32_t qid = (uint32_t)(c * 32 + i32);
+            for (int w = 0; w < (NQB + 3) / 4; ++w) {
+                uint64_t keep = 0;
+                for (uint64_t t = bits[w]; t != 0; t &= t - 1) {
+                    const int bi = __builtin_ctzll(t);
+                    const int r = bi & 15;
+                    if (row0 + (r & 3) + 8 * (r >> 2) + 4 * h < a.row_end) keep |= 1ull << bi;
+                }
+                bits[w] = (row0 + 32 <= a.row_end) ? bits[w] : keep;
+            }
+            uint32_t n_l = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const bool p = active[c] && !(acc[c][r] < thr_s[c]) && row < a.row_end;
-                    const uint64_t m = __builtin_amdgcn_ballot_w64(p);
-                    if (m != 0) {
+            for (int w = 0; w < (NQB + 3) / 4; ++w) n_l += __popcll(bits[w]);
+            // wave total and per-lane offsets through two LDS words (st_tmp[0] = total, [1] = fill)
+            if (lane == 0) { st_tmp[0] = 0; }
+            if (n_l) atomicAdd(&st_tmp[0], n_l);
+            const uint32_t total_hits = st_tmp[0];
+            if (total_hits <= (uint32_t)kCap) {
+                if (st_n + total_hits > (uint32_t)kCap) flush();
+                if (lane == 0) st_tmp[1] = st_n;
+                uint32_t pos = n_l ? atomicAdd(&st_tmp[1], n_l) : 0u;
+#pragma unroll
+                for (int w = 0; w < (NQB + 3) / 4; ++w)
+                    for (uint64_t t = bits[w]; t != 0; t &= t - 1) {
+                        const int bi = __builtin_ctzll(t);
+                        const int r = bi & 15, c = w * 4 + (bi >> 4);
+                        st_key[pos] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        st_q[pos] = (uint32_t)(c * 32 + i32);
+                        ++pos;
+                    }
+                st_n += total_hits;
+            } else {
+                // dense block (adversarial data): one (c, r) slice at a time, at most 64 pairs each
+#pragma unroll
+                for (int w = 0; w < (NQB + 3) / 4; ++w)
+                    for (int bi = 0; bi < 64; ++bi) {
+                        const bool p = (bits[w] >> bi) & 1ull;
+                        const uint64_t m = __builtin_amdgcn_ballot_w64(p);
+                        if (m == 0) continue;
                         const uint32_t n = __popcll(m);
-                        if (st_n + n > (uint32_t)kScreenStageCap) flush();
+                        if (st_n + n > (uint32_t)kCap) flush();
                         if (p) {
                             const uint32_t pos = st_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            st_key[pos] = row;
-                            st_q[pos] = qid;
+                            const int r = bi & 15, c = w * 4 + (bi >> 4);
+                            st_key[pos] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            st_q[pos] = (uint32_t)(c * 32 + i32);
                         }
                         st_n += n;
                     }
-                }
             }
         }
     }
@@ -578,7 +621,7 @@ __global__ void screen_prep_kernel(const float* __restrict__ qpad, uint32_t dim,
                                    uint4* __restrict__ qb16, float* __restrict__ eps) {
     const uint32_t KS = dim / 16;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (uint32_t)kScreenNQB * KS * 64) {
+    if (i < (uint32_t)kScreenMaxNQB * KS * 64) {
         const uint32_t lane = i & 63, ks = (i >> 6) % KS, c = (i >> 6) / KS;
         const float* q = qpad + (size_t)(c * 32 + (lane & 31)) * dim + ks * 16 + 8 * (lane >> 5);
         uint32_t w[4];
@@ -906,13 +949,13 @@ struct RecallScratch {
 };
 
 constexpr uint32_t kFirstChunkRows = 32768;
-constexpr uint32_t kCandSlack = 1u << 20;      // candidate capacity beyond K per query
+constexpr uint32_t kCandSlack = 1u << 19;      // candidate capacity beyond K per query
 
 static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     const uint32_t cap = k + kCandSlack;
     void* small;
     int rc;
-    const size_t qb16_bytes = (size_t)kScreenNQB * (dim / 16) * 64 * 16;
+    const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
     const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 16 + 1024;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
@@ -951,36 +994,43 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     if (t->stats_valid) return PG_OK;
     void* p;
     int rc;
-    if ((rc = scratch_reserve(ctx, 4, 1024, &p))) return rc;
-    float* d_max = (float*)p + 200;
-    uint32_t* d_bad = (uint32_t*)p + 201;
+    if ((rc = scratch_reserve(ctx, 4, 4096, &p))) return rc;
+    float* d_max = (float*)p + 300;
+    uint32_t* d_bad = (uint32_t*)p + 301;
     PG_HIP(hipMemsetAsync(d_max, 0, 8, ctx->stream));
     table_stats_kernel<<<2048, 256, 0, ctx->stream>>>(t->d, t->rows, t->dim, d_max, d_bad);
     PG_HIP(hipGetLastError());
-    PG_HIP(hipMemcpyAsync(ctx->h_status + 200, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(ctx->h_status + 300, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
     float mx;
-    memcpy(&mx, ctx->h_status + 200, 4);
-    t->all_finite = ctx->h_status[201] == 0;
+    memcpy(&mx, ctx->h_status + 300, 4);
+    t->all_finite = ctx->h_status[301] == 0;
     t->max_norm = sqrtf(mx) * 1.0001f;
     t->stats_valid = true;
     return PG_OK;
 }
 
-template <int DIM>
+template <int DIM, int NQB, int WAVES>
 static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        PG_HIP(hipFuncSetAttribute((const void*)screen_kernel<DIM>, hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
+        PG_HIP(hipFuncSetAttribute((const void*)screen_kernel<DIM, NQB, WAVES>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
         attr_set = true;
     }
     const uint32_t total = a.rb_end - a.rb_begin;
     uint32_t grid = (uint32_t)ctx->num_cus;
-    const uint32_t need = (total + kScanWaves - 1) / kScanWaves;
+    const uint32_t need = (total + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
-    screen_kernel<DIM><<<grid, 64 * kScanWaves, kScreenLds, ctx->stream>>>(a);
+    screen_kernel<DIM, NQB, WAVES><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
+}
+
+static int dispatch_screen(pg_ctx* ctx, uint32_t dim, const ScreenArgs& a) {
+    const bool wide = a.nq > 128;
+    if (dim == 64) return wide ? launch_screen<64, 8, 4>(ctx, a) : launch_screen<64, 4, 8>(ctx, a);
+    return wide ? launch_screen<128, 8, 4>(ctx, a) : launch_screen<128, 4, 8>(ctx, a);
 }
 
 // the whole recall for one batch of queries (one table pass); all pointers are device pointers
@@ -991,7 +1041,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
     int rc;
     if ((rc = recall_scratch(ctx, t->dim, k, &rs))) return rc;
     void* d_count;
-    if ((rc = scratch_reserve(ctx, 4, 1024, &d_count))) return rc;
+    if ((rc = scratch_reserve(ctx, 4, 4096, &d_count))) return rc;
 
     const uint32_t rows = (uint32_t)t->rows;
     const uint32_t nblocks = (rows + kPieceRows - 1) / kPieceRows;
@@ -1018,7 +1068,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             d_queries, nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
         PG_HIP(hipGetLastError());
         if (screen) {
-            screen_prep_kernel<<<(kScreenNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
+            screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
                 rs.qpad, t->dim, t->max_norm, rs.qb16, rs.eps);
             PG_HIP(hipGetLastError());
         }
@@ -1037,7 +1087,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
                 const uint64_t grow = (uint64_t)((double)seen * (growth - 1.0));
                 chunk_rows = grow > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (uint32_t)grow;
             }
-            if (safe && chunk_rows > kCandSlack / 4) chunk_rows = kCandSlack / 4;
+            if (safe && chunk_rows > kCandSlack / 2) chunk_rows = kCandSlack / 2;
             uint32_t cb = chunk_rows / kPieceRows;
             if (cb > nblocks - rb) cb = nblocks - rb;
             // HIP events bracket the scan launch only: their sum is the per-pass duration of the
@@ -1063,8 +1113,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
                 sa.rb_begin = rb;
                 sa.rb_end = rb + cb;
                 sa.row_end = rows;
-                rc = t->dim == 64 ? launch_screen<64>(ctx, sa) : launch_screen<128>(ctx, sa);
-                if (rc) return rc;
+                if ((rc = dispatch_screen(ctx, t->dim, sa))) return rc;
             } else {
                 // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
                 // every row is a candidate and there is nothing to screen) in groups of <= 64 queries

@@ -15,7 +15,7 @@ from . import _lib
 
 PREC_F32, PREC_BF16 = 0, 1
 MODEL_DNN3, MODEL_FM_TWOTOWER = 1, 2
-MAX_QUERIES = 128         # per table pass (32 when dim > 128)
+MAX_QUERIES = 256         # per table pass (32 when dim > 128)
 
 
 def _ptr(a: np.ndarray):

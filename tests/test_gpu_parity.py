@@ -58,6 +58,8 @@ def test_table_upload_gather_swap(ctx):
     (140000, 128, 300, 64),      # > 32 queries: bf16 screen + exact re-scoring
     (70000, 64, 100, 45),
     (250000, 128, 5000, 128),    # full 128-query pass, K=5000
+    (200000, 128, 2000, 256),    # 256 queries: 8 B blocks, one wave per SIMD
+    (90000, 64, 300, 200),
     (100003, 128, 1000, 100),
     (300017, 64, 5000, 7),       # ragged row count, K=5000
     (123457, 192, 16384, 2),     # maximum K, dim 192
@@ -81,9 +83,9 @@ def test_recall_batching_invariance(ctx):
     n, d, k = 60000, 128, 300
     t = pa.Table(ctx, n, d)
     t.fill_synthetic(o.SEED_TABLE)
-    q = o.synth_rows(o.SEED_QUERY, 0, 200, d)                # 200 → two table passes (128 + 72)
+    q = o.synth_rows(o.SEED_QUERY, 0, 300, d)                # 300 → two table passes (256 + 44)
     rows, scores, _ = t.recall_topk(q, k)
-    for i in (0, 13, 31, 32, 63, 64, 127, 128, 199):
+    for i in (0, 13, 31, 32, 63, 64, 127, 128, 255, 256, 299):
         r1, s1, _ = t.recall_topk(q[i:i + 1], k)
         assert np.array_equal(r1[0], rows[i]) and np.array_equal(bits(s1[0]), bits(scores[i]))
     t.destroy()
