@@ -373,7 +373,11 @@ struct ScreenArgs {
 // NQB query blocks of 32; WAVES waves per workgroup.  <=128 queries: 8 waves (2 per SIMD), ring of 4
 // pieces per wave; 256 queries: the 256 B-operand registers leave room for one wave per SIMD only, so
 // 4 waves with a ring of 8 pieces each.
-template <int DIM, int NQB, int WAVES>
+// SPLIT = 2: waves (2j, 2j+1) walk the SAME run of blocks, each against its own half of the queries
+// (NQB blocks each).  The table is then requested twice within a few microseconds; the second request
+// is served by L2 / Infinity Cache, so HBM traffic stays ≈ 1x while both waves keep their B operand in
+// 128 registers (two waves per SIMD) — 256 queries per pass without the one-wave-per-SIMD penalty.
+template <int DIM, int NQB, int WAVES, int SPLIT = 1>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PPB = DIM / kPieceCols;
@@ -385,8 +389,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     constexpr int kScanWaves = WAVES;            // (shadows the exact kernel's constant in this scope)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t gw = blockIdx.x * kScanWaves + wave;
-    const uint32_t W = gridDim.x * kScanWaves;
+    const uint32_t gw_raw = blockIdx.x * kScanWaves + wave;
+    const uint32_t gw = gw_raw / SPLIT;                          // block-run owner (shared by a wave group)
+    const uint32_t W = gridDim.x * kScanWaves / SPLIT;
+    const int qb0 = (int)(gw_raw % SPLIT) * NQB;                 // first query block of this wave
     const int i32 = lane & 31;
     const int h = lane >> 5;
 
@@ -397,9 +403,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
 #pragma unroll
     for (int c = 0; c < NQB; ++c) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bfrag[c][ks] = a.qb16[(c * KS + ks) * 64 + lane];
-        thr_s[c] = a.thr_screen[c * 32 + i32];
-        active[c] = (uint32_t)(c * 32 + i32) < a.nq;
+        for (int ks = 0; ks < KS; ++ks) bfrag[c][ks] = a.qb16[((qb0 + c) * KS + ks) * 64 + lane];
+        thr_s[c] = a.thr_screen[(qb0 + c) * 32 + i32];
+        active[c] = (uint32_t)((qb0 + c) * 32 + i32) < a.nq;
     }
 #pragma unroll
     for (int c = 0; c < NQB; ++c) {
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
             const uint32_t e = e0 + lane;
             if (e < st_n) {
                 const uint32_t row = (uint32_t)st_key[e];
-                const uint32_t q = st_q[e];
+                const uint32_t q = (uint32_t)qb0 * 32 + st_q[e];
                 const float4* xr = reinterpret_cast<const float4*>(a.tab + (size_t)row * DIM);
                 const float4* qr = reinterpret_cast<const float4*>(a.qpad + (size_t)q * DIM);
                 float s = 0.0f;
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         for (int part = 0; part < NQB / 2; ++part) {
             const int q = lane + 64 * part;
             const uint32_t c = st_cnt[q];
-            st_base[q] = c ? atomicAdd(&a.cnt[q], c) : 0u;
+            st_base[q] = c ? atomicAdd(&a.cnt[qb0 * 32 + q], c) : 0u;
             st_cnt[q] = 0;
         }
         for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
             if (e < st_n && st_q[e] != 0xFFFFFFFFu) {
                 const uint32_t q = st_q[e];
                 const uint32_t pos = st_base[q] + atomicAdd(&st_cnt[q], 1u);
-                if (pos < a.cap) a.cand[(uint64_t)q * a.cap + pos] = st_key[e];
+                if (pos < a.cap) a.cand[(uint64_t)(qb0 * 32 + q) * a.cap + pos] = st_key[e];
                 else *a.overflow = 1u;
             }
         }
@@ -1010,25 +1016,29 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     return PG_OK;
 }
 
-template <int DIM, int NQB, int WAVES>
+template <int DIM, int NQB, int WAVES, int SPLIT = 1>
 static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        PG_HIP(hipFuncSetAttribute((const void*)screen_kernel<DIM, NQB, WAVES>,
+        PG_HIP(hipFuncSetAttribute((const void*)screen_kernel<DIM, NQB, WAVES, SPLIT>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
         attr_set = true;
     }
     const uint32_t total = a.rb_end - a.rb_begin;
     uint32_t grid = (uint32_t)ctx->num_cus;
-    const uint32_t need = (total + WAVES - 1) / WAVES;
+    const uint32_t need = (total * SPLIT + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
-    screen_kernel<DIM, NQB, WAVES><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
+    screen_kernel<DIM, NQB, WAVES, SPLIT><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
 
 static int dispatch_screen(pg_ctx* ctx, uint32_t dim, const ScreenArgs& a) {
     const bool wide = a.nq > 128;
+    // PG_SCREEN_SPLIT=1 selects the wave-pair variant (measured slower: 18.5 vs 15.2 ms per pass at
+    // 100M x 128 — DESIGN.md "what did not work"); kept for ablation runs.
+    static const bool split = getenv("PG_SCREEN_SPLIT") != nullptr;
+    if (wide && split) return dim == 64 ? launch_screen<64, 4, 8, 2>(ctx, a) : launch_screen<128, 4, 8, 2>(ctx, a);
     if (dim == 64) return wide ? launch_screen<64, 8, 4>(ctx, a) : launch_screen<64, 4, 8>(ctx, a);
     return wide ? launch_screen<128, 8, 4>(ctx, a) : launch_screen<128, 4, 8>(ctx, a);
 }
