@@ -72,7 +72,21 @@ struct ScanArgs {
     uint32_t rb_begin;       // first 32-row block of this launch
     uint32_t rb_end;         // one past the last block
     uint32_t row_end;        // rows >= row_end are ignored (table end)
+    uint32_t stride;         // 1 = every block; S > 1 = pilot sample: logical block L reads table
+                             // block sample_block(L, ...)
+    uint32_t perm_mul, perm_mod;   // pilot sample order: slot = L * perm_mul mod perm_mod
 };
+
+// Pilot sample: logical block L of a stride-S launch is table block slot*S + jitter(slot), where
+// slot = L*mul mod n_slots is a fixed permutation of the n_slots sample slots (mul coprime with
+// n_slots) and jitter < S.  The permutation makes the pilot's own streaming order independent of the
+// table order (a table sorted by score would otherwise defeat its running threshold); the jitter keeps
+// a periodic layout from aliasing with the sample.  S = 1 is the identity.
+__device__ __forceinline__ uint32_t sample_block(uint32_t L, uint32_t S, uint32_t mul, uint32_t mod) {
+    if (S == 1) return L;
+    const uint32_t slot = (uint32_t)(((uint64_t)L * mul) % mod);
+    return slot * S + ((slot * 2654435761u) >> 8) % S;
+}
 
 // One LDS-DMA instruction (64 lanes x 16 B = 1 KiB): global → LDS without touching VGPRs.
 // `base` is the wave-uniform byte address of the piece (first row, first column of the piece),
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
     auto piece_addr = [&](uint32_t t, const char*& ub, uint32_t& dst) {
         uint32_t b = t / PPB;
         if (b >= nblk) b = nblk - 1;
-        const uint64_t rb = (uint64_t)a.rb_begin + first + b;
+        const uint64_t rb = sample_block(a.rb_begin + first + b, a.stride, a.perm_mul, a.perm_mod);
         const char* base = (const char*)a.tab + rb * (uint64_t)(kPieceRows * DIM * 4) + (t % PPB) * (kPieceCols * 4);
         const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)base >> 32));
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
             // Hits are rare (≈ K/rows_seen per row·query), so they are parked in a wave-private LDS
             // staging list and flushed in bulk: a returning atomic costs a full vmcnt drain of the
             // DMA ring, which must not happen once per block.
-            const uint32_t row0 = (a.rb_begin + first + b) * kPieceRows;
+            const uint32_t row0 = sample_block(a.rb_begin + first + b, a.stride, a.perm_mul, a.perm_mod) * kPieceRows;
 #pragma unroll
             for (int c = 0; c < NQB; ++c) {
                 const uint32_t qid = (uint32_t)(c * 32 + i32);
@@ -367,7 +381,7 @@ struct ScreenArgs {
     uint32_t* cnt;
     uint64_t* cand;
     uint32_t* overflow;
-    uint32_t cap, nq, rb_begin, rb_end, row_end;
+    uint32_t cap, nq, rb_begin, rb_end, row_end, stride, perm_mul, perm_mod;
 };
 
 // NQB query blocks of 32; WAVES waves per workgroup.  <=128 queries: 8 waves (2 per SIMD), ring of 4
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     auto piece_addr = [&](uint32_t t, const char*& ub, uint32_t& dst) {
         uint32_t b = t / PPB;
         if (b >= nblk) b = nblk - 1;
-        const uint64_t rb = (uint64_t)a.rb_begin + first + b;
+        const uint64_t rb = sample_block(a.rb_begin + first + b, a.stride, a.perm_mul, a.perm_mod);
         const char* base = (const char*)a.tab + rb * (uint64_t)(kPieceRows * DIM * 4) + (t % PPB) * (kPieceCols * 4);
         const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)base >> 32));
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
@@ -461,13 +475,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 const float4* xr = reinterpret_cast<const float4*>(a.tab + (size_t)row * DIM);
                 const float4* qr = reinterpret_cast<const float4*>(a.qpad + (size_t)q * DIM);
                 float s = 0.0f;
-#pragma unroll 2
-                for (int j = 0; j < DIM / 4; ++j) {
-                    const float4 x = xr[j], y = qr[j];
-                    s = __fmaf_rn(x.x, y.x, s);
-                    s = __fmaf_rn(x.y, y.y, s);
-                    s = __fmaf_rn(x.z, y.z, s);
-                    s = __fmaf_rn(x.w, y.w, s);
+                // RB row quads + RB query quads in flight per round trip (the chain itself is serial);
+                // the 256-query variant has no registers to spare for more than 4
+                constexpr int RB = NQB > 4 ? 4 : 8;
+                for (int j0 = 0; j0 < DIM / 4; j0 += RB) {
+                    float4 x[RB], y[RB];
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) x[j] = xr[j0 + j];
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) y[j] = qr[j0 + j];
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
+                        s = __fmaf_rn(x[j].x, y[j].x, s);
+                        s = __fmaf_rn(x[j].y, y[j].y, s);
+                        s = __fmaf_rn(x[j].z, y[j].z, s);
+                        s = __fmaf_rn(x[j].w, y[j].w, s);
+                    }
                 }
                 const bool keep = !(s < a.thr[q]);
                 st_key[e] = keep ? topk_key(s, row) : 0ull;
@@ -476,17 +499,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         }
         // phase B: per-query reservation (one returning atomic per query present), then scatter
 #pragma unroll
-        for (int part = 0; part < NQB / 2; ++part) st_cnt[lane + 64 * part] = 0;
+        for (int part = 0; part < (NQB + 1) / 2; ++part)
+            if (lane + 64 * part < NQB * 32) st_cnt[lane + 64 * part] = 0;
         for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
             const uint32_t e = e0 + lane;
             if (e < st_n && st_q[e] != 0xFFFFFFFFu) atomicAdd(&st_cnt[st_q[e]], 1u);
         }
 #pragma unroll
-        for (int part = 0; part < NQB / 2; ++part) {
+        for (int part = 0; part < (NQB + 1) / 2; ++part) {
             const int q = lane + 64 * part;
-            const uint32_t c = st_cnt[q];
-            st_base[q] = c ? atomicAdd(&a.cnt[qb0 * 32 + q], c) : 0u;
-            st_cnt[q] = 0;
+            if (q < NQB * 32) {
+                const uint32_t c = st_cnt[q];
+                st_base[q] = c ? atomicAdd(&a.cnt[qb0 * 32 + q], c) : 0u;
+                st_cnt[q] = 0;
+            }
         }
         for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
             const uint32_t e = e0 + lane;
@@ -563,7 +589,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
             bits[c >> 2] |= (uint64_t)m16 << (16 * (c & 3));
         }
         if (__builtin_amdgcn_ballot_w64(any) != 0) {
-            const uint32_t row0 = (a.rb_begin + first + b) * kPieceRows;
+            const uint32_t row0 = sample_block(a.rb_begin + first + b, a.stride, a.perm_mul, a.perm_mod) * kPieceRows;
             // rows past the table end (last block only) are dropped here
 #pragma unroll
             for (int w = 0; w < (NQB + 3) / 4; ++w) {
@@ -661,7 +687,9 @@ __global__ void screen_thr_kernel(const float* __restrict__ thr, const float* __
     const float t = thr[q], e = eps[q];
     float v = t - e;                                   // -inf stays -inf; inf/NaN eps → -inf/NaN
     if (v == v && v > -__builtin_inff()) v = v - fabsf(v) * 1.2e-7f - 1e-37f;
-    if (!(e == e) || e == __builtin_inff()) v = -__builtin_inff();
+    // non-finite queries, or score magnitudes whose bf16 partial sums could overflow: everything
+    // passes the screen and the exact re-scoring decides
+    if (!(e == e) || e > 1e30f) v = -__builtin_inff();
     thr_screen[q] = v;
 }
 
@@ -1039,8 +1067,16 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, const ScreenArgs& a) {
     // 100M x 128 — DESIGN.md "what did not work"); kept for ablation runs.
     static const bool split = getenv("PG_SCREEN_SPLIT") != nullptr;
     if (wide && split) return dim == 64 ? launch_screen<64, 4, 8, 2>(ctx, a) : launch_screen<128, 4, 8, 2>(ctx, a);
-    if (dim == 64) return wide ? launch_screen<64, 8, 4>(ctx, a) : launch_screen<64, 4, 8>(ctx, a);
-    return wide ? launch_screen<128, 8, 4>(ctx, a) : launch_screen<128, 4, 8>(ctx, a);
+    if (dim == 64) {
+        if (wide) return launch_screen<64, 8, 4>(ctx, a);
+        if (a.nq <= 32) return launch_screen<64, 1, 8>(ctx, a);
+        if (a.nq <= 64) return launch_screen<64, 2, 8>(ctx, a);
+        return launch_screen<64, 4, 8>(ctx, a);
+    }
+    if (wide) return launch_screen<128, 8, 4>(ctx, a);
+    if (a.nq <= 32) return launch_screen<128, 1, 8>(ctx, a);
+    if (a.nq <= 64) return launch_screen<128, 2, 8>(ctx, a);
+    return launch_screen<128, 4, 8>(ctx, a);
 }
 
 // the whole recall for one batch of queries (one table pass); all pointers are device pointers
@@ -1062,7 +1098,8 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
     // Policy: up to 32 queries ride the exact fp32-MFMA scan (HBM-bound).  Larger batches use the
     // screened scan (bf16 filter + exact re-scoring), which stays HBM-bound up to 128 queries; it
     // needs a finite table and dim <= 128, otherwise the 64-query exact kernel is used.
-    bool screen = nq > 32 && t->dim <= 128 && !getenv("PG_RECALL_EXACT");
+    const uint32_t screen_min = getenv("PG_SCREEN_MIN") ? (uint32_t)atoi(getenv("PG_SCREEN_MIN")) : 0u;
+    bool screen = nq > screen_min && t->dim <= 128 && !getenv("PG_RECALL_EXACT");
     if (screen) {
         if ((rc = ensure_table_stats(ctx, t))) return rc;
         if (!t->all_finite) screen = false;
@@ -1072,8 +1109,141 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
                   nq, kMaxQueriesExact);
         return PG_ERR_UNSUPPORTED;
     }
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const bool safe = attempt == 1;           // bounded chunks: can never overflow
+    // Plans, tried in order until one completes without overflowing a candidate list:
+    //  pilot — the threshold comes from a jittered 1/S block sample (its K'-th best score, K' chosen six
+    //          sigma above the expected rank K/S, so it is below the true K-th best except with
+    //          negligible probability), then ONE full-rate pass over the whole table collects every row
+    //          at or above it.  Verified exactly: if a query ends with fewer than min(K, rows)
+    //          candidates the sample lied and the next plan runs.  ~1.5 K candidates per query instead
+    //          of K ln(rows/32768) for the growing-chunk plan.
+    //  grow  — geometric chunks, threshold refreshed after each (small tables, and the fallback).
+    //  safe  — bounded chunks that cannot overflow (adversarially ordered tables).
+    enum Plan { kPilot, kGrow, kSafe };
+    Plan plans[3];
+    int n_plans = 0;
+    uint32_t stride = 1, sample_blocks = 0, k_pilot = 0, perm_mul = 1;
+    {
+        const uint32_t full_blocks = rows / kPieceRows;           // the sample only uses whole blocks
+        uint32_t want = full_blocks / 32;
+        if (want < 32768) want = 32768;                          // >= 1M sample rows
+        if (getenv("PG_PILOT_FRACTION")) want = (uint32_t)(full_blocks * atof(getenv("PG_PILOT_FRACTION")));
+        stride = want ? full_blocks / want : 1;
+        if (stride >= 2 && !getenv("PG_NO_PILOT")) {
+            sample_blocks = full_blocks / stride;
+            const double m = (double)k * ((double)sample_blocks * kPieceRows / (double)rows);
+            k_pilot = (uint32_t)ceil(m + 6.0 * sqrt(m) + 8.0);
+            if ((uint64_t)k_pilot * 4 <= (uint64_t)sample_blocks * kPieceRows) plans[n_plans++] = kPilot;
+            perm_mul = 2654435761u % sample_blocks;          // golden-ratio step, made coprime below
+            if (perm_mul < 2) perm_mul = 1;
+            auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t r = x % y; x = y; y = r; } return x; };
+            while (gcd(perm_mul, sample_blocks) != 1) ++perm_mul;
+        }
+        plans[n_plans++] = kGrow;
+        plans[n_plans++] = kSafe;
+    }
+    const double growth_env = getenv("PG_CHUNK_GROWTH") ? atof(getenv("PG_CHUNK_GROWTH")) : 0.0;
+
+    uint32_t n_ev = 0;
+    int cur = 0;
+    // one scan launch over logical blocks [rb, rb+cb) of a stride-`st` view, bracketed by HIP events:
+    // their sum is the per-pass duration of the dominant kernel that bench.py prices against HBM
+    auto scan_range = [&](uint32_t rb, uint32_t cb, uint32_t st, bool thr_is_open) -> int {
+        while (ctx->ev_pool.size() < 2 * (size_t)(n_ev + 1)) {
+            hipEvent_t e;
+            PG_HIP(hipEventCreate(&e));
+            ctx->ev_pool.push_back(e);
+        }
+        PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev], ctx->stream));
+        if (screen && !thr_is_open) {
+            ScreenArgs sa;
+            sa.tab = t->d;
+            sa.qb16 = rs.qb16;
+            sa.qpad = rs.qpad;
+            sa.thr = rs.thr;
+            sa.thr_screen = rs.thr_screen;
+            sa.cnt = rs.cnt;
+            sa.cand = rs.cand[cur];
+            sa.overflow = rs.overflow;
+            sa.cap = rs.cap;
+            sa.nq = nq;
+            sa.rb_begin = rb;
+            sa.rb_end = rb + cb;
+            sa.row_end = rows;
+            sa.stride = st;
+            sa.perm_mul = perm_mul;
+            sa.perm_mod = sample_blocks;
+            int rc2;
+            if ((rc2 = dispatch_screen(ctx, t->dim, sa))) return rc2;
+        } else {
+            // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
+            // every row is a candidate and there is nothing to screen) in groups of <= 64 queries
+            const uint32_t gsz = screen ? (uint32_t)kMaxQueriesExact : nq;
+            for (uint32_t g0 = 0; g0 < nq; g0 += gsz) {
+                ScanArgs a;
+                a.tab = t->d;
+                a.qpad = rs.qpad + (size_t)g0 * t->dim;
+                a.thr = rs.thr + g0;
+                a.cnt = rs.cnt + g0;
+                a.cand = rs.cand[cur] + (size_t)g0 * rs.cap;
+                a.overflow = rs.overflow;
+                a.cap = rs.cap;
+                a.nq = nq - g0 < gsz ? nq - g0 : gsz;
+                a.nq_launch = a.nq;
+                a.rb_begin = rb;
+                a.rb_end = rb + cb;
+                a.row_end = rows;
+                a.stride = st;
+                a.perm_mul = perm_mul;
+                a.perm_mod = sample_blocks;
+                int rc2;
+                if ((rc2 = dispatch_scan(ctx, t->dim, a))) return rc2;
+            }
+        }
+        PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], ctx->stream));
+        ++n_ev;
+        return PG_OK;
+    };
+    // keep the best `kk` candidates per query, refresh the thresholds, swap the ping-pong lists
+    auto refresh = [&](uint32_t kk) -> int {
+        int rc2;
+        if ((rc2 = launch_select(ctx, nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk))) return rc2;
+        if (screen) {
+            screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.thr_screen);
+            PG_HIP(hipGetLastError());
+        }
+        cur ^= 1;
+        return PG_OK;
+    };
+    // geometric chunks over `nb` logical blocks of a stride-`st` view, keeping the best `kk`
+    auto grow_scan = [&](uint32_t nb, uint32_t st, uint32_t kk, double growth, bool safe) -> int {
+        uint32_t rb = 0;
+        while (rb < nb) {
+            uint32_t chunk_rows;
+            if (rb == 0) {
+                // every row of the first chunk becomes a candidate of every query: keep it just large
+                // enough to seed a meaningful threshold (8 x kk rows, 2048..32768)
+                chunk_rows = next_pow2(8 * kk);
+                if (chunk_rows < 2048) chunk_rows = 2048;
+                if (chunk_rows > kFirstChunkRows || chunk_rows < kk) chunk_rows = kFirstChunkRows;
+            }
+            else {
+                // chunk = (growth-1) x rows seen: every chunk stages ≈ (growth-1)*kk candidates per query
+                const uint64_t grow = (uint64_t)((double)rb * kPieceRows * (growth - 1.0));
+                chunk_rows = grow > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (uint32_t)grow;
+            }
+            if (safe && chunk_rows > kCandSlack / 2) chunk_rows = kCandSlack / 2;
+            uint32_t cb = chunk_rows / kPieceRows;
+            if (cb > nb - rb) cb = nb - rb;
+            int rc2;
+            if ((rc2 = scan_range(rb, cb, st, rb == 0))) return rc2;
+            rb += cb;
+            if ((rc2 = refresh(kk))) return rc2;
+        }
+        return PG_OK;
+    };
+
+    for (int pi = 0; pi < n_plans; ++pi) {
+        const Plan plan = plans[pi];
         recall_init_kernel<<<(kMaxQueries * t->dim + 255) / 256, 256, 0, ctx->stream>>>(
             d_queries, nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
         PG_HIP(hipGetLastError());
@@ -1082,79 +1252,20 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
                 rs.qpad, t->dim, t->max_norm, rs.qb16, rs.eps);
             PG_HIP(hipGetLastError());
         }
-        int cur = 0;
-        uint32_t rb = 0, n_ev = 0;
+        cur = 0;
+        n_ev = 0;
         PG_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-        while (rb < nblocks) {
-            uint32_t chunk_rows;
-            if (rb == 0) chunk_rows = kFirstChunkRows;
-            else {
-                const uint64_t seen = (uint64_t)rb * kPieceRows;
-                // chunk = (growth-1) x rows seen: every chunk stages ≈ (growth-1)*K candidates per query
-                // (measured: 4 is best for the exact scan, 2 for the screened scan whose re-scoring
-                // gathers 512 B per staged candidate)
-                const double growth = getenv("PG_CHUNK_GROWTH") ? atof(getenv("PG_CHUNK_GROWTH")) : (screen ? 2.0 : 4.0);
-                const uint64_t grow = (uint64_t)((double)seen * (growth - 1.0));
-                chunk_rows = grow > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (uint32_t)grow;
-            }
-            if (safe && chunk_rows > kCandSlack / 2) chunk_rows = kCandSlack / 2;
-            uint32_t cb = chunk_rows / kPieceRows;
-            if (cb > nblocks - rb) cb = nblocks - rb;
-            // HIP events bracket the scan launch only: their sum is the per-pass duration of the
-            // dominant kernel that bench.py prices against the HBM roofline
-            while (ctx->ev_pool.size() < 2 * (size_t)(n_ev + 1)) {
-                hipEvent_t e;
-                PG_HIP(hipEventCreate(&e));
-                ctx->ev_pool.push_back(e);
-            }
-            PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev], ctx->stream));
-            if (screen && rb > 0) {
-                ScreenArgs sa;
-                sa.tab = t->d;
-                sa.qb16 = rs.qb16;
-                sa.qpad = rs.qpad;
-                sa.thr = rs.thr;
-                sa.thr_screen = rs.thr_screen;
-                sa.cnt = rs.cnt;
-                sa.cand = rs.cand[cur];
-                sa.overflow = rs.overflow;
-                sa.cap = rs.cap;
-                sa.nq = nq;
-                sa.rb_begin = rb;
-                sa.rb_end = rb + cb;
-                sa.row_end = rows;
-                if ((rc = dispatch_screen(ctx, t->dim, sa))) return rc;
-            } else {
-                // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
-                // every row is a candidate and there is nothing to screen) in groups of <= 64 queries
-                const uint32_t gsz = screen ? (uint32_t)kMaxQueriesExact : nq;
-                for (uint32_t g0 = 0; g0 < nq; g0 += gsz) {
-                    ScanArgs a;
-                    a.tab = t->d;
-                    a.qpad = rs.qpad + (size_t)g0 * t->dim;
-                    a.thr = rs.thr + g0;
-                    a.cnt = rs.cnt + g0;
-                    a.cand = rs.cand[cur] + (size_t)g0 * rs.cap;
-                    a.overflow = rs.overflow;
-                    a.cap = rs.cap;
-                    a.nq = nq - g0 < gsz ? nq - g0 : gsz;
-                    a.nq_launch = a.nq;
-                    a.rb_begin = rb;
-                    a.rb_end = rb + cb;
-                    a.row_end = rows;
-                    if ((rc = dispatch_scan(ctx, t->dim, a))) return rc;
-                }
-            }
-            PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], ctx->stream));
-            ++n_ev;
-            rb += cb;
-            if ((rc = launch_select(ctx, nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, k))) return rc;
-            PG_HIP(hipGetLastError());
-            if (screen) {
-                screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.thr_screen);
-                PG_HIP(hipGetLastError());
-            }
-            cur ^= 1;
+        if (plan == kPilot) {
+            // measured: growth 8 on the sample (its K' is small, so chunks stage little)
+            if ((rc = grow_scan(sample_blocks, stride, k_pilot, getenv("PG_PILOT_GROWTH") ? atof(getenv("PG_PILOT_GROWTH")) : 8.0, false))) return rc;
+            PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
+            if ((rc = scan_range(0, nblocks, 1, false))) return rc;
+            if ((rc = refresh(k))) return rc;
+        } else {
+            // measured: growth 4 is best for the exact scan, 2 for the screened scan whose re-scoring
+            // gathers 512 B per staged candidate
+            const double growth = growth_env > 1.0 ? growth_env : (screen ? 2.0 : 4.0);
+            if ((rc = grow_scan(nblocks, 1, k, growth, plan == kSafe))) return rc;
         }
         PG_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
         if ((rc = final_launch(ctx, rs.cand[cur], rs.cnt, rs.cap, nq, k, t->row_offset, d_out_rows,
@@ -1169,13 +1280,18 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
         for (uint32_t i = 0; i < n_ev; ++i) {
             PG_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]));
             scan_ms += ms;
-            if (getenv("PG_DEBUG_SCAN")) fprintf(stderr, "[pg] scan launch %u: %.3f ms\n", i, ms);
+            if (getenv("PG_DEBUG_SCAN")) fprintf(stderr, "[pg] plan %d scan launch %u: %.3f ms\n", (int)plan, i, ms);
         }
         scan_launches += n_ev;
-        scanned_rows += rows;
-        if (ctx->h_status[0] == 0) break;
+        scanned_rows += plan == kPilot ? (uint64_t)rows + (uint64_t)sample_blocks * kPieceRows : rows;
+        bool ok = ctx->h_status[0] == 0;
+        if (ok && plan == kPilot) {
+            const uint32_t want = k < rows ? k : rows;
+            for (uint32_t q = 0; q < nq; ++q) ok = ok && ctx->h_status[1 + q] == want;
+        }
+        if (ok) break;
         ctx->stats.recall_rescans++;
-        if (safe) {
+        if (plan == kSafe) {
             set_error("recall: candidate overflow in safe mode (internal error)");
             return PG_ERR_DEVICE;
         }

@@ -3,6 +3,7 @@ same seeded inputs.  Bar: bit-exact for row ids / ordering / fp32 recall scores 
 pre-activations; the stated tolerance where a transcendental (expf, exp, pow) or the bf16 MFMA's
 internal accumulation order is involved."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -148,9 +149,10 @@ def test_recall_screen_is_exact_on_hostile_data(ctx):
     t.destroy()
 
 
-def test_recall_adversarial_order_forces_safe_rescan(ctx):
-    """Scores ascending with the row index defeat the running threshold: every row is a
-    candidate, the fast path overflows its list and the bounded-chunk path must take over."""
+def test_recall_adversarial_order(ctx):
+    """Scores ascending with the row index defeat a running threshold (every row beats everything seen
+    before it).  The pilot plan samples the whole table and is immune; with the pilot disabled the
+    growing-chunk plan overflows its candidate lists and the bounded-chunk plan must take over."""
     n, d, k = 2_200_000, 64, 100
     tab = np.zeros((n, d), dtype=np.float32)
     tab[:, 3] = np.arange(n, dtype=np.float32)
@@ -161,7 +163,33 @@ def test_recall_adversarial_order_forces_safe_rescan(ctx):
     before = ctx.stats().recall_rescans
     rows, scores, _ = t.recall_topk(q, k)
     assert rows[0].tolist() == list(range(n - 1, n - 1 - k, -1))
+    assert ctx.stats().recall_rescans == before
+    os.environ["PG_NO_PILOT"] = "1"
+    try:
+        rows, scores, _ = t.recall_topk(q, k)
+    finally:
+        del os.environ["PG_NO_PILOT"]
+    assert rows[0].tolist() == list(range(n - 1, n - 1 - k, -1))
     assert ctx.stats().recall_rescans == before + 1
+    t.destroy()
+
+
+def test_recall_all_ties_falls_through_every_plan(ctx):
+    """A table of identical rows: every row ties with any threshold, so the pilot pass and the growing
+    chunks both overflow and the bounded-chunk plan answers; ties resolve to the lowest rows
+    (sort.go SliceStable semantics of the recall order)."""
+    n, d, k = 2_200_000, 64, 100
+    tab = np.zeros((n, d), dtype=np.float32)
+    tab[:, 5] = 1.0
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    q = np.zeros((2, d), dtype=np.float32)
+    q[:, 5] = [1.0, -2.0]
+    before = ctx.stats().recall_rescans
+    rows, scores, _ = t.recall_topk(q, k)
+    assert rows[0].tolist() == list(range(k)) and rows[1].tolist() == list(range(k))
+    assert np.all(scores[0] == 1.0) and np.all(scores[1] == -2.0)
+    assert ctx.stats().recall_rescans == before + 2
     t.destroy()
 
 
