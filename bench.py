@@ -62,6 +62,32 @@ def pmc_traffic(R):
         return None
 
 
+def scan_kernel_name(R, dim):
+    """The kernel recall.hip dispatches for the full-table pass at this batch size (dispatch_screen)."""
+    if dim > 128:
+        return "pg::scan_kernel<%d,1>" % dim
+    nqb, waves = (8, 4) if R > 128 else ((4, 8) if R > 64 else ((2, 8) if R > 32 else (1, 8)))
+    return "pg::screen_kernel<%d,%d,%d>" % (dim, nqb, waves)
+
+
+def device_info():
+    """Marketing name / CU count / max clock from rocminfo (child process; evidence for SURVEY.md 8(d))."""
+    try:
+        import subprocess
+        txt = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=30).stdout
+        blocks = [b for b in txt.split("Agent ") if "gfx" in b and "Device Type:             GPU" in b]
+        b = blocks[0]
+        def field(k):
+            for line in b.splitlines():
+                if line.strip().startswith(k):
+                    return line.split(":", 1)[1].strip()
+            return None
+        return {"name": field("Marketing Name"), "arch": field("Name"), "compute_units": field("Compute Unit"),
+                "max_clock_mhz": field("Max Clock Freq")}
+    except Exception:
+        return None
+
+
 def make_queries(o, step, R, dim):
     # 1000 distinct users cycle through the run (SURVEY.md §8d)
     return o.synth_rows(o.SEED_QUERY, (step * R) % 1000, R, dim)
@@ -193,6 +219,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # measured streaming-read ceiling of this GPU's HBM (plain read-only kernel over the same table)
+    measured_gbs = table.hbm_read_probe(3)
     for s in range(args.warmup):
         run(s)
     sync()
@@ -231,8 +259,9 @@ def main():
                                    % (world, args.rows * world)) if shard else
                                   ("request-parallel x%d, table replicated per GPU, no data-path collective" % world
                                    if world > 1 else "1 GPU")},
-        "roofline": {"bound": "hbm", "kernel": "pg::screen_kernel<128>" if R > 32 else "pg::scan_kernel<128,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": scan_kernel_name(R, args.dim), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R),
+                     "measured_peak": measured_gbs, "frac_of_measured": achieved / measured_gbs,
                      "bytes_per_pass": shard_bytes, "ms_per_pass": scan_avg_ms,
                      "note": "algorithmic bytes = shard rows x dim x 4 per table pass (one pass serves %d requests); "
                              "duration = sum of the pass's scan launches, HIP events on the launch stream" % R},
@@ -257,6 +286,7 @@ def main():
         out["p50_request_latency_ms"] = float(np.median(lat))
 
     if rank == 0:
+        out["device"] = device_info()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(o, args, R, K)
         else:

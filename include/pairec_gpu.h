@@ -191,6 +191,10 @@ int pg_stats(pg_ctx* ctx, pg_stats_t* out);
 /* time (ms) of the dominant kernel of the last pg_recall_* call, measured with HIP events on the
  * context's stream around the scan launches only (bench.py's roofline figure) */
 int pg_last_scan_kernel_ms(pg_ctx* ctx, double* out_ms, uint64_t* out_bytes);
+/* Measured HBM read ceiling: streams the table's rows through a plain read-only kernel `reps` times
+ * and returns the best rate in GB/s.  SURVEY.md 8(d) asks for the roofline fraction against a measured
+ * streaming ceiling beside the nominal 8 TB/s. */
+int pg_hbm_read_probe(pg_ctx* ctx, const pg_table* t, int reps, double* out_gbps);
 
 #ifdef __cplusplus
 }

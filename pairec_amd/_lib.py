@@ -21,6 +21,7 @@ EXPORTS = [
     "pg_rank_fm2t", "pg_rank_fm2t_dev", "pg_expr_compile", "pg_expr_free", "pg_expr_num_vars",
     "pg_expr_var_name", "pg_expr_eval", "pg_expr_eval_dev", "pg_sort_scores", "pg_sort_scores_dev",
     "pg_dpp", "pg_stats", "pg_last_scan_kernel_ms", "pg_rows_to_local_dev", "pg_widen_f32_dev",
+    "pg_hbm_read_probe",
 ]
 
 
@@ -86,6 +87,7 @@ def load():
         "pg_widen_f32_dev": [vp, vp, u32, vp],
         "pg_stats": [vp, P(PgStats)],
         "pg_last_scan_kernel_ms": [vp, P(C.c_double), P(u64)],
+        "pg_hbm_read_probe": [vp, vp, i32, P(C.c_double)],
     }
     missing = [n for n in EXPORTS if not hasattr(L, n)]
     if missing:

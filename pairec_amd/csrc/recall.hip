@@ -418,8 +418,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     for (int c = 0; c < NQB; ++c) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bfrag[c][ks] = a.qb16[((qb0 + c) * KS + ks) * 64 + lane];
-        thr_s[c] = a.thr_screen[(qb0 + c) * 32 + i32];
         active[c] = (uint32_t)((qb0 + c) * 32 + i32) < a.nq;
+        thr_s[c] = active[c] ? a.thr_screen[(qb0 + c) * 32 + i32] : __builtin_inff();
     }
 #pragma unroll
     for (int c = 0; c < NQB; ++c) {
@@ -579,12 +579,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
 #pragma unroll
         for (int w = 0; w < (NQB + 3) / 4; ++w) bits[w] = 0;
         bool any = false;
+        // The compiler's hazard recognizer does not look inside inline asm: when the accumulators live
+        // in VGPRs the compare below would read them too soon after the last MFMA (a 16-pass MFMA needs
+        // up to 18 wait states before a VALU read of its result).
+        asm volatile("s_nop 15\n\ts_nop 7");
 #pragma unroll
         for (int c = 0; c < NQB; ++c) {
+            // two VALU ops per bound: the compare sets VCC, add-with-carry shifts it into the lane's
+            // bit set (m = 2m + pass), so register r ends up at bit 15 - r
             uint32_t m16 = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m16 |= (!(acc[c][r] < thr_s[c]) ? 1u : 0u) << r;
-            if (!active[c]) m16 = 0;
+            for (int r = 0; r < 16; ++r)
+                asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                             : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[c]) : "vcc");
             any |= m16 != 0;
             bits[c >> 2] |= (uint64_t)m16 << (16 * (c & 3));
         }
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 uint64_t keep = 0;
                 for (uint64_t t = bits[w]; t != 0; t &= t - 1) {
                     const int bi = __builtin_ctzll(t);
-                    const int r = bi & 15;
+                    const int r = 15 - (bi & 15);
                     if (row0 + (r & 3) + 8 * (r >> 2) + 4 * h < a.row_end) keep |= 1ull << bi;
                 }
                 bits[w] = (row0 + 32 <= a.row_end) ? bits[w] : keep;
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 for (int w = 0; w < (NQB + 3) / 4; ++w)
                     for (uint64_t t = bits[w]; t != 0; t &= t - 1) {
                         const int bi = __builtin_ctzll(t);
-                        const int r = bi & 15, c = w * 4 + (bi >> 4);
+                        const int r = 15 - (bi & 15), c = w * 4 + (bi >> 4);
                         st_key[pos] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                         st_q[pos] = (uint32_t)(c * 32 + i32);
                         ++pos;
@@ -635,7 +642,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                         if (p) {
                             const uint32_t pos = st_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            const int r = bi & 15, c = w * 4 + (bi >> 4);
+                            const int r = 15 - (bi & 15), c = w * 4 + (bi >> 4);
                             st_key[pos] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                             st_q[pos] = (uint32_t)(c * 32 + i32);
                         }

@@ -103,6 +103,12 @@ class Table:
             _lib.check(self.ctx.L.pg_table_destroy(self.ctx.h, self.h))
             self.h = None
 
+    def hbm_read_probe(self, reps: int = 3) -> float:
+        """Measured streaming-read rate over this table's rows, GB/s."""
+        g = C.c_double()
+        _lib.check(self.ctx.L.pg_hbm_read_probe(self.ctx.h, self.h, reps, C.byref(g)))
+        return g.value
+
     def fill_synthetic(self, seed: int, normalize: bool = True):
         _lib.check(self.ctx.L.pg_table_fill_synthetic(self.ctx.h, self.h, seed, int(normalize)))
 

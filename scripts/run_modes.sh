@@ -11,8 +11,6 @@ for l in sys.stdin:
 run pilot 256 A=1
 run pilot 128 A=1
 run pilot 64 A=1
-run pilot 32 A=1
 run pilot 1 A=1
 run pilot 256 A=1
 run pilot 128 A=1
-PG_DEBUG_SCAN=1 python bench.py --steps 1 --warmup 1 --batch 256 --no-cpu-baseline --latency-reqs 0 2>&1 | grep "pg\]" | tail -6
