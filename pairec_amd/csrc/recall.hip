@@ -82,10 +82,12 @@ struct ScanArgs {
 // n_slots) and jitter < S.  The permutation makes the pilot's own streaming order independent of the
 // table order (a table sorted by score would otherwise defeat its running threshold); the jitter keeps
 // a periodic layout from aliasing with the sample.  S = 1 is the identity.
+__device__ __forceinline__ uint32_t slot_block(uint32_t slot, uint32_t S) {
+    return slot * S + (uint32_t)(((uint64_t)(slot * 2654435761u) * S) >> 32);       // jitter in [0, S)
+}
 __device__ __forceinline__ uint32_t sample_block(uint32_t L, uint32_t S, uint32_t mul, uint32_t mod) {
     if (S == 1) return L;
-    const uint32_t slot = (uint32_t)(((uint64_t)L * mul) % mod);
-    return slot * S + ((slot * 2654435761u) >> 8) % S;
+    return slot_block((uint32_t)(((uint64_t)L * mul) % mod), S);
 }
 
 // One LDS-DMA instruction (64 lanes x 16 B = 1 KiB): global → LDS without touching VGPRs.
@@ -391,7 +393,9 @@ struct ScreenArgs {
 // (NQB blocks each).  The table is then requested twice within a few microseconds; the second request
 // is served by L2 / Infinity Cache, so HBM traffic stays ≈ 1x while both waves keep their B operand in
 // 128 registers (two waves per SIMD) — 256 queries per pass without the one-wave-per-SIMD penalty.
-template <int DIM, int NQB, int WAVES, int SPLIT = 1>
+// VAR: developer ablations (PG_SCAN_VARIANTS builds only; 0 = product; 1 = no screen test; 2 = no MFMA and
+// no test; 3 = no DMA; 4 = test but never take the hit path) — they time the components, results are wrong
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PPB = DIM / kPieceCols;
@@ -424,7 +428,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
 #pragma unroll
     for (int c = 0; c < NQB; ++c) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bfrag[c][ks].x), "+v"(bfrag[c][ks].y), "+v"(bfrag[c][ks].z), "+v"(bfrag[c][ks].w));
+        for (int ks = 0; ks < KS; ++ks) {
+            if (NQB > 4)     // 256 B registers: park them in the AGPR half, where the MFMA reads them directly
+                asm volatile("" : "+a"(bfrag[c][ks].x), "+a"(bfrag[c][ks].y), "+a"(bfrag[c][ks].z), "+a"(bfrag[c][ks].w));
+            else
+                asm volatile("" : "+v"(bfrag[c][ks].x), "+v"(bfrag[c][ks].y), "+v"(bfrag[c][ks].z), "+v"(bfrag[c][ks].w));
+        }
         asm volatile("" : "+v"(thr_s[c]));
     }
 
@@ -447,11 +456,36 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     const uint32_t nblk = first < total ? (total - first < bpw ? total - first : bpw) : 0;
     if (nblk == 0) return;
 
-    auto piece_addr = [&](uint32_t t, const char*& ub, uint32_t& dst) {
-        uint32_t b = t / PPB;
-        if (b >= nblk) b = nblk - 1;
-        const uint64_t rb = sample_block(a.rb_begin + first + b, a.stride, a.perm_mul, a.perm_mod);
-        const char* base = (const char*)a.tab + rb * (uint64_t)(kPieceRows * DIM * 4) + (t % PPB) * (kPieceCols * 4);
+    // Physical table block of each logical block this wave walks, kept D blocks ahead of the one being
+    // scored (the DMA ring runs NS-1 pieces ahead).  Incremental: slot += mul (mod n_slots) per block
+    // for a pilot sample, +1 for a full pass — no division in the loop.  Blocks past the end of the
+    // run repeat the last one (tail pieces re-read it; they are never scored).
+    constexpr int D = (PPB - 1 + NS - 1) / PPB;
+    const bool strided = a.stride != 1;
+    const uint32_t L0 = a.rb_begin + first;
+    uint32_t walk_slot = strided ? (uint32_t)(((uint64_t)L0 * a.perm_mul) % a.perm_mod) : L0;
+    uint32_t walk_n = 0;                          // logical blocks handed out so far
+    auto next_phys = [&]() -> uint32_t {
+        const uint32_t ph = strided ? slot_block(walk_slot, a.stride) : walk_slot;
+        if (walk_n + 1 < nblk) {
+            ++walk_n;
+            if (strided) {
+                walk_slot += a.perm_mul;
+                if (walk_slot >= a.perm_mod) walk_slot -= a.perm_mod;
+            } else {
+                ++walk_slot;
+            }
+        }
+        return __builtin_amdgcn_readfirstlane(ph);
+    };
+    uint32_t phys[D + 1];
+#pragma unroll
+    for (int j = 0; j <= D; ++j) phys[j] = next_phys();
+    // wave-uniform source base and LDS destination of piece `pc_abs` pieces after the start of the
+    // block being scored (compile-time offset), global piece counter t for the ring slot
+    auto piece_addr = [&](int rel_piece, uint32_t t, const char*& ub, uint32_t& dst) {
+        const uint32_t ph = phys[rel_piece / PPB];
+        const char* base = (const char*)a.tab + (uint64_t)ph * (uint64_t)(kPieceRows * DIM * 4) + (rel_piece % PPB) * (kPieceCols * 4);
         const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)base >> 32));
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
         ub = (const char*)(((uint64_t)hi << 32) | lo);
@@ -531,7 +565,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     for (int t = 0; t < NS - 1; ++t) {
         const char* src;
         uint32_t dst;
-        piece_addr(t, src, dst);
+        piece_addr(t, t, src, dst);
 #pragma unroll
         for (int n = 0; n < ND; ++n) dma_one(src, dst + n * 1024, voff[n], 0.0f);
     }
@@ -545,10 +579,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
 #pragma unroll
         for (int pc = 0; pc < PPB; ++pc) {
             const uint32_t t = b * PPB + pc;
-            wait_vmcnt<ND * (NS - 2)>();
+            if (VAR != 3) wait_vmcnt<ND * (NS - 2)>();
             const char* nb_src;
             uint32_t nb_dst;
-            piece_addr(t + NS - 1, nb_src, nb_dst);
+            piece_addr(pc + NS - 1, t + NS - 1, nb_src, nb_dst);
             const char* slot = lds_ptr + (t % NS) * kPieceBytes + rd_row;
             // A fragment of k-step ksl (16 columns of the piece): this lane's 8 columns = quads
             // ksl*4 + 2h and ksl*4 + 2h + 1 of its row
@@ -560,43 +594,65 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < ND; ++n) dma_one(nb_src, nb_dst + n * 1024, voff[n], q4[n].x);
+            for (int n = 0; n < ND; ++n)
+                if (VAR != 3) dma_one(nb_src, nb_dst + n * 1024, voff[n], q4[n].x);
 #pragma unroll
             for (int ksl = 0; ksl < 2; ++ksl) {
                 const f32x4 lo = q4[2 * ksl], hi = q4[2 * ksl + 1];
                 const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 const bf16x8 af = __builtin_convertvector(v, bf16x8);
                 const int ks = pc * 2 + ksl;
+                if (VAR == 2) {
+                    asm volatile("" :: "v"(af));
+                    continue;
+                }
 #pragma unroll
                 for (int c = 0; c < NQB; ++c)
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfrag[c][ks]), acc[c], 0, 0, 0);
             }
         }
+        const uint32_t cur_phys = phys[0];
+#pragma unroll
+        for (int j = 0; j < D; ++j) phys[j] = phys[j + 1];
+        phys[D] = next_phys();
         // ---- screen test.  Each lane packs its hits into a bit set (bit c*16+r ↔ accumulator c,
         // register r); the slow path below only needs (row, query) — both follow from the bit index —
         // so the accumulators are never indexed dynamically.
-        uint64_t bits[(NQB + 3) / 4];
+        if (VAR == 1 || VAR == 2) {
 #pragma unroll
-        for (int w = 0; w < (NQB + 3) / 4; ++w) bits[w] = 0;
+            for (int c = 0; c < NQB; ++c) asm volatile("" :: "v"(acc[c][0]), "v"(acc[c][15]));
+            continue;
+        }
+        // Block reject: the largest of a lane's 16 bounds per query block against the screen threshold
+        // (7 max3 + 1 max + 1 compare per query block).  fmaxf drops a NaN operand, which is safe: the
+        // accumulators of a finite table and a finite, moderate query are finite, and every other query
+        // has thr_screen = -inf (screen_thr_kernel) so that everything passes.  Inactive query columns
+        // carry thr_s = +inf.
         bool any = false;
-        // The compiler's hazard recognizer does not look inside inline asm: when the accumulators live
-        // in VGPRs the compare below would read them too soon after the last MFMA (a 16-pass MFMA needs
-        // up to 18 wait states before a VALU read of its result).
-        asm volatile("s_nop 15\n\ts_nop 7");
 #pragma unroll
         for (int c = 0; c < NQB; ++c) {
-            // two VALU ops per bound: the compare sets VCC, add-with-carry shifts it into the lane's
-            // bit set (m = 2m + pass), so register r ends up at bit 15 - r
-            uint32_t m16 = 0;
+            float m = acc[c][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                             : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[c]) : "vcc");
-            any |= m16 != 0;
-            bits[c >> 2] |= (uint64_t)m16 << (16 * (c & 3));
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[c][r]);
+            any |= !(m < thr_s[c]);
         }
+        if (VAR == 4) any = false;
         if (__builtin_amdgcn_ballot_w64(any) != 0) {
-            const uint32_t row0 = sample_block(a.rb_begin + first + b, a.stride, a.perm_mul, a.perm_mod) * kPieceRows;
+            // the rare block with a hit: per-lane bit sets, bit 16*(c&3) + 15 - r of word c>>2 ↔
+            // accumulator c, register r (compare sets VCC, add-with-carry shifts it in: m = 2m + pass)
+            uint64_t bits[(NQB + 3) / 4];
+#pragma unroll
+            for (int w = 0; w < (NQB + 3) / 4; ++w) bits[w] = 0;
+#pragma unroll
+            for (int c = 0; c < NQB; ++c) {
+                uint32_t m16 = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                 : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[c]) : "vcc");
+                bits[c >> 2] |= (uint64_t)m16 << (16 * (c & 3));
+            }
+            const uint32_t row0 = cur_phys * kPieceRows;
             // rows past the table end (last block only) are dropped here
 #pragma unroll
             for (int w = 0; w < (NQB + 3) / 4; ++w) {
@@ -1051,11 +1107,11 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     return PG_OK;
 }
 
-template <int DIM, int NQB, int WAVES, int SPLIT = 1>
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0>
 static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        PG_HIP(hipFuncSetAttribute((const void*)screen_kernel<DIM, NQB, WAVES, SPLIT>,
+        PG_HIP(hipFuncSetAttribute((const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
         attr_set = true;
     }
@@ -1063,7 +1119,7 @@ static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total * SPLIT + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
-    screen_kernel<DIM, NQB, WAVES, SPLIT><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
+    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
@@ -1080,6 +1136,19 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, const ScreenArgs& a) {
         if (a.nq <= 64) return launch_screen<64, 2, 8>(ctx, a);
         return launch_screen<64, 4, 8>(ctx, a);
     }
+#ifdef PG_SCAN_VARIANTS
+    {
+        const char* v = getenv("PG_SCREEN_VAR");     // developer ablation builds only
+        if (wide && v && v[0] == '1') return launch_screen<128, 8, 4, 1, 1>(ctx, a);
+        if (wide && v && v[0] == '2') return launch_screen<128, 8, 4, 1, 2>(ctx, a);
+        if (wide && v && v[0] == '3') return launch_screen<128, 8, 4, 1, 3>(ctx, a);
+        if (wide && v && v[0] == '4') return launch_screen<128, 8, 4, 1, 4>(ctx, a);
+        if (!wide && v && v[0] == '1') return launch_screen<128, 4, 8, 1, 1>(ctx, a);
+        if (!wide && v && v[0] == '2') return launch_screen<128, 4, 8, 1, 2>(ctx, a);
+        if (!wide && v && v[0] == '3') return launch_screen<128, 4, 8, 1, 3>(ctx, a);
+        if (!wide && v && v[0] == '4') return launch_screen<128, 4, 8, 1, 4>(ctx, a);
+    }
+#endif
     if (wide) return launch_screen<128, 8, 4>(ctx, a);
     if (a.nq <= 32) return launch_screen<128, 1, 8>(ctx, a);
     if (a.nq <= 64) return launch_screen<128, 2, 8>(ctx, a);

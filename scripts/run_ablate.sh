@@ -1,0 +1,5 @@
+# developer ablation timings of the screened scan (needs a -DPG_SCAN_VARIANTS build); results are wrong by design
+for b in 256 128; do
+for v in 0 1 2 3 4; do
+  PG_SCREEN_VAR=$v PG_DEBUG_SCAN=1 python bench.py --steps 2 --warmup 1 --batch $b --no-cpu-baseline --latency-reqs 0 2>&1 | grep "plan 0 scan launch 5" | tail -1 | sed "s/^/batch $b var $v: /"
+done; done
