@@ -377,11 +377,9 @@ constexpr float kScreenEps = 0.008f;
 struct ScreenArgs {
     const float* tab;
     const uint4* qb16;        // [NQB][DIM/16][64] bf16x8 B fragments
-    const float* qpad;        // [128][DIM] fp32 queries (exact re-scoring)
-    const float* thr;         // [128] exact running thresholds
-    const float* thr_screen;  // [128] thr - eps, rounded down
-    uint32_t* cnt;
-    uint64_t* cand;
+    const float* thr_screen;  // [256] thr - eps, rounded down
+    uint32_t* susp_cnt;       // [256] suspects per query of this launch
+    uint32_t* susp;           // [256][cap] suspect rows (passed the bf16 screen; re-scored by rescore_kernel)
     uint32_t* overflow;
     uint32_t cap, nq, rb_begin, rb_end, row_end, stride, perm_mul, perm_mod;
 };
@@ -403,7 +401,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     constexpr int ND = kPieceDmas;
     constexpr int KS = DIM / 16;                 // bf16 k-steps
     constexpr int kStageBytesW = (kScreenLds - kScanLdsRing) / WAVES;
-    constexpr int kCap = (kStageBytesW - NQB * 256 - 16) / 12;      // staged pairs per wave
+    constexpr int kCap = (kStageBytesW - NQB * 256 - 16) / 8;       // staged (row, query) pairs per wave
     constexpr int kScanWaves = WAVES;            // (shadows the exact kernel's constant in this scope)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -492,68 +490,39 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         dst = lds_wave_u + __builtin_amdgcn_readfirstlane(t % NS) * kPieceBytes;
     };
 
-    // staging: (row, query) pairs that passed the bf16 screen
-    uint64_t* const st_key = reinterpret_cast<uint64_t*>(smem + kScanLdsRing + wave * kStageBytesW);
-    uint32_t* const st_q = reinterpret_cast<uint32_t*>(st_key + kCap);
+    // staging: (row, query) pairs that passed the bf16 screen ("suspects").  They are parked in a
+    // wave-private LDS list and flushed in bulk into per-query global suspect lists; the exact
+    // re-scoring runs afterwards in rescore_kernel, with the whole chip hiding the gather latency
+    // (done here it cost one dependent HBM round trip chain per 64 suspects per wave).
+    uint32_t* const st_row = reinterpret_cast<uint32_t*>(smem + kScanLdsRing + wave * kStageBytesW);
+    uint32_t* const st_q = st_row + kCap;
     uint32_t* const st_cnt = st_q + kCap;                 // [NQB*32]
     uint32_t* const st_base = st_cnt + NQB * 32;          // [NQB*32]
-    uint32_t* const st_tmp = st_base + NQB * 32;          // [2] wave total / fill cursor
     uint32_t st_n = 0;
     auto flush = [&]() {
-        // phase A: exact re-scoring (the specification's k-ascending fmaf chain, fp32 table + query)
-        for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
-            const uint32_t e = e0 + lane;
-            if (e < st_n) {
-                const uint32_t row = (uint32_t)st_key[e];
-                const uint32_t q = (uint32_t)qb0 * 32 + st_q[e];
-                const float4* xr = reinterpret_cast<const float4*>(a.tab + (size_t)row * DIM);
-                const float4* qr = reinterpret_cast<const float4*>(a.qpad + (size_t)q * DIM);
-                float s = 0.0f;
-                // RB row quads + RB query quads in flight per round trip (the chain itself is serial);
-                // the 256-query variant has no registers to spare for more than 4
-                constexpr int RB = NQB > 4 ? 4 : 8;
-                for (int j0 = 0; j0 < DIM / 4; j0 += RB) {
-                    float4 x[RB], y[RB];
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) x[j] = xr[j0 + j];
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) y[j] = qr[j0 + j];
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) {
-                        s = __fmaf_rn(x[j].x, y[j].x, s);
-                        s = __fmaf_rn(x[j].y, y[j].y, s);
-                        s = __fmaf_rn(x[j].z, y[j].z, s);
-                        s = __fmaf_rn(x[j].w, y[j].w, s);
-                    }
-                }
-                const bool keep = !(s < a.thr[q]);
-                st_key[e] = keep ? topk_key(s, row) : 0ull;
-                if (!keep) st_q[e] = 0xFFFFFFFFu;
-            }
-        }
-        // phase B: per-query reservation (one returning atomic per query present), then scatter
+        // per-query reservation (one returning atomic per query present), then scatter the row ids
 #pragma unroll
         for (int part = 0; part < (NQB + 1) / 2; ++part)
             if (lane + 64 * part < NQB * 32) st_cnt[lane + 64 * part] = 0;
         for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
             const uint32_t e = e0 + lane;
-            if (e < st_n && st_q[e] != 0xFFFFFFFFu) atomicAdd(&st_cnt[st_q[e]], 1u);
+            if (e < st_n) atomicAdd(&st_cnt[st_q[e]], 1u);
         }
 #pragma unroll
         for (int part = 0; part < (NQB + 1) / 2; ++part) {
             const int q = lane + 64 * part;
             if (q < NQB * 32) {
                 const uint32_t c = st_cnt[q];
-                st_base[q] = c ? atomicAdd(&a.cnt[qb0 * 32 + q], c) : 0u;
+                st_base[q] = c ? atomicAdd(&a.susp_cnt[qb0 * 32 + q], c) : 0u;
                 st_cnt[q] = 0;
             }
         }
         for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
             const uint32_t e = e0 + lane;
-            if (e < st_n && st_q[e] != 0xFFFFFFFFu) {
+            if (e < st_n) {
                 const uint32_t q = st_q[e];
                 const uint32_t pos = st_base[q] + atomicAdd(&st_cnt[q], 1u);
-                if (pos < a.cap) a.cand[(uint64_t)(qb0 * 32 + q) * a.cap + pos] = st_key[e];
+                if (pos < a.cap) a.susp[(uint64_t)(qb0 * 32 + q) * a.cap + pos] = st_row[e];
                 else *a.overflow = 1u;
             }
         }
@@ -628,87 +597,136 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         // accumulators of a finite table and a finite, moderate query are finite, and every other query
         // has thr_screen = -inf (screen_thr_kernel) so that everything passes.  Inactive query columns
         // carry thr_s = +inf.
-        bool any = false;
+        uint64_t cmask[NQB];
+        uint64_t any_mask = 0;
 #pragma unroll
         for (int c = 0; c < NQB; ++c) {
             float m = acc[c][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[c][r]);
-            any |= !(m < thr_s[c]);
+            cmask[c] = __builtin_amdgcn_ballot_w64(!(m < thr_s[c]));
+            any_mask |= cmask[c];
         }
-        if (VAR == 4) any = false;
-        if (__builtin_amdgcn_ballot_w64(any) != 0) {
-            // the rare block with a hit: per-lane bit sets, bit 16*(c&3) + 15 - r of word c>>2 ↔
-            // accumulator c, register r (compare sets VCC, add-with-carry shifts it in: m = 2m + pass)
-            uint64_t bits[(NQB + 3) / 4];
-#pragma unroll
-            for (int w = 0; w < (NQB + 3) / 4; ++w) bits[w] = 0;
+        if (VAR == 4) any_mask = 0;
+        if (any_mask != 0) {
+            // the rare block with a hit: only the query blocks that have one are looked at again
+            const uint32_t row0 = cur_phys * kPieceRows;
 #pragma unroll
             for (int c = 0; c < NQB; ++c) {
+                if (cmask[c] == 0) continue;
+                // per-lane bit set of this query block: bit 15 - r ↔ register r (the compare sets VCC,
+                // add-with-carry shifts it in: m = 2m + pass).  The accumulators were all read by the max
+                // chains above, so the MFMA → VALU hazard the compiler cannot see inside asm is covered.
                 uint32_t m16 = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                                  : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[c]) : "vcc");
-                bits[c >> 2] |= (uint64_t)m16 << (16 * (c & 3));
-            }
-            const uint32_t row0 = cur_phys * kPieceRows;
-            // rows past the table end (last block only) are dropped here
+                if (row0 + kPieceRows > a.row_end) {        // last block of a ragged table: drop rows past the end
 #pragma unroll
-            for (int w = 0; w < (NQB + 3) / 4; ++w) {
-                uint64_t keep = 0;
-                for (uint64_t t = bits[w]; t != 0; t &= t - 1) {
-                    const int bi = __builtin_ctzll(t);
-                    const int r = 15 - (bi & 15);
-                    if (row0 + (r & 3) + 8 * (r >> 2) + 4 * h < a.row_end) keep |= 1ull << bi;
+                    for (int r = 0; r < 16; ++r)
+                        if (row0 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.row_end) m16 &= ~(1u << (15 - r));
                 }
-                bits[w] = (row0 + 32 <= a.row_end) ? bits[w] : keep;
-            }
-            uint32_t n_l = 0;
-#pragma unroll
-            for (int w = 0; w < (NQB + 3) / 4; ++w) n_l += __popcll(bits[w]);
-            // wave total and per-lane offsets through two LDS words (st_tmp[0] = total, [1] = fill)
-            if (lane == 0) { st_tmp[0] = 0; }
-            if (n_l) atomicAdd(&st_tmp[0], n_l);
-            const uint32_t total_hits = st_tmp[0];
-            if (total_hits <= (uint32_t)kCap) {
-                if (st_n + total_hits > (uint32_t)kCap) flush();
-                if (lane == 0) st_tmp[1] = st_n;
-                uint32_t pos = n_l ? atomicAdd(&st_tmp[1], n_l) : 0u;
-#pragma unroll
-                for (int w = 0; w < (NQB + 3) / 4; ++w)
-                    for (uint64_t t = bits[w]; t != 0; t &= t - 1) {
-                        const int bi = __builtin_ctzll(t);
-                        const int r = 15 - (bi & 15), c = w * 4 + (bi >> 4);
-                        st_key[pos] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                // stage the hits, one per lane per round (ballot + prefix count: no LDS atomics, no waits)
+                for (;;) {
+                    const bool p = m16 != 0;
+                    const uint64_t bm = __builtin_amdgcn_ballot_w64(p);
+                    if (bm == 0) break;
+                    const uint32_t n = __popcll(bm);
+                    if (st_n + n > (uint32_t)kCap) flush();
+                    if (p) {
+                        const int r = 15 - __builtin_ctz(m16);
+                        const uint32_t pos = st_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        st_row[pos] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                         st_q[pos] = (uint32_t)(c * 32 + i32);
-                        ++pos;
+                        m16 &= m16 - 1;
                     }
-                st_n += total_hits;
-            } else {
-                // dense block (adversarial data): one (c, r) slice at a time, at most 64 pairs each
-#pragma unroll
-                for (int w = 0; w < (NQB + 3) / 4; ++w)
-                    for (int bi = 0; bi < 64; ++bi) {
-                        const bool p = (bits[w] >> bi) & 1ull;
-                        const uint64_t m = __builtin_amdgcn_ballot_w64(p);
-                        if (m == 0) continue;
-                        const uint32_t n = __popcll(m);
-                        if (st_n + n > (uint32_t)kCap) flush();
-                        if (p) {
-                            const uint32_t pos = st_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            const int r = 15 - (bi & 15), c = w * 4 + (bi >> 4);
-                            st_key[pos] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            st_q[pos] = (uint32_t)(c * 32 + i32);
-                        }
-                        st_n += n;
-                    }
+                    st_n += n;
+                }
             }
         }
     }
     flush();
     wait_vmcnt<0>();
+}
+
+// ---------------------------------------------------------------------------------------------
+// rescore: exact scores of the suspects a screened launch parked in susp[q][0..susp_cnt[q]) — the
+// specification's k-ascending fmaf chain over the fp32 table row and the fp32 query — keeping those
+// with !(s < thr[q]) as candidate keys in cand[q].  One block = 256 suspects of ONE query (grid.y = query,
+// grid.x strides over the list): the query sits in LDS (broadcast reads), each wave gathers its 64 rows
+// with coalesced 256 B segments into a padded LDS tile (16 independent loads per lane in flight), then
+// lane s walks row s.  One returning atomic per block reserves the output range.
+template <int DIM>
+__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ tab, const float* __restrict__ qpad,
+                                                      const float* __restrict__ thr,
+                                                      const uint32_t* __restrict__ susp,
+                                                      const uint32_t* __restrict__ susp_cnt, uint32_t cap,
+                                                      uint32_t* __restrict__ cnt, uint64_t* __restrict__ cand,
+                                                      uint32_t* __restrict__ overflow) {
+    constexpr int kRowB = 64 * 4 + 16;                 // 64 columns per phase, padded: conflict-free b128 column walks
+    __shared__ __attribute__((aligned(16))) char tile[4][64 * kRowB];
+    __shared__ __attribute__((aligned(16))) float qs[DIM];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t base_s;
+    const uint32_t q = blockIdx.y;
+    const uint32_t n_raw = susp_cnt[q];
+    const uint32_t n = n_raw < cap ? n_raw : cap;
+    if (blockIdx.x * 256u >= n) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < DIM) qs[threadIdx.x] = qpad[(size_t)q * DIM + threadIdx.x];
+    const float thr_q = thr[q];
+    __syncthreads();
+    char* const my = tile[w];
+    for (uint32_t t0 = blockIdx.x * 256u; t0 < n; t0 += gridDim.x * 256u) {
+        const uint32_t e = t0 + threadIdx.x;
+        const bool valid = e < n;
+        const uint32_t row = valid ? susp[(uint64_t)q * cap + e] : 0u;
+        float s = 0.0f;
+#pragma unroll
+        for (int ph = 0; ph < DIM / 64; ++ph) {
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t r_i = (uint32_t)__shfl((int)row, 4 * i + (lane >> 4), 64);
+                v[i] = reinterpret_cast<const float4*>(tab + (size_t)r_i * DIM + ph * 64)[lane & 15];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                *reinterpret_cast<float4*>(my + (4 * i + (lane >> 4)) * kRowB + (lane & 15) * 16) = v[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 x = *reinterpret_cast<const float4*>(my + lane * kRowB + k * 16);
+                const float4 y = *reinterpret_cast<const float4*>(&qs[ph * 64 + 4 * k]);
+                s = __fmaf_rn(x.x, y.x, s);
+                s = __fmaf_rn(x.y, y.y, s);
+                s = __fmaf_rn(x.z, y.z, s);
+                s = __fmaf_rn(x.w, y.w, s);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const bool keep = valid && !(s < thr_q);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (lane == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            base_s = tot ? atomicAdd(&cnt[q], tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t pos = base_s + before;
+        for (int j = 0; j < w; ++j) pos += wsum[j];
+        if (keep) {
+            if (pos < cap) cand[(uint64_t)q * cap + pos] = topk_key(s, row);
+            else *overflow = 1u;
+        }
+        __syncthreads();
+    }
+    if (n_raw > cap && threadIdx.x == 0) *overflow = 1u;
 }
 
 // per call: bf16 B fragments of the (zero-padded) queries and eps_q = kScreenEps * max_norm * ||q||
@@ -1043,9 +1061,12 @@ struct RecallScratch {
     uint4* qb16;
     float* eps;
     float* thr_screen;
+    uint32_t* susp_cnt;      // [kMaxQueries]
+    uint32_t* susp;          // [kMaxQueries][cap] suspect rows of the current launch
 };
 
 constexpr uint32_t kFirstChunkRows = 32768;
+constexpr uint32_t kRescoreBlocksPerQuery = 16;   // x 256 suspects per block per stride step
 constexpr uint32_t kCandSlack = 1u << 19;      // candidate capacity beyond K per query
 
 static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
@@ -1053,7 +1074,7 @@ static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* 
     void* small;
     int rc;
     const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
-    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 16 + 1024;
+    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 20 + 1024;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
     rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
@@ -1061,11 +1082,13 @@ static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* 
     rs->eps = rs->thr + kMaxQueries;
     rs->thr_screen = rs->eps + kMaxQueries;
     rs->cnt = (uint32_t*)(rs->thr_screen + kMaxQueries);
-    rs->overflow = rs->cnt + kMaxQueries;
+    rs->susp_cnt = rs->cnt + kMaxQueries;
+    rs->overflow = rs->susp_cnt + kMaxQueries;
     void* c;
-    if ((rc = scratch_reserve(ctx, 3, (size_t)2 * kMaxQueries * cap * 8, &c))) return rc;
+    if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4), &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
     rs->cand[1] = rs->cand[0] + (size_t)kMaxQueries * cap;
+    rs->susp = (uint32_t*)(rs->cand[1] + (size_t)kMaxQueries * cap);
     rs->cap = cap;
     return PG_OK;
 }
@@ -1234,11 +1257,9 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             ScreenArgs sa;
             sa.tab = t->d;
             sa.qb16 = rs.qb16;
-            sa.qpad = rs.qpad;
-            sa.thr = rs.thr;
             sa.thr_screen = rs.thr_screen;
-            sa.cnt = rs.cnt;
-            sa.cand = rs.cand[cur];
+            sa.susp_cnt = rs.susp_cnt;
+            sa.susp = rs.susp;
             sa.overflow = rs.overflow;
             sa.cap = rs.cap;
             sa.nq = nq;
@@ -1249,7 +1270,17 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             sa.perm_mul = perm_mul;
             sa.perm_mod = sample_blocks;
             int rc2;
+            PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
             if ((rc2 = dispatch_screen(ctx, t->dim, sa))) return rc2;
+            // exact re-scoring of the launch's suspects → candidate keys (grid.x strides over each list)
+            const dim3 rg(kRescoreBlocksPerQuery, nq);
+            if (t->dim == 64)
+                rescore_kernel<64><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap,
+                                                                rs.cnt, rs.cand[cur], rs.overflow);
+            else
+                rescore_kernel<128><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap,
+                                                                 rs.cnt, rs.cand[cur], rs.overflow);
+            PG_HIP(hipGetLastError());
         } else {
             // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
             // every row is a candidate and there is nothing to screen) in groups of <= 64 queries
