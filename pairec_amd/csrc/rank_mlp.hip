@@ -57,7 +57,6 @@ __host__ __device__ __forceinline__ float round_prec(float x, int prec) {
 
 constexpr int kBM = 128;       // items per workgroup tile
 constexpr int kDIN = 128;      // gathered input width
-constexpr int kCH = 128;       // layer-1 chunk (hidden columns)
 constexpr int kFmK = 16;       // FM embedding width
 constexpr int kFmFields = 8;   // item fields (= user fields)
 
@@ -93,34 +92,67 @@ template <int PREC>
 __device__ __forceinline__ void store_x_quad(char* tile, int row, int c, float4 v) {
     if constexpr (PREC == 1) {
         // 4 bf16 = 8 B at element 4c: 16-B quad index c/2, XOR-swizzled by row
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
         uint2 p;
-        p.x = (uint32_t)f32_to_bf16_rne(v.x) | ((uint32_t)f32_to_bf16_rne(v.y) << 16);
-        p.y = (uint32_t)f32_to_bf16_rne(v.z) | ((uint32_t)f32_to_bf16_rne(v.w) << 16);
+        p.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+        p.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
         *reinterpret_cast<uint2*>(tile + row * 256 + ((((c >> 1) ^ (row & 15))) << 4) + (c & 1) * 8) = p;
     } else {
         *reinterpret_cast<float4*>(tile + row * 512 + ((c ^ (row & 15)) << 4)) = v;
     }
 }
 
-template <int PREC>
+// element (row, col) of an LDS operand tile with K columns per row: 16-B quads XOR-swizzled by row
+template <int PREC, int K>
 __device__ __forceinline__ void store_h_elem(char* tile, int row, int col, float v) {
+    constexpr int ES = PREC ? 2 : 4;
+    constexpr int ROWB = K * ES;
+    constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
     if constexpr (PREC == 1) {
-        *reinterpret_cast<uint16_t*>(tile + row * 256 + ((((col >> 3) ^ (row & 15))) << 4) + (col & 7) * 2) =
+        *reinterpret_cast<uint16_t*>(tile + row * ROWB + ((((col >> 3) ^ (row & SW))) << 4) + (col & 7) * 2) =
             f32_to_bf16_rne(v);
     } else {
-        *reinterpret_cast<float*>(tile + row * 512 + ((((col >> 2) ^ (row & 15))) << 4) + (col & 3) * 4) = v;
+        *reinterpret_cast<float*>(tile + row * ROWB + ((((col >> 2) ^ (row & SW))) << 4) + (col & 3) * 4) = v;
     }
 }
 
-// C[rows of this wave][n-blocks] += A(tile in LDS)[rows][K=128] · B(pre-packed fragments)
-// frag(nb, step) returns the byte offset of the 1-KiB fragment for n-block nb and k-group `step`.
-template <int PREC, int MB, int NB, typename FragOff>
-__device__ __forceinline__ void gemm_k128(f32x16 (&acc)[MB][NB], const char* tile, int mrow0,
+// 4 consecutive columns col..col+3 (col % 4 == 0) of one row, after relu and operand rounding
+template <int PREC, int K>
+__device__ __forceinline__ void store_h_quad(char* tile, int row, int col, float v0, float v1, float v2, float v3) {
+    constexpr int ES = PREC ? 2 : 4;
+    constexpr int ROWB = K * ES;
+    constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
+    if constexpr (PREC == 1) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const f32x2 lo = {v0, v1}, hi = {v2, v3};
+        uint2 p;
+        p.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+        p.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
+        *reinterpret_cast<uint2*>(tile + row * ROWB + ((((col >> 3) ^ (row & SW))) << 4) + (col & 7) * 2) = p;
+    } else {
+        *reinterpret_cast<float4*>(tile + row * ROWB + ((((col >> 2) ^ (row & SW))) << 4)) = make_float4(v0, v1, v2, v3);
+    }
+}
+
+// C[rows of this wave][n-blocks] += A(tile in LDS)[rows][K] · B(pre-packed fragments)
+// frag(nb, step) returns the byte offset of the 1-KiB fragment for n-block nb and k-group `step`
+// (bf16: 16 k per group, f32: 8 k per group).
+// TR = true swaps the MFMA operands: the accumulator block then holds C^T — lane ↔ item row, register r ↔
+// column (r&3) + 8(r>>2) + 4h of the n-block — so a lane owns 4 consecutive columns of one item, which
+// packs into one LDS store (the products and the k order are unchanged, so the bits are too).
+template <int PREC, int MB, int NB, int K, bool TR, typename FragOff>
+__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[MB][NB], const char* tile, int mrow0,
                                           const char* wpk, FragOff frag, int lane) {
+    constexpr int ES = PREC ? 2 : 4;
+    constexpr int ROWB = K * ES;
+    constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
     const int i32 = lane & 31, h = lane >> 5;
     if constexpr (PREC == 1) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {           // 8 k-steps of 16
+        for (int ks = 0; ks < K / 16; ++ks) {
             bf16x8 bf[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
@@ -129,15 +161,16 @@ __device__ __forceinline__ void gemm_k128(f32x16 (&acc)[MB][NB], const char* til
             for (int mb = 0; mb < MB; ++mb) {
                 const int row = mrow0 + mb * 32 + i32;
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(
-                    tile + row * 256 + ((((ks * 2 + h) ^ (row & 15))) << 4));
+                    tile + row * ROWB + ((((ks * 2 + h) ^ (row & SW))) << 4));
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[nb], af, acc[mb][nb], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nb], acc[mb][nb], 0, 0, 0);
             }
         }
     } else {
 #pragma unroll
-        for (int g8 = 0; g8 < 16; ++g8) {          // 16 groups of 8 k (4 MFMA steps each)
+        for (int g8 = 0; g8 < K / 8; ++g8) {       // groups of 8 k (4 MFMA steps each)
             f32x4 bf[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
@@ -148,13 +181,18 @@ __device__ __forceinline__ void gemm_k128(f32x16 (&acc)[MB][NB], const char* til
 #pragma unroll
                 for (int qd = 0; qd < 2; ++qd) {
                     const f32x4 aq = *reinterpret_cast<const f32x4*>(
-                        tile + row * 512 + ((((g8 * 2 + qd) ^ (row & 15))) << 4));
+                        tile + row * ROWB + ((((g8 * 2 + qd) ^ (row & SW))) << 4));
                     const float a0 = h ? aq.y : aq.x;
                     const float a1 = h ? aq.w : aq.z;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[nb][2 * qd], acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[nb][2 * qd + 1], acc[mb][nb], 0, 0, 0);
+                        if (TR) {
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nb][2 * qd], a0, acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nb][2 * qd + 1], a1, acc[mb][nb], 0, 0, 0);
+                        } else {
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[nb][2 * qd], acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[nb][2 * qd + 1], acc[mb][nb], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -162,28 +200,69 @@ __device__ __forceinline__ void gemm_k128(f32x16 (&acc)[MB][NB], const char* til
     }
 }
 
-constexpr size_t mlp_lds_bytes(int prec, int h2) {
-    const size_t tiles = (size_t)2 * kBM * kDIN * (prec ? 2 : 4);
-    const size_t h2t = (size_t)kBM * (h2 + 1) * 4;
+// bf16 path with the B fragments of a whole GEMM loaded ahead of time (so that their L2 latency hides
+// behind the previous GEMM / the H1 store and the barrier instead of stalling every other MFMA)
+template <int NB, int KS, typename FragOff>
+__device__ __forceinline__ void load_bfrags(bf16x8 (&bfr)[KS][NB], const char* wpk, FragOff frag, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            bfr[ks][nb] = *reinterpret_cast<const bf16x8*>(wpk + frag(nb, ks) + lane * 16);
+}
+template <int MB, int NB, int K>
+__device__ __forceinline__ void gemm_tile_pre(f32x16 (&acc)[MB][NB], const char* tile, int mrow0,
+                                              const bf16x8 (&bfr)[K / 16][NB], int lane) {
+    constexpr int ROWB = K * 2;
+    constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
+    const int i32 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < K / 16; ++ks)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int row = mrow0 + mb * 32 + i32;
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((((ks * 2 + h) ^ (row & SW))) << 4));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)     // operands swapped: transposed accumulators (see gemm_tile)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][nb], af, acc[mb][nb], 0, 0, 0);
+        }
+}
+
+// LDS of one workgroup: X tile + H1 chunk tile, aliased after the GEMMs by the fp32 H2 tile of one
+// epilogue pass (H2 / EP columns, padded rows); then w3 and the per-item head bias.
+constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep) {
+    const size_t es = prec ? 2 : 4;
+    const size_t nh1 = (prec && (size_t)kBM * (kDIN + 2 * ch) * es <= 72 * 1024) ? 2 : 1;   // as NH1 in mlp_kernel
+    const size_t tiles = (size_t)kBM * (kDIN + nh1 * ch) * es;
+    const size_t h2t = (size_t)kBM * (h2 / ep + 4) * 4;
     return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)kBM * 4;
 }
 
-// MODEL 1 = DNN3, 2 = two-tower item side
-template <int PREC, int H1, int H2, bool ACT2, int WM, int WN, int MODEL>
-__global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
+// MODEL 1 = DNN3, 2 = two-tower item side.  WM x WN = wave grid over (items, hidden columns); CH = layer-1
+// chunk width (hidden columns produced, pushed through LDS and consumed by layer 2 at a time); EP = passes of
+// the head epilogue (the fp32 H2 tile goes through LDS H2/EP columns at a time — EP = 2 halves the LDS
+// footprint so that two workgroups share a CU); OCC = workgroups per CU the register budget is set for.
+template <int PREC, int H1, int H2, bool ACT2, int WM, int WN, int MODEL, int CH, int EP, int OCC>
+__global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
     constexpr int MB = 4 / WM;
-    constexpr int L1NB = kCH / 32 / WN;
+    constexpr int L1NB = CH / 32 / WN;
     constexpr int L2NB = H2 / 32 / WN;
     constexpr int ES = PREC ? 2 : 4;
     constexpr int TILE_B = kBM * kDIN * ES;
-    constexpr int NCHUNK = H1 / kCH;
-    constexpr int KG1 = PREC ? 8 : 16;             // k-groups (fragments) per 128-deep GEMM
-    constexpr size_t REGION = (size_t)2 * TILE_B > (size_t)kBM * (H2 + 1) * 4 ? (size_t)2 * TILE_B
-                                                                            : (size_t)kBM * (H2 + 1) * 4;
+    constexpr int H1_B = kBM * CH * ES;
+    constexpr int NCHUNK = H1 / CH;
+    constexpr int KG1 = PREC ? kDIN / 16 : kDIN / 8;   // k-groups (fragments) of the 128-deep layer-1 GEMM
+    constexpr int KGC = PREC ? CH / 16 : CH / 8;       // k-groups of one CH-deep layer-2 partial GEMM
+    constexpr int HH = H2 / EP;                        // head columns per epilogue pass
+    // H1 chunk tiles: double-buffered where two workgroups still fit a CU's 160 KB
+    constexpr int NH1 = (PREC && TILE_B + 2 * H1_B <= 72 * 1024) ? 2 : 1;
+    constexpr size_t REGION = (size_t)(TILE_B + NH1 * H1_B) > (size_t)kBM * (HH + 4) * 4
+                                  ? (size_t)(TILE_B + NH1 * H1_B) : (size_t)kBM * (HH + 4) * 4;
     static_assert(L1NB >= 1 && L2NB >= 1 && MB >= 1, "bad wave layout");
+    static_assert(EP == 1 || (EP == 2 && HH % 32 == 0), "epilogue passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const XT = smem;
-    char* const H1T = smem + TILE_B;
+    char* const H1T0 = smem + TILE_B;
     float* const H2T = reinterpret_cast<float*>(smem);      // aliases XT/H1T after the GEMMs
     float* const w3s = reinterpret_cast<float*>(smem + REGION);
     float* const b3s = w3s + H2;
@@ -276,81 +355,166 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     const int mrow0 = wm * MB * 32;
     f32x16 acc2[MB][L2NB];
 #pragma unroll
-    for (int nb = 0; nb < L2NB; ++nb) {
-        const float bv = a.b2[(wn * L2NB + nb) * 32 + i32];
+    for (int nb = 0; nb < L2NB; ++nb) {          // transposed like acc1: register r ↔ column (r&3)+8(r>>2)+4h
+        const float* bb = a.b2 + (wn * L2NB + nb) * 32 + 4 * h;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(bb + 8 * g);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[mb][nb][r] = bv;
+            for (int mb = 0; mb < MB; ++mb) {
+                acc2[mb][nb][4 * g + 0] = bv.x;
+                acc2[mb][nb][4 * g + 1] = bv.y;
+                acc2[mb][nb][4 * g + 2] = bv.z;
+                acc2[mb][nb][4 * g + 3] = bv.w;
+            }
+        }
     }
+
+    // fragment offsets: W1 n-block (chunk, wave, nb), k-group step; W2 n-block (wave, nb), k-group chunk*KGC + step
+    constexpr int KG2 = NCHUNK * KGC;                  // k-groups over the full H1 depth
+    auto frag1 = [&](int chunk) {
+        const int nbg0 = chunk * (CH / 32) + wn * L1NB;
+        return [=](int nb, int step) { return (size_t)((nbg0 + nb) * KG1 + step) * 1024; };
+    };
+    auto frag2 = [&](int chunk) {
+        const int nbg0 = wn * L2NB;
+        return [=](int nb, int step) { return (size_t)((nbg0 + nb) * KG2 + chunk * KGC + step) * 1024; };
+    };
+    constexpr bool PRE = PREC == 1 && OCC == 2;        // preloaded B fragments (bf16, two workgroups per CU)
+    bf16x8 b1f[PRE ? KG1 : 1][PRE ? L1NB : 1];
+    bf16x8 b2f[PRE ? KGC : 1][PRE ? L2NB : 1];
+    if constexpr (PRE) load_bfrags<L1NB, KG1>(b1f, reinterpret_cast<const char*>(a.w1p), frag1(0), lane);
 
 #pragma unroll 1
     for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        // with two H1 tiles the barrier after the layer-2 GEMM is not needed: the next chunk writes the
+        // other tile, and the barrier before ITS layer-2 GEMM orders everything two chunks apart
+        char* const H1T = H1T0 + (NH1 == 2 ? (chunk & 1) * H1_B : 0);
         // ---- layer 1, columns [chunk*128, +128): wave owns L1NB n-blocks
+        // (transposed accumulators: lane ↔ item mb*32 + i32, register r ↔ hidden column
+        //  (r&3) + 8(r>>2) + 4h of the n-block)
         f32x16 acc1[MB][L1NB];
 #pragma unroll
         for (int nb = 0; nb < L1NB; ++nb) {
-            const float cv = a.c1[(size_t)req * a.c1_stride + chunk * kCH + (wn * L1NB + nb) * 32 + i32];
+            const float* cb = a.c1 + (size_t)req * a.c1_stride + chunk * CH + (wn * L1NB + nb) * 32 + 4 * h;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+            for (int g = 0; g < 4; ++g) {
+                const float4 cv = *reinterpret_cast<const float4*>(cb + 8 * g);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[mb][nb][r] = cv;
+                for (int mb = 0; mb < MB; ++mb) {
+                    acc1[mb][nb][4 * g + 0] = cv.x;
+                    acc1[mb][nb][4 * g + 1] = cv.y;
+                    acc1[mb][nb][4 * g + 2] = cv.z;
+                    acc1[mb][nb][4 * g + 3] = cv.w;
+                }
+            }
         }
-        {
-            const int nbg0 = chunk * (kCH / 32) + wn * L1NB;
-            gemm_k128<PREC, MB, L1NB>(
-                acc1, XT, mrow0, reinterpret_cast<const char*>(a.w1p),
-                [&](int nb, int step) { return (size_t)((nbg0 + nb) * KG1 + step) * 1024; }, lane);
+        if constexpr (PRE) {
+            gemm_tile_pre<MB, L1NB, kDIN>(acc1, XT, mrow0, b1f, lane);
+            load_bfrags<L2NB, KGC>(b2f, reinterpret_cast<const char*>(a.w2p), frag2(chunk), lane);
+        } else {
+            gemm_tile<PREC, MB, L1NB, kDIN, true>(acc1, XT, mrow0, reinterpret_cast<const char*>(a.w1p),
+                                                  frag1(chunk), lane);
         }
-        // relu → P() → H1 chunk tile (A operand of layer 2)
+        // relu → P() → H1 chunk tile (A operand of layer 2): one packed store per 4 columns
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int nb = 0; nb < L1NB; ++nb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mrow0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int col = (wn * L1NB + nb) * 32 + i32;
-                    const float v = acc1[mb][nb][r];
-                    store_h_elem<PREC>(H1T, row, col, v > 0.0f ? v : 0.0f);
+                for (int g = 0; g < 4; ++g) {
+                    const int row = mrow0 + mb * 32 + i32;
+                    const int col = (wn * L1NB + nb) * 32 + 8 * g + 4 * h;
+                    const float v0 = acc1[mb][nb][4 * g + 0], v1 = acc1[mb][nb][4 * g + 1];
+                    const float v2 = acc1[mb][nb][4 * g + 2], v3 = acc1[mb][nb][4 * g + 3];
+                    store_h_quad<PREC, CH>(H1T, row, col, v0 > 0.0f ? v0 : 0.0f, v1 > 0.0f ? v1 : 0.0f,
+                                           v2 > 0.0f ? v2 : 0.0f, v3 > 0.0f ? v3 : 0.0f);
                 }
         __syncthreads();
-        // ---- layer 2 partial: acc2 += H1chunk · W2[chunk*128 .. +128, :]
-        {
-            const int nbg0 = wn * L2NB;
-            constexpr int KG2 = (H1 / kCH) * KG1;      // k-groups over the full H1 depth
-            gemm_k128<PREC, MB, L2NB>(
-                acc2, H1T, mrow0, reinterpret_cast<const char*>(a.w2p),
-                [&](int nb, int step) { return (size_t)((nbg0 + nb) * KG2 + chunk * KG1 + step) * 1024; },
-                lane);
+        // ---- layer 2 partial: acc2 += H1chunk · W2[chunk*CH .. +CH, :]
+        if constexpr (PRE) {
+            gemm_tile_pre<MB, L2NB, CH>(acc2, H1T, mrow0, b2f, lane);
+            if (chunk + 1 < NCHUNK)      // next chunk's layer-1 fragments: in flight across the barrier
+                load_bfrags<L1NB, KG1>(b1f, reinterpret_cast<const char*>(a.w1p), frag1(chunk + 1), lane);
+        } else {
+            gemm_tile<PREC, MB, L2NB, CH, true>(acc2, H1T, mrow0, reinterpret_cast<const char*>(a.w2p),
+                                                frag2(chunk), lane);
         }
-        __syncthreads();
+        if (NH1 == 1 || chunk + 1 == NCHUNK) __syncthreads();
     }
 
-    // ---- layer-2 activation → H2 tile (fp32, padded rows), then the dot head
+    // ---- layer-2 activation → H2 tile (fp32; rows padded by one 16-B quad: an odd number of quads per
+    // row keeps both the float4 stores and the per-thread float4 row walks conflict-free) → dot head: two
+    // half chains over the H2 columns, z = (b3 + Σ_{m < H2/2}) + Σ_{m >= H2/2}, each
+    // sequential in m.
+    constexpr int HS = HH + 4;                            // H2 tile row stride in floats
+    auto relu2 = [](float v) { return ACT2 ? (v > 0.0f ? v : 0.0f) : v; };
+    if constexpr (EP == 1) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < L2NB; ++nb)
+            for (int nb = 0; nb < L2NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int col = (wn * L2NB + nb) * 32 + i32;
-                float v = acc2[mb][nb][r];
-                if (ACT2) v = v > 0.0f ? v : 0.0f;
-                H2T[row * (H2 + 1) + col] = v;
-            }
-    __syncthreads();
-    {
+                for (int g = 0; g < 4; ++g) {
+                    const int row = mrow0 + mb * 32 + i32;
+                    const int col = (wn * L2NB + nb) * 32 + 8 * g + 4 * h;
+                    *reinterpret_cast<float4*>(H2T + row * HS + col) =
+                        make_float4(relu2(acc2[mb][nb][4 * g + 0]), relu2(acc2[mb][nb][4 * g + 1]),
+                                    relu2(acc2[mb][nb][4 * g + 2]), relu2(acc2[mb][nb][4 * g + 3]));
+                }
+        __syncthreads();
         const int row = tid >> 1, half = tid & 1;
-        const float* hr = H2T + row * (H2 + 1) + half * (H2 / 2);
-        const float* wr = w3s + half * (H2 / 2);
+        const float4* hr = reinterpret_cast<const float4*>(H2T + row * HS + half * (H2 / 2));
+        const float4* wr = reinterpret_cast<const float4*>(w3s + half * (H2 / 2));
         float p = half ? 0.0f : b3s[row];
-#pragma unroll 8
-        for (int m = 0; m < H2 / 2; ++m) p = __fmaf_rn(hr[m], wr[m], p);
+#pragma unroll 4
+        for (int m = 0; m < H2 / 8; ++m) {
+            const float4 x = hr[m], y = wr[m];
+            p = __fmaf_rn(x.x, y.x, p);
+            p = __fmaf_rn(x.y, y.y, p);
+            p = __fmaf_rn(x.z, y.z, p);
+            p = __fmaf_rn(x.w, y.w, p);
+        }
         const float o = __shfl_xor(p, 1);
         const float z = half ? (o + p) : (p + o);
         if (half == 0 && (uint32_t)row < cnt) a.out[item0 + row] = 1.0f / (1.0f + expf(-z));
+    } else {
+        // pass e carries columns [e*HH, (e+1)*HH) = half chain e; thread `row` (tid < 128) runs both
+        float ph[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+            if (e) __syncthreads();                       // the previous pass's readers are done
+#pragma unroll
+            for (int nb = 0; nb < L2NB; ++nb) {
+                const int col0 = (wn * L2NB + nb) * 32;
+                if (col0 / HH != e) continue;             // wave-uniform
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = mrow0 + mb * 32 + i32;
+                        *reinterpret_cast<float4*>(H2T + row * HS + (col0 - e * HH) + 8 * g + 4 * h) =
+                            make_float4(relu2(acc2[mb][nb][4 * g + 0]), relu2(acc2[mb][nb][4 * g + 1]),
+                                        relu2(acc2[mb][nb][4 * g + 2]), relu2(acc2[mb][nb][4 * g + 3]));
+                    }
+            }
+            __syncthreads();
+            if (tid < kBM) {
+                const float4* hr = reinterpret_cast<const float4*>(H2T + tid * HS);
+                const float4* wr = reinterpret_cast<const float4*>(w3s + e * HH);
+                float p = e ? 0.0f : b3s[tid];
+#pragma unroll 4
+                for (int m = 0; m < HH / 4; ++m) {
+                    const float4 x = hr[m], y = wr[m];
+                    p = __fmaf_rn(x.x, y.x, p);
+                    p = __fmaf_rn(x.y, y.y, p);
+                    p = __fmaf_rn(x.z, y.z, p);
+                    p = __fmaf_rn(x.w, y.w, p);
+                }
+                ph[e] = p;
+            }
+        }
+        if (tid < kBM && (uint32_t)tid < cnt) a.out[item0 + tid] = 1.0f / (1.0f + expf(-(ph[0] + ph[1])));
     }
 }
 
@@ -575,15 +739,17 @@ static int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* 
     a.w2p = m->w2p;
     a.out = d_out;
     if (m->prec) {
-        constexpr size_t lds = mlp_lds_bytes(1, 256);
+        // bf16: 2 x 2 waves, 64-column chunks, two-pass head → 68 KB of LDS and <= 256 registers: two
+        // workgroups per CU, so one's barriers and weight-fragment loads hide behind the other's MFMAs
+        constexpr size_t lds = mlp_lds_bytes(1, 256, 64, 2);
         static bool once = false;
-        if (!once) { if ((rc = set_lds_attr(mlp_kernel<1, 512, 256, true, 1, 4, 1>, lds))) return rc; once = true; }
-        mlp_kernel<1, 512, 256, true, 1, 4, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
+        if (!once) { if ((rc = set_lds_attr(mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2>, lds))) return rc; once = true; }
+        mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
     } else {
-        constexpr size_t lds = mlp_lds_bytes(0, 256);
+        constexpr size_t lds = mlp_lds_bytes(0, 256, 128, 1);
         static bool once = false;
-        if (!once) { if ((rc = set_lds_attr(mlp_kernel<0, 512, 256, true, 1, 4, 1>, lds))) return rc; once = true; }
-        mlp_kernel<0, 512, 256, true, 1, 4, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
+        if (!once) { if ((rc = set_lds_attr(mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1>, lds))) return rc; once = true; }
+        mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
     }
     PG_HIP(hipGetLastError());
     PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -626,15 +792,15 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     a.w2p = m->w2p;
     a.out = d_out;
     if (m->prec) {
-        constexpr size_t lds = mlp_lds_bytes(1, 64);
+        constexpr size_t lds = mlp_lds_bytes(1, 64, 128, 1);
         static bool once = false;
-        if (!once) { if ((rc = set_lds_attr(mlp_kernel<1, 256, 64, false, 2, 2, 2>, lds))) return rc; once = true; }
-        mlp_kernel<1, 256, 64, false, 2, 2, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
+        if (!once) { if ((rc = set_lds_attr(mlp_kernel<1, 256, 64, false, 2, 2, 2, 128, 1, 2>, lds))) return rc; once = true; }
+        mlp_kernel<1, 256, 64, false, 2, 2, 2, 128, 1, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
     } else {
-        constexpr size_t lds = mlp_lds_bytes(0, 64);
+        constexpr size_t lds = mlp_lds_bytes(0, 64, 128, 1);
         static bool once = false;
-        if (!once) { if ((rc = set_lds_attr(mlp_kernel<0, 256, 64, false, 2, 2, 2>, lds))) return rc; once = true; }
-        mlp_kernel<0, 256, 64, false, 2, 2, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
+        if (!once) { if ((rc = set_lds_attr(mlp_kernel<0, 256, 64, false, 2, 2, 2, 128, 1, 1>, lds))) return rc; once = true; }
+        mlp_kernel<0, 256, 64, false, 2, 2, 2, 128, 1, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
     }
     PG_HIP(hipGetLastError());
     PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
