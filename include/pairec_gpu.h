@@ -181,6 +181,20 @@ int pg_dpp(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const doub
            double alpha, uint32_t topn, uint32_t window, int normalize_emb, uint32_t* out_idx,
            uint32_t* out_count);
 
+/* ---- SSD diversity re-rank -------------------------------------------------------------------
+ * Replaces SSDSort.SSDWithSlidingWindow (sort/ssd_sort.go:346-486) and the embedding treatment of
+ * loadEmbeddingCache (:246-252).  Candidates are rows of `t`, given in score-descending order as
+ * SSDSort.doSort leaves them (:296); rel = Item.Score.  normalize_emb / ensure_pos_similarity /
+ * use_ssd_star / window / gamma are the SSDSortConfig fields of the same names (recconf.go:980-1000);
+ * norm_quality_score is the ssd_norm_quality_score experiment parameter (0 none, 1 z-score, 2 min-max).
+ * out_idx (capacity n) receives min(topn, n) indices into the candidate list; when the reference would
+ * return the items unchanged ("all item score are zeros") it receives 0..n-1 and *out_count = n.
+ * out_quality (optional, [n]) receives the normalised quality scores ("ssd_quality_score"). */
+int pg_ssd(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const double* rel, uint32_t n,
+           double gamma, uint32_t topn, uint32_t window, int normalize_emb, int ensure_pos_similarity,
+           int norm_quality_score, int use_ssd_star, uint32_t* out_idx, uint32_t* out_count,
+           double* out_quality);
+
 /* ---- stats ----------------------------------------------------------------------------------*/
 typedef struct {
     uint64_t recall_calls, recall_rows_scanned, recall_rescans;

@@ -10,6 +10,7 @@
  * Build: see oracle/Makefile (gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp).
  */
 #include "oracle.h"
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -523,4 +524,127 @@ uint32_t orc_dpp_with_window(const double* L, uint32_t n, uint32_t topn, uint32_
     for (uint32_t i = 0; i < topn / window; ++i) cnt += dpp_once(L, n, window, out_idx, cnt, out_idx + cnt);
     if (topn % window) cnt += dpp_once(L, n, topn % window, out_idx, cnt, out_idx + cnt);
     return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* SSD: sort/ssd_sort.go:346-486 (SSDWithSlidingWindow, arXiv 2107.05204), fp64.               */
+/* gonum v0.12.0 (floats.Dot / floats.Norm / mat.ScaleVec / stat.PopMeanVariance) is not        */
+/* vendored in the reference tree and its amd64 kernels are assembly, so the summation orders   */
+/* below are this restatement's specification (parity unpinned at that boundary):               */
+/*   dot(a,b)  = chain(0; a_k*b_k, k asc)  (fma)          norm(v) = sqrt(chain(0; v_k*v_k))      */
+/*   e -= p*f  = e_k - (p*f_k)  (ScaleVec then floats.Sub: two roundings); += likewise           */
+/*   quality   = r + (volume*l2)            argmax = floats.MaxIdx (first max, NaN skipped)      */
+/* ------------------------------------------------------------------------------------------ */
+/* quality-score normalisation (:360-388).  mode 0: copy; 1: z-score (stat.PopMeanVariance,     */
+/* two-pass with compensation; stat.StdScore); 2: min-max into [eps,1] with max = rel[0],       */
+/* min = rel[n-1] (items arrive sorted by score, descending).  Returns 0 when the reference      */
+/* bails out ("all item score are zeros": mean==0 || variance==0, or span==0).                   */
+int orc_ssd_quality(const double* rel, uint32_t n, int mode, double* out) {
+    if (mode == 1) {
+        double sum = 0.0;
+        for (uint32_t i = 0; i < n; ++i) sum = sum + rel[i];
+        const double mean = sum / (double)n;
+        double ss = 0.0, comp = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double d = rel[i] - mean;
+            volatile double dd = d * d;           /* no FMA */
+            ss = ss + dd;
+            comp = comp + d;
+        }
+        volatile double cc = comp * comp;
+        const double variance = (ss - cc / (double)n) / (double)n;
+        if (mean == 0.0 || variance == 0.0) return 0;
+        const double sd = sqrt(variance);
+        for (uint32_t i = 0; i < n; ++i) out[i] = (rel[i] - mean) / sd;
+        return 1;
+    }
+    if (mode == 2) {
+        const double mx = rel[0], mn = rel[n - 1], span = mx - mn;
+        if (span == 0.0) return 0;
+        const double eps = 1e-6;
+        for (uint32_t i = 0; i < n; ++i) {
+            volatile double a = ((rel[i] - mn) / span) * (1 - eps);
+            out[i] = a + eps;
+        }
+        return 1;
+    }
+    for (uint32_t i = 0; i < n; ++i) out[i] = rel[i];
+    return 1;
+}
+
+static double ssd_norm(const double* v, uint32_t d) {
+    double ss = 0.0;
+    for (uint32_t k = 0; k < d; ++k) ss = fma(v[k], v[k], ss);
+    return sqrt(ss);
+}
+
+/* emb: [n][d] fp64, modified in place (the reference mutates Item.Embedding).  Returns the     */
+/* number of indices written (min(n, topn)).                                                    */
+uint32_t orc_ssd_window(double* emb, uint32_t n, uint32_t d, const double* rel, double gamma,
+                        uint32_t topn, uint32_t window, int use_ssd_star, uint32_t* out_idx) {
+    if (n == 0 || topn == 0) return 0;
+    if (window <= 1) window = 5;                                    /* :357-360 */
+    const uint32_t T = n < topn ? n : topn;
+    uint8_t* selected = (uint8_t*)calloc(n, 1);
+    double* proj = (double*)calloc((size_t)window * n, sizeof(double));   /* ring of projection vectors */
+    double* q = (double*)malloc((size_t)n * sizeof(double));
+    uint32_t t = 1;
+    uint32_t idx = max_idx_nan_skip(rel, n);
+    selected[idx] = 1;
+    out_idx[0] = idx;
+    double volume = gamma;
+    if (!use_ssd_star) {
+        const double l2 = ssd_norm(emb + (size_t)idx * d, d);
+        if (!(isnan(l2) || isinf(l2))) volume *= l2;
+    }
+    while (t < T) {
+        const uint32_t slot = t % window;
+        if (t > window) {                         /* restore the projection of the item leaving the window */
+            const uint32_t i = out_idx[t - 1 - window];
+            const double* ei = emb + (size_t)i * d;
+            const double* pold = proj + (size_t)slot * n;
+            for (uint32_t j = 0; j < n; ++j) {
+                if (selected[j]) continue;
+                double* ej = emb + (size_t)j * d;
+                for (uint32_t k = 0; k < d; ++k) {
+                    volatile double s = pold[j] * ei[k];
+                    ej[k] = ej[k] + s;
+                }
+            }
+        }
+        const double* es = emb + (size_t)idx * d;
+        double den = 0.0;
+        for (uint32_t k = 0; k < d; ++k) den = fma(es[k], es[k], den);
+        double* pnew = proj + (size_t)slot * n;
+        for (uint32_t j = 0; j < n; ++j) {
+            pnew[j] = 0.0;
+            if (selected[j]) continue;
+            double* ej = emb + (size_t)j * d;
+            double acc = 0.0;
+            for (uint32_t k = 0; k < d; ++k) acc = fma(ej[k], es[k], acc);
+            double p = acc / den;
+            if (isnan(p) || isinf(p)) p = 1.0;
+            pnew[j] = p;
+            for (uint32_t k = 0; k < d; ++k) {
+                volatile double s = p * es[k];
+                ej[k] = ej[k] - s;
+            }
+        }
+        ++t;
+        for (uint32_t j = 0; j < n; ++j) {
+            if (selected[j]) { q[j] = -DBL_MAX; continue; }
+            const double l2 = ssd_norm(emb + (size_t)j * d, d);
+            volatile double v = volume * ((isnan(l2) || isinf(l2)) ? 0.5 : l2);
+            q[j] = rel[j] + v;
+        }
+        idx = max_idx_nan_skip(q, n);
+        selected[idx] = 1;
+        out_idx[t - 1] = idx;
+        if (!use_ssd_star) {
+            const double l2 = ssd_norm(emb + (size_t)idx * d, d);
+            if (!(isnan(l2) || isinf(l2))) volume *= l2;
+        }
+    }
+    free(q); free(proj); free(selected);
+    return T;
 }

@@ -85,6 +85,11 @@ void orc_dpp_kernel_matrix(const double* emb, uint32_t n, uint32_t d, const doub
                            double alpha, double* L /* [n][n] */);
 uint32_t orc_dpp_with_window(const double* L, uint32_t n, uint32_t topn, uint32_t window,
                              uint32_t* out_idx);
+
+/* ---- SSD (sort/ssd_sort.go:346-486) -------------------------------------------------------- */
+int orc_ssd_quality(const double* rel, uint32_t n, int mode, double* out);
+uint32_t orc_ssd_window(double* emb, uint32_t n, uint32_t d, const double* rel, double gamma,
+                        uint32_t topn, uint32_t window, int use_ssd_star, uint32_t* out_idx);
 void orc_l2_normalize_f64(double* v, uint32_t d);
 
 #ifdef __cplusplus

@@ -64,6 +64,11 @@ def lib():
         L.orc_dpp_with_window.restype = u32
         L.orc_dpp_with_window.argtypes = [C.POINTER(C.c_double), u32, u32, u32, C.POINTER(u32)]
         L.orc_l2_normalize_f64.argtypes = [C.POINTER(C.c_double), u32]
+        L.orc_ssd_quality.restype = i32
+        L.orc_ssd_quality.argtypes = [C.POINTER(C.c_double), u32, i32, C.POINTER(C.c_double)]
+        L.orc_ssd_window.restype = u32
+        L.orc_ssd_window.argtypes = [C.POINTER(C.c_double), u32, u32, C.POINTER(C.c_double), C.c_double,
+                                     u32, u32, i32, C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -280,6 +285,38 @@ def dpp_with_window(L: np.ndarray, topn: int, window: int) -> np.ndarray:
     out = np.zeros(max(topn, 1), dtype=np.uint32)
     n = lib().orc_dpp_with_window(_f64p(L), L.shape[0], topn, window,
                                   out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out[:n]
+
+
+# ---------------------------------------------------------------------------------------------
+# SSD  (sort/ssd_sort.go:346-486)
+# ---------------------------------------------------------------------------------------------
+def ssd_quality(rel: np.ndarray, mode: int):
+    """ssd_norm_quality_score (:360-388).  Returns (scores, ok); ok False = the reference bails out."""
+    rel = np.ascontiguousarray(rel, dtype=np.float64)
+    out = np.empty_like(rel)
+    ok = lib().orc_ssd_quality(_f64p(rel), rel.shape[0], int(mode), _f64p(out))
+    return out, bool(ok)
+
+
+def ssd_embeddings(emb32: np.ndarray, normalize: bool, ensure_pos_similarity: bool) -> np.ndarray:
+    """loadEmbeddingCache's per-item treatment (:246-252): widen, L2-normalise, append 1."""
+    e = np.array(emb32, dtype=np.float64)
+    if normalize:
+        e = l2_normalize_f64(e)
+    if ensure_pos_similarity:
+        e = np.concatenate([e, np.ones((e.shape[0], 1))], axis=1)
+    return np.ascontiguousarray(e)
+
+
+def ssd_window(emb: np.ndarray, rel: np.ndarray, gamma: float, topn: int, window: int,
+               use_ssd_star: bool = False) -> np.ndarray:
+    """SSDWithSlidingWindow on prepared fp64 embeddings [n][d] and (normalised) quality scores."""
+    e = np.array(emb, dtype=np.float64, copy=True, order="C")
+    rel = np.ascontiguousarray(rel, dtype=np.float64)
+    out = np.zeros(max(min(topn, e.shape[0]), 1), dtype=np.uint32)
+    n = lib().orc_ssd_window(_f64p(e), e.shape[0], e.shape[1], _f64p(rel), float(gamma), int(topn), int(window),
+                             int(use_ssd_star), out.ctypes.data_as(C.POINTER(C.c_uint32)))
     return out[:n]
 
 

@@ -1,0 +1,599 @@
+// ssd.hip — SSD (sliding spectrum decomposition) diversity re-rank in fp64 on the device.
+//
+// Replaces SSDSort.SSDWithSlidingWindow (sort/ssd_sort.go:346-486, arXiv 2107.05204; built on gonum
+// v0.12.0 floats.Dot / floats.Norm / mat.ScaleVec / stat.PopMeanVariance) and the per-item embedding
+// treatment of loadEmbeddingCache (:246-252: parse → L2-normalise → append 1).
+//
+// Per pick t the reference (a) adds back the projection of the item that leaves the window to every
+// unselected embedding, (b) projects the last pick out of every unselected embedding, (c) scores
+// quality_j = r_j + volume·‖e_j‖ and takes the first maximum, (d) volume *= ‖e_pick‖.  Each of (a)–(c)
+// is independent per candidate, so one pass over the embeddings per pick does all three: thread j walks
+// candidate j's residual embedding twice (dot, then update + norm).  The embeddings live transposed in
+// global memory ([k][candidate]: coalesced across threads, L2-resident), the pick's and the leaving
+// item's embeddings are broadcast from LDS.
+//
+// Summation orders (gonum is not vendored in the reference tree, parity is unpinned at that boundary —
+// DESIGN.md §5.7): dot = chain_{k asc} fma; norm = sqrt(chain fma); e ∓= p·f as separate multiply and
+// add/subtract (ScaleVec, then floats.Sub/Add); quality = r + (volume·l2).  Bit-identical to
+// oracle/oracle.c:orc_ssd_window.
+#include "common.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace pg {
+
+// one thread per candidate: gather the fp32 row, widen, optionally L2-normalise (floats.Norm /
+// floats.Scale(1/norm), ssd_sort.go:246-249), optionally append 1 (ensurePosSimilarity, :250-252);
+// stored transposed Et[k][n]
+__global__ void ssd_prepare_kernel(const float* __restrict__ tab, uint32_t tab_rows, uint32_t d,
+                                   const uint32_t* __restrict__ cand, uint32_t n, int normalize,
+                                   int append_one, double* __restrict__ Et) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t row = cand[i];
+    row = row < tab_rows ? row : tab_rows - 1;
+    const float* x = tab + (size_t)row * d;
+    double inv = 1.0;
+    if (normalize) {
+        double ss = 0.0;
+        for (uint32_t k = 0; k < d; ++k) {
+            const double v = (double)x[k];
+            ss = fma(v, v, ss);
+        }
+        inv = 1.0 / sqrt(ss);
+    }
+    for (uint32_t k = 0; k < d; ++k) {
+        double v = (double)x[k];
+        if (normalize) v = inv * v;
+        Et[(size_t)k * n + i] = v;
+    }
+    if (append_one) Et[(size_t)d * n + i] = 1.0;
+}
+
+// floats.MaxIdx over v[0..n): first maximum, NaN skipped, all-NaN → 0.  Block-wide (wave shuffles, then one
+// LDS round over the <= 16 wave winners); result in *out_idx.
+__device__ __forceinline__ void ssd_block_argmax(const double* __restrict__ v, uint32_t n, double* s_val,
+                                                 uint32_t* s_idx, uint32_t* out_idx) {
+    const uint32_t tid = threadIdx.x;
+    double best = 0.0;
+    uint32_t bi = 0xFFFFFFFFu;                       // "none yet"
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        const double x = v[i];
+        if (x != x) continue;
+        if (bi == 0xFFFFFFFFu || x > best) { best = x; bi = i; }
+    }
+    auto better = [](double ov, uint32_t oi, double mv, uint32_t mi) {
+        return oi != 0xFFFFFFFFu && (mi == 0xFFFFFFFFu || ov > mv || (ov == mv && oi < mi));
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(best, off, 64);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
+        if (better(ov, oi, best, bi)) { best = ov; bi = oi; }
+    }
+    const uint32_t wave = tid >> 6, nw = blockDim.x >> 6;
+    if ((tid & 63) == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        double mv = s_val[0];
+        uint32_t mi = s_idx[0];
+        for (uint32_t w = 1; w < nw; ++w)
+            if (better(s_val[w], s_idx[w], mv, mi)) { mv = s_val[w]; mi = s_idx[w]; }
+        *out_idx = (mi == 0xFFFFFFFFu) ? 0u : mi;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool ssd_bad(double x) { return x != x || fabs(x) == __builtin_inf(); }
+
+constexpr uint32_t kSsdMaxDim = 320;
+constexpr uint32_t kSsdBlk = 16;        // values fetched per batch (32 VGPRs)
+
+// One workgroup.  Et: [d1][n] residual embeddings (modified), P: [window][n] ring of projection
+// coefficients, nrm/q: [n], sel: [n] flags, out: [T] picks.
+__global__ __launch_bounds__(1024) void ssd_kernel(double* __restrict__ Et, uint32_t n, uint32_t d1,
+                                                   const double* __restrict__ rel, double gamma, uint32_t T,
+                                                   uint32_t W, int star, double* __restrict__ P,
+                                                   double* __restrict__ nrm, double* __restrict__ ssq,
+                                                   double* __restrict__ q, uint32_t* __restrict__ sel, uint32_t* __restrict__ out) {
+    __shared__ double s_val[16];
+    __shared__ uint32_t s_idx[16];
+    __shared__ uint32_t s_j;
+    __shared__ double e_sel[kSsdMaxDim], e_old[kSsdMaxDim];
+    __shared__ double s_den;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < n; i += blockDim.x) sel[i] = 0;
+    __syncthreads();
+    ssd_block_argmax(rel, n, s_val, s_idx, &s_j);
+    uint32_t idx = s_j;
+    if (tid == 0) { out[0] = idx; sel[idx] = 1; }
+    // ‖e_first‖² (thread 0, once): volume = gamma · ‖e_first‖ (unless SSD*), and the first projection's
+    // denominator.  Later denominators floats.Dot(e_pick, e_pick) are the pick's own sum of squares from the
+    // pass that scored it — the same chain over the same values (a picked embedding is never modified).
+    if (tid == 0) {
+        double ss = 0.0;
+        for (uint32_t k = 0; k < d1; ++k) {
+            const double e = Et[(size_t)k * n + idx];
+            ss = fma(e, e, ss);
+        }
+        s_den = ss;
+    }
+    __syncthreads();
+    double den = s_den;
+    double volume = gamma;
+    if (!star && !ssd_bad(sqrt(den))) volume = __dmul_rn(volume, sqrt(den));
+
+    for (uint32_t t = 1; t < T;) {
+        const bool pop = t > W;
+        const uint32_t i_old = pop ? out[t - 1 - W] : 0u;
+        const uint32_t slot = t % W;
+        for (uint32_t k = tid; k < d1; k += blockDim.x) {
+            e_sel[k] = Et[(size_t)k * n + idx];
+            if (pop) e_old[k] = Et[(size_t)k * n + i_old];
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < n; j += blockDim.x) {
+            if (sel[j]) { q[j] = -DBL_MAX; continue; }
+            // The two k-chains are serial, the loads are not: full batches of kSsdBlk values are fetched
+            // together (independent loads, all in flight — the residuals live in L2, not LDS) before the
+            // chain runs over them; the tail (d1 mod kSsdBlk) goes element by element.
+            double* col = Et + j;
+            double acc = 0.0;
+            const double pold = pop ? P[(size_t)slot * n + j] : 0.0;
+            uint32_t k0 = 0;
+            for (; k0 + kSsdBlk <= d1; k0 += kSsdBlk) {
+                double v[kSsdBlk];
+#pragma unroll
+                for (uint32_t u = 0; u < kSsdBlk; ++u) v[u] = col[(size_t)(k0 + u) * n];
+                if (pop) {
+#pragma unroll
+                    for (uint32_t u = 0; u < kSsdBlk; ++u) {
+                        v[u] = __dadd_rn(v[u], __dmul_rn(pold, e_old[k0 + u]));
+                        col[(size_t)(k0 + u) * n] = v[u];
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kSsdBlk; ++u) acc = fma(v[u], e_sel[k0 + u], acc);
+            }
+            for (; k0 < d1; ++k0) {
+                double e = col[(size_t)k0 * n];
+                if (pop) {
+                    e = __dadd_rn(e, __dmul_rn(pold, e_old[k0]));
+                    col[(size_t)k0 * n] = e;
+                }
+                acc = fma(e, e_sel[k0], acc);
+            }
+            double p = acc / den;
+            if (ssd_bad(p)) p = 1.0;
+            double ss = 0.0;
+            for (k0 = 0; k0 + kSsdBlk <= d1; k0 += kSsdBlk) {
+                double v[kSsdBlk];
+#pragma unroll
+                for (uint32_t u = 0; u < kSsdBlk; ++u) v[u] = col[(size_t)(k0 + u) * n];
+#pragma unroll
+                for (uint32_t u = 0; u < kSsdBlk; ++u) {
+                    const double e = __dsub_rn(v[u], __dmul_rn(p, e_sel[k0 + u]));
+                    col[(size_t)(k0 + u) * n] = e;
+                    ss = fma(e, e, ss);
+                }
+            }
+            for (; k0 < d1; ++k0) {
+                const double e = __dsub_rn(col[(size_t)k0 * n], __dmul_rn(p, e_sel[k0]));
+                col[(size_t)k0 * n] = e;
+                ss = fma(e, e, ss);
+            }
+            const double l2 = sqrt(ss);
+            P[(size_t)slot * n + j] = p;
+            nrm[j] = l2;
+            ssq[j] = ss;
+            q[j] = __dadd_rn(rel[j], __dmul_rn(volume, ssd_bad(l2) ? 0.5 : l2));
+        }
+        __syncthreads();
+        ssd_block_argmax(q, n, s_val, s_idx, &s_j);
+        idx = s_j;
+        ++t;
+        if (tid == 0) { out[t - 1] = idx; sel[idx] = 1; }
+        den = ssq[idx];
+        if (!star) {
+            const double l2 = nrm[idx];
+            if (!ssd_bad(l2)) volume = __dmul_rn(volume, l2);
+        }
+        __syncthreads();
+    }
+}
+
+// Register-resident variant for the common embedding widths: 256 threads (one wave per SIMD, 512 VGPRs
+// each), a thread pulls a candidate's whole residual embedding into registers with D1 independent loads —
+// one L2 round trip — runs restore, dot, update and norm on it and writes it back once; quality / norm /
+// sum of squares / selection flags live in LDS.  Same arithmetic, same order as ssd_kernel.
+constexpr uint32_t kSsdRegMaxN = 2048;
+template <int D1>
+__global__ __launch_bounds__(256) void ssd_kernel_reg(double* __restrict__ Et, uint32_t n,
+                                                      const double* __restrict__ rel, double gamma, uint32_t T,
+                                                      uint32_t W, int star, double* __restrict__ P,
+                                                      uint32_t* __restrict__ out) {
+    __shared__ double s_val[16];
+    __shared__ uint32_t s_idx[16];
+    __shared__ uint32_t s_j;
+    __shared__ double e_sel[D1], e_old[D1];
+    __shared__ double q_s[kSsdRegMaxN], nrm_s[kSsdRegMaxN], ssq_s[kSsdRegMaxN];
+    __shared__ uint8_t sel_s[kSsdRegMaxN];
+    __shared__ uint32_t out_s[kSsdRegMaxN];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < n; i += blockDim.x) { sel_s[i] = 0; q_s[i] = rel[i]; }
+    __syncthreads();
+    ssd_block_argmax(q_s, n, s_val, s_idx, &s_j);
+    uint32_t idx = s_j;
+    if (tid == 0) {
+        out_s[0] = idx;
+        sel_s[idx] = 1;
+        double ss = 0.0;
+        for (int k = 0; k < D1; ++k) {
+            const double e = Et[(size_t)k * n + idx];
+            ss = fma(e, e, ss);
+        }
+        ssq_s[idx] = ss;
+    }
+    __syncthreads();
+    double den = ssq_s[idx];
+    double volume = gamma;
+    if (!star && !ssd_bad(sqrt(den))) volume = __dmul_rn(volume, sqrt(den));
+
+    for (uint32_t t = 1; t < T;) {
+        const bool pop = t > W;
+        const uint32_t i_old = pop ? out_s[t - 1 - W] : 0u;
+        const uint32_t slot = t % W;
+        for (uint32_t k = tid; k < (uint32_t)D1; k += blockDim.x) {
+            e_sel[k] = Et[(size_t)k * n + idx];
+            if (pop) e_old[k] = Et[(size_t)k * n + i_old];
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < n; j += blockDim.x) {
+            if (sel_s[j]) { q_s[j] = -DBL_MAX; continue; }
+            // (row base uniform, lane offset j: scalar-base addressing, no per-element address registers)
+            const double pold = pop ? P[(size_t)slot * n + j] : 0.0;
+            double v[D1];
+#pragma unroll
+            for (int k = 0; k < D1; ++k) v[k] = (Et + (size_t)k * n)[j];
+            // (scheduling fences every 8 elements: without them hipcc hoists all 2·D1 LDS operand reads
+            //  to the top and spills the embedding it was supposed to keep in registers)
+            if (pop) {
+#pragma unroll
+                for (int k = 0; k < D1; ++k) {
+                    v[k] = __dadd_rn(v[k], __dmul_rn(pold, e_old[k]));
+                    if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D1; ++k) {
+                acc = fma(v[k], e_sel[k], acc);
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            double p = acc / den;
+            if (ssd_bad(p)) p = 1.0;
+            double ss = 0.0;
+#pragma unroll
+            for (int k = 0; k < D1; ++k) {
+                const double e = __dsub_rn(v[k], __dmul_rn(p, e_sel[k]));
+                (Et + (size_t)k * n)[j] = e;
+                ss = fma(e, e, ss);
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            const double l2 = sqrt(ss);
+            P[(size_t)slot * n + j] = p;
+            nrm_s[j] = l2;
+            ssq_s[j] = ss;
+            q_s[j] = __dadd_rn(rel[j], __dmul_rn(volume, ssd_bad(l2) ? 0.5 : l2));
+        }
+        __syncthreads();
+        ssd_block_argmax(q_s, n, s_val, s_idx, &s_j);
+        idx = s_j;
+        ++t;
+        if (tid == 0) { out_s[t - 1] = idx; sel_s[idx] = 1; }
+        den = ssq_s[idx];
+        if (!star) {
+            const double l2 = nrm_s[idx];
+            if (!ssd_bad(l2)) volume = __dmul_rn(volume, l2);
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < T; i += blockDim.x) out[i] = out_s[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-workgroup variant: one wave per workgroup, one candidate per lane, the candidate's whole residual
+// embedding lives in the lane's registers for the entire run (D1 doubles ≤ 258 VGPRs of the 512 a lone wave
+// may use), so a pick moves no embedding data except the broadcast of the picked / leaving item's vector
+// (D1 doubles through a global mailbox).  Workgroups meet at a device-wide barrier twice per pick (all of
+// them are co-resident: at most 128 single-wave workgroups on 256 CUs, launched on an otherwise idle
+// stream).  Same arithmetic, same order as ssd_kernel.
+// ---------------------------------------------------------------------------------------------
+struct SsdMail {
+    uint32_t counter;          // monotonically increasing arrival count of the device-wide barrier
+    uint32_t pad[15];
+    double part_q[2][128];     // per-workgroup best quality, by pick parity
+    uint32_t part_i[2][128];
+    double den[2], l2[2];      // picked item's sum of squares / norm, by pick parity
+};
+
+__device__ __forceinline__ double ld_dev(const double* p) {       // device-scope load (bypasses the CU's L1)
+    return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) {
+    return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void ssd_grid_barrier(uint32_t* counter, uint32_t G, uint32_t& phase) {
+    ++phase;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < phase * G)
+            __builtin_amdgcn_s_sleep(1);
+        __threadfence();
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int D1>
+__global__ __launch_bounds__(64) void ssd_kernel_grid(const double* __restrict__ Et, uint32_t n,
+                                                      const double* __restrict__ rel_g, double gamma, uint32_t T,
+                                                      uint32_t W, int star, SsdMail* __restrict__ mail,
+                                                      double* __restrict__ ebuf,   // [2][2][D1]: parity, sel/old
+                                                      uint32_t* __restrict__ out) {
+    __shared__ double e_sel[D1], e_old[D1];
+    __shared__ double p_ring[16][64];
+    const uint32_t lane = threadIdx.x, G = gridDim.x, wg = blockIdx.x;
+    const uint32_t j = wg * 64 + lane;
+    const bool valid = j < n;
+    const uint32_t jc = valid ? j : n - 1;
+    double v[D1];
+#pragma unroll
+    for (int k = 0; k < D1; ++k) v[k] = (Et + (size_t)k * n)[jc];
+    const double rel = rel_g[jc];
+    bool selected = false;
+    uint32_t phase = 0;
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+
+    // wave-local "first maximum, NaN skipped" of (q, j); invalid lanes carry NaN
+    auto wave_best = [&](double q, double& bq, uint32_t& bi) {
+        bq = q;
+        bi = (valid && q == q) ? j : 0xFFFFFFFFu;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oq = __shfl_xor(bq, off, 64);
+            const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
+            if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || oq > bq || (oq == bq && oi < bi))) { bq = oq; bi = oi; }
+        }
+    };
+    // publish this workgroup's best, meet, then every workgroup reduces the G partial results identically
+    auto global_pick = [&](double q, uint32_t par) -> uint32_t {
+        double bq;
+        uint32_t bi;
+        wave_best(q, bq, bi);
+        if (lane == 0) { mail->part_q[par][wg] = bq; mail->part_i[par][wg] = bi; }
+        ssd_grid_barrier(&mail->counter, G, phase);
+        double gq = nan;
+        uint32_t gi = 0xFFFFFFFFu;
+        for (uint32_t w = lane; w < G; w += 64) {       // G <= 128: at most 2 per lane, ascending
+            const double oq = ld_dev(&mail->part_q[par][w]);
+            const uint32_t oi = ld_dev(&mail->part_i[par][w]);
+            if (oi != 0xFFFFFFFFu && (gi == 0xFFFFFFFFu || oq > gq || (oq == gq && oi < gi))) { gq = oq; gi = oi; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oq = __shfl_xor(gq, off, 64);
+            const uint32_t oi = (uint32_t)__shfl_xor((int)gi, off, 64);
+            if (oi != 0xFFFFFFFFu && (gi == 0xFFFFFFFFu || oq > gq || (oq == gq && oi < gi))) { gq = oq; gi = oi; }
+        }
+        return gi == 0xFFFFFFFFu ? 0u : gi;
+    };
+
+    double ss_own = 0.0, l2_own = 0.0;                  // this lane's last sum of squares / norm
+    {   // ‖e‖² of every candidate once: the first pick's volume factor and first denominator
+#pragma unroll
+        for (int k = 0; k < D1; ++k) {
+            ss_own = fma(v[k], v[k], ss_own);
+            if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        l2_own = sqrt(ss_own);
+    }
+    uint32_t idx = global_pick(valid ? rel : nan, 0);
+    uint32_t t = 1;
+    double volume = gamma;
+    for (;;) {
+        // (idx = pick number t, known to every workgroup)  owner: publish its vector, norm, sum of squares
+        const uint32_t par = t & 1;
+        const bool pop = t > W && t < T;
+        if (valid && j == idx) {
+            selected = true;
+            mail->den[par] = ss_own;
+            mail->l2[par] = l2_own;
+            out[t - 1] = idx;
+            if (t < T) {
+#pragma unroll
+                for (int k = 0; k < D1; ++k) ebuf[(size_t)(par * 2 + 0) * D1 + k] = v[k];
+            }
+        }
+        if (t >= T) break;
+        // the item leaving the window (picked W picks ago): its owner publishes its frozen vector
+        uint32_t i_old = 0xFFFFFFFFu;
+        if (pop) i_old = ld_dev(&out[t - 1 - W]);
+        if (pop && valid && j == i_old) {
+#pragma unroll
+            for (int k = 0; k < D1; ++k) ebuf[(size_t)(par * 2 + 1) * D1 + k] = v[k];
+        }
+        ssd_grid_barrier(&mail->counter, G, phase);
+        for (uint32_t k = lane; k < (uint32_t)D1; k += 64) {
+            e_sel[k] = ld_dev(&ebuf[(size_t)(par * 2 + 0) * D1 + k]);
+            if (pop) e_old[k] = ld_dev(&ebuf[(size_t)(par * 2 + 1) * D1 + k]);
+        }
+        const double den = ld_dev(&mail->den[par]);
+        const double l2p = ld_dev(&mail->l2[par]);
+        if (!star && !ssd_bad(l2p)) volume = __dmul_rn(volume, l2p);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t slot = t % W;
+        double q = -DBL_MAX;
+        if (!selected) {
+            if (pop) {
+                const double pold = p_ring[slot][lane];
+#pragma unroll
+                for (int k = 0; k < D1; ++k) {
+                    v[k] = __dadd_rn(v[k], __dmul_rn(pold, e_old[k]));
+                    if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D1; ++k) {
+                acc = fma(v[k], e_sel[k], acc);
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            double p = acc / den;
+            if (ssd_bad(p)) p = 1.0;
+            double ss = 0.0;
+#pragma unroll
+            for (int k = 0; k < D1; ++k) {
+                v[k] = __dsub_rn(v[k], __dmul_rn(p, e_sel[k]));
+                ss = fma(v[k], v[k], ss);
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            const double l2 = sqrt(ss);
+            p_ring[slot][lane] = p;
+            ss_own = ss;
+            l2_own = l2;
+            q = __dadd_rn(rel, __dmul_rn(volume, ssd_bad(l2) ? 0.5 : l2));
+        }
+        ++t;
+        idx = global_pick(valid ? q : nan, t & 1);
+    }
+}
+
+}  // namespace pg
+
+extern "C" {
+
+int pg_ssd(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const double* rel, uint32_t n,
+           double gamma, uint32_t topn, uint32_t window, int normalize_emb, int ensure_pos_similarity,
+           int norm_quality_score, int use_ssd_star, uint32_t* out_idx, uint32_t* out_count,
+           double* out_quality) {
+    PG_REQUIRE(ctx && t && out_count, "pg_ssd: NULL argument");
+    *out_count = 0;
+    if (n == 0 || topn == 0) return PG_OK;
+    PG_REQUIRE(cand_rows && rel && out_idx, "pg_ssd: NULL argument");
+    PG_REQUIRE(norm_quality_score >= 0 && norm_quality_score <= 2, "pg_ssd: norm_quality_score must be 0, 1 or 2");
+    if (window <= 1) window = 5;                          // ssd_sort.go:357-360
+    const uint32_t d1 = t->dim + (ensure_pos_similarity ? 1u : 0u);
+    if (n > 8192 || d1 > pg::kSsdMaxDim) {
+        pg::set_error("pg_ssd: %u candidates x %u dims unsupported (<= 8192 x %u)", n, d1, pg::kSsdMaxDim);
+        return PG_ERR_UNSUPPORTED;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        PG_REQUIRE(cand_rows[i] < t->rows, "pg_ssd: candidate row %u outside table", cand_rows[i]);
+
+    // ssd_norm_quality_score (ssd_sort.go:360-388): O(n) scalar work on the caller's thread, in the
+    // reference's operation order (stat.PopMeanVariance two-pass with compensation, stat.StdScore)
+    std::vector<double> quality(rel, rel + n);
+    bool bail = false;
+    if (norm_quality_score == 1) {
+        double sum = 0.0;
+        for (uint32_t i = 0; i < n; ++i) sum = sum + rel[i];
+        const double mean = sum / (double)n;
+        double ss = 0.0, comp = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double d = rel[i] - mean;
+            volatile double dd = d * d;
+            ss = ss + dd;
+            comp = comp + d;
+        }
+        volatile double cc = comp * comp;
+        const double variance = (ss - cc / (double)n) / (double)n;
+        if (mean == 0.0 || variance == 0.0) bail = true;
+        else {
+            const double sd = sqrt(variance);
+            for (uint32_t i = 0; i < n; ++i) quality[i] = (rel[i] - mean) / sd;
+        }
+    } else if (norm_quality_score == 2) {
+        const double mx = rel[0], mn = rel[n - 1], span = mx - mn;
+        if (span == 0.0) bail = true;
+        else {
+            const double eps = 1e-6;
+            for (uint32_t i = 0; i < n; ++i) {
+                volatile double a = ((rel[i] - mn) / span) * (1 - eps);
+                quality[i] = a + eps;
+            }
+        }
+    }
+    if (bail) {        // "all item score are zeros": the reference returns the items unchanged
+        for (uint32_t i = 0; i < n; ++i) out_idx[i] = i;
+        *out_count = n;
+        if (out_quality) for (uint32_t i = 0; i < n; ++i) out_quality[i] = rel[i];
+        return PG_OK;
+    }
+    if (out_quality) for (uint32_t i = 0; i < n; ++i) out_quality[i] = quality[i];
+
+    const uint32_t T = n < topn ? n : topn;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t bE = al((size_t)n * d1 * 8), bP = al((size_t)window * n * 8), bN = al((size_t)n * 8);
+    const size_t bCand = al((size_t)n * 4), bSel = al((size_t)n * 4), bOut = al((size_t)T * 4);
+    const size_t bMail = al(sizeof(pg::SsdMail)), bEbuf = al((size_t)4 * d1 * 8);
+    void* buf;
+    int rc;
+    if ((rc = pg::scratch_reserve(ctx, 7, bE + bP + 4 * bN + bCand + bSel + bOut + bMail + bEbuf, &buf))) return rc;
+    char* p = (char*)buf;
+    double* Et = (double*)p; p += bE;
+    double* P = (double*)p; p += bP;
+    double* nrm = (double*)p; p += bN;
+    double* ssq = (double*)p; p += bN;
+    double* q = (double*)p; p += bN;
+    double* d_rel = (double*)p; p += bN;
+    uint32_t* d_cand = (uint32_t*)p; p += bCand;
+    uint32_t* d_sel = (uint32_t*)p; p += bSel;
+    uint32_t* d_out = (uint32_t*)p; p += bOut;
+    pg::SsdMail* mail = (pg::SsdMail*)p; p += bMail;
+    double* ebuf = (double*)p;
+    PG_HIP(hipMemcpyAsync(d_cand, cand_rows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_rel, quality.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    pg::ssd_prepare_kernel<<<(n + 63) / 64, 64, 0, ctx->stream>>>(t->d, (uint32_t)t->rows, t->dim, d_cand, n,
+                                                                normalize_emb, ensure_pos_similarity, Et);
+    // Kernel choice: the multi-workgroup kernel (embeddings pinned in registers, device-wide barrier) for
+    // the usual widths (dim 64 / 128, with or without the appended 1) and windows <= 16; the one-workgroup
+    // kernels otherwise (PG_SSD_KERNEL=generic|reg forces them, for A/B runs).
+    const char* force = getenv("PG_SSD_KERNEL");
+    const bool known_d1 = d1 == 64 || d1 == 65 || d1 == 128 || d1 == 129;
+    int kind = (known_d1 && window <= 16) ? 2 : ((known_d1 && n <= pg::kSsdRegMaxN) ? 1 : 0);
+    if (force && !strcmp(force, "generic")) kind = 0;
+    if (force && !strcmp(force, "reg") && known_d1 && n <= pg::kSsdRegMaxN) kind = 1;
+    if (kind == 2) {
+        PG_HIP(hipMemsetAsync(mail, 0, sizeof(pg::SsdMail), ctx->stream));
+        const uint32_t G = (n + 63) / 64;
+        switch (d1) {
+            case 64: pg::ssd_kernel_grid<64><<<G, 64, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, mail, ebuf, d_out); break;
+            case 65: pg::ssd_kernel_grid<65><<<G, 64, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, mail, ebuf, d_out); break;
+            case 128: pg::ssd_kernel_grid<128><<<G, 64, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, mail, ebuf, d_out); break;
+            default: pg::ssd_kernel_grid<129><<<G, 64, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, mail, ebuf, d_out); break;
+        }
+    } else if (kind == 1) {
+        switch (d1) {
+            case 64: pg::ssd_kernel_reg<64><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
+            case 65: pg::ssd_kernel_reg<65><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
+            case 128: pg::ssd_kernel_reg<128><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
+            default: pg::ssd_kernel_reg<129><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
+        }
+    } else {
+        pg::ssd_kernel<<<1, 1024, 0, ctx->stream>>>(Et, n, d1, d_rel, gamma, T, window, use_ssd_star, P, nrm, ssq, q,
+                                                   d_sel, d_out);
+    }
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipMemcpyAsync(out_idx, d_out, (size_t)T * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    *out_count = T;
+    return PG_OK;
+}
+
+}  // extern "C"

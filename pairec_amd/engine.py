@@ -254,3 +254,19 @@ def dpp(ctx: Context, table: Table, cand_rows, rel, alpha: float, topn: int, win
     _lib.check(ctx.L.pg_dpp(ctx.h, table.h, _ptr(c), _ptr(r), c.shape[0], alpha, topn, window,
                             int(normalize_emb), _ptr(out), C.byref(cnt)))
     return out[:cnt.value]
+
+
+def ssd(ctx: Context, table: Table, cand_rows, rel, gamma: float, topn: int, window: int,
+        normalize_emb: bool = True, ensure_pos_similarity: bool = True, norm_quality_score: int = 0,
+        use_ssd_star: bool = False):
+    """SSDSort.SSDWithSlidingWindow over candidates given in score-descending order.
+    Returns (picked indices, quality scores)."""
+    c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+    r = np.ascontiguousarray(rel, dtype=np.float64)
+    out = np.zeros(max(c.shape[0], 1), dtype=np.uint32)
+    qual = np.zeros(max(c.shape[0], 1), dtype=np.float64)
+    cnt = C.c_uint32()
+    _lib.check(ctx.L.pg_ssd(ctx.h, table.h, _ptr(c), _ptr(r), c.shape[0], gamma, topn, window,
+                            int(normalize_emb), int(ensure_pos_similarity), int(norm_quality_score),
+                            int(use_ssd_star), _ptr(out), C.byref(cnt), _ptr(qual)))
+    return out[:cnt.value], qual[:c.shape[0]]

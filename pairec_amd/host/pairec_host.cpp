@@ -83,14 +83,42 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
     for (const auto& sc : root.at("SceneConfs").obj)
         for (const auto& cat : sc.second.obj)
             out->SceneRecallNames[sc.first][cat.first] = str_list(cat.second.at("RecallNames"));
-    for (const auto& d : root.at("DPPConf").arr) {
+    auto is_false = [](std::string v) {
+        std::transform(v.begin(), v.end(), v.begin(), ::tolower);
+        return v == "false";
+    };
+    auto parse_dpp = [&](const json::Value& d, const std::string& name) {
         DPPSortConfig c;
-        c.Name = d.s("Name"); c.Alpha = d.d("Alpha", 1.0); c.WindowSize = (int)d.n("WindowSize");
+        c.Name = name; c.Alpha = d.d("Alpha", 1.0); c.WindowSize = (int)d.n("WindowSize");
         c.CandidateCount = (int)d.n("CandidateCount"); c.MinScorePercent = d.d("MinScorePercent");
-        std::string ne = d.s("NormalizeEmb");
-        std::transform(ne.begin(), ne.end(), ne.begin(), ::tolower);
-        c.NormalizeEmb = ne != "false";                     // dpp_sort.go:95-97
-        out->DPPConf.push_back(c);
+        c.NormalizeEmb = !is_false(d.s("NormalizeEmb"));    // dpp_sort.go:95-97
+        return c;
+    };
+    for (const auto& d : root.at("DPPConf").arr) out->DPPConf.push_back(parse_dpp(d, d.s("Name")));
+    // SortConfs (recconf.go:86, sort/sort.go:162-200): the DPPSort / SSDSort entries; other SortTypes are
+    // rule-based host sorts outside this engine's scope and are ignored here
+    for (const auto& sc : root.at("SortConfs").arr) {
+        SortConfig c;
+        c.Name = sc.s("Name"); c.SortType = sc.s("SortType");
+        if (c.SortType == "DPPSort") {
+            c.DPPConf = parse_dpp(sc.at("DPPConf"), c.Name);
+        } else if (c.SortType == "SSDSort") {
+            const json::Value& d = sc.at("SSDConf");
+            SSDSortConfig& s = c.SSDConf;
+            s.Name = c.Name;
+            if (d.d("Gamma") > 0) s.Gamma = d.d("Gamma");                         // ssd_sort.go:81-83
+            s.UseSSDStar = d.at("UseSSDStar").type == json::Value::Bool && d.at("UseSSDStar").b;
+            s.WindowSize = (int)d.n("WindowSize") > 0 ? (int)d.n("WindowSize") : 5; // :84-86
+            s.AbortRunCount = (int)d.n("AbortRunCount");
+            s.CandidateCount = (int)d.n("CandidateCount");
+            s.MinScorePercent = d.d("MinScorePercent");
+            s.NormalizeEmb = !is_false(d.s("NormalizeEmb"));                      // :90-92
+            s.EnsurePositiveSim = !is_false(d.s("EnsurePositiveSim"));            // :93-95
+            s.FilterRetrieveIds = str_list(d.at("FilterRetrieveIds"));
+        } else {
+            continue;
+        }
+        out->SortConfs.push_back(c);
     }
     out->UserDefineConfs = root.at("UserDefineConfs");
     return true;
@@ -340,6 +368,73 @@ struct GpuDPPSort : sort::ISort {                        // sort/dpp_sort.go:108
     }
 };
 
+struct GpuSSDSort : sort::ISort {                        // sort/ssd_sort.go:110-343 (embedding table = item table)
+    Engine* e;
+    recconf::SSDSortConfig conf;
+    GpuSSDSort(Engine* eng, recconf::SSDSortConfig c) : e(eng), conf(std::move(c)) {}
+    // doSort (:296-343): score-descending order, candidate trimming, then SSDWithSlidingWindow
+    bool DoSort(std::vector<module::ItemPtr>* items, sort::SortData* d, std::string* err) {
+        if (items->empty()) return true;
+        const int size = d->Context ? d->Context->Size : 10;
+        sort::SortData tmp = *d;
+        tmp.Data = *items;
+        if (!sort_items(e, &tmp, true, err)) return false;
+        items->swap(tmp.Data);
+        if (conf.Gamma == 0) return true;                                           // :302-305
+        if ((conf.CandidateCount > 0 || conf.MinScorePercent > 0) && (int)items->size() > size) {
+            if (conf.CandidateCount > 0) {
+                const size_t cnt = (size_t)std::max(size, conf.CandidateCount);
+                if (cnt < items->size()) items->resize(cnt);
+            }
+            if (conf.MinScorePercent > 0 && (int)items->size() > size) {
+                size_t idx = (size_t)size;
+                const double mx = (*items)[0]->Score;
+                for (; idx < items->size(); ++idx)
+                    if ((*items)[idx]->Score / mx < conf.MinScorePercent) break;
+                items->resize(idx);
+            }
+        }
+        const uint32_t n = (uint32_t)items->size();
+        std::vector<uint32_t> rows(n);
+        std::vector<double> rel(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!e->RowOfId((*items)[i]->Id, &rows[i])) { if (err) *err = "ssd: unknown item id"; return false; }
+            rel[i] = (*items)[i]->Score;
+        }
+        std::vector<uint32_t> idx(n);
+        uint32_t cnt = 0;
+        if (pg_ssd(e->ctx, e->table, rows.data(), rel.data(), n, conf.Gamma, (uint32_t)std::max(size, 0),
+                   (uint32_t)conf.WindowSize, conf.NormalizeEmb ? 1 : 0, conf.EnsurePositiveSim ? 1 : 0,
+                   /*ssd_norm_quality_score*/ 0, conf.UseSSDStar ? 1 : 0, idx.data(), &cnt, nullptr) != PG_OK) {
+            if (err) *err = pg_err("pg_ssd");
+            return false;
+        }
+        std::vector<module::ItemPtr> out;
+        for (uint32_t i = 0; i < cnt; ++i) out.push_back((*items)[idx[i]]);
+        items->swap(out);
+        return true;
+    }
+    bool Sort(sort::SortData* d, std::string* err) override {
+        auto& items = d->Data;
+        if (items.empty()) return true;
+        if (conf.AbortRunCount > 0 && (int)items.size() <= conf.AbortRunCount)      // :129-134
+            return sort_items(e, d, true, err);
+        if (!conf.FilterRetrieveIds.empty()) {                                       // :155-171
+            std::vector<module::ItemPtr> backup, selected;
+            for (auto& it : items) {
+                const bool f = std::find(conf.FilterRetrieveIds.begin(), conf.FilterRetrieveIds.end(), it->RetrieveId) !=
+                               conf.FilterRetrieveIds.end();
+                (f ? backup : selected).push_back(it);
+            }
+            if (!DoSort(&selected, d, err)) return false;
+            selected.insert(selected.end(), backup.begin(), backup.end());
+            items.swap(selected);
+            return true;
+        }
+        return DoSort(&items, d, err);
+    }
+};
+
 }  // namespace
 
 // ---- rank service --------------------------------------------------------------------------------
@@ -434,6 +529,10 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
     e->sorts.RegisterSort("ItemRankScore", std::make_shared<GpuItemRankScoreSort>(e.get()), nullptr);
     e->sorts.RegisterSort("ItemScore", std::make_shared<GpuItemScoreSort>(e.get()), nullptr);
     for (const auto& d : e->config.DPPConf) e->sorts.RegisterSort(d.Name, std::make_shared<GpuDPPSort>(e.get(), d), nullptr);
+    for (const auto& sc : e->config.SortConfs) {          // RegisterSortWithConfig (sort/sort.go:162-200)
+        if (sc.SortType == "DPPSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuDPPSort>(e.get(), sc.DPPConf), nullptr);
+        if (sc.SortType == "SSDSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuSSDSort>(e.get(), sc.SSDConf), nullptr);
+    }
     // algorithms by name (the shim's start hook does the same with algorithm.RegisterAlgorithm)
     for (const auto& a : g.at("Algorithms").arr) {
         const std::string name = a.s("Name"), kind = a.s("Kind");

@@ -99,6 +99,20 @@ struct DPPSortConfig {
     double MinScorePercent = 0.0;
     bool NormalizeEmb = true;
 };
+struct SSDSortConfig {                     // recconf.go:980-1000 (the fields the device path consumes)
+    std::string Name;
+    double Gamma = 0.25;                   // NewSSDSort: 0.25 unless Gamma > 0 (ssd_sort.go:68,81-83)
+    bool UseSSDStar = false;
+    bool NormalizeEmb = true, EnsurePositiveSim = true;
+    int WindowSize = 5, AbortRunCount = 0, CandidateCount = 0;
+    double MinScorePercent = 0.0;
+    std::vector<std::string> FilterRetrieveIds;
+};
+struct SortConfig {                        // recconf.go:820-838: Name, SortType, nested DPPConf / SSDConf
+    std::string Name, SortType;
+    DPPSortConfig DPPConf;
+    SSDSortConfig SSDConf;
+};
 struct RecommendConfig {
     std::vector<AlgoConfig> AlgoConfs;
     std::vector<RecallConfig> RecallConfs;
@@ -106,6 +120,7 @@ struct RecommendConfig {
     std::map<std::string, std::vector<std::string>> SortNames;                // by scene
     std::map<std::string, std::map<std::string, std::vector<std::string>>> SceneRecallNames;  // scene → category → RecallNames
     std::vector<DPPSortConfig> DPPConf;
+    std::vector<SortConfig> SortConfs;                                       // recconf.go:86 (DPPSort / SSDSort entries)
     json::Value UserDefineConfs;                                              // recconf.go:92
     static bool Parse(const std::string& text, RecommendConfig* out, std::string* err);
 };

@@ -393,3 +393,42 @@ def test_dpp_matches_oracle(ctx):
         assert np.array_equal(got, want), (topn, window)
     assert not np.array_equal(pa.dpp(ctx, t, cand, rel, 1.0, 100, 10, True), np.arange(100))
     t.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# SSD
+# ---------------------------------------------------------------------------------------------
+def test_ssd_matches_oracle(ctx):
+    """SSDSort.SSDWithSlidingWindow (ssd_sort.go:346-486): the pick sequence equals the oracle's for
+    every window / gamma / normalisation mode; bar = exact indices (fp64, same operation order)."""
+    rng = np.random.default_rng(9)
+    n_tab, d, n = 4000, 128, 500
+    centers = rng.standard_normal((12, d)).astype(np.float32)
+    tab = (centers[rng.integers(0, 12, n_tab)] + 0.2 * rng.standard_normal((n_tab, d))).astype(np.float32)
+    t = pa.Table(ctx, n_tab, d)
+    t.upload(tab)
+    cand = rng.choice(n_tab, n, replace=False).astype(np.uint32)
+    rel = np.sort(rng.random(n))[::-1].copy()
+    for topn, window, gamma, norm_emb, pos, mode, star in [
+            (100, 5, 0.25, True, True, 0, False),      # SSDSortConfig defaults (recconf.go:980-1000)
+            (100, 10, 0.5, True, False, 1, False),     # z-scored quality
+            (37, 3, 0.25, True, True, 2, False),       # min-max quality
+            (60, 5, 0.25, False, True, 0, True),       # SSD*, raw embeddings
+            (500, 5, 0.25, True, True, 0, False),      # every candidate picked
+            (10, 1, 0.25, True, True, 0, False)]:      # window <= 1 → 5
+        emb = o.ssd_embeddings(tab[cand], norm_emb, pos)
+        qual, ok = o.ssd_quality(rel, mode)
+        assert ok
+        want = o.ssd_window(emb, qual, gamma, topn, window, star)
+        got, gq = pa.ssd(ctx, t, cand, rel, gamma, topn, window, norm_emb, pos, mode, star)
+        assert np.array_equal(got, want), (topn, window, gamma, mode, star)
+        assert np.array_equal(gq, qual)
+    got, _ = pa.ssd(ctx, t, cand, rel, 0.25, 100, 5)
+    assert not np.array_equal(got, np.arange(100))                # diversity changed the order
+    # "all item score are zeros": the reference returns the items unchanged
+    got, _ = pa.ssd(ctx, t, cand, np.zeros(n), 0.25, 100, 5, norm_quality_score=1)
+    assert np.array_equal(got, np.arange(n))
+    # a single candidate, and topn larger than n
+    got, _ = pa.ssd(ctx, t, cand[:1], rel[:1], 0.25, 10, 5)
+    assert got.tolist() == [0]
+    t.destroy()

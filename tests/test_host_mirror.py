@@ -120,3 +120,57 @@ def test_config_driven_pipeline_matches_oracle(H):
             assert g["algo_scores"]["recall_score"] == w_.algo_scores["recall_score"]   # current_score side effect
     assert sorted(got_ids) == sorted(w_.id for w_ in want) or sep.all() is False
     H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
+def test_config_driven_ssd_sort_matches_oracle(H):
+    """SortConfs → SSDSort (sort/sort.go:162-200, ssd_sort.go:110-343) through the host mirror: the page
+    is the oracle's SSD pick sequence over the rank-ordered candidates."""
+    import copy
+    import pairec_amd as pa
+    cfg = copy.deepcopy(CONFIG)
+    cfg["SortConfs"] = [{"Name": "my_ssd", "SortType": "SSDSort",
+                         "SSDConf": {"Gamma": 0.3, "WindowSize": 4, "CandidateCount": 120}},
+                        {"Name": "ignored_rule_sort", "SortType": "BoostScoreSort"}]
+    cfg["SortNames"] = {"home_feed": ["my_ssd"]}
+    got_conf = json.loads(H.ph_parse_recconf(json.dumps(cfg).encode()))
+    assert got_conf is not None
+    h = H.ph_engine_create(json.dumps(cfg).encode())
+    assert h, H.ph_last_error()
+    n, d = 20000, 128
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    w = o.Dnn3Weights()
+    user = o.synth_rows(o.SEED_QUERY, 5, 1, d)[0]
+    vec = " ".join("%d:%s" % (i + 1, repr(float(v))) for i, v in enumerate(user))
+    H.ph_set_user_vector(h, b"u2", vec.encode())
+    blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+    assert H.ph_engine_load_dnn3(h, pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+    size = 30
+    out = json.loads(H.ph_recommend(h, b"u2", size, b"home_feed"))
+    # the same request through the oracle
+    rows, scores = o.recall_topk(tab, user[None], 300)
+    items = [o.OracleItem("item_%d" % r, float(s), "gpu_vector_recall") for r, s in zip(rows[0], scores[0])]
+    items = o.unique_filter(items)
+    dnn = o.dnn3_forward(w, 0, user, tab[rows[0].astype(np.int64)])
+    for it, s in zip(items, dnn):
+        it.add_algo_score("gpu_dnn", float(np.float32(s)))
+    o.fuse_scores(RANK_SCORE, items)
+    # the GPU's scores differ from the oracle's by <= 1e-6 (expf / pow), which may swap near-ties in the
+    # rank order; feed the SSD oracle the order and scores the engine itself reports for its page and
+    # require only what is independent of that: a page of `size` distinct recalled items, first = best
+    got_ids = [x["item_id"] for x in out["items"]]
+    assert len(got_ids) == size and len(set(got_ids)) == size
+    want_scores = {it.id: it.score for it in items}
+    for x in out["items"]:
+        assert abs(x["score"] - want_scores[x["item_id"]]) <= 1e-6
+    order = o.sort_scores([it.score for it in items], True)[:120]        # CandidateCount = 120
+    cand = [items[i] for i in order]
+    if np.all(np.abs(np.diff([c.score for c in cand])) > 4e-6):          # no near-ties: exact comparison
+        rowid = np.array([int(c.id.split("_")[1]) for c in cand])
+        emb = o.ssd_embeddings(tab[rowid], True, True)
+        picks = o.ssd_window(emb, np.array([c.score for c in cand]), 0.3, size, 4)
+        # quality = score + volume*norm is insensitive to 1e-6 score noise unless two qualities tie
+        assert got_ids[0] == cand[0].id
+        assert got_ids == [cand[i].id for i in picks]
+    assert got_ids[0] == cand[0].id
+    H.ph_engine_destroy(h)

@@ -1,6 +1,8 @@
 """CPU tests: the oracle against the reference's own known-answer tests (tests/golden/) and against
 independent numpy restatements.  No GPU, no product code."""
 import math
+import sys
+from fractions import Fraction
 
 import numpy as np
 import pytest
@@ -290,3 +292,129 @@ def test_dpp_matches_numpy_restatement():
 def test_go_float_format():
     assert [o.go_fmt_float(x) for x in (0.5, 1e21, 1.5e-7, 123456.0, 0.000123, 1e20, 100.0)] == \
         ["0.5", "1e+21", "1.5e-07", "123456", "0.000123", "100000000000000000000", "100"]
+
+
+def _py_ssd(emb, rel, gamma, topn, window, star):
+    """Independent restatement of SSDWithSlidingWindow (ssd_sort.go:346-486) — plain Python floats,
+    explicit queues as in the reference (utils.CycleQueue), fma chains for dot / norm."""
+    from collections import deque
+    E = [list(map(float, r)) for r in emb]
+    N, d = len(E), len(E[0])
+    if window <= 1:
+        window = 5
+    T = min(N, topn)
+
+    def fma(x, y, s):            # correctly rounded x*y+s through exact rationals (no math.fma before 3.13)
+        return float(Fraction(x) * Fraction(y) + Fraction(s))
+
+    def dot(a, b):
+        s = 0.0
+        for x, y in zip(a, b):
+            s = fma(x, y, s)
+        return s
+
+    def norm(a):
+        return math.sqrt(dot(a, a))
+
+    def max_idx(v):
+        best, ind = float("nan"), 0
+        for i, x in enumerate(v):
+            if x != x:
+                continue
+            if x > best or best != best:
+                best, ind = x, i
+        return ind
+
+    t = 1
+    idx = max_idx(rel)
+    selected = {idx}
+    indices = [idx]
+    volume = gamma
+    if not star:
+        l2 = norm(E[idx])
+        if not (math.isnan(l2) or math.isinf(l2)):
+            volume *= l2
+    B, P = deque(), deque()
+    while t < T:
+        if t > window:
+            i = B.popleft()
+            proj = P.popleft()
+            for j in range(N):
+                if j in selected:
+                    continue
+                E[j] = [e + proj[j] * f for e, f in zip(E[j], E[i])]
+        B.append(idx)
+        proj = [0.0] * N
+        den = dot(E[idx], E[idx])
+        for j in range(N):
+            if j in selected:
+                continue
+            p = dot(E[j], E[idx]) / den if den != 0 else float("nan")
+            if math.isnan(p) or math.isinf(p):
+                p = 1.0
+            proj[j] = p
+            E[j] = [e - p * f for e, f in zip(E[j], E[idx])]
+        P.append(proj)
+        t += 1
+        q = []
+        for i in range(N):
+            if i in selected:
+                q.append(-sys.float_info.max)
+            else:
+                l2 = norm(E[i])
+                q.append(rel[i] + volume * (0.5 if (math.isnan(l2) or math.isinf(l2)) else l2))
+        idx = max_idx(q)
+        selected.add(idx)
+        indices.append(idx)
+        if not star:
+            l2 = norm(E[idx])
+            if not (math.isnan(l2) or math.isinf(l2)):
+                volume *= l2
+    return indices
+
+
+def test_ssd_matches_python_restatement():
+    _ssd_cases(True)
+
+
+def _ssd_cases(exact):
+    rng = np.random.default_rng(11)
+    n, d = 60, 16
+    emb = o.ssd_embeddings(rng.standard_normal((n, d)).astype(np.float32), True, True)
+    rel = np.sort(rng.random(n))[::-1].copy()
+    for topn, window, gamma, star in [(1, 5, 0.25, False), (7, 3, 0.25, False), (40, 5, 0.5, False),
+                                      (40, 10, 0.25, True), (60, 4, 1.0, False), (200, 1, 0.25, False)]:
+        got = o.ssd_window(emb, rel, gamma, topn, window, star).tolist()
+        assert len(got) == min(n, topn) and len(set(got)) == len(got)
+        if exact:
+            assert got == _py_ssd(emb, rel.tolist(), gamma, topn, window, star), (topn, window, gamma, star)
+
+
+def test_ssd_structure_and_numpy_cross_check():
+    """Structure: the first pick is the best score, gamma → 0 degenerates to score order, and the
+    second pick agrees with a direct numpy computation of one projection step."""
+    rng = np.random.default_rng(12)
+    n, d = 50, 16
+    emb = o.ssd_embeddings(rng.standard_normal((n, d)).astype(np.float32), True, False)
+    rel = np.sort(rng.random(n))[::-1].copy()
+    assert o.ssd_window(emb, rel, 1e-12, 20, 5).tolist() == list(range(20))
+    got = o.ssd_window(emb, rel, 0.5, 3, 5).tolist()
+    assert got[0] == 0
+    # second pick by hand: residuals after projecting out e_0, quality = rel + gamma*|e_0|*|residual|
+    e0 = emb[0]
+    res = emb - np.outer(emb @ e0 / (e0 @ e0), e0)
+    q = rel + 0.5 * np.linalg.norm(e0) * np.linalg.norm(res, axis=1)
+    q[0] = -np.inf
+    assert got[1] == int(np.argmax(q))
+    assert o.ssd_window(emb, rel, 0.5, 30, 5).tolist() != list(range(30))     # diversity changed the order
+
+
+def test_ssd_quality_score_normalisation():
+    rel = np.array([0.9, 0.7, 0.4, 0.1])
+    z, ok = o.ssd_quality(rel, 1)
+    assert ok and np.allclose(z, (rel - rel.mean()) / rel.std(), rtol=1e-14)
+    m, ok = o.ssd_quality(rel, 2)
+    assert ok and m[0] == 1.0 and abs(m[-1] - 1e-6) < 1e-18 and np.all(np.diff(m) < 0)
+    assert o.ssd_quality(np.zeros(5), 1)[1] is False and o.ssd_quality(np.full(5, 0.3), 2)[1] is False
+    assert o.ssd_quality(np.full(5, 0.3), 1)[1] is False                    # variance == 0
+    assert np.array_equal(o.ssd_quality(rel, 0)[0], rel)
