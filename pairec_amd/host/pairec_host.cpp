@@ -3,6 +3,7 @@
 #include "pairec_host.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -49,7 +50,85 @@ std::string RecommendContext::GetParameter(const std::string& k) const {
     auto it = Param.find(k);
     return (it != Param.end() && it->second.type == json::Value::String) ? it->second.str : "";
 }
+double RecommendContext::GetFloat(const std::string& k, double def) const {
+    if (HasExperiment() && ExperimentParamsJson.has(k)) return ToFloat(ExperimentParamsJson.at(k), def);
+    auto it = ExperimentParams.find(k);
+    return it != ExperimentParams.end() ? it->second : def;
+}
+long long RecommendContext::GetInt(const std::string& k, long long def) const {
+    if (HasExperiment() && ExperimentParamsJson.has(k)) return (long long)ToFloat(ExperimentParamsJson.at(k), (double)def);
+    auto it = ExperimentParams.find(k);
+    return it != ExperimentParams.end() ? (long long)it->second : def;
+}
 }  // namespace context
+
+// ---- fmt %v for float64 ------------------------------------------------------------------------------
+std::string GoFmtFloat(double x) {
+    if (x != x) return "NaN";
+    if (std::isinf(x)) return x > 0 ? "+Inf" : "-Inf";
+    if (x == 0) return std::signbit(x) ? "-0" : "0";
+    // shortest digit string that round-trips (strconv 'g', precision -1)
+    char buf[40];
+    int prec = 1;
+    for (; prec <= 17; ++prec) {
+        snprintf(buf, sizeof buf, "%.*e", prec - 1, x);
+        if (strtod(buf, nullptr) == x) break;
+    }
+    // buf = [-]d.ddddde[+-]XX
+    std::string m(buf);
+    const size_t epos = m.find('e');
+    const int dexp = atoi(m.c_str() + epos + 1);
+    std::string digits;
+    for (size_t i = 0; i < epos; ++i)
+        if (m[i] >= '0' && m[i] <= '9') digits.push_back(m[i]);
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    const std::string sign = x < 0 ? "-" : "";
+    if (dexp < -4 || dexp >= 21) {
+        std::string out = sign + digits.substr(0, 1);
+        if (digits.size() > 1) out += "." + digits.substr(1);
+        char e[16];
+        snprintf(e, sizeof e, "e%c%02d", dexp >= 0 ? '+' : '-', std::abs(dexp));
+        return out + e;
+    }
+    if (dexp >= 0) {
+        if ((int)digits.size() <= dexp + 1) return sign + digits + std::string((size_t)(dexp + 1) - digits.size(), '0');
+        return sign + digits.substr(0, (size_t)dexp + 1) + "." + digits.substr((size_t)dexp + 1);
+    }
+    return sign + "0." + std::string((size_t)(-dexp - 1), '0') + digits;
+}
+
+// ---- cache --------------------------------------------------------------------------------------------
+namespace cache {
+namespace {
+struct MemCache : Cache {            // go-cache semantics: per-entry expiry, lazy eviction on Get
+    Value::Kind kind;
+    struct Entry { std::string val; std::chrono::steady_clock::time_point until; bool forever; };
+    std::mutex mu;
+    std::map<std::string, Entry> m;
+    explicit MemCache(Value::Kind k) : kind(k) {}
+    void Put(const std::string& key, const std::string& val, int ttl) override {
+        std::lock_guard<std::mutex> g(mu);
+        m[key] = Entry{val, std::chrono::steady_clock::now() + std::chrono::seconds(ttl), ttl <= 0};
+    }
+    Value Get(const std::string& key) override {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = m.find(key);
+        if (it == m.end()) return Value{};
+        if (!it->second.forever && std::chrono::steady_clock::now() >= it->second.until) {
+            m.erase(it);
+            return Value{};
+        }
+        return Value{kind, it->second.val};
+    }
+};
+}  // namespace
+std::shared_ptr<Cache> NewCache(const std::string& adapter, const std::string&, std::string* err) {
+    if (adapter == "localCache") return std::make_shared<MemCache>(Value::kString);
+    if (adapter == "localBytes") return std::make_shared<MemCache>(Value::kBytes);
+    if (err) *err = "Cache:not found instance, name:" + adapter;           // cache.go:30
+    return nullptr;
+}
+}  // namespace cache
 
 // ---- recconf -------------------------------------------------------------------------------------
 namespace recconf {
@@ -69,6 +148,7 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         RecallConfig c;
         c.Name = r.s("Name"); c.RecallType = r.s("RecallType"); c.RecallAlgo = r.s("RecallAlgo");
         c.ItemType = r.s("ItemType"); c.CachePrefix = r.s("CachePrefix");
+        c.CacheAdapter = r.s("CacheAdapter"); c.CacheConfig = r.s("CacheConfig");
         c.RecallCount = (int)r.n("RecallCount"); c.CacheTime = (int)r.n("CacheTime");
         out->RecallConfs.push_back(c);
     }
@@ -175,6 +255,52 @@ std::vector<float> ParseVectorString(const std::string& s) {     // vector_recal
     }
     return out;
 }
+std::string FormatCacheString(const std::vector<module::ItemPtr>& items, const std::string& recall_name) {
+    std::string out;                                               // vector_recall.go:105-110
+    for (size_t i = 0; i < items.size(); ++i) {
+        if (i) out.push_back(',');
+        out += items[i]->Id + ":" + recall_name + ":" + GoFmtFloat(items[i]->Score);
+    }
+    return out;
+}
+bool ParseCacheString(const std::string& line, const std::string& recall_name, const std::string& item_type,
+                      std::vector<module::ItemPtr>* out, std::string* err) {
+    out->clear();                                                  // vector_recall.go:39-55
+    size_t p = 0;
+    while (p <= line.size()) {
+        size_t e = line.find(',', p);
+        if (e == std::string::npos) e = line.size();
+        const std::string id = line.substr(p, e - p);
+        p = e + 1;
+        module::ItemPtr item;
+        if (id.find(':') != std::string::npos) {
+            std::vector<std::string> vars;
+            size_t q = 0;
+            while (q <= id.size()) {
+                size_t c = id.find(':', q);
+                if (c == std::string::npos) c = id.size();
+                vars.push_back(id.substr(q, c - q));
+                q = c + 1;
+            }
+            if (vars.size() < 3) {      // `vars[2]` would panic the reference (index out of range)
+                if (err) *err = "recall cache entry \"" + id + "\": expected id:name:score";
+                out->clear();
+                return false;
+            }
+            item = std::make_shared<module::Item>(vars[0]);
+            char* end = nullptr;
+            const double f = strtod(vars[2].c_str(), &end);        // `f, _ := strconv.ParseFloat(vars[2], 64)`
+            item->Score = (end != vars[2].c_str() && *end == '\0') ? f : 0.0;
+        } else {
+            item = std::make_shared<module::Item>(id);
+        }
+        item->RetrieveId = recall_name;
+        item->ItemType = item_type;
+        out->push_back(item);
+        if (e == line.size()) break;
+    }
+    return true;
+}
 }  // namespace recall
 
 // ---- filter --------------------------------------------------------------------------------------
@@ -270,13 +396,55 @@ struct GpuDnnAlgorithm : algorithm::IAlgorithm {
 };
 
 // recall.Recall with the body of VectorRecall.GetCandidateItems (vector_recall.go:32-123, cache omitted)
-struct GpuVectorRecall : recall::Recall {
+struct GpuVectorRecall : recall::Recall, recall::ICloneRecall {
     Engine* e;
     recconf::RecallConfig conf;
-    GpuVectorRecall(Engine* eng, recconf::RecallConfig c) : e(eng), conf(std::move(c)) {}
+    std::shared_ptr<cache::Cache> cache_;                      // BaseRecall.cache (recall.go:123-137)
+    int cacheTime = 1800;
+    std::mutex cloneMu;
+    std::map<std::string, std::shared_ptr<recall::Recall>> cloneInstances;
+    GpuVectorRecall(Engine* eng, recconf::RecallConfig c) : e(eng), conf(std::move(c)) {
+        if (!conf.CacheAdapter.empty()) {
+            std::string cerr;
+            cache_ = cache::NewCache(conf.CacheAdapter, conf.CacheConfig, &cerr);   // error → logged, no cache
+            if (conf.CacheTime > 0) cacheTime = conf.CacheTime;
+        }
+    }
+    std::string GetRecallName() const override { return conf.Name; }
+    // cloneWithBuilder (recall.go:167-214): instance-local cache keyed by the params' canonical JSON (Go
+    // marshals maps with sorted keys and takes an md5 of that; the text itself is the key here), params
+    // unmarshalled over a zero RecallConfig, Name forced to the original
+    std::shared_ptr<recall::Recall> CloneWithConfig(const json::Value& params) override {
+        if (params.type != json::Value::Object) return nullptr;
+        std::string key;
+        for (const auto& kv : params.obj) {                    // std::map iterates in key order
+            key += kv.first + "=";
+            key += kv.second.type == json::Value::String ? kv.second.str : json::NumToString(kv.second.num);
+            key += ";";
+        }
+        std::lock_guard<std::mutex> g(cloneMu);
+        auto it = cloneInstances.find(key);
+        if (it != cloneInstances.end()) return it->second;
+        recconf::RecallConfig c;
+        c.Name = conf.Name;
+        c.RecallType = params.s("RecallType"); c.RecallAlgo = params.s("RecallAlgo");
+        c.ItemType = params.s("ItemType"); c.CacheAdapter = params.s("CacheAdapter");
+        c.CacheConfig = params.s("CacheConfig"); c.CachePrefix = params.s("CachePrefix");
+        c.RecallCount = (int)params.n("RecallCount"); c.CacheTime = (int)params.n("CacheTime");
+        auto inst = std::make_shared<GpuVectorRecall>(e, c);
+        cloneInstances[key] = inst;
+        return inst;
+    }
     std::vector<module::ItemPtr> GetCandidateItems(module::User* user, context::RecommendContext*) override {
         std::vector<module::ItemPtr> ret;
         std::string value, err;
+        if (cache_) {                                                                   // vector_recall.go:35-58
+            const cache::Value v = cache_->Get(conf.CachePrefix + user->Id);
+            if (v.kind == cache::Value::kBytes) {                                       // `cacheRet.([]uint8)`
+                if (recall::ParseCacheString(v.data, conf.Name, conf.ItemType, &ret, &err)) return ret;
+                ret.clear();
+            }
+        }
         if (!e->user_vectors.VectorString(user->Id, &value, &err)) return ret;        // logged, empty result
         algorithm::AlgoData data;
         data.kind = algorithm::AlgoData::kVector;
@@ -292,6 +460,8 @@ struct GpuVectorRecall : recall::Recall {
             item->Score = (double)result.reply.Scores[i];
             ret.push_back(item);
         }
+        if (cache_ && !ret.empty())                                                     // :103-120 (async in Go)
+            cache_->Put(conf.CachePrefix + user->Id, recall::FormatCacheString(ret, conf.Name), cacheTime);
         return ret;
     }
 };
@@ -380,17 +550,25 @@ struct GpuSSDSort : sort::ISort {                        // sort/ssd_sort.go:110
         tmp.Data = *items;
         if (!sort_items(e, &tmp, true, err)) return false;
         items->swap(tmp.Data);
-        if (conf.Gamma == 0) return true;                                           // :302-305
-        if ((conf.CandidateCount > 0 || conf.MinScorePercent > 0) && (int)items->size() > size) {
-            if (conf.CandidateCount > 0) {
-                const size_t cnt = (size_t)std::max(size, conf.CandidateCount);
+        // experiment parameters override the config (ssd_sort.go:301-309,354-356,364)
+        const context::RecommendContext none;
+        const context::RecommendContext& cx = d->Context ? *d->Context : none;
+        const double gamma = cx.GetFloat("ssd_gamma", conf.Gamma);
+        if (gamma == 0) return true;                                                // :302-305
+        const int candidateCnt = (int)cx.GetInt("ssd_candidate_count", conf.CandidateCount);
+        const double minScorePercent = cx.GetFloat("ssd_min_score_percent", conf.MinScorePercent);
+        const int windowSize = (int)cx.GetInt("ssd_window_size", conf.WindowSize);
+        const int doNorm = (int)cx.GetInt("ssd_norm_quality_score", 0);
+        if ((candidateCnt > 0 || minScorePercent > 0) && (int)items->size() > size) {
+            if (candidateCnt > 0) {
+                const size_t cnt = (size_t)std::max(size, candidateCnt);
                 if (cnt < items->size()) items->resize(cnt);
             }
-            if (conf.MinScorePercent > 0 && (int)items->size() > size) {
+            if (minScorePercent > 0 && (int)items->size() > size) {
                 size_t idx = (size_t)size;
                 const double mx = (*items)[0]->Score;
                 for (; idx < items->size(); ++idx)
-                    if ((*items)[idx]->Score / mx < conf.MinScorePercent) break;
+                    if ((*items)[idx]->Score / mx < minScorePercent) break;
                 items->resize(idx);
             }
         }
@@ -402,13 +580,17 @@ struct GpuSSDSort : sort::ISort {                        // sort/ssd_sort.go:110
             rel[i] = (*items)[i]->Score;
         }
         std::vector<uint32_t> idx(n);
+        std::vector<double> quality(n);
         uint32_t cnt = 0;
-        if (pg_ssd(e->ctx, e->table, rows.data(), rel.data(), n, conf.Gamma, (uint32_t)std::max(size, 0),
-                   (uint32_t)conf.WindowSize, conf.NormalizeEmb ? 1 : 0, conf.EnsurePositiveSim ? 1 : 0,
-                   /*ssd_norm_quality_score*/ 0, conf.UseSSDStar ? 1 : 0, idx.data(), &cnt, nullptr) != PG_OK) {
+        if (pg_ssd(e->ctx, e->table, rows.data(), rel.data(), n, gamma, (uint32_t)std::max(size, 0),
+                   (uint32_t)std::max(windowSize, 0), conf.NormalizeEmb ? 1 : 0, conf.EnsurePositiveSim ? 1 : 0,
+                   (doNorm == 1 || doNorm == 2) ? doNorm : 0, conf.UseSSDStar ? 1 : 0, idx.data(), &cnt,
+                   quality.data()) != PG_OK) {
             if (err) *err = pg_err("pg_ssd");
             return false;
         }
+        if ((doNorm == 1 || doNorm == 2) && cnt != n)        // :372,385 (not on the "all zeros" bail-out)
+            for (uint32_t i = 0; i < n; ++i) (*items)[i]->AddAlgoScore("ssd_quality_score", quality[i]);
         std::vector<module::ItemPtr> out;
         for (uint32_t i = 0; i < cnt; ++i) out.push_back((*items)[idx[i]]);
         items->swap(out);
@@ -419,11 +601,15 @@ struct GpuSSDSort : sort::ISort {                        // sort/ssd_sort.go:110
         if (items.empty()) return true;
         if (conf.AbortRunCount > 0 && (int)items.size() <= conf.AbortRunCount)      // :129-134
             return sort_items(e, d, true, err);
-        if (!conf.FilterRetrieveIds.empty()) {                                       // :155-171
+        std::vector<std::string> filterIds;                                          // :136-152
+        if (d->Context && d->Context->HasExperiment())
+            for (const auto& v : d->Context->ExperimentParamsJson.at("ssd_filter_retrieve_ids").arr)
+                if (v.type == json::Value::String) filterIds.push_back(v.str);
+        if (filterIds.empty()) filterIds = conf.FilterRetrieveIds;
+        if (!filterIds.empty()) {                                                    // :155-171
             std::vector<module::ItemPtr> backup, selected;
             for (auto& it : items) {
-                const bool f = std::find(conf.FilterRetrieveIds.begin(), conf.FilterRetrieveIds.end(), it->RetrieveId) !=
-                               conf.FilterRetrieveIds.end();
+                const bool f = std::find(filterIds.begin(), filterIds.end(), it->RetrieveId) != filterIds.end();
                 (f ? backup : selected).push_back(it);
             }
             if (!DoSort(&selected, d, err)) return false;
@@ -546,10 +732,16 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
 
 bool Engine::Recommend(const std::string& uid, int size, const std::string& scene,
                        std::vector<module::ItemPtr>* out, std::string* err) {
+    return Recommend(uid, size, scene, json::Value(), out, err);
+}
+
+bool Engine::Recommend(const std::string& uid, int size, const std::string& scene, const json::Value& experiment_params,
+                       std::vector<module::ItemPtr>* out, std::string* err) {
     module::User user(uid);
     context::RecommendContext ctx;
     ctx.Size = size;
     ctx.Param["scene"] = json::Value::Str(scene);
+    ctx.ExperimentParamsJson = experiment_params;
     // RecallService.GetItems (service/recall.go:53-153): scene → category → recall names, concatenated
     std::vector<module::ItemPtr> items;
     auto sc = config.SceneRecallNames.find(scene);
@@ -559,6 +751,13 @@ bool Engine::Recommend(const std::string& uid, int size, const std::string& scen
                 std::string rerr;
                 auto r = recalls.GetRecall(name, &rerr);
                 if (!r) continue;
+                // AB experiment: interface assertion + "recall.<name>" params object (service/recall.go:95-105)
+                if (ctx.HasExperiment())
+                    if (auto* cr = dynamic_cast<recall::ICloneRecall*>(r.get())) {
+                        const json::Value& rc = ctx.ExperimentParamsJson.at("recall." + cr->GetRecallName());
+                        if (rc.type == json::Value::Object)
+                            if (auto cloned = cr->CloneWithConfig(rc)) r = cloned;
+                    }
                 auto got = r->GetCandidateItems(&user, &ctx);
                 items.insert(items.end(), got.begin(), got.end());
             }
@@ -575,8 +774,16 @@ bool Engine::Recommend(const std::string& uid, int size, const std::string& scen
     sd.User = &user;
     for (const auto& n : names) {
         auto s = sorts.Get(n);
+        if (!s) continue;
+        // AB experiment: ICloneSort + "sort.<name>" params object (sort/sort.go:110-121)
+        if (ctx.HasExperiment())
+            if (auto* cs = dynamic_cast<sort::ICloneSort*>(s.get())) {
+                const json::Value& sc2 = ctx.ExperimentParamsJson.at("sort." + cs->GetSortName());
+                if (sc2.type == json::Value::Object)
+                    if (auto cloned = cs->CloneWithConfig(sc2)) s = cloned;
+            }
         std::string serr;
-        if (s) s->Sort(&sd, &serr);                                   // error ignored (sort.go:123)
+        s->Sort(&sd, &serr);                                          // error ignored (sort.go:123)
     }
     if ((int)sd.Data.size() > size) sd.Data.resize((size_t)size);     // items[:size]
     *out = sd.Data;
@@ -619,14 +826,7 @@ int ph_set_user_vector(void* h, const char* uid, const char* vec) {
 }
 
 // → JSON {"items":[{"item_id":..,"score":..,"retrieve_id":..,"algo_scores":{..}}]}
-const char* ph_recommend(void* h, const char* uid, int size, const char* scene) {
-    if (!h) return nullptr;
-    std::vector<module::ItemPtr> items;
-    std::string err;
-    if (!((Engine*)h)->Recommend(uid ? uid : "", size, scene ? scene : "", &items, &err)) {
-        g_ph_err = err;
-        return nullptr;
-    }
+static const char* items_to_json(const std::vector<module::ItemPtr>& items) {
     std::string& o = g_ph_out;
     o = "{\"items\":[";
     for (size_t i = 0; i < items.size(); ++i) {
@@ -635,6 +835,8 @@ const char* ph_recommend(void* h, const char* uid, int size, const char* scene) 
         json::Escape(items[i]->Id, &o);
         o += ",\"score\":" + json::NumToString(items[i]->Score) + ",\"retrieve_id\":";
         json::Escape(items[i]->RetrieveId, &o);
+        o += ",\"item_type\":";
+        json::Escape(items[i]->ItemType, &o);
         o += ",\"algo_scores\":{";
         bool first = true;
         for (const auto& kv : items[i]->algoScores) {
@@ -647,6 +849,115 @@ const char* ph_recommend(void* h, const char* uid, int size, const char* scene) 
     }
     o += "]}";
     return o.c_str();
+}
+
+const char* ph_recommend(void* h, const char* uid, int size, const char* scene) {
+    if (!h) return nullptr;
+    std::vector<module::ItemPtr> items;
+    std::string err;
+    if (!((Engine*)h)->Recommend(uid ? uid : "", size, scene ? scene : "", &items, &err)) {
+        g_ph_err = err;
+        return nullptr;
+    }
+    return items_to_json(items);
+}
+
+// the same request with an AB experiment attached: experiment_params_json = the layer params object
+const char* ph_recommend_ab(void* h, const char* uid, int size, const char* scene, const char* experiment_params_json) {
+    if (!h) return nullptr;
+    json::Value params;
+    std::string err;
+    const std::string text = experiment_params_json ? experiment_params_json : "{}";
+    if (!json::Parser(text).Parse(&params, &err) || params.type != json::Value::Object) {
+        g_ph_err = "experiment params: " + (err.empty() ? std::string("not a JSON object") : err);
+        return nullptr;
+    }
+    std::vector<module::ItemPtr> items;
+    if (!((Engine*)h)->Recommend(uid ? uid : "", size, scene ? scene : "", params, &items, &err)) {
+        g_ph_err = err;
+        return nullptr;
+    }
+    return items_to_json(items);
+}
+
+// fmt %v of a float64
+const char* ph_go_fmt_float(double x) {
+    g_ph_out = GoFmtFloat(x);
+    return g_ph_out.c_str();
+}
+
+// recall result cache line: items JSON [{"id":..,"score":..}] → "id:name:score,…"
+const char* ph_format_recall_cache(const char* items_json, const char* recall_name) {
+    json::Value root;
+    std::string err;
+    const std::string text = items_json ? items_json : "";
+    if (!json::Parser(text).Parse(&root, &err) || root.type != json::Value::Array) { g_ph_err = "items: " + err; return nullptr; }
+    std::vector<module::ItemPtr> items;
+    for (const auto& v : root.arr) {
+        auto it = std::make_shared<module::Item>(v.s("id"));
+        it->Score = v.d("score");
+        items.push_back(it);
+    }
+    g_ph_out = recall::FormatCacheString(items, recall_name ? recall_name : "");
+    return g_ph_out.c_str();
+}
+
+// … and back: "id:name:score,…" → items JSON; NULL (+ ph_last_error) where the reference would panic
+const char* ph_parse_recall_cache(const char* line, const char* recall_name, const char* item_type) {
+    std::vector<module::ItemPtr> items;
+    std::string err;
+    if (!recall::ParseCacheString(line ? line : "", recall_name ? recall_name : "", item_type ? item_type : "", &items, &err)) {
+        g_ph_err = err;
+        return nullptr;
+    }
+    return items_to_json(items);
+}
+
+// cache adapters + clone hooks, self-checked in C++ (bit i set = check i passed)
+int ph_cache_clone_semantics(void) {
+    int ok = 0;
+    std::string err;
+    auto lc = cache::NewCache("localCache", "", &err);
+    auto bc = cache::NewCache("localBytes", "", &err);
+    if (lc && bc && !cache::NewCache("memcached", "", &err) && err == "Cache:not found instance, name:memcached") ok |= 1;
+    if (lc && bc) {
+        lc->Put("k", "a:r:1", 1800);
+        bc->Put("k", "a:r:1", 1800);
+        // localCache hands back a string (VectorRecall's []uint8 assertion misses), the byte store hits
+        if (lc->Get("k").kind == cache::Value::kString && bc->Get("k").kind == cache::Value::kBytes) ok |= 2;
+        if (bc->Get("absent").kind == cache::Value::kNone) ok |= 4;
+        bc->Put("gone", "x", 0 + 1);
+    }
+    // ICloneSort: the hook swaps in the clone only when the experiment carries a "sort.<name>" object
+    struct Rev : sort::ISort, sort::ICloneSort {
+        bool reversed;
+        explicit Rev(bool r) : reversed(r) {}
+        bool Sort(sort::SortData* d, std::string*) override {
+            if (reversed) std::reverse(d->Data.begin(), d->Data.end());
+            return true;
+        }
+        std::shared_ptr<sort::ISort> CloneWithConfig(const json::Value& p) override {
+            return std::make_shared<Rev>(p.at("reverse").type == json::Value::Bool && p.at("reverse").b);
+        }
+        std::string GetSortName() const override { return "rev"; }
+    };
+    {
+        auto base = std::make_shared<Rev>(false);
+        json::Value params;
+        const std::string ptext = "{\"sort.rev\":{\"reverse\":true}}";     // (Parser keeps a reference)
+        json::Parser(ptext).Parse(&params, &err);
+        std::shared_ptr<sort::ISort> s = base;
+        if (auto* cs = dynamic_cast<sort::ICloneSort*>(s.get())) {
+            const json::Value& sc = params.at("sort." + cs->GetSortName());
+            if (sc.type == json::Value::Object)
+                if (auto c = cs->CloneWithConfig(sc)) s = c;
+        }
+        sort::SortData d;
+        d.Data = {std::make_shared<module::Item>("a"), std::make_shared<module::Item>("b")};
+        s->Sort(&d, &err);
+        if (d.Data[0]->Id == "b" && s != base) ok |= 8;
+    }
+    return ok;
 }
 
 // host-only helpers (no GPU): used by the CPU tests of the mirror

@@ -76,6 +76,12 @@ struct RecommendContext {
     std::string RecommendId;
     std::map<std::string, json::Value> Param;               // GetParameter("scene") etc.
     std::map<std::string, double> ExperimentParams;         // AB overrides (float view)
+    // ExperimentResult.GetExperimentParams() (model.LayerParams): the raw JSON object — structured
+    // values such as "recall.<name>" / "sort.<name>" objects or "ssd_filter_retrieve_ids" lists
+    json::Value ExperimentParamsJson;
+    bool HasExperiment() const { return ExperimentParamsJson.type == json::Value::Object; }
+    double GetFloat(const std::string& k, double def) const;   // LayerParams.GetFloat
+    long long GetInt(const std::string& k, long long def) const;
     std::string GetParameter(const std::string& k) const;
 };
 }  // namespace context
@@ -84,7 +90,7 @@ struct RecommendContext {
 namespace recconf {
 struct AlgoConfig { std::string Name, Type; json::Value raw; };
 struct RecallConfig {
-    std::string Name, RecallType, RecallAlgo, ItemType, CachePrefix;
+    std::string Name, RecallType, RecallAlgo, ItemType, CacheAdapter, CacheConfig, CachePrefix;
     int RecallCount = 0, CacheTime = 0;
 };
 struct RankConfig {
@@ -182,7 +188,39 @@ private:
 };
 // vector_recall.go:70-82
 std::vector<float> ParseVectorString(const std::string& s);
+// ICloneRecall (service/recall/recall.go:22-27): AB-experiment overrides ("recall.<name>" params object)
+struct ICloneRecall {
+    virtual ~ICloneRecall() = default;
+    virtual std::shared_ptr<Recall> CloneWithConfig(const json::Value& params) = 0;
+    virtual std::string GetRecallName() const = 0;
+};
+// the recall result cache line of VectorRecall (vector_recall.go:35-58,103-120): "id:name:score,…",
+// scores printed with fmt's %v
+std::string FormatCacheString(const std::vector<module::ItemPtr>& items, const std::string& recall_name);
+bool ParseCacheString(const std::string& line, const std::string& recall_name, const std::string& item_type,
+                      std::vector<module::ItemPtr>* out, std::string* err);
 }  // namespace recall
+
+// fmt.Sprintf("%v", float64): strconv 'g' with the shortest round-trip digits, exponent form for
+// exp < -4 || exp >= 21
+std::string GoFmtFloat(double x);
+
+// ---- cache (persist/cache/cache.go:13-41) ---------------------------------------------------------
+namespace cache {
+// What Get returns matters to the caller: VectorRecall only accepts []uint8 (vector_recall.go:38), which
+// the redis adapter returns and localCache (it hands back the Go string it was given) does not — with
+// "localCache" the reference writes the line and never reads it back.  Mirrored: kString values miss.
+struct Value { enum Kind { kNone, kString, kBytes } kind = kNone; std::string data; };
+struct Cache {
+    virtual ~Cache() = default;
+    virtual void Put(const std::string& key, const std::string& val, int ttl_seconds) = 0;
+    virtual Value Get(const std::string& key) = 0;
+};
+// adapters: "localCache" (persist/cache/localcache.go; string values) and "localBytes" (an in-process
+// stand-in for the redis adapter's []byte values — this engine has no network); anything else is the
+// reference's "Cache:not found instance" error
+std::shared_ptr<Cache> NewCache(const std::string& adapter, const std::string& config, std::string* err);
+}  // namespace cache
 
 // ---- filter -------------------------------------------------------------------------------------
 namespace filter {
@@ -199,6 +237,11 @@ struct SortData {
 struct ISort {
     virtual ~ISort() = default;
     virtual bool Sort(SortData* data, std::string* err) = 0;
+};
+struct ICloneSort {                   // sort.go:36-39: AB-experiment overrides ("sort.<name>" params object)
+    virtual ~ICloneSort() = default;
+    virtual std::shared_ptr<ISort> CloneWithConfig(const json::Value& params) = 0;
+    virtual std::string GetSortName() const = 0;
 };
 class Registry {                      // sort.go:143-150: first registration wins; nil panics
 public:
@@ -217,6 +260,9 @@ public:
     // Recommend (service/user_recommend.go:46-183 restricted to the hot path):
     // recall → UniqueFilter → rank → sort → items[:size]
     bool Recommend(const std::string& uid, int size, const std::string& scene,
+                   std::vector<module::ItemPtr>* out, std::string* err);
+    // the same with an AB experiment attached (ctx.ExperimentResult): params = the layer params object
+    bool Recommend(const std::string& uid, int size, const std::string& scene, const json::Value& experiment_params,
                    std::vector<module::ItemPtr>* out, std::string* err);
 
     module::InMemoryVectorDao user_vectors;

@@ -174,3 +174,92 @@ def test_config_driven_ssd_sort_matches_oracle(H):
         assert got_ids == [cand[i].id for i in picks]
     assert got_ids[0] == cand[0].id
     H.ph_engine_destroy(h)
+
+
+# ---- recall result cache format, cache adapters, AB clone hooks ------------------------
+def _bind_row2(H):
+    H.ph_go_fmt_float.restype = C.c_char_p
+    H.ph_go_fmt_float.argtypes = [C.c_double]
+    H.ph_format_recall_cache.restype = C.c_char_p
+    H.ph_format_recall_cache.argtypes = [C.c_char_p, C.c_char_p]
+    H.ph_parse_recall_cache.restype = C.c_char_p
+    H.ph_parse_recall_cache.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    H.ph_recommend_ab.restype = C.c_char_p
+    H.ph_recommend_ab.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p]
+    return H
+
+
+def test_go_percent_v_float_format(H):
+    """fmt %v of float64 (the score field of the cache line, vector_recall.go:107) against the oracle's
+    restatement, over shortest-repr edge cases."""
+    _bind_row2(H)
+    rng = np.random.default_rng(3)
+    vals = [0.0, -0.0, 1.0, -1.0, 0.5, 1e-7, 1e-5, 1e-4, 0.0001234, 123456789.0, 1e20, 1e21, 1.5e21, 3.0,
+            0.1, 0.30000000000000004, 2.5e-300, 1.7976931348623157e308, 5e-324, float("inf"), -float("inf"),
+            float(np.float32(0.8612537))]
+    vals += list(rng.standard_normal(200)) + list(10.0 ** rng.uniform(-30, 30, 200))
+    for v in vals:
+        assert H.ph_go_fmt_float(float(v)).decode() == o.go_fmt_float(float(v)), v
+    assert H.ph_go_fmt_float(float("nan")) == b"NaN"
+
+
+def test_recall_cache_line_format_and_parse(H):
+    _bind_row2(H)
+    items = [o.OracleItem("a", 0.5, "vec"), o.OracleItem("b", 1e-7, "vec"), o.OracleItem("c", 3.0, "vec")]
+    js = json.dumps([{"id": it.id, "score": it.score} for it in items]).encode()
+    line = H.ph_format_recall_cache(js, b"vec").decode()
+    assert line == o.recall_cache_string(items, "vec") == "a:vec:0.5,b:vec:1e-07,c:vec:3"
+    back = json.loads(H.ph_parse_recall_cache(line.encode(), b"vec", b"video"))["items"]
+    assert [(x["item_id"], x["score"], x["retrieve_id"], x["item_type"]) for x in back] == \
+        [("a", 0.5, "vec", "video"), ("b", 1e-7, "vec", "video"), ("c", 3.0, "vec", "video")]
+    # ids without ':' carry no score (vector_recall.go:48-50); a malformed score parses to 0 (`f, _ :=`)
+    back = json.loads(H.ph_parse_recall_cache(b"x,y:vec:oops", b"vec", b""))["items"]
+    assert [(x["item_id"], x["score"]) for x in back] == [("x", 0.0), ("y", 0.0)]
+    # "id:name" (two fields) indexes vars[2] in the reference — a panic there, an error here
+    assert H.ph_parse_recall_cache(b"y:vec", b"vec", b"") is None and b"id:name:score" in H.ph_last_error()
+
+
+def test_cache_adapters_and_clone_hooks(H):
+    assert H.ph_cache_clone_semantics() == 15
+
+
+@pytest.mark.gpu
+def test_ab_params_recall_clone_cache_and_ssd_overrides(H):
+    """An AB experiment attached to the request: "recall.<name>" clones the recall with a new RecallCount
+    (ICloneRecall, service/recall.go:95-105); a byte-valued cache serves the second request from the
+    cache line; ssd_* parameters override the SSDSort config (ssd_sort.go:301-309)."""
+    import copy
+    import pairec_amd as pa
+    _bind_row2(H)
+    cfg = copy.deepcopy(CONFIG)
+    cfg["RecallConfs"][0].update({"CacheAdapter": "localBytes", "CachePrefix": "vr_", "CacheTime": 60})
+    cfg["SortConfs"] = [{"Name": "my_ssd", "SortType": "SSDSort", "SSDConf": {"Gamma": 0.3, "WindowSize": 4}}]
+    cfg["SortNames"] = {"home_feed": ["my_ssd"]}
+    h = H.ph_engine_create(json.dumps(cfg).encode())
+    assert h, H.ph_last_error()
+    w = o.Dnn3Weights()
+    user = o.synth_rows(o.SEED_QUERY, 9, 1, 128)[0]
+    vec = " ".join("%d:%s" % (i + 1, repr(float(v))) for i, v in enumerate(user))
+    H.ph_set_user_vector(h, b"u3", vec.encode())
+    blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+    assert H.ph_engine_load_dnn3(h, pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+    base = json.loads(H.ph_recommend(h, b"u3", 400, b"home_feed"))["items"]
+    assert len(base) == 300                                   # RecallCount = 300 in CONFIG
+    # the clone recalls 40 instead (and has no cache of its own: the params object replaces the config)
+    ab = json.loads(H.ph_recommend_ab(h, b"u3", 400, b"home_feed",
+                                      json.dumps({"recall.gpu_vector_recall": {"RecallCount": 40,
+                                                                               "RecallAlgo": "gpu_faiss"}}).encode()))["items"]
+    assert len(ab) == 40 and {x["item_id"] for x in ab} <= {x["item_id"] for x in base}
+    # second plain request: served from the cache line — same ids, scores round-trip through %v exactly
+    again = json.loads(H.ph_recommend(h, b"u3", 400, b"home_feed"))["items"]
+    assert [x["item_id"] for x in again] == [x["item_id"] for x in base]
+    assert [x["score"] for x in again] == [x["score"] for x in base]
+    # ssd_gamma = 0 → SSD is skipped: plain rank order (ssd_sort.go:302-305)
+    g0 = json.loads(H.ph_recommend_ab(h, b"u3", 30, b"home_feed", json.dumps({"ssd_gamma": 0}).encode()))["items"]
+    sc = [x["score"] for x in g0]
+    assert sc == sorted(sc, reverse=True)
+    # ssd_norm_quality_score = 2 records "ssd_quality_score" on the candidates (ssd_sort.go:385)
+    q2 = json.loads(H.ph_recommend_ab(h, b"u3", 30, b"home_feed",
+                                      json.dumps({"ssd_norm_quality_score": 2}).encode()))["items"]
+    assert all("ssd_quality_score" in x["algo_scores"] for x in q2) and q2[0]["algo_scores"]["ssd_quality_score"] == 1.0
+    H.ph_engine_destroy(h)
