@@ -1,0 +1,89 @@
+// bitonic_reg.hpp — workgroup bitonic sort of up to 8192 keys with 8 elements per thread in registers.
+//   partner inside the thread (j < 8)            → register compare-exchange, no memory traffic
+//   partner in the same wave (8 <= j < 512)      → ds_bpermute exchange, no barrier
+//   partner in another wave (j >= 512)           → LDS exchange ([u][thread] layout: conflict-free)
+// 10 of the 91 sub-stages of an 8192-element sort touch LDS.  Ascending by (key, index); callers that
+// want descending order complement their keys.  Position i = 8*t + u lives in thread t, slot u.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace pg {
+
+constexpr int kBitonicE = 8;
+constexpr uint32_t kBitonicMax = 8192;
+
+struct BitonicLds {
+    uint64_t xk[kBitonicE][1024];
+    uint32_t xi[kBitonicE][1024];
+};
+
+// P: power of two, 512 <= P <= 8192; threads t < P/8 are active (whole waves), every thread of the
+// 1024-thread workgroup must call (barriers).  WITH_IDX = false ignores ix (keys are unique).
+template <bool WITH_IDX>
+__device__ __forceinline__ void bitonic_sort_reg(uint64_t (&k)[kBitonicE], uint32_t (&ix)[kBitonicE], uint32_t P,
+                                                 BitonicLds& lds) {
+    const uint32_t t = threadIdx.x;
+    const bool act = t < P / kBitonicE;
+    auto lt = [](uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
+        return WITH_IDX ? (ka < kb || (ka == kb && ia < ib)) : (ka < kb);
+    };
+    for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+        // ---- partners in other threads (j >= 8, so kk >= 16): direction is per thread
+        const bool dir = (t & (kk / kBitonicE)) == 0;     // this thread's sub-sequence ascends
+        for (uint32_t j = kk >> 1; j >= (uint32_t)kBitonicE; j >>= 1) {
+            const uint32_t m = j / kBitonicE;             // partner thread = t ^ m
+            const bool keep_min = ((t & m) == 0) == dir;
+            if (m >= 64) {
+                if (act) {
+#pragma unroll
+                    for (int u = 0; u < kBitonicE; ++u) {
+                        lds.xk[u][t] = k[u];
+                        if (WITH_IDX) lds.xi[u][t] = ix[u];
+                    }
+                }
+                __syncthreads();
+                if (act) {
+#pragma unroll
+                    for (int u = 0; u < kBitonicE; ++u) {
+                        const uint64_t ok = lds.xk[u][t ^ m];
+                        const uint32_t oi = WITH_IDX ? lds.xi[u][t ^ m] : 0u;
+                        const bool mine_first = lt(k[u], ix[u], ok, oi);
+                        if (mine_first != keep_min) { k[u] = ok; ix[u] = oi; }
+                    }
+                }
+                __syncthreads();
+            } else if (act) {
+#pragma unroll
+                for (int u = 0; u < kBitonicE; ++u) {
+                    const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)k[u], (int)m, 64);
+                    const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(k[u] >> 32), (int)m, 64);
+                    const uint32_t oi = WITH_IDX ? (uint32_t)__shfl_xor((int)ix[u], (int)m, 64) : 0u;
+                    const uint64_t ok = ((uint64_t)ohi << 32) | olo;
+                    const bool mine_first = lt(k[u], ix[u], ok, oi);
+                    if (mine_first != keep_min) { k[u] = ok; ix[u] = oi; }
+                }
+            }
+        }
+        // ---- partners inside the thread (j = min(kk/2, 4) .. 1)
+        if (act) {
+#pragma unroll
+            for (int jj = kBitonicE / 2; jj >= 1; jj >>= 1) {
+                if ((uint32_t)jj >= kk) continue;
+#pragma unroll
+                for (int u = 0; u < kBitonicE; ++u) {
+                    if (u & jj) continue;
+                    const int l = u | jj;
+                    const bool up = ((t * kBitonicE + (uint32_t)u) & kk) == 0;      // ascending sub-sequence
+                    const bool first = lt(k[u], ix[u], k[l], ix[l]);
+                    if (first != up) {
+                        const uint64_t tk = k[u]; k[u] = k[l]; k[l] = tk;
+                        const uint32_t ti = ix[u]; ix[u] = ix[l]; ix[l] = ti;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pg

@@ -22,6 +22,7 @@
 //                    so the result is exact for every data distribution).
 //   final_kernel     per query: bitonic sort of the K survivors in LDS, decode to (row, score).
 #include "common.hpp"
+#include "bitonic_reg.hpp"
 
 namespace pg {
 
@@ -964,6 +965,46 @@ __global__ __launch_bounds__(1024) void final_kernel(const uint64_t* __restrict_
     if (tid == 0 && out_count) out_count[q] = n;
 }
 
+// final for K <= 8192: the register-resident bitonic network (bitonic_reg.hpp) on complemented keys
+__global__ __launch_bounds__(1024) void final_kernel_reg(const uint64_t* __restrict__ cand,
+                                                         const uint32_t* __restrict__ cnt, uint32_t cap,
+                                                         uint32_t K, uint64_t row_offset,
+                                                         uint64_t* __restrict__ out_rows,
+                                                         float* __restrict__ out_scores,
+                                                         uint32_t* __restrict__ out_count) {
+    __shared__ BitonicLds lds;
+    const uint32_t q = blockIdx.x, t = threadIdx.x;
+    uint32_t n = cnt[q];
+    if (n > K) n = K;
+    uint32_t P = 512;
+    while (P < K) P <<= 1;
+    const uint64_t* in = cand + (uint64_t)q * cap;
+    uint64_t k[kBitonicE];
+    uint32_t ix[kBitonicE];
+#pragma unroll
+    for (int u = 0; u < kBitonicE; ++u) {
+        const uint32_t i = t * kBitonicE + u;
+        k[u] = (i < n) ? ~in[i] : ~0ull;               // descending = ascending on the complement; pad last
+        ix[u] = 0;
+    }
+    bitonic_sort_reg<false>(k, ix, P, lds);
+#pragma unroll
+    for (int u = 0; u < kBitonicE; ++u) {
+        const uint32_t i = t * kBitonicE + u;
+        if (i < K) {
+            const uint64_t key = ~k[u];
+            if (i < n) {
+                out_rows[(uint64_t)q * K + i] = row_offset + key_row(key);
+                out_scores[(uint64_t)q * K + i] = key_score(key);
+            } else {
+                out_rows[(uint64_t)q * K + i] = ~0ull;
+                out_scores[(uint64_t)q * K + i] = -__builtin_inff();
+            }
+        }
+    }
+    if (t == 0 && out_count) out_count[q] = n;
+}
+
 __global__ void recall_init_kernel(const float* __restrict__ queries, uint32_t nq, uint32_t dim,
                                    float* __restrict__ qpad, float* __restrict__ thr,
                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow) {
@@ -1096,6 +1137,12 @@ static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* 
 static int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap,
                         uint32_t nq, uint32_t k, uint64_t row_offset, uint64_t* d_out_rows,
                         float* d_out_scores, uint32_t* d_out_count) {
+    if (k <= kBitonicMax) {
+        final_kernel_reg<<<nq, 1024, 0, ctx->stream>>>(cand, cnt, cap, k, row_offset, d_out_rows, d_out_scores,
+                                                       d_out_count);
+        PG_HIP(hipGetLastError());
+        return PG_OK;
+    }
     const uint32_t P = next_pow2(k < 2 ? 2 : k);
     const size_t lds = (size_t)P * 8;
     static size_t attr = 0;

@@ -7,6 +7,7 @@
 // One workgroup per request; bitonic network over (ordered-u64 key, u32 index) pairs held in LDS
 // for segments up to 8192 items, in a global scratch slab beyond that.
 #include "common.hpp"
+#include "bitonic_reg.hpp"
 
 namespace pg {
 
@@ -78,6 +79,45 @@ __global__ __launch_bounds__(1024) void sort_kernel(const double* __restrict__ s
     for (uint32_t i = tid; i < n; i += 1024) out_order[b + i] = idx[i];
 }
 
+// Segments of up to 8192 items: the register-resident bitonic network of bitonic_reg.hpp (10 of the 91
+// sub-stages of an 8192-element sort touch LDS; the plain LDS network above: all 91, with a barrier each).
+// Descending order is the ascending network on complemented keys; ties by index either way.
+__global__ __launch_bounds__(1024) void sort_kernel_reg(const double* __restrict__ scores,
+                                                        const uint32_t* __restrict__ seg_offsets, int desc,
+                                                        uint32_t* __restrict__ out_order) {
+    __shared__ BitonicLds lds;
+    const uint32_t seg = blockIdx.x, t = threadIdx.x;
+    const uint32_t b = seg_offsets[seg], e = seg_offsets[seg + 1];
+    const uint32_t n = e - b;
+    if (n == 0) return;
+    uint32_t P = 512;                                  // at least one full wave of 8-element threads
+    while (P < n) P <<= 1;
+    const bool act = t < P / kBitonicE;
+    uint64_t k[kBitonicE];
+    uint32_t ix[kBitonicE];
+#pragma unroll
+    for (int u = 0; u < kBitonicE; ++u) {
+        const uint32_t i = t * kBitonicE + u;
+        if (act && i < n) {
+            const double sc = scores[b + i];
+            const uint64_t key = (sc != sc) ? (desc ? 0ull : ~0ull) : f64_ordered_bits(sc);   // NaN sorts last
+            k[u] = desc ? ~key : key;
+            ix[u] = i;
+        } else {
+            k[u] = ~0ull;                               // padding sorts last
+            ix[u] = 0xFFFFFFFFu;
+        }
+    }
+    bitonic_sort_reg<true>(k, ix, P, lds);
+    if (act) {
+#pragma unroll
+        for (int u = 0; u < kBitonicE; ++u) {
+            const uint32_t i = t * kBitonicE + u;
+            if (i < n) out_order[b + i] = ix[u];
+        }
+    }
+}
+
 static int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg,
                            uint32_t n_items, uint32_t max_seg, int desc, uint32_t* d_out) {
     if (n_seg == 0 || n_items == 0) return PG_OK;
@@ -99,7 +139,10 @@ static int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* 
         g_keys = (uint64_t*)p;
         g_idx = (uint32_t*)(g_keys + (size_t)n_seg * stride);
     }
-    sort_kernel<<<n_seg, 1024, lds, ctx->stream>>>(d_scores, d_seg, desc, g_keys, g_idx, stride, d_out);
+    if (max_seg <= kSortLdsMax && !getenv("PG_SORT_LDS"))
+        sort_kernel_reg<<<n_seg, 1024, 0, ctx->stream>>>(d_scores, d_seg, desc, d_out);
+    else
+        sort_kernel<<<n_seg, 1024, lds, ctx->stream>>>(d_scores, d_seg, desc, g_keys, g_idx, stride, d_out);
     PG_HIP(hipGetLastError());
     ctx->stats.sort_calls++;
     ctx->stats.sort_items += n_items;
