@@ -1410,8 +1410,31 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
         n_ev = 0;
         PG_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         if (plan == kPilot) {
-            // measured: growth 8 on the sample (its K' is small, so chunks stage little)
-            if ((rc = grow_scan(sample_blocks, stride, k_pilot, getenv("PG_PILOT_GROWTH") ? atof(getenv("PG_PILOT_GROWTH")) : 8.0, false))) return rc;
+            // The sample itself is streamed in two launches when it is screened: a seed of `seed_rows` rows
+            // (exact, every row a candidate) whose m0-th best score becomes the threshold of ONE screened
+            // launch over the rest of the sample; m0 is chosen so that fewer than K' sample rows reaching
+            // that threshold has probability < 1e-9 (Poisson tail of seed hits among the sample's top K');
+            // should it happen anyway, select_kernel leaves the threshold at -inf, the full pass overflows
+            // and the next plan takes over.  (Measured against geometric chunks over the sample: 1.0 → 0.7 ms.)
+            const uint32_t seed_rows = 8192;
+            const uint64_t sample_rows = (uint64_t)sample_blocks * kPieceRows;
+            if (screen && !getenv("PG_PILOT_GROWTH") && sample_rows > 8ull * seed_rows && k_pilot < seed_rows / 4) {
+                const double mu = (double)seed_rows * (double)k_pilot / (double)sample_rows;
+                uint32_t m0 = 1;
+                for (double term = exp(-mu) , cdf = term; 1.0 - cdf > 1e-9 && m0 < seed_rows; ++m0) {
+                    term *= mu / (double)m0;          // P(X = m0)
+                    cdf += term;                      // P(X <= m0)  →  loop ends with P(X >= m0+1) <= 1e-9
+                }
+                ++m0;
+                const uint32_t sb = seed_rows / kPieceRows;
+                if ((rc = scan_range(0, sb, stride, true))) return rc;
+                if ((rc = refresh(m0))) return rc;
+                if ((rc = scan_range(sb, sample_blocks - sb, stride, false))) return rc;
+                if ((rc = refresh(k_pilot))) return rc;
+            } else {
+                // geometric chunks over the sample (exact scan, or PG_PILOT_GROWTH set: A/B runs)
+                if ((rc = grow_scan(sample_blocks, stride, k_pilot, getenv("PG_PILOT_GROWTH") ? atof(getenv("PG_PILOT_GROWTH")) : 8.0, false))) return rc;
+            }
             PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
             if ((rc = scan_range(0, nblocks, 1, false))) return rc;
             if ((rc = refresh(k))) return rc;
