@@ -265,7 +265,8 @@ def main():
                      "measured_peak": measured_gbs, "frac_of_measured": achieved / measured_gbs,
                      "bytes_per_pass": shard_bytes, "ms_per_pass": scan_avg_ms,
                      "note": "algorithmic bytes = shard rows x dim x 4 per table pass (one pass serves %d requests); "
-                             "duration = sum of the pass's scan launches, HIP events on the launch stream" % R},
+                             "duration = sum of the pass's scan-stage launches (exact seed of the pilot sample, screened sample launch, "
+                             "screened full pass, exact re-scoring), HIP events on the launch stream" % R},
         "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},
         "rank_roofline": {"bound": "mfma", "kernel": "pg::mlp_kernel<bf16,512,256>",
                           "achieved": (R * K / (world if shard else 1)) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
