@@ -195,6 +195,36 @@ int pg_ssd(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const doub
            int norm_quality_score, int use_ssd_star, uint32_t* out_idx, uint32_t* out_count,
            double* out_quality);
 
+/* ---- item features: typed columns in HBM, assembled by row ----------------------------------
+ * Replaces the per-request host boxing of EasyrecAlgoDataGenerator.AddFeatures / GeneratorAlgoData
+ * (service/rank/algo_data.go:223-306): one column per feature name (the "context features" of
+ * easyrec_predict.proto:150-212), an item that lacks a feature reads the column default
+ * (feature.defaultValue, algo_data.go:154-171 — the Go zero value of the column's type).  Columns are
+ * keyed by item row; a row index >= rows (UINT32_MAX by convention) means "item without the feature".
+ * String features are dictionary-encoded to integer ids by the caller. */
+typedef struct pg_features pg_features;
+typedef enum { PG_F_I32 = 1, PG_F_I64 = 2, PG_F_F32 = 3, PG_F_F64 = 4 } pg_feature_dtype;
+int pg_features_create(pg_ctx* ctx, uint64_t rows, pg_features** out);
+int pg_features_destroy(pg_ctx* ctx, pg_features* fs);
+/* add or replace column `name`; host_values: [rows] of the dtype, or NULL (every row = default) */
+int pg_features_set_column(pg_ctx* ctx, pg_features* fs, const char* name, int dtype,
+                           const void* host_values, double default_value);
+int pg_features_column_index(const pg_features* fs, const char* name);   /* -1 if absent */
+int pg_features_num_columns(const pg_features* fs);
+/* d_out[i][f] = integer column col_idx[f] at d_rows[i] as int32 (int64 saturates) — e.g. the FM field ids */
+int pg_features_gather_i32_dev(pg_ctx* ctx, const pg_features* fs, const int32_t* col_idx, uint32_t n_cols,
+                               const uint32_t* d_rows, uint32_t n, int32_t* d_out);
+/* d_out[i][f] = fmaf((float)value, scale[f], bias[f]) (host arrays [n_cols]; NULL = 1 / 0): dense float
+ * inputs with the simplest normalizer fused; richer ones go through pg_expr_* */
+int pg_features_gather_f32_dev(pg_ctx* ctx, const pg_features* fs, const int32_t* col_idx, uint32_t n_cols,
+                               const float* scale, const float* bias, const uint32_t* d_rows, uint32_t n,
+                               float* d_out);
+/* FM + two-tower rank straight from candidate rows: the model's item field ids are the integer columns
+ * item_field_cols[n_item_fields] of `fs` (out-of-vocabulary ids are clamped as in pg_rank_fm2t_dev) */
+int pg_rank_fm2t_rows_dev(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
+                          const float* d_user_vecs, const int32_t* d_user_field_ids, const uint32_t* d_cand_rows,
+                          const uint32_t* d_req_offsets, uint32_t n_req, uint32_t n_items, float* d_out_scores);
+
 /* ---- stats ----------------------------------------------------------------------------------*/
 typedef struct {
     uint64_t recall_calls, recall_rows_scanned, recall_rescans;

@@ -672,3 +672,72 @@ def go_fmt_float(x: float) -> str:
             return sign + digits + "0" * (dexp + 1 - len(digits))
         return sign + digits[:dexp + 1] + "." + digits[dexp + 1:]
     return sign + "0." + "0" * (-dexp - 1) + digits
+
+
+# ---------------------------------------------------------------------------------------------
+# EasyrecAlgoDataGenerator  (service/rank/algo_data.go:154-306): per-request feature boxing
+# ---------------------------------------------------------------------------------------------
+def _go_zero_like(v):
+    """feature.defaultValue (algo_data.go:154-171): the Go zero value of the first value's type."""
+    if isinstance(v, bool):
+        return ""                      # reflect.Bool falls to the default branch: ""
+    if isinstance(v, int):
+        return 0
+    if isinstance(v, float):
+        return 0.0
+    return ""
+
+
+class EasyrecGenerator:
+    """Restatement of EasyrecAlgoDataGenerator: AddFeatures keeps one list per feature name and fills an
+    item that lacks the feature with the column's zero value; GeneratorAlgoData emits and resets them."""
+
+    def __init__(self, context_features):
+        self.items = []
+        self.context = {}
+        self.parse_feature = True                      # :187 — the schema is the configured list
+        self.item_features = [(n, "") for n in context_features]       # typed string → default ""
+        self.user = {}
+        self.input_features = []
+        self.input_map = None
+        self.parse_input = False
+
+    def set_item_features(self, names):                # :204-221
+        if names:
+            self.input_map = {}
+            if names[0] != "*":
+                self.parse_input = True
+                self.input_features = [(n, "") for n in names]
+        else:
+            self.parse_input = True
+
+    def add_features(self, item_id, item_features, user_features):     # :223-271
+        self.items.append(item_id)
+        if not self.parse_feature:
+            self.item_features = [(k, _go_zero_like(v)) for k, v in item_features.items()]
+            self.user = user_features
+            self.parse_feature = True
+        if not self.parse_input:
+            ctx_names = [n for n, _ in self.item_features]
+            for k, v in item_features.items():
+                if k not in ctx_names:
+                    self.input_features.append((k, _go_zero_like(v)))
+            self.parse_input = True
+        if not self.user:
+            self.user = user_features
+        for n, d in self.item_features:
+            self.context.setdefault(n, []).append(item_features.get(n, d))
+        if self.input_map is not None:
+            for n, d in self.input_features:
+                self.input_map.setdefault(n, []).append(item_features.get(n, d))
+
+    def generate(self):                                # :273-302
+        out = {"user_features": dict(self.user), "item_ids": list(self.items),
+               "context_features": {k: list(v) for k, v in self.context.items()},
+               "item_features": {k: list(v) for k, v in (self.input_map or {}).items()}}
+        for v in self.context.values():
+            del v[:]
+        for v in (self.input_map or {}).values():
+            del v[:]
+        self.items = []
+        return out

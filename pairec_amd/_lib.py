@@ -21,7 +21,9 @@ EXPORTS = [
     "pg_rank_fm2t", "pg_rank_fm2t_dev", "pg_expr_compile", "pg_expr_free", "pg_expr_num_vars",
     "pg_expr_var_name", "pg_expr_eval", "pg_expr_eval_dev", "pg_sort_scores", "pg_sort_scores_dev",
     "pg_dpp", "pg_stats", "pg_last_scan_kernel_ms", "pg_rows_to_local_dev", "pg_widen_f32_dev",
-    "pg_hbm_read_probe", "pg_ssd",
+    "pg_hbm_read_probe", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
+    "pg_features_column_index", "pg_features_num_columns", "pg_features_gather_i32_dev",
+    "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev",
 ]
 
 
@@ -84,6 +86,14 @@ def load():
         "pg_sort_scores_dev": [vp, vp, vp, u32, u32, u32, i32, vp],
         "pg_dpp": [vp, vp, vp, vp, u32, C.c_double, u32, u32, i32, vp, vp],
         "pg_ssd": [vp, vp, vp, vp, u32, C.c_double, u32, u32, i32, i32, i32, i32, vp, vp, vp],
+        "pg_features_create": [vp, u64, P(vp)],
+        "pg_features_destroy": [vp, vp],
+        "pg_features_set_column": [vp, vp, C.c_char_p, i32, vp, C.c_double],
+        "pg_features_column_index": [vp, C.c_char_p],
+        "pg_features_num_columns": [vp],
+        "pg_features_gather_i32_dev": [vp, vp, vp, u32, vp, u32, vp],
+        "pg_features_gather_f32_dev": [vp, vp, vp, u32, vp, vp, vp, u32, vp],
+        "pg_rank_fm2t_rows_dev": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp],
         "pg_rows_to_local_dev": [vp, vp, vp, u32, vp, vp],
         "pg_widen_f32_dev": [vp, vp, u32, vp],
         "pg_stats": [vp, P(PgStats)],

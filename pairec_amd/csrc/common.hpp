@@ -79,4 +79,7 @@ struct pg_ctx {
 
 namespace pg {
 int scratch_reserve(pg_ctx* ctx, int slot, size_t bytes, void** out);
+// features.hip: gather of integer feature columns, caller holds ctx->mu
+int features_gather_i32_locked(pg_ctx* ctx, const pg_features* fs, const int32_t* col_idx, uint32_t n_cols,
+                               const uint32_t* d_rows, uint32_t n, int32_t* d_out, const char* who);
 }

@@ -997,6 +997,27 @@ int pg_rank_fm2t_dev(pg_ctx* ctx, const pg_model* m, const float* d_user_vecs,
                                     n_req, n_items, d_out_scores);
 }
 
+int pg_rank_fm2t_rows_dev(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
+                          const float* d_user_vecs, const int32_t* d_user_field_ids, const uint32_t* d_cand_rows,
+                          const uint32_t* d_req_offsets, uint32_t n_req, uint32_t n_items, float* d_out_scores) {
+    PG_REQUIRE(ctx && m && fs && item_field_cols && d_user_vecs && d_user_field_ids && d_cand_rows && d_req_offsets &&
+                   d_out_scores,
+               "pg_rank_fm2t_rows_dev: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER, "pg_rank_fm2t_rows_dev: model is not FM_TWOTOWER");
+    PG_REQUIRE(n_req <= 65535, "pg_rank_fm2t_rows_dev: at most 65535 requests per call");
+    if (n_items == 0 || n_req == 0) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    // the per-item field ids are assembled on the device from the feature columns (no host boxing)
+    void* ids;
+    int rc;
+    if ((rc = pg::scratch_reserve(ctx, 0, (size_t)n_items * m->nif * 4, &ids))) return rc;
+    if ((rc = pg::features_gather_i32_locked(ctx, fs, item_field_cols, m->nif, d_cand_rows, n_items, (int32_t*)ids,
+                                             "pg_rank_fm2t_rows_dev")))
+        return rc;
+    return pg::rank_fm2t_dev_locked(ctx, m, d_user_vecs, d_user_field_ids, (const int32_t*)ids, d_req_offsets, n_req,
+                                    n_items, d_out_scores);
+}
+
 int pg_rank_fm2t(pg_ctx* ctx, const pg_model* m, const float* user_vecs, const int32_t* user_field_ids,
                  const int32_t* item_field_ids, const uint32_t* req_offsets, uint32_t n_req,
                  float* out_scores) {

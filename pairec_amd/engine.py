@@ -219,6 +219,27 @@ class RankModel:
         return out
 
 
+    def rank_fm2t_rows(self, feats: "Features", item_field_names, user_vecs, user_field_ids, cand_rows,
+                       req_offsets) -> np.ndarray:
+        """FM + two-tower rank from candidate rows: the item field ids come from feature columns."""
+        ctx = self.ctx
+        u = np.ascontiguousarray(user_vecs, dtype=np.float32)
+        uf = np.ascontiguousarray(user_field_ids, dtype=np.int32)
+        cr = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+        ro = np.ascontiguousarray(req_offsets, dtype=np.uint32)
+        cols = feats._cols(item_field_names)
+        n = int(ro[-1])
+        d_u, d_uf, d_cr, d_ro = ctx.to_device(u), ctx.to_device(uf), ctx.to_device(cr), ctx.to_device(ro)
+        d_o = ctx.malloc(max(n * 4, 16))
+        _lib.check(ctx.L.pg_rank_fm2t_rows_dev(ctx.h, self.h, feats.h, _ptr(cols), d_u, d_uf, d_cr, d_ro,
+                                               ro.shape[0] - 1, n, d_o))
+        out = np.zeros(n, dtype=np.float32)
+        ctx.d2h(out, d_o)
+        for p in (d_u, d_uf, d_cr, d_ro, d_o):
+            ctx.free(p)
+        return out
+
+
 class Expr:
     """Compiled RankConfig.RankScore expression (utils/ast replacement)."""
 
@@ -270,3 +291,67 @@ def ssd(ctx: Context, table: Table, cand_rows, rel, gamma: float, topn: int, win
                             int(normalize_emb), int(ensure_pos_similarity), int(norm_quality_score),
                             int(use_ssd_star), _ptr(out), C.byref(cnt), _ptr(qual)))
     return out[:cnt.value], qual[:c.shape[0]]
+
+
+F_I32, F_I64, F_F32, F_F64 = 1, 2, 3, 4
+_F_NP = {F_I32: np.int32, F_I64: np.int64, F_F32: np.float32, F_F64: np.float64}
+
+
+class Features:
+    """Typed item-feature columns in HBM (pg_features_*): the device form of the reference's per-request
+    "context features" (service/rank/algo_data.go:223-306)."""
+
+    def __init__(self, ctx: Context, rows: int):
+        self.ctx, self.rows = ctx, rows
+        h = C.c_void_p()
+        _lib.check(ctx.L.pg_features_create(ctx.h, rows, C.byref(h)))
+        self.h = h
+
+    def destroy(self):
+        if self.h:
+            _lib.check(self.ctx.L.pg_features_destroy(self.ctx.h, self.h))
+            self.h = None
+
+    def set_column(self, name: str, dtype: int, values: Optional[np.ndarray] = None, default: float = 0.0):
+        v = None
+        if values is not None:
+            v = np.ascontiguousarray(values, dtype=_F_NP[dtype])
+            assert v.shape == (self.rows,)
+        _lib.check(self.ctx.L.pg_features_set_column(self.ctx.h, self.h, name.encode(), dtype,
+                                                     _ptr(v) if v is not None else None, float(default)))
+
+    def index(self, name: str) -> int:
+        return int(self.ctx.L.pg_features_column_index(self.h, name.encode()))
+
+    def _cols(self, names) -> np.ndarray:
+        idx = np.asarray([self.index(n) if isinstance(n, str) else int(n) for n in names], dtype=np.int32)
+        return idx
+
+    def gather_i32(self, names, rows: np.ndarray) -> np.ndarray:
+        idx = self._cols(names)
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        d_r = self.ctx.to_device(r)
+        d_o = self.ctx.malloc(max(r.shape[0] * idx.shape[0] * 4, 16))
+        _lib.check(self.ctx.L.pg_features_gather_i32_dev(self.ctx.h, self.h, _ptr(idx), idx.shape[0], d_r,
+                                                         r.shape[0], d_o))
+        out = np.zeros((r.shape[0], idx.shape[0]), dtype=np.int32)
+        self.ctx.d2h(out, d_o)
+        self.ctx.free(d_r)
+        self.ctx.free(d_o)
+        return out
+
+    def gather_f32(self, names, rows: np.ndarray, scale=None, bias=None) -> np.ndarray:
+        idx = self._cols(names)
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+        bi = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        d_r = self.ctx.to_device(r)
+        d_o = self.ctx.malloc(max(r.shape[0] * idx.shape[0] * 4, 16))
+        _lib.check(self.ctx.L.pg_features_gather_f32_dev(self.ctx.h, self.h, _ptr(idx), idx.shape[0],
+                                                         _ptr(sc) if sc is not None else None,
+                                                         _ptr(bi) if bi is not None else None, d_r, r.shape[0], d_o))
+        out = np.zeros((r.shape[0], idx.shape[0]), dtype=np.float32)
+        self.ctx.d2h(out, d_o)
+        self.ctx.free(d_r)
+        self.ctx.free(d_o)
+        return out

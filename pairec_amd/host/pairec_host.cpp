@@ -790,6 +790,112 @@ bool Engine::Recommend(const std::string& uid, int size, const std::string& scen
     return true;
 }
 
+// ---- EasyrecAlgoDataGenerator ------------------------------------------------------------------------
+namespace rank {
+static void value_json(const json::Value& v, std::string* o) {
+    switch (v.type) {
+        case json::Value::String: json::Escape(v.str, o); break;
+        case json::Value::Number: *o += v.is_int ? std::to_string(v.i) : json::NumToString(v.num); break;
+        case json::Value::Bool: *o += v.b ? "true" : "false"; break;
+        default: *o += "null";
+    }
+}
+json::Value EasyrecAlgoDataGenerator::Feature::Default() const {       // feature.defaultValue, :154-171
+    json::Value v;
+    if (type == json::Value::Number) {
+        v.type = json::Value::Number;
+        v.is_int = is_int;
+        v.num = 0.0;
+        v.i = 0;
+    } else {
+        v.type = json::Value::String;                                  // string and everything else: ""
+    }
+    return v;
+}
+EasyrecAlgoDataGenerator::EasyrecAlgoDataGenerator(const std::vector<std::string>& contextFeatures) {
+    // parseFeature starts true (:187): the schema is the configured list, every column typed string
+    for (const auto& n : contextFeatures) itemFeatures_.push_back(Feature{n, json::Value::String, false});
+}
+void EasyrecAlgoDataGenerator::SetItemFeatures(const std::vector<std::string>& in) {
+    if (!in.empty()) {
+        hasInputMap_ = true;
+        if (in[0] != "*") {
+            parseInputItemFeature_ = true;
+            for (const auto& n : in) inputItemFeatures_.push_back(Feature{n, json::Value::String, false});
+        }
+    } else {
+        parseInputItemFeature_ = true;
+    }
+}
+void EasyrecAlgoDataGenerator::AddFeatures(const module::ItemPtr& item,
+                                           const std::map<std::string, json::Value>& itemFeatures,
+                                           const std::map<std::string, json::Value>& userFeatures) {
+    if (item) requestItem_.push_back(item);
+    if (!parseFeature_) {                       // (never taken after the constructor above; kept for fidelity)
+        for (const auto& kv : itemFeatures) itemFeatures_.push_back(Feature{kv.first, kv.second.type, kv.second.is_int});
+        userFeatures_ = userFeatures;
+        parseFeature_ = true;
+    }
+    if (!parseInputItemFeature_) {              // "*": every feature of the first item that is not a context feature
+        for (const auto& kv : itemFeatures) {
+            bool ctxf = false;
+            for (const auto& f : itemFeatures_) ctxf |= f.name == kv.first;
+            if (!ctxf) inputItemFeatures_.push_back(Feature{kv.first, kv.second.type, kv.second.is_int});
+        }
+        parseInputItemFeature_ = true;
+    }
+    if (userFeatures_.empty()) userFeatures_ = userFeatures;
+    for (const auto& f : itemFeatures_) {
+        auto it = itemFeatures.find(f.name);
+        contextFeatures_[f.name].push_back(it != itemFeatures.end() ? it->second : f.Default());
+    }
+    if (hasInputMap_)
+        for (const auto& f : inputItemFeatures_) {
+            auto it = itemFeatures.find(f.name);
+            inputItemFeatureMap_[f.name].push_back(it != itemFeatures.end() ? it->second : f.Default());
+        }
+}
+std::string EasyrecAlgoDataGenerator::GeneratorAlgoData() {
+    std::string o = "{\"user_features\":{";
+    bool first = true;
+    for (const auto& kv : userFeatures_) {
+        if (!first) o += ",";
+        first = false;
+        json::Escape(kv.first, &o);
+        o += ":";
+        value_json(kv.second, &o);
+    }
+    o += "},\"item_ids\":[";
+    for (size_t i = 0; i < requestItem_.size(); ++i) {
+        if (i) o += ",";
+        json::Escape(requestItem_[i]->Id, &o);
+    }
+    o += "]";
+    auto lists = [&](const char* key, std::map<std::string, std::vector<json::Value>>& m) {
+        o += std::string(",\"") + key + "\":{";
+        bool f2 = true;
+        for (auto& kv : m) {
+            if (!f2) o += ",";
+            f2 = false;
+            json::Escape(kv.first, &o);
+            o += ":[";
+            for (size_t i = 0; i < kv.second.size(); ++i) {
+                if (i) o += ",";
+                value_json(kv.second[i], &o);
+            }
+            o += "]";
+            kv.second.clear();                   // g.contextFeatures[k] = g.contextFeatures[k][:0]
+        }
+        o += "}";
+    };
+    lists("context_features", contextFeatures_);
+    lists("item_features", inputItemFeatureMap_);
+    o += "}";
+    requestItem_.clear();
+    return o;
+}
+}  // namespace rank
+
 }  // namespace pairec
 
 // ---- C driver API for the tests ---------------------------------------------------------------------
@@ -911,6 +1017,39 @@ const char* ph_parse_recall_cache(const char* line, const char* recall_name, con
         return nullptr;
     }
     return items_to_json(items);
+}
+
+// EasyrecAlgoDataGenerator driver: {"context_features":[names],"item_features":[names]|null,
+// "user":{..},"items":[{"id":..,"features":{..}}], "batches": [n1, n2, ...]} → [request JSON per batch]
+const char* ph_easyrec_generator(const char* spec_json) {
+    json::Value root;
+    std::string err;
+    const std::string text = spec_json ? spec_json : "";
+    if (!json::Parser(text).Parse(&root, &err)) { g_ph_err = err; return nullptr; }
+    std::vector<std::string> ctxf, inf;
+    for (const auto& v : root.at("context_features").arr) ctxf.push_back(v.str);
+    rank::EasyrecAlgoDataGenerator g(ctxf);
+    if (root.at("item_features").type == json::Value::Array) {
+        for (const auto& v : root.at("item_features").arr) inf.push_back(v.str);
+        g.SetItemFeatures(inf);
+    }
+    std::map<std::string, json::Value> user(root.at("user").obj.begin(), root.at("user").obj.end());
+    std::string& o = g_ph_out;
+    o = "[";
+    size_t pos = 0;
+    bool first = true;
+    for (const auto& b : root.at("batches").arr) {
+        for (long long k = 0; k < (long long)b.num && pos < root.at("items").arr.size(); ++k, ++pos) {
+            const json::Value& it = root.at("items").arr[pos];
+            std::map<std::string, json::Value> feats(it.at("features").obj.begin(), it.at("features").obj.end());
+            g.AddFeatures(std::make_shared<module::Item>(it.s("id")), feats, user);
+        }
+        if (!first) o += ",";
+        first = false;
+        o += g.GeneratorAlgoData();
+    }
+    o += "]";
+    return o.c_str();
 }
 
 // cache adapters + clone hooks, self-checked in C++ (bit i set = check i passed)

@@ -282,6 +282,28 @@ public:
 };
 
 namespace rank {
+// EasyrecAlgoDataGenerator (service/rank/algo_data.go:172-306): the per-request host boxing that the device
+// feature store (pg_features_*) replaces — kept here as the statement of its default-filling semantics.
+// Values are JSON scalars; the "reflect type" of a value is int (integral number), float64 or string.
+class EasyrecAlgoDataGenerator {
+public:
+    explicit EasyrecAlgoDataGenerator(const std::vector<std::string>& contextFeatures);   // :183-201
+    void SetItemFeatures(const std::vector<std::string>& inputItemFeatures);              // :204-221
+    void AddFeatures(const module::ItemPtr& item, const std::map<std::string, json::Value>& itemFeatures,
+                     const std::map<std::string, json::Value>& userFeatures);             // :223-271
+    // GeneratorAlgoData (:273-302): {"user_features":{..},"item_ids":[..],"context_features":{name:[..]},
+    // "item_features":{name:[..]}} and the per-request lists are reset
+    std::string GeneratorAlgoData();
+    bool HasFeatures() const { return !requestItem_.empty(); }
+private:
+    struct Feature { std::string name; json::Value::Type type; bool is_int; json::Value Default() const; };
+    std::vector<module::ItemPtr> requestItem_;
+    std::map<std::string, std::vector<json::Value>> contextFeatures_, inputItemFeatureMap_;
+    bool parseFeature_ = true, parseInputItemFeature_ = false, hasInputMap_ = false;
+    std::vector<Feature> itemFeatures_, inputItemFeatures_;
+    std::map<std::string, json::Value> userFeatures_;
+};
+
 // RankService.Rank (rank_service.go:102-372): batches of BatchCount, one algorithm.Run per batch
 // and algo, scores written back with AddAlgoScore, Item.Score = RankScore expression.
 bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, context::RecommendContext* ctx,

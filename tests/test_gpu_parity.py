@@ -432,3 +432,75 @@ def test_ssd_matches_oracle(ctx):
     got, _ = pa.ssd(ctx, t, cand[:1], rel[:1], 0.25, 10, 5)
     assert got.tolist() == [0]
     t.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# typed feature columns on the device
+# ---------------------------------------------------------------------------------------------
+def test_feature_columns_gather_and_defaults(ctx):
+    """pg_features_*: typed columns keyed by item row; an item without the feature (row past the store)
+    reads the column default — the device form of feature.defaultValue (algo_data.go:154-171).  Integer
+    gathers are exact; the float path is fmaf(value, scale, bias) in fp32."""
+    rng = np.random.default_rng(21)
+    n = 5000
+    fs = pa.Features(ctx, n)
+    cat = rng.integers(0, 1000, n).astype(np.int32)
+    big = rng.integers(-2**40, 2**40, n).astype(np.int64)
+    price = rng.random(n).astype(np.float32) * 100
+    ctr = rng.random(n)
+    fs.set_column("cat", pa.F_I32, cat, default=0)
+    fs.set_column("big", pa.F_I64, big, default=-7)
+    fs.set_column("price", pa.F_F32, price, default=0.0)
+    fs.set_column("ctr", pa.F_F64, ctr, default=0.5)
+    fs.set_column("empty", pa.F_I32, None, default=3)              # declared, no values yet
+    assert fs.index("price") == 2 and fs.index("nope") == -1
+    rows = np.concatenate([rng.integers(0, n, 300), [0xFFFFFFFF, n, n - 1, 0]]).astype(np.uint32)
+    inside = rows < n
+    gi = fs.gather_i32(["cat", "big", "empty"], rows)
+    want_cat = np.where(inside, cat[np.minimum(rows, n - 1)], 0)
+    want_big = np.clip(np.where(inside, big[np.minimum(rows, n - 1)], -7), -2**31, 2**31 - 1)
+    assert np.array_equal(gi[:, 0], want_cat) and np.array_equal(gi[:, 1], want_big) and np.all(gi[:, 2] == 3)
+    scale = np.array([0.01, 2.0, 1.0], np.float32)
+    bias = np.array([0.0, -1.0, 0.25], np.float32)
+    gf = fs.gather_f32(["price", "ctr", "cat"], rows, scale, bias)
+    cols = [np.where(inside, price[np.minimum(rows, n - 1)], np.float32(0.0)).astype(np.float32),
+            np.where(inside, ctr[np.minimum(rows, n - 1)], 0.5).astype(np.float32),
+            want_cat.astype(np.float32)]
+    for f in range(3):
+        want = (cols[f].astype(np.float64) * float(scale[f]) + float(bias[f])).astype(np.float32)   # fmaf in fp32
+        assert np.array_equal(gf[:, f], want), f
+    assert np.array_equal(fs.gather_f32(["price"], rows)[:, 0], cols[0])                       # no normalizer
+    # replacing a column with another dtype keeps its index
+    fs.set_column("cat", pa.F_I64, cat.astype(np.int64), default=0)
+    assert fs.index("cat") == 0 and np.array_equal(fs.gather_i32(["cat"], rows)[:, 0], want_cat)
+    with pytest.raises(RuntimeError):
+        fs.gather_i32(["price"], rows)                              # not an integer column
+    fs.destroy()
+
+
+def test_rank_fm2t_from_candidate_rows(ctx):
+    """pg_rank_fm2t_rows_dev: the item field ids are assembled on the device from 8 integer feature
+    columns; scores are bit-identical to handing the same ids over pre-resolved."""
+    fw = o.Fm2tWeights(vocab=3000)
+    m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, pa.PREC_F32, pa.pack_fm2t(fw))
+    rng = np.random.default_rng(5)
+    n_items_tab = 20000
+    fs = pa.Features(ctx, n_items_tab)
+    fields = rng.integers(0, 3000, (n_items_tab, 8)).astype(np.int32)
+    names = ["item_field_%d" % f for f in range(8)]
+    for f in range(8):
+        fs.set_column(names[f], pa.F_I32 if f % 2 == 0 else pa.F_I64, fields[:, f], default=0)
+    sizes = [3000, 129, 1]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    users = o.synth_rows(o.SEED_QUERY, 9, 3, 128)
+    ufids = rng.integers(0, 3000, (3, 8)).astype(np.int32)
+    cand = rng.integers(0, n_items_tab, int(off[-1])).astype(np.uint32)
+    cand[7] = 0xFFFFFFFF                                            # an item without features: defaults (id 0)
+    ifids = np.where((cand < n_items_tab)[:, None], fields[np.minimum(cand, n_items_tab - 1)], 0).astype(np.int32)
+    got = m.rank_fm2t_rows(fs, names, users, ufids, cand, off)
+    ref = m.rank_fm2t(users, ufids, ifids, off)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    want = np.concatenate([o.fm2t_forward(fw, 0, users[r], ufids[r], ifids[off[r]:off[r + 1]]) for r in range(3)])
+    assert np.max(np.abs(got.astype(np.float64) - want)) <= 3e-7
+    fs.destroy()
+    m.destroy()

@@ -263,3 +263,43 @@ def test_ab_params_recall_clone_cache_and_ssd_overrides(H):
                                       json.dumps({"ssd_norm_quality_score": 2}).encode()))["items"]
     assert all("ssd_quality_score" in x["algo_scores"] for x in q2) and q2[0]["algo_scores"]["ssd_quality_score"] == 1.0
     H.ph_engine_destroy(h)
+
+
+# ---- the host boxing the device feature store replaces ---------------------------------
+def test_easyrec_generator_default_filling(H):
+    """EasyrecAlgoDataGenerator.AddFeatures / GeneratorAlgoData (algo_data.go:172-306) in the C++ mirror
+    against the oracle's restatement: configured context features default to "", "*" item features take
+    the first item's keys and Go zero values, lists reset per batch."""
+    H.ph_easyrec_generator.restype = C.c_char_p
+    H.ph_easyrec_generator.argtypes = [C.c_char_p]
+    items = [{"id": "i1", "features": {"cat": "a", "price": 3.5, "cnt": 7, "extra": "x"}},
+             {"id": "i2", "features": {"cat": "b", "cnt": 2}},
+             {"id": "i3", "features": {"price": 1.25, "late": 9}},
+             {"id": "i4", "features": {}}]
+    user = {"age": 30, "city": "hz"}
+    for ctxf, itemf in ((["cat", "missing"], None), (["cat"], ["*"]), (["cat"], ["price", "nope"]), ([], ["*"]),
+                        (["cat", "price"], [])):
+        spec = {"context_features": ctxf, "item_features": itemf, "user": user, "items": items, "batches": [3, 1]}
+        got = json.loads(H.ph_easyrec_generator(json.dumps(spec).encode()))
+        g = o.EasyrecGenerator(ctxf)
+        if itemf is not None:
+            g.set_item_features(itemf)
+        want, pos = [], 0
+        for b in spec["batches"]:
+            for it in items[pos:pos + b]:
+                g.add_features(it["id"], it["features"], user)
+            pos += b
+            want.append(g.generate())
+        assert got == want, (ctxf, itemf)
+    # spot checks of the semantics themselves
+    g = o.EasyrecGenerator(["cat", "missing"])
+    for it in items[:3]:
+        g.add_features(it["id"], it["features"], user)
+    r = g.generate()
+    assert r["context_features"] == {"cat": ["a", "b", ""], "missing": ["", "", ""]} and r["item_features"] == {}
+    g = o.EasyrecGenerator(["cat"])
+    g.set_item_features(["*"])
+    for it in items:
+        g.add_features(it["id"], it["features"], user)
+    r = g.generate()
+    assert r["item_features"] == {"price": [3.5, 0.0, 1.25, 0.0], "cnt": [7, 2, 0, 0], "extra": ["x", "", "", ""]}
