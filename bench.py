@@ -242,7 +242,13 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = R * K * args.steps / elapsed * (1 if shard else world)
-    shard_bytes = (end - begin) * args.dim * 4
+    # Algorithmic bytes of one table pass: the screen streams the table's bf16 shadow (rows x dim x 2;
+    # DESIGN.md §4.1a) — the fp32 rows (rows x dim x 4, SURVEY.md 8d's figure for a scan of the table itself)
+    # are only gathered for the ~1e-4 fraction of rows that reach the exact re-scoring.  Tables the screen
+    # cannot serve (dim > 128) are scanned in fp32.
+    screened = args.dim <= 128
+    shard_bytes = (end - begin) * args.dim * (2 if screened else 4)
+    fp32_bytes = (end - begin) * args.dim * 4
     scan_avg_ms = float(np.mean(scan_ms))
     achieved = shard_bytes / (scan_avg_ms * 1e-3) / 1e9
     out = {
@@ -264,7 +270,11 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R),
                      "measured_peak": measured_gbs, "frac_of_measured": achieved / measured_gbs,
                      "bytes_per_pass": shard_bytes, "ms_per_pass": scan_avg_ms,
-                     "note": "algorithmic bytes = shard rows x dim x 4 per table pass (one pass serves %d requests); "
+                     "fp32_table_bytes": fp32_bytes,
+                     "fp32_table_equivalent_gbs": fp32_bytes / (scan_avg_ms * 1e-3) / 1e9,
+                     "note": "algorithmic bytes = shard rows x dim x 2 per table pass: the pass streams the bf16 shadow of "
+                             "the fp32 table (exact fp32 re-scoring of the ~1e-4 of rows that pass the screen), one "
+                             "pass serves %d requests; "
                              "duration = sum of the pass's scan-stage launches (exact seed of the pilot sample, screened sample launch, "
                              "screened full pass, exact re-scoring), HIP events on the launch stream" % R},
         "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},

@@ -53,10 +53,14 @@ struct pg_table {
     uint64_t rows = 0;
     uint32_t dim = 0;
     uint64_t row_offset = 0;     // global row id of local row 0 (sharded tables)
-    // lazily computed statistics for the screened recall (invalidated by upload / fill / swap)
+    // lazily computed for the screened recall (invalidated by upload / fill): statistics and the bf16
+    // shadow of the rows — RNE of every fp32 value, [rows + 64][dim] — that the screen streams instead of
+    // the fp32 rows (half the bytes; the exact re-scoring still gathers fp32)
     bool stats_valid = false;
     bool all_finite = false;
     float max_norm = 0.0f;       // upper bound of the rows' L2 norms
+    uint16_t* d16 = nullptr;     // allocated on first use, kept across rebuilds
+    bool shadow_failed = false;  // allocation failed once: stay on the exact scan
 };
 
 struct pg_ctx {

@@ -376,7 +376,7 @@ constexpr int kScreenLds = 163840;              // the whole LDS of a CU: ring (
 constexpr float kScreenEps = 0.008f;
 
 struct ScreenArgs {
-    const float* tab;
+    const uint16_t* tab16;    // bf16 shadow of the table (pg_table::d16)
     const uint4* qb16;        // [NQB][DIM/16][64] bf16x8 B fragments
     const float* thr_screen;  // [256] thr - eps, rounded down
     uint32_t* susp_cnt;       // [256] suspects per query of this launch
@@ -397,7 +397,9 @@ struct ScreenArgs {
 template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PPB = DIM / kPieceCols;
+    // the kernel streams the table's bf16 shadow: a piece is 32 rows x 64 columns (one 128-B line per row)
+    constexpr int kCols16 = 64;
+    constexpr int PPB = DIM / kCols16;           // pieces per 32-row block (1 or 2)
     constexpr int NS = kScanLdsRing / (WAVES * kPieceBytes);        // ring slots per wave
     constexpr int ND = kPieceDmas;
     constexpr int KS = DIM / 16;                 // bf16 k-steps
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     for (int n = 0; n < ND; ++n) {
         const int S = n * 64 + lane;
         const int i = S >> 3, p = S & 7;
-        voff[n] = (uint32_t)(i * DIM + 4 * ((p + (i >> 1)) & 7)) * 4u;
+        voff[n] = (uint32_t)(i * DIM * 2 + 16 * ((p + (i >> 1)) & 7));       // row i, rotated 16-B quad p
     }
     const uint32_t lds_wave_u = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + wave * (NS * kPieceBytes));
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     // block being scored (compile-time offset), global piece counter t for the ring slot
     auto piece_addr = [&](int rel_piece, uint32_t t, const char*& ub, uint32_t& dst) {
         const uint32_t ph = phys[rel_piece / PPB];
-        const char* base = (const char*)a.tab + (uint64_t)ph * (uint64_t)(kPieceRows * DIM * 4) + (rel_piece % PPB) * (kPieceCols * 4);
+        const char* base = (const char*)a.tab16 + (uint64_t)ph * (uint64_t)(kPieceRows * DIM * 2) + (rel_piece % PPB) * (kCols16 * 2);
         const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)base >> 32));
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
         ub = (const char*)(((uint64_t)hi << 32) | lo);
@@ -554,12 +556,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
             uint32_t nb_dst;
             piece_addr(pc + NS - 1, t + NS - 1, nb_src, nb_dst);
             const char* slot = lds_ptr + (t % NS) * kPieceBytes + rd_row;
-            // A fragment of k-step ksl (16 columns of the piece): this lane's 8 columns = quads
-            // ksl*4 + 2h and ksl*4 + 2h + 1 of its row
+            // A fragment of k-step ksl (16 bf16 columns of the piece = quads 2ksl, 2ksl+1 of the row): this
+            // lane's 8 columns are quad 2ksl + h — one ds_read_b128 is one MFMA operand, no conversion
             f32x4 q4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int quad = (j >> 1) * 4 + 2 * h + (j & 1);
+                const int quad = 2 * j + h;
                 q4[j] = *reinterpret_cast<const f32x4*>(slot + ((quad * 16 - rd_rot) & 112));
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -567,11 +569,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
             for (int n = 0; n < ND; ++n)
                 if (VAR != 3) dma_one(nb_src, nb_dst + n * 1024, voff[n], q4[n].x);
 #pragma unroll
-            for (int ksl = 0; ksl < 2; ++ksl) {
-                const f32x4 lo = q4[2 * ksl], hi = q4[2 * ksl + 1];
-                const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const bf16x8 af = __builtin_convertvector(v, bf16x8);
-                const int ks = pc * 2 + ksl;
+            for (int ksl = 0; ksl < 4; ++ksl) {
+                const bf16x8 af = __builtin_bit_cast(bf16x8, q4[ksl]);
+                const int ks = pc * 4 + ksl;
                 if (VAR == 2) {
                     asm volatile("" :: "v"(af));
                     continue;
@@ -775,36 +775,54 @@ __global__ void screen_thr_kernel(const float* __restrict__ thr, const float* __
     thr_screen[q] = v;
 }
 
-// table statistics for the screen: max row L2 norm (upper bound) and finiteness
-__global__ void table_stats_kernel(const float* __restrict__ tab, uint64_t rows, uint32_t dim,
-                                   float* __restrict__ out_max, uint32_t* __restrict__ out_nonfinite) {
-    __shared__ float smax[256];
-    __shared__ uint32_t sbad[256];
+// Table preparation for the screen, one coalesced pass: the bf16 shadow of the rows (RNE, what
+// v_cvt_pk_bf16_f32 gives) and the statistics the error bound needs — max row L2 norm (upper bound) and
+// finiteness.  A thread converts 8 consecutive values; DIM/8 neighbouring lanes share a row.
+template <int DIM>
+__global__ __launch_bounds__(256) void table_shadow_kernel(const float* __restrict__ tab, uint64_t rows,
+                                                           uint16_t* __restrict__ out16,
+                                                           float* __restrict__ out_max,
+                                                           uint32_t* __restrict__ out_nonfinite) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    constexpr int G = DIM / 8;                       // lanes per row (8 or 16)
+    __shared__ float smax[4];
+    __shared__ uint32_t sbad[4];
+    const uint64_t n8 = rows * (uint64_t)G;          // 8-value groups in the table
     float mx = 0.0f;
     uint32_t bad = 0;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
-        const float4* x = reinterpret_cast<const float4*>(tab + r * dim);
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ((n8 + 63) & ~63ull);
+         g += (uint64_t)gridDim.x * blockDim.x) {
         float ss = 0.0f;
-        for (uint32_t j = 0; j < dim / 4; ++j) {
-            const float4 v = x[j];
-            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        if (g < n8) {
+            const float4 a = reinterpret_cast<const float4*>(tab)[2 * g];
+            const float4 b = reinterpret_cast<const float4*>(tab)[2 * g + 1];
+            const f32x2 p0 = {a.x, a.y}, p1 = {a.z, a.w}, p2 = {b.x, b.y}, p3 = {b.z, b.w};
+            uint4 o;
+            o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
+            o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
+            o.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(p2, bf16x2));
+            o.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(p3, bf16x2));
+            reinterpret_cast<uint4*>(out16)[g] = o;
+            ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
         }
-        if (!(ss < 3.0e38f)) bad = 1;                  // NaN, inf or overflow
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) ss += __shfl_xor(ss, off, 64);     // the row's sum of squares
+        if (!(ss < 3.0e38f)) bad = 1;                 // NaN, inf or overflow
         mx = fmaxf(mx, ss);
     }
-    smax[threadIdx.x] = mx;
-    sbad[threadIdx.x] = bad;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
-            sbad[threadIdx.x] |= sbad[threadIdx.x + s];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        bad |= (uint32_t)__shfl_xor((int)bad, off, 64);
     }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smax[w] = mx; sbad[w] = bad; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        atomicMax(reinterpret_cast<uint32_t*>(out_max), __float_as_uint(smax[0]));   // non-negative floats order as uints
-        if (sbad[0]) atomicOr(out_nonfinite, 1u);
+        const float m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        atomicMax(reinterpret_cast<uint32_t*>(out_max), __float_as_uint(m));   // non-negative floats order as uints
+        if (sbad[0] | sbad[1] | sbad[2] | sbad[3]) atomicOr(out_nonfinite, 1u);
     }
 }
 
@@ -1156,16 +1174,31 @@ static int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, 
     return PG_OK;
 }
 
+// statistics + bf16 shadow of a table (lazily, cached until the next upload / fill).  Tables the screen
+// cannot serve (dim other than 64 / 128, no memory for the shadow) keep stats_valid = false.
 static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     pg_table* t = const_cast<pg_table*>(tc);          // lazily computed cache
-    if (t->stats_valid) return PG_OK;
+    if (t->stats_valid || t->shadow_failed) return PG_OK;
+    if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
+    if (!t->d16) {
+        const size_t bytes = (t->rows + 64) * (size_t)t->dim * 2;
+        if (hipMalloc((void**)&t->d16, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            t->d16 = nullptr;
+            t->shadow_failed = true;                  // stay on the exact scan
+            return PG_OK;
+        }
+        PG_HIP(hipMemsetAsync(t->d16 + t->rows * (size_t)t->dim, 0, 64 * (size_t)t->dim * 2, ctx->stream));
+    }
     void* p;
     int rc;
     if ((rc = scratch_reserve(ctx, 4, 4096, &p))) return rc;
     float* d_max = (float*)p + 300;
     uint32_t* d_bad = (uint32_t*)p + 301;
     PG_HIP(hipMemsetAsync(d_max, 0, 8, ctx->stream));
-    table_stats_kernel<<<2048, 256, 0, ctx->stream>>>(t->d, t->rows, t->dim, d_max, d_bad);
+    const uint32_t grid = (uint32_t)ctx->num_cus * 16;
+    if (t->dim == 64) table_shadow_kernel<64><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->d16, d_max, d_bad);
+    else table_shadow_kernel<128><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->d16, d_max, d_bad);
     PG_HIP(hipGetLastError());
     PG_HIP(hipMemcpyAsync(ctx->h_status + 300, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
@@ -1248,7 +1281,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
     bool screen = nq > screen_min && t->dim <= 128 && !getenv("PG_RECALL_EXACT");
     if (screen) {
         if ((rc = ensure_table_stats(ctx, t))) return rc;
-        if (!t->all_finite) screen = false;
+        if (!t->stats_valid || !t->all_finite) screen = false;      // no shadow (dim, memory) or non-finite rows
     }
     if (!screen && nq > (uint32_t)kMaxQueriesExact) {
         set_error("recall: %u queries need the screened scan (finite table, dim <= 128); at most %d otherwise",
@@ -1302,7 +1335,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
         PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev], ctx->stream));
         if (screen && !thr_is_open) {
             ScreenArgs sa;
-            sa.tab = t->d;
+            sa.tab16 = t->d16;
             sa.qb16 = rs.qb16;
             sa.thr_screen = rs.thr_screen;
             sa.susp_cnt = rs.susp_cnt;

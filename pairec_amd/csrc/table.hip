@@ -97,6 +97,7 @@ int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
     std::lock_guard<std::mutex> g(ctx->mu);
     PG_HIP(hipStreamSynchronize(ctx->stream));
     if (t->d) PG_HIP(hipFree(t->d));
+    if (t->d16) PG_HIP(hipFree(t->d16));
     delete t;
     return PG_OK;
 }
@@ -162,6 +163,8 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->stats_valid, b->stats_valid);
     std::swap(a->all_finite, b->all_finite);
     std::swap(a->max_norm, b->max_norm);
+    std::swap(a->d16, b->d16);
+    std::swap(a->shadow_failed, b->shadow_failed);
     return PG_OK;
 }
 

@@ -149,6 +149,37 @@ def test_recall_screen_is_exact_on_hostile_data(ctx):
     t.destroy()
 
 
+def test_recall_follows_table_updates(ctx):
+    """The screen streams a bf16 shadow of the table that is built lazily; uploads, synthetic fills and
+    hot swaps must invalidate / carry it — every recall answers for the rows the table holds now."""
+    n, d, k = 60000, 128, 300
+    a = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    b = o.synth_rows(o.SEED_TABLE, 10 * n, n, d)
+    q = o.synth_rows(o.SEED_QUERY, 0, 40, d)
+    ta, tb = pa.Table(ctx, n, d), pa.Table(ctx, n, d)
+    ta.upload(a)
+    tb.upload(b)
+
+    def check(t, tab):
+        rows, scores, _ = t.recall_topk(q, k)
+        orow, osc = o.recall_topk(tab, q, k)
+        assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+
+    check(ta, a)                                   # builds ta's shadow
+    a2 = a.copy()
+    a2[1000:3000] = b[1000:3000] * 3.0             # partial upload: new rows, new max norm
+    ta.upload(a2[1000:3000], row0=1000)
+    check(ta, a2)
+    check(tb, b)
+    ta.swap(tb)                                    # both shadows valid: they travel with the rows
+    check(ta, b)
+    check(tb, a2)
+    ta.fill_synthetic(o.SEED_TABLE)                # refill in place
+    check(ta, o.synth_rows(o.SEED_TABLE, 0, n, d))
+    ta.destroy()
+    tb.destroy()
+
+
 def test_recall_adversarial_order(ctx):
     """Scores ascending with the row index defeat a running threshold (every row beats everything seen
     before it).  The pilot plan samples the whole table and is immune; with the pilot disabled the
