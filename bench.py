@@ -270,6 +270,9 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R),
                      "measured_peak": measured_gbs, "frac_of_measured": achieved / measured_gbs,
                      "bytes_per_pass": shard_bytes, "ms_per_pass": scan_avg_ms,
+                     "mfma_flops_per_pass": 2.0 * (end - begin) * args.dim * R if screened else None,
+                     "mfma_frac": (2.0 * (end - begin) * args.dim * R / (scan_avg_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS)
+                     if screened else None,
                      "fp32_table_bytes": fp32_bytes,
                      "fp32_table_equivalent_gbs": fp32_bytes / (scan_avg_ms * 1e-3) / 1e9,
                      "note": "algorithmic bytes = shard rows x dim x 2 per table pass: the pass streams the bf16 shadow of "
