@@ -303,3 +303,61 @@ def test_easyrec_generator_default_filling(H):
         g.add_features(it["id"], it["features"], user)
     r = g.generate()
     assert r["item_features"] == {"price": [3.5, 0.0, 1.25, 0.0], "cnt": [7, 2, 0, 0], "extra": ["x", "", "", ""]}
+
+
+# ---- /api/recommend harness --------------------------------------------------------------
+def test_http_harness_parameter_checks_without_engine():
+    """RecommendController.CheckParameter (web/recommend_controller.go:96-113) — the checks that fail before
+    the engine is touched."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import http_harness as hh
+    h = hh.Harness.__new__(hh.Harness)                       # no engine: only the early-exit paths
+    assert h.handle(b"")["code"] == 400 and h.handle(b"")["msg"] == "request body empty"
+    assert h.handle(b"{not json")["code"] == 400
+    r = h.handle(json.dumps({"size": 5}).encode())
+    assert r["code"] == 400 and r["msg"] == "uid not empty" and len(r["request_id"]) == 36
+
+
+@pytest.mark.gpu
+def test_http_harness_end_to_end():
+    """POST /api/recommend over localhost → recall → rank → sort on the GPU → the reference's response
+    shape (code 200 / 299, size, items[{item_id,item_type,retrieve_id}])."""
+    import sys
+    import threading
+    import urllib.request
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import http_harness as hh
+    import pairec_amd as pa
+    h = hh.Harness(CONFIG)
+    w = o.Dnn3Weights()
+    h.load_dnn3(pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    srv = hh.make_server(h, 0)
+    port = srv.server_address[1]
+    th = threading.Thread(target=srv.serve_forever, daemon=True)
+    th.start()
+
+    def post(obj):
+        req = urllib.request.Request("http://127.0.0.1:%d/api/recommend" % port, data=json.dumps(obj).encode(),
+                                     headers={"Content-Type": "application/json"})
+        with urllib.request.urlopen(req, timeout=60) as r:
+            return json.loads(r.read())
+
+    user = o.synth_rows(o.SEED_QUERY, 3, 1, 128)[0]
+    vec = " ".join("%d:%s" % (i + 1, repr(float(v))) for i, v in enumerate(user))
+    r = post({"uid": "u1", "size": 20, "scene_id": "home_feed", "features": {"user_vector": vec}})
+    assert r["code"] == 200 and r["msg"] == "success" and r["size"] == 20 and len(r["items"]) == 20
+    assert set(r["items"][0]) == {"item_id", "item_type", "retrieve_id"}
+    assert r["items"][0]["retrieve_id"] == "gpu_vector_recall" and r["items"][0]["item_type"] == "video"
+    # the same page as the in-process driver
+    L = h.L
+    direct = json.loads(L.ph_recommend(h.h, b"u1", 20, b"home_feed"))["items"]
+    assert [x["item_id"] for x in r["items"]] == [x["item_id"] for x in direct]
+    # more than the recall can deliver → 299 "items size not enough"; size <= 0 → 10; unknown user → empty page
+    assert post({"uid": "u1", "size": 1000, "scene_id": "home_feed"})["code"] == 299
+    assert post({"uid": "u1", "size": 0, "scene_id": "home_feed"})["size"] == 10
+    r = post({"uid": "nobody", "size": 5, "scene_id": "home_feed"})
+    assert r["code"] == 299 and r["size"] == 0 and r["items"] == []
+    assert post({"size": 5})["code"] == 400
+    srv.shutdown()
+    h.close()
