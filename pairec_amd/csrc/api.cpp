@@ -14,6 +14,14 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
+int ensure_dyn_lds(pg_ctx* ctx, const void* kernel, size_t bytes) {
+    auto it = ctx->dyn_lds.find(kernel);
+    if (it != ctx->dyn_lds.end() && it->second >= bytes) return PG_OK;
+    PG_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->dyn_lds[kernel] = bytes;
+    return PG_OK;
+}
+
 int scratch_reserve(pg_ctx* ctx, int slot, size_t bytes, void** out) {
     Scratch& s = ctx->scratch[slot];
     if (s.cap < bytes) {

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -70,6 +71,7 @@ struct pg_ctx {
     int num_cus = 256;
     std::mutex mu;               // serialises calls on this context
     pg::Scratch scratch[8];      // named scratch slots (see users)
+    std::map<const void*, size_t> dyn_lds;   // kernels whose dynamic-LDS limit was raised on this device
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;   // per-launch timing events (scan kernel roofline figure)
     uint32_t last_scan_launches = 0;
@@ -83,6 +85,9 @@ struct pg_ctx {
 
 namespace pg {
 int scratch_reserve(pg_ctx* ctx, int slot, size_t bytes, void** out);
+// raise a kernel's dynamic-LDS limit once per context (the attribute is per device: a process may hold
+// contexts on several GPUs); caller holds ctx->mu
+int ensure_dyn_lds(pg_ctx* ctx, const void* kernel, size_t bytes);
 // features.hip: gather of integer feature columns, caller holds ctx->mu
 int features_gather_i32_locked(pg_ctx* ctx, const pg_features* fs, const int32_t* col_idx, uint32_t n_cols,
                                const uint32_t* d_rows, uint32_t n, int32_t* d_out, const char* who);

@@ -678,11 +678,6 @@ static std::vector<float> rounded(const float* w, size_t n, int prec) {
     return o;
 }
 
-template <typename K>
-static int set_lds_attr(K kernel, size_t bytes) {
-    PG_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return PG_OK;
-}
 
 struct RankScratch {
     uint32_t *tile_req, *tile_item0, *tile_cnt, *n_tiles, *req_tile0;
@@ -742,13 +737,11 @@ static int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* 
         // bf16: 2 x 2 waves, 64-column chunks, two-pass head → 68 KB of LDS and <= 256 registers: two
         // workgroups per CU, so one's barriers and weight-fragment loads hide behind the other's MFMAs
         constexpr size_t lds = mlp_lds_bytes(1, 256, 64, 2);
-        static bool once = false;
-        if (!once) { if ((rc = set_lds_attr(mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2>, lds))) return rc; once = true; }
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2>, lds))) return rc;
         mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
     } else {
         constexpr size_t lds = mlp_lds_bytes(0, 256, 128, 1);
-        static bool once = false;
-        if (!once) { if ((rc = set_lds_attr(mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1>, lds))) return rc; once = true; }
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1>, lds))) return rc;
         mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
     }
     PG_HIP(hipGetLastError());
@@ -793,13 +786,11 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     a.out = d_out;
     if (m->prec) {
         constexpr size_t lds = mlp_lds_bytes(1, 64, 128, 1);
-        static bool once = false;
-        if (!once) { if ((rc = set_lds_attr(mlp_kernel<1, 256, 64, false, 2, 2, 2, 128, 1, 2>, lds))) return rc; once = true; }
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, 256, 64, false, 2, 2, 2, 128, 1, 2>, lds))) return rc;
         mlp_kernel<1, 256, 64, false, 2, 2, 2, 128, 1, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
     } else {
         constexpr size_t lds = mlp_lds_bytes(0, 64, 128, 1);
-        static bool once = false;
-        if (!once) { if ((rc = set_lds_attr(mlp_kernel<0, 256, 64, false, 2, 2, 2, 128, 1, 1>, lds))) return rc; once = true; }
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, 256, 64, false, 2, 2, 2, 128, 1, 1>, lds))) return rc;
         mlp_kernel<0, 256, 64, false, 2, 2, 2, 128, 1, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
     }
     PG_HIP(hipGetLastError());

@@ -1051,11 +1051,8 @@ __global__ void merge_keys_kernel(const uint64_t* __restrict__ rows, const float
 static int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
                          uint32_t cap, uint32_t k) {
     constexpr size_t lds = (size_t)kSelLdsKeys * 8;
-    static bool attr = false;
-    if (!attr) {
-        PG_HIP(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    int rc_attr;
+    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)select_kernel, lds))) return rc_attr;
     select_kernel<<<nq, 1024, lds, ctx->stream>>>(in, out, cnt, thr, cap, k);
     PG_HIP(hipGetLastError());
     return PG_OK;
@@ -1069,12 +1066,8 @@ static uint32_t next_pow2(uint32_t x) {
 
 template <int DIM, int NQB = 1, int VAR = 0>
 static int launch_scan(pg_ctx* ctx, const ScanArgs& a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        PG_HIP(hipFuncSetAttribute((const void*)scan_kernel<DIM, NQB, VAR>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds));
-        attr_set = true;
-    }
+    int rc_attr;
+    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)scan_kernel<DIM, NQB, VAR>, kScanLds))) return rc_attr;
     const uint32_t total = a.rb_end - a.rb_begin;
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total + kScanWaves - 1) / kScanWaves;
@@ -1163,11 +1156,8 @@ static int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, 
     }
     const uint32_t P = next_pow2(k < 2 ? 2 : k);
     const size_t lds = (size_t)P * 8;
-    static size_t attr = 0;
-    if (lds > attr) {
-        PG_HIP(hipFuncSetAttribute((const void*)final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
-    }
+    int rc_attr;
+    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)final_kernel, lds))) return rc_attr;
     final_kernel<<<nq, 1024, lds, ctx->stream>>>(cand, cnt, cap, k, P, row_offset, d_out_rows,
                                                  d_out_scores, d_out_count);
     PG_HIP(hipGetLastError());
@@ -1212,12 +1202,8 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
 
 template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0>
 static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        PG_HIP(hipFuncSetAttribute((const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kScreenLds));
-        attr_set = true;
-    }
+    int rc_attr;
+    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR>, kScreenLds))) return rc_attr;
     const uint32_t total = a.rb_end - a.rb_begin;
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total * SPLIT + WAVES - 1) / WAVES;

@@ -121,12 +121,9 @@ __global__ __launch_bounds__(1024) void sort_kernel_reg(const double* __restrict
 static int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg,
                            uint32_t n_items, uint32_t max_seg, int desc, uint32_t* d_out) {
     if (n_seg == 0 || n_items == 0) return PG_OK;
-    static bool attr = false;
     constexpr size_t lds = (size_t)kSortLdsMax * 12;
-    if (!attr) {
-        PG_HIP(hipFuncSetAttribute((const void*)sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    int rc_attr;
+    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)sort_kernel, lds))) return rc_attr;
     uint64_t* g_keys = nullptr;
     uint32_t* g_idx = nullptr;
     uint32_t stride = 0;
