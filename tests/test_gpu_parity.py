@@ -149,6 +149,32 @@ def test_recall_screen_is_exact_on_hostile_data(ctx):
     t.destroy()
 
 
+def test_recall_random_shapes_bitexact(ctx):
+    """Seeded random sweep over table sizes (down to a single row, ragged tails), widths, K and batch sizes:
+    every kernel variant and plan of the recall (seed / screened sample / full pass / geometric chunks)
+    against the oracle, bit for bit."""
+    rng = np.random.default_rng(2026)
+    shapes = [(1, 64, 1, 1), (31, 128, 40, 3), (33, 64, 33, 70), (100, 128, 5, 256), (513, 64, 512, 130)]
+    for _ in range(10):
+        n = int(rng.integers(600, 260_000))
+        shapes.append((n, int(rng.choice([64, 128])), int(rng.integers(1, min(n, 3000))), int(rng.integers(1, 257))))
+    shapes.append((2_100_001, 128, 700, 200))                # pilot plan on a ragged table
+    for n, d, k, nq in shapes:
+        off = int(rng.integers(0, 1000))
+        t = pa.Table(ctx, n, d, row_offset=off)
+        t.fill_synthetic(o.SEED_TABLE)
+        tab = o.synth_rows(o.SEED_TABLE, off, n, d)
+        q = o.synth_rows(o.SEED_QUERY, int(rng.integers(0, 500)), nq, d)
+        rows, scores, cnt = t.recall_topk(q, k)
+        m = min(k, n)
+        orow, osc = o.recall_topk(tab, q, m, row_offset=off)
+        assert cnt.tolist() == [m] * nq, (n, d, k, nq)
+        assert np.array_equal(rows[:, :m], orow), (n, d, k, nq)
+        assert np.array_equal(bits(scores[:, :m]), bits(osc)), (n, d, k, nq)
+        assert np.all(rows[:, m:] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(np.isneginf(scores[:, m:]))
+        t.destroy()
+
+
 def test_recall_follows_table_updates(ctx):
     """The screen streams a bf16 shadow of the table that is built lazily; uploads, synthetic fills and
     hot swaps must invalidate / carry it — every recall answers for the rows the table holds now."""
