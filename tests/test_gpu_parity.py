@@ -430,6 +430,25 @@ def test_sort_matches_oracle_segmented(ctx):
             assert np.array_equal(got[a:b], o.sort_scores(s[a:b], desc)), (desc, i)
 
 
+def test_sort_register_network_segments_up_to_8192(ctx):
+    """All segments <= 8192: the register-resident bitonic network (shuffle / LDS exchanges) — ties by
+    index, NaN last, -0 == +0, heavy duplicates, every power-of-two boundary."""
+    rng = np.random.default_rng(17)
+    sizes = [8192, 0, 1, 2, 3, 511, 512, 513, 5000, 4096, 4097, 64, 65, 1000, 8191]
+    segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    s = rng.random(int(segs[-1]))
+    s[::7] = np.round(s[::7], 1)                             # heavy ties
+    s[3::501] = np.nan
+    s[10::997] = -0.0
+    s[11::997] = 0.0
+    s[segs[8]:segs[9]] = 0.25                                # one segment of 5000 identical scores
+    for desc in (True, False):
+        got = ctx.sort_scores(s, segs, descending=desc)
+        for i in range(len(sizes)):
+            a, b = int(segs[i]), int(segs[i + 1])
+            assert np.array_equal(got[a:b], o.sort_scores(s[a:b], desc)), (desc, i, sizes[i])
+
+
 # ---------------------------------------------------------------------------------------------
 # DPP
 # ---------------------------------------------------------------------------------------------
