@@ -171,11 +171,20 @@ def main():
 
     torch = dist = None
     stream = None
+    # Developer smoke of the N > 1 code path on a box with fewer GPUs than ranks: PG_BENCH_SHARE_GPU=1 puts
+    # every rank on cuda:0 and rendezvous over gloo (RCCL refuses two ranks on one device).  Never set by the
+    # driver; the real path is one rank per GPU over RCCL.
+    share_gpu = world > 1 and os.environ.get("PG_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         stream = torch.cuda.current_stream().cuda_stream
 
     shard = world > 1 and args.mode == "shard"
@@ -235,7 +244,7 @@ def main():
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
     if world > 1:
-        dev = torch.device("cuda", local_rank)
+        dev = torch.device("cpu") if share_gpu else torch.device("cuda", local_rank)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
