@@ -580,3 +580,44 @@ def test_rank_fm2t_from_candidate_rows(ctx):
     assert np.max(np.abs(got.astype(np.float64) - want)) <= 3e-7
     fs.destroy()
     m.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# concurrency: pairec calls its plugins from many goroutines (rank_service.go:163-166 fans out 50)
+# ---------------------------------------------------------------------------------------------
+def test_concurrent_callers_share_one_context(ctx):
+    """Several host threads drive the same context at once (ctypes drops the GIL during the calls): the
+    context serialises them on its stream and every caller gets its own, correct answer."""
+    import threading
+    n, d, k = 120000, 128, 300
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    w = o.Dnn3Weights()
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    errors = []
+
+    def worker(i):
+        try:
+            q = o.synth_rows(o.SEED_QUERY, 10 * i, 3 + i, d)
+            for _ in range(3):
+                rows, scores, _ = t.recall_topk(q, k)
+                orow, osc = o.recall_topk(tab, q, k)
+                assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+                cand = rows[0].astype(np.uint32)
+                got = m.rank_dnn3(t, q[:1], cand, [0, k])
+                want = o.dnn3_forward(w, 0, q[0], tab[cand.astype(np.int64)])
+                assert np.max(np.abs(got.astype(np.float64) - want)) <= 2e-7
+                order = ctx.sort_scores(got.astype(np.float64))
+                assert np.array_equal(order, o.sort_scores(got.astype(np.float64), True))
+        except Exception as e:                                 # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    m.destroy()
+    t.destroy()
