@@ -235,7 +235,8 @@ constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep) {
     const size_t nh1 = (prec && (size_t)kBM * (kDIN + 2 * ch) * es <= 72 * 1024) ? 2 : 1;   // as NH1 in mlp_kernel
     const size_t tiles = (size_t)kBM * (kDIN + nh1 * ch) * es;
     const size_t h2t = (size_t)kBM * (h2 / ep + 4) * 4;
-    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)kBM * 4;
+    // + the two-tower prologue's FM staging: 8 item groups x (8 fields x 16 embedding values + 8 linear weights)
+    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)kBM * 4 + (size_t)8 * (kFmFields * kFmK + kFmFields) * 4;
 }
 
 // MODEL 1 = DNN3, 2 = two-tower item side.  WM x WN = wave grid over (items, hidden columns); CH = layer-1
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
     float* const H2T = reinterpret_cast<float*>(smem);      // aliases XT/H1T after the GEMMs
     float* const w3s = reinterpret_cast<float*>(smem + REGION);
     float* const b3s = w3s + H2;
+    float* const fm_stage = b3s + kBM;                      // [8 groups][8*16 + 8] (two-tower prologue only)
 
     const uint32_t tile = blockIdx.x;
     if (tile >= *a.n_tiles) return;
@@ -301,52 +303,62 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             const int f = c >> 2, qd = c & 3;
             const float* fu = a.fm_user + (size_t)req * 33;
             const float* emb = a.field_emb[kFmFields + f];
-            const float* lin_t[1] = {nullptr};
-            (void)lin_t;
-#pragma unroll 1
+            const float* lin_tab = a.field_lin[kFmFields + f];
+            // three waves of independent loads (ids → embedding quads + linear weights), then the arithmetic:
+            // one item at a time this was 16 serial round trips per thread
+            int32_t ids[16];
+#pragma unroll
             for (int p = 0; p < 16; ++p) {
                 const uint32_t r = p * 8 + (tid >> 5);
                 const uint32_t idx = item0 + (r < cnt ? r : cnt - 1);
-                int32_t id = a.item_field_ids[(size_t)idx * kFmFields + f];
-                id = id < 0 ? 0 : (id >= (int32_t)a.vocab ? (int32_t)a.vocab - 1 : id);
-                const float4 v = *reinterpret_cast<const float4*>(emb + (size_t)id * kFmK + 4 * qd);
-                store_x_quad<PREC>(XT, r, c, v);
-                float s[4], q[4];
-                const float vv[4] = {v.x, v.y, v.z, v.w};
+                const int32_t id = a.item_field_ids[(size_t)idx * kFmFields + f];
+                ids[p] = id < 0 ? 0 : (id >= (int32_t)a.vocab ? (int32_t)a.vocab - 1 : id);
+            }
+            float4 v[16];
+            float linv[16];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s[e] = fu[1 + 4 * qd + e] + vv[e];
-                    q[e] = __fmaf_rn(vv[e], vv[e], fu[17 + 4 * qd + e]);
-                }
+            for (int p = 0; p < 16; ++p) {
+                v[p] = *reinterpret_cast<const float4*>(emb + (size_t)ids[p] * kFmK + 4 * qd);
+                linv[p] = qd == 0 ? lin_tab[ids[p]] : 0.0f;
+            }
+            // FM sums: the 32 lanes of an item group park their field values in LDS; lane k < 16 then walks the
+            // 8 fields of embedding column k (fields accumulate sequentially, user prefix first), the 16 cross
+            // terms fold in a balanced tree, lane 0 adds the linear chain.  (A shuffle chain across the lanes
+            // cost 63 ds_bpermutes per item per lane.)
+            const int grp = tid >> 5;
+            float* const st = fm_stage + grp * (kFmFields * kFmK + kFmFields);
+            const float fus = c < kFmK ? fu[1 + c] : 0.0f;
+            const float fuq = c < kFmK ? fu[17 + c] : 0.0f;
+            const float fu_lin = fu[0];
 #pragma unroll
-                for (int ff = 1; ff < kFmFields; ++ff) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float sp = __shfl_up(s[e], 4, 32);
-                        const float qp = __shfl_up(q[e], 4, 32);
-                        if (f == ff) {
-                            s[e] = sp + vv[e];
-                            q[e] = __fmaf_rn(vv[e], vv[e], qp);
-                        }
-                    }
-                }
-                // lanes with f == 7 hold the finished sums for k = 4*qd + e
-                float t[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = __fmaf_rn(s[e], s[e], -q[e]);
-                float cr = (t[0] + t[1]) + (t[2] + t[3]);
-                cr = cr + __shfl_xor(cr, 1, 32);
-                cr = cr + __shfl_xor(cr, 2, 32);
-                if (c == 31) {
-                    float lin = fu[0];
+            for (int p = 0; p < 16; ++p) {
+                const uint32_t r = p * 8 + grp;
+                store_x_quad<PREC>(XT, r, c, v[p]);
+                *reinterpret_cast<float4*>(st + f * kFmK + 4 * qd) = v[p];
+                if (qd == 0) st[kFmFields * kFmK + f] = linv[p];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float s_ = fus, q_ = fuq;
+                if (c < kFmK) {
 #pragma unroll
                     for (int ff = 0; ff < kFmFields; ++ff) {
-                        int32_t idf = a.item_field_ids[(size_t)idx * kFmFields + ff];
-                        idf = idf < 0 ? 0 : (idf >= (int32_t)a.vocab ? (int32_t)a.vocab - 1 : idf);
-                        lin = lin + a.field_lin[kFmFields + ff][idf];
+                        const float x = st[ff * kFmK + c];
+                        s_ = s_ + x;
+                        q_ = __fmaf_rn(x, x, q_);
                     }
+                }
+                float cr = c < kFmK ? __fmaf_rn(s_, s_, -q_) : 0.0f;
+                cr = cr + __shfl_xor(cr, 1, 16);            // balanced pairwise tree over k
+                cr = cr + __shfl_xor(cr, 2, 16);
+                cr = cr + __shfl_xor(cr, 4, 16);
+                cr = cr + __shfl_xor(cr, 8, 16);
+                if (c == 0) {
+                    float lin = fu_lin;
+#pragma unroll
+                    for (int ff = 0; ff < kFmFields; ++ff) lin = lin + st[kFmFields * kFmK + ff];
                     b3s[r] = lin + 0.5f * cr;
                 }
+                __builtin_amdgcn_wave_barrier();             // the next item overwrites the staging
             }
         }
     }
