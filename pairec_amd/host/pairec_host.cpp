@@ -716,8 +716,8 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
     e->sorts.RegisterSort("ItemScore", std::make_shared<GpuItemScoreSort>(e.get()), nullptr);
     for (const auto& d : e->config.DPPConf) e->sorts.RegisterSort(d.Name, std::make_shared<GpuDPPSort>(e.get(), d), nullptr);
     for (const auto& sc : e->config.SortConfs) {          // RegisterSortWithConfig (sort/sort.go:162-200)
-        if (sc.SortType == "DPPSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuDPPSort>(e.get(), sc.DPPConf), nullptr);
-        if (sc.SortType == "SSDSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuSSDSort>(e.get(), sc.SSDConf), nullptr);
+        if (sc.SortType == "DPPSort") e->sorts.RegisterSortWithConfig(sc.Name, std::make_shared<GpuDPPSort>(e.get(), sc.DPPConf));
+        if (sc.SortType == "SSDSort") e->sorts.RegisterSortWithConfig(sc.Name, std::make_shared<GpuSSDSort>(e.get(), sc.SSDConf));
     }
     // algorithms by name (the shim's start hook does the same with algorithm.RegisterAlgorithm)
     for (const auto& a : g.at("Algorithms").arr) {

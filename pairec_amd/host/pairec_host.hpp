@@ -246,6 +246,8 @@ struct ICloneSort {                   // sort.go:36-39: AB-experiment overrides 
 class Registry {                      // sort.go:143-150: first registration wins; nil panics
 public:
     bool RegisterSort(const std::string& name, std::shared_ptr<ISort> s, std::string* err);
+    // registerSortWithSign (sort.go:204-207): what RegisterSortWithConfig uses — overwrites
+    void RegisterSortWithConfig(const std::string& name, std::shared_ptr<ISort> s) { sorts_[name] = std::move(s); }
     std::shared_ptr<ISort> Get(const std::string& name);
 private:
     std::map<std::string, std::shared_ptr<ISort>> sorts_;
