@@ -621,3 +621,80 @@ def test_concurrent_callers_share_one_context(ctx):
     assert not errors, errors
     m.destroy()
     t.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json's full size: 100 M x 128 table, K = 5 000, 256 requests — size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_full_size_pipeline_properties(ctx):
+    """The benchmark configuration itself.  The oracle cannot scan 100 M rows x 256 queries in seconds, so:
+    (a) order: scores non-increasing, ties by row, rows unique and in range;
+    (b) exactness: returned scores equal the oracle's dot products of the returned rows, bit for bit;
+    (c) completeness on samples: in random 1 M-row slices (regenerated on the CPU from the synthetic
+        generator), every row whose key beats the K-th returned key is in the answer;
+    (d) batching invariance: a query alone / in a batch of 128 / in the batch of 256 gets the same answer;
+    (e) rank + fusion + sort over all 1.28 M candidates: a sample of scores within tolerance of the
+        oracle, the per-request order equal to the oracle's sort of the device's own scores."""
+    n, d, k, R = 100_000_000, 128, 5000, 256
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    q = o.synth_rows(o.SEED_QUERY, 0, R, d)
+    rows, scores, cnt = t.recall_topk(q, k)
+    assert cnt.tolist() == [k] * R
+    # (a)
+    assert rows.max() < n
+    ds = np.diff(scores.astype(np.float64), axis=1)
+    assert np.all(ds <= 0)
+    tie = ds == 0
+    assert np.all(np.diff(rows.astype(np.int64), axis=1)[tie] > 0)
+    for r in range(0, R, 37):
+        assert len(np.unique(rows[r])) == k
+    # (b) on 4 queries
+    for r in (0, 101, 255, 128):
+        got_rows = t.gather(rows[r].astype(np.uint32))
+        for j in (0, 1, 2500, 4999):                            # the gather itself, against the generator
+            rr = int(rows[r, j])
+            assert np.array_equal(got_rows[j], o.synth_rows(o.SEED_TABLE, rr, 1, d)[0])
+        want = o.dot_scores(got_rows, q[r:r + 1])[0]
+        assert np.array_equal(bits(scores[r]), bits(want))
+    # (c) three random slices, 6 queries each
+    rng = np.random.default_rng(77)
+    for _ in range(3):
+        lo = int(rng.integers(0, n - 1_000_000))
+        sl = o.synth_rows(o.SEED_TABLE, lo, 1_000_000, d)
+        qs = [0, 3, 64, 127, 200, 255]
+        sc = o.dot_scores(sl, q[qs])
+        for j, r in enumerate(qs):
+            kth_s, kth_row = scores[r, -1], int(rows[r, -1])
+            s = sc[j]
+            better = np.nonzero((s > kth_s) | ((s == kth_s) & (np.arange(lo, lo + len(s)) < kth_row)))[0] + lo
+            assert np.all(np.isin(better, rows[r])), (lo, r)
+            inside = rows[r][(rows[r] >= lo) & (rows[r] < lo + len(s))]
+            assert len(inside) == len(better) or (len(inside) == len(better) + 1 and kth_row in inside)
+    # (d)
+    r1, s1, _ = t.recall_topk(q[5:6], k)
+    assert np.array_equal(r1[0], rows[5]) and np.array_equal(bits(s1[0]), bits(scores[5]))
+    r128, s128, _ = t.recall_topk(q[:128], k)
+    assert np.array_equal(r128, rows[:128]) and np.array_equal(bits(s128), bits(scores[:128]))
+    # (e)
+    w = o.Dnn3Weights()
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    off = (np.arange(R + 1) * k).astype(np.uint32)
+    dnn = m.rank_dnn3(t, q, rows.reshape(-1).astype(np.uint32), off)
+    for r in (0, 77, 255):
+        idx = rng.integers(0, k, 40)
+        cand = rows[r, idx].astype(np.uint32)
+        want = o.dnn3_forward(w, 1, q[r], t.gather(cand))
+        assert np.max(np.abs(dnn[r * k + idx].astype(np.float64) - want)) <= 1e-5
+    ex = pa.Expr("${gpu_dnn}*(1+${current_score})^0.1")
+    cols = {"gpu_dnn": dnn.astype(np.float64), "current_score": scores.reshape(-1).astype(np.float64)}
+    fused = ex.eval(ctx, np.stack([cols[v] for v in ex.var_names]))
+    order = ctx.sort_scores(fused, off, descending=True)
+    for r in (0, 13, 254):
+        seg = fused[r * k:(r + 1) * k]
+        assert np.array_equal(order[r * k:(r + 1) * k], o.sort_scores(seg, True))
+    fs = fused.reshape(R, k)
+    sorted_scores = np.take_along_axis(fs, order.reshape(R, k).astype(np.int64), axis=1)
+    assert np.all(np.diff(sorted_scores, axis=1) <= 0)
+    m.destroy()
+    t.destroy()
