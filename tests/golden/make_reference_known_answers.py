@@ -38,6 +38,47 @@ cases = {
          "scores": [float(i) for i in range(20)], "descending": False,
          "expect_order": list(range(20))},
     ],
+    # request-side feature typing (the `features` object of POST /api/recommend)
+    "features_map": [
+        {"ref": "web/features_map_test.go:16-20 int64 array to string array",
+         "json": '{"cellIDNeighbors":[384307167844368384,1921535839221841920,1921535841369325568]}',
+         "key": "cellIDNeighbors", "type": "[]string"},
+        {"ref": "web/features_map_test.go:22-26 float64 array to string array", "json": '{"scores":[1.5,2.5,3.5]}',
+         "key": "scores", "type": "[]string", "value": ["1.5", "2.5", "3.5"]},
+        {"ref": "web/features_map_test.go:28-32", "json": '{"name":"test","count":10,"tags":["a","b"]}',
+         "key": "tags", "type": "[]string", "value": ["a", "b"]},
+        {"ref": "web/features_map_test.go:34-38", "json": '{"name":"test","count":10,"tags":[["a","b"],["c","d"]]}',
+         "key": "tags", "type": "[][]string", "value": [["a", "b"], ["c", "d"]]},
+        {"ref": "web/features_map_test.go:40-44", "json": '{"name":"test","count":10,"tags":[[1,2],[3,4]]}',
+         "key": "tags", "type": "[][]string", "value": [["1", "2"], ["3", "4"]]},
+        {"ref": "web/features_map_test.go:46-50 int_field", "json": '{"name":"test","count":10,"tags":[[1,2],[3,4]]}',
+         "key": "count", "type": "int", "value": 10},
+        {"ref": "web/features_map_test.go:52-56 float_field", "json": '{"name":"test","count":10.2,"tags":[[1,2],[3,4]]}',
+         "key": "count", "type": "float64", "value": 10.2},
+        {"ref": "web/features_map_test.go:95-127 TestFeaturesMap_PrecisionPreservation",
+         "json": '{"cellIDNeighbors":[384307167844368384,1921535839221841920,1921535841369325568,1152921512123039744]}',
+         "key": "cellIDNeighbors", "type": "[]string",
+         "value": ["384307167844368384", "1921535839221841920", "1921535841369325568", "1152921512123039744"]},
+        {"ref": "web/features_map_test.go:129-163 TestFeaturesMap_StringArrayConversion",
+         "json": '{"geoHashWithNeighbors":["s00000000001","s00000000003","s00000000002","kpbpbpbpbpbr","kpbpbpbpbpbp","7zzzzzzzzzzz","ebpbpbpbpbpb","ebpbpbpbpbpc","s00000000000"]}',
+         "key": "geoHashWithNeighbors", "type": "[]string",
+         "value": ["s00000000001", "s00000000003", "s00000000002", "kpbpbpbpbpbr", "kpbpbpbpbpbp", "7zzzzzzzzzzz",
+                   "ebpbpbpbpbpb", "ebpbpbpbpbpc", "s00000000000"]},
+        {"ref": "web/features_map_test.go:173-177", "json": '{"metadata":{"key1":"value1","key2":"value2"}}',
+         "key": "metadata", "type": "map[string]string"},
+        {"ref": "web/features_map_test.go:179-183", "json": '{"counts":{"a":1,"b":2,"c":3}}',
+         "key": "counts", "type": "map[string]string"},
+        {"ref": "web/features_map_test.go:185-189", "json": '{"scores":{"x":1.5,"y":2.5,"z":3.5}}',
+         "key": "scores", "type": "map[string]string"},
+        {"ref": "web/features_map_test.go:191-195", "json": '{"config":{"name":"test","count":10,"rate":0.5}}',
+         "key": "config", "type": "map[string]string"},
+        {"ref": "web/features_map_test.go:197-201", "json": '{"tags":{"ids":[1,2,3],"nums":[10,20,30]}}',
+         "key": "tags", "type": "map[string][]string"},
+        {"ref": "web/features_map_test.go:203-207", "json": '{"names":{"first":["a","b"],"last":["c","d"]}}',
+         "key": "names", "type": "map[string][]string"},
+        {"ref": "web/features_map_test.go:209-213", "json": '{"nested":{"inner":{"key":"value"}}}',
+         "key": "nested", "type": "map[string]interface {}"},
+    ],
     "decode": [
         {"ref": "algorithm/eas/easyrec_response_test.go:44-72 (FloatVal [1,6] per item, value [1][5])",
          "float_val": [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.11, 0.22, 0.33, 0.44, 0.55, 0.66], "dim1": 6,

@@ -418,3 +418,21 @@ def test_ssd_quality_score_normalisation():
     assert o.ssd_quality(np.zeros(5), 1)[1] is False and o.ssd_quality(np.full(5, 0.3), 2)[1] is False
     assert o.ssd_quality(np.full(5, 0.3), 1)[1] is False                    # variance == 0
     assert np.array_equal(o.ssd_quality(rel, 0)[0], rel)
+
+
+def test_features_map_reference_known_answers(golden):
+    """web/features_map_test.go, transcribed: the request's `features` typing as the /api/recommend harness
+    restates it (tools/http_harness.py:features_map)."""
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import http_harness as hh
+    for c in golden["features_map"]:
+        value, typ = hh.features_map(c["json"])[c["key"]]
+        assert typ == c["type"], c["ref"]
+        if "value" in c:
+            assert value == c["value"], c["ref"]
+    # parseNumber: beyond int64 falls to float64; mixed arrays stay untouched
+    v, t = hh.features_map('{"big": 92233720368547758070, "mix": [1, [2]], "m": {"a": [1], "b": 2}}')["big"]
+    assert t == "float64" and v == 9.223372036854776e19
+    assert hh.features_map('{"mix": [1, true]}')["mix"][1] == "[]interface {}"
+    assert hh.features_map('{"m": {"a": [1], "b": 2}}')["m"] == ({"a": ["1"], "b": ["2"]}, "map[string][]string")

@@ -25,6 +25,95 @@ from http.server import BaseHTTPRequestHandler, HTTPServer
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# ---- FeaturesMap (web/features_map.go): the typing of the request's `features` object ------------------------
+class _Num(str):
+    """A JSON number kept as its literal text (Go's json.Number under decoder.UseNumber())."""
+
+
+def _parse_number(n: "_Num"):
+    # parseNumber (features_map.go:170-183): int64 first, then float64, else the literal
+    try:
+        i = int(n)
+        if "." not in n and "e" not in n.lower() and -2**63 <= i < 2**63:
+            return i
+    except ValueError:
+        pass
+    try:
+        return float(n)
+    except ValueError:
+        return str(n)
+
+
+def _format_value(v) -> str:
+    # formatValue (features_map.go:186-195): json.Number → literal text, string → itself, else %v
+    if isinstance(v, str):
+        return str(v)
+    if v is None:
+        return "<nil>"
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    return str(v)
+
+
+def _convert(v):
+    """convertValueToString: returns (value, go_type_name)."""
+    if v is None:
+        return None, "<nil>"
+    if isinstance(v, _Num):
+        x = _parse_number(v)
+        return x, ("int" if isinstance(x, int) else "float64" if isinstance(x, float) else "string")
+    if isinstance(v, list):
+        if not v:
+            return v, "[]interface {}"
+        scalar, nested, mixed = 0, 1, 2
+        kind = scalar
+        for e in v:                                               # convertArray (:55-113)
+            if isinstance(e, list):
+                if kind == scalar:
+                    kind = nested
+            elif isinstance(e, str):                              # json.Number or string
+                if kind == nested:
+                    kind = mixed
+            else:
+                kind = mixed
+            if kind == mixed:
+                break
+        if kind == nested:
+            return [[_format_value(x) for x in e] for e in v if isinstance(e, list)], "[][]string"
+        if kind == scalar:
+            return [_format_value(e) for e in v], "[]string"
+        return v, "[]interface {}"
+    if isinstance(v, dict):                                       # convertMap (:116-167)
+        has_array = any(isinstance(x, list) for x in v.values())
+        has_map = any(isinstance(x, dict) for x in v.values())
+        if has_map:
+            return {k: _convert(x)[0] for k, x in v.items()}, "map[string]interface {}"
+        if has_array:
+            out = {}
+            for k, x in v.items():
+                c, t = _convert(x)
+                if t == "[]string":
+                    out[k] = c
+                elif isinstance(c, list):
+                    out[k] = [_format_value(e) for e in c]
+                else:
+                    out[k] = [_format_value(x)]
+            return out, "map[string][]string"
+        return {k: _format_value(x) for k, x in v.items()}, "map[string]string"
+    if isinstance(v, bool):
+        return v, "bool"
+    return v, "string"
+
+
+def features_map(text: str):
+    """FeaturesMap.UnmarshalJSON: {name: (value, go type)} — numeric arrays become string arrays so that
+    large integers keep every digit (web/features_map_test.go)."""
+    temp = json.loads(text, parse_int=_Num, parse_float=_Num)
+    if not isinstance(temp, dict):
+        raise ValueError("json: cannot unmarshal into FeaturesMap")
+    return {k: _convert(v) for k, v in temp.items()}
+
+
 def load_host():
     L = C.CDLL(os.path.join(ROOT, "pairec_amd", "libpairec_host.so"))
     L.ph_last_error.restype = C.c_char_p
