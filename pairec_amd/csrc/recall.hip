@@ -1215,10 +1215,12 @@ static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
 
 static int dispatch_screen(pg_ctx* ctx, uint32_t dim, const ScreenArgs& a) {
     const bool wide = a.nq > 128;
-    // PG_SCREEN_SPLIT=1 selects the wave-pair variant (measured slower: 18.5 vs 15.2 ms per pass at
-    // 100M x 128 — DESIGN.md "what did not work"); kept for ablation runs.
+#ifdef PG_SCAN_VARIANTS
+    // PG_SCREEN_SPLIT=1 selects the wave-pair variant that fetches every block twice (measured slower: 8.3 vs
+    // 6.9 ms per 256-query pass — DESIGN.md "what did not work"); developer ablation builds only.
     static const bool split = getenv("PG_SCREEN_SPLIT") != nullptr;
     if (wide && split) return dim == 64 ? launch_screen<64, 4, 8, 2>(ctx, a) : launch_screen<128, 4, 8, 2>(ctx, a);
+#endif
     if (dim == 64) {
         if (wide) return launch_screen<64, 8, 4>(ctx, a);
         if (a.nq <= 32) return launch_screen<64, 1, 8>(ctx, a);
