@@ -31,7 +31,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 FLOPS_PER_ITEM = 524800        # SURVEY.md §8(d) cfg 3: 2*(256*512+512*256+256)
-RANK_EXPR = "${rank}*(1+${recall})^0.1"
+RANK_EXPR = "${gpu_dnn}*(1+${current_score})^0.1"      # RankConf.RankScore: model score x recall score
 
 
 def parse_args():
@@ -103,23 +103,18 @@ class Pipeline1:
         n = R * K
         m = ctx.malloc
         self.d_rows, self.d_scores = m(n * 8), m(n * 4)
-        self.d_local, self.d_rank = m(n * 4), m(n * 4)
-        self.d_vars, self.d_fused, self.d_order = m(2 * n * 8), m(n * 8), m(n * 4)
-        self.d_off = ctx.to_device((np.arange(R + 1) * K).astype(np.uint32))
+        self.d_rank = m(n * 4)
+        self.d_fused, self.d_order = m(n * 8), m(n * 4)
 
     def step(self, d_q, R=None):
+        """One request batch = ONE call into the library (pg_recommend_dnn3_dev): recall top-K → DNN3 rank of
+        every candidate → RankScore fusion → ItemRankScore sort, all device-resident."""
         from pairec_amd import _lib
-        import ctypes as C
         R = R or self.R
-        ctx, L, h, K = self.ctx, self.ctx.L, self.ctx.h, self.K
-        n = R * K
-        self.table.recall_topk_dev(d_q, R, K, self.d_rows, self.d_scores)
-        _lib.check(L.pg_rows_to_local_dev(h, self.table.h, self.d_rows, n, self.d_local, None))
-        self.model.rank_dnn3_dev(self.table, d_q, self.d_local, self.d_off, R, n, self.d_rank)
-        _lib.check(L.pg_widen_f32_dev(h, self.d_rank, n, self.d_vars))
-        _lib.check(L.pg_widen_f32_dev(h, self.d_scores, n, self.d_vars + n * 8))
-        _lib.check(L.pg_expr_eval_dev(h, self.expr.h, self.d_vars, n, self.d_fused))
-        _lib.check(L.pg_sort_scores_dev(h, self.d_fused, self.d_off, R, n, K, 1, self.d_order))
+        ctx = self.ctx
+        _lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, self.table.h, self.model.h, self.expr.h, b"gpu_dnn", d_q, R,
+                                               self.K, self.d_rows, self.d_scores, self.d_rank, self.d_fused,
+                                               self.d_order))
 
 
 def cpu_baseline(o, args, R, K):

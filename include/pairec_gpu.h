@@ -225,6 +225,20 @@ int pg_rank_fm2t_rows_dev(pg_ctx* ctx, const pg_model* m, const pg_features* fs,
                           const float* d_user_vecs, const int32_t* d_user_field_ids, const uint32_t* d_cand_rows,
                           const uint32_t* d_req_offsets, uint32_t n_req, uint32_t n_items, float* d_out_scores);
 
+/* ---- the whole hot path in one call ------------------------------------------------------------
+ * One request batch through VectorRecall.GetCandidateItems → RankService.Rank (one DNN3 rank algorithm) →
+ * RankScore fusion → ItemRankScoreSort (service/user_recommend.go:83-151 restricted to the hot path),
+ * device-resident: recall top-k of `t` for nq user vectors, rank every candidate with `m` (the same user
+ * vectors are the model's user features), fuse with `e` — whose variables must be `rank_var` (the model's
+ * name in RankAlgoList) and/or "current_score" (Item.Score, i.e. the recall score, module/item.go:189-212) —
+ * and sort each request's candidates by the fused score, descending.
+ * Outputs, all [nq][k]: global row ids and recall scores in recall order, the model's scores, the fused fp64
+ * scores (same order), and d_out_order = positions 0..k-1 of each request sorted by fused score. */
+int pg_recommend_dnn3_dev(pg_ctx* ctx, const pg_table* t, const pg_model* m, const pg_expr* e, const char* rank_var,
+                          const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
+                          float* d_out_recall_scores, float* d_out_rank_scores, double* d_out_fused,
+                          uint32_t* d_out_order);
+
 /* ---- stats ----------------------------------------------------------------------------------*/
 typedef struct {
     uint64_t recall_calls, recall_rows_scanned, recall_rescans;

@@ -23,7 +23,7 @@ EXPORTS = [
     "pg_dpp", "pg_stats", "pg_last_scan_kernel_ms", "pg_rows_to_local_dev", "pg_widen_f32_dev",
     "pg_hbm_read_probe", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
     "pg_features_column_index", "pg_features_num_columns", "pg_features_gather_i32_dev",
-    "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev",
+    "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev", "pg_recommend_dnn3_dev",
 ]
 
 
@@ -94,6 +94,7 @@ def load():
         "pg_features_gather_i32_dev": [vp, vp, vp, u32, vp, u32, vp],
         "pg_features_gather_f32_dev": [vp, vp, vp, u32, vp, vp, vp, u32, vp],
         "pg_rank_fm2t_rows_dev": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp],
+        "pg_recommend_dnn3_dev": [vp, vp, vp, vp, C.c_char_p, vp, u32, u32, vp, vp, vp, vp, vp],
         "pg_rows_to_local_dev": [vp, vp, vp, u32, vp, vp],
         "pg_widen_f32_dev": [vp, vp, u32, vp],
         "pg_stats": [vp, P(PgStats)],

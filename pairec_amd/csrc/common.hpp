@@ -70,7 +70,8 @@ struct pg_ctx {
     bool own_stream = false;
     int num_cus = 256;
     std::mutex mu;               // serialises calls on this context
-    pg::Scratch scratch[8];      // named scratch slots (see users)
+    pg::Scratch scratch[10];     // named scratch slots (see users; 8 = pg_recommend_dnn3_dev's intermediates)
+    std::mutex pipe_mu;          // serialises whole pg_recommend_* calls (they span several locked stages)
     std::map<const void*, size_t> dyn_lds;   // kernels whose dynamic-LDS limit was raised on this device
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;   // per-launch timing events (scan kernel roofline figure)

@@ -82,7 +82,7 @@ class GpuShardEngine:
         self.fused = torch.empty(n, dtype=torch.float64, device=dev)
         self.order = torch.empty(n, dtype=torch.int32, device=dev)
         self.seg = torch.arange(0, n + 1, k_max, dtype=torch.int32, device=dev)
-        assert expr.var_names == ["rank", "recall"]
+        assert expr.var_names == ["gpu_dnn", "current_score"]       # column order of the vars slab below
 
     def _check(self, rc):
         from . import _lib

@@ -698,3 +698,46 @@ def test_full_size_pipeline_properties(ctx):
     assert np.all(np.diff(sorted_scores, axis=1) <= 0)
     m.destroy()
     t.destroy()
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole hot path in one call
+# ---------------------------------------------------------------------------------------------
+def test_recommend_one_call_equals_the_stages(ctx):
+    """pg_recommend_dnn3_dev = recall → rank → fusion → sort behind one ABI call: every output equals what
+    the stage-by-stage calls produce, and the page order equals the oracle's sort of the fused scores."""
+    n, d, k, R = 150000, 128, 400, 37
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    w = o.Dnn3Weights()
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    ex = pa.Expr("${gpu_dnn}*(1+${current_score})^0.1")
+    q = o.synth_rows(o.SEED_QUERY, 11, R, d)
+    N = R * k
+    d_q = ctx.to_device(q)
+    d_rows, d_sc, d_rk, d_fu, d_or = (ctx.malloc(N * 8), ctx.malloc(N * 4), ctx.malloc(N * 4), ctx.malloc(N * 8),
+                                      ctx.malloc(N * 4))
+    pa._lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, t.h, m.h, ex.h, b"gpu_dnn", d_q, R, k, d_rows, d_sc, d_rk, d_fu, d_or))
+    rows, sc, rk = np.zeros((R, k), np.uint64), np.zeros((R, k), np.float32), np.zeros((R, k), np.float32)
+    fu, order = np.zeros((R, k), np.float64), np.zeros((R, k), np.uint32)
+    for a, p in ((rows, d_rows), (sc, d_sc), (rk, d_rk), (fu, d_fu), (order, d_or)):
+        ctx.d2h(a, p)
+    # stage by stage
+    r2, s2, _ = t.recall_topk(q, k)
+    assert np.array_equal(rows, r2) and np.array_equal(bits(sc), bits(s2))
+    off = (np.arange(R + 1) * k).astype(np.uint32)
+    rk2 = m.rank_dnn3(t, q, r2.reshape(-1).astype(np.uint32), off)
+    assert np.array_equal(bits(rk.reshape(-1)), bits(rk2))
+    cols = {"gpu_dnn": rk2.astype(np.float64), "current_score": s2.reshape(-1).astype(np.float64)}
+    fu2 = ex.eval(ctx, np.stack([cols[v] for v in ex.var_names]))
+    assert np.array_equal(fu.reshape(-1).view(np.uint64), fu2.view(np.uint64))
+    for r in range(R):
+        assert np.array_equal(order[r], o.sort_scores(fu[r], True))
+    # a RankScore that names an unknown variable is refused
+    bad = pa.Expr("${gpu_dnn}+${ctr}")
+    with pytest.raises(RuntimeError):
+        pa._lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, t.h, m.h, bad.h, b"gpu_dnn", d_q, R, k, d_rows, d_sc, d_rk, d_fu, d_or))
+    for p in (d_q, d_rows, d_sc, d_rk, d_fu, d_or):
+        ctx.free(p)
+    m.destroy()
+    t.destroy()
