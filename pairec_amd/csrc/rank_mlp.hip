@@ -19,123 +19,12 @@
 // that go through LDS (as the A operand of layer 2) and are consumed immediately, so h1 never
 // leaves the CU; weights are pre-packed in MFMA-fragment order so each B fragment is one
 // coalesced 1 KiB load shared by all of a wave's row blocks.
-#include "common.hpp"
+#include "rank_mlp.hpp"
 
 #include <algorithm>
 #include <cmath>
 
 namespace pg {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__host__ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
-    uint32_t b;
-#ifdef __HIP_DEVICE_COMPILE__
-    b = __float_as_uint(x);
-#else
-    memcpy(&b, &x, 4);
-#endif
-    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((b >> 16) | 0x0040u);
-    b += 0x7FFFu + ((b >> 16) & 1u);
-    return (uint16_t)(b >> 16);
-}
-__host__ __device__ __forceinline__ float bf16_to_f32(uint16_t v) {
-    uint32_t b = (uint32_t)v << 16;
-#ifdef __HIP_DEVICE_COMPILE__
-    return __uint_as_float(b);
-#else
-    float f;
-    memcpy(&f, &b, 4);
-    return f;
-#endif
-}
-__host__ __device__ __forceinline__ float round_prec(float x, int prec) {
-    return prec ? bf16_to_f32(f32_to_bf16_rne(x)) : x;
-}
-
-constexpr int kBM = 128;       // items per workgroup tile
-constexpr int kDIN = 128;      // gathered input width
-constexpr int kFmK = 16;       // FM embedding width
-constexpr int kFmFields = 8;   // item fields (= user fields)
-
-struct MlpArgs {
-    const uint32_t* tile_req;
-    const uint32_t* tile_item0;
-    const uint32_t* tile_cnt;
-    const uint32_t* n_tiles;
-    // DNN3 gather
-    const float* tab;
-    uint32_t tab_rows;
-    const uint32_t* cand_rows;
-    // two-tower gather
-    const float* const* field_emb;   // device array [16] of [vocab][16]
-    const float* const* field_lin;   // device array [16] of [vocab]
-    const int32_t* item_field_ids;   // [n_items][8]
-    uint32_t vocab;
-    const float* fm_user;            // [n_req][33]: linU, sU[16], qU[16]
-    // per request / shared vectors
-    const float* c1;
-    uint32_t c1_stride;
-    const float* w3;
-    uint32_t w3_stride;
-    float b3;
-    const float* b2;
-    // pre-packed weights
-    const void* w1p;
-    const void* w2p;
-    float* out;
-};
-
-template <int PREC>
-__device__ __forceinline__ void store_x_quad(char* tile, int row, int c, float4 v) {
-    if constexpr (PREC == 1) {
-        // 4 bf16 = 8 B at element 4c: 16-B quad index c/2, XOR-swizzled by row
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-        uint2 p;
-        p.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
-        p.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
-        *reinterpret_cast<uint2*>(tile + row * 256 + ((((c >> 1) ^ (row & 15))) << 4) + (c & 1) * 8) = p;
-    } else {
-        *reinterpret_cast<float4*>(tile + row * 512 + ((c ^ (row & 15)) << 4)) = v;
-    }
-}
-
-// element (row, col) of an LDS operand tile with K columns per row: 16-B quads XOR-swizzled by row
-template <int PREC, int K>
-__device__ __forceinline__ void store_h_elem(char* tile, int row, int col, float v) {
-    constexpr int ES = PREC ? 2 : 4;
-    constexpr int ROWB = K * ES;
-    constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
-    if constexpr (PREC == 1) {
-        *reinterpret_cast<uint16_t*>(tile + row * ROWB + ((((col >> 3) ^ (row & SW))) << 4) + (col & 7) * 2) =
-            f32_to_bf16_rne(v);
-    } else {
-        *reinterpret_cast<float*>(tile + row * ROWB + ((((col >> 2) ^ (row & SW))) << 4) + (col & 3) * 4) = v;
-    }
-}
-
-// 4 consecutive columns col..col+3 (col % 4 == 0) of one row, after relu and operand rounding
-template <int PREC, int K>
-__device__ __forceinline__ void store_h_quad(char* tile, int row, int col, float v0, float v1, float v2, float v3) {
-    constexpr int ES = PREC ? 2 : 4;
-    constexpr int ROWB = K * ES;
-    constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
-    if constexpr (PREC == 1) {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        const f32x2 lo = {v0, v1}, hi = {v2, v3};
-        uint2 p;
-        p.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
-        p.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
-        *reinterpret_cast<uint2*>(tile + row * ROWB + ((((col >> 3) ^ (row & SW))) << 4) + (col & 7) * 2) = p;
-    } else {
-        *reinterpret_cast<float4*>(tile + row * ROWB + ((((col >> 2) ^ (row & SW))) << 4)) = make_float4(v0, v1, v2, v3);
-    }
-}
 
 // C[rows of this wave][n-blocks] += A(tile in LDS)[rows][K] · B(pre-packed fragments)
 // frag(nb, step) returns the byte offset of the 1-KiB fragment for n-block nb and k-group `step`
@@ -531,44 +420,85 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// request → tile table.  One block; requests <= 65535 per call.
+// request → tile table.  One block of 1024 threads; requests <= 65535 per call.
+//   pass 1: tiles per request → exclusive prefix req_tile0 (chunked scan)
+//   pass 2: one thread per TILE (binary search of its request in the prefix), so the three tables are written
+//           with coalesced stores (one thread per request wrote them with a stride of a request's tile count:
+//           60 us for 256 requests x 79 tiles — as long as a tenth of the MLP it feeds)
 // ---------------------------------------------------------------------------------------------
-__global__ void build_tiles_kernel(const uint32_t* __restrict__ req_offsets, uint32_t n_req,
-                                   uint32_t* __restrict__ tile_req, uint32_t* __restrict__ tile_item0,
-                                   uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ n_tiles,
-                                   uint32_t* __restrict__ req_tile0) {
-    // pass 1: per-request tile counts → exclusive prefix in req_tile0 (serial, n_req is small)
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t r = 0; r < n_req; ++r) {
-            req_tile0[r] = acc;
-            acc += (req_offsets[r + 1] - req_offsets[r] + kBM - 1) / kBM;
-        }
-        *n_tiles = acc;
-    }
+constexpr uint32_t kTilesLdsReqs = 8192;     // prefix entries searched in LDS; beyond that, in global memory
+
+__global__ __launch_bounds__(1024) void build_tiles_kernel(
+    const uint32_t* __restrict__ req_offsets, uint32_t n_req, uint32_t* __restrict__ tile_req,
+    uint32_t* __restrict__ tile_item0, uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ n_tiles,
+    uint32_t* __restrict__ req_tile0, uint32_t tile_items) {
+    __shared__ uint32_t chunk_sum[1024];
+    __shared__ uint32_t pre[kTilesLdsReqs];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_req + 1023) / 1024;
+    const uint32_t r0 = tid * per, r1 = (r0 + per < n_req) ? r0 + per : n_req;
+    uint32_t sum = 0;
+    for (uint32_t r = r0; r < r1; ++r) sum += (req_offsets[r + 1] - req_offsets[r] + tile_items - 1) / tile_items;
+    chunk_sum[tid] = sum;
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < n_req; r += blockDim.x) {
-        const uint32_t b = req_offsets[r], e = req_offsets[r + 1];
-        uint32_t t = req_tile0[r];
-        for (uint32_t i = b; i < e; i += kBM, ++t) {
-            tile_req[t] = r;
-            tile_item0[t] = i;
-            tile_cnt[t] = (e - i < (uint32_t)kBM) ? e - i : (uint32_t)kBM;
+    for (uint32_t d = 1; d < 1024; d <<= 1) {            // inclusive scan of the chunk sums
+        const uint32_t v = tid >= d ? chunk_sum[tid - d] : 0;
+        __syncthreads();
+        chunk_sum[tid] += v;
+        __syncthreads();
+    }
+    uint32_t acc = chunk_sum[tid] - sum;
+    for (uint32_t r = r0; r < r1; ++r) {
+        req_tile0[r] = acc;
+        if (r < kTilesLdsReqs) pre[r] = acc;
+        acc += (req_offsets[r + 1] - req_offsets[r] + tile_items - 1) / tile_items;
+    }
+    const uint32_t total = chunk_sum[1023];
+    if (tid == 0) *n_tiles = total;
+    __syncthreads();                                      // pre[] and (through L2, same block) req_tile0[] complete
+    const bool in_lds = n_req <= kTilesLdsReqs;
+    for (uint32_t t = tid; t < total; t += 1024) {
+        // the last request whose first tile is <= t (requests without items share their successor's prefix and
+        // are skipped by taking the LAST such entry)
+        uint32_t lo = 0, hi = n_req - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            const uint32_t v = in_lds ? pre[mid] : req_tile0[mid];
+            if (v <= t) lo = mid;
+            else hi = mid - 1;
         }
+        const uint32_t first = in_lds ? pre[lo] : req_tile0[lo];
+        const uint32_t e = req_offsets[lo + 1];
+        const uint32_t i = req_offsets[lo] + (t - first) * tile_items;
+        tile_req[t] = lo;
+        tile_item0[t] = i;
+        tile_cnt[t] = (e - i < tile_items) ? e - i : tile_items;
     }
 }
 
 // DNN3 request-constant half of layer 1: c1[r][j] = chain(b1[j]; P(u[r][k]) * W1u[k][j], k asc)
-// (W1u is stored already rounded to the model's operand precision)
+// (W1u is stored already rounded to the model's operand precision).  The chain is sequential in k; its loads
+// are not — eight rows of W1u are requested before the eight fmafs that use them.
 __global__ void dnn3_user_partial_kernel(const float* __restrict__ user, uint32_t du,
                                          const float* __restrict__ w1u, const float* __restrict__ b1,
                                          uint32_t h1, int prec, float* __restrict__ c1) {
     const uint32_t r = blockIdx.x;
     const uint32_t j = blockIdx.y * blockDim.x + threadIdx.x;
     if (j >= h1) return;
+    const float* const u = user + (size_t)r * du;
     float acc = b1[j];
-    for (uint32_t k = 0; k < du; ++k)
-        acc = __fmaf_rn(round_prec(user[(size_t)r * du + k], prec), w1u[(size_t)k * h1 + j], acc);
+    uint32_t k = 0;
+    for (; k + 8 <= du; k += 8) {
+        float wv[8], uv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            wv[i] = w1u[(size_t)(k + i) * h1 + j];
+            uv[i] = round_prec(u[k + i], prec);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __fmaf_rn(uv[i], wv[i], acc);
+    }
+    for (; k < du; ++k) acc = __fmaf_rn(round_prec(u[k], prec), w1u[(size_t)k * h1 + j], acc);
     c1[(size_t)r * h1 + j] = acc;
 }
 
@@ -719,13 +649,16 @@ static int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* 
                                 const float* d_user, const uint32_t* d_cand, const uint32_t* d_off,
                                 uint32_t n_req, uint32_t n_items, float* d_out) {
     if (n_items == 0 || n_req == 0) return PG_OK;
-    const uint32_t max_tiles = n_items / kBM + n_req;
+    const uint32_t max_tiles = n_items / kWsItems + n_req;      // sized for the smaller (64-item) tiles
     RankScratch rs;
     int rc;
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->h1, &rs))) return rc;
+    static const bool no_ws = getenv("PG_RANK_NO_WS") != nullptr;        // A/B switch: the streaming kernel
+    const bool ws = m->prec && !no_ws;
+    const uint32_t grid128 = n_items / kBM + n_req;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    build_tiles_kernel<<<1, 256, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
-                                                   rs.n_tiles, rs.req_tile0);
+    build_tiles_kernel<<<1, 1024, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
+                                                   rs.n_tiles, rs.req_tile0, ws ? (uint32_t)kWsItems : (uint32_t)kBM);
     dnn3_user_partial_kernel<<<dim3(n_req, (m->h1 + 255) / 256), 256, 0, ctx->stream>>>(
         d_user, m->d_user, m->w1u, m->b1, m->h1, m->prec, rs.c1);
     MlpArgs a{};
@@ -745,16 +678,19 @@ static int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* 
     a.w1p = m->w1p;
     a.w2p = m->w2p;
     a.out = d_out;
-    if (m->prec) {
+    if (ws) {
+        // bf16: weights-stationary persistent kernel over 64-item tiles
+        if ((rc = launch_dnn3_ws(ctx, a))) return rc;
+    } else if (m->prec) {
         // bf16: 2 x 2 waves, 64-column chunks, two-pass head → 68 KB of LDS and <= 256 registers: two
         // workgroups per CU, so one's barriers and weight-fragment loads hide behind the other's MFMAs
         constexpr size_t lds = mlp_lds_bytes(1, 256, 64, 2);
         if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2>, lds))) return rc;
-        mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
+        mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2><<<grid128, 256, lds, ctx->stream>>>(a);
     } else {
         constexpr size_t lds = mlp_lds_bytes(0, 256, 128, 1);
         if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1>, lds))) return rc;
-        mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
+        mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1><<<grid128, 256, lds, ctx->stream>>>(a);
     }
     PG_HIP(hipGetLastError());
     PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -773,8 +709,8 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     int rc;
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->to, &rs))) return rc;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    build_tiles_kernel<<<1, 256, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
-                                                   rs.n_tiles, rs.req_tile0);
+    build_tiles_kernel<<<1, 1024, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
+                                                   rs.n_tiles, rs.req_tile0, (uint32_t)kBM);
     fm2t_user_kernel<<<n_req, 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th,
                                                      m->to, m->prec, m->d_field_emb, m->d_field_lin, d_ufids,
                                                      m->vocab, m->fm_b, rs.c1, rs.fm_user);

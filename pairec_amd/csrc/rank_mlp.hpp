@@ -1,0 +1,125 @@
+// rank_mlp.hpp — what the rank-stage kernels share: operand types, the bf16 rounding used on both sides of
+// the boundary, the kernel argument block and the swizzled LDS operand-tile stores (rank_mlp.hip, rank_ws.hip).
+#pragma once
+#include "common.hpp"
+
+#include <cstring>
+
+namespace pg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
+    uint32_t b;
+#ifdef __HIP_DEVICE_COMPILE__
+    b = __float_as_uint(x);
+#else
+    memcpy(&b, &x, 4);
+#endif
+    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((b >> 16) | 0x0040u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
+__host__ __device__ __forceinline__ float bf16_to_f32(uint16_t v) {
+    uint32_t b = (uint32_t)v << 16;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(b);
+#else
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+#endif
+}
+__host__ __device__ __forceinline__ float round_prec(float x, int prec) {
+    return prec ? bf16_to_f32(f32_to_bf16_rne(x)) : x;
+}
+
+constexpr int kBM = 128;       // items per workgroup tile
+constexpr int kDIN = 128;      // gathered input width
+constexpr int kFmK = 16;       // FM embedding width
+constexpr int kFmFields = 8;   // item fields (= user fields)
+
+struct MlpArgs {
+    const uint32_t* tile_req;
+    const uint32_t* tile_item0;
+    const uint32_t* tile_cnt;
+    const uint32_t* n_tiles;
+    // DNN3 gather
+    const float* tab;
+    uint32_t tab_rows;
+    const uint32_t* cand_rows;
+    // two-tower gather
+    const float* const* field_emb;   // device array [16] of [vocab][16]
+    const float* const* field_lin;   // device array [16] of [vocab]
+    const int32_t* item_field_ids;   // [n_items][8]
+    uint32_t vocab;
+    const float* fm_user;            // [n_req][33]: linU, sU[16], qU[16]
+    // per request / shared vectors
+    const float* c1;
+    uint32_t c1_stride;
+    const float* w3;
+    uint32_t w3_stride;
+    float b3;
+    const float* b2;
+    // pre-packed weights
+    const void* w1p;
+    const void* w2p;
+    float* out;
+};
+
+template <int PREC>
+__device__ __forceinline__ void store_x_quad(char* tile, int row, int c, float4 v) {
+    if constexpr (PREC == 1) {
+        // 4 bf16 = 8 B at element 4c: 16-B quad index c/2, XOR-swizzled by row
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+        uint2 p;
+        p.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+        p.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
+        *reinterpret_cast<uint2*>(tile + row * 256 + ((((c >> 1) ^ (row & 15))) << 4) + (c & 1) * 8) = p;
+    } else {
+        *reinterpret_cast<float4*>(tile + row * 512 + ((c ^ (row & 15)) << 4)) = v;
+    }
+}
+
+// element (row, col) of an LDS operand tile with K columns per row: 16-B quads XOR-swizzled by row
+template <int PREC, int K>
+__device__ __forceinline__ void store_h_elem(char* tile, int row, int col, float v) {
+    constexpr int ES = PREC ? 2 : 4;
+    constexpr int ROWB = K * ES;
+    constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
+    if constexpr (PREC == 1) {
+        *reinterpret_cast<uint16_t*>(tile + row * ROWB + ((((col >> 3) ^ (row & SW))) << 4) + (col & 7) * 2) =
+            f32_to_bf16_rne(v);
+    } else {
+        *reinterpret_cast<float*>(tile + row * ROWB + ((((col >> 2) ^ (row & SW))) << 4) + (col & 3) * 4) = v;
+    }
+}
+
+// 4 consecutive columns col..col+3 (col % 4 == 0) of one row, after relu and operand rounding
+template <int PREC, int K>
+__device__ __forceinline__ void store_h_quad(char* tile, int row, int col, float v0, float v1, float v2, float v3) {
+    constexpr int ES = PREC ? 2 : 4;
+    constexpr int ROWB = K * ES;
+    constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
+    if constexpr (PREC == 1) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const f32x2 lo = {v0, v1}, hi = {v2, v3};
+        uint2 p;
+        p.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+        p.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
+        *reinterpret_cast<uint2*>(tile + row * ROWB + ((((col >> 3) ^ (row & SW))) << 4) + (col & 7) * 2) = p;
+    } else {
+        *reinterpret_cast<float4*>(tile + row * ROWB + ((((col >> 2) ^ (row & SW))) << 4)) = make_float4(v0, v1, v2, v3);
+    }
+}
+
+// rank_ws.hip: the weights-stationary DNN3 kernel (bf16); `a` describes 64-item tiles
+constexpr int kWsItems = 64;
+int launch_dnn3_ws(pg_ctx* ctx, const MlpArgs& a);
+
+}  // namespace pg
