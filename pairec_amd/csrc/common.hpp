@@ -54,13 +54,19 @@ struct pg_table {
     uint64_t rows = 0;
     uint32_t dim = 0;
     uint64_t row_offset = 0;     // global row id of local row 0 (sharded tables)
-    // lazily computed for the screened recall (invalidated by upload / fill): statistics and the bf16
-    // shadow of the rows — RNE of every fp32 value, [rows + 64][dim] — that the screen streams instead of
-    // the fp32 rows (half the bytes; the exact re-scoring still gathers fp32)
+    // lazily computed for the screened recall (invalidated by upload / fill): statistics and the shadow of
+    // the rows that the screen streams instead of the fp32 rows (the exact re-scoring still gathers fp32):
+    //   dim 128: int8, X = rint(x / s8) with ONE scale s8 = max|x| / 127 for the table, [rows + 64][dim] bytes
+    //            — a quarter of the fp32 bytes; resid8 = max over rows of ||x - s8 X||_2 (measured, not assumed)
+    //   dim 64 : bf16 (RNE of every fp32 value), [rows + 64][dim] — half the bytes
     bool stats_valid = false;
     bool all_finite = false;
     float max_norm = 0.0f;       // upper bound of the rows' L2 norms
-    uint16_t* d16 = nullptr;     // allocated on first use, kept across rebuilds
+    uint16_t* d16 = nullptr;     // bf16 shadow; allocated on first use, kept across rebuilds
+    int8_t* d8 = nullptr;        // int8 shadow; likewise
+    bool shadow_is_i8 = false;   // which of the two the current statistics belong to
+    float s8 = 0.0f;             // int8 scale
+    float resid8 = 0.0f;         // upper bound of the rows' quantisation residual (L2)
     bool shadow_failed = false;  // allocation failed once: stay on the exact scan
 };
 

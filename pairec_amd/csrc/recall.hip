@@ -24,6 +24,8 @@
 #include "common.hpp"
 #include "bitonic_reg.hpp"
 
+#include <type_traits>
+
 namespace pg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -376,9 +378,9 @@ constexpr int kScreenLds = 163840;              // the whole LDS of a CU: ring (
 constexpr float kScreenEps = 0.008f;
 
 struct ScreenArgs {
-    const uint16_t* tab16;    // bf16 shadow of the table (pg_table::d16)
-    const uint4* qb16;        // [NQB][DIM/16][64] bf16x8 B fragments
-    const float* thr_screen;  // [256] thr - eps, rounded down
+    const void* tab16;        // shadow of the table: bf16 (pg_table::d16) or int8 (pg_table::d8)
+    const uint4* qb16;        // [NQB][KS][64] B fragments: 8 bf16 (KS = DIM/16) or 16 int8 (KS = DIM/32) per lane
+    const float* thr_screen;  // [256] bf16: thr - eps, rounded down; int8: the same in integer dot units (int32 bits)
     uint32_t* susp_cnt;       // [256] suspects per query of this launch
     uint32_t* susp;           // [256][cap] suspect rows (passed the bf16 screen; re-scored by rescore_kernel)
     uint32_t* overflow;
@@ -394,15 +396,24 @@ struct ScreenArgs {
 // 128 registers (two waves per SIMD) — 256 queries per pass without the one-wave-per-SIMD penalty.
 // VAR: developer ablations (PG_SCAN_VARIANTS builds only; 0 = product; 1 = no screen test; 2 = no MFMA and
 // no test; 3 = no DMA; 4 = test but never take the hit path) — they time the components, results are wrong
-template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0>
+// I8: the shadow and the queries are int8 and the bound is an exact int32 dot product on
+// v_mfma_i32_32x32x32_i8 — same issue rate as the bf16 MFMA at twice the k per instruction, over half the
+// bytes per row.
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // the kernel streams the table's bf16 shadow: a piece is 32 rows x 64 columns (one 128-B line per row)
-    constexpr int kCols16 = 64;
+    // the kernel streams the table's shadow: a piece is 32 rows x one 128-B line per row (64 bf16 / 128 int8)
+    constexpr int EB = I8 ? 1 : 2;               // bytes per shadow element
+    constexpr int kCols16 = 128 / EB;
+    static_assert(DIM % kCols16 == 0, "a shadow row is a whole number of 128-B lines");
     constexpr int PPB = DIM / kCols16;           // pieces per 32-row block (1 or 2)
     constexpr int NS = kScanLdsRing / (WAVES * kPieceBytes);        // ring slots per wave
     constexpr int ND = kPieceDmas;
-    constexpr int KS = DIM / 16;                 // bf16 k-steps
+    constexpr int KS = DIM * EB / 32;            // k-steps: 16 bf16 or 32 int8 (32 B of a row) each
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    using AccT = typename std::conditional<I8, i32x16, f32x16>::type;
+    using ThrT = typename std::conditional<I8, int, float>::type;
     constexpr int kStageBytesW = (kScreenLds - kScanLdsRing) / WAVES;
     constexpr int kCap = (kStageBytesW - NQB * 256 - 16) / 8;       // staged (row, query) pairs per wave
     constexpr int kScanWaves = WAVES;            // (shadows the exact kernel's constant in this scope)
@@ -417,14 +428,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
 
     // B operand: bfrag[c][ks] = Q[c*32 + (lane&31)][ks*16 + 8h .. +7] as bf16
     uint4 bfrag[NQB][KS];
-    float thr_s[NQB];
+    ThrT thr_s[NQB];
     bool active[NQB];
 #pragma unroll
     for (int c = 0; c < NQB; ++c) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bfrag[c][ks] = a.qb16[((qb0 + c) * KS + ks) * 64 + lane];
         active[c] = (uint32_t)((qb0 + c) * 32 + i32) < a.nq;
-        thr_s[c] = active[c] ? a.thr_screen[(qb0 + c) * 32 + i32] : __builtin_inff();
+        if constexpr (I8) thr_s[c] = active[c] ? __float_as_int(a.thr_screen[(qb0 + c) * 32 + i32]) : 0x7fffffff;
+        else thr_s[c] = active[c] ? a.thr_screen[(qb0 + c) * 32 + i32] : __builtin_inff();
     }
 #pragma unroll
     for (int c = 0; c < NQB; ++c) {
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     for (int n = 0; n < ND; ++n) {
         const int S = n * 64 + lane;
         const int i = S >> 3, p = S & 7;
-        voff[n] = (uint32_t)(i * DIM * 2 + 16 * ((p + (i >> 1)) & 7));       // row i, rotated 16-B quad p
+        voff[n] = (uint32_t)(i * DIM * EB + 16 * ((p + (i >> 1)) & 7));      // row i, rotated 16-B quad p
     }
     const uint32_t lds_wave_u = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + wave * (NS * kPieceBytes));
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     // block being scored (compile-time offset), global piece counter t for the ring slot
     auto piece_addr = [&](int rel_piece, uint32_t t, const char*& ub, uint32_t& dst) {
         const uint32_t ph = phys[rel_piece / PPB];
-        const char* base = (const char*)a.tab16 + (uint64_t)ph * (uint64_t)(kPieceRows * DIM * 2) + (rel_piece % PPB) * (kCols16 * 2);
+        const char* base = (const char*)a.tab16 + (uint64_t)ph * (uint64_t)(kPieceRows * DIM * EB) + (rel_piece % PPB) * 128;
         const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)base >> 32));
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
         ub = (const char*)(((uint64_t)hi << 32) | lo);
@@ -543,11 +555,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     }
 
     for (uint32_t b = 0; b < nblk; ++b) {
-        f32x16 acc[NQB];
+        AccT acc[NQB];
 #pragma unroll
         for (int c = 0; c < NQB; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0;
 #pragma unroll
         for (int pc = 0; pc < PPB; ++pc) {
             const uint32_t t = b * PPB + pc;
@@ -556,8 +568,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
             uint32_t nb_dst;
             piece_addr(pc + NS - 1, t + NS - 1, nb_src, nb_dst);
             const char* slot = lds_ptr + (t % NS) * kPieceBytes + rd_row;
-            // A fragment of k-step ksl (16 bf16 columns of the piece = quads 2ksl, 2ksl+1 of the row): this
-            // lane's 8 columns are quad 2ksl + h — one ds_read_b128 is one MFMA operand, no conversion
+            // A fragment of k-step ksl (32 B of the row = quads 2ksl, 2ksl+1: 16 bf16 or 32 int8 columns): this
+            // lane's half is quad 2ksl + h — one ds_read_b128 is one MFMA operand, no conversion
             f32x4 q4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -577,8 +589,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                     continue;
                 }
 #pragma unroll
-                for (int c = 0; c < NQB; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfrag[c][ks]), acc[c], 0, 0, 0);
+                for (int c = 0; c < NQB; ++c) {
+                    if constexpr (I8)
+                        acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, q4[ksl]),
+                                                                       __builtin_bit_cast(i32x4, bfrag[c][ks]), acc[c], 0, 0, 0);
+                    else
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfrag[c][ks]), acc[c], 0, 0, 0);
+                }
             }
         }
         const uint32_t cur_phys = phys[0];
@@ -602,10 +619,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         uint64_t any_mask = 0;
 #pragma unroll
         for (int c = 0; c < NQB; ++c) {
-            float m = acc[c][0];
+            if constexpr (I8) {
+                int m = acc[c][0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[c][r]);
-            cmask[c] = __builtin_amdgcn_ballot_w64(!(m < thr_s[c]));
+                for (int r = 1; r < 16; ++r) m = acc[c][r] > m ? acc[c][r] : m;
+                cmask[c] = __builtin_amdgcn_ballot_w64(m >= thr_s[c]);
+            } else {
+                float m = acc[c][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[c][r]);
+                cmask[c] = __builtin_amdgcn_ballot_w64(!(m < thr_s[c]));
+            }
             any_mask |= cmask[c];
         }
         if (VAR == 4) any_mask = 0;
@@ -620,9 +644,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 // chains above, so the MFMA → VALU hazard the compiler cannot see inside asm is covered.
                 uint32_t m16 = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                 : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[c]) : "vcc");
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (I8)
+                        asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                     : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[c]) : "vcc");
+                    else
+                        asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                     : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[c]) : "vcc");
+                }
                 if (row0 + kPieceRows > a.row_end) {        // last block of a ragged table: drop rows past the end
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -773,6 +802,164 @@ __global__ void screen_thr_kernel(const float* __restrict__ thr, const float* __
     // passes the screen and the exact re-scoring decides
     if (!(e == e) || e > 1e30f) v = -__builtin_inff();
     thr_screen[q] = v;
+}
+
+// ---- int8 screen (dim 128).  x^ = s_x X, q^ = s_q Q with X, Q in [-127, 127]; the MFMA gives the integer dot
+// product I = sum X_i Q_i exactly.  For the true score s = sum x_i q_i (real arithmetic):
+//     s - s_x s_q I = sum (x_i - x^_i) q_i + sum x^_i (q_i - q^_i)
+//     |s - s_x s_q I| <= ||x - x^|| ||q|| + ||x^|| ||q - q^||  <=  R ||q|| + (N + R) ||q - q^||
+// with R = max row residual (pg_table::resid8, measured when the shadow is built), N = max row norm.  eps_q is
+// that bound plus 1e-5 N ||q|| for the rounding of the specification's fp32 fmaf chain (<= 128 * 2^-24 N ||q||).
+// A row can reach thr only if  I >= (thr - eps_q) / (s_x s_q): the screen compares integers.
+// per call: int8 B fragments of the (zero-padded) queries, eps_q and the per-query scale s_q = max|q| / 127
+__global__ __launch_bounds__(1024) void screen_prep8_kernel(const float* __restrict__ qpad, uint32_t dim,
+                                                             float max_norm, float resid, uint4* __restrict__ qb8,
+                                                             float* __restrict__ eps, float* __restrict__ qscale) {
+    __shared__ float sq[kMaxQueries];
+    const uint32_t tid = threadIdx.x;
+    if (tid < (uint32_t)kMaxQueries) {
+        const float* q = qpad + (size_t)tid * dim;
+        float mx = 0.0f;
+        bool bad = false;
+        for (uint32_t k = 0; k < dim; ++k) {
+            const float v = fabsf(q[k]);
+            if (!(v <= 3.0e38f)) bad = true;
+            mx = fmaxf(mx, v);
+        }
+        const float sc = fmaxf(mx / 127.0f, 1e-30f);
+        double ss = 0.0, dd = 0.0;
+        for (uint32_t k = 0; k < dim; ++k) {
+            const double v = (double)q[k];
+            int Q = __float2int_rn(q[k] / sc);
+            Q = Q > 127 ? 127 : (Q < -127 ? -127 : Q);
+            const double d = v - (double)sc * (double)Q;
+            ss += v * v;
+            dd += d * d;
+        }
+        const double nq = sqrt(ss), dq = sqrt(dd);
+        const double e = ((double)resid * nq + ((double)max_norm + (double)resid) * dq) * 1.0001 +
+                         1e-5 * (double)max_norm * nq + 1e-30;
+        eps[tid] = bad ? __builtin_nanf("") : (float)(e * 1.000001);      // upper bound in fp32
+        qscale[tid] = sc;
+        sq[tid] = sc;
+    }
+    __syncthreads();
+    const uint32_t KS = dim / 32;
+    for (uint32_t i = tid; i < (uint32_t)kScreenMaxNQB * KS * 64; i += blockDim.x) {
+        const uint32_t lane = i & 63, ks = (i >> 6) % KS, c = (i >> 6) / KS;
+        const uint32_t qi = c * 32 + (lane & 31);
+        const float* q = qpad + (size_t)qi * dim + ks * 32 + 16 * (lane >> 5);
+        const float sc = sq[qi];
+        uint32_t w[4];
+        for (int e = 0; e < 4; ++e) {
+            uint32_t word = 0;
+            for (int b = 0; b < 4; ++b) {
+                int Q = __float2int_rn(q[4 * e + b] / sc);
+                Q = Q > 127 ? 127 : (Q < -127 ? -127 : Q);
+                word |= (uint32_t)(Q & 0xff) << (8 * b);
+            }
+            w[e] = word;
+        }
+        qb8[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// integer screen threshold: T = floor((thr - eps) / (s_x s_q)) - 1 as int32 bits (INT_MIN: everything passes)
+__global__ void screen_thr8_kernel(const float* __restrict__ thr, const float* __restrict__ eps,
+                                   const float* __restrict__ qscale, float s_x, float* __restrict__ thr_screen) {
+    const uint32_t q = threadIdx.x;
+    if (q >= (uint32_t)kMaxQueries) return;
+    const float t = thr[q], e = eps[q];
+    int T = (int)0x80000000;
+    if (e == e && e <= 1e30f && t == t && t > -__builtin_inff()) {
+        const double v = floor(((double)t - (double)e) / ((double)s_x * (double)qscale[q])) - 1.0;
+        T = v >= 2147483647.0 ? 0x7fffffff : (v <= -2147483648.0 ? (int)0x80000000 : (int)v);
+    }
+    thr_screen[q] = __int_as_float(T);
+}
+
+// Table statistics without a shadow (first pass of the int8 build): max |x|, max row L2 norm^2, finiteness.
+template <int DIM>
+__global__ __launch_bounds__(256) void table_stats_kernel(const float* __restrict__ tab, uint64_t rows,
+                                                          float* __restrict__ out_max, uint32_t* __restrict__ out_nonfinite,
+                                                          float* __restrict__ out_absmax) {
+    constexpr int G = DIM / 8;
+    __shared__ float smax[4], samax[4];
+    __shared__ uint32_t sbad[4];
+    const uint64_t n8 = rows * (uint64_t)G;
+    float mx = 0.0f, amx = 0.0f;
+    uint32_t bad = 0;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ((n8 + 63) & ~63ull);
+         g += (uint64_t)gridDim.x * blockDim.x) {
+        float ss = 0.0f;
+        if (g < n8) {
+            const float4 a = reinterpret_cast<const float4*>(tab)[2 * g];
+            const float4 b = reinterpret_cast<const float4*>(tab)[2 * g + 1];
+            ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+            amx = fmaxf(amx, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                                   fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+        }
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) ss += __shfl_xor(ss, off, 64);
+        if (!(ss < 3.0e38f)) bad = 1;
+        mx = fmaxf(mx, ss);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        amx = fmaxf(amx, __shfl_xor(amx, off, 64));
+        bad |= (uint32_t)__shfl_xor((int)bad, off, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smax[w] = mx; samax[w] = amx; sbad[w] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(reinterpret_cast<uint32_t*>(out_max), __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))));
+        atomicMax(reinterpret_cast<uint32_t*>(out_absmax),
+                  __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3]))));
+        if (sbad[0] | sbad[1] | sbad[2] | sbad[3]) atomicOr(out_nonfinite, 1u);
+    }
+}
+
+// Second pass: the int8 shadow X = clamp(rint(x / s), +-127) and the largest row residual ||x - s X||^2.
+// A thread converts 8 consecutive values (one 8-byte store); DIM/8 neighbouring lanes share a row.
+template <int DIM>
+__global__ __launch_bounds__(256) void table_quant8_kernel(const float* __restrict__ tab, uint64_t rows, float s,
+                                                           int8_t* __restrict__ out8, float* __restrict__ out_resid) {
+    constexpr int G = DIM / 8;
+    __shared__ float smax[4];
+    const uint64_t n8 = rows * (uint64_t)G;
+    const float inv = 1.0f / s;
+    float mx = 0.0f;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ((n8 + 63) & ~63ull);
+         g += (uint64_t)gridDim.x * blockDim.x) {
+        float rs = 0.0f;
+        if (g < n8) {
+            const float4 a = reinterpret_cast<const float4*>(tab)[2 * g];
+            const float4 b = reinterpret_cast<const float4*>(tab)[2 * g + 1];
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t w[2] = {0, 0};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int X = __float2int_rn(v[i] * inv);
+                X = X > 127 ? 127 : (X < -127 ? -127 : X);
+                const float r = __fmaf_rn(-s, (float)X, v[i]);
+                rs = __fmaf_rn(r, r, rs);
+                w[i >> 2] |= (uint32_t)(X & 0xff) << (8 * (i & 3));
+            }
+            reinterpret_cast<uint2*>(out8)[g] = make_uint2(w[0], w[1]);
+        }
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) rs += __shfl_xor(rs, off, 64);
+        mx = fmaxf(mx, rs);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) smax[w] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<uint32_t*>(out_resid), __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))));
 }
 
 // Table preparation for the screen, one coalesced pass: the bf16 shadow of the rows (RNE, what
@@ -1115,6 +1302,7 @@ struct RecallScratch {
     float* thr_screen;
     uint32_t* susp_cnt;      // [kMaxQueries]
     uint32_t* susp;          // [kMaxQueries][cap] suspect rows of the current launch
+    float* qscale;           // [kMaxQueries] int8 screen: the queries' scales
 };
 
 constexpr uint32_t kFirstChunkRows = 32768;
@@ -1126,7 +1314,7 @@ static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* 
     void* small;
     int rc;
     const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
-    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 20 + 1024;
+    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 24 + 1024;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
     rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
@@ -1136,6 +1324,7 @@ static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* 
     rs->cnt = (uint32_t*)(rs->thr_screen + kMaxQueries);
     rs->susp_cnt = rs->cnt + kMaxQueries;
     rs->overflow = rs->susp_cnt + kMaxQueries;
+    rs->qscale = (float*)(rs->overflow + 64);
     void* c;
     if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4), &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
@@ -1164,12 +1353,58 @@ static int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, 
     return PG_OK;
 }
 
-// statistics + bf16 shadow of a table (lazily, cached until the next upload / fill).  Tables the screen
-// cannot serve (dim other than 64 / 128, no memory for the shadow) keep stats_valid = false.
+// statistics + shadow of a table (lazily, cached until the next upload / fill): int8 for dim 128 (two passes:
+// statistics, then quantisation with the table's scale), bf16 for dim 64 or when PG_SCREEN_BF16 is set (A/B runs).
+// Tables the screen cannot serve (other dims, no memory for the shadow) keep stats_valid = false.
 static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     pg_table* t = const_cast<pg_table*>(tc);          // lazily computed cache
     if (t->stats_valid || t->shadow_failed) return PG_OK;
     if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
+    static const bool force_bf16 = getenv("PG_SCREEN_BF16") != nullptr;
+    const bool i8 = t->dim == 128 && !force_bf16;
+    void* p;
+    int rc;
+    if ((rc = scratch_reserve(ctx, 4, 4096, &p))) return rc;
+    float* d_max = (float*)p + 300;                   // [300] max norm^2, [301] non-finite flag, [302] max |x|, [303] max residual^2
+    uint32_t* d_bad = (uint32_t*)p + 301;
+    PG_HIP(hipMemsetAsync(d_max, 0, 16, ctx->stream));
+    const uint32_t grid = (uint32_t)ctx->num_cus * 16;
+    if (i8) {
+        if (!t->d8) {
+            const size_t bytes = (t->rows + 64) * (size_t)t->dim;
+            if (hipMalloc((void**)&t->d8, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                t->d8 = nullptr;
+                t->shadow_failed = true;              // stay on the exact scan
+                return PG_OK;
+            }
+            PG_HIP(hipMemsetAsync(t->d8 + t->rows * (size_t)t->dim, 0, 64 * (size_t)t->dim, ctx->stream));
+        }
+        table_stats_kernel<128><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, d_max, d_bad, d_max + 2);
+        PG_HIP(hipGetLastError());
+        PG_HIP(hipMemcpyAsync(ctx->h_status + 300, d_max, 16, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(hipStreamSynchronize(ctx->stream));
+        float mx, amx;
+        memcpy(&mx, ctx->h_status + 300, 4);
+        memcpy(&amx, ctx->h_status + 302, 4);
+        t->all_finite = ctx->h_status[301] == 0;
+        t->max_norm = sqrtf(mx) * 1.0001f;
+        t->s8 = fmaxf(amx / 127.0f, 1e-30f);
+        t->resid8 = 0.0f;
+        if (t->all_finite) {
+            table_quant8_kernel<128><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->s8, t->d8, d_max + 3);
+            PG_HIP(hipGetLastError());
+            PG_HIP(hipMemcpyAsync(ctx->h_status + 303, d_max + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
+            PG_HIP(hipStreamSynchronize(ctx->stream));
+            float r2;
+            memcpy(&r2, ctx->h_status + 303, 4);
+            // (the residuals were accumulated in fp32: a relative 1e-3 and an absolute 1e-6 N cover that)
+            t->resid8 = sqrtf(r2) * 1.001f + 1e-6f * t->max_norm;
+        }
+        t->shadow_is_i8 = true;
+        t->stats_valid = true;
+        return PG_OK;
+    }
     if (!t->d16) {
         const size_t bytes = (t->rows + 64) * (size_t)t->dim * 2;
         if (hipMalloc((void**)&t->d16, bytes) != hipSuccess) {
@@ -1180,13 +1415,6 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
         }
         PG_HIP(hipMemsetAsync(t->d16 + t->rows * (size_t)t->dim, 0, 64 * (size_t)t->dim * 2, ctx->stream));
     }
-    void* p;
-    int rc;
-    if ((rc = scratch_reserve(ctx, 4, 4096, &p))) return rc;
-    float* d_max = (float*)p + 300;
-    uint32_t* d_bad = (uint32_t*)p + 301;
-    PG_HIP(hipMemsetAsync(d_max, 0, 8, ctx->stream));
-    const uint32_t grid = (uint32_t)ctx->num_cus * 16;
     if (t->dim == 64) table_shadow_kernel<64><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->d16, d_max, d_bad);
     else table_shadow_kernel<128><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->d16, d_max, d_bad);
     PG_HIP(hipGetLastError());
@@ -1196,25 +1424,39 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     memcpy(&mx, ctx->h_status + 300, 4);
     t->all_finite = ctx->h_status[301] == 0;
     t->max_norm = sqrtf(mx) * 1.0001f;
+    t->shadow_is_i8 = false;
     t->stats_valid = true;
     return PG_OK;
 }
 
-template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0>
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false>
 static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     int rc_attr;
-    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR>, kScreenLds))) return rc_attr;
+    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8>, kScreenLds))) return rc_attr;
     const uint32_t total = a.rb_end - a.rb_begin;
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total * SPLIT + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
-    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
+    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
 
-static int dispatch_screen(pg_ctx* ctx, uint32_t dim, const ScreenArgs& a) {
+static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs& a) {
     const bool wide = a.nq > 128;
+    if (i8) {                                        // int8 shadow (dim 128)
+#ifdef PG_SCAN_VARIANTS
+        const char* v = getenv("PG_SCREEN_VAR");     // developer ablation builds only
+        if (wide && v && v[0] == '1') return launch_screen<128, 8, 4, 1, 1, true>(ctx, a);
+        if (wide && v && v[0] == '2') return launch_screen<128, 8, 4, 1, 2, true>(ctx, a);
+        if (wide && v && v[0] == '3') return launch_screen<128, 8, 4, 1, 3, true>(ctx, a);
+        if (wide && v && v[0] == '4') return launch_screen<128, 8, 4, 1, 4, true>(ctx, a);
+#endif
+        if (wide) return launch_screen<128, 8, 4, 1, 0, true>(ctx, a);
+        if (a.nq <= 32) return launch_screen<128, 1, 8, 1, 0, true>(ctx, a);
+        if (a.nq <= 64) return launch_screen<128, 2, 8, 1, 0, true>(ctx, a);
+        return launch_screen<128, 4, 8, 1, 0, true>(ctx, a);
+    }
 #ifdef PG_SCAN_VARIANTS
     // PG_SCREEN_SPLIT=1 selects the wave-pair variant that fetches every block twice (measured slower: 8.3 vs
     // 6.9 ms per 256-query pass — DESIGN.md "what did not work"); developer ablation builds only.
@@ -1323,7 +1565,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
         PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev], ctx->stream));
         if (screen && !thr_is_open) {
             ScreenArgs sa;
-            sa.tab16 = t->d16;
+            sa.tab16 = t->shadow_is_i8 ? (const void*)t->d8 : (const void*)t->d16;
             sa.qb16 = rs.qb16;
             sa.thr_screen = rs.thr_screen;
             sa.susp_cnt = rs.susp_cnt;
@@ -1339,7 +1581,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             sa.perm_mod = sample_blocks;
             int rc2;
             PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
-            if ((rc2 = dispatch_screen(ctx, t->dim, sa))) return rc2;
+            if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) return rc2;
             // exact re-scoring of the launch's suspects → candidate keys (grid.x strides over each list)
             const dim3 rg(kRescoreBlocksPerQuery, nq);
             if (t->dim == 64)
@@ -1383,7 +1625,8 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
         int rc2;
         if ((rc2 = launch_select(ctx, nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk))) return rc2;
         if (screen) {
-            screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.thr_screen);
+            if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
+            else screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.thr_screen);
             PG_HIP(hipGetLastError());
         }
         cur ^= 1;
@@ -1423,8 +1666,12 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             d_queries, nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
         PG_HIP(hipGetLastError());
         if (screen) {
-            screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
-                rs.qpad, t->dim, t->max_norm, rs.qb16, rs.eps);
+            if (t->shadow_is_i8)
+                screen_prep8_kernel<<<1, 1024, 0, ctx->stream>>>(rs.qpad, t->dim, t->max_norm, t->resid8, rs.qb16, rs.eps,
+                                                                 rs.qscale);
+            else
+                screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
+                    rs.qpad, t->dim, t->max_norm, rs.qb16, rs.eps);
             PG_HIP(hipGetLastError());
         }
         cur = 0;
@@ -1501,7 +1748,8 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
     ctx->stats.last_recall_ms = total_ms;
     ctx->last_scan_ms = scan_ms;
     ctx->last_scan_launches = scan_launches;
-    ctx->last_scan_bytes = scanned_rows * (uint64_t)t->dim * 4;
+    // bytes the scan launches streamed: the shadow's element size when the pass was screened
+    ctx->last_scan_bytes = scanned_rows * (uint64_t)t->dim * (screen ? (t->shadow_is_i8 ? 1 : 2) : 4);
     return PG_OK;
 }
 
