@@ -399,7 +399,10 @@ struct ScreenArgs {
 // I8: the shadow and the queries are int8 and the bound is an exact int32 dot product on
 // v_mfma_i32_32x32x32_i8 — same issue rate as the bf16 MFMA at twice the k per instruction, over half the
 // bytes per row.
-template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false>
+// QH: query halves — the wave serves NQB x QH query blocks, QH groups of NQB one after the other on the same table
+// block, re-using the accumulators (int8, 256 queries: 2 x 4 blocks in 8 waves — two waves per SIMD, so one
+// wave's test, hit path and DMA issue run under the other's MFMAs; all 128 B-operand registers in the AGPR half).
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the kernel streams the table's shadow: a piece is 32 rows x one 128-B line per row (64 bf16 / 128 int8)
@@ -414,35 +417,53 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     using AccT = typename std::conditional<I8, i32x16, f32x16>::type;
     using ThrT = typename std::conditional<I8, int, float>::type;
-    constexpr int kStageBytesW = (kScreenLds - kScanLdsRing) / WAVES;
-    constexpr int kCap = (kStageBytesW - NQB * 256 - 16) / 8;       // staged (row, query) pairs per wave
+    // (query halves: the last two B fragments sit in LDS — 2 KiB for the workgroup — because the allocator wants a
+    // few registers of the AGPR half for itself and would otherwise bring two fragments back from scratch per block,
+    // behind an s_waitcnt vmcnt(0) that also drains the DMA ring)
+    constexpr int kBLds = QH > 1 ? 2048 : 0;
+    constexpr int kStageBytesW = (kScreenLds - kScanLdsRing - kBLds) / WAVES;
+    constexpr int NQT = NQB * QH;                // query blocks of this wave
+    static_assert(QH == 1 || (PPB == 1 && SPLIT == 1), "query halves: one piece per block");
+    constexpr int kCap = (kStageBytesW - NQT * 256 - 16) / 8;       // staged (row, query) pairs per wave
     constexpr int kScanWaves = WAVES;            // (shadows the exact kernel's constant in this scope)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw_raw = blockIdx.x * kScanWaves + wave;
     const uint32_t gw = gw_raw / SPLIT;                          // block-run owner (shared by a wave group)
     const uint32_t W = gridDim.x * kScanWaves / SPLIT;
-    const int qb0 = (int)(gw_raw % SPLIT) * NQB;                 // first query block of this wave
+    const int qb0 = (int)(gw_raw % SPLIT) * NQT;                 // first query block of this wave
     const int i32 = lane & 31;
     const int h = lane >> 5;
 
     // B operand: bfrag[c][ks] = Q[c*32 + (lane&31)][ks*16 + 8h .. +7] as bf16
-    uint4 bfrag[NQB][KS];
-    ThrT thr_s[NQB];
-    bool active[NQB];
+    uint4 bfrag[NQT][KS];
+    ThrT thr_s[NQT];
+    bool active[NQT];
+    char* const b_lds = smem + kScreenLds - kBLds;
+    if constexpr (QH > 1) {
+        if (wave == 0) {
+            *reinterpret_cast<uint4*>(b_lds + lane * 16) = a.qb16[((qb0 + NQT - 1) * KS + KS - 2) * 64 + lane];
+            *reinterpret_cast<uint4*>(b_lds + 1024 + lane * 16) = a.qb16[((qb0 + NQT - 1) * KS + KS - 1) * 64 + lane];
+        }
+        __syncthreads();
+    }
 #pragma unroll
-    for (int c = 0; c < NQB; ++c) {
+    for (int c = 0; c < NQT; ++c) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bfrag[c][ks] = a.qb16[((qb0 + c) * KS + ks) * 64 + lane];
+        for (int ks = 0; ks < KS; ++ks) {
+            if (QH > 1 && c == NQT - 1 && ks >= KS - 2) bfrag[c][ks] = make_uint4(0, 0, 0, 0);     // (in LDS; unused)
+            else bfrag[c][ks] = a.qb16[((qb0 + c) * KS + ks) * 64 + lane];
+        }
         active[c] = (uint32_t)((qb0 + c) * 32 + i32) < a.nq;
         if constexpr (I8) thr_s[c] = active[c] ? __float_as_int(a.thr_screen[(qb0 + c) * 32 + i32]) : 0x7fffffff;
         else thr_s[c] = active[c] ? a.thr_screen[(qb0 + c) * 32 + i32] : __builtin_inff();
     }
 #pragma unroll
-    for (int c = 0; c < NQB; ++c) {
+    for (int c = 0; c < NQT; ++c) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (NQB > 4)     // 256 B registers: park them in the AGPR half, where the MFMA reads them directly
+            if (QH > 1 && c == NQT - 1 && ks >= KS - 2) continue;
+            if (NQT > 4)     // >= 128 B registers: park them in the AGPR half, where the MFMA reads them directly
                 asm volatile("" : "+a"(bfrag[c][ks].x), "+a"(bfrag[c][ks].y), "+a"(bfrag[c][ks].z), "+a"(bfrag[c][ks].w));
             else
                 asm volatile("" : "+v"(bfrag[c][ks].x), "+v"(bfrag[c][ks].y), "+v"(bfrag[c][ks].z), "+v"(bfrag[c][ks].w));
@@ -511,22 +532,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     // (done here it cost one dependent HBM round trip chain per 64 suspects per wave).
     uint32_t* const st_row = reinterpret_cast<uint32_t*>(smem + kScanLdsRing + wave * kStageBytesW);
     uint32_t* const st_q = st_row + kCap;
-    uint32_t* const st_cnt = st_q + kCap;                 // [NQB*32]
-    uint32_t* const st_base = st_cnt + NQB * 32;          // [NQB*32]
+    uint32_t* const st_cnt = st_q + kCap;                 // [NQT*32]
+    uint32_t* const st_base = st_cnt + NQT * 32;          // [NQT*32]
     uint32_t st_n = 0;
     auto flush = [&]() {
         // per-query reservation (one returning atomic per query present), then scatter the row ids
 #pragma unroll
-        for (int part = 0; part < (NQB + 1) / 2; ++part)
-            if (lane + 64 * part < NQB * 32) st_cnt[lane + 64 * part] = 0;
+        for (int part = 0; part < (NQT + 1) / 2; ++part)
+            if (lane + 64 * part < NQT * 32) st_cnt[lane + 64 * part] = 0;
         for (uint32_t e0 = 0; e0 < st_n; e0 += 64) {
             const uint32_t e = e0 + lane;
             if (e < st_n) atomicAdd(&st_cnt[st_q[e]], 1u);
         }
 #pragma unroll
-        for (int part = 0; part < (NQB + 1) / 2; ++part) {
+        for (int part = 0; part < (NQT + 1) / 2; ++part) {
             const int q = lane + 64 * part;
-            if (q < NQB * 32) {
+            if (q < NQT * 32) {
                 const uint32_t c = st_cnt[q];
                 st_base[q] = c ? atomicAdd(&a.susp_cnt[qb0 * 32 + q], c) : 0u;
                 st_cnt[q] = 0;
@@ -554,6 +575,86 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         for (int n = 0; n < ND; ++n) dma_one(src, dst + n * 1024, voff[n], 0.0f);
     }
 
+    if constexpr (QH > 1) {
+        for (uint32_t b = 0; b < nblk; ++b) {
+            wait_vmcnt<ND * (NS - 2)>();
+            const char* nb_src;
+            uint32_t nb_dst;
+            piece_addr(NS - 1, b + NS - 1, nb_src, nb_dst);
+            const char* slot = lds_ptr + (b % NS) * kPieceBytes + rd_row;
+            f32x4 q4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q4[j] = *reinterpret_cast<const f32x4*>(slot + (((2 * j + h) * 16 - rd_rot) & 112));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < ND; ++n) dma_one(nb_src, nb_dst + n * 1024, voff[n], q4[n].x);
+            const uint32_t cur_phys = phys[0];
+#pragma unroll
+            for (int j = 0; j < D; ++j) phys[j] = phys[j + 1];
+            phys[D] = next_phys();
+            const uint32_t row0 = cur_phys * kPieceRows;
+#pragma unroll
+            for (int half = 0; half < QH; ++half) {
+                AccT acc[NQB];
+#pragma unroll
+                for (int c = 0; c < NQB; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][r] = 0;
+#pragma unroll
+                for (int ksl = 0; ksl < 4; ++ksl)
+#pragma unroll
+                    for (int c = 0; c < NQB; ++c) {
+                        uint4 bq;
+                        if (half * NQB + c == NQT - 1 && ksl >= KS - 2) bq = *reinterpret_cast<const uint4*>(b_lds + (ksl - (KS - 2)) * 1024 + lane * 16);
+                        else bq = bfrag[half * NQB + c][ksl];
+                        acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, q4[ksl]),
+                                                                       __builtin_bit_cast(i32x4, bq), acc[c], 0, 0, 0);
+                    }
+                uint64_t cmask[NQB];
+                uint64_t any_mask = 0;
+#pragma unroll
+                for (int c = 0; c < NQB; ++c) {
+                    int m = acc[c][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = acc[c][r] > m ? acc[c][r] : m;
+                    cmask[c] = __builtin_amdgcn_ballot_w64(m >= thr_s[half * NQB + c]);
+                    any_mask |= cmask[c];
+                }
+                if (any_mask != 0) {
+#pragma unroll
+                    for (int c = 0; c < NQB; ++c) {
+                        if (cmask[c] == 0) continue;
+                        uint32_t m16 = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                         : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[half * NQB + c]) : "vcc");
+                        if (row0 + kPieceRows > a.row_end) {        // last block of a ragged table
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (row0 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.row_end) m16 &= ~(1u << (15 - r));
+                        }
+                        for (;;) {
+                            const bool p = m16 != 0;
+                            const uint64_t bm = __builtin_amdgcn_ballot_w64(p);
+                            if (bm == 0) break;
+                            const uint32_t n = __popcll(bm);
+                            if (st_n + n > (uint32_t)kCap) flush();
+                            if (p) {
+                                const int r = 15 - __builtin_ctz(m16);
+                                const uint32_t pos = st_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                                st_row[pos] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                st_q[pos] = (uint32_t)((half * NQB + c) * 32 + i32);
+                                m16 &= m16 - 1;
+                            }
+                            st_n += n;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
     for (uint32_t b = 0; b < nblk; ++b) {
         AccT acc[NQB];
 #pragma unroll
@@ -676,6 +777,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 }
             }
         }
+    }
     }
     flush();
     wait_vmcnt<0>();
@@ -1429,15 +1531,15 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     return PG_OK;
 }
 
-template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false>
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1>
 static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     int rc_attr;
-    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8>, kScreenLds))) return rc_attr;
+    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH>, kScreenLds))) return rc_attr;
     const uint32_t total = a.rb_end - a.rb_begin;
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total * SPLIT + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
-    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
+    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
@@ -1452,7 +1554,7 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
         if (wide && v && v[0] == '3') return launch_screen<128, 8, 4, 1, 3, true>(ctx, a);
         if (wide && v && v[0] == '4') return launch_screen<128, 8, 4, 1, 4, true>(ctx, a);
 #endif
-        if (wide) return launch_screen<128, 8, 4, 1, 0, true>(ctx, a);
+        if (wide) return launch_screen<128, 4, 8, 1, 0, true, 2>(ctx, a);
         if (a.nq <= 32) return launch_screen<128, 1, 8, 1, 0, true>(ctx, a);
         if (a.nq <= 64) return launch_screen<128, 2, 8, 1, 0, true>(ctx, a);
         return launch_screen<128, 4, 8, 1, 0, true>(ctx, a);
