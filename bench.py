@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 (v_mfma_i32_32x32x32_i8 issues at the bf16 rate with twice the k)
 FLOPS_PER_ITEM = 524800        # SURVEY.md §8(d) cfg 3: 2*(256*512+512*256+256)
 RANK_EXPR = "${gpu_dnn}*(1+${current_score})^0.1"      # RankConf.RankScore: model score x recall score
 
@@ -63,12 +64,18 @@ def pmc_traffic(R):
         return None
 
 
-def scan_kernel_name(R, dim):
-    """The kernel recall.hip dispatches for the full-table pass at this batch size (dispatch_screen)."""
-    if dim > 128:
+def scan_kernel_name(R, dim, elem_bytes):
+    """The kernel recall.hip dispatches for the full-table pass at this batch size (dispatch_screen):
+    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH>."""
+    if elem_bytes == 0:
         return "pg::scan_kernel<%d,1>" % dim
+    if elem_bytes == 1:
+        if R > 128:
+            return "pg::screen_kernel<128,4,8,1,0,true,2>"
+        nqb = 4 if R > 64 else (2 if R > 32 else 1)
+        return "pg::screen_kernel<128,%d,8,1,0,true,1>" % nqb
     nqb, waves = (8, 4) if R > 128 else ((4, 8) if R > 64 else ((2, 8) if R > 32 else (1, 8)))
-    return "pg::screen_kernel<%d,%d,%d>" % (dim, nqb, waves)
+    return "pg::screen_kernel<%d,%d,%d,1,0,false,1>" % (dim, nqb, waves)
 
 
 def device_info():
@@ -246,12 +253,13 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = R * K * args.steps / elapsed * (1 if shard else world)
-    # Algorithmic bytes of one table pass: the screen streams the table's bf16 shadow (rows x dim x 2;
-    # DESIGN.md §4.1a) — the fp32 rows (rows x dim x 4, SURVEY.md 8d's figure for a scan of the table itself)
-    # are only gathered for the ~1e-4 fraction of rows that reach the exact re-scoring.  Tables the screen
-    # cannot serve (dim > 128) are scanned in fp32.
-    screened = args.dim <= 128
-    shard_bytes = (end - begin) * args.dim * (2 if screened else 4)
+    # Algorithmic bytes of one table pass: the screen streams the table's shadow — int8 at dim 128 (rows x dim
+    # x 1), bf16 at dim 64 — and the fp32 rows (rows x dim x 4, SURVEY.md 8d's figure for a scan
+    # of the table itself) are only gathered for the ~1e-4 fraction of rows that reach the exact re-scoring.
+    # Tables the screen cannot serve (dim > 128) are scanned in fp32.
+    elem_bytes = table.screen_info()[0]
+    screened = elem_bytes != 0
+    shard_bytes = (end - begin) * args.dim * (elem_bytes if screened else 4)
     fp32_bytes = (end - begin) * args.dim * 4
     scan_avg_ms = float(np.mean(scan_ms))
     achieved = shard_bytes / (scan_avg_ms * 1e-3) / 1e9
@@ -270,22 +278,24 @@ def main():
                                    % (world, args.rows * world)) if shard else
                                   ("request-parallel x%d, table replicated per GPU, no data-path collective" % world
                                    if world > 1 else "1 GPU")},
-        "roofline": {"bound": "hbm", "kernel": scan_kernel_name(R, args.dim), "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": scan_kernel_name(R, args.dim, elem_bytes), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R),
                      "measured_peak": measured_gbs, "frac_of_measured": achieved / measured_gbs,
                      "bytes_per_pass": shard_bytes, "ms_per_pass": scan_avg_ms,
                      "mfma_flops_per_pass": 2.0 * (end - begin) * args.dim * R if screened else None,
-                     "mfma_frac": (2.0 * (end - begin) * args.dim * R / (scan_avg_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS)
+                     "mfma_frac": (2.0 * (end - begin) * args.dim * R / (scan_avg_ms * 1e-3) / 1e12 /
+                                   (MFMA_I8_PEAK_TOPS if elem_bytes == 1 else MFMA_BF16_PEAK_TFLOPS))
                      if screened else None,
+                     "shadow_elem_bytes": elem_bytes,
                      "fp32_table_bytes": fp32_bytes,
                      "fp32_table_equivalent_gbs": fp32_bytes / (scan_avg_ms * 1e-3) / 1e9,
-                     "note": "algorithmic bytes = shard rows x dim x 2 per table pass: the pass streams the bf16 shadow of "
-                             "the fp32 table (exact fp32 re-scoring of the ~1e-4 of rows that pass the screen), one "
-                             "pass serves %d requests; "
+                     "note": "algorithmic bytes = shard rows x dim x shadow_elem_bytes per table pass: the pass streams the "
+                             "int8 (dim 128) / bf16 (dim 64) shadow of the fp32 table, an exact integer / rigorous bound, with "
+                             "exact fp32 re-scoring of the ~1e-4 of rows that pass it; one pass serves %d requests; "
                              "duration = sum of the pass's scan-stage launches (exact seed of the pilot sample, screened sample launch, "
                              "screened full pass, exact re-scoring), HIP events on the launch stream" % R},
         "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},
-        "rank_roofline": {"bound": "mfma", "kernel": "pg::mlp_kernel<bf16,512,256>",
+        "rank_roofline": {"bound": "mfma", "kernel": "pg::dnn3_ws_kernel",
                           "achieved": (R * K / (world if shard else 1)) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
                           "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": (R * K / (world if shard else 1)) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS}

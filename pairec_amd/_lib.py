@@ -21,7 +21,7 @@ EXPORTS = [
     "pg_rank_fm2t", "pg_rank_fm2t_dev", "pg_expr_compile", "pg_expr_free", "pg_expr_num_vars",
     "pg_expr_var_name", "pg_expr_eval", "pg_expr_eval_dev", "pg_sort_scores", "pg_sort_scores_dev",
     "pg_dpp", "pg_stats", "pg_last_scan_kernel_ms", "pg_rows_to_local_dev", "pg_widen_f32_dev",
-    "pg_hbm_read_probe", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
+    "pg_hbm_read_probe", "pg_table_screen_info", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
     "pg_features_column_index", "pg_features_num_columns", "pg_features_gather_i32_dev",
     "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev", "pg_recommend_dnn3_dev",
 ]
@@ -100,6 +100,7 @@ def load():
         "pg_stats": [vp, P(PgStats)],
         "pg_last_scan_kernel_ms": [vp, P(C.c_double), P(u64)],
         "pg_hbm_read_probe": [vp, vp, i32, P(C.c_double)],
+        "pg_table_screen_info": [vp, vp, P(C.c_int), P(C.c_float), P(C.c_float)],
     }
     missing = [n for n in EXPORTS if not hasattr(L, n)]
     if missing:

@@ -1859,6 +1859,18 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
 
 extern "C" {
 
+int pg_table_screen_info(pg_ctx* ctx, const pg_table* t, int* out_elem_bytes, float* out_scale, float* out_resid) {
+    PG_REQUIRE(ctx && t, "pg_table_screen_info: NULL argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    int rc;
+    if ((rc = pg::ensure_table_stats(ctx, t))) return rc;
+    const bool screened = t->stats_valid && t->all_finite;
+    if (out_elem_bytes) *out_elem_bytes = screened ? (t->shadow_is_i8 ? 1 : 2) : 0;
+    if (out_scale) *out_scale = screened && t->shadow_is_i8 ? t->s8 : 0.0f;
+    if (out_resid) *out_resid = screened && t->shadow_is_i8 ? t->resid8 : 0.0f;
+    return PG_OK;
+}
+
 int pg_recall_topk_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq,
                        uint32_t k, uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count) {
     PG_REQUIRE(ctx && t && d_queries && d_out_rows && d_out_scores, "pg_recall_topk_dev: NULL argument");

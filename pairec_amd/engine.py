@@ -109,6 +109,13 @@ class Table:
         _lib.check(self.ctx.L.pg_hbm_read_probe(self.ctx.h, self.h, reps, C.byref(g)))
         return g.value
 
+    def screen_info(self) -> Tuple[int, float, float]:
+        """(element bytes of the shadow the screened recall streams — 1 int8, 2 bf16, 0 exact fp32 scan —,
+        int8 scale, int8 max row residual); builds the shadow if it is not built yet."""
+        eb, sc, rs = C.c_int(), C.c_float(), C.c_float()
+        _lib.check(self.ctx.L.pg_table_screen_info(self.ctx.h, self.h, C.byref(eb), C.byref(sc), C.byref(rs)))
+        return eb.value, sc.value, rs.value
+
     def fill_synthetic(self, seed: int, normalize: bool = True):
         _lib.check(self.ctx.L.pg_table_fill_synthetic(self.ctx.h, self.h, seed, int(normalize)))
 

@@ -124,7 +124,7 @@ def test_recall_edge_cases(ctx):
 
 
 def test_recall_screen_is_exact_on_hostile_data(ctx):
-    """The bf16 screen must never lose a true top-K member: unnormalised rows with a wide range of
+    """The screen (int8 at this width) must never lose a true top-K member: unnormalised rows with a wide range of
     norms, clustered near-duplicates (scores that differ only below bf16 resolution), heavy ties and
     negative scores, scanned with 48 queries (screened path) — ids, order and score bits exact."""
     rng = np.random.default_rng(11)
@@ -147,6 +147,72 @@ def test_recall_screen_is_exact_on_hostile_data(ctx):
     orow, osc = o.recall_topk(tab, q, k)
     assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
     t.destroy()
+
+
+def test_recall_int8_screen_is_exact_on_hostile_data(ctx):
+    """dim 128 is screened on an int8 shadow with ONE scale for the table (max|x| / 127) and an error bound that
+    uses the measured quantisation residual.  Data built against exactly that: a single huge outlier that makes the
+    scale useless (every ordinary row quantises to zero), rows of tiny magnitude, zero rows, a zero query, a query
+    with one dominant component, and winners that differ by less than one quantisation step — ids, order and score
+    bits must match the oracle; only speed may suffer."""
+    rng = np.random.default_rng(23)
+    n, d, k, nq = 150_000, 128, 600, 72
+    tab = rng.standard_normal((n, d)).astype(np.float32) * 0.05
+    tab[1234, 17] = 4.0e4                                              # the outlier: s8 ~ 315, rows ~ 0.05
+    tab[2000:2600] *= 1e-6                                             # tiny rows
+    tab[3000:3100] = 0.0                                               # zero rows
+    near = rng.standard_normal(d).astype(np.float32)
+    tab[5000:5400] = near * (1.0 + 1e-6 * np.arange(400, dtype=np.float32)[:, None])   # sub-step differences
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[0] = 0.0                                                         # zero query: every score is 0 → ties by row id
+    q[1] = 0.0
+    q[1, 17] = 1.0                                                     # one component: picks the outlier's column
+    q[2] = near
+    q[3] = -near
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    eb, scale, resid = t.screen_info()
+    assert eb == 1 and scale > 300.0 and resid > 0.0
+    rows, scores, _ = t.recall_topk(q, k)
+    orow, osc = o.recall_topk(tab, q, k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+    # the same rows without the outlier: a tight scale, the same exactness
+    tab[1234, 17] = 0.01
+    t.upload(tab)
+    eb, scale2, _ = t.screen_info()
+    assert eb == 1 and scale2 < 0.05
+    rows, scores, _ = t.recall_topk(q, k)
+    orow, osc = o.recall_topk(tab, q, k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+    t.destroy()
+
+
+def test_table_screen_info(ctx):
+    """pg_table_screen_info: which shadow a table is screened on (int8 at dim 128, bf16 at dim 64, none when the
+    rows are not finite or the width has no screen), and the int8 statistics against numpy."""
+    rng = np.random.default_rng(5)
+    tab = rng.uniform(-1, 1, (40_000, 128)).astype(np.float32)
+    t = pa.Table(ctx, 40_000, 128)
+    t.upload(tab)
+    eb, scale, resid = t.screen_info()
+    assert eb == 1
+    s = np.float32(np.abs(tab).max()) / np.float32(127.0)
+    assert abs(scale - s) <= 1e-6 * s
+    X = np.clip(np.rint(tab.astype(np.float64) / float(scale)), -127, 127)
+    r = np.sqrt(((tab.astype(np.float64) - float(scale) * X) ** 2).sum(axis=1)).max()
+    assert r <= resid <= r * 1.01 + 1e-4                               # an upper bound, and a tight one
+    tab[7, 7] = np.nan
+    t.upload(tab)
+    assert t.screen_info()[0] == 0
+    t.destroy()
+    t64 = pa.Table(ctx, 5000, 64)
+    t64.fill_synthetic(o.SEED_TABLE)
+    assert t64.screen_info() == (2, 0.0, 0.0)
+    t64.destroy()
+    t256 = pa.Table(ctx, 5000, 256)
+    t256.fill_synthetic(o.SEED_TABLE)
+    assert t256.screen_info()[0] == 0
+    t256.destroy()
 
 
 def test_recall_random_shapes_bitexact(ctx):
