@@ -78,6 +78,8 @@ struct ScanArgs {
     uint32_t stride;         // 1 = every block; S > 1 = pilot sample: logical block L reads table
                              // block sample_block(L, ...)
     uint32_t perm_mul, perm_mod;   // pilot sample order: slot = L * perm_mul mod perm_mod
+    uint32_t group_q;        // > 0: blockIdx.y selects a group of group_q queries (of nq in all) — one launch serves
+                             // every group of a screened recall's exact seed scan instead of one launch per group
 };
 
 // Pilot sample: logical block L of a stride-S launch is table block slot*S + jitter(slot), where
@@ -140,6 +142,14 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
     const uint32_t W = gridDim.x * kScanWaves;
     const int i32 = lane & 31;       // row within block (A), query (B, C)
     const int h = lane >> 5;         // k parity (A, B); row half (C)
+    if (a.group_q) {                 // this workgroup's query group
+        const uint32_t g0 = blockIdx.y * a.group_q;
+        a.qpad += (size_t)g0 * DIM;
+        a.thr += g0;
+        a.cnt += g0;
+        a.cand += (uint64_t)g0 * a.cap;
+        a.nq = a.nq - g0 < a.group_q ? a.nq - g0 : a.group_q;
+    }
 
     // B operand: bq[s] = Q[query = lane&31][k = 2s + h]
     float bq[NQB][DIM / 2];
@@ -604,12 +614,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 for (int ksl = 0; ksl < 4; ++ksl)
 #pragma unroll
                     for (int c = 0; c < NQB; ++c) {
+                        if (VAR == 2) {                      // (ablation: stream only)
+                            asm volatile("" :: "v"(q4[ksl]));
+                            continue;
+                        }
                         uint4 bq;
                         if (half * NQB + c == NQT - 1 && ksl >= KS - 2) bq = *reinterpret_cast<const uint4*>(b_lds + (ksl - (KS - 2)) * 1024 + lane * 16);
                         else bq = bfrag[half * NQB + c][ksl];
                         acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, q4[ksl]),
                                                                        __builtin_bit_cast(i32x4, bq), acc[c], 0, 0, 0);
                     }
+                if (VAR == 1 || VAR == 2) {                  // (ablation: no screen test)
+#pragma unroll
+                    for (int c = 0; c < NQB; ++c) asm volatile("" :: "v"(acc[c][0]), "v"(acc[c][15]));
+                    continue;
+                }
                 uint64_t cmask[NQB];
                 uint64_t any_mask = 0;
 #pragma unroll
@@ -1361,7 +1380,8 @@ static int launch_scan(pg_ctx* ctx, const ScanArgs& a) {
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total + kScanWaves - 1) / kScanWaves;
     if (grid > need) grid = need;
-    scan_kernel<DIM, NQB, VAR><<<grid, 64 * kScanWaves, kScanLds, ctx->stream>>>(a);
+    const uint32_t groups = a.group_q ? (a.nq + a.group_q - 1) / a.group_q : 1;
+    scan_kernel<DIM, NQB, VAR><<<dim3(grid, groups), 64 * kScanWaves, kScanLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
@@ -1549,10 +1569,8 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
     if (i8) {                                        // int8 shadow (dim 128)
 #ifdef PG_SCAN_VARIANTS
         const char* v = getenv("PG_SCREEN_VAR");     // developer ablation builds only
-        if (wide && v && v[0] == '1') return launch_screen<128, 8, 4, 1, 1, true>(ctx, a);
-        if (wide && v && v[0] == '2') return launch_screen<128, 8, 4, 1, 2, true>(ctx, a);
-        if (wide && v && v[0] == '3') return launch_screen<128, 8, 4, 1, 3, true>(ctx, a);
-        if (wide && v && v[0] == '4') return launch_screen<128, 8, 4, 1, 4, true>(ctx, a);
+        if (wide && v && v[0] == '1') return launch_screen<128, 4, 8, 1, 1, true, 2>(ctx, a);
+        if (wide && v && v[0] == '2') return launch_screen<128, 4, 8, 1, 2, true, 2>(ctx, a);
 #endif
         if (wide) return launch_screen<128, 4, 8, 1, 0, true, 2>(ctx, a);
         if (a.nq <= 32) return launch_screen<128, 1, 8, 1, 0, true>(ctx, a);
@@ -1635,7 +1653,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
     uint32_t stride = 1, sample_blocks = 0, k_pilot = 0, perm_mul = 1;
     {
         const uint32_t full_blocks = rows / kPieceRows;           // the sample only uses whole blocks
-        uint32_t want = full_blocks / 32;
+        uint32_t want = full_blocks / 64;                        // (1/64 measured best with the int8 screen: 5.39 vs 5.51 ms per 256-request pass at 1/32, 5.46 at 1/96)
         if (want < 32768) want = 32768;                          // >= 1M sample rows
         if (getenv("PG_PILOT_FRACTION")) want = (uint32_t)(full_blocks * atof(getenv("PG_PILOT_FRACTION")));
         stride = want ? full_blocks / want : 1;
@@ -1696,27 +1714,26 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
         } else {
             // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
             // every row is a candidate and there is nothing to screen) in groups of <= 64 queries
-            const uint32_t gsz = screen ? (uint32_t)kMaxQueriesExact : nq;
-            for (uint32_t g0 = 0; g0 < nq; g0 += gsz) {
-                ScanArgs a;
-                a.tab = t->d;
-                a.qpad = rs.qpad + (size_t)g0 * t->dim;
-                a.thr = rs.thr + g0;
-                a.cnt = rs.cnt + g0;
-                a.cand = rs.cand[cur] + (size_t)g0 * rs.cap;
-                a.overflow = rs.overflow;
-                a.cap = rs.cap;
-                a.nq = nq - g0 < gsz ? nq - g0 : gsz;
-                a.nq_launch = a.nq;
-                a.rb_begin = rb;
-                a.rb_end = rb + cb;
-                a.row_end = rows;
-                a.stride = st;
-                a.perm_mul = perm_mul;
-                a.perm_mod = sample_blocks;
-                int rc2;
-                if ((rc2 = dispatch_scan(ctx, t->dim, a))) return rc2;
-            }
+            // one launch; blockIdx.y walks the groups
+            ScanArgs a;
+            a.tab = t->d;
+            a.qpad = rs.qpad;
+            a.thr = rs.thr;
+            a.cnt = rs.cnt;
+            a.cand = rs.cand[cur];
+            a.overflow = rs.overflow;
+            a.cap = rs.cap;
+            a.nq = nq;
+            a.group_q = screen && nq > (uint32_t)kMaxQueriesExact ? (uint32_t)kMaxQueriesExact : 0u;
+            a.nq_launch = a.group_q ? a.group_q : nq;
+            a.rb_begin = rb;
+            a.rb_end = rb + cb;
+            a.row_end = rows;
+            a.stride = st;
+            a.perm_mul = perm_mul;
+            a.perm_mod = sample_blocks;
+            int rc2;
+            if ((rc2 = dispatch_scan(ctx, t->dim, a))) return rc2;
         }
         PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], ctx->stream));
         ++n_ev;
@@ -1786,7 +1803,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             // that threshold has probability < 1e-9 (Poisson tail of seed hits among the sample's top K');
             // should it happen anyway, select_kernel leaves the threshold at -inf, the full pass overflows
             // and the next plan takes over.  (Measured against geometric chunks over the sample: 1.0 → 0.7 ms.)
-            const uint32_t seed_rows = 8192;
+            const uint32_t seed_rows = getenv("PG_SEED_ROWS") ? (uint32_t)atoi(getenv("PG_SEED_ROWS")) : 8192u;   // (tuning runs)
             const uint64_t sample_rows = (uint64_t)sample_blocks * kPieceRows;
             if (screen && !getenv("PG_PILOT_GROWTH") && sample_rows > 8ull * seed_rows && k_pilot < seed_rows / 4) {
                 const double mu = (double)seed_rows * (double)k_pilot / (double)sample_rows;
