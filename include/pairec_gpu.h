@@ -83,9 +83,9 @@ int pg_table_gather(pg_ctx* ctx, const pg_table* t, const uint32_t* rows, uint32
  *   score(row) = chain_k fmaf(x[row][k], q[k], acc)  (k ascending, fp32) — independent of nq.
  *   order: score descending (IEEE totalOrder, NaN last), then row ascending.
  * queries: [nq][dim] fp32, nq <= 256 per call (<= 32 when dim > 128); one call = one table pass.
- * Finite tables of dim <= 128 are scanned with a bf16-MFMA screen followed by exact re-scoring of the
- * survivors, everything else with the exact fp32-MFMA scan (then nq <= 64) — results are identical
- * bit for bit.  out_rows: [nq][k] global row ids (row_offset + local), out_scores:
+ * Finite tables of dim 128 / 64 are scanned with an int8 / bf16 MFMA screen over a quantised shadow of the rows
+ * (a rigorous bound of every score) followed by exact re-scoring of the survivors, everything else with the
+ * exact fp32-MFMA scan (then nq <= 64) — results are identical bit for bit.  out_rows: [nq][k] global row ids (row_offset + local), out_scores:
  * [nq][k].  If the table has fewer than k rows the tail is filled with
  * row = UINT64_MAX, score = -inf and *out_count (optional) receives the valid count. */
 int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_t nq, uint32_t k,

@@ -29,7 +29,7 @@ with open(os.path.join(out, "summary.txt"), "w") as f:
                 agg[k][0] += float(row.get("Counter_Value", 0) or 0); agg[k][1] += 1
             f.write("== PMC %s (sum over dispatches, n dispatches)\n" % os.path.basename(d))
             for (kn, cn), (v, n) in sorted(agg.items()):
-                if any(t in kn for t in ("scan_kernel", "screen_kernel", "mlp_kernel", "select", "sort_kernel")):
+                if any(t in kn for t in ("scan_kernel", "screen_kernel", "rescore_kernel", "mlp_kernel", "dnn3_ws", "select", "sort_kernel")):
                     f.write("%-62s %-28s %.6g  n=%d  avg=%.6g\n" % (kn, cn, v, n, v / max(n, 1)))
 print(open(os.path.join(out, "summary.txt")).read()[:6000])
 PY
