@@ -38,7 +38,7 @@ void set_error(const char* fmt, ...);
 
 constexpr int kWave = 64;
 constexpr int kMaxQueriesExact = 64;   // exact fp32-MFMA scan: one or two 32-query column blocks
-constexpr int kMaxQueries = 256;       // screened scan (bf16 filter + exact rescoring): up to eight blocks
+constexpr int kMaxQueries = 256;       // screened scan (int8 or bf16 filter + exact rescoring): up to eight blocks
 
 // Scratch arena: grows on demand, never shrinks; owned by the context, used by one call at a time
 // (calls on a context are serialised by ctx->mu).

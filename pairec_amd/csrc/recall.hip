@@ -17,6 +17,10 @@
 //                    from LDS conflict-free thanks to a per-row rotation applied on the DMA's
 //                    *source* address; 32 queries ride in the B operand.  Rows whose score reaches
 //                    the query's running threshold are appended to a candidate list.
+//   screen_kernel    the same walk over a quantised shadow of the rows (int8 at dim 128, bf16 at dim 64): an
+//                    int8 / bf16 MFMA bounds every row·query score rigorously, pairs whose bound reaches the
+//                    threshold are "suspects"; rescore_kernel scores the suspects exactly from the fp32 rows.
+//                    Up to 256 queries per pass; results identical to scan_kernel's, bit for bit.
 //   select_kernel    per query: radix-select the K-th largest key of the candidates, keep the top
 //                    K, publish the new threshold (any K-th-largest-so-far is a valid lower bound,
 //                    so the result is exact for every data distribution).
@@ -392,7 +396,7 @@ struct ScreenArgs {
     const uint4* qb16;        // [NQB][KS][64] B fragments: 8 bf16 (KS = DIM/16) or 16 int8 (KS = DIM/32) per lane
     const float* thr_screen;  // [256] bf16: thr - eps, rounded down; int8: the same in integer dot units (int32 bits)
     uint32_t* susp_cnt;       // [256] suspects per query of this launch
-    uint32_t* susp;           // [256][cap] suspect rows (passed the bf16 screen; re-scored by rescore_kernel)
+    uint32_t* susp;           // [256][cap] suspect rows (passed the screen; re-scored by rescore_kernel)
     uint32_t* overflow;
     uint32_t cap, nq, rb_begin, rb_end, row_end, stride, perm_mul, perm_mod;
 };
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         dst = lds_wave_u + __builtin_amdgcn_readfirstlane(t % NS) * kPieceBytes;
     };
 
-    // staging: (row, query) pairs that passed the bf16 screen ("suspects").  They are parked in a
+    // staging: (row, query) pairs that passed the screen ("suspects").  They are parked in a
     // wave-private LDS list and flushed in bulk into per-query global suspect lists; the exact
     // re-scoring runs afterwards in rescore_kernel, with the whole chip hiding the gather latency
     // (done here it cost one dependent HBM round trip chain per 64 suspects per wave).
@@ -1625,7 +1629,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
     uint32_t scan_launches = 0;
 
     // Policy: up to 32 queries ride the exact fp32-MFMA scan (HBM-bound).  Larger batches use the
-    // screened scan (bf16 filter + exact re-scoring), which stays HBM-bound up to 128 queries; it
+    // screened scan (int8 or bf16 filter + exact re-scoring), which stays HBM-bound up to 128 queries; it
     // needs a finite table and dim <= 128, otherwise the 64-query exact kernel is used.
     const uint32_t screen_min = getenv("PG_SCREEN_MIN") ? (uint32_t)atoi(getenv("PG_SCREEN_MIN")) : 0u;
     bool screen = nq > screen_min && t->dim <= 128 && !getenv("PG_RECALL_EXACT");

@@ -56,7 +56,7 @@ def test_table_upload_gather_swap(ctx):
     (1000, 64, 200, 1),          # cfg 1 shape in miniature (dot-product top-200)
     (40000, 128, 200, 3),        # two chunks, one block per wave
     (140000, 128, 500, 32),      # three chunks, several blocks per wave, full 32-query block
-    (140000, 128, 300, 64),      # > 32 queries: bf16 screen + exact re-scoring
+    (140000, 128, 300, 64),      # > 32 queries: int8 screen + exact re-scoring
     (70000, 64, 100, 45),
     (250000, 128, 5000, 128),    # full 128-query pass, K=5000
     (200000, 128, 2000, 256),    # 256 queries: 8 B blocks, one wave per SIMD
@@ -242,7 +242,7 @@ def test_recall_random_shapes_bitexact(ctx):
 
 
 def test_recall_follows_table_updates(ctx):
-    """The screen streams a bf16 shadow of the table that is built lazily; uploads, synthetic fills and
+    """The screen streams a quantised shadow (int8 here) of the table that is built lazily; uploads, synthetic fills and
     hot swaps must invalidate / carry it — every recall answers for the rows the table holds now."""
     n, d, k = 60000, 128, 300
     a = o.synth_rows(o.SEED_TABLE, 0, n, d)
