@@ -1,17 +1,30 @@
 // bitonic_reg.hpp — workgroup bitonic sort of up to 8192 keys with 8 elements per thread in registers.
 //   partner inside the thread (j < 8)            → register compare-exchange, no memory traffic
-//   partner in the same wave (8 <= j < 512)      → ds_bpermute exchange, no barrier
+//   partner in the same wave (8 <= j < 512)      → lane exchange, no barrier: DPP for lane distance 1, 2, 8 (VALU
+//                                                   rate, no LDS crossbar), ds_swizzle for 4 and 16, ds_bpermute for 32
 //   partner in another wave (j >= 512)           → LDS exchange ([u][thread] layout: conflict-free)
 // 10 of the 91 sub-stages of an 8192-element sort touch LDS.  Ascending by (key, index); callers that
 // want descending order complement their keys.  Position i = 8*t + u lives in thread t, slot u.
 #pragma once
 #include <cstdint>
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 namespace pg {
 
 constexpr int kBitonicE = 8;
 constexpr uint32_t kBitonicMax = 8192;
+
+// value of lane (l ^ M) — M a compile-time power of two below 64
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+    else if constexpr (M == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);              // xor 4 (bit mode)
+    else if constexpr (M == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);             // xor 16
+    else return (uint32_t)__shfl_xor((int)v, M, 64);
+}
 
 struct BitonicLds {
     uint64_t xk[kBitonicE][1024];
@@ -54,14 +67,25 @@ __device__ __forceinline__ void bitonic_sort_reg(uint64_t (&k)[kBitonicE], uint3
                 }
                 __syncthreads();
             } else if (act) {
+                auto exch = [&](auto m_tag) {
+                    constexpr int M = decltype(m_tag)::value;
 #pragma unroll
-                for (int u = 0; u < kBitonicE; ++u) {
-                    const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)k[u], (int)m, 64);
-                    const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(k[u] >> 32), (int)m, 64);
-                    const uint32_t oi = WITH_IDX ? (uint32_t)__shfl_xor((int)ix[u], (int)m, 64) : 0u;
-                    const uint64_t ok = ((uint64_t)ohi << 32) | olo;
-                    const bool mine_first = lt(k[u], ix[u], ok, oi);
-                    if (mine_first != keep_min) { k[u] = ok; ix[u] = oi; }
+                    for (int u = 0; u < kBitonicE; ++u) {
+                        const uint32_t olo = lane_xor<M>((uint32_t)k[u]);
+                        const uint32_t ohi = lane_xor<M>((uint32_t)(k[u] >> 32));
+                        const uint32_t oi = WITH_IDX ? lane_xor<M>(ix[u]) : 0u;
+                        const uint64_t ok = ((uint64_t)ohi << 32) | olo;
+                        const bool mine_first = lt(k[u], ix[u], ok, oi);
+                        if (mine_first != keep_min) { k[u] = ok; ix[u] = oi; }
+                    }
+                };
+                switch (m) {
+                    case 1: exch(std::integral_constant<int, 1>{}); break;
+                    case 2: exch(std::integral_constant<int, 2>{}); break;
+                    case 4: exch(std::integral_constant<int, 4>{}); break;
+                    case 8: exch(std::integral_constant<int, 8>{}); break;
+                    case 16: exch(std::integral_constant<int, 16>{}); break;
+                    default: exch(std::integral_constant<int, 32>{}); break;
                 }
             }
         }
