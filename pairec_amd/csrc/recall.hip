@@ -813,6 +813,39 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
 // grid.x strides over the list): the query sits in LDS (broadcast reads), each wave gathers its 64 rows
 // with coalesced 256 B segments into a padded LDS tile (16 independent loads per lane in flight), then
 // lane s walks row s.  One returning atomic per block reserves the output range.
+// rescore_kernel's two steps on one unit (a 256-B half of 64 rows): the gather of the wave's 64 rows (16
+// independent 16-B loads per lane, four rows per instruction) and the walk (LDS tile, then lane s runs the
+// specification's k-ascending fmaf chain over row s)
+template <int DIM>
+__device__ __forceinline__ void rescore_gather(f32x4 (&buf)[16], const float* __restrict__ tab, uint32_t row, int ph, int lane) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t r_i = (uint32_t)__shfl((int)row, 4 * i + (lane >> 4), 64);
+        buf[i] = reinterpret_cast<const f32x4*>(tab + (size_t)r_i * DIM + ph * 64)[lane & 15];
+    }
+}
+template <int ROWB>
+__device__ __forceinline__ void rescore_walk(const f32x4 (&buf)[16], char* my, const float* qs, int ph, int lane, float& s) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        *reinterpret_cast<f32x4*>(my + (4 * i + (lane >> 4)) * ROWB + (lane & 15) * 16) = buf[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float4 x = *reinterpret_cast<const float4*>(my + lane * ROWB + k * 16);
+        const float4 y = *reinterpret_cast<const float4*>(&qs[ph * 64 + 4 * k]);
+        s = __fmaf_rn(x.x, y.x, s);
+        s = __fmaf_rn(x.y, y.y, s);
+        s = __fmaf_rn(x.z, y.z, s);
+        s = __fmaf_rn(x.w, y.w, s);
+        // (keeps hipcc from hoisting all 32 LDS reads above the chain: with two gathers in flight that pushed the
+        // kernel past 256 registers and one gather buffer into scratch)
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ tab, const float* __restrict__ qpad,
                                                       const float* __restrict__ thr,
@@ -834,34 +867,37 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     const float thr_q = thr[q];
     __syncthreads();
     char* const my = tile[w];
-    for (uint32_t t0 = blockIdx.x * 256u; t0 < n; t0 += gridDim.x * 256u) {
+    // The gathers run one unit (a 256-B half of 64 rows) ahead of the arithmetic: while a wave walks one half-row
+    // tile, the loads of the next half — or of the next chunk's first half — are in flight (one exposed HBM round
+    // trip per chunk and phase before).
+    auto row_of = [&](uint32_t t0) -> uint32_t {
         const uint32_t e = t0 + threadIdx.x;
-        const bool valid = e < n;
-        const uint32_t row = valid ? susp[(uint64_t)q * cap + e] : 0u;
+        return e < n ? susp[(uint64_t)q * cap + e] : 0u;
+    };
+    constexpr int NPH = DIM / 64;
+    const uint32_t step = gridDim.x * 256u;
+    uint32_t t0 = blockIdx.x * 256u;
+    uint32_t row = row_of(t0);
+    f32x4 va[16], vb[16];              // (ext vectors: HIP's float4 struct made these loop-carried buffers memcpy'd stack objects)
+    rescore_gather<DIM>(va, tab, row, 0, lane);
+    for (; t0 < n; t0 += step) {
+        const bool valid = t0 + threadIdx.x < n;
+        const uint32_t row_next = t0 + step < n ? row_of(t0 + step) : 0u;
         float s = 0.0f;
+        // (phases written out: with `v[ph & 1]` inside a loop the buffers stayed in scratch at DIM = 128; past the
+        // last chunk row_next is 0 — a harmless gather of row 0 instead of a conditional one)
+        if constexpr (NPH == 2) {
+            rescore_gather<DIM>(vb, tab, row, 1, lane);
+            rescore_walk<kRowB>(va, my, qs, 0, lane, s);
+            rescore_gather<DIM>(va, tab, row_next, 0, lane);
+            rescore_walk<kRowB>(vb, my, qs, 1, lane, s);
+        } else {
+            rescore_gather<DIM>(vb, tab, row_next, 0, lane);
+            rescore_walk<kRowB>(va, my, qs, 0, lane, s);
+        }
+        if (NPH & 1) {                                   // odd phase count: the prefetched unit sits in v[1], the loop reads v[0]
 #pragma unroll
-        for (int ph = 0; ph < DIM / 64; ++ph) {
-            float4 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint32_t r_i = (uint32_t)__shfl((int)row, 4 * i + (lane >> 4), 64);
-                v[i] = reinterpret_cast<const float4*>(tab + (size_t)r_i * DIM + ph * 64)[lane & 15];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                *reinterpret_cast<float4*>(my + (4 * i + (lane >> 4)) * kRowB + (lane & 15) * 16) = v[i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float4 x = *reinterpret_cast<const float4*>(my + lane * kRowB + k * 16);
-                const float4 y = *reinterpret_cast<const float4*>(&qs[ph * 64 + 4 * k]);
-                s = __fmaf_rn(x.x, y.x, s);
-                s = __fmaf_rn(x.y, y.y, s);
-                s = __fmaf_rn(x.z, y.z, s);
-                s = __fmaf_rn(x.w, y.w, s);
-            }
-            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < 16; ++i) va[i] = vb[i];
         }
         const bool keep = valid && !(s < thr_q);
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
@@ -880,6 +916,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
             else *overflow = 1u;
         }
         __syncthreads();
+        row = row_next;
     }
     if (n_raw > cap && threadIdx.x == 0) *overflow = 1u;
 }
