@@ -118,6 +118,34 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
 #define WS_MARK(i)
 #endif
 
+    // the streamed layer-1 fragments (hidden columns 128w+64..128w+127, used by block B): requested a tile ahead, in
+    // the head phase — a global load costs its wave ~40 issue cycles in a VALU phase, 60-90 between MFMAs, and at
+    // the top of the tile they were a pure stall in front of the barrier (measured with PG_WS_PROFILE)
+    bf16x8 w1g[KS1][2];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            w1g[ks][nb] = *reinterpret_cast<const bf16x8*>(w1w + (16 + nb * KS1 + ks) * 1024 + lane * 16);
+
+    // The scores of a tile are finished — 8 head partials per item summed in slot order, sigmoid, store — under
+    // block A of the NEXT tile's layer 1 (16 items per wave): the partials' LDS reads stand before its first MFMA,
+    // the arithmetic floats between the MFMAs, the store follows its last one.  Done after the head it cost every
+    // wave ~700 idle-pipe cycles per tile.  (hps is rewritten only after the next tile's layer 2: two barriers on.)
+    WsTile fin{0, 0, 0};
+    float fin_p[8];
+    const uint32_t fin_item = (uint32_t)wave * (kWsItems / 4) + (lane & 15);
+    auto finalize_read = [&]() {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fin_p[s] = hps[s * kWsItems + fin_item];
+    };
+    auto finalize_write = [&]() {
+        float z = a.b3;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) z += fin_p[s];
+        if (lane < kWsItems / 4 && fin_item < fin.cnt) a.out[fin.item0 + fin_item] = 1.0f / (1.0f + expf(-z));
+    };
+
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
         // ---- requests issued a phase (or more) ahead of their use
         uint32_t tid_o = tid;                              // opaque copy: what derives from it is recomputed per
@@ -125,16 +153,6 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
         const WsTile nn = load_desc(tile + 2);
         const uint32_t nxt_row = load_rowid(nxt, tid_o >> 2);
         const uint32_t lane_off = (tid_o & 63) * 16;
-        // the streamed layer-1 fragments (hidden columns 128w+64..128w+127), used by block B below.  (A global
-        // load costs its wave ~40 issue cycles here and 60-90 between MFMAs — measured with PG_WS_PROFILE — so
-        // they stand in bunches outside the MFMA pipelines.)
-        bf16x8 w1g[KS1][2];
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                w1g[ks][nb] = *reinterpret_cast<const bf16x8*>(w1w + (16 + nb * KS1 + ks) * 1024 + lane_off);
-
         // ---- X tile from the prefetched rows; the request's layer-1 partial when the request changes
 #pragma unroll
         for (int j = 0; j < 8; ++j) store_x_quad<1>(XT, tid_o >> 2, (tid_o & 3) * 8 + j, xq[j]);
@@ -185,6 +203,7 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
             af[0][1] = *reinterpret_cast<const bf16x8*>(x1 + ((h ^ sw) << 4));
             bl[0][0] = *reinterpret_cast<const bf16x8*>(w1l + lane_off);
             bl[0][1] = *reinterpret_cast<const bf16x8*>(w1l + KS1 * 1024 + lane_off);
+            finalize_read();                               // previous tile's head partials (fin.cnt = 0 on the first)
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 if (ks + 1 < KS1) {
@@ -201,6 +220,7 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) WS_MFMA_VV(accA[mb][nb], bl[ks & 1][nb], af[ks & 1][mb]);
             }
+            finalize_write();
             // block B, with block A's stores between its k-steps (A's last MFMA is >= 4 MFMAs old by the first)
             init(accB, wave * 128 + 64);
             WS_MFMA_READY4(accB[0][0], accB[0][1], accB[1][0], accB[1][1]);
@@ -218,6 +238,8 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
 #pragma unroll
                 for (int q = 2 * ks; q < 2 * ks + 2; ++q) store_h(accA, wave * 128, q >> 3, (q >> 2) & 1, q & 3);
             }
+            // (tried: block B one 32-item block after the other, its first half's stores under the second half's
+            // MFMAs — 440 vs 433 K cycles for layer 1: two accumulators alternating cost what the hidden stores won)
             WS_MFMA_DONE4(accB[0][0], accB[0][1], accB[1][0], accB[1][1]);
 #pragma unroll
             for (int q = 0; q < 16; ++q) store_h(accB, wave * 128 + 64, q >> 3, (q >> 2) & 1, q & 3);
@@ -280,6 +302,13 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
         }
         WS_MARK(4)
 
+        // next tile's streamed fragments (this tile's were last read by block B)
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                w1g[ks][nb] = *reinterpret_cast<const bf16x8*>(w1w + (16 + nb * KS1 + ks) * 1024 + lane_off);
+
         // ---- relu → dot head, from the accumulators: a lane owns 32 of its item's 256 h2 columns — its
         // partial runs over them in ascending order, the 8 partials of an item (wave, h) are then added in
         // slot order: z = (((b3 + p0) + p1) + …) + p7.  (mlp_kernel's order is two 128-column chains; bf16
@@ -311,16 +340,13 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
         WS_MARK(5)
         __syncthreads();                                   // partials visible; also: everyone is done with H1
         WS_MARK(6)
-        if (tid < kWsItems) {
-            float z = a.b3;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) z += hps[s * kWsItems + tid_o];
-            if ((uint32_t)tid < cur.cnt) a.out[cur.item0 + tid] = 1.0f / (1.0f + expf(-z));
-        }
         WS_MARK(7)
+        fin = cur;                                         // its scores are finished under the next tile's layer 1
         cur = nxt;
         nxt = uniform(nn);
     }
+    finalize_read();
+    finalize_write();
 #ifdef PG_WS_PROFILE
     if (lane == 0 && blockIdx.x < 4) {
         uint64_t* o = (uint64_t*)(a.field_emb) + (blockIdx.x * 4 + wave) * 8;
