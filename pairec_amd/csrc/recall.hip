@@ -1901,6 +1901,11 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             scan_ms += ms;
             if (getenv("PG_DEBUG_SCAN")) fprintf(stderr, "[pg] plan %d scan launch %u: %.3f ms\n", (int)plan, i, ms);
         }
+        if (getenv("PG_DEBUG_SCAN") && screen) {          // suspects of the last screened launch vs K (developer aid)
+            uint32_t sc[4] = {0, 0, 0, 0};
+            PG_HIP(hipMemcpy(sc, rs.susp_cnt, sizeof sc, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pg] plan %d last screened launch: suspects of queries 0-3: %u %u %u %u (K = %u)\n", (int)plan, sc[0], sc[1], sc[2], sc[3], k);
+        }
         scan_launches += n_ev;
         scanned_rows += plan == kPilot ? (uint64_t)rows + (uint64_t)sample_blocks * kPieceRows : rows;
         bool ok = ctx->h_status[0] == 0;
