@@ -58,11 +58,13 @@ struct pg_table {
     // the rows that the screen streams instead of the fp32 rows (the exact re-scoring still gathers fp32):
     //   dim 128: int8, X = rint(x / s8) with ONE scale s8 = max|x| / 127 for the table, [rows + 64][dim] bytes
     //            — a quarter of the fp32 bytes; resid8 = max over rows of ||x - s8 X||_2 (measured, not assumed)
-    //   dim 64 : bf16 (RNE of every fp32 value), [rows + 64][dim] — half the bytes
+    //   dim 64, and dim-128 tables whose value range defeats one int8 scale (heavy tails, outliers): bf16 (RNE of
+    //            every fp32 value), [rows + 64][dim] — half the bytes — plus the largest row norm of every 32-row block
     bool stats_valid = false;
     bool all_finite = false;
     float max_norm = 0.0f;       // upper bound of the rows' L2 norms
     uint16_t* d16 = nullptr;     // bf16 shadow; allocated on first use, kept across rebuilds
+    float* dnorm2 = nullptr;     // with the bf16 shadow: largest row norm^2 of every 32-row block (the bf16 bound is relative)
     int8_t* d8 = nullptr;        // int8 shadow; likewise
     bool shadow_is_i8 = false;   // which of the two the current statistics belong to
     float s8 = 0.0f;             // int8 scale

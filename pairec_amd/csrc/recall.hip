@@ -399,6 +399,9 @@ struct ScreenArgs {
     uint32_t* susp;           // [256][cap] suspect rows (passed the screen; re-scored by rescore_kernel)
     uint32_t* overflow;
     uint32_t cap, nq, rb_begin, rb_end, row_end, stride, perm_mul, perm_mod;
+    // bf16 only: the bound is relative to the row's norm — eps = eps_unit[q] x (largest row norm of the 32-row block)
+    const float* blk_norm2;   // [blocks] largest row norm^2 per physical 32-row block (pg_table::dnorm2)
+    const float* eps_unit;    // [256] 0.008 ||q|| (inflated); thr_screen then carries thr itself (or -inf)
 };
 
 // NQB query blocks of 32; WAVES waves per workgroup.  <=128 queries: 8 waves (2 per SIMD), ring of 4
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     // B operand: bfrag[c][ks] = Q[c*32 + (lane&31)][ks*16 + 8h .. +7] as bf16
     uint4 bfrag[NQT][KS];
     ThrT thr_s[NQT];
+    float eu[NQT];                                    // bf16: eps_unit of this lane's query, per query block
     bool active[NQT];
     char* const b_lds = smem + kScreenLds - kBLds;
     if constexpr (QH > 1) {
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         active[c] = (uint32_t)((qb0 + c) * 32 + i32) < a.nq;
         if constexpr (I8) thr_s[c] = active[c] ? __float_as_int(a.thr_screen[(qb0 + c) * 32 + i32]) : 0x7fffffff;
         else thr_s[c] = active[c] ? a.thr_screen[(qb0 + c) * 32 + i32] : __builtin_inff();
+        eu[c] = (!I8 && active[c]) ? a.eps_unit[(qb0 + c) * 32 + i32] : 0.0f;
     }
 #pragma unroll
     for (int c = 0; c < NQT; ++c) {
@@ -483,6 +488,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 asm volatile("" : "+v"(bfrag[c][ks].x), "+v"(bfrag[c][ks].y), "+v"(bfrag[c][ks].z), "+v"(bfrag[c][ks].w));
         }
         asm volatile("" : "+v"(thr_s[c]));
+        if (!I8) asm volatile("" : "+v"(eu[c]));
     }
 
     uint32_t voff[ND];
@@ -738,7 +744,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         // (7 max3 + 1 max + 1 compare per query block).  fmaxf drops a NaN operand, which is safe: the
         // accumulators of a finite table and a finite, moderate query are finite, and every other query
         // has thr_screen = -inf (screen_thr_kernel) so that everything passes.  Inactive query columns
-        // carry thr_s = +inf.
+        // carry thr_s = +inf (and eps_unit 0).
+        // bf16: this block's cutoffs, cut = thr - eps_unit x (largest row norm of the block), rounded down (the margin
+        // term is kept finite so that +-inf thresholds stay what they are)
+        ThrT cut[NQB];
+        if constexpr (I8) {
+#pragma unroll
+            for (int c = 0; c < NQB; ++c) cut[c] = thr_s[c];
+        } else {
+            const float nb = sqrtf(a.blk_norm2[cur_phys]) * 1.0002f;
+#pragma unroll
+            for (int c = 0; c < NQB; ++c) {
+                const float v = __fmaf_rn(-eu[c], nb, thr_s[c]);
+                cut[c] = v - __fmaf_rn(fminf(fabsf(v), 3.0e38f), 1.2e-7f, 1e-37f);
+            }
+        }
         uint64_t cmask[NQB];
         uint64_t any_mask = 0;
 #pragma unroll
@@ -747,12 +767,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 int m = acc[c][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = acc[c][r] > m ? acc[c][r] : m;
-                cmask[c] = __builtin_amdgcn_ballot_w64(m >= thr_s[c]);
+                cmask[c] = __builtin_amdgcn_ballot_w64(m >= cut[c]);
             } else {
                 float m = acc[c][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[c][r]);
-                cmask[c] = __builtin_amdgcn_ballot_w64(!(m < thr_s[c]));
+                cmask[c] = __builtin_amdgcn_ballot_w64(!(m < cut[c]));
             }
             any_mask |= cmask[c];
         }
@@ -771,10 +791,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 for (int r = 0; r < 16; ++r) {
                     if constexpr (I8)
                         asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                     : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[c]) : "vcc");
+                                     : "+v"(m16) : "v"(acc[c][r]), "v"(cut[c]) : "vcc");
                     else
                         asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                     : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[c]) : "vcc");
+                                     : "+v"(m16) : "v"(acc[c][r]), "v"(cut[c]) : "vcc");
                 }
                 if (row0 + kPieceRows > a.row_end) {        // last block of a ragged table: drop rows past the end
 #pragma unroll
@@ -921,8 +941,10 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     if (n_raw > cap && threadIdx.x == 0) *overflow = 1u;
 }
 
-// per call: bf16 B fragments of the (zero-padded) queries and eps_q = kScreenEps * max_norm * ||q||
-__global__ void screen_prep_kernel(const float* __restrict__ qpad, uint32_t dim, float max_norm,
+// per call: bf16 B fragments of the (zero-padded) queries and eps_unit_q = kScreenEps * ||q|| (the screen multiplies it
+// by the largest row norm of each 32-row block: the bf16 bound is relative to the row, so one huge row does not
+// loosen it for the rest of the table)
+__global__ void screen_prep_kernel(const float* __restrict__ qpad, uint32_t dim,
                                    uint4* __restrict__ qb16, float* __restrict__ eps) {
     const uint32_t KS = dim / 16;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -948,21 +970,20 @@ __global__ void screen_prep_kernel(const float* __restrict__ qpad, uint32_t dim,
             ss += v * v;
         }
         // inflated so that it is an upper bound in fp32
-        eps[i] = (float)(sqrt(ss) * (double)max_norm * (double)kScreenEps * 1.0001) + 1e-30f;
+        eps[i] = (float)(sqrt(ss) * (double)kScreenEps * 1.0001) + 1e-30f;
     }
 }
 
-// thr_screen = thr - eps, rounded toward -inf
+// bf16 screen: thr_screen = thr (the margin is applied per block in the kernel), or -inf
 __global__ void screen_thr_kernel(const float* __restrict__ thr, const float* __restrict__ eps,
                                   float* __restrict__ thr_screen) {
     const uint32_t q = threadIdx.x;
     if (q >= (uint32_t)kMaxQueries) return;
     const float t = thr[q], e = eps[q];
-    float v = t - e;                                   // -inf stays -inf; inf/NaN eps → -inf/NaN
-    if (v == v && v > -__builtin_inff()) v = v - fabsf(v) * 1.2e-7f - 1e-37f;
-    // non-finite queries, or score magnitudes whose bf16 partial sums could overflow: everything
-    // passes the screen and the exact re-scoring decides
-    if (!(e == e) || e > 1e30f) v = -__builtin_inff();
+    // the kernel subtracts eps_unit x block norm itself; non-finite queries, or magnitudes whose bf16 partial sums
+    // could overflow: everything passes the screen and the exact re-scoring decides
+    float v = t;
+    if (!(e == e) || e > 1e28f || !(t == t)) v = -__builtin_inff();
     thr_screen[q] = v;
 }
 
@@ -1058,12 +1079,12 @@ __global__ void screen_thr8_kernel(const float* __restrict__ thr, const float* _
 template <int DIM>
 __global__ __launch_bounds__(256) void table_stats_kernel(const float* __restrict__ tab, uint64_t rows,
                                                           float* __restrict__ out_max, uint32_t* __restrict__ out_nonfinite,
-                                                          float* __restrict__ out_absmax) {
+                                                          float* __restrict__ out_absmax, float* __restrict__ out_sumsq) {
     constexpr int G = DIM / 8;
-    __shared__ float smax[4], samax[4];
+    __shared__ float smax[4], samax[4], ssum[4];
     __shared__ uint32_t sbad[4];
     const uint64_t n8 = rows * (uint64_t)G;
-    float mx = 0.0f, amx = 0.0f;
+    float mx = 0.0f, amx = 0.0f, sum = 0.0f;
     uint32_t bad = 0;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ((n8 + 63) & ~63ull);
          g += (uint64_t)gridDim.x * blockDim.x) {
@@ -1072,6 +1093,7 @@ __global__ __launch_bounds__(256) void table_stats_kernel(const float* __restric
             const float4 a = reinterpret_cast<const float4*>(tab)[2 * g];
             const float4 b = reinterpret_cast<const float4*>(tab)[2 * g + 1];
             ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+            sum += ss;
             amx = fmaxf(amx, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
                                    fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
         }
@@ -1084,16 +1106,18 @@ __global__ __launch_bounds__(256) void table_stats_kernel(const float* __restric
     for (int off = 32; off > 0; off >>= 1) {
         mx = fmaxf(mx, __shfl_xor(mx, off, 64));
         amx = fmaxf(amx, __shfl_xor(amx, off, 64));
+        sum += __shfl_xor(sum, off, 64);
         bad |= (uint32_t)__shfl_xor((int)bad, off, 64);
     }
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { smax[w] = mx; samax[w] = amx; sbad[w] = bad; }
+    if ((threadIdx.x & 63) == 0) { smax[w] = mx; samax[w] = amx; ssum[w] = sum; sbad[w] = bad; }
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicMax(reinterpret_cast<uint32_t*>(out_max), __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))));
         atomicMax(reinterpret_cast<uint32_t*>(out_absmax),
                   __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3]))));
         if (sbad[0] | sbad[1] | sbad[2] | sbad[3]) atomicOr(out_nonfinite, 1u);
+        atomicAdd(out_sumsq, ssum[0] + ssum[1] + ssum[2] + ssum[3]);     // (statistics only: decides int8 vs bf16)
     }
 }
 
@@ -1145,7 +1169,8 @@ template <int DIM>
 __global__ __launch_bounds__(256) void table_shadow_kernel(const float* __restrict__ tab, uint64_t rows,
                                                            uint16_t* __restrict__ out16,
                                                            float* __restrict__ out_max,
-                                                           uint32_t* __restrict__ out_nonfinite) {
+                                                           uint32_t* __restrict__ out_nonfinite,
+                                                           float* __restrict__ out_blk_norm2) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     constexpr int G = DIM / 8;                       // lanes per row (8 or 16)
@@ -1173,6 +1198,12 @@ __global__ __launch_bounds__(256) void table_shadow_kernel(const float* __restri
         for (int off = 1; off < G; off <<= 1) ss += __shfl_xor(ss, off, 64);     // the row's sum of squares
         if (!(ss < 3.0e38f)) bad = 1;                 // NaN, inf or overflow
         mx = fmaxf(mx, ss);
+        // largest row norm^2 of the 32-row block: a wave holds 64 / G consecutive rows of one block
+        float wm = ss;
+#pragma unroll
+        for (int off = G; off < 64; off <<= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+        if ((threadIdx.x & 63) == 0 && g < n8)
+            atomicMax(reinterpret_cast<uint32_t*>(out_blk_norm2) + (g / G) / kPieceRows, __float_as_uint(fmaxf(wm, 0.0f)));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1538,14 +1569,36 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     if (t->stats_valid || t->shadow_failed) return PG_OK;
     if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
     static const bool force_bf16 = getenv("PG_SCREEN_BF16") != nullptr;
-    const bool i8 = t->dim == 128 && !force_bf16;
+    bool i8 = t->dim == 128 && !force_bf16;
     void* p;
     int rc;
     if ((rc = scratch_reserve(ctx, 4, 4096, &p))) return rc;
-    float* d_max = (float*)p + 300;                   // [300] max norm^2, [301] non-finite flag, [302] max |x|, [303] max residual^2
+    float* d_max = (float*)p + 300;                   // [300] max norm^2, [301] non-finite flag, [302] max |x|, [303] max residual^2, [304] sum of norm^2
     uint32_t* d_bad = (uint32_t*)p + 301;
-    PG_HIP(hipMemsetAsync(d_max, 0, 16, ctx->stream));
+    PG_HIP(hipMemsetAsync(d_max, 0, 20, ctx->stream));
     const uint32_t grid = (uint32_t)ctx->num_cus * 16;
+    if (i8) {
+        // statistics first: they decide between the two shadows
+        table_stats_kernel<128><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, d_max, d_bad, d_max + 2, d_max + 4);
+        PG_HIP(hipGetLastError());
+        PG_HIP(hipMemcpyAsync(ctx->h_status + 300, d_max, 20, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(hipStreamSynchronize(ctx->stream));
+        float mx, amx, sumsq;
+        memcpy(&mx, ctx->h_status + 300, 4);
+        memcpy(&amx, ctx->h_status + 302, 4);
+        memcpy(&sumsq, ctx->h_status + 304, 4);
+        t->all_finite = ctx->h_status[301] == 0;
+        t->max_norm = sqrtf(mx) * 1.0001f;
+        t->s8 = fmaxf(amx / 127.0f, 1e-30f);
+        t->resid8 = 0.0f;
+        // One scale for the table only works when the largest element is not far above the typical row: the int8
+        // margin is ~ s8 sqrt(dim / 12) per unit of ||q|| for EVERY row, the bf16 margin 0.008 x the row's own norm.
+        // Heavy tails or outliers (a Student-t table: int8 margin 130 x the bf16 one, every row a suspect, 560 ms per
+        // recall instead of 2.4) go to the bf16 shadow with per-block norms.
+        const float rms_norm = sqrtf(sumsq / (float)(t->rows ? t->rows : 1));
+        static const bool force_i8 = getenv("PG_SCREEN_I8") != nullptr;
+        if (t->all_finite && !force_i8 && t->s8 * sqrtf((float)t->dim / 12.0f) > 4.0f * kScreenEps * rms_norm) i8 = false;
+    }
     if (i8) {
         if (!t->d8) {
             const size_t bytes = (t->rows + 64) * (size_t)t->dim;
@@ -1557,17 +1610,6 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
             }
             PG_HIP(hipMemsetAsync(t->d8 + t->rows * (size_t)t->dim, 0, 64 * (size_t)t->dim, ctx->stream));
         }
-        table_stats_kernel<128><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, d_max, d_bad, d_max + 2);
-        PG_HIP(hipGetLastError());
-        PG_HIP(hipMemcpyAsync(ctx->h_status + 300, d_max, 16, hipMemcpyDeviceToHost, ctx->stream));
-        PG_HIP(hipStreamSynchronize(ctx->stream));
-        float mx, amx;
-        memcpy(&mx, ctx->h_status + 300, 4);
-        memcpy(&amx, ctx->h_status + 302, 4);
-        t->all_finite = ctx->h_status[301] == 0;
-        t->max_norm = sqrtf(mx) * 1.0001f;
-        t->s8 = fmaxf(amx / 127.0f, 1e-30f);
-        t->resid8 = 0.0f;
         if (t->all_finite) {
             table_quant8_kernel<128><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->s8, t->d8, d_max + 3);
             PG_HIP(hipGetLastError());
@@ -1582,6 +1624,7 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
         t->stats_valid = true;
         return PG_OK;
     }
+    const size_t n_blk = (size_t)((t->rows + kPieceRows - 1) / kPieceRows) + 2;
     if (!t->d16) {
         const size_t bytes = (t->rows + 64) * (size_t)t->dim * 2;
         if (hipMalloc((void**)&t->d16, bytes) != hipSuccess) {
@@ -1592,8 +1635,16 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
         }
         PG_HIP(hipMemsetAsync(t->d16 + t->rows * (size_t)t->dim, 0, 64 * (size_t)t->dim * 2, ctx->stream));
     }
-    if (t->dim == 64) table_shadow_kernel<64><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->d16, d_max, d_bad);
-    else table_shadow_kernel<128><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->d16, d_max, d_bad);
+    if (!t->dnorm2 && hipMalloc((void**)&t->dnorm2, n_blk * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        t->dnorm2 = nullptr;
+        t->shadow_failed = true;
+        return PG_OK;
+    }
+    PG_HIP(hipMemsetAsync(t->dnorm2, 0, n_blk * sizeof(float), ctx->stream));
+    PG_HIP(hipMemsetAsync(d_max, 0, 8, ctx->stream));
+    if (t->dim == 64) table_shadow_kernel<64><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->d16, d_max, d_bad, t->dnorm2);
+    else table_shadow_kernel<128><<<grid, 256, 0, ctx->stream>>>(t->d, t->rows, t->d16, d_max, d_bad, t->dnorm2);
     PG_HIP(hipGetLastError());
     PG_HIP(hipMemcpyAsync(ctx->h_status + 300, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
@@ -1741,6 +1792,8 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
         if (screen && !thr_is_open) {
             ScreenArgs sa;
             sa.tab16 = t->shadow_is_i8 ? (const void*)t->d8 : (const void*)t->d16;
+            sa.blk_norm2 = t->dnorm2;
+            sa.eps_unit = rs.eps;
             sa.qb16 = rs.qb16;
             sa.thr_screen = rs.thr_screen;
             sa.susp_cnt = rs.susp_cnt;
@@ -1845,7 +1898,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
                                                                  rs.qscale);
             else
                 screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
-                    rs.qpad, t->dim, t->max_norm, rs.qb16, rs.eps);
+                    rs.qpad, t->dim, rs.qb16, rs.eps);
             PG_HIP(hipGetLastError());
         }
         cur = 0;

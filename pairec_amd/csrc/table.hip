@@ -99,6 +99,7 @@ int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
     if (t->d) PG_HIP(hipFree(t->d));
     if (t->d16) PG_HIP(hipFree(t->d16));
     if (t->d8) PG_HIP(hipFree(t->d8));
+    if (t->dnorm2) PG_HIP(hipFree(t->dnorm2));
     delete t;
     return PG_OK;
 }
@@ -166,6 +167,7 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->max_norm, b->max_norm);
     std::swap(a->d16, b->d16);
     std::swap(a->d8, b->d8);
+    std::swap(a->dnorm2, b->dnorm2);
     std::swap(a->shadow_is_i8, b->shadow_is_i8);
     std::swap(a->s8, b->s8);
     std::swap(a->resid8, b->resid8);

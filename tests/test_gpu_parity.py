@@ -151,17 +151,18 @@ def test_recall_screen_is_exact_on_hostile_data(ctx):
 
 def test_recall_int8_screen_is_exact_on_hostile_data(ctx):
     """dim 128 is screened on an int8 shadow with ONE scale for the table (max|x| / 127) and an error bound that
-    uses the measured quantisation residual.  Data built against exactly that: a single huge outlier that makes the
-    scale useless (every ordinary row quantises to zero), rows of tiny magnitude, zero rows, a zero query, a query
-    with one dominant component, and winners that differ by less than one quantisation step — ids, order and score
-    bits must match the oracle; only speed may suffer."""
+    uses the measured quantisation residual.  Data built against exactly that: an outlier that coarsens the scale
+    (13 quantisation levels per sigma), rows of tiny magnitude, zero rows, a zero query, a query with one dominant
+    component, and winners that differ by less than one quantisation step — ids, order and score bits must match
+    the oracle.  An outlier large enough to make the scale useless sends the table to the bf16 shadow instead
+    (relative bound, per-block row norms): same exactness."""
     rng = np.random.default_rng(23)
     n, d, k, nq = 150_000, 128, 600, 72
     tab = rng.standard_normal((n, d)).astype(np.float32) * 0.05
-    tab[1234, 17] = 4.0e4                                              # the outlier: s8 ~ 315, rows ~ 0.05
+    tab[1234, 17] = 0.5                                                # 10 sigma: int8 stays, with a coarse step
     tab[2000:2600] *= 1e-6                                             # tiny rows
     tab[3000:3100] = 0.0                                               # zero rows
-    near = rng.standard_normal(d).astype(np.float32)
+    near = (rng.standard_normal(d) * 0.05).astype(np.float32)
     tab[5000:5400] = near * (1.0 + 1e-6 * np.arange(400, dtype=np.float32)[:, None])   # sub-step differences
     q = rng.standard_normal((nq, d)).astype(np.float32)
     q[0] = 0.0                                                         # zero query: every score is 0 → ties by row id
@@ -172,16 +173,37 @@ def test_recall_int8_screen_is_exact_on_hostile_data(ctx):
     t = pa.Table(ctx, n, d)
     t.upload(tab)
     eb, scale, resid = t.screen_info()
-    assert eb == 1 and scale > 300.0 and resid > 0.0
+    assert eb == 1 and 0.003 < scale < 0.005 and resid > 0.0
     rows, scores, _ = t.recall_topk(q, k)
     orow, osc = o.recall_topk(tab, q, k)
     assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
-    # the same rows without the outlier: a tight scale, the same exactness
-    tab[1234, 17] = 0.01
+    # a huge outlier: one int8 scale would quantise every ordinary row to zero → bf16 shadow
+    tab[1234, 17] = 4.0e4
     t.upload(tab)
-    eb, scale2, _ = t.screen_info()
-    assert eb == 1 and scale2 < 0.05
+    assert t.screen_info()[0] == 2
     rows, scores, _ = t.recall_topk(q, k)
+    orow, osc = o.recall_topk(tab, q, k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+    t.destroy()
+
+
+def test_recall_heavy_tailed_table_stays_fast(ctx):
+    """Student-t(3) rows: the largest element is ~100 x a typical row's, one int8 scale would make every row a
+    suspect (every plan overflows down to the bounded-chunk one: 560 ms per recall instead of 2.4).  The table
+    statistics route it to the bf16 shadow, whose bound is relative to each 32-row block's own largest norm: exact
+    as ever, and the pilot plan completes — no rescans."""
+    rng = np.random.default_rng(31)
+    n, d, k, nq = 2_200_000, 128, 400, 96
+    t = pa.Table(ctx, n, d)
+    tab = np.empty((n, d), dtype=np.float32)
+    for r0 in range(0, n, 200_000):
+        tab[r0:r0 + 200_000] = rng.standard_t(3, (200_000, d)).astype(np.float32)
+    t.upload(tab)
+    assert t.screen_info()[0] == 2
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    before = ctx.stats().recall_rescans
+    rows, scores, _ = t.recall_topk(q, k)
+    assert ctx.stats().recall_rescans == before
     orow, osc = o.recall_topk(tab, q, k)
     assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
     t.destroy()
