@@ -255,7 +255,8 @@ int pg_last_scan_kernel_ms(pg_ctx* ctx, double* out_ms, uint64_t* out_bytes);
  * streaming ceiling beside the nominal 8 TB/s. */
 int pg_hbm_read_probe(pg_ctx* ctx, const pg_table* t, int reps, double* out_gbps);
 /* The shadow the screened recall streams for this table, built now if it is not yet (it is otherwise built by
- * the first recall after an upload): *out_elem_bytes = 1 (int8, dim 128), 2 (bf16, dim 64), 0 when the table
+ * the first recall after an upload): *out_elem_bytes = 1 (int8: dim 128 with a value range one scale can serve),
+ * 2 (bf16: dim 64, and heavy-tailed dim-128 tables), 0 when the table
  * is scanned exactly in fp32 (other dims, non-finite rows, no memory).  int8: *out_scale = the table's
  * quantisation step s (x ~ s X, X in [-127,127]), *out_resid = max over rows of ||x - s X||_2 as measured —
  * the two table-side terms of the screen's error bound; 0 otherwise.  Any out pointer may be NULL. */
