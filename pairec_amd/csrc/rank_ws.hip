@@ -8,16 +8,18 @@ namespace pg {
 // mlp_kernel streams all 384 KB of weights from L2 for every 128-item tile (768 KB per tile through the
 // CU's L1 path: the waves wait on those loads for half their lifetime, profiles/history/r1g).  Here one
 // persistent workgroup per CU — 4 waves, one per SIMD, 512 registers each — walks a contiguous range of
-// 64-item tiles.  Wave w owns output columns 64w..64w+63 of layer 2 and keeps that 512 x 64 slice of W2 (64
-// MFMA B fragments, 256 registers) for the whole launch; it owns hidden columns 128w..128w+127 of layer 1:
-// the fragments of the first 64 stay in LDS (64 KB for the workgroup), those of the other 64 (16 KB per
-// wave and tile) are the only weights still streamed, and they are requested a phase ahead.  Two n-blocks
-// per wave is the point of the shape: an A fragment read from LDS feeds two MFMAs, which keeps the LDS
+// 64-item tiles.  Wave w owns output columns 64w..64w+63 of layer 2 and keeps that 512 x 64 slice of W2 for the
+// whole launch (62 MFMA B fragments in its AGPR half, 2 in LDS); it owns hidden columns 128w..128w+127 of
+// layer 1: the fragments of the first 64 stay in LDS (64 KB for the workgroup), those of the other 64 (16 KB
+// per wave and tile) are the only weights still streamed, requested a tile ahead in the head phase.  Two
+// n-blocks per wave is the point of the shape: an A fragment read from LDS feeds two MFMAs, which keeps the LDS
 // port at half load (one n-block per wave — 8 waves x 128 registers — was LDS-bound at 0.82 ms per 1.28 M
 // items).  With one wave per SIMD nothing hides a memory latency but the code itself, so every load runs a
-// phase ahead of its use: tile descriptors two tiles ahead, the candidate's row id one tile ahead, its
-// table row during layer 2 of the previous tile; the request's layer-1 partial (c1) and the biases sit
-// in LDS.  Same arithmetic and k order as mlp_kernel<1, 512, 256, …>, so the same bits.
+// phase ahead of its use: tile descriptors two tiles ahead, the candidate's row id one tile ahead, its table
+// row during layer 2 of the previous tile; the request's layer-1 partial (c1) and the biases sit in LDS; a
+// tile's scores are finished under the next tile's layer 1.  Layers 1 and 2 have mlp_kernel<1, 512, 256, …>'s
+// arithmetic and k order; the head sums a lane's 32 columns, then the item's 8 partials in slot order (a fixed
+// order of its own, inside the bf16 mode's 1e-5: DESIGN.md 5.2).
 // ---------------------------------------------------------------------------------------------
 constexpr size_t kWsRegion = (size_t)kWsItems * (kDIN + 512) * 2;         // X + H1 tiles (bf16)
 constexpr size_t kWsW1L = 4 * 16 * 1024;     // resident half of W1: 16 fragments per wave
