@@ -237,13 +237,23 @@ def main():
         run(s)
     sync()
     scan_ms, scan_launches, stage = [], 0, {"recall": [], "rank": []}
+    import gc
+    gc.collect()
+    gc.disable()                                      # no collector pauses inside the timed region
     t0 = time.perf_counter()
+    step_wall = []
     for s in range(args.warmup, total_steps):
+        ts = time.perf_counter()
         run(s)
         ms, nbytes = ctx.last_scan_kernel()          # HIP events around the scan launches (this step)
         scan_ms.append(ms)
+        step_wall.append((time.perf_counter() - ts) * 1e3)
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("PG_BENCH_STEPTIMES"):          # developer aid: per-step wall and scan times
+        print("step wall ms:", " ".join("%.2f" % x for x in step_wall), "| scan ms:", " ".join("%.2f" % x for x in scan_ms),
+              "| rescans", ctx.stats().recall_rescans, file=sys.stderr)
     st = ctx.stats()
     if world > 1:
         dev = torch.device("cpu") if share_gpu else torch.device("cuda", local_rank)
