@@ -59,7 +59,8 @@ def test_table_upload_gather_swap(ctx):
     (140000, 128, 300, 64),      # > 32 queries: int8 screen + exact re-scoring
     (70000, 64, 100, 45),
     (250000, 128, 5000, 128),    # full 128-query pass, K=5000
-    (200000, 128, 2000, 256),    # 256 queries: 8 B blocks, one wave per SIMD
+    (200000, 128, 2000, 256),    # 256 queries: two query halves per wave, two waves per SIMD
+    (2_300_000, 128, 12000, 40), # pilot plan with K > 8192: select beyond its LDS list, LDS bitonic final sort
     (90000, 64, 300, 200),
     (100003, 128, 1000, 100),
     (300017, 64, 5000, 7),       # ragged row count, K=5000
