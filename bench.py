@@ -121,7 +121,7 @@ class Pipeline1:
         ctx = self.ctx
         _lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, self.table.h, self.model.h, self.expr.h, b"gpu_dnn", d_q, R,
                                                self.K, self.d_rows, self.d_scores, self.d_rank, self.d_fused,
-                                               self.d_order))
+                                               self.d_order, None))
 
 
 def cpu_baseline(o, args, R, K):

@@ -54,6 +54,10 @@ const char* pg_version(void);
 int pg_init(int device, void* stream, pg_ctx** out);
 int pg_shutdown(pg_ctx* ctx);
 int pg_synchronize(pg_ctx* ctx);
+/* Developer / test knobs of one context (defaults come from PG_* environment variables read once, in pg_init):
+ * "no_pilot", "recall_exact", "screen_min", "pilot_fraction", "chunk_growth", "seed_rows", "pilot_growth",
+ * "debug_scan", "rank_no_ws", "sort_lds"; value is parsed as a number. */
+int pg_set_option(pg_ctx* ctx, const char* name, const char* value);
 int pg_device_malloc(pg_ctx* ctx, size_t bytes, void** out);
 int pg_device_free(pg_ctx* ctx, void* p);
 int pg_memcpy_h2d(pg_ctx* ctx, void* dst, const void* src, size_t bytes);
@@ -85,7 +89,7 @@ int pg_table_gather(pg_ctx* ctx, const pg_table* t, const uint32_t* rows, uint32
  * queries: [nq][dim] fp32, nq <= 256 per call (<= 32 when dim > 128); one call = one table pass.
  * Finite tables of dim 128 / 64 are scanned with an int8 / bf16 MFMA screen over a quantised shadow of the rows
  * (a rigorous bound of every score) followed by exact re-scoring of the survivors, everything else with the
- * exact fp32-MFMA scan (then nq <= 64) — results are identical bit for bit.  out_rows: [nq][k] global row ids (row_offset + local), out_scores:
+ * exact fp32-MFMA scan (groups of 64 queries per launch) — results are identical bit for bit.  out_rows: [nq][k] global row ids (row_offset + local), out_scores:
  * [nq][k].  If the table has fewer than k rows the tail is filled with
  * row = UINT64_MAX, score = -inf and *out_count (optional) receives the valid count. */
 int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_t nq, uint32_t k,
@@ -233,11 +237,64 @@ int pg_rank_fm2t_rows_dev(pg_ctx* ctx, const pg_model* m, const pg_features* fs,
  * name in RankAlgoList) and/or "current_score" (Item.Score, i.e. the recall score, module/item.go:189-212) —
  * and sort each request's candidates by the fused score, descending.
  * Outputs, all [nq][k]: global row ids and recall scores in recall order, the model's scores, the fused fp64
- * scores (same order), and d_out_order = positions 0..k-1 of each request sorted by fused score. */
+ * scores (same order), and d_out_order = positions 0..k-1 of each request sorted by fused score.
+ * d_out_count (optional, [nq]) receives each request's number of real candidates: a table with fewer than k rows
+ * pads every list with row = UINT64_MAX, recall score = -inf, model score = 0, fused score = NaN — the sort puts
+ * those slots last, so the first d_out_count[q] positions of a request's order are its items.
+ * The stages are enqueued back to back and verified once, at the end; the call returns after that check. */
 int pg_recommend_dnn3_dev(pg_ctx* ctx, const pg_table* t, const pg_model* m, const pg_expr* e, const char* rank_var,
                           const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
                           float* d_out_recall_scores, float* d_out_rank_scores, double* d_out_fused,
-                          uint32_t* d_out_order);
+                          uint32_t* d_out_order, uint32_t* d_out_count);
+
+/* ---- request coalescer --------------------------------------------------------------------------
+ * The reference calls its plug-ins once per request from many goroutines at once: one IAlgorithm.Run per recall
+ * (service/recall.go:129-145 → vector_recall.go:88), one per batch of BatchCount = 100 items and per algorithm
+ * (service/rank/rank_service.go:264-289), across overlapping HTTP requests (SURVEY.md 8b "Threading").  A table
+ * pass costs the same for 1 query as for 128, so the library batches across callers itself: the pg_coalescer_*
+ * calls below are issued concurrently from any number of host threads, each with ONE request; they block while a
+ * library-owned dispatcher thread forms a batch — up to max_batch requests; a partial batch goes out once the
+ * device has nothing queued and its oldest request has waited max_wait_us — runs ONE table pass / ONE rank launch
+ * for the whole batch on the context's stream, and hands every caller its slice.  Up to `depth` batches are in
+ * flight, so the next batch is queued behind the running one.  Results are bit-identical to the same request
+ * issued alone through pg_recall_topk / pg_rank_dnn3 / pg_recommend_dnn3_dev (scores do not depend on what else
+ * shares a pass).  cgo note: the calling goroutine's OS thread is parked in a futex wait, not spinning. */
+typedef struct pg_coalescer pg_coalescer;
+typedef struct {
+    uint32_t k;               /* recall depth (RecallConfig.RecallCount), fixed per coalescer: 1..16384            */
+    uint32_t max_batch;       /* requests per table pass, 1..256 (<= 32 when dim > 128); 0 = the maximum           */
+    uint32_t max_wait_us;     /* how long a request may wait for company while the device is idle; 0 = 100         */
+    uint32_t depth;           /* batches in flight, 1..4; 0 = 2                                                    */
+    uint32_t max_top_n;       /* pg_coalescer_recommend: largest page a caller may ask for, <= k; 0 = k            */
+    uint32_t max_rank_items;  /* pg_coalescer_rank_dnn3: most candidates in one call (BatchCount); 0 = k           */
+} pg_coalescer_config;
+/* model / expr / rank_var may be NULL: then only pg_coalescer_recall (and pg_coalescer_rank_dnn3 with a model) work. */
+int pg_coalescer_create(pg_ctx* ctx, const pg_table* t, const pg_model* m, const pg_expr* e, const char* rank_var,
+                        const pg_coalescer_config* cfg, pg_coalescer** out);
+/* fails every waiting request with PG_ERR_INVALID, joins the worker threads, frees the buffers */
+int pg_coalescer_destroy(pg_coalescer* c);
+/* VectorRecall.GetCandidateItems → IAlgorithm.Run(VectorRequest{K, Vector}) for ONE user vector [dim]:
+ * out_rows[k], out_scores[k] as pg_recall_topk, *out_count (optional) = valid entries. */
+int pg_coalescer_recall(pg_coalescer* c, const float* query, uint64_t* out_rows, float* out_scores,
+                        uint32_t* out_count);
+/* IAlgorithm.Run of the rank model for ONE batch of n <= max_rank_items candidates of one user
+ * (rank_service.go:273): cand_rows are local row indices of the table, out_scores[n] in request order. */
+int pg_coalescer_rank_dnn3(pg_coalescer* c, const float* user_vec, const uint32_t* cand_rows, uint32_t n,
+                           float* out_scores);
+/* The whole path for ONE request (what pg_recommend_dnn3_dev does for a batch): recall top-k → DNN3 rank → RankScore
+ * → descending sort; the caller receives the first top_n <= max_top_n entries of the sorted list — global row ids,
+ * recall scores, model scores and fused scores, all [top_n] — and *out_count (optional) = entries that are items
+ * (min(top_n, rows of the table)). */
+int pg_coalescer_recommend(pg_coalescer* c, const float* user_vec, uint32_t top_n, uint64_t* out_rows,
+                           float* out_recall_scores, float* out_rank_scores, double* out_fused,
+                           uint32_t* out_count);
+typedef struct {
+    uint64_t requests[3], batches[3];   /* per flavour: 0 recall, 1 rank, 2 recommend */
+    uint64_t largest_batch[3];
+    uint64_t replans;                   /* batches whose first recall plan did not hold and was re-run */
+    double   device_ms[3];              /* summed enqueue → completion time of the batches */
+} pg_coalescer_stats_t;
+int pg_coalescer_stats(pg_coalescer* c, pg_coalescer_stats_t* out);
 
 /* ---- stats ----------------------------------------------------------------------------------*/
 typedef struct {

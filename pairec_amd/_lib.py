@@ -23,7 +23,9 @@ EXPORTS = [
     "pg_dpp", "pg_stats", "pg_last_scan_kernel_ms", "pg_rows_to_local_dev", "pg_widen_f32_dev",
     "pg_hbm_read_probe", "pg_table_screen_info", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
     "pg_features_column_index", "pg_features_num_columns", "pg_features_gather_i32_dev",
-    "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev", "pg_recommend_dnn3_dev",
+    "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev", "pg_recommend_dnn3_dev", "pg_set_option",
+    "pg_coalescer_create", "pg_coalescer_destroy", "pg_coalescer_recall", "pg_coalescer_rank_dnn3",
+    "pg_coalescer_recommend", "pg_coalescer_stats",
 ]
 
 
@@ -33,6 +35,16 @@ class PgStats(C.Structure):
                 ("rank_items", C.c_uint64), ("sort_calls", C.c_uint64), ("sort_items", C.c_uint64),
                 ("last_recall_ms", C.c_double), ("last_rank_ms", C.c_double),
                 ("last_sort_ms", C.c_double)]
+
+
+class PgCoalescerConfig(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("max_batch", C.c_uint32), ("max_wait_us", C.c_uint32), ("depth", C.c_uint32),
+                ("max_top_n", C.c_uint32), ("max_rank_items", C.c_uint32)]
+
+
+class PgCoalescerStats(C.Structure):
+    _fields_ = [("requests", C.c_uint64 * 3), ("batches", C.c_uint64 * 3), ("largest_batch", C.c_uint64 * 3),
+                ("replans", C.c_uint64), ("device_ms", C.c_double * 3)]
 
 
 _lib = None
@@ -94,7 +106,14 @@ def load():
         "pg_features_gather_i32_dev": [vp, vp, vp, u32, vp, u32, vp],
         "pg_features_gather_f32_dev": [vp, vp, vp, u32, vp, vp, vp, u32, vp],
         "pg_rank_fm2t_rows_dev": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp],
-        "pg_recommend_dnn3_dev": [vp, vp, vp, vp, C.c_char_p, vp, u32, u32, vp, vp, vp, vp, vp],
+        "pg_recommend_dnn3_dev": [vp, vp, vp, vp, C.c_char_p, vp, u32, u32, vp, vp, vp, vp, vp, vp],
+        "pg_set_option": [vp, C.c_char_p, C.c_char_p],
+        "pg_coalescer_create": [vp, vp, vp, vp, C.c_char_p, P(PgCoalescerConfig), P(vp)],
+        "pg_coalescer_destroy": [vp],
+        "pg_coalescer_recall": [vp, vp, vp, vp, P(u32)],
+        "pg_coalescer_rank_dnn3": [vp, vp, vp, u32, vp],
+        "pg_coalescer_recommend": [vp, vp, u32, vp, vp, vp, vp, P(u32)],
+        "pg_coalescer_stats": [vp, P(PgCoalescerStats)],
         "pg_rows_to_local_dev": [vp, vp, vp, u32, vp, vp],
         "pg_widen_f32_dev": [vp, vp, u32, vp],
         "pg_stats": [vp, P(PgStats)],

@@ -1,7 +1,26 @@
 // api.cpp — context lifecycle, error convention, memory helpers of libpairec_gpu.so.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace pg {
+
+static void knobs_from_env(Knobs* k) {
+    auto num = [](const char* name, double dflt) { const char* v = getenv(name); return v ? atof(v) : dflt; };
+    auto flag = [](const char* name) { return getenv(name) != nullptr; };
+    k->screen_min = (uint32_t)num("PG_SCREEN_MIN", 0);
+    k->recall_exact = flag("PG_RECALL_EXACT");
+    k->pilot_fraction = num("PG_PILOT_FRACTION", 0.0);
+    k->no_pilot = flag("PG_NO_PILOT");
+    k->chunk_growth = num("PG_CHUNK_GROWTH", 0.0);
+    k->seed_rows = (uint32_t)num("PG_SEED_ROWS", 8192);
+    k->pilot_growth = num("PG_PILOT_GROWTH", 0.0);
+    k->debug_scan = flag("PG_DEBUG_SCAN");
+    k->screen_bf16 = flag("PG_SCREEN_BF16");
+    k->screen_i8 = flag("PG_SCREEN_I8");
+    k->rank_no_ws = flag("PG_RANK_NO_WS");
+    k->sort_lds = flag("PG_SORT_LDS");
+}
 
 static thread_local std::string g_err;
 
@@ -60,6 +79,7 @@ int pg_init(int device, void* stream, pg_ctx** out) {
         return PG_ERR_UNSUPPORTED;
     }
     pg_ctx* c = new pg_ctx();
+    pg::knobs_from_env(&c->knobs);
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     if (stream) {
@@ -78,6 +98,7 @@ int pg_shutdown(pg_ctx* ctx) {
     if (!ctx) return PG_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    pg::pipe_pool_destroy(ctx);
     for (auto& s : ctx->scratch)
         if (s.p) hipFree(s.p);
     for (auto& e : ctx->ev)
@@ -86,6 +107,30 @@ int pg_shutdown(pg_ctx* ctx) {
     if (ctx->h_status) hipHostFree(ctx->h_status);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+    return PG_OK;
+}
+
+int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
+    PG_REQUIRE(ctx && name && value, "pg_set_option: NULL argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    pg::Knobs& k = ctx->knobs;
+    const double v = atof(value);
+    const bool b = v != 0.0;
+    const std::string n(name);
+    if (n == "screen_min") k.screen_min = (uint32_t)v;
+    else if (n == "recall_exact") k.recall_exact = b;
+    else if (n == "pilot_fraction") k.pilot_fraction = v;
+    else if (n == "no_pilot") k.no_pilot = b;
+    else if (n == "chunk_growth") k.chunk_growth = v;
+    else if (n == "seed_rows") k.seed_rows = v >= 32 ? (uint32_t)v : 8192u;
+    else if (n == "pilot_growth") k.pilot_growth = v;
+    else if (n == "debug_scan") k.debug_scan = b;
+    else if (n == "rank_no_ws") k.rank_no_ws = b;
+    else if (n == "sort_lds") k.sort_lds = b;
+    else {
+        pg::set_error("pg_set_option: unknown option \"%s\"", name);
+        return PG_ERR_INVALID;
+    }
     return PG_OK;
 }
 

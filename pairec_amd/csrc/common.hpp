@@ -16,6 +16,7 @@
 
 namespace pg {
 
+struct PipeRun;          // pipeline.hpp
 void set_error(const char* fmt, ...);
 
 #define PG_HIP(expr)                                                                           \
@@ -47,6 +48,24 @@ struct Scratch {
     size_t cap = 0;
 };
 
+// Developer / tuning knobs.  Read from the environment ONCE, in pg_init (a serving process must not change
+// plans because of a stray variable later on, and getenv races with a host application's setenv); tests and
+// A/B scripts change them per context with pg_set_option.
+struct Knobs {
+    uint32_t screen_min = 0;       // PG_SCREEN_MIN: batches up to this many queries use the exact scan
+    bool recall_exact = false;     // PG_RECALL_EXACT: never screen
+    double pilot_fraction = 0.0;   // PG_PILOT_FRACTION: sample fraction of the pilot plan (0 = default 1/64)
+    bool no_pilot = false;         // PG_NO_PILOT: skip the pilot plan
+    double chunk_growth = 0.0;     // PG_CHUNK_GROWTH: geometric growth of the grow plan (0 = default)
+    uint32_t seed_rows = 8192;     // PG_SEED_ROWS: exact seed of the pilot sample
+    double pilot_growth = 0.0;     // PG_PILOT_GROWTH: > 0 = geometric chunks over the sample instead of seed + one launch
+    bool debug_scan = false;       // PG_DEBUG_SCAN: print per-launch times and suspect counts
+    bool screen_bf16 = false;      // PG_SCREEN_BF16: bf16 shadow for dim-128 tables too
+    bool screen_i8 = false;        // PG_SCREEN_I8: int8 shadow even for heavy-tailed tables
+    bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
+    bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
+};
+
 }  // namespace pg
 
 struct pg_table {
@@ -72,6 +91,29 @@ struct pg_table {
     bool shadow_failed = false;  // allocation failed once: stay on the exact scan
 };
 
+// rank model weights resident in HBM (rank_mlp.hip loads them)
+struct pg_model {
+    pg_model_kind kind;
+    int prec;
+    uint32_t d_user = 0, d_item = 0, h1 = 0, h2 = 0;           // DNN3
+    uint32_t nuf = 0, nif = 0, k = 0, th = 0, to = 0, vocab = 0;  // two-tower
+    float b3 = 0.f, fm_b = 0.f;
+    // device buffers
+    float* w1u = nullptr;   // [d_user][h1] (DNN3) / uw1 (two-tower), operand-rounded fp32
+    float* b1 = nullptr;    // b1 / ub1
+    float* uw2 = nullptr;   // two-tower user layer 2
+    float* ub2 = nullptr;
+    void* w1p = nullptr;    // packed item-side layer 1
+    void* w2p = nullptr;    // packed layer 2
+    float* c1_shared = nullptr;   // two-tower: ib1
+    float* b2 = nullptr;
+    float* w3 = nullptr;    // DNN3 head
+    float* fields = nullptr;          // two-tower: all field tables, one allocation
+    const float** d_field_emb = nullptr;
+    const float** d_field_lin = nullptr;
+    std::vector<void*> allocs;
+};
+
 struct pg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -79,13 +121,15 @@ struct pg_ctx {
     int num_cus = 256;
     std::mutex mu;               // serialises calls on this context
     pg::Scratch scratch[10];     // named scratch slots (see users; 8 = pg_recommend_dnn3_dev's intermediates)
-    std::mutex pipe_mu;          // serialises whole pg_recommend_* calls (they span several locked stages)
+    std::mutex pool_mu;          // guards pipe_free
+    std::vector<pg::PipeRun*> pipe_free;     // per-batch status blocks / events of the device-resident pipelines
     std::map<const void*, size_t> dyn_lds;   // kernels whose dynamic-LDS limit was raised on this device
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0/1 probes, 2/3 rank, 4/5 sort
     std::vector<hipEvent_t> ev_pool;   // per-launch timing events (scan kernel roofline figure)
     uint32_t last_scan_launches = 0;
     bool rank_timing_pending = false;
     pg_stats_t stats{};
+    pg::Knobs knobs;
     double last_scan_ms = 0.0;
     uint64_t last_scan_bytes = 0;
     // pinned host staging for small status words
@@ -93,6 +137,74 @@ struct pg_ctx {
 };
 
 namespace pg {
+
+// ---- recall.hip: a recall whose plans are enqueued without host synchronisation and verified later --------
+struct RecallScratch {
+    float* qpad;
+    float* thr;
+    uint32_t* cnt;
+    uint32_t* overflow;
+    uint64_t* cand[2];
+    uint32_t cap;
+    // screened scan only
+    uint4* qb16;
+    float* eps;
+    float* thr_screen;
+    uint32_t* susp_cnt;      // [kMaxQueries]
+    uint32_t* susp;          // [kMaxQueries][cap] suspect rows of the current launch
+    float* qscale;           // [kMaxQueries] int8 screen: the queries' scales
+};
+struct RecallJob {
+    // set by the caller
+    pg_ctx* ctx = nullptr;
+    const pg_table* t = nullptr;
+    const float* d_queries = nullptr;       // [nq][dim] device
+    uint32_t nq = 0, k = 0;
+    uint64_t* d_out_rows = nullptr;         // [nq][k] device
+    float* d_out_scores = nullptr;          // [nq][k] device
+    uint32_t* d_out_count = nullptr;        // [nq] device, optional
+    uint32_t* h_status = nullptr;           // pinned host, >= 1 + nq words: [0] overflow flag, [1 + q] valid count of query q
+    std::vector<hipEvent_t>* events = nullptr;   // timing events (grown on demand); one job at a time per pool
+    // state (recall_job_*)
+    RecallScratch rs{};
+    uint32_t* d_count = nullptr;
+    uint32_t rows = 0, nblocks = 0;
+    bool screen = false;
+    int plans[3] = {0, 0, 0};
+    int n_plans = 0, next_plan = 0, enqueued_plan = -1;
+    uint32_t stride = 1, sample_blocks = 0, k_pilot = 0, perm_mul = 1;
+    uint32_t n_ev = 0;
+    double scan_ms = 0.0, total_ms = 0.0;
+    uint64_t scanned_rows = 0;
+    uint32_t scan_launches = 0;
+};
+// All four: caller holds ctx->mu.  prepare may synchronise once (a table's statistics / shadow on first use).
+int recall_job_prepare(RecallJob* j);
+int recall_job_enqueue(RecallJob* j);                 // enqueue the next plan + the status copy into h_status
+int recall_job_check(RecallJob* j, bool* ok);         // after the stream passed the status copy: did the plan hold?
+void recall_job_finish(RecallJob* j);                 // publish timing / counters into ctx
+int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq, uint32_t k,
+                      uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count, uint32_t* d_out_count);
+int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs);
+int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
+                  uint32_t cap, uint32_t k);
+int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap, uint32_t nq, uint32_t k,
+                 uint64_t row_offset, uint64_t* d_out_rows, float* d_out_scores, uint32_t* d_out_count);
+int ensure_table_stats(pg_ctx* ctx, const pg_table* tc);
+
+// ---- stage launchers shared with pipeline.hip (caller holds ctx->mu; nothing synchronises) -------------------
+int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float* d_user,
+                         const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items,
+                         float* d_out);
+// d_err: device flags, OR-ed with 1 where an item divides by zero; item i reports into d_err[i / items_per_flag]
+// (items_per_flag = 0: one flag for the call)
+int expr_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items, double* d_out,
+                             uint32_t* d_err, uint32_t items_per_flag);
+void set_expr_arith_error(const pg_expr* e);
+int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg, uint32_t n_items,
+                    uint32_t max_seg, int desc, uint32_t* d_out);
+
+void pipe_pool_destroy(pg_ctx* ctx);      // pipeline.hip
 int scratch_reserve(pg_ctx* ctx, int slot, size_t bytes, void** out);
 // raise a kernel's dynamic-LDS limit once per context (the attribute is per device: a process may hold
 // contexts on several GPUs); caller holds ctx->mu

@@ -261,7 +261,7 @@ struct ExprDev {
 };
 
 __global__ void expr_eval_kernel(ExprDev e, const double* __restrict__ vars, uint32_t n_items,
-                                 double* __restrict__ out, uint32_t* __restrict__ err) {
+                                 double* __restrict__ out, uint32_t* __restrict__ err, uint32_t items_per_flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
     double st[kMaxStack];
@@ -300,7 +300,28 @@ __global__ void expr_eval_kernel(ExprDev e, const double* __restrict__ vars, uin
         }
     }
     out[i] = sp > 0 ? st[sp - 1] : 0.0;
-    if (bad) atomicOr(err, 1u);
+    if (bad) atomicOr(err + (items_per_flag ? i / items_per_flag : 0u), 1u);
+}
+
+int expr_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items, double* d_out,
+                             uint32_t* d_err, uint32_t items_per_flag) {
+    if (e->empty) {
+        // GetExpAST("") == nil: the caller leaves Item.Score untouched; evaluate to 0 like
+        // ExprASTResult on a nil tree would
+        PG_HIP(hipMemsetAsync(d_out, 0, (size_t)n_items * 8, ctx->stream));
+    } else {
+        ExprDev dev;
+        dev.n = (uint32_t)e->prog.size();
+        for (size_t i = 0; i < e->prog.size(); ++i) dev.prog[i] = e->prog[i];
+        expr_eval_kernel<<<(n_items + 255) / 256, 256, 0, ctx->stream>>>(dev, d_vars, n_items, d_out, d_err, items_per_flag);
+        PG_HIP(hipGetLastError());
+    }
+    return PG_OK;
+}
+
+void set_expr_arith_error(const pg_expr* e) {
+    set_error("pg_expr_eval: violation of arithmetic specification: a division by zero in '%s' "
+              "(the reference panics in ExprASTResult, utils/ast/ast.go:243-249)", e->source.c_str());
 }
 
 static int expr_eval_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items,
@@ -310,22 +331,11 @@ static int expr_eval_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars,
     if ((rc = scratch_reserve(ctx, 4, 4096, &p))) return rc;
     uint32_t* d_err = (uint32_t*)p + 320;
     PG_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
-    if (e->empty) {
-        // GetExpAST("") == nil: the caller leaves Item.Score untouched; evaluate to 0 like
-        // ExprASTResult on a nil tree would
-        PG_HIP(hipMemsetAsync(d_out, 0, (size_t)n_items * 8, ctx->stream));
-    } else {
-        ExprDev dev;
-        dev.n = (uint32_t)e->prog.size();
-        for (size_t i = 0; i < e->prog.size(); ++i) dev.prog[i] = e->prog[i];
-        expr_eval_kernel<<<(n_items + 255) / 256, 256, 0, ctx->stream>>>(dev, d_vars, n_items, d_out, d_err);
-        PG_HIP(hipGetLastError());
-    }
+    if ((rc = expr_eval_enqueue_locked(ctx, e, d_vars, n_items, d_out, d_err, 0))) return rc;
     PG_HIP(hipMemcpyAsync(ctx->h_status + 320, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->h_status[320] != 0) {
-        set_error("pg_expr_eval: violation of arithmetic specification: a division by zero in '%s' "
-                  "(the reference panics in ExprASTResult, utils/ast/ast.go:243-249)", e->source.c_str());
+        set_expr_arith_error(e);
         return PG_ERR_ARITH;
     }
     return PG_OK;

@@ -1,5 +1,5 @@
 // misc.hip — small glue kernels that keep a request batch on the device between stages.
-#include "common.hpp"
+#include "pipeline.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -50,6 +50,20 @@ __global__ void uniform_offsets_kernel(uint32_t nq, uint32_t k, uint32_t* __rest
     if (i <= nq) off[i] = i * k;
 }
 
+int rows_to_local_locked(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t n, uint32_t* d_local,
+                         uint8_t* d_owned) {
+    if (n == 0) return PG_OK;
+    rows_to_local_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d_rows, n, t->row_offset, t->rows, d_local, d_owned);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int uniform_offsets_locked(pg_ctx* ctx, uint32_t nq, uint32_t k, uint32_t* d_off) {
+    uniform_offsets_kernel<<<(nq + 256) / 256, 256, 0, ctx->stream>>>(nq, k, d_off);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 }  // namespace pg
 
 extern "C" {
@@ -86,9 +100,7 @@ int pg_rows_to_local_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows,
     PG_REQUIRE(ctx && t && (n == 0 || (d_rows && d_local)), "pg_rows_to_local_dev: NULL argument");
     if (n == 0) return PG_OK;
     std::lock_guard<std::mutex> g(ctx->mu);
-    pg::rows_to_local_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d_rows, n, t->row_offset, t->rows, d_local, d_owned);
-    PG_HIP(hipGetLastError());
-    return PG_OK;
+    return pg::rows_to_local_locked(ctx, t, d_rows, n, d_local, d_owned);
 }
 
 int pg_widen_f32_dev(pg_ctx* ctx, const float* d_in, uint32_t n, double* d_out) {
@@ -98,51 +110,6 @@ int pg_widen_f32_dev(pg_ctx* ctx, const float* d_in, uint32_t n, double* d_out) 
     pg::widen_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d_in, n, d_out);
     PG_HIP(hipGetLastError());
     return PG_OK;
-}
-
-int pg_recommend_dnn3_dev(pg_ctx* ctx, const pg_table* t, const pg_model* m, const pg_expr* e, const char* rank_var,
-                          const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
-                          float* d_out_recall_scores, float* d_out_rank_scores, double* d_out_fused,
-                          uint32_t* d_out_order) {
-    PG_REQUIRE(ctx && t && m && e && rank_var && d_queries && d_out_rows && d_out_recall_scores && d_out_rank_scores &&
-                   d_out_fused && d_out_order,
-               "pg_recommend_dnn3_dev: NULL argument");
-    PG_REQUIRE(nq > 0 && k > 0 && (uint64_t)nq * k < 0x7FFFFFFFull, "pg_recommend_dnn3_dev: bad nq / k");
-    // bind the expression's variables: the rank model's score and Item.Score ("current_score" = recall score)
-    const int nv = pg_expr_num_vars(e);
-    std::vector<int> src((size_t)nv);
-    for (int i = 0; i < nv; ++i) {
-        const char* name = pg_expr_var_name(e, i);
-        if (!strcmp(name, rank_var)) src[(size_t)i] = 1;
-        else if (!strcmp(name, "current_score")) src[(size_t)i] = 0;
-        else {
-            pg::set_error("pg_recommend_dnn3_dev: RankScore variable \"%s\" is neither \"%s\" nor current_score", name, rank_var);
-            return PG_ERR_INVALID;
-        }
-    }
-    std::lock_guard<std::mutex> pipe(ctx->pipe_mu);          // the stages below lock ctx->mu one by one
-    const uint32_t n = nq * k;
-    void* buf;
-    int rc;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b_local = al((size_t)n * 4), b_off = al((size_t)(nq + 1) * 4), b_vars = al((size_t)std::max(nv, 1) * n * 8);
-    {
-        std::lock_guard<std::mutex> g(ctx->mu);
-        if ((rc = pg::scratch_reserve(ctx, 8, b_local + b_off + b_vars, &buf))) return rc;
-        pg::uniform_offsets_kernel<<<(nq + 256) / 256, 256, 0, ctx->stream>>>(nq, k, (uint32_t*)((char*)buf + b_local));
-        PG_HIP(hipGetLastError());
-    }
-    uint32_t* d_local = (uint32_t*)buf;
-    uint32_t* d_off = (uint32_t*)((char*)buf + b_local);
-    double* d_vars = (double*)((char*)buf + b_local + b_off);
-    if ((rc = pg_recall_topk_dev(ctx, t, d_queries, nq, k, d_out_rows, d_out_recall_scores, nullptr))) return rc;
-    if ((rc = pg_rows_to_local_dev(ctx, t, d_out_rows, n, d_local, nullptr))) return rc;
-    if ((rc = pg_rank_dnn3_dev(ctx, m, t, d_queries, d_local, d_off, nq, n, d_out_rank_scores))) return rc;
-    for (int i = 0; i < nv; ++i)
-        if ((rc = pg_widen_f32_dev(ctx, src[(size_t)i] ? d_out_rank_scores : d_out_recall_scores, n, d_vars + (size_t)i * n)))
-            return rc;
-    if ((rc = pg_expr_eval_dev(ctx, e, d_vars, n, d_out_fused))) return rc;
-    return pg_sort_scores_dev(ctx, d_out_fused, d_off, nq, n, k, 1, d_out_order);
 }
 
 }  // extern "C"

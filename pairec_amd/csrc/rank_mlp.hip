@@ -551,28 +551,6 @@ __global__ __launch_bounds__(256) void fm2t_user_kernel(
 // ---------------------------------------------------------------------------------------------
 // host side: model blobs, weight pre-packing, launches
 // ---------------------------------------------------------------------------------------------
-struct pg_model {
-    pg_model_kind kind;
-    int prec;
-    uint32_t d_user = 0, d_item = 0, h1 = 0, h2 = 0;           // DNN3
-    uint32_t nuf = 0, nif = 0, k = 0, th = 0, to = 0, vocab = 0;  // two-tower
-    float b3 = 0.f, fm_b = 0.f;
-    // device buffers
-    float* w1u = nullptr;   // [d_user][h1] (DNN3) / uw1 (two-tower), operand-rounded fp32
-    float* b1 = nullptr;    // b1 / ub1
-    float* uw2 = nullptr;   // two-tower user layer 2
-    float* ub2 = nullptr;
-    void* w1p = nullptr;    // packed item-side layer 1
-    void* w2p = nullptr;    // packed layer 2
-    float* c1_shared = nullptr;   // two-tower: ib1
-    float* b2 = nullptr;
-    float* w3 = nullptr;    // DNN3 head
-    float* fields = nullptr;          // two-tower: all field tables, one allocation
-    const float** d_field_emb = nullptr;
-    const float** d_field_lin = nullptr;
-    std::vector<void*> allocs;
-};
-
 namespace pg {
 
 // Pack W[K][N] (row-major, k major) into MFMA B-fragment order, 1 KiB per (n-block, k-group).
@@ -645,7 +623,7 @@ static int rank_scratch(pg_ctx* ctx, uint32_t n_req, uint32_t max_tiles, uint32_
     return PG_OK;
 }
 
-static int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
+int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
                                 const float* d_user, const uint32_t* d_cand, const uint32_t* d_off,
                                 uint32_t n_req, uint32_t n_items, float* d_out) {
     if (n_items == 0 || n_req == 0) return PG_OK;
@@ -653,7 +631,7 @@ static int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* 
     RankScratch rs;
     int rc;
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->h1, &rs))) return rc;
-    static const bool no_ws = getenv("PG_RANK_NO_WS") != nullptr;        // A/B switch: the streaming kernel
+    const bool no_ws = ctx->knobs.rank_no_ws;        // A/B switch: the streaming kernel
     const bool ws = m->prec && !no_ws;
     const uint32_t grid128 = n_items / kBM + n_req;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));

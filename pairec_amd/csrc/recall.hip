@@ -1442,7 +1442,7 @@ __global__ void merge_keys_kernel(const uint64_t* __restrict__ rows, const float
     if (i == 0) cnt[q] = per_q;
 }
 
-static int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
+int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
                          uint32_t cap, uint32_t k) {
     constexpr size_t lds = (size_t)kSelLdsKeys * 8;
     int rc_attr;
@@ -1497,27 +1497,11 @@ static int dispatch_scan(pg_ctx* ctx, uint32_t dim, const ScanArgs& a) {
     return PG_ERR_UNSUPPORTED;
 }
 
-struct RecallScratch {
-    float* qpad;
-    float* thr;
-    uint32_t* cnt;
-    uint32_t* overflow;
-    uint64_t* cand[2];
-    uint32_t cap;
-    // screened scan only
-    uint4* qb16;
-    float* eps;
-    float* thr_screen;
-    uint32_t* susp_cnt;      // [kMaxQueries]
-    uint32_t* susp;          // [kMaxQueries][cap] suspect rows of the current launch
-    float* qscale;           // [kMaxQueries] int8 screen: the queries' scales
-};
-
 constexpr uint32_t kFirstChunkRows = 32768;
 constexpr uint32_t kRescoreBlocksPerQuery = 16;   // x 256 suspects per block per stride step
 constexpr uint32_t kCandSlack = 1u << 19;      // candidate capacity beyond K per query
 
-static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
+int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     const uint32_t cap = k + kCandSlack;
     void* small;
     int rc;
@@ -1542,7 +1526,7 @@ static int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* 
     return PG_OK;
 }
 
-static int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap,
+int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap,
                         uint32_t nq, uint32_t k, uint64_t row_offset, uint64_t* d_out_rows,
                         float* d_out_scores, uint32_t* d_out_count) {
     if (k <= kBitonicMax) {
@@ -1564,11 +1548,11 @@ static int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, 
 // statistics + shadow of a table (lazily, cached until the next upload / fill): int8 for dim 128 (two passes:
 // statistics, then quantisation with the table's scale), bf16 for dim 64 or when PG_SCREEN_BF16 is set (A/B runs).
 // Tables the screen cannot serve (other dims, no memory for the shadow) keep stats_valid = false.
-static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
+int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     pg_table* t = const_cast<pg_table*>(tc);          // lazily computed cache
     if (t->stats_valid || t->shadow_failed) return PG_OK;
     if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
-    static const bool force_bf16 = getenv("PG_SCREEN_BF16") != nullptr;
+    const bool force_bf16 = ctx->knobs.screen_bf16;
     bool i8 = t->dim == 128 && !force_bf16;
     void* p;
     int rc;
@@ -1596,7 +1580,7 @@ static int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
         // Heavy tails or outliers (a Student-t table: int8 margin 130 x the bf16 one, every row a suspect, 560 ms per
         // recall instead of 2.4) go to the bf16 shadow with per-block norms.
         const float rms_norm = sqrtf(sumsq / (float)(t->rows ? t->rows : 1));
-        static const bool force_i8 = getenv("PG_SCREEN_I8") != nullptr;
+        const bool force_i8 = ctx->knobs.screen_i8;
         if (t->all_finite && !force_i8 && t->s8 * sqrtf((float)t->dim / 12.0f) > 4.0f * kScreenEps * rms_norm) i8 = false;
     }
     if (i8) {
@@ -1714,82 +1698,99 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
     return launch_screen<128, 4, 8>(ctx, a);
 }
 
-// the whole recall for one batch of queries (one table pass); all pointers are device pointers
-static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq,
-                             uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
-                             uint32_t* out_count) {
-    RecallScratch rs;
+// ---------------------------------------------------------------------------------------------
+// One recall = one batch of queries against one table (one table pass when the first plan holds).
+// Plans, tried in order until one completes without overflowing a candidate list:
+//  pilot — the threshold comes from a jittered 1/S block sample (its K'-th best score, K' chosen six
+//          sigma above the expected rank K/S, so it is below the true K-th best except with
+//          negligible probability), then ONE full-rate pass over the whole table collects every row
+//          at or above it.  Verified exactly: if a query ends with fewer than min(K, rows)
+//          candidates the sample lied and the next plan runs.  ~1.5 K candidates per query instead
+//          of K ln(rows/32768) for the growing-chunk plan.
+//  grow  — geometric chunks, threshold refreshed after each (small tables, and the fallback).
+//  safe  — bounded chunks that cannot overflow (adversarially ordered tables).
+// A plan is ENQUEUED as a whole (no host synchronisation inside it) and VERIFIED afterwards from a few status
+// words copied to pinned host memory: recall_dev_locked synchronises right away, the device-resident pipelines
+// (pipeline.hip) defer the check to the end of the whole request batch, so the rank / fusion / sort stages of a
+// batch are queued behind its recall without the GPU ever waiting for the host.
+// ---------------------------------------------------------------------------------------------
+enum RecallPlan { kPilot = 0, kGrow = 1, kSafe = 2 };
+
+int recall_job_prepare(RecallJob* j) {
+    pg_ctx* ctx = j->ctx;
+    const pg_table* t = j->t;
+    const Knobs& kn = ctx->knobs;
     int rc;
-    if ((rc = recall_scratch(ctx, t->dim, k, &rs))) return rc;
+    if ((rc = recall_scratch(ctx, t->dim, j->k, &j->rs))) return rc;
     void* d_count;
     if ((rc = scratch_reserve(ctx, 4, 4096, &d_count))) return rc;
+    j->d_count = (uint32_t*)d_count;
+    j->rows = (uint32_t)t->rows;
+    j->nblocks = (j->rows + kPieceRows - 1) / kPieceRows;
+    j->scan_ms = j->total_ms = 0.0;
+    j->scanned_rows = 0;
+    j->scan_launches = 0;
+    j->next_plan = 0;
+    j->enqueued_plan = -1;
 
-    const uint32_t rows = (uint32_t)t->rows;
-    const uint32_t nblocks = (rows + kPieceRows - 1) / kPieceRows;
-    double scan_ms = 0.0, total_ms = 0.0;
-    uint64_t scanned_rows = 0;
-    uint32_t scan_launches = 0;
-
-    // Policy: up to 32 queries ride the exact fp32-MFMA scan (HBM-bound).  Larger batches use the
-    // screened scan (int8 or bf16 filter + exact re-scoring), which stays HBM-bound up to 128 queries; it
-    // needs a finite table and dim <= 128, otherwise the 64-query exact kernel is used.
-    const uint32_t screen_min = getenv("PG_SCREEN_MIN") ? (uint32_t)atoi(getenv("PG_SCREEN_MIN")) : 0u;
-    bool screen = nq > screen_min && t->dim <= 128 && !getenv("PG_RECALL_EXACT");
+    // Policy: finite tables of dim <= 128 use the screened scan (int8 or bf16 filter + exact re-scoring) for every
+    // batch size (knobs.screen_min = 0), HBM-bound up to 128 queries per pass; everything else rides the exact
+    // fp32-MFMA scan in groups of <= 64 queries, one launch per group.
+    bool screen = j->nq > kn.screen_min && t->dim <= 128 && !kn.recall_exact;
     if (screen) {
         if ((rc = ensure_table_stats(ctx, t))) return rc;
         if (!t->stats_valid || !t->all_finite) screen = false;      // no shadow (dim, memory) or non-finite rows
     }
-    if (!screen && nq > (uint32_t)kMaxQueriesExact) {
-        set_error("recall: %u queries need the screened scan (finite table, dim <= 128); at most %d otherwise",
-                  nq, kMaxQueriesExact);
-        return PG_ERR_UNSUPPORTED;
+    j->screen = screen;
+    j->n_plans = 0;
+    j->stride = 1;
+    j->sample_blocks = 0;
+    j->k_pilot = 0;
+    j->perm_mul = 1;
+    const uint32_t rows = j->rows;
+    const uint32_t full_blocks = rows / kPieceRows;           // the sample only uses whole blocks
+    uint32_t want = full_blocks / 64;                        // (1/64 measured best with the int8 screen: 5.39 vs 5.51 ms per 256-request pass at 1/32, 5.46 at 1/96)
+    if (want < 32768) want = 32768;                          // >= 1M sample rows
+    if (kn.pilot_fraction > 0.0) want = (uint32_t)(full_blocks * kn.pilot_fraction);
+    j->stride = want ? full_blocks / want : 1;
+    if (j->stride >= 2 && !kn.no_pilot) {
+        j->sample_blocks = full_blocks / j->stride;
+        const double m = (double)j->k * ((double)j->sample_blocks * kPieceRows / (double)rows);
+        j->k_pilot = (uint32_t)ceil(m + 6.0 * sqrt(m) + 8.0);
+        if ((uint64_t)j->k_pilot * 4 <= (uint64_t)j->sample_blocks * kPieceRows) j->plans[j->n_plans++] = kPilot;
+        j->perm_mul = 2654435761u % j->sample_blocks;          // golden-ratio step, made coprime below
+        if (j->perm_mul < 2) j->perm_mul = 1;
+        auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t r = x % y; x = y; y = r; } return x; };
+        while (gcd(j->perm_mul, j->sample_blocks) != 1) ++j->perm_mul;
     }
-    // Plans, tried in order until one completes without overflowing a candidate list:
-    //  pilot — the threshold comes from a jittered 1/S block sample (its K'-th best score, K' chosen six
-    //          sigma above the expected rank K/S, so it is below the true K-th best except with
-    //          negligible probability), then ONE full-rate pass over the whole table collects every row
-    //          at or above it.  Verified exactly: if a query ends with fewer than min(K, rows)
-    //          candidates the sample lied and the next plan runs.  ~1.5 K candidates per query instead
-    //          of K ln(rows/32768) for the growing-chunk plan.
-    //  grow  — geometric chunks, threshold refreshed after each (small tables, and the fallback).
-    //  safe  — bounded chunks that cannot overflow (adversarially ordered tables).
-    enum Plan { kPilot, kGrow, kSafe };
-    Plan plans[3];
-    int n_plans = 0;
-    uint32_t stride = 1, sample_blocks = 0, k_pilot = 0, perm_mul = 1;
-    {
-        const uint32_t full_blocks = rows / kPieceRows;           // the sample only uses whole blocks
-        uint32_t want = full_blocks / 64;                        // (1/64 measured best with the int8 screen: 5.39 vs 5.51 ms per 256-request pass at 1/32, 5.46 at 1/96)
-        if (want < 32768) want = 32768;                          // >= 1M sample rows
-        if (getenv("PG_PILOT_FRACTION")) want = (uint32_t)(full_blocks * atof(getenv("PG_PILOT_FRACTION")));
-        stride = want ? full_blocks / want : 1;
-        if (stride >= 2 && !getenv("PG_NO_PILOT")) {
-            sample_blocks = full_blocks / stride;
-            const double m = (double)k * ((double)sample_blocks * kPieceRows / (double)rows);
-            k_pilot = (uint32_t)ceil(m + 6.0 * sqrt(m) + 8.0);
-            if ((uint64_t)k_pilot * 4 <= (uint64_t)sample_blocks * kPieceRows) plans[n_plans++] = kPilot;
-            perm_mul = 2654435761u % sample_blocks;          // golden-ratio step, made coprime below
-            if (perm_mul < 2) perm_mul = 1;
-            auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t r = x % y; x = y; y = r; } return x; };
-            while (gcd(perm_mul, sample_blocks) != 1) ++perm_mul;
-        }
-        plans[n_plans++] = kGrow;
-        plans[n_plans++] = kSafe;
-    }
-    const double growth_env = getenv("PG_CHUNK_GROWTH") ? atof(getenv("PG_CHUNK_GROWTH")) : 0.0;
+    j->plans[j->n_plans++] = kGrow;
+    j->plans[j->n_plans++] = kSafe;
+    return PG_OK;
+}
 
+namespace {
+struct PlanRun {                     // the launches of one plan (helper of recall_job_enqueue)
+    RecallJob* j;
+    pg_ctx* ctx;
+    const pg_table* t;
+    RecallScratch& rs;
     uint32_t n_ev = 0;
     int cur = 0;
+
+    explicit PlanRun(RecallJob* job) : j(job), ctx(job->ctx), t(job->t), rs(job->rs) {}
+
     // one scan launch over logical blocks [rb, rb+cb) of a stride-`st` view, bracketed by HIP events:
     // their sum is the per-pass duration of the dominant kernel that bench.py prices against HBM
-    auto scan_range = [&](uint32_t rb, uint32_t cb, uint32_t st, bool thr_is_open) -> int {
-        while (ctx->ev_pool.size() < 2 * (size_t)(n_ev + 1)) {
+    int scan_range(uint32_t rb, uint32_t cb, uint32_t st, bool thr_is_open) {
+        std::vector<hipEvent_t>& pool = *j->events;
+        while (pool.size() < 2 * (size_t)(n_ev + 1)) {
             hipEvent_t e;
             PG_HIP(hipEventCreate(&e));
-            ctx->ev_pool.push_back(e);
+            pool.push_back(e);
         }
-        PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev], ctx->stream));
-        if (screen && !thr_is_open) {
+        PG_HIP(hipEventRecord(pool[2 * n_ev], ctx->stream));
+        const uint32_t nq = j->nq;
+        if (j->screen && !thr_is_open) {
             ScreenArgs sa;
             sa.tab16 = t->shadow_is_i8 ? (const void*)t->d8 : (const void*)t->d16;
             sa.blk_norm2 = t->dnorm2;
@@ -1803,10 +1804,10 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             sa.nq = nq;
             sa.rb_begin = rb;
             sa.rb_end = rb + cb;
-            sa.row_end = rows;
+            sa.row_end = j->rows;
             sa.stride = st;
-            sa.perm_mul = perm_mul;
-            sa.perm_mod = sample_blocks;
+            sa.perm_mul = j->perm_mul;
+            sa.perm_mod = j->sample_blocks;
             int rc2;
             PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
             if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) return rc2;
@@ -1821,7 +1822,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             PG_HIP(hipGetLastError());
         } else {
             // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
-            // every row is a candidate and there is nothing to screen) in groups of <= 64 queries
+            // every row is a candidate and there is nothing to screen) in groups of <= 64 queries,
             // one launch; blockIdx.y walks the groups
             ScanArgs a;
             a.tab = t->d;
@@ -1832,35 +1833,35 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             a.overflow = rs.overflow;
             a.cap = rs.cap;
             a.nq = nq;
-            a.group_q = screen && nq > (uint32_t)kMaxQueriesExact ? (uint32_t)kMaxQueriesExact : 0u;
+            a.group_q = nq > (uint32_t)kMaxQueriesExact ? (uint32_t)kMaxQueriesExact : 0u;
             a.nq_launch = a.group_q ? a.group_q : nq;
             a.rb_begin = rb;
             a.rb_end = rb + cb;
-            a.row_end = rows;
+            a.row_end = j->rows;
             a.stride = st;
-            a.perm_mul = perm_mul;
-            a.perm_mod = sample_blocks;
+            a.perm_mul = j->perm_mul;
+            a.perm_mod = j->sample_blocks;
             int rc2;
             if ((rc2 = dispatch_scan(ctx, t->dim, a))) return rc2;
         }
-        PG_HIP(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], ctx->stream));
+        PG_HIP(hipEventRecord(pool[2 * n_ev + 1], ctx->stream));
         ++n_ev;
         return PG_OK;
-    };
+    }
     // keep the best `kk` candidates per query, refresh the thresholds, swap the ping-pong lists
-    auto refresh = [&](uint32_t kk) -> int {
+    int refresh(uint32_t kk) {
         int rc2;
-        if ((rc2 = launch_select(ctx, nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk))) return rc2;
-        if (screen) {
+        if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk))) return rc2;
+        if (j->screen) {
             if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
             else screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.thr_screen);
             PG_HIP(hipGetLastError());
         }
         cur ^= 1;
         return PG_OK;
-    };
+    }
     // geometric chunks over `nb` logical blocks of a stride-`st` view, keeping the best `kk`
-    auto grow_scan = [&](uint32_t nb, uint32_t st, uint32_t kk, double growth, bool safe) -> int {
+    int grow_scan(uint32_t nb, uint32_t st, uint32_t kk, double growth, bool safe) {
         uint32_t rb = 0;
         while (rb < nb) {
             uint32_t chunk_rows;
@@ -1870,8 +1871,7 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
                 chunk_rows = next_pow2(8 * kk);
                 if (chunk_rows < 2048) chunk_rows = 2048;
                 if (chunk_rows > kFirstChunkRows || chunk_rows < kk) chunk_rows = kFirstChunkRows;
-            }
-            else {
+            } else {
                 // chunk = (growth-1) x rows seen: every chunk stages ≈ (growth-1)*kk candidates per query
                 const uint64_t grow = (uint64_t)((double)rb * kPieceRows * (growth - 1.0));
                 chunk_rows = grow > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (uint32_t)grow;
@@ -1885,103 +1885,157 @@ static int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_quer
             if ((rc2 = refresh(kk))) return rc2;
         }
         return PG_OK;
-    };
+    }
+};
+}  // namespace
 
-    for (int pi = 0; pi < n_plans; ++pi) {
-        const Plan plan = plans[pi];
-        recall_init_kernel<<<(kMaxQueries * t->dim + 255) / 256, 256, 0, ctx->stream>>>(
-            d_queries, nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
+int recall_job_enqueue(RecallJob* j) {
+    pg_ctx* ctx = j->ctx;
+    const pg_table* t = j->t;
+    const Knobs& kn = ctx->knobs;
+    if (j->next_plan >= j->n_plans) {
+        set_error("recall: candidate overflow in safe mode (internal error)");
+        return PG_ERR_DEVICE;
+    }
+    const int plan = j->plans[j->next_plan];
+    PlanRun r(j);
+    RecallScratch& rs = j->rs;
+    int rc;
+    recall_init_kernel<<<(kMaxQueries * t->dim + 255) / 256, 256, 0, ctx->stream>>>(
+        j->d_queries, j->nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
+    PG_HIP(hipGetLastError());
+    if (j->screen) {
+        if (t->shadow_is_i8)
+            screen_prep8_kernel<<<1, 1024, 0, ctx->stream>>>(rs.qpad, t->dim, t->max_norm, t->resid8, rs.qb16, rs.eps,
+                                                             rs.qscale);
+        else
+            screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
+                rs.qpad, t->dim, rs.qb16, rs.eps);
         PG_HIP(hipGetLastError());
-        if (screen) {
-            if (t->shadow_is_i8)
-                screen_prep8_kernel<<<1, 1024, 0, ctx->stream>>>(rs.qpad, t->dim, t->max_norm, t->resid8, rs.qb16, rs.eps,
-                                                                 rs.qscale);
-            else
-                screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
-                    rs.qpad, t->dim, rs.qb16, rs.eps);
-            PG_HIP(hipGetLastError());
-        }
-        cur = 0;
-        n_ev = 0;
-        PG_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-        if (plan == kPilot) {
-            // The sample itself is streamed in two launches when it is screened: a seed of `seed_rows` rows
-            // (exact, every row a candidate) whose m0-th best score becomes the threshold of ONE screened
-            // launch over the rest of the sample; m0 is chosen so that fewer than K' sample rows reaching
-            // that threshold has probability < 1e-9 (Poisson tail of seed hits among the sample's top K');
-            // should it happen anyway, select_kernel leaves the threshold at -inf, the full pass overflows
-            // and the next plan takes over.  (Measured against geometric chunks over the sample: 1.0 → 0.7 ms.)
-            const uint32_t seed_rows = getenv("PG_SEED_ROWS") ? (uint32_t)atoi(getenv("PG_SEED_ROWS")) : 8192u;   // (tuning runs)
-            const uint64_t sample_rows = (uint64_t)sample_blocks * kPieceRows;
-            if (screen && !getenv("PG_PILOT_GROWTH") && sample_rows > 8ull * seed_rows && k_pilot < seed_rows / 4) {
-                const double mu = (double)seed_rows * (double)k_pilot / (double)sample_rows;
-                uint32_t m0 = 1;
-                for (double term = exp(-mu) , cdf = term; 1.0 - cdf > 1e-9 && m0 < seed_rows; ++m0) {
-                    term *= mu / (double)m0;          // P(X = m0)
-                    cdf += term;                      // P(X <= m0)  →  loop ends with P(X >= m0+1) <= 1e-9
-                }
-                ++m0;
-                const uint32_t sb = seed_rows / kPieceRows;
-                if ((rc = scan_range(0, sb, stride, true))) return rc;
-                if ((rc = refresh(m0))) return rc;
-                if ((rc = scan_range(sb, sample_blocks - sb, stride, false))) return rc;
-                if ((rc = refresh(k_pilot))) return rc;
-            } else {
-                // geometric chunks over the sample (exact scan, or PG_PILOT_GROWTH set: A/B runs)
-                if ((rc = grow_scan(sample_blocks, stride, k_pilot, getenv("PG_PILOT_GROWTH") ? atof(getenv("PG_PILOT_GROWTH")) : 8.0, false))) return rc;
+    }
+    while (j->events->size() < 2) {
+        hipEvent_t e;
+        PG_HIP(hipEventCreate(&e));
+        j->events->push_back(e);
+    }
+    // events 0/1 of the pool bracket the whole plan; PlanRun's launches use the pairs after them
+    r.n_ev = 1;
+    PG_HIP(hipEventRecord((*j->events)[0], ctx->stream));
+    if (plan == kPilot) {
+        // The sample itself is streamed in two launches when it is screened: a seed of `seed_rows` rows
+        // (exact, every row a candidate) whose m0-th best score becomes the threshold of ONE screened
+        // launch over the rest of the sample; m0 is chosen so that fewer than K' sample rows reaching
+        // that threshold has probability < 1e-9 (Poisson tail of seed hits among the sample's top K');
+        // should it happen anyway, select_kernel leaves the threshold at -inf, the full pass overflows
+        // and the next plan takes over.  (Measured against geometric chunks over the sample: 1.0 → 0.7 ms.)
+        const uint32_t seed_rows = kn.seed_rows;
+        const uint64_t sample_rows = (uint64_t)j->sample_blocks * kPieceRows;
+        if (j->screen && kn.pilot_growth <= 0.0 && sample_rows > 8ull * seed_rows && j->k_pilot < seed_rows / 4) {
+            const double mu = (double)seed_rows * (double)j->k_pilot / (double)sample_rows;
+            uint32_t m0 = 1;
+            for (double term = exp(-mu), cdf = term; 1.0 - cdf > 1e-9 && m0 < seed_rows; ++m0) {
+                term *= mu / (double)m0;          // P(X = m0)
+                cdf += term;                      // P(X <= m0)  →  loop ends with P(X >= m0+1) <= 1e-9
             }
-            PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
-            if ((rc = scan_range(0, nblocks, 1, false))) return rc;
-            if ((rc = refresh(k))) return rc;
+            ++m0;
+            const uint32_t sb = seed_rows / kPieceRows;
+            if ((rc = r.scan_range(0, sb, j->stride, true))) return rc;
+            if ((rc = r.refresh(m0))) return rc;
+            if ((rc = r.scan_range(sb, j->sample_blocks - sb, j->stride, false))) return rc;
+            if ((rc = r.refresh(j->k_pilot))) return rc;
         } else {
-            // measured: growth 4 is best for the exact scan, 2 for the screened scan whose re-scoring
-            // gathers 512 B per staged candidate
-            const double growth = growth_env > 1.0 ? growth_env : (screen ? 2.0 : 4.0);
-            if ((rc = grow_scan(nblocks, 1, k, growth, plan == kSafe))) return rc;
+            // geometric chunks over the sample (exact scan, or pilot_growth set: A/B runs)
+            if ((rc = r.grow_scan(j->sample_blocks, j->stride, j->k_pilot, kn.pilot_growth > 0.0 ? kn.pilot_growth : 8.0, false))) return rc;
         }
-        PG_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-        if ((rc = final_launch(ctx, rs.cand[cur], rs.cnt, rs.cap, nq, k, t->row_offset, d_out_rows,
-                               d_out_scores, (uint32_t*)d_count)))
-            return rc;
-        PG_HIP(hipMemcpyAsync(ctx->h_status, rs.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
-        PG_HIP(hipMemcpyAsync(ctx->h_status + 1, d_count, 4 * nq, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
+        if ((rc = r.scan_range(0, j->nblocks, 1, false))) return rc;
+        if ((rc = r.refresh(j->k))) return rc;
+    } else {
+        // measured: growth 4 is best for the exact scan, 2 for the screened scan whose re-scoring
+        // gathers 512 B per staged candidate
+        const double growth = kn.chunk_growth > 1.0 ? kn.chunk_growth : (j->screen ? 2.0 : 4.0);
+        if ((rc = r.grow_scan(j->nblocks, 1, j->k, growth, plan == kSafe))) return rc;
+    }
+    PG_HIP(hipEventRecord((*j->events)[1], ctx->stream));
+    if ((rc = final_launch(ctx, rs.cand[r.cur], rs.cnt, rs.cap, j->nq, j->k, t->row_offset, j->d_out_rows,
+                           j->d_out_scores, j->d_count)))
+        return rc;
+    if (j->d_out_count)
+        PG_HIP(hipMemcpyAsync(j->d_out_count, j->d_count, 4 * j->nq, hipMemcpyDeviceToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(j->h_status, rs.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(j->h_status + 1, j->d_count, 4 * j->nq, hipMemcpyDeviceToHost, ctx->stream));
+    j->n_ev = r.n_ev;
+    j->enqueued_plan = plan;
+    j->next_plan++;
+    return PG_OK;
+}
+
+int recall_job_check(RecallJob* j, bool* ok_out) {
+    pg_ctx* ctx = j->ctx;
+    const int plan = j->enqueued_plan;
+    float ms = 0.f;
+    PG_HIP(hipEventElapsedTime(&ms, (*j->events)[0], (*j->events)[1]));
+    j->total_ms += ms;
+    for (uint32_t i = 1; i < j->n_ev; ++i) {
+        PG_HIP(hipEventElapsedTime(&ms, (*j->events)[2 * i], (*j->events)[2 * i + 1]));
+        j->scan_ms += ms;
+        if (ctx->knobs.debug_scan) fprintf(stderr, "[pg] plan %d scan launch %u: %.3f ms\n", plan, i - 1, ms);
+    }
+    if (ctx->knobs.debug_scan && j->screen) {          // suspects of the last screened launch vs K (developer aid)
+        uint32_t sc[4] = {0, 0, 0, 0};
+        PG_HIP(hipMemcpy(sc, j->rs.susp_cnt, sizeof sc, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pg] plan %d last screened launch: suspects of queries 0-3: %u %u %u %u (K = %u)\n", plan, sc[0], sc[1], sc[2], sc[3], j->k);
+    }
+    j->scan_launches += j->n_ev - 1;
+    j->scanned_rows += plan == kPilot ? (uint64_t)j->rows + (uint64_t)j->sample_blocks * kPieceRows : j->rows;
+    bool ok = j->h_status[0] == 0;
+    if (ok && plan == kPilot) {
+        const uint32_t want = j->k < j->rows ? j->k : j->rows;
+        for (uint32_t q = 0; q < j->nq; ++q) ok = ok && j->h_status[1 + q] == want;
+    }
+    if (!ok) ctx->stats.recall_rescans++;
+    *ok_out = ok;
+    return PG_OK;
+}
+
+void recall_job_finish(RecallJob* j) {
+    pg_ctx* ctx = j->ctx;
+    ctx->stats.recall_calls++;
+    ctx->stats.recall_rows_scanned += j->scanned_rows;
+    ctx->stats.last_recall_ms = j->total_ms;
+    ctx->last_scan_ms = j->scan_ms;
+    ctx->last_scan_launches = j->scan_launches;
+    // bytes the scan launches streamed: the shadow's element size when the pass was screened
+    ctx->last_scan_bytes = j->scanned_rows * (uint64_t)j->t->dim * (j->screen ? (j->t->shadow_is_i8 ? 1 : 2) : 4);
+}
+
+// the whole recall for one batch of queries, verified before it returns; all pointers are device pointers
+int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq,
+                      uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
+                      uint32_t* out_count, uint32_t* d_out_count) {
+    RecallJob j;
+    j.ctx = ctx;
+    j.t = t;
+    j.d_queries = d_queries;
+    j.nq = nq;
+    j.k = k;
+    j.d_out_rows = d_out_rows;
+    j.d_out_scores = d_out_scores;
+    j.d_out_count = d_out_count;
+    j.h_status = ctx->h_status;
+    j.events = &ctx->ev_pool;
+    int rc;
+    if ((rc = recall_job_prepare(&j))) return rc;
+    for (;;) {
+        if ((rc = recall_job_enqueue(&j))) return rc;
         PG_HIP(hipStreamSynchronize(ctx->stream));
-        float ms = 0.f;
-        PG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-        total_ms += ms;
-        for (uint32_t i = 0; i < n_ev; ++i) {
-            PG_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]));
-            scan_ms += ms;
-            if (getenv("PG_DEBUG_SCAN")) fprintf(stderr, "[pg] plan %d scan launch %u: %.3f ms\n", (int)plan, i, ms);
-        }
-        if (getenv("PG_DEBUG_SCAN") && screen) {          // suspects of the last screened launch vs K (developer aid)
-            uint32_t sc[4] = {0, 0, 0, 0};
-            PG_HIP(hipMemcpy(sc, rs.susp_cnt, sizeof sc, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[pg] plan %d last screened launch: suspects of queries 0-3: %u %u %u %u (K = %u)\n", (int)plan, sc[0], sc[1], sc[2], sc[3], k);
-        }
-        scan_launches += n_ev;
-        scanned_rows += plan == kPilot ? (uint64_t)rows + (uint64_t)sample_blocks * kPieceRows : rows;
-        bool ok = ctx->h_status[0] == 0;
-        if (ok && plan == kPilot) {
-            const uint32_t want = k < rows ? k : rows;
-            for (uint32_t q = 0; q < nq; ++q) ok = ok && ctx->h_status[1 + q] == want;
-        }
+        bool ok = false;
+        if ((rc = recall_job_check(&j, &ok))) return rc;
         if (ok) break;
-        ctx->stats.recall_rescans++;
-        if (plan == kSafe) {
-            set_error("recall: candidate overflow in safe mode (internal error)");
-            return PG_ERR_DEVICE;
-        }
     }
     if (out_count)
         for (uint32_t q = 0; q < nq; ++q) out_count[q] = ctx->h_status[1 + q];
-    ctx->stats.recall_calls++;
-    ctx->stats.recall_rows_scanned += scanned_rows;
-    ctx->stats.last_recall_ms = total_ms;
-    ctx->last_scan_ms = scan_ms;
-    ctx->last_scan_launches = scan_launches;
-    // bytes the scan launches streamed: the shadow's element size when the pass was screened
-    ctx->last_scan_bytes = scanned_rows * (uint64_t)t->dim * (screen ? (t->shadow_is_i8 ? 1 : 2) : 4);
+    recall_job_finish(&j);
     return PG_OK;
 }
 
@@ -2011,7 +2065,7 @@ int pg_recall_topk_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, u
         return PG_ERR_UNSUPPORTED;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
-    return pg::recall_dev_locked(ctx, t, d_queries, nq, k, d_out_rows, d_out_scores, out_count);
+    return pg::recall_dev_locked(ctx, t, d_queries, nq, k, d_out_rows, d_out_scores, out_count, nullptr);
 }
 
 int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_t nq, uint32_t k,
@@ -2032,7 +2086,7 @@ int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_
     uint64_t* d_rows = (uint64_t*)((char*)buf + ((qb + 15) & ~(size_t)15));
     float* d_sc = (float*)((char*)d_rows + rb);
     PG_HIP(hipMemcpyAsync(d_q, queries, qb, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = pg::recall_dev_locked(ctx, t, d_q, nq, k, d_rows, d_sc, out_count))) return rc;
+    if ((rc = pg::recall_dev_locked(ctx, t, d_q, nq, k, d_rows, d_sc, out_count, nullptr))) return rc;
     PG_HIP(hipMemcpyAsync(out_rows, d_rows, rb, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipMemcpyAsync(out_scores, d_sc, sb, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(1024) void sort_kernel_reg(const double* __restrict
     }
 }
 
-static int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg,
+int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg,
                            uint32_t n_items, uint32_t max_seg, int desc, uint32_t* d_out) {
     if (n_seg == 0 || n_items == 0) return PG_OK;
     constexpr size_t lds = (size_t)kSortLdsMax * 12;
@@ -136,7 +136,7 @@ static int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* 
         g_keys = (uint64_t*)p;
         g_idx = (uint32_t*)(g_keys + (size_t)n_seg * stride);
     }
-    if (max_seg <= kSortLdsMax && !getenv("PG_SORT_LDS"))
+    if (max_seg <= kSortLdsMax && !ctx->knobs.sort_lds)
         sort_kernel_reg<<<n_seg, 1024, 0, ctx->stream>>>(d_scores, d_seg, desc, d_out);
     else
         sort_kernel<<<n_seg, 1024, lds, ctx->stream>>>(d_scores, d_seg, desc, g_keys, g_idx, stride, d_out);
@@ -183,13 +183,13 @@ int pg_sort_scores(pg_ctx* ctx, const double* scores, const uint32_t* seg_offset
     uint32_t* d_r = (uint32_t*)((char*)d_o + al((size_t)(n_seg + 1) * 4));
     PG_HIP(hipMemcpyAsync(d_s, scores, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(hipMemcpyAsync(d_o, seg_offsets, (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    PG_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     if ((rc = pg::sort_dev_locked(ctx, d_s, d_o, n_seg, n, max_seg, descending, d_r))) return rc;
-    PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    PG_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
     PG_HIP(hipMemcpyAsync(out_order, d_r, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
-    PG_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    PG_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
     ctx->stats.last_sort_ms = ms;
     return PG_OK;
 }

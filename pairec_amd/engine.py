@@ -44,6 +44,10 @@ class Context:
     def synchronize(self):
         _lib.check(self.L.pg_synchronize(self.h))
 
+    def set_option(self, name: str, value) -> None:
+        """Developer / test knob of this context (pg_set_option)."""
+        _lib.check(self.L.pg_set_option(self.h, name.encode(), str(value).encode()))
+
     def malloc(self, nbytes: int) -> int:
         p = C.c_void_p()
         _lib.check(self.L.pg_device_malloc(self.h, nbytes, C.byref(p)))
@@ -271,6 +275,81 @@ class Expr:
         out = np.empty(n, dtype=np.float64)
         _lib.check(self.L.pg_expr_eval(ctx.h, self.h, _ptr(v) if v.size else None, n, _ptr(out)))
         return out
+
+
+def recommend_dnn3(ctx: Context, table: Table, model: "RankModel", expr: "Expr", rank_var: str, queries: np.ndarray,
+                   k: int):
+    """pg_recommend_dnn3_dev on host arrays (tests, tools): queries [R][dim] →
+    rows [R][k] u64, recall scores [R][k] f32, model scores [R][k] f32, fused [R][k] f64, order [R][k] u32, counts [R]."""
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, table.dim)
+    R = q.shape[0]
+    n = R * k
+    d_q = ctx.to_device(q)
+    bufs = [ctx.malloc(n * 8), ctx.malloc(n * 4), ctx.malloc(n * 4), ctx.malloc(n * 8), ctx.malloc(n * 4),
+            ctx.malloc(max(R * 4, 16))]
+    try:
+        _lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, table.h, model.h, expr.h, rank_var.encode(), d_q, R, k, *bufs))
+        outs = [np.zeros((R, k), np.uint64), np.zeros((R, k), np.float32), np.zeros((R, k), np.float32),
+                np.zeros((R, k), np.float64), np.zeros((R, k), np.uint32), np.zeros(R, np.uint32)]
+        for a, p_ in zip(outs, bufs):
+            ctx.d2h(a, p_)
+    finally:
+        for p_ in [d_q] + bufs:
+            ctx.free(p_)
+    return tuple(outs)
+
+
+class Coalescer:
+    """Cross-request batching (pg_coalescer_*): every method serves ONE request and may be called from any number
+    of threads at once (ctypes releases the GIL for the duration of the call); the library forms the batches."""
+
+    def __init__(self, ctx: Context, table: Table, k: int, model: Optional["RankModel"] = None,
+                 expr: Optional["Expr"] = None, rank_var: str = "", max_batch: int = 0, max_wait_us: int = 0,
+                 depth: int = 0, max_top_n: int = 0, max_rank_items: int = 0):
+        self.ctx, self.table, self.k = ctx, table, k
+        self.max_top_n = max_top_n or k
+        cfg = _lib.PgCoalescerConfig(k, max_batch, max_wait_us, depth, max_top_n, max_rank_items)
+        h = C.c_void_p()
+        _lib.check(ctx.L.pg_coalescer_create(ctx.h, table.h, model.h if model else None, expr.h if expr else None,
+                                             rank_var.encode() if rank_var else None, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def destroy(self):
+        if self.h:
+            _lib.check(self.ctx.L.pg_coalescer_destroy(self.h))
+            self.h = None
+
+    def recall(self, query: np.ndarray):
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(self.table.dim)
+        rows = np.empty(self.k, dtype=np.uint64)
+        scores = np.empty(self.k, dtype=np.float32)
+        cnt = C.c_uint32()
+        _lib.check(self.ctx.L.pg_coalescer_recall(self.h, _ptr(q), _ptr(rows), _ptr(scores), C.byref(cnt)))
+        return rows, scores, cnt.value
+
+    def rank_dnn3(self, user_vec: np.ndarray, cand_rows: np.ndarray) -> np.ndarray:
+        u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(-1)
+        c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+        out = np.empty(c.shape[0], dtype=np.float32)
+        _lib.check(self.ctx.L.pg_coalescer_rank_dnn3(self.h, _ptr(u), _ptr(c), c.shape[0], _ptr(out)))
+        return out
+
+    def recommend(self, user_vec: np.ndarray, top_n: int):
+        """→ (rows, recall scores, model scores, fused scores) of the first top_n entries of the sorted list, count."""
+        u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(self.table.dim)
+        rows = np.empty(top_n, dtype=np.uint64)
+        rec = np.empty(top_n, dtype=np.float32)
+        rnk = np.empty(top_n, dtype=np.float32)
+        fus = np.empty(top_n, dtype=np.float64)
+        cnt = C.c_uint32()
+        _lib.check(self.ctx.L.pg_coalescer_recommend(self.h, _ptr(u), top_n, _ptr(rows), _ptr(rec), _ptr(rnk),
+                                                     _ptr(fus), C.byref(cnt)))
+        return rows, rec, rnk, fus, cnt.value
+
+    def stats(self) -> _lib.PgCoalescerStats:
+        s = _lib.PgCoalescerStats()
+        _lib.check(self.ctx.L.pg_coalescer_stats(self.h, C.byref(s)))
+        return s
 
 
 def dpp(ctx: Context, table: Table, cand_rows, rel, alpha: float, topn: int, window: int,

@@ -1,0 +1,199 @@
+"""GPU tests of the request coalescer (pg_coalescer_*): single-request calls from many host threads must give
+bit-identical answers to the same requests issued alone, and share table passes (SURVEY.md 8b "Threading";
+service/recall.go:129-145, service/rank/rank_service.go:264-289 are the concurrent call sites it serves)."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import pairec_amd as pa
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+EXPR = "${gpu_dnn}*(1+${current_score})^0.1"
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def run_threads(n, fn):
+    """fn(i) on n threads; re-raises the first exception."""
+    errs = []
+
+    def wrap(i):
+        try:
+            fn(i)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=wrap, args=(i,)) for i in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+
+
+@pytest.fixture(scope="module")
+def world(ctx):
+    n, d = 400_000, 128
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    w = o.Dnn3Weights()
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    ex = pa.Expr(EXPR)
+    yield t, m, ex
+    m.destroy()
+    t.destroy()
+
+
+def test_coalesced_recommend_equals_solo_calls(ctx, world):
+    """256 threads, one request each (twice over): the page every caller receives equals the first top_n entries of
+    the same request through pg_recommend_dnn3_dev alone — ids, order and every score bit for bit."""
+    t, m, ex = world
+    k, top_n, callers = 500, 100, 256
+    q = o.synth_rows(o.SEED_QUERY, 0, 2 * callers, 128)
+    # solo reference: one request per call
+    ref = []
+    for i in range(0, 2 * callers, 37):          # a sample of the requests, each alone
+        rows, rec, rnk, fus, order, cnt = pa.recommend_dnn3(ctx, t, m, ex, "gpu_dnn", q[i:i + 1], k)
+        p = order[0][:top_n]
+        ref.append((i, rows[0][p], rec[0][p], rnk[0][p], fus[0][p]))
+    co = pa.Coalescer(ctx, t, k, m, ex, "gpu_dnn", max_top_n=top_n, max_wait_us=2000)
+    got = [None] * (2 * callers)
+
+    def call(i):
+        for j in (i, i + callers):
+            got[j] = co.recommend(q[j], top_n)
+    run_threads(callers, call)
+    st = co.stats()
+    co.destroy()
+    for i, rows, rec, rnk, fus in ref:
+        g = got[i]
+        assert g[4] == top_n
+        assert np.array_equal(g[0], rows), "request %d: page ids / order differ from the solo call" % i
+        assert np.array_equal(bits(g[1]), bits(rec)) and np.array_equal(bits(g[2]), bits(rnk))
+        assert np.array_equal(bits(g[3]), bits(fus))
+    assert st.requests[2] == 2 * callers
+    # the calls shared passes: far fewer batches than requests
+    assert st.batches[2] <= 2 * callers // 8, "requests were not coalesced: %d batches" % st.batches[2]
+    assert st.largest_batch[2] >= 32
+
+
+def test_coalesced_recall_and_rank_equal_direct_calls(ctx, world):
+    """The recall flavour (VectorRecall → IAlgorithm.Run) and the rank flavour (one 100-item batch per call, as
+    RankService.Rank issues them) against pg_recall_topk / pg_rank_dnn3 on the same inputs."""
+    t, m, ex = world
+    k, callers = 300, 64
+    q = o.synth_rows(o.SEED_QUERY, 500, callers, 128)
+    rows_ref, sc_ref, _ = t.recall_topk(q, k)
+    co = pa.Coalescer(ctx, t, k, m, max_rank_items=100, max_wait_us=1000)
+    got = [None] * callers
+    run_threads(callers, lambda i: got.__setitem__(i, co.recall(q[i])))
+    for i in range(callers):
+        assert got[i][2] == k
+        assert np.array_equal(got[i][0], rows_ref[i]) and np.array_equal(bits(got[i][1]), bits(sc_ref[i]))
+    # rank: every caller scores its request's candidates in three batches of 100 (BatchCount)
+    ranks = [None] * callers
+
+    def rank(i):
+        cand = rows_ref[i].astype(np.uint32)
+        ranks[i] = np.concatenate([co.rank_dnn3(q[i], cand[b:b + 100]) for b in range(0, k, 100)])
+    run_threads(callers, rank)
+    st = co.stats()
+    co.destroy()
+    off = (np.arange(callers + 1) * k).astype(np.uint32)
+    ref = m.rank_dnn3(t, q, rows_ref.reshape(-1).astype(np.uint32), off).reshape(callers, k)
+    for i in range(callers):
+        assert np.array_equal(bits(ranks[i]), bits(ref[i])), "rank scores of caller %d differ" % i
+    assert st.requests[1] == callers * 3 and st.batches[1] < callers * 3
+    # argument checks
+    co2 = pa.Coalescer(ctx, t, k, m, max_rank_items=100)
+    with pytest.raises(pa._lib.PgError):
+        co2.rank_dnn3(q[0], np.arange(101, dtype=np.uint32))           # more than max_rank_items
+    with pytest.raises(pa._lib.PgError):
+        co2.rank_dnn3(q[0], np.array([t.rows], dtype=np.uint32))        # row outside the table
+    with pytest.raises(pa._lib.PgError):
+        co2.recommend(q[0], 10)                                         # no RankScore expression
+    co2.destroy()
+
+
+def test_coalescer_survives_a_failed_recall_plan(ctx):
+    """A table of identical rows defeats the pilot and the growing-chunk plan (every row ties with every
+    threshold): the batch's verification fails after it has run, the completer re-runs it with the next plans, and
+    the callers still get the exact answer (lowest rows first)."""
+    n, d, k = 2_200_000, 64, 100
+    tab = np.zeros((n, d), dtype=np.float32)
+    tab[:, 5] = 1.0
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    co = pa.Coalescer(ctx, t, k, max_wait_us=500)
+    q = np.zeros((8, d), dtype=np.float32)
+    q[:, 5] = 1.0
+    got = [None] * 8
+    run_threads(8, lambda i: got.__setitem__(i, co.recall(q[i])))
+    st = co.stats()
+    co.destroy()
+    for g in got:
+        assert g[0].tolist() == list(range(k)) and np.all(g[1] == 1.0)
+    assert st.replans >= 1
+    t.destroy()
+
+
+def test_recommend_pads_when_table_is_smaller_than_k(ctx):
+    """Fewer rows than k: the padding slots (row = UINT64_MAX) must not surface in a page — they carry fused = NaN,
+    sort last, and the count says how many entries are items (they used to fuse to +inf and sort first)."""
+    n, d, k, R = 300, 128, 400, 5
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    w = o.Dnn3Weights()
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    ex = pa.Expr(EXPR)
+    q = o.synth_rows(o.SEED_QUERY, 3, R, d)
+    rows, rec, rnk, fus, order, cnt = pa.recommend_dnn3(ctx, t, m, ex, "gpu_dnn", q, k)
+    assert cnt.tolist() == [n] * R
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    for r in range(R):
+        assert np.all(rows[r][n:] == np.uint64(2**64 - 1)) and np.all(np.isnan(fus[r][n:])) and np.all(rnk[r][n:] == 0)
+        head = order[r][:n]
+        assert np.all(head < n), "a padding slot sorted ahead of an item"
+        assert sorted(rows[r][head].tolist()) == list(range(n))
+        assert np.all(np.diff(fus[r][head]) <= 0)
+        ref = o.dnn3_forward(w, pa.PREC_F32, q[r], tab[rows[r][:n].astype(np.int64)])
+        assert np.max(np.abs(rnk[r][:n].astype(np.float64) - ref)) <= 2e-7
+    co = pa.Coalescer(ctx, t, k, m, ex, "gpu_dnn", max_top_n=k)
+    p_rows, p_rec, p_rnk, p_fus, p_cnt = co.recommend(q[0], k)
+    co.destroy()
+    assert p_cnt == n and np.array_equal(p_rows[:n], rows[0][order[0][:n]])
+    m.destroy()
+    t.destroy()
+
+
+def test_concurrent_callers_throughput_is_10x_solo(ctx, world):
+    """The point of the coalescer: 256 closed-loop callers get >= 10x the requests/s of one caller issuing the same
+    single-request calls back to back (native load generator in libpairec_host.so; same checksum semantics)."""
+    t, m, ex = world
+    host = C.CDLL(os.path.join(os.path.dirname(pa.__file__), "libpairec_host.so"))
+
+    class Res(C.Structure):
+        _fields_ = [("requests", C.c_uint64), ("errors", C.c_uint64), ("seconds", C.c_double), ("p50_ms", C.c_double),
+                    ("p90_ms", C.c_double), ("p99_ms", C.c_double), ("max_ms", C.c_double), ("mean_ms", C.c_double),
+                    ("checksum", C.c_uint64)]
+    host.ph_loadgen_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_uint32, C.c_double, C.POINTER(Res)]
+    k, top_n = 1000, 100
+    users = np.ascontiguousarray(o.synth_rows(o.SEED_QUERY, 0, 1000, 128))
+    co = pa.Coalescer(ctx, t, k, m, ex, "gpu_dnn", max_top_n=top_n)
+    solo, many = Res(), Res()
+    assert host.ph_loadgen_run(co.h, 0, users.ctypes.data, 1000, 128, k, top_n, 1, 5, 1.0, C.byref(solo)) == 0
+    assert host.ph_loadgen_run(co.h, 0, users.ctypes.data, 1000, 128, k, top_n, 256, 2, 2.0, C.byref(many)) == 0
+    co.destroy()
+    assert solo.errors == 0 and many.errors == 0
+    rs, rm = solo.requests / solo.seconds, many.requests / many.seconds
+    print("solo %.0f req/s (p50 %.2f ms), 256 callers %.0f req/s (p50 %.2f ms, p99 %.2f ms)" %
+          (rs, solo.p50_ms, rm, many.p50_ms, many.p99_ms))
+    assert rm >= 10 * rs

@@ -310,11 +310,11 @@ def test_recall_adversarial_order(ctx):
     rows, scores, _ = t.recall_topk(q, k)
     assert rows[0].tolist() == list(range(n - 1, n - 1 - k, -1))
     assert ctx.stats().recall_rescans == before
-    os.environ["PG_NO_PILOT"] = "1"
+    ctx.set_option("no_pilot", 1)
     try:
         rows, scores, _ = t.recall_topk(q, k)
     finally:
-        del os.environ["PG_NO_PILOT"]
+        ctx.set_option("no_pilot", 0)
     assert rows[0].tolist() == list(range(n - 1, n - 1 - k, -1))
     assert ctx.stats().recall_rescans == before + 1
     t.destroy()
@@ -806,7 +806,7 @@ def test_recommend_one_call_equals_the_stages(ctx):
     d_q = ctx.to_device(q)
     d_rows, d_sc, d_rk, d_fu, d_or = (ctx.malloc(N * 8), ctx.malloc(N * 4), ctx.malloc(N * 4), ctx.malloc(N * 8),
                                       ctx.malloc(N * 4))
-    pa._lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, t.h, m.h, ex.h, b"gpu_dnn", d_q, R, k, d_rows, d_sc, d_rk, d_fu, d_or))
+    pa._lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, t.h, m.h, ex.h, b"gpu_dnn", d_q, R, k, d_rows, d_sc, d_rk, d_fu, d_or, None))
     rows, sc, rk = np.zeros((R, k), np.uint64), np.zeros((R, k), np.float32), np.zeros((R, k), np.float32)
     fu, order = np.zeros((R, k), np.float64), np.zeros((R, k), np.uint32)
     for a, p in ((rows, d_rows), (sc, d_sc), (rk, d_rk), (fu, d_fu), (order, d_or)):
@@ -825,7 +825,7 @@ def test_recommend_one_call_equals_the_stages(ctx):
     # a RankScore that names an unknown variable is refused
     bad = pa.Expr("${gpu_dnn}+${ctr}")
     with pytest.raises(RuntimeError):
-        pa._lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, t.h, m.h, bad.h, b"gpu_dnn", d_q, R, k, d_rows, d_sc, d_rk, d_fu, d_or))
+        pa._lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, t.h, m.h, bad.h, b"gpu_dnn", d_q, R, k, d_rows, d_sc, d_rk, d_fu, d_or, None))
     for p in (d_q, d_rows, d_sc, d_rk, d_fu, d_or):
         ctx.free(p)
     m.destroy()
