@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — ranked items/sec of pairec's recall → rank → sort hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the config the metric is quoted on): a batch of R=256 requests;
-each request = exact inner-product recall of the top 5000 of a 100M x 128 fp32 item table resident
-in HBM → 3-layer DNN rank (256→512→256→1, bf16 MFMA) of those 5000 candidates → RankScore fusion
-in fp64 → ItemRankScore (descending) sort.  A "step" is one such batch; value = ranked items / s
-(R*5000 per step), inputs resident in HBM when the timed region starts.
+Workload (BASELINE.json configs[1]+[2], the configuration the metric is quoted on): a batch of R=256 requests;
+each request = exact inner-product recall of the top 5000 of a 100M x 128 fp32 item table resident in HBM →
+3-layer DNN rank (256→512→256→1, bf16 MFMA) of those 5000 candidates → RankScore fusion in fp64 → ItemRankScore
+(descending) sort.  A "step" is one such batch; value = ranked items / s (R*5000 per step), inputs resident in HBM
+when the timed region starts.  Steps are issued through pg_recommend_dnn3_begin / pg_recommend_end, two batches
+deep, so the stream never drains between steps (each batch is verified when it is ended).
 
   python bench.py --gpus N --steps K --warmup W
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL), two modes:
   --mode replica (default): the 51.2 GB table fits one GPU, so it is replicated and the *requests*
       are sharded — every rank runs its own batches, no data-path collective, weak scaling.
   --mode shard: cfg-5 style — every rank holds --rows rows of one N x --rows table (contiguous row
-      ranges), all_gather of the per-shard top-K lists + all_reduce of the score slab per step
-      (pairec_amd/dist.py); value counts each request once.
+      ranges), all_gather of the per-shard top-K lists + all_reduce of the score slab per step, DPP on the merged
+      top-500 (pairec_amd/dist.py); value counts each request once.
+
+At N = 1 the same JSON line also carries (each a bounded, separately timed leg after the headline region):
+  "concurrent_callers"  the same table / model / k served through the request coalescer to --callers host threads
+                        that each issue ONE request at a time (how pairec calls its plug-ins), items/s + p50/p99
+  "gaussian_table"      the headline measurement repeated on N(0,1) rows (the int8 screen's less favourable case)
+  "other_configs"       cfg 1 (1M x 64, top-200, ascending ItemScore sort) and cfg 4 (FM + two-tower rank, 1M-row
+                        field tables) with their own rooflines
+  "cpu_baseline"        the oracle (C port of the reference-shaped CPU path) on a bounded sample, all host cores
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -32,7 +42,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 (v_mfma_i32_32x32x32_i8 issues at the bf16 rate with twice the k)
 FLOPS_PER_ITEM = 524800        # SURVEY.md §8(d) cfg 3: 2*(256*512+512*256+256)
+FM2T_BYTES_PER_ITEM = 544      # SURVEY.md §8(d) cfg 4: 8 ids x 4 B + 8 rows x 64 B
+FM2T_FLOPS_PER_ITEM = 99456
 RANK_EXPR = "${gpu_dnn}*(1+${current_score})^0.1"      # RankConf.RankScore: model score x recall score
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r2_scan_traffic.json")
 
 
 def parse_args():
@@ -46,20 +59,29 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=256, help="requests per step (<= 256 = one table pass)")
     ap.add_argument("--prec", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
+    ap.add_argument("--table-dist", choices=["uniform", "gaussian"], default="uniform",
+                    help="headline table: SURVEY.md 8d's normalised uniform rows, or N(0,1) rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline measurement only (profiling runs)")
+    ap.add_argument("--callers", type=int, default=768, help="host threads of the concurrent-callers leg (0 = skip)")
+    ap.add_argument("--callers-seconds", type=float, default=4.0)
+    ap.add_argument("--page", type=int, default=100, help="entries each concurrent caller asks for (ctx.Size)")
     ap.add_argument("--latency-reqs", type=int, default=200,
                     help="single-request latency samples at N=1 (the first 10 % are discarded as warm-up, SURVEY.md 8d)")
     return ap.parse_args()
 
 
-def pmc_traffic(R):
-    """HBM bytes per table pass of the dominant kernel from the committed rocprofv3 PMC pass of this
-    same command (profiles/r1_scan_traffic.json; FETCH_SIZE x2 per the gfx950 correction of
-    MI355X_MICROARCH.md §HBM, + WRITE_SIZE).  None if that profile does not cover this batch size."""
+def profile_numbers(R):
+    """What the committed rocprofv3 PMC passes of this same command measured for the dominant kernel at this batch
+    size (profiles/r2_scan_traffic.json, written by scripts/make_traffic_json.py): HBM bytes per table pass
+    (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md §HBM, + WRITE_SIZE) and the MFMA pipe's busy
+    fraction.  NOT measured in this run — hence the field name traffic_from_profile."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_scan_traffic.json")) as f:
+        with open(PROFILE_JSON) as f:
             d = json.load(f)
-        return d.get(str(R), {}).get("hbm_bytes_per_pass")
+        e = d.get(str(R), {})
+        return {"hbm_bytes_per_pass": e.get("hbm_bytes_per_pass"), "mfma_busy_frac": e.get("mfma_busy_frac"),
+                "source": os.path.relpath(PROFILE_JSON, ROOT)} if e else None
     except Exception:
         return None
 
@@ -85,6 +107,7 @@ def device_info():
         txt = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=30).stdout
         blocks = [b for b in txt.split("Agent ") if "gfx" in b and "Device Type:             GPU" in b]
         b = blocks[0]
+
         def field(k):
             for line in b.splitlines():
                 if line.strip().startswith(k):
@@ -105,23 +128,44 @@ def make_queries(o, step, R, dim):
 # single-GPU pipeline on raw device pointers (no torch on this path)
 # ------------------------------------------------------------------------------------------------
 class Pipeline1:
-    def __init__(self, pa, ctx, table, model, expr, R, K):
+    """pg_recommend_dnn3_begin / _end with `depth` output-buffer sets: step s + 1 is enqueued before step s is
+    ended, so the device always has the next batch queued behind the running one."""
+
+    def __init__(self, pa, ctx, table, model, expr, R, K, depth=2):
         self.pa, self.ctx, self.table, self.model, self.expr, self.R, self.K = pa, ctx, table, model, expr, R, K
         n = R * K
         m = ctx.malloc
-        self.d_rows, self.d_scores = m(n * 8), m(n * 4)
-        self.d_rank = m(n * 4)
-        self.d_fused, self.d_order = m(n * 8), m(n * 4)
+        self.bufs = [(m(n * 8), m(n * 4), m(n * 4), m(n * 8), m(n * 4)) for _ in range(depth)]
+        self.depth = depth
+        self.inflight = []          # tickets, oldest first
+        self.issued = 0
+        self.scan_ms = []
+
+    def begin(self, d_q, R=None):
+        from pairec_amd import _lib
+        ctx = self.ctx
+        b = self.bufs[self.issued % self.depth]
+        tk = C.c_void_p()
+        _lib.check(ctx.L.pg_recommend_dnn3_begin(ctx.h, self.table.h, self.model.h, self.expr.h, b"gpu_dnn", d_q,
+                                                 R or self.R, self.K, b[0], b[1], b[2], b[3], b[4], None, C.byref(tk)))
+        self.inflight.append(tk)
+        self.issued += 1
+
+    def end_oldest(self):
+        from pairec_amd import _lib
+        ms = C.c_double()
+        _lib.check(self.ctx.L.pg_recommend_end(self.ctx.h, self.inflight.pop(0), C.byref(ms)))
+        self.scan_ms.append(ms.value)
 
     def step(self, d_q, R=None):
-        """One request batch = ONE call into the library (pg_recommend_dnn3_dev): recall top-K → DNN3 rank of
-        every candidate → RankScore fusion → ItemRankScore sort, all device-resident."""
-        from pairec_amd import _lib
-        R = R or self.R
-        ctx = self.ctx
-        _lib.check(ctx.L.pg_recommend_dnn3_dev(ctx.h, self.table.h, self.model.h, self.expr.h, b"gpu_dnn", d_q, R,
-                                               self.K, self.d_rows, self.d_scores, self.d_rank, self.d_fused,
-                                               self.d_order, None))
+        """Keep `depth` batches in flight: enqueue this step, end the one issued depth - 1 steps ago."""
+        self.begin(d_q, R)
+        while len(self.inflight) >= self.depth:
+            self.end_oldest()
+
+    def drain(self):
+        while self.inflight:
+            self.end_oldest()
 
 
 def cpu_baseline(o, args, R, K):
@@ -155,6 +199,191 @@ def cpu_baseline(o, args, R, K):
                   "(scaled to %d); sort: %d x %d" % (slice_rows, R, t_recall_slice, args.rows // slice_rows,
                                                      n_sample, R * K, R, K),
         "stage_seconds_per_step": {"recall": t_recall, "rank": t_rank, "sort": t_sort},
+    }
+
+
+def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs):
+    """Both denominators, side by side: `frac` prices the bytes the pass actually streams (the int8 / bf16 shadow),
+    `frac_survey_8d` prices SURVEY.md 8(d)'s algorithmic figure — the fp32 table, rows x dim x 4 — and exceeds 1
+    whenever the screen is on, because the fp32 rows are never streamed (only the ~1e-4 of rows that pass the exact
+    integer / rigorous bound are gathered for re-scoring; the answers are bit-identical).  `bound` names the
+    resource with the larger utilisation (HBM fraction of the streamed bytes vs the matrix pipe)."""
+    elem_bytes = table.screen_info()[0]
+    screened = elem_bytes != 0
+    shard_bytes = rows_local * args.dim * (elem_bytes if screened else 4)
+    fp32_bytes = rows_local * args.dim * 4
+    t = scan_avg_ms * 1e-3
+    achieved = shard_bytes / t / 1e9
+    mfma_ops = 2.0 * rows_local * args.dim * R
+    mfma_peak = MFMA_I8_PEAK_TOPS if elem_bytes == 1 else (MFMA_BF16_PEAK_TFLOPS if elem_bytes == 2 else 157.3)
+    mfma_frac = mfma_ops / t / 1e12 / mfma_peak
+    prof = profile_numbers(R)
+    busy = (prof or {}).get("mfma_busy_frac") or 0.0
+    hbm_frac = achieved / HBM_PEAK_GBS
+    return {
+        "bound": "mfma" if max(mfma_frac, busy) > hbm_frac else "hbm",
+        "kernel": scan_kernel_name(R, args.dim, elem_bytes),
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+        "frac_survey_8d": fp32_bytes / t / 1e9 / HBM_PEAK_GBS,
+        "traffic": None, "traffic_from_profile": prof,
+        "measured_peak": measured_gbs, "frac_of_measured": achieved / measured_gbs if measured_gbs else None,
+        "bytes_per_pass": shard_bytes, "fp32_table_bytes": fp32_bytes, "ms_per_pass": scan_avg_ms,
+        "shadow_elem_bytes": elem_bytes,
+        "mfma_ops_per_pass": mfma_ops, "mfma_achieved": mfma_ops / t / 1e12, "mfma_peak": mfma_peak,
+        "mfma_unit": "Top/s" if elem_bytes == 1 else "TFLOP/s", "mfma_frac": mfma_frac,
+        "note": "bytes_per_pass = rows x dim x shadow_elem_bytes: the pass streams the int8 (dim 128) / bf16 shadow of the "
+                "fp32 table — an exact integer / rigorous bound of every score — and re-scores the survivors exactly in "
+                "fp32; frac_survey_8d > 1 says exactly that (the 51.2 GB fp32 table is not streamed).  One pass serves "
+                "%d requests; ms_per_pass = sum of the pass's scan-stage launches (pilot seed, pilot sample launch, "
+                "full pass, exact re-scoring), HIP events on the launch stream.  traffic is not measured in this run; "
+                "traffic_from_profile quotes the committed rocprofv3 --pmc passes of this command." % R,
+    }
+
+
+def run_headline(pa, ctx, table, model, expr, qs_dev, args, R, K, sync):
+    """warmup + timed steps; returns (elapsed seconds, per-step scan ms)."""
+    pipe = Pipeline1(pa, ctx, table, model, expr, R, K)
+    for s in range(args.warmup):
+        pipe.step(qs_dev[s % len(qs_dev)])
+    pipe.drain()
+    sync()
+    pipe.scan_ms = []
+    import gc
+    gc.collect()
+    gc.disable()                                      # no collector pauses inside the timed region
+    t0 = time.perf_counter()
+    for s in range(args.warmup, args.warmup + args.steps):
+        pipe.step(qs_dev[s % len(qs_dev)])
+    pipe.drain()
+    sync()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    return pipe, elapsed, pipe.scan_ms
+
+
+def concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K):
+    """--callers host threads, each blocked in ONE pg_coalescer_recommend at a time (closed loop) — how pairec's
+    goroutines call IAlgorithm.Run / Recall.GetCandidateItems.  The library forms the batches."""
+    host = C.CDLL(os.path.join(ROOT, "pairec_amd", "libpairec_host.so"))
+
+    class Res(C.Structure):
+        _fields_ = [("requests", C.c_uint64), ("errors", C.c_uint64), ("seconds", C.c_double), ("p50_ms", C.c_double),
+                    ("p90_ms", C.c_double), ("p99_ms", C.c_double), ("max_ms", C.c_double), ("mean_ms", C.c_double),
+                    ("checksum", C.c_uint64)]
+    host.ph_loadgen_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_uint32, C.c_double, C.POINTER(Res)]
+    users = np.ascontiguousarray(o.synth_rows(o.SEED_QUERY, 0, 1000, args.dim))
+    co = pa.Coalescer(ctx, table, K, model, expr, "gpu_dnn", max_top_n=args.page, depth=3)
+    res, solo = Res(), Res()
+    rc = host.ph_loadgen_run(co.h, 0, users.ctypes.data, 1000, args.dim, K, args.page, args.callers, 2,
+                             args.callers_seconds, C.byref(res))
+    rc2 = host.ph_loadgen_run(co.h, 0, users.ctypes.data, 1000, args.dim, K, args.page, 1, 3, 1.0, C.byref(solo))
+    st = co.stats()
+    co.destroy()
+    if rc or rc2 or res.errors or solo.errors:
+        return {"error": "load generator failed (rc %d/%d, %d errors)" % (rc, rc2, res.errors + solo.errors)}
+    return {
+        "mode": "concurrent_callers", "callers": args.callers, "page": args.page, "k": K,
+        "value": res.requests * K / res.seconds, "unit": "ranked items/s",
+        "requests_per_s": res.requests / res.seconds,
+        "p50_ms": res.p50_ms, "p90_ms": res.p90_ms, "p99_ms": res.p99_ms, "mean_ms": res.mean_ms,
+        "avg_batch": st.requests[2] / max(st.batches[2], 1), "batches": st.batches[2], "replans": st.replans,
+        "solo_caller": {"requests_per_s": solo.requests / solo.seconds, "p50_ms": solo.p50_ms, "p99_ms": solo.p99_ms,
+                        "value": solo.requests * K / solo.seconds},
+        "note": "closed loop: every caller has one request outstanding (a goroutine blocked in IAlgorithm.Run); results "
+                "cross PCIe (the page: rows, three scores per entry); the coalescer batches up to 256 requests per table "
+                "pass, 3 batches in flight",
+    }
+
+
+def cfg1_leg(pa, o, ctx):
+    """BASELINE.json configs[0]: 1M x 64 in-memory vector table, dot-product top-200, sort.item_score (ascending) —
+    the reference's CPU-runnable case.  CPU row = the oracle (scan + heap top-K + sort) on all host cores; the GPU
+    row is the same request through the C ABI (host buffers in and out)."""
+    n, d, k, R = 1_000_000, 64, 200, 64
+    cores = os.cpu_count() or 1
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    q = o.synth_rows(o.SEED_QUERY, 0, R, d)
+    t0 = time.time()
+    rows, scores = o.recall_topk(tab, q, k, threads=cores)
+    for r in range(R):
+        o.sort_scores(scores[r].astype(np.float64), False)
+    t_cpu = (time.time() - t0) / R
+    t0 = time.time()
+    o.recall_topk(tab, q[:4], k, threads=1)
+    t_cpu1 = (time.time() - t0) / 4
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    g_rows, g_scores, _ = t.recall_topk(q[:1], k)                 # warm-up (builds the shadow)
+    lat = []
+    for r in range(R):
+        t1 = time.perf_counter()
+        g_rows, g_scores, _ = t.recall_topk(q[r:r + 1], k)
+        order = ctx.sort_scores(g_scores[0].astype(np.float64), descending=False)
+        lat.append(time.perf_counter() - t1)
+    ok = bool(np.array_equal(g_rows[0], rows[R - 1]) and np.array_equal(order, o.sort_scores(scores[R - 1].astype(np.float64), False)))
+    t0 = time.perf_counter()
+    t.recall_topk(q, k)                                            # 64 requests in one pass
+    t_batch = (time.perf_counter() - t0) / R
+    t.destroy()
+    return {
+        "workload": "configs[0]: 1M x 64 fp32, dot-product top-200, ItemScore (ascending) sort; one request per call",
+        "cpu": {"requests_per_s": 1.0 / t_cpu, "ms_per_request": t_cpu * 1e3, "cores": cores, "kind": "port",
+                "single_thread_ms_per_request": t_cpu1 * 1e3,
+                "bytes_per_request": n * d * 4, "gbs": n * d * 4 / t_cpu / 1e9},
+        "gpu": {"requests_per_s": 1.0 / float(np.median(lat)), "p50_ms": float(np.median(lat)) * 1e3,
+                "ms_per_request_batched_64": t_batch * 1e3, "matches_oracle": ok},
+    }
+
+
+def cfg4_leg(pa, o, ctx, R, K):
+    """BASELINE.json configs[3]: FM (8 + 8 fields, k = 16) + two-tower (128 → 256 → 64) rank of R x K candidates,
+    field tables of 1M rows each.  HBM-gather bound: 544 algorithmic bytes per item."""
+    vocab = 1_000_000
+    fw = o.Fm2tWeights(vocab=vocab)
+    m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, pa.PREC_BF16, pa.pack_fm2t(fw))
+    rng = np.random.default_rng(5)
+    users = o.synth_rows(o.SEED_QUERY, 0, R, 128)
+    ufids = rng.integers(0, vocab, (R, 8)).astype(np.int32)
+    ifids = rng.integers(0, vocab, (R * K, 8)).astype(np.int32)
+    off = (np.arange(R + 1) * K).astype(np.uint32)
+    n = R * K
+    d_u, d_uf, d_if, d_off = ctx.to_device(users), ctx.to_device(ufids), ctx.to_device(ifids), ctx.to_device(off)
+    d_out = ctx.malloc(n * 4)
+    from pairec_amd import _lib
+
+    def call():
+        _lib.check(ctx.L.pg_rank_fm2t_dev(ctx.h, m.h, d_u, d_uf, d_if, d_off, R, n, d_out))
+    for _ in range(3):
+        call()
+    ctx.synchronize()
+    dev_ms = []
+    t0 = time.perf_counter()
+    steps = 20
+    for _ in range(steps):
+        call()
+        dev_ms.append(ctx.stats().last_rank_ms)       # HIP events around the rank launches (synchronises)
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    ms = float(np.mean(dev_ms))
+    # spot check against the oracle on one request's first items
+    got = np.zeros(n, dtype=np.float32)
+    ctx.d2h(got, d_out)
+    ref = o.fm2t_forward(fw, 1, users[0], ufids[0], ifids[:64])
+    err = float(np.max(np.abs(got[:64].astype(np.float64) - ref)))
+    for p in (d_u, d_uf, d_if, d_off, d_out):
+        ctx.free(p)
+    m.destroy()
+    gbs = n * FM2T_BYTES_PER_ITEM / (ms * 1e-3) / 1e9
+    tf = n * FM2T_FLOPS_PER_ITEM / (ms * 1e-3) / 1e12
+    return {
+        "workload": "configs[3]: FM(8+8 fields, k=16, 1M-row field tables) + two-tower(128-256-64) rank, %d x %d candidates, bf16" % (R, K),
+        "value": n / (ms * 1e-3), "unit": "ranked items/s", "device_ms_per_step": ms, "wall_ms_per_step": wall * 1e3,
+        "max_abs_err_vs_oracle_64_items": err,
+        "roofline": {"bound": "hbm", "kernel": "pg::mlp_kernel<1,256,64,false,...> (FM + item tower)",
+                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "bytes_per_item": FM2T_BYTES_PER_ITEM, "traffic": None,
+                     "mfma_achieved_tflops": tf, "mfma_frac": tf / MFMA_BF16_PEAK_TFLOPS},
     }
 
 
@@ -197,7 +426,13 @@ def main():
     else:
         begin, end = 0, args.rows                                      # full replica
     table = pa.Table(ctx, end - begin, args.dim, row_offset=begin)
-    table.fill_synthetic(o.SEED_TABLE)
+
+    def fill(dist_name):
+        if dist_name == "gaussian":
+            table.fill_gaussian(o.SEED_TABLE, 1.0)
+        else:
+            table.fill_synthetic(o.SEED_TABLE)
+    fill(args.table_dist)
     w = o.Dnn3Weights()
     prec = pa.PREC_BF16 if args.prec == "bf16" else pa.PREC_F32
     model = pa.RankModel(ctx, pa.MODEL_DNN3, prec, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
@@ -206,54 +441,38 @@ def main():
     total_steps = args.warmup + args.steps
     # replica mode: every rank serves different users
     qs = [make_queries(o, s * (1 if shard else world) + (0 if shard else rank), R, args.dim) for s in range(total_steps)]
+    measured_gbs = table.hbm_read_probe(3)           # measured streaming-read ceiling of this GPU's HBM
+    table.screen_info()                              # build the shadow outside the timed region
 
     if not shard:
-        pipe = Pipeline1(pa, ctx, table, model, expr, R, K)
         d_qs = [ctx.to_device(q) for q in qs]
-
-        def run(s):
-            pipe.step(d_qs[s])
 
         def sync():
             ctx.synchronize()
             if world > 1:
                 dist.barrier()
                 torch.cuda.synchronize()
+        pipe, elapsed, scan_ms = run_headline(pa, ctx, table, model, expr, d_qs, args, R, K, sync)
     else:
         eng = GpuShardEngine(torch, ctx, table, model, expr, K, R)
         dev = torch.device("cuda", local_rank)
         t_qs = [torch.from_numpy(q).to(dev) for q in qs]
 
-        def run(s):
-            sharded_step(eng, dist, torch, t_qs[s], R, K)
-
         def sync():
             dist.barrier()
             torch.cuda.synchronize()
-
-    # measured streaming-read ceiling of this GPU's HBM (plain read-only kernel over the same table)
-    measured_gbs = table.hbm_read_probe(3)
-    for s in range(args.warmup):
-        run(s)
-    sync()
-    scan_ms, scan_launches, stage = [], 0, {"recall": [], "rank": []}
-    import gc
-    gc.collect()
-    gc.disable()                                      # no collector pauses inside the timed region
-    t0 = time.perf_counter()
-    step_wall = []
-    for s in range(args.warmup, total_steps):
-        ts = time.perf_counter()
-        run(s)
-        ms, nbytes = ctx.last_scan_kernel()          # HIP events around the scan launches (this step)
-        scan_ms.append(ms)
-        step_wall.append((time.perf_counter() - ts) * 1e3)
-    sync()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    if os.environ.get("PG_BENCH_STEPTIMES"):          # developer aid: per-step wall and scan times
-        print("step wall ms:", " ".join("%.2f" % x for x in step_wall), "| scan ms:", " ".join("%.2f" % x for x in scan_ms),
-              "| rescans", ctx.stats().recall_rescans, file=sys.stderr)
+        for s in range(args.warmup):
+            sharded_step(eng, dist, torch, t_qs[s], R, K)
+        sync()
+        scan_ms = []
+        t0 = time.perf_counter()
+        for s in range(args.warmup, total_steps):
+            sharded_step(eng, dist, torch, t_qs[s], R, K)
+            scan_ms.append(ctx.last_scan_kernel()[0])
+        sync()
+        elapsed = time.perf_counter() - t0
+    if os.environ.get("PG_BENCH_STEPTIMES"):          # developer aid
+        print("scan ms:", " ".join("%.2f" % x for x in scan_ms), "| rescans", ctx.stats().recall_rescans, file=sys.stderr)
     st = ctx.stats()
     if world > 1:
         dev = torch.device("cpu") if share_gpu else torch.device("cuda", local_rank)
@@ -263,73 +482,69 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = R * K * args.steps / elapsed * (1 if shard else world)
-    # Algorithmic bytes of one table pass: the screen streams the table's shadow — int8 at dim 128 (rows x dim
-    # x 1), bf16 at dim 64 — and the fp32 rows (rows x dim x 4, SURVEY.md 8d's figure for a scan
-    # of the table itself) are only gathered for the ~1e-4 fraction of rows that reach the exact re-scoring.
-    # Tables the screen cannot serve (dim > 128) are scanned in fp32.
-    elem_bytes = table.screen_info()[0]
-    screened = elem_bytes != 0
-    shard_bytes = (end - begin) * args.dim * (elem_bytes if screened else 4)
-    fp32_bytes = (end - begin) * args.dim * 4
     scan_avg_ms = float(np.mean(scan_ms))
-    achieved = shard_bytes / (scan_avg_ms * 1e-3) / 1e9
+    rank_items = R * K / (world if shard else 1)
     out = {
         "metric": "ranked items/sec, 5k-cand DNN rank (recall top-5000 of 100M x 128 -> DNN3 -> fuse -> sort)",
         "value": value, "unit": "ranked items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
-        "config": {"workload": "configs[2]: recall 5k of %dx%d fp32 table in HBM -> 3-layer DNN rank "
+        "config": {"workload": "configs[1]+[2]: recall 5k of %dx%d fp32 table in HBM -> 3-layer DNN rank "
                                "(256-512-256-1, %s MFMA) -> RankScore fusion (fp64) -> ItemRankScore sort"
                                % (args.rows, args.dim, args.prec),
                    "requests_per_step": R, "candidates_per_request": K, "table_rows": args.rows,
-                   "dim": args.dim,
-                   "parallelism": ("table row-range shards x%d (%d rows total), all_gather top-K merge + all_reduce scores"
+                   "dim": args.dim, "table_dist": args.table_dist, "batches_in_flight": 2 if not shard else 1,
+                   "parallelism": ("table row-range shards x%d (%d rows total), all_gather top-K merge + all_reduce scores + DPP top-500"
                                    % (world, args.rows * world)) if shard else
                                   ("request-parallel x%d, table replicated per GPU, no data-path collective" % world
                                    if world > 1 else "1 GPU")},
-        "roofline": {"bound": "hbm", "kernel": scan_kernel_name(R, args.dim, elem_bytes), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R),
-                     "measured_peak": measured_gbs, "frac_of_measured": achieved / measured_gbs,
-                     "bytes_per_pass": shard_bytes, "ms_per_pass": scan_avg_ms,
-                     "mfma_flops_per_pass": 2.0 * (end - begin) * args.dim * R if screened else None,
-                     "mfma_frac": (2.0 * (end - begin) * args.dim * R / (scan_avg_ms * 1e-3) / 1e12 /
-                                   (MFMA_I8_PEAK_TOPS if elem_bytes == 1 else MFMA_BF16_PEAK_TFLOPS))
-                     if screened else None,
-                     "shadow_elem_bytes": elem_bytes,
-                     "fp32_table_bytes": fp32_bytes,
-                     "fp32_table_equivalent_gbs": fp32_bytes / (scan_avg_ms * 1e-3) / 1e9,
-                     "note": "algorithmic bytes = shard rows x dim x shadow_elem_bytes per table pass: the pass streams the "
-                             "int8 (dim 128) / bf16 (dim 64) shadow of the fp32 table, an exact integer / rigorous bound, with "
-                             "exact fp32 re-scoring of the ~1e-4 of rows that pass it; one pass serves %d requests; "
-                             "duration = sum of the pass's scan-stage launches (exact seed of the pilot sample, screened sample launch, "
-                             "screened full pass, exact re-scoring), HIP events on the launch stream" % R},
+        "roofline": roofline_block(table, R, args, end - begin, scan_avg_ms, measured_gbs),
         "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},
         "rank_roofline": {"bound": "mfma", "kernel": "pg::dnn3_ws_kernel",
-                          "achieved": (R * K / (world if shard else 1)) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
+                          "achieved": rank_items * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
                           "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": (R * K / (world if shard else 1)) * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS}
+                          "frac": rank_items * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS}
         if args.prec == "bf16" and st.last_rank_ms > 0 else None,
     }
 
-    if world == 1 and args.latency_reqs > 0:  # noqa: E129
-        # p50 single-request latency (R=1), same pipeline, inputs resident
+    solo = world == 1
+    if solo and args.latency_reqs > 0:
+        # p50 single-request latency (R=1), same pipeline, inputs resident, one batch at a time
         lat = []
         lq = [ctx.to_device(make_queries(o, 7000 + i, 1, args.dim)) for i in range(min(args.latency_reqs, 1000))]
         for i in range(args.latency_reqs):
             dq = lq[i % len(lq)]                      # distinct users
             ctx.synchronize()
             t1 = time.perf_counter()
-            pipe.step(dq, R=1)
-            ctx.synchronize()
+            pipe.begin(dq, R=1)
+            pipe.drain()
             lat.append((time.perf_counter() - t1) * 1e3)
         lat = lat[len(lat) // 10:]
         out["p99_request_latency_ms"] = float(np.percentile(lat, 99))
         out["p50_request_latency_ms"] = float(np.median(lat))
 
+    extras = solo and not args.no_extras
+    if extras and args.callers > 0:
+        out["concurrent_callers"] = concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K)
+    if extras:
+        # the same headline measurement on the other table distribution (uniform rows are the int8 screen's best case)
+        other = "gaussian" if args.table_dist == "uniform" else "uniform"
+        fill(other)
+        table.screen_info()
+        _, el2, scan2 = run_headline(pa, ctx, table, model, expr, d_qs, args, R, K, sync)
+        rf = roofline_block(table, R, args, end - begin, float(np.mean(scan2)), measured_gbs)
+        out["%s_table" % other] = {"table_dist": other, "value": R * K * args.steps / el2, "unit": "ranked items/s",
+                                   "ms_per_step": el2 / args.steps * 1e3,
+                                   "roofline": {k_: rf[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                                      "frac_survey_8d", "ms_per_pass", "shadow_elem_bytes",
+                                                                      "mfma_frac")}}
+        table.destroy()
+        out["other_configs"] = {"cfg1": cfg1_leg(pa, o, ctx), "cfg4": cfg4_leg(pa, o, ctx, R, K)}
+
     if rank == 0:
         out["device"] = device_info()
-        if world == 1 and not args.no_cpu_baseline:
+        if solo and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(o, args, R, K)
         else:
             out["cpu_baseline"] = None

@@ -70,6 +70,10 @@ int pg_table_create(pg_ctx* ctx, uint64_t rows, uint32_t dim, uint64_t row_offse
 int pg_table_destroy(pg_ctx* ctx, pg_table* t);
 /* deterministic synthetic fill: global row = row_offset + local row */
 int pg_table_fill_synthetic(pg_ctx* ctx, pg_table* t, uint64_t seed, int normalize);
+/* i.i.d. N(0, sigma^2) elements, unnormalised rows — the second benchmark distribution (trained embeddings look
+ * Gaussian; the uniform rows of SURVEY.md 8d are the int8 screen's best case).  Defined by the device's own fp64
+ * log / cos: reproducible run to run, compared in tests against downloaded rows. */
+int pg_table_fill_gaussian(pg_ctx* ctx, pg_table* t, uint64_t seed, float sigma);
 int pg_table_upload(pg_ctx* ctx, pg_table* t, uint64_t row0, uint64_t nrows, const float* host_rows);
 int pg_table_download(pg_ctx* ctx, const pg_table* t, uint64_t row0, uint64_t nrows, float* host_rows);
 /* atomically exchange the contents of two tables of equal shape (the analogue of the Hologres
@@ -246,6 +250,18 @@ int pg_recommend_dnn3_dev(pg_ctx* ctx, const pg_table* t, const pg_model* m, con
                           const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
                           float* d_out_recall_scores, float* d_out_rank_scores, double* d_out_fused,
                           uint32_t* d_out_order, uint32_t* d_out_count);
+
+/* The same batch in two halves, for callers that keep several batches queued on the stream (bench.py; a serving loop
+ * that owns its batching): _begin enqueues everything and returns at once with a ticket, _end waits for that batch,
+ * verifies it (re-running it with the fallback recall plan if the first one did not hold) and frees the ticket.
+ * Every ticket must be ended; output buffers belong to the batch until then. */
+typedef struct pg_ticket pg_ticket;
+int pg_recommend_dnn3_begin(pg_ctx* ctx, const pg_table* t, const pg_model* m, const pg_expr* e, const char* rank_var,
+                            const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
+                            float* d_out_recall_scores, float* d_out_rank_scores, double* d_out_fused,
+                            uint32_t* d_out_order, uint32_t* d_out_count, pg_ticket** out);
+/* scan_ms (optional): the batch's scan-stage launches, HIP-event timed (what pg_last_scan_kernel_ms reports) */
+int pg_recommend_end(pg_ctx* ctx, pg_ticket* ticket, double* scan_ms);
 
 /* ---- request coalescer --------------------------------------------------------------------------
  * The reference calls its plug-ins once per request from many goroutines at once: one IAlgorithm.Run per recall

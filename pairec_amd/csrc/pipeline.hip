@@ -150,47 +150,80 @@ int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok) {
 
 }  // namespace pg
 
+struct pg_ticket {
+    pg::RecommendCall call;
+    std::vector<int> var_src;
+    pg::PipeRun* run = nullptr;
+};
+
 extern "C" {
+
+int pg_recommend_dnn3_begin(pg_ctx* ctx, const pg_table* t, const pg_model* m, const pg_expr* e, const char* rank_var,
+                            const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
+                            float* d_out_recall_scores, float* d_out_rank_scores, double* d_out_fused,
+                            uint32_t* d_out_order, uint32_t* d_out_count, pg_ticket** out) {
+    PG_REQUIRE(ctx && t && m && e && rank_var && d_queries && d_out_rows && d_out_recall_scores && d_out_rank_scores &&
+                   d_out_fused && d_out_order && out,
+               "pg_recommend_dnn3: NULL argument");
+    PG_REQUIRE(nq > 0 && nq <= (uint32_t)pg::kMaxQueries && k > 0 && k <= 16384, "pg_recommend_dnn3: bad nq / k");
+    PG_REQUIRE(m->kind == PG_MODEL_DNN3 && t->dim == m->d_item && m->d_user == t->dim,
+               "pg_recommend_dnn3: the model must be DNN3 with d_user = d_item = the table's dim");
+    pg_ticket* tk = new pg_ticket();
+    int rc;
+    if ((rc = pg::recommend_bind_vars(e, rank_var, &tk->var_src, "pg_recommend_dnn3"))) {
+        delete tk;
+        return rc;
+    }
+    pg::RecommendCall& c = tk->call;
+    c.t = t; c.m = m; c.e = e; c.var_src = tk->var_src.data(); c.nv = (int)tk->var_src.size();
+    c.d_queries = d_queries; c.nq = nq; c.k = k;
+    c.d_rows = d_out_rows; c.d_recall = d_out_recall_scores; c.d_rank = d_out_rank_scores;
+    c.d_fused = d_out_fused; c.d_order = d_out_order; c.d_count = d_out_count;
+    if ((rc = pg::pipe_run_acquire(ctx, &tk->run)) || (rc = pg::recommend_enqueue(ctx, c, tk->run, true))) {
+        if (tk->run) pg::pipe_run_release(ctx, tk->run);
+        delete tk;
+        return rc;
+    }
+    *out = tk;
+    return PG_OK;
+}
+
+int pg_recommend_end(pg_ctx* ctx, pg_ticket* tk, double* scan_ms) {
+    PG_REQUIRE(ctx && tk, "pg_recommend_end: NULL argument");
+    int rc = PG_OK;
+    for (bool ok = false; !ok;) {
+        if (hipEventSynchronize(tk->run->done) != hipSuccess) {
+            pg::set_error("pg_recommend_end: %s", hipGetErrorString(hipGetLastError()));
+            rc = PG_ERR_DEVICE;
+            break;
+        }
+        if ((rc = pg::recommend_verify(ctx, tk->run, &ok))) break;
+        if (!ok && (rc = pg::recommend_enqueue(ctx, tk->call, tk->run, false))) break;
+    }
+    if (!rc) {
+        if (scan_ms) *scan_ms = tk->run->job.scan_ms;
+        for (uint32_t q = 0; q < tk->call.nq; ++q)
+            if (tk->run->h_status[pg::kExprFlagAt + q]) {
+                pg::set_expr_arith_error(tk->call.e);
+                rc = PG_ERR_ARITH;
+                break;
+            }
+    }
+    pg::pipe_run_release(ctx, tk->run);
+    delete tk;
+    return rc;
+}
 
 int pg_recommend_dnn3_dev(pg_ctx* ctx, const pg_table* t, const pg_model* m, const pg_expr* e, const char* rank_var,
                           const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
                           float* d_out_recall_scores, float* d_out_rank_scores, double* d_out_fused,
                           uint32_t* d_out_order, uint32_t* d_out_count) {
-    PG_REQUIRE(ctx && t && m && e && rank_var && d_queries && d_out_rows && d_out_recall_scores && d_out_rank_scores &&
-                   d_out_fused && d_out_order,
-               "pg_recommend_dnn3_dev: NULL argument");
-    PG_REQUIRE(nq > 0 && nq <= (uint32_t)pg::kMaxQueries && k > 0 && k <= 16384, "pg_recommend_dnn3_dev: bad nq / k");
-    PG_REQUIRE(m->kind == PG_MODEL_DNN3 && t->dim == m->d_item && m->d_user == t->dim,
-               "pg_recommend_dnn3_dev: the model must be DNN3 with d_user = d_item = the table's dim");
-    std::vector<int> src;
+    pg_ticket* tk = nullptr;
     int rc;
-    if ((rc = pg::recommend_bind_vars(e, rank_var, &src, "pg_recommend_dnn3_dev"))) return rc;
-    pg::RecommendCall c;
-    c.t = t; c.m = m; c.e = e; c.var_src = src.data(); c.nv = (int)src.size();
-    c.d_queries = d_queries; c.nq = nq; c.k = k;
-    c.d_rows = d_out_rows; c.d_recall = d_out_recall_scores; c.d_rank = d_out_rank_scores;
-    c.d_fused = d_out_fused; c.d_order = d_out_order; c.d_count = d_out_count;
-    pg::PipeRun* r;
-    if ((rc = pg::pipe_run_acquire(ctx, &r))) return rc;
-    bool ok = false;
-    for (bool first = true; !ok; first = false) {
-        if ((rc = pg::recommend_enqueue(ctx, c, r, first))) break;
-        if (hipEventSynchronize(r->done) != hipSuccess) {
-            pg::set_error("pg_recommend_dnn3_dev: %s", hipGetErrorString(hipGetLastError()));
-            rc = PG_ERR_DEVICE;
-            break;
-        }
-        if ((rc = pg::recommend_verify(ctx, r, &ok))) break;
-    }
-    if (!rc)
-        for (uint32_t q = 0; q < nq; ++q)
-            if (r->h_status[pg::kExprFlagAt + q]) {
-                pg::set_expr_arith_error(e);
-                rc = PG_ERR_ARITH;
-                break;
-            }
-    pg::pipe_run_release(ctx, r);
-    return rc;
+    if ((rc = pg_recommend_dnn3_begin(ctx, t, m, e, rank_var, d_queries, nq, k, d_out_rows, d_out_recall_scores,
+                                      d_out_rank_scores, d_out_fused, d_out_order, d_out_count, &tk)))
+        return rc;
+    return pg_recommend_end(ctx, tk, nullptr);
 }
 
 }  // extern "C"

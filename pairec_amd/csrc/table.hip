@@ -46,6 +46,21 @@ __global__ __launch_bounds__(256) void table_fill_synth_kernel(float* __restrict
     }
 }
 
+// Gaussian rows for the second benchmark distribution (real embeddings look Gaussian, not uniform): Box-Muller on
+// one splitmix64 draw per element, z = sqrt(-2 ln u1) cos(2 pi u2) with u1 from the draw's upper 53 bits (tails to
+// 8.5 sigma) evaluated in fp64, value = (float)(z * scale).  Device-defined: tests compare against the rows they
+// download, not against a CPU regeneration (log / cos differ by an ulp between libms).
+__global__ __launch_bounds__(256) void table_fill_gauss_kernel(float* __restrict__ out, uint64_t n_elems,
+                                                              uint64_t elem_offset, uint64_t seed, double scale) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems; i += stride) {
+        const uint64_t u = splitmix64(seed ^ (elem_offset + i));
+        const double u1 = (double)((u >> 11) + 1) * (1.0 / 9007199254740992.0);       // (0, 1]
+        const double u2 = (double)(splitmix64(u) >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+        out[i] = (float)(sqrt(-2.0 * log(u1)) * cospi(2.0 * u2) * scale);
+    }
+}
+
 // one wave-half (32 lanes x 16 B = 512 B) per gathered row at dim=128
 __global__ void table_gather_kernel(const float* __restrict__ tab, uint32_t dim,
                                     const uint32_t* __restrict__ rows, uint32_t n,
@@ -125,6 +140,19 @@ int pg_table_fill_synthetic(pg_ctx* ctx, pg_table* t, uint64_t seed, int normali
             pg::set_error("pg_table_fill_synthetic: dim=%u unsupported", t->dim);
             return PG_ERR_UNSUPPORTED;
     }
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    t->stats_valid = false;
+    return PG_OK;
+}
+
+int pg_table_fill_gaussian(pg_ctx* ctx, pg_table* t, uint64_t seed, float sigma) {
+    PG_REQUIRE(ctx && t, "pg_table_fill_gaussian: NULL argument");
+    PG_REQUIRE(sigma > 0.0f && sigma < 1e30f, "pg_table_fill_gaussian: sigma must be positive and finite");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    const uint64_t n = t->rows * (uint64_t)t->dim;
+    pg::table_fill_gauss_kernel<<<(uint32_t)ctx->num_cus * 16, 256, 0, ctx->stream>>>(t->d, n, t->row_offset * (uint64_t)t->dim, seed,
+                                                                                     (double)sigma);
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(ctx->stream));
     t->stats_valid = false;

@@ -123,6 +123,9 @@ class Table:
     def fill_synthetic(self, seed: int, normalize: bool = True):
         _lib.check(self.ctx.L.pg_table_fill_synthetic(self.ctx.h, self.h, seed, int(normalize)))
 
+    def fill_gaussian(self, seed: int, sigma: float = 1.0):
+        _lib.check(self.ctx.L.pg_table_fill_gaussian(self.ctx.h, self.h, seed, float(sigma)))
+
     def upload(self, rows: np.ndarray, row0: int = 0):
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         assert rows.ndim == 2 and rows.shape[1] == self.dim
