@@ -274,26 +274,36 @@ def concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K):
                                     C.c_uint32, C.c_uint32, C.c_double, C.POINTER(Res)]
     users = np.ascontiguousarray(o.synth_rows(o.SEED_QUERY, 0, 1000, args.dim))
     co = pa.Coalescer(ctx, table, K, model, expr, "gpu_dnn", max_top_n=args.page, depth=3)
-    res, solo = Res(), Res()
-    rc = host.ph_loadgen_run(co.h, 0, users.ctypes.data, 1000, args.dim, K, args.page, args.callers, 2,
-                             args.callers_seconds, C.byref(res))
-    rc2 = host.ph_loadgen_run(co.h, 0, users.ctypes.data, 1000, args.dim, K, args.page, 1, 3, 1.0, C.byref(solo))
-    st = co.stats()
+
+    def leg(callers, seconds, warm):
+        res = Res()
+        s0 = co.stats()
+        b0, r0 = s0.batches[2], s0.requests[2]
+        rc = host.ph_loadgen_run(co.h, 0, users.ctypes.data, 1000, args.dim, K, args.page, callers, warm, seconds,
+                                 C.byref(res))
+        s1 = co.stats()
+        if rc or res.errors:
+            raise RuntimeError("load generator failed (rc %d, %d errors)" % (rc, res.errors))
+        return {"callers": callers, "value": res.requests * K / res.seconds, "requests_per_s": res.requests / res.seconds,
+                "p50_ms": res.p50_ms, "p90_ms": res.p90_ms, "p99_ms": res.p99_ms, "mean_ms": res.mean_ms,
+                "avg_batch": (s1.requests[2] - r0) / max(s1.batches[2] - b0, 1), "replans": s1.replans}
+    try:
+        main_leg = leg(args.callers, args.callers_seconds, 2)
+        sweep = [leg(c_, 1.5, 2) for c_ in (256, 512) if c_ != args.callers]
+        solo = leg(1, 1.0, 3)
+    except RuntimeError as e:
+        co.destroy()
+        return {"error": str(e)}
     co.destroy()
-    if rc or rc2 or res.errors or solo.errors:
-        return {"error": "load generator failed (rc %d/%d, %d errors)" % (rc, rc2, res.errors + solo.errors)}
-    return {
-        "mode": "concurrent_callers", "callers": args.callers, "page": args.page, "k": K,
-        "value": res.requests * K / res.seconds, "unit": "ranked items/s",
-        "requests_per_s": res.requests / res.seconds,
-        "p50_ms": res.p50_ms, "p90_ms": res.p90_ms, "p99_ms": res.p99_ms, "mean_ms": res.mean_ms,
-        "avg_batch": st.requests[2] / max(st.batches[2], 1), "batches": st.batches[2], "replans": st.replans,
-        "solo_caller": {"requests_per_s": solo.requests / solo.seconds, "p50_ms": solo.p50_ms, "p99_ms": solo.p99_ms,
-                        "value": solo.requests * K / solo.seconds},
+    out = dict(main_leg)
+    out.update({
+        "mode": "concurrent_callers", "page": args.page, "k": K, "unit": "ranked items/s",
+        "other_caller_counts": sweep, "solo_caller": solo,
         "note": "closed loop: every caller has one request outstanding (a goroutine blocked in IAlgorithm.Run); results "
                 "cross PCIe (the page: rows, three scores per entry); the coalescer batches up to 256 requests per table "
                 "pass, 3 batches in flight",
-    }
+    })
+    return out
 
 
 def cfg1_leg(pa, o, ctx):

@@ -100,6 +100,18 @@ int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_
                    uint64_t* out_rows, float* out_scores, uint32_t* out_count);
 int pg_recall_topk_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq,
                        uint32_t k, uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count);
+/* I2IVectorRecall.GetCandidateItems (service/recall/item_2_item_vector_racall.go:51-152): the embeddings of the
+ * trigger items (context parameter "item_id" → dao.VectorString) are the queries — rows `trigger_rows[n]` of
+ * `trigger_table` (same dim as `t`; usually the same table) against `t`.  Outputs as pg_recall_topk; the trigger
+ * item itself is not excluded (neither does the reference's SQL). */
+int pg_i2i_recall(pg_ctx* ctx, const pg_table* trigger_table, const uint32_t* trigger_rows, uint32_t n,
+                  const pg_table* t, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_count);
+/* OnlineVectorRecall.GetCandidateItems (service/recall/online_vector_recall.go:73-155): user features → the vector
+ * model's user embedding → its FaissNeighNum = k nearest items (TorchrecEmbeddingItemsResponse: match_item_scores +
+ * item_ids, algorithm/eas/easyrec_response.go:700-734).  `m` is a PG_MODEL_FM_TWOTOWER whose user tower produces the
+ * embedding (pg_fm2t_user_embedding), `item_emb` the item-tower outputs as a table of dim t_out. */
+int pg_online_vector_recall(pg_ctx* ctx, const pg_model* m, const pg_table* item_emb, const float* user_vecs,
+                            uint32_t n_req, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_count);
 /* merge `nlists` sorted/unsorted (row,score) lists of `per_list` entries per query into the global
  * top-k (multi-GPU: the lists are the all-gathered per-shard results).  Layout [nq][nlists][per_list]. */
 int pg_topk_merge_dev(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq,
@@ -150,6 +162,11 @@ int pg_rank_fm2t_dev(pg_ctx* ctx, const pg_model* m, const float* d_user_vecs,
                      const int32_t* d_user_field_ids, const int32_t* d_item_field_ids,
                      const uint32_t* d_req_offsets, uint32_t n_req, uint32_t n_items,
                      float* d_out_scores);
+
+/* user-tower output of the two-tower model: out [n_req][t_out] = uw2' relu(uw1' P(u) + ub1) + ub2 —
+ * the user embedding of online_vector_recall.go:97-109 / embedding_service.go:127 */
+int pg_fm2t_user_embedding(pg_ctx* ctx, const pg_model* m, const float* user_vecs, uint32_t n_req, float* out);
+int pg_fm2t_user_embedding_dev(pg_ctx* ctx, const pg_model* m, const float* d_user_vecs, uint32_t n_req, float* d_out);
 
 /* ---- rank: score fusion (RankConfig.RankScore) ----------------------------------------------
  * Replaces ast.GetExpAST + ExprASTResult (utils/ast/ast.go:215-268,368-389): compile once,

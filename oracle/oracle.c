@@ -324,19 +324,12 @@ void orc_dnn3_forward(const orc_dnn3* m, int prec, const float* user_vec, const 
 /*   user tower: u1 = P(relu(chain(ub1; P(u)*P(uw1)))), uo = chain(ub2; u1*P(uw2))  (no act)    */
 /*   item tower: x = concat_f v_f (item fields), same shape via mlp2 (act2 = 0),                */
 /*   score = σ( y_fm + <uo, io> )  with the dot split in two half-chains (see mlp2_dot_row).    */
-void orc_fm2t_forward(const orc_fm2t* m, int prec, const float* const* field_emb,
-                      const float* const* field_lin, const float* user_vec,
-                      const int32_t* user_field_ids, const int32_t* item_field_ids, uint64_t n,
-                      float* out_scores, int threads) {
-    const uint32_t nuf = m->n_user_fields, nif = m->n_item_fields, K = m->k;
-    const uint32_t du = m->d_user, th = m->t_h1, to = m->t_out, din = nif * K;
-    /* user tower */
+/* user tower alone: the user embedding a vector model serves (online_vector_recall.go:97-109)       */
+void orc_fm2t_user_embedding(const orc_fm2t* m, int prec, const float* user_vec, float* uo) {
+    const uint32_t du = m->d_user, th = m->t_h1, to = m->t_out;
     float* uw1 = round_copy(m->uw1, (size_t)du * th, prec);
     float* uw2 = round_copy(m->uw2, (size_t)th * to, prec);
-    float* iw1 = round_copy(m->iw1, (size_t)din * th, prec);
-    float* iw2 = round_copy(m->iw2, (size_t)th * to, prec);
     float* u1 = (float*)malloc(th * sizeof(float));
-    float* uo = (float*)malloc(to * sizeof(float));
     for (uint32_t j = 0; j < th; ++j) u1[j] = m->ub1[j];
     for (uint32_t k = 0; k < du; ++k) {
         const float uv = op_round(user_vec[k], prec);
@@ -346,6 +339,20 @@ void orc_fm2t_forward(const orc_fm2t* m, int prec, const float* const* field_emb
     for (uint32_t o = 0; o < to; ++o) uo[o] = m->ub2[o];
     for (uint32_t j = 0; j < th; ++j)
         for (uint32_t o = 0; o < to; ++o) uo[o] = fmaf(u1[j], uw2[(size_t)j * to + o], uo[o]);
+    free(u1); free(uw2); free(uw1);
+}
+
+void orc_fm2t_forward(const orc_fm2t* m, int prec, const float* const* field_emb,
+                      const float* const* field_lin, const float* user_vec,
+                      const int32_t* user_field_ids, const int32_t* item_field_ids, uint64_t n,
+                      float* out_scores, int threads) {
+    const uint32_t nuf = m->n_user_fields, nif = m->n_item_fields, K = m->k;
+    const uint32_t th = m->t_h1, to = m->t_out, din = nif * K;
+    /* user tower */
+    float* iw1 = round_copy(m->iw1, (size_t)din * th, prec);
+    float* iw2 = round_copy(m->iw2, (size_t)th * to, prec);
+    float* uo = (float*)malloc(to * sizeof(float));
+    orc_fm2t_user_embedding(m, prec, user_vec, uo);
     /* user prefix of the FM sums */
     float linU = m->fm_b;
     float* sU = (float*)calloc(K, sizeof(float));
@@ -389,7 +396,7 @@ void orc_fm2t_forward(const orc_fm2t* m, int prec, const float* const* field_emb
         }
         free(q); free(s); free(hb2); free(hb1); free(x);
     }
-    free(qU); free(sU); free(uo); free(u1); free(iw2); free(iw1); free(uw2); free(uw1);
+    free(qU); free(sU); free(uo); free(iw2); free(iw1);
 }
 
 /* ------------------------------------------------------------------------------------------ */

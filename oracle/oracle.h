@@ -68,6 +68,7 @@ typedef struct {
     const float* iw1; const float* ib1; const float* iw2; const float* ib2; /* item tower  */
 } orc_fm2t;
 /* field_emb: [n_fields] pointers to [vocab][k] tables; field_lin: [n_fields] pointers to [vocab] */
+void orc_fm2t_user_embedding(const orc_fm2t* m, int prec, const float* user_vec, float* uo);
 void orc_fm2t_forward(const orc_fm2t* m, int prec, const float* const* field_emb,
                       const float* const* field_lin, const float* user_vec,
                       const int32_t* user_field_ids, const int32_t* item_field_ids /* [n][nif] */,

@@ -54,6 +54,7 @@ def lib():
         L.orc_dnn3_forward.argtypes = [C.c_void_p, i32, f32p, f32p, u64, f32p, i32]
         L.orc_fm2t_forward.argtypes = [C.c_void_p, i32, C.c_void_p, C.c_void_p, f32p,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64, f32p, i32]
+        L.orc_fm2t_user_embedding.argtypes = [C.c_void_p, i32, f32p, f32p]
         L.orc_f32_to_bf16.restype = C.c_uint16
         L.orc_f32_to_bf16.argtypes = [C.c_float]
         L.orc_bf16_to_f32.restype = C.c_float
@@ -238,6 +239,15 @@ def fm2t_forward(w: Fm2tWeights, prec: int, user_vec, user_field_ids, item_field
                            uf.ctypes.data_as(C.POINTER(C.c_int32)),
                            itf.ctypes.data_as(C.POINTER(C.c_int32)), itf.shape[0], _f32p(out),
                            threads)
+    return out
+
+
+def fm2t_user_embedding(w: Fm2tWeights, prec: int, user_vec) -> np.ndarray:
+    """User-tower output [t_out] — the user embedding of OnlineVectorRecall (online_vector_recall.go:97-109)."""
+    user_vec = np.ascontiguousarray(user_vec, dtype=np.float32)
+    out = np.empty(w.t_out, dtype=np.float32)
+    s = w._struct()
+    lib().orc_fm2t_user_embedding(C.byref(s), prec, _f32p(user_vec), _f32p(out))
     return out
 
 

@@ -196,6 +196,7 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc);
 int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float* d_user,
                          const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items,
                          float* d_out);
+int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_user, uint32_t n_req, float* d_out);
 // d_err: device flags, OR-ed with 1 where an item divides by zero; item i reports into d_err[i / items_per_flag]
 // (items_per_flag = 0: one flag for the call)
 int expr_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items, double* d_out,

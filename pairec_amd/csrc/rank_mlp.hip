@@ -523,6 +523,7 @@ __global__ __launch_bounds__(256) void fm2t_user_kernel(
         for (uint32_t j = 0; j < th; ++j) acc = __fmaf_rn(u1[j], uw2[(size_t)j * to + o], acc);
         uo[(size_t)r * to + o] = acc;
     }
+    if (!user_field_ids) return;                 // embedding only (pg_fm2t_user_embedding)
     if (tid < kFmK) {
         float s = 0.0f, q = 0.0f;
         for (int f = 0; f < kFmFields; ++f) {
@@ -727,6 +728,15 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     return PG_OK;
 }
 
+// user-tower output uo[r][t_out] only: the "user embedding" an EasyRec / TorchRec vector model serves
+int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_user, uint32_t n_req, float* d_out) {
+    if (n_req == 0) return PG_OK;
+    fm2t_user_kernel<<<n_req, 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to,
+                                                     m->prec, nullptr, nullptr, nullptr, m->vocab, m->fm_b, d_out, nullptr);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 static int finish_rank_timing(pg_ctx* ctx) {
     PG_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -899,6 +909,31 @@ int pg_rank_dnn3(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float*
     if ((rc = pg::rank_dnn3_dev_locked(ctx, m, t, d_u, d_c, d_o, n_req, n_items, d_s))) return rc;
     PG_HIP(hipMemcpyAsync(out_scores, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
     return pg::finish_rank_timing(ctx);
+}
+
+int pg_fm2t_user_embedding_dev(pg_ctx* ctx, const pg_model* m, const float* d_user_vecs, uint32_t n_req, float* d_out) {
+    PG_REQUIRE(ctx && m && (n_req == 0 || (d_user_vecs && d_out)), "pg_fm2t_user_embedding_dev: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER, "pg_fm2t_user_embedding_dev: model is not FM_TWOTOWER");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return pg::fm2t_user_embedding_locked(ctx, m, d_user_vecs, n_req, d_out);
+}
+
+int pg_fm2t_user_embedding(pg_ctx* ctx, const pg_model* m, const float* user_vecs, uint32_t n_req, float* out) {
+    PG_REQUIRE(ctx && m && (n_req == 0 || (user_vecs && out)), "pg_fm2t_user_embedding: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER, "pg_fm2t_user_embedding: model is not FM_TWOTOWER");
+    if (n_req == 0) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    int rc;
+    const size_t ub = ((size_t)n_req * m->d_user * 4 + 255) & ~(size_t)255, ob = (size_t)n_req * m->to * 4;
+    if ((rc = pg::scratch_reserve(ctx, 5, ub + ob, &buf))) return rc;
+    float* d_u = (float*)buf;
+    float* d_o = (float*)((char*)buf + ub);
+    PG_HIP(hipMemcpyAsync(d_u, user_vecs, (size_t)n_req * m->d_user * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pg::fm2t_user_embedding_locked(ctx, m, d_u, n_req, d_o))) return rc;
+    PG_HIP(hipMemcpyAsync(out, d_o, ob, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
 }
 
 int pg_rank_fm2t_dev(pg_ctx* ctx, const pg_model* m, const float* d_user_vecs,

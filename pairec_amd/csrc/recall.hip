@@ -2093,6 +2093,73 @@ int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_
     return PG_OK;
 }
 
+// I2IVectorRecall (service/recall/item_2_item_vector_racall.go:51-152): the trigger item's own embedding
+// (dao.VectorString(item_id)) is the query of the same inner-product top-K; the trigger is not excluded (the
+// reference's SQL does not exclude it either).
+int pg_i2i_recall(pg_ctx* ctx, const pg_table* trigger_table, const uint32_t* trigger_rows, uint32_t n,
+                  const pg_table* t, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
+    PG_REQUIRE(ctx && trigger_table && t && trigger_rows && out_rows && out_scores, "pg_i2i_recall: NULL argument");
+    PG_REQUIRE(trigger_table->dim == t->dim, "pg_i2i_recall: trigger table dim %u != searched table dim %u", trigger_table->dim, t->dim);
+    PG_REQUIRE(n >= 1 && n <= (uint32_t)pg::kMaxQueries && (t->dim <= 128 || n <= 32), "pg_i2i_recall: %u trigger items per call unsupported", n);
+    if (k < 1 || k > 16384) {
+        pg::set_error("pg_i2i_recall: k=%u unsupported (1..16384)", k);
+        return PG_ERR_UNSUPPORTED;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        PG_REQUIRE(trigger_rows[i] < trigger_table->rows, "pg_i2i_recall: trigger row %u outside table of %llu rows", trigger_rows[i],
+                   (unsigned long long)trigger_table->rows);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    int rc;
+    const size_t qb = (size_t)n * t->dim * 4, rb = (size_t)n * k * 8, sb = (size_t)n * k * 4;
+    if ((rc = pg::scratch_reserve(ctx, 5, qb + rb + sb + 64, &buf))) return rc;
+    float* d_q = (float*)buf;
+    uint64_t* d_rows = (uint64_t*)((char*)buf + ((qb + 15) & ~(size_t)15));
+    float* d_sc = (float*)((char*)d_rows + rb);
+    // the trigger rows are few: one small device-to-device copy each (coalesced 512-B rows)
+    for (uint32_t i = 0; i < n; ++i)
+        PG_HIP(hipMemcpyAsync(d_q + (size_t)i * t->dim, trigger_table->d + (size_t)trigger_rows[i] * t->dim, (size_t)t->dim * 4,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = pg::recall_dev_locked(ctx, t, d_q, n, k, d_rows, d_sc, out_count, nullptr))) return rc;
+    PG_HIP(hipMemcpyAsync(out_rows, d_rows, rb, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(out_scores, d_sc, sb, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+// OnlineVectorRecall (service/recall/online_vector_recall.go:73-155): the model server turns the user's features
+// into the user-tower embedding and answers with its FaissNeighNum nearest items (match_item_scores + item_ids,
+// algorithm/eas/easyrec_response.go:700-734).  Here: user tower of the two-tower model on the device, then the
+// same exact inner-product top-K over the item-embedding table (dim = the towers' output width).
+int pg_online_vector_recall(pg_ctx* ctx, const pg_model* m, const pg_table* item_emb, const float* user_vecs,
+                            uint32_t n_req, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
+    PG_REQUIRE(ctx && m && item_emb && user_vecs && out_rows && out_scores, "pg_online_vector_recall: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER, "pg_online_vector_recall: model is not FM_TWOTOWER");
+    PG_REQUIRE(item_emb->dim == m->to, "pg_online_vector_recall: item-embedding table dim %u != tower output %u", item_emb->dim, m->to);
+    PG_REQUIRE(n_req >= 1 && n_req <= (uint32_t)pg::kMaxQueries, "pg_online_vector_recall: n_req=%u must be in [1,%d]", n_req, pg::kMaxQueries);
+    if (k < 1 || k > 16384) {
+        pg::set_error("pg_online_vector_recall: k=%u unsupported (1..16384)", k);
+        return PG_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    int rc;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t ub = al((size_t)n_req * m->d_user * 4), qb = al((size_t)n_req * m->to * 4), rb = (size_t)n_req * k * 8, sb = (size_t)n_req * k * 4;
+    if ((rc = pg::scratch_reserve(ctx, 5, ub + qb + rb + sb + 64, &buf))) return rc;
+    float* d_u = (float*)buf;
+    float* d_q = (float*)((char*)buf + ub);
+    uint64_t* d_rows = (uint64_t*)((char*)buf + ub + qb);
+    float* d_sc = (float*)((char*)d_rows + rb);
+    PG_HIP(hipMemcpyAsync(d_u, user_vecs, (size_t)n_req * m->d_user * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pg::fm2t_user_embedding_locked(ctx, m, d_u, n_req, d_q))) return rc;
+    if ((rc = pg::recall_dev_locked(ctx, item_emb, d_q, n_req, k, d_rows, d_sc, out_count, nullptr))) return rc;
+    PG_HIP(hipMemcpyAsync(out_rows, d_rows, rb, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(out_scores, d_sc, sb, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
 int pg_topk_merge_dev(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq,
                       uint32_t nlists, uint32_t per_list, uint32_t k, uint64_t* d_out_rows,
                       float* d_out_scores) {

@@ -161,6 +161,17 @@ class Table:
                                                  _ptr(r_), _ptr(s_), _ptr(c_)))
         return rows, scores, counts
 
+    def i2i_recall(self, trigger_rows, k: int, trigger_table: Optional["Table"] = None):
+        """I2IVectorRecall: rows of `trigger_table` (default: this table) are the queries."""
+        tr = np.ascontiguousarray(trigger_rows, dtype=np.uint32)
+        n = tr.shape[0]
+        rows = np.empty((n, k), dtype=np.uint64)
+        scores = np.empty((n, k), dtype=np.float32)
+        counts = np.zeros(n, dtype=np.uint32)
+        _lib.check(self.ctx.L.pg_i2i_recall(self.ctx.h, (trigger_table or self).h, _ptr(tr), n, self.h, k,
+                                            _ptr(rows), _ptr(scores), _ptr(counts)))
+        return rows, scores, counts
+
     def recall_topk_dev(self, d_queries: int, nq: int, k: int, d_out_rows: int, d_out_scores: int):
         counts = np.zeros(nq, dtype=np.uint32)
         _lib.check(self.ctx.L.pg_recall_topk_dev(self.ctx.h, self.h, C.c_void_p(d_queries), nq, k,
@@ -196,6 +207,7 @@ class RankModel:
 
     def __init__(self, ctx: Context, kind: int, prec: int, blob: bytes):
         self.ctx, self.kind, self.prec = ctx, kind, prec
+        self._blob_head = bytes(blob[:28])
         h = C.c_void_p()
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
         _lib.check(ctx.L.pg_model_load(ctx.h, kind, prec, buf, len(blob), C.byref(h)))
@@ -232,6 +244,27 @@ class RankModel:
                                            _ptr(ro), ro.shape[0] - 1, _ptr(out)))
         return out
 
+
+    def user_embedding(self, user_vecs: np.ndarray) -> np.ndarray:
+        """Two-tower user embedding [n][t_out] (pg_fm2t_user_embedding)."""
+        u = np.ascontiguousarray(user_vecs, dtype=np.float32)
+        u = u.reshape(-1, u.shape[-1])
+        hdr = struct.unpack("<7I", self._blob_head)
+        out = np.empty((u.shape[0], hdr[5]), dtype=np.float32)
+        _lib.check(self.ctx.L.pg_fm2t_user_embedding(self.ctx.h, self.h, _ptr(u), u.shape[0], _ptr(out)))
+        return out
+
+    def online_vector_recall(self, item_emb: Table, user_vecs: np.ndarray, k: int):
+        """OnlineVectorRecall: user tower → top-k of the item-embedding table."""
+        u = np.ascontiguousarray(user_vecs, dtype=np.float32)
+        u = u.reshape(-1, u.shape[-1])
+        n = u.shape[0]
+        rows = np.empty((n, k), dtype=np.uint64)
+        scores = np.empty((n, k), dtype=np.float32)
+        counts = np.zeros(n, dtype=np.uint32)
+        _lib.check(self.ctx.L.pg_online_vector_recall(self.ctx.h, self.h, item_emb.h, _ptr(u), n, k, _ptr(rows),
+                                                      _ptr(scores), _ptr(counts)))
+        return rows, scores, counts
 
     def rank_fm2t_rows(self, feats: "Features", item_field_names, user_vecs, user_field_ids, cand_rows,
                        req_offsets) -> np.ndarray:

@@ -1,0 +1,94 @@
+"""GPU tests of the composed recalls and of BASELINE.json's configs[0] / configs[3]
+at their stated sizes, through the C ABI against the CPU oracle."""
+import numpy as np
+import pytest
+
+import pairec_amd as pa
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def test_i2i_vector_recall_matches_oracle(ctx):
+    """I2IVectorRecall (item_2_item_vector_racall.go:51-152): the trigger item's embedding is the query; the
+    trigger itself comes back first (its own inner product is the largest for normalised rows) and is not
+    excluded, as in the reference's SQL."""
+    n, d, k = 120_000, 128, 50
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    trig = np.array([5, 99_999, 31_337], dtype=np.uint32)
+    rows, scores, cnt = t.i2i_recall(trig, k)
+    orow, osc = o.recall_topk(tab, tab[trig], k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc)) and cnt.tolist() == [k] * 3
+    assert rows[:, 0].tolist() == trig.tolist()
+    with pytest.raises(pa._lib.PgError):
+        t.i2i_recall(np.array([n], dtype=np.uint32), k)
+    t.destroy()
+
+
+@pytest.mark.parametrize("prec,tol", [(pa.PREC_F32, 0.0), (pa.PREC_BF16, 0.0)])
+def test_online_vector_recall_matches_oracle(ctx, prec, tol):
+    """OnlineVectorRecall (online_vector_recall.go:73-155): user features → user tower → k nearest items of the
+    item-embedding table.  The user tower is a sequential fmaf chain in both modes (bit-defined), so the embedding,
+    the ids, the order and the scores all match the oracle exactly."""
+    n, k, R = 200_000, 300, 5
+    fw = o.Fm2tWeights(vocab=1000)
+    m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, prec, pa.pack_fm2t(fw))
+    emb = pa.Table(ctx, n, 64)                          # the item tower's outputs, as served by the vector index
+    emb.fill_synthetic(o.SEED_TABLE ^ 0x77)
+    tab = o.synth_rows(o.SEED_TABLE ^ 0x77, 0, n, 64)
+    users = o.synth_rows(o.SEED_QUERY, 40, R, 128)
+    ue = m.user_embedding(users)
+    ref_ue = np.stack([o.fm2t_user_embedding(fw, prec, users[r]) for r in range(R)])
+    assert np.array_equal(bits(ue), bits(ref_ue))
+    rows, scores, cnt = m.online_vector_recall(emb, users, k)
+    orow, osc = o.recall_topk(tab, ref_ue, k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc)) and cnt.tolist() == [k] * R
+    emb.destroy()
+    m.destroy()
+
+
+def test_cfg1_full_size_recall_and_item_score_sort(ctx):
+    """BASELINE.json configs[0] at its own size: 1M x 64, top-200, then sort.item_score (ASCENDING,
+    sort/item_score.go:36-41) — ids, order and score bits equal the oracle's."""
+    n, d, k, R = 1_000_000, 64, 200, 16
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    q = o.synth_rows(o.SEED_QUERY, 0, R, d)
+    rows, scores, cnt = t.recall_topk(q, k)
+    orow, osc = o.recall_topk(tab, q, k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+    one = t.recall_topk(q[3:4], k)                      # one request per pass gives the same answer
+    assert np.array_equal(one[0][0], orow[3]) and np.array_equal(bits(one[1][0]), bits(osc[3]))
+    off = (np.arange(R + 1) * k).astype(np.uint32)
+    order = ctx.sort_scores(scores.reshape(-1).astype(np.float64), off, descending=False)
+    for r in range(R):
+        assert np.array_equal(order[off[r]:off[r + 1]], o.sort_scores(osc[r].astype(np.float64), False))
+    t.destroy()
+
+
+def test_cfg4_fm_twotower_with_million_row_field_tables(ctx):
+    """BASELINE.json configs[3] with SURVEY.md 8d's field tables (8 + 8 fields x 1M rows x k=16): 5000 candidates
+    of 4 requests, ids spread over the whole vocabulary."""
+    vocab, R, K = 1_000_000, 4, 5000
+    fw = o.Fm2tWeights(vocab=vocab)
+    rng = np.random.default_rng(11)
+    users = o.synth_rows(o.SEED_QUERY, 0, R, 128)
+    ufids = rng.integers(0, vocab, (R, 8)).astype(np.int32)
+    ifids = rng.integers(0, vocab, (R * K, 8)).astype(np.int32)
+    ifids[0] = vocab - 1                                 # last row of every field table
+    ifids[1] = 0
+    off = (np.arange(R + 1) * K).astype(np.uint32)
+    for prec, tol in ((pa.PREC_F32, 2e-7), (pa.PREC_BF16, 1e-5)):
+        m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, prec, pa.pack_fm2t(fw))
+        got = m.rank_fm2t(users, ufids, ifids, off)
+        for r in range(R):
+            ref = o.fm2t_forward(fw, prec, users[r], ufids[r], ifids[off[r]:off[r + 1]])
+            assert np.max(np.abs(got[off[r]:off[r + 1]].astype(np.float64) - ref)) <= tol
+        m.destroy()
