@@ -206,6 +206,28 @@ int pg_dpp(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const doub
            double alpha, uint32_t topn, uint32_t window, int normalize_emb, uint32_t* out_idx,
            uint32_t* out_count);
 
+/* The same with every switch of DPPSort.KernelMatrix (sort/dpp_sort.go:372-475):
+ *   norm_relevance_score  the dpp_norm_relevance_score experiment parameter (:382-405): 0 none, 1 z-score
+ *                         (stat.PopMeanVariance / StdScore), 2 min-max into [1e-6, 1] with max = first, min = last
+ *                         candidate.  When the reference bails out ("all item score is zero") the call returns
+ *                         PG_ERR_ARITH and the caller keeps the items unchanged, as DPPSort.doSort does.
+ *   has_table = 1         embeddings are rows of `t` (DPPSortConfig.TableName set), L2-normalised when normalize_emb;
+ *                         hook_emb (optional, [n][hook_dim] fp64: what the functions registered with
+ *                         RegisterEmbeddingHook return, :52-58,362) is prepended and the row re-normalised (:419-421);
+ *                         always followed by "append 1, scale 1/sqrt 2" (:428-430).
+ *   has_table = 0         hook embeddings only (:434-447): normalised when normalize_emb; ensure_pos_similarity
+ *                         (DPPSortConfig.EnsurePositiveSim) appends 1 and scales by 1/sqrt 2, otherwise appends 0.
+ * out_relevance (optional, [n]) receives the relevance scores as used ("dpp_relevance_score", :410). */
+typedef struct {
+    double   alpha;
+    uint32_t topn, window;
+    int      normalize_emb, ensure_pos_similarity, norm_relevance_score, has_table;
+    uint32_t hook_dim;
+} pg_dpp_options;
+int pg_dpp_ex(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const double* rel, uint32_t n,
+              const pg_dpp_options* opt, const double* hook_emb, uint32_t* out_idx, uint32_t* out_count,
+              double* out_relevance);
+
 /* ---- SSD diversity re-rank -------------------------------------------------------------------
  * Replaces SSDSort.SSDWithSlidingWindow (sort/ssd_sort.go:346-486) and the embedding treatment of
  * loadEmbeddingCache (:246-252).  Candidates are rows of `t`, given in score-descending order as
@@ -279,6 +301,37 @@ int pg_recommend_dnn3_begin(pg_ctx* ctx, const pg_table* t, const pg_model* m, c
                             uint32_t* d_out_order, uint32_t* d_out_count, pg_ticket** out);
 /* scan_ms (optional): the batch's scan-stage launches, HIP-event timed (what pg_last_scan_kernel_ms reports) */
 int pg_recommend_end(pg_ctx* ctx, pg_ticket* ticket, double* scan_ms);
+
+/* ---- shard group: one process, several GPUs --------------------------------------------------------
+ * BASELINE.json configs[4] / SURVEY.md 8e behind the C ABI (a cgo host cannot join a torch.distributed job): the item
+ * table in contiguous row ranges [g*N/G, (g+1)*N/G), one context per shard, model weights replicated.  devices[] may
+ * name one device several times (logical shards on one GPU: tests).  Peer access is enabled between distinct
+ * devices; the two exchanges of a step (per-shard top-k lists; owners' rank scores and DPP embeddings) are direct
+ * peer stores ordered by HIP events — no collective library, no host synchronisation inside a step. */
+typedef struct pg_group pg_group;
+int pg_group_create(const int* devices, uint32_t n_shards, pg_group** out);
+int pg_group_destroy(pg_group* g);
+uint32_t pg_group_size(const pg_group* g);
+pg_ctx* pg_group_ctx(pg_group* g, uint32_t shard);
+pg_table* pg_group_table(pg_group* g, uint32_t shard);
+int pg_group_table_create(pg_group* g, uint64_t total_rows, uint32_t dim);
+int pg_group_table_fill_synthetic(pg_group* g, uint64_t seed, int normalize);
+int pg_group_table_upload(pg_group* g, uint64_t row0, uint64_t nrows, const float* host_rows);   /* global rows */
+int pg_group_model_load(pg_group* g, pg_model_kind kind, pg_prec prec, const void* blob, size_t len);
+typedef struct {
+    uint32_t k;                /* recall depth (RecallCount) */
+    uint32_t dpp_candidates;   /* DPPSortConfig.CandidateCount; 0 = no DPP stage (the page is the head of the sorted list) */
+    double   dpp_alpha;        /* DPPSortConfig.Alpha */
+    uint32_t dpp_window;       /* DPPSortConfig.WindowSize (0 = 10) */
+    int      dpp_normalize_emb;
+} pg_group_plan;
+/* nq requests through sharded recall → merge → owner-computes DNN3 rank → RankScore → ItemRankScore sort → DPPSort on
+ * the first max(top_n, dpp_candidates) entries (sort/dpp_sort.go:271-351; ctx.Size = top_n).  Outputs [nq][top_n] in
+ * page order: global row ids, recall / model / fused scores; out_count[q] (optional) = entries that are items.
+ * Results are identical to the single-shard path (pg_recommend_dnn3_dev + pg_dpp on one table). */
+int pg_group_recommend(pg_group* g, const pg_expr* e, const char* rank_var, const pg_group_plan* plan,
+                       const float* user_vecs, uint32_t nq, uint32_t top_n, uint64_t* out_rows,
+                       float* out_recall_scores, float* out_rank_scores, double* out_fused, uint32_t* out_count);
 
 /* ---- request coalescer --------------------------------------------------------------------------
  * The reference calls its plug-ins once per request from many goroutines at once: one IAlgorithm.Run per recall

@@ -464,6 +464,23 @@ void orc_dpp_kernel_matrix(const double* emb, uint32_t n, uint32_t d, const doub
     free(r); free(F);
 }
 
+/* The same from finished feature rows F [n][d1] (KernelMatrix's featureMat, dpp_sort.go:407-461): covers the     */
+/* hook-embedding and EnsurePositiveSim = false variants, whose rows are built by oracle.py:dpp_features.         */
+void orc_dpp_kernel_matrix_f(const double* F, uint32_t n, uint32_t d1, const double* rel, double alpha, double* L) {
+    double* r = (double*)malloc((size_t)n * sizeof(double));
+    for (uint32_t i = 0; i < n; ++i) r[i] = exp(alpha * rel[i]);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < (int32_t)n; ++i)
+        for (uint32_t j = 0; j < n; ++j) {
+            double s = 0.0;
+            const double* a = F + (size_t)i * d1;
+            const double* b = F + (size_t)j * d1;
+            for (uint32_t k = 0; k < d1; ++k) s = fma(a[k], b[k], s);
+            L[(size_t)i * n + j] = (r[i] * s) * r[j];
+        }
+    free(r);
+}
+
 static int idx_in(const uint32_t* a, uint32_t n, uint32_t e) {
     for (uint32_t i = 0; i < n; ++i) if (a[i] == e) return 1;
     return 0;

@@ -84,6 +84,7 @@ void orc_sort_scores(const double* scores, uint32_t n, int desc, uint32_t* out_o
  * rel: relevance scores; returns selected indices (count = min(topn, n)). */
 void orc_dpp_kernel_matrix(const double* emb, uint32_t n, uint32_t d, const double* rel,
                            double alpha, double* L /* [n][n] */);
+void orc_dpp_kernel_matrix_f(const double* F, uint32_t n, uint32_t d1, const double* rel, double alpha, double* L);
 uint32_t orc_dpp_with_window(const double* L, uint32_t n, uint32_t topn, uint32_t window,
                              uint32_t* out_idx);
 

@@ -62,6 +62,8 @@ def lib():
         L.orc_sort_scores.argtypes = [C.POINTER(C.c_double), u32, i32, C.POINTER(u32)]
         L.orc_dpp_kernel_matrix.argtypes = [C.POINTER(C.c_double), u32, u32, C.POINTER(C.c_double),
                                             C.c_double, C.POINTER(C.c_double)]
+        L.orc_dpp_kernel_matrix_f.argtypes = [C.POINTER(C.c_double), u32, u32, C.POINTER(C.c_double), C.c_double,
+                                              C.POINTER(C.c_double)]
         L.orc_dpp_with_window.restype = u32
         L.orc_dpp_with_window.argtypes = [C.POINTER(C.c_double), u32, u32, u32, C.POINTER(u32)]
         L.orc_l2_normalize_f64.argtypes = [C.POINTER(C.c_double), u32]
@@ -287,6 +289,53 @@ def dpp_kernel_matrix(emb: np.ndarray, rel: np.ndarray, alpha: float) -> np.ndar
     n, d = emb.shape
     L = np.empty((n, n), dtype=np.float64)
     lib().orc_dpp_kernel_matrix(_f64p(emb), n, d, _f64p(rel), alpha, _f64p(L))
+    return L
+
+
+def dpp_relevance(rel: np.ndarray, mode: int):
+    """dpp_norm_relevance_score (dpp_sort.go:382-405): the same two normalisations SSDSort applies to its quality
+    scores (z-score by stat.PopMeanVariance / StdScore; min-max with max = first, min = last item).
+    Returns (scores, ok); ok False = "all item score is zero" (the reference returns the items unchanged)."""
+    return ssd_quality(rel, mode)
+
+
+def dpp_features(emb32, hook, normalize: bool, ensure_pos_similarity: bool) -> np.ndarray:
+    """KernelMatrix's feature rows (dpp_sort.go:408-447).  emb32 [n][d] fp32 item embeddings (the table path;
+    None = hook embeddings only), hook [n][h] fp64 (RegisterEmbeddingHook outputs; None = none).
+    Table path: e = emb (L2-normalised when `normalize`, loadEmbeddingCache :235-236); with hooks the row is
+    [hook ‖ e] re-normalised jointly (:419-421); then append 1 and scale by 1/sqrt 2 (:428-430, EnsurePositiveSim
+    is not consulted).  Hook-only path (:434-447): normalise when asked; ensure_pos → [c,1]/sqrt 2, else [c,0]."""
+    isq2 = 0.70710678118654757
+    has_table = emb32 is not None
+    n = (emb32 if has_table else hook).shape[0]
+    rows = []
+    for i in range(n):
+        c = [] if hook is None else [float(x) for x in np.asarray(hook[i], dtype=np.float64)]
+        if has_table:
+            e = np.asarray(emb32[i], dtype=np.float32).astype(np.float64)
+            if normalize:
+                e = l2_normalize_f64(e[None])[0]
+            c = c + [float(x) for x in e]
+            renorm = hook is not None
+        else:
+            renorm = normalize
+        c = np.array(c, dtype=np.float64)
+        if renorm:
+            c = l2_normalize_f64(c[None])[0]
+        if has_table or ensure_pos_similarity:
+            c = np.concatenate([c * isq2, [isq2 * 1.0]])
+        else:
+            c = np.concatenate([c, [0.0]])
+        rows.append(c)
+    return np.ascontiguousarray(np.stack(rows))
+
+
+def dpp_kernel_matrix_f(F: np.ndarray, rel: np.ndarray, alpha: float) -> np.ndarray:
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    rel = np.ascontiguousarray(rel, dtype=np.float64)
+    n, d1 = F.shape
+    L = np.empty((n, n), dtype=np.float64)
+    lib().orc_dpp_kernel_matrix_f(_f64p(F), n, d1, _f64p(rel), alpha, _f64p(L))
     return L
 
 

@@ -24,10 +24,12 @@ EXPORTS = [
     "pg_hbm_read_probe", "pg_table_screen_info", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
     "pg_features_column_index", "pg_features_num_columns", "pg_features_gather_i32_dev",
     "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev", "pg_recommend_dnn3_dev", "pg_set_option",
-    "pg_table_fill_gaussian", "pg_i2i_recall", "pg_online_vector_recall", "pg_fm2t_user_embedding",
+    "pg_table_fill_gaussian", "pg_dpp_ex", "pg_i2i_recall", "pg_online_vector_recall", "pg_fm2t_user_embedding",
     "pg_fm2t_user_embedding_dev", "pg_recommend_dnn3_begin", "pg_recommend_end",
     "pg_coalescer_create", "pg_coalescer_destroy", "pg_coalescer_recall", "pg_coalescer_rank_dnn3",
     "pg_coalescer_recommend", "pg_coalescer_stats",
+    "pg_group_create", "pg_group_destroy", "pg_group_size", "pg_group_ctx", "pg_group_table", "pg_group_table_create",
+    "pg_group_table_fill_synthetic", "pg_group_table_upload", "pg_group_model_load", "pg_group_recommend",
 ]
 
 
@@ -37,6 +39,17 @@ class PgStats(C.Structure):
                 ("rank_items", C.c_uint64), ("sort_calls", C.c_uint64), ("sort_items", C.c_uint64),
                 ("last_recall_ms", C.c_double), ("last_rank_ms", C.c_double),
                 ("last_sort_ms", C.c_double)]
+
+
+class PgDppOptions(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("topn", C.c_uint32), ("window", C.c_uint32), ("normalize_emb", C.c_int),
+                ("ensure_pos_similarity", C.c_int), ("norm_relevance_score", C.c_int), ("has_table", C.c_int),
+                ("hook_dim", C.c_uint32)]
+
+
+class PgGroupPlan(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("dpp_candidates", C.c_uint32), ("dpp_alpha", C.c_double),
+                ("dpp_window", C.c_uint32), ("dpp_normalize_emb", C.c_int)]
 
 
 class PgCoalescerConfig(C.Structure):
@@ -99,6 +112,7 @@ def load():
         "pg_sort_scores": [vp, vp, vp, u32, i32, vp],
         "pg_sort_scores_dev": [vp, vp, vp, u32, u32, u32, i32, vp],
         "pg_dpp": [vp, vp, vp, vp, u32, C.c_double, u32, u32, i32, vp, vp],
+        "pg_dpp_ex": [vp, vp, vp, vp, u32, P(PgDppOptions), vp, vp, vp, vp],
         "pg_ssd": [vp, vp, vp, vp, u32, C.c_double, u32, u32, i32, i32, i32, i32, vp, vp, vp],
         "pg_features_create": [vp, u64, P(vp)],
         "pg_features_destroy": [vp, vp],
@@ -123,6 +137,13 @@ def load():
         "pg_coalescer_rank_dnn3": [vp, vp, vp, u32, vp],
         "pg_coalescer_recommend": [vp, vp, u32, vp, vp, vp, vp, P(u32)],
         "pg_coalescer_stats": [vp, P(PgCoalescerStats)],
+        "pg_group_create": [P(C.c_int), u32, P(vp)],
+        "pg_group_destroy": [vp],
+        "pg_group_table_create": [vp, u64, u32],
+        "pg_group_table_fill_synthetic": [vp, u64, i32],
+        "pg_group_table_upload": [vp, u64, u64, vp],
+        "pg_group_model_load": [vp, i32, i32, vp, sz],
+        "pg_group_recommend": [vp, vp, C.c_char_p, P(PgGroupPlan), vp, u32, u32, vp, vp, vp, vp, vp],
         "pg_rows_to_local_dev": [vp, vp, vp, u32, vp, vp],
         "pg_widen_f32_dev": [vp, vp, u32, vp],
         "pg_stats": [vp, P(PgStats)],
@@ -138,6 +159,12 @@ def load():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i32
+    L.pg_group_size.argtypes = [vp]
+    L.pg_group_size.restype = u32
+    L.pg_group_ctx.argtypes = [vp, u32]
+    L.pg_group_ctx.restype = vp
+    L.pg_group_table.argtypes = [vp, u32]
+    L.pg_group_table.restype = vp
     L.pg_expr_var_name.argtypes = [vp, i32]
     L.pg_expr_var_name.restype = C.c_char_p
     _lib = L

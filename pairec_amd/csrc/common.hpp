@@ -191,6 +191,9 @@ int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, u
 int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap, uint32_t nq, uint32_t k,
                  uint64_t row_offset, uint64_t* d_out_rows, float* d_out_scores, uint32_t* d_out_count);
 int ensure_table_stats(pg_ctx* ctx, const pg_table* tc);
+int topk_merge_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
+                      uint32_t per_list, int list_major, uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
+                      uint32_t* d_out_count);
 
 // ---- stage launchers shared with pipeline.hip (caller holds ctx->mu; nothing synchronises) -------------------
 int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float* d_user,
@@ -202,6 +205,10 @@ int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_us
 int expr_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items, double* d_out,
                              uint32_t* d_err, uint32_t items_per_flag);
 void set_expr_arith_error(const pg_expr* e);
+int table_gather_locked(pg_ctx* ctx, const pg_table* t, const uint32_t* d_rows, uint32_t n, float* d_out);
+int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, const double* d_rel, uint32_t R, uint32_t n,
+                   uint32_t d, uint32_t hook_dim, double alpha, uint32_t topn, uint32_t window, int normalize,
+                   int ensure_pos, int has_table, uint32_t* d_out, uint32_t* d_out_count);
 int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg, uint32_t n_items,
                     uint32_t max_seg, int desc, uint32_t* d_out);
 

@@ -14,51 +14,85 @@
 // gonum's Dgemm-by-axpy does on amd64, and is bit-identical to oracle/oracle.c given the same L.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <vector>
 
 namespace pg {
 
-// one thread per candidate: gather the fp32 embedding, widen, optionally L2-normalise
-// (floats.Norm / floats.Scale(1/norm), dpp_sort.go:235-236), build F row and r_i.
-__global__ void dpp_prepare_kernel(const float* __restrict__ tab, uint32_t tab_rows, uint32_t d,
-                                   const uint32_t* __restrict__ cand, const double* __restrict__ rel,
-                                   uint32_t n, double alpha, int normalize, double* __restrict__ F,
-                                   double* __restrict__ r) {
+// Feature rows, one thread per candidate of one request (blockIdx.y = request), following KernelMatrix
+// (dpp_sort.go:408-447):
+//   table path (has_table): e = item embedding, L2-normalised when normalize (loadEmbeddingCache :235-236:
+//     floats.Norm / floats.Scale(1/norm)); with hook embeddings (RegisterEmbeddingHook, :362,413) the row is
+//     [hook ‖ e] re-normalised jointly (:419-421); then "append 1, scale 1/√2" (:428-430) — EnsurePositiveSim is
+//     not consulted on this path in the reference;
+//   hook-only path: c = hook, normalised when normalize (:437-440); ensure_pos → [c,1]/√2, else [c,0] unscaled (:441-446).
+// r_i = exp(alpha * relevance_i) (:431).  emb32 rows are fp32 [R][n][d]; hook rows fp64 [R][n][hook_dim].
+struct DppPrep {
+    const float* emb32;
+    const double* hook;
+    const double* rel;
+    uint32_t n, d, hook_dim;
+    double alpha;
+    int normalize, ensure_pos, has_table;
+    double* F;       // [R][n][d1]
+    double* r;       // [R][n]
+};
+__global__ void dpp_prepare_kernel(DppPrep a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t row = cand[i];
-    row = row < tab_rows ? row : tab_rows - 1;
-    const float* x = tab + (size_t)row * d;
-    double inv = 1.0;
-    if (normalize) {
-        double ss = 0.0;
-        for (uint32_t k = 0; k < d; ++k) {
-            const double v = (double)x[k];
-            ss = fma(v, v, ss);
-        }
-        inv = 1.0 / sqrt(ss);
-    }
+    const uint32_t q = blockIdx.y;
+    if (i >= a.n) return;
+    const uint32_t dt = a.has_table ? a.d : 0u;
+    const uint32_t w = a.hook_dim + dt;            // feature width before the appended constant
+    const uint32_t d1 = w + 1;
+    const size_t item = (size_t)q * a.n + i;
+    double* f = a.F + item * d1;
     const double isq2 = 0.70710678118654757;      // Go constant 1/math.Sqrt2
-    double* f = F + (size_t)i * (d + 1);
-    for (uint32_t k = 0; k < d; ++k) {
-        double v = (double)x[k];
-        if (normalize) v = inv * v;
-        f[k] = isq2 * v;
+    // stage the row in F itself: [hook ‖ e]
+    for (uint32_t k = 0; k < a.hook_dim; ++k) f[k] = a.hook[item * a.hook_dim + k];
+    if (a.has_table) {
+        const float* x = a.emb32 + item * a.d;
+        double inv = 1.0;
+        if (a.normalize) {
+            double ss = 0.0;
+            for (uint32_t k = 0; k < a.d; ++k) {
+                const double v = (double)x[k];
+                ss = fma(v, v, ss);
+            }
+            inv = 1.0 / sqrt(ss);
+        }
+        for (uint32_t k = 0; k < a.d; ++k) {
+            const double v = (double)x[k];
+            f[a.hook_dim + k] = a.normalize ? inv * v : v;
+        }
     }
-    f[d] = isq2 * 1.0;
-    r[i] = exp(alpha * rel[i]);
+    const bool renorm = a.has_table ? a.hook_dim > 0 : a.normalize != 0;
+    if (renorm) {
+        double ss = 0.0;
+        for (uint32_t k = 0; k < w; ++k) ss = fma(f[k], f[k], ss);
+        const double inv = 1.0 / sqrt(ss);
+        for (uint32_t k = 0; k < w; ++k) f[k] = inv * f[k];
+    }
+    if (a.has_table || a.ensure_pos) {
+        for (uint32_t k = 0; k < w; ++k) f[k] = isq2 * f[k];
+        f[w] = isq2 * 1.0;
+    } else {
+        f[w] = 0.0;
+    }
+    a.r[item] = exp(a.alpha * a.rel[item]);
 }
 
 __global__ void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
                                          uint32_t n, uint32_t d1, double* __restrict__ L) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = blockIdx.y;
+    const uint32_t q = blockIdx.z;
     if (j >= n) return;
-    const double* a = F + (size_t)i * d1;
-    const double* b = F + (size_t)j * d1;
+    const double* a = F + ((size_t)q * n + i) * d1;
+    const double* b = F + ((size_t)q * n + j) * d1;
     double s = 0.0;
     for (uint32_t k = 0; k < d1; ++k) s = fma(a[k], b[k], s);
-    L[(size_t)i * n + j] = __dmul_rn(__dmul_rn(r[i], s), r[j]);
+    L[((size_t)q * n + i) * n + j] = __dmul_rn(__dmul_rn(r[(size_t)q * n + i], s), r[(size_t)q * n + j]);
 }
 
 // floats.MaxIdx: first maximum, NaN skipped; all-NaN → index 0.  Block-wide, result in *s_idx.
@@ -94,10 +128,17 @@ __device__ __forceinline__ void block_argmax(const double* __restrict__ v, uint3
 
 // DPPWithWindow + DPP (dpp_sort.go:477-551), one workgroup.
 //   d2: [n], c: [window][n] scratch in global memory (L2-resident), Y: output indices.
-__global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restrict__ L, uint32_t N,
+//   One workgroup per request (blockIdx.x): L, d2, c, out are that request's slices.
+__global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restrict__ L_all, uint32_t N,
                                                           uint32_t topn_total, uint32_t window,
-                                                          double* __restrict__ d2, double* __restrict__ c,
-                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ out_count) {
+                                                          double* __restrict__ d2_all, double* __restrict__ c_all,
+                                                          uint32_t* __restrict__ out_all, uint32_t* __restrict__ out_count) {
+    const uint32_t req = blockIdx.x;
+    const uint32_t wrows = window < N ? window : N;
+    const double* __restrict__ L = L_all + (size_t)req * N * N;
+    double* __restrict__ d2 = d2_all + (size_t)req * N;
+    double* __restrict__ c = c_all + (size_t)req * wrows * N;
+    uint32_t* __restrict__ out = out_all + (size_t)req * topn_total;
     __shared__ double s_val[1024];
     __shared__ uint32_t s_idx[1024];
     __shared__ uint32_t s_j;
@@ -172,53 +213,130 @@ __global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restri
         done += ny;
         __syncthreads();
     }
-    if (tid == 0) *out_count = done;
+    if (tid == 0) out_count[req] = done;
+}
+
+// DPP for R independent requests of n candidates each, device-resident: d_emb32 [R][n][d] fp32 (NULL on the
+// hook-only path), d_hook [R][n][hook_dim] fp64 (or NULL), d_rel [R][n] relevance scores as KernelMatrix uses
+// them (already normalised when dpp_norm_relevance_score is on); d_out [R][topn] candidate indices, d_out_count [R].
+// Caller holds ctx->mu; nothing synchronises.
+int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, const double* d_rel, uint32_t R, uint32_t n,
+                   uint32_t d, uint32_t hook_dim, double alpha, uint32_t topn, uint32_t window, int normalize,
+                   int ensure_pos, int has_table, uint32_t* d_out, uint32_t* d_out_count) {
+    if (R == 0 || n == 0 || topn == 0) return PG_OK;
+    if (window == 0) window = 10;                        // NewDPPSort default (dpp_sort.go:89-91)
+    const uint32_t d1 = hook_dim + (has_table ? d : 0u) + 1;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t bF = al((size_t)R * n * d1 * 8), bR = al((size_t)R * n * 8), bL = al((size_t)R * n * n * 8);
+    const size_t bD2 = al((size_t)R * n * 8), bC = al((size_t)R * std::min(window, n) * n * 8);
+    void* buf;
+    int rc;
+    if ((rc = scratch_reserve(ctx, 7, bF + bR + bL + bD2 + bC, &buf))) return rc;
+    char* p = (char*)buf;
+    double* F = (double*)p; p += bF;
+    double* Rr = (double*)p; p += bR;
+    double* L = (double*)p; p += bL;
+    double* D2 = (double*)p; p += bD2;
+    double* Cm = (double*)p;
+    DppPrep a;
+    a.emb32 = d_emb32; a.hook = d_hook; a.rel = d_rel;
+    a.n = n; a.d = d; a.hook_dim = hook_dim; a.alpha = alpha;
+    a.normalize = normalize; a.ensure_pos = ensure_pos; a.has_table = has_table;
+    a.F = F; a.r = Rr;
+    dpp_prepare_kernel<<<dim3((n + 63) / 64, R), 64, 0, ctx->stream>>>(a);
+    dpp_kernel_matrix_kernel<<<dim3((n + 255) / 256, n, R), 256, 0, ctx->stream>>>(F, Rr, n, d1, L);
+    dpp_greedy_kernel<<<R, 1024, 0, ctx->stream>>>(L, n, topn, window, D2, Cm, d_out, d_out_count);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
 }
 
 }  // namespace pg
 
+namespace pg {
+int table_gather_locked(pg_ctx* ctx, const pg_table* t, const uint32_t* d_rows, uint32_t n, float* d_out);   // table.hip
+}
+
 extern "C" {
 
-int pg_dpp(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const double* rel, uint32_t n,
-           double alpha, uint32_t topn, uint32_t window, int normalize_emb, uint32_t* out_idx,
-           uint32_t* out_count) {
-    PG_REQUIRE(ctx && t && out_count, "pg_dpp: NULL argument");
+int pg_dpp_ex(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const double* rel, uint32_t n,
+              const pg_dpp_options* o, const double* hook_emb, uint32_t* out_idx, uint32_t* out_count,
+              double* out_relevance) {
+    PG_REQUIRE(ctx && o && out_count, "pg_dpp_ex: NULL argument");
     *out_count = 0;
-    if (n == 0 || topn == 0) return PG_OK;
-    PG_REQUIRE(cand_rows && rel && out_idx, "pg_dpp: NULL argument");
-    if (window == 0) window = 10;                        // NewDPPSort default (dpp_sort.go:89-91)
-    if (n > 8192) {
-        pg::set_error("pg_dpp: %u candidates unsupported (<= 8192; the reference caps N with CandidateCount)", n);
+    if (n == 0 || o->topn == 0) return PG_OK;
+    PG_REQUIRE(rel && out_idx, "pg_dpp_ex: NULL argument");
+    PG_REQUIRE(o->norm_relevance_score >= 0 && o->norm_relevance_score <= 2, "pg_dpp_ex: norm_relevance_score must be 0, 1 or 2");
+    PG_REQUIRE(!o->has_table || (t && cand_rows), "pg_dpp_ex: has_table needs a table and candidate rows");
+    PG_REQUIRE(o->has_table || o->hook_dim > 0, "pg_dpp_ex: no embedding table and no hook embeddings (the reference returns the items unchanged)");
+    PG_REQUIRE(o->hook_dim == 0 || hook_emb, "pg_dpp_ex: hook_dim > 0 but hook_emb is NULL");
+    const uint32_t dim = o->has_table ? t->dim : 0u;
+    if (n > 8192 || o->hook_dim + dim > 4096) {
+        pg::set_error("pg_dpp: %u candidates x %u dims unsupported (<= 8192 x 4096; the reference caps N with CandidateCount)", n, o->hook_dim + dim);
         return PG_ERR_UNSUPPORTED;
     }
-    for (uint32_t i = 0; i < n; ++i)
-        PG_REQUIRE(cand_rows[i] < t->rows, "pg_dpp: candidate row %u outside table", cand_rows[i]);
+    if (o->has_table)
+        for (uint32_t i = 0; i < n; ++i)
+            PG_REQUIRE(cand_rows[i] < t->rows, "pg_dpp: candidate row %u outside table", cand_rows[i]);
+    // dpp_norm_relevance_score (dpp_sort.go:382-405): O(n) scalar work on the caller's thread, in the reference's
+    // operation order (stat.PopMeanVariance two-pass with compensation, stat.StdScore; min-max takes max = first,
+    // min = last item: the candidates arrive sorted by score)
+    std::vector<double> rs(rel, rel + n);
+    if (o->norm_relevance_score == 1) {
+        double sum = 0.0;
+        for (uint32_t i = 0; i < n; ++i) sum = sum + rel[i];
+        const double mean = sum / (double)n;
+        double ss = 0.0, comp = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double d = rel[i] - mean;
+            volatile double dd = d * d;
+            ss = ss + dd;
+            comp = comp + d;
+        }
+        volatile double cc = comp * comp;
+        const double variance = (ss - cc / (double)n) / (double)n;
+        if (mean == 0.0 || variance == 0.0) {
+            pg::set_error("pg_dpp: all item score is zero (dpp_sort.go:385-388); the caller keeps the items unchanged");
+            return PG_ERR_ARITH;
+        }
+        const double sd = sqrt(variance);
+        for (uint32_t i = 0; i < n; ++i) rs[i] = (rel[i] - mean) / sd;
+    } else if (o->norm_relevance_score == 2) {
+        const double mx = rel[0], mn = rel[n - 1], span = mx - mn;
+        if (span == 0.0) {
+            pg::set_error("pg_dpp: all item score is zero (dpp_sort.go:394-397); the caller keeps the items unchanged");
+            return PG_ERR_ARITH;
+        }
+        const double eps = 1e-6;
+        for (uint32_t i = 0; i < n; ++i) {
+            volatile double a = ((rel[i] - mn) / span) * (1 - eps);
+            rs[i] = a + eps;
+        }
+    }
+    if (out_relevance) memcpy(out_relevance, rs.data(), (size_t)n * 8);      // "dpp_relevance_score" (:410)
+    const uint32_t topn = o->topn;
     std::lock_guard<std::mutex> g(ctx->mu);
-    const uint32_t d1 = t->dim + 1;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t bF = al((size_t)n * d1 * 8), bR = al((size_t)n * 8), bL = al((size_t)n * n * 8);
-    const size_t bD2 = al((size_t)n * 8), bC = al((size_t)std::min(window, n) * n * 8);
-    const size_t bCand = al((size_t)n * 4), bRel = al((size_t)n * 8), bOut = al((size_t)(topn + 1) * 4 + 16);
+    const size_t bCand = al((size_t)n * 4), bRel = al((size_t)n * 8), bEmb = al((size_t)n * std::max(dim, 1u) * 4);
+    const size_t bHook = al((size_t)n * std::max(o->hook_dim, 1u) * 8), bOut = al((size_t)(topn + 1) * 4 + 16);
     void* buf;
     int rc;
-    if ((rc = pg::scratch_reserve(ctx, 7, bF + bR + bL + bD2 + bC + bCand + bRel + bOut, &buf))) return rc;
+    if ((rc = pg::scratch_reserve(ctx, 5, bCand + bRel + bEmb + bHook + bOut, &buf))) return rc;
     char* p = (char*)buf;
-    double* F = (double*)p; p += bF;
-    double* R = (double*)p; p += bR;
-    double* L = (double*)p; p += bL;
-    double* D2 = (double*)p; p += bD2;
-    double* Cm = (double*)p; p += bC;
     uint32_t* d_cand = (uint32_t*)p; p += bCand;
     double* d_rel = (double*)p; p += bRel;
+    float* d_emb = (float*)p; p += bEmb;
+    double* d_hook = (double*)p; p += bHook;
     uint32_t* d_out = (uint32_t*)p;
     uint32_t* d_cnt = d_out + topn;
-    PG_HIP(hipMemcpyAsync(d_cand, cand_rows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    PG_HIP(hipMemcpyAsync(d_rel, rel, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    pg::dpp_prepare_kernel<<<(n + 63) / 64, 64, 0, ctx->stream>>>(t->d, (uint32_t)t->rows, t->dim, d_cand, d_rel, n,
-                                                                alpha, normalize_emb, F, R);
-    pg::dpp_kernel_matrix_kernel<<<dim3((n + 255) / 256, n), 256, 0, ctx->stream>>>(F, R, n, d1, L);
-    pg::dpp_greedy_kernel<<<1, 1024, 0, ctx->stream>>>(L, n, topn, window, D2, Cm, d_out, d_cnt);
-    PG_HIP(hipGetLastError());
+    PG_HIP(hipMemcpyAsync(d_rel, rs.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (o->has_table) {
+        PG_HIP(hipMemcpyAsync(d_cand, cand_rows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = pg::table_gather_locked(ctx, t, d_cand, n, d_emb))) return rc;
+    }
+    if (o->hook_dim) PG_HIP(hipMemcpyAsync(d_hook, hook_emb, (size_t)n * o->hook_dim * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pg::dpp_run_locked(ctx, o->has_table ? d_emb : nullptr, o->hook_dim ? d_hook : nullptr, d_rel, 1, n, dim, o->hook_dim,
+                                 o->alpha, topn, o->window, o->normalize_emb, o->ensure_pos_similarity, o->has_table, d_out, d_cnt)))
+        return rc;
     PG_HIP(hipMemcpyAsync(ctx->h_status + 330, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
     const uint32_t cnt = ctx->h_status[330];
@@ -226,6 +344,21 @@ int pg_dpp(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const doub
     PG_HIP(hipStreamSynchronize(ctx->stream));
     *out_count = cnt;
     return PG_OK;
+}
+
+int pg_dpp(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const double* rel, uint32_t n,
+           double alpha, uint32_t topn, uint32_t window, int normalize_emb, uint32_t* out_idx,
+           uint32_t* out_count) {
+    PG_REQUIRE(ctx && t && out_count, "pg_dpp: NULL argument");
+    pg_dpp_options o;
+    memset(&o, 0, sizeof o);
+    o.alpha = alpha;
+    o.topn = topn;
+    o.window = window;
+    o.normalize_emb = normalize_emb;
+    o.ensure_pos_similarity = 1;
+    o.has_table = 1;
+    return pg_dpp_ex(ctx, t, cand_rows, rel, n, &o, nullptr, out_idx, out_count, nullptr);
 }
 
 }  // extern "C"

@@ -1429,17 +1429,22 @@ __global__ void recall_init_kernel(const float* __restrict__ queries, uint32_t n
     if (i == 0) *overflow = 0;
 }
 
-// merge input lists (global rows, scores) → candidate keys
-__global__ void merge_keys_kernel(const uint64_t* __restrict__ rows, const float* __restrict__ scores,
-                                  uint32_t per_q, uint32_t cap, uint64_t* __restrict__ cand,
-                                  uint32_t* __restrict__ cnt) {
+// merge input lists (global rows, scores) → candidate keys.  Padding entries (row = UINT64_MAX: a shard with fewer
+// than per_list rows) are dropped here, so the keys stay distinct (select_kernel's invariant) and cnt[q] is the number
+// of real candidates.  Input layout: [nq][nlists][per_list] (list_major = 0) or [nlists][nq][per_list] (1: what an
+// all-gather of per-shard [nq][per_list] blocks produces).  cnt must be zero on entry.
+__global__ void merge_keys_kernel(const uint64_t* __restrict__ rows, const float* __restrict__ scores, uint32_t nq,
+                                  uint32_t nlists, uint32_t per_list, int list_major, uint32_t cap,
+                                  uint64_t* __restrict__ cand, uint32_t* __restrict__ cnt) {
     const uint32_t q = blockIdx.y;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < per_q) {
-        const uint64_t r = rows[(uint64_t)q * per_q + i];
-        cand[(uint64_t)q * cap + i] = (r == ~0ull) ? 0ull : topk_key(scores[(uint64_t)q * per_q + i], (uint32_t)r);
-    }
-    if (i == 0) cnt[q] = per_q;
+    const uint32_t per_q = nlists * per_list;
+    if (i >= per_q) return;
+    const uint32_t l = i / per_list, j = i - l * per_list;
+    const size_t src = list_major ? ((size_t)l * nq + q) * per_list + j : (size_t)q * per_q + i;
+    const uint64_t r = rows[src];
+    if (r == ~0ull) return;
+    cand[(uint64_t)q * cap + atomicAdd(&cnt[q], 1u)] = topk_key(scores[src], (uint32_t)r);
 }
 
 int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
@@ -2039,6 +2044,30 @@ int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, ui
     return PG_OK;
 }
 
+// global top-k of nlists per-shard lists per query (identical and deterministic on every shard that runs it)
+int topk_merge_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
+                      uint32_t per_list, int list_major, uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
+                      uint32_t* d_out_count) {
+    if (nq < 1 || nq > (uint32_t)kMaxQueries) {
+        set_error("topk merge: nq=%u out of range", nq);
+        return PG_ERR_INVALID;
+    }
+    const uint64_t per_q = (uint64_t)nlists * per_list;
+    if (k < 1 || k > 16384 || per_q == 0 || per_q > k + kCandSlack) {
+        set_error("topk merge: unsupported sizes k=%u lists=%u x %u", k, nlists, per_list);
+        return PG_ERR_UNSUPPORTED;
+    }
+    RecallScratch rs;
+    int rc;
+    if ((rc = recall_scratch(ctx, 64, k, &rs))) return rc;
+    PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
+    dim3 grid((uint32_t)((per_q + 255) / 256), nq);
+    merge_keys_kernel<<<grid, 256, 0, ctx->stream>>>(d_rows, d_scores, nq, nlists, per_list, list_major, rs.cap, rs.cand[0], rs.cnt);
+    PG_HIP(hipGetLastError());
+    if ((rc = launch_select(ctx, nq, rs.cand[0], rs.cand[1], rs.cnt, rs.thr, rs.cap, k))) return rc;
+    return final_launch(ctx, rs.cand[1], rs.cnt, rs.cap, nq, k, 0, d_out_rows, d_out_scores, d_out_count);
+}
+
 }  // namespace pg
 
 extern "C" {
@@ -2164,21 +2193,8 @@ int pg_topk_merge_dev(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores
                       uint32_t nlists, uint32_t per_list, uint32_t k, uint64_t* d_out_rows,
                       float* d_out_scores) {
     PG_REQUIRE(ctx && d_rows && d_scores && d_out_rows && d_out_scores, "pg_topk_merge_dev: NULL argument");
-    PG_REQUIRE(nq >= 1 && nq <= (uint32_t)pg::kMaxQueries, "pg_topk_merge_dev: nq=%u out of range", nq);
-    const uint64_t per_q = (uint64_t)nlists * per_list;
-    if (k < 1 || k > 16384 || per_q == 0 || per_q > k + pg::kCandSlack) {
-        pg::set_error("pg_topk_merge_dev: unsupported sizes k=%u lists=%u x %u", k, nlists, per_list);
-        return PG_ERR_UNSUPPORTED;
-    }
     std::lock_guard<std::mutex> g(ctx->mu);
-    pg::RecallScratch rs;
-    int rc;
-    if ((rc = pg::recall_scratch(ctx, 64, k, &rs))) return rc;
-    dim3 grid((uint32_t)((per_q + 255) / 256), nq);
-    pg::merge_keys_kernel<<<grid, 256, 0, ctx->stream>>>(d_rows, d_scores, (uint32_t)per_q, rs.cap, rs.cand[0], rs.cnt);
-    PG_HIP(hipGetLastError());
-    if ((rc = pg::launch_select(ctx, nq, rs.cand[0], rs.cand[1], rs.cnt, rs.thr, rs.cap, k))) return rc;
-    return pg::final_launch(ctx, rs.cand[1], rs.cnt, rs.cap, nq, k, 0, d_out_rows, d_out_scores, nullptr);
+    return pg::topk_merge_locked(ctx, d_rows, d_scores, nq, nlists, per_list, 0, k, d_out_rows, d_out_scores, nullptr);
 }
 
 }  // extern "C"

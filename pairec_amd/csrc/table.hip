@@ -74,6 +74,14 @@ __global__ void table_gather_kernel(const float* __restrict__ tab, uint32_t dim,
     *reinterpret_cast<float4*>(out + i * dim + 4 * q) = v;
 }
 
+int table_gather_locked(pg_ctx* ctx, const pg_table* t, const uint32_t* d_rows, uint32_t n, float* d_out) {
+    if (n == 0) return PG_OK;
+    const uint64_t threads = (uint64_t)n * (t->dim / 4);
+    table_gather_kernel<<<(uint32_t)((threads + 255) / 256), 256, 0, ctx->stream>>>(t->d, t->dim, d_rows, n, d_out);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 }  // namespace pg
 
 extern "C" {

@@ -388,6 +388,53 @@ class Coalescer:
         return s
 
 
+class ShardGroup:
+    """pg_group_*: the item table in row-range shards over several GPUs of this process (or logical shards of one)."""
+
+    def __init__(self, devices: Sequence[int]):
+        self.L = _lib.load()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _lib.check(self.L.pg_group_create(arr, len(devices), C.byref(h)))
+        self.h, self.n = h, len(devices)
+        self.dim = 0
+
+    def destroy(self):
+        if self.h:
+            _lib.check(self.L.pg_group_destroy(self.h))
+            self.h = None
+
+    def table_create(self, total_rows: int, dim: int):
+        _lib.check(self.L.pg_group_table_create(self.h, total_rows, dim))
+        self.dim = dim
+
+    def table_fill_synthetic(self, seed: int, normalize: bool = True):
+        _lib.check(self.L.pg_group_table_fill_synthetic(self.h, seed, int(normalize)))
+
+    def table_upload(self, rows: np.ndarray, row0: int = 0):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        _lib.check(self.L.pg_group_table_upload(self.h, row0, rows.shape[0], _ptr(rows)))
+
+    def model_load(self, kind: int, prec: int, blob: bytes):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        _lib.check(self.L.pg_group_model_load(self.h, kind, prec, buf, len(blob)))
+
+    def recommend(self, expr: "Expr", rank_var: str, user_vecs: np.ndarray, k: int, top_n: int,
+                  dpp_candidates: int = 0, dpp_alpha: float = 1.0, dpp_window: int = 10,
+                  dpp_normalize_emb: bool = True):
+        u = np.ascontiguousarray(user_vecs, dtype=np.float32).reshape(-1, self.dim)
+        nq = u.shape[0]
+        plan = _lib.PgGroupPlan(k, dpp_candidates, dpp_alpha, dpp_window, int(dpp_normalize_emb))
+        rows = np.empty((nq, top_n), dtype=np.uint64)
+        rec = np.empty((nq, top_n), dtype=np.float32)
+        rnk = np.empty((nq, top_n), dtype=np.float32)
+        fus = np.empty((nq, top_n), dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        _lib.check(self.L.pg_group_recommend(self.h, expr.h, rank_var.encode(), C.byref(plan), _ptr(u), nq, top_n,
+                                             _ptr(rows), _ptr(rec), _ptr(rnk), _ptr(fus), _ptr(cnt)))
+        return rows, rec, rnk, fus, cnt
+
+
 def dpp(ctx: Context, table: Table, cand_rows, rel, alpha: float, topn: int, window: int,
         normalize_emb: bool = True) -> np.ndarray:
     c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
@@ -397,6 +444,26 @@ def dpp(ctx: Context, table: Table, cand_rows, rel, alpha: float, topn: int, win
     _lib.check(ctx.L.pg_dpp(ctx.h, table.h, _ptr(c), _ptr(r), c.shape[0], alpha, topn, window,
                             int(normalize_emb), _ptr(out), C.byref(cnt)))
     return out[:cnt.value]
+
+
+def dpp_ex(ctx: Context, table: Optional[Table], cand_rows, rel, alpha: float, topn: int, window: int,
+           normalize_emb: bool = True, ensure_pos_similarity: bool = True, norm_relevance_score: int = 0,
+           hook_emb: Optional[np.ndarray] = None):
+    """pg_dpp_ex: DPPSort.KernelMatrix + DPPWithWindow with every option.  table=None → hook embeddings only.
+    Returns (picked indices, relevance scores as used)."""
+    r = np.ascontiguousarray(rel, dtype=np.float64)
+    n = r.shape[0]
+    c = np.ascontiguousarray(cand_rows, dtype=np.uint32) if table is not None else None
+    h = None if hook_emb is None else np.ascontiguousarray(hook_emb, dtype=np.float64).reshape(n, -1)
+    opt = _lib.PgDppOptions(alpha, topn, window, int(normalize_emb), int(ensure_pos_similarity),
+                            int(norm_relevance_score), int(table is not None), 0 if h is None else h.shape[1])
+    out = np.zeros(max(topn, 1), dtype=np.uint32)
+    used = np.zeros(max(n, 1), dtype=np.float64)
+    cnt = C.c_uint32()
+    _lib.check(ctx.L.pg_dpp_ex(ctx.h, table.h if table is not None else None, _ptr(c) if c is not None else None,
+                               _ptr(r), n, C.byref(opt), _ptr(h) if h is not None else None, _ptr(out),
+                               C.byref(cnt), _ptr(used)))
+    return out[:cnt.value], used[:n]
 
 
 def ssd(ctx: Context, table: Table, cand_rows, rel, gamma: float, topn: int, window: int,

@@ -1,0 +1,92 @@
+"""GPU tests of the shard group (pg_group_*): BASELINE.json configs[4] in miniature — the item table in row-range
+shards, recall → merge → owner-computes rank → fusion → sort → DPPSort — with 2..4 LOGICAL shards on one device,
+against the single-shard oracle.  Bar: ids and order exact, recall scores bit-exact, model scores
+within the precision mode's tolerance, the DPP page equal to the oracle's pick sequence."""
+import numpy as np
+import pytest
+
+import pairec_amd as pa
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+EXPR = "${gpu_dnn}*(1+${current_score})^0.1"
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def oracle_pipeline(tab, w, prec, q, k, top_n, dpp_c, alpha, window):
+    """Single-table statement of the step: recall → DNN3 → RankScore → ItemRankScore → DPPSort(doSort)."""
+    rows, rec = o.recall_topk(tab, q, k)
+    out = []
+    for r in range(q.shape[0]):
+        rk = o.dnn3_forward(w, prec, q[r], tab[rows[r].astype(np.int64)])
+        fused = o.widen_f32(rk) * (1 + o.widen_f32(rec[r])) ** 0.1
+        order = o.sort_scores(fused, True)
+        if dpp_c:
+            c = min(k, max(top_n, dpp_c))
+            head = order[:c]
+            emb = o.l2_normalize_f64(tab[rows[r][head].astype(np.int64)].astype(np.float64))
+            L = o.dpp_kernel_matrix(emb, fused[head], alpha)
+            page = head[o.dpp_with_window(L, top_n, window)]
+        else:
+            page = order[:top_n]
+        out.append((rows[r][page], rec[r][page], rk[page], fused[page]))
+    return out
+
+
+@pytest.mark.parametrize("shards,n,dpp_c", [(2, 90_001, 120), (4, 150_000, 0), (3, 70_000, 64)])
+def test_group_equals_single_shard_oracle(shards, n, dpp_c):
+    d, k, R, top_n = 128, 400, 7, 40
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    w = o.Dnn3Weights()
+    g = pa.ShardGroup([0] * shards)
+    g.table_create(n, d)
+    g.table_fill_synthetic(o.SEED_TABLE)
+    g.model_load(pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    ex = pa.Expr(EXPR)
+    q = o.synth_rows(o.SEED_QUERY, 21, R, d)
+    rows, rec, rnk, fus, cnt = g.recommend(ex, "gpu_dnn", q, k, top_n, dpp_candidates=dpp_c, dpp_alpha=1.0, dpp_window=10)
+    want = oracle_pipeline(tab, w, pa.PREC_F32, q, k, top_n, dpp_c, 1.0, 10)
+    for r in range(R):
+        w_rows, w_rec, w_rk, w_fu = want[r]
+        assert cnt[r] == top_n
+        assert np.array_equal(rows[r], w_rows), "request %d: page ids / order differ" % r
+        assert np.array_equal(bits(rec[r]), bits(w_rec))
+        assert np.max(np.abs(rnk[r].astype(np.float64) - w_rk)) <= 2e-7
+        assert np.max(np.abs(fus[r] - w_fu)) <= 1e-6
+    g.destroy()
+
+
+def test_group_upload_and_batch_of_256():
+    """Uploaded (not generated) rows routed to their shards; a full 256-request batch; bf16 model."""
+    n, d, k, R, top_n = 60_000, 128, 200, 256, 10
+    rng = np.random.default_rng(4)
+    tab = rng.standard_normal((n, d)).astype(np.float32)
+    tab /= np.linalg.norm(tab, axis=1, keepdims=True)
+    w = o.Dnn3Weights()
+    g = pa.ShardGroup([0, 0])
+    g.table_create(n, d)
+    g.table_upload(tab[:25_000], 0)
+    g.table_upload(tab[25_000:], 25_000)              # spans the shard boundary
+    g.model_load(pa.MODEL_DNN3, pa.PREC_BF16, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    ex = pa.Expr(EXPR)
+    q = o.synth_rows(o.SEED_QUERY, 0, R, d)
+    rows, rec, rnk, fus, cnt = g.recommend(ex, "gpu_dnn", q, k, top_n)
+    orow, osc = o.recall_topk(tab, q, k)
+    for r in (0, 100, 255):
+        rk = o.dnn3_forward(w, pa.PREC_BF16, q[r], tab[orow[r].astype(np.int64)])
+        fused = o.widen_f32(rk) * (1 + o.widen_f32(osc[r])) ** 0.1
+        # bf16 scores differ from the oracle within 1e-5: compare the page as a set drawn from the oracle's near-top
+        got = {int(x): i for i, x in enumerate(rows[r])}
+        assert set(got) <= set(orow[r].astype(np.int64).tolist())
+        pos = {int(x): i for i, x in enumerate(orow[r])}
+        for row_id, i in got.items():
+            j = pos[row_id]
+            assert bits(rec[r][i:i + 1])[0] == bits(osc[r][j:j + 1])[0]
+            assert abs(float(rnk[r][i]) - rk[j]) <= 1e-5 and abs(fus[r][i] - fused[j]) <= 2e-5
+        assert np.all(np.diff(fus[r]) <= 0)
+        assert fus[r][-1] >= np.sort(fused)[::-1][top_n - 1] - 2e-5
+    g.destroy()

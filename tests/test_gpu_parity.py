@@ -560,6 +560,40 @@ def test_dpp_matches_oracle(ctx):
     t.destroy()
 
 
+def test_dpp_options_match_oracle(ctx):
+    """DPPSort.KernelMatrix's switches (dpp_sort.go:382-447): dpp_norm_relevance_score 1 / 2, hook embeddings
+    prepended to the table embedding, hook-only rows with and without EnsurePositiveSim, un-normalised rows —
+    pick sequences and the relevance scores reported as "dpp_relevance_score" equal the oracle's."""
+    rng = np.random.default_rng(18)
+    n_tab, d, n, h = 3000, 64, 300, 6
+    centers = rng.standard_normal((10, d)).astype(np.float32)
+    tab = (centers[rng.integers(0, 10, n_tab)] + 0.25 * rng.standard_normal((n_tab, d))).astype(np.float32)
+    t = pa.Table(ctx, n_tab, d)
+    t.upload(tab)
+    cand = rng.choice(n_tab, n, replace=False).astype(np.uint32)
+    rel = np.sort(rng.random(n))[::-1].copy()
+    hook = rng.standard_normal((n, h))
+    for has_table, hk, norm, pos, mode, topn, window, alpha in [
+            (True, None, True, True, 1, 50, 10, 1.0),
+            (True, None, True, True, 2, 50, 10, 2.0),
+            (True, hook, True, True, 0, 40, 7, 1.0),
+            (False, hook, True, True, 0, 40, 10, 1.0),
+            (False, hook, False, False, 2, 30, 5, 0.5),
+            (True, None, False, True, 0, 30, 10, 0.1)]:
+        rs, ok = o.dpp_relevance(rel, mode)
+        assert ok
+        F = o.dpp_features(tab[cand] if has_table else None, hk, norm, pos)
+        want = o.dpp_with_window(o.dpp_kernel_matrix_f(F, rs, alpha), topn, window)
+        got, used = pa.dpp_ex(ctx, t if has_table else None, cand, rel, alpha, topn, window, norm, pos, mode, hk)
+        assert np.array_equal(got, want), (has_table, hk is not None, norm, pos, mode)
+        assert np.array_equal(used.view(np.uint64), rs.view(np.uint64))
+    # "all item score is zero": the reference returns the items unchanged; here the call says so
+    with pytest.raises(pa._lib.PgError) as ei:
+        pa.dpp_ex(ctx, t, cand, np.full(n, 0.25), 1.0, 10, 10, norm_relevance_score=1)
+    assert ei.value.code == -5
+    t.destroy()
+
+
 # ---------------------------------------------------------------------------------------------
 # SSD (SURVEY.md 8f row 1)
 # ---------------------------------------------------------------------------------------------

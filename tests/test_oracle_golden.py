@@ -289,6 +289,49 @@ def test_dpp_matches_numpy_restatement():
     assert o.dpp_with_window(L, 25, 10).tolist() != list(range(25))    # diversity changed the order
 
 
+def test_dpp_kernel_matrix_matches_exact_rational_restatement():
+    """KernelMatrix (dpp_sort.go:407-472) restated with exact rationals for the fma chain of S = F F^T and Python
+    floats for L = (r_i S_ij) r_j, over the four feature-row variants (table, table + hook, hook-only with and
+    without EnsurePositiveSim); then the greedy picks of the oracle equal the numpy restatement on each L."""
+    rng = np.random.default_rng(21)
+    n, d, h = 24, 12, 5
+    emb = (rng.standard_normal((n, d)) * 0.5).astype(np.float32)
+    hook = rng.standard_normal((n, h))
+    rel = np.sort(rng.random(n))[::-1].copy()
+
+    def fma(x, y, s_):
+        return float(Fraction(x) * Fraction(y) + Fraction(s_))
+    for emb32, hk, norm, pos in ((emb, None, True, True), (emb, hook, True, True), (None, hook, True, True),
+                                 (None, hook, False, False), (emb, None, False, True)):
+        F = o.dpp_features(emb32, hk, norm, pos)
+        w = (0 if emb32 is None else d) + (0 if hk is None else h)
+        assert F.shape == (n, w + 1)
+        if emb32 is not None or pos:
+            assert np.all(F[:, -1] == 0.70710678118654757)
+            if norm:
+                assert np.allclose(np.sum(F[:, :-1] ** 2, axis=1), 0.5, rtol=1e-12)      # unit rows scaled by 1/sqrt 2
+        else:
+            assert np.all(F[:, -1] == 0.0) and np.array_equal(F[:, :-1], hk)              # raw hook rows, constant 0
+        for mode in (0, 1, 2):
+            rs, ok = o.dpp_relevance(rel, mode)
+            assert ok
+            L = o.dpp_kernel_matrix_f(F, rs, 0.7)
+            r = [math.exp(0.7 * float(x)) for x in rs]
+            for i in (0, 3, n - 1):
+                for j in (0, 5, n - 1):
+                    s_ = 0.0
+                    for k in range(w + 1):
+                        s_ = fma(float(F[i, k]), float(F[j, k]), s_)
+                    assert L[i, j] == (r[i] * s_) * r[j]
+            got = o.dpp_with_window(L, 10, 4).tolist()
+            assert got == _np_dpp(L, 10, 4)
+    # the table variant equals the older entry point that takes normalised embeddings
+    e64 = o.l2_normalize_f64(emb.astype(np.float64))
+    assert np.array_equal(o.dpp_kernel_matrix(e64, rel, 1.0), o.dpp_kernel_matrix_f(o.dpp_features(emb, None, True, True), rel, 1.0))
+    # all-equal scores: both normalisations bail out as the reference does
+    assert not o.dpp_relevance(np.full(5, 0.3), 1)[1] and not o.dpp_relevance(np.full(5, 0.3), 2)[1]
+
+
 def test_go_float_format():
     assert [o.go_fmt_float(x) for x in (0.5, 1e21, 1.5e-7, 123456.0, 0.000123, 1e20, 100.0)] == \
         ["0.5", "1e+21", "1.5e-07", "123456", "0.000123", "100000000000000000000", "100"]
