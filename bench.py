@@ -471,13 +471,15 @@ def main():
         def sync():
             dist.barrier()
             torch.cuda.synchronize()
+        # cfg 5: recall + rank + sort.dpp_sort — DPP candidates = top 500 by score, alpha 1, page (ctx.Size) 100, window 10
+        dpp = {"candidates": 500, "alpha": 1.0, "window": 10}
         for s in range(args.warmup):
-            sharded_step(eng, dist, torch, t_qs[s], R, K)
+            sharded_step(eng, dist, torch, t_qs[s], R, K, args.page, dpp)
         sync()
         scan_ms = []
         t0 = time.perf_counter()
         for s in range(args.warmup, total_steps):
-            sharded_step(eng, dist, torch, t_qs[s], R, K)
+            sharded_step(eng, dist, torch, t_qs[s], R, K, args.page, dpp)
             scan_ms.append(ctx.last_scan_kernel()[0])
         sync()
         elapsed = time.perf_counter() - t0

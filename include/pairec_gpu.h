@@ -333,6 +333,33 @@ int pg_group_recommend(pg_group* g, const pg_expr* e, const char* rank_var, cons
                        const float* user_vecs, uint32_t nq, uint32_t top_n, uint64_t* out_rows,
                        float* out_recall_scores, float* out_rank_scores, double* out_fused, uint32_t* out_count);
 
+/* The shard-side steps of the same flow as device-level calls, for a one-process-per-GPU host that runs the two
+ * exchanges itself (pairec_amd/dist.py over torch.distributed / RCCL).  Everything is fixed-size and stays on the
+ * stream: no counts travel to the host.
+ *   pg_topk_merge_lists_dev   pg_topk_merge_dev with the input layout selectable: list_major = 1 takes
+ *                             [nlists][nq][per_list], what an all-gather of per-shard [nq][per_list] blocks produces
+ *   pg_owned_compact_dev      of the merged global rows [nq][k], the candidates whose rows live in `t`: their local row
+ *                             indices and their slots q * k + j, compacted request by request (stable), and the CSR
+ *                             offsets d_req_offsets[nq + 1] — inputs of pg_rank_dnn3_dev (pass n_items = nq * k, an upper bound)
+ *   pg_scatter_f32_dev        d_out[d_slot[i]] = d_vals[i] for i < *d_total (= d_req_offsets[nq]); d_out is pre-zeroed by the
+ *                             caller, the owners' slots are disjoint, so a sum all-reduce of the slabs is exact
+ *   pg_dpp_candidates_dev     global rows and relevance (fused score) of the first n_cand entries of every sorted list
+ *   pg_gather_owned_rows_dev  d_out[i][dim] = row d_global_rows[i] where this shard owns it; other rows are left as they are
+ *   pg_dpp_batch_dev          DPPSort.KernelMatrix + DPPWithWindow for n_req independent requests of n candidates given as
+ *                             embedding rows d_emb [n_req][n][dim]; d_out_idx [n_req][topn], d_out_count [n_req] */
+int pg_topk_merge_lists_dev(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
+                            uint32_t per_list, int list_major, uint32_t k, uint64_t* d_out_rows, float* d_out_scores);
+int pg_owned_compact_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t nq, uint32_t k,
+                         uint32_t* d_local, uint32_t* d_slot, uint32_t* d_req_offsets);
+int pg_scatter_f32_dev(pg_ctx* ctx, const float* d_vals, const uint32_t* d_slot, const uint32_t* d_total, uint32_t cap,
+                       float* d_out);
+int pg_dpp_candidates_dev(pg_ctx* ctx, const uint32_t* d_order, const uint64_t* d_rows, const double* d_fused, uint32_t nq,
+                          uint32_t k, uint32_t n_cand, uint64_t* d_c_rows, double* d_c_rel);
+int pg_gather_owned_rows_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_global_rows, uint32_t n, float* d_out);
+int pg_dpp_batch_dev(pg_ctx* ctx, const float* d_emb, const double* d_rel, uint32_t n_req, uint32_t n, uint32_t dim,
+                     double alpha, uint32_t topn, uint32_t window, int normalize_emb, uint32_t* d_out_idx,
+                     uint32_t* d_out_count);
+
 /* ---- request coalescer --------------------------------------------------------------------------
  * The reference calls its plug-ins once per request from many goroutines at once: one IAlgorithm.Run per recall
  * (service/recall.go:129-145 → vector_recall.go:88), one per batch of BatchCount = 100 items and per algorithm

@@ -28,6 +28,8 @@ EXPORTS = [
     "pg_fm2t_user_embedding_dev", "pg_recommend_dnn3_begin", "pg_recommend_end",
     "pg_coalescer_create", "pg_coalescer_destroy", "pg_coalescer_recall", "pg_coalescer_rank_dnn3",
     "pg_coalescer_recommend", "pg_coalescer_stats",
+    "pg_topk_merge_lists_dev", "pg_owned_compact_dev", "pg_scatter_f32_dev", "pg_dpp_candidates_dev",
+    "pg_gather_owned_rows_dev", "pg_dpp_batch_dev",
     "pg_group_create", "pg_group_destroy", "pg_group_size", "pg_group_ctx", "pg_group_table", "pg_group_table_create",
     "pg_group_table_fill_synthetic", "pg_group_table_upload", "pg_group_model_load", "pg_group_recommend",
 ]
@@ -137,6 +139,12 @@ def load():
         "pg_coalescer_rank_dnn3": [vp, vp, vp, u32, vp],
         "pg_coalescer_recommend": [vp, vp, u32, vp, vp, vp, vp, P(u32)],
         "pg_coalescer_stats": [vp, P(PgCoalescerStats)],
+        "pg_topk_merge_lists_dev": [vp, vp, vp, u32, u32, u32, i32, u32, vp, vp],
+        "pg_owned_compact_dev": [vp, vp, vp, u32, u32, vp, vp, vp],
+        "pg_scatter_f32_dev": [vp, vp, vp, vp, u32, vp],
+        "pg_dpp_candidates_dev": [vp, vp, vp, vp, u32, u32, u32, vp, vp],
+        "pg_gather_owned_rows_dev": [vp, vp, vp, u32, vp],
+        "pg_dpp_batch_dev": [vp, vp, vp, u32, u32, u32, C.c_double, u32, u32, i32, vp, vp],
         "pg_group_create": [P(C.c_int), u32, P(vp)],
         "pg_group_destroy": [vp],
         "pg_group_table_create": [vp, u64, u32],

@@ -286,6 +286,70 @@ __global__ void group_bind_vars_kernel(const float* __restrict__ recall, const f
 
 extern "C" {
 
+// ---- the shard-side steps as device-level calls (pairec_amd/dist.py drives them around torch.distributed collectives) ----
+int pg_owned_compact_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t nq, uint32_t k,
+                         uint32_t* d_local, uint32_t* d_slot, uint32_t* d_req_offsets) {
+    PG_REQUIRE(ctx && t && d_rows && d_local && d_slot && d_req_offsets, "pg_owned_compact_dev: NULL argument");
+    PG_REQUIRE(nq >= 1 && nq <= (uint32_t)pg::kMaxQueries && k >= 1, "pg_owned_compact_dev: bad nq / k");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* p;
+    int rc;
+    if ((rc = pg::scratch_reserve(ctx, 9, 4096, &p))) return rc;
+    uint32_t* d_cnt = (uint32_t*)p;
+    pg::owned_count_kernel<<<nq, 256, 0, ctx->stream>>>(d_rows, k, t->row_offset, t->rows, d_cnt);
+    pg::owned_scan_kernel<<<1, 256, 0, ctx->stream>>>(d_cnt, nq, d_req_offsets);
+    pg::owned_fill_kernel<<<nq, 1024, 0, ctx->stream>>>(d_rows, k, t->row_offset, t->rows, d_req_offsets, d_local, d_slot);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int pg_scatter_f32_dev(pg_ctx* ctx, const float* d_vals, const uint32_t* d_slot, const uint32_t* d_total, uint32_t cap,
+                       float* d_out) {
+    PG_REQUIRE(ctx && d_vals && d_slot && d_total && d_out, "pg_scatter_f32_dev: NULL argument");
+    if (cap == 0) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    pg::scatter_scores_kernel<<<(cap + 255) / 256, 256, 0, ctx->stream>>>(d_vals, d_slot, d_total, cap, d_out);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int pg_dpp_candidates_dev(pg_ctx* ctx, const uint32_t* d_order, const uint64_t* d_rows, const double* d_fused, uint32_t nq,
+                          uint32_t k, uint32_t n_cand, uint64_t* d_c_rows, double* d_c_rel) {
+    PG_REQUIRE(ctx && d_order && d_rows && d_fused && d_c_rows && d_c_rel, "pg_dpp_candidates_dev: NULL argument");
+    PG_REQUIRE(n_cand >= 1 && n_cand <= k, "pg_dpp_candidates_dev: n_cand %u outside 1..k", n_cand);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    pg::dpp_select_kernel<<<(nq * n_cand + 255) / 256, 256, 0, ctx->stream>>>(d_order, d_rows, d_fused, nq, k, n_cand, d_c_rows, d_c_rel);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int pg_gather_owned_rows_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_global_rows, uint32_t n, float* d_out) {
+    PG_REQUIRE(ctx && t && (n == 0 || (d_global_rows && d_out)), "pg_gather_owned_rows_dev: NULL argument");
+    if (n == 0) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    const uint64_t threads = (uint64_t)n * (t->dim / 4);
+    pg::gather_owned_emb_kernel<<<(uint32_t)((threads + 255) / 256), 256, 0, ctx->stream>>>(t->d, t->dim, t->row_offset, t->rows,
+                                                                                          d_global_rows, n, d_out);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int pg_dpp_batch_dev(pg_ctx* ctx, const float* d_emb, const double* d_rel, uint32_t n_req, uint32_t n, uint32_t dim,
+                     double alpha, uint32_t topn, uint32_t window, int normalize_emb, uint32_t* d_out_idx,
+                     uint32_t* d_out_count) {
+    PG_REQUIRE(ctx && d_emb && d_rel && d_out_idx && d_out_count, "pg_dpp_batch_dev: NULL argument");
+    PG_REQUIRE(n <= 8192 && dim <= 4096 && n_req <= 65535, "pg_dpp_batch_dev: %u requests x %u candidates x %u dims unsupported", n_req, n, dim);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return pg::dpp_run_locked(ctx, d_emb, nullptr, d_rel, n_req, n, dim, 0, alpha, topn, window, normalize_emb, 1, 1, d_out_idx, d_out_count);
+}
+
+int pg_topk_merge_lists_dev(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
+                            uint32_t per_list, int list_major, uint32_t k, uint64_t* d_out_rows, float* d_out_scores) {
+    PG_REQUIRE(ctx && d_rows && d_scores && d_out_rows && d_out_scores, "pg_topk_merge_lists_dev: NULL argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return pg::topk_merge_locked(ctx, d_rows, d_scores, nq, nlists, per_list, list_major, k, d_out_rows, d_out_scores, nullptr);
+}
+
 int pg_group_create(const int* devices, uint32_t n_shards, pg_group** out) {
     PG_REQUIRE(devices && out && n_shards >= 1 && n_shards <= 64, "pg_group_create: bad argument");
     pg_group* g = new pg_group();

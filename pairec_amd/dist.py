@@ -7,9 +7,15 @@ collectives rather than anything ring-tuned:
 
   1. every rank scans its shard → local top-K (global row id, score) per request
   2. all_gather of the [R][K] lists → identical deterministic merge on every rank → global top-K
-  3. every rank ranks the candidates whose embedding rows it owns (no feature traffic)
+  3. every rank ranks the candidates whose embedding rows it owns (no feature traffic); they are compacted on
+     the device (pg_owned_compact_dev), nothing is read back
   4. all_reduce(sum) of the [R][K] score slab (each slot is written by exactly one owner, the
      other ranks contribute +0.0, so the sum is exact) → fusion + sort, replicated on every rank
+  5. (cfg 5) sort.dpp_sort on the merged list: the first max(page, CandidateCount) entries' embedding rows are
+     contributed by their owners (a second all_reduce, 256 KB per request) and DPP runs replicated
+
+The same flow inside ONE process over several GPUs, with direct peer stores instead of collectives, is
+pg_group_recommend (csrc/group.hip) — what a cgo host calls.
 
 The step is written against a small engine interface so that the same orchestration runs on HIP
 (GpuShardEngine, the product) and, in tests/test_dist_gloo.py, on a CPU stand-in that checks the
@@ -31,35 +37,43 @@ def shard_range(total_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def sharded_step(engine, dist, torch, queries, nq: int, k: int):
-    """One request batch through recall → exchange → rank → exchange → fuse+sort.
+def sharded_step(engine, dist, torch, queries, nq: int, k: int, page: int = 0, dpp=None):
+    """One request batch through recall → exchange → owner-computes rank → exchange → fuse + sort → (DPP).
 
-    Returns (rows [nq,k] global ids, fused scores [nq,k] f64, order [nq,k] int32) — identical on
-    every rank.  `dist` is torch.distributed (or None for world_size 1)."""
+    Returns (rows [nq,k] global ids, fused scores [nq,k] f64, order [nq,k] int32) — identical on every rank —
+    and, with page > 0, additionally the page: positions [nq,page] into each request's list (the head of the
+    sorted list, or DPPSort's picks among its first max(page, dpp["candidates"]) entries when dpp is given:
+    {"candidates": C, "alpha": a, "window": w}).  `dist` is torch.distributed (or None for world_size 1).
+
+    Nothing in the step depends on a value read back from the device: buffers are fixed-size (K-padded), the
+    owned candidates are compacted on the device, so the host only enqueues (no .item(), no mask indexing)."""
     world = dist.get_world_size() if dist is not None else 1
     rows, scores = engine.recall_local(queries, nq, k)                       # [nq,k] i64 / f32
     if world > 1:
-        # concatenation along dim 0 (the layout every backend accepts), viewed as [G, nq, k]
+        # concatenation along dim 0 (the layout every backend accepts) = list-major [G, nq, k], which the merge reads
+        # directly
         g_rows = torch.empty((world * nq, k), dtype=rows.dtype, device=rows.device)
         g_scores = torch.empty((world * nq, k), dtype=scores.dtype, device=scores.device)
         dist.all_gather_into_tensor(g_rows, rows.contiguous())
         dist.all_gather_into_tensor(g_scores, scores.contiguous())
-        # [G,nq,k] → [nq,G,k]: the merge wants all of a request's lists contiguous
-        rows, scores = engine.merge(g_rows.view(world, nq, k).permute(1, 0, 2).contiguous(),
-                                    g_scores.view(world, nq, k).permute(1, 0, 2).contiguous(), k)
-    local, owned = engine.rows_to_local(rows)                                # [nq,k] i32 / bool
-    counts = owned.sum(dim=1, dtype=torch.int32)
-    req_offsets = torch.zeros(nq + 1, dtype=torch.int32, device=rows.device)
-    req_offsets[1:] = torch.cumsum(counts, 0)
-    n_items = int(req_offsets[-1].item())
-    slab = torch.zeros(nq * k, dtype=torch.float32, device=rows.device)
-    if n_items:
-        mine = engine.rank(queries, local[owned].contiguous(), req_offsets, nq, n_items)
-        slab[owned.reshape(-1)] = mine                                       # request order kept
+        rows, scores = engine.merge(g_rows.view(world, nq, k), g_scores.view(world, nq, k), k)
+    local, slot, req_offsets = engine.owned_compact(rows, nq, k)             # compacted on the device, CSR offsets
+    mine = engine.rank(queries, local, req_offsets, nq, nq * k)              # n_items = upper bound
+    slab = engine.scatter(mine, slot, req_offsets, nq, k)                    # [nq*k] f32, zero where not owned
     if world > 1:
-        dist.all_reduce(slab)                                                # sum; owners are disjoint
+        dist.all_reduce(slab)                                                # sum; owners are disjoint → exact
     fused, order = engine.fuse_sort(slab.view(nq, k), scores, nq, k)
-    return rows, fused, order
+    if page <= 0:
+        return rows, fused, order
+    if dpp is None:
+        return rows, fused, order, order[:, :page]
+    n_cand = min(k, max(page, int(dpp["candidates"])))
+    c_rows, c_rel = engine.dpp_candidates(order, rows, fused, nq, k, n_cand)
+    emb = engine.gather_owned(c_rows, nq * n_cand)                           # [nq*C, dim] f32, zero where not owned
+    if world > 1:
+        dist.all_reduce(emb)                                                 # 256 KB per request; sum with zeros: exact
+    picks = engine.dpp(emb, c_rel, nq, n_cand, float(dpp["alpha"]), page, int(dpp["window"]))     # [nq,page] into the head
+    return rows, fused, order, torch.gather(order, 1, picks.long()).to(order.dtype)
 
 
 class GpuShardEngine:
@@ -71,17 +85,21 @@ class GpuShardEngine:
         self.dev = dev
         self.k_max = k_max
         n = nq_max * k_max
-        self.t_rows = torch.empty((nq_max, k_max), dtype=torch.int64, device=dev)
-        self.t_scores = torch.empty((nq_max, k_max), dtype=torch.float32, device=dev)
-        self.m_rows = torch.empty((nq_max, k_max), dtype=torch.int64, device=dev)
-        self.m_scores = torch.empty((nq_max, k_max), dtype=torch.float32, device=dev)
-        self.local = torch.empty((nq_max, k_max), dtype=torch.int32, device=dev)
-        self.owned = torch.empty((nq_max, k_max), dtype=torch.uint8, device=dev)
-        self.rank_out = torch.empty(n, dtype=torch.float32, device=dev)
-        self.vars = torch.empty((2, n), dtype=torch.float64, device=dev)
-        self.fused = torch.empty(n, dtype=torch.float64, device=dev)
-        self.order = torch.empty(n, dtype=torch.int32, device=dev)
-        self.seg = torch.arange(0, n + 1, k_max, dtype=torch.int32, device=dev)
+        i32, i64, f32, f64 = torch.int32, torch.int64, torch.float32, torch.float64
+        self.t_rows = torch.empty((nq_max, k_max), dtype=i64, device=dev)
+        self.t_scores = torch.empty((nq_max, k_max), dtype=f32, device=dev)
+        self.m_rows = torch.empty((nq_max, k_max), dtype=i64, device=dev)
+        self.m_scores = torch.empty((nq_max, k_max), dtype=f32, device=dev)
+        self.local = torch.empty(n, dtype=i32, device=dev)
+        self.slot = torch.empty(n, dtype=i32, device=dev)
+        self.req_off = torch.empty(nq_max + 1, dtype=i32, device=dev)
+        self.rank_out = torch.empty(n, dtype=f32, device=dev)
+        self.slab = torch.empty(n, dtype=f32, device=dev)
+        self.vars = torch.empty((2, n), dtype=f64, device=dev)
+        self.fused = torch.empty(n, dtype=f64, device=dev)
+        self.order = torch.empty(n, dtype=i32, device=dev)
+        self.seg = torch.arange(0, n + 1, k_max, dtype=i32, device=dev)
+        self.c_rows = self.c_rel = self.c_emb = self.picks = self.pick_cnt = None
         assert expr.var_names == ["gpu_dnn", "current_score"]       # column order of the vars slab below
 
     def _check(self, rc):
@@ -95,24 +113,29 @@ class GpuShardEngine:
         return rows, scores
 
     def merge(self, g_rows, g_scores, k):
-        nq, G, per = g_rows.shape
+        G, nq, per = g_rows.shape                                   # list-major, as all-gathered
         rows, scores = self.m_rows[:nq, :k], self.m_scores[:nq, :k]
-        self._check(self.ctx.L.pg_topk_merge_dev(self.ctx.h, g_rows.data_ptr(), g_scores.data_ptr(), nq, G,
-                                                 per, k, rows.data_ptr(), scores.data_ptr()))
+        self._check(self.ctx.L.pg_topk_merge_lists_dev(self.ctx.h, g_rows.data_ptr(), g_scores.data_ptr(), nq, G,
+                                                       per, 1, k, rows.data_ptr(), scores.data_ptr()))
         return rows, scores
 
-    def rows_to_local(self, rows):
-        nq, k = rows.shape
-        local, owned = self.local[:nq, :k], self.owned[:nq, :k]
-        self._check(self.ctx.L.pg_rows_to_local_dev(self.ctx.h, self.table.h, rows.data_ptr(), nq * k,
-                                                    local.data_ptr(), owned.data_ptr()))
-        return local, owned.bool()
+    def owned_compact(self, rows, nq, k):
+        self._check(self.ctx.L.pg_owned_compact_dev(self.ctx.h, self.table.h, rows.data_ptr(), nq, k,
+                                                    self.local.data_ptr(), self.slot.data_ptr(),
+                                                    self.req_off.data_ptr()))
+        return self.local, self.slot, self.req_off[:nq + 1]
 
     def rank(self, queries, local_compact, req_offsets, nq, n_items):
-        out = self.rank_out[:n_items]
         self.model.rank_dnn3_dev(self.table, queries.data_ptr(), local_compact.data_ptr(),
-                                 req_offsets.data_ptr(), nq, n_items, out.data_ptr())
-        return out
+                                 req_offsets.data_ptr(), nq, n_items, self.rank_out.data_ptr())
+        return self.rank_out
+
+    def scatter(self, mine, slot, req_offsets, nq, k):
+        slab = self.slab[:nq * k]
+        slab.zero_()
+        self._check(self.ctx.L.pg_scatter_f32_dev(self.ctx.h, mine.data_ptr(), slot.data_ptr(),
+                                                  req_offsets[nq:].data_ptr(), nq * k, slab.data_ptr()))
+        return slab
 
     def fuse_sort(self, rank_scores, recall_scores, nq, k):
         n = nq * k
@@ -127,3 +150,34 @@ class GpuShardEngine:
             self.torch.arange(0, n + 1, k, dtype=self.torch.int32, device=self.dev)
         self._check(L.pg_sort_scores_dev(h, fused.data_ptr(), seg.data_ptr(), nq, n, k, 1, order.data_ptr()))
         return fused.view(nq, k), order.view(nq, k)
+
+    def _dpp_buffers(self, n):
+        t = self.torch
+        if self.c_rows is None or self.c_rows.numel() < n:
+            self.c_rows = t.empty(n, dtype=t.int64, device=self.dev)
+            self.c_rel = t.empty(n, dtype=t.float64, device=self.dev)
+            self.c_emb = t.empty((n, self.table.dim), dtype=t.float32, device=self.dev)
+
+    def dpp_candidates(self, order, rows, fused, nq, k, n_cand):
+        self._dpp_buffers(nq * n_cand)
+        c_rows, c_rel = self.c_rows[:nq * n_cand], self.c_rel[:nq * n_cand]
+        self._check(self.ctx.L.pg_dpp_candidates_dev(self.ctx.h, order.contiguous().data_ptr(), rows.contiguous().data_ptr(),
+                                                     fused.contiguous().data_ptr(), nq, k, n_cand, c_rows.data_ptr(),
+                                                     c_rel.data_ptr()))
+        return c_rows, c_rel
+
+    def gather_owned(self, c_rows, n):
+        emb = self.c_emb[:n]
+        emb.zero_()
+        self._check(self.ctx.L.pg_gather_owned_rows_dev(self.ctx.h, self.table.h, c_rows.data_ptr(), n, emb.data_ptr()))
+        return emb
+
+    def dpp(self, emb, c_rel, nq, n_cand, alpha, topn, window):
+        t = self.torch
+        if self.picks is None or self.picks.numel() < nq * topn:
+            self.picks = t.empty(nq * topn, dtype=t.int32, device=self.dev)
+            self.pick_cnt = t.empty(max(nq, 256), dtype=t.int32, device=self.dev)
+        picks = self.picks[:nq * topn]
+        self._check(self.ctx.L.pg_dpp_batch_dev(self.ctx.h, emb.data_ptr(), c_rel.data_ptr(), nq, n_cand, self.table.dim,
+                                                alpha, topn, window, 1, picks.data_ptr(), self.pick_cnt.data_ptr()))
+        return picks.view(nq, topn)

@@ -2,8 +2,9 @@
 
 The step function under test is the product's; only the engine behind it is a CPU stand-in built
 on the oracle, so what is verified here is everything that is multi-rank specific: shard ranges,
-the all_gather layout handed to the merge, ownership bookkeeping, request-order preservation of
-the owner-computes rank, the all_reduce'd score slab, and that every rank ends with the same,
+the all_gather layout handed to the merge, ownership bookkeeping (device-style compaction into fixed
+buffers), request-order preservation of the owner-computes rank, the all_reduce'd score slab, the DPP stage
+on the merged list with owners contributing the embeddings, and that every rank ends with the same,
 oracle-identical answer."""
 import os
 
@@ -41,21 +42,30 @@ class CpuEngine:
         return torch.from_numpy(rows), torch.from_numpy(scores)
 
     def merge(self, g_rows, g_scores, k):
-        nq = g_rows.shape[0]
+        G, nq, per = g_rows.shape                                    # list-major, exactly as all-gathered
         out_r = np.zeros((nq, k), dtype=np.int64)
         out_s = np.zeros((nq, k), dtype=np.float32)
         for q in range(nq):
-            rr, ss = g_rows[q].numpy().reshape(-1), g_scores[q].numpy().reshape(-1)
+            rr, ss = g_rows[:, q].numpy().reshape(-1), g_scores[:, q].numpy().reshape(-1)
             keep = rr >= 0
             r, s = o.topk_merge(rr[keep].astype(np.uint64)[None], ss[keep][None], k)
             out_r[q], out_s[q] = r.astype(np.int64), s
         return torch.from_numpy(out_r), torch.from_numpy(out_s)
 
-    def rows_to_local(self, rows):
+    def owned_compact(self, rows, nq, k):
         r = rows.numpy()
         owned = (r >= self.off) & (r < self.off + self.tab.shape[0])
-        local = np.where(owned, r - self.off, 0).astype(np.int32)
-        return torch.from_numpy(local), torch.from_numpy(owned)
+        local = np.zeros(nq * k, dtype=np.int32)
+        slot = np.zeros(nq * k, dtype=np.int32)
+        off = np.zeros(nq + 1, dtype=np.int32)
+        p = 0
+        for q in range(nq):                                          # stable, request by request
+            for j in range(k):
+                if owned[q, j]:
+                    local[p], slot[p] = r[q, j] - self.off, q * k + j
+                    p += 1
+            off[q + 1] = p
+        return torch.from_numpy(local), torch.from_numpy(slot), torch.from_numpy(off)
 
     def rank(self, queries, local_compact, req_offsets, nq, n_items):
         ro = req_offsets.numpy()
@@ -67,12 +77,43 @@ class CpuEngine:
                 out[a:b] = o.dnn3_forward(self.w, 0, user, np.tile(self.tab[local_compact[a:b].numpy()], (1, 2)))
         return torch.from_numpy(out)
 
+    def scatter(self, mine, slot, req_offsets, nq, k):
+        slab = np.zeros(nq * k, dtype=np.float32)
+        total = int(req_offsets[nq])
+        slab[slot.numpy()[:total]] = mine.numpy()[:total]
+        return torch.from_numpy(slab)
+
     def fuse_sort(self, rank_scores, recall_scores, nq, k):
         rs = o.widen_f32(rank_scores.numpy())
         cs = o.widen_f32(recall_scores.numpy())
         fused = rs * (1 + cs) ** 0.1
         order = np.stack([o.sort_scores(fused[q], True) for q in range(nq)]).astype(np.int32)
         return torch.from_numpy(fused), torch.from_numpy(order)
+
+    def dpp_candidates(self, order, rows, fused, nq, k, n_cand):
+        head = order.numpy()[:, :n_cand].astype(np.int64)
+        c_rows = np.take_along_axis(rows.numpy(), head, axis=1).reshape(-1)
+        c_rel = np.take_along_axis(fused.numpy(), head, axis=1).reshape(-1)
+        return torch.from_numpy(c_rows.copy()), torch.from_numpy(c_rel.copy())
+
+    def gather_owned(self, c_rows, n):
+        r = c_rows.numpy()
+        emb = np.zeros((n, self.tab.shape[1]), dtype=np.float32)
+        owned = (r >= self.off) & (r < self.off + self.tab.shape[0])
+        emb[owned] = self.tab[r[owned] - self.off]
+        return torch.from_numpy(emb)
+
+    def dpp(self, emb, c_rel, nq, n_cand, alpha, topn, window):
+        e = emb.numpy().reshape(nq, n_cand, -1)
+        rel = c_rel.numpy().reshape(nq, n_cand)
+        out = np.zeros((nq, topn), dtype=np.int32)
+        for q in range(nq):
+            L = o.dpp_kernel_matrix(o.l2_normalize_f64(e[q].astype(np.float64)), rel[q], alpha)
+            out[q] = o.dpp_with_window(L, topn, window)
+        return torch.from_numpy(out)
+
+
+PAGE, DPP = 20, {"candidates": 60, "alpha": 1.0, "window": 10}
 
 
 def _worker(rank, world, port, q):
@@ -84,8 +125,8 @@ def _worker(rank, world, port, q):
         b, e = shard_range(N_ROWS, world, rank)
         eng = CpuEngine(tab[b:e], b, o.Dnn3Weights())
         queries = torch.from_numpy(o.synth_rows(o.SEED_QUERY, 0, NQ, DIM))
-        rows, fused, order = sharded_step(eng, dist if world > 1 else None, torch, queries, NQ, K)
-        q.put((rank, rows.numpy(), fused.numpy(), order.numpy()))
+        rows, fused, order, page = sharded_step(eng, dist if world > 1 else None, torch, queries, NQ, K, PAGE, DPP)
+        q.put((rank, rows.numpy(), fused.numpy(), order.numpy(), page.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -125,11 +166,18 @@ def test_sharded_step_world2_equals_single():
     single = _run(1)[0]
     two = _run(2)
     # every rank ends with the same answer, and it is the single-shard answer
-    for rank, rows, fused, order in two:
+    for rank, rows, fused, order, page in two:
         assert np.array_equal(rows, single[1]), rank
         assert np.array_equal(fused.view(np.uint64), single[2].view(np.uint64)), rank
         assert np.array_equal(order, single[3]), rank
+        assert np.array_equal(page, single[4]), rank                 # the DPP page (cfg 5's sort.dpp_sort stage)
     # and the recall part is the oracle's global top-K
     tab = o.synth_rows(o.SEED_TABLE, 0, N_ROWS, DIM)
     g_rows, _ = o.recall_topk(tab, o.synth_rows(o.SEED_QUERY, 0, NQ, DIM), K)
     assert np.array_equal(single[1].astype(np.uint64), g_rows)
+    # the page is DPP's pick among the head of the sorted list: inside it, PAGE distinct entries, diversity reordered it
+    for qi in range(NQ):
+        head = single[3][qi][:DPP["candidates"]].tolist()
+        pg_ = single[4][qi].tolist()
+        assert len(set(pg_)) == PAGE and set(pg_) <= set(head)
+    assert any(single[4][qi].tolist() != single[3][qi][:PAGE].tolist() for qi in range(NQ))
