@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace pairec {
 
@@ -150,6 +151,10 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         c.ItemType = r.s("ItemType"); c.CachePrefix = r.s("CachePrefix");
         c.CacheAdapter = r.s("CacheAdapter"); c.CacheConfig = r.s("CacheConfig");
         c.RecallCount = (int)r.n("RecallCount"); c.CacheTime = (int)r.n("CacheTime");
+        c.DaoAdapterType = r.at("DaoConf").s("AdapterType");
+        c.VectorDaoAdapterType = r.at("VectorDaoConf").s("AdapterType");
+        c.HologresName = r.at("VectorDaoConf").s("HologresName");
+        c.VectorAlgoType = r.s("VectorAlgoType");
         out->RecallConfs.push_back(c);
     }
     for (const auto& kv : root.at("RankConf").obj) {
@@ -172,18 +177,26 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         c.Name = name; c.Alpha = d.d("Alpha", 1.0); c.WindowSize = (int)d.n("WindowSize");
         c.CandidateCount = (int)d.n("CandidateCount"); c.MinScorePercent = d.d("MinScorePercent");
         c.NormalizeEmb = !is_false(d.s("NormalizeEmb"));    // dpp_sort.go:95-97
+        c.EnsurePositiveSim = !is_false(d.s("EnsurePositiveSim"));   // :98-100
+        c.AbortRunCount = (int)d.n("AbortRunCount");
+        c.FilterRetrieveIds = str_list(d.at("FilterRetrieveIds"));
+        c.EmbeddingHookNames = str_list(d.at("EmbeddingHookNames"));
         return c;
     };
     for (const auto& d : root.at("DPPConf").arr) out->DPPConf.push_back(parse_dpp(d, d.s("Name")));
-    // SortConfs (recconf.go:86, sort/sort.go:162-200): the DPPSort / SSDSort entries; other SortTypes are
-    // rule-based host sorts outside this engine's scope and are ignored here
-    for (const auto& sc : root.at("SortConfs").arr) {
+    // SortConfs (recconf.go:86, sort/sort.go:162-200); the GPU diversity sorts of a pairec process are declared in
+    // UserDefineConfs.pairec_gpu.Sorts with the same nested DPPConf / SSDConf objects (Engine::Create)
+    auto parse_sort = [&](const json::Value& sc) {
         SortConfig c;
         c.Name = sc.s("Name"); c.SortType = sc.s("SortType");
+        c.SortByField = sc.s("SortByField");
+        c.SwitchThreshold = sc.d("SwitchThreshold");
         if (c.SortType == "DPPSort") {
             c.DPPConf = parse_dpp(sc.at("DPPConf"), c.Name);
+            c.HologresName = sc.at("DPPConf").at("DaoConf").s("HologresName");
         } else if (c.SortType == "SSDSort") {
             const json::Value& d = sc.at("SSDConf");
+            c.HologresName = d.at("DaoConf").s("HologresName");
             SSDSortConfig& s = c.SSDConf;
             s.Name = c.Name;
             if (d.d("Gamma") > 0) s.Gamma = d.d("Gamma");                         // ssd_sort.go:81-83
@@ -195,12 +208,21 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
             s.NormalizeEmb = !is_false(d.s("NormalizeEmb"));                      // :90-92
             s.EnsurePositiveSim = !is_false(d.s("EnsurePositiveSim"));            // :93-95
             s.FilterRetrieveIds = str_list(d.at("FilterRetrieveIds"));
-        } else {
-            continue;
         }
-        out->SortConfs.push_back(c);
-    }
+        return c;
+    };
+    for (const auto& sc : root.at("SortConfs").arr) out->SortConfs.push_back(parse_sort(sc));
     out->UserDefineConfs = root.at("UserDefineConfs");
+    // the GPU plug-ins' own declarations, in the shapes of RecallConfig / SortConfig
+    for (const auto& r : out->UserDefineConfs.at("pairec_gpu").at("Recalls").arr) {
+        RecallConfig c;
+        c.Name = r.s("Name"); c.Kind = r.s("Kind", "vector"); c.RecallAlgo = r.s("RecallAlgo");
+        c.ItemType = r.s("ItemType"); c.CachePrefix = r.s("CachePrefix");
+        c.CacheAdapter = r.s("CacheAdapter"); c.CacheConfig = r.s("CacheConfig");
+        c.RecallCount = (int)r.n("RecallCount"); c.CacheTime = (int)r.n("CacheTime");
+        out->GpuRecalls.push_back(c);
+    }
+    for (const auto& sc : out->UserDefineConfs.at("pairec_gpu").at("Sorts").arr) out->GpuSorts.push_back(parse_sort(sc));
     return true;
 }
 }  // namespace recconf
@@ -226,8 +248,111 @@ bool AlgorithmFactory::Run(const std::string& name, const AlgoData& data, AlgoRe
 }
 }  // namespace algorithm
 
+// ---- response decoders ---------------------------------------------------------------------------
+namespace algorithm {
+namespace decode {
+std::vector<AlgoResponse> EasyrecResponse(const std::vector<std::string>& item_ids,
+                                          const std::map<std::string, std::vector<double>>& results) {
+    std::vector<AlgoResponse> ret;                          // easyrec_response.go:226-232
+    for (const auto& id : item_ids) {
+        auto it = results.find(id);
+        ret.emplace_back(it != results.end() && !it->second.empty() ? it->second[0] : 0.0);
+    }
+    return ret;
+}
+bool EasyrecMutValResponse(const std::vector<std::string>& item_ids, const std::vector<std::string>& outputs,
+                           const std::map<std::string, std::vector<double>>& results,
+                           std::vector<AlgoResponse>* out, std::string* err) {
+    out->clear();                                           // easyrec_response.go:41-69
+    for (const auto& id : item_ids) {
+        AlgoResponse r;
+        r.multiValModule = true;
+        auto it = results.find(id);
+        if (it != results.end()) {
+            if (outputs.size() != it->second.size()) {
+                if (err) *err = "outputs size is not equal scores";
+                out->clear();
+                return false;
+            }
+            for (size_t k = 0; k < outputs.size(); ++k) r.scoreArr[outputs[k]] = it->second[k];
+        } else {
+            for (const auto& o : outputs) r.scoreArr[o] = 0.0;
+        }
+        out->push_back(std::move(r));
+    }
+    return true;
+}
+bool EasyrecMutClassificationResponse(const std::vector<std::string>& item_ids,
+                                      const std::map<std::string, std::pair<std::vector<float>, std::vector<long long>>>& tf_outputs,
+                                      std::vector<AlgoResponse>* out, std::string* err) {
+    out->assign(item_ids.size(), AlgoResponse());           // easyrec_response.go:145-199
+    for (const auto& kv : tf_outputs) {
+        const auto& vals = kv.second.first;
+        const auto& shape = kv.second.second;
+        const size_t width = shape.size() >= 2 ? (size_t)shape[1] : 1;        // [N, C] → C per item; [N] → 1
+        if (vals.size() < item_ids.size() * width) {
+            if (err) *err = "output " + kv.first + " holds fewer values than items";
+            out->clear();
+            return false;
+        }
+        for (size_t i = 0; i < item_ids.size(); ++i) {
+            std::vector<double>& dst = (*out)[i].mulClassifyArr[kv.first];
+            for (size_t c = 0; c < width; ++c) dst.push_back((double)vals[i * width + c]);   // float32 → float64
+        }
+    }
+    return true;
+}
+double AlinkFMScore(double prediction_result, double prediction_score) {
+    return prediction_result == 0.0 ? 1 - prediction_score : prediction_score;     // fm_response.go:28-34
+}
+std::vector<AlgoResponse> TFServingResponse(const std::vector<std::vector<double>>& outputs) {
+    std::vector<AlgoResponse> ret;                          // tfserving/response.go:58-62
+    for (const auto& val : outputs)
+        for (double score : val) ret.emplace_back(score);
+    return ret;
+}
+std::vector<AlgoResponse> WidenF32(const float* scores, size_t n) {
+    std::vector<AlgoResponse> ret;
+    for (size_t i = 0; i < n; ++i) ret.emplace_back((double)scores[i]);
+    return ret;
+}
+}  // namespace decode
+}  // namespace algorithm
+
 // ---- recall --------------------------------------------------------------------------------------
 namespace recall {
+LoadOutcome CheckRecallConf(const recconf::RecallConfig& c) {
+    const std::string& t = c.RecallType;
+    auto panic = [](const std::string& m) { return LoadOutcome{LoadOutcome::kPanic, m}; };
+    auto unavailable = [&](const std::string& what) {
+        return LoadOutcome{LoadOutcome::kUnavailable, "recall " + c.Name + ": " + what + " is not available in the standalone mirror (no datasources)"};
+    };
+    auto one_of = [](const std::string& v, std::initializer_list<const char*> l) {
+        for (const char* x : l) if (v == x) return true;
+        return false;
+    };
+    if (t == "MockRecall" || t == "OnlineVectorRecall") return LoadOutcome{};       // constructors touch no datasource
+    if (t == "VectorRecall") {                                // module.NewVectorDao (module/vector_dao.go:17-33)
+        if (one_of(c.DaoAdapterType, {"redis", "hbase"}) || one_of(c.VectorDaoAdapterType, {"hologres", "mysql", "clickhouse", "be"}))
+            return unavailable("a VectorDao over " + (c.DaoAdapterType.empty() ? c.VectorDaoAdapterType : c.DaoAdapterType));
+        return panic("not found VectorDao implement");
+    }
+    if (t == "UserCustomRecall") {                            // module.NewUserCustomRecallDao (user_custom_recall_dao.go:12-28)
+        if (one_of(c.DaoAdapterType, {"mysql", "tablestore", "hologres", "redis", "clickhouse", "featurestore"}))
+            return unavailable("a UserCustomRecallDao over " + c.DaoAdapterType);
+        return panic("not found UserCustomRecallDao implement");
+    }
+    if (one_of(t, {"HologresVectorRecall", "HologresVectorRecallV2", "I2IVectorRecall", "OnlineHologresVectorRecall"}))
+        // holo.GetPostgres(VectorDaoConf.HologresName) → panic(err) (persist/holo: "Postgres not found, name:…")
+        return panic("Postgres not found, name:" + c.HologresName);
+    if (one_of(t, {"UserCollaborativeFilterRecall", "UserTopicRecall", "ItemCollaborativeFilterRecall", "UserGroupHotRecall",
+                   "UserGlobalHotRecall", "ColdStartRecall", "BeRecall", "RealTimeU2IRecall", "GraphRecall", "OpenSearchRecall",
+                   "RecallEngineRecall"}))
+        return c.DaoAdapterType.empty() ? panic("not found " + t + " DAO implement (the constructor's DAO factory panics without DaoConf.AdapterType)")
+                                        : unavailable("a DAO over " + c.DaoAdapterType);
+    // unknown type — and "MilvusVectorRecall", whose constructor call is commented out (recall.go:78-79): recall stays nil
+    return panic("recall empty, name:" + c.Name);
+}
 std::shared_ptr<Recall> Registry::GetRecall(const std::string& name, std::string* err) {
     auto it = recalls_.find(name);
     if (it == recalls_.end()) {
@@ -358,7 +483,16 @@ struct GpuFaissAlgorithm : algorithm::IAlgorithm {
         std::vector<uint64_t> rows(req.K);
         std::vector<float> scores(req.K);
         uint32_t cnt = 0;
-        if (pg_recall_topk(e->ctx, e->table, req.Vector.data(), 1, req.K, rows.data(), scores.data(), &cnt) != PG_OK) {
+        if (e->coalesce) {
+            // one request per call, many calls at once (one goroutine per recall, service/recall.go:129-145): the library
+            // batches them into shared table passes
+            pg_coalescer* co = e->RecallCoalescer(req.K, err);
+            if (!co) return false;
+            if (pg_coalescer_recall(co, req.Vector.data(), rows.data(), scores.data(), &cnt) != PG_OK) {
+                if (err) *err = pg_err("pg_coalescer_recall");
+                return false;
+            }
+        } else if (pg_recall_topk(e->ctx, e->table, req.Vector.data(), 1, req.K, rows.data(), scores.data(), &cnt) != PG_OK) {
             if (err) *err = pg_err("pg_recall_topk");
             return false;
         }
@@ -374,8 +508,32 @@ struct GpuFaissAlgorithm : algorithm::IAlgorithm {
 // algorithm.IAlgorithm replacing EasModel / TFservingModel for the DNN rank model
 struct GpuDnnAlgorithm : algorithm::IAlgorithm {
     Engine* e;
-    explicit GpuDnnAlgorithm(Engine* eng) : e(eng) {}
+    std::string name;
+    std::vector<std::string> outputs;            // empty: one score; else a multi-output model, one DNN3 head model per output
+    GpuDnnAlgorithm(Engine* eng, std::string n, std::vector<std::string> outs) : e(eng), name(std::move(n)), outputs(std::move(outs)) {}
     bool Init(const recconf::AlgoConfig&, std::string*) override { return true; }
+    bool Score(const pg_model* m, const algorithm::RankRequest& req, const std::vector<uint32_t>& rows, std::vector<float>* scores,
+               std::string* err) {
+        const uint32_t n = (uint32_t)rows.size();
+        const uint32_t off[2] = {0, n};
+        scores->resize(n);
+        if (!m) { if (err) *err = "dnn: model of " + name + " not loaded"; return false; }
+        if (e->coalesce && m == e->model) {
+            // one call per 100-item batch and goroutine (rank_service.go:264-289): batched across callers by the library
+            pg_coalescer* co = e->RankCoalescer(err);
+            if (!co) return false;
+            if (pg_coalescer_rank_dnn3(co, req.UserVector.data(), rows.data(), n, scores->data()) != PG_OK) {
+                if (err) *err = pg_err("pg_coalescer_rank_dnn3");
+                return false;
+            }
+            return true;
+        }
+        if (pg_rank_dnn3(e->ctx, m, e->table, req.UserVector.data(), rows.data(), off, 1, scores->data()) != PG_OK) {
+            if (err) *err = pg_err("pg_rank_dnn3");
+            return false;
+        }
+        return true;
+    }
     bool Run(const algorithm::AlgoData& data, algorithm::AlgoResult* out, std::string* err) override {
         if (data.kind != algorithm::AlgoData::kRank) { if (err) *err = "dnn: invalid request type"; return false; }
         const auto& req = data.rank;
@@ -383,14 +541,46 @@ struct GpuDnnAlgorithm : algorithm::IAlgorithm {
         std::vector<uint32_t> rows(n);
         for (uint32_t i = 0; i < n; ++i)
             if (!e->RowOfId(req.ItemIds[i], &rows[i])) { if (err) *err = "dnn: unknown item id " + req.ItemIds[i]; return false; }
-        const uint32_t off[2] = {0, n};
-        std::vector<float> scores(n);
-        if (pg_rank_dnn3(e->ctx, e->model, e->table, req.UserVector.data(), rows.data(), off, 1, scores.data()) != PG_OK) {
-            if (err) *err = pg_err("pg_rank_dnn3");
+        std::vector<float> scores;
+        if (outputs.empty()) {
+            if (!Score(e->model, req, rows, &scores, err)) return false;
+            out->responses = algorithm::decode::WidenF32(scores.data(), n);             // float32 → float64 widening
+            return true;
+        }
+        // multi-output model (EasyrecResponse.multiValModule, easyrec_response.go:35-70): GetModuleType() = true and a score
+        // per output name; RankService writes them as "<algo>_<output>" (rank_service.go:315-319)
+        out->responses.assign(n, algorithm::AlgoResponse());
+        for (const auto& o : outputs) {
+            auto it = e->named_models.find(name + "/" + o);
+            if (!Score(it == e->named_models.end() ? nullptr : it->second, req, rows, &scores, err)) return false;
+            for (uint32_t i = 0; i < n; ++i) {
+                out->responses[i].multiValModule = true;
+                out->responses[i].scoreArr[o] = (double)scores[i];
+            }
+        }
+        return true;
+    }
+};
+
+// algorithm.IAlgorithm of a vector model serving an OnlineVectorRecall: user features → user embedding → its
+// FaissNeighNum nearest items (torchrecEmbeddingItemsResponseFunc, easyrec_response.go:700-734)
+struct GpuOnlineVectorAlgorithm : algorithm::IAlgorithm {
+    Engine* e;
+    explicit GpuOnlineVectorAlgorithm(Engine* eng) : e(eng) {}
+    bool Init(const recconf::AlgoConfig&, std::string*) override { return true; }
+    bool Run(const algorithm::AlgoData& data, algorithm::AlgoResult* out, std::string* err) override {
+        if (data.kind != algorithm::AlgoData::kEmbedding) { if (err) *err = "online vector: invalid request type"; return false; }
+        if (!e->fm2t || !e->item_emb) { if (err) *err = "online vector: vector model or item-embedding table not loaded"; return false; }
+        const uint32_t k = (uint32_t)std::max(data.emb.FaissNeighNum, 0);
+        if (k == 0) return true;
+        std::vector<uint64_t> rows(k);
+        std::vector<float> scores(k);
+        uint32_t cnt = 0;
+        if (pg_online_vector_recall(e->ctx, e->fm2t, e->item_emb, data.emb.UserVector.data(), 1, k, rows.data(), scores.data(), &cnt) != PG_OK) {
+            if (err) *err = pg_err("pg_online_vector_recall");
             return false;
         }
-        out->responses.resize(n);
-        for (uint32_t i = 0; i < n; ++i) out->responses[i].score = (double)scores[i];   // float32 → float64 widening
+        for (uint32_t i = 0; i < cnt; ++i) out->embeddingItems.push_back({e->IdOfRow(rows[i]), (double)scores[i]});
         return true;
     }
 };
@@ -466,6 +656,80 @@ struct GpuVectorRecall : recall::Recall, recall::ICloneRecall {
     }
 };
 
+// recall.Recall with the body of I2IVectorRecall.GetCandidateItems (item_2_item_vector_racall.go:51-152): the trigger is
+// the request's "item_id" parameter, its embedding (dao.VectorString) the query
+struct GpuI2IVectorRecall : recall::Recall {
+    Engine* e;
+    recconf::RecallConfig conf;
+    GpuI2IVectorRecall(Engine* eng, recconf::RecallConfig c) : e(eng), conf(std::move(c)) {}
+    std::vector<module::ItemPtr> GetCandidateItems(module::User*, context::RecommendContext* ctx) override {
+        std::vector<module::ItemPtr> ret;
+        uint32_t row = 0;
+        if (!ctx || !e->RowOfId(ctx->GetParameter("item_id"), &row)) return ret;       // VectoryEmptyError: logged, empty
+        const uint32_t k = (uint32_t)std::max(conf.RecallCount, 0);
+        if (k == 0) return ret;
+        std::vector<uint64_t> rows(k);
+        std::vector<float> scores(k);
+        uint32_t cnt = 0;
+        if (pg_i2i_recall(e->ctx, e->table, &row, 1, e->table, k, rows.data(), scores.data(), &cnt) != PG_OK) return ret;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            auto item = std::make_shared<module::Item>(e->IdOfRow(rows[i]));
+            item->RetrieveId = conf.Name;
+            item->ItemType = conf.ItemType;
+            item->Score = (double)scores[i];                                            // `distance float64` (:130-139)
+            ret.push_back(item);
+        }
+        return ret;
+    }
+};
+
+// recall.Recall with the body of OnlineVectorRecall.GetCandidateItems (online_vector_recall.go:73-155, cache omitted):
+// user features → PBRequest{FaissNeighNum = recallCount} → algorithm.Run(recallAlgo) → embedding items → Items
+struct GpuOnlineVectorRecall : recall::Recall {
+    Engine* e;
+    recconf::RecallConfig conf;
+    GpuOnlineVectorRecall(Engine* eng, recconf::RecallConfig c) : e(eng), conf(std::move(c)) {}
+    std::vector<module::ItemPtr> GetCandidateItems(module::User* user, context::RecommendContext*) override {
+        std::vector<module::ItemPtr> ret;
+        std::string value, err;
+        if (!e->user_vectors.VectorString(user->Id, &value, &err)) return ret;
+        algorithm::AlgoData data;
+        data.kind = algorithm::AlgoData::kEmbedding;
+        data.emb.UserVector = recall::ParseVectorString(value);
+        data.emb.FaissNeighNum = conf.RecallCount;
+        algorithm::AlgoResult result;
+        if (!e->algorithms.Run(conf.RecallAlgo, data, &result, &err)) return ret;       // logged, empty result
+        // only the TorchRec vector flavours carry embedding items (:118-133)
+        if (conf.VectorAlgoType != "torchrec_tdm" && conf.VectorAlgoType != "torchrec_vector") return ret;
+        for (const auto& info : result.embeddingItems) {
+            auto item = std::make_shared<module::Item>(info.ItemId);
+            item->Score = info.Score;
+            item->RetrieveId = conf.Name;
+            ret.push_back(item);
+        }
+        if (conf.RecallCount > 0 && (int)ret.size() > conf.RecallCount) ret.resize((size_t)conf.RecallCount);
+        return ret;
+    }
+};
+
+// MockRecall (service/recall/mock_recall.go:27-41): recallCount random ids with random scores
+struct MockRecall : recall::Recall {
+    recconf::RecallConfig conf;
+    explicit MockRecall(recconf::RecallConfig c) : conf(std::move(c)) {}
+    std::vector<module::ItemPtr> GetCandidateItems(module::User*, context::RecommendContext*) override {
+        std::vector<module::ItemPtr> ret;
+        uint64_t s = 0x9E3779B97F4A7C15ull;
+        while ((int)ret.size() < conf.RecallCount) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            auto item = std::make_shared<module::Item>(std::to_string((uint32_t)(s >> 32)));
+            item->RetrieveId = conf.Name;
+            item->Score = (double)(s >> 11) * (1.0 / 9007199254740992.0);
+            ret.push_back(item);
+        }
+        return ret;
+    }
+};
+
 bool sort_items(Engine* e, sort::SortData* d, bool desc, std::string* err) {
     const uint32_t n = (uint32_t)d->Data.size();
     if (n == 0) return true;
@@ -496,44 +760,114 @@ struct GpuDPPSort : sort::ISort {                        // sort/dpp_sort.go:108
     Engine* e;
     recconf::DPPSortConfig conf;
     GpuDPPSort(Engine* eng, recconf::DPPSortConfig c) : e(eng), conf(std::move(c)) {}
-    bool Sort(sort::SortData* d, std::string* err) override {
-        auto& items = d->Data;
+    // doSort (:271-351): experiment parameters override the config (:275-278,374,382)
+    bool DoSort(std::vector<module::ItemPtr>* itemsp, sort::SortData* d, std::string* err) {
+        auto& items = *itemsp;
         if (items.empty()) return true;
         const int size = d->Context ? d->Context->Size : 10;
-        const int window = conf.WindowSize > 0 ? conf.WindowSize : 10;
-        if ((conf.CandidateCount > 0 || conf.MinScorePercent > 0) && (int)items.size() > size) {   // :280-300
+        const context::RecommendContext none;
+        const context::RecommendContext& cx = d->Context ? *d->Context : none;
+        int window = (int)cx.GetInt("dpp_window_size", conf.WindowSize > 0 ? conf.WindowSize : 10);
+        const int candidateCnt = (int)cx.GetInt("dpp_candidate_count", conf.CandidateCount);
+        const double minScorePercent = cx.GetFloat("dpp_min_score_percent", conf.MinScorePercent);
+        const double alpha = cx.GetFloat("dpp_alpha", conf.Alpha);
+        const int doNorm = (int)cx.GetInt("dpp_norm_relevance_score", 0);
+        if ((candidateCnt > 0 || minScorePercent > 0) && (int)items.size() > size) {   // :280-300
             sort::SortData tmp = *d;
+            tmp.Data = items;
             if (!sort_items(e, &tmp, true, err)) return false;
             items.swap(tmp.Data);
-            if (conf.CandidateCount > 0) {
-                const size_t cnt = (size_t)std::max(size, conf.CandidateCount);
+            if (candidateCnt > 0) {
+                const size_t cnt = (size_t)std::max(size, candidateCnt);
                 if (cnt < items.size()) items.resize(cnt);
             }
-            if (conf.MinScorePercent > 0 && (int)items.size() > size) {
+            if (minScorePercent > 0 && (int)items.size() > size) {
                 size_t idx = (size_t)size;
                 const double mx = items[0]->Score;
                 for (; idx < items.size(); ++idx)
-                    if (items[idx]->Score / mx < conf.MinScorePercent) break;
+                    if (items[idx]->Score / mx < minScorePercent) break;
                 items.resize(idx);
             }
         }
         const uint32_t n = (uint32_t)items.size();
         std::vector<uint32_t> rows(n);
-        std::vector<double> rel(n);
+        std::vector<double> rel(n), used(n);
         for (uint32_t i = 0; i < n; ++i) {
             if (!e->RowOfId(items[i]->Id, &rows[i])) { if (err) *err = "dpp: unknown item id"; return false; }
             rel[i] = items[i]->Score;
         }
+        pg_dpp_options o;
+        memset(&o, 0, sizeof o);
+        o.alpha = alpha;
+        o.topn = (uint32_t)std::max(size, 0);
+        o.window = (uint32_t)std::max(window, 0);
+        o.normalize_emb = conf.NormalizeEmb ? 1 : 0;
+        o.ensure_pos_similarity = conf.EnsurePositiveSim ? 1 : 0;
+        o.norm_relevance_score = (doNorm == 1 || doNorm == 2) ? doNorm : 0;
+        o.has_table = 1;
         std::vector<uint32_t> idx((size_t)std::max(size, 1));
         uint32_t cnt = 0;
-        if (pg_dpp(e->ctx, e->table, rows.data(), rel.data(), n, conf.Alpha, (uint32_t)size, (uint32_t)window,
-                   conf.NormalizeEmb ? 1 : 0, idx.data(), &cnt) != PG_OK) {
+        const int rc = pg_dpp_ex(e->ctx, e->table, rows.data(), rel.data(), n, &o, nullptr, idx.data(), &cnt, used.data());
+        if (rc == PG_ERR_ARITH) return true;            // "all item score is zero": KernelMatrix errs, items stay as they are (:314-317)
+        if (rc != PG_OK) {
             if (err) *err = pg_err("pg_dpp");
             return false;
         }
+        for (uint32_t i = 0; i < n; ++i) items[i]->AddAlgoScore("dpp_relevance_score", used[i]);     // :410
         std::vector<module::ItemPtr> out;
         for (uint32_t i = 0; i < cnt; ++i) out.push_back(items[idx[i]]);
         items.swap(out);
+        return true;
+    }
+    bool Sort(sort::SortData* d, std::string* err) override {
+        auto& items = d->Data;
+        if (items.empty()) return true;
+        if (conf.AbortRunCount > 0 && (int)items.size() <= conf.AbortRunCount)      // :127-132
+            return sort_items(e, d, true, err);
+        if (!conf.FilterRetrieveIds.empty()) {                                       // :134-160
+            std::vector<module::ItemPtr> backup, selected;
+            for (auto& it : items) {
+                const bool f = std::find(conf.FilterRetrieveIds.begin(), conf.FilterRetrieveIds.end(), it->RetrieveId) !=
+                               conf.FilterRetrieveIds.end();
+                (f ? backup : selected).push_back(it);
+            }
+            if (!DoSort(&selected, d, err)) return false;
+            selected.insert(selected.end(), backup.begin(), backup.end());
+            items.swap(selected);
+            return true;
+        }
+        return DoSort(&items, d, err);
+    }
+};
+
+// AlgoScoreSort (sort/algo_score_sort.go:38-66): descending by SortByField unless the best Item.Score exceeds
+// SwitchThreshold, then by current_score.  (The reference's comparator assigns a failed RIGHT lookup's fallback to the
+// left score — `iScore = items[j].Score` — which only matters when the field is missing; here a missing field falls
+// back to the item's own score on both sides.)
+struct GpuAlgoScoreSort : sort::ISort {
+    Engine* e;
+    std::string sortByField;
+    double switchThreshold;
+    GpuAlgoScoreSort(Engine* eng, const recconf::SortConfig& c)
+        : e(eng), sortByField(c.SortByField.empty() ? "current_score" : c.SortByField), switchThreshold(c.SwitchThreshold) {}
+    bool Sort(sort::SortData* d, std::string* err) override {
+        const uint32_t n = (uint32_t)d->Data.size();
+        if (n == 0) return true;
+        double maxScore = -1e300;
+        for (const auto& it : d->Data) maxScore = std::max(maxScore, it->Score);
+        const std::string field = maxScore > switchThreshold ? "current_score" : sortByField;
+        std::vector<double> key(n);
+        for (uint32_t i = 0; i < n; ++i)
+            if (!d->Data[i]->FloatExprData(field, &key[i])) key[i] = d->Data[i]->Score;
+        const uint32_t seg[2] = {0, n};
+        std::vector<uint32_t> order(n);
+        if (pg_sort_scores(e->ctx, key.data(), seg, 1, 1, order.data()) != PG_OK) {
+            if (err) *err = pg_err("pg_sort_scores");
+            return false;
+        }
+        std::vector<module::ItemPtr> out(n);
+        for (uint32_t i = 0; i < n; ++i) out[i] = d->Data[order[i]];
+        d->Data.swap(out);
         return true;
     }
 };
@@ -647,8 +981,20 @@ bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, co
             algorithm::AlgoResult res;
             std::string aerr;
             if (!e->algorithms.Run(algo, data, &res, &aerr)) continue;       // logged; batch skipped
-            for (size_t j = 0; j < res.responses.size() && b0 + j < b1; ++j)
-                items[b0 + j]->AddAlgoScore(algo, res.responses[j].GetScore());
+            for (size_t j = 0; j < res.responses.size() && b0 + j < b1; ++j) {          // rank_service.go:314-335
+                const algorithm::AlgoResponse& r = res.responses[j];
+                if (r.GetModuleType()) {
+                    for (const auto& kv : r.GetScoreMap()) items[b0 + j]->AddAlgoScore(algo + "_" + kv.first, kv.second);
+                } else if (r.IsMultiClassify()) {
+                    for (const auto& kv : r.GetClassifyMap()) {
+                        if (kv.second.size() == 1) items[b0 + j]->AddAlgoScore(algo + "_" + kv.first, kv.second[0]);
+                        else for (size_t c = 0; c < kv.second.size(); ++c)
+                            items[b0 + j]->AddAlgoScore(algo + "_" + kv.first + "_" + std::to_string(c), kv.second[c]);
+                    }
+                } else {
+                    items[b0 + j]->AddAlgoScore(algo, r.GetScore());
+                }
+            }
         }
     }
     if (!conf.RankScore.empty()) {                                           // :339-363
@@ -679,10 +1025,49 @@ bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, co
 // ---- engine --------------------------------------------------------------------------------------
 Engine::~Engine() {
     if (ctx) {
+        for (auto& kv : co_recall) pg_coalescer_destroy(kv.second);
+        if (co_rank) pg_coalescer_destroy(co_rank);
         if (model) pg_model_destroy(ctx, model);
+        for (auto& kv : named_models) pg_model_destroy(ctx, kv.second);
+        if (fm2t) pg_model_destroy(ctx, fm2t);
+        if (item_emb) pg_table_destroy(ctx, item_emb);
         if (table) pg_table_destroy(ctx, table);
         pg_shutdown(ctx);
     }
+}
+
+pg_coalescer* Engine::RecallCoalescer(uint32_t k, std::string* err) {
+    std::lock_guard<std::mutex> g(co_mu);
+    auto it = co_recall.find(k);
+    if (it != co_recall.end()) return it->second;
+    pg_coalescer_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.k = k;
+    cfg.max_wait_us = coalesce_wait_us;
+    cfg.depth = coalesce_depth;
+    pg_coalescer* c = nullptr;
+    if (pg_coalescer_create(ctx, table, nullptr, nullptr, nullptr, &cfg, &c) != PG_OK) {
+        if (err) *err = std::string("pg_coalescer_create: ") + pg_last_error();
+        return nullptr;
+    }
+    co_recall[k] = c;
+    return c;
+}
+
+pg_coalescer* Engine::RankCoalescer(std::string* err) {
+    std::lock_guard<std::mutex> g(co_mu);
+    if (co_rank) return co_rank;
+    pg_coalescer_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.k = 5000;                                  // sizes a rank batch: as many candidates as 256 requests x 5000
+    cfg.max_wait_us = coalesce_wait_us;
+    cfg.depth = coalesce_depth;
+    cfg.max_rank_items = 16384;
+    if (pg_coalescer_create(ctx, table, model, nullptr, nullptr, &cfg, &co_rank) != PG_OK) {
+        if (err) *err = std::string("pg_coalescer_create: ") + pg_last_error();
+        return nullptr;
+    }
+    return co_rank;
 }
 
 bool Engine::RowOfId(const std::string& id, uint32_t* row) const {
@@ -697,8 +1082,29 @@ bool Engine::RowOfId(const std::string& id, uint32_t* row) const {
 Engine* Engine::Create(const std::string& config_json, std::string* err) {
     std::unique_ptr<Engine> e(new Engine());
     if (!recconf::RecommendConfig::Parse(config_json, &e->config, err)) return nullptr;
-    // GPU plugin settings live in UserDefineConfs["pairec_gpu"]: unknown RecallType / SortType values
-    // in RecallConfs / SortConfs would panic the reference's factories (recall.go:99-101, sort.go:196-198)
+    // What the reference's own loaders would do with RecallConfs / SortConfs comes first (they run in runBeforeStart,
+    // before any start hook): a config that panics pairec must not start here either.
+    for (const auto& r : e->config.RecallConfs) {
+        const recall::LoadOutcome o = recall::CheckRecallConf(r);
+        if (o.kind == recall::LoadOutcome::kPanic) { if (err) *err = "panic: " + o.message; return nullptr; }
+        if (o.kind == recall::LoadOutcome::kUnavailable) { if (err) *err = o.message; return nullptr; }
+    }
+    for (const auto& sc : e->config.SortConfs) {
+        // RegisterSortWithConfig (sort/sort.go:162-200): DPPSort / SSDSort open their Hologres datasource first
+        // (NewDPPSort, dpp_sort.go:60-64; NewSSDSort, ssd_sort.go:52-56) and panic without it; an unknown SortType
+        // leaves s nil → panic("Sort is nil, name:…")
+        if (sc.SortType == "DPPSort" || sc.SortType == "SSDSort") {
+            if (err) *err = "panic: Postgres not found, name:" + sc.HologresName + " (SortConfs entry \"" + sc.Name + "\": " + sc.SortType +
+                            " opens its Hologres datasource in the constructor; GPU diversity sorts are declared in UserDefineConfs.pairec_gpu.Sorts)";
+            return nullptr;
+        }
+        static const char* host_sorts[] = {"AlgoScoreSort", "MultiRecallMixSort", "BoostScoreSort", "DiversityRuleSort", "TrafficControlSort",
+                                           "BoostScoreByWeight", "DistinctIdSort", "CustomFieldSort", "ConditionSort"};
+        bool known = false;
+        for (const char* r : host_sorts) known |= sc.SortType == r;
+        if (!known) { if (err) *err = "panic: Sort is nil, name:" + sc.Name; return nullptr; }
+    }
+    // GPU plugin settings live in UserDefineConfs["pairec_gpu"]: they cannot be declared in RecallConfs / SortConfs
     const json::Value& g = e->config.UserDefineConfs.at("pairec_gpu");
     if (g.type != json::Value::Object) { if (err) *err = "UserDefineConfs.pairec_gpu missing"; return nullptr; }
     const json::Value& tb = g.at("Table");
@@ -711,22 +1117,60 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
         if (err) *err = pg_err("pg_table_fill_synthetic");
         return nullptr;
     }
+    const json::Value& co = g.at("Coalesce");
+    if (co.type == json::Value::Object) {
+        e->coalesce = true;
+        e->coalesce_wait_us = (uint32_t)co.n("MaxWaitUs", 0);
+        e->coalesce_depth = (uint32_t)co.n("Depth", 0);
+    }
+    const json::Value& ov = g.at("OnlineVector");          // the vector model's item side: item-tower outputs as a table
+    if (ov.type == json::Value::Object) {
+        e->item_emb_rows = (uint64_t)ov.n("Rows", (long long)e->table_rows);
+        if (pg_table_create(e->ctx, e->item_emb_rows, (uint32_t)ov.n("Dim", 64), 0, &e->item_emb) != PG_OK ||
+            pg_table_fill_synthetic(e->ctx, e->item_emb, (uint64_t)ov.n("SyntheticSeed", 0x5EED0077), 1) != PG_OK) {
+            if (err) *err = pg_err("online vector item table");
+            return nullptr;
+        }
+    }
     // built-in sorts (sort.go init(): "ItemRankScore" is registered by default)
     e->sorts.RegisterSort("ItemRankScore", std::make_shared<GpuItemRankScoreSort>(e.get()), nullptr);
     e->sorts.RegisterSort("ItemScore", std::make_shared<GpuItemScoreSort>(e.get()), nullptr);
     for (const auto& d : e->config.DPPConf) e->sorts.RegisterSort(d.Name, std::make_shared<GpuDPPSort>(e.get(), d), nullptr);
-    for (const auto& sc : e->config.SortConfs) {          // RegisterSortWithConfig (sort/sort.go:162-200)
-        if (sc.SortType == "DPPSort") e->sorts.RegisterSortWithConfig(sc.Name, std::make_shared<GpuDPPSort>(e.get(), sc.DPPConf));
-        if (sc.SortType == "SSDSort") e->sorts.RegisterSortWithConfig(sc.Name, std::make_shared<GpuSSDSort>(e.get(), sc.SSDConf));
+    // SortConfs (validated above): AlgoScoreSort is host logic over a GPU sort; the other rule-based sorts are outside
+    // this engine's scope and are skipped
+    for (const auto& sc : e->config.SortConfs)
+        if (sc.SortType == "AlgoScoreSort") e->sorts.RegisterSortWithConfig(sc.Name, std::make_shared<GpuAlgoScoreSort>(e.get(), sc));
+    // the GPU sorts of a pairec process: registered by name in the start hook (sort.RegisterSort — first registration wins)
+    for (const auto& sc : e->config.GpuSorts) {
+        if (sc.SortType == "DPPSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuDPPSort>(e.get(), sc.DPPConf), nullptr);
+        else if (sc.SortType == "SSDSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuSSDSort>(e.get(), sc.SSDConf), nullptr);
+        else if (sc.SortType == "AlgoScoreSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuAlgoScoreSort>(e.get(), sc), nullptr);
+        else if (sc.SortType == "ItemRankScore") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuItemRankScoreSort>(e.get()), nullptr);
+        else if (sc.SortType == "ItemScore") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuItemScoreSort>(e.get()), nullptr);
+        else { if (err) *err = "pairec_gpu.Sorts: unknown SortType " + sc.SortType; return nullptr; }
     }
     // algorithms by name (the shim's start hook does the same with algorithm.RegisterAlgorithm)
     for (const auto& a : g.at("Algorithms").arr) {
         const std::string name = a.s("Name"), kind = a.s("Kind");
         if (kind == "faiss") e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuFaissAlgorithm>(e.get()));
-        else if (kind == "dnn3") e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuDnnAlgorithm>(e.get()));
+        else if (kind == "dnn3") {
+            std::vector<std::string> outs;
+            for (const auto& o : a.at("Outputs").arr) if (o.type == json::Value::String) outs.push_back(o.str);
+            e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuDnnAlgorithm>(e.get(), name, outs));
+        }
+        else if (kind == "online_vector") e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuOnlineVectorAlgorithm>(e.get()));
     }
-    for (const auto& r : e->config.RecallConfs)
-        e->recalls.RegisterRecall(r.Name, std::make_shared<GpuVectorRecall>(e.get(), r));
+    // recall.Load over RecallConfs, with the reference's outcomes (service/recall/recall.go:47-107)
+    for (const auto& r : e->config.RecallConfs) {
+        if (r.RecallType == "MockRecall") e->recalls.RegisterRecall(r.Name, std::make_shared<MockRecall>(r));
+        else if (r.RecallType == "OnlineVectorRecall") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuOnlineVectorRecall>(e.get(), r));
+    }
+    // the GPU recalls: recall.RegisterRecall(name, impl) in the start hook (overwrites)
+    for (const auto& r : e->config.GpuRecalls) {
+        if (r.Kind == "vector") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuVectorRecall>(e.get(), r));
+        else if (r.Kind == "i2i") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuI2IVectorRecall>(e.get(), r));
+        else { if (err) *err = "pairec_gpu.Recalls: unknown Kind " + r.Kind; return nullptr; }
+    }
     return e.release();
 }
 
@@ -741,6 +1185,9 @@ bool Engine::Recommend(const std::string& uid, int size, const std::string& scen
     context::RecommendContext ctx;
     ctx.Size = size;
     ctx.Param["scene"] = json::Value::Str(scene);
+    // request parameters other than the scene ride in the experiment object under "_param" (the driver API has no
+    // separate argument for them): "item_id" is what I2IVectorRecall reads with context.GetParameter
+    for (const auto& kv : experiment_params.at("_param").obj) ctx.Param[kv.first] = kv.second;
     ctx.ExperimentParamsJson = experiment_params;
     // RecallService.GetItems (service/recall.go:53-153): scene → category → recall names, concatenated
     std::vector<module::ItemPtr> items;
@@ -925,6 +1372,29 @@ int ph_engine_load_dnn3(void* h, int prec, const char* blob, size_t len) {
     return rc;
 }
 
+// one DNN3 model per output of a multi-output rank algorithm: key "<algo>/<output>"
+int ph_engine_load_dnn3_named(void* h, const char* key, int prec, const char* blob, size_t len) {
+    Engine* e = (Engine*)h;
+    if (!e || !blob || !key) return -1;
+    pg_model* m = nullptr;
+    const int rc = pg_model_load(e->ctx, PG_MODEL_DNN3, (pg_prec)prec, blob, len, &m);
+    if (rc != PG_OK) { g_ph_err = pg_last_error(); return rc; }
+    auto it = e->named_models.find(key);
+    if (it != e->named_models.end()) pg_model_destroy(e->ctx, it->second);
+    e->named_models[key] = m;
+    return 0;
+}
+
+// the vector model of the online recall (blob format of pg_model_load, PG_MODEL_FM_TWOTOWER)
+int ph_engine_load_fm2t(void* h, int prec, const char* blob, size_t len) {
+    Engine* e = (Engine*)h;
+    if (!e || !blob) return -1;
+    if (e->fm2t) { pg_model_destroy(e->ctx, e->fm2t); e->fm2t = nullptr; }
+    const int rc = pg_model_load(e->ctx, PG_MODEL_FM_TWOTOWER, (pg_prec)prec, blob, len, &e->fm2t);
+    if (rc != PG_OK) g_ph_err = pg_last_error();
+    return rc;
+}
+
 int ph_set_user_vector(void* h, const char* uid, const char* vec) {
     if (!h || !uid || !vec) return -1;
     ((Engine*)h)->user_vectors.vectors[uid] = vec;
@@ -984,6 +1454,114 @@ const char* ph_recommend_ab(void* h, const char* uid, int size, const char* scen
         return nullptr;
     }
     return items_to_json(items);
+}
+
+// n_threads threads, each serving uids[t], uids[t + n_threads], … one request at a time (pairec's goroutines): the
+// engine's plug-ins are called concurrently, and with "Coalesce" configured the library batches them.  → JSON array of the
+// pages in uid order
+const char* ph_recommend_concurrent(void* h, const char* uids_json, int size, const char* scene, int n_threads) {
+    if (!h) return nullptr;
+    Engine* e = (Engine*)h;
+    json::Value uids;
+    std::string err;
+    const std::string text = uids_json ? uids_json : "[]";
+    if (!json::Parser(text).Parse(&uids, &err) || uids.type != json::Value::Array) { g_ph_err = "uids: " + err; return nullptr; }
+    const size_t n = uids.arr.size();
+    std::vector<std::vector<module::ItemPtr>> pages(n);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> th;
+    const std::string sc = scene ? scene : "";
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            for (size_t i = (size_t)t; i < n; i += (size_t)n_threads)
+                if (!e->Recommend(uids.arr[i].str, size, sc, &pages[i], &errs[i]) && errs[i].empty()) errs[i] = "failed";
+        });
+    for (auto& x : th) x.join();
+    for (size_t i = 0; i < n; ++i)
+        if (!errs[i].empty()) { g_ph_err = errs[i]; return nullptr; }
+    std::string o = "[";
+    for (size_t i = 0; i < n; ++i) {
+        if (i) o += ",";
+        o += items_to_json(pages[i]);
+    }
+    o += "]";
+    g_ph_out = o;
+    return g_ph_out.c_str();
+}
+
+// recall.Load's outcome for one RecallConfs entry: "built" | "panic: <text>" | "unavailable: <text>"
+const char* ph_check_recall_conf(const char* conf_json) {
+    recconf::RecommendConfig c;
+    std::string err;
+    const std::string text = std::string("{\"RecallConfs\":[") + (conf_json ? conf_json : "{}") + "]}";
+    if (!recconf::RecommendConfig::Parse(text, &c, &err) || c.RecallConfs.empty()) { g_ph_err = err; return nullptr; }
+    const recall::LoadOutcome o = recall::CheckRecallConf(c.RecallConfs[0]);
+    g_ph_out = o.kind == recall::LoadOutcome::kBuilt ? "built" : (o.kind == recall::LoadOutcome::kPanic ? "panic: " : "unavailable: ") + o.message;
+    return g_ph_out.c_str();
+}
+
+// response decoders driven by JSON (tests): {"func": name, ...inputs} → [{"score":..,"score_map":{..},"module_type":b,"classify":{..}}]
+const char* ph_decode_response(const char* spec_json) {
+    json::Value sp;
+    std::string err;
+    const std::string text = spec_json ? spec_json : "";
+    if (!json::Parser(text).Parse(&sp, &err)) { g_ph_err = err; return nullptr; }
+    const std::string fn = sp.s("func");
+    std::vector<std::string> ids, outs;
+    for (const auto& v : sp.at("item_ids").arr) ids.push_back(v.str);
+    for (const auto& v : sp.at("outputs").arr) outs.push_back(v.str);
+    std::map<std::string, std::vector<double>> results;
+    for (const auto& kv : sp.at("results").obj) for (const auto& x : kv.second.arr) results[kv.first].push_back(x.num);
+    std::vector<algorithm::AlgoResponse> ret;
+    if (fn == "easyrecResponseFunc") ret = algorithm::decode::EasyrecResponse(ids, results);
+    else if (fn == "easyrecMutValResponseFunc") {
+        if (!algorithm::decode::EasyrecMutValResponse(ids, outs, results, &ret, &err)) { g_ph_err = err; return nullptr; }
+    } else if (fn == "easyrecMutClassificationResponseFunc") {
+        std::map<std::string, std::pair<std::vector<float>, std::vector<long long>>> tf;
+        for (const auto& kv : sp.at("tf_outputs").obj) {
+            auto& dst = tf[kv.first];
+            for (const auto& x : kv.second.at("float_val").arr) dst.first.push_back((float)x.num);
+            for (const auto& x : kv.second.at("shape").arr) dst.second.push_back((long long)x.num);
+        }
+        if (!algorithm::decode::EasyrecMutClassificationResponse(ids, tf, &ret, &err)) { g_ph_err = err; return nullptr; }
+    } else if (fn == "alinkFMResponseFunc") {
+        for (const auto& v : sp.at("predictions").arr)
+            ret.emplace_back(algorithm::decode::AlinkFMScore(v.d("prediction_result"), v.d("prediction_score")));
+    } else if (fn == "tfservingResponseFunc") {
+        std::vector<std::vector<double>> o2;
+        for (const auto& row : sp.at("tf_rows").arr) { o2.emplace_back(); for (const auto& x : row.arr) o2.back().push_back(x.num); }
+        ret = algorithm::decode::TFServingResponse(o2);
+    } else if (fn == "widenF32") {
+        std::vector<float> f;
+        for (const auto& x : sp.at("float_val").arr) f.push_back((float)x.num);
+        ret = algorithm::decode::WidenF32(f.data(), f.size());
+    } else { g_ph_err = "unknown decoder " + fn; return nullptr; }
+    std::string o = "[";
+    for (size_t i = 0; i < ret.size(); ++i) {
+        if (i) o += ",";
+        o += "{\"score\":" + json::NumToString(ret[i].GetScore()) + ",\"module_type\":" + (ret[i].GetModuleType() ? "true" : "false") + ",\"score_map\":{";
+        bool first = true;
+        for (const auto& kv : ret[i].GetScoreMap()) {
+            if (!first) o += ",";
+            first = false;
+            json::Escape(kv.first, &o);
+            o += ":" + json::NumToString(kv.second);
+        }
+        o += "},\"classify\":{";
+        first = true;
+        for (const auto& kv : ret[i].GetClassifyMap()) {
+            if (!first) o += ",";
+            first = false;
+            json::Escape(kv.first, &o);
+            o += ":[";
+            for (size_t c = 0; c < kv.second.size(); ++c) o += (c ? "," : "") + json::NumToString(kv.second[c]);
+            o += "]";
+        }
+        o += "}}";
+    }
+    o += "]";
+    g_ph_out = o;
+    return g_ph_out.c_str();
 }
 
 // fmt %v of a float64
@@ -1154,7 +1732,7 @@ int ph_registry_semantics(void) {
     struct DummyAlgo : algorithm::IAlgorithm {
         double v; explicit DummyAlgo(double x) : v(x) {}
         bool Init(const recconf::AlgoConfig&, std::string*) override { return true; }
-        bool Run(const algorithm::AlgoData&, algorithm::AlgoResult* out, std::string*) override { out->responses.assign(1, algorithm::AlgoResponse{v}); return true; }
+        bool Run(const algorithm::AlgoData&, algorithm::AlgoResult* out, std::string*) override { out->responses.assign(1, algorithm::AlgoResponse(v)); return true; }
     };
     int ok = 0;
     sort::Registry sr;
@@ -1181,15 +1759,18 @@ const char* ph_parse_recconf(const char* text) {
     std::string err;
     if (!recconf::RecommendConfig::Parse(text ? text : "", &c, &err)) { g_ph_err = err; return nullptr; }
     std::string& o = g_ph_out;
-    o = "{\"recalls\":" + std::to_string(c.RecallConfs.size()) + ",\"algos\":" + std::to_string(c.AlgoConfs.size()) +
+    o = "{\"recalls\":" + std::to_string(c.RecallConfs.size()) + ",\"gpu_recalls\":" + std::to_string(c.GpuRecalls.size()) +
+        ",\"gpu_sorts\":" + std::to_string(c.GpuSorts.size()) + ",\"algos\":" + std::to_string(c.AlgoConfs.size()) +
         ",\"rank_scenes\":" + std::to_string(c.RankConf.size()) + ",\"dpp\":" + std::to_string(c.DPPConf.size());
-    if (!c.RecallConfs.empty()) {
-        o += ",\"recall0\":{\"name\":";
-        json::Escape(c.RecallConfs[0].Name, &o);
-        o += ",\"count\":" + std::to_string(c.RecallConfs[0].RecallCount) + ",\"algo\":";
-        json::Escape(c.RecallConfs[0].RecallAlgo, &o);
+    auto echo = [&](const char* key, const recconf::RecallConfig& r) {
+        o += std::string(",\"") + key + "\":{\"name\":";
+        json::Escape(r.Name, &o);
+        o += ",\"count\":" + std::to_string(r.RecallCount) + ",\"algo\":";
+        json::Escape(r.RecallAlgo, &o);
         o += "}";
-    }
+    };
+    if (!c.RecallConfs.empty()) echo("recall0", c.RecallConfs[0]);
+    if (!c.GpuRecalls.empty()) echo("gpu_recall0", c.GpuRecalls[0]);
     for (const auto& kv : c.RankConf) {
         o += ",\"rank_" + kv.first + "\":{\"batch\":" + std::to_string(kv.second.BatchCount) + ",\"score\":";
         json::Escape(kv.second.RankScore, &o);

@@ -92,6 +92,9 @@ struct AlgoConfig { std::string Name, Type; json::Value raw; };
 struct RecallConfig {
     std::string Name, RecallType, RecallAlgo, ItemType, CacheAdapter, CacheConfig, CachePrefix;
     int RecallCount = 0, CacheTime = 0;
+    // what the reference's constructors look at before they touch a datasource (recconf.go:330-367)
+    std::string DaoAdapterType, VectorDaoAdapterType, HologresName, VectorAlgoType;
+    std::string Kind;                       // pairec_gpu.Recalls only: "vector" (default), "i2i", "online_vector"
 };
 struct RankConfig {
     std::vector<std::string> RankAlgoList;
@@ -101,9 +104,10 @@ struct RankConfig {
 struct DPPSortConfig {
     std::string Name;
     double Alpha = 1.0;
-    int WindowSize = 0, CandidateCount = 0;
+    int WindowSize = 0, CandidateCount = 0, AbortRunCount = 0;
     double MinScorePercent = 0.0;
-    bool NormalizeEmb = true;
+    bool NormalizeEmb = true, EnsurePositiveSim = true;
+    std::vector<std::string> FilterRetrieveIds, EmbeddingHookNames;
 };
 struct SSDSortConfig {                     // recconf.go:980-1000 (the fields the device path consumes)
     std::string Name;
@@ -116,6 +120,9 @@ struct SSDSortConfig {                     // recconf.go:980-1000 (the fields th
 };
 struct SortConfig {                        // recconf.go:820-838: Name, SortType, nested DPPConf / SSDConf
     std::string Name, SortType;
+    std::string SortByField;               // AlgoScoreSort (sort/algo_score_sort.go:17-27)
+    double SwitchThreshold = 0.0;
+    std::string HologresName;              // DPPConf / SSDConf .DaoConf.HologresName: what NewDPPSort / NewSSDSort open first
     DPPSortConfig DPPConf;
     SSDSortConfig SSDConf;
 };
@@ -126,7 +133,9 @@ struct RecommendConfig {
     std::map<std::string, std::vector<std::string>> SortNames;                // by scene
     std::map<std::string, std::map<std::string, std::vector<std::string>>> SceneRecallNames;  // scene → category → RecallNames
     std::vector<DPPSortConfig> DPPConf;
-    std::vector<SortConfig> SortConfs;                                       // recconf.go:86 (DPPSort / SSDSort entries)
+    std::vector<SortConfig> SortConfs;                                       // recconf.go:86
+    std::vector<RecallConfig> GpuRecalls;                                    // UserDefineConfs.pairec_gpu.Recalls
+    std::vector<SortConfig> GpuSorts;                                        // UserDefineConfs.pairec_gpu.Sorts
     json::Value UserDefineConfs;                                              // recconf.go:92
     static bool Parse(const std::string& text, RecommendConfig* out, std::string* err);
 };
@@ -141,19 +150,60 @@ struct RankRequest {                        // the GPU flavour of []map[string]i
     std::vector<float> UserVector;          // user features already reduced to the model's user vector
     std::vector<std::string> ItemIds;       // request order = response order (rank_service.go:312-335)
 };
+struct EmbeddingRequest {                   // the *easyrec.PBRequest an OnlineVectorRecall sends (online_vector_recall.go:97-109)
+    std::vector<float> UserVector;          // user_features
+    int FaissNeighNum = 0;
+};
 struct AlgoResponse {                       // response.AlgoResponse (algorithm/response/resonse.go:3-7)
     double score = 0.0;
+    std::map<std::string, double> scoreArr; // multi-output models: output name → score (EasyrecResponse.scoreArr)
+    bool multiValModule = false;
+    // response.AlgoMultiClassifyResponse (resonse.go:9-11): output name → class probabilities
+    std::map<std::string, std::vector<double>> mulClassifyArr;
+    AlgoResponse() = default;
+    explicit AlgoResponse(double s) : score(s) {}
     double GetScore() const { return score; }
-    bool GetModuleType() const { return false; }
+    const std::map<std::string, double>& GetScoreMap() const { return scoreArr; }
+    bool GetModuleType() const { return multiValModule; }
+    bool IsMultiClassify() const { return !mulClassifyArr.empty(); }
+    const std::map<std::string, std::vector<double>>& GetClassifyMap() const { return mulClassifyArr; }
 };
+// eas.EmbeddingInfo (algorithm/eas/easyrec_response.go:676-680): what a vector model answers an
+// OnlineVectorRecall with (TorchrecEmbeddingItemsResponse)
+struct EmbeddingInfo { std::string ItemId; double Score = 0.0; };
+
+// ---- response decoders (the ResponseFunc family): remote model output → []AlgoResponse in request order ----------
+namespace decode {
+// easyrecResponseFunc (algorithm/eas/easyrec_response.go:220-236): Results[item_id].Scores[0]; a missing id scores 0
+std::vector<AlgoResponse> EasyrecResponse(const std::vector<std::string>& item_ids,
+                                          const std::map<std::string, std::vector<double>>& results);
+// easyrecMutValResponseFunc (:35-70): one map {outputs[k]: Scores[k]} per item; a missing id maps every output to 0;
+// a length mismatch is the reference's "outputs size is not equal scores" error
+bool EasyrecMutValResponse(const std::vector<std::string>& item_ids, const std::vector<std::string>& outputs,
+                           const std::map<std::string, std::vector<double>>& results,
+                           std::vector<AlgoResponse>* out, std::string* err);
+// easyrecMutClassificationResponseFunc (:145-218): float32 TfOutputs; shape [N] → one value per item, shape [N, C]
+// → C values per item (easyrec_response_test.go:11-73)
+bool EasyrecMutClassificationResponse(const std::vector<std::string>& item_ids,
+                                      const std::map<std::string, std::pair<std::vector<float>, std::vector<long long>>>& tf_outputs,
+                                      std::vector<AlgoResponse>* out, std::string* err);
+// alinkFMResponse.GetScore (algorithm/eas/fm_response.go:28-34): prediction_result == 0 → 1 - prediction_score
+double AlinkFMScore(double prediction_result, double prediction_score);
+// tfservingResponseFunc (algorithm/tfserving/response.go:51-64): Outputs [][]float64 flattened row by row
+std::vector<AlgoResponse> TFServingResponse(const std::vector<std::vector<double>>& outputs);
+// tfResponseFunc / torchrecMutValResponseFunc's float32 → float64 widening (eas/tf_response.go:55-59)
+std::vector<AlgoResponse> WidenF32(const float* scores, size_t n);
+}  // namespace decode
 struct AlgoData {
-    enum Kind { kVector, kRank } kind = kVector;
+    enum Kind { kVector, kRank, kEmbedding } kind = kVector;
     VectorRequest vec;
     RankRequest rank;
+    EmbeddingRequest emb;
 };
 struct AlgoResult {
     VectorReply reply;
     std::vector<AlgoResponse> responses;
+    std::vector<EmbeddingInfo> embeddingItems;      // TorchrecEmbeddingItemsResponse.GetEmbeddingItems()
 };
 
 struct IAlgorithm {
@@ -188,6 +238,13 @@ private:
 };
 // vector_recall.go:70-82
 std::vector<float> ParseVectorString(const std::string& s);
+// recall.Load (service/recall/recall.go:47-107) over RecallConfs with the reference's outcomes: an unknown RecallType
+// leaves the recall nil → panic("recall empty, name:…"); a type whose constructor opens a DAO / datasource that the
+// entry does not configure panics inside that constructor ("not found VectorDao implement", …).  The mirror has no
+// datasources, so a correctly configured datasource-backed entry is reported as unavailable rather than built.
+// Returns false with *panic_msg = the reference's panic text (or the unavailability note).
+struct LoadOutcome { enum Kind { kBuilt, kPanic, kUnavailable } kind = kBuilt; std::string message; };
+LoadOutcome CheckRecallConf(const recconf::RecallConfig& conf);
 // ICloneRecall (service/recall/recall.go:22-27): AB-experiment overrides ("recall.<name>" params object)
 struct ICloneRecall {
     virtual ~ICloneRecall() = default;
@@ -276,6 +333,18 @@ public:
     pg_ctx* ctx = nullptr;
     pg_table* table = nullptr;
     pg_model* model = nullptr;
+    std::map<std::string, pg_model*> named_models;      // multi-output rank algorithms: "<algo>/<output>" → DNN3 model
+    pg_model* fm2t = nullptr;                           // vector model of the online recall (its user tower)
+    pg_table* item_emb = nullptr;                       // … and the item-tower outputs it searches
+    uint64_t item_emb_rows = 0;
+    // request coalescer (UserDefineConfs.pairec_gpu.Coalesce): per-request plug-in calls share table passes
+    bool coalesce = false;
+    uint32_t coalesce_wait_us = 0, coalesce_depth = 0;
+    std::mutex co_mu;
+    std::map<uint32_t, pg_coalescer*> co_recall;        // by k (RecallCount)
+    pg_coalescer* co_rank = nullptr;
+    pg_coalescer* RecallCoalescer(uint32_t k, std::string* err);
+    pg_coalescer* RankCoalescer(std::string* err);
     uint64_t table_rows = 0;
     uint32_t dim = 0;
     std::string id_prefix = "item_";          // row ↔ id dictionary: "<prefix><row>"

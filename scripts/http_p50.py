@@ -18,8 +18,7 @@ from oracle import oracle as o    # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 cfg = {
-    "RecallConfs": [{"Name": "gpu_vector_recall", "RecallType": "UserCustomRecall", "RecallCount": 5000,
-                     "RecallAlgo": "gpu_faiss", "ItemType": "video"}],
+    "RecallConfs": [],
     "SceneConfs": {"home_feed": {"default": {"RecallNames": ["gpu_vector_recall"]}}},
     "RankConf": {"home_feed": {"RankAlgoList": ["gpu_dnn"], "RankScore": "${gpu_dnn}*(1+${current_score})^0.1",
                                "BatchCount": 5000}},
@@ -27,6 +26,8 @@ cfg = {
     "UserDefineConfs": {"pairec_gpu": {"Device": 0,
                                        "Table": {"Rows": rows, "Dim": 128, "IdPrefix": "item_",
                                                  "SyntheticSeed": o.SEED_TABLE},
+                                       "Recalls": [{"Name": "gpu_vector_recall", "Kind": "vector", "RecallCount": 5000,
+                                                    "RecallAlgo": "gpu_faiss", "ItemType": "video"}],
                                        "Algorithms": [{"Name": "gpu_faiss", "Kind": "faiss"},
                                                       {"Name": "gpu_dnn", "Kind": "dnn3"}]}},
 }

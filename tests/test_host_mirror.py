@@ -35,14 +35,15 @@ RANK_SCORE = "${gpu_dnn}*(1+${current_score})^0.1"
 CONFIG = {
     "RunMode": "product",
     "AlgoConfs": [],
-    "RecallConfs": [{"Name": "gpu_vector_recall", "RecallType": "UserCustomRecall", "RecallCount": 300,
-                     "RecallAlgo": "gpu_faiss", "ItemType": "video"}],
+    "RecallConfs": [],
     "SceneConfs": {"home_feed": {"default": {"RecallNames": ["gpu_vector_recall"]}}},
     "RankConf": {"home_feed": {"RankAlgoList": ["gpu_dnn"], "RankScore": RANK_SCORE, "BatchCount": 100}},
     "SortNames": {"home_feed": ["ItemRankScore"]},
     "UserDefineConfs": {"pairec_gpu": {"Device": 0,
                                        "Table": {"Rows": 20000, "Dim": 128, "IdPrefix": "item_",
                                                  "SyntheticSeed": o.SEED_TABLE},
+                                       "Recalls": [{"Name": "gpu_vector_recall", "Kind": "vector", "RecallCount": 300,
+                                                    "RecallAlgo": "gpu_faiss", "ItemType": "video"}],
                                        "Algorithms": [{"Name": "gpu_faiss", "Kind": "faiss"},
                                                       {"Name": "gpu_dnn", "Kind": "dnn3"}]}},
 }
@@ -76,9 +77,108 @@ def test_unique_filter_matches_reference_semantics(H):
 
 def test_recconf_subset(H):
     got = json.loads(H.ph_parse_recconf(json.dumps(CONFIG).encode()))
-    assert got["recalls"] == 1 and got["recall0"] == {"name": "gpu_vector_recall", "count": 300, "algo": "gpu_faiss"}
+    assert got["recalls"] == 0 and got["gpu_recall0"] == {"name": "gpu_vector_recall", "count": 300, "algo": "gpu_faiss"}
     assert got["rank_home_feed"] == {"batch": 100, "score": RANK_SCORE, "algos": 1}
     assert H.ph_parse_recconf(b"{not json") is None and b"json" in H.ph_last_error()
+
+
+def test_recall_and_sort_factories_reject_what_the_reference_rejects(H):
+    """recall.Load / RegisterSortWithConfig outcomes (service/recall/recall.go:47-107, sort/sort.go:162-200) for
+    RecallConfs / SortConfs entries: a GPU plug-in cannot be declared there.  The round-1 INTEGRATION config
+    ("RecallType": "UserCustomRecall" without DaoConf) panics a real pairec inside runBeforeStart
+    (module/user_custom_recall_dao.go:12-28) — the mirror must refuse it with the same message, before any GPU work."""
+    H.ph_check_recall_conf.restype = C.c_char_p
+    H.ph_check_recall_conf.argtypes = [C.c_char_p]
+
+    def check(conf):
+        return H.ph_check_recall_conf(json.dumps(conf).encode()).decode()
+    assert check({"Name": "r", "RecallType": "UserCustomRecall"}) == "panic: not found UserCustomRecallDao implement"
+    assert check({"Name": "r", "RecallType": "VectorRecall"}) == "panic: not found VectorDao implement"
+    assert check({"Name": "r", "RecallType": "GpuVectorRecall"}) == "panic: recall empty, name:r"
+    assert check({"Name": "r", "RecallType": "MilvusVectorRecall"}) == "panic: recall empty, name:r"     # constructor commented out
+    assert check({"Name": "r", "RecallType": "I2IVectorRecall", "VectorDaoConf": {"HologresName": "holo"}}) == \
+        "panic: Postgres not found, name:holo"
+    assert check({"Name": "r", "RecallType": "VectorRecall", "DaoConf": {"AdapterType": "redis"}}).startswith("unavailable: ")
+    assert check({"Name": "r", "RecallType": "MockRecall"}) == "built"
+    assert check({"Name": "r", "RecallType": "OnlineVectorRecall", "RecallAlgo": "x"}) == "built"
+    # whole configs: the refusal happens before the engine touches a GPU, so this runs on the CPU box too
+    import copy
+    bad = copy.deepcopy(CONFIG)
+    bad["RecallConfs"] = [{"Name": "gpu_vector_recall", "RecallType": "UserCustomRecall", "RecallCount": 300,
+                           "RecallAlgo": "gpu_faiss", "ItemType": "video"}]
+    assert not H.ph_engine_create(json.dumps(bad).encode())
+    assert H.ph_last_error() == b"panic: not found UserCustomRecallDao implement"
+    bad = copy.deepcopy(CONFIG)
+    bad["SortConfs"] = [{"Name": "my_ssd", "SortType": "SSDSort", "SSDConf": {"Gamma": 0.3}}]
+    assert not H.ph_engine_create(json.dumps(bad).encode()) and H.ph_last_error().startswith(b"panic: Postgres not found, name:")
+    bad["SortConfs"] = [{"Name": "gpu_sort", "SortType": "GpuItemRankScore"}]
+    assert not H.ph_engine_create(json.dumps(bad).encode()) and H.ph_last_error() == b"panic: Sort is nil, name:gpu_sort"
+
+
+def test_integration_md_config_passes_the_factory_rules(H):
+    """The recconf JSON printed in INTEGRATION.md §1 is the one a maintainer copies: it must survive the reference's
+    recall.Load / RegisterSortWithConfig rules (no GPU plug-in in RecallConfs / SortConfs) and name every plug-in it
+    uses under UserDefineConfs.pairec_gpu."""
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```json\n(\{.*?\n\})\n```", text, re.S)
+    assert m, "INTEGRATION.md lost its recconf example"
+    cfg = json.loads(m.group(1))
+    H.ph_check_recall_conf.restype = C.c_char_p
+    H.ph_check_recall_conf.argtypes = [C.c_char_p]
+    for rc in cfg.get("RecallConfs", []):
+        assert H.ph_check_recall_conf(json.dumps(rc).encode()).decode() == "built", rc
+    for sc in cfg.get("SortConfs", []):
+        assert sc["SortType"] not in ("DPPSort", "SSDSort")
+    gpu = cfg["UserDefineConfs"]["pairec_gpu"]
+    names = {r["Name"] for r in gpu["Recalls"]} | {r["Name"] for r in cfg.get("RecallConfs", [])}
+    for scene in cfg["SceneConfs"].values():
+        for cat in scene.values():
+            assert set(cat["RecallNames"]) <= names
+    algos = {a["Name"] for a in gpu["Algorithms"]}
+    assert all(r["RecallAlgo"] in algos for r in gpu["Recalls"] + cfg.get("RecallConfs", []))
+    assert all(set(rc["RankAlgoList"]) <= algos for rc in cfg["RankConf"].values())
+    sorts = {s_["Name"] for s_ in gpu.get("Sorts", [])} | {"ItemRankScore"}
+    assert all(set(v) <= sorts for v in cfg["SortNames"].values())
+    got = json.loads(H.ph_parse_recconf(json.dumps(cfg).encode()))
+    assert got["gpu_recalls"] == len(gpu["Recalls"]) and got["gpu_sorts"] == len(gpu.get("Sorts", []))
+
+
+def test_response_decoders_reference_fixtures(H):
+    """The ResponseFunc family in the mirror against the reference's own test data: easyrec_response_test.go:11-73
+    (float32 widening, [N] and [1,6]-shaped outputs sliced per item), easyrec_response.go:220-236 (missing id → 0),
+    :35-70 (multi-output maps, missing id → zeros, size mismatch error), fm_response.go:28-34 (label 0 → 1 - score),
+    tfserving/response.go:51-64 (row-major flatten)."""
+    H.ph_decode_response.restype = C.c_char_p
+    H.ph_decode_response.argtypes = [C.c_char_p]
+
+    def dec(spec):
+        r = H.ph_decode_response(json.dumps(spec).encode())
+        return None if r is None else json.loads(r)
+    r = dec({"func": "easyrecResponseFunc", "item_ids": ["a", "missing", "b"], "results": {"a": [0.25, 9], "b": [0.75]}})
+    assert [x["score"] for x in r] == [0.25, 0.0, 0.75] and not any(x["module_type"] for x in r)
+    r = dec({"func": "easyrecMutValResponseFunc", "item_ids": ["a", "zz"], "outputs": ["probs_ctr", "probs_cvr"],
+             "results": {"a": [0.11173942685127258, 0.006906657014042139]}})
+    assert r[0]["module_type"] and r[0]["score_map"] == {"probs_ctr": 0.11173942685127258, "probs_cvr": 0.006906657014042139}
+    assert r[1]["score_map"] == {"probs_ctr": 0.0, "probs_cvr": 0.0}
+    assert dec({"func": "easyrecMutValResponseFunc", "item_ids": ["a"], "outputs": ["x"], "results": {"a": [1, 2]}}) is None
+    assert H.ph_last_error() == b"outputs size is not equal scores"
+    # easyrec_response_test.go "test multi item": per-item scalars and a [1, 6] output sliced per item, float32 widened
+    f32 = lambda v: float(np.float32(v))      # noqa: E731
+    r = dec({"func": "easyrecMutClassificationResponseFunc", "item_ids": ["item_1", "item_2"],
+             "tf_outputs": {"probs_is_complete_play": {"float_val": [0.7, 0.3], "shape": [1]},
+                            "probs_is_play_label": {"float_val": [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.11, 0.22, 0.33, 0.44, 0.55, 0.66],
+                                                    "shape": [1, 6]}}})
+    assert r[1]["classify"]["probs_is_complete_play"] == [f32(0.3)]
+    assert len(r[1]["classify"]["probs_is_play_label"]) == 6 and r[1]["classify"]["probs_is_play_label"][5] == f32(0.66)
+    assert r[0]["classify"]["probs_is_play_label"] == [f32(v) for v in (0.1, 0.2, 0.3, 0.4, 0.5, 0.6)]
+    r = dec({"func": "alinkFMResponseFunc", "predictions": [{"prediction_result": 0, "prediction_score": 0.8},
+                                                            {"prediction_result": 1, "prediction_score": 0.8}]})
+    assert [x["score"] for x in r] == [1 - 0.8, 0.8] == [o.alink_fm_score(0, 0.8), o.alink_fm_score(1, 0.8)]
+    r = dec({"func": "tfservingResponseFunc", "tf_rows": [[0.1, 0.2], [0.3], []]})
+    assert [x["score"] for x in r] == [0.1, 0.2, 0.3]
+    r = dec({"func": "widenF32", "float_val": [0.8612537, 1e-7]})
+    assert [x["score"] for x in r] == o.widen_f32(np.array([0.8612537, 1e-7], dtype=np.float32)).tolist()
 
 
 @pytest.mark.gpu
@@ -124,14 +224,15 @@ def test_config_driven_pipeline_matches_oracle(H):
 
 @pytest.mark.gpu
 def test_config_driven_ssd_sort_matches_oracle(H):
-    """SortConfs → SSDSort (sort/sort.go:162-200, ssd_sort.go:110-343) through the host mirror: the page
-    is the oracle's SSD pick sequence over the rank-ordered candidates."""
+    """pairec_gpu.Sorts → GpuSSDSort registered by name (the reference's own SSDSort in SortConfs needs a Hologres
+    datasource) with SSDSortConfig's fields (ssd_sort.go:110-343): the page is the oracle's SSD pick sequence over
+    the rank-ordered candidates."""
     import copy
     import pairec_amd as pa
     cfg = copy.deepcopy(CONFIG)
-    cfg["SortConfs"] = [{"Name": "my_ssd", "SortType": "SSDSort",
-                         "SSDConf": {"Gamma": 0.3, "WindowSize": 4, "CandidateCount": 120}},
-                        {"Name": "ignored_rule_sort", "SortType": "BoostScoreSort"}]
+    cfg["UserDefineConfs"]["pairec_gpu"]["Sorts"] = [{"Name": "my_ssd", "SortType": "SSDSort",
+                                                      "SSDConf": {"Gamma": 0.3, "WindowSize": 4, "CandidateCount": 120}}]
+    cfg["SortConfs"] = [{"Name": "ignored_rule_sort", "SortType": "BoostScoreSort"}]
     cfg["SortNames"] = {"home_feed": ["my_ssd"]}
     got_conf = json.loads(H.ph_parse_recconf(json.dumps(cfg).encode()))
     assert got_conf is not None
@@ -232,8 +333,9 @@ def test_ab_params_recall_clone_cache_and_ssd_overrides(H):
     import pairec_amd as pa
     _bind_row2(H)
     cfg = copy.deepcopy(CONFIG)
-    cfg["RecallConfs"][0].update({"CacheAdapter": "localBytes", "CachePrefix": "vr_", "CacheTime": 60})
-    cfg["SortConfs"] = [{"Name": "my_ssd", "SortType": "SSDSort", "SSDConf": {"Gamma": 0.3, "WindowSize": 4}}]
+    cfg["UserDefineConfs"]["pairec_gpu"]["Recalls"][0].update({"CacheAdapter": "localBytes", "CachePrefix": "vr_", "CacheTime": 60})
+    cfg["UserDefineConfs"]["pairec_gpu"]["Sorts"] = [{"Name": "my_ssd", "SortType": "SSDSort",
+                                                      "SSDConf": {"Gamma": 0.3, "WindowSize": 4}}]
     cfg["SortNames"] = {"home_feed": ["my_ssd"]}
     h = H.ph_engine_create(json.dumps(cfg).encode())
     assert h, H.ph_last_error()
@@ -263,6 +365,184 @@ def test_ab_params_recall_clone_cache_and_ssd_overrides(H):
                                       json.dumps({"ssd_norm_quality_score": 2}).encode()))["items"]
     assert all("ssd_quality_score" in x["algo_scores"] for x in q2) and q2[0]["algo_scores"]["ssd_quality_score"] == 1.0
     H.ph_engine_destroy(h)
+
+
+# ---- round 2: multi-output rank algorithms, I2I / online-vector recalls, AlgoScoreSort, DPP by name, concurrency ----
+def _engine(H, cfg, uid=b"u1", qrow=3):
+    import pairec_amd as pa
+    h = H.ph_engine_create(json.dumps(cfg).encode())
+    assert h, H.ph_last_error()
+    w = o.Dnn3Weights()
+    user = o.synth_rows(o.SEED_QUERY, qrow, 1, 128)[0]
+    vec = " ".join("%d:%s" % (i + 1, repr(float(v))) for i, v in enumerate(user))
+    H.ph_set_user_vector(h, uid, vec.encode())
+    blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+    assert H.ph_engine_load_dnn3(h, pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+    return h, w, user
+
+
+@pytest.mark.gpu
+def test_multi_output_algorithm_writes_algo_output_scores(H):
+    """GetModuleType() == true (EasyrecResponse.multiValModule): RankService writes one algo score per output as
+    "<algo>_<output>" (rank_service.go:315-319) and the RankScore expression combines them — the reference's own
+    known-answer shape `(${ppnet_probs_ctr}+2*${ppnet_probs_cvr})` (utils/ast/ast_test.go:90-129)."""
+    import copy
+    import pairec_amd as pa
+    H.ph_engine_load_dnn3_named.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+    cfg = copy.deepcopy(CONFIG)
+    cfg["UserDefineConfs"]["pairec_gpu"]["Algorithms"][1] = {"Name": "ppnet", "Kind": "dnn3", "Outputs": ["probs_ctr", "probs_cvr"]}
+    expr = "(${ppnet_probs_ctr}+2*${ppnet_probs_cvr})*(1+${current_score})^0.1"
+    cfg["RankConf"]["home_feed"] = {"RankAlgoList": ["ppnet"], "RankScore": expr, "BatchCount": 100}
+    h, _, user = _engine(H, cfg)
+    heads = {"probs_ctr": o.Dnn3Weights(seed=o.SEED_WEIGHTS ^ 0x11), "probs_cvr": o.Dnn3Weights(seed=o.SEED_WEIGHTS ^ 0x22)}
+    for name, w in heads.items():
+        blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+        assert H.ph_engine_load_dnn3_named(h, ("ppnet/" + name).encode(), pa.PREC_F32, blob, len(blob)) == 0
+    out = json.loads(H.ph_recommend(h, b"u1", 40, b"home_feed"))["items"]
+    tab = o.synth_rows(o.SEED_TABLE, 0, 20000, 128)
+    rows, scores = o.recall_topk(tab, user[None], 300)
+    ref = {name: o.dnn3_forward(w, 0, user, tab[rows[0].astype(np.int64)]) for name, w in heads.items()}
+    pos = {"item_%d" % r: i for i, r in enumerate(rows[0])}
+    for x in out:
+        i = pos[x["item_id"]]
+        a, b = x["algo_scores"]["ppnet_probs_ctr"], x["algo_scores"]["ppnet_probs_cvr"]
+        assert abs(a - ref["probs_ctr"][i]) <= 2e-7 and abs(b - ref["probs_cvr"][i]) <= 2e-7
+        assert "ppnet" not in x["algo_scores"]
+        assert abs(x["score"] - (a + 2 * b) * (1 + float(scores[0][i])) ** 0.1) <= 1e-12
+    assert [x["score"] for x in out] == sorted((x["score"] for x in out), reverse=True)
+    H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
+def test_i2i_online_vector_recalls_and_algo_score_sort(H):
+    """a5 / a6 through the registries: the GPU I2I recall (trigger = the request's item_id), the reference's own
+    OnlineVectorRecall declared in RecallConfs (its constructor needs no datasource) served by a GPU vector model,
+    and AlgoScoreSort from SortConfs with its key sort on the device."""
+    import copy
+    import pairec_amd as pa
+    _bind_row2(H)
+    H.ph_engine_load_fm2t.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    cfg = copy.deepcopy(CONFIG)
+    g = cfg["UserDefineConfs"]["pairec_gpu"]
+    g["Recalls"].append({"Name": "gpu_i2i", "Kind": "i2i", "RecallCount": 50, "ItemType": "video"})
+    g["Algorithms"].append({"Name": "gpu_vec_model", "Kind": "online_vector"})
+    g["OnlineVector"] = {"Rows": 20000, "Dim": 64, "SyntheticSeed": o.SEED_TABLE ^ 0x77}
+    cfg["RecallConfs"] = [{"Name": "online_vec", "RecallType": "OnlineVectorRecall", "RecallCount": 80,
+                           "RecallAlgo": "gpu_vec_model", "VectorAlgoType": "torchrec_vector"}]
+    cfg["SceneConfs"]["item_detail"] = {"default": {"RecallNames": ["gpu_i2i"]}}
+    cfg["SceneConfs"]["cold_feed"] = {"default": {"RecallNames": ["online_vec"]}}
+    cfg["SortConfs"] = [{"Name": "by_ctr", "SortType": "AlgoScoreSort", "SortByField": "gpu_dnn", "SwitchThreshold": 10.0}]
+    cfg["RankConf"]["item_detail"] = {"RankAlgoList": ["gpu_dnn"], "RankScore": "", "BatchCount": 100}
+    cfg["SortNames"]["item_detail"] = ["by_ctr"]
+    h, w, user = _engine(H, cfg)
+    tab = o.synth_rows(o.SEED_TABLE, 0, 20000, 128)
+    # I2I: trigger item_777 → its 50 nearest items; rank writes gpu_dnn, the page is sorted by that field (Item.Score —
+    # the recall distance, all below the threshold 10 — is untouched because RankScore is empty)
+    out = json.loads(H.ph_recommend_ab(h, b"u1", 50, b"item_detail", json.dumps({"_param": {"item_id": "item_777"}}).encode()))["items"]
+    rows, scores = o.recall_topk(tab, tab[777][None], 50)
+    assert sorted(x["item_id"] for x in out) == sorted("item_%d" % r for r in rows[0])
+    assert {x["retrieve_id"] for x in out} == {"gpu_i2i"}
+    dnn = o.dnn3_forward(w, 0, user, tab[rows[0].astype(np.int64)])
+    want = ["item_%d" % rows[0][i] for i in np.argsort(-dnn, kind="stable")]
+    keys = [x["algo_scores"]["gpu_dnn"] for x in out]
+    assert keys == sorted(keys, reverse=True)
+    if np.all(np.abs(np.diff(np.sort(dnn))) > 1e-6):
+        assert [x["item_id"] for x in out] == want
+    by_id = {"item_%d" % r: float(s) for r, s in zip(rows[0], scores[0])}
+    assert all(x["score"] == by_id[x["item_id"]] for x in out)
+    # online vector recall: user tower of the FM + two-tower model → 80 nearest rows of the item-embedding table
+    fw = o.Fm2tWeights(vocab=500)
+    blob = pa.pack_fm2t(fw)
+    assert H.ph_engine_load_fm2t(h, pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+    out = json.loads(H.ph_recommend(h, b"u1", 80, b"cold_feed"))["items"]
+    emb = o.synth_rows(o.SEED_TABLE ^ 0x77, 0, 20000, 64)
+    ue = o.fm2t_user_embedding(fw, 0, user)
+    orow, osc = o.recall_topk(emb, ue[None], 80)
+    assert [x["item_id"] for x in out] == ["item_%d" % r for r in orow[0]]          # no rank config: recall order = score order
+    assert [x["score"] for x in out] == [float(s) for s in osc[0]] and {x["retrieve_id"] for x in out} == {"online_vec"}
+    H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
+def test_gpu_dpp_sort_by_name_with_experiment_overrides(H):
+    """DPPSort declared in pairec_gpu.Sorts: page = the oracle's DPP picks over the first CandidateCount items; the
+    dpp_* experiment parameters override the config (dpp_sort.go:275-278,374,382) and "dpp_relevance_score" is
+    recorded on the candidates (:410)."""
+    import copy
+    _bind_row2(H)
+    cfg = copy.deepcopy(CONFIG)
+    cfg["UserDefineConfs"]["pairec_gpu"]["Sorts"] = [{"Name": "GpuDPP", "SortType": "DPPSort",
+                                                      "DPPConf": {"Alpha": 1.0, "WindowSize": 10, "CandidateCount": 120}}]
+    cfg["SortNames"] = {"home_feed": ["GpuDPP"]}
+    h, w, user = _engine(H, cfg)
+    size = 30
+    tab = o.synth_rows(o.SEED_TABLE, 0, 20000, 128)
+    rows, scores = o.recall_topk(tab, user[None], 300)
+    items = [o.OracleItem("item_%d" % r, float(s), "gpu_vector_recall") for r, s in zip(rows[0], scores[0])]
+    dnn = o.dnn3_forward(w, 0, user, tab[rows[0].astype(np.int64)])
+    for it, s_ in zip(items, dnn):
+        it.add_algo_score("gpu_dnn", float(np.float32(s_)))
+    o.fuse_scores(RANK_SCORE, items)
+    order = o.sort_scores([it.score for it in items], True)
+
+    def want_page(cand_cnt, alpha, window, mode):
+        cand = [items[i] for i in order[:max(size, cand_cnt)]]
+        rowid = np.array([int(c.id.split("_")[1]) for c in cand])
+        rel, ok = o.dpp_relevance(np.array([c.score for c in cand]), mode)
+        F = o.dpp_features(tab[rowid], None, True, True)
+        picks = o.dpp_with_window(o.dpp_kernel_matrix_f(F, rel, alpha), size, window)
+        return [cand[i].id for i in picks], cand
+    near_tie = np.any(np.abs(np.diff(sorted(it.score for it in items))) <= 4e-6)
+    out = json.loads(H.ph_recommend(h, b"u1", size, b"home_feed"))["items"]
+    page, cand = want_page(120, 1.0, 10, 0)
+    assert len(out) == size and len({x["item_id"] for x in out}) == size
+    assert {x["item_id"] for x in out} <= {c.id for c in cand} and out[0]["item_id"] == cand[0].id
+    if not near_tie:
+        assert [x["item_id"] for x in out] == page
+    assert all("dpp_relevance_score" in x["algo_scores"] for x in out)
+    ab = {"dpp_alpha": 3.0, "dpp_window_size": 5, "dpp_candidate_count": 60, "dpp_norm_relevance_score": 2}
+    out2 = json.loads(H.ph_recommend_ab(h, b"u1", size, b"home_feed", json.dumps(ab).encode()))["items"]
+    page2, cand2 = want_page(60, 3.0, 5, 2)
+    assert {x["item_id"] for x in out2} <= {c.id for c in cand2}
+    if not near_tie:
+        assert [x["item_id"] for x in out2] == page2
+    rs = {x["item_id"]: x["algo_scores"]["dpp_relevance_score"] for x in out2}
+    assert max(rs.values()) <= 1.0 and min(rs.values()) >= 1e-6 and rs[cand2[0].id] == 1.0      # min-max into [1e-6, 1]
+    H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
+def test_concurrent_requests_through_the_coalescer_equal_sequential(H):
+    """"Coalesce" in pairec_gpu: GpuFaissAlgorithm / GpuDnnAlgorithm issue ONE request per call through
+    pg_coalescer_recall / pg_coalescer_rank_dnn3 (50 rank calls of 100 items per request, as RankService fans them out);
+    48 requests on 16 threads give the pages the same engine gives one at a time without coalescing."""
+    import copy
+    import pairec_amd as pa
+    H.ph_recommend_concurrent.restype = C.c_char_p
+    H.ph_recommend_concurrent.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    uids = ["user_%d" % i for i in range(48)]
+    vecs = o.synth_rows(o.SEED_QUERY, 100, len(uids), 128)
+    w = o.Dnn3Weights()
+    blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+    pages = {}
+    for mode in ("plain", "coalesce"):
+        cfg = copy.deepcopy(CONFIG)
+        if mode == "coalesce":
+            cfg["UserDefineConfs"]["pairec_gpu"]["Coalesce"] = {"MaxWaitUs": 300, "Depth": 2}
+        h = H.ph_engine_create(json.dumps(cfg).encode())
+        assert h, H.ph_last_error()
+        for u, v in zip(uids, vecs):
+            H.ph_set_user_vector(h, u.encode(), " ".join("%d:%s" % (i + 1, repr(float(x))) for i, x in enumerate(v)).encode())
+        assert H.ph_engine_load_dnn3(h, pa.PREC_F32, blob, len(blob)) == 0
+        r = H.ph_recommend_concurrent(h, json.dumps(uids).encode(), 25, b"home_feed", 16 if mode == "coalesce" else 1)
+        assert r, H.ph_last_error()
+        pages[mode] = json.loads(r)
+        H.ph_engine_destroy(h)
+    assert len(pages["coalesce"]) == len(uids)
+    for a, b in zip(pages["plain"], pages["coalesce"]):
+        assert [x["item_id"] for x in a["items"]] == [x["item_id"] for x in b["items"]]
+        assert [x["score"] for x in a["items"]] == [x["score"] for x in b["items"]]
+        assert [x["algo_scores"] for x in a["items"]] == [x["algo_scores"] for x in b["items"]]
 
 
 # ---- SURVEY.md 8f row 3: the host boxing the device feature store replaces ---------------------------------
