@@ -21,11 +21,14 @@ def bits(a):
 
 
 def run_threads(n, fn):
-    """fn(i) on n threads; re-raises the first exception."""
+    """fn(i) on n threads, released together by a barrier (Python starts threads one by one, far slower than the
+    coalescer's window); re-raises the first exception."""
     errs = []
+    gate = threading.Barrier(n)
 
     def wrap(i):
         try:
+            gate.wait()
             fn(i)
         except BaseException as e:      # noqa: BLE001
             errs.append(e)
