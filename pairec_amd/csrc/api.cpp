@@ -12,6 +12,7 @@ static void knobs_from_env(Knobs* k) {
     k->recall_exact = flag("PG_RECALL_EXACT");
     k->pilot_fraction = num("PG_PILOT_FRACTION", 0.0);
     k->no_pilot = flag("PG_NO_PILOT");
+    k->pilot_sigmas = num("PG_PILOT_SIGMAS", 6.0);
     k->chunk_growth = num("PG_CHUNK_GROWTH", 0.0);
     k->seed_rows = (uint32_t)num("PG_SEED_ROWS", 8192);
     k->pilot_growth = num("PG_PILOT_GROWTH", 0.0);
@@ -121,6 +122,7 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "recall_exact") k.recall_exact = b;
     else if (n == "pilot_fraction") k.pilot_fraction = v;
     else if (n == "no_pilot") k.no_pilot = b;
+    else if (n == "pilot_sigmas") k.pilot_sigmas = v;
     else if (n == "chunk_growth") k.chunk_growth = v;
     else if (n == "seed_rows") k.seed_rows = v >= 32 ? (uint32_t)v : 8192u;
     else if (n == "pilot_growth") k.pilot_growth = v;

@@ -63,6 +63,7 @@ struct Slot {
     uint32_t n_req = 0;                    // requests in the batch (reqs is handed back to the callers at wake-up)
     uint32_t n_items = 0;                  // rank: candidates in the batch; recommend: page width of the output image
     PipeRun* run = nullptr;
+    pg_ctx* ctx = nullptr;                 // the context (stream + scratch) this slot's batches run on
     hipEvent_t done = nullptr;             // behind the batch's device → host copies
     hipEvent_t computed = nullptr;         // behind its last kernel (the copy stream waits for it)
     Clock::time_point enqueued;
@@ -114,6 +115,9 @@ __global__ void page_gather_kernel(const uint32_t* __restrict__ order, const uin
 
 struct pg_coalescer {
     pg_ctx* ctx = nullptr;
+    pg_ctx* sibling = nullptr;       // a second context on the same device (own stream and scratch): the slots alternate
+                                     // between the two, so the latency-bound head and tail of one batch (pilot, selects,
+                                     // fusion, sort) run under the other batch's scan / rank kernels
     const pg_table* t = nullptr;
     const pg_model* m = nullptr;
     const pg_expr* e = nullptr;
@@ -173,11 +177,11 @@ int alloc_slot(pg_coalescer* c, Slot* s) {
         PG_HIP(hipMalloc((void**)&s->d_order, nb * k * 4));
         PG_HIP(hipMalloc((void**)&s->d_page, page_bytes(c)));
     }
-    return pipe_run_acquire(c->ctx, &s->run);
+    return pipe_run_acquire(s->ctx, &s->run);
 }
 
 void free_slot(pg_coalescer* c, Slot* s) {
-    if (s->run) pipe_run_release(c->ctx, s->run);
+    if (s->run) pipe_run_release(s->ctx, s->run);
     if (s->done) hipEventDestroy(s->done);
     if (s->computed) hipEventDestroy(s->computed);
     for (void* p : {(void*)s->h_vec, (void*)s->h_cand, (void*)s->h_off, (void*)s->h_out})
@@ -192,7 +196,7 @@ void free_slot(pg_coalescer* c, Slot* s) {
 // so the next batch's kernels do not queue behind a PCIe transfer), the completion event.  first = false: the
 // recall plan of a recall / recommend batch did not hold; run its next plan and everything behind it again.
 int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
-    pg_ctx* ctx = c->ctx;
+    pg_ctx* ctx = s->ctx;
     hipStream_t st = ctx->stream;
     const uint32_t nq = (uint32_t)s->reqs.size();
     int rc;
@@ -329,8 +333,8 @@ void dispatcher_main(pg_coalescer* c) {
             continue;
         }
         std::deque<Req*>& q = c->queue[kind];
-        Slot* s = c->free_slots.back();
-        c->free_slots.pop_back();
+        Slot* s = c->free_slots.front();               // oldest first: consecutive batches alternate between the contexts
+        c->free_slots.erase(c->free_slots.begin());
         s->kind = (Flavour)kind;
         s->reqs.clear();
         s->n_items = 0;
@@ -413,7 +417,7 @@ void completer_main(pg_coalescer* c) {
             }
             if (s->kind == kRank) break;
             bool ok = false;
-            if ((rc = recommend_verify(c->ctx, s->run, &ok))) break;     // (recall_job_check + finish under ctx->mu)
+            if ((rc = recommend_verify(s->ctx, s->run, &ok))) break;     // (recall_job_check + finish under ctx->mu)
             if (ok) break;
             replanned = true;
             if ((rc = slot_enqueue(c, s, false))) break;
@@ -512,13 +516,16 @@ int pg_coalescer_create(pg_ctx* ctx, const pg_table* t, const pg_model* m, const
         delete c;
         return PG_ERR_DEVICE;
     }
+    if (c->depth >= 2 && pg_init(ctx->device, nullptr, &c->sibling) != PG_OK) c->sibling = nullptr;   // (optional: one stream works too)
     for (uint32_t i = 0; i < c->depth; ++i) {
         pg::Slot* s = new pg::Slot();
         s->id = (int)i;
+        s->ctx = (c->sibling && (i & 1)) ? c->sibling : ctx;
         if ((rc = pg::alloc_slot(c, s))) {
             pg::free_slot(c, s);
             for (pg::Slot* o : c->slots) pg::free_slot(c, o);
             hipStreamDestroy(c->copy_stream);
+            if (c->sibling) pg_shutdown(c->sibling);
             delete c;
             return rc;
         }
@@ -531,6 +538,7 @@ int pg_coalescer_create(pg_ctx* ctx, const pg_table* t, const pg_model* m, const
         if ((rc = pg::ensure_table_stats(ctx, t))) {
             for (pg::Slot* o : c->slots) pg::free_slot(c, o);
             hipStreamDestroy(c->copy_stream);
+            if (c->sibling) pg_shutdown(c->sibling);
             delete c;
             return rc;
         }
@@ -557,8 +565,10 @@ int pg_coalescer_destroy(pg_coalescer* c) {
     hipSetDevice(c->ctx->device);
     hipStreamSynchronize(c->copy_stream);
     hipStreamSynchronize(c->ctx->stream);
+    if (c->sibling) hipStreamSynchronize(c->sibling->stream);
     for (pg::Slot* s : c->slots) pg::free_slot(c, s);
     hipStreamDestroy(c->copy_stream);
+    if (c->sibling) pg_shutdown(c->sibling);
     delete c;
     return PG_OK;
 }

@@ -56,6 +56,7 @@ struct Knobs {
     bool recall_exact = false;     // PG_RECALL_EXACT: never screen
     double pilot_fraction = 0.0;   // PG_PILOT_FRACTION: sample fraction of the pilot plan (0 = default 1/64)
     bool no_pilot = false;         // PG_NO_PILOT: skip the pilot plan
+    double pilot_sigmas = 6.0;     // PG_PILOT_SIGMAS: K' = m + sigmas sqrt(m) + 8 (margin of the pilot threshold)
     double chunk_growth = 0.0;     // PG_CHUNK_GROWTH: geometric growth of the grow plan (0 = default)
     uint32_t seed_rows = 8192;     // PG_SEED_ROWS: exact seed of the pilot sample
     double pilot_growth = 0.0;     // PG_PILOT_GROWTH: > 0 = geometric chunks over the sample instead of seed + one launch

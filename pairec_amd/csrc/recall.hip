@@ -1761,7 +1761,7 @@ int recall_job_prepare(RecallJob* j) {
     if (j->stride >= 2 && !kn.no_pilot) {
         j->sample_blocks = full_blocks / j->stride;
         const double m = (double)j->k * ((double)j->sample_blocks * kPieceRows / (double)rows);
-        j->k_pilot = (uint32_t)ceil(m + 6.0 * sqrt(m) + 8.0);
+        j->k_pilot = (uint32_t)ceil(m + ctx->knobs.pilot_sigmas * sqrt(m) + 8.0);
         if ((uint64_t)j->k_pilot * 4 <= (uint64_t)j->sample_blocks * kPieceRows) j->plans[j->n_plans++] = kPilot;
         j->perm_mul = 2654435761u % j->sample_blocks;          // golden-ratio step, made coprime below
         if (j->perm_mul < 2) j->perm_mul = 1;
