@@ -133,11 +133,15 @@ int pg_rows_to_local_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows,
  * PG_MODEL_DNN3 blob (little-endian fp32 unless noted):
  *   u32 d_user, d_item, h1, h2;  w1[(d_user+d_item)][h1]; b1[h1]; w2[h1][h2]; b2[h2]; w3[h2]; b3
  *   score = sigmoid( w3 · relu( W2ᵀ relu( W1ᵀ [user ‖ item_row] + b1 ) + b2 ) + b3 )
+ *   shapes: d_user 1..4096; d_item 64 or 128 (= the table's dim); (h1, h2) in {128-128, 256-128, 256-256, 512-256,
+ *   1024-512}; the benchmark shape [128+128]-512-256 in bf16 runs on the weights-stationary kernel
  * PG_MODEL_FM_TWOTOWER blob:
  *   u32 n_user_fields, n_item_fields, k, d_user, t_h1, t_out, vocab; f32 fm_b;
  *   uw1[d_user][t_h1]; ub1; uw2[t_h1][t_out]; ub2; iw1[nif*k][t_h1]; ib1; iw2[t_h1][t_out]; ib2;
  *   then per field f (user fields first): emb_f[vocab][k], lin_f[vocab]
  *   score = sigmoid( y_fm + <user_tower(user), item_tower(concat item field embeddings)> )
+ *   shapes: 1..16 user fields; n_item_fields x k = 128 with k in {8, 16, 32}; towers (t_h1, t_out, k) in
+ *   {256-64 k16, 256-64 k32, 128-64 k8, 512-128 k16}
  * Summation orders are specified in DESIGN.md §5 (they are what makes PG_PREC_F32 bit-reproducible).
  */
 int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blob, size_t len,
@@ -271,6 +275,12 @@ int pg_features_gather_f32_dev(pg_ctx* ctx, const pg_features* fs, const int32_t
 int pg_rank_fm2t_rows_dev(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
                           const float* d_user_vecs, const int32_t* d_user_field_ids, const uint32_t* d_cand_rows,
                           const uint32_t* d_req_offsets, uint32_t n_req, uint32_t n_items, float* d_out_scores);
+
+/* host-buffer form of the same: the EasyRec flavour of IAlgorithm.Run (service/rank/algo_data.go:79-86: item ids + columnar
+ * context features) with the columns already resident — the shim passes candidate rows, nothing is boxed per request */
+int pg_rank_fm2t_rows(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
+                      const float* user_vecs, const int32_t* user_field_ids, const uint32_t* cand_rows,
+                      const uint32_t* req_offsets, uint32_t n_req, float* out_scores);
 
 /* ---- the whole hot path in one call ------------------------------------------------------------
  * One request batch through VectorRecall.GetCandidateItems → RankService.Rank (one DNN3 rank algorithm) →

@@ -23,7 +23,7 @@ EXPORTS = [
     "pg_dpp", "pg_stats", "pg_last_scan_kernel_ms", "pg_rows_to_local_dev", "pg_widen_f32_dev",
     "pg_hbm_read_probe", "pg_table_screen_info", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
     "pg_features_column_index", "pg_features_num_columns", "pg_features_gather_i32_dev",
-    "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev", "pg_recommend_dnn3_dev", "pg_set_option",
+    "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev", "pg_rank_fm2t_rows", "pg_recommend_dnn3_dev", "pg_set_option",
     "pg_table_fill_gaussian", "pg_dpp_ex", "pg_i2i_recall", "pg_online_vector_recall", "pg_fm2t_user_embedding",
     "pg_fm2t_user_embedding_dev", "pg_recommend_dnn3_begin", "pg_recommend_end",
     "pg_coalescer_create", "pg_coalescer_destroy", "pg_coalescer_recall", "pg_coalescer_rank_dnn3",
@@ -124,6 +124,7 @@ def load():
         "pg_features_gather_i32_dev": [vp, vp, vp, u32, vp, u32, vp],
         "pg_features_gather_f32_dev": [vp, vp, vp, u32, vp, vp, vp, u32, vp],
         "pg_rank_fm2t_rows_dev": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp],
+        "pg_rank_fm2t_rows": [vp, vp, vp, vp, vp, vp, vp, vp, u32, vp],
         "pg_recommend_dnn3_dev": [vp, vp, vp, vp, C.c_char_p, vp, u32, u32, vp, vp, vp, vp, vp, vp],
         "pg_set_option": [vp, C.c_char_p, C.c_char_p],
         "pg_table_fill_gaussian": [vp, vp, u64, C.c_float],

@@ -125,14 +125,15 @@ constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep) {
     const size_t tiles = (size_t)kBM * (kDIN + nh1 * ch) * es;
     const size_t h2t = (size_t)kBM * (h2 / ep + 4) * 4;
     // + the two-tower prologue's FM staging: 8 item groups x (8 fields x 16 embedding values + 8 linear weights)
-    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)kBM * 4 + (size_t)8 * (kFmFields * kFmK + kFmFields) * 4;
+    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)kBM * 4 + (size_t)8 * (kDIN + 16) * 4;
 }
 
 // MODEL 1 = DNN3, 2 = two-tower item side.  WM x WN = wave grid over (items, hidden columns); CH = layer-1
 // chunk width (hidden columns produced, pushed through LDS and consumed by layer 2 at a time); EP = passes of
 // the head epilogue (the fp32 H2 tile goes through LDS H2/EP columns at a time — EP = 2 halves the LDS
 // footprint so that two workgroups share a CU); OCC = workgroups per CU the register budget is set for.
-template <int PREC, int H1, int H2, bool ACT2, int WM, int WN, int MODEL, int CH, int EP, int OCC>
+// FK: two-tower only — width of a field embedding; the item side has kDIN / FK fields (8 x 16, 4 x 32, 16 x 8).
+template <int PREC, int H1, int H2, bool ACT2, int WM, int WN, int MODEL, int CH, int EP, int OCC, int FK = 16>
 __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
     constexpr int MB = 4 / WM;
     constexpr int L1NB = CH / 32 / WN;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
     // ---------------- gather prologue: 32 lanes x 16 B per item, 8 items per pass ------------
     {
         const int c = tid & 31;
-        if (tid < H2) w3s[tid] = a.w3[(size_t)req * a.w3_stride + tid];
+        for (int i = tid; i < H2; i += 256) w3s[i] = a.w3[(size_t)req * a.w3_stride + i];
         if constexpr (MODEL == 1) {
             if (tid < kBM) b3s[tid] = a.b3;
             float4 v[16];
@@ -182,17 +183,20 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                 const uint32_t idx = item0 + (r < cnt ? r : cnt - 1);
                 uint32_t row = a.cand_rows[idx];
                 row = row < a.tab_rows ? row : a.tab_rows - 1;
-                v[p] = *reinterpret_cast<const float4*>(a.tab + (size_t)row * kDIN + 4 * c);
+                v[p] = (uint32_t)(4 * c) < a.tab_dim ? *reinterpret_cast<const float4*>(a.tab + (size_t)row * a.tab_dim + 4 * c)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int p = 0; p < 16; ++p) store_x_quad<PREC>(XT, p * 8 + (tid >> 5), c, v[p]);
         } else {
             // two-tower: field f = c/4, quad qd = c%4 of that field's 16-wide embedding; the FM
             // sums ride along in registers (fields accumulate sequentially, f ascending).
-            const int f = c >> 2, qd = c & 3;
-            const float* fu = a.fm_user + (size_t)req * 33;
-            const float* emb = a.field_emb[kFmFields + f];
-            const float* lin_tab = a.field_lin[kFmFields + f];
+            constexpr int NF = kDIN / FK;          // item fields
+            constexpr int QPF = FK / 4;            // 16-B quads per field embedding
+            const int f = c / QPF, qd = c % QPF;
+            const float* fu = a.fm_user + (size_t)req * kFmUserStride;
+            const float* emb = a.field_emb[a.n_user_fields + f];
+            const float* lin_tab = a.field_lin[a.n_user_fields + f];
             // three waves of independent loads (ids → embedding quads + linear weights), then the arithmetic:
             // one item at a time this was 16 serial round trips per thread
             int32_t ids[16];
@@ -200,14 +204,14 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             for (int p = 0; p < 16; ++p) {
                 const uint32_t r = p * 8 + (tid >> 5);
                 const uint32_t idx = item0 + (r < cnt ? r : cnt - 1);
-                const int32_t id = a.item_field_ids[(size_t)idx * kFmFields + f];
+                const int32_t id = a.item_field_ids[(size_t)idx * NF + f];
                 ids[p] = id < 0 ? 0 : (id >= (int32_t)a.vocab ? (int32_t)a.vocab - 1 : id);
             }
             float4 v[16];
             float linv[16];
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                v[p] = *reinterpret_cast<const float4*>(emb + (size_t)ids[p] * kFmK + 4 * qd);
+                v[p] = *reinterpret_cast<const float4*>(emb + (size_t)ids[p] * FK + 4 * qd);
                 linv[p] = qd == 0 ? lin_tab[ids[p]] : 0.0f;
             }
             // FM sums: the 32 lanes of an item group park their field values in LDS; lane k < 16 then walks the
@@ -215,36 +219,34 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             // terms fold in a balanced tree, lane 0 adds the linear chain.  (A shuffle chain across the lanes
             // cost 63 ds_bpermutes per item per lane.)
             const int grp = tid >> 5;
-            float* const st = fm_stage + grp * (kFmFields * kFmK + kFmFields);
-            const float fus = c < kFmK ? fu[1 + c] : 0.0f;
-            const float fuq = c < kFmK ? fu[17 + c] : 0.0f;
+            float* const st = fm_stage + grp * (kDIN + 16);
+            const float fus = c < FK ? fu[1 + c] : 0.0f;
+            const float fuq = c < FK ? fu[1 + kFmMaxK + c] : 0.0f;
             const float fu_lin = fu[0];
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 const uint32_t r = p * 8 + grp;
                 store_x_quad<PREC>(XT, r, c, v[p]);
-                *reinterpret_cast<float4*>(st + f * kFmK + 4 * qd) = v[p];
-                if (qd == 0) st[kFmFields * kFmK + f] = linv[p];
+                *reinterpret_cast<float4*>(st + f * FK + 4 * qd) = v[p];
+                if (qd == 0) st[kDIN + f] = linv[p];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 float s_ = fus, q_ = fuq;
-                if (c < kFmK) {
+                if (c < FK) {
 #pragma unroll
-                    for (int ff = 0; ff < kFmFields; ++ff) {
-                        const float x = st[ff * kFmK + c];
+                    for (int ff = 0; ff < NF; ++ff) {
+                        const float x = st[ff * FK + c];
                         s_ = s_ + x;
                         q_ = __fmaf_rn(x, x, q_);
                     }
                 }
-                float cr = c < kFmK ? __fmaf_rn(s_, s_, -q_) : 0.0f;
-                cr = cr + __shfl_xor(cr, 1, 16);            // balanced pairwise tree over k
-                cr = cr + __shfl_xor(cr, 2, 16);
-                cr = cr + __shfl_xor(cr, 4, 16);
-                cr = cr + __shfl_xor(cr, 8, 16);
+                float cr = c < FK ? __fmaf_rn(s_, s_, -q_) : 0.0f;
+#pragma unroll
+                for (int off = 1; off < FK; off <<= 1) cr = cr + __shfl_xor(cr, off, FK);     // balanced pairwise tree over k
                 if (c == 0) {
                     float lin = fu_lin;
 #pragma unroll
-                    for (int ff = 0; ff < kFmFields; ++ff) lin = lin + st[kFmFields * kFmK + ff];
+                    for (int ff = 0; ff < NF; ++ff) lin = lin + st[kDIN + ff];
                     b3s[r] = lin + 0.5f * cr;
                 }
                 __builtin_amdgcn_wave_barrier();             // the next item overwrites the staging
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(256) void fm2t_user_kernel(
     const float* __restrict__ ub1, const float* __restrict__ uw2, const float* __restrict__ ub2,
     uint32_t th, uint32_t to, int prec, const float* const* __restrict__ field_emb,
     const float* const* __restrict__ field_lin, const int32_t* __restrict__ user_field_ids,
-    uint32_t vocab, float fm_b, float* __restrict__ uo, float* __restrict__ fm_user) {
+    uint32_t vocab, float fm_b, float* __restrict__ uo, float* __restrict__ fm_user, uint32_t nuf, uint32_t fk) {
     __shared__ float u1[1024];
     const uint32_t r = blockIdx.x, tid = threadIdx.x;
     for (uint32_t j = tid; j < th; j += blockDim.x) {
@@ -524,26 +526,26 @@ __global__ __launch_bounds__(256) void fm2t_user_kernel(
         uo[(size_t)r * to + o] = acc;
     }
     if (!user_field_ids) return;                 // embedding only (pg_fm2t_user_embedding)
-    if (tid < kFmK) {
+    if (tid < fk) {
         float s = 0.0f, q = 0.0f;
-        for (int f = 0; f < kFmFields; ++f) {
-            int32_t id = user_field_ids[(size_t)r * kFmFields + f];
+        for (uint32_t f = 0; f < nuf; ++f) {
+            int32_t id = user_field_ids[(size_t)r * nuf + f];
             id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
-            const float v = field_emb[f][(size_t)id * kFmK + tid];
+            const float v = field_emb[f][(size_t)id * fk + tid];
             s = s + v;
             q = __fmaf_rn(v, v, q);
         }
-        fm_user[(size_t)r * 33 + 1 + tid] = s;
-        fm_user[(size_t)r * 33 + 17 + tid] = q;
+        fm_user[(size_t)r * kFmUserStride + 1 + tid] = s;
+        fm_user[(size_t)r * kFmUserStride + 1 + kFmMaxK + tid] = q;
     }
-    if (tid == 32) {
+    if (tid == 64) {
         float lin = fm_b;
-        for (int f = 0; f < kFmFields; ++f) {
-            int32_t id = user_field_ids[(size_t)r * kFmFields + f];
+        for (uint32_t f = 0; f < nuf; ++f) {
+            int32_t id = user_field_ids[(size_t)r * nuf + f];
             id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
             lin = lin + field_lin[f][id];
         }
-        fm_user[(size_t)r * 33] = lin;
+        fm_user[(size_t)r * kFmUserStride] = lin;
     }
 }
 
@@ -603,7 +605,7 @@ static std::vector<float> rounded(const float* w, size_t n, int prec) {
 struct RankScratch {
     uint32_t *tile_req, *tile_item0, *tile_cnt, *n_tiles, *req_tile0;
     float* c1;       // [n_req][h1]  (DNN3) or uo [n_req][to] (two-tower)
-    float* fm_user;  // [n_req][33]
+    float* fm_user;  // [n_req][kFmUserStride]
 };
 
 static int rank_scratch(pg_ctx* ctx, uint32_t n_req, uint32_t max_tiles, uint32_t per_req_floats,
@@ -611,7 +613,7 @@ static int rank_scratch(pg_ctx* ctx, uint32_t n_req, uint32_t max_tiles, uint32_
     void* p;
     int rc;
     const size_t ints = (size_t)3 * max_tiles + 64 + n_req;
-    const size_t bytes = ints * 4 + ((size_t)n_req * per_req_floats + (size_t)n_req * 33) * 4 + 256;
+    const size_t bytes = ints * 4 + ((size_t)n_req * per_req_floats + (size_t)n_req * kFmUserStride) * 4 + 256;
     if ((rc = scratch_reserve(ctx, 6, bytes, &p))) return rc;
     uint32_t* u = (uint32_t*)p;
     rs->tile_req = u;
@@ -624,6 +626,69 @@ static int rank_scratch(pg_ctx* ctx, uint32_t n_req, uint32_t max_tiles, uint32_
     return PG_OK;
 }
 
+// ---- shapes the fused kernel is instantiated for ----------------------------------------------------------------
+// Tiling per precision.  bf16: 2 x 2 waves, 64-column layer-1 chunks, two-pass head, two workgroups
+// per CU with pre-loaded B fragments while the accumulators fit 256 registers (h2 <= 256), one workgroup per CU beyond;
+// fp32: 1 x 4 waves, 128-column chunks, head in one pass (two when the fp32 H2 tile would not fit the LDS).
+template <int PREC, int H1, int H2>
+static int launch_dnn3_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
+    int rc;
+    if constexpr (PREC == 1) {
+        constexpr int OCC = H2 <= 256 ? 2 : 1;
+        constexpr size_t lds = mlp_lds_bytes(1, H2, 64, 2);
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, H1, H2, true, 2, 2, 1, 64, 2, OCC>, lds))) return rc;
+        mlp_kernel<1, H1, H2, true, 2, 2, 1, 64, 2, OCC><<<grid, 256, lds, ctx->stream>>>(a);
+    } else {
+        constexpr int EP = H2 > 256 ? 2 : 1;
+        constexpr size_t lds = mlp_lds_bytes(0, H2, 128, EP);
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, H1, H2, true, 1, 4, 1, 128, EP, 1>, lds))) return rc;
+        mlp_kernel<0, H1, H2, true, 1, 4, 1, 128, EP, 1><<<grid, 256, lds, ctx->stream>>>(a);
+    }
+    return PG_OK;
+}
+template <int PREC, int TH, int TO, int FK>
+static int launch_fm2t_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
+    int rc;
+    constexpr int OCC = PREC ? 2 : 1;
+    constexpr size_t lds = mlp_lds_bytes(PREC, TO, 128, 1);
+    if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<PREC, TH, TO, false, 2, 2, 2, 128, 1, OCC, FK>, lds))) return rc;
+    mlp_kernel<PREC, TH, TO, false, 2, 2, 2, 128, 1, OCC, FK><<<grid, 256, lds, ctx->stream>>>(a);
+    return PG_OK;
+}
+// (h1, h2) of DNN3 and (t_h1, t_out, k) of the two-tower model; d_item is 64 or 128 (64: the gathered row is padded
+// with zero columns whose W1 rows are zero), n_item_fields x k = 128, n_user_fields <= 16
+#define PG_DNN3_SHAPES(X) X(128, 128) X(256, 128) X(256, 256) X(512, 256) X(1024, 512)
+#define PG_FM2T_SHAPES(X) X(256, 64, 16) X(256, 64, 32) X(128, 64, 8) X(512, 128, 16)
+static bool dnn3_shape_ok(uint32_t h1, uint32_t h2) {
+#define X(A, B) if (h1 == A && h2 == B) return true;
+    PG_DNN3_SHAPES(X)
+#undef X
+    return false;
+}
+static bool fm2t_shape_ok(uint32_t th, uint32_t to, uint32_t k) {
+#define X(A, B, C) if (th == A && to == B && k == C) return true;
+    PG_FM2T_SHAPES(X)
+#undef X
+    return false;
+}
+static int dispatch_dnn3_mlp(pg_ctx* ctx, const pg_model* m, const MlpArgs& a, uint32_t grid) {
+#define X(A, B)                                                                                          \
+    if (m->h1 == A && m->h2 == B) return m->prec ? launch_dnn3_mlp<1, A, B>(ctx, a, grid) : launch_dnn3_mlp<0, A, B>(ctx, a, grid);
+    PG_DNN3_SHAPES(X)
+#undef X
+    set_error("rank: DNN3 shape ->%u->%u has no kernel", m->h1, m->h2);
+    return PG_ERR_UNSUPPORTED;
+}
+static int dispatch_fm2t_mlp(pg_ctx* ctx, const pg_model* m, const MlpArgs& a, uint32_t grid) {
+#define X(A, B, C)                                                                                       \
+    if (m->th == A && m->to == B && m->k == C)                                                           \
+        return m->prec ? launch_fm2t_mlp<1, A, B, C>(ctx, a, grid) : launch_fm2t_mlp<0, A, B, C>(ctx, a, grid);
+    PG_FM2T_SHAPES(X)
+#undef X
+    set_error("rank: two-tower shape ->%u->%u, k=%u has no kernel", m->th, m->to, m->k);
+    return PG_ERR_UNSUPPORTED;
+}
+
 int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
                                 const float* d_user, const uint32_t* d_cand, const uint32_t* d_off,
                                 uint32_t n_req, uint32_t n_items, float* d_out) {
@@ -633,7 +698,8 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     int rc;
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->h1, &rs))) return rc;
     const bool no_ws = ctx->knobs.rank_no_ws;        // A/B switch: the streaming kernel
-    const bool ws = m->prec && !no_ws;
+    // the weights-stationary kernel is built for the benchmark's shape: [d_user + 128] -> 512 -> 256 -> 1 in bf16
+    const bool ws = m->prec && !no_ws && m->h1 == 512 && m->h2 == 256 && t->dim == 128;
     const uint32_t grid128 = n_items / kBM + n_req;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     build_tiles_kernel<<<1, 1024, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
@@ -647,6 +713,7 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     a.n_tiles = rs.n_tiles;
     a.tab = t->d;
     a.tab_rows = (uint32_t)t->rows;
+    a.tab_dim = t->dim;
     a.cand_rows = d_cand;
     a.c1 = rs.c1;
     a.c1_stride = m->h1;
@@ -660,16 +727,8 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     if (ws) {
         // bf16: weights-stationary persistent kernel over 64-item tiles
         if ((rc = launch_dnn3_ws(ctx, a))) return rc;
-    } else if (m->prec) {
-        // bf16: 2 x 2 waves, 64-column chunks, two-pass head → 68 KB of LDS and <= 256 registers: two
-        // workgroups per CU, so one's barriers and weight-fragment loads hide behind the other's MFMAs
-        constexpr size_t lds = mlp_lds_bytes(1, 256, 64, 2);
-        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2>, lds))) return rc;
-        mlp_kernel<1, 512, 256, true, 2, 2, 1, 64, 2, 2><<<grid128, 256, lds, ctx->stream>>>(a);
-    } else {
-        constexpr size_t lds = mlp_lds_bytes(0, 256, 128, 1);
-        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1>, lds))) return rc;
-        mlp_kernel<0, 512, 256, true, 1, 4, 1, 128, 1, 1><<<grid128, 256, lds, ctx->stream>>>(a);
+    } else if ((rc = dispatch_dnn3_mlp(ctx, m, a, grid128))) {
+        return rc;
     }
     PG_HIP(hipGetLastError());
     PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -692,7 +751,7 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
                                                    rs.n_tiles, rs.req_tile0, (uint32_t)kBM);
     fm2t_user_kernel<<<n_req, 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th,
                                                      m->to, m->prec, m->d_field_emb, m->d_field_lin, d_ufids,
-                                                     m->vocab, m->fm_b, rs.c1, rs.fm_user);
+                                                     m->vocab, m->fm_b, rs.c1, rs.fm_user, m->nuf, m->k);
     MlpArgs a{};
     a.tile_req = rs.tile_req;
     a.tile_item0 = rs.tile_item0;
@@ -702,6 +761,7 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     a.field_lin = m->d_field_lin;
     a.item_field_ids = d_ifids;
     a.vocab = m->vocab;
+    a.n_user_fields = m->nuf;
     a.fm_user = rs.fm_user;
     a.c1 = m->c1_shared;
     a.c1_stride = 0;
@@ -711,15 +771,7 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     a.w1p = m->w1p;
     a.w2p = m->w2p;
     a.out = d_out;
-    if (m->prec) {
-        constexpr size_t lds = mlp_lds_bytes(1, 64, 128, 1);
-        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, 256, 64, false, 2, 2, 2, 128, 1, 2>, lds))) return rc;
-        mlp_kernel<1, 256, 64, false, 2, 2, 2, 128, 1, 2><<<max_tiles, 256, lds, ctx->stream>>>(a);
-    } else {
-        constexpr size_t lds = mlp_lds_bytes(0, 64, 128, 1);
-        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, 256, 64, false, 2, 2, 2, 128, 1, 1>, lds))) return rc;
-        mlp_kernel<0, 256, 64, false, 2, 2, 2, 128, 1, 1><<<max_tiles, 256, lds, ctx->stream>>>(a);
-    }
+    if ((rc = dispatch_fm2t_mlp(ctx, m, a, max_tiles))) return rc;
     PG_HIP(hipGetLastError());
     PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->rank_timing_pending = true;
@@ -732,7 +784,7 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
 int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_user, uint32_t n_req, float* d_out) {
     if (n_req == 0) return PG_OK;
     fm2t_user_kernel<<<n_req, 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to,
-                                                     m->prec, nullptr, nullptr, nullptr, m->vocab, m->fm_b, d_out, nullptr);
+                                                     m->prec, nullptr, nullptr, nullptr, m->vocab, m->fm_b, d_out, nullptr, m->nuf, m->k);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
@@ -771,9 +823,9 @@ int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blo
         uint32_t hdr[4];
         memcpy(hdr, p, 16);
         m->d_user = hdr[0]; m->d_item = hdr[1]; m->h1 = hdr[2]; m->h2 = hdr[3];
-        if (m->d_item != 128 || m->h1 != 512 || m->h2 != 256 || m->d_user == 0 || m->d_user > 4096) {
-            pg::set_error("pg_model_load: DNN3 shape [%u+%u]->%u->%u->1 unsupported (kernels are built for "
-                          "[d_user+128]->512->256->1)", m->d_user, m->d_item, m->h1, m->h2);
+        if ((m->d_item != 128 && m->d_item != 64) || !pg::dnn3_shape_ok(m->h1, m->h2) || m->d_user == 0 || m->d_user > 4096) {
+            pg::set_error("pg_model_load: DNN3 shape [%u+%u]->%u->%u->1 unsupported (d_item 64 or 128; hidden widths "
+                          "128-128, 256-128, 256-256, 512-256, 1024-512)", m->d_user, m->d_item, m->h1, m->h2);
             return fail(PG_ERR_UNSUPPORTED);
         }
         const size_t din = (size_t)m->d_user + m->d_item;
@@ -786,7 +838,10 @@ int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blo
         const float* w3 = b2 + m->h2;
         m->b3 = w3[m->h2];
         auto w1u = pg::rounded(w1, (size_t)m->d_user * m->h1, m->prec);
-        auto w1p = pg::pack_weights(w1 + (size_t)m->d_user * m->h1, m->d_item, m->h1, m->prec);
+        // the kernel's layer 1 is 128 deep: a 64-wide item row is padded with zero columns, W1 with zero rows
+        std::vector<float> w1i((size_t)pg::kDIN * m->h1, 0.0f);
+        memcpy(w1i.data(), w1 + (size_t)m->d_user * m->h1, (size_t)m->d_item * m->h1 * 4);
+        auto w1p = pg::pack_weights(w1i.data(), pg::kDIN, m->h1, m->prec);
         auto w2p = pg::pack_weights(w2, m->h1, m->h2, m->prec);
         if ((rc = pg::upload(ctx, m, w1u.data(), w1u.size() * 4, (void**)&m->w1u))) return fail(rc);
         if ((rc = pg::upload(ctx, m, b1, m->h1 * 4, (void**)&m->b1))) return fail(rc);
@@ -801,10 +856,10 @@ int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blo
         memcpy(&m->fm_b, p + 28, 4);
         m->nuf = hdr[0]; m->nif = hdr[1]; m->k = hdr[2]; m->d_user = hdr[3];
         m->th = hdr[4]; m->to = hdr[5]; m->vocab = hdr[6];
-        if (m->nuf != 8 || m->nif != 8 || m->k != 16 || m->th != 256 || m->to != 64 || m->d_user == 0 ||
-            m->d_user > 4096 || m->vocab == 0) {
-            pg::set_error("pg_model_load: two-tower shape unsupported (kernels are built for 8+8 fields, k=16, "
-                          "towers ->256->64)");
+        if (m->nuf == 0 || m->nuf > 16 || m->nif * m->k != (uint32_t)pg::kDIN || !pg::fm2t_shape_ok(m->th, m->to, m->k) ||
+            m->d_user == 0 || m->d_user > 4096 || m->vocab == 0) {
+            pg::set_error("pg_model_load: two-tower shape unsupported (1..16 user fields; item fields x k = 128 with "
+                          "k = 8, 16 or 32; towers 256-64 (k 16 / 32), 128-64 (k 8), 512-128 (k 16))");
             return fail(PG_ERR_UNSUPPORTED);
         }
         const size_t din = (size_t)m->nif * m->k;
@@ -968,6 +1023,48 @@ int pg_rank_fm2t_rows_dev(pg_ctx* ctx, const pg_model* m, const pg_features* fs,
         return rc;
     return pg::rank_fm2t_dev_locked(ctx, m, d_user_vecs, d_user_field_ids, (const int32_t*)ids, d_req_offsets, n_req,
                                     n_items, d_out_scores);
+}
+
+// host-buffer form of pg_rank_fm2t_rows_dev: what an IAlgorithm.Run of the EasyRec flavour passes — item ids resolved
+// to rows, the per-item "context features" read from the device-resident columns instead of being boxed per request
+int pg_rank_fm2t_rows(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
+                      const float* user_vecs, const int32_t* user_field_ids, const uint32_t* cand_rows,
+                      const uint32_t* req_offsets, uint32_t n_req, float* out_scores) {
+    PG_REQUIRE(ctx && m && fs && item_field_cols && req_offsets, "pg_rank_fm2t_rows: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER, "pg_rank_fm2t_rows: model is not FM_TWOTOWER");
+    PG_REQUIRE(n_req <= 65535, "pg_rank_fm2t_rows: at most 65535 requests per call");
+    if (n_req == 0) return PG_OK;
+    PG_REQUIRE(req_offsets[0] == 0, "pg_rank_fm2t_rows: req_offsets[0] must be 0");
+    for (uint32_t r = 0; r < n_req; ++r)
+        PG_REQUIRE(req_offsets[r + 1] >= req_offsets[r], "pg_rank_fm2t_rows: req_offsets not monotone at %u", r);
+    const uint32_t n_items = req_offsets[n_req];
+    if (n_items == 0) return PG_OK;
+    PG_REQUIRE(user_vecs && user_field_ids && cand_rows && out_scores, "pg_rank_fm2t_rows: NULL argument");
+    for (size_t i = 0; i < (size_t)n_req * m->nuf; ++i)
+        PG_REQUIRE(user_field_ids[i] >= 0 && (uint32_t)user_field_ids[i] < m->vocab,
+                   "pg_rank_fm2t_rows: user field id %d outside vocab %u", user_field_ids[i], m->vocab);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    int rc;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t ub = (size_t)n_req * m->d_user * 4, ufb = (size_t)n_req * m->nuf * 4, cb = (size_t)n_items * 4;
+    const size_t ifb = (size_t)n_items * m->nif * 4, ob = (size_t)(n_req + 1) * 4, sb = (size_t)n_items * 4;
+    if ((rc = pg::scratch_reserve(ctx, 5, al(ub) + al(ufb) + al(cb) + al(ifb) + al(ob) + al(sb), &buf))) return rc;
+    char* b = (char*)buf;
+    float* d_u = (float*)b; b += al(ub);
+    int32_t* d_uf = (int32_t*)b; b += al(ufb);
+    uint32_t* d_c = (uint32_t*)b; b += al(cb);
+    int32_t* d_if = (int32_t*)b; b += al(ifb);
+    uint32_t* d_o = (uint32_t*)b; b += al(ob);
+    float* d_s = (float*)b;
+    PG_HIP(hipMemcpyAsync(d_u, user_vecs, ub, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_uf, user_field_ids, ufb, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_c, cand_rows, cb, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_o, req_offsets, ob, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pg::features_gather_i32_locked(ctx, fs, item_field_cols, m->nif, d_c, n_items, d_if, "pg_rank_fm2t_rows"))) return rc;
+    if ((rc = pg::rank_fm2t_dev_locked(ctx, m, d_u, d_uf, d_if, d_o, n_req, n_items, d_s))) return rc;
+    PG_HIP(hipMemcpyAsync(out_scores, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
+    return pg::finish_rank_timing(ctx);
 }
 
 int pg_rank_fm2t(pg_ctx* ctx, const pg_model* m, const float* user_vecs, const int32_t* user_field_ids,

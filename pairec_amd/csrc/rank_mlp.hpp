@@ -38,8 +38,8 @@ __host__ __device__ __forceinline__ float round_prec(float x, int prec) {
 
 constexpr int kBM = 128;       // items per workgroup tile
 constexpr int kDIN = 128;      // gathered input width
-constexpr int kFmK = 16;       // FM embedding width
-constexpr int kFmFields = 8;   // item fields (= user fields)
+constexpr int kFmMaxK = 32;        // largest FM embedding width (item fields x width = kDIN)
+constexpr int kFmUserStride = 1 + 2 * kFmMaxK;   // per-request FM prefix: lin, s[<=32] at +1, q[<=32] at +33
 
 struct MlpArgs {
     const uint32_t* tile_req;
@@ -49,13 +49,15 @@ struct MlpArgs {
     // DNN3 gather
     const float* tab;
     uint32_t tab_rows;
+    uint32_t tab_dim;                // 64 or 128 floats per row; columns beyond it read as 0 (their W1 rows are 0 too)
     const uint32_t* cand_rows;
     // two-tower gather
-    const float* const* field_emb;   // device array [16] of [vocab][16]
-    const float* const* field_lin;   // device array [16] of [vocab]
-    const int32_t* item_field_ids;   // [n_items][8]
+    const float* const* field_emb;   // device array [n_user_fields + n_item_fields] of [vocab][k]
+    const float* const* field_lin;   // device array [...] of [vocab]
+    const int32_t* item_field_ids;   // [n_items][n_item_fields]
     uint32_t vocab;
-    const float* fm_user;            // [n_req][33]: linU, sU[16], qU[16]
+    uint32_t n_user_fields;          // the item fields' tables follow the user fields' in field_emb / field_lin
+    const float* fm_user;            // [n_req][kFmUserStride]: linU, sU[k] at +1, qU[k] at +33
     // per request / shared vectors
     const float* c1;
     uint32_t c1_stride;

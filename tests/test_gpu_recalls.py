@@ -92,3 +92,50 @@ def test_cfg4_fm_twotower_with_million_row_field_tables(ctx):
             ref = o.fm2t_forward(fw, prec, users[r], ufids[r], ifids[off[r]:off[r + 1]])
             assert np.max(np.abs(got[off[r]:off[r + 1]].astype(np.float64) - ref)) <= tol
         m.destroy()
+
+
+@pytest.mark.parametrize("d_user,d_item,h1,h2", [(128, 128, 128, 128), (64, 64, 256, 128), (128, 128, 256, 256),
+                                                 (200, 128, 1024, 512), (128, 64, 512, 256)])
+def test_dnn3_shapes_match_oracle(ctx, d_user, d_item, h1, h2):
+    """EAS-shaped DNN predict beyond the benchmark's 256-512-256-1 (algorithm/eas/model.go:197-222 serves whatever
+    the model is): hidden widths, user widths and 64-wide item rows, both precision modes against the oracle."""
+    n, R, K = 5000, 3, 700
+    t = pa.Table(ctx, n, d_item)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d_item)
+    w = o.Dnn3Weights(d_user=d_user, d_item=d_item, h1=h1, h2=h2, seed=o.SEED_WEIGHTS ^ (h1 + h2))
+    users = o.synth_rows(o.SEED_QUERY, 9, R, 256)[:, :d_user].copy()
+    rng = np.random.default_rng(h1)
+    cand = rng.integers(0, n, R * K).astype(np.uint32)
+    off = (np.arange(R + 1) * K).astype(np.uint32)
+    for prec, tol in ((pa.PREC_F32, 2e-7), (pa.PREC_BF16, 1e-5)):
+        m = pa.RankModel(ctx, pa.MODEL_DNN3, prec, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, d_user))
+        got = m.rank_dnn3(t, users, cand, off)
+        for r in range(R):
+            ref = o.dnn3_forward(w, prec, users[r], tab[cand[off[r]:off[r + 1]].astype(np.int64)])
+            assert np.max(np.abs(got[off[r]:off[r + 1]].astype(np.float64) - ref)) <= tol, (prec, r)
+        m.destroy()
+    t.destroy()
+    with pytest.raises(pa._lib.PgError):
+        bad = o.Dnn3Weights(d_user=128, d_item=128, h1=384, h2=256)
+        pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(bad.w1, bad.b1, bad.w2, bad.b2, bad.w3, bad.b3, 128))
+
+
+@pytest.mark.parametrize("nuf,nif,k,th,to", [(8, 8, 16, 256, 64), (3, 4, 32, 256, 64), (16, 16, 8, 128, 64),
+                                             (5, 8, 16, 512, 128)])
+def test_fm2t_shapes_match_oracle(ctx, nuf, nif, k, th, to):
+    """FM + two-tower over field counts / embedding widths / tower widths (n_item_fields x k = 128)."""
+    vocab, R, K = 3000, 3, 500
+    fw = o.Fm2tWeights(n_user_fields=nuf, n_item_fields=nif, k=k, d_user=96, t_h1=th, t_out=to, vocab=vocab)
+    rng = np.random.default_rng(k + th)
+    users = o.synth_rows(o.SEED_QUERY, 1, R, 128)[:, :96].copy()
+    ufids = rng.integers(0, vocab, (R, nuf)).astype(np.int32)
+    ifids = rng.integers(0, vocab, (R * K, nif)).astype(np.int32)
+    off = (np.arange(R + 1) * K).astype(np.uint32)
+    for prec, tol in ((pa.PREC_F32, 2e-7), (pa.PREC_BF16, 1e-5)):
+        m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, prec, pa.pack_fm2t(fw))
+        got = m.rank_fm2t(users, ufids, ifids, off)
+        for r in range(R):
+            ref = o.fm2t_forward(fw, prec, users[r], ufids[r], ifids[off[r]:off[r + 1]])
+            assert np.max(np.abs(got[off[r]:off[r + 1]].astype(np.float64) - ref)) <= tol, (prec, r)
+        m.destroy()
