@@ -562,6 +562,40 @@ struct GpuDnnAlgorithm : algorithm::IAlgorithm {
     }
 };
 
+// algorithm.IAlgorithm for the EasyRec flavour (service/rank/algo_data.go:79-86, algorithm/eas/easyrec_request.go:20-73):
+// the request names item ids; the per-item context features are device columns (pg_features_*), the user side arrives
+// as a dense vector + dictionary-encoded categorical ids.  FM + two-tower predict (pg_rank_fm2t_rows).
+struct GpuFm2tAlgorithm : algorithm::IAlgorithm {
+    Engine* e;
+    std::vector<std::string> columns;
+    GpuFm2tAlgorithm(Engine* eng, std::vector<std::string> cols) : e(eng), columns(std::move(cols)) {}
+    bool Init(const recconf::AlgoConfig&, std::string*) override { return true; }
+    bool Run(const algorithm::AlgoData& data, algorithm::AlgoResult* out, std::string* err) override {
+        if (data.kind != algorithm::AlgoData::kRank) { if (err) *err = "fm2t: invalid request type"; return false; }
+        if (!e->fm2t || !e->feats) { if (err) *err = "fm2t: model or feature columns not loaded"; return false; }
+        const auto& req = data.rank;
+        const uint32_t n = (uint32_t)req.ItemIds.size();
+        std::vector<uint32_t> rows(n);
+        for (uint32_t i = 0; i < n; ++i)
+            if (!e->RowOfId(req.ItemIds[i], &rows[i])) { if (err) *err = "fm2t: unknown item id " + req.ItemIds[i]; return false; }
+        std::vector<int32_t> cols;
+        for (const auto& c : columns) {
+            const int idx = pg_features_column_index(e->feats, c.c_str());
+            if (idx < 0) { if (err) *err = "fm2t: no feature column " + c; return false; }
+            cols.push_back(idx);
+        }
+        const uint32_t off[2] = {0, n};
+        std::vector<float> scores(n);
+        if (pg_rank_fm2t_rows(e->ctx, e->fm2t, e->feats, cols.data(), req.UserVector.data(), req.UserFieldIds.data(), rows.data(), off, 1,
+                              scores.data()) != PG_OK) {
+            if (err) *err = pg_err("pg_rank_fm2t_rows");
+            return false;
+        }
+        out->responses = algorithm::decode::WidenF32(scores.data(), n);
+        return true;
+    }
+};
+
 // algorithm.IAlgorithm of a vector model serving an OnlineVectorRecall: user features → user embedding → its
 // FaissNeighNum nearest items (torchrecEmbeddingItemsResponseFunc, easyrec_response.go:700-734)
 struct GpuOnlineVectorAlgorithm : algorithm::IAlgorithm {
@@ -977,6 +1011,8 @@ bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, co
             algorithm::AlgoData data;
             data.kind = algorithm::AlgoData::kRank;
             data.rank.UserVector = user_vec;
+            auto uf = e->user_fields.find(user->Id);
+            if (uf != e->user_fields.end()) data.rank.UserFieldIds = uf->second;
             for (size_t i = b0; i < b1; ++i) data.rank.ItemIds.push_back(items[i]->Id);
             algorithm::AlgoResult res;
             std::string aerr;
@@ -1030,6 +1066,7 @@ Engine::~Engine() {
         if (model) pg_model_destroy(ctx, model);
         for (auto& kv : named_models) pg_model_destroy(ctx, kv.second);
         if (fm2t) pg_model_destroy(ctx, fm2t);
+        if (feats) pg_features_destroy(ctx, feats);
         if (item_emb) pg_table_destroy(ctx, item_emb);
         if (table) pg_table_destroy(ctx, table);
         pg_shutdown(ctx);
@@ -1159,6 +1196,11 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
             e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuDnnAlgorithm>(e.get(), name, outs));
         }
         else if (kind == "online_vector") e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuOnlineVectorAlgorithm>(e.get()));
+        else if (kind == "fm2t") {
+            std::vector<std::string> cols;
+            for (const auto& c : a.at("ItemFieldColumns").arr) if (c.type == json::Value::String) cols.push_back(c.str);
+            e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuFm2tAlgorithm>(e.get(), cols));
+        }
     }
     // recall.Load over RecallConfs, with the reference's outcomes (service/recall/recall.go:47-107)
     for (const auto& r : e->config.RecallConfs) {
@@ -1393,6 +1435,22 @@ int ph_engine_load_fm2t(void* h, int prec, const char* blob, size_t len) {
     const int rc = pg_model_load(e->ctx, PG_MODEL_FM_TWOTOWER, (pg_prec)prec, blob, len, &e->fm2t);
     if (rc != PG_OK) g_ph_err = pg_last_error();
     return rc;
+}
+
+// one int32 item feature column (dictionary-encoded categorical feature), keyed by item row
+int ph_engine_set_feature_column(void* h, const char* name, const int32_t* values, uint64_t n) {
+    Engine* e = (Engine*)h;
+    if (!e || !name || !values || n != e->table_rows) { g_ph_err = "feature column: bad argument (one value per table row)"; return -1; }
+    if (!e->feats && pg_features_create(e->ctx, e->table_rows, &e->feats) != PG_OK) { g_ph_err = pg_last_error(); return -1; }
+    const int rc = pg_features_set_column(e->ctx, e->feats, name, PG_F_I32, values, 0.0);
+    if (rc != PG_OK) g_ph_err = pg_last_error();
+    return rc;
+}
+
+int ph_set_user_fields(void* h, const char* uid, const int32_t* ids, int n) {
+    if (!h || !uid || !ids || n < 0) return -1;
+    ((Engine*)h)->user_fields[uid] = std::vector<int32_t>(ids, ids + n);
+    return 0;
 }
 
 int ph_set_user_vector(void* h, const char* uid, const char* vec) {

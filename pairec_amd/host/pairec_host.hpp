@@ -149,6 +149,7 @@ struct VectorReply { std::vector<uint64_t> Retval; std::vector<float> Scores; st
 struct RankRequest {                        // the GPU flavour of []map[string]interface{} / PBRequest:
     std::vector<float> UserVector;          // user features already reduced to the model's user vector
     std::vector<std::string> ItemIds;       // request order = response order (rank_service.go:312-335)
+    std::vector<int32_t> UserFieldIds;      // EasyRec flavour: the user's categorical features, dictionary-encoded
 };
 struct EmbeddingRequest {                   // the *easyrec.PBRequest an OnlineVectorRecall sends (online_vector_recall.go:97-109)
     std::vector<float> UserVector;          // user_features
@@ -334,7 +335,9 @@ public:
     pg_table* table = nullptr;
     pg_model* model = nullptr;
     std::map<std::string, pg_model*> named_models;      // multi-output rank algorithms: "<algo>/<output>" → DNN3 model
-    pg_model* fm2t = nullptr;                           // vector model of the online recall (its user tower)
+    pg_features* feats = nullptr;                       // item "context features" as device columns (EasyRec request flavour)
+    std::map<std::string, std::vector<int32_t>> user_fields;   // uid → dictionary-encoded user categorical features
+    pg_model* fm2t = nullptr;                           // FM + two-tower model: rank algorithm "fm2t", and the vector model of the online recall
     pg_table* item_emb = nullptr;                       // … and the item-tower outputs it searches
     uint64_t item_emb_rows = 0;
     // request coalescer (UserDefineConfs.pairec_gpu.Coalesce): per-request plug-in calls share table passes

@@ -464,6 +464,45 @@ def test_i2i_online_vector_recalls_and_algo_score_sort(H):
 
 
 @pytest.mark.gpu
+def test_fm2t_algorithm_easyrec_flavour(H):
+    """FM + two-tower registered as an IAlgorithm: the EasyRec request flavour (item ids + columnar context features,
+    service/rank/algo_data.go:79-86,223-306) with the columns resident on the device — scores equal the oracle's
+    forward on the same field ids, rank order follows."""
+    import copy
+    import pairec_amd as pa
+    H.ph_engine_load_fm2t.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    H.ph_engine_set_feature_column.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+    H.ph_set_user_fields.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+    cfg = copy.deepcopy(CONFIG)
+    cols = ["cat%d" % f for f in range(8)]
+    cfg["UserDefineConfs"]["pairec_gpu"]["Algorithms"].append({"Name": "gpu_fm", "Kind": "fm2t", "ItemFieldColumns": cols})
+    cfg["RankConf"]["home_feed"] = {"RankAlgoList": ["gpu_fm"], "RankScore": "${gpu_fm}", "BatchCount": 100}
+    h, _, user = _engine(H, cfg)
+    vocab, n = 700, 20000
+    fw = o.Fm2tWeights(vocab=vocab)
+    blob = pa.pack_fm2t(fw)
+    assert H.ph_engine_load_fm2t(h, pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+    rng = np.random.default_rng(2)
+    item_fields = rng.integers(0, vocab, (n, 8)).astype(np.int32)
+    for f, c in enumerate(cols):
+        col = np.ascontiguousarray(item_fields[:, f])
+        assert H.ph_engine_set_feature_column(h, c.encode(), col.ctypes.data, n) == 0, H.ph_last_error()
+    ufields = rng.integers(0, vocab, 8).astype(np.int32)
+    assert H.ph_set_user_fields(h, b"u1", ufields.ctypes.data, 8) == 0
+    out = json.loads(H.ph_recommend(h, b"u1", 60, b"home_feed"))["items"]
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, 128)
+    rows, _ = o.recall_topk(tab, user[None], 300)
+    ref = o.fm2t_forward(fw, 0, user, ufields, item_fields[rows[0].astype(np.int64)])
+    pos = {"item_%d" % r: i for i, r in enumerate(rows[0])}
+    assert len(out) == 60
+    for x in out:
+        assert abs(x["algo_scores"]["gpu_fm"] - ref[pos[x["item_id"]]]) <= 2e-7 and x["score"] == x["algo_scores"]["gpu_fm"]
+    assert [x["score"] for x in out] == sorted((x["score"] for x in out), reverse=True)
+    assert min(x["score"] for x in out) >= np.sort(ref)[::-1][59] - 2e-7
+    H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
 def test_gpu_dpp_sort_by_name_with_experiment_overrides(H):
     """DPPSort declared in pairec_gpu.Sorts: page = the oracle's DPP picks over the first CandidateCount items; the
     dpp_* experiment parameters override the config (dpp_sort.go:275-278,374,382) and "dpp_relevance_score" is
