@@ -119,13 +119,13 @@ __device__ __forceinline__ void gemm_tile_pre(f32x16 (&acc)[MB][NB], const char*
 
 // LDS of one workgroup: X tile + H1 chunk tile, aliased after the GEMMs by the fp32 H2 tile of one
 // epilogue pass (H2 / EP columns, padded rows); then w3 and the per-item head bias.
-constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep) {
+constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep, int bm = kBM) {
     const size_t es = prec ? 2 : 4;
-    const size_t nh1 = (prec && (size_t)kBM * (kDIN + 2 * ch) * es <= 72 * 1024) ? 2 : 1;   // as NH1 in mlp_kernel
-    const size_t tiles = (size_t)kBM * (kDIN + nh1 * ch) * es;
-    const size_t h2t = (size_t)kBM * (h2 / ep + 4) * 4;
+    const size_t nh1 = (prec && (size_t)bm * (kDIN + 2 * ch) * es <= 72 * 1024) ? 2 : 1;   // as NH1 in mlp_kernel
+    const size_t tiles = (size_t)bm * (kDIN + nh1 * ch) * es;
+    const size_t h2t = (size_t)bm * (h2 / ep + 4) * 4;
     // + the two-tower prologue's FM staging: 8 item groups x (8 fields x 16 embedding values + 8 linear weights)
-    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)kBM * 4 + (size_t)8 * (kDIN + 16) * 4;
+    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)bm * 4 + (size_t)8 * (kDIN + 16) * 4;
 }
 
 // MODEL 1 = DNN3, 2 = two-tower item side.  WM x WN = wave grid over (items, hidden columns); CH = layer-1
@@ -133,22 +133,24 @@ constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep) {
 // the head epilogue (the fp32 H2 tile goes through LDS H2/EP columns at a time — EP = 2 halves the LDS
 // footprint so that two workgroups share a CU); OCC = workgroups per CU the register budget is set for.
 // FK: two-tower only — width of a field embedding; the item side has kDIN / FK fields (8 x 16, 4 x 32, 16 x 8).
-template <int PREC, int H1, int H2, bool ACT2, int WM, int WN, int MODEL, int CH, int EP, int OCC, int FK = 16>
+// BM: items per workgroup tile (128; 64 where more, smaller workgroups per CU hide the gathers' latency better).
+template <int PREC, int H1, int H2, bool ACT2, int WM, int WN, int MODEL, int CH, int EP, int OCC, int FK = 16, int BM = kBM>
 __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
-    constexpr int MB = 4 / WM;
+    constexpr int MB = BM / 32 / WM;
+    constexpr int NP = BM / 8;                         // gather passes: 8 items (32 lanes x 16 B each) per pass
     constexpr int L1NB = CH / 32 / WN;
     constexpr int L2NB = H2 / 32 / WN;
     constexpr int ES = PREC ? 2 : 4;
-    constexpr int TILE_B = kBM * kDIN * ES;
-    constexpr int H1_B = kBM * CH * ES;
+    constexpr int TILE_B = BM * kDIN * ES;
+    constexpr int H1_B = BM * CH * ES;
     constexpr int NCHUNK = H1 / CH;
     constexpr int KG1 = PREC ? kDIN / 16 : kDIN / 8;   // k-groups (fragments) of the 128-deep layer-1 GEMM
     constexpr int KGC = PREC ? CH / 16 : CH / 8;       // k-groups of one CH-deep layer-2 partial GEMM
     constexpr int HH = H2 / EP;                        // head columns per epilogue pass
     // H1 chunk tiles: double-buffered where two workgroups still fit a CU's 160 KB
     constexpr int NH1 = (PREC && TILE_B + 2 * H1_B <= 72 * 1024) ? 2 : 1;
-    constexpr size_t REGION = (size_t)(TILE_B + NH1 * H1_B) > (size_t)kBM * (HH + 4) * 4
-                                  ? (size_t)(TILE_B + NH1 * H1_B) : (size_t)kBM * (HH + 4) * 4;
+    constexpr size_t REGION = (size_t)(TILE_B + NH1 * H1_B) > (size_t)BM * (HH + 4) * 4
+                                  ? (size_t)(TILE_B + NH1 * H1_B) : (size_t)BM * (HH + 4) * 4;
     static_assert(L1NB >= 1 && L2NB >= 1 && MB >= 1, "bad wave layout");
     static_assert(EP == 1 || (EP == 2 && HH % 32 == 0), "epilogue passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
     float* const H2T = reinterpret_cast<float*>(smem);      // aliases XT/H1T after the GEMMs
     float* const w3s = reinterpret_cast<float*>(smem + REGION);
     float* const b3s = w3s + H2;
-    float* const fm_stage = b3s + kBM;                      // [8 groups][8*16 + 8] (two-tower prologue only)
+    float* const fm_stage = b3s + BM;                       // [8 groups][8*16 + 8] (two-tower prologue only)
 
     const uint32_t tile = blockIdx.x;
     if (tile >= *a.n_tiles) return;
@@ -175,10 +177,10 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
         const int c = tid & 31;
         for (int i = tid; i < H2; i += 256) w3s[i] = a.w3[(size_t)req * a.w3_stride + i];
         if constexpr (MODEL == 1) {
-            if (tid < kBM) b3s[tid] = a.b3;
-            float4 v[16];
+            if (tid < BM) b3s[tid] = a.b3;
+            float4 v[NP];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const uint32_t r = p * 8 + (tid >> 5);
                 const uint32_t idx = item0 + (r < cnt ? r : cnt - 1);
                 uint32_t row = a.cand_rows[idx];
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int p = 0; p < 16; ++p) store_x_quad<PREC>(XT, p * 8 + (tid >> 5), c, v[p]);
+            for (int p = 0; p < NP; ++p) store_x_quad<PREC>(XT, p * 8 + (tid >> 5), c, v[p]);
         } else {
             // two-tower: field f = c/4, quad qd = c%4 of that field's 16-wide embedding; the FM
             // sums ride along in registers (fields accumulate sequentially, f ascending).
@@ -199,18 +201,18 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             const float* lin_tab = a.field_lin[a.n_user_fields + f];
             // three waves of independent loads (ids → embedding quads + linear weights), then the arithmetic:
             // one item at a time this was 16 serial round trips per thread
-            int32_t ids[16];
+            int32_t ids[NP];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const uint32_t r = p * 8 + (tid >> 5);
                 const uint32_t idx = item0 + (r < cnt ? r : cnt - 1);
                 const int32_t id = a.item_field_ids[(size_t)idx * NF + f];
                 ids[p] = id < 0 ? 0 : (id >= (int32_t)a.vocab ? (int32_t)a.vocab - 1 : id);
             }
-            float4 v[16];
-            float linv[16];
+            float4 v[NP];
+            float linv[NP];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 v[p] = *reinterpret_cast<const float4*>(emb + (size_t)ids[p] * FK + 4 * qd);
                 linv[p] = qd == 0 ? lin_tab[ids[p]] : 0.0f;
             }
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             const float fuq = c < FK ? fu[1 + kFmMaxK + c] : 0.0f;
             const float fu_lin = fu[0];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const uint32_t r = p * 8 + grp;
                 store_x_quad<PREC>(XT, r, c, v[p]);
                 *reinterpret_cast<float4*>(st + f * FK + 4 * qd) = v[p];
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                                     relu2(acc2[mb][nb][4 * g + 2]), relu2(acc2[mb][nb][4 * g + 3]));
                 }
         __syncthreads();
-        const int row = tid >> 1, half = tid & 1;
+        const int row = (tid >> 1) < BM ? (tid >> 1) : BM - 1, half = tid & 1;      // (BM < 128: the surplus threads idle along)
         const float4* hr = reinterpret_cast<const float4*>(H2T + row * HS + half * (H2 / 2));
         const float4* wr = reinterpret_cast<const float4*>(w3s + half * (H2 / 2));
         float p = half ? 0.0f : b3s[row];
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
         }
         const float o = __shfl_xor(p, 1);
         const float z = half ? (o + p) : (p + o);
-        if (half == 0 && (uint32_t)row < cnt) a.out[item0 + row] = 1.0f / (1.0f + expf(-z));
+        if (half == 0 && (tid >> 1) < BM && (uint32_t)row < cnt) a.out[item0 + row] = 1.0f / (1.0f + expf(-z));
     } else {
         // pass e carries columns [e*HH, (e+1)*HH) = half chain e; thread `row` (tid < 128) runs both
         float ph[2] = {0.0f, 0.0f};
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                     }
             }
             __syncthreads();
-            if (tid < kBM) {
+            if (tid < BM) {
                 const float4* hr = reinterpret_cast<const float4*>(H2T + tid * HS);
                 const float4* wr = reinterpret_cast<const float4*>(w3s + e * HH);
                 float p = e ? 0.0f : b3s[tid];
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                 ph[e] = p;
             }
         }
-        if (tid < kBM && (uint32_t)tid < cnt) a.out[item0 + tid] = 1.0f / (1.0f + expf(-(ph[0] + ph[1])));
+        if (tid < BM && (uint32_t)tid < cnt) a.out[item0 + tid] = 1.0f / (1.0f + expf(-(ph[0] + ph[1])));
     }
 }
 
@@ -512,40 +514,62 @@ __global__ __launch_bounds__(256) void fm2t_user_kernel(
     const float* const* __restrict__ field_lin, const int32_t* __restrict__ user_field_ids,
     uint32_t vocab, float fm_b, float* __restrict__ uo, float* __restrict__ fm_user, uint32_t nuf, uint32_t fk) {
     __shared__ float u1[1024];
+    __shared__ float us[4096];
     const uint32_t r = blockIdx.x, tid = threadIdx.x;
+    if (blockIdx.y == 1) {                       // the FM prefix of the request, beside the tower (its own workgroup)
+        if (!user_field_ids) return;
+        if (tid < fk) {
+            float s = 0.0f, q = 0.0f;
+            for (uint32_t f = 0; f < nuf; ++f) {
+                int32_t id = user_field_ids[(size_t)r * nuf + f];
+                id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
+                const float v = field_emb[f][(size_t)id * fk + tid];
+                s = s + v;
+                q = __fmaf_rn(v, v, q);
+            }
+            fm_user[(size_t)r * kFmUserStride + 1 + tid] = s;
+            fm_user[(size_t)r * kFmUserStride + 1 + kFmMaxK + tid] = q;
+        }
+        if (tid == 64) {
+            float lin = fm_b;
+            for (uint32_t f = 0; f < nuf; ++f) {
+                int32_t id = user_field_ids[(size_t)r * nuf + f];
+                id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
+                lin = lin + field_lin[f][id];
+            }
+            fm_user[(size_t)r * kFmUserStride] = lin;
+        }
+        return;
+    }
+    for (uint32_t k = tid; k < du; k += blockDim.x) us[k] = round_prec(user[(size_t)r * du + k], prec);
+    __syncthreads();
+    // the chains are sequential in k; their loads are not — eight weight rows are requested ahead of the eight fmafs
     for (uint32_t j = tid; j < th; j += blockDim.x) {
         float acc = ub1[j];
-        for (uint32_t k = 0; k < du; ++k)
-            acc = __fmaf_rn(round_prec(user[(size_t)r * du + k], prec), uw1[(size_t)k * th + j], acc);
+        uint32_t k = 0;
+        for (; k + 8 <= du; k += 8) {
+            float wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] = uw1[(size_t)(k + i) * th + j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = __fmaf_rn(us[k + i], wv[i], acc);
+        }
+        for (; k < du; ++k) acc = __fmaf_rn(us[k], uw1[(size_t)k * th + j], acc);
         u1[j] = round_prec(acc > 0.0f ? acc : 0.0f, prec);
     }
     __syncthreads();
     for (uint32_t o = tid; o < to; o += blockDim.x) {
         float acc = ub2[o];
-        for (uint32_t j = 0; j < th; ++j) acc = __fmaf_rn(u1[j], uw2[(size_t)j * to + o], acc);
+        uint32_t j = 0;
+        for (; j + 8 <= th; j += 8) {
+            float wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] = uw2[(size_t)(j + i) * to + o];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = __fmaf_rn(u1[j + i], wv[i], acc);
+        }
+        for (; j < th; ++j) acc = __fmaf_rn(u1[j], uw2[(size_t)j * to + o], acc);
         uo[(size_t)r * to + o] = acc;
-    }
-    if (!user_field_ids) return;                 // embedding only (pg_fm2t_user_embedding)
-    if (tid < fk) {
-        float s = 0.0f, q = 0.0f;
-        for (uint32_t f = 0; f < nuf; ++f) {
-            int32_t id = user_field_ids[(size_t)r * nuf + f];
-            id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
-            const float v = field_emb[f][(size_t)id * fk + tid];
-            s = s + v;
-            q = __fmaf_rn(v, v, q);
-        }
-        fm_user[(size_t)r * kFmUserStride + 1 + tid] = s;
-        fm_user[(size_t)r * kFmUserStride + 1 + kFmMaxK + tid] = q;
-    }
-    if (tid == 64) {
-        float lin = fm_b;
-        for (uint32_t f = 0; f < nuf; ++f) {
-            int32_t id = user_field_ids[(size_t)r * nuf + f];
-            id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
-            lin = lin + field_lin[f][id];
-        }
-        fm_user[(size_t)r * kFmUserStride] = lin;
     }
 }
 
@@ -646,13 +670,23 @@ static int launch_dnn3_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
     }
     return PG_OK;
 }
+// two-tower bf16 tiles.  64-item tiles (four workgroups per CU, no pre-loaded B fragments) measured SLOWER than 128-item
+// tiles with two workgroups per CU and pre-loaded fragments (0.66 vs 0.52 ms per 1.28 M items): every tile re-reads the
+// towers' 96 KB of weight fragments from L2, so halving the tile doubles that traffic — the kernel wants its weights
+// stationary, not more occupancy
+constexpr int kFmBM = 128;
 template <int PREC, int TH, int TO, int FK>
 static int launch_fm2t_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
     int rc;
-    constexpr int OCC = PREC ? 2 : 1;
-    constexpr size_t lds = mlp_lds_bytes(PREC, TO, 128, 1);
-    if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<PREC, TH, TO, false, 2, 2, 2, 128, 1, OCC, FK>, lds))) return rc;
-    mlp_kernel<PREC, TH, TO, false, 2, 2, 2, 128, 1, OCC, FK><<<grid, 256, lds, ctx->stream>>>(a);
+    if constexpr (PREC == 1) {
+        constexpr size_t lds = mlp_lds_bytes(1, TO, 128, 1, kFmBM);
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, TH, TO, false, 2, 2, 2, 128, 1, 2, FK, kFmBM>, lds))) return rc;
+        mlp_kernel<1, TH, TO, false, 2, 2, 2, 128, 1, 2, FK, kFmBM><<<grid, 256, lds, ctx->stream>>>(a);
+    } else {
+        constexpr size_t lds = mlp_lds_bytes(0, TO, 128, 1);
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, TH, TO, false, 2, 2, 2, 128, 1, 1, FK>, lds))) return rc;
+        mlp_kernel<0, TH, TO, false, 2, 2, 2, 128, 1, 1, FK><<<grid, 256, lds, ctx->stream>>>(a);
+    }
     return PG_OK;
 }
 // (h1, h2) of DNN3 and (t_h1, t_out, k) of the two-tower model; d_item is 64 or 128 (64: the gathered row is padded
@@ -742,14 +776,15 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
                                 const int32_t* d_ufids, const int32_t* d_ifids, const uint32_t* d_off,
                                 uint32_t n_req, uint32_t n_items, float* d_out) {
     if (n_items == 0 || n_req == 0) return PG_OK;
-    const uint32_t max_tiles = n_items / kBM + n_req;
+    const uint32_t bm = m->prec ? (uint32_t)kFmBM : (uint32_t)kBM;
+    const uint32_t max_tiles = n_items / bm + n_req;
     RankScratch rs;
     int rc;
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->to, &rs))) return rc;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     build_tiles_kernel<<<1, 1024, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
-                                                   rs.n_tiles, rs.req_tile0, (uint32_t)kBM);
-    fm2t_user_kernel<<<n_req, 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th,
+                                                   rs.n_tiles, rs.req_tile0, bm);
+    fm2t_user_kernel<<<dim3(n_req, 2), 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th,
                                                      m->to, m->prec, m->d_field_emb, m->d_field_lin, d_ufids,
                                                      m->vocab, m->fm_b, rs.c1, rs.fm_user, m->nuf, m->k);
     MlpArgs a{};
