@@ -124,8 +124,7 @@ constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep, int bm = kBM) {
     const size_t nh1 = (prec && (size_t)bm * (kDIN + 2 * ch) * es <= 72 * 1024) ? 2 : 1;   // as NH1 in mlp_kernel
     const size_t tiles = (size_t)bm * (kDIN + nh1 * ch) * es;
     const size_t h2t = (size_t)bm * (h2 / ep + 4) * 4;
-    // + the two-tower prologue's FM staging: 8 item groups x (8 fields x 16 embedding values + 8 linear weights)
-    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)bm * 4 + (size_t)8 * (kDIN + 16) * 4;
+    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)bm * 4;
 }
 
 // MODEL 1 = DNN3, 2 = two-tower item side.  WM x WN = wave grid over (items, hidden columns); CH = layer-1
@@ -159,7 +158,6 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
     float* const H2T = reinterpret_cast<float*>(smem);      // aliases XT/H1T after the GEMMs
     float* const w3s = reinterpret_cast<float*>(smem + REGION);
     float* const b3s = w3s + H2;
-    float* const fm_stage = b3s + BM;                       // [8 groups][8*16 + 8] (two-tower prologue only)
 
     const uint32_t tile = blockIdx.x;
     if (tile >= *a.n_tiles) return;
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
         const int nbg0 = wn * L2NB;
         return [=](int nb, int step) { return (size_t)((nbg0 + nb) * KG2 + chunk * KGC + step) * 1024; };
     };
-    constexpr bool PRE = PREC == 1 && OCC == 2;        // preloaded B fragments (bf16, two workgroups per CU)
+    constexpr bool PRE = PREC == 1 && OCC >= 2;        // preloaded B fragments (bf16, several workgroups per CU)
     bf16x8 b1f[PRE ? KG1 : 1][PRE ? L1NB : 1];
     bf16x8 b2f[PRE ? KGC : 1][PRE ? L2NB : 1];
     if constexpr (PRE) load_bfrags<L1NB, KG1>(b1f, reinterpret_cast<const char*>(a.w1p), frag1(0), lane);
@@ -679,6 +677,8 @@ template <int PREC, int TH, int TO, int FK>
 static int launch_fm2t_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
     int rc;
     if constexpr (PREC == 1) {
+        // (three workgroups per CU — 64-column layer-1 chunks, 48 KB of LDS, <= 168 registers — measured 0.53 vs 0.45 ms:
+        //  twice the chunks and barriers per tile cost more than the extra waves hide)
         constexpr size_t lds = mlp_lds_bytes(1, TO, 128, 1, kFmBM);
         if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, TH, TO, false, 2, 2, 2, 128, 1, 2, FK, kFmBM>, lds))) return rc;
         mlp_kernel<1, TH, TO, false, 2, 2, 2, 128, 1, 2, FK, kFmBM><<<grid, 256, lds, ctx->stream>>>(a);
