@@ -975,15 +975,16 @@ __global__ void screen_prep_kernel(const float* __restrict__ qpad, uint32_t dim,
 }
 
 // bf16 screen: thr_screen = thr (the margin is applied per block in the kernel), or -inf
-__global__ void screen_thr_kernel(const float* __restrict__ thr, const float* __restrict__ eps,
+__global__ void screen_thr_kernel(const float* __restrict__ thr, const float* __restrict__ eps, float max_norm,
                                   float* __restrict__ thr_screen) {
     const uint32_t q = threadIdx.x;
     if (q >= (uint32_t)kMaxQueries) return;
     const float t = thr[q], e = eps[q];
     // the kernel subtracts eps_unit x block norm itself; non-finite queries, or magnitudes whose bf16 partial sums
-    // could overflow: everything passes the screen and the exact re-scoring decides
+    // could overflow — |partial sum| <= ||x|| ||q|| = 125 eps_unit ||x||, and an inf - inf accumulator would be a NaN
+    // that the block-reject max chain drops silently — : everything passes the screen and the exact re-scoring decides
     float v = t;
-    if (!(e == e) || e > 1e28f || !(t == t)) v = -__builtin_inff();
+    if (!(e == e) || e > 1e28f || !(t == t) || !(e * max_norm < 1e35f)) v = -__builtin_inff();
     thr_screen[q] = v;
 }
 
@@ -1859,7 +1860,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
         if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk))) return rc2;
         if (j->screen) {
             if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
-            else screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.thr_screen);
+            else screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, t->max_norm, rs.thr_screen);
             PG_HIP(hipGetLastError());
         }
         cur ^= 1;

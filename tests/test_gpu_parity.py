@@ -150,6 +150,24 @@ def test_recall_screen_is_exact_on_hostile_data(ctx):
     t.destroy()
 
 
+def test_recall_bf16_screen_with_huge_row_norms(ctx):
+    """dim 64 is screened in bf16.  Rows and queries of norm ~1e18-1e19 are finite, but their bf16 partial sums can
+    reach inf - inf = NaN, which a max chain drops silently: the screen must stand aside for such
+    magnitudes (threshold -inf: every row is re-scored exactly).  Half the queries are huge, half ordinary."""
+    rng = np.random.default_rng(31)
+    n, d, k, nq = 90_000, 64, 300, 40
+    tab = rng.standard_normal((n, d)).astype(np.float32)
+    tab[::7] *= np.float32(2e18)
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[::2] *= np.float32(1e18)
+    rows, scores, _ = t.recall_topk(q, k)
+    orow, osc = o.recall_topk(tab, q, k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+    t.destroy()
+
+
 def test_recall_int8_screen_is_exact_on_hostile_data(ctx):
     """dim 128 is screened on an int8 shadow with ONE scale for the table (max|x| / 127) and an error bound that
     uses the measured quantisation residual.  Data built against exactly that: an outlier that coarsens the scale
