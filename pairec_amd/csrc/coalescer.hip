@@ -84,6 +84,7 @@ struct Slot {
     uint32_t* d_order = nullptr;
     uint32_t* d_count = nullptr;           // [max_batch]
     char* d_page = nullptr;                // recommend: the sorted pages, layout as h_out
+    RecommendCall call;                    // recommend: what was enqueued (the verification may re-run single requests)
 };
 
 inline void futex_wait(std::atomic<uint32_t>* w, uint32_t expect) {
@@ -192,13 +193,52 @@ void free_slot(pg_coalescer* c, Slot* s) {
     delete s;
 }
 
-// Enqueue the slot's batch: inputs host → device, the kernels, outputs device → pinned host (on the copy stream,
-// so the next batch's kernels do not queue behind a PCIe transfer), the completion event.  first = false: the
-// recall plan of a recall / recommend batch did not hold; run its next plan and everything behind it again.
+// Outputs device → pinned host on the copy stream (so the next batch's kernels do not queue behind a PCIe transfer),
+// then the completion event.  Called behind the batch's kernels, and again when the verification patched single
+// requests in place.
+int slot_copy_out(pg_coalescer* c, Slot* s) {
+    hipStream_t st = s->ctx->stream;
+    const uint32_t nq = s->n_req;
+    if (s->kind == kRank) {
+        PG_HIP(hipEventRecord(s->computed, st));
+        PG_HIP(hipStreamWaitEvent(c->copy_stream, s->computed, 0));
+        PG_HIP(hipMemcpyAsync(s->h_out, s->d_rank, (size_t)s->n_items * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        PG_HIP(hipEventRecord(s->done, c->copy_stream));
+        return PG_OK;
+    }
+    if (s->kind == kRecall) {
+        PG_HIP(hipEventRecord(s->computed, st));
+        PG_HIP(hipStreamWaitEvent(c->copy_stream, s->computed, 0));
+        const size_t nk = (size_t)nq * c->k;
+        PG_HIP(hipMemcpyAsync(s->h_out, s->d_rows, nk * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        PG_HIP(hipMemcpyAsync(s->h_out + (size_t)c->max_batch * c->k * 8, s->d_recall, nk * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        PG_HIP(hipEventRecord(s->done, c->copy_stream));
+        return PG_OK;
+    }
+    // recommend: the largest page any request of the batch asked for
+    const uint32_t top = s->n_items;
+    const size_t np = (size_t)nq * top;
+    uint64_t* p_rows = (uint64_t*)s->d_page;
+    double* p_fused = (double*)(p_rows + np);
+    float* p_recall = (float*)(p_fused + np);
+    float* p_rank = p_recall + np;
+    page_gather_kernel<<<(uint32_t)((np + 255) / 256), 256, 0, st>>>(s->d_order, s->d_rows, s->d_recall, s->d_rank, s->d_fused, nq,
+                                                                    c->k, top, p_rows, p_fused, p_recall, p_rank);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipEventRecord(s->computed, st));
+    PG_HIP(hipStreamWaitEvent(c->copy_stream, s->computed, 0));
+    PG_HIP(hipMemcpyAsync(s->h_out, s->d_page, np * 24, hipMemcpyDeviceToHost, c->copy_stream));
+    PG_HIP(hipMemcpyAsync(s->h_out + page_bytes(c), s->d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, c->copy_stream));
+    PG_HIP(hipEventRecord(s->done, c->copy_stream));
+    return PG_OK;
+}
+
+// Enqueue the slot's batch: inputs host → device, the kernels, the copy-out.  first = false: the recall plan of a
+// recall / recommend batch did not hold; run its next plan and everything behind it again.
 int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
     pg_ctx* ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    const uint32_t nq = (uint32_t)s->reqs.size();
+    const uint32_t nq = (uint32_t)s->n_req;
     int rc;
     if (s->kind == kRank) {
         PG_HIP(hipMemcpyAsync(s->d_vec, s->h_vec, (size_t)nq * c->d_user * 4, hipMemcpyHostToDevice, st));
@@ -208,11 +248,7 @@ int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
             std::lock_guard<std::mutex> g(ctx->mu);
             if ((rc = rank_dnn3_dev_locked(ctx, c->m, c->t, s->d_vec, s->d_cand, s->d_off, nq, s->n_items, s->d_rank))) return rc;
         }
-        PG_HIP(hipEventRecord(s->computed, st));
-        PG_HIP(hipStreamWaitEvent(c->copy_stream, s->computed, 0));
-        PG_HIP(hipMemcpyAsync(s->h_out, s->d_rank, (size_t)s->n_items * 4, hipMemcpyDeviceToHost, c->copy_stream));
-        PG_HIP(hipEventRecord(s->done, c->copy_stream));
-        return PG_OK;
+        return slot_copy_out(c, s);
     }
     if (first) PG_HIP(hipMemcpyAsync(s->d_vec, s->h_vec, (size_t)nq * c->dim * 4, hipMemcpyHostToDevice, st));
     if (s->kind == kRecall) {
@@ -233,18 +269,14 @@ int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
                 j.events = &s->run->events;
                 if ((rc = recall_job_prepare(&j))) return rc;
             }
+            s->run->patched = false;
             if ((rc = recall_job_enqueue(&j))) return rc;
         }
-        PG_HIP(hipEventRecord(s->computed, st));
-        PG_HIP(hipStreamWaitEvent(c->copy_stream, s->computed, 0));
-        const size_t nk = (size_t)nq * c->k;
-        PG_HIP(hipMemcpyAsync(s->h_out, s->d_rows, nk * 8, hipMemcpyDeviceToHost, c->copy_stream));
-        PG_HIP(hipMemcpyAsync(s->h_out + (size_t)c->max_batch * c->k * 8, s->d_recall, nk * 4, hipMemcpyDeviceToHost, c->copy_stream));
-        PG_HIP(hipEventRecord(s->done, c->copy_stream));
-        return PG_OK;
+        return slot_copy_out(c, s);
     }
     // recommend
-    RecommendCall rc_call;
+    RecommendCall& rc_call = s->call;
+    rc_call = RecommendCall();
     rc_call.t = c->t;
     rc_call.m = c->m;
     rc_call.e = c->e;
@@ -260,24 +292,10 @@ int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
     rc_call.d_order = s->d_order;
     rc_call.d_count = s->d_count;
     if ((rc = recommend_enqueue(ctx, rc_call, s->run, first))) return rc;
-    // the largest page any request of the batch asked for
     uint32_t top = 1;
     for (const Req* r : s->reqs) top = std::max(top, r->n);
-    const size_t np = (size_t)nq * top;
-    uint64_t* p_rows = (uint64_t*)s->d_page;
-    double* p_fused = (double*)(p_rows + np);
-    float* p_recall = (float*)(p_fused + np);
-    float* p_rank = p_recall + np;
-    page_gather_kernel<<<(uint32_t)((np + 255) / 256), 256, 0, st>>>(s->d_order, s->d_rows, s->d_recall, s->d_rank, s->d_fused, nq,
-                                                                    c->k, top, p_rows, p_fused, p_recall, p_rank);
-    PG_HIP(hipGetLastError());
-    PG_HIP(hipEventRecord(s->computed, st));
-    PG_HIP(hipStreamWaitEvent(c->copy_stream, s->computed, 0));
-    PG_HIP(hipMemcpyAsync(s->h_out, s->d_page, np * 24, hipMemcpyDeviceToHost, c->copy_stream));
-    PG_HIP(hipMemcpyAsync(s->h_out + page_bytes(c), s->d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, c->copy_stream));
-    PG_HIP(hipEventRecord(s->done, c->copy_stream));
     s->n_items = top;
-    return PG_OK;
+    return slot_copy_out(c, s);
 }
 
 // finish every request of a slot with (rc, message of this thread) and wake the callers
@@ -417,7 +435,14 @@ void completer_main(pg_coalescer* c) {
             }
             if (s->kind == kRank) break;
             bool ok = false;
-            if ((rc = recommend_verify(s->ctx, s->run, &ok))) break;     // (recall_job_check + finish under ctx->mu)
+            // (recall_job_check + finish under ctx->mu; a few failed requests are re-run in place)
+            if ((rc = recommend_verify(s->ctx, s->run, &ok, s->kind == kRecommend ? &s->call : nullptr))) break;
+            if (ok && s->run->patched) {                 // device outputs changed after the copy-out: copy again
+                s->run->patched = false;
+                replanned = true;
+                if ((rc = slot_copy_out(c, s))) break;
+                continue;
+            }
             if (ok) break;
             replanned = true;
             if ((rc = slot_enqueue(c, s, false))) break;

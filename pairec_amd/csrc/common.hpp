@@ -166,6 +166,7 @@ struct RecallJob {
     uint32_t* d_out_count = nullptr;        // [nq] device, optional
     uint32_t* h_status = nullptr;           // pinned host, >= 1 + nq words: [0] overflow flag, [1 + q] valid count of query q
     std::vector<hipEvent_t>* events = nullptr;   // timing events (grown on demand); one job at a time per pool
+    bool skip_pilot = false;                // start with the growing-chunk plan (the re-run of a query the pilot failed)
     // state (recall_job_*)
     RecallScratch rs{};
     uint32_t* d_count = nullptr;
@@ -178,14 +179,22 @@ struct RecallJob {
     double scan_ms = 0.0, total_ms = 0.0;
     uint64_t scanned_rows = 0;
     uint32_t scan_launches = 0;
+    // after a failed check of the pilot plan without overflow: the queries that ended short of K candidates (their
+    // sample threshold was too high).  A handful can be re-run one by one instead of re-running the whole batch.
+    std::vector<uint32_t> failed;
 };
+constexpr size_t kMaxPatchQueries = 8;
 // All four: caller holds ctx->mu.  prepare may synchronise once (a table's statistics / shadow on first use).
 int recall_job_prepare(RecallJob* j);
 int recall_job_enqueue(RecallJob* j);                 // enqueue the next plan + the status copy into h_status
 int recall_job_check(RecallJob* j, bool* ok);         // after the stream passed the status copy: did the plan hold?
 void recall_job_finish(RecallJob* j);                 // publish timing / counters into ctx
 int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq, uint32_t k,
-                      uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count, uint32_t* d_out_count);
+                      uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count, uint32_t* d_out_count,
+                      bool skip_pilot = false);
+// re-run the failed queries of `j` (at most kMaxPatchQueries) one by one, synchronously, writing into their slices of
+// the job's outputs and their valid counts into counts[q]; caller holds ctx->mu
+int recall_patch_failed_locked(RecallJob* j, uint32_t* counts);
 int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs);
 int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
                   uint32_t cap, uint32_t k);

@@ -90,19 +90,55 @@ int recommend_bind_vars(const pg_expr* e, const char* rank_var, std::vector<int>
     return PG_OK;
 }
 
-int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool first) {
-    std::lock_guard<std::mutex> g(ctx->mu);
-    const uint32_t n = c.nq * c.k;
+// the stages behind the recall for requests [q0, q0 + nq) of the call (caller holds ctx->mu; d_err is indexed from 0)
+static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, uint32_t* d_local,
+                                 uint32_t* d_off, uint32_t* d_err, double* d_vars) {
+    const uint32_t n = nq * c.k;
+    const size_t o = (size_t)q0 * c.k;
     int rc;
+    if ((rc = uniform_offsets_locked(ctx, nq, c.k, d_off))) return rc;
+    if ((rc = rows_to_local_locked(ctx, c.t, c.d_rows + o, n, d_local, nullptr))) return rc;
+    if ((rc = rank_dnn3_dev_locked(ctx, c.m, c.t, c.d_queries + (size_t)q0 * c.t->dim, d_local, d_off, nq, n, c.d_rank + o))) return rc;
+    uint32_t mask = 0;
+    for (int i = 0; i < c.nv; ++i) mask |= (c.var_src[i] ? 1u : 0u) << i;
+    if (c.nv > 0) {
+        bind_vars_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(c.d_recall + o, c.d_rank + o, n, (uint32_t)c.nv, mask, d_vars);
+        PG_HIP(hipGetLastError());
+    }
+    PG_HIP(hipMemsetAsync(d_err, 0, (size_t)kMaxQueries * 4, ctx->stream));
+    if ((rc = expr_eval_enqueue_locked(ctx, c.e, d_vars, n, c.d_fused + o, d_err, c.k))) return rc;
+    if (c.t->rows < c.k) {
+        mask_pads_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(c.d_rows + o, n, c.d_rank + o, c.d_fused + o);
+        PG_HIP(hipGetLastError());
+    }
+    return sort_dev_locked(ctx, c.d_fused + o, d_off, nq, n, c.k, 1, c.d_order + o);
+}
+
+struct PostScratch {
+    uint32_t *d_local, *d_off, *d_err;
+    double* d_vars;
+};
+static int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostScratch* ps) {
+    const uint32_t n = nq * c.k;
     void* buf;
+    int rc;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b_local = al((size_t)n * 4), b_off = al((size_t)(c.nq + 1) * 4), b_err = al((size_t)kMaxQueries * 4);
+    const size_t b_local = al((size_t)n * 4), b_off = al((size_t)(nq + 1) * 4), b_err = al((size_t)kMaxQueries * 4);
     const size_t b_vars = al((size_t)std::max(c.nv, 1) * n * 8);
     if ((rc = scratch_reserve(ctx, 8, b_local + b_off + b_err + b_vars, &buf))) return rc;
-    uint32_t* d_local = (uint32_t*)buf;
-    uint32_t* d_off = (uint32_t*)((char*)buf + b_local);
-    uint32_t* d_err = (uint32_t*)((char*)buf + b_local + b_off);
-    double* d_vars = (double*)((char*)buf + b_local + b_off + b_err);
+    ps->d_local = (uint32_t*)buf;
+    ps->d_off = (uint32_t*)((char*)buf + b_local);
+    ps->d_err = (uint32_t*)((char*)buf + b_local + b_off);
+    ps->d_vars = (double*)((char*)buf + b_local + b_off + b_err);
+    return PG_OK;
+}
+
+int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool first) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    int rc;
+    PostScratch ps;
+    if ((rc = post_scratch(ctx, c, c.nq, &ps))) return rc;
+    r->patched = false;
     if (first) {
         RecallJob& j = r->job;
         j = RecallJob();
@@ -118,32 +154,40 @@ int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool firs
         j.events = &r->events;
         if ((rc = recall_job_prepare(&j))) return rc;
     }
-    if ((rc = uniform_offsets_locked(ctx, c.nq, c.k, d_off))) return rc;
     if ((rc = recall_job_enqueue(&r->job))) return rc;
-    if ((rc = rows_to_local_locked(ctx, c.t, c.d_rows, n, d_local, nullptr))) return rc;
-    if ((rc = rank_dnn3_dev_locked(ctx, c.m, c.t, c.d_queries, d_local, d_off, c.nq, n, c.d_rank))) return rc;
-    uint32_t mask = 0;
-    for (int i = 0; i < c.nv; ++i) mask |= (c.var_src[i] ? 1u : 0u) << i;
-    if (c.nv > 0) {
-        bind_vars_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(c.d_recall, c.d_rank, n, (uint32_t)c.nv, mask, d_vars);
-        PG_HIP(hipGetLastError());
-    }
-    PG_HIP(hipMemsetAsync(d_err, 0, (size_t)kMaxQueries * 4, ctx->stream));
-    if ((rc = expr_eval_enqueue_locked(ctx, c.e, d_vars, n, c.d_fused, d_err, c.k))) return rc;
-    if (c.t->rows < c.k) {
-        mask_pads_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(c.d_rows, n, c.d_rank, c.d_fused);
-        PG_HIP(hipGetLastError());
-    }
-    if ((rc = sort_dev_locked(ctx, c.d_fused, d_off, c.nq, n, c.k, 1, c.d_order))) return rc;
-    PG_HIP(hipMemcpyAsync(r->h_status + kExprFlagAt, d_err, (size_t)c.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = recommend_post_locked(ctx, c, 0, c.nq, ps.d_local, ps.d_off, ps.d_err, ps.d_vars))) return rc;
+    PG_HIP(hipMemcpyAsync(r->h_status + kExprFlagAt, ps.d_err, (size_t)c.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipEventRecord(r->done, ctx->stream));
     return PG_OK;
 }
 
-int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok) {
+int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok, const RecommendCall* c) {
     std::lock_guard<std::mutex> g(ctx->mu);
     int rc;
     if ((rc = recall_job_check(&r->job, ok))) return rc;
+    RecallJob& j = r->job;
+    if (!*ok && !j.failed.empty() && j.failed.size() <= kMaxPatchQueries && j.nq > 1) {
+        // The pilot's threshold was too high for a few requests only (a 1e-4 event per request at the default margin):
+        // re-run those requests — recall from the growing-chunk plan, then the stages behind it — synchronously and in
+        // place, instead of the whole batch.  The nested recalls use the context's own status block.
+        const std::vector<uint32_t> failed = j.failed;
+        uint32_t counts[kMaxQueries];
+        for (uint32_t q = 0; q < j.nq; ++q) counts[q] = r->h_status[1 + q];
+        if ((rc = recall_patch_failed_locked(&j, counts))) return rc;
+        for (uint32_t q = 0; q < j.nq; ++q) r->h_status[1 + q] = counts[q];
+        if (c) {
+            PostScratch ps;
+            if ((rc = post_scratch(ctx, *c, 1, &ps))) return rc;
+            for (uint32_t q : failed) {
+                if ((rc = recommend_post_locked(ctx, *c, q, 1, ps.d_local, ps.d_off, ps.d_err, ps.d_vars))) return rc;
+                PG_HIP(hipMemcpyAsync(r->h_status + kExprFlagAt + q, ps.d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+                PG_HIP(hipStreamSynchronize(ctx->stream));
+            }
+        }
+        PG_HIP(hipStreamSynchronize(ctx->stream));
+        r->patched = true;
+        *ok = true;
+    }
     if (*ok) recall_job_finish(&r->job);
     return PG_OK;
 }
@@ -197,7 +241,7 @@ int pg_recommend_end(pg_ctx* ctx, pg_ticket* tk, double* scan_ms) {
             rc = PG_ERR_DEVICE;
             break;
         }
-        if ((rc = pg::recommend_verify(ctx, tk->run, &ok))) break;
+        if ((rc = pg::recommend_verify(ctx, tk->run, &ok, &tk->call))) break;
         if (!ok && (rc = pg::recommend_enqueue(ctx, tk->call, tk->run, false))) break;
     }
     if (!rc) {

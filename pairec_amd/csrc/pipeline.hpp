@@ -8,11 +8,13 @@ namespace pg {
 
 // Private resources of one in-flight batch: several may be queued on a context's stream at once, so whatever the
 // host reads back later (status words, timing events) cannot live in the context.
+struct RecommendCall;
 struct PipeRun {
     RecallJob job;
     uint32_t* h_status = nullptr;      // pinned: [0 .. 256] recall status, [kExprFlagAt .. +256) RankScore flags per request
     std::vector<hipEvent_t> events;    // the recall's timing events
     hipEvent_t done = nullptr;         // recorded behind the batch's last command
+    bool patched = false;              // the last verification re-ran a few requests in place: device outputs changed after `done`
 };
 constexpr uint32_t kExprFlagAt = 320;
 constexpr uint32_t kPipeStatusWords = 640;
@@ -45,7 +47,9 @@ int recommend_bind_vars(const pg_expr* e, const char* rank_var, std::vector<int>
 int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool first);
 // After r->done has completed: *ok = false → the recall plan did not hold (call recommend_enqueue(first = false) and wait
 // again).  With *ok = true, r->h_status[kExprFlagAt + q] != 0 marks requests whose RankScore divided by zero.
-int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok);
+// When the pilot threshold was too high for a few requests only, they are re-run here, synchronously and in place
+// (c != NULL: recall and everything behind it; c == NULL: a recall-only job), r->patched is set and *ok = true.
+int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok, const RecommendCall* c = nullptr);
 
 // misc.hip launchers (caller holds ctx->mu)
 int rows_to_local_locked(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t n, uint32_t* d_local,

@@ -1738,6 +1738,7 @@ int recall_job_prepare(RecallJob* j) {
     j->scan_launches = 0;
     j->next_plan = 0;
     j->enqueued_plan = -1;
+    j->failed.clear();
 
     // Policy: finite tables of dim <= 128 use the screened scan (int8 or bf16 filter + exact re-scoring) for every
     // batch size (knobs.screen_min = 0), HBM-bound up to 128 queries per pass; everything else rides the exact
@@ -1771,6 +1772,7 @@ int recall_job_prepare(RecallJob* j) {
     }
     j->plans[j->n_plans++] = kGrow;
     j->plans[j->n_plans++] = kSafe;
+    if (j->skip_pilot && j->plans[0] == kPilot) j->next_plan = 1;
     return PG_OK;
 }
 
@@ -1995,9 +1997,14 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
     j->scan_launches += j->n_ev - 1;
     j->scanned_rows += plan == kPilot ? (uint64_t)j->rows + (uint64_t)j->sample_blocks * kPieceRows : j->rows;
     bool ok = j->h_status[0] == 0;
+    j->failed.clear();
     if (ok && plan == kPilot) {
         const uint32_t want = j->k < j->rows ? j->k : j->rows;
-        for (uint32_t q = 0; q < j->nq; ++q) ok = ok && j->h_status[1 + q] == want;
+        for (uint32_t q = 0; q < j->nq; ++q)
+            if (j->h_status[1 + q] != want) {
+                ok = false;
+                j->failed.push_back(q);
+            }
     }
     if (!ok) ctx->stats.recall_rescans++;
     *ok_out = ok;
@@ -2015,11 +2022,27 @@ void recall_job_finish(RecallJob* j) {
     ctx->last_scan_bytes = j->scanned_rows * (uint64_t)j->t->dim * (j->screen ? (j->t->shadow_is_i8 ? 1 : 2) : 4);
 }
 
+int recall_patch_failed_locked(RecallJob* j, uint32_t* counts) {
+    pg_ctx* ctx = j->ctx;
+    const std::vector<uint32_t> failed = j->failed;
+    for (uint32_t q : failed) {
+        uint32_t cnt = 0;
+        int rc;
+        if ((rc = recall_dev_locked(ctx, j->t, j->d_queries + (size_t)q * j->t->dim, 1, j->k, j->d_out_rows + (size_t)q * j->k,
+                                    j->d_out_scores + (size_t)q * j->k, &cnt, j->d_out_count ? j->d_out_count + q : nullptr, true)))
+            return rc;
+        counts[q] = cnt;
+    }
+    j->failed.clear();
+    return PG_OK;
+}
+
 // the whole recall for one batch of queries, verified before it returns; all pointers are device pointers
 int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq,
                       uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
-                      uint32_t* out_count, uint32_t* d_out_count) {
+                      uint32_t* out_count, uint32_t* d_out_count, bool skip_pilot) {
     RecallJob j;
+    j.skip_pilot = skip_pilot;
     j.ctx = ctx;
     j.t = t;
     j.d_queries = d_queries;
@@ -2032,15 +2055,23 @@ int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, ui
     j.events = &ctx->ev_pool;
     int rc;
     if ((rc = recall_job_prepare(&j))) return rc;
+    uint32_t counts[kMaxQueries];
     for (;;) {
         if ((rc = recall_job_enqueue(&j))) return rc;
         PG_HIP(hipStreamSynchronize(ctx->stream));
         bool ok = false;
         if ((rc = recall_job_check(&j, &ok))) return rc;
+        for (uint32_t q = 0; q < nq; ++q) counts[q] = ctx->h_status[1 + q];
         if (ok) break;
+        if (!j.failed.empty() && j.failed.size() <= kMaxPatchQueries && nq > 1) {
+            // the pilot's threshold was too high for a few queries only: re-run those, not the batch
+            // (the nested calls reuse ctx->h_status: the counts are kept on the stack)
+            if ((rc = recall_patch_failed_locked(&j, counts))) return rc;
+            break;
+        }
     }
     if (out_count)
-        for (uint32_t q = 0; q < nq; ++q) out_count[q] = ctx->h_status[1 + q];
+        for (uint32_t q = 0; q < nq; ++q) out_count[q] = counts[q];
     recall_job_finish(&j);
     return PG_OK;
 }

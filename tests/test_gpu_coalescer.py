@@ -147,6 +147,58 @@ def test_coalescer_survives_a_failed_recall_plan(ctx):
     t.destroy()
 
 
+def test_partial_fallback_reruns_only_the_failed_requests(ctx):
+    """With a deliberately thin pilot margin (pilot_sigmas 0.5 instead of 6) the sampled threshold is too high for a
+    few requests of a batch: their candidate lists come up short, the verification notices, and only those requests
+    are re-run (recall from the growing-chunk plan + rank + fusion + sort) — every answer stays exact, through the
+    batch call, the recall call and the coalescer."""
+    n, d, k, R = 2_300_000, 64, 100, 64
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    w = o.Dnn3Weights(d_user=64, d_item=64, h1=256, h2=128)
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 64))
+    ex = pa.Expr(EXPR)
+    ctx.set_option("pilot_sigmas", 0.5)
+    try:
+        before = ctx.stats().recall_rescans
+        hit = 0
+        for b in range(4):
+            q = o.synth_rows(o.SEED_QUERY, 64 * b, R, d)
+            r0 = ctx.stats().recall_rescans
+            rows, scores, cnt = t.recall_topk(q, k)
+            orow, osc = o.recall_topk(tab, q, k)
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc)) and cnt.tolist() == [k] * R
+            r1 = ctx.stats().recall_rescans
+            rows2, rec2, rnk2, fus2, order2, cnt2 = pa.recommend_dnn3(ctx, t, m, ex, "gpu_dnn", q, k)
+            assert np.array_equal(rows2, orow) and np.array_equal(bits(rec2), bits(osc)) and cnt2.tolist() == [k] * R
+            for r in range(0, R, 9):
+                ref = o.dnn3_forward(w, pa.PREC_F32, q[r], tab[orow[r].astype(np.int64)])
+                assert np.max(np.abs(rnk2[r].astype(np.float64) - ref)) <= 2e-7
+                fused = o.widen_f32(rnk2[r]) * (1 + o.widen_f32(rec2[r])) ** 0.1
+                assert np.max(np.abs(fus2[r] - fused)) <= 1e-12 and np.array_equal(order2[r], o.sort_scores(fus2[r], True))
+            hit += (r1 > r0)
+        assert hit >= 1, "the thin margin never failed: the partial fallback was not exercised"
+        co = pa.Coalescer(ctx, t, k, m, ex, "gpu_dnn", max_top_n=20, max_wait_us=1000)
+        q = o.synth_rows(o.SEED_QUERY, 0, 128, d)
+        got = [None] * 128
+        run_threads(128, lambda i: got.__setitem__(i, co.recommend(q[i], 20)))
+        co.destroy()
+        orow, osc = o.recall_topk(tab, q, k)
+        for i in range(0, 128, 5):
+            ref = o.dnn3_forward(w, pa.PREC_F32, q[i], tab[orow[i].astype(np.int64)])
+            fused = o.widen_f32(ref.astype(np.float32)) * (1 + o.widen_f32(osc[i])) ** 0.1
+            top = orow[i][np.argsort(-fused, kind="stable")[:20]]
+            assert set(got[i][0].tolist()) <= set(orow[i].tolist())
+            if np.all(np.abs(np.diff(np.sort(fused)[::-1][:21])) > 1e-6):
+                assert np.array_equal(got[i][0], top)
+        assert ctx.stats().recall_rescans > before
+    finally:
+        ctx.set_option("pilot_sigmas", 6)
+    m.destroy()
+    t.destroy()
+
+
 def test_recommend_pads_when_table_is_smaller_than_k(ctx):
     """Fewer rows than k: the padding slots (row = UINT64_MAX) must not surface in a page — they carry fused = NaN,
     sort last, and the count says how many entries are items (they used to fuse to +inf and sort first)."""
