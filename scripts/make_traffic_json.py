@@ -36,7 +36,7 @@ def main():
     out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ passes of `python3 bench.py --steps 5 --warmup 2 "
                    "--no-extras --contexts 1 --batch R` (scripts/profile.sh, scripts/make_traffic_json.py); mfma_busy_frac = "
                    "SQ_VALU_MFMA_BUSY_CYCLES of the full-pass screen_kernel launch / (1024 SIMDs x GRBM_GUI_ACTIVE of that "
-                   "launch); FETCH_SIZE is KB and is doubled per "
+                   "launch / 8 XCDs); FETCH_SIZE is KB and is doubled per "
                    "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide 16 B/lane reads); per table pass = sum "
                    "over the pass's scan-stage launches (exact seed of the pilot, screened sample launch, screened "
                    "full pass over the int8 shadow, exact fp32 re-scoring gathers) / 7 passes; algorithmic bytes per "
@@ -55,7 +55,7 @@ def main():
             mf = [float(r_["Counter_Value"]) for r_ in rows if r_["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES"]
             ga = [float(r_["Counter_Value"]) for r_ in rows if r_["Counter_Name"] == "GRBM_GUI_ACTIVE"]
             if mf and ga:
-                busy = max(mf) / (SIMDS * max(ga))
+                busy = max(mf) / (SIMDS * max(ga) / 8.0)      # GRBM_GUI_ACTIVE is summed over the 8 XCDs
         except Exception:
             busy = None
         out[str(R)] = {
