@@ -164,17 +164,34 @@ uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint6
         tid = omp_get_thread_num();
 #endif
         const uint64_t r0 = nrows * (uint64_t)tid / nth, r1 = nrows * (uint64_t)(tid + 1) / nth;
-        float* acc = (float*)malloc(nq * sizeof(float));
+        /* four rows per sweep over the transposed queries (each (row, query) chain is still its own k-ascending
+         * fmaf chain — same bits — but the 4 x nq accumulators stay in L1 and the queries are read once per four rows) */
+        enum { RB = 4 };
+        float* accb = (float*)malloc((size_t)RB * nq * sizeof(float));
         uint64_t* myh = heaps + (size_t)tid * nq * kk;
         uint32_t* myn = hn + (size_t)tid * nq;
-        for (uint64_t r = r0; r < r1; ++r) {
-            const float* x = table + (size_t)r * dim;
-            for (uint32_t q = 0; q < nq; ++q) acc[q] = 0.0f;
+        for (uint64_t rb = r0; rb < r1; rb += RB) {
+            const uint32_t nr = (uint32_t)((r1 - rb) < RB ? (r1 - rb) : RB);
+            const float* x0 = table + (size_t)rb * dim;
+            const float* x1 = table + (size_t)(rb + (nr > 1 ? 1 : 0)) * dim;
+            const float* x2 = table + (size_t)(rb + (nr > 2 ? 2 : 0)) * dim;
+            const float* x3 = table + (size_t)(rb + (nr > 3 ? 3 : 0)) * dim;
+            float* a0 = accb; float* a1 = accb + nq; float* a2 = accb + 2 * (size_t)nq; float* a3 = accb + 3 * (size_t)nq;
+            for (uint32_t q = 0; q < nq; ++q) { a0[q] = 0.0f; a1[q] = 0.0f; a2[q] = 0.0f; a3[q] = 0.0f; }
             for (uint32_t c = 0; c < dim; ++c) {
-                const float xv = x[c];
+                const float v0 = x0[c], v1 = x1[c], v2 = x2[c], v3 = x3[c];
                 const float* qk = qt + (size_t)c * nq;
-                for (uint32_t q = 0; q < nq; ++q) acc[q] = fmaf(xv, qk[q], acc[q]);
+                for (uint32_t q = 0; q < nq; ++q) {
+                    const float qv = qk[q];
+                    a0[q] = fmaf(v0, qv, a0[q]);
+                    a1[q] = fmaf(v1, qv, a1[q]);
+                    a2[q] = fmaf(v2, qv, a2[q]);
+                    a3[q] = fmaf(v3, qv, a3[q]);
+                }
             }
+          for (uint32_t ri = 0; ri < nr; ++ri) {
+            const uint64_t r = rb + ri;
+            const float* acc = accb + (size_t)ri * nq;
             for (uint32_t q = 0; q < nq; ++q) {
                 uint64_t* h = myh + (size_t)q * kk;
                 const uint64_t key = orc_topk_key(acc[q], (uint32_t)r);
@@ -189,8 +206,9 @@ uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint6
                     heap_sift_down(h, kk, 0);
                 }
             }
+          }
         }
-        free(acc);
+        free(accb);
     }
 #pragma omp parallel for schedule(dynamic, 1)
     for (int32_t q = 0; q < (int32_t)nq; ++q) {
