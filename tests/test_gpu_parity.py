@@ -150,6 +150,27 @@ def test_recall_screen_is_exact_on_hostile_data(ctx):
     t.destroy()
 
 
+def test_recall_non_finite_table_with_many_queries(ctx):
+    """A table with non-finite rows cannot be screened; batches beyond 64 queries used to be refused
+    (PG_ERR_UNSUPPORTED) and now ride the exact fp32-MFMA scan in groups of 64 queries per launch —
+    100 and 256 queries, ids / order / score bits against the oracle (NaN scores sort last)."""
+    rng = np.random.default_rng(41)
+    n, d, k = 70_000, 128, 150
+    tab = rng.standard_normal((n, d)).astype(np.float32)
+    tab[17, 3] = np.inf
+    tab[4000, 100] = np.nan
+    tab[69_999, 0] = -np.inf
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    assert t.screen_info()[0] == 0                       # exact scan
+    for nq in (100, 256):
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        rows, scores, cnt = t.recall_topk(q, k)
+        orow, osc = o.recall_topk(tab, q, k)
+        assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc)) and cnt.tolist() == [k] * nq
+    t.destroy()
+
+
 def test_recall_bf16_screen_with_huge_row_norms(ctx):
     """dim 64 is screened in bf16.  Rows and queries of norm ~1e18-1e19 are finite, but their bf16 partial sums can
     reach inf - inf = NaN, which a max chain drops silently: the screen must stand aside for such
