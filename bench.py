@@ -21,8 +21,8 @@ At N = 1 the same JSON line also carries (each a bounded, separately timed leg a
   "concurrent_callers"  the same table / model / k served through the request coalescer to --callers host threads
                         that each issue ONE request at a time (how pairec calls its plug-ins), items/s + p50/p99
   "gaussian_table"      the headline measurement repeated on N(0,1) rows (the int8 screen's less favourable case)
-  "other_configs"       cfg 1 (1M x 64, top-200, ascending ItemScore sort) and cfg 4 (FM + two-tower rank, 1M-row
-                        field tables) with their own rooflines
+  "other_configs"       cfg 1 (1M x 64, top-200, ascending ItemScore sort), cfg 4 (FM + two-tower rank, 1M-row field
+                        tables) with their own rooflines, and one shard of cfg 5 (125M rows, recall + rank + DPP)
   "cpu_baseline"        the oracle (C port of the reference-shaped CPU path) on a bounded sample, all host cores
 
 Prints ONE JSON line on rank 0.
@@ -195,7 +195,7 @@ def cpu_baseline(o, args, R, K):
     t_recall_slice = time.time() - t0
     t_recall = t_recall_slice * (share * ts / slice_rows)
     w = o.Dnn3Weights()
-    n_sample = 20000
+    n_sample = max(20000, min(R * K, cores * 1000))        # enough items per worker that start-up does not dominate
     cand = tab[rows[0][:K].astype(np.int64) % slice_rows]
     items = np.tile(cand, (n_sample // K + 1, 1))[:n_sample]
     t0 = time.time()
@@ -411,6 +411,33 @@ def cfg4_leg(pa, o, ctx, R, K):
     }
 
 
+def cfg5_leg(pa, o, R, K, prec):
+    """BASELINE.json configs[4] as far as one GPU goes: ONE shard of the 8-way 1 B x 128 table (125 M rows: 64 GB of fp32
+    rows + 16 GB int8 shadow) through the shard-group API (pg_group_recommend) — recall, merge, owner-computes rank,
+    fusion, sort, DPPSort on the first 500 of every sorted list (alpha 1, window 10), page of 100.  The per-GPU work of the
+    8-GPU configuration; the exchanges between shards are not in it (one GPU per box on this pool)."""
+    rows = 125_000_000
+    g = pa.ShardGroup([0])
+    g.table_create(rows, 128)
+    g.table_fill_synthetic(o.SEED_TABLE)
+    w = o.Dnn3Weights()
+    g.model_load(pa.MODEL_DNN3, prec, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    ex = pa.Expr(RANK_EXPR)
+    out = {}
+    for dpp in (500, 0):
+        q = make_queries(o, 0, R, 128)
+        g.recommend(ex, "gpu_dnn", q, K, 100, dpp_candidates=dpp)            # warm-up: shadow, buffers
+        steps, t0 = 5, time.perf_counter()
+        for s_ in range(steps):
+            g.recommend(ex, "gpu_dnn", make_queries(o, s_ + 1, R, 128), K, 100, dpp_candidates=dpp)
+        dt = (time.perf_counter() - t0) / steps
+        out["with_dpp" if dpp else "without_dpp"] = {"ms_per_step": dt * 1e3, "value": R * K / dt, "unit": "ranked items/s"}
+    g.destroy()
+    out["workload"] = ("configs[4], one of 8 shards: 125M x 128 rows, %d requests x top-%d -> DNN3 rank -> fuse -> sort -> "
+                       "DPPSort(500 candidates, page 100, window 10); host buffers in and out, one batch at a time" % (R, K))
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -581,7 +608,8 @@ def main():
                                                                       "frac_survey_8d", "ms_per_pass", "shadow_elem_bytes",
                                                                       "mfma_frac")}}
         table.destroy()
-        out["other_configs"] = {"cfg1": cfg1_leg(pa, o, ctx), "cfg4": cfg4_leg(pa, o, ctx, R, K)}
+        out["other_configs"] = {"cfg1": cfg1_leg(pa, o, ctx), "cfg4": cfg4_leg(pa, o, ctx, R, K),
+                                "cfg5_one_shard": cfg5_leg(pa, o, R, K, prec)}
 
     if rank == 0:
         out["device"] = device_info()
