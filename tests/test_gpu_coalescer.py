@@ -147,6 +147,74 @@ def test_coalescer_survives_a_failed_recall_plan(ctx):
     t.destroy()
 
 
+def test_coalescer_mixed_flavours_errors_and_shutdown(ctx, world):
+    """All three flavours in flight at once from different threads; a RankScore that divides by zero fails only the
+    requests it concerns (the reference panics in ExprASTResult; here PG_ERR_ARITH for that caller); destroying the
+    coalescer while callers are queued fails them cleanly instead of hanging."""
+    t, m, ex = world
+    k = 200
+    q = o.synth_rows(o.SEED_QUERY, 900, 96, 128)
+    rows_ref, sc_ref, _ = t.recall_topk(q, k)
+    co = pa.Coalescer(ctx, t, k, m, ex, "gpu_dnn", max_top_n=50, max_rank_items=100, max_wait_us=500)
+    out = [None] * 96
+
+    def work(i):
+        if i % 3 == 0:
+            out[i] = ("recall", co.recall(q[i]))
+        elif i % 3 == 1:
+            out[i] = ("rank", co.rank_dnn3(q[i], rows_ref[i][:100].astype(np.uint32)))
+        else:
+            out[i] = ("recommend", co.recommend(q[i], 50))
+    run_threads(96, work)
+    off = np.array([0, 100], dtype=np.uint32)
+    for i in range(96):
+        kind, r = out[i]
+        if kind == "recall":
+            assert np.array_equal(r[0], rows_ref[i]) and np.array_equal(bits(r[1]), bits(sc_ref[i]))
+        elif kind == "rank":
+            assert np.array_equal(bits(r), bits(m.rank_dnn3(t, q[i:i + 1], rows_ref[i][:100].astype(np.uint32), off)))
+        else:
+            assert r[4] == 50 and set(r[0].tolist()) <= set(rows_ref[i].tolist()) and np.all(np.diff(r[3]) <= 0)
+    st = co.stats()
+    assert st.requests[0] == 32 and st.requests[1] == 32 and st.requests[2] == 32
+    co.destroy()
+    # division by zero: 1 / (current_score - s) is undefined for the candidate whose recall score equals s exactly
+    s_hit = float(sc_ref[5][3])
+    bad = pa.Expr("${gpu_dnn}/(${current_score}-%r)" % s_hit)
+    co = pa.Coalescer(ctx, t, k, m, bad, "gpu_dnn", max_top_n=10, max_wait_us=2000)
+    res = [None] * 8
+
+    def call(i):
+        try:
+            res[i] = co.recommend(q[i], 10)
+        except pa._lib.PgError as e_:
+            res[i] = e_
+    run_threads(8, call)
+    assert isinstance(res[5], pa._lib.PgError) and res[5].code == -5 and "division by zero" in str(res[5])
+    assert all(not isinstance(res[i], Exception) for i in range(8) if i != 5), "one request's arithmetic error leaked into the batch"
+    co.destroy()
+    bad.free()
+    # shutdown with callers queued: a long wait and one slot keep requests in the queue while destroy runs
+    co = pa.Coalescer(ctx, t, k, max_wait_us=200_000, depth=1)
+    got = []
+
+    def late(i):
+        try:
+            got.append(co.recall(q[i])[2])
+        except pa._lib.PgError as e_:
+            got.append(e_)
+    th = [threading.Thread(target=late, args=(i,)) for i in range(6)]
+    for x in th:
+        x.start()
+    import time
+    time.sleep(0.05)
+    co.destroy()
+    for x in th:
+        x.join(30)
+        assert not x.is_alive(), "a caller is still blocked after pg_coalescer_destroy"
+    assert len(got) == 6 and all(g == k or isinstance(g, pa._lib.PgError) for g in got)
+
+
 def test_partial_fallback_reruns_only_the_failed_requests(ctx):
     """With a deliberately thin pilot margin (pilot_sigmas 0.5 instead of 6) the sampled threshold is too high for a
     few requests of a batch: their candidate lists come up short, the verification notices, and only those requests
