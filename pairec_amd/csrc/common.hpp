@@ -63,6 +63,9 @@ struct Knobs {
     bool debug_scan = false;       // PG_DEBUG_SCAN: print per-launch times and suspect counts
     bool screen_bf16 = false;      // PG_SCREEN_BF16: bf16 shadow for dim-128 tables too
     bool screen_i8 = false;        // PG_SCREEN_I8: int8 shadow even for heavy-tailed tables
+    bool no_screen_i4 = false;     // PG_NO_SCREEN_I4: small batches stay on the int8 screen
+    uint32_t i4_min_rows = 1u << 22; // PG_I4_MIN_ROWS: smallest table the 4-bit screen is built for
+    double i4_max_lambda = 1.7;    // PG_I4_MAX_LAMBDA: largest pg_table::lam4 the 4-bit screen is used for
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
     bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
 };
@@ -90,6 +93,14 @@ struct pg_table {
     float s8 = 0.0f;             // int8 scale
     float resid8 = 0.0f;         // upper bound of the rows' quantisation residual (L2)
     bool shadow_failed = false;  // allocation failed once: stay on the exact scan
+    // recall_i4.hip: the 4-bit shadow that the full pass of a small batch streams (dim 128, built on the first such
+    // recall, 72 B per row): nibbles [rows + 64][64 B], one fp32 scale per row, and the bound's measured constants
+    uint8_t* d4 = nullptr;
+    float2* d4s = nullptr;       // {row scale, row residual (upper bound)}
+    bool i4_ok = false, i4_failed = false;
+    float rho4 = 0.0f;           // max over rows of ||x - x^|| / (s_row sqrt(dim)) (diagnostic)
+    float rmax4 = 0.0f;          // max over rows of ||x - x^|| (upper bound)
+    float lam4 = 0.0f;           // mean residual term in units of the score spread (decides whether the shadow pays)
 };
 
 // rank model weights resident in HBM (rank_mlp.hip loads them)
@@ -154,6 +165,7 @@ struct RecallScratch {
     uint32_t* susp_cnt;      // [kMaxQueries]
     uint32_t* susp;          // [kMaxQueries][cap] suspect rows of the current launch
     float* qscale;           // [kMaxQueries] int8 screen: the queries' scales
+    uint32_t* q4;            // 4-bit screen: [4][32] int8 queries + [4][4] constants (recall_i4.hip)
 };
 struct RecallJob {
     // set by the caller
@@ -172,6 +184,7 @@ struct RecallJob {
     uint32_t* d_count = nullptr;
     uint32_t rows = 0, nblocks = 0;
     bool screen = false;
+    bool screen4 = false;                   // the pilot plan's full pass streams the 4-bit shadow (nq <= kI4MaxQueries)
     int plans[3] = {0, 0, 0};
     int n_plans = 0, next_plan = 0, enqueued_plan = -1;
     uint32_t stride = 1, sample_blocks = 0, k_pilot = 0, perm_mul = 1;
@@ -201,6 +214,12 @@ int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, u
 int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap, uint32_t nq, uint32_t k,
                  uint64_t row_offset, uint64_t* d_out_rows, float* d_out_scores, uint32_t* d_out_count);
 int ensure_table_stats(pg_ctx* ctx, const pg_table* tc);
+// recall_i4.hip (caller holds ctx->mu)
+constexpr uint32_t kI4MaxQueries = 4;
+int ensure_table_i4(pg_ctx* ctx, const pg_table* tc);
+int screen4_prep_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs);
+int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t rows, uint32_t cap4);
+uint32_t screen4_rescore_blocks();
 int topk_merge_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
                       uint32_t per_list, int list_major, uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
                       uint32_t* d_out_count);

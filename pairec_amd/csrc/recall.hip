@@ -872,7 +872,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
                                                       const uint32_t* __restrict__ susp,
                                                       const uint32_t* __restrict__ susp_cnt, uint32_t cap,
                                                       uint32_t* __restrict__ cnt, uint64_t* __restrict__ cand,
-                                                      uint32_t* __restrict__ overflow) {
+                                                      uint32_t* __restrict__ overflow, uint32_t scap) {
+    // (scap: capacity and stride of the suspect lists; cap: of the candidate lists)
     constexpr int kRowB = 64 * 4 + 16;                 // 64 columns per phase, padded: conflict-free b128 column walks
     __shared__ __attribute__((aligned(16))) char tile[4][64 * kRowB];
     __shared__ __attribute__((aligned(16))) float qs[DIM];
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     __shared__ uint32_t base_s;
     const uint32_t q = blockIdx.y;
     const uint32_t n_raw = susp_cnt[q];
-    const uint32_t n = n_raw < cap ? n_raw : cap;
+    const uint32_t n = n_raw < scap ? n_raw : scap;
     if (blockIdx.x * 256u >= n) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x < DIM) qs[threadIdx.x] = qpad[(size_t)q * DIM + threadIdx.x];
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     // trip per chunk and phase before).
     auto row_of = [&](uint32_t t0) -> uint32_t {
         const uint32_t e = t0 + threadIdx.x;
-        return e < n ? susp[(uint64_t)q * cap + e] : 0u;
+        return e < n ? susp[(uint64_t)q * scap + e] : 0u;
     };
     constexpr int NPH = DIM / 64;
     const uint32_t step = gridDim.x * 256u;
@@ -938,7 +939,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
         __syncthreads();
         row = row_next;
     }
-    if (n_raw > cap && threadIdx.x == 0) *overflow = 1u;
+    if (n_raw > scap && threadIdx.x == 0) *overflow = 1u;
 }
 
 // per call: bf16 B fragments of the (zero-padded) queries and eps_unit_q = kScreenEps * ||q|| (the screen multiplies it
@@ -1512,7 +1513,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     void* small;
     int rc;
     const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
-    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 24 + 1024;
+    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 28 + 2048;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
     rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
@@ -1523,6 +1524,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     rs->susp_cnt = rs->cnt + kMaxQueries;
     rs->overflow = rs->susp_cnt + kMaxQueries;
     rs->qscale = (float*)(rs->overflow + 64);
+    rs->q4 = (uint32_t*)(rs->qscale + kMaxQueries);      // 4 x 128 B + 4 x 16 B
     void* c;
     if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4), &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
@@ -1557,6 +1559,7 @@ int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_
 int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     pg_table* t = const_cast<pg_table*>(tc);          // lazily computed cache
     if (t->stats_valid || t->shadow_failed) return PG_OK;
+    t->i4_ok = t->i4_failed = false;                  // the 4-bit shadow (recall_i4.hip) follows the rows too
     if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
     const bool force_bf16 = ctx->knobs.screen_bf16;
     bool i8 = t->dim == 128 && !force_bf16;
@@ -1722,6 +1725,8 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
 // ---------------------------------------------------------------------------------------------
 enum RecallPlan { kPilot = 0, kGrow = 1, kSafe = 2 };
 
+static inline uint64_t rs_cap_bound(uint32_t k) { return (uint64_t)k + kCandSlack; }
+
 int recall_job_prepare(RecallJob* j) {
     pg_ctx* ctx = j->ctx;
     const pg_table* t = j->t;
@@ -1749,6 +1754,7 @@ int recall_job_prepare(RecallJob* j) {
         if (!t->stats_valid || !t->all_finite) screen = false;      // no shadow (dim, memory) or non-finite rows
     }
     j->screen = screen;
+    j->screen4 = false;
     j->n_plans = 0;
     j->stride = 1;
     j->sample_blocks = 0;
@@ -1773,6 +1779,15 @@ int recall_job_prepare(RecallJob* j) {
     j->plans[j->n_plans++] = kGrow;
     j->plans[j->n_plans++] = kSafe;
     if (j->skip_pilot && j->plans[0] == kPilot) j->next_plan = 1;
+    // small batches: the pilot plan's full pass is HBM-bound on the shadow it streams — use the 4-bit one (recall_i4.hip)
+    if (screen && t->shadow_is_i8 && j->nq <= kI4MaxQueries && j->plans[0] == kPilot && !kn.no_screen_i4 &&
+        rows >= kn.i4_min_rows && (uint64_t)kMaxQueries * rs_cap_bound(j->k) / kI4MaxQueries < 0xFFFFFFFFull) {
+        if ((rc = ensure_table_i4(ctx, t))) return rc;
+        // (measured at 100M x 128, int8 pass 2.1 ms: uniform rows, lambda 0.8: 1.37 / 1.38 / 1.59 / 1.66 ms at 1..4
+        // queries; Gaussian rows, lambda 1.3: 1.46 / 1.59 / 1.78 / 2.02 — every query re-scores its own suspects)
+        static const double kLamScale[kI4MaxQueries] = {1.0, 1.0, 0.88, 0.7};
+        j->screen4 = t->i4_ok && (double)t->lam4 <= kn.i4_max_lambda * kLamScale[j->nq - 1];
+    }
     return PG_OK;
 }
 
@@ -1818,15 +1833,22 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             sa.perm_mod = j->sample_blocks;
             int rc2;
             PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
-            if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) return rc2;
+            // the full pass of a small batch streams the 4-bit shadow; its few suspect lists share the whole buffer
+            const bool i4 = j->screen4 && st == 1 && rb == 0 && cb == j->nblocks;
+            const uint32_t scap = i4 ? rs.cap * (uint32_t)(kMaxQueries / kI4MaxQueries) : rs.cap;
+            if (i4) {
+                if ((rc2 = screen4_launch(ctx, t, rs, nq, j->rows, scap))) return rc2;
+            } else if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) {
+                return rc2;
+            }
             // exact re-scoring of the launch's suspects → candidate keys (grid.x strides over each list)
-            const dim3 rg(kRescoreBlocksPerQuery, nq);
+            const dim3 rg(i4 ? screen4_rescore_blocks() : kRescoreBlocksPerQuery, nq);
             if (t->dim == 64)
                 rescore_kernel<64><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap,
-                                                                rs.cnt, rs.cand[cur], rs.overflow);
+                                                                rs.cnt, rs.cand[cur], rs.overflow, scap);
             else
                 rescore_kernel<128><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap,
-                                                                 rs.cnt, rs.cand[cur], rs.overflow);
+                                                                 rs.cnt, rs.cand[cur], rs.overflow, scap);
             PG_HIP(hipGetLastError());
         } else {
             // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
@@ -1920,6 +1942,7 @@ int recall_job_enqueue(RecallJob* j) {
             screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
                 rs.qpad, t->dim, rs.qb16, rs.eps);
         PG_HIP(hipGetLastError());
+        if (j->screen4 && (rc = screen4_prep_launch(ctx, t, rs))) return rc;
     }
     while (j->events->size() < 2) {
         hipEvent_t e;
@@ -2020,6 +2043,8 @@ void recall_job_finish(RecallJob* j) {
     ctx->last_scan_launches = j->scan_launches;
     // bytes the scan launches streamed: the shadow's element size when the pass was screened
     ctx->last_scan_bytes = j->scanned_rows * (uint64_t)j->t->dim * (j->screen ? (j->t->shadow_is_i8 ? 1 : 2) : 4);
+    if (j->screen4 && j->enqueued_plan == kPilot)      // the full pass read 64 + 8 B per row instead of 128
+        ctx->last_scan_bytes -= (uint64_t)j->rows * (128 - 72);
 }
 
 int recall_patch_failed_locked(RecallJob* j, uint32_t* counts) {

@@ -122,6 +122,8 @@ int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
     if (t->d) PG_HIP(hipFree(t->d));
     if (t->d16) PG_HIP(hipFree(t->d16));
     if (t->d8) PG_HIP(hipFree(t->d8));
+    if (t->d4) PG_HIP(hipFree(t->d4));
+    if (t->d4s) PG_HIP(hipFree(t->d4s));
     if (t->dnorm2) PG_HIP(hipFree(t->dnorm2));
     delete t;
     return PG_OK;
@@ -208,6 +210,13 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->s8, b->s8);
     std::swap(a->resid8, b->resid8);
     std::swap(a->shadow_failed, b->shadow_failed);
+    std::swap(a->d4, b->d4);
+    std::swap(a->d4s, b->d4s);
+    std::swap(a->i4_ok, b->i4_ok);
+    std::swap(a->i4_failed, b->i4_failed);
+    std::swap(a->rho4, b->rho4);
+    std::swap(a->rmax4, b->rmax4);
+    std::swap(a->lam4, b->lam4);
     return PG_OK;
 }
 

@@ -227,6 +227,79 @@ def test_recall_int8_screen_is_exact_on_hostile_data(ctx):
     t.destroy()
 
 
+def test_recall_small_batch_4bit_screen_is_exact(ctx):
+    """Batches of <= 4 queries stream a 4-bit shadow (one scale and one measured residual per row, csrc/recall_i4.hip)
+    in the pilot plan's full pass.  Forced on for a small table (i4_min_rows 0, a quarter of the rows as the sample),
+    with data built against it — an outlier inside a row (coarsens that row's scale), tiny rows, zero rows, winners
+    that differ by far less than a 4-bit step, a zero query, one-hot and non-finite queries: ids, order and score bits
+    must match the oracle, the pass must really have read the narrow shadow, and the shadow must follow uploads and
+    swaps.  A heavy-tailed table (lambda above the limit) stays on the wider shadow."""
+    rng = np.random.default_rng(29)
+    n, d, k = 400_000, 128, 200
+    tab = rng.standard_normal((n, d)).astype(np.float32) * 0.05
+    tab[1234, 17] = 0.5
+    tab[2000:2600] *= 1e-6
+    tab[3000:3100] = 0.0
+    near = (rng.standard_normal(d) * 0.05).astype(np.float32)
+    tab[5000:5400] = near * (1.0 + 1e-6 * np.arange(400, dtype=np.float32)[:, None])
+    qs = rng.standard_normal((12, d)).astype(np.float32)
+    qs[0] = 0.0
+    qs[1] = 0.0
+    qs[1, 17] = 1.0
+    qs[2] = near
+    qs[3] = -near
+    qs[4, 5] = np.inf
+    qs[5, 9] = np.nan
+    qs[6] *= np.float32(1e-20)
+    qs[7] *= np.float32(1e15)
+    # (i4_max_lambda: Gaussian rows sit at lambda 1.3, above the default limit for 4 queries — lifted here so that
+    # every batch size exercises the narrow shadow)
+    for name, v in (("i4_min_rows", "0"), ("pilot_fraction", "0.25"), ("i4_max_lambda", "3")):
+        ctx.set_option(name, v)
+    try:
+        t = pa.Table(ctx, n, d)
+        t.upload(tab)
+
+        def check(t_, tab_, q, expect_i4=True):
+            rows, scores, _ = t_.recall_topk(q, k)
+            _, nbytes = ctx.last_scan_kernel()
+            orow, osc = o.recall_topk(tab_, q, k)
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+            finite = bool(np.all(np.isfinite(q)))
+            if finite:          # (a non-finite query overflows the pilot plan by design: the next plan answers)
+                assert (nbytes < n * 128) == expect_i4, (nbytes, expect_i4)
+
+        for lo, hi in ((0, 1), (1, 2), (2, 4), (4, 5), (5, 6), (6, 8), (8, 11), (8, 12), (0, 4)):
+            check(t, tab, qs[lo:hi])
+        tab2 = tab.copy()
+        tab2[100_000:160_000] = rng.standard_normal((60_000, d)).astype(np.float32) * 0.2
+        t.upload(tab2[100_000:160_000], row0=100_000)
+        check(t, tab2, qs[8:10])
+        other = pa.Table(ctx, n, d)
+        tab3 = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+        other.upload(tab3)
+        check(other, tab3, qs[8:11])
+        t.swap(other)
+        check(t, tab3, qs[9:10])
+        check(other, tab2, qs[10:12])
+        ctx.set_option("no_screen_i4", "1")
+        check(t, tab3, qs[8:9], expect_i4=False)
+        ctx.set_option("no_screen_i4", "0")
+        ctx.set_option("i4_max_lambda", "1.7")
+        # Student-t(2.2) columns scaled into the int8 shadow's range: rows whose largest element is far above the rest
+        heavy = (rng.standard_t(2.2, (n, d)) * 0.01).astype(np.float32)
+        np.clip(heavy, -0.4, 0.4, out=heavy)
+        other.upload(heavy)
+        if other.screen_info()[0] == 1:
+            check(other, heavy, qs[8:9], expect_i4=False)
+        t.destroy()
+        other.destroy()
+    finally:
+        ctx.set_option("i4_min_rows", str(1 << 22))
+        ctx.set_option("pilot_fraction", "0")
+        ctx.set_option("i4_max_lambda", "1.7")
+
+
 def test_recall_heavy_tailed_table_stays_fast(ctx):
     """Student-t(3) rows: the largest element is ~100 x a typical row's, one int8 scale would make every row a
     suspect (every plan overflows down to the bounded-chunk one: 560 ms per recall instead of 2.4).  The table
