@@ -14,6 +14,7 @@ namespace pg {
 
 constexpr int kBitonicE = 8;
 constexpr uint32_t kBitonicMax = 8192;
+constexpr uint32_t kRankSortMaxSegments = 8;    // up to this many lists per call: ranks by counting, spread over the chip (final_rank_kernel, sort_rank_kernel)
 
 // value of lane (l ^ M) — M a compile-time power of two below 64
 template <int M>

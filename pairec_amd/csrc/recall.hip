@@ -999,10 +999,13 @@ __global__ void screen_thr_kernel(const float* __restrict__ thr, const float* __
 // per call: int8 B fragments of the (zero-padded) queries, eps_q and the per-query scale s_q = max|q| / 127
 __global__ __launch_bounds__(1024) void screen_prep8_kernel(const float* __restrict__ qpad, uint32_t dim,
                                                              float max_norm, float resid, uint4* __restrict__ qb8,
-                                                             float* __restrict__ eps, float* __restrict__ qscale) {
+                                                             float* __restrict__ eps, float* __restrict__ qscale,
+                                                             uint32_t nqb) {
+    // nqb: query blocks of 32 in use — the rest of the 256 slots is neither read by the scan nor prepared here
+    // (a single request spent 36 us preparing 255 zero queries)
     __shared__ float sq[kMaxQueries];
     const uint32_t tid = threadIdx.x;
-    {
+    if ((tid >> 2) < nqb * 32) {
         // four threads per query, a quarter of the columns each (the serial version took 40 us of every recall)
         static_assert(kMaxQueries * 4 == 1024, "screen_prep8_kernel: 1024 threads = 256 queries x 4");
         const uint32_t qi = tid >> 2, part = tid & 3, per = dim / 4;
@@ -1044,7 +1047,7 @@ __global__ __launch_bounds__(1024) void screen_prep8_kernel(const float* __restr
     }
     __syncthreads();
     const uint32_t KS = dim / 32;
-    for (uint32_t i = tid; i < (uint32_t)kScreenMaxNQB * KS * 64; i += blockDim.x) {
+    for (uint32_t i = tid; i < nqb * KS * 64; i += blockDim.x) {
         const uint32_t lane = i & 63, ks = (i >> 6) % KS, c = (i >> 6) / KS;
         const uint32_t qi = c * 32 + (lane & 31);
         const float* q = qpad + (size_t)qi * dim + ks * 32 + 16 * (lane >> 5);
@@ -1419,6 +1422,70 @@ __global__ __launch_bounds__(1024) void final_kernel_reg(const uint64_t* __restr
     if (t == 0 && out_count) out_count[q] = n;
 }
 
+// final for a handful of queries (K <= 8192): counting ranks instead of a sorting network.  One workgroup sorts a
+// query's 8192-slot network on ONE CU in 48 us whatever the chip is doing; with only a few queries in the call the
+// other 250 CUs are idle, so every 64 candidates get a workgroup of their own: it stages the query's n keys in LDS
+// (broadcast reads), wave p counts the keys above each of its 64 within the p-th quarter, the four counts add up
+// to the candidate's rank — its output position, the keys being distinct.  n^2 / 4 compares per wave: ~6 us at 5 000.
+// EPB candidates per workgroup, 256 / EPB threads each: 16 for one or two queries, 64 beyond.
+template <int EPB>
+__global__ __launch_bounds__(256) void final_rank_kernel(const uint64_t* __restrict__ cand, const uint32_t* __restrict__ cnt,
+                                                         uint32_t cap, uint32_t K, uint64_t row_offset,
+                                                         uint64_t* __restrict__ out_rows, float* __restrict__ out_scores,
+                                                         uint32_t* __restrict__ out_count) {
+    constexpr uint32_t PARTS = 256 / EPB;
+    extern __shared__ __attribute__((aligned(16))) uint64_t rk_keys[];       // [n rounded up to 32]
+    __shared__ uint32_t part[PARTS][EPB];
+    const uint32_t q = blockIdx.y, tid = threadIdx.x;
+    uint32_t n = cnt[q];
+    if (n > K) n = K;
+    // positions past the candidates (fewer than K rows in the table)
+    for (uint32_t i = n + blockIdx.x * 256u + tid; i < K; i += gridDim.x * 256u) {
+        out_rows[(uint64_t)q * K + i] = ~0ull;
+        out_scores[(uint64_t)q * K + i] = -__builtin_inff();
+    }
+    if (blockIdx.x == 0 && tid == 0 && out_count) out_count[q] = n;
+    if (blockIdx.x * (uint32_t)EPB >= n) return;
+    const uint64_t* in = cand + (uint64_t)q * cap;
+    const uint32_t n8 = (n + 31u) & ~31u;
+    for (uint32_t i0 = tid; i0 < n8; i0 += 8u * 256u) {                     // eight independent loads per thread in flight
+        uint64_t kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * 256u;
+            kv[u] = in[i < n ? i : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * 256u;
+            if (i < n8) rk_keys[i] = i < n ? kv[u] : 0ull;                  // padding: below every real key
+        }
+    }
+    __syncthreads();
+    const uint32_t el = tid % (uint32_t)EPB, p = tid / (uint32_t)EPB;
+    const uint32_t e = blockIdx.x * (uint32_t)EPB + el;
+    const uint64_t mine = e < n ? rk_keys[e] : ~0ull;
+    const uint32_t chunk = n8 / PARTS;                                     // n8 % 32 == 0: even chunks
+    const uint32_t j0 = p * chunk, j1 = j0 + chunk;
+    uint32_t above = 0;
+    // (unrolled: one wave per SIMD here, so a broadcast read's LDS latency is hidden only by the reads behind it)
+#pragma unroll 4
+    for (uint32_t j = j0; j < j1; j += 2) {
+        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&rk_keys[j]);
+        above += (kk.x > mine) ? 1u : 0u;
+        above += (kk.y > mine) ? 1u : 0u;
+    }
+    part[p][el] = above;
+    __syncthreads();
+    if (p == 0 && e < n) {
+        uint32_t r = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < PARTS; ++i) r += part[i][el];
+        out_rows[(uint64_t)q * K + r] = row_offset + key_row(mine);
+        out_scores[(uint64_t)q * K + r] = key_score(mine);
+    }
+}
+
 __global__ void recall_init_kernel(const float* __restrict__ queries, uint32_t nq, uint32_t dim,
                                    float* __restrict__ qpad, float* __restrict__ thr,
                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow) {
@@ -1537,6 +1604,21 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
 int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap,
                         uint32_t nq, uint32_t k, uint64_t row_offset, uint64_t* d_out_rows,
                         float* d_out_scores, uint32_t* d_out_count) {
+    if (k <= kBitonicMax && nq <= kRankSortMaxSegments && !ctx->knobs.sort_lds) {
+        const size_t lds = (size_t)((k + 31u) & ~31u) * 8;
+        int rc_attr;
+        if (nq <= 2) {
+            if ((rc_attr = ensure_dyn_lds(ctx, (const void*)final_rank_kernel<16>, lds))) return rc_attr;
+            final_rank_kernel<16><<<dim3((k + 15) / 16, nq), 256, lds, ctx->stream>>>(cand, cnt, cap, k, row_offset, d_out_rows,
+                                                                                      d_out_scores, d_out_count);
+        } else {
+            if ((rc_attr = ensure_dyn_lds(ctx, (const void*)final_rank_kernel<64>, lds))) return rc_attr;
+            final_rank_kernel<64><<<dim3((k + 63) / 64, nq), 256, lds, ctx->stream>>>(cand, cnt, cap, k, row_offset, d_out_rows,
+                                                                                      d_out_scores, d_out_count);
+        }
+        PG_HIP(hipGetLastError());
+        return PG_OK;
+    }
     if (k <= kBitonicMax) {
         final_kernel_reg<<<nq, 1024, 0, ctx->stream>>>(cand, cnt, cap, k, row_offset, d_out_rows, d_out_scores,
                                                        d_out_count);
@@ -1763,7 +1845,10 @@ int recall_job_prepare(RecallJob* j) {
     const uint32_t rows = j->rows;
     const uint32_t full_blocks = rows / kPieceRows;           // the sample only uses whole blocks
     uint32_t want = full_blocks / 64;                        // (1/64 measured best with the int8 screen: 5.39 vs 5.51 ms per 256-request pass at 1/32, 5.46 at 1/96)
-    if (want < 32768) want = 32768;                          // >= 1M sample rows
+    // >= 1M sample rows, but never more than an eighth of the table: small tables are launch-bound, and the pilot's
+    // three scan launches beat the growing-chunk plan's nine (1M x 64, K = 200: 0.31 -> 0.13 ms per recall)
+    const uint32_t floor_blocks = full_blocks / 8 < 32768 ? full_blocks / 8 : 32768;
+    if (want < floor_blocks) want = floor_blocks;
     if (kn.pilot_fraction > 0.0) want = (uint32_t)(full_blocks * kn.pilot_fraction);
     j->stride = want ? full_blocks / want : 1;
     if (j->stride >= 2 && !kn.no_pilot) {
@@ -1937,7 +2022,7 @@ int recall_job_enqueue(RecallJob* j) {
     if (j->screen) {
         if (t->shadow_is_i8)
             screen_prep8_kernel<<<1, 1024, 0, ctx->stream>>>(rs.qpad, t->dim, t->max_norm, t->resid8, rs.qb16, rs.eps,
-                                                             rs.qscale);
+                                                             rs.qscale, j->nq <= 32 ? 1u : (j->nq <= 64 ? 2u : (j->nq <= 128 ? 4u : 8u)));   // = the scan's NQB x QH
         else
             screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
                 rs.qpad, t->dim, rs.qb16, rs.eps);

@@ -118,6 +118,67 @@ __global__ __launch_bounds__(1024) void sort_kernel_reg(const double* __restrict
     }
 }
 
+// A handful of segments of up to 8192 items: ranks by counting, 64 items per workgroup (see final_rank_kernel in
+// recall.hip — the network above keeps one CU busy for 66 us per segment while the rest of the chip idles).
+// item i's position = #{j : key_j < key_i} + #{j < i : key_j = key_i}: the same order as the network (ties by index).
+// EPB items per workgroup, 256 / EPB threads per item (each counts within its share of the keys): 16 for one or two
+// segments (a 5 000-item segment then spreads over 313 workgroups), 64 beyond.
+template <int EPB>
+__global__ __launch_bounds__(256) void sort_rank_kernel(const double* __restrict__ scores, const uint32_t* __restrict__ seg_offsets,
+                                                        int desc, uint32_t* __restrict__ out_order) {
+    constexpr uint32_t PARTS = 256 / EPB;
+    extern __shared__ __attribute__((aligned(16))) uint64_t rk_keys[];       // [n rounded up to 32]
+    __shared__ uint32_t part[PARTS][EPB];
+    const uint32_t seg = blockIdx.y, tid = threadIdx.x;
+    const uint32_t b = seg_offsets[seg], n = seg_offsets[seg + 1] - b;
+    if (blockIdx.x * (uint32_t)EPB >= n) return;
+    const uint32_t n8 = (n + 31u) & ~31u;
+    // (eight independent loads per thread in flight: written as a plain strided loop this staging was 20 dependent
+    // L2 round trips — most of the kernel)
+    for (uint32_t i0 = tid; i0 < n8; i0 += 8u * 256u) {
+        double sc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * 256u;
+            sc[u] = scores[b + (i < n ? i : 0u)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * 256u;
+            if (i >= n8) break;
+            uint64_t k = ~0ull;                                              // padding sorts last
+            if (i < n) {
+                const uint64_t key = (sc[u] != sc[u]) ? (desc ? 0ull : ~0ull) : f64_ordered_bits(sc[u]);   // NaN sorts last
+                k = desc ? ~key : key;
+            }
+            rk_keys[i] = k;
+        }
+    }
+    __syncthreads();
+    const uint32_t el = tid % (uint32_t)EPB, p = tid / (uint32_t)EPB;
+    const uint32_t e = blockIdx.x * (uint32_t)EPB + el;
+    const uint64_t mine = e < n ? rk_keys[e] : 0ull;
+    const uint32_t chunk = n8 / PARTS;                                     // n8 % 32 == 0: even chunks
+    uint32_t j0 = p * chunk, j1 = j0 + chunk;
+    // (the padding keys ~0 are never counted: nothing is above them, and an equal key — a NaN item — has j >= n > e.
+    // Unrolled: one wave per SIMD here, so the LDS latency of a broadcast read is hidden only by the reads behind it)
+    uint32_t below = 0;
+#pragma unroll 4
+    for (uint32_t j = j0; j < j1; j += 2) {
+        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&rk_keys[j]);
+        below += ((kk.x < mine) | ((kk.x == mine) & (j < e))) ? 1u : 0u;
+        below += ((kk.y < mine) | ((kk.y == mine) & (j + 1 < e))) ? 1u : 0u;
+    }
+    part[p][el] = below;
+    __syncthreads();
+    if (p == 0 && e < n) {
+        uint32_t r = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < PARTS; ++i) r += part[i][el];
+        out_order[b + r] = e;
+    }
+}
+
 int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg,
                            uint32_t n_items, uint32_t max_seg, int desc, uint32_t* d_out) {
     if (n_seg == 0 || n_items == 0) return PG_OK;
@@ -136,7 +197,16 @@ int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, 
         g_keys = (uint64_t*)p;
         g_idx = (uint32_t*)(g_keys + (size_t)n_seg * stride);
     }
-    if (max_seg <= kSortLdsMax && !ctx->knobs.sort_lds)
+    if (max_seg <= kSortLdsMax && n_seg <= kRankSortMaxSegments && !ctx->knobs.sort_lds) {
+        const size_t rl = (size_t)((max_seg + 31u) & ~31u) * 8;
+        if (n_seg <= 2) {
+            if ((rc_attr = ensure_dyn_lds(ctx, (const void*)sort_rank_kernel<16>, rl))) return rc_attr;
+            sort_rank_kernel<16><<<dim3((max_seg + 15) / 16, n_seg), 256, rl, ctx->stream>>>(d_scores, d_seg, desc, d_out);
+        } else {
+            if ((rc_attr = ensure_dyn_lds(ctx, (const void*)sort_rank_kernel<64>, rl))) return rc_attr;
+            sort_rank_kernel<64><<<dim3((max_seg + 63) / 64, n_seg), 256, rl, ctx->stream>>>(d_scores, d_seg, desc, d_out);
+        }
+    } else if (max_seg <= kSortLdsMax && !ctx->knobs.sort_lds)
         sort_kernel_reg<<<n_seg, 1024, 0, ctx->stream>>>(d_scores, d_seg, desc, d_out);
     else
         sort_kernel<<<n_seg, 1024, lds, ctx->stream>>>(d_scores, d_seg, desc, g_keys, g_idx, stride, d_out);

@@ -650,6 +650,27 @@ def test_sort_register_network_segments_up_to_8192(ctx):
             assert np.array_equal(got[a:b], o.sort_scores(s[a:b], desc)), (desc, i, sizes[i])
 
 
+def test_sort_few_segments_rank_by_counting(ctx):
+    """Up to 8 segments of <= 8192 items take the counting kernel (64 items per workgroup, spread over the chip — the
+    single-request path): same order as the network — ties by index, NaN last, -0 == +0, an all-equal segment, the
+    chunk boundaries of the four-way split."""
+    rng = np.random.default_rng(19)
+    for sizes in ([8192, 0, 1, 5000, 513, 63, 4097, 2], [5000], [7], [8191, 8185]):
+        segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+        s = rng.random(int(segs[-1]))
+        s[::7] = np.round(s[::7], 1)
+        s[3::501] = np.nan
+        s[10::997] = -0.0
+        s[11::997] = 0.0
+        if len(sizes) > 3:
+            s[segs[3]:segs[4]] = 0.25
+        for desc in (True, False):
+            got = ctx.sort_scores(s, segs, descending=desc)
+            for i in range(len(sizes)):
+                a, b = int(segs[i]), int(segs[i + 1])
+                assert np.array_equal(got[a:b], o.sort_scores(s[a:b], desc)), (desc, i, sizes[i])
+
+
 # ---------------------------------------------------------------------------------------------
 # DPP
 # ---------------------------------------------------------------------------------------------
