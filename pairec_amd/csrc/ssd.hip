@@ -306,17 +306,21 @@ __global__ __launch_bounds__(256) void ssd_kernel_reg(double* __restrict__ Et, u
 // ---------------------------------------------------------------------------------------------
 // Multi-workgroup variant: one wave per workgroup, one candidate per lane, the candidate's whole residual
 // embedding lives in the lane's registers for the entire run (D1 doubles ≤ 258 VGPRs of the 512 a lone wave
-// may use), so a pick moves no embedding data except the broadcast of the picked / leaving item's vector
-// (D1 doubles through a global mailbox).  Workgroups meet at a device-wide barrier twice per pick (all of
-// them are co-resident: at most 128 single-wave workgroups on 256 CUs, launched on an otherwise idle
-// stream).  Same arithmetic, same order as ssd_kernel.
+// may use), so a pick moves no embedding data except through a global mailbox.  Workgroups meet at a device-wide
+// barrier ONCE per pick (all of them are co-resident: at most 128 single-wave workgroups on 256 CUs): before it every
+// workgroup publishes its own best candidate — quality, index, sum of squares, norm AND residual vector — and the
+// owner of the item leaving the window publishes that item's frozen vector; after it every workgroup reduces the G
+// partial results identically and reads the winner's vector from the winner's slot.  (Publishing only the global
+// winner's vector needs a second barrier per pick — the first version: 10 us per pick, of which the two barriers
+// were most.)  Same arithmetic, same order as ssd_kernel.
 // ---------------------------------------------------------------------------------------------
 struct SsdMail {
     uint32_t counter;          // monotonically increasing arrival count of the device-wide barrier
     uint32_t pad[15];
     double part_q[2][128];     // per-workgroup best quality, by pick parity
     uint32_t part_i[2][128];
-    double den[2], l2[2];      // picked item's sum of squares / norm, by pick parity
+    double part_ss[2][128];    // that candidate's sum of squares / norm
+    double part_l2[2][128];
 };
 
 __device__ __forceinline__ double ld_dev(const double* p) {       // device-scope load (bypasses the CU's L1)
@@ -328,24 +332,27 @@ __device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) {
 
 __device__ __forceinline__ void ssd_grid_barrier(uint32_t* counter, uint32_t G, uint32_t& phase) {
     ++phase;
+    // (the other lanes' published stores are ordered before lane 0's release by the wave-scope fence: one wave per workgroup)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (threadIdx.x == 0) {
-        __threadfence();
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < phase * G)
             __builtin_amdgcn_s_sleep(1);
-        __threadfence();
+        // (no fence on the way out: everything read after the barrier is read with device-scope loads, ld_dev)
     }
     __builtin_amdgcn_wave_barrier();
 }
 
+// ebuf: [2 parities][G + 1 slots][D1]: slot w = workgroup w's best candidate, slot G = the item leaving the window
 template <int D1>
 __global__ __launch_bounds__(64) void ssd_kernel_grid(const double* __restrict__ Et, uint32_t n,
                                                       const double* __restrict__ rel_g, double gamma, uint32_t T,
                                                       uint32_t W, int star, SsdMail* __restrict__ mail,
-                                                      double* __restrict__ ebuf,   // [2][2][D1]: parity, sel/old
-                                                      uint32_t* __restrict__ out) {
+                                                      double* __restrict__ ebuf, uint32_t* __restrict__ out) {
     __shared__ double e_sel[D1], e_old[D1];
     __shared__ double p_ring[16][64];
+    __shared__ uint32_t pick_ring[32];                   // the last picks (W <= 16 back is all that is needed)
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
     const uint32_t lane = threadIdx.x, G = gridDim.x, wg = blockIdx.x;
     const uint32_t j = wg * 64 + lane;
     const bool valid = j < n;
@@ -358,40 +365,6 @@ __global__ __launch_bounds__(64) void ssd_kernel_grid(const double* __restrict__
     uint32_t phase = 0;
     const double nan = __longlong_as_double(0x7FF8000000000000ll);
 
-    // wave-local "first maximum, NaN skipped" of (q, j); invalid lanes carry NaN
-    auto wave_best = [&](double q, double& bq, uint32_t& bi) {
-        bq = q;
-        bi = (valid && q == q) ? j : 0xFFFFFFFFu;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double oq = __shfl_xor(bq, off, 64);
-            const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
-            if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || oq > bq || (oq == bq && oi < bi))) { bq = oq; bi = oi; }
-        }
-    };
-    // publish this workgroup's best, meet, then every workgroup reduces the G partial results identically
-    auto global_pick = [&](double q, uint32_t par) -> uint32_t {
-        double bq;
-        uint32_t bi;
-        wave_best(q, bq, bi);
-        if (lane == 0) { mail->part_q[par][wg] = bq; mail->part_i[par][wg] = bi; }
-        ssd_grid_barrier(&mail->counter, G, phase);
-        double gq = nan;
-        uint32_t gi = 0xFFFFFFFFu;
-        for (uint32_t w = lane; w < G; w += 64) {       // G <= 128: at most 2 per lane, ascending
-            const double oq = ld_dev(&mail->part_q[par][w]);
-            const uint32_t oi = ld_dev(&mail->part_i[par][w]);
-            if (oi != 0xFFFFFFFFu && (gi == 0xFFFFFFFFu || oq > gq || (oq == gq && oi < gi))) { gq = oq; gi = oi; }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double oq = __shfl_xor(gq, off, 64);
-            const uint32_t oi = (uint32_t)__shfl_xor((int)gi, off, 64);
-            if (oi != 0xFFFFFFFFu && (gi == 0xFFFFFFFFu || oq > gq || (oq == gq && oi < gi))) { gq = oq; gi = oi; }
-        }
-        return gi == 0xFFFFFFFFu ? 0u : gi;
-    };
-
     double ss_own = 0.0, l2_own = 0.0;                  // this lane's last sum of squares / norm
     {   // ‖e‖² of every candidate once: the first pick's volume factor and first denominator
 #pragma unroll
@@ -401,43 +374,87 @@ __global__ __launch_bounds__(64) void ssd_kernel_grid(const double* __restrict__
         }
         l2_own = sqrt(ss_own);
     }
-    uint32_t idx = global_pick(valid ? rel : nan, 0);
+    double q = valid ? rel : nan;                        // quality of the coming pick ("first maximum, NaN skipped")
     uint32_t t = 1;
     double volume = gamma;
     for (;;) {
-        // (idx = pick number t, known to every workgroup)  owner: publish its vector, norm, sum of squares
         const uint32_t par = t & 1;
         const bool pop = t > W && t < T;
-        if (valid && j == idx) {
-            selected = true;
-            mail->den[par] = ss_own;
-            mail->l2[par] = l2_own;
-            out[t - 1] = idx;
-            if (t < T) {
+        // ---- publish: this workgroup's best (with its vector), the item leaving the window
+        double bq = q;
+        uint32_t bi = (valid && q == q) ? j : kNone;
 #pragma unroll
-                for (int k = 0; k < D1; ++k) ebuf[(size_t)(par * 2 + 0) * D1 + k] = v[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oq = __shfl_xor(bq, off, 64);
+            const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
+            if (oi != kNone && (bi == kNone || oq > bq || (oq == bq && oi < bi))) { bq = oq; bi = oi; }
+        }
+        if (lane == 0) { mail->part_q[par][wg] = bq; mail->part_i[par][wg] = bi; }
+        // (nothing pickable anywhere → pick 0, as floats.MaxIdx does: workgroup 0 then publishes candidate 0)
+        const uint32_t pub = bi != kNone ? bi : (wg == 0 ? 0u : kNone);
+        if (valid && j == pub) {
+            mail->part_ss[par][wg] = ss_own;
+            mail->part_l2[par][wg] = l2_own;
+            if (t < T) {
+                double* dst = ebuf + ((size_t)par * (G + 1) + wg) * D1;
+#pragma unroll
+                for (int k = 0; k < D1; ++k) dst[k] = v[k];
             }
         }
-        if (t >= T) break;
-        // the item leaving the window (picked W picks ago): its owner publishes its frozen vector
-        uint32_t i_old = 0xFFFFFFFFu;
-        if (pop) i_old = ld_dev(&out[t - 1 - W]);
+        uint32_t i_old = kNone;
+        if (pop) i_old = pick_ring[(t - 1 - W) & 31];
         if (pop && valid && j == i_old) {
+            double* dst = ebuf + ((size_t)par * (G + 1) + G) * D1;
 #pragma unroll
-            for (int k = 0; k < D1; ++k) ebuf[(size_t)(par * 2 + 1) * D1 + k] = v[k];
+            for (int k = 0; k < D1; ++k) dst[k] = v[k];
         }
         ssd_grid_barrier(&mail->counter, G, phase);
-        for (uint32_t k = lane; k < (uint32_t)D1; k += 64) {
-            e_sel[k] = ld_dev(&ebuf[(size_t)(par * 2 + 0) * D1 + k]);
-            if (pop) e_old[k] = ld_dev(&ebuf[(size_t)(par * 2 + 1) * D1 + k]);
+        // ---- every workgroup reduces the G partial results identically
+        double gq = nan;
+        uint32_t gi = kNone;
+        for (uint32_t w = lane; w < G; w += 64) {       // G <= 128: at most 2 per lane, ascending
+            const double oq = ld_dev(&mail->part_q[par][w]);
+            const uint32_t oi = ld_dev(&mail->part_i[par][w]);
+            if (oi != kNone && (gi == kNone || oq > gq || (oq == gq && oi < gi))) { gq = oq; gi = oi; }
         }
-        const double den = ld_dev(&mail->den[par]);
-        const double l2p = ld_dev(&mail->l2[par]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oq = __shfl_xor(gq, off, 64);
+            const uint32_t oi = (uint32_t)__shfl_xor((int)gi, off, 64);
+            if (oi != kNone && (gi == kNone || oq > gq || (oq == gq && oi < gi))) { gq = oq; gi = oi; }
+        }
+        const uint32_t idx = gi == kNone ? 0u : gi;      // pick number t
+        const uint32_t wwg = idx >> 6;
+        if (valid && j == idx) {
+            selected = true;
+            out[t - 1] = idx;
+        }
+        if (lane == 0) pick_ring[(t - 1) & 31] = idx;
+        if (t >= T) break;
+        {   // all the loads of the two vectors first (independent: one L2 round trip, not three)
+            constexpr int NR = (D1 + 63) / 64;
+            const double* ps = ebuf + ((size_t)par * (G + 1) + wwg) * D1;
+            const double* po = ebuf + ((size_t)par * (G + 1) + G) * D1;
+            double ts[NR], to[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const uint32_t k = lane + 64u * (uint32_t)r;
+                ts[r] = k < (uint32_t)D1 ? ld_dev(ps + k) : 0.0;
+                to[r] = (pop && k < (uint32_t)D1) ? ld_dev(po + k) : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const uint32_t k = lane + 64u * (uint32_t)r;
+                if (k < (uint32_t)D1) { e_sel[k] = ts[r]; e_old[k] = to[r]; }
+            }
+        }
+        const double den = ld_dev(&mail->part_ss[par][wwg]);
+        const double l2p = ld_dev(&mail->part_l2[par][wwg]);
         if (!star && !ssd_bad(l2p)) volume = __dmul_rn(volume, l2p);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const uint32_t slot = t % W;
-        double q = -DBL_MAX;
+        q = -DBL_MAX;
         if (!selected) {
             if (pop) {
                 const double pold = p_ring[slot][lane];
@@ -468,8 +485,8 @@ __global__ __launch_bounds__(64) void ssd_kernel_grid(const double* __restrict__
             l2_own = l2;
             q = __dadd_rn(rel, __dmul_rn(volume, ssd_bad(l2) ? 0.5 : l2));
         }
+        if (!valid) q = nan;
         ++t;
-        idx = global_pick(valid ? q : nan, t & 1);
     }
 }
 
@@ -541,7 +558,7 @@ int pg_ssd(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const doub
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t bE = al((size_t)n * d1 * 8), bP = al((size_t)window * n * 8), bN = al((size_t)n * 8);
     const size_t bCand = al((size_t)n * 4), bSel = al((size_t)n * 4), bOut = al((size_t)T * 4);
-    const size_t bMail = al(sizeof(pg::SsdMail)), bEbuf = al((size_t)4 * d1 * 8);
+    const size_t bMail = al(sizeof(pg::SsdMail)), bEbuf = al((size_t)2 * ((n + 63) / 64 + 1) * d1 * 8);
     void* buf;
     int rc;
     if ((rc = pg::scratch_reserve(ctx, 7, bE + bP + 4 * bN + bCand + bSel + bOut + bMail + bEbuf, &buf))) return rc;
