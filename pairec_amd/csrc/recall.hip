@@ -1865,7 +1865,7 @@ int recall_job_prepare(RecallJob* j) {
     j->plans[j->n_plans++] = kSafe;
     if (j->skip_pilot && j->plans[0] == kPilot) j->next_plan = 1;
     // small batches: the pilot plan's full pass is HBM-bound on the shadow it streams — use the 4-bit one (recall_i4.hip)
-    if (screen && t->shadow_is_i8 && j->nq <= kI4MaxQueries && j->plans[0] == kPilot && !kn.no_screen_i4 &&
+    if (screen && t->dim == 128 && j->nq <= kI4MaxQueries && j->plans[0] == kPilot && !kn.no_screen_i4 &&
         rows >= kn.i4_min_rows && (uint64_t)kMaxQueries * rs_cap_bound(j->k) / kI4MaxQueries < 0xFFFFFFFFull) {
         if ((rc = ensure_table_i4(ctx, t))) return rc;
         // (measured at 100M x 128, int8 pass 2.1 ms: uniform rows, lambda 0.8: 1.37 / 1.38 / 1.59 / 1.66 ms at 1..4
@@ -2128,8 +2128,8 @@ void recall_job_finish(RecallJob* j) {
     ctx->last_scan_launches = j->scan_launches;
     // bytes the scan launches streamed: the shadow's element size when the pass was screened
     ctx->last_scan_bytes = j->scanned_rows * (uint64_t)j->t->dim * (j->screen ? (j->t->shadow_is_i8 ? 1 : 2) : 4);
-    if (j->screen4 && j->enqueued_plan == kPilot)      // the full pass read 64 + 8 B per row instead of 128
-        ctx->last_scan_bytes -= (uint64_t)j->rows * (128 - 72);
+    if (j->screen4 && j->enqueued_plan == kPilot)      // the full pass read 64 + 8 B per row instead of 128 (int8) / 256 (bf16)
+        ctx->last_scan_bytes -= (uint64_t)j->rows * ((j->t->shadow_is_i8 ? 128 : 256) - 72);
 }
 
 int recall_patch_failed_locked(RecallJob* j, uint32_t* counts) {

@@ -11,9 +11,13 @@
 // of dword w holds dims 8w+b (low nibble) and 8w+4+b (high nibble), each stored as X + 8 — plus {s_r, R_r} in fp32,
 // R_r >= ||x - x^|| being the row's own MEASURED residual (72 B per row in all).
 // Bound, for the true score s = sum x_i q_i and the integer dot product I = sum X_i Q_i (Q = int8 query, scale s_q):
-//     |s - s_r s_q I| <= ||x - x^|| ||q|| + ||x^|| ||q - q^||  <=  R_r ||q|| + (N + R4) ||q - q^||
-// with R4 = max_r R_r and N = max row norm.  So a row can reach thr only if
-//     s_r s_q I + R_r C_q >= thr - E_q,   C_q = ||q||,   E_q = (N + R4) ||q - q^|| + rounding slack.
+//     |s - s_r s_q I| <= ||x - x^|| ||q|| + ||x^|| ||q - q^||  <=  R_r ||q|| + H_r ||q - q^||,
+//     H_r = min(7 sqrt(dim) s_r, N + R4) >= ||x^||     (|X_i| <= 7; N = max row norm, R4 = max_r R_r)
+// so a row can reach thr only if
+//     s_r s_q I + R_r B_q + H_r A_q >= thr,   B_q = ||q|| (1 + slack),   A_q = ||q - q^|| + slack (||q|| + ||q - q^||)
+// (slack: the rounding of the specification's fmaf chain, <= 128 x 2^-24 ||x|| ||q||, and of this fp32 evaluation).
+// Every term is relative to the ROW — scale, residual, norm bound — so rows of very different magnitude (heavy-tailed
+// norms, the tables whose range defeats the int8 shadow's single scale) screen as well as uniform ones.
 #include "common.hpp"
 
 namespace pg {
@@ -29,7 +33,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct Screen4Args {
     const u32x4* d4;          // [rows + 64][4] quads
     const float2* d4s;        // [rows + 64] {row scale, row residual}
-    const uint32_t* q4;       // [4][32] int8 queries, then [4][4] {s_q, C_q, E_q, 8 sum(Q) as int bits}
+    const uint32_t* q4;       // [4][32] int8 queries, then [4][4] {s_q, B_q, A_q, 8 sum(Q) as int bits}
+    float h_cap;              // N + R4
     const float* thr;         // [>= 4] running thresholds
     uint32_t* susp_cnt;
     uint32_t* susp;           // [4][cap4]
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int part = lane & 3;                         // which 32 dims of the row this lane holds
     int Q[NQ][8];
-    float sq[NQ], cq[NQ], tq[NQ];
+    float sq[NQ], bq[NQ], aq[NQ], tq[NQ];
     int bias[NQ];
     uint32_t cnt[NQ];
 #pragma unroll
@@ -52,12 +57,12 @@ __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
         for (int j = 0; j < 8; ++j) Q[qi][j] = (int)a.q4[qi * 32 + part * 8 + j];
         const float* c = reinterpret_cast<const float*>(a.q4 + 4 * 32) + qi * 4;
         sq[qi] = c[0];
-        cq[qi] = c[1];
-        const float e = c[2], t = a.thr[qi];
+        bq[qi] = c[1];
+        aq[qi] = c[2];
+        const float t = a.thr[qi];
         bias[qi] = __float_as_int(c[3]);
-        // thr - E rounded down; anything not finite: every row is a suspect (the lists overflow, the next plan runs)
-        tq[qi] = (t == t && e == e && e < 1e30f && t > -__builtin_inff()) ? __double2float_rd((double)t - (double)e)
-                                                                         : -__builtin_inff();
+        // anything not finite: every row is a suspect (the lists overflow, the next plan runs)
+        tq[qi] = (t == t && aq[qi] == aq[qi] && aq[qi] < 1e30f && t > -__builtin_inff()) ? t : -__builtin_inff();
         cnt[qi] = 0;
     }
     auto flush = [&](int qi) {
@@ -86,6 +91,9 @@ __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
             v[u] = __builtin_nontemporal_load(a.d4 + (size_t)(row0 + 16 * u) * 4 + part);
             s[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(a.d4s) + row0 + 16 * u);
         }
+        float hr[4];                                   // H_r (7 sqrt(128) = 79.196 rounded up)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hr[u] = fminf(s[u].x * 79.1961f, a.h_cap);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t row = row0 + 16 * u;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
                 for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_sdot4(b[i], Q[qi][i], acc, false);
                 acc += __builtin_amdgcn_update_dpp(0, acc, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
                 acc += __builtin_amdgcn_update_dpp(0, acc, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
-                const float f = __fmaf_rn(s[u].x * sq[qi], (float)(acc - bias[qi]), s[u].y * cq[qi]);
+                const float f = __fmaf_rn(s[u].x * sq[qi], (float)(acc - bias[qi]), __fmaf_rn(hr[u], aq[qi], s[u].y * bq[qi]));
                 const bool hit = part == 0 && row < a.rows && !(f < tq[qi]);
                 const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
                 if (m) {
@@ -154,11 +162,12 @@ __global__ __launch_bounds__(256) void screen4_prep_kernel(const float* __restri
     if (lane == 0) {
         const double nq = sqrt(ss), dq = sqrt(dd);
         const double N = (double)max_norm, R = (double)rmax4;
-        // C: ||q||, the factor of the row's residual; E: the query-side term, the rounding of the specification's
-        // fp32 fmaf chain (<= 128 x 2^-24 N ||q||) and of this kernel's own fp32 evaluation of the bound
-        // (four roundings of values below 2 (N + R)(||q|| + dq))
-        const double C = nq * 1.000001 + 1e-30;
-        const double E = (N + R) * dq * 1.0001 + 1e-5 * N * nq + 2e-6 * (N + R) * (nq + dq) + 1e-30;
+        // B: the factor of the row's residual R_r; A: the factor of the row's norm bound H_r >= ||x^||.  Slack: the
+        // specification's fp32 fmaf chain rounds by <= 128 x 2^-24 ||x|| ||q|| <= 1e-5 (H_r + R_r) ||q||, this kernel's own
+        // fp32 evaluation (five roundings of values below 2 (H_r + R_r)(||q|| + dq)) by <= 2e-6 (H_r + R_r)(||q|| + dq)
+        (void)N; (void)R;
+        const double C = nq * (1.0 + 1e-5 + 2e-6) * 1.000001 + 2e-6 * dq + 1e-30;
+        const double E = dq * 1.0001 + (1e-5 + 2e-6) * nq + 2e-6 * dq + 1e-30;
         float* c = reinterpret_cast<float*>(q4 + 4 * 32) + qi * 4;
         c[0] = sc;
         c[1] = (float)(C * 1.000001);
@@ -303,6 +312,7 @@ int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint
     a.overflow = rs.overflow;
     a.cap4 = cap4;
     a.rows = rows;
+    a.h_cap = (t->max_norm + t->rmax4) * 1.000001f;
     // a persistent grid of exactly the resident workgroups (the group walk is interleaved over all waves, so waves
     // that started late would leave a tail); 4 KiB of loads in flight per wave
     static int per_cu[kI4MaxQueries + 1] = {0, 0, 0, 0, 0};

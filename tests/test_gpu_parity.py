@@ -233,7 +233,8 @@ def test_recall_small_batch_4bit_screen_is_exact(ctx):
     with data built against it — an outlier inside a row (coarsens that row's scale), tiny rows, zero rows, winners
     that differ by far less than a 4-bit step, a zero query, one-hot and non-finite queries: ids, order and score bits
     must match the oracle, the pass must really have read the narrow shadow, and the shadow must follow uploads and
-    swaps.  A heavy-tailed table (lambda above the limit) stays on the wider shadow."""
+    swaps.  A table with heavy-tailed ELEMENTS (lambda above the limit) stays on the wider shadow; one with heavy-tailed
+    ROW NORMS (bf16 main shadow) still uses the 4-bit one."""
     rng = np.random.default_rng(29)
     n, d, k = 400_000, 128, 200
     tab = rng.standard_normal((n, d)).astype(np.float32) * 0.05
@@ -267,7 +268,8 @@ def test_recall_small_batch_4bit_screen_is_exact(ctx):
             assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
             finite = bool(np.all(np.isfinite(q)))
             if finite:          # (a non-finite query overflows the pilot plan by design: the next plan answers)
-                assert (nbytes < n * 128) == expect_i4, (nbytes, expect_i4)
+                # less than one pass over the table's main shadow (int8: 128 B per row, bf16: 256) <=> the full pass was 4-bit
+                assert (nbytes < n * 128 * t_.screen_info()[0]) == expect_i4, (nbytes, expect_i4)
 
         for lo, hi in ((0, 1), (1, 2), (2, 4), (4, 5), (5, 6), (6, 8), (8, 11), (8, 12), (0, 4)):
             check(t, tab, qs[lo:hi])
@@ -290,8 +292,13 @@ def test_recall_small_batch_4bit_screen_is_exact(ctx):
         heavy = (rng.standard_t(2.2, (n, d)) * 0.01).astype(np.float32)
         np.clip(heavy, -0.4, 0.4, out=heavy)
         other.upload(heavy)
-        if other.screen_info()[0] == 1:
-            check(other, heavy, qs[8:9], expect_i4=False)
+        check(other, heavy, qs[8:9], expect_i4=False)              # elements far above their row's norm: lambda > limit
+        # rows of very different magnitude (log-normal row scales): one int8 scale is useless → bf16 main shadow, but
+        # every term of the 4-bit bound is relative to the row, so small batches still stream 72 B per row
+        scaled = tab * np.exp(rng.standard_normal((n, 1)) * 1.5).astype(np.float32)
+        other.upload(scaled)
+        assert other.screen_info()[0] == 2
+        check(other, scaled, qs[8:10], expect_i4=True)
         t.destroy()
         other.destroy()
     finally:
