@@ -13,7 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCAN_KERNELS = ("screen_kernel", "rescore_kernel", "scan_kernel")
+SCAN_KERNELS = ("screen_kernel", "screen4_kernel", "rescore_kernel", "scan_kernel")
 PASSES = 7  # bench.py --steps 5 --warmup 2 --no-extras --contexts 1
 SIMDS = 1024  # 256 CUs x 4
 
@@ -40,7 +40,8 @@ def main():
                    "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide 16 B/lane reads); per table pass = sum "
                    "over the pass's scan-stage launches (exact seed of the pilot, screened sample launch, screened "
                    "full pass over the int8 shadow, exact fp32 re-scoring gathers) / 7 passes; algorithmic bytes per "
-                   "pass = 12.8e9 (int8 shadow of the 51.2e9-byte fp32 table)"}
+                   "pass = 12.8e9 (int8 shadow of the 51.2e9-byte fp32 table); batches of <= 4 queries stream the 4-bit shadow "
+                   "(7.2e9 bytes) in the full pass, the int8 one in the pilot sample"}
     for R in sizes:
         d = os.path.join(ROOT, "gpurun_out", "prof_%s_%d" % (tag, R))
         f, nf = counter_totals(d, "FETCH_SIZE")
@@ -60,10 +61,11 @@ def main():
             busy = None
         out[str(R)] = {
             "mfma_busy_frac": None if busy is None else round(busy, 4),
-            "kernels": "screen_kernel + rescore_kernel + seed scan_kernel",
+            "kernels": "screen_kernel (+ screen4_kernel: the 4-bit full pass of batches of <= 4) + rescore_kernel + seed scan_kernel",
             "source": "profiles/%s_%d_rocprofv3_summary.txt" % (tag, R),
             "fetch_kb_per_pass": round(fetch_kb), "write_kb_per_pass": round(write_kb),
             "screen_kernel_fetch_kb_per_pass": round(f["screen_kernel"] / PASSES),
+            "screen4_kernel_fetch_kb_per_pass": round(f["screen4_kernel"] / PASSES),
             "rescore_kernel_fetch_kb_per_pass": round(f["rescore_kernel"] / PASSES),
             "dispatches": dict(nf),
             "hbm_bytes_per_pass": round((2 * fetch_kb + write_kb) * 1024),
