@@ -215,7 +215,7 @@ def cpu_baseline(o, args, R, K):
     }
 
 
-def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs):
+def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs, scan_bytes=None):
     """Both denominators, side by side: `frac` prices the bytes the pass actually streams (the int8 / bf16 shadow),
     `frac_survey_8d` prices SURVEY.md 8(d)'s algorithmic figure — the fp32 table, rows x dim x 4 — and exceeds 1
     whenever the screen is on, because the fp32 rows are never streamed (only the ~1e-4 of rows that pass the exact
@@ -224,6 +224,11 @@ def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs):
     elem_bytes = table.screen_info()[0]
     screened = elem_bytes != 0
     shard_bytes = rows_local * args.dim * (elem_bytes if screened else 4)
+    # batches of <= 4 queries: the full pass streams the 4-bit shadow (72 B per row, csrc/recall_i4.hip) — the engine's own
+    # byte count of the last recall's scan launches (pilot sample on the main shadow + that pass) says whether it did
+    four_bit = bool(screened and R <= 4 and args.dim == 128 and scan_bytes and scan_bytes < shard_bytes)
+    if four_bit:
+        shard_bytes = int(scan_bytes)
     fp32_bytes = rows_local * args.dim * 4
     t = scan_avg_ms * 1e-3
     achieved = shard_bytes / t / 1e9
@@ -234,8 +239,8 @@ def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs):
     busy = (prof or {}).get("mfma_busy_frac") or 0.0
     hbm_frac = achieved / HBM_PEAK_GBS
     return {
-        "bound": "mfma" if max(mfma_frac, busy) > hbm_frac else "hbm",
-        "kernel": scan_kernel_name(R, args.dim, elem_bytes),
+        "bound": "mfma" if (max(mfma_frac, busy) > hbm_frac and not four_bit) else "hbm",
+        "kernel": ("pg::screen4_kernel<%d>" % R) if four_bit else scan_kernel_name(R, args.dim, elem_bytes),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
         "frac_survey_8d": fp32_bytes / t / 1e9 / HBM_PEAK_GBS,
         "traffic": None, "traffic_from_profile": prof,
@@ -565,7 +570,7 @@ def main():
                                    % (world, args.rows * world)) if shard else
                                   ("request-parallel x%d, table replicated per GPU, no data-path collective" % world
                                    if world > 1 else "1 GPU")},
-        "roofline": roofline_block(table, R, args, end - begin, scan_avg_ms, measured_gbs),
+        "roofline": roofline_block(table, R, args, end - begin, scan_avg_ms, measured_gbs, ctx.last_scan_kernel()[1]),
         "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},
         "rank_roofline": {"bound": "mfma", "kernel": "pg::dnn3_ws_kernel",
                           "achieved": rank_items * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
@@ -589,6 +594,13 @@ def main():
         lat = lat[len(lat) // 10:]
         out["p99_request_latency_ms"] = float(np.percentile(lat, 99))
         out["p50_request_latency_ms"] = float(np.median(lat))
+        # the scan stage of that single request (HBM-bound on the shadow it streams: the 4-bit one for dim 128)
+        ms1, bytes1 = ctx.last_scan_kernel()
+        if ms1 > 0:
+            rf1 = roofline_block(table, 1, args, end - begin, ms1, measured_gbs, bytes1)
+            out["single_request_roofline"] = {k_: rf1[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                                     "measured_peak", "frac_of_measured", "bytes_per_pass",
+                                                                     "ms_per_pass", "traffic_from_profile")}
 
     extras = solo and not args.no_extras
     if extras and args.callers > 0:
