@@ -63,6 +63,7 @@ struct Knobs {
     bool debug_scan = false;       // PG_DEBUG_SCAN: print per-launch times and suspect counts
     bool screen_bf16 = false;      // PG_SCREEN_BF16: bf16 shadow for dim-128 tables too
     bool screen_i8 = false;        // PG_SCREEN_I8: int8 shadow even for heavy-tailed tables
+    bool no_refine = false;        // PG_NO_REFINE: the pilot plan's full pass keeps the sample's threshold throughout
     bool no_screen_i4 = false;     // PG_NO_SCREEN_I4: small batches stay on the int8 screen
     uint32_t i4_min_rows = 1u << 22; // PG_I4_MIN_ROWS: smallest table the 4-bit screen is built for
     double i4_max_lambda = 1.7;    // PG_I4_MAX_LAMBDA: largest pg_table::lam4 the 4-bit screen is used for
@@ -210,7 +211,7 @@ int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, ui
 int recall_patch_failed_locked(RecallJob* j, uint32_t* counts);
 int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs);
 int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
-                  uint32_t cap, uint32_t k);
+                  uint32_t cap, uint32_t k, int thr_only = 0);
 int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap, uint32_t nq, uint32_t k,
                  uint64_t row_offset, uint64_t* d_out_rows, float* d_out_scores, uint32_t* d_out_count);
 int ensure_table_stats(pg_ctx* ctx, const pg_table* tc);

@@ -649,6 +649,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                     cmask[c] = __builtin_amdgcn_ballot_w64(m >= thr_s[half * NQB + c]);
                     any_mask |= cmask[c];
                 }
+                if (VAR == 4) {                              // (ablation: test, never the hit path)
+                    asm volatile("" :: "s"(any_mask));
+                    any_mask = 0;
+                }
                 if (any_mask != 0) {
 #pragma unroll
                     for (int c = 0; c < NQB; ++c) {
@@ -1236,7 +1240,9 @@ __global__ __launch_bounds__(1024) void select_kernel(const uint64_t* __restrict
                                                       uint64_t* __restrict__ cand_out,
                                                       uint32_t* __restrict__ cnt,
                                                       float* __restrict__ thr, uint32_t cap,
-                                                      uint32_t K) {
+                                                      uint32_t K, int thr_only) {
+    // thr_only: the lists stay as they are (cand_out is not written, cnt unchanged); the query's threshold rises to the
+    // score of its K-th largest candidate so far — when it has that many (the refinement step of the pilot plan)
     extern __shared__ __attribute__((aligned(16))) char sel_smem[];
     uint64_t* const lkeys = reinterpret_cast<uint64_t*>(sel_smem);          // [kSelLdsKeys] when used
     __shared__ uint32_t hist[256];
@@ -1273,9 +1279,10 @@ __global__ __launch_bounds__(1024) void select_kernel(const uint64_t* __restrict
     const uint64_t kmin = s_min, kmax = s_max;
     const uint64_t* src = in_lds ? lkeys : in;
     if (M <= K) {
-        for (uint32_t i = tid; i < M; i += 1024) out[i] = src[i];
+        if (!thr_only)
+            for (uint32_t i = tid; i < M; i += 1024) out[i] = src[i];
         if (tid == 0) {
-            cnt[q] = M;
+            if (!thr_only) cnt[q] = M;
             if (M == K && K > 0) thr[q] = key_score(kmin);     // threshold = score of the smallest key
         }
         return;
@@ -1327,6 +1334,10 @@ __global__ __launch_bounds__(1024) void select_kernel(const uint64_t* __restrict
         prefix = s_min;
     }
     const uint64_t kth = prefix + kmin;          // exactly K keys are >= kth
+    if (thr_only) {
+        if (tid == 0) thr[q] = key_score(kth);
+        return;
+    }
     if (tid == 0) s_out = 0;
     __syncthreads();
     for (uint32_t i = tid; i < M; i += 1024) {
@@ -1517,11 +1528,11 @@ __global__ void merge_keys_kernel(const uint64_t* __restrict__ rows, const float
 }
 
 int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
-                         uint32_t cap, uint32_t k) {
+                         uint32_t cap, uint32_t k, int thr_only) {
     constexpr size_t lds = (size_t)kSelLdsKeys * 8;
     int rc_attr;
     if ((rc_attr = ensure_dyn_lds(ctx, (const void*)select_kernel, lds))) return rc_attr;
-    select_kernel<<<nq, 1024, lds, ctx->stream>>>(in, out, cnt, thr, cap, k);
+    select_kernel<<<nq, 1024, lds, ctx->stream>>>(in, out, cnt, thr, cap, k, thr_only);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
@@ -1752,6 +1763,7 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
         const char* v = getenv("PG_SCREEN_VAR");     // developer ablation builds only
         if (wide && v && v[0] == '1') return launch_screen<128, 4, 8, 1, 1, true, 2>(ctx, a);
         if (wide && v && v[0] == '2') return launch_screen<128, 4, 8, 1, 2, true, 2>(ctx, a);
+        if (wide && v && v[0] == '4') return launch_screen<128, 4, 8, 1, 4, true, 2>(ctx, a);
 #endif
         if (wide) return launch_screen<128, 4, 8, 1, 0, true, 2>(ctx, a);
         if (a.nq <= 32) return launch_screen<128, 1, 8, 1, 0, true>(ctx, a);
@@ -1844,7 +1856,10 @@ int recall_job_prepare(RecallJob* j) {
     j->perm_mul = 1;
     const uint32_t rows = j->rows;
     const uint32_t full_blocks = rows / kPieceRows;           // the sample only uses whole blocks
-    uint32_t want = full_blocks / 64;                        // (1/64 measured best with the int8 screen: 5.39 vs 5.51 ms per 256-request pass at 1/32, 5.46 at 1/96)
+    // 1/96 of the blocks: with the refinement step of the pilot plan (below) the sample's threshold only serves the
+    // first quarter of the full pass, so a thinner, cheaper sample wins (256 requests: 291 vs 286 M items/s at 1/64,
+    // 261 M at 1/32; before the refinement 1/64 was best)
+    uint32_t want = full_blocks / 96;
     // >= 1M sample rows, but never more than an eighth of the table: small tables are launch-bound, and the pilot's
     // three scan launches beat the growing-chunk plan's nine (1M x 64, K = 200: 0.31 -> 0.13 ms per recall)
     const uint32_t floor_blocks = full_blocks / 8 < 32768 ? full_blocks / 8 : 32768;
@@ -1966,13 +1981,24 @@ struct PlanRun {                     // the launches of one plan (helper of reca
     // keep the best `kk` candidates per query, refresh the thresholds, swap the ping-pong lists
     int refresh(uint32_t kk) {
         int rc2;
-        if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk))) return rc2;
+        if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk, 0))) return rc2;
         if (j->screen) {
             if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
             else screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, t->max_norm, rs.thr_screen);
             PG_HIP(hipGetLastError());
         }
         cur ^= 1;
+        return PG_OK;
+    }
+    // raise the thresholds to every query's kk-th best candidate so far (lists untouched)
+    int refine(uint32_t kk) {
+        int rc2;
+        if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk, 1))) return rc2;
+        if (j->screen) {
+            if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
+            else screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, t->max_norm, rs.thr_screen);
+            PG_HIP(hipGetLastError());
+        }
         return PG_OK;
     }
     // geometric chunks over `nb` logical blocks of a stride-`st` view, keeping the best `kk`
@@ -2064,7 +2090,27 @@ int recall_job_enqueue(RecallJob* j) {
             if ((rc = r.grow_scan(j->sample_blocks, j->stride, j->k_pilot, kn.pilot_growth > 0.0 ? kn.pilot_growth : 8.0, false))) return rc;
         }
         PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
-        if ((rc = r.scan_range(0, j->nblocks, 1, false))) return rc;
+        // The sample's threshold is deliberately low (K' = m + 6 sqrt(m) + 8 of a 1/64 sample: ~1.8 K rows reach it where K
+        // are needed), and every row that reaches it costs a suspect's hit path and an exact re-scoring — a quarter of
+        // the 256-query pass.  After the first quarter of the table the candidates found so far ARE a 16x larger sample:
+        // their k2-th best (k2 from the same formula) is a much tighter threshold for the other three quarters.  A
+        // contiguous prefix is not a random sample, but the rule is safe for any row order: with a fraction f of the
+        // rows above the first threshold inside the prefix, the pass ends with about c1 f + k2 (1 - f) / f candidates
+        // (c1 = expected rows above the first threshold), at least 2 sqrt(c1 k2) - k2 > K for the slack both carry; and
+        // the result is verified like every pilot plan's.
+        const uint32_t nb_q = j->nblocks / 4;
+        const double m2 = (double)j->k * 0.25;
+        const uint32_t k2 = (uint32_t)ceil(m2 + kn.pilot_sigmas * sqrt(m2) + 8.0);
+        const double c1 = (double)j->k_pilot * (double)j->rows / ((double)j->sample_blocks * kPieceRows);
+        const bool refine = j->screen && !j->screen4 && !kn.no_refine && j->rows >= (1u << 24) &&
+                            2.0 * sqrt(c1 * (double)k2) - (double)k2 >= 1.1 * (double)j->k;
+        if (refine) {
+            if ((rc = r.scan_range(0, nb_q, 1, false))) return rc;
+            if ((rc = r.refine(k2))) return rc;
+            if ((rc = r.scan_range(nb_q, j->nblocks - nb_q, 1, false))) return rc;
+        } else if ((rc = r.scan_range(0, j->nblocks, 1, false))) {
+            return rc;
+        }
         if ((rc = r.refresh(j->k))) return rc;
     } else {
         // measured: growth 4 is best for the exact scan, 2 for the screened scan whose re-scoring
@@ -2206,7 +2252,7 @@ int topk_merge_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores
     dim3 grid((uint32_t)((per_q + 255) / 256), nq);
     merge_keys_kernel<<<grid, 256, 0, ctx->stream>>>(d_rows, d_scores, nq, nlists, per_list, list_major, rs.cap, rs.cand[0], rs.cnt);
     PG_HIP(hipGetLastError());
-    if ((rc = launch_select(ctx, nq, rs.cand[0], rs.cand[1], rs.cnt, rs.thr, rs.cap, k))) return rc;
+    if ((rc = launch_select(ctx, nq, rs.cand[0], rs.cand[1], rs.cnt, rs.thr, rs.cap, k, 0))) return rc;
     return final_launch(ctx, rs.cand[1], rs.cnt, rs.cap, nq, k, 0, d_out_rows, d_out_scores, d_out_count);
 }
 
