@@ -57,7 +57,8 @@ int pg_synchronize(pg_ctx* ctx);
 /* Developer / test knobs of one context (defaults come from PG_* environment variables read once, in pg_init):
  * "no_pilot", "recall_exact", "screen_min", "pilot_fraction", "chunk_growth", "seed_rows", "pilot_growth",
  * "pilot_sigmas", "debug_scan", "rank_no_ws", "sort_lds", and for the 4-bit screen of batches of <= 4 queries
- * (csrc/recall_i4.hip) "no_screen_i4", "i4_min_rows" (default 2^22), "i4_max_lambda"; value is parsed as a number. */
+ * (csrc/recall_i4.hip) "no_screen_i4", "i4_min_rows" (default 2^22), "i4_max_lambda", and for the threshold refinement inside the pilot plan's
+ * full pass "no_refine", "refine_min_rows" (default 2^24); value is parsed as a number. */
 int pg_set_option(pg_ctx* ctx, const char* name, const char* value);
 int pg_device_malloc(pg_ctx* ctx, size_t bytes, void** out);
 int pg_device_free(pg_ctx* ctx, void* p);

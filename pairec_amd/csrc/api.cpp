@@ -20,6 +20,7 @@ static void knobs_from_env(Knobs* k) {
     k->screen_bf16 = flag("PG_SCREEN_BF16");
     k->screen_i8 = flag("PG_SCREEN_I8");
     k->no_refine = flag("PG_NO_REFINE");
+    k->refine_min_rows = (uint32_t)num("PG_REFINE_MIN_ROWS", (double)(1u << 24));
     k->no_screen_i4 = flag("PG_NO_SCREEN_I4");
     k->i4_max_lambda = num("PG_I4_MAX_LAMBDA", 1.7);
     k->i4_min_rows = (uint32_t)num("PG_I4_MIN_ROWS", (double)(1u << 22));
@@ -132,6 +133,7 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "pilot_growth") k.pilot_growth = v;
     else if (n == "debug_scan") k.debug_scan = b;
     else if (n == "no_refine") k.no_refine = b;
+    else if (n == "refine_min_rows") k.refine_min_rows = (uint32_t)v;
     else if (n == "no_screen_i4") k.no_screen_i4 = b;
     else if (n == "i4_max_lambda") k.i4_max_lambda = v;
     else if (n == "i4_min_rows") k.i4_min_rows = (uint32_t)v;

@@ -64,6 +64,7 @@ struct Knobs {
     bool screen_bf16 = false;      // PG_SCREEN_BF16: bf16 shadow for dim-128 tables too
     bool screen_i8 = false;        // PG_SCREEN_I8: int8 shadow even for heavy-tailed tables
     bool no_refine = false;        // PG_NO_REFINE: the pilot plan's full pass keeps the sample's threshold throughout
+    uint32_t refine_min_rows = 1u << 24;   // PG_REFINE_MIN_ROWS: smallest table whose full pass is split for the refinement
     bool no_screen_i4 = false;     // PG_NO_SCREEN_I4: small batches stay on the int8 screen
     uint32_t i4_min_rows = 1u << 22; // PG_I4_MIN_ROWS: smallest table the 4-bit screen is built for
     double i4_max_lambda = 1.7;    // PG_I4_MAX_LAMBDA: largest pg_table::lam4 the 4-bit screen is used for
@@ -166,6 +167,7 @@ struct RecallScratch {
     uint32_t* susp_cnt;      // [kMaxQueries]
     uint32_t* susp;          // [kMaxQueries][cap] suspect rows of the current launch
     float* qscale;           // [kMaxQueries] int8 screen: the queries' scales
+    float* thr_ref;          // [kMaxQueries] the thresholds the pilot plan's refinement step raised (verified after the pass)
     uint32_t* q4;            // 4-bit screen: [4][32] int8 queries + [4][4] constants (recall_i4.hip)
 };
 struct RecallJob {

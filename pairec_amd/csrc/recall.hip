@@ -1497,6 +1497,13 @@ __global__ __launch_bounds__(256) void final_rank_kernel(const uint64_t* __restr
     }
 }
 
+// after a refined pilot plan: thr = score of the K-th best candidate kept (select_kernel), thr_ref = the raised threshold
+__global__ void refine_verify_kernel(const float* __restrict__ thr, const float* __restrict__ thr_ref,
+                                     uint32_t* __restrict__ count, uint32_t nq) {
+    const uint32_t q = threadIdx.x;
+    if (q < nq && !(thr[q] >= thr_ref[q])) count[q] = 0u;
+}
+
 __global__ void recall_init_kernel(const float* __restrict__ queries, uint32_t nq, uint32_t dim,
                                    float* __restrict__ qpad, float* __restrict__ thr,
                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow) {
@@ -1603,6 +1610,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     rs->overflow = rs->susp_cnt + kMaxQueries;
     rs->qscale = (float*)(rs->overflow + 64);
     rs->q4 = (uint32_t*)(rs->qscale + kMaxQueries);      // 4 x 128 B + 4 x 16 B
+    rs->thr_ref = (float*)(rs->q4 + 160);                // [kMaxQueries]
     void* c;
     if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4), &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
@@ -2060,6 +2068,7 @@ int recall_job_enqueue(RecallJob* j) {
         PG_HIP(hipEventCreate(&e));
         j->events->push_back(e);
     }
+    bool refined = false;
     // events 0/1 of the pool bracket the whole plan; PlanRun's launches use the pairs after them
     r.n_ev = 1;
     PG_HIP(hipEventRecord((*j->events)[0], ctx->stream));
@@ -2094,19 +2103,20 @@ int recall_job_enqueue(RecallJob* j) {
         // are needed), and every row that reaches it costs a suspect's hit path and an exact re-scoring — a quarter of
         // the 256-query pass.  After the first quarter of the table the candidates found so far ARE a 16x larger sample:
         // their k2-th best (k2 from the same formula) is a much tighter threshold for the other three quarters.  A
-        // contiguous prefix is not a random sample, but the rule is safe for any row order: with a fraction f of the
-        // rows above the first threshold inside the prefix, the pass ends with about c1 f + k2 (1 - f) / f candidates
-        // (c1 = expected rows above the first threshold), at least 2 sqrt(c1 k2) - k2 > K for the slack both carry; and
-        // the result is verified like every pilot plan's.
+        // contiguous prefix is not a random sample: if the prefix holds more than its share of the best rows the raised
+        // threshold can exceed the true K-th score — which is CHECKED after the pass (refine_verify_kernel: the K-th
+        // best score that came out must reach the raised threshold), and such a query is re-run like one whose sample
+        // threshold was too high.  Randomly ordered rows fail with the sample's own probability (six sigma).
         const uint32_t nb_q = j->nblocks / 4;
         const double m2 = (double)j->k * 0.25;
         const uint32_t k2 = (uint32_t)ceil(m2 + kn.pilot_sigmas * sqrt(m2) + 8.0);
-        const double c1 = (double)j->k_pilot * (double)j->rows / ((double)j->sample_blocks * kPieceRows);
-        const bool refine = j->screen && !j->screen4 && !kn.no_refine && j->rows >= (1u << 24) &&
-                            2.0 * sqrt(c1 * (double)k2) - (double)k2 >= 1.1 * (double)j->k;
+        const bool refine = j->screen && !j->screen4 && !kn.no_refine && j->rows >= kn.refine_min_rows && nb_q >= 64 &&
+                            k2 < j->k;
         if (refine) {
             if ((rc = r.scan_range(0, nb_q, 1, false))) return rc;
             if ((rc = r.refine(k2))) return rc;
+            PG_HIP(hipMemcpyAsync(rs.thr_ref, rs.thr, sizeof(float) * kMaxQueries, hipMemcpyDeviceToDevice, ctx->stream));
+            refined = true;
             if ((rc = r.scan_range(nb_q, j->nblocks - nb_q, 1, false))) return rc;
         } else if ((rc = r.scan_range(0, j->nblocks, 1, false))) {
             return rc;
@@ -2122,6 +2132,15 @@ int recall_job_enqueue(RecallJob* j) {
     if ((rc = final_launch(ctx, rs.cand[r.cur], rs.cnt, rs.cap, j->nq, j->k, t->row_offset, j->d_out_rows,
                            j->d_out_scores, j->d_count)))
         return rc;
+    if (refined) {
+        // Two thresholds were in force during the full pass, so "K candidates were found" no longer proves that none
+        // of the true top K was rejected: the raised one must not exceed the K-th best score that came out — then at
+        // least K rows reach it, and every row it rejected is below K rows that were kept.  A query that fails reports
+        // zero items, which the plan check reads as "re-run this query" (the same path as a sample threshold that
+        // turned out too high).
+        refine_verify_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.thr_ref, j->d_count, j->nq);
+        PG_HIP(hipGetLastError());
+    }
     if (j->d_out_count)
         PG_HIP(hipMemcpyAsync(j->d_out_count, j->d_count, 4 * j->nq, hipMemcpyDeviceToDevice, ctx->stream));
     PG_HIP(hipMemcpyAsync(j->h_status, rs.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));

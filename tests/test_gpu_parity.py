@@ -439,6 +439,48 @@ def test_recall_adversarial_order(ctx):
     t.destroy()
 
 
+def test_recall_threshold_refinement_any_row_order(ctx):
+    """The pilot plan raises its threshold after the first quarter of the full pass to the k2-th best candidate found
+    so far (csrc/recall.hip).  A contiguous prefix is not a random sample: forced on for a small table, with the rows
+    ordered so that the prefix holds none, all, or a disproportionate share of the best rows — results must be exact
+    for every order, and for the random order no plan may fail."""
+    rng = np.random.default_rng(41)
+    n, d, k, nq = 400_000, 64, 500, 40
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    key = base @ q[0]                                          # order by the first query's score
+    asc = np.argsort(key)
+    orders = {
+        "random": np.arange(n),
+        "ascending": asc,                                      # the prefix holds the worst rows
+        "descending": asc[::-1],                               # ... all of the best
+        "clustered": np.concatenate([asc[-3000:][::2], asc[:n - 3000], asc[-3000:][1::2]]),   # ... half of the best
+    }
+    for name, v in (("refine_min_rows", "0"), ("pilot_fraction", "0.125")):
+        ctx.set_option(name, v)
+    try:
+        t = pa.Table(ctx, n, d)
+        for name, perm in orders.items():
+            tab = np.ascontiguousarray(base[perm])
+            t.upload(tab)
+            before = ctx.stats().recall_rescans
+            rows, scores, _ = t.recall_topk(q, k)
+            launches = ctx.last_scan_launches() if hasattr(ctx, "last_scan_launches") else None
+            orow, osc = o.recall_topk(tab, q, k)
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc)), name
+            if name == "random":
+                assert ctx.stats().recall_rescans == before, "the refined threshold failed on randomly ordered rows"
+            # and the same answers without the refinement
+            ctx.set_option("no_refine", "1")
+            rows2, scores2, _ = t.recall_topk(q, k)
+            ctx.set_option("no_refine", "0")
+            assert np.array_equal(rows2, orow) and np.array_equal(bits(scores2), bits(osc)), name
+        t.destroy()
+    finally:
+        ctx.set_option("refine_min_rows", str(1 << 24))
+        ctx.set_option("pilot_fraction", "0")
+
+
 def test_recall_all_ties_falls_through_every_plan(ctx):
     """A table of identical rows: every row ties with any threshold, so the pilot pass and the growing
     chunks both overflow and the bounded-chunk plan answers; ties resolve to the lowest rows
