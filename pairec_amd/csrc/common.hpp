@@ -103,6 +103,7 @@ struct pg_table {
     float rho4 = 0.0f;           // max over rows of ||x - x^|| / (s_row sqrt(dim)) (diagnostic)
     float rmax4 = 0.0f;          // max over rows of ||x - x^|| (upper bound)
     float lam4 = 0.0f;           // mean residual term in units of the score spread (decides whether the shadow pays)
+    uint32_t prefix_failures = 0; // batches whose refined thresholds failed verification for most queries (ordered rows): two → no refinement
 };
 
 // rank model weights resident in HBM (rank_mlp.hip loads them)
@@ -189,11 +190,13 @@ struct RecallJob {
     bool screen = false;
     bool screen4 = false;                   // the pilot plan's full pass streams the 4-bit shadow (nq <= kI4MaxQueries)
     int plans[3] = {0, 0, 0};
+    bool refined = false;                   // the enqueued pilot plan raised its thresholds after the first quarter
     int n_plans = 0, next_plan = 0, enqueued_plan = -1;
     uint32_t stride = 1, sample_blocks = 0, k_pilot = 0, perm_mul = 1;
     uint32_t n_ev = 0;
     double scan_ms = 0.0, total_ms = 0.0;
     uint64_t scanned_rows = 0;
+    uint64_t scan_bytes = 0;
     uint32_t scan_launches = 0;
     // after a failed check of the pilot plan without overflow: the queries that ended short of K candidates (their
     // sample threshold was too high).  A handful can be re-run one by one instead of re-running the whole batch.
@@ -221,7 +224,8 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc);
 constexpr uint32_t kI4MaxQueries = 4;
 int ensure_table_i4(pg_ctx* ctx, const pg_table* tc);
 int screen4_prep_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs);
-int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t rows, uint32_t cap4);
+int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t row_begin, uint32_t row_end,
+                   uint32_t cap4);
 uint32_t screen4_rescore_blocks();
 int topk_merge_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
                       uint32_t per_list, int list_major, uint32_t k, uint64_t* d_out_rows, float* d_out_scores,

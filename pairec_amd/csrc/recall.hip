@@ -1001,18 +1001,16 @@ __global__ void screen_thr_kernel(const float* __restrict__ thr, const float* __
 // that bound plus 1e-5 N ||q|| for the rounding of the specification's fp32 fmaf chain (<= 128 * 2^-24 N ||q||).
 // A row can reach thr only if  I >= (thr - eps_q) / (s_x s_q): the screen compares integers.
 // per call: int8 B fragments of the (zero-padded) queries, eps_q and the per-query scale s_q = max|q| / 127
-__global__ __launch_bounds__(1024) void screen_prep8_kernel(const float* __restrict__ qpad, uint32_t dim,
-                                                             float max_norm, float resid, uint4* __restrict__ qb8,
-                                                             float* __restrict__ eps, float* __restrict__ qscale,
-                                                             uint32_t nqb) {
-    // nqb: query blocks of 32 in use — the rest of the 256 slots is neither read by the scan nor prepared here
-    // (a single request spent 36 us preparing 255 zero queries)
-    __shared__ float sq[kMaxQueries];
-    const uint32_t tid = threadIdx.x;
-    if ((tid >> 2) < nqb * 32) {
-        // four threads per query, a quarter of the columns each (the serial version took 40 us of every recall)
-        static_assert(kMaxQueries * 4 == 1024, "screen_prep8_kernel: 1024 threads = 256 queries x 4");
-        const uint32_t qi = tid >> 2, part = tid & 3, per = dim / 4;
+// One workgroup per query block of 32 in use (the other slots of the 256 are neither read by the scan nor prepared:
+// a single request used to spend 36 us preparing 255 zero queries, a full batch 37 us in one 1024-thread workgroup).
+__global__ __launch_bounds__(128) void screen_prep8_kernel(const float* __restrict__ qpad, uint32_t dim,
+                                                            float max_norm, float resid, uint4* __restrict__ qb8,
+                                                            float* __restrict__ eps, float* __restrict__ qscale) {
+    __shared__ float sq[32];
+    const uint32_t tid = threadIdx.x, c = blockIdx.x;
+    {
+        // four threads per query, a quarter of the columns each
+        const uint32_t ql = tid >> 2, qi = c * 32 + ql, part = tid & 3, per = dim / 4;
         const float* q = qpad + (size_t)qi * dim + part * per;
         float mx = 0.0f;
         bool bad = false;
@@ -1046,16 +1044,16 @@ __global__ __launch_bounds__(1024) void screen_prep8_kernel(const float* __restr
                              1e-5 * (double)max_norm * nq + 1e-30;
             eps[qi] = bad ? __builtin_nanf("") : (float)(e * 1.000001);      // upper bound in fp32
             qscale[qi] = sc;
-            sq[qi] = sc;
+            sq[ql] = sc;
         }
     }
     __syncthreads();
     const uint32_t KS = dim / 32;
-    for (uint32_t i = tid; i < nqb * KS * 64; i += blockDim.x) {
-        const uint32_t lane = i & 63, ks = (i >> 6) % KS, c = (i >> 6) / KS;
-        const uint32_t qi = c * 32 + (lane & 31);
-        const float* q = qpad + (size_t)qi * dim + ks * 32 + 16 * (lane >> 5);
-        const float sc = sq[qi];
+    for (uint32_t i = tid; i < KS * 64; i += blockDim.x) {
+        const uint32_t lane = i & 63, ks = i >> 6;
+        const uint32_t ql = lane & 31;
+        const float* q = qpad + (size_t)(c * 32 + ql) * dim + ks * 32 + 16 * (lane >> 5);
+        const float sc = sq[ql];
         uint32_t w[4];
         for (int e = 0; e < 4; ++e) {
             uint32_t word = 0;
@@ -1066,7 +1064,7 @@ __global__ __launch_bounds__(1024) void screen_prep8_kernel(const float* __restr
             }
             w[e] = word;
         }
-        qb8[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        qb8[(c * KS + ks) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -1661,6 +1659,7 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     pg_table* t = const_cast<pg_table*>(tc);          // lazily computed cache
     if (t->stats_valid || t->shadow_failed) return PG_OK;
     t->i4_ok = t->i4_failed = false;                  // the 4-bit shadow (recall_i4.hip) follows the rows too
+    t->prefix_failures = 0;
     if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
     const bool force_bf16 = ctx->knobs.screen_bf16;
     bool i8 = t->dim == 128 && !force_bf16;
@@ -1842,6 +1841,7 @@ int recall_job_prepare(RecallJob* j) {
     j->nblocks = (j->rows + kPieceRows - 1) / kPieceRows;
     j->scan_ms = j->total_ms = 0.0;
     j->scanned_rows = 0;
+    j->scan_bytes = 0;
     j->scan_launches = 0;
     j->next_plan = 0;
     j->enqueued_plan = -1;
@@ -1886,7 +1886,7 @@ int recall_job_prepare(RecallJob* j) {
     }
     j->plans[j->n_plans++] = kGrow;
     j->plans[j->n_plans++] = kSafe;
-    if (j->skip_pilot && j->plans[0] == kPilot) j->next_plan = 1;
+    if (j->skip_pilot && j->plans[0] == kPilot) j->next_plan = 1;    // the re-run of a query a sampled threshold failed
     // small batches: the pilot plan's full pass is HBM-bound on the shadow it streams — use the 4-bit one (recall_i4.hip)
     if (screen && t->dim == 128 && j->nq <= kI4MaxQueries && j->plans[0] == kPilot && !kn.no_screen_i4 &&
         rows >= kn.i4_min_rows && (uint64_t)kMaxQueries * rs_cap_bound(j->k) / kI4MaxQueries < 0xFFFFFFFFull) {
@@ -1912,7 +1912,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
 
     // one scan launch over logical blocks [rb, rb+cb) of a stride-`st` view, bracketed by HIP events:
     // their sum is the per-pass duration of the dominant kernel that bench.py prices against HBM
-    int scan_range(uint32_t rb, uint32_t cb, uint32_t st, bool thr_is_open) {
+    int scan_range(uint32_t rb, uint32_t cb, uint32_t st, bool thr_is_open, bool allow_i4 = false) {
         std::vector<hipEvent_t>& pool = *j->events;
         while (pool.size() < 2 * (size_t)(n_ev + 1)) {
             hipEvent_t e;
@@ -1942,13 +1942,19 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             int rc2;
             PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
             // the full pass of a small batch streams the 4-bit shadow; its few suspect lists share the whole buffer
-            const bool i4 = j->screen4 && st == 1 && rb == 0 && cb == j->nblocks;
+            // (whole 64-row groups: a range starts on an even block and ends on one or at the table's end)
+            const bool i4 = j->screen4 && allow_i4 && st == 1 && (rb & 1) == 0 && (((rb + cb) & 1) == 0 || rb + cb == j->nblocks);
             const uint32_t scap = i4 ? rs.cap * (uint32_t)(kMaxQueries / kI4MaxQueries) : rs.cap;
+            const uint64_t r_begin = (uint64_t)rb * kPieceRows;
+            const uint64_t r_end = (uint64_t)(rb + cb) * kPieceRows < j->rows ? (uint64_t)(rb + cb) * kPieceRows : j->rows;
             if (i4) {
-                if ((rc2 = screen4_launch(ctx, t, rs, nq, j->rows, scap))) return rc2;
-            } else if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) {
-                return rc2;
+                if ((rc2 = screen4_launch(ctx, t, rs, nq, (uint32_t)r_begin, (uint32_t)r_end, scap))) return rc2;
+                j->scan_bytes += (r_end - r_begin) * 72;
+            } else {
+                if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) return rc2;
+                j->scan_bytes += (uint64_t)cb * kPieceRows * t->dim * (t->shadow_is_i8 ? 1 : 2);
             }
+            j->scanned_rows += (uint64_t)cb * kPieceRows;
             // exact re-scoring of the launch's suspects → candidate keys (grid.x strides over each list)
             const dim3 rg(i4 ? screen4_rescore_blocks() : kRescoreBlocksPerQuery, nq);
             if (t->dim == 64)
@@ -1981,6 +1987,8 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             a.perm_mod = j->sample_blocks;
             int rc2;
             if ((rc2 = dispatch_scan(ctx, t->dim, a))) return rc2;
+            j->scan_bytes += (uint64_t)cb * kPieceRows * t->dim * 4;
+            j->scanned_rows += (uint64_t)cb * kPieceRows;
         }
         PG_HIP(hipEventRecord(pool[2 * n_ev + 1], ctx->stream));
         ++n_ev;
@@ -2055,8 +2063,8 @@ int recall_job_enqueue(RecallJob* j) {
     PG_HIP(hipGetLastError());
     if (j->screen) {
         if (t->shadow_is_i8)
-            screen_prep8_kernel<<<1, 1024, 0, ctx->stream>>>(rs.qpad, t->dim, t->max_norm, t->resid8, rs.qb16, rs.eps,
-                                                             rs.qscale, j->nq <= 32 ? 1u : (j->nq <= 64 ? 2u : (j->nq <= 128 ? 4u : 8u)));   // = the scan's NQB x QH
+            screen_prep8_kernel<<<j->nq <= 32 ? 1u : (j->nq <= 64 ? 2u : (j->nq <= 128 ? 4u : 8u)), 128, 0, ctx->stream>>>(
+                rs.qpad, t->dim, t->max_norm, t->resid8, rs.qb16, rs.eps, rs.qscale);     // grid = the scan's NQB x QH
         else
             screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
                 rs.qpad, t->dim, rs.qb16, rs.eps);
@@ -2111,14 +2119,14 @@ int recall_job_enqueue(RecallJob* j) {
         const double m2 = (double)j->k * 0.25;
         const uint32_t k2 = (uint32_t)ceil(m2 + kn.pilot_sigmas * sqrt(m2) + 8.0);
         const bool refine = j->screen && !j->screen4 && !kn.no_refine && j->rows >= kn.refine_min_rows && nb_q >= 64 &&
-                            k2 < j->k;
+                            k2 < j->k && t->prefix_failures < 2;
         if (refine) {
-            if ((rc = r.scan_range(0, nb_q, 1, false))) return rc;
+            if ((rc = r.scan_range(0, nb_q, 1, false, true))) return rc;
             if ((rc = r.refine(k2))) return rc;
             PG_HIP(hipMemcpyAsync(rs.thr_ref, rs.thr, sizeof(float) * kMaxQueries, hipMemcpyDeviceToDevice, ctx->stream));
             refined = true;
-            if ((rc = r.scan_range(nb_q, j->nblocks - nb_q, 1, false))) return rc;
-        } else if ((rc = r.scan_range(0, j->nblocks, 1, false))) {
+            if ((rc = r.scan_range(nb_q, j->nblocks - nb_q, 1, false, true))) return rc;
+        } else if ((rc = r.scan_range(0, j->nblocks, 1, false, true))) {
             return rc;
         }
         if ((rc = r.refresh(j->k))) return rc;
@@ -2146,6 +2154,7 @@ int recall_job_enqueue(RecallJob* j) {
     PG_HIP(hipMemcpyAsync(j->h_status, rs.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipMemcpyAsync(j->h_status + 1, j->d_count, 4 * j->nq, hipMemcpyDeviceToHost, ctx->stream));
     j->n_ev = r.n_ev;
+    j->refined = refined;
     j->enqueued_plan = plan;
     j->next_plan++;
     return PG_OK;
@@ -2168,7 +2177,6 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
         fprintf(stderr, "[pg] plan %d last screened launch: suspects of queries 0-3: %u %u %u %u (K = %u)\n", plan, sc[0], sc[1], sc[2], sc[3], j->k);
     }
     j->scan_launches += j->n_ev - 1;
-    j->scanned_rows += plan == kPilot ? (uint64_t)j->rows + (uint64_t)j->sample_blocks * kPieceRows : j->rows;
     bool ok = j->h_status[0] == 0;
     j->failed.clear();
     if (ok && plan == kPilot) {
@@ -2180,6 +2188,9 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
             }
     }
     if (!ok) ctx->stats.recall_rescans++;
+    // a refined threshold that fails verification on most of a batch says the head of the table is not representative
+    // (ordered rows): after two such batches the table's recalls stop refining (a hint, not state anyone relies on)
+    if (!ok && plan == kPilot && j->refined && j->failed.size() > j->nq / 2) const_cast<pg_table*>(j->t)->prefix_failures++;
     *ok_out = ok;
     return PG_OK;
 }
@@ -2191,10 +2202,7 @@ void recall_job_finish(RecallJob* j) {
     ctx->stats.last_recall_ms = j->total_ms;
     ctx->last_scan_ms = j->scan_ms;
     ctx->last_scan_launches = j->scan_launches;
-    // bytes the scan launches streamed: the shadow's element size when the pass was screened
-    ctx->last_scan_bytes = j->scanned_rows * (uint64_t)j->t->dim * (j->screen ? (j->t->shadow_is_i8 ? 1 : 2) : 4);
-    if (j->screen4 && j->enqueued_plan == kPilot)      // the full pass read 64 + 8 B per row instead of 128 (int8) / 256 (bf16)
-        ctx->last_scan_bytes -= (uint64_t)j->rows * ((j->t->shadow_is_i8 ? 128 : 256) - 72);
+    ctx->last_scan_bytes = j->scan_bytes;              // bytes the scan launches streamed (fp32 rows, int8 / bf16 / 4-bit shadow)
 }
 
 int recall_patch_failed_locked(RecallJob* j, uint32_t* counts) {

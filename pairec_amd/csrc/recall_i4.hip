@@ -39,7 +39,7 @@ struct Screen4Args {
     uint32_t* susp_cnt;
     uint32_t* susp;           // [4][cap4]
     uint32_t* overflow;
-    uint32_t cap4, rows;
+    uint32_t cap4, rows, row_begin;     // rows [row_begin, rows), row_begin a multiple of 64
 };
 
 template <int NQ>
@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
         cnt[qi] = 0;
     };
     const uint32_t wave = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
-    const uint32_t ngroups = (a.rows + 63) / 64;       // 64 rows (4 KiB of shadow) per wave step, 4 loads in flight
+    const uint32_t ngroups = (a.rows - a.row_begin + 63) / 64;   // 64 rows (4 KiB of shadow) per wave step, 4 loads in flight
     for (uint32_t g = wave; g < ngroups; g += nwaves) {
-        const uint32_t row0 = g * 64 + (lane >> 2);
+        const uint32_t row0 = a.row_begin + g * 64 + (lane >> 2);
         u32x4 v[4];
         f32x2 s[4];
 #pragma unroll
@@ -301,7 +301,8 @@ int screen4_prep_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs)
 
 uint32_t screen4_rescore_blocks() { return kRescore4Blocks; }
 
-int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t rows, uint32_t cap4) {
+int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t row_begin, uint32_t rows,
+                   uint32_t cap4) {
     Screen4Args a;
     a.d4 = reinterpret_cast<const u32x4*>(t->d4);
     a.d4s = t->d4s;
@@ -312,6 +313,7 @@ int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint
     a.overflow = rs.overflow;
     a.cap4 = cap4;
     a.rows = rows;
+    a.row_begin = row_begin;
     a.h_cap = (t->max_norm + t->rmax4) * 1.000001f;
     // a persistent grid of exactly the resident workgroups (the group walk is interleaved over all waves, so waves
     // that started late would leave a tail); 4 KiB of loads in flight per wave
@@ -324,7 +326,7 @@ int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint
         PG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, f, 256, 0));
         per_cu[n] = b < 1 ? 1 : (b > 8 ? 8 : b);
     }
-    const uint32_t groups = (rows + 63) / 64;
+    const uint32_t groups = (rows - row_begin + 63) / 64;
     uint32_t grid = (uint32_t)ctx->num_cus * (uint32_t)per_cu[n];
     if (grid > (groups + 3) / 4) grid = (groups + 3) / 4;
     switch (n) {

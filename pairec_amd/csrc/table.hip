@@ -217,6 +217,7 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->rho4, b->rho4);
     std::swap(a->rmax4, b->rmax4);
     std::swap(a->lam4, b->lam4);
+    std::swap(a->prefix_failures, b->prefix_failures);
     return PG_OK;
 }
 
