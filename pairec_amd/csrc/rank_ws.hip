@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i32 = lane & 31, h = lane >> 5;
+    const int h = lane >> 5;
     char* const w2l = smem + kWsRegion + kWsW1L + wave * 2048;
     const uint32_t n_tiles = *a.n_tiles;
     const uint32_t t_begin = (uint32_t)(((uint64_t)n_tiles * blockIdx.x) / gridDim.x);
