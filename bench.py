@@ -412,6 +412,9 @@ def cfg4_leg(pa, o, ctx, R, K):
         "roofline": {"bound": "hbm", "kernel": "pg::mlp_kernel<1,256,64,false,...> (FM + item tower)",
                      "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                      "bytes_per_item": FM2T_BYTES_PER_ITEM, "traffic": None,
+                     # the memory side moves one 128-B line per 64-B embedding row (scripts/micro/gather_gran.hip):
+                     "hbm_bytes_per_item_moved": 8 * 4 + 8 * 128,
+                     "frac_on_bytes_moved": n * (8 * 4 + 8 * 128) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "mfma_achieved_tflops": tf, "mfma_frac": tf / MFMA_BF16_PEAK_TFLOPS},
     }
 
