@@ -700,11 +700,11 @@ def test_sort_register_network_segments_up_to_8192(ctx):
 
 
 def test_sort_few_segments_rank_by_counting(ctx):
-    """Up to 8 segments of <= 8192 items take the counting kernel (64 items per workgroup, spread over the chip — the
+    """Up to 8 segments of <= 16384 items take the counting kernel (64 items per workgroup, spread over the chip — the
     single-request path): same order as the network — ties by index, NaN last, -0 == +0, an all-equal segment, the
     chunk boundaries of the four-way split."""
     rng = np.random.default_rng(19)
-    for sizes in ([8192, 0, 1, 5000, 513, 63, 4097, 2], [5000], [7], [8191, 8185]):
+    for sizes in ([8192, 0, 1, 5000, 513, 63, 4097, 2], [5000], [7], [8191, 8185], [16384, 9000, 8193], [12345]):
         segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
         s = rng.random(int(segs[-1]))
         s[::7] = np.round(s[::7], 1)
