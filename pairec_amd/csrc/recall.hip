@@ -1816,7 +1816,10 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
 //          negligible probability), then ONE full-rate pass over the whole table collects every row
 //          at or above it.  Verified exactly: if a query ends with fewer than min(K, rows)
 //          candidates the sample lied and the next plan runs.  ~1.5 K candidates per query instead
-//          of K ln(rows/32768) for the growing-chunk plan.
+//          of K ln(rows/32768) for the growing-chunk plan.  On big tables the pass is split after its first
+//          quarter and the thresholds are raised to the k2-th best candidate found so far (a 16x larger sample:
+//          ~1.2 K candidates per query for the rest); the raised threshold is verified against the K-th best
+//          score that comes out.  Batches of <= 4 queries stream the 4-bit shadow instead (recall_i4.hip).
 //  grow  — geometric chunks, threshold refreshed after each (small tables, and the fallback).
 //  safe  — bounded chunks that cannot overflow (adversarially ordered tables).
 // A plan is ENQUEUED as a whole (no host synchronisation inside it) and VERIFIED afterwards from a few status
