@@ -25,6 +25,7 @@ static void knobs_from_env(Knobs* k) {
     k->i4_max_lambda = num("PG_I4_MAX_LAMBDA", 1.7);
     k->i4_min_rows = (uint32_t)num("PG_I4_MIN_ROWS", (double)(1u << 22));
     k->rank_no_ws = flag("PG_RANK_NO_WS");
+    k->rank_sort_max = (uint32_t)num("PG_RANK_SORT_MAX", 8);
     k->sort_lds = flag("PG_SORT_LDS");
 }
 
@@ -138,6 +139,7 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "i4_max_lambda") k.i4_max_lambda = v;
     else if (n == "i4_min_rows") k.i4_min_rows = (uint32_t)v;
     else if (n == "rank_no_ws") k.rank_no_ws = b;
+    else if (n == "rank_sort_max") k.rank_sort_max = (uint32_t)v;
     else if (n == "sort_lds") k.sort_lds = b;
     else {
         pg::set_error("pg_set_option: unknown option \"%s\"", name);

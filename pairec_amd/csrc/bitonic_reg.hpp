@@ -15,7 +15,7 @@ namespace pg {
 constexpr int kBitonicE = 8;
 constexpr uint32_t kBitonicMax = 8192;
 constexpr uint32_t kRankSortMaxItems = 16384;     // ... of up to this many items each (the list's keys sit in LDS: 128 KB)
-constexpr uint32_t kRankSortMaxSegments = 8;    // up to this many lists per call: ranks by counting, spread over the chip (final_rank_kernel, sort_rank_kernel)
+constexpr uint32_t kRankSortMaxSegments = 8;      // (default of Knobs::rank_sort_max)    // up to this many lists per call: ranks by counting, spread over the chip (final_rank_kernel, sort_rank_kernel)
 
 // value of lane (l ^ M) — M a compile-time power of two below 64
 template <int M>

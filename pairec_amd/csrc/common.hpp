@@ -69,6 +69,7 @@ struct Knobs {
     uint32_t i4_min_rows = 1u << 22; // PG_I4_MIN_ROWS: smallest table the 4-bit screen is built for
     double i4_max_lambda = 1.7;    // PG_I4_MAX_LAMBDA: largest pg_table::lam4 the 4-bit screen is used for
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
+    uint32_t rank_sort_max = 8;    // PG_RANK_SORT_MAX: up to this many lists per call are sorted by counting ranks (0 = never)
     bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
 };
 

@@ -1621,7 +1621,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
 int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap,
                         uint32_t nq, uint32_t k, uint64_t row_offset, uint64_t* d_out_rows,
                         float* d_out_scores, uint32_t* d_out_count) {
-    if (k <= kRankSortMaxItems && nq <= kRankSortMaxSegments && !ctx->knobs.sort_lds) {
+    if (k <= kRankSortMaxItems && nq <= ctx->knobs.rank_sort_max && !ctx->knobs.sort_lds) {
         const size_t lds = (size_t)((k + 31u) & ~31u) * 8;
         int rc_attr;
         if (nq <= 2) {

@@ -197,7 +197,7 @@ int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, 
         g_keys = (uint64_t*)p;
         g_idx = (uint32_t*)(g_keys + (size_t)n_seg * stride);
     }
-    if (max_seg <= kRankSortMaxItems && n_seg <= kRankSortMaxSegments && !ctx->knobs.sort_lds) {
+    if (max_seg <= kRankSortMaxItems && n_seg <= ctx->knobs.rank_sort_max && !ctx->knobs.sort_lds) {
         const size_t rl = (size_t)((max_seg + 31u) & ~31u) * 8;
         if (n_seg <= 2) {
             if ((rc_attr = ensure_dyn_lds(ctx, (const void*)sort_rank_kernel<16>, rl))) return rc_attr;
