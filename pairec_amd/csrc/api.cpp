@@ -70,7 +70,7 @@ int scratch_reserve(pg_ctx* ctx, int slot, size_t bytes, void** out) {
 extern "C" {
 
 const char* pg_last_error(void) { return pg::g_err.c_str(); }
-const char* pg_version(void) { return "pairec_gpu 0.1 (gfx950)"; }
+const char* pg_version(void) { return "pairec_gpu 0.2 (gfx950)"; }
 
 int pg_init(int device, void* stream, pg_ctx** out) {
     PG_REQUIRE(out != nullptr, "pg_init: out is NULL");
