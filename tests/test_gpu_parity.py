@@ -481,6 +481,36 @@ def test_recall_threshold_refinement_any_row_order(ctx):
         ctx.set_option("pilot_fraction", "0")
 
 
+def test_recall_refinement_gives_up_on_a_table_with_an_unrepresentative_head(ctx):
+    """Rows of three times the norm in the first fifth of the table: for every query the head holds all of the best
+    rows, the threshold raised after the first quarter is far above the true K-th score, the verification rejects every
+    query and the batch is answered by the next plan — exactly.  After two such batches the table's recalls stop
+    refining (pg_table::prefix_failures): the third recall needs no re-run."""
+    rng = np.random.default_rng(43)
+    n, d, k, nq = 400_000, 128, 300, 24
+    tab = rng.standard_normal((n, d)).astype(np.float32)
+    tab[: n // 5] *= np.float32(3.0)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    for name, v in (("refine_min_rows", "0"), ("pilot_fraction", "0.125")):
+        ctx.set_option(name, v)
+    try:
+        t = pa.Table(ctx, n, d)
+        t.upload(tab)
+        orow, osc = o.recall_topk(tab, q, k)
+        rescans = []
+        for _ in range(4):
+            before = ctx.stats().recall_rescans
+            rows, scores, _ = t.recall_topk(q, k)
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+            rescans.append(ctx.stats().recall_rescans - before)
+        assert rescans[0] >= 1 and rescans[1] >= 1, rescans        # the raised threshold was rejected ...
+        assert rescans[2] == 0 and rescans[3] == 0, rescans        # ... and the table stopped being refined
+        t.destroy()
+    finally:
+        ctx.set_option("refine_min_rows", str(1 << 24))
+        ctx.set_option("pilot_fraction", "0")
+
+
 def test_recall_all_ties_falls_through_every_plan(ctx):
     """A table of identical rows: every row ties with any threshold, so the pilot pass and the growing
     chunks both overflow and the bounded-chunk plan answers; ties resolve to the lowest rows
