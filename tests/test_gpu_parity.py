@@ -301,6 +301,19 @@ def test_recall_small_batch_4bit_screen_is_exact(ctx):
         check(other, scaled, qs[8:10], expect_i4=True)
         t.destroy()
         other.destroy()
+        # a ragged end (rows not a multiple of the 64-row groups / 32-row blocks), winners in the last rows
+        n3 = 300_011
+        tab4 = rng.standard_normal((n3, d)).astype(np.float32) * 0.05
+        tab4[-5:] *= 6.0
+        r3 = pa.Table(ctx, n3, d)
+        r3.upload(tab4)
+        for lo, hi in ((8, 9), (8, 12)):
+            rows, scores, _ = r3.recall_topk(qs[lo:hi], k)
+            orow, osc = o.recall_topk(tab4, qs[lo:hi], k)
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+            if hi - lo <= 2:         # (four Gaussian queries are above the default lambda limit: wide shadow)
+                assert ctx.last_scan_kernel()[1] < n3 * 128
+        r3.destroy()
     finally:
         ctx.set_option("i4_min_rows", str(1 << 22))
         ctx.set_option("pilot_fraction", "0")
