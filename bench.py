@@ -242,6 +242,9 @@ def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs, scan_b
         "bound": "mfma" if (max(mfma_frac, busy) > hbm_frac and not four_bit) else "hbm",
         "kernel": ("pg::screen4_kernel<%d>" % R) if four_bit else scan_kernel_name(R, args.dim, elem_bytes),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+        "frac_basis": "achieved / peak / unit / frac price the bytes the pass streams against HBM whatever `bound` says (the "
+                      "series is comparable across rounds); the matrix-pipe side of the same pass is mfma_achieved / mfma_peak "
+                      "/ mfma_frac (algorithmic int8 ops on the nominal dense peak) and traffic_from_profile.mfma_busy_frac",
         "frac_survey_8d": fp32_bytes / t / 1e9 / HBM_PEAK_GBS,
         "traffic": None, "traffic_from_profile": prof,
         "measured_peak": measured_gbs, "frac_of_measured": achieved / measured_gbs if measured_gbs else None,
