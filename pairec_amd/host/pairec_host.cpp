@@ -220,6 +220,7 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         c.ItemType = r.s("ItemType"); c.CachePrefix = r.s("CachePrefix");
         c.CacheAdapter = r.s("CacheAdapter"); c.CacheConfig = r.s("CacheConfig");
         c.RecallCount = (int)r.n("RecallCount"); c.CacheTime = (int)r.n("CacheTime");
+        c.RankScore = r.s("RankScore"); c.RankVar = r.s("RankVar");
         out->GpuRecalls.push_back(c);
     }
     for (const auto& sc : out->UserDefineConfs.at("pairec_gpu").at("Sorts").arr) out->GpuSorts.push_back(parse_sort(sc));
@@ -717,6 +718,42 @@ struct GpuI2IVectorRecall : recall::Recall {
     }
 };
 
+// recall.Recall that returns the FINISHED page: recall → DNN rank → RankScore → ItemRankScore sort all happen where the
+// rows live, one single-request call into the library's coalescer (pg_coalescer_recommend), and only ctx.Size items are
+// materialised on the host.  A scene served this way names it as its only recall and leaves RankConf / SortNames empty
+// (the default ItemRankScore sort keeps the order: Score is the fused score).  The reference has no such plug-in — it
+// is what its Recall interface permits (recall.go:18-20) once the stages behind it are local.
+struct GpuPageRecall : recall::Recall {
+    Engine* e;
+    recconf::RecallConfig conf;
+    GpuPageRecall(Engine* eng, recconf::RecallConfig c) : e(eng), conf(std::move(c)) {}
+    std::vector<module::ItemPtr> GetCandidateItems(module::User* user, context::RecommendContext* ctx) override {
+        std::vector<module::ItemPtr> ret;
+        std::string value, err;
+        if (!e->user_vectors.VectorString(user->Id, &value, &err)) return ret;          // logged, empty result
+        const std::vector<float> vec = recall::ParseVectorString(value);
+        if (vec.empty()) return ret;
+        pg_coalescer* co = e->PageCoalescer(conf, &err);
+        if (!co) return ret;                                                            // logged, empty result
+        const uint32_t size = (uint32_t)std::max(1, std::min(ctx ? ctx->Size : 10, std::min(conf.RecallCount, 1000)));
+        std::vector<uint64_t> rows(size);
+        std::vector<float> rec(size), rnk(size);
+        std::vector<double> fused(size);
+        uint32_t cnt = 0;
+        if (pg_coalescer_recommend(co, vec.data(), size, rows.data(), rec.data(), rnk.data(), fused.data(), &cnt) != PG_OK) return ret;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            auto item = std::make_shared<module::Item>(e->IdOfRow(rows[i]));
+            item->RetrieveId = conf.Name;
+            item->ItemType = conf.ItemType;
+            item->Score = fused[i];
+            item->AddProperty("recall_score", json::Value::Num((double)rec[i]));                        // what ${current_score} leaves behind
+            item->AddAlgoScore(conf.RankVar, (double)rnk[i]);
+            ret.push_back(item);
+        }
+        return ret;
+    }
+};
+
 // recall.Recall with the body of OnlineVectorRecall.GetCandidateItems (online_vector_recall.go:73-155, cache omitted):
 // user features → PBRequest{FaissNeighNum = recallCount} → algorithm.Run(recallAlgo) → embedding items → Items
 struct GpuOnlineVectorRecall : recall::Recall {
@@ -1061,6 +1098,10 @@ bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, co
 // ---- engine --------------------------------------------------------------------------------------
 Engine::~Engine() {
     if (ctx) {
+        for (auto& kv : co_page) {
+            pg_coalescer_destroy(kv.second.first);
+            pg_expr_free(kv.second.second);
+        }
         for (auto& kv : co_recall) pg_coalescer_destroy(kv.second);
         if (co_rank) pg_coalescer_destroy(co_rank);
         if (model) pg_model_destroy(ctx, model);
@@ -1088,6 +1129,35 @@ pg_coalescer* Engine::RecallCoalescer(uint32_t k, std::string* err) {
         return nullptr;
     }
     co_recall[k] = c;
+    return c;
+}
+
+pg_coalescer* Engine::PageCoalescer(const recconf::RecallConfig& conf, std::string* err) {
+    std::lock_guard<std::mutex> g(co_mu);
+    auto it = co_page.find(conf.Name);
+    if (it != co_page.end()) return it->second.first;
+    if (!model) {
+        if (err) *err = "page recall: no rank model loaded";
+        return nullptr;
+    }
+    pg_expr* ex = nullptr;
+    if (pg_expr_compile(conf.RankScore.c_str(), &ex) != PG_OK) {
+        if (err) *err = std::string("pg_expr_compile: ") + pg_last_error();
+        return nullptr;
+    }
+    pg_coalescer_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.k = (uint32_t)conf.RecallCount;
+    cfg.max_wait_us = coalesce_wait_us;
+    cfg.depth = coalesce_depth;
+    cfg.max_top_n = (uint32_t)std::min(conf.RecallCount, 1000);
+    pg_coalescer* c = nullptr;
+    if (pg_coalescer_create(ctx, table, model, ex, conf.RankVar.c_str(), &cfg, &c) != PG_OK) {
+        if (err) *err = std::string("pg_coalescer_create: ") + pg_last_error();
+        pg_expr_free(ex);
+        return nullptr;
+    }
+    co_page[conf.Name] = std::make_pair(c, ex);
     return c;
 }
 
@@ -1211,6 +1281,13 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
     for (const auto& r : e->config.GpuRecalls) {
         if (r.Kind == "vector") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuVectorRecall>(e.get(), r));
         else if (r.Kind == "i2i") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuI2IVectorRecall>(e.get(), r));
+        else if (r.Kind == "page") {
+            if (r.RankScore.empty() || r.RankVar.empty() || r.RecallCount <= 0) {
+                if (err) *err = "pairec_gpu.Recalls: Kind \"page\" needs RecallCount, RankScore and RankVar";
+                return nullptr;
+            }
+            e->recalls.RegisterRecall(r.Name, std::make_shared<GpuPageRecall>(e.get(), r));
+        }
         else { if (err) *err = "pairec_gpu.Recalls: unknown Kind " + r.Kind; return nullptr; }
     }
     return e.release();

@@ -94,7 +94,8 @@ struct RecallConfig {
     int RecallCount = 0, CacheTime = 0;
     // what the reference's constructors look at before they touch a datasource (recconf.go:330-367)
     std::string DaoAdapterType, VectorDaoAdapterType, HologresName, VectorAlgoType;
-    std::string Kind;                       // pairec_gpu.Recalls only: "vector" (default), "i2i", "online_vector"
+    std::string Kind;                       // pairec_gpu.Recalls only: "vector" (default), "i2i", "page"
+    std::string RankScore, RankVar;         // Kind "page": the RankScore expression and the name the model's score has in it
 };
 struct RankConfig {
     std::vector<std::string> RankAlgoList;
@@ -346,8 +347,10 @@ public:
     std::mutex co_mu;
     std::map<uint32_t, pg_coalescer*> co_recall;        // by k (RecallCount)
     pg_coalescer* co_rank = nullptr;
+    std::map<std::string, std::pair<pg_coalescer*, pg_expr*>> co_page;   // page recalls: name → (coalescer, compiled RankScore)
     pg_coalescer* RecallCoalescer(uint32_t k, std::string* err);
     pg_coalescer* RankCoalescer(std::string* err);
+    pg_coalescer* PageCoalescer(const recconf::RecallConfig& conf, std::string* err);
     uint64_t table_rows = 0;
     uint32_t dim = 0;
     std::string id_prefix = "item_";          // row ↔ id dictionary: "<prefix><row>"

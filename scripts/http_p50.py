@@ -1,5 +1,7 @@
 """End-to-end p50 / p99 of POST /api/recommend over the GPU engine (tools/http_harness.py) at the benchmark
-shape: 100 M x 128 table, recall 5 000, DNN3 rank of all 5 000, ItemRankScore sort, page of 100."""
+shape: 100 M x 128 table, recall 5 000, DNN3 rank of all 5 000, ItemRankScore sort, page of 100.
+Two scenes over the same engine: "home_feed" runs the stages one plug-in at a time (5 000 Items on the host per
+request, as pairec does), "home_feed_page" has ONE recall of Kind "page" that returns the finished page."""
 import json
 import os
 import sys
@@ -19,7 +21,8 @@ from oracle import oracle as o    # noqa: E402
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 cfg = {
     "RecallConfs": [],
-    "SceneConfs": {"home_feed": {"default": {"RecallNames": ["gpu_vector_recall"]}}},
+    "SceneConfs": {"home_feed": {"default": {"RecallNames": ["gpu_vector_recall"]}},
+                   "home_feed_page": {"default": {"RecallNames": ["gpu_page"]}}},
     "RankConf": {"home_feed": {"RankAlgoList": ["gpu_dnn"], "RankScore": "${gpu_dnn}*(1+${current_score})^0.1",
                                "BatchCount": 5000}},
     "SortNames": {"home_feed": ["ItemRankScore"]},
@@ -27,7 +30,9 @@ cfg = {
                                        "Table": {"Rows": rows, "Dim": 128, "IdPrefix": "item_",
                                                  "SyntheticSeed": o.SEED_TABLE},
                                        "Recalls": [{"Name": "gpu_vector_recall", "Kind": "vector", "RecallCount": 5000,
-                                                    "RecallAlgo": "gpu_faiss", "ItemType": "video"}],
+                                                    "RecallAlgo": "gpu_faiss", "ItemType": "video"},
+                                                   {"Name": "gpu_page", "Kind": "page", "RecallCount": 5000, "ItemType": "video",
+                                                    "RankScore": "${gpu_dnn}*(1+${current_score})^0.1", "RankVar": "gpu_dnn"}],
                                        "Algorithms": [{"Name": "gpu_faiss", "Kind": "faiss"},
                                                       {"Name": "gpu_dnn", "Kind": "dnn3"}]}},
 }
@@ -49,14 +54,21 @@ def post(obj):
         return json.loads(r.read())
 
 
-lat = []
-for i in range(220):
-    t0 = time.perf_counter()
-    r = post({"uid": "u%d" % (i % 200), "size": 100, "scene_id": "home_feed"})
-    lat.append((time.perf_counter() - t0) * 1e3)
-    assert r["code"] == 200 and r["size"] == 100, r.get("msg")
-lat = lat[20:]
-print(json.dumps({"rows": rows, "requests": len(lat), "p50_ms": float(np.median(lat)),
-                  "p99_ms": float(np.percentile(lat, 99)), "min_ms": float(min(lat))}))
+out = {"rows": rows}
+pages = {}
+for scene in ("home_feed", "home_feed_page"):
+    lat = []
+    for i in range(220):
+        t0 = time.perf_counter()
+        r = post({"uid": "u%d" % (i % 200), "size": 100, "scene_id": scene})
+        lat.append((time.perf_counter() - t0) * 1e3)
+        assert r["code"] == 200 and r["size"] == 100, r.get("msg")
+        if i == 0:
+            pages[scene] = [x["item_id"] for x in r["items"]]
+    lat = lat[20:]
+    out[scene] = {"requests": len(lat), "p50_ms": float(np.median(lat)), "p99_ms": float(np.percentile(lat, 99)),
+                  "min_ms": float(min(lat))}
+out["same_page"] = pages["home_feed"] == pages["home_feed_page"]
+print(json.dumps(out))
 srv.shutdown()
 h.close()

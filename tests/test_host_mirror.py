@@ -414,6 +414,35 @@ def test_multi_output_algorithm_writes_algo_output_scores(H):
 
 
 @pytest.mark.gpu
+def test_page_recall_returns_the_staged_scenes_page(H):
+    """pairec_gpu.Recalls Kind "page": one recall plug-in that returns the finished page (recall → DNN rank → RankScore →
+    ItemRankScore sort on the device, one coalesced single-request call) — the same ids, order and scores as the scene
+    that runs the stages one plug-in at a time, with only ctx.Size items materialised on the host."""
+    import copy
+    staged, _, user = _engine(H, CONFIG)
+    want = json.loads(H.ph_recommend(staged, b"u1", 25, b"home_feed"))["items"]
+    H.ph_engine_destroy(staged)
+    cfg = copy.deepcopy(CONFIG)
+    cfg["SceneConfs"] = {"home_feed": {"default": {"RecallNames": ["gpu_page"]}}}
+    cfg["RankConf"] = {}
+    cfg["SortNames"] = {}
+    cfg["UserDefineConfs"]["pairec_gpu"]["Recalls"] = [{"Name": "gpu_page", "Kind": "page", "RecallCount": 300,
+                                                       "ItemType": "video", "RankScore": RANK_SCORE, "RankVar": "gpu_dnn"}]
+    h, _, _ = _engine(H, cfg)
+    got = json.loads(H.ph_recommend(h, b"u1", 25, b"home_feed"))["items"]
+    assert [x["item_id"] for x in got] == [x["item_id"] for x in want]
+    for a, b in zip(got, want):
+        assert abs(a["score"] - b["score"]) <= 1e-12 * max(1.0, abs(b["score"]))
+        assert abs(a["algo_scores"]["gpu_dnn"] - b["algo_scores"]["gpu_dnn"]) <= 1e-7
+        assert a["retrieve_id"] == "gpu_page"
+    # a page recall without its expression is refused when the engine is created
+    bad = copy.deepcopy(cfg)
+    del bad["UserDefineConfs"]["pairec_gpu"]["Recalls"][0]["RankScore"]
+    assert not H.ph_engine_create(json.dumps(bad).encode()) and b"RankScore" in H.ph_last_error()
+    H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
 def test_i2i_online_vector_recalls_and_algo_score_sort(H):
     """a5 / a6 through the registries: the GPU I2I recall (trigger = the request's item_id), the reference's own
     OnlineVectorRecall declared in RecallConfs (its constructor needs no datasource) served by a GPU vector model,
