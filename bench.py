@@ -478,11 +478,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        stream = torch.cuda.current_stream().cuda_stream
 
     shard = world > 1 and args.mode == "shard"
-    ctx = pa.Context(local_rank, stream if shard else None)
-    from pairec_amd.dist import shard_range, sharded_step, GpuShardEngine
+    from pairec_amd.dist import shard_range, sharded_step, shard_context, GpuShardEngine
+    if shard:
+        # one dedicated torch stream shared by the library's kernels and the step's torch ops / RCCL collectives
+        ctx, tstream = shard_context(torch, pa, local_rank)
+    else:
+        ctx = pa.Context(local_rank, None)
     if shard:
         begin, end = shard_range(args.rows * world, world, rank)       # N x rows table, one range per rank
     else:
@@ -531,6 +534,7 @@ def main():
         eng = GpuShardEngine(torch, ctx, table, model, expr, K, R)
         dev = torch.device("cuda", local_rank)
         t_qs = [torch.from_numpy(q).to(dev) for q in qs]
+        torch.cuda.synchronize()                      # the uploads ran on torch's default stream
 
         def sync():
             dist.barrier()

@@ -39,7 +39,9 @@ typedef enum {
     PG_ERR_NOMEM = -3,
     PG_ERR_UNSUPPORTED = -4, /* shape outside what the kernels are built for */
     PG_ERR_ARITH = -5,       /* expression: division by zero / modulo by zero (reference panics) */
-    PG_ERR_PARSE = -6        /* expression: lexer "symbol error" (utils/ast/parse.go:125-133) */
+    PG_ERR_PARSE = -6,       /* expression: lexer "symbol error" (utils/ast/parse.go:125-133) */
+    PG_ERR_TIMEOUT = -7      /* the call's deadline passed (algorithm/eas/client.go:53-58: 100 ms default per predict); the
+                                work it belonged to still completes for the other callers of its batch */
 } pg_status;
 
 typedef enum { PG_PREC_F32 = 0, PG_PREC_BF16 = 1 } pg_prec;
@@ -49,8 +51,10 @@ const char* pg_last_error(void);
 const char* pg_version(void);
 
 /* ---- context --------------------------------------------------------------------------------
- * One context = one GPU + one HIP stream.  `stream` may be an existing hipStream_t (e.g. the
- * stream torch.distributed's collectives are ordered on) or NULL to create a private one. */
+ * One context = one GPU + one HIP stream.  `stream` may be an existing hipStream_t (e.g. a dedicated stream
+ * torch.distributed's collectives are ordered on) or NULL to create a private one.  The null stream (handle 0,
+ * torch's default stream) cannot be adopted — NULL always means "private": a host that mixes its own device work
+ * with library calls creates a stream of its own and passes it here (pairec_amd/dist.py shard_context). */
 int pg_init(int device, void* stream, pg_ctx** out);
 int pg_shutdown(pg_ctx* ctx);
 int pg_synchronize(pg_ctx* ctx);
@@ -391,35 +395,109 @@ typedef struct {
     uint32_t max_wait_us;     /* how long a request may wait for company while the device is idle; 0 = 100         */
     uint32_t depth;           /* batches in flight, 1..4; 0 = 2                                                    */
     uint32_t max_top_n;       /* pg_coalescer_recommend: largest page a caller may ask for, <= k; 0 = k            */
-    uint32_t max_rank_items;  /* pg_coalescer_rank_dnn3: most candidates in one call (BatchCount); 0 = k           */
+    uint32_t max_rank_items;  /* pg_coalescer_rank*: most candidates in one call (BatchCount); 0 = k               */
+    uint32_t timeout_us;      /* deadline of every call, from its arrival (eas/client.go:53-58, 100 ms there);
+                                 0 = none.  A caller whose deadline passes returns PG_ERR_TIMEOUT; its batch still
+                                 completes for the other callers, and later calls are served as usual             */
 } pg_coalescer_config;
 /* model / expr / rank_var may be NULL: then only pg_coalescer_recall (and pg_coalescer_rank_dnn3 with a model) work. */
 int pg_coalescer_create(pg_ctx* ctx, const pg_table* t, const pg_model* m, const pg_expr* e, const char* rank_var,
                         const pg_coalescer_config* cfg, pg_coalescer** out);
+
+/* A scene's whole plug-in set behind one coalescer — what recconf names per scene (RecallConfs, RankConf.RankAlgoList +
+ * RankScore, SortNames; recconf/recconf.go:54-57,736-745), so that EVERY per-request plug-in call of the reference has a
+ * coalesced single-request entry point below:
+ *   algos[]            RankAlgoList: up to 4 rank algorithms, each scoring every candidate (rank_service.go:259-289) —
+ *                      PG_MODEL_DNN3 over the table's rows, or PG_MODEL_FM_TWOTOWER whose item field ids are the integer
+ *                      columns item_field_cols[n_item_fields] of `features` (keyed by the same rows); `name` is the
+ *                      algorithm's name = its variable in RankScore (rank_service.go:312-335)
+ *   rank_score         RankConf.RankScore over the algorithms' names and current_score (needed by pg_coalescer_recommend*)
+ *   rerank             1: DPPSort behind the ItemRankScore sort (SortNames: [ItemRankScore, DPPSort]): the first
+ *                      rerank_candidates = max(ctx.Size, CandidateCount) entries of every sorted list are the DPP
+ *                      candidates (sort/dpp_sort.go:280-291), `dpp` carries alpha / window / normalize_emb /
+ *                      norm_relevance_score, the page is DPPWithWindow's pick sequence; max_top_n <= rerank_candidates
+ *   query_model        OnlineVectorRecall: a PG_MODEL_FM_TWOTOWER whose user tower turns a request's user features into
+ *                      the query (pg_coalescer_online_recall); the table is then the item-embedding table (dim = t_out)
+ *   trigger_table      I2IVectorRecall: where trigger rows are looked up (NULL = the table itself)
+ *   max_rerank_items   pg_coalescer_dpp: most candidates in one call (0 = 1024); max_hook_dim: widest hook embedding (0 = none) */
+typedef struct {
+    const pg_model* model;
+    const char* name;
+    const pg_features* features;
+    const int32_t* item_field_cols;
+} pg_rank_algo;
+typedef struct {
+    pg_coalescer_config base;
+    const pg_rank_algo* algos;
+    uint32_t n_algos;
+    const pg_expr* rank_score;
+    int rerank;
+    uint32_t rerank_candidates;
+    pg_dpp_options dpp;
+    const pg_model* query_model;
+    const pg_table* trigger_table;
+    uint32_t max_rerank_items;
+    uint32_t max_hook_dim;
+} pg_scene_config;
+int pg_coalescer_create_scene(pg_ctx* ctx, const pg_table* t, const pg_scene_config* cfg, pg_coalescer** out);
 /* fails every waiting request with PG_ERR_INVALID, joins the worker threads, frees the buffers */
 int pg_coalescer_destroy(pg_coalescer* c);
 /* VectorRecall.GetCandidateItems → IAlgorithm.Run(VectorRequest{K, Vector}) for ONE user vector [dim]:
  * out_rows[k], out_scores[k] as pg_recall_topk, *out_count (optional) = valid entries. */
 int pg_coalescer_recall(pg_coalescer* c, const float* query, uint64_t* out_rows, float* out_scores,
                         uint32_t* out_count);
-/* IAlgorithm.Run of the rank model for ONE batch of n <= max_rank_items candidates of one user
- * (rank_service.go:273): cand_rows are local row indices of the table, out_scores[n] in request order. */
+/* I2IVectorRecall.GetCandidateItems for ONE trigger item (pg_i2i_recall with n = 1): the query is row `trigger_row` of
+ * the scene's trigger table; rides the same table pass as the vector recalls of other callers. */
+int pg_coalescer_i2i_recall(pg_coalescer* c, uint32_t trigger_row, uint64_t* out_rows, float* out_scores,
+                            uint32_t* out_count);
+/* OnlineVectorRecall.GetCandidateItems for ONE user (pg_online_vector_recall with n_req = 1): user_vec[d_user] goes
+ * through the scene's query_model user tower on the device, the embedding is the query. */
+int pg_coalescer_online_recall(pg_coalescer* c, const float* user_vec, uint64_t* out_rows, float* out_scores,
+                               uint32_t* out_count);
+/* IAlgorithm.Run of rank algorithm `algo` (index into the scene's list) for ONE batch of n <= max_rank_items
+ * candidates of one user (rank_service.go:273): cand_rows are local row indices, out_scores[n] in request order.
+ * user_vec is [d_user] of that model; user_field_ids [n_user_fields] for an FM + two-tower model, else NULL.
+ * Calls for one algorithm from any number of threads and requests become one launch. */
+int pg_coalescer_rank(pg_coalescer* c, uint32_t algo, const float* user_vec, const int32_t* user_field_ids,
+                      const uint32_t* cand_rows, uint32_t n, float* out_scores);
+/* the same for the first DNN3 / the first FM + two-tower algorithm of the scene */
 int pg_coalescer_rank_dnn3(pg_coalescer* c, const float* user_vec, const uint32_t* cand_rows, uint32_t n,
                            float* out_scores);
-/* The whole path for ONE request (what pg_recommend_dnn3_dev does for a batch): recall top-k → DNN3 rank → RankScore
- * → descending sort; the caller receives the first top_n <= max_top_n entries of the sorted list — global row ids,
- * recall scores, model scores and fused scores, all [top_n] — and *out_count (optional) = entries that are items
- * (min(top_n, rows of the table)). */
+int pg_coalescer_rank_fm2t(pg_coalescer* c, const float* user_vec, const int32_t* user_field_ids,
+                           const uint32_t* cand_rows, uint32_t n, float* out_scores);
+/* The whole path for ONE request (what pg_recommend_dnn3_dev does for a batch): recall top-k → every rank algorithm →
+ * RankScore → descending sort → (DPPSort when the scene has the stage); the caller receives the page of top_n <=
+ * max_top_n entries — the head of the sorted list, or DPP's picks in pick order — as global row ids, recall scores,
+ * model scores and fused scores, all [top_n], and *out_count (optional) = entries that are items.
+ * pg_coalescer_recommend reports the first algorithm's scores; _ex takes the FM models' user field ids and reports
+ * every algorithm's scores, out_rank_scores [n_algos][top_n]. */
 int pg_coalescer_recommend(pg_coalescer* c, const float* user_vec, uint32_t top_n, uint64_t* out_rows,
                            float* out_recall_scores, float* out_rank_scores, double* out_fused,
                            uint32_t* out_count);
+int pg_coalescer_recommend_ex(pg_coalescer* c, const float* user_vec, const int32_t* user_field_ids, uint32_t top_n,
+                              uint64_t* out_rows, float* out_recall_scores, float* out_rank_scores, double* out_fused,
+                              uint32_t* out_count);
+/* DPPSort.Sort for ONE request (pg_dpp_ex; sort/sort.go:65-125 calls it once per request, requests overlap): calls
+ * with the same candidate count and options share one batched launch (KernelMatrix for all of them, one wave per
+ * request for the greedy part).  has_table = 1: embeddings are rows cand_rows[n] of the table; hook_emb as pg_dpp_ex. */
+int pg_coalescer_dpp(pg_coalescer* c, const uint32_t* cand_rows, const double* rel, uint32_t n,
+                     const pg_dpp_options* opt, const double* hook_emb, uint32_t* out_idx, uint32_t* out_count,
+                     double* out_relevance);
 typedef struct {
-    uint64_t requests[3], batches[3];   /* per flavour: 0 recall, 1 rank, 2 recommend */
-    uint64_t largest_batch[3];
+    uint64_t requests[6], batches[6];   /* per flavour: 0 recall (vector / i2i / online), 1 rank, 2 recommend, 3 dpp, 4-5 reserved */
+    uint64_t largest_batch[6];
     uint64_t replans;                   /* batches whose first recall plan did not hold and was re-run */
-    double   device_ms[3];              /* summed enqueue → completion time of the batches */
+    uint64_t timeouts;                  /* calls that returned PG_ERR_TIMEOUT */
+    double   device_ms[6];              /* summed enqueue → completion time of the batches */
 } pg_coalescer_stats_t;
 int pg_coalescer_stats(pg_coalescer* c, pg_coalescer_stats_t* out);
+
+/* Deadline form of pg_recommend_end: waits at most timeout_us for the batch; PG_ERR_TIMEOUT leaves the ticket valid
+ * (end it again later — every ticket must be ended). */
+int pg_recommend_end_timed(pg_ctx* ctx, pg_ticket* ticket, uint32_t timeout_us, double* scan_ms);
+/* Test aid: occupies the context's stream for `ms` milliseconds with a kernel that only watches the clock — what a
+ * hung or slow device looks like to callers with a deadline. */
+int pg_debug_stall(pg_ctx* ctx, uint32_t ms);
 
 /* ---- stats ----------------------------------------------------------------------------------*/
 typedef struct {

@@ -27,7 +27,9 @@ EXPORTS = [
     "pg_table_fill_gaussian", "pg_dpp_ex", "pg_i2i_recall", "pg_online_vector_recall", "pg_fm2t_user_embedding",
     "pg_fm2t_user_embedding_dev", "pg_recommend_dnn3_begin", "pg_recommend_end",
     "pg_coalescer_create", "pg_coalescer_destroy", "pg_coalescer_recall", "pg_coalescer_rank_dnn3",
-    "pg_coalescer_recommend", "pg_coalescer_stats",
+    "pg_coalescer_recommend", "pg_coalescer_stats", "pg_coalescer_create_scene", "pg_coalescer_i2i_recall",
+    "pg_coalescer_online_recall", "pg_coalescer_rank", "pg_coalescer_rank_fm2t", "pg_coalescer_recommend_ex",
+    "pg_coalescer_dpp", "pg_recommend_end_timed", "pg_debug_stall",
     "pg_topk_merge_lists_dev", "pg_owned_compact_dev", "pg_scatter_f32_dev", "pg_dpp_candidates_dev",
     "pg_gather_owned_rows_dev", "pg_dpp_batch_dev",
     "pg_group_create", "pg_group_destroy", "pg_group_size", "pg_group_ctx", "pg_group_table", "pg_group_table_create",
@@ -56,12 +58,25 @@ class PgGroupPlan(C.Structure):
 
 class PgCoalescerConfig(C.Structure):
     _fields_ = [("k", C.c_uint32), ("max_batch", C.c_uint32), ("max_wait_us", C.c_uint32), ("depth", C.c_uint32),
-                ("max_top_n", C.c_uint32), ("max_rank_items", C.c_uint32)]
+                ("max_top_n", C.c_uint32), ("max_rank_items", C.c_uint32), ("timeout_us", C.c_uint32)]
+
+
+class PgRankAlgo(C.Structure):
+    _fields_ = [("model", C.c_void_p), ("name", C.c_char_p), ("features", C.c_void_p),
+                ("item_field_cols", C.POINTER(C.c_int32))]
+
+
+class PgSceneConfig(C.Structure):
+    _fields_ = [("base", PgCoalescerConfig), ("algos", C.POINTER(PgRankAlgo)), ("n_algos", C.c_uint32),
+                ("rank_score", C.c_void_p), ("rerank", C.c_int), ("rerank_candidates", C.c_uint32),
+                ("dpp", PgDppOptions), ("query_model", C.c_void_p), ("trigger_table", C.c_void_p),
+                ("max_rerank_items", C.c_uint32), ("max_hook_dim", C.c_uint32)]
 
 
 class PgCoalescerStats(C.Structure):
-    _fields_ = [("requests", C.c_uint64 * 3), ("batches", C.c_uint64 * 3), ("largest_batch", C.c_uint64 * 3),
-                ("replans", C.c_uint64), ("device_ms", C.c_double * 3)]
+    # flavours: 0 recall (vector / i2i / online), 1 rank, 2 recommend, 3 dpp
+    _fields_ = [("requests", C.c_uint64 * 6), ("batches", C.c_uint64 * 6), ("largest_batch", C.c_uint64 * 6),
+                ("replans", C.c_uint64), ("timeouts", C.c_uint64), ("device_ms", C.c_double * 6)]
 
 
 _lib = None
@@ -140,6 +155,15 @@ def load():
         "pg_coalescer_rank_dnn3": [vp, vp, vp, u32, vp],
         "pg_coalescer_recommend": [vp, vp, u32, vp, vp, vp, vp, P(u32)],
         "pg_coalescer_stats": [vp, P(PgCoalescerStats)],
+        "pg_coalescer_create_scene": [vp, vp, P(PgSceneConfig), P(vp)],
+        "pg_coalescer_i2i_recall": [vp, u32, vp, vp, P(u32)],
+        "pg_coalescer_online_recall": [vp, vp, vp, vp, P(u32)],
+        "pg_coalescer_rank": [vp, u32, vp, vp, vp, u32, vp],
+        "pg_coalescer_rank_fm2t": [vp, vp, vp, vp, u32, vp],
+        "pg_coalescer_recommend_ex": [vp, vp, vp, u32, vp, vp, vp, vp, P(u32)],
+        "pg_coalescer_dpp": [vp, vp, vp, u32, P(PgDppOptions), vp, vp, P(u32), vp],
+        "pg_recommend_end_timed": [vp, vp, u32, P(C.c_double)],
+        "pg_debug_stall": [vp, u32],
         "pg_topk_merge_lists_dev": [vp, vp, vp, u32, u32, u32, i32, u32, vp, vp],
         "pg_owned_compact_dev": [vp, vp, vp, u32, u32, vp, vp, vp],
         "pg_scatter_f32_dev": [vp, vp, vp, vp, u32, vp],

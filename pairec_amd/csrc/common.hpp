@@ -136,7 +136,7 @@ struct pg_ctx {
     bool own_stream = false;
     int num_cus = 256;
     std::mutex mu;               // serialises calls on this context
-    pg::Scratch scratch[10];     // named scratch slots (see users; 8 = pg_recommend_dnn3_dev's intermediates)
+    pg::Scratch scratch[12];     // named scratch slots (see users; 8 = the recommend pipeline's intermediates, 10 = its re-rank stage)
     std::mutex pool_mu;          // guards pipe_free
     std::vector<pg::PipeRun*> pipe_free;     // per-batch status blocks / events of the device-resident pipelines
     std::map<const void*, size_t> dyn_lds;   // kernels whose dynamic-LDS limit was raised on this device
@@ -237,6 +237,9 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t, cons
                          const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items,
                          float* d_out);
 int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_user, uint32_t n_req, float* d_out);
+int rank_fm2t_rows_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
+                              const float* d_user, const int32_t* d_ufids, const uint32_t* d_cand, const uint32_t* d_off,
+                              uint32_t n_req, uint32_t n_items, float* d_out);
 // d_err: device flags, OR-ed with 1 where an item divides by zero; item i reports into d_err[i / items_per_flag]
 // (items_per_flag = 0: one flag for the call)
 int expr_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items, double* d_out,

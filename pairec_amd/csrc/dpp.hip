@@ -12,7 +12,7 @@
 // is unknowable here (module not vendored), parity with the reference is unpinned at that boundary;
 // the greedy update uses separate multiply and add, sequential over earlier picks, exactly as
 // gonum's Dgemm-by-axpy does on amd64, and is bit-identical to oracle/oracle.c given the same L.
-#include "common.hpp"
+#include "pipeline.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -478,6 +478,88 @@ int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, cons
     return PG_OK;
 }
 
+// dpp_norm_relevance_score (dpp_sort.go:382-405): O(n) scalar work in the reference's operation order
+// (stat.PopMeanVariance two-pass with compensation, stat.StdScore; min-max takes max = first, min = last item: the
+// candidates arrive sorted by score).  One implementation for the host (a caller's thread) and the device (one thread
+// per request inside a batch): IEEE fp64 add / mul / div / sqrt, no contraction, so both give the same bits.
+__host__ __device__ inline bool dpp_norm_relevance_one(const double* rel, uint32_t n, int mode, double* out) {
+#ifdef __HIP_DEVICE_COMPILE__
+#define PG_DMUL(a, b) __dmul_rn((a), (b))
+#define PG_DADD(a, b) __dadd_rn((a), (b))
+#else
+#define PG_DMUL(a, b) ([](double x_, double y_) { volatile double r_ = x_ * y_; return (double)r_; }((a), (b)))
+#define PG_DADD(a, b) ([](double x_, double y_) { volatile double r_ = x_ + y_; return (double)r_; }((a), (b)))
+#endif
+    if (mode == 1) {
+        double sum = 0.0;
+        for (uint32_t i = 0; i < n; ++i) sum = PG_DADD(sum, rel[i]);
+        const double mean = sum / (double)n;
+        double ss = 0.0, comp = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double d = PG_DADD(rel[i], -mean);
+            ss = PG_DADD(ss, PG_DMUL(d, d));
+            comp = PG_DADD(comp, d);
+        }
+        const double variance = PG_DADD(ss, -(PG_DMUL(comp, comp) / (double)n)) / (double)n;
+        if (mean == 0.0 || variance == 0.0) return false;
+        const double sd = sqrt(variance);
+        for (uint32_t i = 0; i < n; ++i) out[i] = PG_DADD(rel[i], -mean) / sd;
+        return true;
+    }
+    if (mode == 2) {
+        const double mx = rel[0], mn = rel[n - 1], span = PG_DADD(mx, -mn);
+        if (span == 0.0) return false;
+        const double eps = 1e-6;
+        for (uint32_t i = 0; i < n; ++i) out[i] = PG_DADD(PG_DMUL(PG_DADD(rel[i], -mn) / span, 1 - eps), eps);
+        return true;
+    }
+    if (out != rel)
+        for (uint32_t i = 0; i < n; ++i) out[i] = rel[i];
+    return true;
+#undef PG_DMUL
+#undef PG_DADD
+}
+
+bool dpp_norm_relevance_host(const double* rel, uint32_t n, int mode, double* out) {
+    return dpp_norm_relevance_one(rel, n, mode, out);
+}
+
+__global__ void dpp_norm_relevance_kernel(double* __restrict__ rel, uint32_t nq, uint32_t n, int mode,
+                                          uint32_t* __restrict__ bail) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    bail[q] = dpp_norm_relevance_one(rel + (size_t)q * n, n, mode, rel + (size_t)q * n) ? 0u : 1u;
+}
+
+__global__ void dpp_bail_fix_kernel(const uint32_t* __restrict__ bail, uint32_t nq, uint32_t n, uint32_t top_n,
+                                    uint32_t* __restrict__ pick, uint32_t* __restrict__ pick_cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * top_n) return;
+    const uint32_t q = i / top_n, p = i - q * top_n;
+    if (!bail[q]) return;
+    pick[i] = p;
+    if (p == 0) pick_cnt[q] = top_n < n ? top_n : n;
+}
+
+int dpp_norm_relevance_launch(hipStream_t st, double* d_rel, uint32_t nq, uint32_t n, int mode, uint32_t* d_bail) {
+    if (nq == 0) return PG_OK;
+    if (mode == 0) {
+        PG_HIP(hipMemsetAsync(d_bail, 0, (size_t)nq * 4, st));
+        return PG_OK;
+    }
+    dpp_norm_relevance_kernel<<<(nq + 63) / 64, 64, 0, st>>>(d_rel, nq, n, mode, d_bail);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int dpp_bail_fix_launch(hipStream_t st, const uint32_t* d_bail, uint32_t nq, uint32_t n, uint32_t top_n, uint32_t* d_pick,
+                        uint32_t* d_pick_cnt) {
+    if (nq == 0 || top_n == 0) return PG_OK;
+    dpp_bail_fix_kernel<<<(nq * top_n + 255) / 256, 256, 0, st>>>(d_bail, nq, n, top_n, d_pick, d_pick_cnt);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 }  // namespace pg
 
 namespace pg {
@@ -508,37 +590,10 @@ int pg_dpp_ex(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const d
     // dpp_norm_relevance_score (dpp_sort.go:382-405): O(n) scalar work on the caller's thread, in the reference's
     // operation order (stat.PopMeanVariance two-pass with compensation, stat.StdScore; min-max takes max = first,
     // min = last item: the candidates arrive sorted by score)
-    std::vector<double> rs(rel, rel + n);
-    if (o->norm_relevance_score == 1) {
-        double sum = 0.0;
-        for (uint32_t i = 0; i < n; ++i) sum = sum + rel[i];
-        const double mean = sum / (double)n;
-        double ss = 0.0, comp = 0.0;
-        for (uint32_t i = 0; i < n; ++i) {
-            const double d = rel[i] - mean;
-            volatile double dd = d * d;
-            ss = ss + dd;
-            comp = comp + d;
-        }
-        volatile double cc = comp * comp;
-        const double variance = (ss - cc / (double)n) / (double)n;
-        if (mean == 0.0 || variance == 0.0) {
-            pg::set_error("pg_dpp: all item score is zero (dpp_sort.go:385-388); the caller keeps the items unchanged");
-            return PG_ERR_ARITH;
-        }
-        const double sd = sqrt(variance);
-        for (uint32_t i = 0; i < n; ++i) rs[i] = (rel[i] - mean) / sd;
-    } else if (o->norm_relevance_score == 2) {
-        const double mx = rel[0], mn = rel[n - 1], span = mx - mn;
-        if (span == 0.0) {
-            pg::set_error("pg_dpp: all item score is zero (dpp_sort.go:394-397); the caller keeps the items unchanged");
-            return PG_ERR_ARITH;
-        }
-        const double eps = 1e-6;
-        for (uint32_t i = 0; i < n; ++i) {
-            volatile double a = ((rel[i] - mn) / span) * (1 - eps);
-            rs[i] = a + eps;
-        }
+    std::vector<double> rs(n);
+    if (!pg::dpp_norm_relevance_host(rel, n, o->norm_relevance_score, rs.data())) {
+        pg::set_error("pg_dpp: all item score is zero (dpp_sort.go:385-397); the caller keeps the items unchanged");
+        return PG_ERR_ARITH;
     }
     if (out_relevance) memcpy(out_relevance, rs.data(), (size_t)n * 8);      // "dpp_relevance_score" (:410)
     const uint32_t topn = o->topn;

@@ -122,8 +122,45 @@ static int stage_descs(pg_ctx* ctx, const pg_features* fs, const int32_t* col_id
     return PG_OK;
 }
 
+// up to 16 columns (an FM model's item fields): the descriptors travel as kernel arguments — nothing is staged, nothing
+// synchronises, so the gather can sit inside a batch that is only enqueued (coalescer.hip)
+struct ColDescs16 { ColDesc c[16]; };
+__global__ void features_gather_i32_args_kernel(ColDescs16 cols, uint32_t F, uint64_t rows, const uint32_t* __restrict__ cand,
+                                                uint32_t n, int32_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * F) return;
+    const uint32_t i = t / F, f = t % F;
+    const ColDesc c = cols.c[f];
+    const uint32_t row = cand[i];
+    int64_t v;
+    if (row >= rows) v = (int64_t)c.def;
+    else v = c.dtype == PG_F_I32 ? (int64_t)((const int32_t*)c.base)[row] : ((const int64_t*)c.base)[row];
+    v = v > 2147483647ll ? 2147483647ll : (v < -2147483648ll ? -2147483648ll : v);
+    out[t] = (int32_t)v;
+}
+
 int features_gather_i32_locked(pg_ctx* ctx, const pg_features* fs, const int32_t* col_idx, uint32_t n_cols,
                                const uint32_t* d_rows, uint32_t n, int32_t* d_out, const char* who) {
+    if (n_cols <= 16) {
+        ColDescs16 h;
+        memset(&h, 0, sizeof h);
+        for (uint32_t f = 0; f < n_cols; ++f) {
+            if (col_idx[f] < 0 || (size_t)col_idx[f] >= fs->cols.size()) {
+                set_error("%s: column index %d out of range (%zu columns)", who, col_idx[f], fs->cols.size());
+                return PG_ERR_INVALID;
+            }
+            const auto& c = fs->cols[(size_t)col_idx[f]];
+            if (c.dtype != PG_F_I32 && c.dtype != PG_F_I64) {
+                set_error("%s: column \"%s\" is not an integer column", who, c.name.c_str());
+                return PG_ERR_INVALID;
+            }
+            h.c[f] = ColDesc{c.d, c.dtype, 0, c.def};
+        }
+        const uint32_t total = n * n_cols;
+        features_gather_i32_args_kernel<<<(total + 255) / 256, 256, 0, ctx->stream>>>(h, n_cols, fs->rows, d_rows, n, d_out);
+        PG_HIP(hipGetLastError());
+        return PG_OK;
+    }
     ColDesc* d_desc;
     float *d_scale, *d_bias;
     int rc;

@@ -120,54 +120,6 @@ __global__ void scatter_scores_kernel(const float* __restrict__ score, const uin
     if (i < cap && i < *total) slab[slot[i]] = score[i];
 }
 
-// DPP candidates of request q: the first C entries of its sorted list → global row and relevance (fused score)
-__global__ void dpp_select_kernel(const uint32_t* __restrict__ order, const uint64_t* __restrict__ rows,
-                                  const double* __restrict__ fused, uint32_t nq, uint32_t k, uint32_t C,
-                                  uint64_t* __restrict__ c_rows, double* __restrict__ c_rel) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * C) return;
-    const uint32_t q = i / C, j = i - q * C;
-    const size_t src = (size_t)q * k + order[(size_t)q * k + j];
-    c_rows[i] = rows[src];
-    c_rel[i] = fused[src];
-}
-
-// every shard: the embedding rows it owns among the DPP candidates → the lead's [nq * C][dim] buffer (16-B stores)
-__global__ void gather_owned_emb_kernel(const float* __restrict__ tab, uint32_t dim, uint64_t off, uint64_t nrows,
-                                        const uint64_t* __restrict__ c_rows, uint32_t n, float* __restrict__ out) {
-    const uint32_t qpr = dim / 4;
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t i = gid / qpr;
-    const uint32_t c = (uint32_t)(gid % qpr);
-    if (i >= n) return;
-    const uint64_t r = c_rows[i];
-    if (r == ~0ull || r < off || r - off >= nrows) return;
-    *reinterpret_cast<float4*>(out + i * dim + 4 * c) = *reinterpret_cast<const float4*>(tab + (r - off) * dim + 4 * c);
-}
-
-// page[q][p] = entry pick[q][p] of request q's sorted list (pick = DPP's choice among the first C, or p itself)
-__global__ void group_page_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ pick,
-                                  const uint32_t* __restrict__ pick_cnt, const uint64_t* __restrict__ rows,
-                                  const float* __restrict__ recall, const float* __restrict__ rank,
-                                  const double* __restrict__ fused, uint32_t nq, uint32_t k, uint32_t top_n,
-                                  uint64_t* __restrict__ p_rows, double* __restrict__ p_fused,
-                                  float* __restrict__ p_recall, float* __restrict__ p_rank) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * top_n) return;
-    const uint32_t q = i / top_n, p = i - q * top_n;
-    uint32_t j = p;
-    bool valid = true;
-    if (pick) {
-        valid = p < pick_cnt[q];
-        j = valid ? pick[(size_t)q * top_n + p] : 0u;
-    }
-    const size_t src = (size_t)q * k + order[(size_t)q * k + j];
-    p_rows[i] = valid ? rows[src] : ~0ull;
-    p_fused[i] = valid ? fused[src] : __longlong_as_double(0x7FF8000000000000ll);
-    p_recall[i] = valid ? recall[src] : -__builtin_inff();
-    p_rank[i] = valid ? rank[src] : 0.0f;
-}
-
 }  // namespace
 }  // namespace pg
 
@@ -176,7 +128,7 @@ struct pg_group {
     std::vector<int> dev;
     uint64_t total_rows = 0;
     uint32_t dim = 0;
-    uint32_t nq_cap = 0, k_cap = 0, c_cap = 0, top_cap = 0;
+    uint32_t nq_cap = 0, k_cap = 0, c_cap = 0, top_cap = 0, nv_cap = 0;
     std::mutex mu;                 // one step at a time
     hipEvent_t ev_ready = nullptr, ev_sel = nullptr, ev_done = nullptr;
     // lead-only buffers
@@ -225,15 +177,19 @@ void free_step_buffers(pg_group* g) {
     g->slab = nullptr; g->vars = nullptr; g->fused = nullptr; g->order = nullptr; g->seg = nullptr; g->d_err = nullptr;
     g->d_count = nullptr; g->c_rows = nullptr; g->c_rel = nullptr; g->c_emb = nullptr; g->pick = nullptr; g->pick_cnt = nullptr;
     g->d_page = nullptr; g->h_page = nullptr; g->h_flags = nullptr;
-    g->nq_cap = g->k_cap = g->c_cap = g->top_cap = 0;
+    g->nq_cap = g->k_cap = g->c_cap = g->top_cap = g->nv_cap = 0;
 }
 
 int ensure_step_buffers(pg_group* g, uint32_t nq, uint32_t k, uint32_t C, uint32_t top_n, int nv) {
-    if (nq <= g->nq_cap && k <= g->k_cap && C <= g->c_cap && top_n <= g->top_cap) return PG_OK;
+    if (nq <= g->nq_cap && k <= g->k_cap && C <= g->c_cap && top_n <= g->top_cap && (uint32_t)nv <= g->nv_cap) return PG_OK;
     for (auto& s : g->sh) {
         hipSetDevice(s.ctx->device);
         hipStreamSynchronize(s.ctx->stream);
     }
+    // grow every dimension to the largest seen so far: alternating shapes must not re-allocate on every call, and a
+    // later expression with more variables must not find `vars` sized for the first one's
+    nq = std::max(nq, g->nq_cap); k = std::max(k, g->k_cap); C = std::max(C, g->c_cap); top_n = std::max(top_n, g->top_cap);
+    nv = std::max(nv, (int)g->nv_cap);
     free_step_buffers(g);
     const uint32_t G = (uint32_t)g->sh.size();
     const size_t n = (size_t)nq * k;
@@ -268,7 +224,7 @@ int ensure_step_buffers(pg_group* g, uint32_t nq, uint32_t k, uint32_t C, uint32
     PG_HIP(hipMalloc((void**)&g->d_page, page));
     PG_HIP(hipHostMalloc((void**)&g->h_page, page));
     PG_HIP(hipHostMalloc((void**)&g->h_flags, 1024 * 4));
-    g->nq_cap = nq; g->k_cap = k; g->c_cap = C; g->top_cap = top_n;
+    g->nq_cap = nq; g->k_cap = k; g->c_cap = C; g->top_cap = top_n; g->nv_cap = (uint32_t)std::max(nv, 1);
     return PG_OK;
 }
 
@@ -318,20 +274,14 @@ int pg_dpp_candidates_dev(pg_ctx* ctx, const uint32_t* d_order, const uint64_t* 
     PG_REQUIRE(ctx && d_order && d_rows && d_fused && d_c_rows && d_c_rel, "pg_dpp_candidates_dev: NULL argument");
     PG_REQUIRE(n_cand >= 1 && n_cand <= k, "pg_dpp_candidates_dev: n_cand %u outside 1..k", n_cand);
     std::lock_guard<std::mutex> g(ctx->mu);
-    pg::dpp_select_kernel<<<(nq * n_cand + 255) / 256, 256, 0, ctx->stream>>>(d_order, d_rows, d_fused, nq, k, n_cand, d_c_rows, d_c_rel);
-    PG_HIP(hipGetLastError());
-    return PG_OK;
+    return pg::sorted_head_launch(ctx->stream, d_order, d_rows, d_fused, nq, k, n_cand, d_c_rows, d_c_rel);
 }
 
 int pg_gather_owned_rows_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_global_rows, uint32_t n, float* d_out) {
     PG_REQUIRE(ctx && t && (n == 0 || (d_global_rows && d_out)), "pg_gather_owned_rows_dev: NULL argument");
     if (n == 0) return PG_OK;
     std::lock_guard<std::mutex> g(ctx->mu);
-    const uint64_t threads = (uint64_t)n * (t->dim / 4);
-    pg::gather_owned_emb_kernel<<<(uint32_t)((threads + 255) / 256), 256, 0, ctx->stream>>>(t->d, t->dim, t->row_offset, t->rows,
-                                                                                          d_global_rows, n, d_out);
-    PG_HIP(hipGetLastError());
-    return PG_OK;
+    return pg::gather_global_rows_launch(ctx->stream, t, d_global_rows, n, d_out);
 }
 
 int pg_dpp_batch_dev(pg_ctx* ctx, const float* d_emb, const double* d_rel, uint32_t n_req, uint32_t n, uint32_t dim,
@@ -513,10 +463,10 @@ int pg_group_recommend(pg_group* g, const pg_expr* e, const char* rank_var, cons
     PG_REQUIRE(C <= 8192, "pg_group_recommend: %u DPP candidates (at most 8192)", C);
     std::vector<int> src;
     int rc;
-    if ((rc = pg::recommend_bind_vars(e, rank_var, &src, "pg_group_recommend"))) return rc;
+    if ((rc = pg::recommend_bind_vars(e, &rank_var, 1, &src, "pg_group_recommend"))) return rc;
     const int nv = (int)src.size();
     uint32_t mask = 0;
-    for (int i = 0; i < nv; ++i) mask |= (src[(size_t)i] ? 1u : 0u) << i;
+    for (int i = 0; i < nv; ++i) mask |= (src[(size_t)i] >= 0 ? 1u : 0u) << i;
 
     std::lock_guard<std::mutex> lk(g->mu);
     if ((rc = pg::ensure_step_buffers(g, nq, k, C, top_n, nv))) return rc;
@@ -598,8 +548,7 @@ int pg_group_recommend(pg_group* g, const pg_expr* e, const char* rank_var, cons
             if ((rc = pg::expr_eval_enqueue_locked(lead.ctx, e, g->vars, n, g->fused, g->d_err, k))) return rc;
             if ((rc = pg::sort_dev_locked(lead.ctx, g->fused, g->seg, nq, n, k, 1, g->order))) return rc;
             if (C) {
-                pg::dpp_select_kernel<<<(nq * C + 255) / 256, 256, 0, ls>>>(g->order, lead.m_rows, g->fused, nq, k, C, g->c_rows, g->c_rel);
-                PG_HIP(hipGetLastError());
+                if ((rc = pg::sorted_head_launch(ls, g->order, lead.m_rows, g->fused, nq, k, C, g->c_rows, g->c_rel))) return rc;
             }
         }
         if (C) {
@@ -610,10 +559,7 @@ int pg_group_recommend(pg_group* g, const pg_expr* e, const char* rank_var, cons
                 PG_HIP(hipSetDevice(s.ctx->device));
                 hipStream_t st = s.ctx->stream;
                 if (h) PG_HIP(hipStreamWaitEvent(st, g->ev_sel, 0));
-                const uint64_t threads = (uint64_t)nq * C * (g->dim / 4);
-                pg::gather_owned_emb_kernel<<<(uint32_t)((threads + 255) / 256), 256, 0, st>>>(s.tab->d, g->dim, s.tab->row_offset,
-                                                                                              s.tab->rows, g->c_rows, nq * C, g->c_emb);
-                PG_HIP(hipGetLastError());
+                if ((rc = pg::gather_global_rows_launch(st, s.tab, g->c_rows, nq * C, g->c_emb))) return rc;
                 if (h) PG_HIP(hipEventRecord(s.ev_emb, st));
             }
             PG_HIP(hipSetDevice(lead.ctx->device));
@@ -625,13 +571,9 @@ int pg_group_recommend(pg_group* g, const pg_expr* e, const char* rank_var, cons
         }
         // ---- 6. the page ------------------------------------------------------------------------------------------------
         const size_t np = (size_t)nq * top_n;
-        uint64_t* p_rows = (uint64_t*)g->d_page;
-        double* p_fused = (double*)(p_rows + np);
-        float* p_recall = (float*)(p_fused + np);
-        float* p_rank = p_recall + np;
-        pg::group_page_kernel<<<(uint32_t)((np + 255) / 256), 256, 0, ls>>>(g->order, C ? g->pick : nullptr, g->pick_cnt, lead.m_rows, lead.m_sc,
-                                                                           g->slab, g->fused, nq, k, top_n, p_rows, p_fused, p_recall, p_rank);
-        PG_HIP(hipGetLastError());
+        if ((rc = pg::page_launch(ls, g->order, C ? g->pick : nullptr, g->pick_cnt, lead.m_rows, lead.m_sc, g->slab, (size_t)n, 1, g->fused, nq, k,
+                                  top_n, g->d_page)))
+            return rc;
         PG_HIP(hipMemcpyAsync(g->h_page, g->d_page, np * 24, hipMemcpyDeviceToHost, ls));
         PG_HIP(hipMemcpyAsync(g->h_flags, g->d_err, (size_t)nq * 4, hipMemcpyDeviceToHost, ls));
         PG_HIP(hipMemcpyAsync(g->h_flags + 256, g->d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, ls));

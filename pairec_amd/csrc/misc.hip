@@ -50,6 +50,88 @@ __global__ void uniform_offsets_kernel(uint32_t nq, uint32_t k, uint32_t* __rest
     if (i <= nq) off[i] = i * k;
 }
 
+// DPP candidates of request q: the first C entries of its sorted list → global row and relevance (fused score)
+__global__ void sorted_head_kernel(const uint32_t* __restrict__ order, const uint64_t* __restrict__ rows,
+                                   const double* __restrict__ fused, uint32_t nq, uint32_t k, uint32_t C,
+                                   uint64_t* __restrict__ c_rows, double* __restrict__ c_rel) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * C) return;
+    const uint32_t q = i / C, j = i - q * C;
+    const size_t src = (size_t)q * k + order[(size_t)q * k + j];
+    c_rows[i] = rows[src];
+    c_rel[i] = fused[src];
+}
+
+// the embedding rows this table holds among `c_rows` → out [n][dim] (16-B stores; out may live on a peer device)
+__global__ void gather_global_rows_kernel(const float* __restrict__ tab, uint32_t dim, uint64_t off, uint64_t nrows,
+                                          const uint64_t* __restrict__ c_rows, uint32_t n, float* __restrict__ out) {
+    const uint32_t qpr = dim / 4;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = gid / qpr;
+    const uint32_t c = (uint32_t)(gid % qpr);
+    if (i >= n) return;
+    const uint64_t r = c_rows[i];
+    if (r == ~0ull || r < off || r - off >= nrows) return;
+    *reinterpret_cast<float4*>(out + i * dim + 4 * c) = *reinterpret_cast<const float4*>(tab + (r - off) * dim + 4 * c);
+}
+
+// page[q][p] = entry pick[q][p] of request q's sorted list (pick = DPP's choice among the first C, or p itself)
+__global__ void page_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ pick,
+                            const uint32_t* __restrict__ pick_cnt, const uint64_t* __restrict__ rows,
+                            const float* __restrict__ recall, const float* __restrict__ rank, size_t rank_stride, int n_algos,
+                            const double* __restrict__ fused, uint32_t nq, uint32_t k, uint32_t top_n,
+                            uint64_t* __restrict__ p_rows, double* __restrict__ p_fused,
+                            float* __restrict__ p_recall, float* __restrict__ p_rank) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t np = nq * top_n;
+    if (i >= np) return;
+    const uint32_t q = i / top_n, p = i - q * top_n;
+    uint32_t j = p;
+    bool valid = true;
+    if (pick) {
+        valid = p < pick_cnt[q];
+        j = valid ? pick[(size_t)q * top_n + p] : 0u;
+    }
+    const size_t src = (size_t)q * k + order[(size_t)q * k + j];
+    p_rows[i] = valid ? rows[src] : ~0ull;
+    p_fused[i] = valid ? fused[src] : __longlong_as_double(0x7FF8000000000000ll);
+    p_recall[i] = valid ? recall[src] : -__builtin_inff();
+    for (int a = 0; a < n_algos; ++a) p_rank[(size_t)a * np + i] = valid ? rank[(size_t)a * rank_stride + src] : 0.0f;
+}
+
+int sorted_head_launch(hipStream_t st, const uint32_t* d_order, const uint64_t* d_rows, const double* d_fused, uint32_t nq,
+                       uint32_t k, uint32_t C, uint64_t* d_c_rows, double* d_c_rel) {
+    if (nq == 0 || C == 0) return PG_OK;
+    sorted_head_kernel<<<(nq * C + 255) / 256, 256, 0, st>>>(d_order, d_rows, d_fused, nq, k, C, d_c_rows, d_c_rel);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int gather_global_rows_launch(hipStream_t st, const pg_table* t, const uint64_t* d_global_rows, uint32_t n, float* d_out) {
+    if (n == 0) return PG_OK;
+    const uint64_t threads = (uint64_t)n * (t->dim / 4);
+    gather_global_rows_kernel<<<(uint32_t)((threads + 255) / 256), 256, 0, st>>>(t->d, t->dim, t->row_offset, t->rows, d_global_rows, n, d_out);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+size_t page_entry_bytes(int n_algos) { return 20 + 4 * (size_t)n_algos; }
+
+int page_launch(hipStream_t st, const uint32_t* d_order, const uint32_t* d_pick, const uint32_t* d_pick_cnt,
+                const uint64_t* d_rows, const float* d_recall, const float* d_rank, size_t rank_stride, int n_algos,
+                const double* d_fused, uint32_t nq, uint32_t k, uint32_t top_n, char* d_page) {
+    const size_t np = (size_t)nq * top_n;
+    if (np == 0) return PG_OK;
+    uint64_t* p_rows = (uint64_t*)d_page;
+    double* p_fused = (double*)(p_rows + np);
+    float* p_recall = (float*)(p_fused + np);
+    float* p_rank = p_recall + np;
+    page_kernel<<<(uint32_t)((np + 255) / 256), 256, 0, st>>>(d_order, d_pick, d_pick_cnt, d_rows, d_recall, d_rank, rank_stride, n_algos,
+                                                             d_fused, nq, k, top_n, p_rows, p_fused, p_recall, p_rank);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 int rows_to_local_locked(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t n, uint32_t* d_local,
                          uint8_t* d_owned) {
     if (n == 0) return PG_OK;

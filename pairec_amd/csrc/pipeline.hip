@@ -10,27 +10,33 @@
 #include "pipeline.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 
 namespace pg {
 
-// vars[v][i] = (double) (src[v] ? rank[i] : recall[i]) — the float32 → float64 widening every response decoder of
-// the reference performs (algorithm/eas/easyrec_response.go:479-483), for all variables of the expression at once
-__global__ void bind_vars_kernel(const float* __restrict__ recall, const float* __restrict__ rank, uint32_t n,
-                                 uint32_t nv, uint32_t src_mask, double* __restrict__ vars) {
+// vars[v][i] = (double) (src[v] >= 0 ? rank plane src[v] : recall)[i] — the float32 → float64 widening every response
+// decoder of the reference performs (algorithm/eas/easyrec_response.go:479-483), for all variables of the expression
+struct VarSrc { int8_t src[32]; };
+__global__ void bind_vars_kernel(const float* __restrict__ recall, const float* __restrict__ rank, size_t rank_stride,
+                                 uint32_t n, uint32_t nv, VarSrc vs, double* __restrict__ vars) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double a = (double)recall[i], b = (double)rank[i];
-    for (uint32_t v = 0; v < nv; ++v) vars[(size_t)v * n + i] = ((src_mask >> v) & 1u) ? b : a;
+    const double a = (double)recall[i];
+    for (uint32_t v = 0; v < nv; ++v) {
+        const int sa = vs.src[v];
+        vars[(size_t)v * n + i] = sa >= 0 ? (double)rank[(size_t)sa * rank_stride + i] : a;
+    }
 }
 
 // A table with fewer than k rows leaves padding slots (row = UINT64_MAX, recall score = -inf) at the end of every
-// request.  They are not items: their model score is reported as 0 and their fused score as NaN, which the sort
+// request.  They are not items: their model scores are reported as 0 and their fused score as NaN, which the sort
 // places last in either direction, so a page never starts with them.
-__global__ void mask_pads_kernel(const uint64_t* __restrict__ rows, uint32_t n, float* __restrict__ rank,
-                                 double* __restrict__ fused) {
+__global__ void mask_pads_kernel(const uint64_t* __restrict__ rows, uint32_t n, float* __restrict__ rank, size_t rank_stride,
+                                 int n_algos, double* __restrict__ fused) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || rows[i] != ~0ull) return;
-    rank[i] = 0.0f;
+    for (int a = 0; a < n_algos; ++a) rank[(size_t)a * rank_stride + i] = 0.0f;
     fused[i] = __longlong_as_double(0x7FF8000000000000ll);
 }
 
@@ -71,52 +77,36 @@ void pipe_pool_destroy(pg_ctx* ctx) {
     ctx->pipe_free.clear();
 }
 
-int recommend_bind_vars(const pg_expr* e, const char* rank_var, std::vector<int>* var_src, const char* who) {
+int recommend_bind_vars(const pg_expr* e, const char* const* names, int n_algos, std::vector<int>* var_src, const char* who) {
     const int nv = pg_expr_num_vars(e);
     if (nv > 32) {
         set_error("%s: RankScore has %d variables (at most 32)", who, nv);
         return PG_ERR_UNSUPPORTED;
     }
-    var_src->assign((size_t)nv, 0);
+    var_src->assign((size_t)nv, -1);
     for (int i = 0; i < nv; ++i) {
         const char* name = pg_expr_var_name(e, i);
-        if (!strcmp(name, rank_var)) (*var_src)[(size_t)i] = 1;
-        else if (!strcmp(name, "current_score")) (*var_src)[(size_t)i] = 0;
-        else {
-            set_error("%s: RankScore variable \"%s\" is neither \"%s\" nor current_score", who, name, rank_var);
+        int found = -2;
+        for (int a = 0; a < n_algos; ++a)
+            if (names[a] && !strcmp(name, names[a])) found = a;
+        if (found == -2 && !strcmp(name, "current_score")) found = -1;
+        if (found == -2) {
+            set_error("%s: RankScore variable \"%s\" is neither a rank algorithm of the scene nor current_score", who, name);
             return PG_ERR_INVALID;
         }
+        (*var_src)[(size_t)i] = found;
     }
     return PG_OK;
-}
-
-// the stages behind the recall for requests [q0, q0 + nq) of the call (caller holds ctx->mu; d_err is indexed from 0)
-static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, uint32_t* d_local,
-                                 uint32_t* d_off, uint32_t* d_err, double* d_vars) {
-    const uint32_t n = nq * c.k;
-    const size_t o = (size_t)q0 * c.k;
-    int rc;
-    if ((rc = uniform_offsets_locked(ctx, nq, c.k, d_off))) return rc;
-    if ((rc = rows_to_local_locked(ctx, c.t, c.d_rows + o, n, d_local, nullptr))) return rc;
-    if ((rc = rank_dnn3_dev_locked(ctx, c.m, c.t, c.d_queries + (size_t)q0 * c.t->dim, d_local, d_off, nq, n, c.d_rank + o))) return rc;
-    uint32_t mask = 0;
-    for (int i = 0; i < c.nv; ++i) mask |= (c.var_src[i] ? 1u : 0u) << i;
-    if (c.nv > 0) {
-        bind_vars_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(c.d_recall + o, c.d_rank + o, n, (uint32_t)c.nv, mask, d_vars);
-        PG_HIP(hipGetLastError());
-    }
-    PG_HIP(hipMemsetAsync(d_err, 0, (size_t)kMaxQueries * 4, ctx->stream));
-    if ((rc = expr_eval_enqueue_locked(ctx, c.e, d_vars, n, c.d_fused + o, d_err, c.k))) return rc;
-    if (c.t->rows < c.k) {
-        mask_pads_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(c.d_rows + o, n, c.d_rank + o, c.d_fused + o);
-        PG_HIP(hipGetLastError());
-    }
-    return sort_dev_locked(ctx, c.d_fused + o, d_off, nq, n, c.k, 1, c.d_order + o);
 }
 
 struct PostScratch {
     uint32_t *d_local, *d_off, *d_err;
     double* d_vars;
+    // re-rank stage (scratch slot 10)
+    uint64_t* c_rows;
+    double* c_rel;
+    float* c_emb;
+    uint32_t* c_bail;
 };
 static int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostScratch* ps) {
     const uint32_t n = nq * c.k;
@@ -130,6 +120,81 @@ static int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostSc
     ps->d_off = (uint32_t*)((char*)buf + b_local);
     ps->d_err = (uint32_t*)((char*)buf + b_local + b_off);
     ps->d_vars = (double*)((char*)buf + b_local + b_off + b_err);
+    ps->c_rows = nullptr; ps->c_rel = nullptr; ps->c_emb = nullptr; ps->c_bail = nullptr;
+    if (c.rerank.kind) {
+        const size_t nc = (size_t)nq * c.rerank.candidates;
+        const size_t b_rows = al(nc * 8), b_rel = al(nc * 8), b_emb = al(nc * c.t->dim * 4), b_bail = al((size_t)kMaxQueries * 4);
+        if ((rc = scratch_reserve(ctx, 10, b_rows + b_rel + b_emb + b_bail, &buf))) return rc;
+        ps->c_rows = (uint64_t*)buf;
+        ps->c_rel = (double*)((char*)buf + b_rows);
+        ps->c_emb = (float*)((char*)buf + b_rows + b_rel);
+        ps->c_bail = (uint32_t*)((char*)buf + b_rows + b_rel + b_emb);
+    }
+    return PG_OK;
+}
+
+// the stages behind the recall for requests [q0, q0 + nq) of the call (caller holds ctx->mu; d_err is indexed from 0)
+static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps) {
+    const uint32_t n = nq * c.k;
+    const size_t o = (size_t)q0 * c.k;
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = uniform_offsets_locked(ctx, nq, c.k, ps.d_off))) return rc;
+    if ((rc = rows_to_local_locked(ctx, c.t, c.d_rows + o, n, ps.d_local, nullptr))) return rc;
+    // RankAlgoList: every algorithm scores every candidate (rank_service.go:259-289 fans them out as goroutines)
+    for (int a = 0; a < c.n_algos; ++a) {
+        const RankAlgoRef& al = c.algos[a];
+        float* out = c.d_rank + (size_t)a * c.rank_stride + o;
+        const float* users = c.d_queries + (size_t)q0 * c.t->dim;
+        if (al.m->kind == PG_MODEL_DNN3) {
+            if ((rc = rank_dnn3_dev_locked(ctx, al.m, c.t, users, ps.d_local, ps.d_off, nq, n, out))) return rc;
+        } else {
+            if ((rc = rank_fm2t_rows_dev_locked(ctx, al.m, al.fs, al.item_field_cols, users, c.d_ufids + (size_t)q0 * c.ufid_stride,
+                                                ps.d_local, ps.d_off, nq, n, out)))
+                return rc;
+        }
+    }
+    VarSrc vs;
+    for (int i = 0; i < 32; ++i) vs.src[i] = i < c.nv ? (int8_t)c.var_src[i] : (int8_t)-1;
+    if (c.nv > 0) {
+        bind_vars_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n, (uint32_t)c.nv, vs, ps.d_vars);
+        PG_HIP(hipGetLastError());
+    }
+    PG_HIP(hipMemsetAsync(ps.d_err, 0, (size_t)kMaxQueries * 4, st));
+    if ((rc = expr_eval_enqueue_locked(ctx, c.e, ps.d_vars, n, c.d_fused + o, ps.d_err, c.k))) return rc;
+    if (c.t->rows < c.k) {
+        mask_pads_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_rows + o, n, c.d_rank + o, c.rank_stride, c.n_algos, c.d_fused + o);
+        PG_HIP(hipGetLastError());
+    }
+    if ((rc = sort_dev_locked(ctx, c.d_fused + o, ps.d_off, nq, n, c.k, 1, c.d_order + o))) return rc;
+    if (c.rerank.kind == 1) {
+        // DPPSort.doSort (sort/dpp_sort.go:271-351) on the sorted list: candidates = its first C entries, their embeddings
+        // are rows of the table (loadEmbeddingCache), KernelMatrix + DPPWithWindow for the whole batch at once
+        const uint32_t C = c.rerank.candidates;
+        if (c.t->rows < C || c.k < C) {
+            set_error("recommend: the DPP stage wants %u candidates, the lists hold min(k = %u, %llu rows)", C, c.k, (unsigned long long)c.t->rows);
+            return PG_ERR_UNSUPPORTED;
+        }
+        if ((rc = sorted_head_launch(st, c.d_order + o, c.d_rows + o, c.d_fused + o, nq, c.k, C, ps.c_rows, ps.c_rel))) return rc;
+        if ((rc = dpp_norm_relevance_launch(st, ps.c_rel, nq, C, c.rerank.dpp.norm_relevance_score, ps.c_bail))) return rc;
+        if ((rc = gather_global_rows_launch(st, c.t, ps.c_rows, nq * C, ps.c_emb))) return rc;
+        if ((rc = dpp_run_locked(ctx, ps.c_emb, nullptr, ps.c_rel, nq, C, c.t->dim, 0, c.rerank.dpp.alpha, c.top_n, c.rerank.dpp.window,
+                                 c.rerank.dpp.normalize_emb, 1, 1, c.d_pick + (size_t)q0 * c.top_n, c.d_pick_cnt + q0)))
+            return rc;
+        if (c.rerank.dpp.norm_relevance_score &&
+            (rc = dpp_bail_fix_launch(st, ps.c_bail, nq, C, c.top_n, c.d_pick + (size_t)q0 * c.top_n, c.d_pick_cnt + q0)))
+            return rc;
+    }
+    return PG_OK;
+}
+
+int recommend_post_enqueue(pg_ctx* ctx, const RecommendCall& c, uint32_t* d_err_out) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    int rc;
+    PostScratch ps;
+    if ((rc = post_scratch(ctx, c, c.nq, &ps))) return rc;
+    if ((rc = recommend_post_locked(ctx, c, 0, c.nq, ps))) return rc;
+    if (d_err_out) PG_HIP(hipMemcpyAsync(d_err_out, ps.d_err, (size_t)c.nq * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return PG_OK;
 }
 
@@ -155,7 +220,7 @@ int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool firs
         if ((rc = recall_job_prepare(&j))) return rc;
     }
     if ((rc = recall_job_enqueue(&r->job))) return rc;
-    if ((rc = recommend_post_locked(ctx, c, 0, c.nq, ps.d_local, ps.d_off, ps.d_err, ps.d_vars))) return rc;
+    if ((rc = recommend_post_locked(ctx, c, 0, c.nq, ps))) return rc;
     PG_HIP(hipMemcpyAsync(r->h_status + kExprFlagAt, ps.d_err, (size_t)c.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipEventRecord(r->done, ctx->stream));
     return PG_OK;
@@ -179,7 +244,7 @@ int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok, const RecommendCall* c) 
             PostScratch ps;
             if ((rc = post_scratch(ctx, *c, 1, &ps))) return rc;
             for (uint32_t q : failed) {
-                if ((rc = recommend_post_locked(ctx, *c, q, 1, ps.d_local, ps.d_off, ps.d_err, ps.d_vars))) return rc;
+                if ((rc = recommend_post_locked(ctx, *c, q, 1, ps))) return rc;
                 PG_HIP(hipMemcpyAsync(r->h_status + kExprFlagAt + q, ps.d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
                 PG_HIP(hipStreamSynchronize(ctx->stream));
             }
@@ -214,14 +279,14 @@ int pg_recommend_dnn3_begin(pg_ctx* ctx, const pg_table* t, const pg_model* m, c
                "pg_recommend_dnn3: the model must be DNN3 with d_user = d_item = the table's dim");
     pg_ticket* tk = new pg_ticket();
     int rc;
-    if ((rc = pg::recommend_bind_vars(e, rank_var, &tk->var_src, "pg_recommend_dnn3"))) {
+    if ((rc = pg::recommend_bind_vars(e, &rank_var, 1, &tk->var_src, "pg_recommend_dnn3"))) {
         delete tk;
         return rc;
     }
     pg::RecommendCall& c = tk->call;
-    c.t = t; c.m = m; c.e = e; c.var_src = tk->var_src.data(); c.nv = (int)tk->var_src.size();
+    c.t = t; c.algos[0].m = m; c.n_algos = 1; c.e = e; c.var_src = tk->var_src.data(); c.nv = (int)tk->var_src.size();
     c.d_queries = d_queries; c.nq = nq; c.k = k;
-    c.d_rows = d_out_rows; c.d_recall = d_out_recall_scores; c.d_rank = d_out_rank_scores;
+    c.d_rows = d_out_rows; c.d_recall = d_out_recall_scores; c.d_rank = d_out_rank_scores; c.rank_stride = (size_t)nq * k;
     c.d_fused = d_out_fused; c.d_order = d_out_order; c.d_count = d_out_count;
     if ((rc = pg::pipe_run_acquire(ctx, &tk->run)) || (rc = pg::recommend_enqueue(ctx, c, tk->run, true))) {
         if (tk->run) pg::pipe_run_release(ctx, tk->run);
@@ -256,6 +321,29 @@ int pg_recommend_end(pg_ctx* ctx, pg_ticket* tk, double* scan_ms) {
     pg::pipe_run_release(ctx, tk->run);
     delete tk;
     return rc;
+}
+
+int pg_recommend_end_timed(pg_ctx* ctx, pg_ticket* tk, uint32_t timeout_us, double* scan_ms) {
+    PG_REQUIRE(ctx && tk, "pg_recommend_end_timed: NULL argument");
+    if (timeout_us) {
+        // poll the batch's event up to the deadline; the verification (and a possible re-plan) only starts once it has
+        // completed, so a PG_ERR_TIMEOUT leaves the ticket exactly as it was
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(timeout_us);
+        for (;;) {
+            const hipError_t q = hipEventQuery(tk->run->done);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) {
+                pg::set_error("pg_recommend_end_timed: %s", hipGetErrorString(q));
+                return PG_ERR_DEVICE;
+            }
+            if (std::chrono::steady_clock::now() >= deadline) {
+                pg::set_error("pg_recommend_end_timed: the batch did not complete within %u us (the ticket stays valid)", timeout_us);
+                return PG_ERR_TIMEOUT;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+    return pg_recommend_end(ctx, tk, scan_ms);
 }
 
 int pg_recommend_dnn3_dev(pg_ctx* ctx, const pg_table* t, const pg_model* m, const pg_expr* e, const char* rank_var,

@@ -22,26 +22,50 @@ constexpr uint32_t kPipeStatusWords = 640;
 int pipe_run_acquire(pg_ctx* ctx, PipeRun** out);      // from the context's pool (creates on demand)
 void pipe_run_release(pg_ctx* ctx, PipeRun* r);
 
-// VectorRecall → DNN3 rank → RankScore fusion → ItemRankScore sort for nq requests of k candidates each; every
-// pointer is a device pointer, layouts as pg_recommend_dnn3_dev.  var_src[i] = 1: variable i of `e` is the model's
-// score, 0: Item.Score (the recall score).
+// One entry of RankConf.RankAlgoList (service/rank/rank_service.go:259-289): a DNN3 over the table's rows, or an
+// FM + two-tower whose item field ids are integer columns of `fs` keyed by the same rows.
+constexpr int kMaxAlgos = 4;
+struct RankAlgoRef {
+    const pg_model* m = nullptr;
+    const pg_features* fs = nullptr;
+    int32_t item_field_cols[16] = {0};
+};
+// The diversity re-rank behind the sort (SortNames: [.., DPPSort], sort/dpp_sort.go:271-351): the first `candidates`
+// entries of every sorted list are the DPP candidates, the page is DPPWithWindow's pick sequence among them.
+struct RerankStage {
+    int kind = 0;                      // 0 none, 1 DPPSort
+    uint32_t candidates = 0;           // max(ctx.Size, CandidateCount) — fixed per call (callers keep top_n <= candidates)
+    pg_dpp_options dpp{};              // alpha, window, normalize_emb, norm_relevance_score; topn is the call's top_n
+};
+
+// VectorRecall → rank with every algorithm of the list → RankScore fusion → ItemRankScore sort → (DPPSort) for nq
+// requests of k candidates each; every pointer is a device pointer, layouts as pg_recommend_dnn3_dev.  var_src[i] = a:
+// variable i of `e` is algorithm a's score (its name in RankAlgoList), -1: Item.Score (the recall score).
 struct RecommendCall {
     const pg_table* t = nullptr;
-    const pg_model* m = nullptr;
+    RankAlgoRef algos[kMaxAlgos];
+    int n_algos = 0;
     const pg_expr* e = nullptr;
     const int* var_src = nullptr;
     int nv = 0;
     const float* d_queries = nullptr;
+    const int32_t* d_ufids = nullptr;  // [nq][ufid_stride] user field ids of the FM + two-tower algorithms (each reads its first nuf)
+    uint32_t ufid_stride = 0;
     uint32_t nq = 0, k = 0;
     uint64_t* d_rows = nullptr;
     float* d_recall = nullptr;
-    float* d_rank = nullptr;
+    float* d_rank = nullptr;           // n_algos planes of rank_stride floats, each [nq][k]
+    size_t rank_stride = 0;
     double* d_fused = nullptr;
     uint32_t* d_order = nullptr;
     uint32_t* d_count = nullptr;       // optional
+    RerankStage rerank;
+    uint32_t top_n = 0;                // re-rank: picks per request
+    uint32_t* d_pick = nullptr;        // re-rank: [nq][top_n] positions in the sorted list
+    uint32_t* d_pick_cnt = nullptr;    // re-rank: [nq]
 };
-// Resolve the expression's variables against the rank algorithm's name and "current_score" (module/item.go:189-212).
-int recommend_bind_vars(const pg_expr* e, const char* rank_var, std::vector<int>* var_src, const char* who);
+// Resolve the expression's variables against the rank algorithms' names and "current_score" (module/item.go:189-212).
+int recommend_bind_vars(const pg_expr* e, const char* const* names, int n_algos, std::vector<int>* var_src, const char* who);
 // Enqueue the batch (first = true) or its next recall plan plus everything behind it (first = false, after a failed
 // verification).  Takes ctx->mu for the duration of the enqueue only; never synchronises after the first use of a table.
 int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool first);
@@ -50,10 +74,34 @@ int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool firs
 // When the pilot threshold was too high for a few requests only, they are re-run here, synchronously and in place
 // (c != NULL: recall and everything behind it; c == NULL: a recall-only job), r->patched is set and *ok = true.
 int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok, const RecommendCall* c = nullptr);
+// the stages behind a recall whose outputs are already in c.d_rows / c.d_recall (the shard group's merged lists):
+// rank → fusion → sort → re-rank for requests [0, c.nq); d_err_out (device, [nq]) receives the RankScore flags
+int recommend_post_enqueue(pg_ctx* ctx, const RecommendCall& c, uint32_t* d_err_out);
 
 // misc.hip launchers (caller holds ctx->mu)
 int rows_to_local_locked(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t n, uint32_t* d_local,
                          uint8_t* d_owned);
 int uniform_offsets_locked(pg_ctx* ctx, uint32_t nq, uint32_t k, uint32_t* d_off);
+// the first C entries of every sorted list → their global rows and relevance (fused score), [nq][C]
+int sorted_head_launch(hipStream_t st, const uint32_t* d_order, const uint64_t* d_rows, const double* d_fused, uint32_t nq,
+                       uint32_t k, uint32_t C, uint64_t* d_c_rows, double* d_c_rel);
+// d_out[i][dim] = row d_global_rows[i] of `t` where the table holds it; other entries are left as they are
+int gather_global_rows_launch(hipStream_t st, const pg_table* t, const uint64_t* d_global_rows, uint32_t n, float* d_out);
+// The page of every request: entry order[q][pick[q][p]] (pick = NULL: p itself) of its list, p < top_n, as planes
+// [nq][top_n]: rows u64 | fused f64 | recall f32 | n_algos x rank f32.  Entries beyond pick_cnt[q] are padding
+// (row = UINT64_MAX, fused = NaN, recall = -inf, rank = 0).
+size_t page_entry_bytes(int n_algos);
+int page_launch(hipStream_t st, const uint32_t* d_order, const uint32_t* d_pick, const uint32_t* d_pick_cnt,
+                const uint64_t* d_rows, const float* d_recall, const float* d_rank, size_t rank_stride, int n_algos,
+                const double* d_fused, uint32_t nq, uint32_t k, uint32_t top_n, char* d_page);
+// dpp.hip: dpp_norm_relevance_score (sort/dpp_sort.go:382-405) for nq lists of n relevance scores on the device, in
+// the reference's operation order; mode 0 leaves them; d_bail[q] = 1 where the reference bails out ("all item score
+// is zero": the items stay as they are)
+int dpp_norm_relevance_launch(hipStream_t st, double* d_rel, uint32_t nq, uint32_t n, int mode, uint32_t* d_bail);
+// picks of bailed requests := 0 .. top_n - 1 (the sorted list's own order)
+int dpp_bail_fix_launch(hipStream_t st, const uint32_t* d_bail, uint32_t nq, uint32_t n, uint32_t top_n, uint32_t* d_pick,
+                        uint32_t* d_pick_cnt);
+// host form of the same normalisation (pg_dpp_ex and the coalescer's single-request DPP calls): returns false on bail-out
+bool dpp_norm_relevance_host(const double* rel, uint32_t n, int mode, double* out);
 
 }  // namespace pg

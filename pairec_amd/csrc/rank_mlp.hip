@@ -815,6 +815,19 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     return PG_OK;
 }
 
+// FM + two-tower straight from candidate rows: the per-item field ids are assembled on the device from the feature
+// columns (no host boxing), then ranked.  Caller holds ctx->mu; nothing synchronises (<= 16 item fields).
+int rank_fm2t_rows_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
+                              const float* d_user, const int32_t* d_ufids, const uint32_t* d_cand, const uint32_t* d_off,
+                              uint32_t n_req, uint32_t n_items, float* d_out) {
+    if (n_items == 0 || n_req == 0) return PG_OK;
+    void* ids;
+    int rc;
+    if ((rc = scratch_reserve(ctx, 0, (size_t)n_items * m->nif * 4, &ids))) return rc;
+    if ((rc = features_gather_i32_locked(ctx, fs, item_field_cols, m->nif, d_cand, n_items, (int32_t*)ids, "rank_fm2t_rows"))) return rc;
+    return rank_fm2t_dev_locked(ctx, m, d_user, d_ufids, (const int32_t*)ids, d_off, n_req, n_items, d_out);
+}
+
 // user-tower output uo[r][t_out] only: the "user embedding" an EasyRec / TorchRec vector model serves
 int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_user, uint32_t n_req, float* d_out) {
     if (n_req == 0) return PG_OK;
@@ -1049,15 +1062,8 @@ int pg_rank_fm2t_rows_dev(pg_ctx* ctx, const pg_model* m, const pg_features* fs,
     PG_REQUIRE(n_req <= 65535, "pg_rank_fm2t_rows_dev: at most 65535 requests per call");
     if (n_items == 0 || n_req == 0) return PG_OK;
     std::lock_guard<std::mutex> g(ctx->mu);
-    // the per-item field ids are assembled on the device from the feature columns (no host boxing)
-    void* ids;
-    int rc;
-    if ((rc = pg::scratch_reserve(ctx, 0, (size_t)n_items * m->nif * 4, &ids))) return rc;
-    if ((rc = pg::features_gather_i32_locked(ctx, fs, item_field_cols, m->nif, d_cand_rows, n_items, (int32_t*)ids,
-                                             "pg_rank_fm2t_rows_dev")))
-        return rc;
-    return pg::rank_fm2t_dev_locked(ctx, m, d_user_vecs, d_user_field_ids, (const int32_t*)ids, d_req_offsets, n_req,
-                                    n_items, d_out_scores);
+    return pg::rank_fm2t_rows_dev_locked(ctx, m, fs, item_field_cols, d_user_vecs, d_user_field_ids, d_cand_rows, d_req_offsets,
+                                         n_req, n_items, d_out_scores);
 }
 
 // host-buffer form of pg_rank_fm2t_rows_dev: what an IAlgorithm.Run of the EasyRec flavour passes — item ids resolved

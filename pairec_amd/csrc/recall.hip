@@ -1655,8 +1655,10 @@ int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_
 // statistics + shadow of a table (lazily, cached until the next upload / fill): int8 for dim 128 (two passes:
 // statistics, then quantisation with the table's scale), bf16 for dim 64 or when PG_SCREEN_BF16 is set (A/B runs).
 // Tables the screen cannot serve (other dims, no memory for the shadow) keep stats_valid = false.
+static std::mutex g_stats_build_mu;   // a table is shared by the contexts of a device (a coalescer's sibling): one of them builds
 int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     pg_table* t = const_cast<pg_table*>(tc);          // lazily computed cache
+    std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
     if (t->stats_valid || t->shadow_failed) return PG_OK;
     t->i4_ok = t->i4_failed = false;                  // the 4-bit shadow (recall_i4.hip) follows the rows too
     t->prefix_failures = 0;
@@ -2058,9 +2060,17 @@ int recall_job_enqueue(RecallJob* j) {
         return PG_ERR_DEVICE;
     }
     const int plan = j->plans[j->next_plan];
+    int rc;
+    // another call on this context may have grown the scratch arenas since recall_job_prepare (a re-plan reaches
+    // here long after it): fetch the pointers again rather than trust the cached ones
+    if ((rc = recall_scratch(ctx, t->dim, j->k, &j->rs))) return rc;
+    {
+        void* d_count;
+        if ((rc = scratch_reserve(ctx, 4, 4096, &d_count))) return rc;
+        j->d_count = (uint32_t*)d_count;
+    }
     PlanRun r(j);
     RecallScratch& rs = j->rs;
-    int rc;
     recall_init_kernel<<<(kMaxQueries * t->dim + 255) / 256, 256, 0, ctx->stream>>>(
         j->d_queries, j->nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
     PG_HIP(hipGetLastError());

@@ -37,7 +37,30 @@ def shard_range(total_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def shard_context(torch, pa, device: int):
+    """A library context and the torch stream it shares, for one rank of the sharded path.
+
+    The step interleaves torch ops (zero_, all_gather, all_reduce, gather) with library kernels; both must be
+    ordered on ONE stream.  torch's default stream has handle 0, which pg_init cannot adopt (NULL means "create a
+    private stream"), so the rank gets a dedicated torch.cuda.Stream: the library launches on it, and
+    sharded_step runs every torch op of the step under `torch.cuda.stream(...)` of the same stream (RCCL
+    collectives order themselves against the current stream)."""
+    stream = torch.cuda.Stream(device=torch.device("cuda", device))
+    ctx = pa.Context(device, stream.cuda_stream)
+    ctx.torch_stream = stream
+    return ctx, stream
+
+
 def sharded_step(engine, dist, torch, queries, nq: int, k: int, page: int = 0, dpp=None):
+    """One request batch (see _sharded_step), with every torch op of the step on the engine's stream."""
+    guard = getattr(engine, "stream_guard", None)
+    if guard is None:
+        return _sharded_step(engine, dist, torch, queries, nq, k, page, dpp)
+    with guard():
+        return _sharded_step(engine, dist, torch, queries, nq, k, page, dpp)
+
+
+def _sharded_step(engine, dist, torch, queries, nq: int, k: int, page: int = 0, dpp=None):
     """One request batch through recall → exchange → owner-computes rank → exchange → fuse + sort → (DPP).
 
     Returns (rows [nq,k] global ids, fused scores [nq,k] f64, order [nq,k] int32) — identical on every rank —
@@ -83,6 +106,12 @@ class GpuShardEngine:
         self.torch, self.ctx, self.table, self.model, self.expr = torch, ctx, table, model, expr
         dev = torch.device("cuda", ctx.device)
         self.dev = dev
+        # the torch stream the context launches on (shard_context): torch ops and library kernels of a step are
+        # ordered by being on the same stream, nothing else orders them
+        self.stream = getattr(ctx, "torch_stream", None)
+        if self.stream is None or self.stream.cuda_stream != ctx.stream_handle:
+            raise ValueError("GpuShardEngine: the context must share a torch.cuda.Stream (use dist.shard_context); "
+                             "a context with a private stream would race with the torch ops of the step")
         self.k_max = k_max
         n = nq_max * k_max
         i32, i64, f32, f64 = torch.int32, torch.int64, torch.float32, torch.float64
@@ -101,10 +130,14 @@ class GpuShardEngine:
         self.seg = torch.arange(0, n + 1, k_max, dtype=i32, device=dev)
         self.c_rows = self.c_rel = self.c_emb = self.picks = self.pick_cnt = None
         assert expr.var_names == ["gpu_dnn", "current_score"]       # column order of the vars slab below
+        torch.cuda.synchronize(dev)                                 # (arange above ran on torch's default stream)
 
     def _check(self, rc):
         from . import _lib
         _lib.check(rc)
+
+    def stream_guard(self):
+        return self.torch.cuda.stream(self.stream)
 
     def recall_local(self, queries, nq, k):
         rows, scores = self.t_rows[:nq, :k], self.t_scores[:nq, :k]

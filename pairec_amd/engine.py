@@ -25,10 +25,17 @@ def _ptr(a: np.ndarray):
 class Context:
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         self.L = _lib.load()
+        if stream is not None and int(stream) == 0:
+            # handle 0 is HIP's null stream (torch's default stream): pg_init reads NULL as "create a private
+            # stream", which would silently leave the caller's torch ops and the library's kernels unordered
+            raise ValueError("Context: cannot adopt the null stream (handle 0); pass a dedicated stream's handle "
+                             "(torch.cuda.Stream().cuda_stream) or None for a private one")
         h = C.c_void_p()
         _lib.check(self.L.pg_init(device, C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
         self.device = device
+        self.stream_handle = int(stream) if stream else None
+        self.torch_stream = None
 
     def close(self):
         if self.h:
@@ -43,6 +50,10 @@ class Context:
 
     def synchronize(self):
         _lib.check(self.L.pg_synchronize(self.h))
+
+    def debug_stall(self, ms: int) -> None:
+        """Occupy this context's stream for `ms` milliseconds (test aid for the deadline paths)."""
+        _lib.check(self.L.pg_debug_stall(self.h, int(ms)))
 
     def set_option(self, name: str, value) -> None:
         """Developer / test knob of this context (pg_set_option)."""
@@ -337,17 +348,63 @@ def recommend_dnn3(ctx: Context, table: Table, model: "RankModel", expr: "Expr",
 
 class Coalescer:
     """Cross-request batching (pg_coalescer_*): every method serves ONE request and may be called from any number
-    of threads at once (ctypes releases the GIL for the duration of the call); the library forms the batches."""
+    of threads at once (ctypes releases the GIL for the duration of the call); the library forms the batches.
+
+    Two ways to build one: the single-DNN form (model / expr / rank_var: pg_coalescer_create), or a scene
+    (`algos` = [(name, RankModel) or (name, RankModel, Features, item field column names)], expr, `dpp` =
+    {"candidates": C, "alpha": a, "window": w, "normalize_emb": True, "norm_relevance_score": 0},
+    query_model, trigger_table: pg_coalescer_create_scene)."""
 
     def __init__(self, ctx: Context, table: Table, k: int, model: Optional["RankModel"] = None,
                  expr: Optional["Expr"] = None, rank_var: str = "", max_batch: int = 0, max_wait_us: int = 0,
-                 depth: int = 0, max_top_n: int = 0, max_rank_items: int = 0):
+                 depth: int = 0, max_top_n: int = 0, max_rank_items: int = 0, timeout_us: int = 0,
+                 algos=None, dpp: Optional[dict] = None, query_model: Optional["RankModel"] = None,
+                 trigger_table: Optional[Table] = None, max_rerank_items: int = 0, max_hook_dim: int = 0):
         self.ctx, self.table, self.k = ctx, table, k
         self.max_top_n = max_top_n or k
-        cfg = _lib.PgCoalescerConfig(k, max_batch, max_wait_us, depth, max_top_n, max_rank_items)
+        cfg = _lib.PgCoalescerConfig(k, max_batch, max_wait_us, depth, max_top_n, max_rank_items, timeout_us)
         h = C.c_void_p()
-        _lib.check(ctx.L.pg_coalescer_create(ctx.h, table.h, model.h if model else None, expr.h if expr else None,
-                                             rank_var.encode() if rank_var else None, C.byref(cfg), C.byref(h)))
+        scene = algos is not None or dpp is not None or query_model is not None or trigger_table is not None \
+            or max_rerank_items or max_hook_dim
+        self.n_algos = 1 if model else 0
+        if not scene:
+            _lib.check(ctx.L.pg_coalescer_create(ctx.h, table.h, model.h if model else None, expr.h if expr else None,
+                                                 rank_var.encode() if rank_var else None, C.byref(cfg), C.byref(h)))
+        else:
+            if algos is None:
+                algos = [(rank_var, model)] if model else []
+            arr = (_lib.PgRankAlgo * max(len(algos), 1))()
+            self._keep = []
+            for i, a in enumerate(algos):
+                name, m = a[0], a[1]
+                nm = name.encode()
+                self._keep.append(nm)
+                arr[i].model = m.h
+                arr[i].name = nm
+                if len(a) > 2:
+                    feats, cols = a[2], a[3]
+                    idx = feats._cols(cols)
+                    carr = (C.c_int32 * len(idx))(*[int(x) for x in idx])
+                    self._keep.append(carr)
+                    arr[i].features = feats.h
+                    arr[i].item_field_cols = carr
+            sc = _lib.PgSceneConfig()
+            sc.base = cfg
+            sc.algos = arr
+            sc.n_algos = len(algos)
+            sc.rank_score = expr.h if expr else None
+            if dpp is not None:
+                sc.rerank = 1
+                sc.rerank_candidates = int(dpp["candidates"])
+                sc.dpp = _lib.PgDppOptions(float(dpp.get("alpha", 1.0)), 0, int(dpp.get("window", 10)),
+                                           int(dpp.get("normalize_emb", True)), 1,
+                                           int(dpp.get("norm_relevance_score", 0)), 1, 0)
+            sc.query_model = query_model.h if query_model else None
+            sc.trigger_table = trigger_table.h if trigger_table else None
+            sc.max_rerank_items = max_rerank_items
+            sc.max_hook_dim = max_hook_dim
+            self.n_algos = len(algos)
+            _lib.check(ctx.L.pg_coalescer_create_scene(ctx.h, table.h, C.byref(sc), C.byref(h)))
         self.h = h
 
     def destroy(self):
@@ -355,12 +412,24 @@ class Coalescer:
             _lib.check(self.ctx.L.pg_coalescer_destroy(self.h))
             self.h = None
 
+    def _recall_out(self):
+        return np.empty(self.k, dtype=np.uint64), np.empty(self.k, dtype=np.float32), C.c_uint32()
+
     def recall(self, query: np.ndarray):
         q = np.ascontiguousarray(query, dtype=np.float32).reshape(self.table.dim)
-        rows = np.empty(self.k, dtype=np.uint64)
-        scores = np.empty(self.k, dtype=np.float32)
-        cnt = C.c_uint32()
+        rows, scores, cnt = self._recall_out()
         _lib.check(self.ctx.L.pg_coalescer_recall(self.h, _ptr(q), _ptr(rows), _ptr(scores), C.byref(cnt)))
+        return rows, scores, cnt.value
+
+    def i2i_recall(self, trigger_row: int):
+        rows, scores, cnt = self._recall_out()
+        _lib.check(self.ctx.L.pg_coalescer_i2i_recall(self.h, int(trigger_row), _ptr(rows), _ptr(scores), C.byref(cnt)))
+        return rows, scores, cnt.value
+
+    def online_recall(self, user_vec: np.ndarray):
+        u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(-1)
+        rows, scores, cnt = self._recall_out()
+        _lib.check(self.ctx.L.pg_coalescer_online_recall(self.h, _ptr(u), _ptr(rows), _ptr(scores), C.byref(cnt)))
         return rows, scores, cnt.value
 
     def rank_dnn3(self, user_vec: np.ndarray, cand_rows: np.ndarray) -> np.ndarray:
@@ -370,17 +439,59 @@ class Coalescer:
         _lib.check(self.ctx.L.pg_coalescer_rank_dnn3(self.h, _ptr(u), _ptr(c), c.shape[0], _ptr(out)))
         return out
 
-    def recommend(self, user_vec: np.ndarray, top_n: int):
-        """→ (rows, recall scores, model scores, fused scores) of the first top_n entries of the sorted list, count."""
+    def rank(self, algo: int, user_vec: np.ndarray, cand_rows: np.ndarray, user_field_ids=None) -> np.ndarray:
+        u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(-1)
+        c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+        uf = None if user_field_ids is None else np.ascontiguousarray(user_field_ids, dtype=np.int32)
+        out = np.empty(c.shape[0], dtype=np.float32)
+        _lib.check(self.ctx.L.pg_coalescer_rank(self.h, algo, _ptr(u), _ptr(uf) if uf is not None else None, _ptr(c),
+                                                c.shape[0], _ptr(out)))
+        return out
+
+    def rank_fm2t(self, user_vec: np.ndarray, user_field_ids, cand_rows: np.ndarray) -> np.ndarray:
+        u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(-1)
+        uf = np.ascontiguousarray(user_field_ids, dtype=np.int32)
+        c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+        out = np.empty(c.shape[0], dtype=np.float32)
+        _lib.check(self.ctx.L.pg_coalescer_rank_fm2t(self.h, _ptr(u), _ptr(uf), _ptr(c), c.shape[0], _ptr(out)))
+        return out
+
+    def recommend(self, user_vec: np.ndarray, top_n: int, user_field_ids=None):
+        """→ (rows, recall scores, model scores, fused scores) of the page (the first top_n entries of the sorted list,
+        or DPPSort's picks when the scene has the stage), count.  With several rank algorithms (or user_field_ids)
+        the model scores are [n_algos][top_n]."""
         u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(self.table.dim)
         rows = np.empty(top_n, dtype=np.uint64)
         rec = np.empty(top_n, dtype=np.float32)
-        rnk = np.empty(top_n, dtype=np.float32)
         fus = np.empty(top_n, dtype=np.float64)
         cnt = C.c_uint32()
-        _lib.check(self.ctx.L.pg_coalescer_recommend(self.h, _ptr(u), top_n, _ptr(rows), _ptr(rec), _ptr(rnk),
-                                                     _ptr(fus), C.byref(cnt)))
+        if user_field_ids is None and self.n_algos <= 1:
+            rnk = np.empty(top_n, dtype=np.float32)
+            _lib.check(self.ctx.L.pg_coalescer_recommend(self.h, _ptr(u), top_n, _ptr(rows), _ptr(rec), _ptr(rnk),
+                                                         _ptr(fus), C.byref(cnt)))
+        else:
+            rnk = np.empty((self.n_algos, top_n), dtype=np.float32)
+            uf = None if user_field_ids is None else np.ascontiguousarray(user_field_ids, dtype=np.int32)
+            _lib.check(self.ctx.L.pg_coalescer_recommend_ex(self.h, _ptr(u), _ptr(uf) if uf is not None else None, top_n,
+                                                            _ptr(rows), _ptr(rec), _ptr(rnk), _ptr(fus), C.byref(cnt)))
         return rows, rec, rnk, fus, cnt.value
+
+    def dpp(self, cand_rows, rel, alpha: float, topn: int, window: int, normalize_emb: bool = True,
+            ensure_pos_similarity: bool = True, norm_relevance_score: int = 0, hook_emb: Optional[np.ndarray] = None,
+            has_table: bool = True):
+        """pg_coalescer_dpp: one request's DPPSort; → (picked indices, relevance scores as used)."""
+        r = np.ascontiguousarray(rel, dtype=np.float64)
+        n = r.shape[0]
+        c = np.ascontiguousarray(cand_rows, dtype=np.uint32) if has_table else None
+        hk = None if hook_emb is None else np.ascontiguousarray(hook_emb, dtype=np.float64).reshape(n, -1)
+        opt = _lib.PgDppOptions(alpha, topn, window, int(normalize_emb), int(ensure_pos_similarity),
+                                int(norm_relevance_score), int(has_table), 0 if hk is None else hk.shape[1])
+        out = np.zeros(max(topn, 1), dtype=np.uint32)
+        used = np.zeros(max(n, 1), dtype=np.float64)
+        cnt = C.c_uint32()
+        _lib.check(self.ctx.L.pg_coalescer_dpp(self.h, _ptr(c) if c is not None else None, _ptr(r), n, C.byref(opt),
+                                               _ptr(hk) if hk is not None else None, _ptr(out), C.byref(cnt), _ptr(used)))
+        return out[:cnt.value], used[:n]
 
     def stats(self) -> _lib.PgCoalescerStats:
         s = _lib.PgCoalescerStats()

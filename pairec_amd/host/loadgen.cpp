@@ -26,11 +26,35 @@ typedef struct {
     uint64_t checksum;            // sum over requests of (first row id + count): run-to-run comparable
 } ph_loadgen_result;
 
-// mode 0: pg_coalescer_recommend(top_n); mode 1: pg_coalescer_recall.
+// What a caller issues (one call = one "request" in the result):
+//   mode 0  pg_coalescer_recommend(top_n)            user vector u
+//   mode 1  pg_coalescer_recall                      user vector u
+//   mode 2  pg_coalescer_rank_fm2t                   user vector u + its field ids, `rank_items` candidate rows drawn from cand_pool
+//   mode 3  pg_coalescer_dpp                         `rank_items` candidate rows from cand_pool, relevance rel_pool (descending), *dpp
+//   mode 4  pg_coalescer_i2i_recall                  trigger row cand_pool[u]
+//   mode 5  pg_coalescer_online_recall               user vector u (width dim = the query model's d_user)
+//   mode 6  pg_coalescer_rank_dnn3                   user vector u, `rank_items` candidate rows from cand_pool
+typedef struct {
+    int mode;
+    const float* user_vecs;       // [n_users][dim]
+    uint32_t n_users, dim, k, top_n;
+    const int32_t* user_field_ids;   // [n_users][n_user_fields] (mode 2)
+    uint32_t n_user_fields;
+    const uint32_t* cand_pool;    // candidate rows; caller t's request i uses a window starting at a pseudo-random offset
+    uint32_t pool_size, rank_items;
+    const double* rel_pool;       // [rank_items] relevance scores, descending (mode 3)
+    const pg_dpp_options* dpp;    // mode 3
+} ph_loadgen_spec;
+
 // Every caller issues `warmup` unmeasured requests, waits at a barrier, then loops until `seconds` have elapsed.
-int ph_loadgen_run(pg_coalescer* c, int mode, const float* user_vecs, uint32_t n_users, uint32_t dim, uint32_t k,
-                   uint32_t top_n, uint32_t callers, uint32_t warmup, double seconds, ph_loadgen_result* out) {
-    if (!c || !user_vecs || !out || n_users == 0 || callers == 0) return -1;
+int ph_loadgen_run_ex(pg_coalescer* c, const ph_loadgen_spec* sp, uint32_t callers, uint32_t warmup, double seconds,
+                      ph_loadgen_result* out) {
+    if (!c || !sp || !out || callers == 0) return -1;
+    const int mode = sp->mode;
+    const float* user_vecs = sp->user_vecs;
+    const uint32_t n_users = sp->n_users, dim = sp->dim, k = sp->k, top_n = sp->top_n;
+    if ((mode != 3 && (!user_vecs || n_users == 0)) || ((mode == 2 || mode == 3 || mode == 4 || mode == 6) && (!sp->cand_pool || sp->pool_size < sp->rank_items + 1)))
+        return -1;
     using Clock = std::chrono::steady_clock;
     std::atomic<uint32_t> ready{0};
     std::atomic<bool> go{false}, stop{false};
@@ -39,17 +63,41 @@ int ph_loadgen_run(pg_coalescer* c, int mode, const float* user_vecs, uint32_t n
     std::vector<std::thread> th;
     for (uint32_t t = 0; t < callers; ++t) {
         th.emplace_back([&, t]() {
-            const uint32_t n_out = mode == 0 ? top_n : k;
+            const uint32_t n_out = std::max<uint32_t>(1, mode == 0 ? top_n : (mode == 2 || mode == 3 || mode == 6 ? sp->rank_items : k));
             std::vector<uint64_t> rows(n_out);
             std::vector<float> rec(n_out), rnk(n_out);
             std::vector<double> fus(n_out);
-            uint32_t u = t % n_users;
+            std::vector<uint32_t> idx(n_out);
+            uint32_t u = n_users ? t % n_users : 0;
+            uint64_t rng = 0x9E3779B97F4A7C15ull * (t + 1);
             auto one = [&]() -> int {
                 uint32_t cnt = 0;
-                const float* v = user_vecs + (size_t)u * dim;
-                u = (u + callers) % n_users;
-                int rc = mode == 0 ? pg_coalescer_recommend(c, v, top_n, rows.data(), rec.data(), rnk.data(), fus.data(), &cnt)
-                                   : pg_coalescer_recall(c, v, rows.data(), rec.data(), &cnt);
+                const float* v = user_vecs ? user_vecs + (size_t)u * dim : nullptr;
+                const uint32_t u_now = u;
+                if (n_users) u = (u + callers) % n_users;
+                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                const uint32_t off = sp->pool_size > sp->rank_items ? (uint32_t)((rng >> 33) % (sp->pool_size - sp->rank_items)) : 0u;
+                int rc;
+                switch (mode) {
+                    case 0: rc = pg_coalescer_recommend(c, v, top_n, rows.data(), rec.data(), rnk.data(), fus.data(), &cnt); break;
+                    case 1: rc = pg_coalescer_recall(c, v, rows.data(), rec.data(), &cnt); break;
+                    case 2:
+                        rc = pg_coalescer_rank_fm2t(c, v, sp->user_field_ids + (size_t)u_now * sp->n_user_fields, sp->cand_pool + off, sp->rank_items,
+                                                    rec.data());
+                        rows[0] = (uint64_t)(rec[0] * 1e6f);
+                        cnt = sp->rank_items;
+                        break;
+                    case 3:
+                        rc = pg_coalescer_dpp(c, sp->cand_pool + off, sp->rel_pool, sp->rank_items, sp->dpp, nullptr, idx.data(), &cnt, nullptr);
+                        rows[0] = idx[0];
+                        break;
+                    case 4: rc = pg_coalescer_i2i_recall(c, sp->cand_pool[off], rows.data(), rec.data(), &cnt); break;
+                    case 5: rc = pg_coalescer_online_recall(c, v, rows.data(), rec.data(), &cnt); break;
+                    default:
+                        rc = pg_coalescer_rank_dnn3(c, v, sp->cand_pool + off, sp->rank_items, rec.data());
+                        rows[0] = (uint64_t)(rec[0] * 1e6f);
+                        cnt = sp->rank_items;
+                }
                 if (rc == 0) sums[t] += rows[0] + cnt;
                 else errs[t]++;
                 return rc;
@@ -98,6 +146,21 @@ int ph_loadgen_run(pg_coalescer* c, int mode, const float* user_vecs, uint32_t n
         out->mean_ms = s / all.size();
     }
     return 0;
+}
+
+// the two original modes (0 recommend, 1 recall)
+int ph_loadgen_run(pg_coalescer* c, int mode, const float* user_vecs, uint32_t n_users, uint32_t dim, uint32_t k,
+                   uint32_t top_n, uint32_t callers, uint32_t warmup, double seconds, ph_loadgen_result* out) {
+    if (mode != 0 && mode != 1) return -1;
+    ph_loadgen_spec sp;
+    memset(&sp, 0, sizeof sp);
+    sp.mode = mode;
+    sp.user_vecs = user_vecs;
+    sp.n_users = n_users;
+    sp.dim = dim;
+    sp.k = k;
+    sp.top_n = top_n;
+    return ph_loadgen_run_ex(c, &sp, callers, warmup, seconds, out);
 }
 
 }  // extern "C"

@@ -487,7 +487,7 @@ struct GpuFaissAlgorithm : algorithm::IAlgorithm {
         if (e->coalesce) {
             // one request per call, many calls at once (one goroutine per recall, service/recall.go:129-145): the library
             // batches them into shared table passes
-            pg_coalescer* co = e->RecallCoalescer(req.K, err);
+            pg_coalescer* co = e->SceneCoalescer(req.K, err);
             if (!co) return false;
             if (pg_coalescer_recall(co, req.Vector.data(), rows.data(), scores.data(), &cnt) != PG_OK) {
                 if (err) *err = pg_err("pg_coalescer_recall");
@@ -521,7 +521,7 @@ struct GpuDnnAlgorithm : algorithm::IAlgorithm {
         if (!m) { if (err) *err = "dnn: model of " + name + " not loaded"; return false; }
         if (e->coalesce && m == e->model) {
             // one call per 100-item batch and goroutine (rank_service.go:264-289): batched across callers by the library
-            pg_coalescer* co = e->RankCoalescer(err);
+            pg_coalescer* co = e->SceneCoalescer(0, err);
             if (!co) return false;
             if (pg_coalescer_rank_dnn3(co, req.UserVector.data(), rows.data(), n, scores->data()) != PG_OK) {
                 if (err) *err = pg_err("pg_coalescer_rank_dnn3");
@@ -587,8 +587,20 @@ struct GpuFm2tAlgorithm : algorithm::IAlgorithm {
         }
         const uint32_t off[2] = {0, n};
         std::vector<float> scores(n);
-        if (pg_rank_fm2t_rows(e->ctx, e->fm2t, e->feats, cols.data(), req.UserVector.data(), req.UserFieldIds.data(), rows.data(), off, 1,
-                              scores.data()) != PG_OK) {
+        if (req.UserVector.size() != e->fm2t_d_user || req.UserFieldIds.size() < e->fm2t_nuf) {
+            if (err) *err = "fm2t: user vector / field ids do not match the model";
+            return false;
+        }
+        if (e->coalesce && columns == e->fm2t_columns) {
+            // 50 calls of 100 items per request, from as many goroutines (rank_service.go:264-289): one launch for all of them
+            pg_coalescer* co = e->SceneCoalescer(0, err);
+            if (!co) return false;
+            if (pg_coalescer_rank_fm2t(co, req.UserVector.data(), req.UserFieldIds.data(), rows.data(), n, scores.data()) != PG_OK) {
+                if (err) *err = pg_err("pg_coalescer_rank_fm2t");
+                return false;
+            }
+        } else if (pg_rank_fm2t_rows(e->ctx, e->fm2t, e->feats, cols.data(), req.UserVector.data(), req.UserFieldIds.data(), rows.data(), off, 1,
+                                     scores.data()) != PG_OK) {
             if (err) *err = pg_err("pg_rank_fm2t_rows");
             return false;
         }
@@ -611,7 +623,15 @@ struct GpuOnlineVectorAlgorithm : algorithm::IAlgorithm {
         std::vector<uint64_t> rows(k);
         std::vector<float> scores(k);
         uint32_t cnt = 0;
-        if (pg_online_vector_recall(e->ctx, e->fm2t, e->item_emb, data.emb.UserVector.data(), 1, k, rows.data(), scores.data(), &cnt) != PG_OK) {
+        if (data.emb.UserVector.size() != e->fm2t_d_user) { if (err) *err = "online vector: user vector width does not match the model"; return false; }
+        if (e->coalesce) {
+            pg_coalescer* co = e->OnlineCoalescer(k, err);
+            if (!co) return false;
+            if (pg_coalescer_online_recall(co, data.emb.UserVector.data(), rows.data(), scores.data(), &cnt) != PG_OK) {
+                if (err) *err = pg_err("pg_coalescer_online_recall");
+                return false;
+            }
+        } else if (pg_online_vector_recall(e->ctx, e->fm2t, e->item_emb, data.emb.UserVector.data(), 1, k, rows.data(), scores.data(), &cnt) != PG_OK) {
             if (err) *err = pg_err("pg_online_vector_recall");
             return false;
         }
@@ -706,7 +726,13 @@ struct GpuI2IVectorRecall : recall::Recall {
         std::vector<uint64_t> rows(k);
         std::vector<float> scores(k);
         uint32_t cnt = 0;
-        if (pg_i2i_recall(e->ctx, e->table, &row, 1, e->table, k, rows.data(), scores.data(), &cnt) != PG_OK) return ret;
+        if (e->coalesce) {
+            std::string cerr;
+            pg_coalescer* co = e->SceneCoalescer(k, &cerr);
+            if (!co || pg_coalescer_i2i_recall(co, row, rows.data(), scores.data(), &cnt) != PG_OK) return ret;
+        } else if (pg_i2i_recall(e->ctx, e->table, &row, 1, e->table, k, rows.data(), scores.data(), &cnt) != PG_OK) {
+            return ret;
+        }
         for (uint32_t i = 0; i < cnt; ++i) {
             auto item = std::make_shared<module::Item>(e->IdOfRow(rows[i]));
             item->RetrieveId = conf.Name;
@@ -732,7 +758,7 @@ struct GpuPageRecall : recall::Recall {
         std::string value, err;
         if (!e->user_vectors.VectorString(user->Id, &value, &err)) return ret;          // logged, empty result
         const std::vector<float> vec = recall::ParseVectorString(value);
-        if (vec.empty()) return ret;
+        if (vec.size() != e->dim) return ret;                                           // (logged) the library copies exactly dim floats
         pg_coalescer* co = e->PageCoalescer(conf, &err);
         if (!co) return ret;                                                            // logged, empty result
         const uint32_t size = (uint32_t)std::max(1, std::min(ctx ? ctx->Size : 10, std::min(conf.RecallCount, 1000)));
@@ -878,7 +904,11 @@ struct GpuDPPSort : sort::ISort {                        // sort/dpp_sort.go:108
         o.has_table = 1;
         std::vector<uint32_t> idx((size_t)std::max(size, 1));
         uint32_t cnt = 0;
-        const int rc = pg_dpp_ex(e->ctx, e->table, rows.data(), rel.data(), n, &o, nullptr, idx.data(), &cnt, used.data());
+        int rc;
+        pg_coalescer* co = e->coalesce ? e->SceneCoalescer(0, err) : nullptr;
+        // SortService.Sort runs once per request, requests overlap (sort/sort.go:65-125): equal-shaped DPP calls share a launch
+        if (co && n <= 1024) rc = pg_coalescer_dpp(co, rows.data(), rel.data(), n, &o, nullptr, idx.data(), &cnt, used.data());
+        else rc = pg_dpp_ex(e->ctx, e->table, rows.data(), rel.data(), n, &o, nullptr, idx.data(), &cnt, used.data());
         if (rc == PG_ERR_ARITH) return true;            // "all item score is zero": KernelMatrix errs, items stay as they are (:314-317)
         if (rc != PG_OK) {
             if (err) *err = pg_err("pg_dpp");
@@ -1102,8 +1132,8 @@ Engine::~Engine() {
             pg_coalescer_destroy(kv.second.first);
             pg_expr_free(kv.second.second);
         }
-        for (auto& kv : co_recall) pg_coalescer_destroy(kv.second);
-        if (co_rank) pg_coalescer_destroy(co_rank);
+        for (auto& kv : co_scene) pg_coalescer_destroy(kv.second);
+        for (auto& kv : co_online) pg_coalescer_destroy(kv.second);
         if (model) pg_model_destroy(ctx, model);
         for (auto& kv : named_models) pg_model_destroy(ctx, kv.second);
         if (fm2t) pg_model_destroy(ctx, fm2t);
@@ -1114,22 +1144,98 @@ Engine::~Engine() {
     }
 }
 
-pg_coalescer* Engine::RecallCoalescer(uint32_t k, std::string* err) {
+// One coalescer per recall depth serves every per-request plug-in call of the scene: vector / i2i recalls, both rank
+// algorithms (the DNN as algorithm 0, FM + two-tower behind it) and DPPSort.  k = 0: any (rank / sort calls do not
+// depend on the recall depth).  At most kMaxSceneCoalescers depths are kept (each holds slots and a sibling context's
+// scratch); a request with yet another K is served by the direct call.
+pg_coalescer* Engine::SceneCoalescer(uint32_t k, std::string* err) {
     std::lock_guard<std::mutex> g(co_mu);
-    auto it = co_recall.find(k);
-    if (it != co_recall.end()) return it->second;
-    pg_coalescer_config cfg;
-    memset(&cfg, 0, sizeof cfg);
-    cfg.k = k;
-    cfg.max_wait_us = coalesce_wait_us;
-    cfg.depth = coalesce_depth;
-    pg_coalescer* c = nullptr;
-    if (pg_coalescer_create(ctx, table, nullptr, nullptr, nullptr, &cfg, &c) != PG_OK) {
-        if (err) *err = std::string("pg_coalescer_create: ") + pg_last_error();
+    if (k == 0 && !co_scene.empty()) return co_scene.begin()->second;
+    if (k == 0) k = 5000;                          // sizes a rank batch: as many candidates as 256 requests x 5000
+    auto it = co_scene.find(k);
+    if (it != co_scene.end()) return it->second;
+    if (co_scene.size() >= kMaxSceneCoalescers) {
+        if (err) *err = "coalescer: too many distinct recall depths";
         return nullptr;
     }
-    co_recall[k] = c;
+    pg_scene_config sc;
+    memset(&sc, 0, sizeof sc);
+    sc.base.k = k;
+    sc.base.max_wait_us = coalesce_wait_us;
+    sc.base.depth = coalesce_depth;
+    sc.base.max_rank_items = 16384;
+    sc.base.timeout_us = coalesce_timeout_us;
+    pg_rank_algo algos[2];
+    memset(algos, 0, sizeof algos);
+    std::vector<int32_t> cols;
+    if (model) {
+        algos[sc.n_algos].model = model;
+        algos[sc.n_algos].name = "dnn";
+        sc.n_algos++;
+    }
+    if (fm2t && feats && !fm2t_columns.empty()) {
+        bool ok = true;
+        for (const auto& cname : fm2t_columns) {
+            const int idx = pg_features_column_index(feats, cname.c_str());
+            ok = ok && idx >= 0;
+            cols.push_back(idx);
+        }
+        if (ok) {
+            algos[sc.n_algos].model = fm2t;
+            algos[sc.n_algos].name = "fm2t";
+            algos[sc.n_algos].features = feats;
+            algos[sc.n_algos].item_field_cols = cols.data();
+            sc.n_algos++;
+        }
+    }
+    sc.algos = algos;
+    pg_coalescer* c = nullptr;
+    if (pg_coalescer_create_scene(ctx, table, &sc, &c) != PG_OK) {
+        if (err) *err = std::string("pg_coalescer_create_scene: ") + pg_last_error();
+        return nullptr;
+    }
+    co_scene[k] = c;
     return c;
+}
+
+// the OnlineVectorRecall's coalescer: user features → the vector model's user tower → top-k of the item-embedding table
+pg_coalescer* Engine::OnlineCoalescer(uint32_t k, std::string* err) {
+    std::lock_guard<std::mutex> g(co_mu);
+    auto it = co_online.find(k);
+    if (it != co_online.end()) return it->second;
+    if (co_online.size() >= kMaxSceneCoalescers) {
+        if (err) *err = "coalescer: too many distinct recall depths";
+        return nullptr;
+    }
+    pg_scene_config sc;
+    memset(&sc, 0, sizeof sc);
+    sc.base.k = k;
+    sc.base.max_wait_us = coalesce_wait_us;
+    sc.base.depth = coalesce_depth;
+    sc.base.timeout_us = coalesce_timeout_us;
+    sc.query_model = fm2t;
+    pg_coalescer* c = nullptr;
+    if (pg_coalescer_create_scene(ctx, item_emb, &sc, &c) != PG_OK) {
+        if (err) *err = std::string("pg_coalescer_create_scene: ") + pg_last_error();
+        return nullptr;
+    }
+    co_online[k] = c;
+    return c;
+}
+
+// configuration-time changes (a model or a feature column is replaced) retire the coalescers that hold the old objects;
+// the next call builds new ones.  Not to be called while requests are in flight.
+void Engine::DropCoalescers() {
+    std::lock_guard<std::mutex> g(co_mu);
+    for (auto& kv : co_page) {
+        pg_coalescer_destroy(kv.second.first);
+        pg_expr_free(kv.second.second);
+    }
+    co_page.clear();
+    for (auto& kv : co_scene) pg_coalescer_destroy(kv.second);
+    co_scene.clear();
+    for (auto& kv : co_online) pg_coalescer_destroy(kv.second);
+    co_online.clear();
 }
 
 pg_coalescer* Engine::PageCoalescer(const recconf::RecallConfig& conf, std::string* err) {
@@ -1151,6 +1257,7 @@ pg_coalescer* Engine::PageCoalescer(const recconf::RecallConfig& conf, std::stri
     cfg.max_wait_us = coalesce_wait_us;
     cfg.depth = coalesce_depth;
     cfg.max_top_n = (uint32_t)std::min(conf.RecallCount, 1000);
+    cfg.timeout_us = coalesce_timeout_us;
     pg_coalescer* c = nullptr;
     if (pg_coalescer_create(ctx, table, model, ex, conf.RankVar.c_str(), &cfg, &c) != PG_OK) {
         if (err) *err = std::string("pg_coalescer_create: ") + pg_last_error();
@@ -1159,22 +1266,6 @@ pg_coalescer* Engine::PageCoalescer(const recconf::RecallConfig& conf, std::stri
     }
     co_page[conf.Name] = std::make_pair(c, ex);
     return c;
-}
-
-pg_coalescer* Engine::RankCoalescer(std::string* err) {
-    std::lock_guard<std::mutex> g(co_mu);
-    if (co_rank) return co_rank;
-    pg_coalescer_config cfg;
-    memset(&cfg, 0, sizeof cfg);
-    cfg.k = 5000;                                  // sizes a rank batch: as many candidates as 256 requests x 5000
-    cfg.max_wait_us = coalesce_wait_us;
-    cfg.depth = coalesce_depth;
-    cfg.max_rank_items = 16384;
-    if (pg_coalescer_create(ctx, table, model, nullptr, nullptr, &cfg, &co_rank) != PG_OK) {
-        if (err) *err = std::string("pg_coalescer_create: ") + pg_last_error();
-        return nullptr;
-    }
-    return co_rank;
 }
 
 bool Engine::RowOfId(const std::string& id, uint32_t* row) const {
@@ -1229,6 +1320,7 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
         e->coalesce = true;
         e->coalesce_wait_us = (uint32_t)co.n("MaxWaitUs", 0);
         e->coalesce_depth = (uint32_t)co.n("Depth", 0);
+        e->coalesce_timeout_us = (uint32_t)co.n("TimeoutUs", 0);       // the EAS client's per-call timeout (eas/client.go:53-58)
     }
     const json::Value& ov = g.at("OnlineVector");          // the vector model's item side: item-tower outputs as a table
     if (ov.type == json::Value::Object) {
@@ -1269,6 +1361,7 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
         else if (kind == "fm2t") {
             std::vector<std::string> cols;
             for (const auto& c : a.at("ItemFieldColumns").arr) if (c.type == json::Value::String) cols.push_back(c.str);
+            if (e->fm2t_columns.empty()) e->fm2t_columns = cols;       // the scene coalescer's FM algorithm uses the first one's columns
             e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuFm2tAlgorithm>(e.get(), cols));
         }
     }
@@ -1485,6 +1578,7 @@ void ph_engine_destroy(void* h) { delete (Engine*)h; }
 int ph_engine_load_dnn3(void* h, int prec, const char* blob, size_t len) {
     Engine* e = (Engine*)h;
     if (!e || !blob) return -1;
+    e->DropCoalescers();                               // they hold the old model
     if (e->model) { pg_model_destroy(e->ctx, e->model); e->model = nullptr; }
     const int rc = pg_model_load(e->ctx, PG_MODEL_DNN3, (pg_prec)prec, blob, len, &e->model);
     if (rc != PG_OK) g_ph_err = pg_last_error();
@@ -1508,9 +1602,16 @@ int ph_engine_load_dnn3_named(void* h, const char* key, int prec, const char* bl
 int ph_engine_load_fm2t(void* h, int prec, const char* blob, size_t len) {
     Engine* e = (Engine*)h;
     if (!e || !blob) return -1;
+    e->DropCoalescers();                               // they hold the old model
     if (e->fm2t) { pg_model_destroy(e->ctx, e->fm2t); e->fm2t = nullptr; }
     const int rc = pg_model_load(e->ctx, PG_MODEL_FM_TWOTOWER, (pg_prec)prec, blob, len, &e->fm2t);
     if (rc != PG_OK) g_ph_err = pg_last_error();
+    else if (len >= 16) {
+        uint32_t hdr[4];
+        memcpy(hdr, blob, sizeof hdr);                  // u32 n_user_fields, n_item_fields, k, d_user (include/pairec_gpu.h)
+        e->fm2t_nuf = hdr[0];
+        e->fm2t_d_user = hdr[3];
+    }
     return rc;
 }
 
@@ -1518,6 +1619,7 @@ int ph_engine_load_fm2t(void* h, int prec, const char* blob, size_t len) {
 int ph_engine_set_feature_column(void* h, const char* name, const int32_t* values, uint64_t n) {
     Engine* e = (Engine*)h;
     if (!e || !name || !values || n != e->table_rows) { g_ph_err = "feature column: bad argument (one value per table row)"; return -1; }
+    e->DropCoalescers();
     if (!e->feats && pg_features_create(e->ctx, e->table_rows, &e->feats) != PG_OK) { g_ph_err = pg_last_error(); return -1; }
     const int rc = pg_features_set_column(e->ctx, e->feats, name, PG_F_I32, values, 0.0);
     if (rc != PG_OK) g_ph_err = pg_last_error();

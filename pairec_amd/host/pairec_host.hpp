@@ -345,11 +345,16 @@ public:
     bool coalesce = false;
     uint32_t coalesce_wait_us = 0, coalesce_depth = 0;
     std::mutex co_mu;
-    std::map<uint32_t, pg_coalescer*> co_recall;        // by k (RecallCount)
-    pg_coalescer* co_rank = nullptr;
+    uint32_t coalesce_timeout_us = 0;                    // UserDefineConfs.pairec_gpu.TimeoutUs: deadline of every coalesced call
+    static constexpr size_t kMaxSceneCoalescers = 4;
+    std::map<uint32_t, pg_coalescer*> co_scene;         // by k (RecallCount): recalls, both rank algorithms, DPPSort
+    std::map<uint32_t, pg_coalescer*> co_online;        // by k: OnlineVectorRecall over the item-embedding table
+    std::vector<std::string> fm2t_columns;              // the FM model's item field columns (the "fm2t" algorithm's configuration)
+    uint32_t fm2t_d_user = 0, fm2t_nuf = 0;
     std::map<std::string, std::pair<pg_coalescer*, pg_expr*>> co_page;   // page recalls: name → (coalescer, compiled RankScore)
-    pg_coalescer* RecallCoalescer(uint32_t k, std::string* err);
-    pg_coalescer* RankCoalescer(std::string* err);
+    pg_coalescer* SceneCoalescer(uint32_t k, std::string* err);
+    pg_coalescer* OnlineCoalescer(uint32_t k, std::string* err);
+    void DropCoalescers();
     pg_coalescer* PageCoalescer(const recconf::RecallConfig& conf, std::string* err);
     uint64_t table_rows = 0;
     uint32_t dim = 0;

@@ -12,11 +12,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pairec_amd as pa                                # noqa: E402
 from oracle import oracle as o                          # noqa: E402
-from pairec_amd.dist import GpuShardEngine, sharded_step   # noqa: E402
+from pairec_amd.dist import GpuShardEngine, shard_context, sharded_step   # noqa: E402
 from test_gpu_group import EXPR, oracle_pipeline       # noqa: E402
 
 n, d, k, R, top_n, dpp_c = 80_000, 128, 300, 6, 25, 90
-ctx = pa.Context(0, torch.cuda.current_stream().cuda_stream)
+ctx, _stream = shard_context(torch, pa, 0)
 t = pa.Table(ctx, n, d)
 t.fill_synthetic(o.SEED_TABLE)
 tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
@@ -26,6 +26,7 @@ ex = pa.Expr(EXPR)
 eng = GpuShardEngine(torch, ctx, t, m, ex, k, R)
 q = o.synth_rows(o.SEED_QUERY, 77, R, d)
 tq = torch.from_numpy(q).to("cuda:0")
+torch.cuda.synchronize()                                # the upload ran on the default stream
 rows, fused, order, page = sharded_step(eng, None, torch, tq, R, k, top_n, {"candidates": dpp_c, "alpha": 1.0, "window": 10})
 torch.cuda.synchronize()
 rows, page = rows.cpu().numpy().astype(np.uint64), page.cpu().numpy().astype(np.int64)
