@@ -283,44 +283,116 @@ def run_headline(pa, ctx, table, model, expr, qs_dev, args, R, K, sync, extra_ct
     return pipe, elapsed, pipe.scan_ms
 
 
+class LoadgenResult(C.Structure):
+    _fields_ = [("requests", C.c_uint64), ("errors", C.c_uint64), ("seconds", C.c_double), ("p50_ms", C.c_double),
+                ("p90_ms", C.c_double), ("p99_ms", C.c_double), ("max_ms", C.c_double), ("mean_ms", C.c_double),
+                ("checksum", C.c_uint64)]
+
+
+class LoadgenSpec(C.Structure):
+    _fields_ = [("mode", C.c_int), ("user_vecs", C.c_void_p), ("n_users", C.c_uint32), ("dim", C.c_uint32),
+                ("k", C.c_uint32), ("top_n", C.c_uint32), ("user_field_ids", C.c_void_p), ("n_user_fields", C.c_uint32),
+                ("cand_pool", C.c_void_p), ("pool_size", C.c_uint32), ("rank_items", C.c_uint32),
+                ("rel_pool", C.c_void_p), ("dpp", C.c_void_p)]
+
+
+_host_lib = None
+
+
+def host_lib():
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = C.CDLL(os.path.join(ROOT, "pairec_amd", "libpairec_host.so"))
+        _host_lib.ph_loadgen_run_ex.argtypes = [C.c_void_p, C.POINTER(LoadgenSpec), C.c_uint32, C.c_uint32, C.c_double,
+                                                C.POINTER(LoadgenResult)]
+    return _host_lib
+
+
+def loadgen(co, spec, callers, seconds, warm, flavour, items_per_request):
+    """`callers` host threads in closed loops of single-request calls (pairec_amd/host/loadgen.cpp) → a result row."""
+    res = LoadgenResult()
+    s0 = co.stats()
+    b0, r0 = s0.batches[flavour], s0.requests[flavour]
+    rc = host_lib().ph_loadgen_run_ex(co.h, C.byref(spec), callers, warm, seconds, C.byref(res))
+    s1 = co.stats()
+    if rc or res.errors:
+        raise RuntimeError("load generator failed (rc %d, %d errors)" % (rc, res.errors))
+    return {"callers": callers, "value": res.requests * items_per_request / res.seconds,
+            "requests_per_s": res.requests / res.seconds, "p50_ms": res.p50_ms, "p90_ms": res.p90_ms, "p99_ms": res.p99_ms,
+            "mean_ms": res.mean_ms, "avg_batch": (s1.requests[flavour] - r0) / max(s1.batches[flavour] - b0, 1),
+            "replans": s1.replans}
+
+
+DPP_CANDIDATES, DPP_WINDOW, DPP_ALPHA = 500, 10, 1.0       # cfg 5's DPPSort: top 500 by score, alpha 1, window 10
+
+
+def dpp_batch_rate(pa, ctx, table, model, expr, users, R, K, page, steps=6):
+    """The caller-made batch the coalesced recommend + DPP leg is compared with: R requests per call through the
+    device-level ABI (pg_recommend_dnn3_dev → pg_dpp_candidates_dev → pg_gather_owned_rows_dev → pg_dpp_batch_dev),
+    pages copied to the host, one batch at a time on one context."""
+    from pairec_amd import _lib
+    L, h = ctx.L, ctx.h
+    n, Cn = R * K, DPP_CANDIDATES
+    bufs = [ctx.malloc(n * 8), ctx.malloc(n * 4), ctx.malloc(n * 4), ctx.malloc(n * 8), ctx.malloc(n * 4), ctx.malloc(R * 4)]
+    c_rows, c_rel, c_emb = ctx.malloc(R * Cn * 8), ctx.malloc(R * Cn * 8), ctx.malloc(R * Cn * table.dim * 4)
+    picks, pcnt = ctx.malloc(R * page * 4), ctx.malloc(max(R, 256) * 4)
+    h_picks = np.zeros((R, page), np.uint32)
+    h_rows = np.zeros((R, K), np.uint64)
+
+    def step(i):
+        d_q = ctx.to_device(users[(i * R) % 512:(i * R) % 512 + R])
+        _lib.check(L.pg_recommend_dnn3_dev(h, table.h, model.h, expr.h, b"gpu_dnn", d_q, R, K, *bufs))
+        _lib.check(L.pg_dpp_candidates_dev(h, bufs[4], bufs[0], bufs[3], R, K, Cn, c_rows, c_rel))
+        _lib.check(L.pg_gather_owned_rows_dev(h, table.h, c_rows, R * Cn, c_emb))
+        _lib.check(L.pg_dpp_batch_dev(h, c_emb, c_rel, R, Cn, table.dim, DPP_ALPHA, page, DPP_WINDOW, 1, picks, pcnt))
+        ctx.d2h(h_picks, picks)
+        ctx.d2h(h_rows[:, :Cn].copy(), c_rows)
+        ctx.free(d_q)
+    step(0)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i + 1)
+    dt = (time.perf_counter() - t0) / steps
+    for p in bufs + [c_rows, c_rel, c_emb, picks, pcnt]:
+        ctx.free(p)
+    return {"ms_per_batch": dt * 1e3, "value": R * K / dt, "requests_per_s": R / dt}
+
+
 def concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K):
     """--callers host threads, each blocked in ONE pg_coalescer_recommend at a time (closed loop) — how pairec's
-    goroutines call IAlgorithm.Run / Recall.GetCandidateItems.  The library forms the batches."""
-    host = C.CDLL(os.path.join(ROOT, "pairec_amd", "libpairec_host.so"))
-
-    class Res(C.Structure):
-        _fields_ = [("requests", C.c_uint64), ("errors", C.c_uint64), ("seconds", C.c_double), ("p50_ms", C.c_double),
-                    ("p90_ms", C.c_double), ("p99_ms", C.c_double), ("max_ms", C.c_double), ("mean_ms", C.c_double),
-                    ("checksum", C.c_uint64)]
-    host.ph_loadgen_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                    C.c_uint32, C.c_uint32, C.c_double, C.POINTER(Res)]
+    goroutines call IAlgorithm.Run / Recall.GetCandidateItems.  The library forms the batches.  A second leg serves a
+    [ItemRankScore, DPPSort] scene the same way: the DPP stage runs inside the coalesced call."""
     users = np.ascontiguousarray(o.synth_rows(o.SEED_QUERY, 0, 1000, args.dim))
+    spec = LoadgenSpec(mode=0, user_vecs=users.ctypes.data, n_users=1000, dim=args.dim, k=K, top_n=args.page)
+    out = {}
     co = pa.Coalescer(ctx, table, K, model, expr, "gpu_dnn", max_top_n=args.page, depth=3)
-
-    def leg(callers, seconds, warm):
-        res = Res()
-        s0 = co.stats()
-        b0, r0 = s0.batches[2], s0.requests[2]
-        rc = host.ph_loadgen_run(co.h, 0, users.ctypes.data, 1000, args.dim, K, args.page, callers, warm, seconds,
-                                 C.byref(res))
-        s1 = co.stats()
-        if rc or res.errors:
-            raise RuntimeError("load generator failed (rc %d, %d errors)" % (rc, res.errors))
-        return {"callers": callers, "value": res.requests * K / res.seconds, "requests_per_s": res.requests / res.seconds,
-                "p50_ms": res.p50_ms, "p90_ms": res.p90_ms, "p99_ms": res.p99_ms, "mean_ms": res.mean_ms,
-                "avg_batch": (s1.requests[2] - r0) / max(s1.batches[2] - b0, 1), "replans": s1.replans}
     try:
-        main_leg = leg(args.callers, args.callers_seconds, 2)
-        sweep = [leg(c_, 1.5, 2) for c_ in (256, 512) if c_ != args.callers]
-        solo = leg(1, 1.0, 3)
+        main_leg = loadgen(co, spec, args.callers, args.callers_seconds, 2, 2, K)
+        sweep = [loadgen(co, spec, c_, 1.5, 2, 2, K) for c_ in (256, 512) if c_ != args.callers]
+        solo = loadgen(co, spec, 1, 1.0, 3, 2, K)
+        out = dict(main_leg)
+        out.update({"other_caller_counts": sweep, "solo_caller": solo})
     except RuntimeError as e:
-        co.destroy()
-        return {"error": str(e)}
+        out = {"error": str(e)}
     co.destroy()
-    out = dict(main_leg)
+    # the same scene with DPPSort behind the sort (cfg 5's stage: 500 candidates, page of ctx.Size, window 10)
+    co = pa.Coalescer(ctx, table, K, expr=expr, algos=[("gpu_dnn", model)], max_top_n=args.page, depth=3,
+                      dpp={"candidates": DPP_CANDIDATES, "alpha": DPP_ALPHA, "window": DPP_WINDOW})
+    try:
+        d_main = loadgen(co, spec, args.callers, max(2.0, args.callers_seconds / 2), 2, 2, K)
+        d_solo = loadgen(co, spec, 1, 1.0, 3, 2, K)
+        d_main.update({"solo_caller": d_solo, "vs_solo": d_main["value"] / d_solo["value"],
+                       "caller_made_batch": dpp_batch_rate(pa, ctx, table, model, expr, users, 256, K, args.page)})
+        d_main["vs_caller_made_batch"] = d_main["value"] / d_main["caller_made_batch"]["value"]
+        d_main["note"] = ("recall -> DNN3 -> RankScore -> sort -> DPPSort(%d candidates, window %d) in ONE coalesced call per "
+                          "request; the caller-made batch is the device-level ABI sequence for 256 requests, one batch at a time"
+                          % (DPP_CANDIDATES, DPP_WINDOW))
+        out["recommend_dpp"] = d_main
+    except RuntimeError as e:
+        out["recommend_dpp"] = {"error": str(e)}
+    co.destroy()
     out.update({
         "mode": "concurrent_callers", "page": args.page, "k": K, "unit": "ranked items/s",
-        "other_caller_counts": sweep, "solo_caller": solo,
         "note": "closed loop: every caller has one request outstanding (a goroutine blocked in IAlgorithm.Run); results "
                 "cross PCIe (the page: rows, three scores per entry); the coalescer batches up to 256 requests per table "
                 "pass, 3 batches in flight",
@@ -403,23 +475,110 @@ def cfg4_leg(pa, o, ctx, R, K):
     ctx.d2h(got, d_out)
     ref = o.fm2t_forward(fw, 1, users[0], ufids[0], ifids[:64])
     err = float(np.max(np.abs(got[:64].astype(np.float64) - ref)))
+    per_field_ms = ms
+    # the product path: candidates are rows of an item catalogue whose field ids are static columns, the item side is
+    # materialised once (pg_fm2t_item_rows_build: one 640-B record per item) and gathered with ONE access per candidate
+    n_cat = 20_000_000
+    feats = pa.Features(ctx, n_cat)
+    cols = ["if%d" % f for f in range(8)]
+    for c_ in cols:
+        feats.set_column(c_, pa.F_I32, rng.integers(0, vocab, n_cat).astype(np.int32))
+    t_b = time.perf_counter()
+    ir = pa.ItemRows(m, feats, cols)
+    build_s = time.perf_counter() - t_b
+    cand = rng.integers(0, n_cat, n).astype(np.uint32)
+    d_c = ctx.to_device(cand)
+
+    def call_ir():
+        _lib.check(ctx.L.pg_rank_fm2t_irows_dev(ctx.h, m.h, ir.h, d_u, d_uf, d_c, d_off, R, n, d_out))
+    for _ in range(3):
+        call_ir()
+    ctx.synchronize()
+    dev_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call_ir()
+        dev_ms.append(ctx.stats().last_rank_ms)
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    ms = float(np.mean(dev_ms))
+    ctx.d2h(got, d_out)
+    cat_ids = np.stack([feats.gather_i32([c_], cand[:64])[:, 0] for c_ in cols], axis=1)
+    ref = o.fm2t_forward(fw, 1, users[0], ufids[0], cat_ids)
+    err = float(np.max(np.abs(got[:64].astype(np.float64) - ref)))
+    ctx.free(d_c)
+    ir.destroy()
+    feats.destroy()
     for p in (d_u, d_uf, d_if, d_off, d_out):
         ctx.free(p)
+    callers = cfg4_callers_leg(pa, o, ctx, m, fw, users, ufids, R, K)
     m.destroy()
     gbs = n * FM2T_BYTES_PER_ITEM / (ms * 1e-3) / 1e9
     tf = n * FM2T_FLOPS_PER_ITEM / (ms * 1e-3) / 1e12
     return {
-        "workload": "configs[3]: FM(8+8 fields, k=16, 1M-row field tables) + two-tower(128-256-64) rank, %d x %d candidates, bf16" % (R, K),
+        "workload": "configs[3]: FM(8+8 fields, k=16, 1M-row field tables) + two-tower(128-256-64) rank, %d x %d candidates of a "
+                    "%d-item catalogue (item side materialised: one 640-B record per item), bf16" % (R, K, n_cat),
         "value": n / (ms * 1e-3), "unit": "ranked items/s", "device_ms_per_step": ms, "wall_ms_per_step": wall * 1e3,
         "max_abs_err_vs_oracle_64_items": err,
-        "roofline": {"bound": "hbm", "kernel": "pg::mlp_kernel<1,256,64,false,...> (FM + item tower)",
+        "item_records_build_s": build_s,
+        "per_field_path": {"device_ms_per_step": per_field_ms, "value": n / (per_field_ms * 1e-3),
+                           "note": "pg_rank_fm2t_dev: 8 ids + 8 scattered 64-B embedding rows per item (1056 B of HBM traffic)"},
+        "concurrent_callers": callers,
+        "roofline": {"bound": "hbm", "kernel": "pg::mlp_kernel<1,256,64,false,2,2,3,...> (FM + item tower over materialised item records)",
                      "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                      "bytes_per_item": FM2T_BYTES_PER_ITEM, "traffic": None,
-                     # the memory side moves one 128-B line per 64-B embedding row (scripts/micro/gather_gran.hip):
-                     "hbm_bytes_per_item_moved": 8 * 4 + 8 * 128,
-                     "frac_on_bytes_moved": n * (8 * 4 + 8 * 128) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     # the materialised record is five 128-B lines (544 B used)
+                     "hbm_bytes_per_item_moved": 640,
+                     "frac_on_bytes_moved": n * 640 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "mfma_achieved_tflops": tf, "mfma_frac": tf / MFMA_BF16_PEAK_TFLOPS},
     }
+
+
+def cfg4_callers_leg(pa, o, ctx, m, fw, users, ufids, R, K, n_items=4_000_000, callers=768):
+    """cfg 4 through per-request plug-in calls: the FM + two-tower IAlgorithm.Run (GpuFm2tAlgorithm) from `callers`
+    host threads, one call = one user's candidates (a whole request's 5000, and the reference's BatchCount = 100),
+    against one caller alone and against the caller-made batch through host buffers (pg_rank_fm2t_rows, 256 x 5000)."""
+    rng = np.random.default_rng(6)
+    feats = pa.Features(ctx, n_items)
+    cols = ["if%d" % f for f in range(8)]
+    for c_ in cols:
+        feats.set_column(c_, pa.F_I32, rng.integers(0, fw.vocab, n_items).astype(np.int32))
+    table = pa.Table(ctx, 4096, 128)                  # (the scene's table: the FM algorithm only reads the feature columns)
+    table.fill_synthetic(o.SEED_TABLE)
+    pool = np.ascontiguousarray(rng.integers(0, n_items, 1 << 20).astype(np.uint32))
+    users = np.ascontiguousarray(users, dtype=np.float32)
+    ufids = np.ascontiguousarray(ufids, dtype=np.int32)
+    out = {}
+    try:
+        # caller-made batch, host buffers in and out (what the coalesced calls can at best equal)
+        cand = np.ascontiguousarray(pool[:R * K])
+        off = (np.arange(R + 1) * K).astype(np.uint32)
+        ir = pa.ItemRows(m, feats, cols)
+        ir.rank(users, ufids, cand, off)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ir.rank(users, ufids, cand, off)
+        dt = (time.perf_counter() - t0) / 5
+        out["caller_made_batch"] = {"ms_per_batch": dt * 1e3, "value": R * K / dt,
+                                    "note": "pg_rank_fm2t_irows on 256 x 5000 candidates, inputs and scores across PCIe (pageable host buffers)"}
+        for per_call in (K, 100):
+            co = pa.Coalescer(ctx, table, K, algos=[("fm2t", m, ir)], max_rank_items=K, depth=3)
+            spec = LoadgenSpec(mode=2, user_vecs=users.ctypes.data, n_users=R, dim=128, k=K, top_n=0,
+                               user_field_ids=ufids.ctypes.data, n_user_fields=8, cand_pool=pool.ctypes.data,
+                               pool_size=pool.shape[0], rank_items=per_call)
+            leg = loadgen(co, spec, callers, 2.5, 2, 1, per_call)
+            solo = loadgen(co, spec, 1, 1.0, 3, 1, per_call)
+            leg.update({"items_per_call": per_call, "solo_caller": solo, "vs_solo": leg["value"] / solo["value"],
+                        "vs_caller_made_batch": leg["value"] / out["caller_made_batch"]["value"]})
+            out["calls_of_%d" % per_call] = leg
+            co.destroy()
+        ir.destroy()
+    except RuntimeError as e:
+        out["error"] = str(e)
+    table.destroy()
+    feats.destroy()
+    out["unit"] = "ranked items/s"
+    return out
 
 
 def cfg5_leg(pa, o, R, K, prec):

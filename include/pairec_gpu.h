@@ -288,6 +288,28 @@ int pg_rank_fm2t_rows(pg_ctx* ctx, const pg_model* m, const pg_features* fs, con
                       const float* user_vecs, const int32_t* user_field_ids, const uint32_t* cand_rows,
                       const uint32_t* req_offsets, uint32_t n_req, float* out_scores);
 
+/* ---- materialised item records (FM + two-tower) ---------------------------------------------------------------
+ * An item's field ids are static per item (the columns of `fs`), so the item side of model `m` can be laid out once, at
+ * model-load / column-set time: record r = the embeddings of row r's ids concatenated in field order (128 fp32) followed
+ * by their linear weights — 640 B, ONE contiguous gather per candidate at rank time instead of the id row plus
+ * n_item_fields scattered 64-B embedding rows (each of which costs a whole 128-B line of HBM traffic).  The records
+ * hold the very values the per-field path reads and the kernel sums them in the same order, so scores are bit-identical
+ * to pg_rank_fm2t_rows_dev in both precision modes; candidates outside the store read the columns' defaults as there.
+ * After a column changes (pg_features_set_column) or the model's field tables are reloaded, _update re-materialises
+ * rows [row0, row0 + nrows); the per-field path stays available for field-table hot-swaps. */
+typedef struct pg_item_rows pg_item_rows;
+int pg_fm2t_item_rows_build(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
+                            pg_item_rows** out);
+int pg_fm2t_item_rows_update(pg_ctx* ctx, pg_item_rows* ir, uint64_t row0, uint64_t nrows);
+int pg_fm2t_item_rows_destroy(pg_ctx* ctx, pg_item_rows* ir);
+/* pg_rank_fm2t_rows_dev / pg_rank_fm2t_rows over the materialised records */
+int pg_rank_fm2t_irows_dev(pg_ctx* ctx, const pg_model* m, const pg_item_rows* ir, const float* d_user_vecs,
+                           const int32_t* d_user_field_ids, const uint32_t* d_cand_rows, const uint32_t* d_req_offsets,
+                           uint32_t n_req, uint32_t n_items, float* d_out_scores);
+int pg_rank_fm2t_irows(pg_ctx* ctx, const pg_model* m, const pg_item_rows* ir, const float* user_vecs,
+                       const int32_t* user_field_ids, const uint32_t* cand_rows, const uint32_t* req_offsets, uint32_t n_req,
+                       float* out_scores);
+
 /* ---- the whole hot path in one call ------------------------------------------------------------
  * One request batch through VectorRecall.GetCandidateItems → RankService.Rank (one DNN3 rank algorithm) →
  * RankScore fusion → ItemRankScoreSort (service/user_recommend.go:83-151 restricted to the hot path),
@@ -425,6 +447,7 @@ typedef struct {
     const char* name;
     const pg_features* features;
     const int32_t* item_field_cols;
+    const pg_item_rows* item_rows;   /* optional: the materialised records of (model, features, columns) — preferred when set */
 } pg_rank_algo;
 typedef struct {
     pg_coalescer_config base;

@@ -30,6 +30,8 @@ EXPORTS = [
     "pg_coalescer_recommend", "pg_coalescer_stats", "pg_coalescer_create_scene", "pg_coalescer_i2i_recall",
     "pg_coalescer_online_recall", "pg_coalescer_rank", "pg_coalescer_rank_fm2t", "pg_coalescer_recommend_ex",
     "pg_coalescer_dpp", "pg_recommend_end_timed", "pg_debug_stall",
+    "pg_fm2t_item_rows_build", "pg_fm2t_item_rows_update", "pg_fm2t_item_rows_destroy", "pg_rank_fm2t_irows_dev",
+    "pg_rank_fm2t_irows",
     "pg_topk_merge_lists_dev", "pg_owned_compact_dev", "pg_scatter_f32_dev", "pg_dpp_candidates_dev",
     "pg_gather_owned_rows_dev", "pg_dpp_batch_dev",
     "pg_group_create", "pg_group_destroy", "pg_group_size", "pg_group_ctx", "pg_group_table", "pg_group_table_create",
@@ -63,7 +65,7 @@ class PgCoalescerConfig(C.Structure):
 
 class PgRankAlgo(C.Structure):
     _fields_ = [("model", C.c_void_p), ("name", C.c_char_p), ("features", C.c_void_p),
-                ("item_field_cols", C.POINTER(C.c_int32))]
+                ("item_field_cols", C.POINTER(C.c_int32)), ("item_rows", C.c_void_p)]
 
 
 class PgSceneConfig(C.Structure):
@@ -164,6 +166,11 @@ def load():
         "pg_coalescer_dpp": [vp, vp, vp, u32, P(PgDppOptions), vp, vp, P(u32), vp],
         "pg_recommend_end_timed": [vp, vp, u32, P(C.c_double)],
         "pg_debug_stall": [vp, u32],
+        "pg_fm2t_item_rows_build": [vp, vp, vp, vp, P(vp)],
+        "pg_fm2t_item_rows_update": [vp, vp, u64, u64],
+        "pg_fm2t_item_rows_destroy": [vp, vp],
+        "pg_rank_fm2t_irows_dev": [vp, vp, vp, vp, vp, vp, vp, u32, u32, vp],
+        "pg_rank_fm2t_irows": [vp, vp, vp, vp, vp, vp, vp, u32, vp],
         "pg_topk_merge_lists_dev": [vp, vp, vp, u32, u32, u32, i32, u32, vp, vp],
         "pg_owned_compact_dev": [vp, vp, vp, u32, u32, vp, vp, vp],
         "pg_scatter_f32_dev": [vp, vp, vp, vp, u32, vp],

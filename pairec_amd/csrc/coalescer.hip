@@ -200,6 +200,7 @@ struct pg_coalescer {
     std::condition_variable cv_dispatch;             // new request, slot freed, batch completed
     std::condition_variable cv_complete;             // batch enqueued
     std::deque<pg::Req*> queue[pg::kNumQueues];
+    uint64_t queue_items[pg::kNumQueues] = {0};      // rank queues: candidates waiting (kept in step with the deque under mu)
     std::vector<pg::Slot*> slots;
     std::vector<pg::Slot*> free_slots;
     std::deque<pg::Slot*> inflight;
@@ -398,10 +399,8 @@ int enqueue_rank_batch(pg_coalescer* c, Slot* s) {
     PG_HIP(hipMemcpyAsync(s->d_cand, s->h_cand, (size_t)s->n_items * 4, hipMemcpyHostToDevice, st));
     PG_HIP(hipMemcpyAsync(s->d_off, s->h_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, st));
     std::lock_guard<std::mutex> g(ctx->mu);
-    if (al.m->kind == PG_MODEL_DNN3) return rank_dnn3_dev_locked(ctx, al.m, c->t, s->d_vec, s->d_cand, s->d_off, nq, s->n_items, s->d_rank);
-    PG_HIP(hipMemcpyAsync(s->d_ufid, s->h_ufid, (size_t)nq * al.m->nuf * 4, hipMemcpyHostToDevice, st));
-    return rank_fm2t_rows_dev_locked(ctx, al.m, al.fs, al.item_field_cols, s->d_vec, s->d_ufid, s->d_cand, s->d_off, nq, s->n_items,
-                                     s->d_rank);
+    if (al.m->kind != PG_MODEL_DNN3) PG_HIP(hipMemcpyAsync(s->d_ufid, s->h_ufid, (size_t)nq * al.m->nuf * 4, hipMemcpyHostToDevice, st));
+    return rank_algo_locked(ctx, al, c->t, s->d_vec, s->d_ufid, s->d_cand, s->d_off, nq, s->n_items, s->d_rank);
 }
 
 int enqueue_dpp_batch(pg_coalescer* c, Slot* s) {
@@ -523,6 +522,7 @@ void take_batch(pg_coalescer* c, int kind, Slot* s) {
             q.pop_front();
             r->item0 = s->n_items;
             s->n_items += r->n;
+            c->queue_items[kind] -= r->n;
             s->reqs.push_back(r);
         }
     } else if (kind == kQDpp) {
@@ -616,22 +616,24 @@ void dispatcher_main(pg_coalescer* c) {
             any = true;
             bool full;
             if (f >= kQRank0) {
-                size_t items = 0;
-                for (const Req* r : qf) items += r->n;
-                full = qf.size() >= c->max_rank_reqs || items >= (size_t)c->max_batch * c->k;
+                full = qf.size() >= c->max_rank_reqs || c->queue_items[f] >= (uint64_t)c->max_batch * c->k;
             } else if (f == kQDpp) {
                 full = qf.size() >= dpp_batch_limit(c, qf.front()->key.n);
             } else {
                 full = qf.size() >= c->max_batch;
             }
             const auto deadline = qf.front()->arrived + std::chrono::microseconds(c->max_wait_us);
-            if (deadline < earliest) earliest = deadline;
-            if ((full || (idle && now >= deadline)) && (kind < 0 || qf.front()->arrived < c->queue[kind].front()->arrived)) kind = f;
+            // recall-based flavours: a table pass costs the same for 1 query as for 256, so a partial batch only goes out
+            // when the device has nothing to do; rank / DPP launches cost what their items cost, so a partial batch goes out
+            // as soon as its head has waited (a free slot permitting) and pipelines behind the running one
+            const bool per_item = f >= kQRank0 || f == kQDpp;
+            if ((idle || per_item) && deadline < earliest) earliest = deadline;      // (a deadline that time alone will make ready)
+            if ((full || ((idle || per_item) && now >= deadline)) && (kind < 0 || qf.front()->arrived < c->queue[kind].front()->arrived)) kind = f;
         }
         if (kind < 0 || c->free_slots.empty()) {
             // nothing ready (or `depth` batches already in flight: keep collecting).  A new request, a completion
             // or a released slot wakes us; an idle device additionally at the oldest request's deadline.
-            if (any && idle && kind < 0) c->cv_dispatch.wait_until(lk, earliest);
+            if (any && kind < 0 && !c->free_slots.empty() && earliest != Clock::time_point::max()) c->cv_dispatch.wait_until(lk, earliest);
             else c->cv_dispatch.wait(lk);
             continue;
         }
@@ -745,6 +747,7 @@ void completer_main(pg_coalescer* c) {
                     orphans.push_back(r);
                 }
                 q.clear();
+                c->queue_items[&q - c->queue] = 0;
             }
         }
         lk.unlock();
@@ -770,6 +773,7 @@ int submit_and_wait(pg_coalescer* c, Req* r) {
             return rc;
         }
         c->queue[r->queue].push_back(r);
+        if (r->queue >= kQRank0) c->queue_items[r->queue] += r->n;
     }
     c->cv_dispatch.notify_one();
     const bool timed = c->timeout_us != 0;
@@ -799,6 +803,7 @@ int submit_and_wait(pg_coalescer* c, Req* r) {
                 auto it = std::find(q.begin(), q.end(), r);
                 if (it != q.end()) {                   // (always, while the state is kQueued: both change under c->mu)
                     q.erase(it);
+                    if (r->queue >= kQRank0) c->queue_items[r->queue] -= r->n;
                     c->stats.timeouts++;
                     delete r;
                     set_error("pg_coalescer: deadline of %u us passed while the request was queued", c->timeout_us);
@@ -862,7 +867,9 @@ int pg_coalescer_create_scene(pg_ctx* ctx, const pg_table* t, const pg_scene_con
             PG_REQUIRE(al.model->d_item == t->dim, "pg_coalescer_create: DNN3 algorithm \"%s\" must rank the table's rows (d_item %u, dim %u)",
                        al.name, al.model->d_item, t->dim);
         } else {
-            PG_REQUIRE(al.features && al.item_field_cols, "pg_coalescer_create: FM + two-tower algorithm \"%s\" needs its feature columns", al.name);
+            PG_REQUIRE((al.features && al.item_field_cols) || al.item_rows,
+                       "pg_coalescer_create: FM + two-tower algorithm \"%s\" needs its feature columns or its materialised item records", al.name);
+            PG_REQUIRE(!al.item_rows || al.item_rows->m == al.model, "pg_coalescer_create: \"%s\": the item records belong to another model", al.name);
             PG_REQUIRE(al.model->nif <= 16, "pg_coalescer_create: \"%s\": at most 16 item fields", al.name);
             nuf_max = std::max(nuf_max, al.model->nuf);
         }
@@ -898,6 +905,7 @@ int pg_coalescer_create_scene(pg_ctx* ctx, const pg_table* t, const pg_scene_con
     for (int a = 0; a < c->n_algos; ++a) {
         c->algos[a].m = sc->algos[a].model;
         c->algos[a].fs = sc->algos[a].features;
+        c->algos[a].irows = sc->algos[a].item_rows;
         if (sc->algos[a].item_field_cols)
             for (uint32_t f = 0; f < sc->algos[a].model->nif && f < 16; ++f) c->algos[a].item_field_cols[f] = sc->algos[a].item_field_cols[f];
         c->algo_names[a] = sc->algos[a].name;

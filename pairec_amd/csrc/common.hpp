@@ -130,6 +130,27 @@ struct pg_model {
     std::vector<void*> allocs;
 };
 
+// features.hip owns the columns; rank_mlp.hip reads them when it materialises item records
+struct pg_features {
+    uint64_t rows = 0;
+    struct Column {
+        std::string name;
+        int dtype = 0;
+        void* d = nullptr;          // [rows] of the column type
+        double def = 0.0;           // default for rows outside the store
+    };
+    std::vector<Column> cols;
+};
+
+// materialised item side of an FM + two-tower model (rank_mlp.hip): [rows + 1][kItemRowFloats] fp32
+struct pg_item_rows {
+    const pg_model* m = nullptr;
+    const pg_features* fs = nullptr;
+    int32_t cols[16] = {0};
+    uint64_t rows = 0;
+    float* d = nullptr;
+};
+
 struct pg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -237,6 +258,8 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t, cons
                          const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items,
                          float* d_out);
 int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_user, uint32_t n_req, float* d_out);
+int rank_fm2t_irows_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_item_rows* ir, const float* d_user, const int32_t* d_ufids,
+                               const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items, float* d_out);
 int rank_fm2t_rows_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
                               const float* d_user, const int32_t* d_ufids, const uint32_t* d_cand, const uint32_t* d_off,
                               uint32_t n_req, uint32_t n_items, float* d_out);

@@ -18,17 +18,6 @@
 #include <string>
 #include <vector>
 
-struct pg_features {
-    uint64_t rows = 0;
-    struct Column {
-        std::string name;
-        int dtype = 0;
-        void* d = nullptr;          // [rows] of the column type
-        double def = 0.0;           // default for rows outside the store
-    };
-    std::vector<Column> cols;
-};
-
 namespace pg {
 
 struct ColDesc {

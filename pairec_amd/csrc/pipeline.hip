@@ -146,13 +146,9 @@ static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q
         const RankAlgoRef& al = c.algos[a];
         float* out = c.d_rank + (size_t)a * c.rank_stride + o;
         const float* users = c.d_queries + (size_t)q0 * c.t->dim;
-        if (al.m->kind == PG_MODEL_DNN3) {
-            if ((rc = rank_dnn3_dev_locked(ctx, al.m, c.t, users, ps.d_local, ps.d_off, nq, n, out))) return rc;
-        } else {
-            if ((rc = rank_fm2t_rows_dev_locked(ctx, al.m, al.fs, al.item_field_cols, users, c.d_ufids + (size_t)q0 * c.ufid_stride,
-                                                ps.d_local, ps.d_off, nq, n, out)))
-                return rc;
-        }
+        if ((rc = rank_algo_locked(ctx, al, c.t, users, c.d_ufids ? c.d_ufids + (size_t)q0 * c.ufid_stride : nullptr, ps.d_local, ps.d_off, nq, n,
+                                   out)))
+            return rc;
     }
     VarSrc vs;
     for (int i = 0; i < 32; ++i) vs.src[i] = i < c.nv ? (int8_t)c.var_src[i] : (int8_t)-1;
@@ -186,6 +182,13 @@ static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q
             return rc;
     }
     return PG_OK;
+}
+
+int rank_algo_locked(pg_ctx* ctx, const RankAlgoRef& al, const pg_table* t, const float* d_user, const int32_t* d_ufids,
+                     const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items, float* d_out) {
+    if (al.m->kind == PG_MODEL_DNN3) return rank_dnn3_dev_locked(ctx, al.m, t, d_user, d_cand, d_off, n_req, n_items, d_out);
+    if (al.irows) return rank_fm2t_irows_dev_locked(ctx, al.m, al.irows, d_user, d_ufids, d_cand, d_off, n_req, n_items, d_out);
+    return rank_fm2t_rows_dev_locked(ctx, al.m, al.fs, al.item_field_cols, d_user, d_ufids, d_cand, d_off, n_req, n_items, d_out);
 }
 
 int recommend_post_enqueue(pg_ctx* ctx, const RecommendCall& c, uint32_t* d_err_out) {

@@ -29,7 +29,11 @@ struct RankAlgoRef {
     const pg_model* m = nullptr;
     const pg_features* fs = nullptr;
     int32_t item_field_cols[16] = {0};
+    const pg_item_rows* irows = nullptr;   // FM + two-tower: the materialised item records (preferred over fs / columns)
 };
+// rank the candidates of n_req requests with one algorithm of the list (caller holds ctx->mu)
+int rank_algo_locked(pg_ctx* ctx, const RankAlgoRef& al, const pg_table* t, const float* d_user, const int32_t* d_ufids,
+                     const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items, float* d_out);
 // The diversity re-rank behind the sort (SortNames: [.., DPPSort], sort/dpp_sort.go:271-351): the first `candidates`
 // entries of every sorted list are the DPP candidates, the page is DPPWithWindow's pick sequence among them.
 struct RerankStage {

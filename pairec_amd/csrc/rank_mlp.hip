@@ -124,7 +124,7 @@ constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep, int bm = kBM) {
     const size_t nh1 = (prec && (size_t)bm * (kDIN + 2 * ch) * es <= 72 * 1024) ? 2 : 1;   // as NH1 in mlp_kernel
     const size_t tiles = (size_t)bm * (kDIN + nh1 * ch) * es;
     const size_t h2t = (size_t)bm * (h2 / ep + 4) * 4;
-    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)bm * 4;
+    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)bm * 4 * 3;     // w3, head bias, two FM partials per item (MODEL 3)
 }
 
 // MODEL 1 = DNN3, 2 = two-tower item side.  WM x WN = wave grid over (items, hidden columns); CH = layer-1
@@ -188,6 +188,73 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) store_x_quad<PREC>(XT, p * 8 + (tid >> 5), c, v[p]);
+        } else if constexpr (MODEL == 3) {
+            // two-tower from MATERIALISED item records (pg_fm2t_item_rows_build): the item's 8 field embeddings and linear
+            // weights are one contiguous 544-B record found from the candidate row alone — no ids → rows second hop, five
+            // 128-B lines per item instead of eight (a 64-B embedding row costs a whole line) plus the id line.  All 256
+            // threads gather: thread (r, kh) takes columns [kh FK/2, (kh+1) FK/2) of every field of item r (waves 0-1: kh = 0,
+            // waves 2-3: kh = 1), accumulates its half of s_k / q_k in the specification's order (user prefix first, fields
+            // ascending), reduces its half of the balanced tree; the tree's last level and `lin + 0.5 cross` are finished
+            // after the barrier — the same operations in the same order as the per-field path: bit-identical.
+            constexpr int NF = kDIN / FK;          // item fields
+            constexpr int HK = FK / 2;             // columns of a field per thread
+            constexpr int QPH = HK / 4;            // 16-B quads of a field per thread
+            static_assert(BM == 128 && HK % 4 == 0, "MODEL 3: 128-item tiles, field width a multiple of 8");
+            (void)c;
+            const uint32_t r = (uint32_t)tid & (BM - 1);
+            const int kh = tid >> 7;               // wave-uniform
+            const uint32_t idx = item0 + (r < cnt ? r : cnt - 1);
+            uint32_t row = a.cand_rows[idx];
+            row = row < a.irow_count ? row : a.irow_count;
+            const float4* rec = reinterpret_cast<const float4*>(a.irows + (size_t)row * kItemRowFloats);
+            const float* fu = a.fm_user + (size_t)req * kFmUserStride;
+            float4 v[NF][QPH];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int j = 0; j < QPH; ++j) v[f][j] = rec[f * (FK / 4) + kh * QPH + j];
+            float linv[NF];
+            if (kh == 0) {
+#pragma unroll
+                for (int j = 0; j < NF / 4; ++j) {
+                    const float4 l4 = rec[kDIN / 4 + j];
+                    linv[4 * j + 0] = l4.x; linv[4 * j + 1] = l4.y; linv[4 * j + 2] = l4.z; linv[4 * j + 3] = l4.w;
+                }
+            }
+            float s_[HK], q_[HK];
+#pragma unroll
+            for (int k = 0; k < HK; ++k) {
+                s_[k] = fu[1 + kh * HK + k];
+                q_[k] = fu[1 + kFmMaxK + kh * HK + k];
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int j = 0; j < QPH; ++j) {
+                    const float4 x = v[f][j];
+                    s_[4 * j + 0] = s_[4 * j + 0] + x.x; q_[4 * j + 0] = __fmaf_rn(x.x, x.x, q_[4 * j + 0]);
+                    s_[4 * j + 1] = s_[4 * j + 1] + x.y; q_[4 * j + 1] = __fmaf_rn(x.y, x.y, q_[4 * j + 1]);
+                    s_[4 * j + 2] = s_[4 * j + 2] + x.z; q_[4 * j + 2] = __fmaf_rn(x.z, x.z, q_[4 * j + 2]);
+                    s_[4 * j + 3] = s_[4 * j + 3] + x.w; q_[4 * j + 3] = __fmaf_rn(x.w, x.w, q_[4 * j + 3]);
+                    store_x_quad<PREC>(XT, (int)r, f * (FK / 4) + kh * QPH + j, x);
+                }
+#pragma unroll
+            for (int k = 0; k < HK; ++k) s_[k] = __fmaf_rn(s_[k], s_[k], -q_[k]);
+#pragma unroll
+            for (int off = 1; off < HK; off <<= 1)              // this half's levels of the balanced pairwise tree over k
+#pragma unroll
+                for (int k = 0; k < HK; k += 2 * off) s_[k] = s_[k] + s_[k + off];
+            float* const fmp = b3s + BM;                         // [2][BM] partial cross terms
+            fmp[kh * BM + r] = s_[0];
+            if (kh == 0) {
+                float lin = fu[0];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) lin = lin + linv[f];
+                b3s[r] = lin;
+            }
+            __syncthreads();
+            // the tree's last level (k = 0 with k = FK/2), then y_fm = lin + 0.5 cross
+            if (tid < BM) b3s[tid] = b3s[tid] + 0.5f * (fmp[tid] + fmp[BM + tid]);
         } else {
             // two-tower: ONE THREAD PER ITEM.  The thread reads its item's field ids, then walks the fields in order:
             // 64 B (FK = 16) of each field's embedding row as 16-B loads, FM sums s_k / q_k accumulated in registers in
@@ -676,6 +743,18 @@ constexpr int kFmBM = 128;
 template <int PREC, int TH, int TO, int FK>
 static int launch_fm2t_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
     int rc;
+    if (a.irows) {               // candidates come as rows of materialised item records (MODEL 3)
+        if constexpr (PREC == 1) {
+            constexpr size_t lds = mlp_lds_bytes(1, TO, 128, 1, kFmBM);
+            if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, TH, TO, false, 2, 2, 3, 128, 1, 2, FK, kFmBM>, lds))) return rc;
+            mlp_kernel<1, TH, TO, false, 2, 2, 3, 128, 1, 2, FK, kFmBM><<<grid, 256, lds, ctx->stream>>>(a);
+        } else {
+            constexpr size_t lds = mlp_lds_bytes(0, TO, 128, 1);
+            if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, TH, TO, false, 2, 2, 3, 128, 1, 1, FK>, lds))) return rc;
+            mlp_kernel<0, TH, TO, false, 2, 2, 3, 128, 1, 1, FK><<<grid, 256, lds, ctx->stream>>>(a);
+        }
+        return PG_OK;
+    }
     if constexpr (PREC == 1) {
         // (three workgroups per CU — 64-column layer-1 chunks, 48 KB of LDS, <= 168 registers — measured 0.53 vs 0.45 ms:
         //  twice the chunks and barriers per tile cost more than the extra waves hide)
@@ -774,7 +853,8 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
 
 static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_user,
                                 const int32_t* d_ufids, const int32_t* d_ifids, const uint32_t* d_off,
-                                uint32_t n_req, uint32_t n_items, float* d_out) {
+                                uint32_t n_req, uint32_t n_items, float* d_out, const pg_item_rows* ir = nullptr,
+                                const uint32_t* d_cand = nullptr) {
     if (n_items == 0 || n_req == 0) return PG_OK;
     const uint32_t bm = m->prec ? (uint32_t)kFmBM : (uint32_t)kBM;
     const uint32_t max_tiles = n_items / bm + n_req;
@@ -795,6 +875,11 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     a.field_emb = m->d_field_emb;
     a.field_lin = m->d_field_lin;
     a.item_field_ids = d_ifids;
+    if (ir) {
+        a.irows = ir->d;
+        a.irow_count = (uint32_t)ir->rows;
+        a.cand_rows = d_cand;
+    }
     a.vocab = m->vocab;
     a.n_user_fields = m->nuf;
     a.fm_user = rs.fm_user;
@@ -813,6 +898,76 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     ctx->stats.rank_calls++;
     ctx->stats.rank_items += n_items;
     return PG_OK;
+}
+
+// ---- materialised item records --------------------------------------------------------------------------------
+// An item's field ids are static, so its side of the model can be laid out once: record r = the embeddings of the ids in
+// row r of the item-field columns, concatenated in field order (kDIN floats), followed by their linear weights — ONE
+// contiguous gather per candidate at rank time instead of the id row plus n_item_fields scattered embedding rows.  Record
+// `rows` (one past the last item) holds the columns' defaults: what a candidate outside the feature store reads.
+__global__ void item_rows_build_kernel(ItemRowCols cols, const float* const* __restrict__ field_emb,
+                                       const float* const* __restrict__ field_lin, uint32_t nuf, uint32_t nif, uint32_t fk,
+                                       uint32_t vocab, uint64_t fs_rows, uint64_t row0, uint64_t nrows, float* __restrict__ out) {
+    // one thread per 16-B quad of a record: quads [0, 32) embeddings, [32, 40) linear weights + padding
+    constexpr uint32_t QPR = kItemRowFloats / 4;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = gid / QPR;
+    const uint32_t qd = (uint32_t)(gid % QPR);
+    if (i >= nrows) return;
+    const uint64_t row = row0 + i;
+    auto id_of = [&](uint32_t f) -> int32_t {
+        int64_t v;
+        if (row >= fs_rows) v = (int64_t)cols.def[f];
+        else v = cols.dtype[f] == PG_F_I32 ? (int64_t)((const int32_t*)cols.base[f])[row] : ((const int64_t*)cols.base[f])[row];
+        v = v > 2147483647ll ? 2147483647ll : (v < -2147483648ll ? -2147483648ll : v);      // as features_gather_i32
+        int32_t id = (int32_t)v;
+        return id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);                // as the per-field gather clamps
+    };
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qd < kDIN / 4) {
+        const uint32_t f = qd * 4 / fk, c0 = qd * 4 % fk;
+        o = *reinterpret_cast<const float4*>(field_emb[nuf + f] + (size_t)id_of(f) * fk + c0);
+    } else {
+        float l[4] = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t f = (qd - kDIN / 4) * 4 + j;
+            if (f < nif) l[j] = field_lin[nuf + f][id_of(f)];
+        }
+        o = make_float4(l[0], l[1], l[2], l[3]);
+    }
+    *reinterpret_cast<float4*>(out + row * kItemRowFloats + 4 * qd) = o;
+}
+
+int item_rows_fill_locked(pg_ctx* ctx, pg_item_rows* ir, uint64_t row0, uint64_t nrows) {
+    const pg_model* m = ir->m;
+    ItemRowCols cols;
+    memset(&cols, 0, sizeof cols);
+    for (uint32_t f = 0; f < m->nif; ++f) {
+        const int32_t ci = ir->cols[f];
+        if (ci < 0 || (size_t)ci >= ir->fs->cols.size()) {
+            set_error("pg_fm2t_item_rows: column index %d out of range (%zu columns)", ci, ir->fs->cols.size());
+            return PG_ERR_INVALID;
+        }
+        const auto& c = ir->fs->cols[(size_t)ci];
+        if (c.dtype != PG_F_I32 && c.dtype != PG_F_I64) {
+            set_error("pg_fm2t_item_rows: column \"%s\" is not an integer column", c.name.c_str());
+            return PG_ERR_INVALID;
+        }
+        cols.base[f] = c.d;
+        cols.dtype[f] = c.dtype;
+        cols.def[f] = c.def;
+    }
+    if (nrows == 0) return PG_OK;
+    const uint64_t threads = nrows * (kItemRowFloats / 4);
+    item_rows_build_kernel<<<(uint32_t)((threads + 255) / 256), 256, 0, ctx->stream>>>(cols, m->d_field_emb, m->d_field_lin, m->nuf, m->nif, m->k,
+                                                                                      m->vocab, ir->fs->rows, row0, nrows, ir->d);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int rank_fm2t_irows_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_item_rows* ir, const float* d_user, const int32_t* d_ufids,
+                               const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items, float* d_out) {
+    return rank_fm2t_dev_locked(ctx, m, d_user, d_ufids, nullptr, d_off, n_req, n_items, d_out, ir, d_cand);
 }
 
 // FM + two-tower straight from candidate rows: the per-item field ids are assembled on the device from the feature
@@ -1145,6 +1300,109 @@ int pg_rank_fm2t(pg_ctx* ctx, const pg_model* m, const float* user_vecs, const i
     PG_HIP(hipMemcpyAsync(d_if, item_field_ids, ifb, hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(hipMemcpyAsync(d_o, req_offsets, ob, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = pg::rank_fm2t_dev_locked(ctx, m, d_u, d_uf, d_if, d_o, n_req, n_items, d_s))) return rc;
+    PG_HIP(hipMemcpyAsync(out_scores, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
+    return pg::finish_rank_timing(ctx);
+}
+
+int pg_fm2t_item_rows_build(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,
+                            pg_item_rows** out) {
+    PG_REQUIRE(ctx && m && fs && item_field_cols && out, "pg_fm2t_item_rows_build: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER, "pg_fm2t_item_rows_build: model is not FM_TWOTOWER");
+    PG_REQUIRE(m->nif <= 16 && m->nif * m->k == (uint32_t)pg::kDIN, "pg_fm2t_item_rows_build: unsupported item side (%u fields x %u)", m->nif, m->k);
+    PG_REQUIRE(fs->rows < 0xFFFFFFFEull, "pg_fm2t_item_rows_build: too many rows");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    PG_HIP(hipSetDevice(ctx->device));
+    pg_item_rows* ir = new pg_item_rows();
+    ir->m = m;
+    ir->fs = fs;
+    ir->rows = fs->rows;
+    for (uint32_t f = 0; f < m->nif; ++f) ir->cols[f] = item_field_cols[f];
+    const size_t bytes = (size_t)(fs->rows + 1) * pg::kItemRowFloats * 4;
+    const hipError_t e = hipMalloc((void**)&ir->d, bytes);
+    if (e != hipSuccess) {
+        pg::set_error("pg_fm2t_item_rows_build: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        delete ir;
+        return PG_ERR_NOMEM;
+    }
+    int rc;
+    if ((rc = pg::item_rows_fill_locked(ctx, ir, 0, fs->rows + 1))) {       // + the defaults' record
+        hipFree(ir->d);
+        delete ir;
+        return rc;
+    }
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    *out = ir;
+    return PG_OK;
+}
+
+int pg_fm2t_item_rows_update(pg_ctx* ctx, pg_item_rows* ir, uint64_t row0, uint64_t nrows) {
+    PG_REQUIRE(ctx && ir, "pg_fm2t_item_rows_update: NULL argument");
+    PG_REQUIRE(row0 + nrows <= ir->rows, "pg_fm2t_item_rows_update: rows %llu..%llu outside the store", (unsigned long long)row0,
+               (unsigned long long)(row0 + nrows));
+    std::lock_guard<std::mutex> g(ctx->mu);
+    int rc;
+    if ((rc = pg::item_rows_fill_locked(ctx, ir, row0, nrows))) return rc;
+    if ((rc = pg::item_rows_fill_locked(ctx, ir, ir->rows, 1))) return rc;     // the defaults may have changed with the column
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+int pg_fm2t_item_rows_destroy(pg_ctx* ctx, pg_item_rows* ir) {
+    PG_REQUIRE(ctx, "pg_fm2t_item_rows_destroy: NULL context");
+    if (!ir) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ir->d) PG_HIP(hipFree(ir->d));
+    delete ir;
+    return PG_OK;
+}
+
+int pg_rank_fm2t_irows_dev(pg_ctx* ctx, const pg_model* m, const pg_item_rows* ir, const float* d_user_vecs,
+                           const int32_t* d_user_field_ids, const uint32_t* d_cand_rows, const uint32_t* d_req_offsets,
+                           uint32_t n_req, uint32_t n_items, float* d_out_scores) {
+    PG_REQUIRE(ctx && m && ir && d_user_vecs && d_user_field_ids && d_cand_rows && d_req_offsets && d_out_scores,
+               "pg_rank_fm2t_irows_dev: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER && ir->m == m, "pg_rank_fm2t_irows_dev: the item records belong to another model");
+    PG_REQUIRE(n_req <= 65535, "pg_rank_fm2t_irows_dev: at most 65535 requests per call");
+    if (n_items == 0 || n_req == 0) return PG_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return pg::rank_fm2t_irows_dev_locked(ctx, m, ir, d_user_vecs, d_user_field_ids, d_cand_rows, d_req_offsets, n_req, n_items, d_out_scores);
+}
+
+int pg_rank_fm2t_irows(pg_ctx* ctx, const pg_model* m, const pg_item_rows* ir, const float* user_vecs,
+                       const int32_t* user_field_ids, const uint32_t* cand_rows, const uint32_t* req_offsets, uint32_t n_req,
+                       float* out_scores) {
+    PG_REQUIRE(ctx && m && ir && req_offsets, "pg_rank_fm2t_irows: NULL argument");
+    PG_REQUIRE(m->kind == PG_MODEL_FM_TWOTOWER && ir->m == m, "pg_rank_fm2t_irows: the item records belong to another model");
+    PG_REQUIRE(n_req <= 65535, "pg_rank_fm2t_irows: at most 65535 requests per call");
+    if (n_req == 0) return PG_OK;
+    PG_REQUIRE(req_offsets[0] == 0, "pg_rank_fm2t_irows: req_offsets[0] must be 0");
+    for (uint32_t r = 0; r < n_req; ++r)
+        PG_REQUIRE(req_offsets[r + 1] >= req_offsets[r], "pg_rank_fm2t_irows: req_offsets not monotone at %u", r);
+    const uint32_t n_items = req_offsets[n_req];
+    if (n_items == 0) return PG_OK;
+    PG_REQUIRE(user_vecs && user_field_ids && cand_rows && out_scores, "pg_rank_fm2t_irows: NULL argument");
+    for (size_t i = 0; i < (size_t)n_req * m->nuf; ++i)
+        PG_REQUIRE(user_field_ids[i] >= 0 && (uint32_t)user_field_ids[i] < m->vocab,
+                   "pg_rank_fm2t_irows: user field id %d outside vocab %u", user_field_ids[i], m->vocab);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    int rc;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t ub = (size_t)n_req * m->d_user * 4, ufb = (size_t)n_req * m->nuf * 4, cb = (size_t)n_items * 4;
+    const size_t ob = (size_t)(n_req + 1) * 4, sb = (size_t)n_items * 4;
+    if ((rc = pg::scratch_reserve(ctx, 5, al(ub) + al(ufb) + al(cb) + al(ob) + al(sb), &buf))) return rc;
+    char* b = (char*)buf;
+    float* d_u = (float*)b; b += al(ub);
+    int32_t* d_uf = (int32_t*)b; b += al(ufb);
+    uint32_t* d_c = (uint32_t*)b; b += al(cb);
+    uint32_t* d_o = (uint32_t*)b; b += al(ob);
+    float* d_s = (float*)b;
+    PG_HIP(hipMemcpyAsync(d_u, user_vecs, ub, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_uf, user_field_ids, ufb, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_c, cand_rows, cb, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipMemcpyAsync(d_o, req_offsets, ob, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pg::rank_fm2t_irows_dev_locked(ctx, m, ir, d_u, d_uf, d_c, d_o, n_req, n_items, d_s))) return rc;
     PG_HIP(hipMemcpyAsync(out_scores, d_s, sb, hipMemcpyDeviceToHost, ctx->stream));
     return pg::finish_rank_timing(ctx);
 }

@@ -40,6 +40,14 @@ constexpr int kBM = 128;       // items per workgroup tile
 constexpr int kDIN = 128;      // gathered input width
 constexpr int kFmMaxK = 32;        // largest FM embedding width (item fields x width = kDIN)
 constexpr int kFmUserStride = 1 + 2 * kFmMaxK;   // per-request FM prefix: lin, s[<=32] at +1, q[<=32] at +33
+constexpr int kItemRowFloats = 160;    // a materialised item record: 128 embedding floats + <= 16 linear weights, padded to 5 x 128 B
+
+// the item-field columns of a feature store, by value (kernel argument of the item-record builder)
+struct ItemRowCols {
+    const void* base[16];
+    double def[16];
+    int32_t dtype[16];
+};
 
 struct MlpArgs {
     const uint32_t* tile_req;
@@ -58,6 +66,11 @@ struct MlpArgs {
     uint32_t vocab;
     uint32_t n_user_fields;          // the item fields' tables follow the user fields' in field_emb / field_lin
     const float* fm_user;            // [n_req][kFmUserStride]: linU, sU[k] at +1, qU[k] at +33
+    // two-tower gather from materialised item records (MODEL 3): record r = [kDIN embedding floats | n_item_fields
+    // linear weights | pad] at irows + r * kItemRowFloats; candidates at or past irow_count read record irow_count
+    // (the columns' defaults)
+    const float* irows;
+    uint32_t irow_count;
     // per request / shared vectors
     const float* c1;
     uint32_t c1_stride;

@@ -298,6 +298,52 @@ class RankModel:
         return out
 
 
+class ItemRows:
+    """Materialised item records of an FM + two-tower model (pg_fm2t_item_rows_*): one contiguous 640-B record per
+    item row, built once from the model's field tables and the item-field columns."""
+
+    def __init__(self, model: "RankModel", feats: "Features", item_field_names):
+        self.ctx, self.model, self.feats = model.ctx, model, feats
+        cols = feats._cols(item_field_names)
+        h = C.c_void_p()
+        _lib.check(self.ctx.L.pg_fm2t_item_rows_build(self.ctx.h, model.h, feats.h, _ptr(cols), C.byref(h)))
+        self.h = h
+
+    def update(self, row0: int, nrows: int):
+        _lib.check(self.ctx.L.pg_fm2t_item_rows_update(self.ctx.h, self.h, row0, nrows))
+
+    def destroy(self):
+        if self.h:
+            _lib.check(self.ctx.L.pg_fm2t_item_rows_destroy(self.ctx.h, self.h))
+            self.h = None
+
+    def rank(self, user_vecs, user_field_ids, cand_rows, req_offsets) -> np.ndarray:
+        """pg_rank_fm2t_irows (host buffers)."""
+        u = np.ascontiguousarray(user_vecs, dtype=np.float32)
+        uf = np.ascontiguousarray(user_field_ids, dtype=np.int32)
+        cr = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+        ro = np.ascontiguousarray(req_offsets, dtype=np.uint32)
+        out = np.empty(int(ro[-1]), dtype=np.float32)
+        _lib.check(self.ctx.L.pg_rank_fm2t_irows(self.ctx.h, self.model.h, self.h, _ptr(u), _ptr(uf), _ptr(cr), _ptr(ro),
+                                                 ro.shape[0] - 1, _ptr(out)))
+        return out
+
+
+def rank_fm2t_rows_host(model: "RankModel", feats: "Features", item_field_names, user_vecs, user_field_ids, cand_rows,
+                        req_offsets) -> np.ndarray:
+    """pg_rank_fm2t_rows: the host-buffer form (what a caller-made batch of IAlgorithm.Run calls passes)."""
+    ctx = model.ctx
+    u = np.ascontiguousarray(user_vecs, dtype=np.float32)
+    uf = np.ascontiguousarray(user_field_ids, dtype=np.int32)
+    cr = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+    ro = np.ascontiguousarray(req_offsets, dtype=np.uint32)
+    cols = feats._cols(item_field_names)
+    out = np.empty(int(ro[-1]), dtype=np.float32)
+    _lib.check(ctx.L.pg_rank_fm2t_rows(ctx.h, model.h, feats.h, _ptr(cols), _ptr(u), _ptr(uf), _ptr(cr), _ptr(ro),
+                                       ro.shape[0] - 1, _ptr(out)))
+    return out
+
+
 class Expr:
     """Compiled RankConfig.RankScore expression (utils/ast replacement)."""
 
@@ -381,7 +427,9 @@ class Coalescer:
                 self._keep.append(nm)
                 arr[i].model = m.h
                 arr[i].name = nm
-                if len(a) > 2:
+                if len(a) == 3:                       # (name, model, ItemRows)
+                    arr[i].item_rows = a[2].h
+                elif len(a) > 3:                      # (name, model, Features, item field column names)
                     feats, cols = a[2], a[3]
                     idx = feats._cols(cols)
                     carr = (C.c_int32 * len(idx))(*[int(x) for x in idx])

@@ -139,3 +139,46 @@ def test_fm2t_shapes_match_oracle(ctx, nuf, nif, k, th, to):
             ref = o.fm2t_forward(fw, prec, users[r], ufids[r], ifids[off[r]:off[r + 1]])
             assert np.max(np.abs(got[off[r]:off[r + 1]].astype(np.float64) - ref)) <= tol, (prec, r)
         m.destroy()
+
+
+@pytest.mark.parametrize("nuf,nif,k,th,to", [(8, 8, 16, 256, 64), (3, 4, 32, 256, 64), (16, 16, 8, 128, 64),
+                                             (5, 8, 16, 512, 128)])
+def test_fm2t_materialised_item_records_are_bit_identical(ctx, nuf, nif, k, th, to):
+    """pg_fm2t_item_rows_*: one contiguous record per item (the field embeddings of its static ids + linear weights)
+    instead of n_item_fields scattered gathers.  Same values, same summation order: scores equal the per-field path's
+    bit for bit in BOTH precision modes, for every shape; candidates outside the store read the columns' defaults;
+    after a column changes, _update re-materialises the rows."""
+    vocab, n_items, R, K = 3000, 20_000, 3, 700
+    fw = o.Fm2tWeights(n_user_fields=nuf, n_item_fields=nif, k=k, d_user=96, t_h1=th, t_out=to, vocab=vocab)
+    rng = np.random.default_rng(k + th + 1)
+    users = o.synth_rows(o.SEED_QUERY, 1, R, 128)[:, :96].copy()
+    ufids = rng.integers(0, vocab, (R, nuf)).astype(np.int32)
+    ids = rng.integers(0, vocab, (n_items, nif)).astype(np.int32)
+    feats = pa.Features(ctx, n_items)
+    cols = ["c%d" % f for f in range(nif)]
+    for f, c in enumerate(cols):
+        feats.set_column(c, pa.F_I32 if f % 2 else pa.F_I64, ids[:, f].astype(np.int64 if f % 2 == 0 else np.int32), default=7 + f)
+    cand = rng.integers(0, n_items, R * K).astype(np.uint32)
+    cand[5] = n_items + 3                                # outside the store: the defaults' record
+    cand[6] = 0xFFFFFFFF
+    off = (np.arange(R + 1) * K).astype(np.uint32)
+    for prec, tol in ((pa.PREC_F32, 2e-7), (pa.PREC_BF16, 1e-5)):
+        m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, prec, pa.pack_fm2t(fw))
+        ir = pa.ItemRows(m, feats, cols)
+        want = m.rank_fm2t_rows(feats, cols, users, ufids, cand, off)
+        got = ir.rank(users, ufids, cand, off)
+        assert np.array_equal(bits(got), bits(want)), "precision mode %d: materialised records differ from the per-field path" % prec
+        ids_c = np.where(cand[:, None] < n_items, ids[np.minimum(cand, n_items - 1).astype(np.int64)],
+                         np.array([7 + f for f in range(nif)], dtype=np.int32)[None, :])
+        for r in range(R):
+            ref = o.fm2t_forward(fw, prec, users[r], ufids[r], ids_c[off[r]:off[r + 1]])
+            assert np.max(np.abs(got[off[r]:off[r + 1]].astype(np.float64) - ref)) <= tol, (prec, r)
+        # a column changes: the records follow after _update
+        new0 = rng.integers(0, vocab, n_items).astype(np.int64)
+        feats.set_column(cols[0], pa.F_I64, new0, default=7)
+        ir.update(0, n_items)
+        assert np.array_equal(bits(ir.rank(users, ufids, cand, off)), bits(m.rank_fm2t_rows(feats, cols, users, ufids, cand, off)))
+        feats.set_column(cols[0], pa.F_I64, ids[:, 0].astype(np.int64), default=7)
+        ir.destroy()
+        m.destroy()
+    feats.destroy()

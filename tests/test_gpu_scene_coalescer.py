@@ -132,6 +132,15 @@ def test_coalesced_fm2t_rank_equals_direct_call(ctx, world):
     with pytest.raises(pa._lib.PgError):
         co.rank_fm2t(users[0], np.full(8, world["vocab"], np.int32), cand[0][:10])       # user field id outside the vocabulary
     co.destroy()
+    # the same algorithm over its materialised item records: same bits
+    ir = pa.ItemRows(fm, feats, cols)
+    co = pa.Coalescer(ctx, t, 300, algos=[("fm", fm, ir)], max_rank_items=100, max_wait_us=2000)
+    got2 = [None] * CALLERS
+    run_threads(CALLERS, lambda i: got2.__setitem__(i, co.rank_fm2t(users[i], ufids[i], cand[i][:100])))
+    co.destroy()
+    ir.destroy()
+    for i in range(CALLERS):
+        assert np.array_equal(bits(got2[i]), bits(ref[i][:100])), "caller %d (item records)" % i
 
 
 def test_coalesced_recalls_of_every_kind_share_passes(ctx, world):
