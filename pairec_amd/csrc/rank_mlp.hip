@@ -124,7 +124,7 @@ constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep, int bm = kBM) {
     const size_t nh1 = (prec && (size_t)bm * (kDIN + 2 * ch) * es <= 72 * 1024) ? 2 : 1;   // as NH1 in mlp_kernel
     const size_t tiles = (size_t)bm * (kDIN + nh1 * ch) * es;
     const size_t h2t = (size_t)bm * (h2 / ep + 4) * 4;
-    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)bm * 4 * 3;     // w3, head bias, two FM partials per item (MODEL 3)
+    return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)bm * 4;
 }
 
 // MODEL 1 = DNN3, 2 = two-tower item side.  WM x WN = wave grid over (items, hidden columns); CH = layer-1
@@ -170,6 +170,20 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int i32 = lane & 31, h = lane >> 5;
 
+    // fragment offsets: W1 n-block (chunk, wave, nb), k-group step; W2 n-block (wave, nb), k-group chunk*KGC + step
+    constexpr int KG2 = NCHUNK * KGC;                  // k-groups over the full H1 depth
+    auto frag1 = [&](int chunk) {
+        const int nbg0 = chunk * (CH / 32) + wn * L1NB;
+        return [=](int nb, int step) { return (size_t)((nbg0 + nb) * KG1 + step) * 1024; };
+    };
+    auto frag2 = [&](int chunk) {
+        const int nbg0 = wn * L2NB;
+        return [=](int nb, int step) { return (size_t)((nbg0 + nb) * KG2 + chunk * KGC + step) * 1024; };
+    };
+    constexpr bool PRE = PREC == 1 && OCC >= 2;        // preloaded B fragments (bf16, several workgroups per CU)
+    bf16x8 b1f[PRE ? KG1 : 1][PRE ? L1NB : 1];
+    bf16x8 b2f[PRE ? KGC : 1][PRE ? L2NB : 1];
+
     // ---------------- gather prologue: 32 lanes x 16 B per item, 8 items per pass ------------
     {
         const int c = tid & 31;
@@ -189,20 +203,24 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) store_x_quad<PREC>(XT, p * 8 + (tid >> 5), c, v[p]);
         } else if constexpr (MODEL == 3) {
-            // two-tower from MATERIALISED item records (pg_fm2t_item_rows_build): the item's 8 field embeddings and linear
+            // two-tower from MATERIALISED item records (pg_fm2t_item_rows_build): the item's field embeddings and linear
             // weights are one contiguous 544-B record found from the candidate row alone — no ids → rows second hop, five
             // 128-B lines per item instead of eight (a 64-B embedding row costs a whole line) plus the id line.  All 256
-            // threads gather: thread (r, kh) takes columns [kh FK/2, (kh+1) FK/2) of every field of item r (waves 0-1: kh = 0,
-            // waves 2-3: kh = 1), accumulates its half of s_k / q_k in the specification's order (user prefix first, fields
-            // ascending), reduces its half of the balanced tree; the tree's last level and `lin + 0.5 cross` are finished
-            // after the barrier — the same operations in the same order as the per-field path: bit-identical.
+            // threads gather, TWO ADJACENT LANES PER RECORD: lane kh of the pair takes the 16-B quads 2j + kh of every
+            // field, so a load instruction covers 32 contiguous bytes per record.  (One lane per record — 64 different
+            // records per instruction — reaches 1.5 TB/s on a 12.8 GB catalogue, two lanes per record 5.8 TB/s:
+            // scripts/micro/gather_rec.hip.)  Each lane accumulates its columns of s_k / q_k in the specification's order
+            // (user prefix first, fields ascending) and reduces the levels of the balanced tree that stay inside its
+            // quads; the level that pairs quad 2m with quad 2m + 1 crosses the lane pair (one exchange per m), the rest
+            // is lane 0's — the same operations in the same order as the per-field path: bit-identical.
             constexpr int NF = kDIN / FK;          // item fields
-            constexpr int HK = FK / 2;             // columns of a field per thread
-            constexpr int QPH = HK / 4;            // 16-B quads of a field per thread
-            static_assert(BM == 128 && HK % 4 == 0, "MODEL 3: 128-item tiles, field width a multiple of 8");
+            constexpr int QPF = FK / 4;            // 16-B quads per field
+            constexpr int QPH = QPF / 2;           // quads of a field per lane
+            constexpr int HK = QPH * 4;            // columns of a field per lane
+            static_assert(BM == 128 && QPF % 2 == 0, "MODEL 3: 128-item tiles, field width a multiple of 8");
             (void)c;
-            const uint32_t r = (uint32_t)tid & (BM - 1);
-            const int kh = tid >> 7;               // wave-uniform
+            const uint32_t r = (uint32_t)tid >> 1;
+            const int kh = tid & 1;
             const uint32_t idx = item0 + (r < cnt ? r : cnt - 1);
             uint32_t row = a.cand_rows[idx];
             row = row < a.irow_count ? row : a.irow_count;
@@ -212,21 +230,26 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int j = 0; j < QPH; ++j) v[f][j] = rec[f * (FK / 4) + kh * QPH + j];
+                for (int j = 0; j < QPH; ++j) v[f][j] = rec[f * QPF + 2 * j + kh];
             float linv[NF];
             if (kh == 0) {
 #pragma unroll
-                for (int j = 0; j < NF / 4; ++j) {
+                for (int j = 0; j < (NF + 3) / 4; ++j) {
                     const float4 l4 = rec[kDIN / 4 + j];
-                    linv[4 * j + 0] = l4.x; linv[4 * j + 1] = l4.y; linv[4 * j + 2] = l4.z; linv[4 * j + 3] = l4.w;
+                    linv[4 * j + 0] = l4.x;
+                    if (4 * j + 1 < NF) linv[4 * j + 1] = l4.y;
+                    if (4 * j + 2 < NF) linv[4 * j + 2] = l4.z;
+                    if (4 * j + 3 < NF) linv[4 * j + 3] = l4.w;
                 }
             }
-            float s_[HK], q_[HK];
+            float s_[HK], q_[HK];                  // local column 4j + i is column 4 (2j + kh) + i of the field
 #pragma unroll
-            for (int k = 0; k < HK; ++k) {
-                s_[k] = fu[1 + kh * HK + k];
-                q_[k] = fu[1 + kFmMaxK + kh * HK + k];
-            }
+            for (int j = 0; j < QPH; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s_[4 * j + i] = fu[1 + 4 * (2 * j + kh) + i];
+                    q_[4 * j + i] = fu[1 + kFmMaxK + 4 * (2 * j + kh) + i];
+                }
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -236,25 +259,31 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                     s_[4 * j + 1] = s_[4 * j + 1] + x.y; q_[4 * j + 1] = __fmaf_rn(x.y, x.y, q_[4 * j + 1]);
                     s_[4 * j + 2] = s_[4 * j + 2] + x.z; q_[4 * j + 2] = __fmaf_rn(x.z, x.z, q_[4 * j + 2]);
                     s_[4 * j + 3] = s_[4 * j + 3] + x.w; q_[4 * j + 3] = __fmaf_rn(x.w, x.w, q_[4 * j + 3]);
-                    store_x_quad<PREC>(XT, (int)r, f * (FK / 4) + kh * QPH + j, x);
+                    store_x_quad<PREC>(XT, (int)r, f * QPF + 2 * j + kh, x);
                 }
 #pragma unroll
             for (int k = 0; k < HK; ++k) s_[k] = __fmaf_rn(s_[k], s_[k], -q_[k]);
+            // balanced pairwise tree over the field's FK columns: levels 1 and 2 stay inside a quad ...
 #pragma unroll
-            for (int off = 1; off < HK; off <<= 1)              // this half's levels of the balanced pairwise tree over k
+            for (int j = 0; j < QPH; ++j) {
+                s_[4 * j + 0] = s_[4 * j + 0] + s_[4 * j + 1];
+                s_[4 * j + 2] = s_[4 * j + 2] + s_[4 * j + 3];
+                s_[4 * j + 0] = s_[4 * j + 0] + s_[4 * j + 2];
+            }
+            // ... level 4 adds quad 2m + 1 (the odd lane's) to quad 2m (the even lane's) ...
 #pragma unroll
-                for (int k = 0; k < HK; k += 2 * off) s_[k] = s_[k] + s_[k + off];
-            float* const fmp = b3s + BM;                         // [2][BM] partial cross terms
-            fmp[kh * BM + r] = s_[0];
+            for (int j = 0; j < QPH; ++j) s_[4 * j] = s_[4 * j] + __shfl_xor(s_[4 * j], 1);
+            // ... and the levels above pair the even lane's quads (column 8m ↔ local 4m)
+#pragma unroll
+            for (int off = 1; off < QPH; off <<= 1)
+#pragma unroll
+                for (int j = 0; j < QPH; j += 2 * off) s_[4 * j] = s_[4 * j] + s_[4 * (j + off)];
             if (kh == 0) {
                 float lin = fu[0];
 #pragma unroll
                 for (int f = 0; f < NF; ++f) lin = lin + linv[f];
-                b3s[r] = lin;
+                b3s[r] = lin + 0.5f * s_[0];
             }
-            __syncthreads();
-            // the tree's last level (k = 0 with k = FK/2), then y_fm = lin + 0.5 cross
-            if (tid < BM) b3s[tid] = b3s[tid] + 0.5f * (fmp[tid] + fmp[BM + tid]);
         } else {
             // two-tower: ONE THREAD PER ITEM.  The thread reads its item's field ids, then walks the fields in order:
             // 64 B (FK = 16) of each field's embedding row as 16-B loads, FM sums s_k / q_k accumulated in registers in
@@ -340,19 +369,6 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
         }
     }
 
-    // fragment offsets: W1 n-block (chunk, wave, nb), k-group step; W2 n-block (wave, nb), k-group chunk*KGC + step
-    constexpr int KG2 = NCHUNK * KGC;                  // k-groups over the full H1 depth
-    auto frag1 = [&](int chunk) {
-        const int nbg0 = chunk * (CH / 32) + wn * L1NB;
-        return [=](int nb, int step) { return (size_t)((nbg0 + nb) * KG1 + step) * 1024; };
-    };
-    auto frag2 = [&](int chunk) {
-        const int nbg0 = wn * L2NB;
-        return [=](int nb, int step) { return (size_t)((nbg0 + nb) * KG2 + chunk * KGC + step) * 1024; };
-    };
-    constexpr bool PRE = PREC == 1 && OCC >= 2;        // preloaded B fragments (bf16, several workgroups per CU)
-    bf16x8 b1f[PRE ? KG1 : 1][PRE ? L1NB : 1];
-    bf16x8 b2f[PRE ? KGC : 1][PRE ? L2NB : 1];
     if constexpr (PRE) load_bfrags<L1NB, KG1>(b1f, reinterpret_cast<const char*>(a.w1p), frag1(0), lane);
 
 #pragma unroll 1
