@@ -345,11 +345,13 @@ int pg_recommend_end(pg_ctx* ctx, pg_ticket* ticket, double* scan_ms);
  * table in contiguous row ranges [g*N/G, (g+1)*N/G), one context per shard, model weights replicated.  devices[] may
  * name one device several times (logical shards on one GPU: tests).  Peer access is enabled between distinct
  * devices; the two exchanges of a step (per-shard top-k lists; owners' rank scores and DPP embeddings) are direct
- * peer stores ordered by HIP events — no collective library, no host synchronisation inside a step. */
+ * peer stores ordered by HIP events — no collective library, no host synchronisation inside a step.  The tail of a
+ * step (RankScore, sort, DPPSort, page) is spread over the shards by request: shard s finishes requests q = s (mod G). */
 typedef struct pg_group pg_group;
 int pg_group_create(const int* devices, uint32_t n_shards, pg_group** out);
 int pg_group_destroy(pg_group* g);
 uint32_t pg_group_size(const pg_group* g);
+int pg_group_info(const pg_group* g, uint64_t* total_rows, uint32_t* dim);
 pg_ctx* pg_group_ctx(pg_group* g, uint32_t shard);
 pg_table* pg_group_table(pg_group* g, uint32_t shard);
 int pg_group_table_create(pg_group* g, uint64_t total_rows, uint32_t dim);
@@ -370,6 +372,16 @@ typedef struct {
 int pg_group_recommend(pg_group* g, const pg_expr* e, const char* rank_var, const pg_group_plan* plan,
                        const float* user_vecs, uint32_t nq, uint32_t top_n, uint64_t* out_rows,
                        float* out_recall_scores, float* out_rank_scores, double* out_fused, uint32_t* out_count);
+/* The same step in two halves, as pg_recommend_dnn3_begin / pg_recommend_end on one GPU: _begin enqueues the whole
+ * step on every shard and returns at once (user_vecs are copied), _end waits for it, verifies every shard's recall
+ * plan (re-running the step where one did not hold) and delivers the pages.  Up to two steps may be outstanding: each
+ * shard runs them on two lanes (contexts with their own stream and scratch), so one batch's fusion / sort / DPP tail
+ * overlaps the next batch's scans.  Every ticket must be ended; table / model changes need the group idle. */
+typedef struct pg_group_ticket pg_group_ticket;
+int pg_group_recommend_begin(pg_group* g, const pg_expr* e, const char* rank_var, const pg_group_plan* plan,
+                             const float* user_vecs, uint32_t nq, uint32_t top_n, pg_group_ticket** out);
+int pg_group_recommend_end(pg_group* g, pg_group_ticket* ticket, uint64_t* out_rows, float* out_recall_scores,
+                           float* out_rank_scores, double* out_fused, uint32_t* out_count);
 
 /* The shard-side steps of the same flow as device-level calls, for a one-process-per-GPU host that runs the two
  * exchanges itself (pairec_amd/dist.py over torch.distributed / RCCL).  Everything is fixed-size and stays on the
@@ -506,6 +518,24 @@ int pg_coalescer_recommend_ex(pg_coalescer* c, const float* user_vec, const int3
 int pg_coalescer_dpp(pg_coalescer* c, const uint32_t* cand_rows, const double* rel, uint32_t n,
                      const pg_dpp_options* opt, const double* hook_emb, uint32_t* out_idx, uint32_t* out_count,
                      double* out_relevance);
+/* ---- per-request calls over several GPUs ------------------------------------------------------------------------
+ * (a) The sharded table (BASELINE.json configs[4]): a coalescer over a shard group — pg_coalescer_recommend takes ONE
+ *     request, the library batches up to 256 of them into pg_group_recommend_begin / _end steps (two in flight, one per
+ *     lane), DPPSort included when plan->dpp_candidates > 0.  Only pg_coalescer_recommend / _stats / _destroy apply.
+ * (b) Replicas (the 51 GB table of configs[1] fits every GPU): a router over one coalescer per replica; each request
+ *     goes to the replica with the fewest requests outstanding (ties: round robin), so per-request calls from one
+ *     process reach all N GPUs with no data-path exchange at all.  The router does not own the coalescers. */
+int pg_coalescer_create_group(pg_group* g, const pg_expr* e, const char* rank_var, const pg_group_plan* plan,
+                              const pg_coalescer_config* cfg, pg_coalescer** out);
+typedef struct pg_router pg_router;
+int pg_router_create(pg_coalescer* const* replicas, uint32_t n, pg_router** out);
+int pg_router_destroy(pg_router* r);
+int pg_router_recommend(pg_router* r, const float* user_vec, uint32_t top_n, uint64_t* out_rows,
+                        float* out_recall_scores, float* out_rank_scores, double* out_fused, uint32_t* out_count);
+int pg_router_recall(pg_router* r, const float* query, uint64_t* out_rows, float* out_scores, uint32_t* out_count);
+/* requests each replica has served so far, [n] */
+int pg_router_stats(pg_router* r, uint64_t* out_served);
+
 typedef struct {
     uint64_t requests[6], batches[6];   /* per flavour: 0 recall (vector / i2i / online), 1 rank, 2 recommend, 3 dpp, 4-5 reserved */
     uint64_t largest_batch[6];

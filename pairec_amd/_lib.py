@@ -36,6 +36,8 @@ EXPORTS = [
     "pg_gather_owned_rows_dev", "pg_dpp_batch_dev",
     "pg_group_create", "pg_group_destroy", "pg_group_size", "pg_group_ctx", "pg_group_table", "pg_group_table_create",
     "pg_group_table_fill_synthetic", "pg_group_table_upload", "pg_group_model_load", "pg_group_recommend",
+    "pg_group_recommend_begin", "pg_group_recommend_end", "pg_group_info", "pg_coalescer_create_group",
+    "pg_router_create", "pg_router_destroy", "pg_router_recommend", "pg_router_recall", "pg_router_stats",
 ]
 
 
@@ -184,6 +186,15 @@ def load():
         "pg_group_table_upload": [vp, u64, u64, vp],
         "pg_group_model_load": [vp, i32, i32, vp, sz],
         "pg_group_recommend": [vp, vp, C.c_char_p, P(PgGroupPlan), vp, u32, u32, vp, vp, vp, vp, vp],
+        "pg_group_recommend_begin": [vp, vp, C.c_char_p, P(PgGroupPlan), vp, u32, u32, P(vp)],
+        "pg_group_recommend_end": [vp, vp, vp, vp, vp, vp, vp],
+        "pg_group_info": [vp, P(u64), P(u32)],
+        "pg_coalescer_create_group": [vp, vp, C.c_char_p, P(PgGroupPlan), P(PgCoalescerConfig), P(vp)],
+        "pg_router_create": [P(vp), u32, P(vp)],
+        "pg_router_destroy": [vp],
+        "pg_router_recommend": [vp, vp, u32, vp, vp, vp, vp, P(u32)],
+        "pg_router_recall": [vp, vp, vp, vp, P(u32)],
+        "pg_router_stats": [vp, P(u64)],
         "pg_rows_to_local_dev": [vp, vp, vp, u32, vp, vp],
         "pg_widen_f32_dev": [vp, vp, u32, vp],
         "pg_stats": [vp, P(PgStats)],

@@ -136,6 +136,13 @@ struct Slot {
     uint32_t* d_pick_cnt = nullptr;
     char* d_page = nullptr;                // recommend: the pages, layout as h_out
     RecommendCall call;                    // recommend: what was enqueued (the verification may re-run single requests)
+    // a coalescer over a shard group: the step's ticket and its pages (host memory, [max_batch][max_top_n] planes)
+    pg_group_ticket* gticket = nullptr;
+    uint64_t* g_rows = nullptr;
+    float* g_rec = nullptr;
+    float* g_rnk = nullptr;
+    double* g_fus = nullptr;
+    uint32_t* g_cnt = nullptr;
     // dpp flavour (allocated by the first such batch)
     bool dpp_ready = false;
     uint32_t* h_dcand = nullptr;
@@ -189,6 +196,10 @@ struct pg_coalescer {
     const pg_expr* e = nullptr;
     std::vector<int> var_src;
     pg::RerankStage rerank;
+    pg_group* group = nullptr;       // a coalescer over a shard group (pg_coalescer_create_group): recommend only
+    pg_group_plan gplan{};
+    std::string grank_var;
+    std::atomic<uint32_t> outstanding{0};            // requests between submit and return (the router's load measure)
     uint32_t k = 0, max_batch = 0, max_wait_us = 0, depth = 0, max_top_n = 0, max_rank_items = 0, timeout_us = 0;
     uint32_t max_rank_reqs = 0, rank_item_cap = 0;
     uint32_t dim = 0, vec_w = 0, ufid_stride = 0, vec_rows = 0;
@@ -232,6 +243,16 @@ uint32_t dpp_batch_limit(const pg_coalescer* c, uint32_t n) {
 }
 
 int alloc_slot(pg_coalescer* c, Slot* s) {
+    if (c->group) {                      // host staging only: the group owns every device buffer
+        const size_t np = (size_t)c->max_batch * c->max_top_n;
+        PG_HIP(hipHostMalloc((void**)&s->h_vec, (size_t)c->max_batch * c->dim * 4));
+        s->g_rows = new uint64_t[np];
+        s->g_rec = new float[np];
+        s->g_rnk = new float[np];
+        s->g_fus = new double[np];
+        s->g_cnt = new uint32_t[c->max_batch];
+        return PG_OK;
+    }
     const size_t nb = c->max_batch, k = c->k;
     const bool rank = c->n_algos > 0;
     PG_HIP(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
@@ -296,6 +317,11 @@ int ensure_dpp_buffers(pg_coalescer* c, Slot* s) {
 }
 
 void free_slot(pg_coalescer* c, Slot* s) {
+    delete[] s->g_rows;
+    delete[] s->g_rec;
+    delete[] s->g_rnk;
+    delete[] s->g_fus;
+    delete[] s->g_cnt;
     if (s->run) pipe_run_release(s->ctx, s->run);
     if (s->done) hipEventDestroy(s->done);
     if (s->computed) hipEventDestroy(s->computed);
@@ -423,6 +449,13 @@ int enqueue_dpp_batch(pg_coalescer* c, Slot* s) {
 // Enqueue the slot's batch: inputs host → device, the kernels, the copy-out.  first = false: the recall plan of a
 // recall / recommend batch did not hold; run its next plan and everything behind it again.
 int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
+    if (c->group) {
+        // one step of the shard group for the whole batch: enqueued on every shard, collected by the completer
+        uint32_t top = 1;
+        for (const Req* r : s->reqs) top = std::max(top, r->n);
+        s->n_items = top;
+        return pg_group_recommend_begin(c->group, c->e, c->grank_var.c_str(), &c->gplan, s->h_vec, s->n_req, top, &s->gticket);
+    }
     pg_ctx* ctx = s->ctx;
     hipStream_t st = ctx->stream;
     const uint32_t nq = (uint32_t)s->n_req;
@@ -466,6 +499,7 @@ int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
     call.d_fused = s->d_fused;
     call.d_order = s->d_order;
     call.d_count = s->d_count;
+    call.pads = c->t->rows < c->k;
     call.rerank = c->rerank;
     call.top_n = top;
     call.d_pick = s->d_pick;
@@ -697,7 +731,7 @@ void completer_main(pg_coalescer* c) {
         int rc = PG_OK;
         bool replanned = false, device_fault = false;
         const int fl = flavour_of(s->queue);
-        for (;;) {
+        for (; !c->group;) {
             if (hipEventSynchronize(s->done) != hipSuccess) {
                 set_error("pg_coalescer: %s", hipGetErrorString(hipGetLastError()));
                 rc = PG_ERR_DEVICE;
@@ -719,9 +753,15 @@ void completer_main(pg_coalescer* c) {
             replanned = true;
             if ((rc = slot_enqueue(c, s, false))) break;
         }
+        if (c->group) {
+            // waits for the step, verifies every shard's plan (re-running the step where one failed), assembles the pages
+            rc = pg_group_recommend_end(c->group, s->gticket, s->g_rows, s->g_rec, s->g_rnk, s->g_fus, s->g_cnt);
+            s->gticket = nullptr;
+            device_fault = rc == PG_ERR_DEVICE;
+        }
         if (rc) {
             slot_fail(s, rc);
-        } else if (fl == kRecommend) {
+        } else if (fl == kRecommend && !c->group) {
             for (Req* r : s->reqs)
                 if (s->run->h_status[kExprFlagAt + r->index]) {
                     set_expr_arith_error(c->e);
@@ -761,7 +801,14 @@ void completer_main(pg_coalescer* c) {
 // caller side: queue the request, sleep until a worker finished it (or the deadline passes).  Returns PG_OK when
 // the request was finished (r->rc holds its status), PG_ERR_TIMEOUT / PG_ERR_* when the caller leaves without it —
 // in that case the record must not be touched any more.
+int submit_and_wait_inner(pg_coalescer* c, Req* r);
 int submit_and_wait(pg_coalescer* c, Req* r) {
+    c->outstanding.fetch_add(1, std::memory_order_relaxed);
+    const int rc = submit_and_wait_inner(c, r);
+    if (rc != PG_OK) c->outstanding.fetch_sub(1, std::memory_order_relaxed);     // (finished calls leave through finish_call)
+    return rc;
+}
+int submit_and_wait_inner(pg_coalescer* c, Req* r) {
     r->arrived = Clock::now();
     {
         std::lock_guard<std::mutex> g(c->mu);
@@ -828,6 +875,7 @@ int submit_and_wait(pg_coalescer* c, Req* r) {
 
 // what every entry point does after submit_and_wait returned PG_OK and the slice was copied
 int finish_call(pg_coalescer* c, Req* r) {
+    c->outstanding.fetch_sub(1, std::memory_order_relaxed);
     Slot* s = r->slot;
     const int rc = r->rc;
     if (rc != PG_OK) set_error("%s", r->err);
@@ -1010,17 +1058,22 @@ int pg_coalescer_destroy(pg_coalescer* c) {
     for (pg::Slot* s : c->slots)
         while (s->pending.load(std::memory_order_acquire) != 0) std::this_thread::yield();
     hipSetDevice(c->ctx->device);
-    hipStreamSynchronize(c->copy_stream);
-    hipStreamSynchronize(c->ctx->stream);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+    if (!c->group) hipStreamSynchronize(c->ctx->stream);
     if (c->sibling) hipStreamSynchronize(c->sibling->stream);
     for (pg::Slot* s : c->slots) pg::free_slot(c, s);
-    hipStreamDestroy(c->copy_stream);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->sibling) pg_shutdown(c->sibling);
     delete c;
     return PG_OK;
 }
 
 static int coalescer_recall_common(pg_coalescer* c, pg::Req* r, uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
+    if (c->group) {
+        delete r;
+        pg::set_error("pg_coalescer: a coalescer over a shard group serves pg_coalescer_recommend only");
+        return PG_ERR_UNSUPPORTED;
+    }
     r->queue = pg::kQRecall;
     int rc;
     if ((rc = pg::submit_and_wait(c, r))) return rc;
@@ -1138,7 +1191,14 @@ static int coalescer_recommend_common(pg_coalescer* c, const float* user_vec, co
     int rc;
     if ((rc = pg::submit_and_wait(c, r))) return rc;
     pg::Slot* s = r->slot;
-    if (r->rc == PG_OK) {
+    if (r->rc == PG_OK && c->group) {
+        const size_t o = (size_t)r->index * s->n_items;                 // the step's pages are [n_req][batch top_n]
+        memcpy(out_rows, s->g_rows + o, (size_t)top_n * 8);
+        memcpy(out_fused, s->g_fus + o, (size_t)top_n * 8);
+        memcpy(out_recall_scores, s->g_rec + o, (size_t)top_n * 4);
+        memcpy(out_rank_scores, s->g_rnk + o, (size_t)top_n * 4);
+        if (out_count) *out_count = std::min(top_n, s->g_cnt[r->index]);
+    } else if (r->rc == PG_OK) {
         const size_t nq_top = (size_t)s->n_items;                       // page width of the batch's image: planes are [n_req][nq_top]
         const uint32_t* counts = (const uint32_t*)(s->h_out + pg::page_bytes(c));
         const uint32_t* pick_counts = counts + c->max_batch;
@@ -1180,6 +1240,7 @@ int pg_coalescer_dpp(pg_coalescer* c, const uint32_t* cand_rows, const double* r
                      const pg_dpp_options* o, const double* hook_emb, uint32_t* out_idx, uint32_t* out_count,
                      double* out_relevance) {
     PG_REQUIRE(c && o && out_count, "pg_coalescer_dpp: NULL argument");
+    PG_REQUIRE(!c->group, "pg_coalescer_dpp: a coalescer over a shard group serves pg_coalescer_recommend only");
     *out_count = 0;
     if (n == 0 || o->topn == 0) return PG_OK;
     PG_REQUIRE(rel && out_idx, "pg_coalescer_dpp: NULL argument");
@@ -1244,6 +1305,122 @@ int pg_debug_stall(pg_ctx* ctx, uint32_t ms) {
     std::lock_guard<std::mutex> g(ctx->mu);
     pg::stall_kernel<<<1, 64, 0, ctx->stream>>>((uint64_t)ms * (uint64_t)khz);
     PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int pg_coalescer_create_group(pg_group* g, const pg_expr* e, const char* rank_var, const pg_group_plan* plan,
+                              const pg_coalescer_config* cfg, pg_coalescer** out) {
+    PG_REQUIRE(g && e && rank_var && plan && cfg && out, "pg_coalescer_create_group: NULL argument");
+    uint64_t total = 0;
+    uint32_t dim = 0;
+    pg_group_info(g, &total, &dim);
+    PG_REQUIRE(total > 0 && pg_group_ctx(g, 0), "pg_coalescer_create_group: the group has no table");
+    PG_REQUIRE(plan->k >= 1 && plan->k <= 16384 && (cfg->k == 0 || cfg->k == plan->k), "pg_coalescer_create_group: k comes from the plan");
+    PG_REQUIRE(cfg->max_batch <= (uint32_t)pg::kMaxQueries, "pg_coalescer_create_group: max_batch %u exceeds %d", cfg->max_batch, pg::kMaxQueries);
+    PG_REQUIRE(cfg->depth <= 2, "pg_coalescer_create_group: depth %u (a group runs at most two steps at a time)", cfg->depth);
+    PG_REQUIRE(cfg->max_top_n <= plan->k, "pg_coalescer_create_group: max_top_n %u exceeds k %u", cfg->max_top_n, plan->k);
+    const char* names[1] = {rank_var};
+    std::vector<int> src;
+    int rc;
+    if ((rc = pg::recommend_bind_vars(e, names, 1, &src, "pg_coalescer_create_group"))) return rc;
+    pg_coalescer* c = new pg_coalescer();
+    c->group = g;
+    c->gplan = *plan;
+    c->grank_var = rank_var;
+    c->ctx = pg_group_ctx(g, 0);
+    c->e = e;
+    c->k = plan->k;
+    c->max_batch = cfg->max_batch ? cfg->max_batch : (uint32_t)pg::kMaxQueries;
+    c->max_wait_us = cfg->max_wait_us ? cfg->max_wait_us : 100;
+    c->depth = cfg->depth ? cfg->depth : 2;
+    c->max_top_n = cfg->max_top_n ? cfg->max_top_n : std::min<uint32_t>(plan->k, 1000);
+    if (plan->dpp_candidates && c->max_top_n > plan->dpp_candidates) c->max_top_n = plan->dpp_candidates;   // DPP candidates must not depend on the request
+    c->timeout_us = cfg->timeout_us;
+    c->dim = dim;
+    PG_HIP(hipSetDevice(c->ctx->device));
+    for (uint32_t i = 0; i < c->depth; ++i) {
+        pg::Slot* s = new pg::Slot();
+        s->id = (int)i;
+        s->ctx = c->ctx;
+        if ((rc = pg::alloc_slot(c, s))) {
+            pg::free_slot(c, s);
+            pg::destroy_partial(c);
+            return rc;
+        }
+        c->slots.push_back(s);
+        c->free_slots.push_back(s);
+    }
+    c->dispatcher = std::thread(pg::dispatcher_main, c);
+    c->completer = std::thread(pg::completer_main, c);
+    *out = c;
+    return PG_OK;
+}
+
+}  // extern "C"
+
+struct pg_router {
+    std::vector<pg_coalescer*> rep;
+    std::vector<std::atomic<uint64_t>> served;
+    std::atomic<uint32_t> rr{0};
+    explicit pg_router(size_t n) : served(n) {}
+};
+
+namespace pg {
+namespace {
+// the replica with the fewest requests outstanding; ties go round robin
+uint32_t router_pick(pg_router* r) {
+    const uint32_t n = (uint32_t)r->rep.size();
+    const uint32_t start = r->rr.fetch_add(1, std::memory_order_relaxed) % n;
+    uint32_t best = start, load = r->rep[start]->outstanding.load(std::memory_order_relaxed);
+    for (uint32_t i = 1; i < n; ++i) {
+        const uint32_t j = (start + i) % n;
+        const uint32_t l = r->rep[j]->outstanding.load(std::memory_order_relaxed);
+        if (l < load) {
+            load = l;
+            best = j;
+        }
+    }
+    r->served[best].fetch_add(1, std::memory_order_relaxed);
+    return best;
+}
+}  // namespace
+}  // namespace pg
+
+extern "C" {
+
+int pg_router_create(pg_coalescer* const* replicas, uint32_t n, pg_router** out) {
+    PG_REQUIRE(replicas && out && n >= 1 && n <= 64, "pg_router_create: bad argument");
+    for (uint32_t i = 0; i < n; ++i) {
+        PG_REQUIRE(replicas[i], "pg_router_create: replica %u is NULL", i);
+        PG_REQUIRE(replicas[i]->k == replicas[0]->k && replicas[i]->dim == replicas[0]->dim && replicas[i]->max_top_n == replicas[0]->max_top_n,
+                   "pg_router_create: replica %u differs from replica 0 in k / dim / max_top_n", i);
+    }
+    pg_router* r = new pg_router(n);
+    r->rep.assign(replicas, replicas + n);
+    for (auto& s : r->served) s.store(0);
+    *out = r;
+    return PG_OK;
+}
+
+int pg_router_destroy(pg_router* r) {
+    delete r;
+    return PG_OK;
+}
+
+int pg_router_recommend(pg_router* r, const float* user_vec, uint32_t top_n, uint64_t* out_rows,
+                        float* out_recall_scores, float* out_rank_scores, double* out_fused, uint32_t* out_count) {
+    PG_REQUIRE(r, "pg_router_recommend: NULL argument");
+    return pg_coalescer_recommend(r->rep[pg::router_pick(r)], user_vec, top_n, out_rows, out_recall_scores, out_rank_scores, out_fused, out_count);
+}
+
+int pg_router_recall(pg_router* r, const float* query, uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
+    PG_REQUIRE(r, "pg_router_recall: NULL argument");
+    return pg_coalescer_recall(r->rep[pg::router_pick(r)], query, out_rows, out_scores, out_count);
+}
+
+int pg_router_stats(pg_router* r, uint64_t* out_served) {
+    PG_REQUIRE(r && out_served, "pg_router_stats: NULL argument");
+    for (size_t i = 0; i < r->rep.size(); ++i) out_served[i] = r->served[i].load(std::memory_order_relaxed);
     return PG_OK;
 }
 

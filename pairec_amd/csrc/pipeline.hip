@@ -99,16 +99,7 @@ int recommend_bind_vars(const pg_expr* e, const char* const* names, int n_algos,
     return PG_OK;
 }
 
-struct PostScratch {
-    uint32_t *d_local, *d_off, *d_err;
-    double* d_vars;
-    // re-rank stage (scratch slot 10)
-    uint64_t* c_rows;
-    double* c_rel;
-    float* c_emb;
-    uint32_t* c_bail;
-};
-static int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostScratch* ps) {
+int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostScratch* ps) {
     const uint32_t n = nq * c.k;
     void* buf;
     int rc;
@@ -133,11 +124,58 @@ static int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostSc
     return PG_OK;
 }
 
+// RankScore fusion over the algorithms' score planes + ItemRankScore sort for requests [q0, q0 + nq) of the call
+// (rank_service.go:339-363, sort/item_rank_score.go:26-32); ps.d_off must hold the uniform offsets
+int post_fuse_sort_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps) {
+    const uint32_t n = nq * c.k;
+    const size_t o = (size_t)q0 * c.k;
+    hipStream_t st = ctx->stream;
+    int rc;
+    VarSrc vs;
+    for (int i = 0; i < 32; ++i) vs.src[i] = i < c.nv ? (int8_t)c.var_src[i] : (int8_t)-1;
+    if (c.nv > 0) {
+        bind_vars_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n, (uint32_t)c.nv, vs, ps.d_vars);
+        PG_HIP(hipGetLastError());
+    }
+    PG_HIP(hipMemsetAsync(ps.d_err, 0, (size_t)kMaxQueries * 4, st));
+    if ((rc = expr_eval_enqueue_locked(ctx, c.e, ps.d_vars, n, c.d_fused + o, ps.d_err, c.k))) return rc;
+    if (c.pads) {
+        mask_pads_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_rows + o, n, c.d_rank + o, c.rank_stride, c.n_algos, c.d_fused + o);
+        PG_HIP(hipGetLastError());
+    }
+    return sort_dev_locked(ctx, c.d_fused + o, ps.d_off, nq, n, c.k, 1, c.d_order + o);
+}
+
+// DPPSort.doSort (sort/dpp_sort.go:271-351) on the sorted lists, in two halves with the embedding gather between them
+// (local rows here, rows spread over shards in group.hip): the candidates = the first C entries (their global rows and
+// relevance, normalised as dpp_norm_relevance_score asks) ...
+int rerank_select_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps) {
+    const uint32_t C = c.rerank.candidates;
+    const size_t o = (size_t)q0 * c.k;
+    if (c.k < C) {
+        set_error("recommend: the DPP stage wants %u candidates, the lists hold k = %u", C, c.k);
+        return PG_ERR_UNSUPPORTED;
+    }
+    int rc;
+    if ((rc = sorted_head_launch(ctx->stream, c.d_order + o, c.d_rows + o, c.d_fused + o, nq, c.k, C, ps.c_rows, ps.c_rel))) return rc;
+    return dpp_norm_relevance_launch(ctx->stream, ps.c_rel, nq, C, c.rerank.dpp.norm_relevance_score, ps.c_bail);
+}
+// ... and KernelMatrix + DPPWithWindow for the whole batch at once over their embedding rows ps.c_emb [nq][C][dim]
+int rerank_run_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps) {
+    const uint32_t C = c.rerank.candidates;
+    int rc;
+    if ((rc = dpp_run_locked(ctx, ps.c_emb, nullptr, ps.c_rel, nq, C, c.t->dim, 0, c.rerank.dpp.alpha, c.top_n, c.rerank.dpp.window,
+                             c.rerank.dpp.normalize_emb, 1, 1, c.d_pick + (size_t)q0 * c.top_n, c.d_pick_cnt + q0)))
+        return rc;
+    if (c.rerank.dpp.norm_relevance_score)
+        return dpp_bail_fix_launch(ctx->stream, ps.c_bail, nq, C, c.top_n, c.d_pick + (size_t)q0 * c.top_n, c.d_pick_cnt + q0);
+    return PG_OK;
+}
+
 // the stages behind the recall for requests [q0, q0 + nq) of the call (caller holds ctx->mu; d_err is indexed from 0)
 static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps) {
     const uint32_t n = nq * c.k;
     const size_t o = (size_t)q0 * c.k;
-    hipStream_t st = ctx->stream;
     int rc;
     if ((rc = uniform_offsets_locked(ctx, nq, c.k, ps.d_off))) return rc;
     if ((rc = rows_to_local_locked(ctx, c.t, c.d_rows + o, n, ps.d_local, nullptr))) return rc;
@@ -150,36 +188,15 @@ static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q
                                    out)))
             return rc;
     }
-    VarSrc vs;
-    for (int i = 0; i < 32; ++i) vs.src[i] = i < c.nv ? (int8_t)c.var_src[i] : (int8_t)-1;
-    if (c.nv > 0) {
-        bind_vars_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n, (uint32_t)c.nv, vs, ps.d_vars);
-        PG_HIP(hipGetLastError());
-    }
-    PG_HIP(hipMemsetAsync(ps.d_err, 0, (size_t)kMaxQueries * 4, st));
-    if ((rc = expr_eval_enqueue_locked(ctx, c.e, ps.d_vars, n, c.d_fused + o, ps.d_err, c.k))) return rc;
-    if (c.t->rows < c.k) {
-        mask_pads_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_rows + o, n, c.d_rank + o, c.rank_stride, c.n_algos, c.d_fused + o);
-        PG_HIP(hipGetLastError());
-    }
-    if ((rc = sort_dev_locked(ctx, c.d_fused + o, ps.d_off, nq, n, c.k, 1, c.d_order + o))) return rc;
+    if ((rc = post_fuse_sort_locked(ctx, c, q0, nq, ps))) return rc;
     if (c.rerank.kind == 1) {
-        // DPPSort.doSort (sort/dpp_sort.go:271-351) on the sorted list: candidates = its first C entries, their embeddings
-        // are rows of the table (loadEmbeddingCache), KernelMatrix + DPPWithWindow for the whole batch at once
-        const uint32_t C = c.rerank.candidates;
-        if (c.t->rows < C || c.k < C) {
-            set_error("recommend: the DPP stage wants %u candidates, the lists hold min(k = %u, %llu rows)", C, c.k, (unsigned long long)c.t->rows);
+        if (c.t->rows < c.rerank.candidates) {
+            set_error("recommend: the DPP stage wants %u candidates, the table has %llu rows", c.rerank.candidates, (unsigned long long)c.t->rows);
             return PG_ERR_UNSUPPORTED;
         }
-        if ((rc = sorted_head_launch(st, c.d_order + o, c.d_rows + o, c.d_fused + o, nq, c.k, C, ps.c_rows, ps.c_rel))) return rc;
-        if ((rc = dpp_norm_relevance_launch(st, ps.c_rel, nq, C, c.rerank.dpp.norm_relevance_score, ps.c_bail))) return rc;
-        if ((rc = gather_global_rows_launch(st, c.t, ps.c_rows, nq * C, ps.c_emb))) return rc;
-        if ((rc = dpp_run_locked(ctx, ps.c_emb, nullptr, ps.c_rel, nq, C, c.t->dim, 0, c.rerank.dpp.alpha, c.top_n, c.rerank.dpp.window,
-                                 c.rerank.dpp.normalize_emb, 1, 1, c.d_pick + (size_t)q0 * c.top_n, c.d_pick_cnt + q0)))
-            return rc;
-        if (c.rerank.dpp.norm_relevance_score &&
-            (rc = dpp_bail_fix_launch(st, ps.c_bail, nq, C, c.top_n, c.d_pick + (size_t)q0 * c.top_n, c.d_pick_cnt + q0)))
-            return rc;
+        if ((rc = rerank_select_locked(ctx, c, q0, nq, ps))) return rc;
+        if ((rc = gather_global_rows_launch(ctx->stream, c.t, ps.c_rows, nq * c.rerank.candidates, ps.c_emb))) return rc;
+        if ((rc = rerank_run_locked(ctx, c, q0, nq, ps))) return rc;
     }
     return PG_OK;
 }
@@ -189,16 +206,6 @@ int rank_algo_locked(pg_ctx* ctx, const RankAlgoRef& al, const pg_table* t, cons
     if (al.m->kind == PG_MODEL_DNN3) return rank_dnn3_dev_locked(ctx, al.m, t, d_user, d_cand, d_off, n_req, n_items, d_out);
     if (al.irows) return rank_fm2t_irows_dev_locked(ctx, al.m, al.irows, d_user, d_ufids, d_cand, d_off, n_req, n_items, d_out);
     return rank_fm2t_rows_dev_locked(ctx, al.m, al.fs, al.item_field_cols, d_user, d_ufids, d_cand, d_off, n_req, n_items, d_out);
-}
-
-int recommend_post_enqueue(pg_ctx* ctx, const RecommendCall& c, uint32_t* d_err_out) {
-    std::lock_guard<std::mutex> g(ctx->mu);
-    int rc;
-    PostScratch ps;
-    if ((rc = post_scratch(ctx, c, c.nq, &ps))) return rc;
-    if ((rc = recommend_post_locked(ctx, c, 0, c.nq, ps))) return rc;
-    if (d_err_out) PG_HIP(hipMemcpyAsync(d_err_out, ps.d_err, (size_t)c.nq * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    return PG_OK;
 }
 
 int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool first) {
@@ -291,6 +298,7 @@ int pg_recommend_dnn3_begin(pg_ctx* ctx, const pg_table* t, const pg_model* m, c
     c.d_queries = d_queries; c.nq = nq; c.k = k;
     c.d_rows = d_out_rows; c.d_recall = d_out_recall_scores; c.d_rank = d_out_rank_scores; c.rank_stride = (size_t)nq * k;
     c.d_fused = d_out_fused; c.d_order = d_out_order; c.d_count = d_out_count;
+    c.pads = t->rows < k;
     if ((rc = pg::pipe_run_acquire(ctx, &tk->run)) || (rc = pg::recommend_enqueue(ctx, c, tk->run, true))) {
         if (tk->run) pg::pipe_run_release(ctx, tk->run);
         delete tk;

@@ -63,6 +63,7 @@ struct RecommendCall {
     double* d_fused = nullptr;
     uint32_t* d_order = nullptr;
     uint32_t* d_count = nullptr;       // optional
+    bool pads = false;                 // the table has fewer than k rows: lists end in padding slots (masked before the sort)
     RerankStage rerank;
     uint32_t top_n = 0;                // re-rank: picks per request
     uint32_t* d_pick = nullptr;        // re-rank: [nq][top_n] positions in the sorted list
@@ -78,9 +79,22 @@ int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool firs
 // When the pilot threshold was too high for a few requests only, they are re-run here, synchronously and in place
 // (c != NULL: recall and everything behind it; c == NULL: a recall-only job), r->patched is set and *ok = true.
 int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok, const RecommendCall* c = nullptr);
-// the stages behind a recall whose outputs are already in c.d_rows / c.d_recall (the shard group's merged lists):
-// rank → fusion → sort → re-rank for requests [0, c.nq); d_err_out (device, [nq]) receives the RankScore flags
-int recommend_post_enqueue(pg_ctx* ctx, const RecommendCall& c, uint32_t* d_err_out);
+// The stages behind the rank as separate steps, for hosts that put something between them (group.hip: the score
+// and embedding exchanges between shards).  All take the call's device buffers, requests [q0, q0 + nq), and the
+// context's post-stage scratch (post_scratch; caller holds ctx->mu).
+struct PostScratch {
+    uint32_t *d_local, *d_off, *d_err;
+    double* d_vars;
+    // re-rank stage (scratch slot 10)
+    uint64_t* c_rows;
+    double* c_rel;
+    float* c_emb;
+    uint32_t* c_bail;
+};
+int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostScratch* ps);
+int post_fuse_sort_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps);
+int rerank_select_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps);
+int rerank_run_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps);
 
 // misc.hip launchers (caller holds ctx->mu)
 int rows_to_local_locked(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t n, uint32_t* d_local,

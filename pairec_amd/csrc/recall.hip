@@ -1518,18 +1518,19 @@ __global__ void recall_init_kernel(const float* __restrict__ queries, uint32_t n
 // than per_list rows) are dropped here, so the keys stay distinct (select_kernel's invariant) and cnt[q] is the number
 // of real candidates.  Input layout: [nq][nlists][per_list] (list_major = 0) or [nlists][nq][per_list] (1: what an
 // all-gather of per-shard [nq][per_list] blocks produces).  cnt must be zero on entry.
+// list l of query q starts at rows + l * row_ls + q * row_qs (scores likewise): covers the query-major layout
+// [nq][nlists][per_list], the list-major one an all-gather produces, and packed per-shard (rows | scores) blocks
 __global__ void merge_keys_kernel(const uint64_t* __restrict__ rows, const float* __restrict__ scores, uint32_t nq,
-                                  uint32_t nlists, uint32_t per_list, int list_major, uint32_t cap,
-                                  uint64_t* __restrict__ cand, uint32_t* __restrict__ cnt) {
+                                  uint32_t nlists, uint32_t per_list, size_t row_ls, size_t row_qs, size_t sc_ls, size_t sc_qs,
+                                  uint32_t cap, uint64_t* __restrict__ cand, uint32_t* __restrict__ cnt) {
     const uint32_t q = blockIdx.y;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t per_q = nlists * per_list;
     if (i >= per_q) return;
     const uint32_t l = i / per_list, j = i - l * per_list;
-    const size_t src = list_major ? ((size_t)l * nq + q) * per_list + j : (size_t)q * per_q + i;
-    const uint64_t r = rows[src];
+    const uint64_t r = rows[l * row_ls + q * row_qs + j];
     if (r == ~0ull) return;
-    cand[(uint64_t)q * cap + atomicAdd(&cnt[q], 1u)] = topk_key(scores[src], (uint32_t)r);
+    cand[(uint64_t)q * cap + atomicAdd(&cnt[q], 1u)] = topk_key(scores[l * sc_ls + q * sc_qs + j], (uint32_t)r);
 }
 
 int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
@@ -2272,10 +2273,9 @@ int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, ui
     return PG_OK;
 }
 
-// global top-k of nlists per-shard lists per query (identical and deterministic on every shard that runs it)
-int topk_merge_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
-                      uint32_t per_list, int list_major, uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
-                      uint32_t* d_out_count) {
+int topk_merge_strided_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
+                              uint32_t per_list, size_t row_ls, size_t row_qs, size_t sc_ls, size_t sc_qs, uint32_t k,
+                              uint64_t* d_out_rows, float* d_out_scores, uint32_t* d_out_count) {
     if (nq < 1 || nq > (uint32_t)kMaxQueries) {
         set_error("topk merge: nq=%u out of range", nq);
         return PG_ERR_INVALID;
@@ -2290,10 +2290,20 @@ int topk_merge_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores
     if ((rc = recall_scratch(ctx, 64, k, &rs))) return rc;
     PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
     dim3 grid((uint32_t)((per_q + 255) / 256), nq);
-    merge_keys_kernel<<<grid, 256, 0, ctx->stream>>>(d_rows, d_scores, nq, nlists, per_list, list_major, rs.cap, rs.cand[0], rs.cnt);
+    merge_keys_kernel<<<grid, 256, 0, ctx->stream>>>(d_rows, d_scores, nq, nlists, per_list, row_ls, row_qs, sc_ls, sc_qs, rs.cap, rs.cand[0],
+                                                    rs.cnt);
     PG_HIP(hipGetLastError());
     if ((rc = launch_select(ctx, nq, rs.cand[0], rs.cand[1], rs.cnt, rs.thr, rs.cap, k, 0))) return rc;
     return final_launch(ctx, rs.cand[1], rs.cnt, rs.cap, nq, k, 0, d_out_rows, d_out_scores, d_out_count);
+}
+
+// global top-k of nlists per-shard lists per query (identical and deterministic on every shard that runs it)
+int topk_merge_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
+                      uint32_t per_list, int list_major, uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
+                      uint32_t* d_out_count) {
+    const size_t ls = list_major ? (size_t)nq * per_list : (size_t)per_list;
+    const size_t qs = list_major ? (size_t)per_list : (size_t)nlists * per_list;
+    return topk_merge_strided_locked(ctx, d_rows, d_scores, nq, nlists, per_list, ls, qs, ls, qs, k, d_out_rows, d_out_scores, d_out_count);
 }
 
 }  // namespace pg

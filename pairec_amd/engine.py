@@ -547,6 +547,72 @@ class Coalescer:
         return s
 
 
+class GroupCoalescer(Coalescer):
+    """pg_coalescer_create_group: single-request recommend calls batched into steps of a shard group."""
+
+    def __init__(self, group: "ShardGroup", expr: "Expr", rank_var: str, k: int, max_top_n: int = 0, dpp_candidates: int = 0,
+                 dpp_alpha: float = 1.0, dpp_window: int = 10, dpp_normalize_emb: bool = True, max_batch: int = 0,
+                 max_wait_us: int = 0, depth: int = 0, timeout_us: int = 0):
+        self.L = group.L
+        self.group, self.k, self.n_algos = group, k, 1
+        self.max_top_n = max_top_n or k
+        plan = _lib.PgGroupPlan(k, dpp_candidates, dpp_alpha, dpp_window, int(dpp_normalize_emb))
+        cfg = _lib.PgCoalescerConfig(k, max_batch, max_wait_us, depth, max_top_n, 0, timeout_us)
+        h = C.c_void_p()
+        _lib.check(self.L.pg_coalescer_create_group(group.h, expr.h, rank_var.encode(), C.byref(plan), C.byref(cfg), C.byref(h)))
+        self.h = h
+
+        class _T:          # (what Coalescer.recommend reads off its table / context)
+            dim = group.dim
+        self.table = _T()
+
+        class _Cx:
+            L = group.L
+        self.ctx = _Cx()
+
+
+class Router:
+    """pg_router_*: per-request calls spread over replica coalescers (least outstanding requests first)."""
+
+    def __init__(self, replicas: Sequence["Coalescer"]):
+        self.L = _lib.load()
+        self.replicas = list(replicas)
+        arr = (C.c_void_p * len(replicas))(*[r.h for r in replicas])
+        h = C.c_void_p()
+        _lib.check(self.L.pg_router_create(arr, len(replicas), C.byref(h)))
+        self.h = h
+        self.dim = replicas[0].table.dim
+        self.k = replicas[0].k
+
+    def destroy(self):
+        if self.h:
+            self.L.pg_router_destroy(self.h)
+            self.h = None
+
+    def recommend(self, user_vec: np.ndarray, top_n: int):
+        u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(self.dim)
+        rows = np.empty(top_n, dtype=np.uint64)
+        rec = np.empty(top_n, dtype=np.float32)
+        rnk = np.empty(top_n, dtype=np.float32)
+        fus = np.empty(top_n, dtype=np.float64)
+        cnt = C.c_uint32()
+        _lib.check(self.L.pg_router_recommend(self.h, _ptr(u), top_n, _ptr(rows), _ptr(rec), _ptr(rnk), _ptr(fus), C.byref(cnt)))
+        return rows, rec, rnk, fus, cnt.value
+
+    def recall(self, query: np.ndarray):
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(self.dim)
+        rows = np.empty(self.k, dtype=np.uint64)
+        scores = np.empty(self.k, dtype=np.float32)
+        cnt = C.c_uint32()
+        _lib.check(self.L.pg_router_recall(self.h, _ptr(q), _ptr(rows), _ptr(scores), C.byref(cnt)))
+        return rows, scores, cnt.value
+
+    def served(self) -> np.ndarray:
+        out = np.zeros(len(self.replicas), dtype=np.uint64)
+        _lib.check(self.L.pg_router_stats(self.h, _ptr(out)))
+        return out
+
+
 class ShardGroup:
     """pg_group_*: the item table in row-range shards over several GPUs of this process (or logical shards of one)."""
 
@@ -591,6 +657,28 @@ class ShardGroup:
         cnt = np.zeros(nq, dtype=np.uint32)
         _lib.check(self.L.pg_group_recommend(self.h, expr.h, rank_var.encode(), C.byref(plan), _ptr(u), nq, top_n,
                                              _ptr(rows), _ptr(rec), _ptr(rnk), _ptr(fus), _ptr(cnt)))
+        return rows, rec, rnk, fus, cnt
+
+
+    def recommend_begin(self, expr: "Expr", rank_var: str, user_vecs: np.ndarray, k: int, top_n: int,
+                        dpp_candidates: int = 0, dpp_alpha: float = 1.0, dpp_window: int = 10,
+                        dpp_normalize_emb: bool = True):
+        """pg_group_recommend_begin: enqueue a step, return its ticket (up to two may be outstanding)."""
+        u = np.ascontiguousarray(user_vecs, dtype=np.float32).reshape(-1, self.dim)
+        plan = _lib.PgGroupPlan(k, dpp_candidates, dpp_alpha, dpp_window, int(dpp_normalize_emb))
+        tk = C.c_void_p()
+        _lib.check(self.L.pg_group_recommend_begin(self.h, expr.h, rank_var.encode(), C.byref(plan), _ptr(u), u.shape[0], top_n,
+                                                   C.byref(tk)))
+        return (tk, u.shape[0], top_n)
+
+    def recommend_end(self, ticket):
+        tk, nq, top_n = ticket
+        rows = np.empty((nq, top_n), dtype=np.uint64)
+        rec = np.empty((nq, top_n), dtype=np.float32)
+        rnk = np.empty((nq, top_n), dtype=np.float32)
+        fus = np.empty((nq, top_n), dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        _lib.check(self.L.pg_group_recommend_end(self.h, tk, _ptr(rows), _ptr(rec), _ptr(rnk), _ptr(fus), _ptr(cnt)))
         return rows, rec, rnk, fus, cnt
 
 

@@ -60,6 +60,107 @@ def test_group_equals_single_shard_oracle(shards, n, dpp_c):
     g.destroy()
 
 
+def test_group_two_steps_in_flight_and_distributed_tail():
+    """pg_group_recommend_begin / _end: two steps outstanding (one per lane) over 3 logical shards, each shard finishing
+    the requests q = s (mod 3) — fusion, sort, DPP on its own share — against the single-table oracle; a third _begin
+    while two are outstanding is refused, table changes too."""
+    shards, n, d, k, R, top_n, dpp_c = 3, 110_000, 128, 300, 11, 30, 80
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    w = o.Dnn3Weights()
+    g = pa.ShardGroup([0] * shards)
+    g.table_create(n, d)
+    g.table_fill_synthetic(o.SEED_TABLE)
+    g.model_load(pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    ex = pa.Expr(EXPR)
+    qa = o.synth_rows(o.SEED_QUERY, 300, R, d)
+    qb = o.synth_rows(o.SEED_QUERY, 400, R - 4, d)
+    ta = g.recommend_begin(ex, "gpu_dnn", qa, k, top_n, dpp_candidates=dpp_c)
+    tb = g.recommend_begin(ex, "gpu_dnn", qb, k, top_n, dpp_candidates=dpp_c)
+    with pytest.raises(pa._lib.PgError):
+        g.recommend_begin(ex, "gpu_dnn", qa, k, top_n)
+    with pytest.raises(pa._lib.PgError):
+        g.table_fill_synthetic(o.SEED_TABLE)
+    for tk, q in ((tb, qb), (ta, qa)):                     # collected out of order
+        rows, rec, rnk, fus, cnt = g.recommend_end(tk)
+        want = oracle_pipeline(tab, w, pa.PREC_F32, q, k, top_n, dpp_c, 1.0, 10)
+        for r in range(q.shape[0]):
+            assert cnt[r] == top_n and np.array_equal(rows[r], want[r][0]), "request %d" % r
+            assert np.array_equal(bits(rec[r]), bits(want[r][1])) and np.max(np.abs(fus[r] - want[r][3])) <= 1e-6
+    # a later expression with more variables, and larger shapes, on the same group (buffers grow while it is idle)
+    ex2 = pa.Expr("${gpu_dnn}*0.5+${current_score}*${current_score}+${gpu_dnn}")
+    rows, rec, rnk, fus, cnt = g.recommend(ex2, "gpu_dnn", qa, k + 50, top_n)
+    assert cnt.tolist() == [top_n] * R and np.all(np.diff(fus, axis=1) <= 0)
+    g.destroy()
+
+
+def test_coalescer_over_group_and_replica_router(ctx):
+    """Per-request calls over several GPUs (here: logical shards / replicas of one device): 256 threads through a
+    coalescer over a 2-shard group get the pages of the caller-made group step; through a router over two replica
+    coalescers they get the single-GPU pages, and both replicas serve."""
+    import threading
+    n, d, k, top_n, callers = 120_000, 128, 300, 20, 256
+    w = o.Dnn3Weights()
+    blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+    ex = pa.Expr(EXPR)
+    q = o.synth_rows(o.SEED_QUERY, 50, callers, d)
+
+    def run(fn):
+        errs, gate = [], threading.Barrier(callers)
+
+        def wrap(i):
+            try:
+                gate.wait()
+                fn(i)
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=wrap, args=(i,)) for i in range(callers)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if errs:
+            raise errs[0]
+    g = pa.ShardGroup([0, 0])
+    g.table_create(n, d)
+    g.table_fill_synthetic(o.SEED_TABLE)
+    g.model_load(pa.MODEL_DNN3, pa.PREC_BF16, blob)
+    want = g.recommend(ex, "gpu_dnn", q, k, top_n, dpp_candidates=60)
+    co = pa.GroupCoalescer(g, ex, "gpu_dnn", k, max_top_n=top_n, dpp_candidates=60, max_wait_us=2000)
+    got = [None] * callers
+    run(lambda i: got.__setitem__(i, co.recommend(q[i], top_n)))
+    st = co.stats()
+    co.destroy()
+    for i in range(callers):
+        assert got[i][4] == top_n and np.array_equal(got[i][0], want[0][i]), "request %d through the group coalescer" % i
+        assert np.array_equal(bits(got[i][1]), bits(want[1][i])) and np.array_equal(bits(got[i][2]), bits(want[2][i]))
+        assert np.array_equal(bits(got[i][3]), bits(want[3][i]))
+    assert st.requests[2] == callers and st.batches[2] <= callers // 8
+    g.destroy()
+    # replicas: the same table twice, one coalescer each, one router
+    tabs, models, cos = [], [], []
+    for _ in range(2):
+        t = pa.Table(ctx, n, d)
+        t.fill_synthetic(o.SEED_TABLE)
+        m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16, blob)
+        tabs.append(t)
+        models.append(m)
+        cos.append(pa.Coalescer(ctx, t, k, m, ex, "gpu_dnn", max_top_n=top_n, max_wait_us=500))
+    router = pa.Router(cos)
+    got = [None] * callers
+    run(lambda i: [got.__setitem__(i, router.recommend(q[i], top_n)) for _ in range(3)])
+    served = router.served()
+    router.destroy()
+    for i in range(0, callers, 29):
+        rows, rec, rnk, fus, order, _ = pa.recommend_dnn3(ctx, tabs[0], models[0], ex, "gpu_dnn", q[i:i + 1], k)
+        p = order[0][:top_n]
+        assert np.array_equal(got[i][0], rows[0][p]) and np.array_equal(bits(got[i][3]), bits(fus[0][p]))
+    assert served.sum() == 3 * callers and served.min() >= callers // 2, served
+    for c_ in cos:
+        c_.destroy()
+    for m in models:
+        m.destroy()
+    for t in tabs:
+        t.destroy()
+
+
 def test_group_upload_and_batch_of_256():
     """Uploaded (not generated) rows routed to their shards; a full 256-request batch; bf16 model."""
     n, d, k, R, top_n = 60_000, 128, 200, 256, 10
