@@ -124,58 +124,106 @@ __global__ __launch_bounds__(64) void dpp_prepare_table_kernel(DppPrep a) {
 // one-thread-per-element version — which read every F row n times from L2: 66 GB for 256 requests x 500 candidates
 // (cfg 5's batch), 30 ms; tiled it is ~1 ms.
 constexpr int kDppTile = 64, kDppKc = 16;
-__global__ __launch_bounds__(256) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
-                                                                uint32_t n, uint32_t d1, double* __restrict__ L) {
-    __shared__ double sa[kDppKc][kDppTile + 1];      // [k][row]: a thread's 4 rows are 16 apart → distinct banks
-    __shared__ double sb[kDppKc][kDppTile + 1];
+// One WAVE per 64 x 64 tile of S = F F^T, upper triangle only (blockIdx.x walks the tile pairs ti <= tj): lane (ty, tx)
+// of an 8 x 8 grid owns the 8 x 8 patch rows {2ty, 2ty + 1} + 16a, columns {2tx, 2tx + 1} + 16b — 64 accumulators per
+// lane, and an operand pair is ONE 16-B LDS read: 8 reads per 64 fma (the round-2 kernel's 4 x 4 patches needed 8
+// reads per 16 fma and were LDS-bound at 28 % of the fp64 rate).  The panels are staged with 16 lanes per row (128
+// contiguous bytes per row and instruction).  Every element is its own k-ascending fma chain, as the specification
+// wants it; S is symmetric bit for bit (a product commutes), L is not — L_ij = (r_i S_ij) r_j and L_ji = (r_j S_ij) r_i
+// are both formed from the one S_ij.
+__global__ __launch_bounds__(64) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
+                                                               uint32_t n, uint32_t d1, uint32_t nt, double* __restrict__ L) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) double sa[kDppKc][kDppTile + 2];      // [k][row], rows padded to a 16-B multiple
+    __shared__ __attribute__((aligned(16))) double sb[kDppKc][kDppTile + 2];
     const uint32_t q = blockIdx.z;
-    const uint32_t i0 = blockIdx.y * kDppTile, j0 = blockIdx.x * kDppTile;
-    const uint32_t tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // patch: rows ty + 16a, cols tx + 16b
+    // tile pair p → (ti, tj), ti <= tj: row ti holds nt - ti pairs
+    uint32_t ti = 0, p = blockIdx.x;
+    while (p >= nt - ti) {
+        p -= nt - ti;
+        ++ti;
+    }
+    const uint32_t tj = ti + p;
+    const uint32_t i0 = ti * kDppTile, j0 = tj * kDppTile;
+    const uint32_t lane = threadIdx.x, tx = lane & 7, ty = lane >> 3;
+    const uint32_t kk = lane & 15, rr = lane >> 4;             // staging: column kk of rows rr + 4 it
     const double* Fq = F + (size_t)q * n * d1;
-    double acc[4][4];
+    double acc[8][8];                                          // [2a + u][2b + v]: row 2ty + u + 16a, column 2tx + v + 16b
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
     for (uint32_t k0 = 0; k0 < d1; k0 += kDppKc) {
-        // stage: 64 rows x 16 columns of each panel; thread t loads (row = t >> 2, 4 columns (t & 3) * 4 ..)
-        {
-            const uint32_t row = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
+        const uint32_t kc = d1 - k0 < (uint32_t)kDppKc ? d1 - k0 : (uint32_t)kDppKc;
+        double va[16], vb[16];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t k = k0 + c4 + c;
-                const uint32_t ri = i0 + row, rj = j0 + row;
-                sa[c4 + c][row] = (ri < n && k < d1) ? Fq[(size_t)ri * d1 + k] : 0.0;
-                sb[c4 + c][row] = (rj < n && k < d1) ? Fq[(size_t)rj * d1 + k] : 0.0;
-            }
+        for (int it = 0; it < 16; ++it) {
+            const uint32_t row = (uint32_t)it * 4 + rr;
+            const uint32_t ri = i0 + row, rj = j0 + row;
+            va[it] = (ri < n && kk < kc) ? Fq[(size_t)ri * d1 + k0 + kk] : 0.0;
+            vb[it] = (rj < n && kk < kc) ? Fq[(size_t)rj * d1 + k0 + kk] : 0.0;
+        }
+        __syncthreads();                                       // the previous step's readers are done
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            sa[kk][it * 4 + rr] = va[it];
+            sb[kk][it * 4 + rr] = vb[it];
         }
         __syncthreads();
-        const uint32_t kc = d1 - k0 < (uint32_t)kDppKc ? d1 - k0 : (uint32_t)kDppKc;
         for (uint32_t k = 0; k < kc; ++k) {
-            double av[4], bv[4];
+            f64x2 av[4], bv[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = sa[k][ty + 16 * a];
+            for (int a = 0; a < 4; ++a) av[a] = *reinterpret_cast<const f64x2*>(&sa[k][2 * ty + 16 * a]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = sb[k][tx + 16 * b];
+            for (int b = 0; b < 4; ++b) bv[b] = *reinterpret_cast<const f64x2*>(&sb[k][2 * tx + 16 * b]);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+                for (int b = 0; b < 4; ++b) {
+                    acc[2 * a][2 * b] = fma(av[a].x, bv[b].x, acc[2 * a][2 * b]);
+                    acc[2 * a][2 * b + 1] = fma(av[a].x, bv[b].y, acc[2 * a][2 * b + 1]);
+                    acc[2 * a + 1][2 * b] = fma(av[a].y, bv[b].x, acc[2 * a + 1][2 * b]);
+                    acc[2 * a + 1][2 * b + 1] = fma(av[a].y, bv[b].y, acc[2 * a + 1][2 * b + 1]);
+                }
         }
-        __syncthreads();
     }
+    // L tile and (off the diagonal) its mirror, written as whole 512-B rows: the patches go through LDS — half a tile
+    // (32 rows) at a time, in the panels' space — so that a store instruction covers one contiguous row of 64 doubles
+    // (patch-wise stores are 16-B runs scattered over eight rows: 512 MB of them per 256-request batch)
     const double* rq = r + (size_t)q * n;
+    double* const stage = &sa[0][0];                            // 32 x 65 doubles fit the two panels (2 x 16 x 66)
+    static_assert(32 * 65 <= 2 * kDppKc * (kDppTile + 2), "the output staging aliases the panels");
+    double rjv[8], riv[8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const uint32_t i = i0 + ty + 16 * a;
-        if (i >= n) continue;
-        const double ri = rq[i];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t j = j0 + tx + 16 * b;
-            if (j < n) L[((size_t)q * n + i) * n + j] = __dmul_rn(__dmul_rn(ri, acc[a][b]), rq[j]);
-        }
+    for (int b = 0; b < 8; ++b) {
+        const uint32_t j = j0 + 2 * tx + (b & 1) + 16 * (b >> 1);
+        rjv[b] = j < n ? rq[j] : 0.0;
+        const uint32_t i = i0 + 2 * ty + (b & 1) + 16 * (b >> 1);
+        riv[b] = i < n ? rq[i] : 0.0;
     }
+    for (int mirror = 0; mirror < (ti != tj ? 2 : 1); ++mirror)
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();                                    // the panels' / the previous half's readers are done
+            // this lane's elements whose OUTPUT row falls into rows [32 half, 32 half + 32) of the (mirrored) tile
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int row_t = 2 * (int)ty + (a & 1) + 16 * (a >> 1);        // row of the tile
+                    const int col_t = 2 * (int)tx + (b & 1) + 16 * (b >> 1);
+                    const int orow = mirror ? col_t : row_t, ocol = mirror ? row_t : col_t;
+                    if ((orow >> 5) != half) continue;
+                    const double v = mirror ? __dmul_rn(__dmul_rn(rjv[b], acc[a][b]), riv[a])
+                                            : __dmul_rn(__dmul_rn(riv[a], acc[a][b]), rjv[b]);
+                    stage[(orow & 31) * 65 + ocol] = v;
+                }
+            __syncthreads();
+            const uint32_t r0 = (mirror ? j0 : i0) + 32 * half, c0 = mirror ? i0 : j0;
+            for (int rr2 = 0; rr2 < 32; ++rr2) {
+                const uint32_t gi = r0 + rr2, gj = c0 + lane;
+                if (gi < n && gj < n) L[((size_t)q * n + gi) * n + gj] = stage[rr2 * 65 + lane];
+            }
+        }
 }
 
 // floats.MaxIdx: first maximum, NaN skipped; all-NaN → index 0.  Block-wide, result in *s_idx.
@@ -461,7 +509,7 @@ int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, cons
     else if (has_table && hook_dim == 0 && d == 64) dpp_prepare_table_kernel<64><<<dim3((n + 63) / 64, R), 64, 0, ctx->stream>>>(a);
     else dpp_prepare_kernel<<<dim3((n + 63) / 64, R), 64, 0, ctx->stream>>>(a);
     const uint32_t nt = (n + kDppTile - 1) / kDppTile;
-    dpp_kernel_matrix_kernel<<<dim3(nt, nt, R), 256, 0, ctx->stream>>>(F, Rr, n, d1, L);
+    dpp_kernel_matrix_kernel<<<dim3(nt * (nt + 1) / 2, 1, R), 64, 0, ctx->stream>>>(F, Rr, n, d1, nt, L);
     const uint32_t wrows = window < n ? window : n;
     if (n <= 512 && window <= 16) {
         const size_t lds = (size_t)wrows * 512 * 8;

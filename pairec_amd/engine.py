@@ -608,8 +608,9 @@ class Router:
         return rows, scores, cnt.value
 
     def served(self) -> np.ndarray:
-        out = np.zeros(len(self.replicas), dtype=np.uint64)
-        _lib.check(self.L.pg_router_stats(self.h, _ptr(out)))
+        out = (C.c_uint64 * len(self.replicas))()
+        _lib.check(self.L.pg_router_stats(self.h, out))
+        out = np.array(list(out), dtype=np.uint64)
         return out
 
 
