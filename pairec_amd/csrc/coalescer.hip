@@ -382,6 +382,9 @@ int enqueue_recall_batch(pg_coalescer* c, Slot* s, bool first) {
     const uint32_t nq = s->n_req;
     int rc;
     std::lock_guard<std::mutex> g(ctx->mu);
+    TableRead tr(c->t->rw);
+    TableRead tr2;
+    if (c->trigger_table != c->t) tr2 = TableRead(c->trigger_table->rw);
     RecallJob& j = s->run->job;
     if (first) {
         bool any_trigger = false, any_online = false;
@@ -425,6 +428,7 @@ int enqueue_rank_batch(pg_coalescer* c, Slot* s) {
     PG_HIP(hipMemcpyAsync(s->d_cand, s->h_cand, (size_t)s->n_items * 4, hipMemcpyHostToDevice, st));
     PG_HIP(hipMemcpyAsync(s->d_off, s->h_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, st));
     std::lock_guard<std::mutex> g(ctx->mu);
+    TableRead tr(c->t->rw);
     if (al.m->kind != PG_MODEL_DNN3) PG_HIP(hipMemcpyAsync(s->d_ufid, s->h_ufid, (size_t)nq * al.m->nuf * 4, hipMemcpyHostToDevice, st));
     return rank_algo_locked(ctx, al, c->t, s->d_vec, s->d_ufid, s->d_cand, s->d_off, nq, s->n_items, s->d_rank);
 }
@@ -439,6 +443,7 @@ int enqueue_dpp_batch(pg_coalescer* c, Slot* s) {
     if (key.has_table) PG_HIP(hipMemcpyAsync(s->d_dcand, s->h_dcand, items * 4, hipMemcpyHostToDevice, st));
     if (key.hook_dim) PG_HIP(hipMemcpyAsync(s->d_dhook, s->h_dhook, items * key.hook_dim * 8, hipMemcpyHostToDevice, st));
     std::lock_guard<std::mutex> g(ctx->mu);
+    TableRead tr(c->t->rw);
     int rc;
     if (key.has_table && (rc = table_gather_locked(ctx, c->t, s->d_dcand, (uint32_t)items, s->d_demb))) return rc;
     return dpp_run_locked(ctx, key.has_table ? s->d_demb : nullptr, key.hook_dim ? s->d_dhook : nullptr, s->d_drel, R, key.n,

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -76,6 +77,11 @@ struct Knobs {
 }  // namespace pg
 
 struct pg_table {
+    // Readers — every enqueue that dereferences the table's pointers, for as long as it reads them — share this lock;
+    // pg_table_swap / _upload / _fill take it exclusively and drain the device first.  A request batch (recall, rank,
+    // DPP gather: one enqueue) therefore sees ONE table version even when a second context (a coalescer's sibling)
+    // enqueues while the table is being swapped.  Lock order: ctx->mu, then the table.
+    mutable std::shared_mutex rw;
     float* d = nullptr;          // [rows][dim] fp32 row-major
     uint64_t rows = 0;
     uint32_t dim = 0;
@@ -174,6 +180,17 @@ struct pg_ctx {
 };
 
 namespace pg {
+
+typedef std::shared_lock<std::shared_mutex> TableRead;
+// exclusive access to one or two tables (address order) with nothing in flight on the device
+struct TableWrite {
+    std::unique_lock<std::shared_mutex> a, b;
+    TableWrite(const pg_table* x, const pg_table* y = nullptr) {
+        if (y && y < x) std::swap(x, y);
+        a = std::unique_lock<std::shared_mutex>(x->rw);
+        if (y && y != x) b = std::unique_lock<std::shared_mutex>(y->rw);
+    }
+};
 
 // ---- recall.hip: a recall whose plans are enqueued without host synchronisation and verified later --------
 struct RecallScratch {

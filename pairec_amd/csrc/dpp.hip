@@ -646,6 +646,8 @@ int pg_dpp_ex(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const d
     if (out_relevance) memcpy(out_relevance, rs.data(), (size_t)n * 8);      // "dpp_relevance_score" (:410)
     const uint32_t topn = o->topn;
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr;
+    if (o->has_table) tr = pg::TableRead(t->rw);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t bCand = al((size_t)n * 4), bRel = al((size_t)n * 8), bEmb = al((size_t)n * std::max(dim, 1u) * 4);
     const size_t bHook = al((size_t)n * std::max(o->hook_dim, 1u) * 8), bOut = al((size_t)(topn + 1) * 4 + 16);

@@ -210,6 +210,7 @@ int rank_algo_locked(pg_ctx* ctx, const RankAlgoRef& al, const pg_table* t, cons
 
 int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool first) {
     std::lock_guard<std::mutex> g(ctx->mu);
+    TableRead tr(c.t->rw);               // recall, rank and the DPP gather of one batch read one version of the table
     int rc;
     PostScratch ps;
     if ((rc = post_scratch(ctx, c, c.nq, &ps))) return rc;
@@ -238,6 +239,7 @@ int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool firs
 
 int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok, const RecommendCall* c) {
     std::lock_guard<std::mutex> g(ctx->mu);
+    TableRead tr(r->job.t->rw);
     int rc;
     if ((rc = recall_job_check(&r->job, ok))) return rc;
     RecallJob& j = r->job;

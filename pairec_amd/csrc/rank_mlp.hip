@@ -1144,6 +1144,7 @@ int pg_rank_dnn3_dev(pg_ctx* ctx, const pg_model* m, const pg_table* t, const fl
     PG_REQUIRE(t->dim == m->d_item, "pg_rank_dnn3_dev: table dim %u != model d_item %u", t->dim, m->d_item);
     PG_REQUIRE(n_req <= 65535, "pg_rank_dnn3_dev: at most 65535 requests per call");
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
     return pg::rank_dnn3_dev_locked(ctx, m, t, d_user_vecs, d_cand_rows, d_req_offsets, n_req, n_items,
                                     d_out_scores);
 }
@@ -1166,6 +1167,7 @@ int pg_rank_dnn3(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float*
         PG_REQUIRE(cand_rows[i] < t->rows, "pg_rank_dnn3: candidate %u row %u outside table of %llu rows", i,
                    cand_rows[i], (unsigned long long)t->rows);
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
     void* buf;
     int rc;
     const size_t ub = (size_t)n_req * m->d_user * 4, cb = (size_t)n_items * 4, ob = (size_t)(n_req + 1) * 4;

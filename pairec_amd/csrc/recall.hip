@@ -2332,6 +2332,7 @@ int pg_recall_topk_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, u
         return PG_ERR_UNSUPPORTED;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
     return pg::recall_dev_locked(ctx, t, d_queries, nq, k, d_out_rows, d_out_scores, out_count, nullptr);
 }
 
@@ -2345,6 +2346,7 @@ int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_
         return PG_ERR_UNSUPPORTED;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
     void* buf;
     int rc;
     const size_t qb = (size_t)nq * t->dim * 4, rb = (size_t)nq * k * 8, sb = (size_t)nq * k * 4;
@@ -2376,6 +2378,9 @@ int pg_i2i_recall(pg_ctx* ctx, const pg_table* trigger_table, const uint32_t* tr
         PG_REQUIRE(trigger_rows[i] < trigger_table->rows, "pg_i2i_recall: trigger row %u outside table of %llu rows", trigger_rows[i],
                    (unsigned long long)trigger_table->rows);
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
+    pg::TableRead tr2;
+    if (trigger_table != t) tr2 = pg::TableRead(trigger_table->rw);
     void* buf;
     int rc;
     const size_t qb = (size_t)n * t->dim * 4, rb = (size_t)n * k * 8, sb = (size_t)n * k * 4;
@@ -2409,6 +2414,7 @@ int pg_online_vector_recall(pg_ctx* ctx, const pg_model* m, const pg_table* item
         return PG_ERR_UNSUPPORTED;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(item_emb->rw);
     void* buf;
     int rc;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };

@@ -555,6 +555,7 @@ int pg_ssd(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const doub
 
     const uint32_t T = n < topn ? n : topn;
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t bE = al((size_t)n * d1 * 8), bP = al((size_t)window * n * 8), bN = al((size_t)n * 8);
     const size_t bCand = al((size_t)n * 4), bSel = al((size_t)n * 4), bOut = al((size_t)T * 4);

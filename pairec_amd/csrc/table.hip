@@ -132,6 +132,7 @@ int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
 int pg_table_fill_synthetic(pg_ctx* ctx, pg_table* t, uint64_t seed, int normalize) {
     PG_REQUIRE(ctx && t, "pg_table_fill_synthetic: NULL argument");
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableWrite w(t);
     const uint32_t blocks = (uint32_t)((t->rows + 255) / 256);
     switch (t->dim) {
         case 64:
@@ -160,6 +161,7 @@ int pg_table_fill_gaussian(pg_ctx* ctx, pg_table* t, uint64_t seed, float sigma)
     PG_REQUIRE(ctx && t, "pg_table_fill_gaussian: NULL argument");
     PG_REQUIRE(sigma > 0.0f && sigma < 1e30f, "pg_table_fill_gaussian: sigma must be positive and finite");
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableWrite w(t);
     const uint64_t n = t->rows * (uint64_t)t->dim;
     pg::table_fill_gauss_kernel<<<(uint32_t)ctx->num_cus * 16, 256, 0, ctx->stream>>>(t->d, n, t->row_offset * (uint64_t)t->dim, seed,
                                                                                      (double)sigma);
@@ -175,6 +177,9 @@ int pg_table_upload(pg_ctx* ctx, pg_table* t, uint64_t row0, uint64_t nrows, con
                (unsigned long long)row0, (unsigned long long)(row0 + nrows), (unsigned long long)t->rows);
     std::lock_guard<std::mutex> g(ctx->mu);
     if (nrows == 0) return PG_OK;
+    pg::TableWrite w(t);                             // no enqueue reads the table's pointers meanwhile (rows of a table that is
+                                                     // being served change under batches already in flight: load into a
+                                                     // second table and pg_table_swap for an atomic change-over)
     PG_HIP(hipMemcpyAsync(t->d + row0 * t->dim, host_rows, nrows * (size_t)t->dim * sizeof(float),
                           hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
@@ -197,7 +202,11 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     PG_REQUIRE(ctx && a && b, "pg_table_swap: NULL argument");
     PG_REQUIRE(a->rows == b->rows && a->dim == b->dim, "pg_table_swap: shapes differ");
     std::lock_guard<std::mutex> g(ctx->mu);          // no call on this context is mid-flight
-    PG_HIP(hipStreamSynchronize(ctx->stream));
+    pg::TableWrite w(a, b);                          // ... and no other context is enqueueing against either table
+    // Everything already enqueued holds the old pointers and stays valid (both buffers live on), but whoever swapped
+    // will soon refill the table that now holds the old rows: drain the device so that nothing still reads them.
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipDeviceSynchronize());
     std::swap(a->d, b->d);
     std::swap(a->row_offset, b->row_offset);
     std::swap(a->stats_valid, b->stats_valid);
@@ -235,6 +244,7 @@ int pg_table_gather(pg_ctx* ctx, const pg_table* t, const uint32_t* rows, uint32
     for (uint32_t i = 0; i < n; ++i)
         PG_REQUIRE(rows[i] < t->rows, "pg_table_gather: row %u out of range", rows[i]);
     std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
     void *d_rows, *d_out;
     int rc;
     if ((rc = pg::scratch_reserve(ctx, 0, (size_t)n * 4, &d_rows))) return rc;

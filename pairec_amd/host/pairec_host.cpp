@@ -1139,6 +1139,7 @@ Engine::~Engine() {
         if (fm2t) pg_model_destroy(ctx, fm2t);
         if (feats) pg_features_destroy(ctx, feats);
         if (item_emb) pg_table_destroy(ctx, item_emb);
+        if (staging) pg_table_destroy(ctx, staging);
         if (table) pg_table_destroy(ctx, table);
         pg_shutdown(ctx);
     }
@@ -1268,15 +1269,6 @@ pg_coalescer* Engine::PageCoalescer(const recconf::RecallConfig& conf, std::stri
     return c;
 }
 
-bool Engine::RowOfId(const std::string& id, uint32_t* row) const {
-    if (id.compare(0, id_prefix.size(), id_prefix) != 0) return false;
-    char* e = nullptr;
-    const unsigned long long r = strtoull(id.c_str() + id_prefix.size(), &e, 10);
-    if (e == id.c_str() + id_prefix.size() || *e != '\0' || r >= table_rows) return false;
-    *row = (uint32_t)r;
-    return true;
-}
-
 Engine* Engine::Create(const std::string& config_json, std::string* err) {
     std::unique_ptr<Engine> e(new Engine());
     if (!recconf::RecommendConfig::Parse(config_json, &e->config, err)) return nullptr;
@@ -1311,7 +1303,12 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
     e->id_prefix = tb.s("IdPrefix", "item_");
     if (pg_init((int)g.n("Device", 0), nullptr, &e->ctx) != PG_OK) { if (err) *err = pg_err("pg_init"); return nullptr; }
     if (pg_table_create(e->ctx, e->table_rows, e->dim, 0, &e->table) != PG_OK) { if (err) *err = pg_err("pg_table_create"); return nullptr; }
-    if (pg_table_fill_synthetic(e->ctx, e->table, (uint64_t)tb.n("SyntheticSeed", 0x5EED0001), 1) != PG_OK) {
+    const std::string table_path = tb.s("Path", "");
+    if (!table_path.empty()) {
+        // (item_id, embedding) rows from a file: the loader streams them in chunks and commits (ingest.cpp); the same
+        // call replaces the table later while the engine serves (ph_engine_ingest_file)
+        if (!e->IngestFile(table_path, err)) return nullptr;
+    } else if (pg_table_fill_synthetic(e->ctx, e->table, (uint64_t)tb.n("SyntheticSeed", 0x5EED0001), 1) != PG_OK) {
         if (err) *err = pg_err("pg_table_fill_synthetic");
         return nullptr;
     }
@@ -1393,6 +1390,7 @@ bool Engine::Recommend(const std::string& uid, int size, const std::string& scen
 
 bool Engine::Recommend(const std::string& uid, int size, const std::string& scene, const json::Value& experiment_params,
                        std::vector<module::ItemPtr>* out, std::string* err) {
+    VersionLock::Read generation_guard(version);     // one generation of rows and ids for the whole request
     module::User user(uid);
     context::RecommendContext ctx;
     ctx.Size = size;

@@ -14,6 +14,8 @@
 // The GPU-backed plugins (GpuFaissAlgorithm, GpuDnnAlgorithm, GpuVectorRecall, Gpu*Sort) are what
 // the cgo shim of INTEGRATION.md registers under the same registries in a real pairec process.
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -313,6 +315,62 @@ private:
 };
 }  // namespace sort
 
+// ---- item ids (ingest.cpp) ------------------------------------------------------------------------------------------
+// row ↔ module.ItemId: the ids back to back in one arena, an offset per row, an open-addressing table of row numbers
+class IdDict {
+public:
+    void Reserve(uint64_t rows, uint64_t id_bytes);
+    void Append(const char* id, size_t len);                 // the next row's id
+    bool BuildIndex(std::string* err);                       // after the last Append; fails on a duplicate id
+    uint64_t size() const { return off_.empty() ? 0 : off_.size() - 1; }
+    std::string IdOf(uint64_t row) const { return std::string(arena_.data() + off_[row], (size_t)(off_[row + 1] - off_[row])); }
+    bool RowOf(const char* id, size_t len, uint32_t* row) const;
+private:
+    static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+    std::vector<char> arena_;
+    std::vector<uint64_t> off_;
+    std::unique_ptr<std::atomic<uint32_t>[]> slots_;
+    uint64_t mask_ = 0;
+};
+
+// Readers (requests) share, the table generation change-over is exclusive and goes first once it waits
+// (a plain pthread rwlock lets a steady stream of readers starve the writer)
+class VersionLock {
+public:
+    struct Read {
+        explicit Read(VersionLock& l) : l_(l) {
+            std::unique_lock<std::mutex> g(l_.mu_);
+            l_.cv_.wait(g, [&] { return !l_.writing_ && l_.writers_waiting_ == 0; });
+            ++l_.readers_;
+        }
+        ~Read() {
+            std::lock_guard<std::mutex> g(l_.mu_);
+            if (--l_.readers_ == 0) l_.cv_.notify_all();
+        }
+        VersionLock& l_;
+    };
+    struct Write {
+        explicit Write(VersionLock& l) : l_(l) {
+            std::unique_lock<std::mutex> g(l_.mu_);
+            ++l_.writers_waiting_;
+            l_.cv_.wait(g, [&] { return !l_.writing_ && l_.readers_ == 0; });
+            --l_.writers_waiting_;
+            l_.writing_ = true;
+        }
+        ~Write() {
+            std::lock_guard<std::mutex> g(l_.mu_);
+            l_.writing_ = false;
+            l_.cv_.notify_all();
+        }
+        VersionLock& l_;
+    };
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int readers_ = 0, writers_waiting_ = 0;
+    bool writing_ = false;
+};
+
 // ---- the engine: GPU-backed plugins wired under the registries -------------------------------------
 class Engine {
 public:
@@ -358,9 +416,23 @@ public:
     pg_coalescer* PageCoalescer(const recconf::RecallConfig& conf, std::string* err);
     uint64_t table_rows = 0;
     uint32_t dim = 0;
-    std::string id_prefix = "item_";          // row ↔ id dictionary: "<prefix><row>"
+    std::string id_prefix = "item_";          // without a dictionary: "<prefix><row>"
+    // row ↔ item id: the dictionary of the table's current generation (ingest.cpp), else the prefix scheme
+    std::shared_ptr<const IdDict> dict;
     bool RowOfId(const std::string& id, uint32_t* row) const;
-    std::string IdOfRow(uint64_t row) const { return id_prefix + std::to_string(row); }
+    std::string IdOfRow(uint64_t row) const;
+    // table generations: a request holds `version` shared from its first plug-in call to its last label lookup; a
+    // commit swaps table and dictionary exclusively
+    VersionLock version;
+    std::atomic<uint64_t> generation{0};
+    std::mutex ingest_mu;
+    pg_table* staging = nullptr;
+    std::unique_ptr<IdDict> staging_dict;
+    uint64_t staging_filled = 0;
+    bool IngestBegin(std::string* err);
+    bool IngestChunk(const char* ids, size_t ids_bytes, const float* rows, uint64_t n, std::string* err);
+    bool IngestCommit(std::string* err);
+    bool IngestFile(const std::string& path, std::string* err);       // the table's "Path" (UserDefineConfs.pairec_gpu.Table.Path)
 };
 
 namespace rank {
