@@ -11,6 +11,7 @@
  */
 #include "oracle.h"
 #include <float.h>
+#include <immintrin.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -297,6 +298,73 @@ static void mlp2_dot_row(int prec, uint32_t din, uint32_t h1n, uint32_t h2n, con
     *out = sigmoidf_spec(p0 + p1);
 }
 
+/* The same arithmetic for ORC_MB items at a time: every output element is still its own k-ascending fmaf chain, so
+ * the bits are those of mlp2_dot_row — but a row of W1 / W2 is loaded once per ORC_MB items instead of once per item,
+ * and the accumulators of a 16-column tile stay in registers (the row-wise form streams the 512-float hidden buffer
+ * through L1 for every input element: that is what made the CPU baseline's rank leg a 0.3 TFLOP/s scalar chain). */
+#define ORC_MB 4
+#define ORC_JT 16
+static void mlp2_dot_rows_blocked(int prec, uint32_t din, uint32_t h1n, uint32_t h2n, const float* x /* [ORC_MB][din] */,
+                                  const float* c1, const float* w1, const float* w2, const float* b2, int act2,
+                                  const float* w3, float bias3, float* xr /* [ORC_MB][din] */, float* h1buf /* [ORC_MB][h1n] */,
+                                  float* h2buf /* [ORC_MB][h2n] */, float* out /* [ORC_MB] */) {
+    for (uint32_t b = 0; b < ORC_MB; ++b)
+        for (uint32_t k = 0; k < din; ++k) xr[(size_t)b * din + k] = op_round(x[(size_t)b * din + k], prec);
+    /* (AVX2: _mm256_fmadd_ps is the correctly rounded fused multiply-add of fmaf, eight lanes at a time) */
+    for (uint32_t j0 = 0; j0 < h1n; j0 += ORC_JT) {
+        __m256 acc[ORC_MB][2];
+        for (uint32_t b = 0; b < ORC_MB; ++b) {
+            acc[b][0] = _mm256_loadu_ps(c1 + j0);
+            acc[b][1] = _mm256_loadu_ps(c1 + j0 + 8);
+        }
+        for (uint32_t k = 0; k < din; ++k) {
+            const float* wr = w1 + (size_t)k * h1n + j0;
+            const __m256 w0 = _mm256_loadu_ps(wr), w1v = _mm256_loadu_ps(wr + 8);
+            for (uint32_t b = 0; b < ORC_MB; ++b) {
+                const __m256 xv = _mm256_broadcast_ss(xr + (size_t)b * din + k);
+                acc[b][0] = _mm256_fmadd_ps(xv, w0, acc[b][0]);
+                acc[b][1] = _mm256_fmadd_ps(xv, w1v, acc[b][1]);
+            }
+        }
+        for (uint32_t b = 0; b < ORC_MB; ++b) {
+            float tmp[ORC_JT];
+            _mm256_storeu_ps(tmp, acc[b][0]);
+            _mm256_storeu_ps(tmp + 8, acc[b][1]);
+            for (uint32_t t = 0; t < ORC_JT; ++t) h1buf[(size_t)b * h1n + j0 + t] = op_round(tmp[t] > 0.0f ? tmp[t] : 0.0f, prec);
+        }
+    }
+    for (uint32_t m0 = 0; m0 < h2n; m0 += ORC_JT) {
+        __m256 acc[ORC_MB][2];
+        for (uint32_t b = 0; b < ORC_MB; ++b) {
+            acc[b][0] = _mm256_loadu_ps(b2 + m0);
+            acc[b][1] = _mm256_loadu_ps(b2 + m0 + 8);
+        }
+        for (uint32_t j = 0; j < h1n; ++j) {
+            const float* wr = w2 + (size_t)j * h2n + m0;
+            const __m256 w0 = _mm256_loadu_ps(wr), w1v = _mm256_loadu_ps(wr + 8);
+            for (uint32_t b = 0; b < ORC_MB; ++b) {
+                const __m256 hv = _mm256_broadcast_ss(h1buf + (size_t)b * h1n + j);
+                acc[b][0] = _mm256_fmadd_ps(hv, w0, acc[b][0]);
+                acc[b][1] = _mm256_fmadd_ps(hv, w1v, acc[b][1]);
+            }
+        }
+        for (uint32_t b = 0; b < ORC_MB; ++b) {
+            float tmp[ORC_JT];
+            _mm256_storeu_ps(tmp, acc[b][0]);
+            _mm256_storeu_ps(tmp + 8, acc[b][1]);
+            for (uint32_t t = 0; t < ORC_JT; ++t) h2buf[(size_t)b * h2n + m0 + t] = (act2 && !(tmp[t] > 0.0f)) ? 0.0f : tmp[t];
+        }
+    }
+    const uint32_t half = h2n / 2;
+    for (uint32_t b = 0; b < ORC_MB; ++b) {
+        const float* hb = h2buf + (size_t)b * h2n;
+        float p0 = bias3, p1 = 0.0f;
+        for (uint32_t m = 0; m < half; ++m) p0 = fmaf(hb[m], w3[m], p0);
+        for (uint32_t m = half; m < h2n; ++m) p1 = fmaf(hb[m], w3[m], p1);
+        out[b] = sigmoidf_spec(p0 + p1);
+    }
+}
+
 static float* round_copy(const float* w, size_t n, int prec) {
     float* o = (float*)malloc(n * sizeof(float));
     for (size_t i = 0; i < n; ++i) o[i] = op_round(w[i], prec);
@@ -320,15 +388,22 @@ void orc_dnn3_forward(const orc_dnn3* m, int prec, const float* user_vec, const 
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #endif
+    const int blocked = threads >= 0 && h1 % ORC_JT == 0 && h2 % ORC_JT == 0;      /* threads < 0: the row-wise form (tests compare the two) */
 #pragma omp parallel
     {
-        float* hb1 = (float*)malloc(h1 * sizeof(float));
-        float* hb2 = (float*)malloc(h2 * sizeof(float));
+        float* hb1 = (float*)malloc((size_t)ORC_MB * h1 * sizeof(float));
+        float* hb2 = (float*)malloc((size_t)ORC_MB * h2 * sizeof(float));
+        float* xr = (float*)malloc((size_t)ORC_MB * di * sizeof(float));
+        const int64_t nb = blocked ? (int64_t)(n / ORC_MB) : 0;
+#pragma omp for schedule(static) nowait
+        for (int64_t g = 0; g < nb; ++g)
+            mlp2_dot_rows_blocked(prec, di, h1, h2, item_rows + (size_t)g * ORC_MB * di, c1, w1 + (size_t)du * h1, w2, m->b2, 1, m->w3,
+                                  m->b3, xr, hb1, hb2, out_scores + g * ORC_MB);
 #pragma omp for schedule(static)
-        for (int64_t i = 0; i < (int64_t)n; ++i)
+        for (int64_t i = nb * ORC_MB; i < (int64_t)n; ++i)
             mlp2_dot_row(prec, di, h1, h2, item_rows + (size_t)i * di, c1, w1 + (size_t)du * h1, w2,
                          m->b2, 1, m->w3, m->b3, hb1, hb2, out_scores + i);
-        free(hb1); free(hb2);
+        free(xr); free(hb1); free(hb2);
     }
     free(c1); free(w2); free(w1);
 }

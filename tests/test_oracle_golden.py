@@ -479,3 +479,17 @@ def test_features_map_reference_known_answers(golden):
     assert t == "float64" and v == 9.223372036854776e19
     assert hh.features_map('{"mix": [1, true]}')["mix"][1] == "[]interface {}"
     assert hh.features_map('{"m": {"a": [1], "b": 2}}')["m"] == ({"a": ["1"], "b": ["2"]}, "map[string][]string")
+
+
+def test_dnn3_blocked_form_equals_the_rowwise_form():
+    """The oracle's rank forward runs 4 items per weight pass (AVX2 fma; the CPU baseline's rank leg); every output is
+    still its own k-ascending fmaf chain, so the bits are those of the one-item-at-a-time form (threads < 0 selects it)."""
+    w = o.Dnn3Weights()
+    rng = np.random.default_rng(12)
+    items = rng.standard_normal((1003, 128)).astype(np.float32)
+    u = rng.standard_normal(128).astype(np.float32)
+    for prec in (0, 1):
+        a = o.dnn3_forward(w, prec, u, items, threads=4)
+        b = o.dnn3_forward(w, prec, u, items, threads=-4)
+        assert np.array_equal(np.asarray(a).view(np.uint64 if a.dtype == np.float64 else np.uint32),
+                              np.asarray(b).view(np.uint64 if b.dtype == np.float64 else np.uint32))
