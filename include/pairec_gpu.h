@@ -536,8 +536,14 @@ int pg_router_recall(pg_router* r, const float* query, uint64_t* out_rows, float
 /* requests each replica has served so far, [n] */
 int pg_router_stats(pg_router* r, uint64_t* out_served);
 
+/* SSDSort.Sort for ONE request (pg_ssd): calls of equal shape share one launch — every request its own set of
+ * single-wave workgroups with its own barrier.  Shapes: dim 64 / 128, window <= 16, n <= max_rerank_items (others:
+ * PG_ERR_UNSUPPORTED, use pg_ssd).  Arguments and outputs as pg_ssd. */
+int pg_coalescer_ssd(pg_coalescer* c, const uint32_t* cand_rows, const double* rel, uint32_t n, double gamma, uint32_t topn,
+                     uint32_t window, int normalize_emb, int ensure_pos_similarity, int norm_quality_score, int use_ssd_star,
+                     uint32_t* out_idx, uint32_t* out_count, double* out_quality);
 typedef struct {
-    uint64_t requests[6], batches[6];   /* per flavour: 0 recall (vector / i2i / online), 1 rank, 2 recommend, 3 dpp, 4-5 reserved */
+    uint64_t requests[6], batches[6];   /* per flavour: 0 recall (vector / i2i / online), 1 rank, 2 recommend, 3 dpp, 4 ssd, 5 reserved */
     uint64_t largest_batch[6];
     uint64_t replans;                   /* batches whose first recall plan did not hold and was re-run */
     uint64_t timeouts;                  /* calls that returned PG_ERR_TIMEOUT */

@@ -29,7 +29,7 @@ EXPORTS = [
     "pg_coalescer_create", "pg_coalescer_destroy", "pg_coalescer_recall", "pg_coalescer_rank_dnn3",
     "pg_coalescer_recommend", "pg_coalescer_stats", "pg_coalescer_create_scene", "pg_coalescer_i2i_recall",
     "pg_coalescer_online_recall", "pg_coalescer_rank", "pg_coalescer_rank_fm2t", "pg_coalescer_recommend_ex",
-    "pg_coalescer_dpp", "pg_recommend_end_timed", "pg_debug_stall",
+    "pg_coalescer_dpp", "pg_coalescer_ssd", "pg_recommend_end_timed", "pg_debug_stall",
     "pg_fm2t_item_rows_build", "pg_fm2t_item_rows_update", "pg_fm2t_item_rows_destroy", "pg_rank_fm2t_irows_dev",
     "pg_rank_fm2t_irows",
     "pg_topk_merge_lists_dev", "pg_owned_compact_dev", "pg_scatter_f32_dev", "pg_dpp_candidates_dev",
@@ -166,6 +166,7 @@ def load():
         "pg_coalescer_rank_fm2t": [vp, vp, vp, vp, u32, vp],
         "pg_coalescer_recommend_ex": [vp, vp, vp, u32, vp, vp, vp, vp, P(u32)],
         "pg_coalescer_dpp": [vp, vp, vp, u32, P(PgDppOptions), vp, vp, P(u32), vp],
+        "pg_coalescer_ssd": [vp, vp, vp, u32, C.c_double, u32, u32, i32, i32, i32, i32, vp, P(u32), vp],
         "pg_recommend_end_timed": [vp, vp, u32, P(C.c_double)],
         "pg_debug_stall": [vp, u32],
         "pg_fm2t_item_rows_build": [vp, vp, vp, vp, P(vp)],

@@ -50,7 +50,7 @@ namespace {
 
 using Clock = std::chrono::steady_clock;
 
-enum Flavour { kRecall = 0, kRank = 1, kRecommend = 2, kDpp = 3 };                // statistics index
+enum Flavour { kRecall = 0, kRank = 1, kRecommend = 2, kDpp = 3, kSsd = 4 };      // statistics index
 enum Queue { kQRecall = 0, kQRecommend = 1, kQDpp = 2, kQRank0 = 3 };             // kQRank0 + algorithm index
 constexpr int kNumQueues = kQRank0 + kMaxAlgos;
 enum QueryKind : uint32_t { kVector = 0, kTrigger = 1, kOnline = 2 };
@@ -58,13 +58,15 @@ enum ReqState : uint32_t { kQueued = 0, kStaging = 1, kStaged = 2, kDone = 3, kA
 
 struct Slot;
 
+// the shape of a diversity re-rank call (DPPSort or SSDSort): calls of equal shape share a batched launch
 struct DppKey {
     uint32_t n = 0, topn = 0, window = 0, hook_dim = 0;
     int normalize = 0, ensure_pos = 0, has_table = 0;
+    int ssd = 0, star = 0;           // SSDSort: alpha carries gamma, star = UseSSDStar
     double alpha = 0.0;
     bool operator==(const DppKey& o) const {
         return n == o.n && topn == o.topn && window == o.window && hook_dim == o.hook_dim && normalize == o.normalize &&
-               ensure_pos == o.ensure_pos && has_table == o.has_table && alpha == o.alpha;
+               ensure_pos == o.ensure_pos && has_table == o.has_table && ssd == o.ssd && star == o.star && alpha == o.alpha;
     }
 };
 
@@ -445,6 +447,9 @@ int enqueue_dpp_batch(pg_coalescer* c, Slot* s) {
     std::lock_guard<std::mutex> g(ctx->mu);
     TableRead tr(c->t->rw);
     int rc;
+    if (key.ssd)
+        return ssd_run_locked(ctx, c->t, s->d_dcand, s->d_drel, R, key.n, key.alpha, key.topn, key.window, key.normalize, key.ensure_pos,
+                              key.star, s->d_dout);
     if (key.has_table && (rc = table_gather_locked(ctx, c->t, s->d_dcand, (uint32_t)items, s->d_demb))) return rc;
     return dpp_run_locked(ctx, key.has_table ? s->d_demb : nullptr, key.hook_dim ? s->d_dhook : nullptr, s->d_drel, R, key.n,
                           key.has_table ? c->dim : 0u, key.hook_dim, key.alpha, key.topn, key.window, key.normalize, key.ensure_pos,
@@ -694,7 +699,7 @@ void dispatcher_main(pg_coalescer* c) {
             }
         }
         lk.lock();
-        const int fl = flavour_of(kind);
+        const int fl = (kind == kQDpp && s->key.ssd) ? (int)kSsd : flavour_of(kind);
         c->stats.requests[fl] += s->n_req;
         c->stats.batches[fl] += 1;
         c->stats.largest_batch[fl] = std::max<uint64_t>(c->stats.largest_batch[fl], s->n_req);
@@ -776,7 +781,7 @@ void completer_main(pg_coalescer* c) {
         const double ms = std::chrono::duration<double, std::milli>(Clock::now() - s->enqueued).count();
         lk.lock();
         c->inflight.pop_front();
-        c->stats.device_ms[fl] += ms;
+        c->stats.device_ms[(fl == kDpp && s->key.ssd) ? (int)kSsd : fl] += ms;
         if (replanned) c->stats.replans++;
         std::vector<Req*> orphans;
         if (device_fault) {
@@ -1290,6 +1295,58 @@ int pg_coalescer_dpp(pg_coalescer* c, const uint32_t* cand_rows, const double* r
         const uint32_t cnt = std::min(topn, s->h_dout[c->dpp_item_cap + r->index]);
         memcpy(out_idx, s->h_dout + (size_t)r->index * topn, (size_t)cnt * 4);
         *out_count = cnt;
+    }
+    return pg::finish_call(c, r);
+}
+
+int pg_coalescer_ssd(pg_coalescer* c, const uint32_t* cand_rows, const double* rel, uint32_t n, double gamma, uint32_t topn,
+                     uint32_t window, int normalize_emb, int ensure_pos_similarity, int norm_quality_score, int use_ssd_star,
+                     uint32_t* out_idx, uint32_t* out_count, double* out_quality) {
+    PG_REQUIRE(c && out_count, "pg_coalescer_ssd: NULL argument");
+    PG_REQUIRE(!c->group, "pg_coalescer_ssd: a coalescer over a shard group serves pg_coalescer_recommend only");
+    *out_count = 0;
+    if (n == 0 || topn == 0) return PG_OK;
+    PG_REQUIRE(cand_rows && rel && out_idx, "pg_coalescer_ssd: NULL argument");
+    PG_REQUIRE(norm_quality_score >= 0 && norm_quality_score <= 2, "pg_coalescer_ssd: norm_quality_score must be 0, 1 or 2");
+    if (window <= 1) window = 5;                          // ssd_sort.go:357-360
+    const uint32_t d1 = c->dim + (ensure_pos_similarity ? 1u : 0u);
+    if (n > c->dpp_max_n || !pg::ssd_batchable(d1, window)) {
+        pg::set_error("pg_coalescer_ssd: %u candidates (max_rerank_items %u) / dim %u / window %u: not a batchable shape (pg_ssd serves it)", n,
+                      c->dpp_max_n, c->dim, window);
+        return PG_ERR_UNSUPPORTED;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        PG_REQUIRE(cand_rows[i] < c->t->rows, "pg_coalescer_ssd: candidate row %u outside table", cand_rows[i]);
+    pg::Req* r = new pg::Req();
+    r->rel.resize(n);
+    // ssd_norm_quality_score: O(n) scalar work on the caller's thread, as pg_ssd does it
+    if (!pg::ssd_norm_quality_host(rel, n, norm_quality_score, r->rel.data())) {
+        delete r;                                         // "all item score are zeros": the items stay as they are
+        for (uint32_t i = 0; i < n; ++i) out_idx[i] = i;
+        *out_count = n;
+        if (out_quality) memcpy(out_quality, rel, (size_t)n * 8);
+        return PG_OK;
+    }
+    if (out_quality) memcpy(out_quality, r->rel.data(), (size_t)n * 8);
+    r->queue = pg::kQDpp;
+    r->cand = cand_rows;
+    r->n = n;
+    r->key.n = n;
+    r->key.topn = std::min(topn, n);
+    r->key.window = window;
+    r->key.normalize = normalize_emb ? 1 : 0;
+    r->key.ensure_pos = ensure_pos_similarity ? 1 : 0;
+    r->key.has_table = 1;
+    r->key.ssd = 1;
+    r->key.star = use_ssd_star ? 1 : 0;
+    r->key.alpha = gamma;
+    int rc;
+    if ((rc = pg::submit_and_wait(c, r))) return rc;
+    pg::Slot* s = r->slot;
+    if (r->rc == PG_OK) {
+        const uint32_t T = s->key.topn;
+        memcpy(out_idx, s->h_dout + (size_t)r->index * T, (size_t)T * 4);
+        *out_count = T;
     }
     return pg::finish_call(c, r);
 }

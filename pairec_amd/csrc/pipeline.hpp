@@ -121,5 +121,12 @@ int dpp_bail_fix_launch(hipStream_t st, const uint32_t* d_bail, uint32_t nq, uin
                         uint32_t* d_pick_cnt);
 // host form of the same normalisation (pg_dpp_ex and the coalescer's single-request DPP calls): returns false on bail-out
 bool dpp_norm_relevance_host(const double* rel, uint32_t n, int mode, double* out);
+// ssd.hip: SSDWithSlidingWindow for R requests of n candidates (d_cand [R][n] rows of t, d_rel [R][n] quality scores,
+// d_out [R][T]); R > 1 needs ssd_batchable(d1, window).  Caller holds ctx->mu.
+int ssd_run_locked(pg_ctx* ctx, const pg_table* t, const uint32_t* d_cand, const double* d_rel, uint32_t R, uint32_t n,
+                   double gamma, uint32_t T, uint32_t window, int normalize_emb, int ensure_pos_similarity, int use_ssd_star,
+                   uint32_t* d_out);
+bool ssd_batchable(uint32_t d1, uint32_t window);
+bool ssd_norm_quality_host(const double* rel, uint32_t n, int mode, double* out);
 
 }  // namespace pg

@@ -16,7 +16,7 @@
 // DESIGN.md §5.7): dot = chain_{k asc} fma; norm = sqrt(chain fma); e ∓= p·f as separate multiply and
 // add/subtract (ScaleVec, then floats.Sub/Add); quality = r + (volume·l2).  Bit-identical to
 // oracle/oracle.c:orc_ssd_window.
-#include "common.hpp"
+#include "pipeline.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -32,6 +32,8 @@ __global__ void ssd_prepare_kernel(const float* __restrict__ tab, uint32_t tab_r
                                    int append_one, double* __restrict__ Et) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    cand += (size_t)blockIdx.y * n;                               // request blockIdx.y of a batch
+    Et += (size_t)blockIdx.y * n * (d + (append_one ? 1u : 0u));
     uint32_t row = cand[i];
     row = row < tab_rows ? row : tab_rows - 1;
     const float* x = tab + (size_t)row * d;
@@ -354,6 +356,14 @@ __global__ __launch_bounds__(64) void ssd_kernel_grid(const double* __restrict__
     __shared__ uint32_t pick_ring[32];                   // the last picks (W <= 16 back is all that is needed)
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     const uint32_t lane = threadIdx.x, G = gridDim.x, wg = blockIdx.x;
+    {   // request blockIdx.y of a batch: its own embeddings, mailbox (and barrier counter), vector slots, output
+        const uint32_t req = blockIdx.y;
+        Et += (size_t)req * n * D1;
+        rel_g += (size_t)req * n;
+        mail += req;
+        ebuf += (size_t)req * 2 * (G + 1) * D1;
+        out += (size_t)req * T;
+    }
     const uint32_t j = wg * 64 + lane;
     const bool valid = j < n;
     const uint32_t jc = valid ? j : n - 1;
@@ -490,6 +500,126 @@ __global__ __launch_bounds__(64) void ssd_kernel_grid(const double* __restrict__
     }
 }
 
+// ssd_norm_quality_score (ssd_sort.go:360-388) on the caller's thread, in the reference's operation order
+// (stat.PopMeanVariance two-pass with compensation, stat.StdScore; min-max with eps = 1e-6).  false: "all item score are
+// zeros" — the reference returns the items unchanged.
+bool ssd_norm_quality_host(const double* rel, uint32_t n, int mode, double* out) {
+    if (mode == 1) {
+        double sum = 0.0;
+        for (uint32_t i = 0; i < n; ++i) sum = sum + rel[i];
+        const double mean = sum / (double)n;
+        double ss = 0.0, comp = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double d = rel[i] - mean;
+            volatile double dd = d * d;
+            ss = ss + dd;
+            comp = comp + d;
+        }
+        volatile double cc = comp * comp;
+        const double variance = (ss - cc / (double)n) / (double)n;
+        if (mean == 0.0 || variance == 0.0) return false;
+        const double sd = sqrt(variance);
+        for (uint32_t i = 0; i < n; ++i) out[i] = (rel[i] - mean) / sd;
+        return true;
+    }
+    if (mode == 2) {
+        const double mx = rel[0], mn = rel[n - 1], span = mx - mn;
+        if (span == 0.0) return false;
+        const double eps = 1e-6;
+        for (uint32_t i = 0; i < n; ++i) {
+            volatile double a = ((rel[i] - mn) / span) * (1 - eps);
+            out[i] = a + eps;
+        }
+        return true;
+    }
+    for (uint32_t i = 0; i < n; ++i) out[i] = rel[i];
+    return true;
+}
+
+bool ssd_batchable(uint32_t d1, uint32_t window) { return (d1 == 64 || d1 == 65 || d1 == 128 || d1 == 129) && window <= 16; }
+
+// SSDWithSlidingWindow for R requests of n candidates each, device-resident: d_cand [R][n] rows of `t`, d_rel [R][n]
+// quality scores (normalised already), d_out [R][T] picks.  R > 1 needs the multi-workgroup kernel's shapes
+// (ssd_batchable): every request is its own set of G single-wave workgroups with its own mailbox and barrier; a launch
+// carries as many requests as are co-resident (4 single-wave workgroups per CU).  Caller holds ctx->mu.
+int ssd_run_locked(pg_ctx* ctx, const pg_table* t, const uint32_t* d_cand, const double* d_rel, uint32_t R, uint32_t n,
+                   double gamma, uint32_t T, uint32_t window, int normalize_emb, int ensure_pos_similarity, int use_ssd_star,
+                   uint32_t* d_out) {
+    if (R == 0 || n == 0 || T == 0) return PG_OK;
+    if (window <= 1) window = 5;                          // ssd_sort.go:357-360
+    const uint32_t d1 = t->dim + (ensure_pos_similarity ? 1u : 0u);
+    const uint32_t G = (n + 63) / 64;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t bE = al((size_t)n * d1 * 8), bP = al((size_t)window * n * 8), bN = al((size_t)n * 8), bSel = al((size_t)n * 4);
+    const size_t bMail = al(sizeof(SsdMail)), bEbuf = al((size_t)2 * (G + 1) * d1 * 8);
+    // Kernel choice: the multi-workgroup kernel (embeddings pinned in registers, device-wide barrier) for the usual
+    // widths (dim 64 / 128, with or without the appended 1) and windows <= 16; the one-workgroup kernels otherwise
+    // (PG_SSD_KERNEL=generic|reg forces them, for A/B runs; single requests only).
+    const char* force = getenv("PG_SSD_KERNEL");
+    const bool known_d1 = d1 == 64 || d1 == 65 || d1 == 128 || d1 == 129;
+    int kind = ssd_batchable(d1, window) ? 2 : ((known_d1 && n <= kSsdRegMaxN) ? 1 : 0);
+    if (R == 1 && force && !strcmp(force, "generic")) kind = 0;
+    if (R == 1 && force && !strcmp(force, "reg") && known_d1 && n <= kSsdRegMaxN) kind = 1;
+    if (R > 1 && kind != 2) {
+        set_error("ssd: a batch of %u requests needs dim 64 / 128 and a window <= 16 (d1 = %u, window %u)", R, d1, window);
+        return PG_ERR_UNSUPPORTED;
+    }
+    void* buf;
+    int rc;
+    if (kind == 2) {
+        if ((rc = scratch_reserve(ctx, 7, (size_t)R * (bE + bMail + bEbuf), &buf))) return rc;
+        char* p = (char*)buf;
+        double* Et = (double*)p; p += (size_t)R * bE;
+        // (requests are strided by their exact sizes inside the kernels: n * d1 doubles, one SsdMail, 2 (G + 1) d1 doubles)
+        SsdMail* mail = (SsdMail*)p; p += (size_t)R * bMail;
+        double* ebuf = (double*)p;
+        ssd_prepare_kernel<<<dim3((n + 63) / 64, R), 64, 0, ctx->stream>>>(t->d, (uint32_t)t->rows, t->dim, d_cand, n, normalize_emb,
+                                                                           ensure_pos_similarity, Et);
+        PG_HIP(hipMemsetAsync(mail, 0, (size_t)R * sizeof(SsdMail), ctx->stream));
+        // as many requests per launch as are certainly co-resident: 4 single-wave workgroups (one per SIMD) per CU
+        const uint32_t per_launch = std::max(1u, (uint32_t)ctx->num_cus * 4u / G);
+        for (uint32_t r0 = 0; r0 < R; r0 += per_launch) {
+            const uint32_t rn = std::min(per_launch, R - r0);
+            const double* Et_r = Et + (size_t)r0 * n * d1;
+            const double* rel_r = d_rel + (size_t)r0 * n;
+            SsdMail* mail_r = mail + r0;
+            double* ebuf_r = ebuf + (size_t)r0 * 2 * (G + 1) * d1;
+            uint32_t* out_r = d_out + (size_t)r0 * T;
+            const dim3 grid(G, rn);
+            switch (d1) {
+                case 64: ssd_kernel_grid<64><<<grid, 64, 0, ctx->stream>>>(Et_r, n, rel_r, gamma, T, window, use_ssd_star, mail_r, ebuf_r, out_r); break;
+                case 65: ssd_kernel_grid<65><<<grid, 64, 0, ctx->stream>>>(Et_r, n, rel_r, gamma, T, window, use_ssd_star, mail_r, ebuf_r, out_r); break;
+                case 128: ssd_kernel_grid<128><<<grid, 64, 0, ctx->stream>>>(Et_r, n, rel_r, gamma, T, window, use_ssd_star, mail_r, ebuf_r, out_r); break;
+                default: ssd_kernel_grid<129><<<grid, 64, 0, ctx->stream>>>(Et_r, n, rel_r, gamma, T, window, use_ssd_star, mail_r, ebuf_r, out_r); break;
+            }
+        }
+        PG_HIP(hipGetLastError());
+        return PG_OK;
+    }
+    if ((rc = scratch_reserve(ctx, 7, bE + bP + 3 * bN + bSel, &buf))) return rc;
+    char* p = (char*)buf;
+    double* Et = (double*)p; p += bE;
+    double* P = (double*)p; p += bP;
+    double* nrm = (double*)p; p += bN;
+    double* ssq = (double*)p; p += bN;
+    double* q = (double*)p; p += bN;
+    uint32_t* d_sel = (uint32_t*)p;
+    ssd_prepare_kernel<<<dim3((n + 63) / 64, 1), 64, 0, ctx->stream>>>(t->d, (uint32_t)t->rows, t->dim, d_cand, n, normalize_emb,
+                                                                       ensure_pos_similarity, Et);
+    if (kind == 1) {
+        switch (d1) {
+            case 64: ssd_kernel_reg<64><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
+            case 65: ssd_kernel_reg<65><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
+            case 128: ssd_kernel_reg<128><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
+            default: ssd_kernel_reg<129><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
+        }
+    } else {
+        ssd_kernel<<<1, 1024, 0, ctx->stream>>>(Et, n, d1, d_rel, gamma, T, window, use_ssd_star, P, nrm, ssq, q, d_sel, d_out);
+    }
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 }  // namespace pg
 
 extern "C" {
@@ -512,39 +642,8 @@ int pg_ssd(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const doub
     for (uint32_t i = 0; i < n; ++i)
         PG_REQUIRE(cand_rows[i] < t->rows, "pg_ssd: candidate row %u outside table", cand_rows[i]);
 
-    // ssd_norm_quality_score (ssd_sort.go:360-388): O(n) scalar work on the caller's thread, in the
-    // reference's operation order (stat.PopMeanVariance two-pass with compensation, stat.StdScore)
-    std::vector<double> quality(rel, rel + n);
-    bool bail = false;
-    if (norm_quality_score == 1) {
-        double sum = 0.0;
-        for (uint32_t i = 0; i < n; ++i) sum = sum + rel[i];
-        const double mean = sum / (double)n;
-        double ss = 0.0, comp = 0.0;
-        for (uint32_t i = 0; i < n; ++i) {
-            const double d = rel[i] - mean;
-            volatile double dd = d * d;
-            ss = ss + dd;
-            comp = comp + d;
-        }
-        volatile double cc = comp * comp;
-        const double variance = (ss - cc / (double)n) / (double)n;
-        if (mean == 0.0 || variance == 0.0) bail = true;
-        else {
-            const double sd = sqrt(variance);
-            for (uint32_t i = 0; i < n; ++i) quality[i] = (rel[i] - mean) / sd;
-        }
-    } else if (norm_quality_score == 2) {
-        const double mx = rel[0], mn = rel[n - 1], span = mx - mn;
-        if (span == 0.0) bail = true;
-        else {
-            const double eps = 1e-6;
-            for (uint32_t i = 0; i < n; ++i) {
-                volatile double a = ((rel[i] - mn) / span) * (1 - eps);
-                quality[i] = a + eps;
-            }
-        }
-    }
+    std::vector<double> quality(n);
+    const bool bail = !pg::ssd_norm_quality_host(rel, n, norm_quality_score, quality.data());
     if (bail) {        // "all item score are zeros": the reference returns the items unchanged
         for (uint32_t i = 0; i < n; ++i) out_idx[i] = i;
         *out_count = n;
@@ -556,58 +655,17 @@ int pg_ssd(pg_ctx* ctx, const pg_table* t, const uint32_t* cand_rows, const doub
     const uint32_t T = n < topn ? n : topn;
     std::lock_guard<std::mutex> g(ctx->mu);
     pg::TableRead tr(t->rw);
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t bE = al((size_t)n * d1 * 8), bP = al((size_t)window * n * 8), bN = al((size_t)n * 8);
-    const size_t bCand = al((size_t)n * 4), bSel = al((size_t)n * 4), bOut = al((size_t)T * 4);
-    const size_t bMail = al(sizeof(pg::SsdMail)), bEbuf = al((size_t)2 * ((n + 63) / 64 + 1) * d1 * 8);
-    void* buf;
+    void* io;
     int rc;
-    if ((rc = pg::scratch_reserve(ctx, 7, bE + bP + 4 * bN + bCand + bSel + bOut + bMail + bEbuf, &buf))) return rc;
-    char* p = (char*)buf;
-    double* Et = (double*)p; p += bE;
-    double* P = (double*)p; p += bP;
-    double* nrm = (double*)p; p += bN;
-    double* ssq = (double*)p; p += bN;
-    double* q = (double*)p; p += bN;
-    double* d_rel = (double*)p; p += bN;
-    uint32_t* d_cand = (uint32_t*)p; p += bCand;
-    uint32_t* d_sel = (uint32_t*)p; p += bSel;
-    uint32_t* d_out = (uint32_t*)p; p += bOut;
-    pg::SsdMail* mail = (pg::SsdMail*)p; p += bMail;
-    double* ebuf = (double*)p;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    if ((rc = pg::scratch_reserve(ctx, 5, al((size_t)n * 4) + al((size_t)n * 8) + al((size_t)T * 4), &io))) return rc;
+    uint32_t* d_cand = (uint32_t*)io;
+    double* d_rel = (double*)((char*)io + al((size_t)n * 4));
+    uint32_t* d_out = (uint32_t*)((char*)io + al((size_t)n * 4) + al((size_t)n * 8));
     PG_HIP(hipMemcpyAsync(d_cand, cand_rows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(hipMemcpyAsync(d_rel, quality.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    pg::ssd_prepare_kernel<<<(n + 63) / 64, 64, 0, ctx->stream>>>(t->d, (uint32_t)t->rows, t->dim, d_cand, n,
-                                                                normalize_emb, ensure_pos_similarity, Et);
-    // Kernel choice: the multi-workgroup kernel (embeddings pinned in registers, device-wide barrier) for
-    // the usual widths (dim 64 / 128, with or without the appended 1) and windows <= 16; the one-workgroup
-    // kernels otherwise (PG_SSD_KERNEL=generic|reg forces them, for A/B runs).
-    const char* force = getenv("PG_SSD_KERNEL");
-    const bool known_d1 = d1 == 64 || d1 == 65 || d1 == 128 || d1 == 129;
-    int kind = (known_d1 && window <= 16) ? 2 : ((known_d1 && n <= pg::kSsdRegMaxN) ? 1 : 0);
-    if (force && !strcmp(force, "generic")) kind = 0;
-    if (force && !strcmp(force, "reg") && known_d1 && n <= pg::kSsdRegMaxN) kind = 1;
-    if (kind == 2) {
-        PG_HIP(hipMemsetAsync(mail, 0, sizeof(pg::SsdMail), ctx->stream));
-        const uint32_t G = (n + 63) / 64;
-        switch (d1) {
-            case 64: pg::ssd_kernel_grid<64><<<G, 64, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, mail, ebuf, d_out); break;
-            case 65: pg::ssd_kernel_grid<65><<<G, 64, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, mail, ebuf, d_out); break;
-            case 128: pg::ssd_kernel_grid<128><<<G, 64, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, mail, ebuf, d_out); break;
-            default: pg::ssd_kernel_grid<129><<<G, 64, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, mail, ebuf, d_out); break;
-        }
-    } else if (kind == 1) {
-        switch (d1) {
-            case 64: pg::ssd_kernel_reg<64><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
-            case 65: pg::ssd_kernel_reg<65><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
-            case 128: pg::ssd_kernel_reg<128><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
-            default: pg::ssd_kernel_reg<129><<<1, 256, 0, ctx->stream>>>(Et, n, d_rel, gamma, T, window, use_ssd_star, P, d_out); break;
-        }
-    } else {
-        pg::ssd_kernel<<<1, 1024, 0, ctx->stream>>>(Et, n, d1, d_rel, gamma, T, window, use_ssd_star, P, nrm, ssq, q,
-                                                   d_sel, d_out);
-    }
-    PG_HIP(hipGetLastError());
+    if ((rc = pg::ssd_run_locked(ctx, t, d_cand, d_rel, 1, n, gamma, T, window, normalize_emb, ensure_pos_similarity, use_ssd_star, d_out)))
+        return rc;
     PG_HIP(hipMemcpyAsync(out_idx, d_out, (size_t)T * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
     *out_count = T;

@@ -541,6 +541,19 @@ class Coalescer:
                                                _ptr(hk) if hk is not None else None, _ptr(out), C.byref(cnt), _ptr(used)))
         return out[:cnt.value], used[:n]
 
+    def ssd(self, cand_rows, rel, gamma: float, topn: int, window: int, normalize_emb: bool = True,
+            ensure_pos_similarity: bool = True, norm_quality_score: int = 0, use_ssd_star: bool = False):
+        """pg_coalescer_ssd: one request's SSDSort; → (picked indices, quality scores)."""
+        c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
+        r = np.ascontiguousarray(rel, dtype=np.float64)
+        out = np.zeros(max(c.shape[0], 1), dtype=np.uint32)
+        qual = np.zeros(max(c.shape[0], 1), dtype=np.float64)
+        cnt = C.c_uint32()
+        _lib.check(self.ctx.L.pg_coalescer_ssd(self.h, _ptr(c), _ptr(r), c.shape[0], gamma, topn, window, int(normalize_emb),
+                                               int(ensure_pos_similarity), int(norm_quality_score), int(use_ssd_star),
+                                               _ptr(out), C.byref(cnt), _ptr(qual)))
+        return out[:cnt.value], qual[:c.shape[0]]
+
     def stats(self) -> _lib.PgCoalescerStats:
         s = _lib.PgCoalescerStats()
         _lib.check(self.ctx.L.pg_coalescer_stats(self.h, C.byref(s)))

@@ -246,6 +246,36 @@ def test_coalesced_dpp_calls_equal_pg_dpp_ex(ctx, world):
     co.destroy()
 
 
+def test_coalesced_ssd_calls_equal_pg_ssd(ctx, world):
+    """SSDSort.Sort once per request from 256 threads (sort/ssd_sort.go:110-343): two shapes mixed, quality-score
+    normalisation, against pg_ssd alone — the batched launch gives every request its own workgroups and barrier."""
+    t = world["t"]
+    rng = np.random.default_rng(78)
+    co = pa.Coalescer(ctx, t, 100, algos=[], max_wait_us=3000, max_rerank_items=512)
+    shapes = [(300, 40, 5, 0.25, 0, False), (130, 25, 8, 0.4, 1, True)]
+    cand, rel = [], []
+    for i in range(CALLERS):
+        n = shapes[i % 2][0]
+        cand.append(rng.choice(world["n"], n, replace=False).astype(np.uint32))
+        rel.append(np.sort(rng.random(n))[::-1].copy())
+    got = [None] * CALLERS
+
+    def call(i):
+        n, topn, window, gamma, norm, star = shapes[i % 2]
+        got[i] = co.ssd(cand[i], rel[i], gamma, topn, window, norm_quality_score=norm, use_ssd_star=star)
+    run_threads(CALLERS, call)
+    st = co.stats()
+    for i in range(0, CALLERS, 7):
+        n, topn, window, gamma, norm, star = shapes[i % 2]
+        picks, qual = pa.ssd(ctx, t, cand[i], rel[i], gamma, topn, window, norm_quality_score=norm, use_ssd_star=star)
+        assert np.array_equal(got[i][0], picks), "caller %d: pick sequence differs from pg_ssd" % i
+        assert np.array_equal(bits(got[i][1]), bits(qual))
+    assert st.requests[4] == CALLERS and st.batches[4] <= CALLERS // 8
+    with pytest.raises(pa._lib.PgError):
+        co.ssd(cand[0], rel[0], 0.25, 10, 20)              # window > 16: not a batchable shape
+    co.destroy()
+
+
 def test_deadline_returns_timeout_and_later_calls_succeed(ctx, world):
     """timeout_us (eas/client.go:53-58): with the stream stalled, every caller returns PG_ERR_TIMEOUT within the bound —
     those whose batch is on the device and those still queued — and once the stall is over the same coalescer serves
