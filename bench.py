@@ -607,7 +607,8 @@ def cfg5_leg(pa, o, R, K, prec):
     out = {}
     for dpp in (500, 0):
         q = make_queries(o, 0, R, 128)
-        g.recommend(ex, "gpu_dnn", q, K, 100, dpp_candidates=dpp)            # warm-up: shadow, buffers
+        for _ in range(2):                                                    # warm-up: shadow, buffers, both lanes' scratch
+            g.recommend(ex, "gpu_dnn", q, K, 100, dpp_candidates=dpp)
         steps = 6
         qs = [make_queries(o, s_ + 1, R, 128) for s_ in range(steps + 1)]
         t0 = time.perf_counter()

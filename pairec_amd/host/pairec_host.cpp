@@ -1017,10 +1017,19 @@ struct GpuSSDSort : sort::ISort {                        // sort/ssd_sort.go:110
         std::vector<uint32_t> idx(n);
         std::vector<double> quality(n);
         uint32_t cnt = 0;
-        if (pg_ssd(e->ctx, e->table, rows.data(), rel.data(), n, gamma, (uint32_t)std::max(size, 0),
-                   (uint32_t)std::max(windowSize, 0), conf.NormalizeEmb ? 1 : 0, conf.EnsurePositiveSim ? 1 : 0,
-                   (doNorm == 1 || doNorm == 2) ? doNorm : 0, conf.UseSSDStar ? 1 : 0, idx.data(), &cnt,
-                   quality.data()) != PG_OK) {
+        // SortService.Sort runs once per request, requests overlap (sort/sort.go:65-125): equal-shaped SSD calls of concurrent
+        // requests share one launch (every request its own workgroups and barrier); other shapes take the direct call
+        int src = PG_ERR_UNSUPPORTED;
+        if (e->coalesce && n <= 1024)
+            if (pg_coalescer* co = e->SceneCoalescer(0, err))
+                src = pg_coalescer_ssd(co, rows.data(), rel.data(), n, gamma, (uint32_t)std::max(size, 0), (uint32_t)std::max(windowSize, 0),
+                                       conf.NormalizeEmb ? 1 : 0, conf.EnsurePositiveSim ? 1 : 0, (doNorm == 1 || doNorm == 2) ? doNorm : 0,
+                                       conf.UseSSDStar ? 1 : 0, idx.data(), &cnt, quality.data());
+        if (src == PG_ERR_UNSUPPORTED)
+            src = pg_ssd(e->ctx, e->table, rows.data(), rel.data(), n, gamma, (uint32_t)std::max(size, 0),
+                         (uint32_t)std::max(windowSize, 0), conf.NormalizeEmb ? 1 : 0, conf.EnsurePositiveSim ? 1 : 0,
+                         (doNorm == 1 || doNorm == 2) ? doNorm : 0, conf.UseSSDStar ? 1 : 0, idx.data(), &cnt, quality.data());
+        if (src != PG_OK) {
             if (err) *err = pg_err("pg_ssd");
             return false;
         }
