@@ -62,7 +62,9 @@ int pg_synchronize(pg_ctx* ctx);
  * "no_pilot", "recall_exact", "screen_min", "pilot_fraction", "chunk_growth", "seed_rows", "pilot_growth",
  * "pilot_sigmas", "debug_scan", "rank_no_ws", "sort_lds", and for the 4-bit screen of batches of <= 4 queries
  * (csrc/recall_i4.hip) "no_screen_i4", "i4_min_rows" (default 2^22), "i4_max_lambda", and for the threshold refinement inside the pilot plan's
- * full pass "no_refine", "refine_min_rows" (default 2^24); value is parsed as a number. */
+ * full pass "no_refine", "refine_min_rows" (default 2^24), and for the threshold model that replaces the pilot sample
+ * once a table has seen >= 1024 queries of one K "no_predict", "predict_sigmas" (default 4.5),
+ * "predict_min_rows" (default 2^22); value is parsed as a number. */
 int pg_set_option(pg_ctx* ctx, const char* name, const char* value);
 int pg_device_malloc(pg_ctx* ctx, size_t bytes, void** out);
 int pg_device_free(pg_ctx* ctx, void* p);
@@ -564,6 +566,7 @@ typedef struct {
     uint64_t rank_calls, rank_items;
     uint64_t sort_calls, sort_items;
     double   last_recall_ms, last_rank_ms, last_sort_ms;   /* hipEvent-timed, device side */
+    uint64_t recall_predicted;          /* batches whose screening threshold came from the table's threshold model and held */
 } pg_stats_t;
 int pg_stats(pg_ctx* ctx, pg_stats_t* out);
 /* time (ms) of the dominant kernel of the last pg_recall_* call, measured with HIP events on the

@@ -46,7 +46,7 @@ class PgStats(C.Structure):
                 ("recall_rescans", C.c_uint64), ("rank_calls", C.c_uint64),
                 ("rank_items", C.c_uint64), ("sort_calls", C.c_uint64), ("sort_items", C.c_uint64),
                 ("last_recall_ms", C.c_double), ("last_rank_ms", C.c_double),
-                ("last_sort_ms", C.c_double)]
+                ("last_sort_ms", C.c_double), ("recall_predicted", C.c_uint64)]
 
 
 class PgDppOptions(C.Structure):

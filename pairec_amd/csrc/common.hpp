@@ -72,6 +72,9 @@ struct Knobs {
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
     uint32_t rank_sort_max = 8;    // PG_RANK_SORT_MAX: up to this many lists per call are sorted by counting ranks (0 = never)
     bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
+    bool no_predict = false;       // PG_NO_PREDICT: never replace the pilot sample by the learned threshold model
+    double predict_sigmas = 4.5;   // PG_PREDICT_SIGMAS: margin of the predicted threshold, in standard deviations of the observed quantile
+    uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way
 };
 
 }  // namespace pg
@@ -111,6 +114,16 @@ struct pg_table {
     float rmax4 = 0.0f;          // max over rows of ||x - x^|| (upper bound)
     float lam4 = 0.0f;           // mean residual term in units of the score spread (decides whether the shadow pays)
     uint32_t prefix_failures = 0; // batches whose refined thresholds failed verification for most queries (ordered rows): two → no refinement
+    // Threshold predictor (recall.hip, §4.1e of DESIGN.md): a Gaussian model of a query's scores over the rows — mean
+    // vector and covariance from a row sample, built with the statistics — and the quantile z = (K-th best score −
+    // mean) / sigma actually observed for the batches served so far.  Once the observed z is tight, a batch's first
+    // thresholds come from the model instead of a pilot sample.  A hint only: every plan is verified, results are exact.
+    float* d_pred = nullptr;      // [dim] mean | [dim][dim] covariance | 4 doubles: n, sum z, sum z^2, min z
+    bool pred_model = false;      // mean / covariance belong to the current rows
+    uint32_t pred_k = 0;          // the K the observations belong to
+    double pred_n = 0.0, pred_sum = 0.0, pred_sum2 = 0.0, pred_min = 0.0, pred_total = 0.0;   // host copy as of the last verified batch
+    uint32_t pred_backoff = 0;    // batches that stay on the pilot plan after a prediction failed verification
+    uint32_t pred_failures = 0;
 };
 
 // rank model weights resident in HBM (rank_mlp.hip loads them)
@@ -209,6 +222,7 @@ struct RecallScratch {
     float* qscale;           // [kMaxQueries] int8 screen: the queries' scales
     float* thr_ref;          // [kMaxQueries] the thresholds the pilot plan's refinement step raised (verified after the pass)
     uint32_t* q4;            // 4-bit screen: [4][32] int8 queries + [4][4] constants (recall_i4.hip)
+    float* pred_ms;          // [kMaxQueries][2] the threshold model's mean and sigma of every query's scores
 };
 struct RecallJob {
     // set by the caller
@@ -228,7 +242,11 @@ struct RecallJob {
     uint32_t rows = 0, nblocks = 0;
     bool screen = false;
     bool screen4 = false;                   // the pilot plan's full pass streams the 4-bit shadow (nq <= kI4MaxQueries)
-    int plans[3] = {0, 0, 0};
+    int plans[4] = {0, 0, 0, 0};
+    bool predict = false;                   // plans[0] takes its first thresholds from the table's threshold model
+    bool pred_observe = false;              // the table has a model: this job contributes its observed quantiles
+    bool observed = false;                  // ... and the enqueued plan did
+    double z_lo = 0.0;
     bool refined = false;                   // the enqueued pilot plan raised its thresholds after the first quarter
     int n_plans = 0, next_plan = 0, enqueued_plan = -1;
     uint32_t stride = 1, sample_blocks = 0, k_pilot = 0, perm_mul = 1;

@@ -1533,6 +1533,161 @@ __global__ void merge_keys_kernel(const uint64_t* __restrict__ rows, const float
     cand[(uint64_t)q * cap + atomicAdd(&cnt[q], 1u)] = topk_key(scores[l * sc_ls + q * sc_qs + j], (uint32_t)r);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Threshold predictor.  A query's scores over the table are a projection of the rows: mean mu.q, variance q'Sq, and —
+// 128 terms each — close to Gaussian, so the K-th best of N rows sits z standard deviations above the mean, with z
+// nearly the same for every query of a workload.  mu and S come from a row sample (with the table's statistics); z is
+// not assumed but OBSERVED: every verified batch reports (K-th best − mu.q) / sigma_q of its queries.  Once the
+// observed z is tight, the first thresholds of a batch are mu.q + (mean z − margin) sigma_q: the pilot sample — two
+// small scan launches, a re-scoring and two selects, 0.35 ms that nothing overlaps — is skipped.  Exactness does
+// not depend on any of this: a threshold that turns out too high leaves a query short of K candidates, which the
+// plan check sees, and the batch re-runs on the pilot plan (and the table stays on it for a while).
+// ---------------------------------------------------------------------------------------------
+// second moments of a row sample: workgroup b walks sample rows b, b + G, ...; thread (ty, tx) of a 16 x 16 grid owns
+// the 8 x 8 patch (i = ty + 16a, j = tx + 16b) of sum x_i x_j; 16 rows are staged per barrier pair
+__global__ __launch_bounds__(256) void pred_moments_kernel(const float* __restrict__ tab, uint64_t rows, uint64_t stride,
+                                                           uint64_t n_sample, float* __restrict__ sum1, float* __restrict__ sum2) {
+    __shared__ float xs[16][128 + 4];
+    const uint32_t tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    float acc[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0.0f;
+    float s1 = 0.0f;                                       // thread t < 128: sum of column t
+    for (uint64_t r0 = (uint64_t)blockIdx.x * 16; r0 < n_sample; r0 += (uint64_t)gridDim.x * 16) {
+        __syncthreads();
+        for (uint32_t e = tid; e < 16 * 32; e += 256) {    // 16 rows x 32 quads
+            const uint32_t rr = e >> 5, qd = e & 31;
+            const uint64_t sr = r0 + rr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sr < n_sample) {
+                const uint64_t row = sr * stride < rows ? sr * stride : rows - 1;
+                v = *reinterpret_cast<const float4*>(tab + row * 128 + 4 * qd);
+            }
+            *reinterpret_cast<float4*>(&xs[rr][4 * qd]) = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = 0; rr < 16; ++rr) {
+            float xi[8], xj[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                xi[a] = xs[rr][ty + 16 * a];
+                xj[a] = xs[rr][tx + 16 * a];
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[a][b] = __fmaf_rn(xi[a], xj[b], acc[a][b]);
+            if (tid < 128) s1 += xs[rr][tid];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) atomicAdd(&sum2[(ty + 16 * a) * 128 + tx + 16 * b], acc[a][b]);
+    if (tid < 128) atomicAdd(&sum1[tid], s1);
+}
+// sums → mean and covariance in place; the observation block behind them is cleared
+__global__ void pred_finish_kernel(float* __restrict__ pred, uint64_t n_sample) {
+    const uint32_t i = blockIdx.x, j = threadIdx.x;        // 128 x 128
+    const float inv = 1.0f / (float)n_sample;
+    const float mi = pred[i] * inv, mj = pred[j] * inv;
+    const float c = pred[128 + i * 128 + j] * inv - mi * mj;
+    pred[128 + i * 128 + j] = c;                           // (the raw column sums pred[0..127] are turned into means by the next launch)
+}
+__global__ void pred_means_kernel(float* __restrict__ pred, uint64_t n_sample) {
+    const uint32_t j = threadIdx.x;
+    if (j < 128) pred[j] = pred[j] / (float)n_sample;
+    if (j < 8) reinterpret_cast<uint32_t*>(pred + 128 + 128 * 128)[j] = 0u;          // n, sum z, sum z^2, min z (doubles)
+    if (j == 0) reinterpret_cast<double*>(pred + 128 + 128 * 128)[3] = 1e300;
+}
+// per query: mean mu.q and sigma sqrt(q'Sq) of its scores (one workgroup of 128 threads per query)
+__global__ __launch_bounds__(128) void pred_query_kernel(const float* __restrict__ qpad, const float* __restrict__ pred,
+                                                         float* __restrict__ ms) {
+    __shared__ float qs[128];
+    __shared__ double red[2][2];
+    const uint32_t q = blockIdx.x, t = threadIdx.x;
+    qs[t] = qpad[(size_t)q * 128 + t];
+    __syncthreads();
+    const float* S = pred + 128;
+    float sq = 0.0f;
+    for (int i = 0; i < 128; ++i) sq = __fmaf_rn(S[i * 128 + t], qs[i], sq);          // (S q)_t: S symmetric, column t coalesced
+    double v = (double)sq * (double)qs[t], m = (double)pred[t] * (double)qs[t];
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_xor(v, off, 64);
+        m += __shfl_xor(m, off, 64);
+    }
+    if ((t & 63) == 0) { red[t >> 6][0] = v; red[t >> 6][1] = m; }
+    __syncthreads();
+    if (t == 0) {
+        const double var = red[0][0] + red[1][0], mean = red[0][1] + red[1][1];
+        ms[2 * q] = (float)mean;
+        ms[2 * q + 1] = var > 0.0 ? (float)sqrt(var) : 0.0f;
+    }
+}
+// first thresholds from the model: thr = mean + z_lo sigma, rounded down; anything odd → +inf, which leaves the query
+// without candidates: the plan check then sends the batch to the pilot plan
+__global__ void pred_thr_kernel(const float* __restrict__ ms, uint32_t nq, float z_lo, float* __restrict__ thr) {
+    const uint32_t q = threadIdx.x;
+    if (q >= (uint32_t)kMaxQueries) return;
+    float t = -__builtin_inff();                           // (inactive query columns: as recall_init leaves them)
+    if (q < nq) {
+        const float m = ms[2 * q], sg = ms[2 * q + 1];
+        t = __fmaf_rn(z_lo, sg, m);
+        t = t - fabsf(t) * 1e-6f;
+        if (!(sg > 0.0f) || !(t == t) || fabsf(t) > 1e30f) t = __builtin_inff();
+    }
+    thr[q] = t;
+}
+// after a verified-to-be pass: fold the batch's observed quantiles into the table's statistics (queries that came up
+// short of K, or whose model sigma is 0, do not count), then they travel to the host with the status words
+__global__ void pred_update_kernel(const float* __restrict__ thr, const float* __restrict__ ms, const uint32_t* __restrict__ cnt,
+                                   uint32_t nq, uint32_t k, double* __restrict__ stats) {
+    const uint32_t q = threadIdx.x;
+    double z = 0.0, z2 = 0.0, n = 0.0, mn = 1e300;
+    if (q < nq && cnt[q] >= k && ms[2 * q + 1] > 0.0f) {
+        const float t = thr[q];
+        if (t == t && fabsf(t) < 1e30f) {
+            z = ((double)t - (double)ms[2 * q]) / (double)ms[2 * q + 1];
+            z2 = z * z;
+            n = 1.0;
+            mn = z;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        z += __shfl_xor(z, off, 64);
+        z2 += __shfl_xor(z2, off, 64);
+        n += __shfl_xor(n, off, 64);
+        const double o = __shfl_xor(mn, off, 64);
+        mn = o < mn ? o : mn;
+    }
+    if ((q & 63) == 0 && n > 0.0) {
+        atomicAdd(&stats[4], n);                       // observations ever (orders the host's snapshots; never decays)
+        atomicAdd(&stats[0], n);
+        atomicAdd(&stats[1], z);
+        atomicAdd(&stats[2], z2);
+        // (min via compare-and-swap on the bit pattern: the values are positive in every workload this is for, and a
+        //  stale minimum only makes the margin more careful)
+        unsigned long long* a = reinterpret_cast<unsigned long long*>(&stats[3]);
+        unsigned long long old = *a;
+        while (__longlong_as_double((long long)old) > mn) {
+            const unsigned long long seen = atomicCAS(a, old, (unsigned long long)__double_as_longlong(mn));
+            if (seen == old) break;
+            old = seen;
+        }
+    }
+    // a sliding window in effect: past 2^17 observations the sums halve, so a drifting query population moves the
+    // model within ~100 batches (the halving may race another stream's add and drop it: these are statistics)
+    __syncthreads();
+    if (q == 0 && stats[0] >= 131072.0) {
+        stats[0] *= 0.5;
+        stats[1] *= 0.5;
+        stats[2] *= 0.5;
+    }
+}
+
 int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
                          uint32_t cap, uint32_t k, int thr_only) {
     constexpr size_t lds = (size_t)kSelLdsKeys * 8;
@@ -1597,7 +1752,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     void* small;
     int rc;
     const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
-    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 28 + 2048;
+    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 36 + 2048;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
     rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
@@ -1610,6 +1765,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     rs->qscale = (float*)(rs->overflow + 64);
     rs->q4 = (uint32_t*)(rs->qscale + kMaxQueries);      // 4 x 128 B + 4 x 16 B
     rs->thr_ref = (float*)(rs->q4 + 160);                // [kMaxQueries]
+    rs->pred_ms = rs->thr_ref + kMaxQueries;             // [kMaxQueries][2]
     void* c;
     if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4), &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
@@ -1662,6 +1818,7 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
     if (t->stats_valid || t->shadow_failed) return PG_OK;
     t->i4_ok = t->i4_failed = false;                  // the 4-bit shadow (recall_i4.hip) follows the rows too
+    t->pred_model = false;                            // ... and the threshold model
     t->prefix_failures = 0;
     if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
     const bool force_bf16 = ctx->knobs.screen_bf16;
@@ -1753,6 +1910,35 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     return PG_OK;
 }
 
+constexpr uint32_t kPredStatsAt = 600;        // words [600, 608) of a job's status block: the table's observation sums
+
+// the threshold model of a table (dim 128): mean and covariance of a row sample, built once per generation of the rows
+static int ensure_pred_model(pg_ctx* ctx, const pg_table* tc) {
+    pg_table* t = const_cast<pg_table*>(tc);
+    std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
+    if (t->pred_model) return PG_OK;
+    const size_t bytes = (size_t)(128 + 128 * 128) * 4 + 5 * 8;   // mean | covariance (→ factor) | n, sum, sum2, min, total
+    if (!t->d_pred && hipMalloc((void**)&t->d_pred, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        t->d_pred = nullptr;
+        return PG_OK;                                 // no model: the pilot plan serves
+    }
+    PG_HIP(hipMemsetAsync(t->d_pred, 0, bytes, ctx->stream));
+    const uint64_t n_sample = t->rows < (1u << 20) ? t->rows : (1u << 20);
+    const uint64_t stride = t->rows / n_sample;
+    pred_moments_kernel<<<(uint32_t)ctx->num_cus, 256, 0, ctx->stream>>>(t->d, t->rows, stride, n_sample, t->d_pred, t->d_pred + 128);
+    pred_finish_kernel<<<128, 128, 0, ctx->stream>>>(t->d_pred, n_sample);
+    pred_means_kernel<<<1, 128, 0, ctx->stream>>>(t->d_pred, n_sample);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(ctx->stream));        // other contexts of the device use the model from their own streams
+    t->pred_model = true;
+    t->pred_k = 0;
+    t->pred_n = t->pred_sum = t->pred_sum2 = t->pred_total = 0.0;
+    t->pred_min = 1e300;
+    t->pred_backoff = 0;
+    return PG_OK;
+}
+
 template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1>
 static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     int rc_attr;
@@ -1830,7 +2016,7 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
 // (pipeline.hip) defer the check to the end of the whole request batch, so the rank / fusion / sort stages of a
 // batch are queued behind its recall without the GPU ever waiting for the host.
 // ---------------------------------------------------------------------------------------------
-enum RecallPlan { kPilot = 0, kGrow = 1, kSafe = 2 };
+enum RecallPlan { kPilot = 0, kGrow = 1, kSafe = 2, kPredict = 3 };
 
 static inline uint64_t rs_cap_bound(uint32_t k) { return (uint64_t)k + kCandSlack; }
 
@@ -1901,6 +2087,39 @@ int recall_job_prepare(RecallJob* j) {
         // queries; Gaussian rows, lambda 1.3: 1.46 / 1.59 / 1.78 / 2.02 — every query re-scores its own suspects)
         static const double kLamScale[kI4MaxQueries] = {1.0, 1.0, 0.88, 0.7};
         j->screen4 = t->i4_ok && (double)t->lam4 <= kn.i4_max_lambda * kLamScale[j->nq - 1];
+    }
+    // the threshold model: observe with every pilot-plan batch of a big int8-screened table; predict once the observed
+    // quantile is tight
+    j->predict = j->pred_observe = false;
+    if (screen && t->dim == 128 && t->shadow_is_i8 && j->plans[0] == kPilot && !j->screen4 && !j->skip_pilot && !kn.no_predict &&
+        rows >= kn.predict_min_rows && j->k < rows / 64) {
+        if ((rc = ensure_pred_model(ctx, t))) return rc;
+        pg_table* tm = const_cast<pg_table*>(t);
+        std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
+        if (t->pred_model) {
+            if (tm->pred_k != j->k) {                  // the observations belong to one K
+                PG_HIP(hipMemsetAsync(t->d_pred + 128 + 128 * 128, 0, 24, ctx->stream));
+                tm->pred_k = j->k;
+                tm->pred_n = tm->pred_sum = tm->pred_sum2 = 0.0;
+                tm->pred_backoff = 4;                  // (batches already in flight still report the old K's quantiles)
+            }
+            j->pred_observe = true;
+            if (tm->pred_backoff > 0) {
+                --tm->pred_backoff;
+            } else if (t->pred_n >= 1024.0) {
+                const double mean = t->pred_sum / t->pred_n;
+                const double var = t->pred_sum2 / t->pred_n - mean * mean;
+                const double sd = var > 0.0 ? sqrt(var) : 0.0;
+                // tight enough to beat the sample's own six-sigma margin (a threshold 3 % low in z doubles the rows that reach it)
+                if (mean > 0.5 && sd <= 0.025 * mean) {
+                    j->predict = true;
+                    j->z_lo = mean - kn.predict_sigmas * sd - 0.002 * mean;
+                    for (int i = j->n_plans; i > 0; --i) j->plans[i] = j->plans[i - 1];
+                    j->plans[0] = kPredict;
+                    j->n_plans++;
+                }
+            }
+        }
     }
     return PG_OK;
 }
@@ -2085,6 +2304,11 @@ int recall_job_enqueue(RecallJob* j) {
         PG_HIP(hipGetLastError());
         if (j->screen4 && (rc = screen4_prep_launch(ctx, t, rs))) return rc;
     }
+    const bool observe = j->pred_observe && (plan == kPilot || plan == kPredict);
+    if (observe) {
+        pred_query_kernel<<<j->nq, 128, 0, ctx->stream>>>(rs.qpad, t->d_pred, rs.pred_ms);
+        PG_HIP(hipGetLastError());
+    }
     while (j->events->size() < 2) {
         hipEvent_t e;
         PG_HIP(hipEventCreate(&e));
@@ -2094,7 +2318,14 @@ int recall_job_enqueue(RecallJob* j) {
     // events 0/1 of the pool bracket the whole plan; PlanRun's launches use the pairs after them
     r.n_ev = 1;
     PG_HIP(hipEventRecord((*j->events)[0], ctx->stream));
-    if (plan == kPilot) {
+    if (plan == kPredict) {
+        // no sample: the first thresholds are the model's (then exactly the pilot plan's full pass)
+        pred_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.pred_ms, j->nq, (float)j->z_lo, rs.thr);
+        screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
+        PG_HIP(hipGetLastError());
+    }
+    if (plan == kPilot || plan == kPredict) {
+      if (plan == kPilot) {
         // The sample itself is streamed in two launches when it is screened: a seed of `seed_rows` rows
         // (exact, every row a candidate) whose m0-th best score becomes the threshold of ONE screened
         // launch over the rest of the sample; m0 is chosen so that fewer than K' sample rows reaching
@@ -2120,6 +2351,7 @@ int recall_job_enqueue(RecallJob* j) {
             // geometric chunks over the sample (exact scan, or pilot_growth set: A/B runs)
             if ((rc = r.grow_scan(j->sample_blocks, j->stride, j->k_pilot, kn.pilot_growth > 0.0 ? kn.pilot_growth : 8.0, false))) return rc;
         }
+      }
         PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
         // The sample's threshold is deliberately low (K' = m + 6 sqrt(m) + 8 of a 1/64 sample: ~1.8 K rows reach it where K
         // are needed), and every row that reaches it costs a suspect's hit path and an exact re-scoring — a quarter of
@@ -2132,8 +2364,10 @@ int recall_job_enqueue(RecallJob* j) {
         const uint32_t nb_q = j->nblocks / 4;
         const double m2 = (double)j->k * 0.25;
         const uint32_t k2 = (uint32_t)ceil(m2 + kn.pilot_sigmas * sqrt(m2) + 8.0);
+        // (not behind a predicted threshold: that one already sits tighter than what a quarter of the table can certify —
+        //  rank ~1.1 K against k2's ~1.18 K — so the split would only add a launch boundary)
         const bool refine = j->screen && !j->screen4 && !kn.no_refine && j->rows >= kn.refine_min_rows && nb_q >= 64 &&
-                            k2 < j->k && t->prefix_failures < 2;
+                            k2 < j->k && t->prefix_failures < 2 && plan != kPredict;
         if (refine) {
             if ((rc = r.scan_range(0, nb_q, 1, false, true))) return rc;
             if ((rc = r.refine(k2))) return rc;
@@ -2163,6 +2397,14 @@ int recall_job_enqueue(RecallJob* j) {
         refine_verify_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.thr_ref, j->d_count, j->nq);
         PG_HIP(hipGetLastError());
     }
+    if (observe) {
+        // the K-th best scores that came out (rs.thr after the last refresh) as quantiles of the model; queries that
+        // failed report 0 items and do not count.  The sums travel to the host with the status words.
+        double* stats = reinterpret_cast<double*>(t->d_pred + 128 + 128 * 128);
+        pred_update_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.pred_ms, j->d_count, j->nq, j->k < j->rows ? j->k : j->rows, stats);
+        PG_HIP(hipGetLastError());
+        PG_HIP(hipMemcpyAsync(j->h_status + kPredStatsAt, stats, 40, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (j->d_out_count)
         PG_HIP(hipMemcpyAsync(j->d_out_count, j->d_count, 4 * j->nq, hipMemcpyDeviceToDevice, ctx->stream));
     PG_HIP(hipMemcpyAsync(j->h_status, rs.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2170,6 +2412,7 @@ int recall_job_enqueue(RecallJob* j) {
     j->n_ev = r.n_ev;
     j->refined = refined;
     j->enqueued_plan = plan;
+    j->observed = observe;
     j->next_plan++;
     return PG_OK;
 }
@@ -2193,7 +2436,7 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
     j->scan_launches += j->n_ev - 1;
     bool ok = j->h_status[0] == 0;
     j->failed.clear();
-    if (ok && plan == kPilot) {
+    if (ok && (plan == kPilot || plan == kPredict)) {
         const uint32_t want = j->k < j->rows ? j->k : j->rows;
         for (uint32_t q = 0; q < j->nq; ++q)
             if (j->h_status[1 + q] != want) {
@@ -2201,10 +2444,40 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
                 j->failed.push_back(q);
             }
     }
+    if (j->observed || plan == kPredict) {
+        pg_table* tm = const_cast<pg_table*>(j->t);
+        std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
+        if (j->observed && tm->pred_k == j->k) {
+            double st[5];
+            memcpy(st, j->h_status + kPredStatsAt, sizeof st);
+            if (st[4] >= tm->pred_total) {              // (two streams report: keep the later snapshot)
+                tm->pred_total = st[4];
+                tm->pred_n = st[0];
+                tm->pred_sum = st[1];
+                tm->pred_sum2 = st[2];
+                tm->pred_min = st[3];
+            }
+        }
+        if (ctx->knobs.debug_scan && tm->pred_n > 0.0) {
+            const double mean = tm->pred_sum / tm->pred_n, var = tm->pred_sum2 / tm->pred_n - mean * mean;
+            fprintf(stderr, "[pg] plan %d %s: threshold model n = %.0f, z mean %.5f sd %.5f min %.5f (z_lo of this job %.5f)\n", plan,
+                    ok ? "held" : "FAILED", tm->pred_n, mean, var > 0 ? sqrt(var) : 0.0, tm->pred_min, j->z_lo);
+        }
+        if (plan == kPredict && !ok) {
+            // the model's threshold was too high for some query: this table stays on the pilot plan for a while (the
+            // whole batch re-runs when more than a handful failed — that must stay rare)
+            // and the model starts over: what it learnt no longer describes the queries
+            tm->pred_failures++;
+            tm->pred_backoff = 64u << (tm->pred_failures < 6 ? tm->pred_failures : 6);
+            PG_HIP(hipMemsetAsync(tm->d_pred + 128 + 128 * 128, 0, 24, ctx->stream));
+            tm->pred_n = tm->pred_sum = tm->pred_sum2 = 0.0;
+        }
+    }
     if (!ok) ctx->stats.recall_rescans++;
+    if (ok && plan == kPredict) ctx->stats.recall_predicted++;
     // a refined threshold that fails verification on most of a batch says the head of the table is not representative
     // (ordered rows): after two such batches the table's recalls stop refining (a hint, not state anyone relies on)
-    if (!ok && plan == kPilot && j->refined && j->failed.size() > j->nq / 2) const_cast<pg_table*>(j->t)->prefix_failures++;
+    if (!ok && (plan == kPilot || plan == kPredict) && j->refined && j->failed.size() > j->nq / 2) const_cast<pg_table*>(j->t)->prefix_failures++;
     *ok_out = ok;
     return PG_OK;
 }

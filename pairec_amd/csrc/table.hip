@@ -125,6 +125,7 @@ int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
     if (t->d4) PG_HIP(hipFree(t->d4));
     if (t->d4s) PG_HIP(hipFree(t->d4s));
     if (t->dnorm2) PG_HIP(hipFree(t->dnorm2));
+    if (t->d_pred) PG_HIP(hipFree(t->d_pred));
     delete t;
     return PG_OK;
 }
@@ -227,6 +228,16 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->rmax4, b->rmax4);
     std::swap(a->lam4, b->lam4);
     std::swap(a->prefix_failures, b->prefix_failures);
+    std::swap(a->d_pred, b->d_pred);
+    std::swap(a->pred_model, b->pred_model);
+    std::swap(a->pred_k, b->pred_k);
+    std::swap(a->pred_n, b->pred_n);
+    std::swap(a->pred_sum, b->pred_sum);
+    std::swap(a->pred_sum2, b->pred_sum2);
+    std::swap(a->pred_min, b->pred_min);
+    std::swap(a->pred_total, b->pred_total);
+    std::swap(a->pred_backoff, b->pred_backoff);
+    std::swap(a->pred_failures, b->pred_failures);
     return PG_OK;
 }
 

@@ -1090,3 +1090,62 @@ def test_recommend_one_call_equals_the_stages(ctx):
         ctx.free(p)
     m.destroy()
     t.destroy()
+
+
+def test_recall_threshold_model_predicts_then_backs_off_on_queries_it_does_not_describe(ctx):
+    """After 1024 observed queries of one K the screening threshold comes from the table's threshold model instead of
+    the pilot sample (csrc/recall.hip): mean + z * sd of the query's score distribution, z learnt from
+    the K-th best scores of verified batches.  Exactness never depends on it — a threshold that leaves fewer than K
+    candidates fails the same verification as a sampled one.  Forced on for a small table: (1) it takes over and the
+    answers stay the oracle's; (2) queries along a two-valued column, whose K-th best score sits far below what the
+    Gaussian-tail model says, are caught, re-run and answered exactly; (3) the table then stays on the pilot plan."""
+    rng = np.random.default_rng(47)
+    n, d, k, nq = 600_000, 128, 300, 160
+    tab = rng.standard_normal((n, d)).astype(np.float32)
+    tab[:, 127] = np.where(rng.random(n) < 0.5, np.float32(3.0), np.float32(-3.0))
+    for name, v in (("predict_min_rows", "0"), ("pilot_fraction", "0.125")):
+        ctx.set_option(name, v)
+    try:
+        t = pa.Table(ctx, n, d)
+        t.upload(tab)
+        s0 = ctx.stats()
+        batches = []
+        for b in range(10):
+            q = rng.standard_normal((nq, d)).astype(np.float32)
+            q[:, 127] = 0.0
+            rows, scores, _ = t.recall_topk(q, k)
+            batches.append((q, rows, scores))
+        s1 = ctx.stats()
+        assert s1.recall_rescans == s0.recall_rescans
+        assert s1.recall_predicted - s0.recall_predicted >= 2, "the model never took over"
+        for q, rows, scores in (batches[0], batches[-1]):
+            orow, osc = o.recall_topk(tab, q, k)
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+        # (2) three queries of the batch look along the two-valued column: half the table scores +3|q|, the K-th best
+        # is ~1 sd above the mean where the model expects ~3.3
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        q[:, 127] = 0.0
+        for i in (5, 77, 159):
+            q[i] = 0.0
+            q[i, 127] = 1.0 + i
+            q[i, :8] = 0.01 * rng.standard_normal(8)           # (break the ties between the 300 K rows at +3)
+        rows, scores, _ = t.recall_topk(q, k)
+        s2 = ctx.stats()
+        assert s2.recall_rescans == s1.recall_rescans + 1 and s2.recall_predicted == s1.recall_predicted
+        orow, osc = o.recall_topk(tab, q, k)
+        assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+        # (3) backed off: the next batches run the pilot plan (and teach the model again)
+        q, rows0, scores0 = batches[3]
+        rows, scores, _ = t.recall_topk(q, k)
+        s3 = ctx.stats()
+        assert s3.recall_predicted == s2.recall_predicted and s3.recall_rescans == s2.recall_rescans
+        assert np.array_equal(rows, rows0) and np.array_equal(bits(scores), bits(scores0))
+        # the knob turns it off
+        ctx.set_option("no_predict", "1")
+        rows, scores, _ = t.recall_topk(q, k)
+        ctx.set_option("no_predict", "0")
+        assert np.array_equal(rows, rows0) and np.array_equal(bits(scores), bits(scores0))
+        t.destroy()
+    finally:
+        ctx.set_option("predict_min_rows", str(1 << 22))
+        ctx.set_option("pilot_fraction", "0")
