@@ -561,6 +561,67 @@ __global__ __launch_bounds__(1024) void build_tiles_kernel(
     }
 }
 
+// The same table from many workgroups (n_req <= kTilesLdsReqs): every workgroup of 256 threads recomputes the request
+// prefix for itself in LDS — a few loads per thread — and then writes ITS 256 tiles; workgroup 0 also publishes the
+// prefix and the tile count.  One workgroup walking 20 000 tiles took 70-90 us of a 0.6 ms rank stage (r3 profile);
+// this takes one short launch.  The grid covers the host's upper bound n_items / tile_items + n_req.
+__global__ __launch_bounds__(256) void build_tiles_wide_kernel(
+    const uint32_t* __restrict__ req_offsets, uint32_t n_req, uint32_t* __restrict__ tile_req,
+    uint32_t* __restrict__ tile_item0, uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ n_tiles,
+    uint32_t* __restrict__ req_tile0, uint32_t tile_items) {
+    __shared__ uint32_t chunk_sum[256];
+    __shared__ uint32_t pre[kTilesLdsReqs];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_req + 255) / 256;
+    const uint32_t r0 = tid * per < n_req ? tid * per : n_req, r1 = (r0 + per < n_req) ? r0 + per : n_req;
+    uint32_t sum = 0;
+    for (uint32_t r = r0; r < r1; ++r) sum += (req_offsets[r + 1] - req_offsets[r] + tile_items - 1) / tile_items;
+    chunk_sum[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = tid >= d ? chunk_sum[tid - d] : 0;
+        __syncthreads();
+        chunk_sum[tid] += v;
+        __syncthreads();
+    }
+    uint32_t acc = chunk_sum[tid] - sum;
+    const bool publish = blockIdx.x == 0;
+    for (uint32_t r = r0; r < r1; ++r) {
+        pre[r] = acc;
+        if (publish) req_tile0[r] = acc;
+        acc += (req_offsets[r + 1] - req_offsets[r] + tile_items - 1) / tile_items;
+    }
+    const uint32_t total = chunk_sum[255];
+    if (publish && tid == 0) *n_tiles = total;
+    __syncthreads();
+    const uint32_t t = blockIdx.x * 256 + tid;
+    if (t >= total) return;
+    uint32_t lo = 0, hi = n_req - 1;                       // the LAST request whose first tile is <= t (see above)
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (pre[mid] <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    const uint32_t e = req_offsets[lo + 1];
+    const uint32_t i = req_offsets[lo] + (t - pre[lo]) * tile_items;
+    tile_req[t] = lo;
+    tile_item0[t] = i;
+    tile_cnt[t] = (e - i < tile_items) ? e - i : tile_items;
+}
+
+static int build_tiles_launch(pg_ctx* ctx, const uint32_t* d_off, uint32_t n_req, uint32_t max_tiles, uint32_t tile_items,
+                              uint32_t* tile_req, uint32_t* tile_item0, uint32_t* tile_cnt, uint32_t* n_tiles,
+                              uint32_t* req_tile0) {
+    if (n_req <= kTilesLdsReqs)
+        build_tiles_wide_kernel<<<(max_tiles + 255) / 256, 256, 0, ctx->stream>>>(d_off, n_req, tile_req, tile_item0, tile_cnt,
+                                                                                  n_tiles, req_tile0, tile_items);
+    else
+        build_tiles_kernel<<<1, 1024, 0, ctx->stream>>>(d_off, n_req, tile_req, tile_item0, tile_cnt, n_tiles, req_tile0,
+                                                        tile_items);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 // DNN3 request-constant half of layer 1: c1[r][j] = chain(b1[j]; P(u[r][k]) * W1u[k][j], k asc)
 // (W1u is stored already rounded to the model's operand precision).  The chain is sequential in k; its loads
 // are not — eight rows of W1u are requested before the eight fmafs that use them.
@@ -829,10 +890,13 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     const bool no_ws = ctx->knobs.rank_no_ws;        // A/B switch: the streaming kernel
     // the weights-stationary kernel is built for the benchmark's shape: [d_user + 128] -> 512 -> 256 -> 1 in bf16
     const bool ws = m->prec && !no_ws && m->h1 == 512 && m->h2 == 256 && t->dim == 128;
+    // the small shapes, gather-bound: the whole model in registers (rank_rs.hip)
+    const bool rs_k = m->prec && !no_ws && t->dim == 128 && dnn3_rs_shape(m->h1, m->h2);
     const uint32_t grid128 = n_items / kBM + n_req;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    build_tiles_kernel<<<1, 1024, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
-                                                   rs.n_tiles, rs.req_tile0, ws ? (uint32_t)kWsItems : (uint32_t)kBM);
+    if ((rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, ws || rs_k ? (uint32_t)kWsItems : (uint32_t)kBM, rs.tile_req, rs.tile_item0,
+                                 rs.tile_cnt, rs.n_tiles, rs.req_tile0)))
+        return rc;
     dnn3_user_partial_kernel<<<dim3(n_req, (m->h1 + 255) / 256), 256, 0, ctx->stream>>>(
         d_user, m->d_user, m->w1u, m->b1, m->h1, m->prec, rs.c1);
     MlpArgs a{};
@@ -856,6 +920,8 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     if (ws) {
         // bf16: weights-stationary persistent kernel over 64-item tiles
         if ((rc = launch_dnn3_ws(ctx, a))) return rc;
+    } else if (rs_k) {
+        if ((rc = launch_dnn3_rs(ctx, m->h1, m->h2, a))) return rc;
     } else if ((rc = dispatch_dnn3_mlp(ctx, m, a, grid128))) {
         return rc;
     }
@@ -878,8 +944,9 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     int rc;
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->to, &rs))) return rc;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    build_tiles_kernel<<<1, 1024, 0, ctx->stream>>>(d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt,
-                                                   rs.n_tiles, rs.req_tile0, bm);
+    if ((rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, bm, rs.tile_req, rs.tile_item0, rs.tile_cnt, rs.n_tiles,
+                                 rs.req_tile0)))
+        return rc;
     fm2t_user_kernel<<<dim3(n_req, 2), 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th,
                                                      m->to, m->prec, m->d_field_emb, m->d_field_lin, d_ufids,
                                                      m->vocab, m->fm_b, rs.c1, rs.fm_user, m->nuf, m->k);

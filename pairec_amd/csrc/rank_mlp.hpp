@@ -136,5 +136,8 @@ __device__ __forceinline__ void store_h_quad(char* tile, int row, int col, float
 // rank_ws.hip: the weights-stationary DNN3 kernel (bf16); `a` describes 64-item tiles
 constexpr int kWsItems = 64;
 int launch_dnn3_ws(pg_ctx* ctx, const MlpArgs& a);
+// rank_rs.hip: the register-stationary DNN3 kernel (bf16) for the small hidden shapes; 64-item tiles as well
+bool dnn3_rs_shape(uint32_t h1, uint32_t h2);
+int launch_dnn3_rs(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
 
 }  // namespace pg
