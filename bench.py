@@ -64,6 +64,7 @@ def parse_args():
                     help="headline table: SURVEY.md 8d's normalised uniform rows, or N(0,1) rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only (profiling runs)")
+    ap.add_argument("--no-rank-shapes", action="store_true", help="skip the rank-stage-alone leg (DNN3 per hidden shape)")
     ap.add_argument("--contexts", type=int, default=2,
                     help="library contexts (= HIP streams with their own scratch) the batches alternate between")
     ap.add_argument("--callers", type=int, default=768, help="host threads of the concurrent-callers leg (0 = skip)")
@@ -408,6 +409,57 @@ def concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K):
                 "cross PCIe (the page: rows, three scores per entry); the coalescer batches up to 256 requests per table "
                 "pass, 3 batches in flight",
     })
+    return out
+
+
+RANK_SHAPES_JSON = os.path.join(ROOT, "profiles", "r3_rank_shapes_pmc.json")
+RANK_SHAPES = ((128, 128), (256, 128), (256, 256), (512, 256), (1024, 512))
+
+
+def rank_shapes_leg(pa, o, ctx, table, R, K):
+    """The DNN3 rank stage ALONE (tile table + request partial + MLP kernel), bf16, per hidden shape: R requests x K
+    random candidate rows of the resident table, nothing else on the device — the kernel's own duration, which the
+    pipelined headline loop cannot show (there a rank kernel shares the CUs with the other context's scan).  FLOP are
+    SURVEY.md 8(d)'s 2*(256*h1 + h1*h2 + h2) per item; mfma_busy comes from the committed PMC pass when there is one."""
+    n = table.rows
+    rng = np.random.default_rng(5)
+    nI = R * K
+    cand = rng.integers(0, n, nI).astype(np.uint32)
+    offs = (np.arange(R + 1) * K).astype(np.uint32)
+    us = o.synth_rows(o.SEED_QUERY, 0, R, 128)
+    d_u, d_c, d_o = ctx.to_device(us), ctx.to_device(cand), ctx.to_device(offs)
+    d_out = ctx.malloc(nI * 4)
+    pmc = {}
+    try:
+        with open(RANK_SHAPES_JSON) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        pass
+    kernels = {(512, 256): "pg::dnn3_ws_kernel", (1024, 512): "pg::mlp_kernel<1, 1024, 512, ...>"}
+    out = []
+    for h1, h2 in RANK_SHAPES:
+        w = o.Dnn3Weights(d_user=128, d_item=128, h1=h1, h2=h2, seed=o.SEED_WEIGHTS ^ (h1 + h2))
+        m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+        flop = 2 * (256 * h1 + h1 * h2 + h2)
+        best = 1e9
+        for _ in range(3):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                m.rank_dnn3_dev(table, d_u, d_c, d_o, R, nI, d_out)
+            ctx.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 10)
+        dev_ms = ctx.stats().last_rank_ms
+        m.destroy()
+        key = "%d-%d" % (h1, h2)
+        out.append({"shape": "256-%d-%d-1" % (h1, h2), "kernel": kernels.get((h1, h2), "pg::dnn3_rs_kernel<%d, %d, ...>" % (h1, h2)),
+                    "ms_per_%d_items" % nI: best * 1e3, "device_ms": dev_ms, "items_per_s": nI / best,
+                    "achieved": nI * flop / best / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": nI * flop / best / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "gather_gbs": nI * 512 / best / 1e9,
+                    "mfma_busy_from_profile": (pmc.get(key) or {}).get("mfma_busy")})
+    for p_ in (d_u, d_c, d_o, d_out):
+        ctx.free(p_)
     return out
 
 
@@ -793,6 +845,23 @@ def main():
             out["single_request_roofline"] = {k_: rf1[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac",
                                                                      "measured_peak", "frac_of_measured", "bytes_per_pass",
                                                                      "ms_per_pass", "traffic_from_profile")}
+
+    if solo and args.prec == "bf16" and not args.no_rank_shapes:
+        # the rank stage alone, per hidden shape; the benchmark shape's entry is the rank roofline proper
+        for c_ in [ctx] + list(extra_ctxs):
+            c_.synchronize()
+        shapes = rank_shapes_leg(pa, o, ctx, table, R, K)
+        out["rank_shapes"] = shapes
+        bs = [e for e in shapes if e["shape"] == "256-512-256-1"][0]
+        in_pipe = out["rank_roofline"]
+        out["rank_roofline"] = {"bound": "mfma", "kernel": bs["kernel"], "achieved": bs["achieved"], "peak": bs["peak"],
+                                "unit": "TFLOP/s", "frac": bs["frac"], "ms": bs["ms_per_%d_items" % (R * K)],
+                                "measured": "rank stage alone on the device (tile table + request partial + MLP kernel), "
+                                            "%d x %d random candidate rows of the resident table" % (R, K),
+                                "mfma_busy_from_profile": bs["mfma_busy_from_profile"],
+                                "in_pipeline": {"ms": st.last_rank_ms, "frac": in_pipe["frac"] if in_pipe else None,
+                                                "note": "HIP events around the stage inside the headline loop, where it "
+                                                        "shares the CUs with the other context's scan kernel"}}
 
     extras = solo and not args.no_extras
     if extras and args.callers > 0:

@@ -19,18 +19,20 @@ namespace pg {
 // Arithmetic and k order of layers 1 and 2 are mlp_kernel<1, H1, H2, …>'s; the head sums a lane's H2/8 columns, then the
 // item's 8 partials in slot order, as dnn3_ws_kernel does (a fixed order inside the bf16 mode's 1e-5).
 // ---------------------------------------------------------------------------------------------
-template <int H1, int H2>
+template <int H1, int H2, bool W1L>
 constexpr size_t rs_lds_bytes() {
-    return (size_t)kWsItems * (kDIN + H1) * 2 + (size_t)(H1 + 2 * H2 + 8 * kWsItems) * 4;
+    return (size_t)kWsItems * (kDIN + H1) * 2 + (size_t)(H1 + 2 * H2 + 8 * kWsItems) * 4 + (W1L ? (size_t)kDIN * H1 * 2 : 0);
 }
 
 struct RsTile {
     uint32_t req, item0, cnt;
 };
 
-template <int H1, int H2>
-__global__ __launch_bounds__(256, 1) void dnn3_rs_kernel(MlpArgs a) {
+template <int H1, int H2, int WPC, int MBG, int MSPLIT, bool W1L>
+__global__ __launch_bounds__(256 * MSPLIT, WPC) void dnn3_rs_kernel(MlpArgs a) {
     constexpr int NB1 = H1 / 128, NB2 = H2 / 128, KS1 = kDIN / 16, KS2 = H1 / 16;
+    constexpr int MPW = 2 / MSPLIT;                        // 32-item blocks per wave
+    constexpr int GL = 4 * MSPLIT, GQ = 32 / GL;           // gather: lanes per item, 16-B quads per lane
     constexpr int XT_B = kWsItems * kDIN * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const XT = smem;
@@ -39,22 +41,30 @@ __global__ __launch_bounds__(256, 1) void dnn3_rs_kernel(MlpArgs a) {
     float* const b2s = c1s + H1;
     float* const w3s = b2s + H2;
     float* const hps = w3s + H2;                                          // head partials [8 slots][64 items]
+    char* const W1S = reinterpret_cast<char*>(hps + 8 * kWsItems);        // W1L: layer 1's fragments, shared by the waves of a column slice
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_id & 3;                          // column slice
+    const int mbase = MSPLIT == 2 ? (wave_id >> 2) : 0;    // MSPLIT = 2: eight waves, waves w and w + 4 share a column slice and take one item block each
     const uint32_t n_tiles = *a.n_tiles;
     const uint32_t t_begin = (uint32_t)(((uint64_t)n_tiles * blockIdx.x) / gridDim.x);
     const uint32_t t_end = (uint32_t)(((uint64_t)n_tiles * (blockIdx.x + 1)) / gridDim.x);
     if (t_begin >= t_end) return;
 
     // the model, for the whole launch
-    bf16x8 w1r[NB1][KS1], w2r[NB2][KS2];
+    bf16x8 w1r[W1L ? 1 : NB1][W1L ? 1 : KS1], w2r[NB2][KS2];
+    if constexpr (W1L) {
+        for (int i = tid; i < kDIN * H1 * 2 / 16; i += 256 * MSPLIT)
+            reinterpret_cast<uint4*>(W1S)[i] = reinterpret_cast<const uint4*>(a.w1p)[i];
+    } else {
 #pragma unroll
-    for (int nb = 0; nb < NB1; ++nb)
+        for (int nb = 0; nb < NB1; ++nb)
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks)
-            w1r[nb][ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(a.w1p) +
-                                                           (size_t)((wave * NB1 + nb) * KS1 + ks) * 1024 + lane * 16);
+            for (int ks = 0; ks < KS1; ++ks)
+                w1r[nb][ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(a.w1p) +
+                                                               (size_t)((wave * NB1 + nb) * KS1 + ks) * 1024 + lane * 16);
+    }
 #pragma unroll
     for (int nb = 0; nb < NB2; ++nb)
 #pragma unroll
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void dnn3_rs_kernel(MlpArgs a) {
     }
 
     // gather role: 4 adjacent lanes per item, lane l of them takes quads 4j + l (64 contiguous bytes per instruction)
-    const int g_item = tid >> 2, g_l = tid & 3;
+    const int g_item = tid / GL, g_l = tid % GL;
     auto load_desc = [&](uint32_t t) {
         RsTile d{0, 0, 0};
         if (t < t_end) {
@@ -85,46 +95,57 @@ __global__ __launch_bounds__(256, 1) void dnn3_rs_kernel(MlpArgs a) {
         if (d.cnt == 0) return 0;
         return a.cand_rows[d.item0 + ((uint32_t)g_item < d.cnt ? (uint32_t)g_item : d.cnt - 1)];
     };
-    float4 xq[8];
+    float4 xq[GQ];
     auto load_rows = [&](uint32_t row) {
         row = row < a.tab_rows ? row : a.tab_rows - 1;
         const float4* src = reinterpret_cast<const float4*>(a.tab + (size_t)row * kDIN) + g_l;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xq[j] = src[4 * j];
+        for (int j = 0; j < GQ; ++j) xq[j] = src[GL * j];
     };
     RsTile cur = uniform(load_desc(t_begin)), nxt = uniform(load_desc(t_begin + 1)), nn = uniform(load_desc(t_begin + 2));
     load_rows(load_rowid(cur));
     uint32_t row_n1 = load_rowid(nxt);
     uint32_t c1_req = 0xffffffffu;
-    const int i32 = lane & 31, h = lane >> 5, sw = lane & 15;
-    const uint32_t fin_item = (uint32_t)wave * (kWsItems / 4) + (lane & 15);
+    constexpr int FPW = kWsItems / (4 * MSPLIT);           // items a wave finishes
+    const uint32_t fin_item = (uint32_t)wave_id * FPW + (lane & (FPW - 1));
 
+#ifdef PG_RS_PROFILE
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_readcyclecounter();
+#define RS_MARK(i) { const uint64_t tn = __builtin_readcyclecounter(); ph[i] += tn - tp; tp = tn; }
+#else
+#define RS_MARK(i)
+#endif
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
         const RsTile d3 = load_desc(tile + 3);
+        // (per-lane addresses from an opaque copy of the thread id: hoisted out of the tile loop they are spilled)
+        uint32_t tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int i32 = tid_o & 31, h = (tid_o >> 5) & 1, sw = tid_o & 15;
         // ---- X tile from the rows requested a tile ago; then the next tile's rows and the row ids behind them
 #pragma unroll
-        for (int j = 0; j < 8; ++j) store_x_quad<1>(XT, g_item, 4 * j + g_l, xq[j]);
+        for (int j = 0; j < GQ; ++j) store_x_quad<1>(XT, g_item, GL * j + g_l, xq[j]);
         load_rows(nxt.cnt ? row_n1 : 0);
         const uint32_t row_n2 = load_rowid(nn);
         if (cur.req != c1_req) {
             c1_req = cur.req;
             if (tid < H1) c1s[tid] = a.c1[(size_t)cur.req * a.c1_stride + tid];
         }
+        RS_MARK(0)
         __syncthreads();
+        RS_MARK(1)
 
         // ---- layer 1: hidden columns of n-blocks wave * NB1 + nb, transposed accumulators (a lane owns 4 consecutive
-        // columns of one item)
-        {
-            const char* const x0 = XT + i32 * 256;
-            const char* const x1 = XT + (32 + i32) * 256;
-            f32x16 acc[2][NB1];
+        // columns of one item); MBG item blocks at a time (one where two workgroups share the CU's registers)
+#pragma unroll 1
+        for (int m0 = 0; m0 < MPW; m0 += MBG) {
+            f32x16 acc[MBG][NB1];
 #pragma unroll
             for (int nb = 0; nb < NB1; ++nb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 cv = *reinterpret_cast<const float4*>(c1s + (wave * NB1 + nb) * 32 + 8 * g + 4 * h);
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) {
+                    for (int mb = 0; mb < MBG; ++mb) {
                         acc[mb][nb][4 * g + 0] = cv.x;
                         acc[mb][nb][4 * g + 1] = cv.y;
                         acc[mb][nb][4 * g + 2] = cv.z;
@@ -133,38 +154,47 @@ __global__ __launch_bounds__(256, 1) void dnn3_rs_kernel(MlpArgs a) {
                 }
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(x0 + (((ks * 2 + h) ^ sw) << 4));
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(x1 + (((ks * 2 + h) ^ sw) << 4));
+                bf16x8 af[MBG];
+#pragma unroll
+                for (int mb = 0; mb < MBG; ++mb)
+                    af[mb] = *reinterpret_cast<const bf16x8*>(XT + ((mbase + m0 + mb) * 32 + i32) * 256 + (((ks * 2 + h) ^ sw) << 4));
 #pragma unroll
                 for (int nb = 0; nb < NB1; ++nb) {
-                    acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1r[nb][ks], a0, acc[0][nb], 0, 0, 0);
-                    acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1r[nb][ks], a1, acc[1][nb], 0, 0, 0);
+                    bf16x8 bw;
+                    if constexpr (W1L)
+                        bw = *reinterpret_cast<const bf16x8*>(W1S + ((wave * NB1 + nb) * KS1 + ks) * 1024 + (tid_o & 63) * 16);
+                    else
+                        bw = w1r[nb][ks];
+#pragma unroll
+                    for (int mb = 0; mb < MBG; ++mb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, af[mb], acc[mb][nb], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < MBG; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB1; ++nb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        store_h_quad<1, H1>(H1T, mb * 32 + i32, (wave * NB1 + nb) * 32 + 8 * g + 4 * h,
+                        store_h_quad<1, H1>(H1T, (mbase + m0 + mb) * 32 + i32, (wave * NB1 + nb) * 32 + 8 * g + 4 * h,
                                             fmaxf(acc[mb][nb][4 * g + 0], 0.0f), fmaxf(acc[mb][nb][4 * g + 1], 0.0f),
                                             fmaxf(acc[mb][nb][4 * g + 2], 0.0f), fmaxf(acc[mb][nb][4 * g + 3], 0.0f));
         }
+        RS_MARK(2)
         __syncthreads();
+        RS_MARK(3)
 
         // ---- layer 2 + head partials
-        {
-            const char* const h1r0 = H1T + i32 * (H1 * 2);
-            const char* const h1r1 = H1T + (32 + i32) * (H1 * 2);
-            f32x16 acc[2][NB2];
+#pragma unroll 1
+        for (int m0 = 0; m0 < MPW; m0 += MBG) {
+            f32x16 acc[MBG][NB2];
 #pragma unroll
             for (int nb = 0; nb < NB2; ++nb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 bv = *reinterpret_cast<const float4*>(b2s + (wave * NB2 + nb) * 32 + 8 * g + 4 * h);
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) {
+                    for (int mb = 0; mb < MBG; ++mb) {
                         acc[mb][nb][4 * g + 0] = bv.x;
                         acc[mb][nb][4 * g + 1] = bv.y;
                         acc[mb][nb][4 * g + 2] = bv.z;
@@ -173,17 +203,19 @@ __global__ __launch_bounds__(256, 1) void dnn3_rs_kernel(MlpArgs a) {
                 }
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(h1r0 + (((ks * 2 + h) ^ sw) << 4));
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(h1r1 + (((ks * 2 + h) ^ sw) << 4));
+                bf16x8 af[MBG];
 #pragma unroll
-                for (int nb = 0; nb < NB2; ++nb) {
-                    acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2r[nb][ks], a0, acc[0][nb], 0, 0, 0);
-                    acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2r[nb][ks], a1, acc[1][nb], 0, 0, 0);
-                }
+                for (int mb = 0; mb < MBG; ++mb)
+                    af[mb] = *reinterpret_cast<const bf16x8*>(H1T + ((mbase + m0 + mb) * 32 + i32) * (H1 * 2) + (((ks * 2 + h) ^ sw) << 4));
+#pragma unroll
+                for (int nb = 0; nb < NB2; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < MBG; ++mb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2r[nb][ks], af[mb], acc[mb][nb], 0, 0, 0);
             }
             // relu → dot head from the accumulators: the lane's partial runs over its columns in ascending order
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < MBG; ++mb) {
                 float p = 0.0f;
 #pragma unroll
                 for (int nb = 0; nb < NB2; ++nb)
@@ -195,13 +227,15 @@ __global__ __launch_bounds__(256, 1) void dnn3_rs_kernel(MlpArgs a) {
                         p = __fmaf_rn(fmaxf(acc[mb][nb][4 * g + 2], 0.0f), wv.z, p);
                         p = __fmaf_rn(fmaxf(acc[mb][nb][4 * g + 3], 0.0f), wv.w, p);
                     }
-                hps[(wave * 2 + h) * kWsItems + mb * 32 + i32] = p;
+                hps[(wave * 2 + h) * kWsItems + (mbase + m0 + mb) * 32 + i32] = p;
             }
         }
+        RS_MARK(4)
         __syncthreads();                                   // partials visible; everyone is done with X and H1
+        RS_MARK(5)
 
         // ---- scores: z = (((b3 + p0) + p1) + …) + p7, 16 items per wave
-        if (lane < kWsItems / 4 && fin_item < cur.cnt) {
+        if (lane < FPW && fin_item < cur.cnt) {
             float z = a.b3;
 #pragma unroll
             for (int s = 0; s < 8; ++s) z += hps[s * kWsItems + fin_item];
@@ -211,15 +245,41 @@ __global__ __launch_bounds__(256, 1) void dnn3_rs_kernel(MlpArgs a) {
         nxt = nn;
         nn = uniform(d3);
         row_n1 = row_n2;
+        RS_MARK(6)
     }
+#ifdef PG_RS_PROFILE
+    if (lane == 0 && blockIdx.x < 4) {
+        uint64_t* o = (uint64_t*)(a.field_emb) + (blockIdx.x * 4 + (wave_id & 3)) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = ph[i];
+    }
+#endif
 }
 
-template <int H1, int H2>
+// WPC workgroups per CU: 128-128 needs 206 registers, so two of them share a CU (one's barriers and LDS phases run
+// under the other's MFMAs); the wider shapes take 304 / 352 and run one
+template <int H1, int H2, int WPC, int MBG, int MSPLIT, bool W1L>
 static int launch_rs(pg_ctx* ctx, const MlpArgs& a) {
-    constexpr size_t lds = rs_lds_bytes<H1, H2>();
+    constexpr size_t lds = rs_lds_bytes<H1, H2, W1L>();
     int rc;
-    if ((rc = ensure_dyn_lds(ctx, (const void*)dnn3_rs_kernel<H1, H2>, lds))) return rc;
-    dnn3_rs_kernel<H1, H2><<<ctx->num_cus, 256, lds, ctx->stream>>>(a);
+    if ((rc = ensure_dyn_lds(ctx, (const void*)dnn3_rs_kernel<H1, H2, WPC, MBG, MSPLIT, W1L>, lds))) return rc;
+#ifdef PG_RS_PROFILE
+    static uint64_t* dbg = nullptr;
+    if (!dbg) hipMalloc(&dbg, 4 * 4 * 8 * 8);
+    MlpArgs b = a;
+    b.field_emb = reinterpret_cast<const float* const*>(dbg);
+    dnn3_rs_kernel<H1, H2, WPC, MBG, MSPLIT, W1L><<<ctx->num_cus * WPC, 256 * MSPLIT, lds, ctx->stream>>>(b);
+    uint64_t hcyc[128];
+    hipMemcpy(hcyc, dbg, sizeof hcyc, hipMemcpyDeviceToHost);
+    static int calls = 0;
+    if (++calls % 40 == 3)
+        for (int wv = 0; wv < 8; ++wv) {
+            fprintf(stderr, "rs<%d,%d> wg %d wave %d:", H1, H2, wv / 4, wv % 4);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %8llu", (unsigned long long)hcyc[wv * 8 + i]);
+            fprintf(stderr, "\n");
+        }
+#else
+    dnn3_rs_kernel<H1, H2, WPC, MBG, MSPLIT, W1L><<<ctx->num_cus * WPC, 256 * MSPLIT, lds, ctx->stream>>>(a);
+#endif
     return PG_OK;
 }
 
@@ -228,9 +288,9 @@ bool dnn3_rs_shape(uint32_t h1, uint32_t h2) {
 }
 
 int launch_dnn3_rs(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a) {
-    if (h1 == 128 && h2 == 128) return launch_rs<128, 128>(ctx, a);
-    if (h1 == 256 && h2 == 128) return launch_rs<256, 128>(ctx, a);
-    if (h1 == 256 && h2 == 256) return launch_rs<256, 256>(ctx, a);
+    if (h1 == 128 && h2 == 128) return launch_rs<128, 128, 2, 2, 1, false>(ctx, a);
+    if (h1 == 256 && h2 == 128) return launch_rs<256, 128, 2, 1, 1, false>(ctx, a);
+    if (h1 == 256 && h2 == 256) return launch_rs<256, 256, 1, 1, 2, true>(ctx, a);
     set_error("rank: no register-stationary kernel for hidden widths %u-%u", h1, h2);
     return PG_ERR_UNSUPPORTED;
 }
