@@ -892,6 +892,7 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     const bool ws = m->prec && !no_ws && m->h1 == 512 && m->h2 == 256 && t->dim == 128;
     // the small shapes, gather-bound: the whole model in registers (rank_rs.hip)
     const bool rs_k = m->prec && !no_ws && t->dim == 128 && dnn3_rs_shape(m->h1, m->h2);
+    const bool ls_k = m->prec && !no_ws && t->dim == 128 && dnn3_ls_shape(m->h1, m->h2);
     const uint32_t grid128 = n_items / kBM + n_req;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     if ((rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, ws || rs_k ? (uint32_t)kWsItems : (uint32_t)kBM, rs.tile_req, rs.tile_item0,
@@ -922,6 +923,8 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
         if ((rc = launch_dnn3_ws(ctx, a))) return rc;
     } else if (rs_k) {
         if ((rc = launch_dnn3_rs(ctx, m->h1, m->h2, a))) return rc;
+    } else if (ls_k) {
+        if ((rc = launch_dnn3_ls(ctx, m->h1, m->h2, a))) return rc;
     } else if ((rc = dispatch_dnn3_mlp(ctx, m, a, grid128))) {
         return rc;
     }

@@ -139,5 +139,8 @@ int launch_dnn3_ws(pg_ctx* ctx, const MlpArgs& a);
 // rank_rs.hip: the register-stationary DNN3 kernel (bf16) for the small hidden shapes; 64-item tiles as well
 bool dnn3_rs_shape(uint32_t h1, uint32_t h2);
 int launch_dnn3_rs(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
+// ... and the eight-wave streamed-weights kernel for 1024-512; 128-item tiles
+bool dnn3_ls_shape(uint32_t h1, uint32_t h2);
+int launch_dnn3_ls(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
 
 }  // namespace pg

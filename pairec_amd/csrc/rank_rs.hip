@@ -283,6 +283,194 @@ static int launch_rs(pg_ctx* ctx, const MlpArgs& a) {
     return PG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// dnn3_ls_kernel<H1, H2>: DNN3 in bf16 for the LARGE hidden shape (1024-512), weights streamed.
+// W1 (256 KB) + W2 (1 MB) fit neither the CU's registers nor its LDS, so they stream from L2 — once per 128-item tile
+// (12.5 GB per 1.28 M items chip-wide; a 64-item tile would double that and be L2-bound).  The fp32 layer-2 accumulators
+// of 128 items x 512 columns are 256 KB, half the register file, which is why mlp_kernel ran this shape with four waves
+// of 256 accumulator registers, one per SIMD, every weight-fragment load exposed (wave wait 64 %, MFMA busy 22 %).
+// Here EIGHT waves (two per SIMD, 256 registers each) share a tile: wave w owns output columns 64w..64w+63 of layer 2
+// for all 128 items (128 accumulator registers).  Layer 1 runs in chunks of 64 hidden columns: wave w computes the
+// 32 x 32 block (item block w & 3, column block w >> 2) of the chunk, relu → bf16 → a double-buffered 16-KB LDS tile;
+// one barrier per chunk; layer 2 then adds the chunk's 64-deep partial product.  Weight fragments go global → registers
+// (each is used by exactly one wave), single-buffered but re-requested as soon as their last MFMA has issued: layer 1's
+// eight fragments of the next chunk right after this chunk's layer-1 MFMAs, layer 2's in two halves (k-steps 0-1, 2-3),
+// so that every load has half a chunk of the other wave's MFMAs to arrive.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLsItems = 128;
+template <int H1, int H2>
+constexpr size_t ls_lds_bytes() {
+    return (size_t)kLsItems * kDIN * 2 + 2 * (size_t)kLsItems * 64 * 2 + (size_t)(H1 + 2 * H2 + 16 * kLsItems) * 4;
+}
+
+template <int H1, int H2>
+__global__ __launch_bounds__(512, 1) void dnn3_ls_kernel(MlpArgs a) {
+    constexpr int M = kLsItems, CH = 64, NCH = H1 / CH, KS1 = kDIN / 16, KS2 = H1 / 16, KSC = CH / 16;
+    static_assert(H2 == 512, "eight waves x 64 output columns");
+    constexpr int XT_B = M * kDIN * 2, H1C_B = M * CH * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const XT = smem;
+    char* const H1C = smem + XT_B;
+    float* const c1s = reinterpret_cast<float*>(smem + XT_B + 2 * H1C_B);
+    float* const b2s = c1s + H1;
+    float* const w3s = b2s + H2;
+    float* const hps = w3s + H2;                           // head partials [16 slots][128 items]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n_tiles = *a.n_tiles;
+    const uint32_t t_begin = (uint32_t)(((uint64_t)n_tiles * blockIdx.x) / gridDim.x);
+    const uint32_t t_end = (uint32_t)(((uint64_t)n_tiles * (blockIdx.x + 1)) / gridDim.x);
+    if (t_begin >= t_end) return;
+    for (int i = tid; i < H2; i += 512) {
+        w3s[i] = a.w3[i];
+        b2s[i] = a.b2[i];
+    }
+    const char* const w1base = reinterpret_cast<const char*>(a.w1p);
+    const char* const w2base = reinterpret_cast<const char*>(a.w2p) + (size_t)(wave * 2) * KS2 * 1024;
+    const int mb1 = wave & 3, nb1 = wave >> 2;
+    uint32_t c1_req = 0xffffffffu;
+
+    for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+        const uint32_t req = a.tile_req[tile], item0 = a.tile_item0[tile], cnt = a.tile_cnt[tile];
+        uint32_t tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int lane = tid_o & 63, i32 = tid_o & 31, h = (tid_o >> 5) & 1;
+        // ---- gather: 4 adjacent lanes per item, 64 contiguous bytes per instruction
+        {
+            const uint32_t g_item = tid_o >> 2, g_l = tid_o & 3;
+            uint32_t row = a.cand_rows[item0 + (g_item < cnt ? g_item : cnt - 1)];
+            row = row < a.tab_rows ? row : a.tab_rows - 1;
+            const float4* src = reinterpret_cast<const float4*>(a.tab + (size_t)row * kDIN) + g_l;
+            float4 xq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xq[j] = src[4 * j];
+            if (req != c1_req) {
+                c1_req = req;
+                for (int i = tid_o; i < H1; i += 512) c1s[i] = a.c1[(size_t)req * a.c1_stride + i];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) store_x_quad<1>(XT, g_item, 4 * j + g_l, xq[j]);
+        }
+        // ---- the first chunk's weight fragments
+        bf16x8 w1f[KS1], w2f[2][KSC];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+            w1f[ks] = *reinterpret_cast<const bf16x8*>(w1base + (size_t)(nb1 * KS1 + ks) * 1024 + lane * 16);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks)
+                w2f[nb][ks] = *reinterpret_cast<const bf16x8*>(w2base + (size_t)(nb * KS2 + ks) * 1024 + lane * 16);
+        f32x16 acc2[4][2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(b2s + (wave * 2 + nb) * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    acc2[mb][nb][4 * g + 0] = bv.x;
+                    acc2[mb][nb][4 * g + 1] = bv.y;
+                    acc2[mb][nb][4 * g + 2] = bv.z;
+                    acc2[mb][nb][4 * g + 3] = bv.w;
+                }
+            }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            char* const h1c = H1C + (c & 1) * H1C_B;
+            const int cn = c + 1 < NCH ? c + 1 : c;        // the last chunk re-requests its own fragments (unused)
+            // ---- layer 1: block (mb1, nb1) of the chunk's 128 x 64
+            {
+                f32x16 acc1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 cv = *reinterpret_cast<const float4*>(c1s + c * CH + nb1 * 32 + 8 * g + 4 * h);
+                    acc1[4 * g + 0] = cv.x;
+                    acc1[4 * g + 1] = cv.y;
+                    acc1[4 * g + 2] = cv.z;
+                    acc1[4 * g + 3] = cv.w;
+                }
+                const char* const xr = XT + (mb1 * 32 + i32) * 256;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(xr + (((ks * 2 + h) ^ (i32 & 15)) << 4));
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ks], af, acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks)
+                    w1f[ks] = *reinterpret_cast<const bf16x8*>(w1base + (size_t)((cn * 2 + nb1) * KS1 + ks) * 1024 + lane * 16);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    store_h_quad<1, CH>(h1c, mb1 * 32 + i32, nb1 * 32 + 8 * g + 4 * h, fmaxf(acc1[4 * g + 0], 0.0f),
+                                        fmaxf(acc1[4 * g + 1], 0.0f), fmaxf(acc1[4 * g + 2], 0.0f), fmaxf(acc1[4 * g + 3], 0.0f));
+            }
+            __syncthreads();
+            // ---- layer 2: += H1 chunk (128 x 64) · W2[c*64 .. +64][64w .. +64]
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) {
+                bf16x8 af[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    af[mb] = *reinterpret_cast<const bf16x8*>(h1c + (mb * 32 + i32) * (CH * 2) + (((ks * 2 + h) ^ (i32 & 7)) << 4));
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[nb][ks], af[mb], acc2[mb][nb], 0, 0, 0);
+                if (ks == 1 || ks == 3) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int k2 = ks - 1; k2 <= ks; ++k2)
+                            w2f[nb][k2] = *reinterpret_cast<const bf16x8*>(w2base + (size_t)(nb * KS2 + cn * KSC + k2) * 1024 + lane * 16);
+                }
+            }
+        }
+
+        // ---- relu → dot head from the accumulators; 16 partials per item (wave, h), summed in slot order
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            float p = 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 wv = *reinterpret_cast<const float4*>(w3s + (wave * 2 + nb) * 32 + 8 * g + 4 * h);
+                    p = __fmaf_rn(fmaxf(acc2[mb][nb][4 * g + 0], 0.0f), wv.x, p);
+                    p = __fmaf_rn(fmaxf(acc2[mb][nb][4 * g + 1], 0.0f), wv.y, p);
+                    p = __fmaf_rn(fmaxf(acc2[mb][nb][4 * g + 2], 0.0f), wv.z, p);
+                    p = __fmaf_rn(fmaxf(acc2[mb][nb][4 * g + 3], 0.0f), wv.w, p);
+                }
+            hps[(wave * 2 + h) * M + mb * 32 + i32] = p;
+        }
+        __syncthreads();
+        if (tid_o < (uint32_t)M && tid_o < cnt) {
+            float z = a.b3;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) z += hps[s * M + tid_o];
+            a.out[item0 + tid_o] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+}
+
+template <int H1, int H2>
+static int launch_ls(pg_ctx* ctx, const MlpArgs& a) {
+    constexpr size_t lds = ls_lds_bytes<H1, H2>();
+    int rc;
+    if ((rc = ensure_dyn_lds(ctx, (const void*)dnn3_ls_kernel<H1, H2>, lds))) return rc;
+    dnn3_ls_kernel<H1, H2><<<ctx->num_cus, 512, lds, ctx->stream>>>(a);
+    return PG_OK;
+}
+
+bool dnn3_ls_shape(uint32_t h1, uint32_t h2) { return h1 == 1024 && h2 == 512; }
+int launch_dnn3_ls(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a) {
+    if (h1 == 1024 && h2 == 512) return launch_ls<1024, 512>(ctx, a);
+    set_error("rank: no streamed-weights kernel for hidden widths %u-%u", h1, h2);
+    return PG_ERR_UNSUPPORTED;
+}
+
 bool dnn3_rs_shape(uint32_t h1, uint32_t h2) {
     return (h1 == 128 && h2 == 128) || (h1 == 256 && h2 == 128) || (h1 == 256 && h2 == 256);
 }
