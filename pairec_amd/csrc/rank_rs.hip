@@ -24,6 +24,13 @@ constexpr size_t rs_lds_bytes() {
     return (size_t)kWsItems * (kDIN + H1) * 2 + (size_t)(H1 + 2 * H2 + 8 * kWsItems) * 4 + (W1L ? (size_t)kDIN * H1 * 2 : 0);
 }
 
+// make WS_EXTRA=-DPG_RS_PROFILE: per-phase cycle counts of the first workgroups (developer aid)
+#ifdef PG_RS_PROFILE
+#define RS_MARK(i) { const uint64_t tn = __builtin_readcyclecounter(); ph[i] += tn - tp; tp = tn; }
+#else
+#define RS_MARK(i)
+#endif
+
 struct RsTile {
     uint32_t req, item0, cnt;
 };
@@ -111,9 +118,6 @@ __global__ __launch_bounds__(256 * MSPLIT, WPC) void dnn3_rs_kernel(MlpArgs a) {
 
 #ifdef PG_RS_PROFILE
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_readcyclecounter();
-#define RS_MARK(i) { const uint64_t tn = __builtin_readcyclecounter(); ph[i] += tn - tp; tp = tn; }
-#else
-#define RS_MARK(i)
 #endif
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
         const RsTile d3 = load_desc(tile + 3);
@@ -297,7 +301,23 @@ static int launch_rs(pg_ctx* ctx, const MlpArgs& a) {
 // eight fragments of the next chunk right after this chunk's layer-1 MFMAs, layer 2's in two halves (k-steps 0-1, 2-3),
 // so that every load has half a chunk of the other wave's MFMAs to arrive.
 // ---------------------------------------------------------------------------------------------
+#define LS_MFMA(acc, b, x) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(b), "v"(x))
+#define LS_MFMA_READY(a0, a1) asm volatile("s_nop 3" : "+v"(a0), "+v"(a1))
+#define LS_MFMA_DONE(a0, a1) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a0), "+v"(a1))
 constexpr int kLsItems = 128;
+// A 64-column bf16 operand tile has 128-B rows: two rows share the LDS's 256-B bank window, so the quad swizzle is keyed
+// by (row >> 1) & 7 — rows of one parity then take eight different quads and 16 consecutive rows cover the window exactly
+// (keyed by row & 7, as the shared store_h_quad does, rows r and r + 8 collide: every A-fragment read was 2-way
+// conflicted, SQ_LDS_BANK_CONFLICT = 37 % of the LDS cycles of this kernel)
+__device__ __forceinline__ void ls_store_h_quad(char* tile, int row, int col, float v0, float v1, float v2, float v3) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 lo = {v0, v1}, hi = {v2, v3};
+    uint2 p;
+    p.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
+    p.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
+    *reinterpret_cast<uint2*>(tile + row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + (col & 7) * 2) = p;
+}
 template <int H1, int H2>
 constexpr size_t ls_lds_bytes() {
     return (size_t)kLsItems * kDIN * 2 + 2 * (size_t)kLsItems * 64 * 2 + (size_t)(H1 + 2 * H2 + 16 * kLsItems) * 4;
@@ -330,11 +350,15 @@ __global__ __launch_bounds__(512, 1) void dnn3_ls_kernel(MlpArgs a) {
     const int mb1 = wave & 3, nb1 = wave >> 2;
     uint32_t c1_req = 0xffffffffu;
 
+#ifdef PG_RS_PROFILE
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_readcyclecounter();
+#endif
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
         const uint32_t req = a.tile_req[tile], item0 = a.tile_item0[tile], cnt = a.tile_cnt[tile];
         uint32_t tid_o = tid;
         asm volatile("" : "+v"(tid_o));
-        const int lane = tid_o & 63, i32 = tid_o & 31, h = (tid_o >> 5) & 1;
+        const int i32 = tid_o & 31, h = (tid_o >> 5) & 1;
+        const uint32_t lane_off = (tid_o & 63) * 16;       // unsigned: the loads then take the SGPR-base + 32-bit-offset form
         // ---- gather: 4 adjacent lanes per item, 64 contiguous bytes per instruction
         {
             const uint32_t g_item = tid_o >> 2, g_l = tid_o & 3;
@@ -355,12 +379,7 @@ __global__ __launch_bounds__(512, 1) void dnn3_ls_kernel(MlpArgs a) {
         bf16x8 w1f[KS1], w2f[2][KSC];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks)
-            w1f[ks] = *reinterpret_cast<const bf16x8*>(w1base + (size_t)(nb1 * KS1 + ks) * 1024 + lane * 16);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int ks = 0; ks < KSC; ++ks)
-                w2f[nb][ks] = *reinterpret_cast<const bf16x8*>(w2base + (size_t)(nb * KS2 + ks) * 1024 + lane * 16);
+            w1f[ks] = *reinterpret_cast<const bf16x8*>(w1base + (size_t)(nb1 * KS1 + ks) * 1024 + lane_off);
         f32x16 acc2[4][2];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
@@ -375,61 +394,117 @@ __global__ __launch_bounds__(512, 1) void dnn3_ls_kernel(MlpArgs a) {
                     acc2[mb][nb][4 * g + 3] = bv.w;
                 }
             }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) LS_MFMA_READY(acc2[mb][0], acc2[mb][1]);
+        RS_MARK(0)
         __syncthreads();
+        RS_MARK(1)
 
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            char* const h1c = H1C + (c & 1) * H1C_B;
-            const int cn = c + 1 < NCH ? c + 1 : c;        // the last chunk re-requests its own fragments (unused)
-            // ---- layer 1: block (mb1, nb1) of the chunk's 128 x 64
-            {
-                f32x16 acc1;
+        // layer 1 of chunk `cl` → H1 buffer `buf`; then its fragments are re-requested for chunk cl + 1
+        auto layer1 = [&](int cl, int buf) {
+            f32x16 acc1;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 cv = *reinterpret_cast<const float4*>(c1s + c * CH + nb1 * 32 + 8 * g + 4 * h);
-                    acc1[4 * g + 0] = cv.x;
-                    acc1[4 * g + 1] = cv.y;
-                    acc1[4 * g + 2] = cv.z;
-                    acc1[4 * g + 3] = cv.w;
-                }
-                const char* const xr = XT + (mb1 * 32 + i32) * 256;
-#pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(xr + (((ks * 2 + h) ^ (i32 & 15)) << 4));
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ks], af, acc1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int ks = 0; ks < KS1; ++ks)
-                    w1f[ks] = *reinterpret_cast<const bf16x8*>(w1base + (size_t)((cn * 2 + nb1) * KS1 + ks) * 1024 + lane * 16);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    store_h_quad<1, CH>(h1c, mb1 * 32 + i32, nb1 * 32 + 8 * g + 4 * h, fmaxf(acc1[4 * g + 0], 0.0f),
-                                        fmaxf(acc1[4 * g + 1], 0.0f), fmaxf(acc1[4 * g + 2], 0.0f), fmaxf(acc1[4 * g + 3], 0.0f));
+            for (int g = 0; g < 4; ++g) {
+                const float4 cv = *reinterpret_cast<const float4*>(c1s + cl * CH + nb1 * 32 + 8 * g + 4 * h);
+                acc1[4 * g + 0] = cv.x;
+                acc1[4 * g + 1] = cv.y;
+                acc1[4 * g + 2] = cv.z;
+                acc1[4 * g + 3] = cv.w;
             }
-            __syncthreads();
-            // ---- layer 2: += H1 chunk (128 x 64) · W2[c*64 .. +64][64w .. +64]
+            const char* const xr = XT + (mb1 * 32 + i32) * 256;
 #pragma unroll
-            for (int ks = 0; ks < KSC; ++ks) {
-                bf16x8 af[4];
+            for (int ks = 0; ks < KS1; ++ks) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(xr + (((ks * 2 + h) ^ (i32 & 15)) << 4));
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ks], af, acc1, 0, 0, 0);
+            }
+            const int cn = cl + 1 < NCH ? cl + 1 : cl;     // the last chunk re-requests its own fragments (unused)
+            // (wave-uniform part of the address through readfirstlane: SGPR base + 32-bit lane offset, no 64-bit VGPR adds)
+            const char* const w1n = w1base + (uint32_t)__builtin_amdgcn_readfirstlane((cn * 2 + nb1) * KS1 * 1024);
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-                    af[mb] = *reinterpret_cast<const bf16x8*>(h1c + (mb * 32 + i32) * (CH * 2) + (((ks * 2 + h) ^ (i32 & 7)) << 4));
+            for (int ks = 0; ks < KS1; ++ks) w1f[ks] = *reinterpret_cast<const bf16x8*>(w1n + ks * 1024 + lane_off);
+            char* const h1c = H1C + buf * H1C_B;
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
+            for (int g = 0; g < 4; ++g)
+                ls_store_h_quad(h1c, mb1 * 32 + i32, nb1 * 32 + 8 * g + 4 * h, fmaxf(acc1[4 * g + 0], 0.0f),
+                                fmaxf(acc1[4 * g + 1], 0.0f), fmaxf(acc1[4 * g + 2], 0.0f), fmaxf(acc1[4 * g + 3], 0.0f));
+        };
+        // layer 2 of chunk c: += H1 chunk (128 x 64) · W2[c*64 .. +64][64w .. +64]; its fragments are re-requested for
+        // chunk cn in two halves.  The MFMAs are volatile asm (as in dnn3_ws_kernel): their order, and that of the LDS
+        // reads written between them, is then the source order — A fragments three ahead (six MFMAs = 190 cycles) in four
+        // rotating buffers.  Left to the scheduler this became read → s_waitcnt lgkmcnt(0) → two MFMAs, sixteen times.
+        auto layer2 = [&](int c, int cn) {
+            const char* const h1c = H1C + (c & 1) * H1C_B;
+            const char* const w2n = w2base + (uint32_t)__builtin_amdgcn_readfirstlane(cn * KSC * 1024);
+            bf16x8 af[4];
+            auto frag = [&](int f) {                       // fragment f = (k-step f / 4, item block f % 4)
+                return *reinterpret_cast<const bf16x8*>(h1c + ((f & 3) * 32 + i32) * (CH * 2) +
+                                                        ((((f >> 2) * 2 + h) ^ ((i32 >> 1) & 7)) << 4));
+            };
+            af[0] = frag(0);
+            af[1] = frag(1);
+            af[2] = frag(2);
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        acc2[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[nb][ks], af[mb], acc2[mb][nb], 0, 0, 0);
-                if (ks == 1 || ks == 3) {
+            for (int f = 0; f < 4 * KSC; ++f) {
+                const int ks = f >> 2, mb = f & 3;
+                if (f + 3 < 4 * KSC) af[(f + 3) & 3] = frag(f + 3);
+                LS_MFMA(acc2[mb][0], w2f[0][ks], af[f & 3]);
+                LS_MFMA(acc2[mb][1], w2f[1][ks], af[f & 3]);
+                if ((ks == 1 || ks == 3) && mb == 3) {
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                         for (int k2 = ks - 1; k2 <= ks; ++k2)
-                            w2f[nb][k2] = *reinterpret_cast<const bf16x8*>(w2base + (size_t)(nb * KS2 + cn * KSC + k2) * 1024 + lane * 16);
+                            w2f[nb][k2] = *reinterpret_cast<const bf16x8*>(w2n + (nb * KS2 + k2) * 1024 + lane_off);
                 }
             }
+        };
+        auto first_w2f = [&]() {
+#pragma unroll
+            for (int kh = 0; kh < KSC; kh += 2)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int k2 = kh; k2 < kh + 2; ++k2)
+                        w2f[nb][k2] = *reinterpret_cast<const bf16x8*>(w2base + (size_t)(nb * KS2 + k2) * 1024 + lane_off);
+        };
+        // Between two barriers a wave runs layer 1 of one chunk and layer 2 of another, and the two waves of a SIMD (w and
+        // w + 4) are HALF AN INTERVAL APART: layer 1 is a chain of 8 dependent MFMAs between LDS reads, relu and stores
+        // — latency, 1 300-2 000 cycles by itself — while layer 2 is 32 back-to-back MFMAs; in step, both waves idled the
+        // matrix pipe together and then competed for it (PG_RS_PROFILE: 5 000 cycles per chunk for 2 600 of MFMA work).
+        //   waves 0-3:  L1(0) b0 | L1(1) L2(0) b1 | L1(2) L2(1) b2 | …
+        //   waves 4-7:  L1(0) b0 L2(0) | L1(1) b1 L2(1) | L1(2) b2 L2(2) | …
+        // ONE code path (the same loop body, the barrier before or after its layer 2): L2(k) runs behind b_k, by which
+        // every wave has written L1(k); L1(k + 2) overwrites the buffer L2(k) read only behind b_(k+1).  Two code paths
+        // cost 261 spilled registers.  The first chunk's fragments are requested in the order the loop re-requests them —
+        // the waitcnt pass merges the pending loads of the loop's entry and back edges, and where the orders differ, or a
+        // path skips a group (hence waves 0-3 redo the last chunk's layer 1 into the idle buffer), it falls back to
+        // counts that wait for loads issued moments ago: vmcnt(7) in front of the first MFMA of every chunk.
+        const int ahead = wave >> 2;                       // waves 4-7 run layer 2 half an interval ahead
+        layer1(0, 0);
+        first_w2f();
+        RS_MARK(2)
+        __syncthreads();
+        RS_MARK(3)
+        if (ahead) layer2(0, 1);
+        const int n_it = NCH - ahead;
+#pragma unroll 1
+        for (int c = 0; c < n_it; ++c) {
+            const int c1 = c + 1 < NCH ? c + 1 : c;        // layer 1's chunk
+            const int c2 = c + ahead;                      // layer 2's chunk
+            layer1(c1, (c + 1) & 1);
+            RS_MARK(2)
+            if (ahead) __syncthreads();
+            RS_MARK(3)
+            layer2(c2, c2 + 1 < NCH ? c2 + 1 : c2);
+            RS_MARK(4)
+            if (!ahead) __syncthreads();
+            RS_MARK(3)
         }
+        if (ahead) __syncthreads();
 
         // ---- relu → dot head from the accumulators; 16 partials per item (wave, h), summed in slot order
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) LS_MFMA_DONE(acc2[mb][0], acc2[mb][1]);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             float p = 0.0f;
@@ -452,7 +527,14 @@ __global__ __launch_bounds__(512, 1) void dnn3_ls_kernel(MlpArgs a) {
             for (int s = 0; s < 16; ++s) z += hps[s * M + tid_o];
             a.out[item0 + tid_o] = 1.0f / (1.0f + expf(-z));
         }
+        RS_MARK(5)
     }
+#ifdef PG_RS_PROFILE
+    if ((tid & 63) == 0 && blockIdx.x < 2) {
+        uint64_t* o = (uint64_t*)(a.field_emb) + (blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = ph[i];
+    }
+#endif
 }
 
 template <int H1, int H2>
@@ -460,7 +542,24 @@ static int launch_ls(pg_ctx* ctx, const MlpArgs& a) {
     constexpr size_t lds = ls_lds_bytes<H1, H2>();
     int rc;
     if ((rc = ensure_dyn_lds(ctx, (const void*)dnn3_ls_kernel<H1, H2>, lds))) return rc;
+#ifdef PG_RS_PROFILE
+    static uint64_t* dbg = nullptr;
+    if (!dbg) hipMalloc(&dbg, 2 * 8 * 8 * 8);
+    MlpArgs b = a;
+    b.field_emb = reinterpret_cast<const float* const*>(dbg);
+    dnn3_ls_kernel<H1, H2><<<ctx->num_cus, 512, lds, ctx->stream>>>(b);
+    uint64_t hcyc[128];
+    hipMemcpy(hcyc, dbg, sizeof hcyc, hipMemcpyDeviceToHost);
+    static int calls = 0;
+    if (++calls == 43)
+        for (int wv = 0; wv < 16; ++wv) {
+            fprintf(stderr, "ls<%d,%d> wg %d wave %d:", H1, H2, wv / 8, wv % 8);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %8llu", (unsigned long long)hcyc[wv * 8 + i]);
+            fprintf(stderr, "\n");
+        }
+#else
     dnn3_ls_kernel<H1, H2><<<ctx->num_cus, 512, lds, ctx->stream>>>(a);
+#endif
     return PG_OK;
 }
 

@@ -28,7 +28,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     for p in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(p)):
             kn = row.get("Kernel_Name", "?")
-            if "dnn3_rs_kernel" in kn or "dnn3_ws_kernel" in kn or "mlp_kernel" in kn:
+            if "dnn3_rs_kernel" in kn or "dnn3_ws_kernel" in kn or "dnn3_ls_kernel" in kn or "mlp_kernel" in kn:
                 k = (kn[:70], row.get("Counter_Name", "?"))
                 agg[k][0] += float(row.get("Counter_Value", 0) or 0); agg[k][1] += 1
 lines.append("== PMC (average per dispatch)")
@@ -41,7 +41,7 @@ res = {"_how": "rocprofv3 --pmc <group> -- python3 scripts/dev_rank_shapes.py 10
                "fetch_bytes = FETCH_SIZE (KB) x 1024 x 2 (gfx950 reports half the bytes of 16 B/lane reads, MI355X_MICROARCH.md); "
                "1.28 M items = 655 MB of table rows"}
 def shape_of(kn):
-    m = re.search(r"dnn3_rs_kernel<(\d+), (\d+)", kn)
+    m = re.search(r"dnn3_[rl]s_kernel<(\d+), (\d+)", kn)
     if m: return "%s-%s" % (m.group(1), m.group(2))
     if "dnn3_ws_kernel" in kn: return "512-256"
     m = re.search(r"mlp_kernel<1, (\d+), (\d+)", kn)
