@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--calibrate", type=int, default=10,
+                    help="untimed batches served before the warm-up steps, like the shadow build: the table's threshold "
+                         "model (DESIGN.md 4.1e) starts predicting once it has observed 1024 verified queries of one K")
     ap.add_argument("--rows", type=int, default=100_000_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=5000)
@@ -71,7 +74,7 @@ def parse_args():
     ap.add_argument("--callers-seconds", type=float, default=4.0)
     ap.add_argument("--page", type=int, default=100, help="entries each concurrent caller asks for (ctx.Size)")
     ap.add_argument("--latency-reqs", type=int, default=200,
-                    help="single-request latency samples at N=1 (the first 10 % are discarded as warm-up, SURVEY.md 8d)")
+                    help="single-request latency samples at N=1 (the first 10 %% are discarded as warm-up, SURVEY.md 8d)")
     return ap.parse_args()
 
 
@@ -755,7 +758,18 @@ def main():
             if world > 1:
                 dist.barrier()
                 torch.cuda.synchronize()
+        if args.calibrate > 0:
+            # service start-up, like the shadow build above: the first batches run on the pilot plan and teach the table's
+            # threshold model (other users than the measured ones)
+            import copy
+            a0 = copy.copy(args)
+            a0.warmup, a0.steps = args.calibrate, 0
+            d_cal = [ctx.to_device(make_queries(o, 100_000 + s * world + rank, R, args.dim)) for s in range(args.calibrate)]
+            run_headline(pa, ctx, table, model, expr, d_cal, a0, R, K, sync, extra_ctxs)
+            del d_cal
+        predicted0 = sum(c_.stats().recall_predicted for c_ in [ctx] + extra_ctxs)
         pipe, elapsed, scan_ms = run_headline(pa, ctx, table, model, expr, d_qs, args, R, K, sync, extra_ctxs)
+        predicted_batches = sum(c_.stats().recall_predicted for c_ in [ctx] + extra_ctxs) - predicted0
         if extra_ctxs:
             # the roofline figure is a per-kernel property: with batches overlapping on two streams a kernel's event-timed
             # duration includes the other stream's work, so the scan-stage time is measured in a short un-overlapped leg
@@ -810,6 +824,8 @@ def main():
                    "requests_per_step": R, "candidates_per_request": K, "table_rows": args.rows,
                    "dim": args.dim, "table_dist": args.table_dist, "batches_in_flight": 2 if not shard else 1,
                    "contexts": args.contexts,
+                   "calibration_batches": 0 if shard else args.calibrate,
+                   "timed_batches_on_predicted_thresholds": None if shard else int(predicted_batches),
                    "parallelism": ("table row-range shards x%d (%d rows total), all_gather top-K merge + all_reduce scores + DPP top-500"
                                    % (world, args.rows * world)) if shard else
                                   ("request-parallel x%d, table replicated per GPU, no data-path collective" % world
@@ -871,6 +887,10 @@ def main():
         other = "gaussian" if args.table_dist == "uniform" else "uniform"
         fill(other)
         table.screen_info()
+        if args.calibrate > 0:
+            d_cal = [ctx.to_device(make_queries(o, 100_000 + s * world + rank, R, args.dim)) for s in range(args.calibrate)]
+            run_headline(pa, ctx, table, model, expr, d_cal, a0, R, K, sync, extra_ctxs)
+            del d_cal
         _, el2, scan2 = run_headline(pa, ctx, table, model, expr, d_qs, args, R, K, sync, extra_ctxs)
         if extra_ctxs:
             _, _, scan2 = run_headline(pa, ctx, table, model, expr, d_qs, a1, R, K, sync)

@@ -402,7 +402,36 @@ struct ScreenArgs {
     // bf16 only: the bound is relative to the row's norm — eps = eps_unit[q] x (largest row norm of the 32-row block)
     const float* blk_norm2;   // [blocks] largest row norm^2 per physical 32-row block (pg_table::dnorm2)
     const float* eps_unit;    // [256] 0.008 ||q|| (inflated); thr_screen then carries thr itself (or -inf)
+    // query halves (int8, > 128 queries): hit records instead of staged (row, query) pairs — see kRecBytes
+    char* rec;                // [waves][rec_cap] records of kRecBytes: one region per wave of the launch
+    uint32_t* rec_cnt;        // [waves] records in each region (zeroed per launch); [waves]: records in the spill pool
+    uint32_t rec_cap;
+    char* rec_pool;           // [rec_pool_cap] records: where a wave whose region is full puts its staged records
+    uint32_t rec_pool_cap, rec_waves;
+    uint32_t early_share;     // 8-wave variants: share (x 1024) of a SIMD's blocks that goes to its older wave; 512 = even
+#ifdef PG_SCREEN_PROFILE
+    unsigned long long* prof; // [waves][8]
+#endif
 };
+
+// Hit records (query halves).  A 32-row x 32-query tile with a suspect in it has, as a rule, exactly one: one lane, one of
+// its 16 accumulators.  Finding the register inside the scan kernel — 16 compare / add-with-carry pairs and a staging
+// loop, issued for the whole wave on behalf of that one lane — cost about as many VALU slots as the reject test itself.
+// Instead the lane parks its 16 accumulators as they are (64 B) with a tag (first row of the block; query column and
+// lane half) in the wave's LDS staging area and moves on: five LDS writes under the hit lanes' exec mask.  Every
+// kRecStage records the area is copied to the wave's region of a global record buffer (plain coalesced stores, no
+// atomics, no wait: the stores add to vmcnt, which only makes the ring's counted waits conservative for a moment —
+// loads return in order among themselves).  screen_decode_kernel then does the compares with one record per lane — all
+// 64 lanes busy — and fills the per-query suspect lists that rescore_kernel reads.  (Stores straight from the hit path,
+// without the LDS stage, were measured: 4.35 vs 3.1 ms per pass — with stores in flight in every second block the
+// counted waits over-wait all the time and the ring runs one piece deep.)
+constexpr uint32_t kRecBytes = 80;
+// make SCAN_EXTRA=-DPG_SCREEN_PROFILE: per-phase cycle counts of the query-halves loop, printed by launch_screen (developer aid)
+#ifdef PG_SCREEN_PROFILE
+#define SP_MARK(i) { const uint64_t tn = __builtin_readcyclecounter(); sp[i] += tn - sp_t; sp_t = tn; }
+#else
+#define SP_MARK(i)
+#endif
 
 // NQB query blocks of 32; WAVES waves per workgroup.  <=128 queries: 8 waves (2 per SIMD), ring of 4
 // pieces per wave; 256 queries: the 256 B-operand registers leave room for one wave per SIMD only, so
@@ -505,10 +534,30 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     const int rd_rot = (i32 >> 1) * 16;
 
     const uint32_t total = a.rb_end - a.rb_begin;
-    const uint32_t bpw = (total + W - 1) / W;
-    const uint32_t first = gw * bpw;
-    const uint32_t nblk = first < total ? (total - first < bpw ? total - first : bpw) : 0;
-    if (nblk == 0) return;
+    uint32_t first, nblk;
+    if (WAVES == 8 && SPLIT == 1 && a.early_share != 512) {
+        // Two waves per SIMD (w and w + 4), and the SIMD's arbiter favours the older one: per-phase cycle counts of the
+        // 256-query kernel had waves 0-3 finish an equal share in 78 % of the time of waves 4-7, which then ran the last fifth
+        // of the launch alone — one wave per SIMD, nothing to overlap with.  So the pair's run of blocks is split unevenly
+        // (early_share / 1024 of it to the early wave) and both finish together.
+        const uint32_t P = gridDim.x * 4;
+        const uint32_t pb = (total + P - 1) / P;
+        const uint32_t pbase = (blockIdx.x * 4 + (wave & 3)) * pb;
+        const uint32_t pend = pbase + pb < total ? pbase + pb : total;
+        uint32_t cut = pbase + (uint32_t)(((uint64_t)pb * a.early_share + 512) >> 10);
+        if (cut > pend) cut = pend;
+        first = wave < 4 ? pbase : cut;
+        const uint32_t last = wave < 4 ? cut : pend;
+        nblk = first < last ? last - first : 0;
+    } else {
+        const uint32_t bpw = (total + W - 1) / W;
+        first = gw * bpw;
+        nblk = first < total ? (total - first < bpw ? total - first : bpw) : 0;
+    }
+    if (nblk == 0) {
+        if (QH > 1 && lane == 0) a.rec_cnt[gw_raw] = 0;
+        return;
+    }
 
     // Physical table block of each logical block this wave walks, kept D blocks ahead of the one being
     // scored (the DMA ring runs NS-1 pieces ahead).  Incremental: slot += mul (mod n_slots) per block
@@ -596,8 +645,39 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     }
 
     if constexpr (QH > 1) {
+        // hit records: staged in LDS (the area the other variants stage (row, query) pairs in), flushed to this wave's region
+        constexpr uint32_t kRecStage = (uint32_t)kStageBytesW / kRecBytes;
+        char* const rec_lds = smem + kScanLdsRing + wave * kStageBytesW;
+        char* const rec_glb = a.rec + (size_t)gw_raw * a.rec_cap * kRecBytes;
+        uint32_t rec_st = 0, rec_total = 0;
+        auto rec_flush = [&]() {
+            if (rec_total + rec_st > a.rec_cap) {
+                // region full (the table's best rows sit together): the staged records go to the shared pool — one returning
+                // atomic, which also drains the ring; rare by construction.  A full pool fails the plan (the caller falls back).
+                uint32_t g = 0;
+                if (lane == 0) g = atomicAdd(&a.rec_cnt[a.rec_waves], rec_st);
+                g = __builtin_amdgcn_readfirstlane(g);
+                if (g + rec_st > a.rec_pool_cap) {
+                    if (lane == 0) *a.overflow = 1u;
+                } else {
+                    char* const dst = a.rec_pool + (size_t)g * kRecBytes;
+                    for (uint32_t o = lane * 16; o < rec_st * kRecBytes; o += 1024)
+                        *reinterpret_cast<i32x4*>(dst + o) = *reinterpret_cast<const i32x4*>(rec_lds + o);
+                }
+            } else {
+                char* const dst = rec_glb + (size_t)rec_total * kRecBytes;
+                for (uint32_t o = lane * 16; o < rec_st * kRecBytes; o += 1024)
+                    *reinterpret_cast<i32x4*>(dst + o) = *reinterpret_cast<const i32x4*>(rec_lds + o);
+                rec_total += rec_st;
+            }
+            rec_st = 0;
+        };
+#ifdef PG_SCREEN_PROFILE
+        uint64_t sp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sp_t = __builtin_readcyclecounter();
+#endif
         for (uint32_t b = 0; b < nblk; ++b) {
             wait_vmcnt<ND * (NS - 2)>();
+            SP_MARK(0)
             const char* nb_src;
             uint32_t nb_dst;
             piece_addr(NS - 1, b + NS - 1, nb_src, nb_dst);
@@ -608,6 +688,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int n = 0; n < ND; ++n) dma_one(nb_src, nb_dst + n * 1024, voff[n], q4[n].x);
+            SP_MARK(1)
             const uint32_t cur_phys = phys[0];
 #pragma unroll
             for (int j = 0; j < D; ++j) phys[j] = phys[j + 1];
@@ -640,53 +721,59 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                     continue;
                 }
                 uint64_t cmask[NQB];
+                bool hit[NQB];
                 uint64_t any_mask = 0;
 #pragma unroll
                 for (int c = 0; c < NQB; ++c) {
                     int m = acc[c][0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) m = acc[c][r] > m ? acc[c][r] : m;
-                    cmask[c] = __builtin_amdgcn_ballot_w64(m >= thr_s[half * NQB + c]);
+                    hit[c] = m >= thr_s[half * NQB + c];
+                    cmask[c] = __builtin_amdgcn_ballot_w64(hit[c]);
                     any_mask |= cmask[c];
                 }
                 if (VAR == 4) {                              // (ablation: test, never the hit path)
                     asm volatile("" :: "s"(any_mask));
                     any_mask = 0;
                 }
+                SP_MARK(2 + 2 * half)
                 if (any_mask != 0) {
 #pragma unroll
                     for (int c = 0; c < NQB; ++c) {
                         if (cmask[c] == 0) continue;
-                        uint32_t m16 = 0;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                         : "+v"(m16) : "v"(acc[c][r]), "v"(thr_s[half * NQB + c]) : "vcc");
-                        if (row0 + kPieceRows > a.row_end) {        // last block of a ragged table
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                if (row0 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.row_end) m16 &= ~(1u << (15 - r));
-                        }
+                        uint64_t pend = cmask[c];
+                        bool mine = hit[c];
                         for (;;) {
-                            const bool p = m16 != 0;
-                            const uint64_t bm = __builtin_amdgcn_ballot_w64(p);
-                            if (bm == 0) break;
-                            const uint32_t n = __popcll(bm);
-                            if (st_n + n > (uint32_t)kCap) flush();
-                            if (p) {
-                                const int r = 15 - __builtin_ctz(m16);
-                                const uint32_t pos = st_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                                st_row[pos] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                st_q[pos] = (uint32_t)((half * NQB + c) * 32 + i32);
-                                m16 &= m16 - 1;
+                            const uint32_t n = (uint32_t)__popcll(pend);
+                            if (rec_st + n > kRecStage && rec_st != 0) rec_flush();
+                            const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+                            const bool take = mine && pre < kRecStage;      // (more than kRecStage hit lanes: in rounds)
+                            if (take) {
+                                char* const r = rec_lds + (rec_st + pre) * kRecBytes;
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) {
+                                    const i32x4 v = {acc[c][4 * jj], acc[c][4 * jj + 1], acc[c][4 * jj + 2], acc[c][4 * jj + 3]};
+                                    *reinterpret_cast<i32x4*>(r + 16 * jj) = v;
+                                }
+                                *reinterpret_cast<uint2*>(r + 64) = make_uint2(row0, (uint32_t)((qb0 + half * NQB + c) * 32 + i32) | ((uint32_t)h << 8));
                             }
-                            st_n += n;
+                            rec_st += n < kRecStage ? n : kRecStage;
+                            if (n <= kRecStage) break;
+                            mine = mine && !take;
+                            pend = __builtin_amdgcn_ballot_w64(mine);
                         }
                     }
                 }
+                SP_MARK(3 + 2 * half)
             }
         }
+        rec_flush();
+        if (lane == 0) a.rec_cnt[gw_raw] = rec_total;
+#ifdef PG_SCREEN_PROFILE
+        if (lane == 0 && a.prof)
+            for (int i = 0; i < 8; ++i) a.prof[gw_raw * 8 + i] = sp[i];
+#endif
     } else {
     for (uint32_t b = 0; b < nblk; ++b) {
         AccT acc[NQB];
@@ -826,8 +913,88 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         }
     }
     }
-    flush();
+    if constexpr (QH == 1) flush();
     wait_vmcnt<0>();
+}
+
+// hit records → per-query suspect lists (see kRecBytes).  One workgroup per scan workgroup (its eight wave regions), one
+// record per thread and round.  Two passes over the records: count per query in LDS, ONE global atomic per query and
+// workgroup to reserve the range (one per suspect — 2.3 M returning atomics on 256 counters — made this kernel take 1.08 ms),
+// then place the rows.
+__device__ __forceinline__ uint32_t rec_mask(const char* r, const float* __restrict__ thr_screen, uint32_t row_end, uint32_t& q,
+                                             uint32_t& row0h) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const uint2 tag = *reinterpret_cast<const uint2*>(r + 64);
+    q = tag.y & 255u;
+    const uint32_t h = (tag.y >> 8) & 1u;
+    row0h = tag.x + 4 * h;
+    const int t = __float_as_int(thr_screen[q]);
+    uint32_t m = 0;                                        // bit rr: accumulator register rr of the lane is a suspect
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const i32x4 v = *reinterpret_cast<const i32x4*>(r + 16 * jj);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rr = 4 * jj + e;
+            if (v[e] >= t && row0h + (rr & 3) + 8 * (rr >> 2) < row_end) m |= 1u << rr;
+        }
+    }
+    return m;
+}
+constexpr uint32_t kRecPoolSlice = 8192;       // records of the spill pool per decode workgroup
+__global__ __launch_bounds__(1024) void screen_decode_kernel(const char* __restrict__ rec, const uint32_t* __restrict__ rec_cnt,
+                                                             uint32_t rec_cap, uint32_t rec_waves, const char* __restrict__ rec_pool,
+                                                             uint32_t rec_pool_cap, const float* __restrict__ thr_screen, uint32_t row_end,
+                                                             uint32_t* __restrict__ susp_cnt, uint32_t* __restrict__ susp,
+                                                             uint32_t cap, uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t cntq[kMaxQueries], baseq[kMaxQueries], nreg[8];
+    // workgroups [0, rec_waves / 8): the eight wave regions of one scan workgroup; the ones behind: a slice of the spill pool
+    const bool pool = blockIdx.x >= rec_waves / 8;
+    if (threadIdx.x < kMaxQueries) cntq[threadIdx.x] = 0;
+    if (threadIdx.x < 8) {
+        uint32_t n;
+        if (pool) {
+            const uint32_t filled = rec_cnt[rec_waves] < rec_pool_cap ? rec_cnt[rec_waves] : rec_pool_cap;
+            const uint32_t begin = (blockIdx.x - rec_waves / 8) * kRecPoolSlice;
+            n = threadIdx.x == 0 && begin < filled ? (filled - begin < kRecPoolSlice ? filled - begin : kRecPoolSlice) : 0u;
+        } else {
+            const uint32_t n_raw = rec_cnt[blockIdx.x * 8 + threadIdx.x];
+            n = n_raw < rec_cap ? n_raw : rec_cap;
+        }
+        nreg[threadIdx.x] = n;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t w = 0; w < 8; ++w) {
+            const uint32_t n = nreg[w];
+            const char* const base = pool ? rec_pool + (size_t)(blockIdx.x - rec_waves / 8) * kRecPoolSlice * kRecBytes
+                                          : rec + (size_t)(blockIdx.x * 8 + w) * rec_cap * kRecBytes;
+            for (uint32_t e = threadIdx.x; e < n; e += 1024) {
+                uint32_t q, row0h;
+                uint32_t m = rec_mask(base + (size_t)e * kRecBytes, thr_screen, row_end, q, row0h);
+                if (m == 0) continue;
+                const uint32_t nh = __popc(m);
+                if (pass == 0) {
+                    atomicAdd(&cntq[q], nh);
+                } else {
+                    uint32_t pos = baseq[q] + atomicAdd(&cntq[q], nh);
+                    if (pos + nh > cap) { *overflow = 1u; continue; }
+                    while (m) {
+                        const uint32_t rr = __builtin_ctz(m);
+                        m &= m - 1;
+                        susp[(uint64_t)q * cap + pos++] = row0h + (rr & 3) + 8 * (rr >> 2);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0 && threadIdx.x < kMaxQueries) {
+            const uint32_t c = cntq[threadIdx.x];
+            baseq[threadIdx.x] = c ? atomicAdd(&susp_cnt[threadIdx.x], c) : 0u;
+            cntq[threadIdx.x] = 0;
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1947,6 +2114,24 @@ static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total * SPLIT + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
+#ifdef PG_SCREEN_PROFILE
+    if (QH > 1) {
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) hipMalloc(&dbg, 4096 * 64);
+        ScreenArgs b = a;
+        b.prof = dbg;
+        screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(b);
+        static int calls = 0;
+        if (total > 2000000 && ++calls == 12) {
+            std::vector<unsigned long long> h(4096 * 8);
+            hipMemcpy(h.data(), dbg, 4096 * 64, hipMemcpyDeviceToHost);
+            for (int w : {0, 1, 4, 5, 8 * 100, 8 * 100 + 4, 8 * 255 + 3})
+                fprintf(stderr, "[pg] screen wave %4d: wait %9llu lds+dma %9llu | half0 %9llu hit %9llu | half1 %9llu hit %9llu (cycles, %u blocks)\n", w,
+                        h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5], (total + grid * WAVES - 1) / (grid * WAVES));
+        }
+        return PG_OK;
+    }
+#endif
     screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
@@ -2165,6 +2350,34 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             sa.perm_mul = j->perm_mul;
             sa.perm_mod = j->sample_blocks;
             int rc2;
+            // > 128 queries on the int8 shadow: the scan leaves hit records, decoded into the suspect lists below
+            const bool records = t->shadow_is_i8 && nq > 128;
+            sa.rec = nullptr;
+            sa.rec_cnt = nullptr;
+            sa.rec_cap = 0;
+            sa.rec_pool = nullptr;
+            sa.rec_pool_cap = sa.rec_waves = 0;
+            sa.early_share = records ? ctx->knobs.screen_early_share : 512u;
+            const uint32_t rec_waves = (uint32_t)ctx->num_cus * 8u;
+            if (records) {
+                // a region per wave: four times the share of 256 x K suspects a wave expects, never below the 2 048 records the
+                // safe plan's bounded chunks can leave in one region (kCandSlack / 2 rows over >= 2 048 waves: 4 blocks x 8 x 64)
+                uint32_t cap_w = (uint32_t)(((uint64_t)kMaxQueries * j->k * 4 / rec_waves + 255) / 256 * 256);
+                const uint32_t floor_w = (kCandSlack / 2 / kPieceRows + rec_waves - 1) / rec_waves * 512;
+                if (cap_w < floor_w) cap_w = floor_w;
+                // + a spill pool for tables whose best rows sit together: room for all of 256 x 2 K suspects
+                const uint32_t pool_cap = (uint32_t)(((uint64_t)kMaxQueries * j->k * 2 + kRecPoolSlice - 1) / kRecPoolSlice * kRecPoolSlice);
+                const size_t head = ((size_t)(rec_waves + 1) * 4 + 255) & ~(size_t)255;
+                void* p;
+                if ((rc2 = scratch_reserve(ctx, 11, head + ((size_t)rec_waves * cap_w + pool_cap) * kRecBytes, &p))) return rc2;
+                sa.rec_cnt = (uint32_t*)p;
+                sa.rec = (char*)p + head;
+                sa.rec_cap = cap_w;
+                sa.rec_pool = sa.rec + (size_t)rec_waves * cap_w * kRecBytes;
+                sa.rec_pool_cap = pool_cap;
+                sa.rec_waves = rec_waves;
+                PG_HIP(hipMemsetAsync(sa.rec_cnt, 0, (size_t)(rec_waves + 1) * 4, ctx->stream));
+            }
             PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
             // the full pass of a small batch streams the 4-bit shadow; its few suspect lists share the whole buffer
             // (whole 64-row groups: a range starts on an even block and ends on one or at the table's end)
@@ -2177,6 +2390,12 @@ struct PlanRun {                     // the launches of one plan (helper of reca
                 j->scan_bytes += (r_end - r_begin) * 72;
             } else {
                 if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) return rc2;
+                if (records) {
+                    screen_decode_kernel<<<rec_waves / 8 + sa.rec_pool_cap / kRecPoolSlice, 1024, 0, ctx->stream>>>(
+                        sa.rec, sa.rec_cnt, sa.rec_cap, rec_waves, sa.rec_pool, sa.rec_pool_cap, rs.thr_screen, j->rows,
+                                                                            rs.susp_cnt, rs.susp, rs.cap, rs.overflow);
+                    PG_HIP(hipGetLastError());
+                }
                 j->scan_bytes += (uint64_t)cb * kPieceRows * t->dim * (t->shadow_is_i8 ? 1 : 2);
             }
             j->scanned_rows += (uint64_t)cb * kPieceRows;
@@ -2432,6 +2651,16 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
         uint32_t sc[4] = {0, 0, 0, 0};
         PG_HIP(hipMemcpy(sc, j->rs.susp_cnt, sizeof sc, hipMemcpyDeviceToHost));
         fprintf(stderr, "[pg] plan %d last screened launch: suspects of queries 0-3: %u %u %u %u (K = %u)\n", plan, sc[0], sc[1], sc[2], sc[3], j->k);
+        if (j->t->shadow_is_i8 && j->nq > 128 && ctx->scratch[11].p) {     // hit records: the fullest wave region, the spill pool
+            const uint32_t waves = (uint32_t)ctx->num_cus * 8u;
+            std::vector<uint32_t> rc(waves + 1);
+            PG_HIP(hipMemcpy(rc.data(), ctx->scratch[11].p, rc.size() * 4, hipMemcpyDeviceToHost));
+            uint32_t mx = 0;
+            uint64_t sum = 0;
+            for (uint32_t w = 0; w < waves; ++w) { mx = rc[w] > mx ? rc[w] : mx; sum += rc[w]; }
+            fprintf(stderr, "[pg] plan %d last screened launch: hit records %llu in wave regions (fullest %u), %u in the spill pool\n", plan,
+                    (unsigned long long)sum, mx, rc[waves]);
+        }
     }
     j->scan_launches += j->n_ev - 1;
     bool ok = j->h_status[0] == 0;

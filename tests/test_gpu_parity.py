@@ -494,6 +494,37 @@ def test_recall_threshold_refinement_any_row_order(ctx):
         ctx.set_option("pilot_fraction", "0")
 
 
+def test_recall_hit_records_spill_pool_on_a_table_whose_best_rows_sit_together(ctx, capfd):
+    """More than 128 queries on the int8 shadow: the scan parks hit records (a lane's 16 accumulators + a tag) in a region
+    per wave and screen_decode_kernel turns them into the suspect lists (csrc/recall.hip, kRecBytes).  Rows of three times
+    the norm packed into a few thousand rows: every query's best rows — and nearly all suspects — fall into a handful of
+    wave regions, which overflow into the shared spill pool.  Answers must be exact, without a fallback to another plan."""
+    rng = np.random.default_rng(77)
+    n, d, k, nq = 3_000_000, 128, 2000, 200
+    tab = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    tab /= np.linalg.norm(tab, axis=1, keepdims=True)
+    hot = slice(1_500_000, 1_506_000)                          # 6 000 rows: a handful of 32-row-block runs
+    tab[hot] *= 3.0
+    q = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    ctx.set_option("debug_scan", "1")
+    try:
+        before = ctx.stats().recall_rescans
+        rows, scores, _ = t.recall_topk(q, k)
+        assert ctx.stats().recall_rescans == before, "the spill pool should have absorbed the skew without a re-plan"
+    finally:
+        ctx.set_option("debug_scan", "0")
+    err = capfd.readouterr().err
+    spilled = [int(l.rsplit(",", 1)[1].split()[0]) for l in err.splitlines() if "in the spill pool" in l]
+    assert spilled and max(spilled) > 0, "the skewed table did not exercise the spill pool:\n" + err[-2000:]
+    qs = rng.choice(nq, 6, replace=False)
+    orow, osc = o.recall_topk(tab, q[qs], k)
+    assert np.array_equal(rows[qs], orow) and np.array_equal(bits(scores[qs]), bits(osc))
+    assert np.mean((rows >= hot.start) & (rows < hot.stop)) > 0.25     # a large part of every answer comes from the hot rows
+    t.destroy()
+
+
 def test_recall_refinement_gives_up_on_a_table_with_an_unrepresentative_head(ctx):
     """Rows of three times the norm in the first fifth of the table: for every query the head holds all of the best
     rows, the threshold raised after the first quarter is far above the true K-th score, the verification rejects every
