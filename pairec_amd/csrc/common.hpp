@@ -75,6 +75,7 @@ struct Knobs {
     bool no_predict = false;       // PG_NO_PREDICT: never replace the pilot sample by the learned threshold model
     double predict_sigmas = 4.5;   // PG_PREDICT_SIGMAS: margin of the predicted threshold, in standard deviations of the observed quantile
     uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way
+    uint32_t screen_early_share_narrow = 512;   // PG_SCREEN_EARLY_SHARE_NARROW: the same for the 8-wave kernels of <= 128 queries
     uint32_t screen_early_share = 604;      // PG_SCREEN_EARLY_SHARE: share (x 1024) of a SIMD's blocks given to its older wave (256-query screen)
 };
 

@@ -563,6 +563,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     // scored (the DMA ring runs NS-1 pieces ahead).  Incremental: slot += mul (mod n_slots) per block
     // for a pilot sample, +1 for a full pass — no division in the loop.  Blocks past the end of the
     // run repeat the last one (tail pieces re-read it; they are never scored).
+    // (Tried for the query halves: the next piece sent into the slot just READ — its four fragments are in registers at the top
+    // of the iteration — i.e. the whole ring, NS pieces = 128 KiB per CU, in flight instead of NS - 1: 311 vs 318 M items/s.
+    // More requests in flight than the memory pipeline queues only stall the wave at the DMA issue.)
     constexpr int D = (PPB - 1 + NS - 1) / PPB;
     const bool strided = a.stride != 1;
     const uint32_t L0 = a.rb_begin + first;
@@ -2357,7 +2360,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             sa.rec_cap = 0;
             sa.rec_pool = nullptr;
             sa.rec_pool_cap = sa.rec_waves = 0;
-            sa.early_share = records ? ctx->knobs.screen_early_share : 512u;
+            sa.early_share = records ? ctx->knobs.screen_early_share : ctx->knobs.screen_early_share_narrow;
             const uint32_t rec_waves = (uint32_t)ctx->num_cus * 8u;
             if (records) {
                 // a region per wave: four times the share of 256 x K suspects a wave expects, never below the 2 048 records the

@@ -20,7 +20,7 @@ done
 python3 - "$OUT" "$TAIL" <<'PY'
 import sys, os, csv, glob, collections, json
 out, tail = sys.argv[1], int(sys.argv[2])
-KERNELS = ("screen_kernel", "rescore_kernel", "scan_kernel", "select_kernel", "final_kernel", "dnn3_ws_kernel", "sort_kernel", "pred_")
+KERNELS = ("screen_kernel", "screen_decode_kernel", "rescore_kernel", "scan_kernel", "select_kernel", "final_kernel", "dnn3_ws_kernel", "sort_kernel", "pred_")
 res = {"_how": "rocprofv3 --kernel-trace --stats / --pmc <group> -- python3 bench.py --steps 6 --warmup 2 --no-extras --contexts 1 "
                "(scripts/profile_r3_headline.sh); per kernel: the last %d dispatches of the run = steady state "
                "(thresholds predicted by the table's model, one screened launch per 256-query pass); "
@@ -50,7 +50,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         by = collections.defaultdict(list)
         for r in rows:
             kn = r.get("Kernel_Name", "?")
-            if any(k in kn for k in ("screen_kernel", "rescore_kernel", "dnn3_ws_kernel")):
+            if any(k in kn for k in ("screen_kernel", "screen_decode_kernel", "rescore_kernel", "dnn3_ws_kernel")):
                 by[(kn[:80], r.get("Counter_Name", "?"))].append((int(r.get("Dispatch_Id", 0)), float(r.get("Counter_Value", 0) or 0)))
         lines.append("== PMC %s: mean over the last %d dispatches" % (os.path.basename(d), tail))
         for (kn, cn), v in sorted(by.items()):
