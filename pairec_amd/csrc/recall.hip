@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         uint64_t sp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sp_t = __builtin_readcyclecounter();
 #endif
         for (uint32_t b = 0; b < nblk; ++b) {
-            wait_vmcnt<ND * (NS - 2)>();
+            if (VAR != 3 && VAR != 5) wait_vmcnt<ND * (NS - 2)>();
             SP_MARK(0)
             const char* nb_src;
             uint32_t nb_dst;
@@ -690,7 +690,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
             for (int j = 0; j < 4; ++j) q4[j] = *reinterpret_cast<const f32x4*>(slot + (((2 * j + h) * 16 - rd_rot) & 112));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < ND; ++n) dma_one(nb_src, nb_dst + n * 1024, voff[n], q4[n].x);
+            for (int n = 0; n < ND; ++n)
+                if (VAR != 3 && VAR != 5) dma_one(nb_src, nb_dst + n * 1024, voff[n], q4[n].x);
             SP_MARK(1)
             const uint32_t cur_phys = phys[0];
 #pragma unroll
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                         acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, q4[ksl]),
                                                                        __builtin_bit_cast(i32x4, bq), acc[c], 0, 0, 0);
                     }
-                if (VAR == 1 || VAR == 2) {                  // (ablation: no screen test)
+                if (VAR == 1 || VAR == 2 || VAR == 5) {      // (ablation: no screen test)
 #pragma unroll
                     for (int c = 0; c < NQB; ++c) asm volatile("" :: "v"(acc[c][0]), "v"(acc[c][15]));
                     continue;
@@ -951,6 +952,10 @@ __global__ __launch_bounds__(1024) void screen_decode_kernel(const char* __restr
                                                              uint32_t* __restrict__ susp_cnt, uint32_t* __restrict__ susp,
                                                              uint32_t cap, uint32_t* __restrict__ overflow) {
     __shared__ uint32_t cntq[kMaxQueries], baseq[kMaxQueries], nreg[8];
+    // pass 1 leaves (first row + lane half, query | mask << 16) of every record with a suspect here, pass 2 reads them back
+    // (records beyond the buffer — a workgroup of a skewed table — are read from global memory again)
+    constexpr uint32_t kKeep = 12288;
+    __shared__ uint2 keep[kKeep];
     // workgroups [0, rec_waves / 8): the eight wave regions of one scan workgroup; the ones behind: a slice of the spill pool
     const bool pool = blockIdx.x >= rec_waves / 8;
     if (threadIdx.x < kMaxQueries) cntq[threadIdx.x] = 0;
@@ -968,13 +973,23 @@ __global__ __launch_bounds__(1024) void screen_decode_kernel(const char* __restr
     }
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {
+        uint32_t off = 0;
         for (uint32_t w = 0; w < 8; ++w) {
             const uint32_t n = nreg[w];
             const char* const base = pool ? rec_pool + (size_t)(blockIdx.x - rec_waves / 8) * kRecPoolSlice * kRecBytes
                                           : rec + (size_t)(blockIdx.x * 8 + w) * rec_cap * kRecBytes;
             for (uint32_t e = threadIdx.x; e < n; e += 1024) {
-                uint32_t q, row0h;
-                uint32_t m = rec_mask(base + (size_t)e * kRecBytes, thr_screen, row_end, q, row0h);
+                uint32_t q, row0h, m;
+                const uint32_t slot = off + e;
+                if (pass == 1 && slot < kKeep) {
+                    const uint2 kp = keep[slot];
+                    row0h = kp.x;
+                    q = kp.y & 0xffffu;
+                    m = kp.y >> 16;
+                } else {
+                    m = rec_mask(base + (size_t)e * kRecBytes, thr_screen, row_end, q, row0h);
+                    if (pass == 0 && slot < kKeep) keep[slot] = make_uint2(row0h, q | (m << 16));
+                }
                 if (m == 0) continue;
                 const uint32_t nh = __popc(m);
                 if (pass == 0) {
@@ -989,6 +1004,7 @@ __global__ __launch_bounds__(1024) void screen_decode_kernel(const char* __restr
                     }
                 }
             }
+            off += n;
         }
         __syncthreads();
         if (pass == 0 && threadIdx.x < kMaxQueries) {
@@ -2148,6 +2164,8 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
         if (wide && v && v[0] == '1') return launch_screen<128, 4, 8, 1, 1, true, 2>(ctx, a);
         if (wide && v && v[0] == '2') return launch_screen<128, 4, 8, 1, 2, true, 2>(ctx, a);
         if (wide && v && v[0] == '4') return launch_screen<128, 4, 8, 1, 4, true, 2>(ctx, a);
+        if (wide && v && v[0] == '3') return launch_screen<128, 4, 8, 1, 3, true, 2>(ctx, a);     // no DMA (stale LDS): MFMA + tests
+        if (wide && v && v[0] == '5') return launch_screen<128, 4, 8, 1, 5, true, 2>(ctx, a);     // no DMA, no tests: MFMA only
 #endif
         if (wide) return launch_screen<128, 4, 8, 1, 0, true, 2>(ctx, a);
         if (a.nq <= 32) return launch_screen<128, 1, 8, 1, 0, true>(ctx, a);
