@@ -46,7 +46,7 @@ FLOPS_PER_ITEM = 524800        # SURVEY.md §8(d) cfg 3: 2*(256*512+512*256+256)
 FM2T_BYTES_PER_ITEM = 544      # SURVEY.md §8(d) cfg 4: 8 ids x 4 B + 8 rows x 64 B
 FM2T_FLOPS_PER_ITEM = 99456
 RANK_EXPR = "${gpu_dnn}*(1+${current_score})^0.1"      # RankConf.RankScore: model score x recall score
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r2_scan_traffic.json")
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r3_scan_traffic.json")
 
 
 def parse_args():
@@ -80,7 +80,7 @@ def parse_args():
 
 def profile_numbers(R):
     """What the committed rocprofv3 PMC passes of this same command measured for the dominant kernel at this batch
-    size (profiles/r2_scan_traffic.json, written by scripts/make_traffic_json.py): HBM bytes per table pass
+    size (profiles/r3_scan_traffic.json, written by scripts/make_traffic_json_r3.py): HBM bytes per table pass
     (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md §HBM, + WRITE_SIZE) and the MFMA pipe's busy
     fraction.  NOT measured in this run — hence the field name traffic_from_profile."""
     try:
