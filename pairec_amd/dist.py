@@ -6,13 +6,16 @@ request batch then costs exactly two exchanges, both latency-bound (KB-scale), s
 collectives rather than anything ring-tuned:
 
   1. every rank scans its shard → local top-K (global row id, score) per request
-  2. all_gather of the [R][K] lists → identical deterministic merge on every rank → global top-K
+  2. ONE all_gather of the packed [R][K] lists (global rows and scores in one byte block per rank) → identical
+     deterministic merge on every rank → global top-K
   3. every rank ranks the candidates whose embedding rows it owns (no feature traffic); they are compacted on
      the device (pg_owned_compact_dev), nothing is read back
   4. all_reduce(sum) of the [R][K] score slab (each slot is written by exactly one owner, the
      other ranks contribute +0.0, so the sum is exact) → fusion + sort, replicated on every rank
-  5. (cfg 5) sort.dpp_sort on the merged list: the first max(page, CandidateCount) entries' embedding rows are
-     contributed by their owners (a second all_reduce, 256 KB per request) and DPP runs replicated
+  5. (cfg 5) sort.dpp_sort on the merged list, spread over the ranks BY REQUEST: the first max(page, CandidateCount)
+     entries' embedding rows are contributed by their owners through a reduce_scatter (256 KB per request; rank r
+     receives the summed rows of its block of requests only — half an all_reduce's traffic), every rank runs DPP on
+     its R / world requests, and the picks ([R / world][page] int32) come back with an all_gather
 
 The same flow inside ONE process over several GPUs, with direct peer stores instead of collectives, is
 pg_group_recommend (csrc/group.hip) — what a cgo host calls.
@@ -73,13 +76,18 @@ def _sharded_step(engine, dist, torch, queries, nq: int, k: int, page: int = 0, 
     world = dist.get_world_size() if dist is not None else 1
     rows, scores = engine.recall_local(queries, nq, k)                       # [nq,k] i64 / f32
     if world > 1:
-        # concatenation along dim 0 (the layout every backend accepts) = list-major [G, nq, k], which the merge reads
-        # directly
-        g_rows = torch.empty((world * nq, k), dtype=rows.dtype, device=rows.device)
-        g_scores = torch.empty((world * nq, k), dtype=scores.dtype, device=scores.device)
-        dist.all_gather_into_tensor(g_rows, rows.contiguous())
-        dist.all_gather_into_tensor(g_scores, scores.contiguous())
-        rows, scores = engine.merge(g_rows.view(world, nq, k), g_scores.view(world, nq, k), k)
+        # one collective for both arrays: every rank contributes ONE byte block [rows (8 B each) | scores (4 B each)];
+        # the gathered block of rank g is list g of the list-major [G, nq, k] layout the merge reads
+        nb_r, nb_s = nq * k * 8, nq * k * 4
+        mine = torch.empty(nb_r + nb_s, dtype=torch.uint8, device=rows.device)
+        mine[:nb_r].copy_(rows.contiguous().view(torch.uint8).reshape(-1))
+        mine[nb_r:].copy_(scores.contiguous().view(torch.uint8).reshape(-1))
+        g = torch.empty(world * (nb_r + nb_s), dtype=torch.uint8, device=rows.device)
+        dist.all_gather_into_tensor(g, mine)                                 # (concatenation along dim 0: every backend's layout)
+        g = g.view(world, nb_r + nb_s)
+        g_rows = g[:, :nb_r].contiguous().view(rows.dtype).view(world, nq, k)
+        g_scores = g[:, nb_r:].contiguous().view(scores.dtype).view(world, nq, k)
+        rows, scores = engine.merge(g_rows, g_scores, k)
     local, slot, req_offsets = engine.owned_compact(rows, nq, k)             # compacted on the device, CSR offsets
     mine = engine.rank(queries, local, req_offsets, nq, nq * k)              # n_items = upper bound
     slab = engine.scatter(mine, slot, req_offsets, nq, k)                    # [nq*k] f32, zero where not owned
@@ -93,9 +101,30 @@ def _sharded_step(engine, dist, torch, queries, nq: int, k: int, page: int = 0, 
     n_cand = min(k, max(page, int(dpp["candidates"])))
     c_rows, c_rel = engine.dpp_candidates(order, rows, fused, nq, k, n_cand)
     emb = engine.gather_owned(c_rows, nq * n_cand)                           # [nq*C, dim] f32, zero where not owned
-    if world > 1:
-        dist.all_reduce(emb)                                                 # 256 KB per request; sum with zeros: exact
-    picks = engine.dpp(emb, c_rel, nq, n_cand, float(dpp["alpha"]), page, int(dpp["window"]))     # [nq,page] into the head
+    alpha, window = float(dpp["alpha"]), int(dpp["window"])
+    if world == 1:
+        picks = engine.dpp(emb, c_rel, nq, n_cand, alpha, page, window)      # [nq,page] into the head
+        return rows, fused, order, torch.gather(order, 1, picks.long()).to(order.dtype)
+    # DPP by request: rank r takes requests [r * per, (r + 1) * per).  reduce_scatter hands it the summed embedding rows of
+    # exactly those (owners are disjoint, the others contribute +0.0: exact), all_gather returns everybody's picks.
+    rank = dist.get_rank()
+    per = (nq + world - 1) // world
+    dim = emb.shape[1]
+    if per * world != nq:                                                    # pad the request axis to a multiple of world
+        padded = torch.zeros((per * world * n_cand, dim), dtype=emb.dtype, device=emb.device)
+        padded[:nq * n_cand].copy_(emb)
+        emb = padded
+    my_emb = torch.empty((per * n_cand, dim), dtype=emb.dtype, device=emb.device)
+    dist.reduce_scatter_tensor(my_emb, emb.contiguous())                     # (chunks along dim 0)
+    q0 = rank * per
+    n_mine = max(0, min(per, nq - q0))
+    my_picks = torch.zeros((per, page), dtype=torch.int32, device=emb.device)
+    if n_mine > 0:
+        p = engine.dpp(my_emb[:n_mine * n_cand], c_rel[q0 * n_cand:(q0 + n_mine) * n_cand], n_mine, n_cand, alpha, page, window)
+        my_picks[:n_mine].copy_(p.to(torch.int32))
+    g_picks = torch.empty((per * world, page), dtype=torch.int32, device=emb.device)
+    dist.all_gather_into_tensor(g_picks, my_picks)
+    picks = g_picks[:nq]
     return rows, fused, order, torch.gather(order, 1, picks.long()).to(order.dtype)
 
 
