@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--calibrate", type=int, default=10,
                     help="untimed batches served before the warm-up steps, like the shadow build: the table's threshold "
-                         "model (DESIGN.md 4.1e) starts predicting once it has observed 1024 verified queries of one K")
+                         "model (DESIGN.md 4.1, plan 0) starts predicting once it has observed 1024 verified queries of one K")
     ap.add_argument("--rows", type=int, default=100_000_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=5000)

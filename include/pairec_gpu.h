@@ -63,8 +63,10 @@ int pg_synchronize(pg_ctx* ctx);
  * "pilot_sigmas", "debug_scan", "rank_no_ws", "sort_lds", and for the 4-bit screen of batches of <= 4 queries
  * (csrc/recall_i4.hip) "no_screen_i4", "i4_min_rows" (default 2^22), "i4_max_lambda", and for the threshold refinement inside the pilot plan's
  * full pass "no_refine", "refine_min_rows" (default 2^24), and for the threshold model that replaces the pilot sample
- * once a table has seen >= 1024 queries of one K "no_predict", "predict_sigmas" (default 4.5),
- * "predict_min_rows" (default 2^22); value is parsed as a number. */
+ * once a table has seen >= 1024 queries of one K (plan 0) "no_predict", "predict_sigmas" (default 4.5),
+ * "predict_min_rows" (default 2^22), and for the 256-query screen "screen_early_share" (default 604: the share
+ * x 1024 of a SIMD's blocks its older wave takes; 512 = even), "screen_early_share_narrow" (the <= 128-query kernels, default
+ * 512); value is parsed as a number. */
 int pg_set_option(pg_ctx* ctx, const char* name, const char* value);
 int pg_device_malloc(pg_ctx* ctx, size_t bytes, void** out);
 int pg_device_free(pg_ctx* ctx, void* p);

@@ -116,7 +116,7 @@ struct pg_table {
     float rmax4 = 0.0f;          // max over rows of ||x - x^|| (upper bound)
     float lam4 = 0.0f;           // mean residual term in units of the score spread (decides whether the shadow pays)
     uint32_t prefix_failures = 0; // batches whose refined thresholds failed verification for most queries (ordered rows): two → no refinement
-    // Threshold predictor (recall.hip, §4.1e of DESIGN.md): a Gaussian model of a query's scores over the rows — mean
+    // Threshold predictor (recall.hip, DESIGN.md 4.1, plan 0): a Gaussian model of a query's scores over the rows — mean
     // vector and covariance from a row sample, built with the statistics — and the quantile z = (K-th best score −
     // mean) / sigma actually observed for the batches served so far.  Once the observed z is tight, a batch's first
     // thresholds come from the model instead of a pilot sample.  A hint only: every plan is verified, results are exact.

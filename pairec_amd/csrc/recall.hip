@@ -2295,7 +2295,7 @@ int recall_job_prepare(RecallJob* j) {
         j->screen4 = t->i4_ok && (double)t->lam4 <= kn.i4_max_lambda * kLamScale[j->nq - 1];
     }
     // the threshold model: observe with every pilot-plan batch of a big int8-screened table; predict once the observed
-    // quantile is tight
+    // quantile is tight (plan 0)
     j->predict = j->pred_observe = false;
     if (screen && t->dim == 128 && t->shadow_is_i8 && j->plans[0] == kPilot && !j->screen4 && !j->skip_pilot && !kn.no_predict &&
         rows >= kn.predict_min_rows && j->k < rows / 64) {
