@@ -494,6 +494,34 @@ def test_recall_threshold_refinement_any_row_order(ctx):
         ctx.set_option("pilot_fraction", "0")
 
 
+def test_recall_hit_records_with_every_lane_hit(ctx):
+    """The hit-record path of the > 128-query int8 screen (csrc/recall.hip, kRecBytes) under data that fills whole tiles
+    with suspects: zero queries (threshold 0: every row of every tile is a suspect of that query — more hit lanes per
+    tile than the wave's LDS stage holds, regions and spill pool overflow, the plan falls back), blocks of identical rows
+    (ties by row id inside one tile), a ragged row count (the last block's rows past the end must not be emitted).
+    Ids, order and score bits must match the oracle for every query."""
+    rng = np.random.default_rng(83)
+    n, d, k, nq = 300_011, 128, 700, 200
+    tab = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    tab /= np.linalg.norm(tab, axis=1, keepdims=True)
+    tab[1000:1064] = tab[1000]                                  # 64 identical rows: two whole tiles of ties
+    tab[n - 11:] = tab[1000] * 1.5                              # the best rows sit in the ragged last block
+    q = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    q[0] = 0.0
+    q[77] = 0.0
+    q[150] = tab[1000]
+    q[151] = -tab[1000]
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    assert t.screen_info()[0] == 1
+    rows, scores, cnt = t.recall_topk(q, k)
+    qs = [0, 77, 150, 151, 3, 199]
+    orow, osc = o.recall_topk(tab, q[qs], k)
+    assert np.array_equal(rows[qs], orow) and np.array_equal(bits(scores[qs]), bits(osc))
+    assert rows.max() < n
+    t.destroy()
+
+
 def test_recall_hit_records_spill_pool_on_a_table_whose_best_rows_sit_together(ctx, capfd):
     """More than 128 queries on the int8 shadow: the scan parks hit records (a lane's 16 accumulators + a tag) in a region
     per wave and screen_decode_kernel turns them into the suspect lists (csrc/recall.hip, kRecBytes).  Rows of three times
