@@ -93,6 +93,60 @@ def profile_numbers(R):
         return None
 
 
+def measure_traffic_live(args, R):
+    """HBM bytes per table pass of the scan stage, measured in THIS run: two child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE — one counter per run, no trace domains, the program directly behind `--`),
+    steady state = the last dispatches of the run, FETCH_SIZE (KB) x 1024 x 2 per the gfx950 correction of
+    MI355X_MICROARCH.md, WRITE_SIZE (KB) x 1024.  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    kernels = ("screen_kernel", "screen4_kernel", "screen_decode_kernel", "rescore_kernel")
+    steps = 6
+    detail = {}
+    total = 0.0
+    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+        d = tempfile.mkdtemp(prefix="pg_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", PG_BENCH_CHILD="1")
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   "python3", os.path.abspath(__file__), "--steps", str(steps), "--warmup", "2", "--batch", str(R),
+                   "--rows", str(args.rows), "--dim", str(args.dim), "--k", str(args.k), "--prec", args.prec,
+                   "--table-dist", args.table_dist, "--calibrate", str(args.calibrate),
+                   "--no-cpu-baseline", "--latency-reqs", "0", "--no-extras", "--no-rank-shapes", "--contexts", "1", "--callers", "0"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited with %d" % (counter, r.returncode)
+            by = {}
+            for p in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(p)):
+                    kn = row.get("Kernel_Name", "")
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    for k_ in kernels:
+                        if k_ in kn:
+                            by.setdefault(k_, []).append((int(row.get("Dispatch_Id", 0)), float(row.get("Counter_Value", 0) or 0)))
+                            break
+            if not by:
+                return None, "no %s rows for the scan-stage kernels" % counter
+            for k_, v in by.items():
+                v.sort()
+                # the timed steps' passes are the last dispatches (one screened launch per pass in the steady state)
+                tail = [x[1] for x in v[-steps:]]
+                b = sum(tail) / len(tail) * scale
+                detail["%s_%s_bytes" % (k_, counter.lower())] = int(b)
+                total += b
+        except Exception as e:                      # noqa: BLE001 — the measurement is optional
+            return None, "%s: %s" % (type(e).__name__, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(total), detail
+
+
 def scan_kernel_name(R, dim, elem_bytes):
     """The kernel recall.hip dispatches for the full-table pass at this batch size (dispatch_screen):
     screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH>."""
@@ -272,8 +326,9 @@ def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs, scan_b
                 "fp32; frac_survey_8d > 1 says exactly that (the 51.2 GB fp32 table is not streamed).  One pass serves "
                 "%d requests; ms_per_pass = sum of the pass's scan-stage launches (pilot seed, pilot sample launch, "
                 "full pass, exact re-scoring), HIP events on the launch stream, measured with ONE batch in flight (the "
-                "headline region overlaps two batches on two streams, which inflates per-kernel event times).  traffic is not measured in this run; "
-                "traffic_from_profile quotes the committed rocprofv3 --pmc passes of this command." % R,
+                "headline region overlaps two batches on two streams, which inflates per-kernel event times).  traffic = HBM bytes per pass of "
+                "these launches from two child runs of this script under rocprofv3 --pmc (FETCH_SIZE x 2 per the gfx950 correction, + "
+                "WRITE_SIZE; null when rocprofv3 is unavailable); traffic_from_profile quotes the committed PMC passes of the same command." % R,
     }
 
 
@@ -904,6 +959,14 @@ def main():
         out["other_configs"] = {"cfg1": cfg1_leg(pa, o, ctx), "cfg4": cfg4_leg(pa, o, ctx, R, K),
                                 "cfg5_one_shard": cfg5_leg(pa, o, R, K, prec)}
 
+    if rank == 0 and extras and not os.environ.get("PG_BENCH_CHILD"):
+        # roofline.traffic, live: the same scan stage under rocprofv3 --pmc in two child runs (the tables of this process are
+        # gone by now; the children build their own)
+        tb, detail = measure_traffic_live(args, R)
+        out["roofline"]["traffic"] = tb
+        out["roofline"]["traffic_detail"] = detail
+        if tb:
+            out["roofline"]["traffic_over_streamed_bytes"] = tb / out["roofline"]["bytes_per_pass"]
     if rank == 0:
         out["device"] = device_info()
         if solo and not args.no_cpu_baseline:
