@@ -67,6 +67,8 @@ def parse_args():
                     help="headline table: SURVEY.md 8d's normalised uniform rows, or N(0,1) rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only (profiling runs)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs behind roofline.traffic")
     ap.add_argument("--no-rank-shapes", action="store_true", help="skip the rank-stage-alone leg (DNN3 per hidden shape)")
     ap.add_argument("--contexts", type=int, default=2,
                     help="library contexts (= HIP streams with their own scratch) the batches alternate between")
@@ -105,6 +107,8 @@ def measure_traffic_live(args, R):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ):
+        return None, "this run is itself being profiled: no nested rocprofv3"
     kernels = ("screen_kernel", "screen4_kernel", "screen_decode_kernel", "rescore_kernel")
     steps = 6
     detail = {}
@@ -959,7 +963,7 @@ def main():
         out["other_configs"] = {"cfg1": cfg1_leg(pa, o, ctx), "cfg4": cfg4_leg(pa, o, ctx, R, K),
                                 "cfg5_one_shard": cfg5_leg(pa, o, R, K, prec)}
 
-    if rank == 0 and extras and not os.environ.get("PG_BENCH_CHILD"):
+    if rank == 0 and extras and not args.no_live_traffic and not os.environ.get("PG_BENCH_CHILD"):
         # roofline.traffic, live: the same scan stage under rocprofv3 --pmc in two child runs (the tables of this process are
         # gone by now; the children build their own)
         tb, detail = measure_traffic_live(args, R)
