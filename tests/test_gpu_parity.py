@@ -1180,6 +1180,21 @@ def test_recall_threshold_model_predicts_then_backs_off_on_queries_it_does_not_d
         for q, rows, scores in (batches[0], batches[-1]):
             orow, osc = o.recall_topk(tab, q, k)
             assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+        # (1b) a lone request rides the same model (its full pass streams the 4-bit shadow when the table has one)
+        for name, v in (("i4_min_rows", "0"),):
+            ctx.set_option(name, v)
+        q1 = rng.standard_normal((2, d)).astype(np.float32)
+        q1[:, 127] = 0.0
+        sa = ctx.stats()
+        rows, scores, _ = t.recall_topk(q1[:1], k)
+        rows2, scores2, _ = t.recall_topk(q1, k)
+        sb = ctx.stats()
+        ctx.set_option("i4_min_rows", str(1 << 22))
+        assert sb.recall_predicted - sa.recall_predicted == 2 and sb.recall_rescans == sa.recall_rescans
+        orow, osc = o.recall_topk(tab, q1, k)
+        assert np.array_equal(rows, orow[:1]) and np.array_equal(bits(scores), bits(osc[:1]))
+        assert np.array_equal(rows2, orow) and np.array_equal(bits(scores2), bits(osc))
+        s1 = ctx.stats()
         # (2) three queries of the batch look along the two-valued column: half the table scores +3|q|, the K-th best
         # is ~1 sd above the mean where the model expects ~3.3
         q = rng.standard_normal((nq, d)).astype(np.float32)
