@@ -1696,6 +1696,7 @@ __global__ void recall_init_kernel(const float* __restrict__ queries, uint32_t n
     if (i < kMaxQueries) {
         thr[i] = -__builtin_inff();
         cnt[i] = 0;
+        cnt[kMaxQueries + i] = 0;                          // susp_cnt (RecallScratch: right behind cnt)
     }
     if (i == 0) *overflow = 0;
 }
@@ -1791,7 +1792,7 @@ __global__ void pred_means_kernel(float* __restrict__ pred, uint64_t n_sample) {
 }
 // per query: mean mu.q and sigma sqrt(q'Sq) of its scores (one workgroup of 128 threads per query)
 __global__ __launch_bounds__(128) void pred_query_kernel(const float* __restrict__ qpad, const float* __restrict__ pred,
-                                                         float* __restrict__ ms) {
+                                                         float* __restrict__ ms, float* __restrict__ thr, float z_lo) {
     __shared__ float qs[128];
     __shared__ double red[2][2];
     const uint32_t q = blockIdx.x, t = threadIdx.x;
@@ -1809,23 +1810,19 @@ __global__ __launch_bounds__(128) void pred_query_kernel(const float* __restrict
     __syncthreads();
     if (t == 0) {
         const double var = red[0][0] + red[1][0], mean = red[0][1] + red[1][1];
-        ms[2 * q] = (float)mean;
-        ms[2 * q + 1] = var > 0.0 ? (float)sqrt(var) : 0.0f;
+        const float m = (float)mean, sg = var > 0.0 ? (float)sqrt(var) : 0.0f;
+        ms[2 * q] = m;
+        ms[2 * q + 1] = sg;
+        if (thr) {
+            // first threshold from the model: mean + z_lo sigma, rounded down; anything odd → +inf, which leaves the query
+            // without candidates: the plan check then sends the batch to the pilot plan.  (Query columns >= nq keep the
+            // -inf recall_init_kernel gave them.)
+            float t = __fmaf_rn(z_lo, sg, m);
+            t = t - fabsf(t) * 1e-6f;
+            if (!(sg > 0.0f) || !(t == t) || fabsf(t) > 1e30f) t = __builtin_inff();
+            thr[q] = t;
+        }
     }
-}
-// first thresholds from the model: thr = mean + z_lo sigma, rounded down; anything odd → +inf, which leaves the query
-// without candidates: the plan check then sends the batch to the pilot plan
-__global__ void pred_thr_kernel(const float* __restrict__ ms, uint32_t nq, float z_lo, float* __restrict__ thr) {
-    const uint32_t q = threadIdx.x;
-    if (q >= (uint32_t)kMaxQueries) return;
-    float t = -__builtin_inff();                           // (inactive query columns: as recall_init leaves them)
-    if (q < nq) {
-        const float m = ms[2 * q], sg = ms[2 * q + 1];
-        t = __fmaf_rn(z_lo, sg, m);
-        t = t - fabsf(t) * 1e-6f;
-        if (!(sg > 0.0f) || !(t == t) || fabsf(t) > 1e30f) t = __builtin_inff();
-    }
-    thr[q] = t;
 }
 // after a verified-to-be pass: fold the batch's observed quantiles into the table's statistics (queries that came up
 // short of K, or whose model sigma is 0, do not count), then they travel to the host with the status words
@@ -2340,6 +2337,9 @@ struct PlanRun {                     // the launches of one plan (helper of reca
     RecallScratch& rs;
     uint32_t n_ev = 0;
     int cur = 0;
+    bool susp_clean = true;          // recall_init_kernel left the suspect counters at zero: the plan's first screened launch skips its memset
+    bool no_i8 = false;              // the plan launches no int8 / bf16 screen (thresholds predicted, full pass on the 4-bit shadow):
+                                     // its integer-unit thresholds are not needed
 
     explicit PlanRun(RecallJob* job) : j(job), ctx(job->ctx), t(job->t), rs(job->rs) {}
 
@@ -2401,7 +2401,8 @@ struct PlanRun {                     // the launches of one plan (helper of reca
                 sa.rec_waves = rec_waves;
                 PG_HIP(hipMemsetAsync(sa.rec_cnt, 0, (size_t)(rec_waves + 1) * 4, ctx->stream));
             }
-            PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
+            if (!susp_clean) PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
+            susp_clean = false;
             // the full pass of a small batch streams the 4-bit shadow; its few suspect lists share the whole buffer
             // (whole 64-row groups: a range starts on an even block and ends on one or at the table's end)
             const bool i4 = j->screen4 && allow_i4 && st == 1 && (rb & 1) == 0 && (((rb + cb) & 1) == 0 || rb + cb == j->nblocks);
@@ -2465,7 +2466,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
     int refresh(uint32_t kk) {
         int rc2;
         if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk, 0))) return rc2;
-        if (j->screen) {
+        if (j->screen && !no_i8) {
             if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
             else screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, t->max_norm, rs.thr_screen);
             PG_HIP(hipGetLastError());
@@ -2536,19 +2537,26 @@ int recall_job_enqueue(RecallJob* j) {
     recall_init_kernel<<<(kMaxQueries * t->dim + 255) / 256, 256, 0, ctx->stream>>>(
         j->d_queries, j->nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
     PG_HIP(hipGetLastError());
+    // thresholds predicted and the full pass on the 4-bit shadow: the plan launches no int8 screen, so neither the int8 query
+    // fragments nor the integer-unit thresholds are needed (two launches less in front of a lone request, two behind)
+    r.no_i8 = plan == kPredict && j->screen4;
     if (j->screen) {
-        if (t->shadow_is_i8)
-            screen_prep8_kernel<<<j->nq <= 32 ? 1u : (j->nq <= 64 ? 2u : (j->nq <= 128 ? 4u : 8u)), 128, 0, ctx->stream>>>(
-                rs.qpad, t->dim, t->max_norm, t->resid8, rs.qb16, rs.eps, rs.qscale);     // grid = the scan's NQB x QH
-        else
-            screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
-                rs.qpad, t->dim, rs.qb16, rs.eps);
-        PG_HIP(hipGetLastError());
+        if (!r.no_i8) {
+            if (t->shadow_is_i8)
+                screen_prep8_kernel<<<j->nq <= 32 ? 1u : (j->nq <= 64 ? 2u : (j->nq <= 128 ? 4u : 8u)), 128, 0, ctx->stream>>>(
+                    rs.qpad, t->dim, t->max_norm, t->resid8, rs.qb16, rs.eps, rs.qscale);     // grid = the scan's NQB x QH
+            else
+                screen_prep_kernel<<<(kScreenMaxNQB * (t->dim / 16) * 64 + 255) / 256, 256, 0, ctx->stream>>>(
+                    rs.qpad, t->dim, rs.qb16, rs.eps);
+            PG_HIP(hipGetLastError());
+        }
         if (j->screen4 && (rc = screen4_prep_launch(ctx, t, rs))) return rc;
     }
     const bool observe = j->pred_observe && (plan == kPilot || plan == kPredict);
-    if (observe) {
-        pred_query_kernel<<<j->nq, 128, 0, ctx->stream>>>(rs.qpad, t->d_pred, rs.pred_ms);
+    if (observe || plan == kPredict) {
+        // mean and sigma of every query's scores; under prediction the same launch writes the first thresholds
+        pred_query_kernel<<<j->nq, 128, 0, ctx->stream>>>(rs.qpad, t->d_pred, rs.pred_ms, plan == kPredict ? rs.thr : nullptr,
+                                                          (float)j->z_lo);
         PG_HIP(hipGetLastError());
     }
     while (j->events->size() < 2) {
@@ -2560,9 +2568,8 @@ int recall_job_enqueue(RecallJob* j) {
     // events 0/1 of the pool bracket the whole plan; PlanRun's launches use the pairs after them
     r.n_ev = 1;
     PG_HIP(hipEventRecord((*j->events)[0], ctx->stream));
-    if (plan == kPredict) {
-        // no sample: the first thresholds are the model's (then exactly the pilot plan's full pass)
-        pred_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.pred_ms, j->nq, (float)j->z_lo, rs.thr);
+    if (plan == kPredict && !r.no_i8) {
+        // no sample: the first thresholds are the model's (pred_query_kernel above), here in the int8 screen's units
         screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
         PG_HIP(hipGetLastError());
     }
@@ -2594,7 +2601,7 @@ int recall_job_enqueue(RecallJob* j) {
             if ((rc = r.grow_scan(j->sample_blocks, j->stride, j->k_pilot, kn.pilot_growth > 0.0 ? kn.pilot_growth : 8.0, false))) return rc;
         }
       }
-        PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
+        if (plan == kPilot) PG_HIP(hipMemsetAsync(rs.cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));    // (kPredict: still zero from recall_init_kernel)
         // The sample's threshold is deliberately low (K' = m + 6 sqrt(m) + 8 of a 1/64 sample: ~1.8 K rows reach it where K
         // are needed), and every row that reaches it costs a suspect's hit path and an exact re-scoring — a quarter of
         // the 256-query pass.  After the first quarter of the table the candidates found so far ARE a 16x larger sample:

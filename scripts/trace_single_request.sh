@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/lat1
 mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $GRAFT_REPO_ROOT/bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --latency-reqs 0 --no-extras --no-rank-shapes --contexts 1 --callers 0 --no-live-traffic > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --latency-reqs 40 --no-extras --no-rank-shapes --contexts 1 --callers 0 --no-live-traffic > $OUT/log.txt 2>&1
 python3 - $OUT <<'PY'
 import sys, csv, glob, os
 rows=[]
@@ -10,7 +10,7 @@ for p in glob.glob(os.path.join(sys.argv[1],"**","*kernel_trace.csv"),recursive=
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # last step: find last 'recall_init_kernel' start
 idx=[i for i,r in enumerate(rows) if "recall_init_kernel" in r["Kernel_Name"]]
-i0=idx[-2]; i1=idx[-1]
+i0=idx[-2]; i1=idx[-1]          # the last but one single request of the latency leg
 t0=int(rows[i0]["Start_Timestamp"])
 for r in rows[i0:i1]:
     s=(int(r["Start_Timestamp"])-t0)/1e3; e=(int(r["End_Timestamp"])-t0)/1e3
