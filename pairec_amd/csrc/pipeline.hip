@@ -19,8 +19,9 @@ namespace pg {
 // decoder of the reference performs (algorithm/eas/easyrec_response.go:479-483), for all variables of the expression
 struct VarSrc { int8_t src[32]; };
 __global__ void bind_vars_kernel(const float* __restrict__ recall, const float* __restrict__ rank, size_t rank_stride,
-                                 uint32_t n, uint32_t nv, VarSrc vs, double* __restrict__ vars) {
+                                 uint32_t n, uint32_t nv, VarSrc vs, double* __restrict__ vars, uint32_t* __restrict__ err) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (uint32_t)kMaxQueries) err[i] = 0;             // the RankScore flags of the evaluation behind this launch
     if (i >= n) return;
     const double a = (double)recall[i];
     for (uint32_t v = 0; v < nv; ++v) {
@@ -134,10 +135,12 @@ int post_fuse_sort_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint
     VarSrc vs;
     for (int i = 0; i < 32; ++i) vs.src[i] = i < c.nv ? (int8_t)c.var_src[i] : (int8_t)-1;
     if (c.nv > 0) {
-        bind_vars_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n, (uint32_t)c.nv, vs, ps.d_vars);
+        bind_vars_kernel<<<(std::max(n, (uint32_t)kMaxQueries) + 255) / 256, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n,
+                                                                                        (uint32_t)c.nv, vs, ps.d_vars, ps.d_err);
         PG_HIP(hipGetLastError());
+    } else {
+        PG_HIP(hipMemsetAsync(ps.d_err, 0, (size_t)kMaxQueries * 4, st));
     }
-    PG_HIP(hipMemsetAsync(ps.d_err, 0, (size_t)kMaxQueries * 4, st));
     if ((rc = expr_eval_enqueue_locked(ctx, c.e, ps.d_vars, n, c.d_fused + o, ps.d_err, c.k))) return rc;
     if (c.pads) {
         mask_pads_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_rows + o, n, c.d_rank + o, c.rank_stride, c.n_algos, c.d_fused + o);

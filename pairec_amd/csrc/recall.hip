@@ -1935,7 +1935,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     void* small;
     int rc;
     const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
-    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 36 + 2048;
+    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 40 + 2048;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
     rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
@@ -1945,7 +1945,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     rs->cnt = (uint32_t*)(rs->thr_screen + kMaxQueries);
     rs->susp_cnt = rs->cnt + kMaxQueries;
     rs->overflow = rs->susp_cnt + kMaxQueries;
-    rs->qscale = (float*)(rs->overflow + 64);
+    rs->qscale = (float*)(rs->overflow + 64 + kMaxQueries);      // overflow word, the valid counts [kMaxQueries] right behind it (+ 1), padding
     rs->q4 = (uint32_t*)(rs->qscale + kMaxQueries);      // 4 x 128 B + 4 x 16 B
     rs->thr_ref = (float*)(rs->q4 + 160);                // [kMaxQueries]
     rs->pred_ms = rs->thr_ref + kMaxQueries;             // [kMaxQueries][2]
@@ -2229,9 +2229,7 @@ int recall_job_prepare(RecallJob* j) {
     const Knobs& kn = ctx->knobs;
     int rc;
     if ((rc = recall_scratch(ctx, t->dim, j->k, &j->rs))) return rc;
-    void* d_count;
-    if ((rc = scratch_reserve(ctx, 4, 4096, &d_count))) return rc;
-    j->d_count = (uint32_t*)d_count;
+    j->d_count = j->rs.overflow + 1;              // status words in one block: one device → host copy
     j->rows = (uint32_t)t->rows;
     j->nblocks = (j->rows + kPieceRows - 1) / kPieceRows;
     j->scan_ms = j->total_ms = 0.0;
@@ -2527,11 +2525,7 @@ int recall_job_enqueue(RecallJob* j) {
     // another call on this context may have grown the scratch arenas since recall_job_prepare (a re-plan reaches
     // here long after it): fetch the pointers again rather than trust the cached ones
     if ((rc = recall_scratch(ctx, t->dim, j->k, &j->rs))) return rc;
-    {
-        void* d_count;
-        if ((rc = scratch_reserve(ctx, 4, 4096, &d_count))) return rc;
-        j->d_count = (uint32_t*)d_count;
-    }
+    j->d_count = j->rs.overflow + 1;
     PlanRun r(j);
     RecallScratch& rs = j->rs;
     recall_init_kernel<<<(kMaxQueries * t->dim + 255) / 256, 256, 0, ctx->stream>>>(
@@ -2656,8 +2650,7 @@ int recall_job_enqueue(RecallJob* j) {
     }
     if (j->d_out_count)
         PG_HIP(hipMemcpyAsync(j->d_out_count, j->d_count, 4 * j->nq, hipMemcpyDeviceToDevice, ctx->stream));
-    PG_HIP(hipMemcpyAsync(j->h_status, rs.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
-    PG_HIP(hipMemcpyAsync(j->h_status + 1, j->d_count, 4 * j->nq, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(j->h_status, rs.overflow, 4 * (1 + (size_t)j->nq), hipMemcpyDeviceToHost, ctx->stream));     // [overflow | counts]
     j->n_ev = r.n_ev;
     j->refined = refined;
     j->enqueued_plan = plan;
