@@ -297,7 +297,7 @@ def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs, scan_b
     elem_bytes = table.screen_info()[0]
     screened = elem_bytes != 0
     shard_bytes = rows_local * args.dim * (elem_bytes if screened else 4)
-    # batches of <= 4 queries: the full pass streams the 4-bit shadow (72 B per row, csrc/recall_i4.hip) — the engine's own
+    # batches of <= 4 queries: the full pass streams the 4-bit shadow (68 B per row, csrc/recall_i4.hip) — the engine's own
     # byte count of the last recall's scan launches (pilot sample on the main shadow + that pass) says whether it did
     four_bit = bool(screened and R <= 4 and args.dim == 128 and scan_bytes and scan_bytes < shard_bytes)
     if four_bit:

@@ -108,9 +108,9 @@ struct pg_table {
     float resid8 = 0.0f;         // upper bound of the rows' quantisation residual (L2)
     bool shadow_failed = false;  // allocation failed once: stay on the exact scan
     // recall_i4.hip: the 4-bit shadow that the full pass of a small batch streams (dim 128, built on the first such
-    // recall, 72 B per row): nibbles [rows + 64][64 B], one fp32 scale per row, and the bound's measured constants
+    // recall, 68 B per row): nibbles [rows + 64][64 B], one fp32 scale per row, and the bound's measured constants
     uint8_t* d4 = nullptr;
-    float2* d4s = nullptr;       // {row scale, row residual (upper bound)}
+    uint32_t* d4s = nullptr;     // row scale (bf16, low half) | row residual bound (bf16, high half)
     bool i4_ok = false, i4_failed = false;
     float rho4 = 0.0f;           // max over rows of ||x - x^|| / (s_row sqrt(dim)) (diagnostic)
     float rmax4 = 0.0f;          // max over rows of ||x - x^|| (upper bound)

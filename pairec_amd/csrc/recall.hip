@@ -2409,7 +2409,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             const uint64_t r_end = (uint64_t)(rb + cb) * kPieceRows < j->rows ? (uint64_t)(rb + cb) * kPieceRows : j->rows;
             if (i4) {
                 if ((rc2 = screen4_launch(ctx, t, rs, nq, (uint32_t)r_begin, (uint32_t)r_end, scap))) return rc2;
-                j->scan_bytes += (r_end - r_begin) * 72;
+                j->scan_bytes += (r_end - r_begin) * 68;
             } else {
                 if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) return rc2;
                 if (records) {

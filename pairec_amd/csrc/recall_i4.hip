@@ -8,8 +8,10 @@
 // external faiss service's IndexFlatIP) — results are bit-identical, the screen only decides what is re-scored.
 //
 // Shadow: x^_i = s_r X_i, X_i in [-7, 7], ONE scale per row s_r = max_i |x_i| / 7; a row is 64 B of nibbles — byte b
-// of dword w holds dims 8w+b (low nibble) and 8w+4+b (high nibble), each stored as X + 8 — plus {s_r, R_r} in fp32,
-// R_r >= ||x - x^|| being the row's own MEASURED residual (72 B per row in all).
+// of dword w holds dims 8w+b (low nibble) and 8w+4+b (high nibble), each stored as X + 8 — plus {s_r, R_r} as two bf16 in
+// one dword (68 B per row in all; two fp32 until round 3: 72 B): s_r is the row's scale ROUNDED UP to a bf16 value BEFORE
+// the row is quantised with it (so the stored scale is exactly the one the nibbles mean), R_r >= ||x - x^|| the row's own
+// MEASURED residual, rounded up to bf16.
 // Bound, for the true score s = sum x_i q_i and the integer dot product I = sum X_i Q_i (Q = int8 query, scale s_q):
 //     |s - s_r s_q I| <= ||x - x^|| ||q|| + ||x^|| ||q - q^||  <=  R_r ||q|| + H_r ||q - q^||,
 //     H_r = min(7 sqrt(dim) s_r, N + R4) >= ||x^||     (|X_i| <= 7; N = max row norm, R4 = max_r R_r)
@@ -32,7 +34,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Screen4Args {
     const u32x4* d4;          // [rows + 64][4] quads
-    const float2* d4s;        // [rows + 64] {row scale, row residual}
+    const uint32_t* d4s;      // [rows + 64] row scale (bf16, low half) | row residual bound (bf16, high half)
     const uint32_t* q4;       // [4][32] int8 queries, then [4][4] {s_q, B_q, A_q, 8 sum(Q) as int bits}
     float h_cap;              // N + R4
     const float* thr;         // [>= 4] running thresholds
@@ -85,11 +87,17 @@ __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
     for (uint32_t g = wave; g < ngroups; g += nwaves) {
         const uint32_t row0 = a.row_begin + g * 64 + (lane >> 2);
         u32x4 v[4];
+        uint32_t sr[4];
         f32x2 s[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             v[u] = __builtin_nontemporal_load(a.d4 + (size_t)(row0 + 16 * u) * 4 + part);
-            s[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(a.d4s) + row0 + 16 * u);
+            sr[u] = __builtin_nontemporal_load(a.d4s + row0 + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[u].x = __uint_as_float(sr[u] << 16);
+            s[u].y = __uint_as_float(sr[u] & 0xffff0000u);
         }
         float hr[4];                                   // H_r (7 sqrt(128) = 79.196 rounded up)
 #pragma unroll
@@ -178,8 +186,13 @@ __global__ __launch_bounds__(256) void screen4_prep_kernel(const float* __restri
 
 // the 4-bit shadow, its row scales and the measured constants of the bound.  A thread converts 8 consecutive values
 // (one dword of shadow); 16 neighbouring lanes share a row.
+// the smallest bf16 value >= f (f finite, >= 0), as fp32
+__device__ __forceinline__ float bf16_up(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return __uint_as_float((b & 0xffffu) ? (b | 0xffffu) + 1u : b);
+}
 __global__ __launch_bounds__(256) void table_quant4_kernel(const float* __restrict__ tab, uint64_t rows,
-                                                           uint32_t* __restrict__ out4, float2* __restrict__ out_scale,
+                                                           uint32_t* __restrict__ out4, uint32_t* __restrict__ out_scale,
                                                            float* __restrict__ out_stats) {
     constexpr int DIM = 128, G = 16;
     __shared__ float s_rho[4], s_r[4], s_lam[4];
@@ -204,8 +217,8 @@ __global__ __launch_bounds__(256) void table_quant4_kernel(const float* __restri
             amax = fmaxf(amax, __shfl_xor(amax, off, 64));
             ss += __shfl_xor(ss, off, 64);
         }
-        const float s = amax / 7.0f;
-        const float inv = amax > 0.0f ? 7.0f / amax : 0.0f;
+        const float s = bf16_up(amax / 7.0f);              // the stored scale IS the scale of the nibbles
+        const float inv = amax > 0.0f ? 1.0f / s : 0.0f;
         float rs = 0.0f;
         uint32_t word = 0;
 #pragma unroll
@@ -221,8 +234,8 @@ __global__ __launch_bounds__(256) void table_quant4_kernel(const float* __restri
         for (int off = 1; off < G; off <<= 1) rs += __shfl_xor(rs, off, 64);
         if (g < n8 && (g % G) == 0) {
             // (the residual was accumulated in fp32: a relative 1e-3 covers that, as for the int8 shadow)
-            const float R = sqrtf(rs) * 1.001f + 1e-30f;
-            out_scale[g / G] = make_float2(s, R);
+            const float R = bf16_up(sqrtf(rs) * 1.001f + 1e-30f);
+            out_scale[g / G] = (__float_as_uint(s) >> 16) | (__float_as_uint(R) & 0xffff0000u);
             if (ss > 0.0f) lam += R / sqrtf(ss);
             rho_mx = fmaxf(rho_mx, s > 0.0f ? rs / (s * s * (float)DIM) : 0.0f);
             r_mx = fmaxf(r_mx, R);
@@ -261,7 +274,7 @@ int ensure_table_i4(pg_ctx* ctx, const pg_table* tc) {
     float* d_st = (float*)p + 320;
     if (!t->d4) {
         if (hipMalloc((void**)&t->d4, (t->rows + 64) * (size_t)64) != hipSuccess ||
-            hipMalloc((void**)&t->d4s, (t->rows + 64) * sizeof(float2)) != hipSuccess) {
+            hipMalloc((void**)&t->d4s, (t->rows + 64) * sizeof(uint32_t)) != hipSuccess) {
             (void)hipGetLastError();
             if (t->d4) (void)hipFree(t->d4);
             t->d4 = nullptr;
@@ -270,7 +283,7 @@ int ensure_table_i4(pg_ctx* ctx, const pg_table* tc) {
             return PG_OK;
         }
         PG_HIP(hipMemsetAsync(t->d4 + t->rows * (size_t)64, 0x88, 64 * (size_t)64, ctx->stream));
-        PG_HIP(hipMemsetAsync(t->d4s + t->rows, 0, 64 * sizeof(float2), ctx->stream));
+        PG_HIP(hipMemsetAsync(t->d4s + t->rows, 0, 64 * sizeof(uint32_t), ctx->stream));
     }
     PG_HIP(hipMemsetAsync(d_st, 0, 12, ctx->stream));
     table_quant4_kernel<<<(uint32_t)ctx->num_cus * 16, 256, 0, ctx->stream>>>(t->d, t->rows, (uint32_t*)t->d4, t->d4s, d_st);

@@ -294,7 +294,7 @@ def test_recall_small_batch_4bit_screen_is_exact(ctx):
         other.upload(heavy)
         check(other, heavy, qs[8:9], expect_i4=False)              # elements far above their row's norm: lambda > limit
         # rows of very different magnitude (log-normal row scales): one int8 scale is useless → bf16 main shadow, but
-        # every term of the 4-bit bound is relative to the row, so small batches still stream 72 B per row
+        # every term of the 4-bit bound is relative to the row, so small batches still stream 68 B per row
         scaled = tab * np.exp(rng.standard_normal((n, 1)) * 1.5).astype(np.float32)
         other.upload(scaled)
         assert other.screen_info()[0] == 2
