@@ -7,10 +7,12 @@
 
 namespace pg {
 
+// (uni_off != nullptr: the same launch also writes the uniform request offsets uni_off[r] = r * uni_k, r <= uni_nq <= n)
 __global__ void rows_to_local_kernel(const uint64_t* __restrict__ rows, uint32_t n, uint64_t off,
                                      uint64_t nrows, uint32_t* __restrict__ local,
-                                     uint8_t* __restrict__ owned) {
+                                     uint8_t* __restrict__ owned, uint32_t* __restrict__ uni_off, uint32_t uni_nq, uint32_t uni_k) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (uni_off && i <= uni_nq) uni_off[i] = i * uni_k;
     if (i >= n) return;
     const uint64_t r = rows[i];
     const bool mine = r != ~0ull && r >= off && r - off < nrows;
@@ -135,7 +137,20 @@ int page_launch(hipStream_t st, const uint32_t* d_order, const uint32_t* d_pick,
 int rows_to_local_locked(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t n, uint32_t* d_local,
                          uint8_t* d_owned) {
     if (n == 0) return PG_OK;
-    rows_to_local_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d_rows, n, t->row_offset, t->rows, d_local, d_owned);
+    rows_to_local_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d_rows, n, t->row_offset, t->rows, d_local, d_owned, nullptr, 0, 0);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+// rows_to_local_locked + uniform_offsets_locked in one launch (n = nq * k > nq)
+int rows_to_local_offsets_locked(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t nq, uint32_t k, uint32_t* d_local,
+                                 uint32_t* d_off) {
+    const uint32_t n = nq * k;
+    if (n <= nq) {
+        int rc = uniform_offsets_locked(ctx, nq, k, d_off);
+        return rc ? rc : rows_to_local_locked(ctx, t, d_rows, n, d_local, nullptr);
+    }
+    rows_to_local_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d_rows, n, t->row_offset, t->rows, d_local, nullptr, d_off, nq, k);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }

@@ -180,8 +180,7 @@ static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q
     const uint32_t n = nq * c.k;
     const size_t o = (size_t)q0 * c.k;
     int rc;
-    if ((rc = uniform_offsets_locked(ctx, nq, c.k, ps.d_off))) return rc;
-    if ((rc = rows_to_local_locked(ctx, c.t, c.d_rows + o, n, ps.d_local, nullptr))) return rc;
+    if ((rc = rows_to_local_offsets_locked(ctx, c.t, c.d_rows + o, nq, c.k, ps.d_local, ps.d_off))) return rc;
     // RankAlgoList: every algorithm scores every candidate (rank_service.go:259-289 fans them out as goroutines)
     for (int a = 0; a < c.n_algos; ++a) {
         const RankAlgoRef& al = c.algos[a];

@@ -100,6 +100,8 @@ int rerank_run_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t
 int rows_to_local_locked(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t n, uint32_t* d_local,
                          uint8_t* d_owned);
 int uniform_offsets_locked(pg_ctx* ctx, uint32_t nq, uint32_t k, uint32_t* d_off);
+int rows_to_local_offsets_locked(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows, uint32_t nq, uint32_t k, uint32_t* d_local,
+                                 uint32_t* d_off);
 // the first C entries of every sorted list → their global rows and relevance (fused score), [nq][C]
 int sorted_head_launch(hipStream_t st, const uint32_t* d_order, const uint64_t* d_rows, const double* d_fused, uint32_t nq,
                        uint32_t k, uint32_t C, uint64_t* d_c_rows, double* d_c_rel);

@@ -2306,7 +2306,8 @@ int recall_job_prepare(RecallJob* j) {
                 tm->pred_n = tm->pred_sum = tm->pred_sum2 = 0.0;
                 tm->pred_backoff = 4;                  // (batches already in flight still report the old K's quantiles)
             }
-            j->pred_observe = true;
+            // (a mature model learns nothing from a lone request: its two launches and the 40-byte copy are spared)
+            j->pred_observe = !(j->nq <= (uint32_t)kI4MaxQueries && t->pred_n >= 8192.0);
             if (tm->pred_backoff > 0) {
                 --tm->pred_backoff;
             } else if (t->pred_n >= 1024.0) {
