@@ -624,7 +624,7 @@ static int build_tiles_launch(pg_ctx* ctx, const uint32_t* d_off, uint32_t n_req
 
 // DNN3 request-constant half of layer 1: c1[r][j] = chain(b1[j]; P(u[r][k]) * W1u[k][j], k asc)
 // (W1u is stored already rounded to the model's operand precision).  The chain is sequential in k; its loads
-// are not — eight rows of W1u are requested before the eight fmafs that use them.
+// are not — 64 (then eight) rows of W1u are requested before the fmafs that use them.
 __global__ void dnn3_user_partial_kernel(const float* __restrict__ user, uint32_t du,
                                          const float* __restrict__ w1u, const float* __restrict__ b1,
                                          uint32_t h1, int prec, float* __restrict__ c1) {
@@ -634,6 +634,14 @@ __global__ void dnn3_user_partial_kernel(const float* __restrict__ user, uint32_
     const float* const u = user + (size_t)r * du;
     float acc = b1[j];
     uint32_t k = 0;
+    // (64 rows per step: a lone request's launch is one round trip per step long — 16 steps of 8 rows took 14.8 us)
+    for (; k + 64 <= du; k += 64) {
+        float wv[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) wv[i] = w1u[(size_t)(k + i) * h1 + j];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) acc = __fmaf_rn(round_prec(u[k + i], prec), wv[i], acc);
+    }
     for (; k + 8 <= du; k += 8) {
         float wv[8], uv[8];
 #pragma unroll
