@@ -430,7 +430,9 @@ typedef struct pg_coalescer pg_coalescer;
 typedef struct {
     uint32_t k;               /* recall depth (RecallConfig.RecallCount), fixed per coalescer: 1..16384            */
     uint32_t max_batch;       /* requests per table pass, 1..256 (<= 32 when dim > 128); 0 = the maximum           */
-    uint32_t max_wait_us;     /* how long a request may wait for company while the device is idle; 0 = 100         */
+    uint32_t max_wait_us;     /* how long a request may wait for company while the device is idle; 0 = 100.  Only
+                               * while company is likely: once the recent gap between arrivals exceeds it, a request
+                               * that finds the device idle is dispatched at once                                    */
     uint32_t depth;           /* batches in flight, 1..4; 0 = 2                                                    */
     uint32_t max_top_n;       /* pg_coalescer_recommend: largest page a caller may ask for, <= k; 0 = k            */
     uint32_t max_rank_items;  /* pg_coalescer_rank*: most candidates in one call (BatchCount); 0 = k               */

@@ -203,6 +203,11 @@ struct pg_coalescer {
     std::string grank_var;
     std::atomic<uint32_t> outstanding{0};            // requests between submit and return (the router's load measure)
     uint32_t k = 0, max_batch = 0, max_wait_us = 0, depth = 0, max_top_n = 0, max_rank_items = 0, timeout_us = 0;
+    // arrival statistics per queue (under mu): a request that arrives at an idle device only waits for company when company is likely —
+    // when the recent inter-arrival gap (EWMA) is below max_wait_us; a lone caller is dispatched at once
+    pg::Clock::time_point last_arrival[pg::kNumQueues];
+    double gap_ewma_us[pg::kNumQueues] = {};
+    bool seen_arrival[pg::kNumQueues] = {};
     uint32_t max_rank_reqs = 0, rank_item_cap = 0;
     uint32_t dim = 0, vec_w = 0, ufid_stride = 0, vec_rows = 0;
     uint32_t dpp_item_cap = 0, dpp_max_n = 0, dpp_max_hook = 0;
@@ -666,7 +671,8 @@ void dispatcher_main(pg_coalescer* c) {
             } else {
                 full = qf.size() >= c->max_batch;
             }
-            const auto deadline = qf.front()->arrived + std::chrono::microseconds(c->max_wait_us);
+            const uint32_t wait_us = c->gap_ewma_us[f] > (double)c->max_wait_us ? 0u : c->max_wait_us;
+            const auto deadline = qf.front()->arrived + std::chrono::microseconds(wait_us);
             // recall-based flavours: a table pass costs the same for 1 query as for 256, so a partial batch only goes out
             // when the device has nothing to do; rank / DPP launches cost what their items cost, so a partial batch goes out
             // as soon as its head has waited (a free slot permitting) and pipelines behind the running one
@@ -831,6 +837,16 @@ int submit_and_wait_inner(pg_coalescer* c, Req* r) {
         }
         c->queue[r->queue].push_back(r);
         if (r->queue >= kQRank0) c->queue_items[r->queue] += r->n;
+        const int f = r->queue;
+        if (c->seen_arrival[f]) {
+            double gap = std::chrono::duration<double, std::micro>(r->arrived - c->last_arrival[f]).count();
+            gap = gap < 0.0 ? 0.0 : (gap > 1e5 ? 1e5 : gap);
+            c->gap_ewma_us[f] = 0.75 * c->gap_ewma_us[f] + 0.25 * gap;
+        } else {
+            c->seen_arrival[f] = true;
+            c->gap_ewma_us[f] = 0.0;                   // (the first request waits: nothing is known yet)
+        }
+        c->last_arrival[f] = r->arrived;
     }
     c->cv_dispatch.notify_one();
     const bool timed = c->timeout_us != 0;
