@@ -110,6 +110,14 @@ int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_
                    uint64_t* out_rows, float* out_scores, uint32_t* out_count);
 int pg_recall_topk_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq,
                        uint32_t k, uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count);
+/* HologresVectorRecallV2 (service/recall/hologres_vector_recall_v2.go:23,96-206): the k rows of SMALLEST squared Euclidean
+ * distance to each query, ascending, the distance as the item's score (:181-189).  Exact (the reference's Proxima index is
+ * approximate): d = fmaf(-2, ip, |x|^2 + |q|^2), each sum a k-ascending fp32 fmaf chain; ties by row ascending; slots beyond
+ * the table's rows carry row UINT64_MAX and distance +inf.  dim 64 or 128; the pass streams the fp32 rows (no screen). */
+int pg_recall_topk_l2(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
+                      float* out_dist, uint32_t* out_count);
+int pg_recall_topk_l2_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
+                          float* d_out_dist, uint32_t* out_count);
 /* I2IVectorRecall.GetCandidateItems (service/recall/item_2_item_vector_racall.go:51-152): the embeddings of the
  * trigger items (context parameter "item_id" → dao.VectorString) are the queries — rows `trigger_rows[n]` of
  * `trigger_table` (same dim as `t`; usually the same table) against `t`.  Outputs as pg_recall_topk; the trigger

@@ -139,17 +139,26 @@ static void emit_sorted(uint64_t* keys, uint32_t n, uint64_t row_offset, uint64_
     }
 }
 
-uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint64_t row_offset,
-                         const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
-                         float* out_scores, int threads) {
+/* metric 0: inner product, descending (service/recall/hologres_vector_recall.go:23, pm_approx_inner_product_distance … ORDER BY
+ * distance desc).  metric 1: squared Euclidean distance, ascending (service/recall/hologres_vector_recall_v2.go:23,
+ * pm_approx_squared_euclidean_distance … ORDER BY distance): specified as d = fmaf(-2, ip, nx + nq) with ip, nx = |x|^2 and
+ * nq = |q|^2 each a k-ascending fp32 fmaf chain; rows are ranked by -d = fmaf(2, ip, -(nx + nq)) (exactly the negation), ties by
+ * row ascending, and the distance is what comes out as the item's score (hologres_vector_recall_v2.go:181-189). */
+static uint32_t recall_topk_metric(const float* table, uint64_t nrows, uint32_t dim, uint64_t row_offset,
+                                   const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
+                                   float* out_scores, int threads, int metric) {
     /* The reference-shaped CPU path: each worker scans a contiguous row range,
      * scores a row against all queries (k-ascending fmaf chains, vectorised across queries) and
      * keeps one min-heap of K keys per query; the per-worker heaps are merged at the end. */
     uint32_t kk = (nrows < k) ? (uint32_t)nrows : k;
     if (kk == 0) return 0;
     float* qt = (float*)malloc((size_t)dim * nq * sizeof(float));
+    float* qn = (float*)calloc(nq, sizeof(float));
     for (uint32_t q = 0; q < nq; ++q)
-        for (uint32_t c = 0; c < dim; ++c) qt[(size_t)c * nq + q] = queries[(size_t)q * dim + c];
+        for (uint32_t c = 0; c < dim; ++c) {
+            qt[(size_t)c * nq + q] = queries[(size_t)q * dim + c];
+            qn[q] = fmaf(queries[(size_t)q * dim + c], queries[(size_t)q * dim + c], qn[q]);
+        }
     int nth = 1;
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
@@ -192,7 +201,13 @@ uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint6
             }
           for (uint32_t ri = 0; ri < nr; ++ri) {
             const uint64_t r = rb + ri;
-            const float* acc = accb + (size_t)ri * nq;
+            float* acc = accb + (size_t)ri * nq;
+            if (metric == 1) {
+                const float* x = table + (size_t)r * dim;
+                float nx = 0.0f;
+                for (uint32_t c = 0; c < dim; ++c) nx = fmaf(x[c], x[c], nx);
+                for (uint32_t q = 0; q < nq; ++q) acc[q] = fmaf(2.0f, acc[q], -(nx + qn[q]));
+            }
             for (uint32_t q = 0; q < nq; ++q) {
                 uint64_t* h = myh + (size_t)q * kk;
                 const uint64_t key = orc_topk_key(acc[q], (uint32_t)r);
@@ -222,10 +237,24 @@ uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint6
         }
         qsort(all, n, sizeof(uint64_t), cmp_key_desc);
         emit_sorted(all, kk, row_offset, out_rows + (size_t)q * k, out_scores + (size_t)q * k, NULL);
+        if (metric == 1)
+            for (uint32_t i = 0; i < kk; ++i) out_scores[(size_t)q * k + i] = 0.0f - out_scores[(size_t)q * k + i];   /* (a zero distance comes out as +0) */
         free(all);
     }
-    free(hn); free(heaps); free(qt);
+    free(hn); free(heaps); free(qt); free(qn);
     return kk;
+}
+
+uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint64_t row_offset,
+                         const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
+                         float* out_scores, int threads) {
+    return recall_topk_metric(table, nrows, dim, row_offset, queries, nq, k, out_rows, out_scores, threads, 0);
+}
+
+uint32_t orc_recall_topk_l2(const float* table, uint64_t nrows, uint32_t dim, uint64_t row_offset,
+                            const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
+                            float* out_dist, int threads) {
+    return recall_topk_metric(table, nrows, dim, row_offset, queries, nq, k, out_rows, out_dist, threads, 1);
 }
 
 uint32_t orc_topk_merge(const uint64_t* rows, const float* scores, uint32_t nlists,

@@ -37,6 +37,10 @@ void orc_dot_scores(const float* table, uint64_t nrows, uint32_t dim, const floa
 uint32_t orc_recall_topk(const float* table, uint64_t nrows, uint32_t dim, uint64_t row_offset,
                          const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
                          float* out_scores, int threads);
+/* squared Euclidean distance, ascending (hologres_vector_recall_v2.go:23): d = fmaf(-2, ip, |x|^2 + |q|^2), chains k-ascending */
+uint32_t orc_recall_topk_l2(const float* table, uint64_t nrows, uint32_t dim, uint64_t row_offset,
+                            const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
+                            float* out_dist, int threads);
 /* merge G per-shard top-K lists (keys = score,row) into the global top-K */
 uint32_t orc_topk_merge(const uint64_t* rows, const float* scores, uint32_t nlists,
                         uint32_t per_list, uint32_t k, uint64_t* out_rows, float* out_scores);

@@ -49,6 +49,8 @@ def lib():
         L.orc_dot_scores.argtypes = [f32p, u64, u32, f32p, u32, f32p, i32]
         L.orc_recall_topk.restype = u32
         L.orc_recall_topk.argtypes = [f32p, u64, u32, u64, f32p, u32, u32, C.POINTER(u64), f32p, i32]
+        L.orc_recall_topk_l2.restype = u32
+        L.orc_recall_topk_l2.argtypes = [f32p, u64, u32, u64, f32p, u32, u32, C.POINTER(u64), f32p, i32]
         L.orc_topk_merge.restype = u32
         L.orc_topk_merge.argtypes = [C.POINTER(u64), f32p, u32, u32, u32, C.POINTER(u64), f32p]
         L.orc_dnn3_forward.argtypes = [C.c_void_p, i32, f32p, f32p, u64, f32p, i32]
@@ -130,6 +132,21 @@ def recall_topk(table: np.ndarray, queries: np.ndarray, k: int, row_offset: int 
                               _f32p(queries), nq, k, rows.ctypes.data_as(C.POINTER(C.c_uint64)),
                               _f32p(scores), threads)
     return rows[:, :n], scores[:, :n]
+
+
+def recall_topk_l2(table: np.ndarray, queries: np.ndarray, k: int, row_offset: int = 0, threads: int = 0):
+    """Top-k by SMALLEST squared Euclidean distance (service/recall/hologres_vector_recall_v2.go:23: ORDER BY
+    pm_approx_squared_euclidean_distance ascending; the distance is the item's score, :181-189).  Specified as
+    d = fmaf(-2, ip, |x|^2 + |q|^2), every sum a k-ascending fp32 fmaf chain; ties by row ascending."""
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    queries = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, table.shape[1])
+    nq = queries.shape[0]
+    rows = np.zeros((nq, k), dtype=np.uint64)
+    dist = np.zeros((nq, k), dtype=np.float32)
+    n = lib().orc_recall_topk_l2(_f32p(table), table.shape[0], table.shape[1], row_offset,
+                                 _f32p(queries), nq, k, rows.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                 _f32p(dist), threads)
+    return rows[:, :n], dist[:, :n]
 
 
 def topk_merge(rows: np.ndarray, scores: np.ndarray, k: int):

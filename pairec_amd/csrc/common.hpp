@@ -107,6 +107,8 @@ struct pg_table {
     float s8 = 0.0f;             // int8 scale
     float resid8 = 0.0f;         // upper bound of the rows' quantisation residual (L2)
     bool shadow_failed = false;  // allocation failed once: stay on the exact scan
+    float* d_nx = nullptr;       // squared-Euclidean recall: |x|^2 of every row [rows + 64] (lazily, invalidated by upload / fill)
+    bool nx_valid = false;
     // recall_i4.hip: the 4-bit shadow that the full pass of a small batch streams (dim 128, built on the first such
     // recall, 68 B per row): nibbles [rows + 64][64 B], one fp32 scale per row, and the bound's measured constants
     uint8_t* d4 = nullptr;
@@ -238,6 +240,7 @@ struct RecallJob {
     uint32_t* h_status = nullptr;           // pinned host, >= 1 + nq words: [0] overflow flag, [1 + q] valid count of query q
     std::vector<hipEvent_t>* events = nullptr;   // timing events (grown on demand); one job at a time per pool
     bool skip_pilot = false;                // start with the growing-chunk plan (the re-run of a query the pilot failed)
+    bool l2 = false;                        // rank by smallest squared Euclidean distance (exact scan; scores out = distances)
     // state (recall_job_*)
     RecallScratch rs{};
     uint32_t* d_count = nullptr;
@@ -269,7 +272,7 @@ int recall_job_check(RecallJob* j, bool* ok);         // after the stream passed
 void recall_job_finish(RecallJob* j);                 // publish timing / counters into ctx
 int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq, uint32_t k,
                       uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count, uint32_t* d_out_count,
-                      bool skip_pilot = false);
+                      bool skip_pilot = false, bool l2 = false);
 // re-run the failed queries of `j` (at most kMaxPatchQueries) one by one, synchronously, writing into their slices of
 // the job's outputs and their valid counts into counts[q]; caller holds ctx->mu
 int recall_patch_failed_locked(RecallJob* j, uint32_t* counts);

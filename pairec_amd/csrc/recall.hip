@@ -84,6 +84,9 @@ struct ScanArgs {
     uint32_t perm_mul, perm_mod;   // pilot sample order: slot = L * perm_mul mod perm_mod
     uint32_t group_q;        // > 0: blockIdx.y selects a group of group_q queries (of nq in all) — one launch serves
                              // every group of a screened recall's exact seed scan instead of one launch per group
+    // squared-Euclidean recall (scan_kernel<…, L2 = true>): a row·query pair is ranked by -d = fmaf(2, ip, -(|x|^2 + |q|^2))
+    const float* nx;         // [rows + 64] |x|^2 of every row (k-ascending fmaf chain; pg_table::d_nx)
+    const float* nqv;        // [nq] |q|^2 of every query
 };
 
 // Pilot sample: logical block L of a stride-S launch is table block slot*S + jitter(slot), where
@@ -133,7 +136,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NQB = number of 32-query column blocks riding in the B operand (1: up to 32 queries, 2: up to 64).
 // With two blocks every A fragment feeds two independent accumulator chains and the kernel becomes
 // fp32-MFMA-bound instead of HBM-bound (2 x 64 cycles per 32 B of table per SIMD).
-template <int DIM, int NQB = 1, int VAR = 0>
+// L2: the candidates are the rows of SMALLEST squared Euclidean distance (service/recall/hologres_vector_recall_v2.go:23).  The
+// inner products come out of the same MFMA chains; every accumulator is then turned into -d = fmaf(2, ip, -(|x|^2 + |q|^2))
+// — the block's 32 row norms arrive by scalar loads (the block's first row is wave-uniform; lgkmcnt, not the ring's vmcnt) —
+// and everything behind (threshold streaming, keys, select, final) works on -d unchanged.  HBM-bound like the exact scan.
+template <int DIM, int NQB = 1, int VAR = 0, bool L2 = false>
 __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PPB = DIM / kPieceCols;       // pieces per 32-row block
@@ -152,12 +159,14 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
         a.thr += g0;
         a.cnt += g0;
         a.cand += (uint64_t)g0 * a.cap;
+        if (L2) a.nqv += g0;
         a.nq = a.nq - g0 < a.group_q ? a.nq - g0 : a.group_q;
     }
 
     // B operand: bq[s] = Q[query = lane&31][k = 2s + h]
     float bq[NQB][DIM / 2];
     float thr[NQB];
+    float nq2[NQB];                  // L2: |q|^2 of this lane's query
     bool active[NQB];
 #pragma unroll
     for (int c = 0; c < NQB; ++c) {
@@ -165,6 +174,8 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
         for (int s = 0; s < DIM / 2; ++s) bq[c][s] = a.qpad[(c * 32 + i32) * DIM + 2 * s + h];
         thr[c] = a.thr[c * 32 + i32];
         active[c] = (uint32_t)(c * 32 + i32) < a.nq;
+        nq2[c] = (L2 && active[c]) ? a.nqv[c * 32 + i32] : 0.0f;
+        if (L2) asm volatile("" : "+v"(nq2[c]));
     }
     // Pin the operand loads' completion HERE: hipcc places a load's s_waitcnt at its first use,
     // which would otherwise land inside the streaming loop as vmcnt(0) and drain the DMA ring.
@@ -297,6 +308,19 @@ __global__ __launch_bounds__(64 * kScanWaves, 2) void scan_kernel(ScanArgs a) {
 #pragma unroll
             for (int c = 0; c < NQB; ++c) asm volatile("" ::"v"(acc[c][0]), "v"(acc[c][15]));   // keep the chain live
             continue;
+        }
+        if constexpr (L2) {
+            const uint32_t l2_row0 = __builtin_amdgcn_readfirstlane(
+                sample_block(a.rb_begin + first + b, a.stride, a.perm_mul, a.perm_mod) * kPieceRows);
+            const float* const nxp = a.nx + l2_row0;               // wave-uniform: scalar loads
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const float nxa = nxp[ro], nxb = nxp[ro + 4];
+                const float nxr = h ? nxb : nxa;
+#pragma unroll
+                for (int c = 0; c < NQB; ++c) acc[c][r] = __fmaf_rn(2.0f, acc[c][r], -(nxr + nq2[c]));
+            }
         }
         // ---- threshold test: C layout col = lane&31 (query within its block), row = (r&3)+8*(r>>2)+4*h.
         // Fast path: one not-less-than compare per accumulator register, OR-reduced.
@@ -1701,6 +1725,33 @@ __global__ void recall_init_kernel(const float* __restrict__ queries, uint32_t n
     if (i == 0) *overflow = 0;
 }
 
+// squared-Euclidean recall: |x|^2 of every row and |q|^2 of every query as k-ascending fmaf chains (the specification's), and
+// the sign flip of the scores that come out (-d → d; padding -inf → +inf)
+__global__ void row_norm2_kernel(const float* __restrict__ tab, uint64_t rows, uint32_t dim, float* __restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float4* x = reinterpret_cast<const float4*>(tab + r * dim);
+    float s = 0.0f;
+    for (uint32_t c = 0; c < dim / 4; ++c) {
+        const float4 v = x[c];
+        s = __fmaf_rn(v.x, v.x, s);
+        s = __fmaf_rn(v.y, v.y, s);
+        s = __fmaf_rn(v.z, v.z, s);
+        s = __fmaf_rn(v.w, v.w, s);
+    }
+    out[r] = s;
+}
+__global__ void query_norm2_kernel(const float* __restrict__ qpad, uint32_t dim, float* __restrict__ out) {
+    const uint32_t q = threadIdx.x;
+    float s = 0.0f;
+    for (uint32_t c = 0; c < dim; ++c) s = __fmaf_rn(qpad[(size_t)q * dim + c], qpad[(size_t)q * dim + c], s);
+    out[q] = s;
+}
+__global__ void negate_kernel(float* __restrict__ v, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = 0.0f - v[i];                     // (a zero distance comes out as +0, padding as +inf)
+}
+
 // merge input lists (global rows, scores) → candidate keys.  Padding entries (row = UINT64_MAX: a shard with fewer
 // than per_list rows) are dropped here, so the keys stay distinct (select_kernel's invariant) and cnt[q] is the number
 // of real candidates.  Input layout: [nq][nlists][per_list] (list_major = 0) or [nlists][nq][per_list] (1: what an
@@ -1887,22 +1938,28 @@ static uint32_t next_pow2(uint32_t x) {
     return p;
 }
 
-template <int DIM, int NQB = 1, int VAR = 0>
+template <int DIM, int NQB = 1, int VAR = 0, bool L2 = false>
 static int launch_scan(pg_ctx* ctx, const ScanArgs& a) {
     int rc_attr;
-    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)scan_kernel<DIM, NQB, VAR>, kScanLds))) return rc_attr;
+    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)scan_kernel<DIM, NQB, VAR, L2>, kScanLds))) return rc_attr;
     const uint32_t total = a.rb_end - a.rb_begin;
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total + kScanWaves - 1) / kScanWaves;
     if (grid > need) grid = need;
     const uint32_t groups = a.group_q ? (a.nq + a.group_q - 1) / a.group_q : 1;
-    scan_kernel<DIM, NQB, VAR><<<dim3(grid, groups), 64 * kScanWaves, kScanLds, ctx->stream>>>(a);
+    scan_kernel<DIM, NQB, VAR, L2><<<dim3(grid, groups), 64 * kScanWaves, kScanLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
 
 static int dispatch_scan(pg_ctx* ctx, uint32_t dim, const ScanArgs& a) {
     const bool wide = a.nq_launch > 32;          // two 32-query column blocks
+    if (a.nx) {                                   // squared-Euclidean recall
+        if (dim == 64) return wide ? launch_scan<64, 2, 0, true>(ctx, a) : launch_scan<64, 1, 0, true>(ctx, a);
+        if (dim == 128) return wide ? launch_scan<128, 2, 0, true>(ctx, a) : launch_scan<128, 1, 0, true>(ctx, a);
+        set_error("recall (squared Euclidean): dim=%u unsupported (64 or 128)", dim);
+        return PG_ERR_UNSUPPORTED;
+    }
     switch (dim) {
         case 64: return wide ? launch_scan<64, 2>(ctx, a) : launch_scan<64, 1>(ctx, a);
         case 128: {
@@ -2223,11 +2280,33 @@ enum RecallPlan { kPilot = 0, kGrow = 1, kSafe = 2, kPredict = 3 };
 
 static inline uint64_t rs_cap_bound(uint32_t k) { return (uint64_t)k + kCandSlack; }
 
+// |x|^2 of every row, for the squared-Euclidean recall (lazily, cached until the next upload / fill; shared by the contexts
+// of a device like the shadows)
+static int ensure_table_nx(pg_ctx* ctx, const pg_table* tc) {
+    pg_table* t = const_cast<pg_table*>(tc);
+    std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
+    if (t->nx_valid) return PG_OK;
+    if (!t->d_nx) PG_HIP(hipMalloc((void**)&t->d_nx, (t->rows + 64) * sizeof(float)));
+    PG_HIP(hipMemsetAsync(t->d_nx + t->rows, 0, 64 * sizeof(float), ctx->stream));
+    row_norm2_kernel<<<(uint32_t)((t->rows + 255) / 256), 256, 0, ctx->stream>>>(t->d, t->rows, t->dim, t->d_nx);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    t->nx_valid = true;
+    return PG_OK;
+}
+
 int recall_job_prepare(RecallJob* j) {
     pg_ctx* ctx = j->ctx;
     const pg_table* t = j->t;
     const Knobs& kn = ctx->knobs;
     int rc;
+    if (j->l2) {
+        if (t->dim != 64 && t->dim != 128) {
+            set_error("recall (squared Euclidean): dim=%u unsupported (64 or 128)", t->dim);
+            return PG_ERR_UNSUPPORTED;
+        }
+        if ((rc = ensure_table_nx(ctx, t))) return rc;
+    }
     if ((rc = recall_scratch(ctx, t->dim, j->k, &j->rs))) return rc;
     j->d_count = j->rs.overflow + 1;              // status words in one block: one device → host copy
     j->rows = (uint32_t)t->rows;
@@ -2243,7 +2322,7 @@ int recall_job_prepare(RecallJob* j) {
     // Policy: finite tables of dim <= 128 use the screened scan (int8 or bf16 filter + exact re-scoring) for every
     // batch size (knobs.screen_min = 0), HBM-bound up to 128 queries per pass; everything else rides the exact
     // fp32-MFMA scan in groups of <= 64 queries, one launch per group.
-    bool screen = j->nq > kn.screen_min && t->dim <= 128 && !kn.recall_exact;
+    bool screen = j->nq > kn.screen_min && t->dim <= 128 && !kn.recall_exact && !j->l2;      // (squared Euclidean: exact scan only)
     if (screen) {
         if ((rc = ensure_table_stats(ctx, t))) return rc;
         if (!t->stats_valid || !t->all_finite) screen = false;      // no shadow (dim, memory) or non-finite rows
@@ -2452,6 +2531,8 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             a.stride = st;
             a.perm_mul = j->perm_mul;
             a.perm_mod = j->sample_blocks;
+            a.nx = j->l2 ? t->d_nx : nullptr;
+            a.nqv = j->l2 ? rs.eps : nullptr;          // (the screen's per-query margins are not in use: no screen)
             int rc2;
             if ((rc2 = dispatch_scan(ctx, t->dim, a))) return rc2;
             j->scan_bytes += (uint64_t)cb * kPieceRows * t->dim * 4;
@@ -2532,6 +2613,10 @@ int recall_job_enqueue(RecallJob* j) {
     recall_init_kernel<<<(kMaxQueries * t->dim + 255) / 256, 256, 0, ctx->stream>>>(
         j->d_queries, j->nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
     PG_HIP(hipGetLastError());
+    if (j->l2) {
+        query_norm2_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.qpad, t->dim, rs.eps);
+        PG_HIP(hipGetLastError());
+    }
     // thresholds predicted and the full pass on the 4-bit shadow: the plan launches no int8 screen, so neither the int8 query
     // fragments nor the integer-unit thresholds are needed (two launches less in front of a lone request, two behind)
     r.no_i8 = plan == kPredict && j->screen4;
@@ -2632,6 +2717,11 @@ int recall_job_enqueue(RecallJob* j) {
     if ((rc = final_launch(ctx, rs.cand[r.cur], rs.cnt, rs.cap, j->nq, j->k, t->row_offset, j->d_out_rows,
                            j->d_out_scores, j->d_count)))
         return rc;
+    if (j->l2) {                                       // the lists were ranked by -d: the distances go out
+        const uint64_t n = (uint64_t)j->nq * j->k;
+        negate_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, ctx->stream>>>(j->d_out_scores, n);
+        PG_HIP(hipGetLastError());
+    }
     if (refined) {
         // Two thresholds were in force during the full pass, so "K candidates were found" no longer proves that none
         // of the true top K was rejected: the raised one must not exceed the K-th best score that came out — then at
@@ -2752,7 +2842,7 @@ int recall_patch_failed_locked(RecallJob* j, uint32_t* counts) {
         uint32_t cnt = 0;
         int rc;
         if ((rc = recall_dev_locked(ctx, j->t, j->d_queries + (size_t)q * j->t->dim, 1, j->k, j->d_out_rows + (size_t)q * j->k,
-                                    j->d_out_scores + (size_t)q * j->k, &cnt, j->d_out_count ? j->d_out_count + q : nullptr, true)))
+                                    j->d_out_scores + (size_t)q * j->k, &cnt, j->d_out_count ? j->d_out_count + q : nullptr, true, j->l2)))
             return rc;
         counts[q] = cnt;
     }
@@ -2763,9 +2853,10 @@ int recall_patch_failed_locked(RecallJob* j, uint32_t* counts) {
 // the whole recall for one batch of queries, verified before it returns; all pointers are device pointers
 int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq,
                       uint32_t k, uint64_t* d_out_rows, float* d_out_scores,
-                      uint32_t* out_count, uint32_t* d_out_count, bool skip_pilot) {
+                      uint32_t* out_count, uint32_t* d_out_count, bool skip_pilot, bool l2) {
     RecallJob j;
     j.skip_pilot = skip_pilot;
+    j.l2 = l2;
     j.ctx = ctx;
     j.t = t;
     j.d_queries = d_queries;
@@ -2884,6 +2975,48 @@ int pg_recall_topk(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_
     if ((rc = pg::recall_dev_locked(ctx, t, d_q, nq, k, d_rows, d_sc, out_count, nullptr))) return rc;
     PG_HIP(hipMemcpyAsync(out_rows, d_rows, rb, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipMemcpyAsync(out_scores, d_sc, sb, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+
+// HologresVectorRecallV2 (service/recall/hologres_vector_recall_v2.go:23,96-206): "SELECT id, pm_approx_squared_euclidean_distance
+// (emb, $1) as distance … ORDER BY distance LIMIT n" — the K rows of SMALLEST squared Euclidean distance, ascending, the distance
+// as the item's score (:181-189).  Exact here (the reference's Proxima index is approximate): d = fmaf(-2, ip, |x|^2 + |q|^2),
+// every sum a k-ascending fp32 fmaf chain; ties by row ascending; slots beyond the table's rows: row UINT64_MAX, distance +inf.
+int pg_recall_topk_l2_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
+                          float* d_out_dist, uint32_t* out_count) {
+    PG_REQUIRE(ctx && t && d_queries && d_out_rows && d_out_dist, "pg_recall_topk_l2_dev: NULL argument");
+    PG_REQUIRE(nq >= 1 && nq <= (uint32_t)pg::kMaxQueries, "pg_recall_topk_l2_dev: nq=%u must be in [1,%d]", nq, pg::kMaxQueries);
+    if (k < 1 || k > 16384) {
+        pg::set_error("pg_recall_topk_l2_dev: k=%u unsupported (1..16384)", k);
+        return PG_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
+    return pg::recall_dev_locked(ctx, t, d_queries, nq, k, d_out_rows, d_out_dist, out_count, nullptr, false, true);
+}
+
+int pg_recall_topk_l2(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
+                      float* out_dist, uint32_t* out_count) {
+    PG_REQUIRE(ctx && t && queries && out_rows && out_dist, "pg_recall_topk_l2: NULL argument");
+    PG_REQUIRE(nq >= 1 && nq <= (uint32_t)pg::kMaxQueries, "pg_recall_topk_l2: nq=%u must be in [1,%d]", nq, pg::kMaxQueries);
+    if (k < 1 || k > 16384) {
+        pg::set_error("pg_recall_topk_l2: k=%u unsupported (1..16384)", k);
+        return PG_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
+    void* buf;
+    int rc;
+    const size_t qb = (size_t)nq * t->dim * 4, rb = (size_t)nq * k * 8, sb = (size_t)nq * k * 4;
+    if ((rc = pg::scratch_reserve(ctx, 5, qb + rb + sb + 64, &buf))) return rc;
+    float* d_q = (float*)buf;
+    uint64_t* d_rows = (uint64_t*)((char*)buf + ((qb + 15) & ~(size_t)15));
+    float* d_sc = (float*)((char*)d_rows + rb);
+    PG_HIP(hipMemcpyAsync(d_q, queries, qb, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pg::recall_dev_locked(ctx, t, d_q, nq, k, d_rows, d_sc, out_count, nullptr, false, true))) return rc;
+    PG_HIP(hipMemcpyAsync(out_rows, d_rows, rb, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(out_dist, d_sc, sb, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
     return PG_OK;
 }

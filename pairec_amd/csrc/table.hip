@@ -126,6 +126,7 @@ int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
     if (t->d4s) PG_HIP(hipFree(t->d4s));
     if (t->dnorm2) PG_HIP(hipFree(t->dnorm2));
     if (t->d_pred) PG_HIP(hipFree(t->d_pred));
+    if (t->d_nx) PG_HIP(hipFree(t->d_nx));
     delete t;
     return PG_OK;
 }
@@ -155,6 +156,7 @@ int pg_table_fill_synthetic(pg_ctx* ctx, pg_table* t, uint64_t seed, int normali
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(ctx->stream));
     t->stats_valid = false;
+    t->nx_valid = false;
     return PG_OK;
 }
 
@@ -169,6 +171,7 @@ int pg_table_fill_gaussian(pg_ctx* ctx, pg_table* t, uint64_t seed, float sigma)
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(ctx->stream));
     t->stats_valid = false;
+    t->nx_valid = false;
     return PG_OK;
 }
 
@@ -185,6 +188,7 @@ int pg_table_upload(pg_ctx* ctx, pg_table* t, uint64_t row0, uint64_t nrows, con
                           hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
     t->stats_valid = false;
+    t->nx_valid = false;
     return PG_OK;
 }
 
@@ -229,6 +233,8 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->lam4, b->lam4);
     std::swap(a->prefix_failures, b->prefix_failures);
     std::swap(a->d_pred, b->d_pred);
+    std::swap(a->d_nx, b->d_nx);
+    std::swap(a->nx_valid, b->nx_valid);
     std::swap(a->pred_model, b->pred_model);
     std::swap(a->pred_k, b->pred_k);
     std::swap(a->pred_n, b->pred_n);

@@ -172,6 +172,19 @@ class Table:
                                                  _ptr(r_), _ptr(s_), _ptr(c_)))
         return rows, scores, counts
 
+    def recall_topk_l2(self, queries: np.ndarray, k: int):
+        """HologresVectorRecallV2: queries [nq][dim] → (rows [nq][k], squared Euclidean distances [nq][k] ascending, counts)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        rows = np.empty((nq, k), dtype=np.uint64)
+        dist = np.empty((nq, k), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        for s in range(0, nq, MAX_QUERIES):
+            e = min(nq, s + MAX_QUERIES)
+            r_, d_, c_ = rows[s:e], dist[s:e], counts[s:e]
+            _lib.check(self.ctx.L.pg_recall_topk_l2(self.ctx.h, self.h, _ptr(q[s:e]), e - s, k, _ptr(r_), _ptr(d_), _ptr(c_)))
+        return rows, dist, counts
+
     def i2i_recall(self, trigger_rows, k: int, trigger_table: Optional["Table"] = None):
         """I2IVectorRecall: rows of `trigger_table` (default: this table) are the queries."""
         tr = np.ascontiguousarray(trigger_rows, dtype=np.uint32)

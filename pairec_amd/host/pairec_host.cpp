@@ -744,6 +744,53 @@ struct GpuI2IVectorRecall : recall::Recall {
     }
 };
 
+// recall.Recall with the body of HologresVectorRecallV2.GetCandidateItems (service/recall/hologres_vector_recall_v2.go:96-206):
+// the user's embedding from the VectorDao (handed to the SQL as it is — "v1,v2,…" or "{v1,v2,…}", module/vector_hologres_dao.go:
+// 67-114; the libsvm form of the other DAOs is accepted too), then "ORDER BY pm_approx_squared_euclidean_distance(emb, $1) LIMIT
+// RecallCount" (:23): the RecallCount items of smallest squared Euclidean distance, ascending, Score = distance (:181-189).
+// (The user-vector cache of :100-115 is the VectorDao's business here; the result cache of :118-143 / :191-204 is GpuVectorRecall's.)
+struct GpuHologresVectorRecallV2 : recall::Recall {
+    Engine* e;
+    recconf::RecallConfig conf;
+    GpuHologresVectorRecallV2(Engine* eng, recconf::RecallConfig c) : e(eng), conf(std::move(c)) {}
+    static std::vector<float> ParseEmbedding(const std::string& s) {
+        if (s.find(':') != std::string::npos) return recall::ParseVectorString(s);
+        std::vector<float> out;
+        size_t p = 0;
+        while (p < s.size()) {
+            while (p < s.size() && (s[p] == '{' || s[p] == '}' || s[p] == ',' || s[p] == ' ')) ++p;
+            if (p >= s.size()) break;
+            char* end = nullptr;
+            const double d = strtod(s.c_str() + p, &end);
+            if (end == s.c_str() + p) break;
+            out.push_back((float)d);
+            p = (size_t)(end - s.c_str());
+        }
+        return out;
+    }
+    std::vector<module::ItemPtr> GetCandidateItems(module::User* user, context::RecommendContext*) override {
+        std::vector<module::ItemPtr> ret;
+        std::string value, err;
+        if (!e->user_vectors.VectorString(user->Id, &value, &err) || value.empty()) return ret;      // (:105-110) logged unless VectoryEmptyError
+        user->Properties[conf.Name + "_embedding"] = json::Value::Str(value);                        // user.AddProperty (:111)
+        const std::vector<float> vec = ParseEmbedding(value);
+        const uint32_t k = (uint32_t)std::max(conf.RecallCount, 0);
+        if (k == 0 || vec.size() != e->dim) return ret;                                               // the SQL would fail: logged, empty (:170-176)
+        std::vector<uint64_t> rows(k);
+        std::vector<float> dist(k);
+        uint32_t cnt = 0;
+        if (pg_recall_topk_l2(e->ctx, e->table, vec.data(), 1, k, rows.data(), dist.data(), &cnt) != PG_OK) return ret;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            auto item = std::make_shared<module::Item>(e->IdOfRow(rows[i]));
+            item->RetrieveId = conf.Name;
+            item->ItemType = conf.ItemType;
+            item->Score = (double)dist[i];                                                            // `item.Score = distance` (:189)
+            ret.push_back(item);
+        }
+        return ret;
+    }
+};
+
 // recall.Recall that returns the FINISHED page: recall → DNN rank → RankScore → ItemRankScore sort all happen where the
 // rows live, one single-request call into the library's coalescer (pg_coalescer_recommend), and only ctx.Size items are
 // materialised on the host.  A scene served this way names it as its only recall and leaves RankConf / SortNames empty
@@ -1380,6 +1427,7 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
     for (const auto& r : e->config.GpuRecalls) {
         if (r.Kind == "vector") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuVectorRecall>(e.get(), r));
         else if (r.Kind == "i2i") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuI2IVectorRecall>(e.get(), r));
+        else if (r.Kind == "hologres_v2") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuHologresVectorRecallV2>(e.get(), r));
         else if (r.Kind == "page") {
             if (r.RankScore.empty() || r.RankVar.empty() || r.RecallCount <= 0) {
                 if (err) *err = "pairec_gpu.Recalls: Kind \"page\" needs RecallCount, RankScore and RankVar";

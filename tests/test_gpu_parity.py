@@ -396,6 +396,41 @@ def test_recall_random_shapes_bitexact(ctx):
         t.destroy()
 
 
+@pytest.mark.parametrize("n,d,k,nq", [
+    (1000, 64, 200, 1),
+    (140_000, 128, 500, 32),
+    (300_017, 128, 1000, 50),     # two 32-query column blocks, ragged row count
+    (250_000, 64, 300, 130),      # three groups of <= 64 queries
+    (2_300_000, 128, 2000, 3),    # pilot plan on the exact scan
+])
+def test_recall_l2_matches_oracle_bitexact(ctx, n, d, k, nq):
+    """HologresVectorRecallV2 (service/recall/hologres_vector_recall_v2.go:23): the k rows of smallest squared Euclidean
+    distance, ascending, distance as the score.  Rows of different norms (so that the order differs from the inner
+    product's), duplicates (ties by row id), a query equal to a row (distance ~ 0): ids, order and distance bits = oracle."""
+    rng = np.random.default_rng(n + nq)
+    tab = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.3, 2.0, (n, 1)).astype(np.float32)
+    tab[100:140] = tab[100]
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[0] = tab[7]
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    rows, dist, cnt = t.recall_topk_l2(q, k)
+    orow, od = o.recall_topk_l2(tab, q, k)
+    m = min(n, k)
+    assert cnt.tolist() == [m] * nq
+    assert np.array_equal(rows[:, :m], orow) and np.array_equal(bits(dist[:, :m]), bits(od))
+    assert np.all(np.diff(dist[:, :m].astype(np.float64), axis=1) >= 0)
+    irow, _, _ = t.recall_topk(q[:2], k)
+    assert not np.array_equal(irow[:, :m], rows[:2, :m])        # not the inner product's order
+    # the norms follow an upload
+    tab[5] = q[min(1, nq - 1)]
+    t.upload(tab[5:6], 5)
+    rows, dist, _ = t.recall_topk_l2(q[:2], k)
+    orow, od = o.recall_topk_l2(tab, q[:2], k)
+    assert np.array_equal(rows[:, :m], orow) and np.array_equal(bits(dist[:, :m]), bits(od))
+    t.destroy()
+
+
 def test_recall_follows_table_updates(ctx):
     """The screen streams a quantised shadow (int8 here) of the table that is built lazily; uploads, synthetic fills and
     hot swaps must invalidate / carry it — every recall answers for the rows the table holds now."""

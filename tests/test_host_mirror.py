@@ -493,6 +493,41 @@ def test_i2i_online_vector_recalls_and_algo_score_sort(H):
 
 
 @pytest.mark.gpu
+def test_hologres_vector_recall_v2_squared_euclidean(H):
+    """HologresVectorRecallV2 (service/recall/hologres_vector_recall_v2.go:23,96-206): the RecallCount items of smallest
+    squared Euclidean distance to the user's embedding, ascending, Score = distance — through the recall registry, with the
+    embedding in the Hologres DAO's own "{v1,v2,…}" text form.  Rows of different norms, so that the order is not the
+    inner product's."""
+    import copy
+    cfg = copy.deepcopy(CONFIG)
+    g = cfg["UserDefineConfs"]["pairec_gpu"]
+    g["Recalls"].append({"Name": "holo_v2", "Kind": "hologres_v2", "RecallCount": 120, "ItemType": "video"})
+    cfg["SceneConfs"]["near_feed"] = {"default": {"RecallNames": ["holo_v2"]}}
+    h, _, user = _engine(H, cfg)
+    tab = o.synth_rows(o.SEED_TABLE, 0, 20000, 128)
+    scaled = (tab * np.linspace(0.5, 1.5, 20000, dtype=np.float32)[:, None]).astype(np.float32)
+    # a new table generation with those rows (ids as before): the ingestion path of host/ingest.cpp
+    H.ph_engine_ingest_begin.argtypes = [C.c_void_p]
+    H.ph_engine_ingest_chunk.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint64]
+    H.ph_engine_ingest_commit.argtypes = [C.c_void_p]
+    assert H.ph_engine_ingest_begin(h) == 0
+    ids = b"".join(b"item_%d\0" % i for i in range(20000))
+    assert H.ph_engine_ingest_chunk(h, ids, len(ids), scaled.ctypes.data, 20000) == 0
+    assert H.ph_engine_ingest_commit(h) == 0
+    H.ph_set_user_vector(h, b"u2", ("{" + ",".join(repr(float(v)) for v in user) + "}").encode())
+    out = json.loads(H.ph_recommend(h, b"u2", 120, b"near_feed"))["items"]
+    orow, od = o.recall_topk_l2(scaled, user[None], 120)
+    # no rank / sort configured for the scene: the default ItemRankScore sort orders by Score descending — the SET and the
+    # distances are what the recall contributes
+    assert sorted(x["item_id"] for x in out) == sorted("item_%d" % r for r in orow[0])
+    by_id = {"item_%d" % r: float(d) for r, d in zip(orow[0], od[0])}
+    assert all(x["score"] == by_id[x["item_id"]] for x in out) and {x["retrieve_id"] for x in out} == {"holo_v2"}
+    irow, _ = o.recall_topk(scaled, user[None], 120)
+    assert set(irow[0].tolist()) != set(orow[0].tolist())
+    H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
 def test_fm2t_algorithm_easyrec_flavour(H):
     """FM + two-tower registered as an IAlgorithm: the EasyRec request flavour (item ids + columnar context features,
     service/rank/algo_data.go:79-86,223-306) with the columns resident on the device — scores equal the oracle's

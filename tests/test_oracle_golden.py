@@ -156,6 +156,38 @@ def test_recall_topk_order_and_ties():
     assert rows.shape == (1, 5)
 
 
+def test_recall_topk_l2_is_the_specified_chain_and_order():
+    """Squared-Euclidean top-k (hologres_vector_recall_v2.go:23: ORDER BY distance ascending, Score = distance): the oracle's
+    distances are fmaf(-2, ip, |x|^2 + |q|^2) with k-ascending fp32 fmaf chains — restated here with numpy scalars —, the
+    order is distance ascending with ties by row, and it agrees with a float64 brute force wherever that one has no ties."""
+    rng = np.random.default_rng(5)
+    n, d, k = 700, 64, 40
+    tab = (rng.standard_normal((n, d)) * rng.uniform(0.3, 2.0, (n, 1))).astype(np.float32)
+    tab[50:54] = tab[50]                                        # ties: rows 50..53 in row order
+    q = rng.standard_normal((3, d)).astype(np.float32)
+    q[1] = tab[50]
+    rows, dist = o.recall_topk_l2(tab, q, k)
+
+    def chain(a, b):
+        acc = np.float32(0.0)
+        for x, y in zip(a, b):
+            acc = np.float32(np.float64(x) * np.float64(y) + np.float64(acc))      # fmaf: one rounding of the exact product-sum
+        return acc
+    for qi in range(3):
+        nq = chain(q[qi], q[qi])
+        for j in (0, 1, 7, k - 1):
+            r = int(rows[qi, j])
+            ip, nx = chain(tab[r], q[qi]), chain(tab[r], tab[r])
+            t = np.float32(nx + nq)
+            want = np.float32(np.float64(-2.0) * np.float64(ip) + np.float64(t))
+            assert dist[qi, j].view(np.uint32) == want.view(np.uint32)
+        assert np.all(np.diff(dist[qi].astype(np.float64)) >= 0)
+    assert rows[1, :4].tolist() == [50, 51, 52, 53]
+    d64 = ((tab[None].astype(np.float64) - q[:, None].astype(np.float64)) ** 2).sum(-1)
+    ref = np.argsort(d64, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(rows[0], ref[0]) and np.array_equal(rows[2], ref[2])
+
+
 def test_topk_merge_equals_global():
     tab = o.synth_rows(o.SEED_TABLE, 0, 4000, 64)
     q = o.synth_rows(o.SEED_QUERY, 0, 1, 64)
