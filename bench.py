@@ -827,8 +827,10 @@ def main():
             run_headline(pa, ctx, table, model, expr, d_cal, a0, R, K, sync, extra_ctxs)
             del d_cal
         predicted0 = sum(c_.stats().recall_predicted for c_ in [ctx] + extra_ctxs)
+        rescans0 = sum(c_.stats().recall_rescans for c_ in [ctx] + extra_ctxs)
         pipe, elapsed, scan_ms = run_headline(pa, ctx, table, model, expr, d_qs, args, R, K, sync, extra_ctxs)
         predicted_batches = sum(c_.stats().recall_predicted for c_ in [ctx] + extra_ctxs) - predicted0
+        rescans = sum(c_.stats().recall_rescans for c_ in [ctx] + extra_ctxs) - rescans0
         if extra_ctxs:
             # the roofline figure is a per-kernel property: with batches overlapping on two streams a kernel's event-timed
             # duration includes the other stream's work, so the scan-stage time is measured in a short un-overlapped leg
@@ -885,6 +887,7 @@ def main():
                    "contexts": args.contexts,
                    "calibration_batches": 0 if shard else args.calibrate,
                    "timed_batches_on_predicted_thresholds": None if shard else int(predicted_batches),
+                   "batches_re_run_after_a_failed_plan": None if shard else int(rescans),
                    "parallelism": ("table row-range shards x%d (%d rows total), all_gather top-K merge + all_reduce scores + DPP top-500"
                                    % (world, args.rows * world)) if shard else
                                   ("request-parallel x%d, table replicated per GPU, no data-path collective" % world
