@@ -497,6 +497,9 @@ int pg_coalescer_recall(pg_coalescer* c, const float* query, uint64_t* out_rows,
                         uint32_t* out_count);
 /* I2IVectorRecall.GetCandidateItems for ONE trigger item (pg_i2i_recall with n = 1): the query is row `trigger_row` of
  * the scene's trigger table; rides the same table pass as the vector recalls of other callers. */
+/* HologresVectorRecallV2 through the coalescer: one request per call, up to 32 share one pass of the exact squared-Euclidean
+ * scan (pg_recall_topk_l2: a pass costs the same for 32 queries as for one); out_dist ascending. */
+int pg_coalescer_recall_l2(pg_coalescer* c, const float* query, uint64_t* out_rows, float* out_dist, uint32_t* out_count);
 int pg_coalescer_i2i_recall(pg_coalescer* c, uint32_t trigger_row, uint64_t* out_rows, float* out_scores,
                             uint32_t* out_count);
 /* OnlineVectorRecall.GetCandidateItems for ONE user (pg_online_vector_recall with n_req = 1): user_vec[d_user] goes

@@ -27,7 +27,7 @@ EXPORTS = [
     "pg_table_fill_gaussian", "pg_dpp_ex", "pg_i2i_recall", "pg_online_vector_recall", "pg_fm2t_user_embedding",
     "pg_fm2t_user_embedding_dev", "pg_recommend_dnn3_begin", "pg_recommend_end",
     "pg_coalescer_create", "pg_coalescer_destroy", "pg_coalescer_recall", "pg_coalescer_rank_dnn3",
-    "pg_coalescer_recommend", "pg_coalescer_stats", "pg_coalescer_create_scene", "pg_coalescer_i2i_recall",
+    "pg_coalescer_recommend", "pg_coalescer_stats", "pg_coalescer_create_scene", "pg_coalescer_i2i_recall", "pg_coalescer_recall_l2",
     "pg_coalescer_online_recall", "pg_coalescer_rank", "pg_coalescer_rank_fm2t", "pg_coalescer_recommend_ex",
     "pg_coalescer_dpp", "pg_coalescer_ssd", "pg_recommend_end_timed", "pg_debug_stall",
     "pg_fm2t_item_rows_build", "pg_fm2t_item_rows_update", "pg_fm2t_item_rows_destroy", "pg_rank_fm2t_irows_dev",
@@ -163,6 +163,7 @@ def load():
         "pg_coalescer_stats": [vp, P(PgCoalescerStats)],
         "pg_coalescer_create_scene": [vp, vp, P(PgSceneConfig), P(vp)],
         "pg_coalescer_i2i_recall": [vp, u32, vp, vp, P(u32)],
+        "pg_coalescer_recall_l2": [vp, vp, vp, vp, P(u32)],
         "pg_coalescer_online_recall": [vp, vp, vp, vp, P(u32)],
         "pg_coalescer_rank": [vp, u32, vp, vp, vp, u32, vp],
         "pg_coalescer_rank_fm2t": [vp, vp, vp, vp, u32, vp],

@@ -51,7 +51,8 @@ namespace {
 using Clock = std::chrono::steady_clock;
 
 enum Flavour { kRecall = 0, kRank = 1, kRecommend = 2, kDpp = 3, kSsd = 4 };      // statistics index
-enum Queue { kQRecall = 0, kQRecommend = 1, kQDpp = 2, kQRank0 = 3 };             // kQRank0 + algorithm index
+enum Queue { kQRecall = 0, kQRecommend = 1, kQDpp = 2, kQRecallL2 = 3, kQRank0 = 4 };     // kQRank0 + algorithm index
+constexpr uint32_t kL2Batch = 32;      // squared-Euclidean recalls per pass: the exact scan serves 32 queries at the price of one
 constexpr int kNumQueues = kQRank0 + kMaxAlgos;
 enum QueryKind : uint32_t { kVector = 0, kTrigger = 1, kOnline = 2 };
 enum ReqState : uint32_t { kQueued = 0, kStaging = 1, kStaged = 2, kDone = 3, kAbandoned = 4 };
@@ -232,7 +233,9 @@ struct pg_coalescer {
 namespace pg {
 namespace {
 
-int flavour_of(int queue) { return queue == kQRecall ? kRecall : (queue == kQRecommend ? kRecommend : (queue == kQDpp ? kDpp : kRank)); }
+int flavour_of(int queue) {
+    return (queue == kQRecall || queue == kQRecallL2) ? kRecall : (queue == kQRecommend ? kRecommend : (queue == kQDpp ? kDpp : kRank));
+}
 
 size_t page_bytes(const pg_coalescer* c) { return (size_t)c->max_batch * c->max_top_n * page_entry_bytes(std::max(c->n_algos, 1)); }
 
@@ -419,6 +422,7 @@ int enqueue_recall_batch(pg_coalescer* c, Slot* s, bool first) {
         j.d_out_count = nullptr;
         j.h_status = s->run->h_status;
         j.events = &s->run->events;
+        j.l2 = s->queue == kQRecallL2;
         if ((rc = recall_job_prepare(&j))) return rc;
     }
     s->run->patched = false;
@@ -588,7 +592,8 @@ void take_batch(pg_coalescer* c, int kind, Slot* s) {
         }
         s->n_items = (uint32_t)s->reqs.size() * s->key.n;
     } else {
-        while (!q.empty() && s->reqs.size() < c->max_batch) {
+        const uint32_t limit = kind == kQRecallL2 ? std::min(c->max_batch, kL2Batch) : c->max_batch;
+        while (!q.empty() && s->reqs.size() < limit) {
             s->reqs.push_back(q.front());
             q.pop_front();
         }
@@ -629,8 +634,12 @@ void stage_batch(pg_coalescer* c, Slot* s) {
                 else if (c->query_model) memset(s->h_uq + (size_t)i * c->query_model->d_user, 0, (size_t)c->query_model->d_user * 4);
             } else {
                 memcpy(s->h_vec + (size_t)i * w, r->vec, (size_t)w * 4);
+                if (kind == kQRecallL2) {              // plain vector queries (enqueue_recall_batch looks at the kinds)
+                    s->h_qk[2 * i] = kVector;
+                    s->h_qk[2 * i + 1] = 0;
+                }
             }
-            if (uw && kind != kQRecall) {
+            if (uw && kind != kQRecall && kind != kQRecallL2) {
                 if (r->ufids) memcpy(s->h_ufid + (size_t)i * uw, r->ufids, (size_t)uw * 4);
                 else memset(s->h_ufid + (size_t)i * uw, 0, (size_t)uw * 4);
             }
@@ -669,7 +678,7 @@ void dispatcher_main(pg_coalescer* c) {
             } else if (f == kQDpp) {
                 full = qf.size() >= dpp_batch_limit(c, qf.front()->key.n);
             } else {
-                full = qf.size() >= c->max_batch;
+                full = qf.size() >= (f == kQRecallL2 ? std::min(c->max_batch, kL2Batch) : c->max_batch);
             }
             const uint32_t wait_us = c->gap_ewma_us[f] > (double)c->max_wait_us ? 0u : c->max_wait_us;
             const auto deadline = qf.front()->arrived + std::chrono::microseconds(wait_us);
@@ -1120,6 +1129,29 @@ int pg_coalescer_recall(pg_coalescer* c, const float* query, uint64_t* out_rows,
     r->vec = query;
     r->qkind = pg::kVector;
     return coalescer_recall_common(c, r, out_rows, out_scores, out_count);
+}
+
+int pg_coalescer_recall_l2(pg_coalescer* c, const float* query, uint64_t* out_rows, float* out_dist, uint32_t* out_count) {
+    PG_REQUIRE(c && query && out_rows && out_dist, "pg_coalescer_recall_l2: NULL argument");
+    PG_REQUIRE(c->dim == 64 || c->dim == 128, "pg_coalescer_recall_l2: dim %u unsupported (64 or 128)", c->dim);
+    if (c->group) {
+        pg::set_error("pg_coalescer: a coalescer over a shard group serves pg_coalescer_recommend only");
+        return PG_ERR_UNSUPPORTED;
+    }
+    pg::Req* r = new pg::Req();
+    r->vec = query;
+    r->qkind = pg::kVector;
+    r->queue = pg::kQRecallL2;
+    int rc;
+    if ((rc = pg::submit_and_wait(c, r))) return rc;
+    pg::Slot* s = r->slot;
+    if (r->rc == PG_OK) {
+        const size_t k = c->k;
+        memcpy(out_rows, s->h_out + (size_t)r->index * k * 8, k * 8);
+        memcpy(out_dist, s->h_out + (size_t)c->max_batch * k * 8 + (size_t)r->index * k * 4, k * 4);
+        if (out_count) *out_count = s->run->h_status[1 + r->index];
+    }
+    return pg::finish_call(c, r);
 }
 
 int pg_coalescer_i2i_recall(pg_coalescer* c, uint32_t trigger_row, uint64_t* out_rows, float* out_scores,

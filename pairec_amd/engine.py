@@ -482,6 +482,13 @@ class Coalescer:
         _lib.check(self.ctx.L.pg_coalescer_recall(self.h, _ptr(q), _ptr(rows), _ptr(scores), C.byref(cnt)))
         return rows, scores, cnt.value
 
+    def recall_l2(self, query: np.ndarray):
+        """HologresVectorRecallV2: one request; (rows, squared Euclidean distances ascending, count)."""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(self.table.dim)
+        rows, dist, cnt = self._recall_out()
+        _lib.check(self.ctx.L.pg_coalescer_recall_l2(self.h, _ptr(q), _ptr(rows), _ptr(dist), C.byref(cnt)))
+        return rows, dist, cnt.value
+
     def i2i_recall(self, trigger_row: int):
         rows, scores, cnt = self._recall_out()
         _lib.check(self.ctx.L.pg_coalescer_i2i_recall(self.h, int(trigger_row), _ptr(rows), _ptr(scores), C.byref(cnt)))

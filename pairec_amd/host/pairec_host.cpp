@@ -779,7 +779,13 @@ struct GpuHologresVectorRecallV2 : recall::Recall {
         std::vector<uint64_t> rows(k);
         std::vector<float> dist(k);
         uint32_t cnt = 0;
-        if (pg_recall_topk_l2(e->ctx, e->table, vec.data(), 1, k, rows.data(), dist.data(), &cnt) != PG_OK) return ret;
+        if (e->coalesce) {                                  // concurrent requests share the exact pass (up to 32 per pass)
+            std::string cerr;
+            pg_coalescer* co = e->SceneCoalescer(k, &cerr);
+            if (!co || pg_coalescer_recall_l2(co, vec.data(), rows.data(), dist.data(), &cnt) != PG_OK) return ret;
+        } else if (pg_recall_topk_l2(e->ctx, e->table, vec.data(), 1, k, rows.data(), dist.data(), &cnt) != PG_OK) {
+            return ret;
+        }
         for (uint32_t i = 0; i < cnt; ++i) {
             auto item = std::make_shared<module::Item>(e->IdOfRow(rows[i]));
             item->RetrieveId = conf.Name;

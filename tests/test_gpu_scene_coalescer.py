@@ -180,6 +180,28 @@ def test_coalesced_recalls_of_every_kind_share_passes(ctx, world):
     emb.destroy()
 
 
+def test_coalesced_squared_euclidean_recalls_beside_inner_product_ones(ctx, world):
+    """HologresVectorRecallV2 calls (pg_coalescer_recall_l2) and VectorRecall calls on the same scene coalescer, from 256
+    threads at once: each metric has its own queue and passes (up to 32 squared-Euclidean queries per exact pass), every
+    answer equals the solo call's — ids, order and score / distance bits."""
+    t = world["t"]
+    k = 150
+    q = o.synth_rows(o.SEED_QUERY, 400, CALLERS, 128) * np.linspace(0.6, 1.4, CALLERS, dtype=np.float32)[:, None]
+    co = pa.Coalescer(ctx, t, k, algos=[], max_wait_us=2000)
+    got = [None] * CALLERS
+    run_threads(CALLERS, lambda i: got.__setitem__(i, co.recall_l2(q[i]) if i % 3 else co.recall(q[i])))
+    st = co.stats()
+    co.destroy()
+    sel = list(range(0, CALLERS, 7))
+    rl, dl, _ = t.recall_topk_l2(q[sel], k)
+    rv, sv, _ = t.recall_topk(q[sel], k)
+    for n_, i in enumerate(sel):
+        want = (rl[n_], dl[n_]) if i % 3 else (rv[n_], sv[n_])
+        assert np.array_equal(got[i][0], want[0]) and np.array_equal(bits(got[i][1]), bits(want[1])), i
+        assert got[i][2] == k
+    assert st.requests[0] == CALLERS and st.batches[0] <= CALLERS // 8 + 8
+
+
 def test_coalesced_recommend_with_three_rank_algorithms(ctx, world):
     """RankAlgoList with three entries (two DNNs, one FM + two-tower) and a RankScore over all of them plus
     current_score (rank_service.go:259-289,339-363): the coalesced page against the stages called one by one."""
