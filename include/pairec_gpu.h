@@ -113,7 +113,9 @@ int pg_recall_topk_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, u
 /* HologresVectorRecallV2 (service/recall/hologres_vector_recall_v2.go:23,96-206): the k rows of SMALLEST squared Euclidean
  * distance to each query, ascending, the distance as the item's score (:181-189).  Exact (the reference's Proxima index is
  * approximate): d = fmaf(-2, ip, |x|^2 + |q|^2), each sum a k-ascending fp32 fmaf chain; ties by row ascending; slots beyond
- * the table's rows carry row UINT64_MAX and distance +inf.  dim 64 or 128; the pass streams the fp32 rows (no screen). */
+ * the table's rows carry row UINT64_MAX and distance +inf.  dim 64 or 128.  A dim-128 table whose rows have (nearly) one norm is
+ * served from its int8 shadow with per-block cutoffs (suspects re-scored exactly; knob "l2_max_slack", "l2_exact"), any other
+ * by the exact scan over the fp32 rows. */
 int pg_recall_topk_l2(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
                       float* out_dist, uint32_t* out_count);
 int pg_recall_topk_l2_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,
@@ -497,8 +499,8 @@ int pg_coalescer_recall(pg_coalescer* c, const float* query, uint64_t* out_rows,
                         uint32_t* out_count);
 /* I2IVectorRecall.GetCandidateItems for ONE trigger item (pg_i2i_recall with n = 1): the query is row `trigger_row` of
  * the scene's trigger table; rides the same table pass as the vector recalls of other callers. */
-/* HologresVectorRecallV2 through the coalescer: one request per call, up to 32 share one pass of the exact squared-Euclidean
- * scan (pg_recall_topk_l2: a pass costs the same for 32 queries as for one); out_dist ascending. */
+/* HologresVectorRecallV2 through the coalescer: one request per call, up to 128 share one screened pass (32 one pass of the
+ * exact scan, where the table needs that: pg_recall_topk_l2); out_dist ascending. */
 int pg_coalescer_recall_l2(pg_coalescer* c, const float* query, uint64_t* out_rows, float* out_dist, uint32_t* out_count);
 int pg_coalescer_i2i_recall(pg_coalescer* c, uint32_t trigger_row, uint64_t* out_rows, float* out_scores,
                             uint32_t* out_count);

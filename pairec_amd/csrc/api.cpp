@@ -31,6 +31,8 @@ static void knobs_from_env(Knobs* k) {
     k->predict_sigmas = num("PG_PREDICT_SIGMAS", 4.5);
     k->predict_min_rows = (uint32_t)num("PG_PREDICT_MIN_ROWS", (double)(1u << 22));
     k->screen_early_share = (uint32_t)num("PG_SCREEN_EARLY_SHARE", 604);
+    k->l2_exact = flag("PG_L2_EXACT");
+    k->l2_max_slack = num("PG_L2_MAX_SLACK", 0.15);
     k->screen_early_share_narrow = (uint32_t)num("PG_SCREEN_EARLY_SHARE_NARROW", 512);
 }
 
@@ -150,6 +152,8 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "predict_sigmas") k.predict_sigmas = v;
     else if (n == "predict_min_rows") k.predict_min_rows = (uint32_t)v;
     else if (n == "screen_early_share") k.screen_early_share = (uint32_t)v;
+    else if (n == "l2_exact") k.l2_exact = b;
+    else if (n == "l2_max_slack") k.l2_max_slack = v;
     else if (n == "screen_early_share_narrow") k.screen_early_share_narrow = (uint32_t)v;
     else {
         pg::set_error("pg_set_option: unknown option \"%s\"", name);

@@ -52,7 +52,9 @@ using Clock = std::chrono::steady_clock;
 
 enum Flavour { kRecall = 0, kRank = 1, kRecommend = 2, kDpp = 3, kSsd = 4 };      // statistics index
 enum Queue { kQRecall = 0, kQRecommend = 1, kQDpp = 2, kQRecallL2 = 3, kQRank0 = 4 };     // kQRank0 + algorithm index
-constexpr uint32_t kL2Batch = 32;      // squared-Euclidean recalls per pass: the exact scan serves 32 queries at the price of one
+constexpr uint32_t kL2Batch = 32;      // squared-Euclidean recalls per pass: the exact scan serves 32 queries at the price of one;
+                                       // 128 when the table has an int8 shadow (the screened pass)
+inline uint32_t l2_batch_limit(const pg_coalescer* c);
 constexpr int kNumQueues = kQRank0 + kMaxAlgos;
 enum QueryKind : uint32_t { kVector = 0, kTrigger = 1, kOnline = 2 };
 enum ReqState : uint32_t { kQueued = 0, kStaging = 1, kStaged = 2, kDone = 3, kAbandoned = 4 };
@@ -233,6 +235,11 @@ struct pg_coalescer {
 namespace pg {
 namespace {
 
+inline uint32_t l2_batch_limit(const pg_coalescer* c) {
+    const bool screened = c->t->dim == 128 && c->t->stats_valid && c->t->all_finite && c->t->shadow_is_i8 && c->t->nx_valid &&
+                          c->t->l2_slack <= c->ctx->knobs.l2_max_slack;
+    return std::min(c->max_batch, screened ? 128u : kL2Batch);
+}
 int flavour_of(int queue) {
     return (queue == kQRecall || queue == kQRecallL2) ? kRecall : (queue == kQRecommend ? kRecommend : (queue == kQDpp ? kDpp : kRank));
 }
@@ -592,7 +599,7 @@ void take_batch(pg_coalescer* c, int kind, Slot* s) {
         }
         s->n_items = (uint32_t)s->reqs.size() * s->key.n;
     } else {
-        const uint32_t limit = kind == kQRecallL2 ? std::min(c->max_batch, kL2Batch) : c->max_batch;
+        const uint32_t limit = kind == kQRecallL2 ? l2_batch_limit(c) : c->max_batch;
         while (!q.empty() && s->reqs.size() < limit) {
             s->reqs.push_back(q.front());
             q.pop_front();
@@ -678,7 +685,7 @@ void dispatcher_main(pg_coalescer* c) {
             } else if (f == kQDpp) {
                 full = qf.size() >= dpp_batch_limit(c, qf.front()->key.n);
             } else {
-                full = qf.size() >= (f == kQRecallL2 ? std::min(c->max_batch, kL2Batch) : c->max_batch);
+                full = qf.size() >= (f == kQRecallL2 ? l2_batch_limit(c) : c->max_batch);
             }
             const uint32_t wait_us = c->gap_ewma_us[f] > (double)c->max_wait_us ? 0u : c->max_wait_us;
             const auto deadline = qf.front()->arrived + std::chrono::microseconds(wait_us);

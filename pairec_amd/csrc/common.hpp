@@ -76,6 +76,8 @@ struct Knobs {
     double predict_sigmas = 4.5;   // PG_PREDICT_SIGMAS: margin of the predicted threshold, in standard deviations of the observed quantile
     uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way
     uint32_t screen_early_share_narrow = 512;   // PG_SCREEN_EARLY_SHARE_NARROW: the same for the 8-wave kernels of <= 128 queries
+    bool l2_exact = false;                  // PG_L2_EXACT: squared-Euclidean recalls always on the exact scan (A/B runs)
+    double l2_max_slack = 0.15;             // PG_L2_MAX_SLACK: largest pg_table::l2_slack the screened squared-Euclidean pass is used for
     uint32_t screen_early_share = 604;      // PG_SCREEN_EARLY_SHARE: share (x 1024) of a SIMD's blocks given to its older wave (256-query screen)
 };
 
@@ -108,7 +110,9 @@ struct pg_table {
     float resid8 = 0.0f;         // upper bound of the rows' quantisation residual (L2)
     bool shadow_failed = false;  // allocation failed once: stay on the exact scan
     float* d_nx = nullptr;       // squared-Euclidean recall: |x|^2 of every row [rows + 64] (lazily, invalidated by upload / fill)
+    float* d_nxmin = nullptr;    // ... and the smallest of every 32-row block (the int8 screen's per-block cutoff under that metric)
     bool nx_valid = false;
+    float l2_slack = 0.0f;       // mean (|x|^2 - the block's smallest) / 2 in units of the score spread: above Knobs::l2_max_slack the exact scan serves that metric
     // recall_i4.hip: the 4-bit shadow that the full pass of a small batch streams (dim 128, built on the first such
     // recall, 68 B per row): nibbles [rows + 64][64 B], one fp32 scale per row, and the bound's measured constants
     uint8_t* d4 = nullptr;

@@ -433,6 +433,10 @@ struct ScreenArgs {
     char* rec_pool;           // [rec_pool_cap] records: where a wave whose region is full puts its staged records
     uint32_t rec_pool_cap, rec_waves;
     uint32_t early_share;     // 8-wave variants: share (x 1024) of a SIMD's blocks that goes to its older wave; 512 = even
+    // squared-Euclidean recall on the int8 screen (L2 = true, <= 128 queries): a pair is a suspect iff
+    // I >= floor(A_q + B_q * min|x|^2 of the block) - 2, with thr_screen = A_q (float) and l2_b = B_q (screen_thr8_l2_kernel)
+    const float* blk_nxmin;   // [blocks] smallest |x|^2 of every physical 32-row block (pg_table::d_nxmin)
+    const float* l2_b;        // [256]
 #ifdef PG_SCREEN_PROFILE
     unsigned long long* prof; // [waves][8]
 #endif
@@ -472,8 +476,9 @@ constexpr uint32_t kRecBytes = 80;
 // QH: query halves — the wave serves NQB x QH query blocks, QH groups of NQB one after the other on the same table
 // block, re-using the accumulators (int8, 256 queries: 2 x 4 blocks in 8 waves — two waves per SIMD, so one
 // wave's test, hit path and DMA issue run under the other's MFMAs; all 128 B-operand registers in the AGPR half).
-template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1>
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1, bool L2 = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArgs a) {
+    static_assert(!L2 || (I8 && QH == 1 && SPLIT == 1), "squared-Euclidean screen: the int8 kernels of <= 128 queries");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the kernel streams the table's shadow: a piece is 32 rows x one 128-B line per row (64 bf16 / 128 int8)
     constexpr int EB = I8 ? 1 : 2;               // bytes per shadow element
@@ -509,6 +514,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
     uint4 bfrag[NQT][KS];
     ThrT thr_s[NQT];
     float eu[NQT];                                    // bf16: eps_unit of this lane's query, per query block
+    float la[NQT];                                    // L2: A_q
     bool active[NQT];
     char* const b_lds = smem + kScreenLds - kBLds;
     if constexpr (QH > 1) {
@@ -529,6 +535,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         if constexpr (I8) thr_s[c] = active[c] ? __float_as_int(a.thr_screen[(qb0 + c) * 32 + i32]) : 0x7fffffff;
         else thr_s[c] = active[c] ? a.thr_screen[(qb0 + c) * 32 + i32] : __builtin_inff();
         eu[c] = (!I8 && active[c]) ? a.eps_unit[(qb0 + c) * 32 + i32] : 0.0f;
+        if constexpr (L2) {                           // A_q in la, B_q in eu (inactive columns: never a suspect)
+            la[c] = active[c] ? a.thr_screen[(qb0 + c) * 32 + i32] : __builtin_inff();
+            eu[c] = active[c] ? a.l2_b[(qb0 + c) * 32 + i32] : 0.0f;
+        }
     }
 #pragma unroll
     for (int c = 0; c < NQT; ++c) {
@@ -541,7 +551,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 asm volatile("" : "+v"(bfrag[c][ks].x), "+v"(bfrag[c][ks].y), "+v"(bfrag[c][ks].z), "+v"(bfrag[c][ks].w));
         }
         asm volatile("" : "+v"(thr_s[c]));
-        if (!I8) asm volatile("" : "+v"(eu[c]));
+        if (!I8 || L2) asm volatile("" : "+v"(eu[c]));
+        if (L2) asm volatile("" : "+v"(la[c]));
     }
 
     uint32_t voff[ND];
@@ -867,7 +878,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         // bf16: this block's cutoffs, cut = thr - eps_unit x (largest row norm of the block), rounded down (the margin
         // term is kept finite so that +-inf thresholds stay what they are)
         ThrT cut[NQB];
-        if constexpr (I8) {
+        if constexpr (L2) {
+            // the block's integer cutoffs: floor(A_q + B_q * (smallest |x|^2 of the block)) - 2 (rounded down twice over;
+            // -inf / NaN / below the int range: everything is a suspect)
+            const float nxm = a.blk_nxmin[cur_phys];
+#pragma unroll
+            for (int c = 0; c < NQB; ++c) {
+                const float v = __fmaf_rn(eu[c], nxm, la[c]);
+                // (-inf or NaN: everything is a suspect; +inf — an inactive query column — or beyond the int range: nothing is)
+                cut[c] = !(v > -2.0e9f) ? (int)0x80000000
+                                        : (v >= 2.0e9f ? 0x7fffffff : __float2int_rd(v - fabsf(v) * 2.4e-7f - 2.0f));
+            }
+        } else if constexpr (I8) {
 #pragma unroll
             for (int c = 0; c < NQB; ++c) cut[c] = thr_s[c];
         } else {
@@ -1080,13 +1102,15 @@ __device__ __forceinline__ void rescore_walk(const f32x4 (&buf)[16], char* my, c
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int DIM>
+// (L2: the exact inner product is turned into -d = fmaf(2, ip, -(|x|^2 + |q|^2)) before the threshold test and the key)
+template <int DIM, bool L2 = false>
 __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ tab, const float* __restrict__ qpad,
                                                       const float* __restrict__ thr,
                                                       const uint32_t* __restrict__ susp,
                                                       const uint32_t* __restrict__ susp_cnt, uint32_t cap,
                                                       uint32_t* __restrict__ cnt, uint64_t* __restrict__ cand,
-                                                      uint32_t* __restrict__ overflow, uint32_t scap) {
+                                                      uint32_t* __restrict__ overflow, uint32_t scap,
+                                                      const float* __restrict__ nx = nullptr, const float* __restrict__ nqv = nullptr) {
     // (scap: capacity and stride of the suspect lists; cap: of the candidate lists)
     constexpr int kRowB = 64 * 4 + 16;                 // 64 columns per phase, padded: conflict-free b128 column walks
     __shared__ __attribute__((aligned(16))) char tile[4][64 * kRowB];
@@ -1134,6 +1158,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 16; ++i) va[i] = vb[i];
         }
+        if constexpr (L2) s = __fmaf_rn(2.0f, s, -(nx[row] + nqv[q]));
         const bool keep = valid && !(s < thr_q);
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1290,6 +1315,60 @@ __global__ void screen_thr8_kernel(const float* __restrict__ thr, const float* _
         T = v >= 2147483647.0 ? 0x7fffffff : (v <= -2147483648.0 ? (int)0x80000000 : (int)v);
     }
     thr_screen[q] = __int_as_float(T);
+}
+
+// Squared-Euclidean recall on the int8 screen.  A pair can reach the threshold thr (in -d units) only if, in exact arithmetic,
+// 2 ip - |x|^2 - |q|^2 >= thr - delta (delta: the rounding of the specification's own fp32 evaluation of -d), i.e.
+// ip >= (thr - delta + |q|^2) / 2 + |x|^2 / 2; with ip <= s_x s_q I + eps_q (the inner-product screen's bound) and |x|^2 >= the
+// block's smallest: I >= A_q + B_q min|x|^2,  A_q = ((thr - delta + |q|^2) / 2 - eps_q) / (s_x s_q),  B_q = 1 / (2 s_x s_q).
+// Both are rounded down here, the kernel rounds the sum down again.  thr = -inf (or anything odd): A_q = -inf, everything passes.
+__global__ void screen_thr8_l2_kernel(const float* __restrict__ thr, const float* __restrict__ eps, const float* __restrict__ qscale,
+                                      const float* __restrict__ nqv, float s_x, float max_norm, float* __restrict__ a_out,
+                                      float* __restrict__ b_out) {
+    const uint32_t q = threadIdx.x;
+    if (q >= (uint32_t)kMaxQueries) return;
+    const float t = thr[q], e = eps[q];
+    const double nq = (double)nqv[q], N = (double)max_norm;
+    const double sq = (double)s_x * (double)qscale[q];
+    float A = -__builtin_inff(), B = 0.0f;
+    if (e == e && e <= 1e30f && t == t && t > -__builtin_inff() && sq > 0.0 && nq == nq && nq < 1e30) {
+        const double delta = 2e-6 * (N * N + nq + 2.0 * N * sqrt(nq)) + 1e-30;
+        const double a = (((double)t - delta + nq) * 0.5 - (double)e) / sq;
+        const double b = 0.5 / sq;
+        A = (float)(a - fabs(a) * 1e-6 - 1.0);
+        B = (float)(b * (1.0 - 1e-6));
+        if (!(A == A) || !(B == B) || B > 1e30f) { A = -__builtin_inff(); B = 0.0f; }
+    }
+    a_out[q] = A;
+    b_out[q] = B;
+}
+// smallest |x|^2 of every 32-row block (rows past the table's end do not count)
+// stats[0] += sum over rows of (|x|^2 - the block's smallest), stats[1] += sum of |x|^2: how much the per-block cutoff gives away
+__global__ void block_nxmin_kernel(const float* __restrict__ nx, uint64_t rows, float* __restrict__ out, uint32_t nblocks,
+                                   double* __restrict__ stats) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    double slack = 0.0, sum = 0.0;
+    if (b < nblocks) {
+        float m = __builtin_inff();
+        for (uint32_t i = 0; i < (uint32_t)kPieceRows; ++i) {
+            const uint64_t r = (uint64_t)b * kPieceRows + i;
+            if (r < rows) m = fminf(m, nx[r]);
+        }
+        m = m == m ? m : 0.0f;                       // (a NaN norm: no help from this block)
+        out[b] = m;
+        for (uint32_t i = 0; i < (uint32_t)kPieceRows; ++i) {
+            const uint64_t r = (uint64_t)b * kPieceRows + i;
+            if (r < rows && nx[r] == nx[r] && nx[r] < 1e30f) { slack += (double)nx[r] - (double)m; sum += (double)nx[r]; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        slack += __shfl_xor(slack, off, 64);
+        sum += __shfl_xor(sum, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && sum > 0.0) {
+        atomicAdd(&stats[0], slack);
+        atomicAdd(&stats[1], sum);
+    }
 }
 
 // Table statistics without a shadow (first pass of the int8 build): max |x|, max row L2 norm^2, finiteness.
@@ -2179,10 +2258,10 @@ static int ensure_pred_model(pg_ctx* ctx, const pg_table* tc) {
     return PG_OK;
 }
 
-template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1>
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1, bool L2 = false>
 static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     int rc_attr;
-    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH>, kScreenLds))) return rc_attr;
+    if ((rc_attr = ensure_dyn_lds(ctx, (const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH, L2>, kScreenLds))) return rc_attr;
     const uint32_t total = a.rb_end - a.rb_begin;
     uint32_t grid = (uint32_t)ctx->num_cus;
     const uint32_t need = (total * SPLIT + WAVES - 1) / WAVES;
@@ -2193,7 +2272,7 @@ static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
         if (!dbg) hipMalloc(&dbg, 4096 * 64);
         ScreenArgs b = a;
         b.prof = dbg;
-        screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(b);
+        screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH, L2><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(b);
         static int calls = 0;
         if (total > 2000000 && ++calls == 12) {
             std::vector<unsigned long long> h(4096 * 8);
@@ -2205,13 +2284,18 @@ static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
         return PG_OK;
     }
 #endif
-    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
+    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH, L2><<<grid, 64 * WAVES, kScreenLds, ctx->stream>>>(a);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
 
 static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs& a) {
     const bool wide = a.nq > 128;
+    if (a.blk_nxmin) {                               // squared-Euclidean recall: int8 shadow, <= 128 queries (recall_job_prepare)
+        if (a.nq <= 32) return launch_screen<128, 1, 8, 1, 0, true, 1, true>(ctx, a);
+        if (a.nq <= 64) return launch_screen<128, 2, 8, 1, 0, true, 1, true>(ctx, a);
+        return launch_screen<128, 4, 8, 1, 0, true, 1, true>(ctx, a);
+    }
     if (i8) {                                        // int8 shadow (dim 128)
 #ifdef PG_SCAN_VARIANTS
         const char* v = getenv("PG_SCREEN_VAR");     // developer ablation builds only
@@ -2286,11 +2370,28 @@ static int ensure_table_nx(pg_ctx* ctx, const pg_table* tc) {
     pg_table* t = const_cast<pg_table*>(tc);
     std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
     if (t->nx_valid) return PG_OK;
+    const uint32_t nblocks = (uint32_t)((t->rows + kPieceRows - 1) / kPieceRows);
     if (!t->d_nx) PG_HIP(hipMalloc((void**)&t->d_nx, (t->rows + 64) * sizeof(float)));
+    if (!t->d_nxmin) PG_HIP(hipMalloc((void**)&t->d_nxmin, ((size_t)nblocks + 64) * sizeof(float)));
     PG_HIP(hipMemsetAsync(t->d_nx + t->rows, 0, 64 * sizeof(float), ctx->stream));
+    PG_HIP(hipMemsetAsync(t->d_nxmin + nblocks, 0, 64 * sizeof(float), ctx->stream));
     row_norm2_kernel<<<(uint32_t)((t->rows + 255) / 256), 256, 0, ctx->stream>>>(t->d, t->rows, t->dim, t->d_nx);
+    void* p;
+    int rc;
+    if ((rc = scratch_reserve(ctx, 4, 4096, &p))) return rc;
+    double* d_st = reinterpret_cast<double*>((char*)p + 2048);
+    PG_HIP(hipMemsetAsync(d_st, 0, 16, ctx->stream));
+    block_nxmin_kernel<<<(nblocks + 255) / 256, 256, 0, ctx->stream>>>(t->d_nx, t->rows, t->d_nxmin, nblocks, d_st);
     PG_HIP(hipGetLastError());
+    double h_st[2] = {0.0, 0.0};
+    PG_HIP(hipMemcpyAsync(h_st, d_st, 16, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
+    // What the per-block cutoff gives away: a row's cutoff sits (|x|^2 - min of its block) / 2 below its own, in inner-product
+    // units whose spread over the table is about |x| |q| / sqrt(dim) ~ mean|x|^2 / sqrt(dim) for queries like the rows.  Normalised
+    // rows: 0.  N(0, 1) rows: 1.5 spreads — then nearly every block holds suspects and the exact scan is the faster pass.
+    const double mean_nx = t->rows ? h_st[1] / (double)t->rows : 0.0;
+    t->l2_slack = mean_nx > 0.0 ? (float)((h_st[0] / (double)t->rows) * 0.5 / (mean_nx / sqrt((double)t->dim))) : 0.0f;
+    if (ctx->knobs.debug_scan) fprintf(stderr, "[pg] squared-Euclidean recall: per-block cutoff slack %.3f score spreads\n", t->l2_slack);
     t->nx_valid = true;
     return PG_OK;
 }
@@ -2322,11 +2423,13 @@ int recall_job_prepare(RecallJob* j) {
     // Policy: finite tables of dim <= 128 use the screened scan (int8 or bf16 filter + exact re-scoring) for every
     // batch size (knobs.screen_min = 0), HBM-bound up to 128 queries per pass; everything else rides the exact
     // fp32-MFMA scan in groups of <= 64 queries, one launch per group.
-    bool screen = j->nq > kn.screen_min && t->dim <= 128 && !kn.recall_exact && !j->l2;      // (squared Euclidean: exact scan only)
+    bool screen = j->nq > kn.screen_min && t->dim <= 128 && !kn.recall_exact;
     if (screen) {
         if ((rc = ensure_table_stats(ctx, t))) return rc;
         if (!t->stats_valid || !t->all_finite) screen = false;      // no shadow (dim, memory) or non-finite rows
     }
+    // squared Euclidean: the int8 screen with per-block cutoffs for up to 128 queries (dim 128, int8 shadow); else the exact scan
+    if (j->l2 && !(screen && t->dim == 128 && t->shadow_is_i8 && j->nq <= 128 && !kn.l2_exact && t->l2_slack <= kn.l2_max_slack)) screen = false;
     j->screen = screen;
     j->screen4 = false;
     j->n_plans = 0;
@@ -2360,7 +2463,7 @@ int recall_job_prepare(RecallJob* j) {
     j->plans[j->n_plans++] = kSafe;
     if (j->skip_pilot && j->plans[0] == kPilot) j->next_plan = 1;    // the re-run of a query a sampled threshold failed
     // small batches: the pilot plan's full pass is HBM-bound on the shadow it streams — use the 4-bit one (recall_i4.hip)
-    if (screen && t->dim == 128 && j->nq <= kI4MaxQueries && j->plans[0] == kPilot && !kn.no_screen_i4 &&
+    if (screen && !j->l2 && t->dim == 128 && j->nq <= kI4MaxQueries && j->plans[0] == kPilot && !kn.no_screen_i4 &&
         rows >= kn.i4_min_rows && (uint64_t)kMaxQueries * rs_cap_bound(j->k) / kI4MaxQueries < 0xFFFFFFFFull) {
         if ((rc = ensure_table_i4(ctx, t))) return rc;
         // (measured at 100M x 128, int8 pass 2.1 ms: uniform rows, lambda 0.8: 1.37 / 1.38 / 1.59 / 1.66 ms at 1..4
@@ -2373,7 +2476,7 @@ int recall_job_prepare(RecallJob* j) {
     j->predict = j->pred_observe = false;
     // (batches of <= 4 queries too: their full pass — the 4-bit shadow's — takes the same float thresholds, and the pilot's five
     //  launches are 0.15 ms of a lone request's 1.45)
-    if (screen && t->dim == 128 && t->shadow_is_i8 && j->plans[0] == kPilot && !j->skip_pilot && !kn.no_predict &&
+    if (screen && !j->l2 && t->dim == 128 && t->shadow_is_i8 && j->plans[0] == kPilot && !j->skip_pilot && !kn.no_predict &&
         rows >= kn.predict_min_rows && j->k < rows / 64) {
         if ((rc = ensure_pred_model(ctx, t))) return rc;
         pg_table* tm = const_cast<pg_table*>(t);
@@ -2459,6 +2562,8 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             sa.rec_pool = nullptr;
             sa.rec_pool_cap = sa.rec_waves = 0;
             sa.early_share = records ? ctx->knobs.screen_early_share : ctx->knobs.screen_early_share_narrow;
+            sa.blk_nxmin = j->l2 ? t->d_nxmin : nullptr;
+            sa.l2_b = j->l2 ? rs.thr_ref : nullptr;    // (no refinement step under this metric: its buffer carries B_q)
             const uint32_t rec_waves = (uint32_t)ctx->num_cus * 8u;
             if (records) {
                 // a region per wave: four times the share of 256 x K suspects a wave expects, never below the 2 048 records the
@@ -2503,7 +2608,10 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             j->scanned_rows += (uint64_t)cb * kPieceRows;
             // exact re-scoring of the launch's suspects → candidate keys (grid.x strides over each list)
             const dim3 rg(i4 ? screen4_rescore_blocks() : kRescoreBlocksPerQuery, nq);
-            if (t->dim == 64)
+            if (j->l2)
+                rescore_kernel<128, true><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap, rs.cnt,
+                                                                       rs.cand[cur], rs.overflow, scap, t->d_nx, rs.pred_ms);
+            else if (t->dim == 64)
                 rescore_kernel<64><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap,
                                                                 rs.cnt, rs.cand[cur], rs.overflow, scap);
             else
@@ -2532,7 +2640,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             a.perm_mul = j->perm_mul;
             a.perm_mod = j->sample_blocks;
             a.nx = j->l2 ? t->d_nx : nullptr;
-            a.nqv = j->l2 ? rs.eps : nullptr;          // (the screen's per-query margins are not in use: no screen)
+            a.nqv = j->l2 ? rs.pred_ms : nullptr;
             int rc2;
             if ((rc2 = dispatch_scan(ctx, t->dim, a))) return rc2;
             j->scan_bytes += (uint64_t)cb * kPieceRows * t->dim * 4;
@@ -2547,7 +2655,9 @@ struct PlanRun {                     // the launches of one plan (helper of reca
         int rc2;
         if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk, 0))) return rc2;
         if (j->screen && !no_i8) {
-            if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
+            if (j->l2) screen_thr8_l2_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, rs.pred_ms, t->s8, t->max_norm,
+                                                                                rs.thr_screen, rs.thr_ref);
+            else if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
             else screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, t->max_norm, rs.thr_screen);
             PG_HIP(hipGetLastError());
         }
@@ -2614,7 +2724,7 @@ int recall_job_enqueue(RecallJob* j) {
         j->d_queries, j->nq, t->dim, rs.qpad, rs.thr, rs.cnt, rs.overflow);
     PG_HIP(hipGetLastError());
     if (j->l2) {
-        query_norm2_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.qpad, t->dim, rs.eps);
+        query_norm2_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.qpad, t->dim, rs.pred_ms);      // (the threshold model is off: its buffer is free)
         PG_HIP(hipGetLastError());
     }
     // thresholds predicted and the full pass on the 4-bit shadow: the plan launches no int8 screen, so neither the int8 query
@@ -2695,7 +2805,7 @@ int recall_job_enqueue(RecallJob* j) {
         const uint32_t k2 = (uint32_t)ceil(m2 + kn.pilot_sigmas * sqrt(m2) + 8.0);
         // (not behind a predicted threshold: that one already sits tighter than what a quarter of the table can certify —
         //  rank ~1.1 K against k2's ~1.18 K — so the split would only add a launch boundary)
-        const bool refine = j->screen && !j->screen4 && !kn.no_refine && j->rows >= kn.refine_min_rows && nb_q >= 64 &&
+        const bool refine = j->screen && !j->l2 && !j->screen4 && !kn.no_refine && j->rows >= kn.refine_min_rows && nb_q >= 64 &&
                             k2 < j->k && t->prefix_failures < 2 && plan != kPredict;
         if (refine) {
             if ((rc = r.scan_range(0, nb_q, 1, false, true))) return rc;
@@ -2993,7 +3103,14 @@ int pg_recall_topk_l2_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries
     }
     std::lock_guard<std::mutex> g(ctx->mu);
     pg::TableRead tr(t->rw);
-    return pg::recall_dev_locked(ctx, t, d_queries, nq, k, d_out_rows, d_out_dist, out_count, nullptr, false, true);
+    // (the screened pass serves up to 128 queries; the exact scan runs groups of 64 either way: at most 128 per job)
+    for (uint32_t q0 = 0; q0 < nq; q0 += 128) {
+        const uint32_t n = nq - q0 < 128 ? nq - q0 : 128;
+        const int rc = pg::recall_dev_locked(ctx, t, d_queries + (size_t)q0 * t->dim, n, k, d_out_rows + (size_t)q0 * k,
+                                             d_out_dist + (size_t)q0 * k, out_count ? out_count + q0 : nullptr, nullptr, false, true);
+        if (rc) return rc;
+    }
+    return PG_OK;
 }
 
 int pg_recall_topk_l2(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
@@ -3014,7 +3131,12 @@ int pg_recall_topk_l2(pg_ctx* ctx, const pg_table* t, const float* queries, uint
     uint64_t* d_rows = (uint64_t*)((char*)buf + ((qb + 15) & ~(size_t)15));
     float* d_sc = (float*)((char*)d_rows + rb);
     PG_HIP(hipMemcpyAsync(d_q, queries, qb, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = pg::recall_dev_locked(ctx, t, d_q, nq, k, d_rows, d_sc, out_count, nullptr, false, true))) return rc;
+    for (uint32_t q0 = 0; q0 < nq; q0 += 128) {
+        const uint32_t n = nq - q0 < 128 ? nq - q0 : 128;
+        if ((rc = pg::recall_dev_locked(ctx, t, d_q + (size_t)q0 * t->dim, n, k, d_rows + (size_t)q0 * k, d_sc + (size_t)q0 * k,
+                                        out_count ? out_count + q0 : nullptr, nullptr, false, true)))
+            return rc;
+    }
     PG_HIP(hipMemcpyAsync(out_rows, d_rows, rb, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipMemcpyAsync(out_dist, d_sc, sb, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));

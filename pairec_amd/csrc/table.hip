@@ -127,6 +127,7 @@ int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
     if (t->dnorm2) PG_HIP(hipFree(t->dnorm2));
     if (t->d_pred) PG_HIP(hipFree(t->d_pred));
     if (t->d_nx) PG_HIP(hipFree(t->d_nx));
+    if (t->d_nxmin) PG_HIP(hipFree(t->d_nxmin));
     delete t;
     return PG_OK;
 }
@@ -234,6 +235,8 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->prefix_failures, b->prefix_failures);
     std::swap(a->d_pred, b->d_pred);
     std::swap(a->d_nx, b->d_nx);
+    std::swap(a->d_nxmin, b->d_nxmin);
+    std::swap(a->l2_slack, b->l2_slack);
     std::swap(a->nx_valid, b->nx_valid);
     std::swap(a->pred_model, b->pred_model);
     std::swap(a->pred_k, b->pred_k);

@@ -431,6 +431,42 @@ def test_recall_l2_matches_oracle_bitexact(ctx, n, d, k, nq):
     t.destroy()
 
 
+def test_recall_l2_screened_pass_on_rows_of_equal_norm(ctx):
+    """Squared-Euclidean recall of a dim-128 table whose rows have (nearly) one norm: the pass streams the int8 shadow with
+    per-block integer cutoffs (csrc/recall.hip, screen_thr8_l2_kernel) and re-scores the suspects exactly — ids, order
+    and distance bits still the oracle's, no plan fails (inactive query columns must not produce suspects), and the pass
+    reads a quarter of the fp32 bytes.  Rows of very different norms send the same call to the exact scan."""
+    n, d, k = 1_200_000, 128, 400
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    tab[500:532] = tab[500]                                     # a block of duplicates: ties by row id
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    assert t.screen_info()[0] == 1
+    for nq in (1, 3, 40, 128, 200):
+        q = o.synth_rows(o.SEED_QUERY, 50, nq, d) * np.float32(1.7)
+        q[0] = tab[500]
+        before = ctx.stats().recall_rescans
+        rows, dist, cnt = t.recall_topk_l2(q, k)
+        assert ctx.stats().recall_rescans == before, nq
+        _, nbytes = ctx.last_scan_kernel()
+        assert nbytes < n * d * 2, (nq, nbytes)                # the int8 shadow (+ samples), not the fp32 rows
+        sel = sorted(set([0, nq - 1, nq // 2]))
+        orow, od = o.recall_topk_l2(tab, q[sel], k)
+        assert np.array_equal(rows[sel], orow) and np.array_equal(bits(dist[sel]), bits(od)), nq
+    assert rows[0, :32].tolist() == list(range(500, 532))
+    # norms spread over a factor of four: the per-block cutoff would give too much away → exact scan, same answers
+    scaled = tab * np.linspace(0.5, 2.0, n, dtype=np.float32)[::-1, None].copy()
+    rng = np.random.default_rng(3)
+    scaled = scaled[rng.permutation(n)]
+    t.upload(scaled)
+    q = o.synth_rows(o.SEED_QUERY, 9, 5, d)
+    rows, dist, _ = t.recall_topk_l2(q, k)
+    assert ctx.last_scan_kernel()[1] >= n * d * 4
+    orow, od = o.recall_topk_l2(scaled, q, k)
+    assert np.array_equal(rows, orow) and np.array_equal(bits(dist), bits(od))
+    t.destroy()
+
+
 def test_recall_follows_table_updates(ctx):
     """The screen streams a quantised shadow (int8 here) of the table that is built lazily; uploads, synthetic fills and
     hot swaps must invalidate / carry it — every recall answers for the rows the table holds now."""
