@@ -32,7 +32,7 @@ static void knobs_from_env(Knobs* k) {
     k->predict_min_rows = (uint32_t)num("PG_PREDICT_MIN_ROWS", (double)(1u << 22));
     k->screen_early_share = (uint32_t)num("PG_SCREEN_EARLY_SHARE", 604);
     k->l2_exact = flag("PG_L2_EXACT");
-    k->l2_max_slack = num("PG_L2_MAX_SLACK", 0.15);
+    k->l2_max_slack = num("PG_L2_MAX_SLACK", 1.0);
     k->screen_early_share_narrow = (uint32_t)num("PG_SCREEN_EARLY_SHARE_NARROW", 512);
 }
 

@@ -454,7 +454,7 @@ def test_recall_l2_screened_pass_on_rows_of_equal_norm(ctx):
         orow, od = o.recall_topk_l2(tab, q[sel], k)
         assert np.array_equal(rows[sel], orow) and np.array_equal(bits(dist[sel]), bits(od)), nq
     assert rows[0, :32].tolist() == list(range(500, 532))
-    # norms spread over a factor of four: the per-block cutoff would give too much away → exact scan, same answers
+    # norms spread over a factor of four (slack ~ 8 score spreads): the per-block cutoff would give too much away → exact scan, same answers
     scaled = tab * np.linspace(0.5, 2.0, n, dtype=np.float32)[::-1, None].copy()
     rng = np.random.default_rng(3)
     scaled = scaled[rng.permutation(n)]
