@@ -113,9 +113,9 @@ int pg_recall_topk_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, u
 /* HologresVectorRecallV2 (service/recall/hologres_vector_recall_v2.go:23,96-206): the k rows of SMALLEST squared Euclidean
  * distance to each query, ascending, the distance as the item's score (:181-189).  Exact (the reference's Proxima index is
  * approximate): d = fmaf(-2, ip, |x|^2 + |q|^2), each sum a k-ascending fp32 fmaf chain; ties by row ascending; slots beyond
- * the table's rows carry row UINT64_MAX and distance +inf.  dim 64 or 128.  A dim-128 table whose rows have (nearly) one norm is
- * served from its int8 shadow with per-block cutoffs (suspects re-scored exactly; knob "l2_max_slack", "l2_exact"), any other
- * by the exact scan over the fp32 rows. */
+ * the table's rows carry row UINT64_MAX and distance +inf.  dim 64 or 128.  A dim-128 table with an int8 shadow is served from
+ * it — one integer cutoff per 32-row block where the rows have (nearly) one norm, a per-row test otherwise (knob "l2_max_slack");
+ * suspects are re-scored exactly — any other table (and knob "l2_exact") by the exact scan over the fp32 rows. */
 int pg_recall_topk_l2(pg_ctx* ctx, const pg_table* t, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows,
                       float* out_dist, uint32_t* out_count);
 int pg_recall_topk_l2_dev(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq, uint32_t k, uint64_t* d_out_rows,

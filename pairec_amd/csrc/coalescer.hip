@@ -236,8 +236,7 @@ namespace pg {
 namespace {
 
 inline uint32_t l2_batch_limit(const pg_coalescer* c) {
-    const bool screened = c->t->dim == 128 && c->t->stats_valid && c->t->all_finite && c->t->shadow_is_i8 && c->t->nx_valid &&
-                          c->t->l2_slack <= c->ctx->knobs.l2_max_slack;
+    const bool screened = c->t->dim == 128 && c->t->stats_valid && c->t->all_finite && c->t->shadow_is_i8 && !c->ctx->knobs.l2_exact;
     return std::min(c->max_batch, screened ? 128u : kL2Batch);
 }
 int flavour_of(int queue) {

@@ -77,7 +77,7 @@ struct Knobs {
     uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way
     uint32_t screen_early_share_narrow = 512;   // PG_SCREEN_EARLY_SHARE_NARROW: the same for the 8-wave kernels of <= 128 queries
     bool l2_exact = false;                  // PG_L2_EXACT: squared-Euclidean recalls always on the exact scan (A/B runs)
-    double l2_max_slack = 1.0;              // PG_L2_MAX_SLACK: largest pg_table::l2_slack the screened squared-Euclidean pass is used for
+    double l2_max_slack = 1.0;              // PG_L2_MAX_SLACK: largest pg_table::l2_slack the per-BLOCK cutoff is used for (above: the per-row test)
     uint32_t screen_early_share = 604;      // PG_SCREEN_EARLY_SHARE: share (x 1024) of a SIMD's blocks given to its older wave (256-query screen)
 };
 
@@ -244,7 +244,8 @@ struct RecallJob {
     uint32_t* h_status = nullptr;           // pinned host, >= 1 + nq words: [0] overflow flag, [1 + q] valid count of query q
     std::vector<hipEvent_t>* events = nullptr;   // timing events (grown on demand); one job at a time per pool
     bool skip_pilot = false;                // start with the growing-chunk plan (the re-run of a query the pilot failed)
-    bool l2 = false;                        // rank by smallest squared Euclidean distance (exact scan; scores out = distances)
+    bool l2 = false;                        // rank by smallest squared Euclidean distance (scores out = distances)
+    bool l2_per_row = false;                // ... its screened pass tests every row against its own norm (rows of mixed norms)
     // state (recall_job_*)
     RecallScratch rs{};
     uint32_t* d_count = nullptr;

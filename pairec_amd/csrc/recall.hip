@@ -437,6 +437,7 @@ struct ScreenArgs {
     // I >= floor(A_q + B_q * min|x|^2 of the block) - 2, with thr_screen = A_q (float) and l2_b = B_q (screen_thr8_l2_kernel)
     const float* blk_nxmin;   // [blocks] smallest |x|^2 of every physical 32-row block (pg_table::d_nxmin)
     const float* l2_b;        // [256]
+    const float* nx_rows;     // L2 = 2 (per-row test: g = 2 s_x s_q I - |x|^2 >= C'_q, thr_screen = C'_q, l2_b = 2 s_x s_q): |x|^2 of every row
 #ifdef PG_SCREEN_PROFILE
     unsigned long long* prof; // [waves][8]
 #endif
@@ -476,7 +477,7 @@ constexpr uint32_t kRecBytes = 80;
 // QH: query halves — the wave serves NQB x QH query blocks, QH groups of NQB one after the other on the same table
 // block, re-using the accumulators (int8, 256 queries: 2 x 4 blocks in 8 waves — two waves per SIMD, so one
 // wave's test, hit path and DMA issue run under the other's MFMAs; all 128 B-operand registers in the AGPR half).
-template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1, bool L2 = false>
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1, int L2 = 0>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArgs a) {
     static_assert(!L2 || (I8 && QH == 1 && SPLIT == 1), "squared-Euclidean screen: the int8 kernels of <= 128 queries");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         if constexpr (I8) thr_s[c] = active[c] ? __float_as_int(a.thr_screen[(qb0 + c) * 32 + i32]) : 0x7fffffff;
         else thr_s[c] = active[c] ? a.thr_screen[(qb0 + c) * 32 + i32] : __builtin_inff();
         eu[c] = (!I8 && active[c]) ? a.eps_unit[(qb0 + c) * 32 + i32] : 0.0f;
-        if constexpr (L2) {                           // A_q in la, B_q in eu (inactive columns: never a suspect)
+        if constexpr (L2 != 0) {                      // A_q in la, B_q in eu (L2 = 2: C'_q and 2 s_x s_q; inactive columns: never a suspect)
             la[c] = active[c] ? a.thr_screen[(qb0 + c) * 32 + i32] : __builtin_inff();
             eu[c] = active[c] ? a.l2_b[(qb0 + c) * 32 + i32] : 0.0f;
         }
@@ -878,7 +879,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         // bf16: this block's cutoffs, cut = thr - eps_unit x (largest row norm of the block), rounded down (the margin
         // term is kept finite so that +-inf thresholds stay what they are)
         ThrT cut[NQB];
-        if constexpr (L2) {
+        float nxr[16];                                   // L2 = 2: |x|^2 of this lane's 16 rows of the block
+        if constexpr (L2 == 2) {
+            const float* const nxp = a.nx_rows + (size_t)cur_phys * kPieceRows;      // wave-uniform: scalar loads
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const float nxa = nxp[ro], nxb = nxp[ro + 4];
+                nxr[r] = h ? nxb : nxa;
+            }
+#pragma unroll
+            for (int c = 0; c < NQB; ++c) cut[c] = 0;
+        } else if constexpr (L2 == 1) {
             // the block's integer cutoffs: floor(A_q + B_q * (smallest |x|^2 of the block)) - 2 (rounded down twice over;
             // -inf / NaN / below the int range: everything is a suspect)
             const float nxm = a.blk_nxmin[cur_phys];
@@ -904,7 +916,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
         uint64_t any_mask = 0;
 #pragma unroll
         for (int c = 0; c < NQB; ++c) {
-            if constexpr (I8) {
+            if constexpr (L2 == 2) {
+                // per-ROW test: 2 s_x s_q I - |x|^2 against C'_q, in fp32 (|I| < 2^24 converts exactly; the roundings are in C'_q)
+                float m = -__builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, __fmaf_rn((float)acc[c][r], eu[c], -nxr[r]));
+                cmask[c] = __builtin_amdgcn_ballot_w64(!(m < la[c]));
+            } else if constexpr (I8) {
                 int m = acc[c][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = acc[c][r] > m ? acc[c][r] : m;
@@ -930,7 +948,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 uint32_t m16 = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if constexpr (I8)
+                    if constexpr (L2 == 2) {
+                        const float g = __fmaf_rn((float)acc[c][r], eu[c], -nxr[r]);
+                        asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                     : "+v"(m16) : "v"(g), "v"(la[c]) : "vcc");
+                    } else if constexpr (I8)
                         asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                                      : "+v"(m16) : "v"(acc[c][r]), "v"(cut[c]) : "vcc");
                     else
@@ -1324,7 +1346,7 @@ __global__ void screen_thr8_kernel(const float* __restrict__ thr, const float* _
 // Both are rounded down here, the kernel rounds the sum down again.  thr = -inf (or anything odd): A_q = -inf, everything passes.
 __global__ void screen_thr8_l2_kernel(const float* __restrict__ thr, const float* __restrict__ eps, const float* __restrict__ qscale,
                                       const float* __restrict__ nqv, float s_x, float max_norm, float* __restrict__ a_out,
-                                      float* __restrict__ b_out) {
+                                      float* __restrict__ b_out, int per_row) {
     const uint32_t q = threadIdx.x;
     if (q >= (uint32_t)kMaxQueries) return;
     const float t = thr[q], e = eps[q];
@@ -1333,11 +1355,21 @@ __global__ void screen_thr8_l2_kernel(const float* __restrict__ thr, const float
     float A = -__builtin_inff(), B = 0.0f;
     if (e == e && e <= 1e30f && t == t && t > -__builtin_inff() && sq > 0.0 && nq == nq && nq < 1e30) {
         const double delta = 2e-6 * (N * N + nq + 2.0 * N * sqrt(nq)) + 1e-30;
-        const double a = (((double)t - delta + nq) * 0.5 - (double)e) / sq;
-        const double b = 0.5 / sq;
-        A = (float)(a - fabs(a) * 1e-6 - 1.0);
-        B = (float)(b * (1.0 - 1e-6));
-        if (!(A == A) || !(B == B) || B > 1e30f) { A = -__builtin_inff(); B = 0.0f; }
+        if (per_row) {
+            // per-row form: 2 s_x s_q I - |x|^2 >= thr - delta + |q|^2 - 2 eps_q =: C_q, evaluated by the kernel as
+            // fmaf((float)I, c1, -|x|^2) with c1 = 2 s_x s_q rounded UP (I can be negative: the product's error is covered
+            // with the fma's by a second delta)
+            const double c = (double)t - 2.0 * delta + nq - 2.0 * (double)e;
+            A = (float)(c - fabs(c) * 1e-6 - 1e-30);
+            B = (float)(2.0 * sq);
+            if (!(A == A) || !(B == B) || B > 1e30f) { A = -__builtin_inff(); B = 0.0f; }
+        } else {
+            const double a = (((double)t - delta + nq) * 0.5 - (double)e) / sq;
+            const double b = 0.5 / sq;
+            A = (float)(a - fabs(a) * 1e-6 - 1.0);
+            B = (float)(b * (1.0 - 1e-6));
+            if (!(A == A) || !(B == B) || B > 1e30f) { A = -__builtin_inff(); B = 0.0f; }
+        }
     }
     a_out[q] = A;
     b_out[q] = B;
@@ -2258,7 +2290,7 @@ static int ensure_pred_model(pg_ctx* ctx, const pg_table* tc) {
     return PG_OK;
 }
 
-template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1, bool L2 = false>
+template <int DIM, int NQB, int WAVES, int SPLIT = 1, int VAR = 0, bool I8 = false, int QH = 1, int L2 = 0>
 static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
     int rc_attr;
     if ((rc_attr = ensure_dyn_lds(ctx, (const void*)screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH, L2>, kScreenLds))) return rc_attr;
@@ -2291,10 +2323,15 @@ static int launch_screen(pg_ctx* ctx, const ScreenArgs& a) {
 
 static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs& a) {
     const bool wide = a.nq > 128;
+    if (a.nx_rows) {                                 // squared-Euclidean recall, per-row test (rows of mixed norms)
+        if (a.nq <= 32) return launch_screen<128, 1, 8, 1, 0, true, 1, 2>(ctx, a);
+        if (a.nq <= 64) return launch_screen<128, 2, 8, 1, 0, true, 1, 2>(ctx, a);
+        return launch_screen<128, 4, 8, 1, 0, true, 1, 2>(ctx, a);
+    }
     if (a.blk_nxmin) {                               // squared-Euclidean recall: int8 shadow, <= 128 queries (recall_job_prepare)
-        if (a.nq <= 32) return launch_screen<128, 1, 8, 1, 0, true, 1, true>(ctx, a);
-        if (a.nq <= 64) return launch_screen<128, 2, 8, 1, 0, true, 1, true>(ctx, a);
-        return launch_screen<128, 4, 8, 1, 0, true, 1, true>(ctx, a);
+        if (a.nq <= 32) return launch_screen<128, 1, 8, 1, 0, true, 1, 1>(ctx, a);
+        if (a.nq <= 64) return launch_screen<128, 2, 8, 1, 0, true, 1, 1>(ctx, a);
+        return launch_screen<128, 4, 8, 1, 0, true, 1, 1>(ctx, a);
     }
     if (i8) {                                        // int8 shadow (dim 128)
 #ifdef PG_SCAN_VARIANTS
@@ -2429,7 +2466,9 @@ int recall_job_prepare(RecallJob* j) {
         if (!t->stats_valid || !t->all_finite) screen = false;      // no shadow (dim, memory) or non-finite rows
     }
     // squared Euclidean: the int8 screen with per-block cutoffs for up to 128 queries (dim 128, int8 shadow); else the exact scan
-    if (j->l2 && !(screen && t->dim == 128 && t->shadow_is_i8 && j->nq <= 128 && !kn.l2_exact && t->l2_slack <= kn.l2_max_slack)) screen = false;
+    if (j->l2 && !(screen && t->dim == 128 && t->shadow_is_i8 && j->nq <= 128 && !kn.l2_exact)) screen = false;
+    // rows of (nearly) one norm: one cutoff per 32-row block; beyond: the per-row test (three VALU instructions per bound instead of half a one)
+    j->l2_per_row = j->l2 && screen && t->l2_slack > kn.l2_max_slack;
     j->screen = screen;
     j->screen4 = false;
     j->n_plans = 0;
@@ -2562,7 +2601,8 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             sa.rec_pool = nullptr;
             sa.rec_pool_cap = sa.rec_waves = 0;
             sa.early_share = records ? ctx->knobs.screen_early_share : ctx->knobs.screen_early_share_narrow;
-            sa.blk_nxmin = j->l2 ? t->d_nxmin : nullptr;
+            sa.blk_nxmin = j->l2 && !j->l2_per_row ? t->d_nxmin : nullptr;
+            sa.nx_rows = j->l2 && j->l2_per_row ? t->d_nx : nullptr;
             sa.l2_b = j->l2 ? rs.thr_ref : nullptr;    // (no refinement step under this metric: its buffer carries B_q)
             const uint32_t rec_waves = (uint32_t)ctx->num_cus * 8u;
             if (records) {
@@ -2656,7 +2696,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
         if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk, 0))) return rc2;
         if (j->screen && !no_i8) {
             if (j->l2) screen_thr8_l2_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, rs.pred_ms, t->s8, t->max_norm,
-                                                                                rs.thr_screen, rs.thr_ref);
+                                                                                rs.thr_screen, rs.thr_ref, j->l2_per_row ? 1 : 0);
             else if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
             else screen_thr_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, t->max_norm, rs.thr_screen);
             PG_HIP(hipGetLastError());

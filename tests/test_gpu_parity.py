@@ -435,7 +435,7 @@ def test_recall_l2_screened_pass_on_rows_of_equal_norm(ctx):
     """Squared-Euclidean recall of a dim-128 table whose rows have (nearly) one norm: the pass streams the int8 shadow with
     per-block integer cutoffs (csrc/recall.hip, screen_thr8_l2_kernel) and re-scores the suspects exactly — ids, order
     and distance bits still the oracle's, no plan fails (inactive query columns must not produce suspects), and the pass
-    reads a quarter of the fp32 bytes.  Rows of very different norms send the same call to the exact scan."""
+    reads a quarter of the fp32 bytes.  Rows of very different norms: the per-row form of the test, on the same shadow."""
     n, d, k = 1_200_000, 128, 400
     tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
     tab[500:532] = tab[500]                                     # a block of duplicates: ties by row id
@@ -454,16 +454,25 @@ def test_recall_l2_screened_pass_on_rows_of_equal_norm(ctx):
         orow, od = o.recall_topk_l2(tab, q[sel], k)
         assert np.array_equal(rows[sel], orow) and np.array_equal(bits(dist[sel]), bits(od)), nq
     assert rows[0, :32].tolist() == list(range(500, 532))
-    # norms spread over a factor of four (slack ~ 8 score spreads): the per-block cutoff would give too much away → exact scan, same answers
+    # norms spread over a factor of four (slack ~ 8 score spreads): one cutoff per block would give too much away — the pass
+    # tests every row against its own norm instead (still the int8 shadow); same answers, and the same from the exact scan
     scaled = tab * np.linspace(0.5, 2.0, n, dtype=np.float32)[::-1, None].copy()
     rng = np.random.default_rng(3)
     scaled = scaled[rng.permutation(n)]
     t.upload(scaled)
-    q = o.synth_rows(o.SEED_QUERY, 9, 5, d)
-    rows, dist, _ = t.recall_topk_l2(q, k)
+    for nq in (5, 70, 128):
+        q = o.synth_rows(o.SEED_QUERY, 9, nq, d) * np.float32(1.3)
+        before = ctx.stats().recall_rescans
+        rows, dist, _ = t.recall_topk_l2(q, k)
+        assert ctx.stats().recall_rescans == before and ctx.last_scan_kernel()[1] < n * d * 2, nq
+        sel = sorted(set([0, nq - 1, nq // 2]))
+        orow, od = o.recall_topk_l2(scaled, q[sel], k)
+        assert np.array_equal(rows[sel], orow) and np.array_equal(bits(dist[sel]), bits(od)), nq
+    ctx.set_option("l2_exact", "1")
+    rows2, dist2, _ = t.recall_topk_l2(q[:9], k)
+    ctx.set_option("l2_exact", "0")
     assert ctx.last_scan_kernel()[1] >= n * d * 4
-    orow, od = o.recall_topk_l2(scaled, q, k)
-    assert np.array_equal(rows, orow) and np.array_equal(bits(dist), bits(od))
+    assert np.array_equal(rows2, rows[:9]) and np.array_equal(bits(dist2), bits(dist[:9]))
     t.destroy()
 
 
