@@ -7,7 +7,7 @@ import sys, glob, csv, os
 out = sys.argv[1]
 lines = ["Round 3: squared-Euclidean recall (pg_recall_topk_l2), 100 M x 128, K = 5000 — rocprofv3 --kernel-trace --stats -- python3 scripts/dev_l2.py",
          "(N(0,1) rows: int8 screen, per-row test; normalised rows: int8 screen with per-block cutoffs; 1 / 32 / 64 / 128 / 256 queries per call, 4 calls each)", ""]
-lines += open(os.path.join(out, "log.txt")).read().strip().splitlines()[-14:]
+lines += [l.rstrip() for l in open(os.path.join(out, "log.txt")) if ("l2 nq" in l or "rows shadow" in l or "slice matches" in l)]
 lines.append("")
 for p in glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(p)):
