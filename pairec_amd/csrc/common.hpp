@@ -292,7 +292,7 @@ constexpr uint32_t kI4MaxQueries = 4;
 int ensure_table_i4(pg_ctx* ctx, const pg_table* tc);
 int screen4_prep_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs);
 int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t row_begin, uint32_t row_end,
-                   uint32_t cap4);
+                   uint32_t cap4, const float* l2_nqv = nullptr);
 uint32_t screen4_rescore_blocks();
 int topk_merge_strided_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
                               uint32_t per_list, size_t row_ls, size_t row_qs, size_t sc_ls, size_t sc_qs, uint32_t k,

@@ -2502,7 +2502,7 @@ int recall_job_prepare(RecallJob* j) {
     j->plans[j->n_plans++] = kSafe;
     if (j->skip_pilot && j->plans[0] == kPilot) j->next_plan = 1;    // the re-run of a query a sampled threshold failed
     // small batches: the pilot plan's full pass is HBM-bound on the shadow it streams — use the 4-bit one (recall_i4.hip)
-    if (screen && !j->l2 && t->dim == 128 && j->nq <= kI4MaxQueries && j->plans[0] == kPilot && !kn.no_screen_i4 &&
+    if (screen && t->dim == 128 && j->nq <= kI4MaxQueries && j->plans[0] == kPilot && !kn.no_screen_i4 &&
         rows >= kn.i4_min_rows && (uint64_t)kMaxQueries * rs_cap_bound(j->k) / kI4MaxQueries < 0xFFFFFFFFull) {
         if ((rc = ensure_table_i4(ctx, t))) return rc;
         // (measured at 100M x 128, int8 pass 2.1 ms: uniform rows, lambda 0.8: 1.37 / 1.38 / 1.59 / 1.66 ms at 1..4
@@ -2633,8 +2633,8 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             const uint64_t r_begin = (uint64_t)rb * kPieceRows;
             const uint64_t r_end = (uint64_t)(rb + cb) * kPieceRows < j->rows ? (uint64_t)(rb + cb) * kPieceRows : j->rows;
             if (i4) {
-                if ((rc2 = screen4_launch(ctx, t, rs, nq, (uint32_t)r_begin, (uint32_t)r_end, scap))) return rc2;
-                j->scan_bytes += (r_end - r_begin) * 68;
+                if ((rc2 = screen4_launch(ctx, t, rs, nq, (uint32_t)r_begin, (uint32_t)r_end, scap, j->l2 ? rs.pred_ms : nullptr))) return rc2;
+                j->scan_bytes += (r_end - r_begin) * (j->l2 ? 72 : 68);      // (squared Euclidean: + the row's |x|^2)
             } else {
                 if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) return rc2;
                 if (records) {

@@ -42,15 +42,19 @@ struct Screen4Args {
     uint32_t* susp;           // [4][cap4]
     uint32_t* overflow;
     uint32_t cap4, rows, row_begin;     // rows [row_begin, rows), row_begin a multiple of 64
+    // squared-Euclidean recall (L2): a row is a suspect iff fmaf(2, f, -(|x|^2 + |q|^2)) >= thr - 2 delta, f = the bound of the
+    // inner product above (thr in -d units; delta: the rounding of the specification's and of this evaluation)
+    const float* nx;          // [rows + 64] |x|^2 of every row
+    const float* l2c;         // [4][2] {|q|^2, 2 delta}
 };
 
-template <int NQ>
+template <int NQ, bool L2 = false>
 __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
     __shared__ uint32_t stage[4][NQ][kStage4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int part = lane & 3;                         // which 32 dims of the row this lane holds
     int Q[NQ][8];
-    float sq[NQ], bq[NQ], aq[NQ], tq[NQ];
+    float sq[NQ], bq[NQ], aq[NQ], tq[NQ], nqc[NQ];
     int bias[NQ];
     uint32_t cnt[NQ];
 #pragma unroll
@@ -65,6 +69,12 @@ __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
         bias[qi] = __float_as_int(c[3]);
         // anything not finite: every row is a suspect (the lists overflow, the next plan runs)
         tq[qi] = (t == t && aq[qi] == aq[qi] && aq[qi] < 1e30f && t > -__builtin_inff()) ? t : -__builtin_inff();
+        nqc[qi] = 0.0f;
+        if constexpr (L2) {
+            nqc[qi] = a.l2c[2 * qi];
+            const float d2 = a.l2c[2 * qi + 1];
+            tq[qi] = (tq[qi] > -__builtin_inff() && d2 == d2 && d2 < 1e30f && nqc[qi] == nqc[qi]) ? tq[qi] - d2 : -__builtin_inff();
+        }
         cnt[qi] = 0;
     }
     auto flush = [&](int qi) {
@@ -89,10 +99,12 @@ __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
         u32x4 v[4];
         uint32_t sr[4];
         f32x2 s[4];
+        float nxv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             v[u] = __builtin_nontemporal_load(a.d4 + (size_t)(row0 + 16 * u) * 4 + part);
             sr[u] = __builtin_nontemporal_load(a.d4s + row0 + 16 * u);
+            if constexpr (L2) nxv[u] = __builtin_nontemporal_load(a.nx + row0 + 16 * u);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -119,7 +131,8 @@ __global__ __launch_bounds__(256) void screen4_kernel(Screen4Args a) {
                 for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_sdot4(b[i], Q[qi][i], acc, false);
                 acc += __builtin_amdgcn_update_dpp(0, acc, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
                 acc += __builtin_amdgcn_update_dpp(0, acc, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
-                const float f = __fmaf_rn(s[u].x * sq[qi], (float)(acc - bias[qi]), __fmaf_rn(hr[u], aq[qi], s[u].y * bq[qi]));
+                float f = __fmaf_rn(s[u].x * sq[qi], (float)(acc - bias[qi]), __fmaf_rn(hr[u], aq[qi], s[u].y * bq[qi]));
+                if constexpr (L2) f = __fmaf_rn(2.0f, f, -(nxv[u] + nqc[qi]));
                 const bool hit = part == 0 && row < a.rows && !(f < tq[qi]);
                 const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
                 if (m) {
@@ -314,9 +327,27 @@ int screen4_prep_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs)
 
 uint32_t screen4_rescore_blocks() { return kRescore4Blocks; }
 
+// squared-Euclidean recall: |q|^2 (the chain value the recall job computed) and twice the evaluation slack, per query
+__global__ void screen4_l2_consts_kernel(const float* __restrict__ nqv, float max_norm, float* __restrict__ out) {
+    const uint32_t q = threadIdx.x;
+    if (q >= (uint32_t)kI4MaxQueries) return;
+    const double nq = (double)nqv[q], N = (double)max_norm;
+    out[2 * q] = nqv[q];
+    out[2 * q + 1] = (float)((4e-6 * (N * N + nq + 2.0 * N * sqrt(nq)) + 1e-30) * 1.000001);
+}
+
 int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t row_begin, uint32_t rows,
-                   uint32_t cap4) {
+                   uint32_t cap4, const float* l2_nqv) {
     Screen4Args a;
+    a.nx = nullptr;
+    a.l2c = nullptr;
+    if (l2_nqv) {
+        float* l2c = reinterpret_cast<float*>(rs.q4 + 4 * 32 + 16);       // behind the queries and their constants
+        screen4_l2_consts_kernel<<<1, 64, 0, ctx->stream>>>(l2_nqv, t->max_norm, l2c);
+        PG_HIP(hipGetLastError());
+        a.nx = t->d_nx;
+        a.l2c = l2c;
+    }
     a.d4 = reinterpret_cast<const u32x4*>(t->d4);
     a.d4s = t->d4s;
     a.q4 = rs.q4;
@@ -342,6 +373,16 @@ int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint
     const uint32_t groups = (rows - row_begin + 63) / 64;
     uint32_t grid = (uint32_t)ctx->num_cus * (uint32_t)per_cu[n];
     if (grid > (groups + 3) / 4) grid = (groups + 3) / 4;
+    if (l2_nqv) {
+        switch (n) {
+            case 1: screen4_kernel<1, true><<<grid, 256, 0, ctx->stream>>>(a); break;
+            case 2: screen4_kernel<2, true><<<grid, 256, 0, ctx->stream>>>(a); break;
+            case 3: screen4_kernel<3, true><<<grid, 256, 0, ctx->stream>>>(a); break;
+            default: screen4_kernel<4, true><<<grid, 256, 0, ctx->stream>>>(a); break;
+        }
+        PG_HIP(hipGetLastError());
+        return PG_OK;
+    }
     switch (n) {
         case 1: screen4_kernel<1><<<grid, 256, 0, ctx->stream>>>(a); break;
         case 2: screen4_kernel<2><<<grid, 256, 0, ctx->stream>>>(a); break;

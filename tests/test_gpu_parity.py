@@ -476,6 +476,40 @@ def test_recall_l2_screened_pass_on_rows_of_equal_norm(ctx):
     t.destroy()
 
 
+def test_recall_l2_small_batches_on_the_4bit_shadow(ctx):
+    """Squared-Euclidean recalls of 1-4 queries stream the 4-bit shadow in their full pass (csrc/recall_i4.hip, L2 form of the
+    per-row test: 2 x the inner-product bound - |x|^2 - |q|^2 against the threshold) — forced on for a small table: ids,
+    order and distance bits = oracle on rows of one norm and of mixed norms, the pass reads less than the int8 shadow, and
+    the same answers come from the int8 pass."""
+    rng = np.random.default_rng(61)
+    n, d, k = 500_000, 128, 300
+    for name, v in (("i4_min_rows", "0"), ("pilot_fraction", "0.25"), ("i4_max_lambda", "3")):
+        ctx.set_option(name, v)
+    try:
+        base = o.synth_rows(o.SEED_TABLE, 0, n, d)
+        mixed = (base * rng.uniform(0.4, 1.8, (n, 1)).astype(np.float32)).astype(np.float32)
+        t = pa.Table(ctx, n, d)
+        for tab in (base, mixed):
+            t.upload(tab)
+            for nq in (1, 2, 4):
+                q = (o.synth_rows(o.SEED_QUERY, 70 + nq, nq, d) * np.float32(1.2)).astype(np.float32)
+                before = ctx.stats().recall_rescans
+                rows, dist, _ = t.recall_topk_l2(q, k)
+                assert ctx.stats().recall_rescans == before
+                assert ctx.last_scan_kernel()[1] < n * d, "the full pass did not stream the 4-bit shadow"
+                orow, od = o.recall_topk_l2(tab, q, k)
+                assert np.array_equal(rows, orow) and np.array_equal(bits(dist), bits(od)), nq
+                ctx.set_option("no_screen_i4", "1")
+                rows8, dist8, _ = t.recall_topk_l2(q, k)
+                ctx.set_option("no_screen_i4", "0")
+                assert np.array_equal(rows8, rows) and np.array_equal(bits(dist8), bits(dist))
+        t.destroy()
+    finally:
+        ctx.set_option("i4_min_rows", str(1 << 22))
+        ctx.set_option("pilot_fraction", "0")
+        ctx.set_option("i4_max_lambda", "1.7")
+
+
 def test_recall_follows_table_updates(ctx):
     """The screen streams a quantised shadow (int8 here) of the table that is built lazily; uploads, synthetic fills and
     hot swaps must invalidate / carry it — every recall answers for the rows the table holds now."""
