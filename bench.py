@@ -565,6 +565,44 @@ def cfg1_leg(pa, o, ctx):
     }
 
 
+def l2_recall_leg(pa, o, ctx, rows, K):
+    """HologresVectorRecallV2's metric (service/recall/hologres_vector_recall_v2.go:23): top-K by smallest squared Euclidean
+    distance on the benchmark's table shape, host buffers in and out — 1 and 128 queries per pass, normalised rows (one
+    integer cutoff per 32-row block) and N(0,1) rows (per-row test), with a slice checked against the oracle."""
+    d = 128
+    t = pa.Table(ctx, rows, d)
+    out = {"workload": "squared-Euclidean top-%d of %d x %d fp32 rows (exact; int8 / 4-bit shadows as filters)" % (K, rows, d)}
+    rng = np.random.default_rng(17)
+    for name in ("normalised_rows", "gaussian_rows"):
+        if name == "normalised_rows":
+            t.fill_synthetic(o.SEED_TABLE)
+        else:
+            t.fill_gaussian(o.SEED_TABLE, 1.0)
+        res = {}
+        for nq in (1, 128):
+            q = rng.standard_normal((nq, d)).astype(np.float32) if name == "gaussian_rows" else o.synth_rows(o.SEED_QUERY, 0, nq, d)
+            t.recall_topk_l2(q, K)                          # warm-up (builds shadows and row norms)
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                t.recall_topk_l2(q, K)
+                best = min(best, time.perf_counter() - t0)
+            res["ms_per_pass_%d_queries" % nq] = best * 1e3
+        res["requests_per_s_at_128"] = 128 / (res["ms_per_pass_128_queries"] * 1e-3)
+        out[name] = res
+    m = min(rows, 200_000)
+    tab = t.download(0, m)
+    ts = pa.Table(ctx, m, d)
+    ts.upload(tab)
+    q = rng.standard_normal((6, d)).astype(np.float32)
+    r_, d_, _ = ts.recall_topk_l2(q, 100)
+    orow, od = o.recall_topk_l2(tab, q, 100)
+    out["slice_matches_oracle"] = bool(np.array_equal(r_, orow) and np.array_equal(d_.view(np.uint32), od.view(np.uint32)))
+    ts.destroy()
+    t.destroy()
+    return out
+
+
 def cfg4_leg(pa, o, ctx, R, K):
     """BASELINE.json configs[3]: FM (8 + 8 fields, k = 16) + two-tower (128 → 256 → 64) rank of R x K candidates,
     field tables of 1M rows each.  HBM-gather bound: 544 algorithmic bytes per item."""
@@ -965,6 +1003,7 @@ def main():
         table.destroy()
         out["other_configs"] = {"cfg1": cfg1_leg(pa, o, ctx), "cfg4": cfg4_leg(pa, o, ctx, R, K),
                                 "cfg5_one_shard": cfg5_leg(pa, o, R, K, prec)}
+        out["l2_recall"] = l2_recall_leg(pa, o, ctx, args.rows, K)
 
     if rank == 0 and extras and not args.no_live_traffic and not os.environ.get("PG_BENCH_CHILD"):
         # roofline.traffic, live: the same scan stage under rocprofv3 --pmc in two child runs (the tables of this process are
