@@ -221,6 +221,12 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         c.CacheAdapter = r.s("CacheAdapter"); c.CacheConfig = r.s("CacheConfig");
         c.RecallCount = (int)r.n("RecallCount"); c.CacheTime = (int)r.n("CacheTime");
         c.RankScore = r.s("RankScore"); c.RankVar = r.s("RankVar");
+        // HologresVectorConf.WhereClause / TimeInterval (recconf.go:492-497, hologres_vector_recall.go:49-62) restrict the SQL's
+        // candidates; the device recalls search the whole table — refuse the declaration rather than answer something else
+        if (!r.s("WhereClause").empty() || !r.at("HologresVectorConf").s("WhereClause").empty()) {
+            if (err) *err = "pairec_gpu.Recalls: " + c.Name + ": WhereClause is not supported (the device recalls rank every row of the table)";
+            return false;
+        }
         out->GpuRecalls.push_back(c);
     }
     for (const auto& sc : out->UserDefineConfs.at("pairec_gpu").at("Sorts").arr) out->GpuSorts.push_back(parse_sort(sc));

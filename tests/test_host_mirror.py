@@ -55,6 +55,18 @@ def test_registry_semantics(H):
     assert H.ph_registry_semantics() == 31
 
 
+def test_gpu_recall_with_a_where_clause_is_refused(H):
+    """HologresVectorConf.WhereClause restricts the reference's SQL candidates (hologres_vector_recall.go:49-62); the device
+    recalls rank the whole table, so a pairec_gpu.Recalls entry that carries one is an error at load time — not a silent
+    full-table answer."""
+    import copy
+    cfg = copy.deepcopy(CONFIG)
+    cfg["UserDefineConfs"]["pairec_gpu"]["Recalls"][0]["WhereClause"] = "create_time > ${time}"
+    assert not H.ph_parse_recconf(json.dumps(cfg).encode())
+    assert b"WhereClause is not supported" in H.ph_last_error()
+    assert not H.ph_engine_create(json.dumps(cfg).encode()) and b"WhereClause" in H.ph_last_error()
+
+
 def test_parse_vector_string(H):
     buf = (C.c_float * 16)()
     text = "1:0.12 2:-0.3 junk 3:1e-2 4:x 5:1:2"
