@@ -290,6 +290,18 @@ int pg_features_gather_i32_dev(pg_ctx* ctx, const pg_features* fs, const int32_t
 int pg_features_gather_f32_dev(pg_ctx* ctx, const pg_features* fs, const int32_t* col_idx, uint32_t n_cols,
                                const float* scale, const float* bias, const uint32_t* d_rows, uint32_t n,
                                float* d_out);
+
+/* A Hologres vector recall with its WhereClause (HologresVectorConf.WhereClause, recconf.go:492-497; hologres_vector_recall.go:
+ * 23,49-62 and _v2.go:23,56-61: "FROM table WHERE … ORDER BY distance LIMIT n"), in the shape the device serves: `column OP
+ * constant` over an int32 / int64 feature column keyed by item row ("create_time > ${time}" with the constant substituted by the
+ * caller).  Only rows that pass are candidates; out_count[q] = min(k, rows that pass), the slots behind it carry row UINT64_MAX.
+ * metric 0: inner product, descending (pg_recall_topk); 1: squared Euclidean distance, ascending (pg_recall_topk_l2).  Exact.
+ * A filter that admits at most an eighth of the table (and at most 8 M rows; knobs "where_compact_max_rows",
+ * "where_compact_min_ratio") is served from a compact copy of the admitted rows, gathered per call; a wider one in place, the
+ * predicate evaluated where candidates are made.  0.7-6 ms per call of 1-128 queries at 100 M x 128 for any selectivity. */
+typedef enum { PG_WHERE_GT = 0, PG_WHERE_GE = 1, PG_WHERE_LT = 2, PG_WHERE_LE = 3, PG_WHERE_EQ = 4, PG_WHERE_NE = 5 } pg_where_op;
+int pg_recall_topk_where(pg_ctx* ctx, const pg_table* t, const pg_features* fs, int column, int op, long long value, int metric,
+                         const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_count);
 /* FM + two-tower rank straight from candidate rows: the model's item field ids are the integer columns
  * item_field_cols[n_item_fields] of `fs` (out-of-vocabulary ids are clamped as in pg_rank_fm2t_dev) */
 int pg_rank_fm2t_rows_dev(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,

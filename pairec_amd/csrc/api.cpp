@@ -33,6 +33,8 @@ static void knobs_from_env(Knobs* k) {
     k->screen_early_share = (uint32_t)num("PG_SCREEN_EARLY_SHARE", 604);
     k->l2_exact = flag("PG_L2_EXACT");
     k->l2_max_slack = num("PG_L2_MAX_SLACK", 1.0);
+    k->where_compact_max_rows = (uint32_t)num("PG_WHERE_COMPACT_MAX_ROWS", (double)(8u << 20));
+    k->where_compact_min_ratio = (uint32_t)num("PG_WHERE_COMPACT_MIN_RATIO", 8);
     k->screen_early_share_narrow = (uint32_t)num("PG_SCREEN_EARLY_SHARE_NARROW", 512);
 }
 
@@ -154,6 +156,8 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "screen_early_share") k.screen_early_share = (uint32_t)v;
     else if (n == "l2_exact") k.l2_exact = b;
     else if (n == "l2_max_slack") k.l2_max_slack = v;
+    else if (n == "where_compact_max_rows") k.where_compact_max_rows = (uint32_t)v;
+    else if (n == "where_compact_min_ratio") k.where_compact_min_ratio = v >= 1 ? (uint32_t)v : 1u;
     else if (n == "screen_early_share_narrow") k.screen_early_share_narrow = (uint32_t)v;
     else {
         pg::set_error("pg_set_option: unknown option \"%s\"", name);

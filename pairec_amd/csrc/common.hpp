@@ -77,6 +77,8 @@ struct Knobs {
     uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way
     uint32_t screen_early_share_narrow = 512;   // PG_SCREEN_EARLY_SHARE_NARROW: the same for the 8-wave kernels of <= 128 queries
     bool l2_exact = false;                  // PG_L2_EXACT: squared-Euclidean recalls always on the exact scan (A/B runs)
+    uint32_t where_compact_max_rows = 8u << 20;   // PG_WHERE_COMPACT_MAX_ROWS: a filter admitting at most this many rows ...
+    uint32_t where_compact_min_ratio = 8;         // PG_WHERE_COMPACT_MIN_RATIO: ... and at most 1/ratio of the table is served from a compact copy of them
     double l2_max_slack = 1.0;              // PG_L2_MAX_SLACK: largest pg_table::l2_slack the per-BLOCK cutoff is used for (above: the per-row test)
     uint32_t screen_early_share = 604;      // PG_SCREEN_EARLY_SHARE: share (x 1024) of a SIMD's blocks given to its older wave (256-query screen)
 };
@@ -184,7 +186,7 @@ struct pg_ctx {
     bool own_stream = false;
     int num_cus = 256;
     std::mutex mu;               // serialises calls on this context
-    pg::Scratch scratch[12];     // named scratch slots (see users; 8 = the recommend pipeline's intermediates, 10 = its re-rank stage)
+    pg::Scratch scratch[14];     // named scratch slots (see users; 8 = the recommend pipeline's intermediates, 10 = its re-rank stage)
     std::mutex pool_mu;          // guards pipe_free
     std::vector<pg::PipeRun*> pipe_free;     // per-batch status blocks / events of the device-resident pipelines
     std::map<const void*, size_t> dyn_lds;   // kernels whose dynamic-LDS limit was raised on this device
@@ -232,6 +234,30 @@ struct RecallScratch {
     uint32_t* q4;            // 4-bit screen: [4][32] int8 queries + [4][4] constants (recall_i4.hip)
     float* pred_ms;          // [kMaxQueries][2] the threshold model's mean and sigma of every query's scores
 };
+// A predicate over an integer feature column that restricts a recall's candidates (HologresVectorConf.WhereClause of the
+// reference, hologres_vector_recall.go:49-62, in the one shape the device serves: `column OP constant`).  Rows that fail it
+// never become candidates — it is applied where candidates are made (exact re-scoring, the exact scan's hit path), so every
+// threshold the plans derive is a threshold of the FILTERED top-K and the answers stay exact.
+struct RowFilter {
+    const void* col = nullptr;   // [rows] int32 / int64 device column; nullptr = no filter
+    int dtype = 0;               // PG_F_I32 or PG_F_I64
+    int op = 0;                  // pg_where_op: 0 >, 1 >=, 2 <, 3 <=, 4 ==, 5 !=
+    long long val = 0;
+    long long admitted = -1;     // host side: rows the filter admits when the caller has counted them already (-1: not yet)
+};
+__host__ __device__ inline bool row_filter_pass(const RowFilter& f, uint32_t row) {
+    if (!f.col) return true;
+    const long long v = f.dtype == 2 ? reinterpret_cast<const long long*>(f.col)[row] : (long long)reinterpret_cast<const int32_t*>(f.col)[row];
+    switch (f.op) {
+        case 0: return v > f.val;
+        case 1: return v >= f.val;
+        case 2: return v < f.val;
+        case 3: return v <= f.val;
+        case 4: return v == f.val;
+        default: return v != f.val;
+    }
+}
+
 struct RecallJob {
     // set by the caller
     pg_ctx* ctx = nullptr;
@@ -246,6 +272,9 @@ struct RecallJob {
     bool skip_pilot = false;                // start with the growing-chunk plan (the re-run of a query the pilot failed)
     bool l2 = false;                        // rank by smallest squared Euclidean distance (scores out = distances)
     bool l2_per_row = false;                // ... its screened pass tests every row against its own norm (rows of mixed norms)
+    RowFilter filter{};                     // restrict the candidates to the rows that pass (col = nullptr: none)
+    uint32_t rows_qualified = 0;            // ... how many rows do (counted in recall_job_prepare)
+    bool exact_only = false;                // no statistics, no shadow: the exact scan (the compact table of a selective filter)
     // state (recall_job_*)
     RecallScratch rs{};
     uint32_t* d_count = nullptr;
@@ -277,7 +306,7 @@ int recall_job_check(RecallJob* j, bool* ok);         // after the stream passed
 void recall_job_finish(RecallJob* j);                 // publish timing / counters into ctx
 int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, uint32_t nq, uint32_t k,
                       uint64_t* d_out_rows, float* d_out_scores, uint32_t* out_count, uint32_t* d_out_count,
-                      bool skip_pilot = false, bool l2 = false);
+                      bool skip_pilot = false, bool l2 = false, const RowFilter* filter = nullptr, bool exact_only = false);
 // re-run the failed queries of `j` (at most kMaxPatchQueries) one by one, synchronously, writing into their slices of
 // the job's outputs and their valid counts into counts[q]; caller holds ctx->mu
 int recall_patch_failed_locked(RecallJob* j, uint32_t* counts);

@@ -185,6 +185,23 @@ class Table:
             _lib.check(self.ctx.L.pg_recall_topk_l2(self.ctx.h, self.h, _ptr(q[s:e]), e - s, k, _ptr(r_), _ptr(d_), _ptr(c_)))
         return rows, dist, counts
 
+    def recall_topk_where(self, feats: "Features", column: str, op: str, value: int, queries: np.ndarray, k: int, l2: bool = False):
+        """A Hologres vector recall with its WhereClause `column OP value` (op in > >= < <= == !=): only rows that pass are
+        candidates.  → (rows, scores or distances, counts)."""
+        ops = {">": 0, ">=": 1, "<": 2, "<=": 3, "==": 4, "!=": 5}
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        rows = np.empty((nq, k), dtype=np.uint64)
+        scores = np.empty((nq, k), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        col = self.ctx.L.pg_features_column_index(feats.h, column.encode())
+        for s in range(0, nq, MAX_QUERIES):
+            e = min(nq, s + MAX_QUERIES)
+            r_, s_, c_ = rows[s:e], scores[s:e], counts[s:e]
+            _lib.check(self.ctx.L.pg_recall_topk_where(self.ctx.h, self.h, feats.h, col, ops[op], int(value), 1 if l2 else 0,
+                                                       _ptr(q[s:e]), e - s, k, _ptr(r_), _ptr(s_), _ptr(c_)))
+        return rows, scores, counts
+
     def i2i_recall(self, trigger_rows, k: int, trigger_table: Optional["Table"] = None):
         """I2IVectorRecall: rows of `trigger_table` (default: this table) are the queries."""
         tr = np.ascontiguousarray(trigger_rows, dtype=np.uint32)

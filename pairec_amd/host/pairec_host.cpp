@@ -4,8 +4,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cerrno>
 #include <cmath>
 #include <cstring>
+#include <ctime>
 #include <thread>
 
 namespace pairec {
@@ -221,11 +223,21 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         c.CacheAdapter = r.s("CacheAdapter"); c.CacheConfig = r.s("CacheConfig");
         c.RecallCount = (int)r.n("RecallCount"); c.CacheTime = (int)r.n("CacheTime");
         c.RankScore = r.s("RankScore"); c.RankVar = r.s("RankVar");
-        // HologresVectorConf.WhereClause / TimeInterval (recconf.go:492-497, hologres_vector_recall.go:49-62) restrict the SQL's
-        // candidates; the device recalls search the whole table — refuse the declaration rather than answer something else
-        if (!r.s("WhereClause").empty() || !r.at("HologresVectorConf").s("WhereClause").empty()) {
-            if (err) *err = "pairec_gpu.Recalls: " + c.Name + ": WhereClause is not supported (the device recalls rank every row of the table)";
-            return false;
+        // HologresVectorConf.WhereClause / TimeInterval (recconf.go:492-497) restrict the SQL's candidates.  The device serves
+        // the form `column OP integer` over an int32 item column keyed by row, "${time}" standing for now - TimeInterval as in
+        // hologres_vector_recall.go:56-61; anything else is refused here rather than answered over other candidates.
+        c.WhereClause = !r.s("WhereClause").empty() ? r.s("WhereClause") : r.at("HologresVectorConf").s("WhereClause");
+        c.TimeInterval = (int)(r.n("TimeInterval") != 0 ? r.n("TimeInterval") : r.at("HologresVectorConf").n("TimeInterval"));
+        if (!c.WhereClause.empty()) {
+            if (c.Kind != "hologres" && c.Kind != "hologres_v2") {
+                if (err) *err = "pairec_gpu.Recalls: " + c.Name + ": WhereClause is not supported by Kind \"" + c.Kind + "\" (Kinds hologres, hologres_v2 take one)";
+                return false;
+            }
+            if (!recall::ParseWhereClause(c.WhereClause, c.TimeInterval, &c.WhereColumn, &c.WhereOp, &c.WhereValue)) {
+                if (err) *err = "pairec_gpu.Recalls: " + c.Name + ": WhereClause \"" + c.WhereClause +
+                                "\" is not supported (the device serves `column OP integer`, OP one of > >= < <= = != <>, the integer or ${time})";
+                return false;
+            }
         }
         out->GpuRecalls.push_back(c);
     }
@@ -368,6 +380,35 @@ std::shared_ptr<Recall> Registry::GetRecall(const std::string& name, std::string
     }
     return it->second;
 }
+bool ParseWhereClause(const std::string& s, int time_interval, std::string* column, int* op, long long* value) {
+    size_t p = 0;
+    auto skip = [&]() { while (p < s.size() && isspace((unsigned char)s[p])) ++p; };
+    skip();
+    const size_t c0 = p;
+    while (p < s.size() && (isalnum((unsigned char)s[p]) || s[p] == '_')) ++p;
+    if (p == c0 || isdigit((unsigned char)s[c0])) return false;
+    *column = s.substr(c0, p - c0);
+    skip();
+    static const struct { const char* text; int op; } kOps[] = {{">=", 1}, {"<=", 3}, {"!=", 5}, {"<>", 5}, {"==", 4}, {">", 0}, {"<", 2}, {"=", 4}};
+    *op = -1;
+    for (const auto& o : kOps)
+        if (s.compare(p, strlen(o.text), o.text) == 0) { *op = o.op; p += strlen(o.text); break; }
+    if (*op < 0) return false;
+    skip();
+    if (s.compare(p, 7, "${time}") == 0) {
+        *value = (long long)time(nullptr) - (long long)time_interval;
+        p += 7;
+    } else {
+        char* end = nullptr;
+        errno = 0;
+        *value = strtoll(s.c_str() + p, &end, 10);
+        if (end == s.c_str() + p || errno) return false;
+        p = (size_t)(end - s.c_str());
+    }
+    skip();
+    return p == s.size();
+}
+
 std::vector<float> ParseVectorString(const std::string& s) {     // vector_recall.go:70-82
     std::vector<float> out;
     size_t p = 0;
@@ -750,15 +791,18 @@ struct GpuI2IVectorRecall : recall::Recall {
     }
 };
 
-// recall.Recall with the body of HologresVectorRecallV2.GetCandidateItems (service/recall/hologres_vector_recall_v2.go:96-206):
-// the user's embedding from the VectorDao (handed to the SQL as it is — "v1,v2,…" or "{v1,v2,…}", module/vector_hologres_dao.go:
-// 67-114; the libsvm form of the other DAOs is accepted too), then "ORDER BY pm_approx_squared_euclidean_distance(emb, $1) LIMIT
-// RecallCount" (:23): the RecallCount items of smallest squared Euclidean distance, ascending, Score = distance (:181-189).
+// recall.Recall with the bodies of HologresVectorRecall.GetCandidateItems (service/recall/hologres_vector_recall.go:94-206: "ORDER
+// BY pm_approx_inner_product_distance(emb, $1) desc LIMIT RecallCount", :23) and HologresVectorRecallV2.GetCandidateItems
+// (hologres_vector_recall_v2.go:96-206: "ORDER BY pm_approx_squared_euclidean_distance(emb, $1) LIMIT RecallCount", :23): the user's
+// embedding from the VectorDao (handed to the SQL as it is — "v1,v2,…" or "{v1,v2,…}", module/vector_hologres_dao.go:67-114; the
+// libsvm form of the other DAOs is accepted too), the RecallCount items of largest inner product (descending) / smallest squared
+// Euclidean distance (ascending), Score = distance (v1 :175-183, v2 :181-189), among the rows the WhereClause admits (:56-61).
 // (The user-vector cache of :100-115 is the VectorDao's business here; the result cache of :118-143 / :191-204 is GpuVectorRecall's.)
-struct GpuHologresVectorRecallV2 : recall::Recall {
+struct GpuHologresVectorRecall : recall::Recall {
     Engine* e;
     recconf::RecallConfig conf;
-    GpuHologresVectorRecallV2(Engine* eng, recconf::RecallConfig c) : e(eng), conf(std::move(c)) {}
+    bool l2;
+    GpuHologresVectorRecall(Engine* eng, recconf::RecallConfig c, bool squared_euclidean = true) : e(eng), conf(std::move(c)), l2(squared_euclidean) {}
     static std::vector<float> ParseEmbedding(const std::string& s) {
         if (s.find(':') != std::string::npos) return recall::ParseVectorString(s);
         std::vector<float> out;
@@ -785,11 +829,22 @@ struct GpuHologresVectorRecallV2 : recall::Recall {
         std::vector<uint64_t> rows(k);
         std::vector<float> dist(k);
         uint32_t cnt = 0;
-        if (e->coalesce) {                                  // concurrent requests share the exact pass (up to 32 per pass)
+        if (conf.WhereOp >= 0) {
+            // the filter's column is looked up per request: feature columns may be (re)loaded after the engine is built
+            const int col = e->feats ? pg_features_column_index(e->feats, conf.WhereColumn.c_str()) : -1;
+            if (col < 0) return ret;                        // the SQL would fail on an unknown column: logged, empty (:170-176)
+            if (pg_recall_topk_where(e->ctx, e->table, e->feats, col, conf.WhereOp, conf.WhereValue, l2 ? 1 : 0, vec.data(), 1, k, rows.data(),
+                                     dist.data(), &cnt) != PG_OK)
+                return ret;
+        } else if (e->coalesce) {                           // concurrent requests share the exact pass
             std::string cerr;
             pg_coalescer* co = e->SceneCoalescer(k, &cerr);
-            if (!co || pg_coalescer_recall_l2(co, vec.data(), rows.data(), dist.data(), &cnt) != PG_OK) return ret;
-        } else if (pg_recall_topk_l2(e->ctx, e->table, vec.data(), 1, k, rows.data(), dist.data(), &cnt) != PG_OK) {
+            if (!co) return ret;
+            const int rc = l2 ? pg_coalescer_recall_l2(co, vec.data(), rows.data(), dist.data(), &cnt)
+                              : pg_coalescer_recall(co, vec.data(), rows.data(), dist.data(), &cnt);
+            if (rc != PG_OK) return ret;
+        } else if ((l2 ? pg_recall_topk_l2(e->ctx, e->table, vec.data(), 1, k, rows.data(), dist.data(), &cnt)
+                       : pg_recall_topk(e->ctx, e->table, vec.data(), 1, k, rows.data(), dist.data(), &cnt)) != PG_OK) {
             return ret;
         }
         for (uint32_t i = 0; i < cnt; ++i) {
@@ -1439,7 +1494,8 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
     for (const auto& r : e->config.GpuRecalls) {
         if (r.Kind == "vector") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuVectorRecall>(e.get(), r));
         else if (r.Kind == "i2i") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuI2IVectorRecall>(e.get(), r));
-        else if (r.Kind == "hologres_v2") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuHologresVectorRecallV2>(e.get(), r));
+        else if (r.Kind == "hologres_v2") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuHologresVectorRecall>(e.get(), r, true));
+        else if (r.Kind == "hologres") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuHologresVectorRecall>(e.get(), r, false));
         else if (r.Kind == "page") {
             if (r.RankScore.empty() || r.RankVar.empty() || r.RecallCount <= 0) {
                 if (err) *err = "pairec_gpu.Recalls: Kind \"page\" needs RecallCount, RankScore and RankVar";

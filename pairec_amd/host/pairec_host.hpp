@@ -96,7 +96,12 @@ struct RecallConfig {
     int RecallCount = 0, CacheTime = 0;
     // what the reference's constructors look at before they touch a datasource (recconf.go:330-367)
     std::string DaoAdapterType, VectorDaoAdapterType, HologresName, VectorAlgoType;
-    std::string Kind;                       // pairec_gpu.Recalls only: "vector" (default), "i2i", "page"
+    std::string Kind;                       // pairec_gpu.Recalls only: "vector" (default), "i2i", "hologres", "hologres_v2", "page"
+    // HologresVectorConf.WhereClause / TimeInterval (recconf.go:492-497), in the form the device serves: `column OP constant`
+    std::string WhereClause, WhereColumn;
+    int WhereOp = -1;                       // pg_where_op
+    long long WhereValue = 0;
+    int TimeInterval = 0;
     std::string RankScore, RankVar;         // Kind "page": the RankScore expression and the name the model's score has in it
 };
 struct RankConfig {
@@ -242,6 +247,9 @@ private:
 };
 // vector_recall.go:70-82
 std::vector<float> ParseVectorString(const std::string& s);
+// `column OP integer` of a HologresVectorConf.WhereClause ("${time}" = now - time_interval, hologres_vector_recall.go:56-61);
+// op: pg_where_op.  False for anything else (conjunctions, functions, strings, floats).
+bool ParseWhereClause(const std::string& s, int time_interval, std::string* column, int* op, long long* value);
 // recall.Load (service/recall/recall.go:47-107) over RecallConfs with the reference's outcomes: an unknown RecallType
 // leaves the recall nil → panic("recall empty, name:…"); a type whose constructor opens a DAO / datasource that the
 // entry does not configure panics inside that constructor ("not found VectorDao implement", …).  The mirror has no

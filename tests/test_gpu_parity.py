@@ -510,6 +510,65 @@ def test_recall_l2_small_batches_on_the_4bit_shadow(ctx):
         ctx.set_option("i4_max_lambda", "1.7")
 
 
+def test_recall_with_a_where_clause_matches_the_oracle_on_the_admitted_rows(ctx):
+    """A Hologres vector recall with its WhereClause (hologres_vector_recall.go:23,49-62 / _v2.go:23: "FROM table WHERE …
+    ORDER BY distance LIMIT n"), `column OP constant` over an integer column keyed by item row: only rows that pass are
+    candidates.  Against the oracle run on the admitted rows alone (same row ids, same tie order) for selectivities from one
+    row in two to fewer rows than K, both metrics, 1 to 200 queries, int32 and int64 columns, every operator."""
+    rng = np.random.default_rng(71)
+    n, d, k = 900_000, 128, 500
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d) * rng.uniform(0.7, 1.3, (n, 1)).astype(np.float32)
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    feats = pa.Features(ctx, n)
+    ts32 = rng.integers(0, 1_000_000, n).astype(np.int32)
+    ts64 = (rng.integers(0, 1_000_000, n).astype(np.int64) + (1 << 40))
+    feats.set_column("create_time", pa.F_I32, ts32)
+    feats.set_column("stamp64", pa.F_I64, ts64)
+    ops = {">": np.greater, ">=": np.greater_equal, "<": np.less, "<=": np.less_equal, "==": np.equal, "!=": np.not_equal}
+
+    def check(col, vals, op, value, nq, l2):
+        mask = ops[op](vals, value)
+        idx = np.nonzero(mask)[0]
+        q = (o.synth_rows(o.SEED_QUERY, 11 * nq, nq, d) * np.float32(1.1)).astype(np.float32)
+        rows, sc, cnt = t.recall_topk_where(feats, col, op, value, q, k, l2=l2)
+        m = min(k, idx.size)
+        assert cnt.tolist() == [m] * nq, (op, value, cnt[:4], m)
+        sel = sorted(set([0, nq - 1, nq // 2]))
+        if m:
+            f = o.recall_topk_l2 if l2 else o.recall_topk
+            orow, osc = f(tab[idx], q[sel], k)
+            assert np.array_equal(rows[sel][:, :m], idx[orow.astype(np.int64)].astype(np.uint64)), (op, value, nq, l2)
+            assert np.array_equal(bits(sc[sel][:, :m]), bits(osc)), (op, value, nq, l2)
+        assert np.all(rows[:, m:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+
+    check("create_time", ts32, ">", 500_000, 40, False)          # one row in two
+    check("create_time", ts32, ">=", 900_000, 200, False)        # one in ten, 200 queries (hit records + filter)
+    check("create_time", ts32, "<", 10_000, 3, False)            # one in a hundred, a small batch (4-bit pass + filter)
+    check("create_time", ts32, "<=", 300, 5, False)              # ~ 270 rows: fewer than K
+    check("create_time", ts32, "==", int(ts32[12345]), 2, False)  # a handful of rows
+    check("create_time", ts32, "!=", int(ts32[0]), 17, False)
+    check("stamp64", ts64, ">", (1 << 40) + 700_000, 9, False)
+    check("create_time", ts32, ">", 500_000, 40, True)           # squared Euclidean
+    check("create_time", ts32, ">=", 990_000, 130, True)
+    check("stamp64", ts64, "<", (1 << 40) + 200, 1, True)        # fewer than K, one query
+    check("create_time", ts32, "<", 0, 6, False)                 # nothing passes
+    check("create_time", ts32, ">", 2_000_000, 1, True)
+    # (filters that admit at most an eighth of the table are served from a compact copy of the admitted rows; the same
+    #  answers with the predicate applied in place)
+    ctx.set_option("where_compact_max_rows", 0)
+    check("create_time", ts32, ">=", 900_000, 200, False)
+    check("create_time", ts32, "<", 10_000, 3, False)
+    check("create_time", ts32, "<=", 300, 5, False)
+    check("create_time", ts32, ">=", 990_000, 130, True)
+    ctx.set_option("where_compact_max_rows", 8 << 20)
+    with pytest.raises(pa._lib.PgError):
+        feats.set_column("price", pa.F_F32, np.zeros(n, np.float32))
+        t.recall_topk_where(feats, "price", ">", 1, tab[:1], k)
+    feats.destroy()
+    t.destroy()
+
+
 def test_recall_follows_table_updates(ctx):
     """The screen streams a quantised shadow (int8 here) of the table that is built lazily; uploads, synthetic fills and
     hot swaps must invalidate / carry it — every recall answers for the rows the table holds now."""

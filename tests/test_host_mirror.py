@@ -55,16 +55,28 @@ def test_registry_semantics(H):
     assert H.ph_registry_semantics() == 31
 
 
-def test_gpu_recall_with_a_where_clause_is_refused(H):
-    """HologresVectorConf.WhereClause restricts the reference's SQL candidates (hologres_vector_recall.go:49-62); the device
-    recalls rank the whole table, so a pairec_gpu.Recalls entry that carries one is an error at load time — not a silent
-    full-table answer."""
+def test_gpu_recall_where_clause_forms(H):
+    """HologresVectorConf.WhereClause restricts the reference's SQL candidates (hologres_vector_recall.go:49-62).  The device
+    serves `column OP integer` (with ${time}) on the Kinds hologres / hologres_v2; any other clause, or a clause on another
+    Kind, is an error at load time — not a silent answer over other candidates."""
     import copy
     cfg = copy.deepcopy(CONFIG)
-    cfg["UserDefineConfs"]["pairec_gpu"]["Recalls"][0]["WhereClause"] = "create_time > ${time}"
+    rec = cfg["UserDefineConfs"]["pairec_gpu"]["Recalls"]
+    rec[0]["WhereClause"] = "create_time > ${time}"                     # Kind "vector" (an IAlgorithm's search): no filter there
     assert not H.ph_parse_recconf(json.dumps(cfg).encode())
-    assert b"WhereClause is not supported" in H.ph_last_error()
+    assert b"WhereClause is not supported by Kind" in H.ph_last_error()
     assert not H.ph_engine_create(json.dumps(cfg).encode()) and b"WhereClause" in H.ph_last_error()
+    del rec[0]["WhereClause"]
+    rec.append({"Name": "holo", "Kind": "hologres", "RecallCount": 50, "HologresVectorConf": {"WhereClause": "create_time > ${time}", "TimeInterval": 3600}})
+    assert H.ph_parse_recconf(json.dumps(cfg).encode()), H.ph_last_error()
+    for ok in ("stock>=5", " cat_id = 17 ", "cat_id <> -3", "ts<=1700000000", "a_b1 != 0", "x == 2", "x < ${time}"):
+        rec[1]["HologresVectorConf"]["WhereClause"] = ok
+        assert H.ph_parse_recconf(json.dumps(cfg).encode()), (ok, H.ph_last_error())
+    for bad in ("create_time > ${time} and stock > 0", "lower(name) = 'x'", "price > 1.5", "cat in (1,2)", "> 5", "1x > 5", "x >", "x > 5 5",
+                "x > 99999999999999999999"):
+        rec[1]["HologresVectorConf"]["WhereClause"] = bad
+        assert not H.ph_parse_recconf(json.dumps(cfg).encode()), bad
+        assert b"is not supported (the device serves" in H.ph_last_error()
 
 
 def test_parse_vector_string(H):
@@ -536,6 +548,59 @@ def test_hologres_vector_recall_v2_squared_euclidean(H):
     assert all(x["score"] == by_id[x["item_id"]] for x in out) and {x["retrieve_id"] for x in out} == {"holo_v2"}
     irow, _ = o.recall_topk(scaled, user[None], 120)
     assert set(irow[0].tolist()) != set(orow[0].tolist())
+    H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
+def test_hologres_vector_recalls_with_a_where_clause(H):
+    """HologresVectorRecall / HologresVectorRecallV2 with HologresVectorConf.WhereClause (hologres_vector_recall.go:23,49-62,
+    _v2.go:23): "FROM table WHERE create_time > ${time} ORDER BY distance LIMIT n" — ${time} = now - TimeInterval, fixed when the
+    recall is built.  Against the oracle on the admitted rows alone: a filter that keeps half the table (served in place), one
+    that keeps a fiftieth (served from the compact copy), one that keeps fewer rows than RecallCount, and an unknown column
+    (the reference's SQL error: logged, empty list)."""
+    import copy, time
+    H.ph_engine_set_feature_column.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+    cfg = copy.deepcopy(CONFIG)
+    g = cfg["UserDefineConfs"]["pairec_gpu"]
+    now = int(time.time())
+    g["Recalls"] += [
+        {"Name": "holo_recent", "Kind": "hologres", "RecallCount": 150, "ItemType": "video",
+         "HologresVectorConf": {"WhereClause": "create_time > ${time}", "TimeInterval": 86400}},
+        {"Name": "holo_v2_recent", "Kind": "hologres_v2", "RecallCount": 150, "ItemType": "video",
+         "HologresVectorConf": {"WhereClause": "create_time > ${time}", "TimeInterval": 86400}},
+        {"Name": "holo_cat", "Kind": "hologres", "RecallCount": 150, "WhereClause": "cat_id = 7"},
+        {"Name": "holo_rare", "Kind": "hologres_v2", "RecallCount": 150, "WhereClause": "cat_id >= 49"},
+        {"Name": "holo_nocol", "Kind": "hologres", "RecallCount": 150, "WhereClause": "missing < 3"}]
+    for name in ("holo_recent", "holo_v2_recent", "holo_cat", "holo_rare", "holo_nocol"):
+        cfg["SceneConfs"]["s_" + name] = {"default": {"RecallNames": [name]}}
+    h, _, user = _engine(H, cfg)
+    n = 20000
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, 128)
+    rng = np.random.default_rng(9)
+    # half the items are newer than a day (the clause's constant was fixed within the last seconds: keep a margin around it)
+    age = np.where(rng.random(n) < 0.5, rng.integers(0, 80000, n), rng.integers(90000, 900000, n))
+    create_time = (now - age).astype(np.int32)
+    cat = rng.integers(0, 50, n).astype(np.int32)
+    cat[rng.random(n) < 0.996] %= 49                                    # category 49: a few dozen rows
+    assert H.ph_engine_set_feature_column(h, b"create_time", create_time.ctypes.data, n) == 0, H.ph_last_error()
+    assert H.ph_engine_set_feature_column(h, b"cat_id", cat.ctypes.data, n) == 0, H.ph_last_error()
+    H.ph_set_user_vector(h, b"u3", ("{" + ",".join(repr(float(v)) for v in user) + "}").encode())
+
+    def check(scene, mask, l2, k=150):
+        out = json.loads(H.ph_recommend(h, b"u3", k, scene.encode()))["items"]
+        idx = np.nonzero(mask)[0]
+        f = o.recall_topk_l2 if l2 else o.recall_topk
+        orow, osc = f(tab[idx], user[None], k)
+        m = min(k, idx.size)
+        want = {"item_%d" % idx[int(r)]: float(sc) for r, sc in zip(orow[0][:m], osc[0][:m])}
+        assert len(out) == m and {x["item_id"]: x["score"] for x in out} == want, scene
+
+    check("s_holo_recent", age < 86400, False)
+    check("s_holo_v2_recent", age < 86400, True)
+    check("s_holo_cat", cat == 7, False)
+    assert 0 < int((cat >= 49).sum()) < 150
+    check("s_holo_rare", cat >= 49, True)
+    assert json.loads(H.ph_recommend(h, b"u3", 150, b"s_holo_nocol"))["items"] == []
     H.ph_engine_destroy(h)
 
 
