@@ -75,7 +75,7 @@ def parse_args():
     ap.add_argument("--callers", type=int, default=768, help="host threads of the concurrent-callers leg (0 = skip)")
     ap.add_argument("--callers-seconds", type=float, default=4.0)
     ap.add_argument("--page", type=int, default=100, help="entries each concurrent caller asks for (ctx.Size)")
-    ap.add_argument("--latency-reqs", type=int, default=200,
+    ap.add_argument("--latency-reqs", type=int, default=500,
                     help="single-request latency samples at N=1 (the first 10 %% are discarded as warm-up, SURVEY.md 8d)")
     return ap.parse_args()
 
@@ -951,6 +951,10 @@ def main():
             pipe.begin(dq, R=1)
             pipe.drain()
             lat.append((time.perf_counter() - t1) * 1e3)
+        if os.environ.get("PG_BENCH_LATENCY_TRACE"):
+            med = float(np.median(lat))
+            print("[bench] single-request latencies above twice the median (index, ms): %s" %
+                  [(i, round(v, 2)) for i, v in enumerate(lat) if v > 2 * med], file=sys.stderr, flush=True)
         lat = lat[len(lat) // 10:]
         out["p99_request_latency_ms"] = float(np.percentile(lat, 99))
         out["p50_request_latency_ms"] = float(np.median(lat))

@@ -77,7 +77,7 @@ struct Knobs {
     uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way
     uint32_t screen_early_share_narrow = 512;   // PG_SCREEN_EARLY_SHARE_NARROW: the same for the 8-wave kernels of <= 128 queries
     bool l2_exact = false;                  // PG_L2_EXACT: squared-Euclidean recalls always on the exact scan (A/B runs)
-    uint32_t where_compact_max_rows = 8u << 20;   // PG_WHERE_COMPACT_MAX_ROWS: a filter admitting at most this many rows ...
+    uint32_t where_compact_max_rows = 8u << 20;   // PG_WHERE_COMPACT_MAX_ROWS: a filter admitting at most this many rows (half of it for <= 4 queries) ...
     uint32_t where_compact_min_ratio = 8;         // PG_WHERE_COMPACT_MIN_RATIO: ... and at most 1/ratio of the table is served from a compact copy of them
     double l2_max_slack = 1.0;              // PG_L2_MAX_SLACK: largest pg_table::l2_slack the per-BLOCK cutoff is used for (above: the per-row test)
     uint32_t screen_early_share = 604;      // PG_SCREEN_EARLY_SHARE: share (x 1024) of a SIMD's blocks given to its older wave (256-query screen)

@@ -3361,12 +3361,14 @@ int pg_recall_topk_where(pg_ctx* ctx, const pg_table* t, const pg_features* fs, 
         pg::recall_pad_kernel<<<(uint32_t)(((size_t)nq * k + 255) / 256), 256, 0, ctx->stream>>>(d_rows, d_sc, (size_t)nq * k, metric == 1);
         PG_HIP(hipGetLastError());
         if (out_count) for (uint32_t q = 0; q < nq; ++q) out_count[q] = 0;
-    } else if (admitted <= ctx->knobs.where_compact_max_rows && (uint64_t)admitted * ctx->knobs.where_compact_min_ratio <= t->rows &&
+    } else if (admitted <= (nq <= 4 ? ctx->knobs.where_compact_max_rows / 2 : ctx->knobs.where_compact_max_rows) &&
+               (uint64_t)admitted * ctx->knobs.where_compact_min_ratio <= t->rows &&
                (metric == 0 || t->dim == 64 || t->dim == 128)) {
         // A selective filter: the thresholds the scan plans estimate from samples of the table say little about the few rows
         // that pass (1 % admitted of 100 M rows, 128 queries: 180 ms of re-planned passes).  Gather the admitted rows, in row
         // order, into a compact table and run the exact scan over that: its rows are the candidates, its row order the tie
-        // order, and the answer's local rows map back through the id list.
+        // order, and the answer's local rows map back through the id list.  (The gather is 1 KB of traffic per admitted row: at
+        // 100 M x 128 the copy wins below ~4 M rows for a lone query — in place 2.2 ms at 4 % — and below ~8 M for 16+ queries.)
         const size_t idb = (((size_t)admitted + 64) * 4 + 255) & ~(size_t)255;
         const size_t tabb = (((size_t)admitted + 64) * t->dim * 4 + 255) & ~(size_t)255;
         const size_t nxb = metric == 1 ? (((size_t)admitted + 64) * 4 + 255) & ~(size_t)255 : 0;
