@@ -34,6 +34,11 @@ import os
 import sys
 import time
 
+# The oracle (the checker and the cpu_baseline leg) is an OpenMP library: its worker threads spin for a while after every
+# parallel region, on the cores the HIP runtime's own threads want — single-request latencies measured right after the oracle
+# made the queries picked up 10-100 ms outliers from that.  Passive waiting keeps the checker out of the measurement.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

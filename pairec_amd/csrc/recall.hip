@@ -2414,59 +2414,115 @@ __global__ void filter_count_kernel(RowFilter f, uint64_t rows, unsigned long lo
 
 // ---- selective filters: the admitted rows, in row order (stable compaction), gathered into a compact table ----
 constexpr uint32_t kCompactBlockRows = 1024;
+__device__ __forceinline__ bool filter_cmp(int op, long long v, long long val) {
+    switch (op) {
+        case 0: return v > val;
+        case 1: return v >= val;
+        case 2: return v < val;
+        case 3: return v <= val;
+        case 4: return v == val;
+        default: return v != val;
+    }
+}
+// bit i: row r0 + i passes (r0 a multiple of 4: one 16-B load of an int32 column, two of an int64 one)
+__device__ __forceinline__ uint32_t row_filter_mask4(const RowFilter& f, uint64_t r0, uint64_t rows) {
+    uint32_t m = 0;
+    if (r0 + 4 <= rows) {
+        if (f.dtype == PG_F_I64) {
+            const longlong2 a = reinterpret_cast<const longlong2*>(reinterpret_cast<const long long*>(f.col) + r0)[0];
+            const longlong2 b = reinterpret_cast<const longlong2*>(reinterpret_cast<const long long*>(f.col) + r0)[1];
+            m = (filter_cmp(f.op, a.x, f.val) ? 1u : 0u) | (filter_cmp(f.op, a.y, f.val) ? 2u : 0u) | (filter_cmp(f.op, b.x, f.val) ? 4u : 0u) |
+                (filter_cmp(f.op, b.y, f.val) ? 8u : 0u);
+        } else {
+            const int4 a = *reinterpret_cast<const int4*>(reinterpret_cast<const int32_t*>(f.col) + r0);
+            m = (filter_cmp(f.op, a.x, f.val) ? 1u : 0u) | (filter_cmp(f.op, a.y, f.val) ? 2u : 0u) | (filter_cmp(f.op, a.z, f.val) ? 4u : 0u) |
+                (filter_cmp(f.op, a.w, f.val) ? 8u : 0u);
+        }
+    } else {
+        for (uint32_t i = 0; i < 4 && r0 + i < rows; ++i) m |= row_filter_pass(f, (uint32_t)(r0 + i)) ? 1u << i : 0u;
+    }
+    return m;
+}
 __global__ __launch_bounds__(256) void filter_block_count_kernel(RowFilter f, uint64_t rows, uint32_t* __restrict__ block_n) {
     __shared__ uint32_t ws[4];
-    uint32_t n = 0;
-    for (uint32_t i = threadIdx.x; i < kCompactBlockRows; i += 256) {
-        const uint64_t r = (uint64_t)blockIdx.x * kCompactBlockRows + i;
-        n += (r < rows && row_filter_pass(f, (uint32_t)r)) ? 1u : 0u;
-    }
+    const uint64_t r0 = (uint64_t)blockIdx.x * kCompactBlockRows + threadIdx.x * 4;
+    uint32_t n = r0 < rows ? (uint32_t)__popc(row_filter_mask4(f, r0, rows)) : 0u;
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = n;
     __syncthreads();
     if (threadIdx.x == 0) block_n[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
-// exclusive scan of the block counts in place (one workgroup; n up to a few hundred thousand); total → block_n[n]
-__global__ __launch_bounds__(1024) void filter_scan_kernel(uint32_t* __restrict__ block_n, uint32_t n) {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (n + 1023) / 1024, b = threadIdx.x * per, e = b + per < n ? b + per : n;
-    uint32_t s = 0;
-    for (uint32_t i = b; i < e; ++i) s += block_n[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t i = 0; i < 1024; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; }
-        block_n[n] = acc;
-    }
-    __syncthreads();
-    uint32_t acc = part[threadIdx.x];
-    for (uint32_t i = b; i < e; ++i) { const uint32_t v = block_n[i]; block_n[i] = acc; acc += v; }
-}
-// ids[block offset + rank inside the block] = row, ranks in row order: a wave takes 64 consecutive rows per step
-__global__ __launch_bounds__(256) void filter_scatter_kernel(RowFilter f, uint64_t rows, const uint32_t* __restrict__ block_off,
-                                                             uint32_t* __restrict__ ids) {
-    __shared__ uint32_t wn[4][4];                    // [step][wave] admitted rows
+// The block counts' exclusive scan in two parallel levels: every group of 1024 counts is scanned in place by a workgroup of its
+// own (its total → group_n[g]); one small workgroup then scans the <= 4096 group totals (grand total → group_n[ngroups]).  A
+// block's offset is block_n[b] + group_n[b / 1024].
+__device__ __forceinline__ uint32_t wg1024_exclusive_scan(uint32_t v, uint32_t* wsum, uint32_t* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    bool p[4];
-    uint32_t before[4];
+    uint32_t incl = v;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {                 // rows block * 1024 + st * 256 + thread
-        const uint64_t r = (uint64_t)blockIdx.x * kCompactBlockRows + st * 256 + threadIdx.x;
-        p[st] = r < rows && row_filter_pass(f, (uint32_t)r);
-        const uint64_t m = __builtin_amdgcn_ballot_w64(p[st]);
-        before[st] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (lane == 0) wn[st][w] = (uint32_t)__popcll(m);
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
     }
+    if (lane == 63) wsum[w] = incl;
     __syncthreads();
-    uint32_t base = block_off[blockIdx.x];
+    uint32_t excl = incl - v, all = 0;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        uint32_t pos = base + before[st];
-        for (int j = 0; j < w; ++j) pos += wn[st][j];
-        if (p[st]) ids[pos] = (uint32_t)((uint64_t)blockIdx.x * kCompactBlockRows + st * 256 + threadIdx.x);
-        base += wn[st][0] + wn[st][1] + wn[st][2] + wn[st][3];
+    for (int j = 0; j < 16; ++j) {
+        if (j < w) excl += wsum[j];
+        all += wsum[j];
     }
+    *total = all;
+    return excl;
+}
+__global__ __launch_bounds__(1024) void filter_group_scan_kernel(uint32_t* __restrict__ block_n, uint32_t n, uint32_t* __restrict__ group_n) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = i < n ? block_n[i] : 0u;
+    uint32_t total;
+    const uint32_t excl = wg1024_exclusive_scan(v, wsum, &total);
+    if (i < n) block_n[i] = excl;
+    if (threadIdx.x == 0) group_n[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void filter_total_scan_kernel(uint32_t* __restrict__ group_n, uint32_t ngroups) {
+    __shared__ uint32_t wsum[16];
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = threadIdx.x * 4 + j;
+        v[j] = i < ngroups ? group_n[i] : 0u;
+        s += v[j];
+    }
+    uint32_t total;
+    uint32_t acc = wg1024_exclusive_scan(s, wsum, &total);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = threadIdx.x * 4 + j;
+        if (i < ngroups) group_n[i] = acc;
+        acc += v[j];
+    }
+    if (threadIdx.x == 0) group_n[ngroups] = total;
+}
+// ids[block offset + rank inside the block] = row, ranks in row order: a thread takes 4 consecutive rows, a wave 256
+__global__ __launch_bounds__(256) void filter_scatter_kernel(RowFilter f, uint64_t rows, const uint32_t* __restrict__ block_off,
+                                                             const uint32_t* __restrict__ group_off, uint32_t* __restrict__ ids) {
+    __shared__ uint32_t wn[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t r0 = (uint64_t)blockIdx.x * kCompactBlockRows + threadIdx.x * 4;
+    const uint32_t m = r0 < rows ? row_filter_mask4(f, r0, rows) : 0u;
+    const uint32_t c = (uint32_t)__popc(m);
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wn[w] = incl;
+    __syncthreads();
+    uint32_t pos = block_off[blockIdx.x] + group_off[blockIdx.x >> 10] + incl - c;
+    for (int j = 0; j < w; ++j) pos += wn[j];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i)
+        if (m & (1u << i)) ids[pos++] = (uint32_t)(r0 + i);
 }
 // compact[i][:] = tab[ids[i]][:] (a wave per row-quad: 16 B per lane)
 __global__ void compact_gather_kernel(const float* __restrict__ tab, const uint32_t* __restrict__ ids, uint32_t n, uint32_t dim,
@@ -3344,14 +3400,18 @@ int pg_recall_topk_where(pg_ctx* ctx, const pg_table* t, const pg_features* fs, 
     // Count the admitted rows per 1024-row block (one pass over the column); the scan of those counts is also the compaction's map.
     const uint32_t cblocks = (uint32_t)((t->rows + pg::kCompactBlockRows - 1) / pg::kCompactBlockRows);
     void* cbuf;
-    if ((rc = pg::scratch_reserve(ctx, 12, ((size_t)cblocks + 2) * 4, &cbuf))) return rc;
+    const uint32_t cgroups = (cblocks + 1023) / 1024;
+    PG_REQUIRE(cgroups <= 4096, "pg_recall_topk_where: table of %llu rows too large", (unsigned long long)t->rows);
+    if ((rc = pg::scratch_reserve(ctx, 12, ((size_t)cblocks + cgroups + 2) * 4, &cbuf))) return rc;
     uint32_t* d_blk = (uint32_t*)cbuf;
+    uint32_t* d_grp = d_blk + cblocks;
     uint32_t admitted = 0;
     if (cblocks) {
         pg::filter_block_count_kernel<<<cblocks, 256, 0, ctx->stream>>>(f, t->rows, d_blk);
-        pg::filter_scan_kernel<<<1, 1024, 0, ctx->stream>>>(d_blk, cblocks);
+        pg::filter_group_scan_kernel<<<cgroups, 1024, 0, ctx->stream>>>(d_blk, cblocks, d_grp);
+        pg::filter_total_scan_kernel<<<1, 1024, 0, ctx->stream>>>(d_grp, cgroups);
         PG_HIP(hipGetLastError());
-        PG_HIP(hipMemcpyAsync(&admitted, d_blk + cblocks, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(hipMemcpyAsync(&admitted, d_grp + cgroups, 4, hipMemcpyDeviceToHost, ctx->stream));
         PG_HIP(hipStreamSynchronize(ctx->stream));
     }
     f.admitted = admitted;
@@ -3377,7 +3437,7 @@ int pg_recall_topk_where(pg_ctx* ctx, const pg_table* t, const pg_features* fs, 
         uint32_t* d_ids = (uint32_t*)gbuf;
         float* d_tab = (float*)((char*)gbuf + idb);
         float* d_cnx = nxb ? (float*)((char*)gbuf + idb + tabb) : nullptr;
-        pg::filter_scatter_kernel<<<cblocks, 256, 0, ctx->stream>>>(f, t->rows, d_blk, d_ids);
+        pg::filter_scatter_kernel<<<cblocks, 256, 0, ctx->stream>>>(f, t->rows, d_blk, d_grp, d_ids);
         const uint64_t quads = (uint64_t)admitted * (t->dim / 4);
         pg::compact_gather_kernel<<<(uint32_t)((quads + 255) / 256), 256, 0, ctx->stream>>>(t->d, d_ids, admitted, t->dim, d_tab);
         PG_HIP(hipMemsetAsync(d_tab + (size_t)admitted * t->dim, 0, (size_t)64 * t->dim * 4, ctx->stream));
