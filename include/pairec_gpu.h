@@ -302,6 +302,15 @@ int pg_features_gather_f32_dev(pg_ctx* ctx, const pg_features* fs, const int32_t
 typedef enum { PG_WHERE_GT = 0, PG_WHERE_GE = 1, PG_WHERE_LT = 2, PG_WHERE_LE = 3, PG_WHERE_EQ = 4, PG_WHERE_NE = 5 } pg_where_op;
 int pg_recall_topk_where(pg_ctx* ctx, const pg_table* t, const pg_features* fs, int column, int op, long long value, int metric,
                          const float* queries, uint32_t nq, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_count);
+/* A filtered VIEW of a table: the rows `column OP value` admits, in row order, copied into a table of their own whose recalls answer
+ * with the SOURCE's row ids (ties by source row, as pg_recall_topk_where).  For a WhereClause whose constant is fixed when the recall
+ * is built (hologres_vector_recall.go:56-61 substitutes "${time}" in the constructor): build the view once per table generation and
+ * every recall call — pg_recall_topk[_l2][_dev], pg_coalescer_recall[_l2] / _online_recall of a coalescer created over the view —
+ * serves it at the speed of an unfiltered table of that size (its own shadows, statistics and threshold model; requests of many
+ * callers share a pass).  A snapshot: later changes of the source or the column do not reach it.  Views serve recall calls only: the
+ * recommend calls, and a view as i2i TRIGGER table, are refused (PG_ERR_UNSUPPORTED / PG_ERR_INVALID); rank / DPP / SSD calls take the
+ * source table and the recalled ids.  PG_ERR_INVALID when no row passes.  Destroyed with pg_table_destroy. */
+int pg_table_view_create(pg_ctx* ctx, const pg_table* t, const pg_features* fs, int column, int op, long long value, pg_table** out_view);
 /* FM + two-tower rank straight from candidate rows: the model's item field ids are the integer columns
  * item_field_cols[n_item_fields] of `fs` (out-of-vocabulary ids are clamped as in pg_rank_fm2t_dev) */
 int pg_rank_fm2t_rows_dev(pg_ctx* ctx, const pg_model* m, const pg_features* fs, const int32_t* item_field_cols,

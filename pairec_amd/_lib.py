@@ -16,7 +16,7 @@ EXPORTS = [
     "pg_last_error", "pg_version", "pg_init", "pg_shutdown", "pg_synchronize", "pg_device_malloc",
     "pg_device_free", "pg_memcpy_h2d", "pg_memcpy_d2h", "pg_table_create", "pg_table_destroy",
     "pg_table_fill_synthetic", "pg_table_upload", "pg_table_download", "pg_table_swap",
-    "pg_table_info", "pg_table_gather", "pg_recall_topk", "pg_recall_topk_dev", "pg_recall_topk_l2", "pg_recall_topk_l2_dev", "pg_recall_topk_where",
+    "pg_table_info", "pg_table_gather", "pg_recall_topk", "pg_recall_topk_dev", "pg_recall_topk_l2", "pg_recall_topk_l2_dev", "pg_recall_topk_where", "pg_table_view_create",
     "pg_topk_merge_dev", "pg_model_load", "pg_model_destroy", "pg_rank_dnn3", "pg_rank_dnn3_dev",
     "pg_rank_fm2t", "pg_rank_fm2t_dev", "pg_expr_compile", "pg_expr_free", "pg_expr_num_vars",
     "pg_expr_var_name", "pg_expr_eval", "pg_expr_eval_dev", "pg_sort_scores", "pg_sort_scores_dev",
@@ -121,6 +121,7 @@ def load():
         "pg_recall_topk_l2": [vp, vp, vp, u32, u32, vp, vp, vp],
         "pg_recall_topk_l2_dev": [vp, vp, vp, u32, u32, vp, vp, vp],
         "pg_recall_topk_where": [vp, vp, vp, i32, i32, C.c_longlong, i32, vp, u32, u32, vp, vp, vp],
+        "pg_table_view_create": [vp, vp, vp, i32, i32, C.c_longlong, vp],
         "pg_topk_merge_dev": [vp, vp, vp, u32, u32, u32, u32, vp, vp],
         "pg_model_load": [vp, i32, i32, vp, sz, P(vp)],
         "pg_model_destroy": [vp, vp],

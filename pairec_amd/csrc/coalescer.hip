@@ -1163,6 +1163,7 @@ int pg_coalescer_recall_l2(pg_coalescer* c, const float* query, uint64_t* out_ro
 int pg_coalescer_i2i_recall(pg_coalescer* c, uint32_t trigger_row, uint64_t* out_rows, float* out_scores,
                             uint32_t* out_count) {
     PG_REQUIRE(c && out_rows && out_scores, "pg_coalescer_i2i_recall: NULL argument");
+    PG_REQUIRE(!c->trigger_table->d_row_map, "pg_coalescer_i2i_recall: the trigger table is a filtered view (trigger rows are rows of the source)");
     PG_REQUIRE(trigger_row < c->trigger_table->rows, "pg_coalescer_i2i_recall: trigger row %u outside table of %llu rows", trigger_row,
                (unsigned long long)c->trigger_table->rows);
     pg::Req* r = new pg::Req();

@@ -95,6 +95,10 @@ struct pg_table {
     uint64_t rows = 0;
     uint32_t dim = 0;
     uint64_t row_offset = 0;     // global row id of local row 0 (sharded tables)
+    // a filtered view (pg_table_view_create): the rows of a source table that a WhereClause admits, in row order; recalls
+    // report d_row_map[local row] + map_offset — the source's row ids
+    uint32_t* d_row_map = nullptr;
+    uint64_t map_offset = 0;
     // lazily computed for the screened recall (invalidated by upload / fill): statistics and the shadow of
     // the rows that the screen streams instead of the fp32 rows (the exact re-scoring still gathers fp32):
     //   dim 128: int8, X = rint(x / s8) with ONE scale s8 = max|x| / 127 for the table, [rows + 64][dim] bytes

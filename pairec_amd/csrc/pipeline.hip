@@ -211,6 +211,10 @@ int rank_algo_locked(pg_ctx* ctx, const RankAlgoRef& al, const pg_table* t, cons
 }
 
 int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool first) {
+    if (c.t->d_row_map) {                // the rank stage gathers the recalled rows from the same table: a view reports its source's ids
+        set_error("recommend: the table is a filtered view (pg_table_view_create) — views serve the recall calls only");
+        return PG_ERR_UNSUPPORTED;
+    }
     std::lock_guard<std::mutex> g(ctx->mu);
     TableRead tr(c.t->rw);               // recall, rank and the DPP gather of one batch read one version of the table
     int rc;

@@ -2545,9 +2545,41 @@ __global__ void recall_pad_kernel(uint64_t* __restrict__ rows, float* __restrict
     }
 }
 // local rows of the compact table → the table's global row ids (padding stays UINT64_MAX)
-__global__ void compact_map_rows_kernel(uint64_t* __restrict__ rows, uint64_t n, const uint32_t* __restrict__ ids, uint64_t row_offset) {
+__global__ void compact_map_rows_kernel(uint64_t* __restrict__ rows, uint64_t n, const uint32_t* __restrict__ ids, uint64_t row_offset,
+                                        uint64_t n_ids) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && rows[i] != ~0ull) rows[i] = row_offset + ids[rows[i]];
+    if (i < n && rows[i] < n_ids) rows[i] = row_offset + ids[rows[i]];      // (padding, UINT64_MAX, stays)
+}
+
+// Count the rows `f` admits per 1024-row block (one pass over the column) and scan the counts — the scan is also the compaction's
+// map (filter_scatter_kernel); buffers in scratch slot 12.  Synchronises the stream (the count comes back to the host).
+int filter_count_locked(pg_ctx* ctx, const RowFilter& f, uint64_t rows, uint32_t** d_blk_out, uint32_t** d_grp_out, uint32_t* cblocks_out,
+                        uint32_t* admitted_out) {
+    const uint32_t cblocks = (uint32_t)((rows + kCompactBlockRows - 1) / kCompactBlockRows);
+    const uint32_t cgroups = (cblocks + 1023) / 1024;
+    if (cgroups > 4096) {
+        set_error("filtered recall: table of %llu rows too large", (unsigned long long)rows);
+        return PG_ERR_UNSUPPORTED;
+    }
+    void* cbuf;
+    int rc;
+    if ((rc = scratch_reserve(ctx, 12, ((size_t)cblocks + cgroups + 2) * 4, &cbuf))) return rc;
+    uint32_t* d_blk = (uint32_t*)cbuf;
+    uint32_t* d_grp = d_blk + cblocks;
+    uint32_t admitted = 0;
+    if (cblocks) {
+        filter_block_count_kernel<<<cblocks, 256, 0, ctx->stream>>>(f, rows, d_blk);
+        filter_group_scan_kernel<<<cgroups, 1024, 0, ctx->stream>>>(d_blk, cblocks, d_grp);
+        filter_total_scan_kernel<<<1, 1024, 0, ctx->stream>>>(d_grp, cgroups);
+        PG_HIP(hipGetLastError());
+        PG_HIP(hipMemcpyAsync(&admitted, d_grp + cgroups, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PG_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *d_blk_out = d_blk;
+    *d_grp_out = d_grp;
+    *cblocks_out = cblocks;
+    *admitted_out = admitted;
+    return PG_OK;
 }
 
 // |x|^2 of every row, for the squared-Euclidean recall (lazily, cached until the next upload / fill; shared by the contexts
@@ -3037,6 +3069,11 @@ int recall_job_enqueue(RecallJob* j) {
     if ((rc = final_launch(ctx, rs.cand[r.cur], rs.cnt, rs.cap, j->nq, j->k, t->row_offset, j->d_out_rows,
                            j->d_out_scores, j->d_count)))
         return rc;
+    if (t->d_row_map) {                                // a filtered view answers with its source's row ids
+        const uint64_t n = (uint64_t)j->nq * j->k;
+        compact_map_rows_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, ctx->stream>>>(j->d_out_rows, n, t->d_row_map, t->map_offset, t->rows);
+        PG_HIP(hipGetLastError());
+    }
     if (j->l2) {                                       // the lists were ranked by -d: the distances go out
         const uint64_t n = (uint64_t)j->nq * j->k;
         negate_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, ctx->stream>>>(j->d_out_scores, n);
@@ -3397,23 +3434,8 @@ int pg_recall_topk_where(pg_ctx* ctx, const pg_table* t, const pg_features* fs, 
     uint64_t* d_rows = (uint64_t*)((char*)buf + ((qb + 15) & ~(size_t)15));
     float* d_sc = (float*)((char*)d_rows + rb);
     PG_HIP(hipMemcpyAsync(d_q, queries, qb, hipMemcpyHostToDevice, ctx->stream));
-    // Count the admitted rows per 1024-row block (one pass over the column); the scan of those counts is also the compaction's map.
-    const uint32_t cblocks = (uint32_t)((t->rows + pg::kCompactBlockRows - 1) / pg::kCompactBlockRows);
-    void* cbuf;
-    const uint32_t cgroups = (cblocks + 1023) / 1024;
-    PG_REQUIRE(cgroups <= 4096, "pg_recall_topk_where: table of %llu rows too large", (unsigned long long)t->rows);
-    if ((rc = pg::scratch_reserve(ctx, 12, ((size_t)cblocks + cgroups + 2) * 4, &cbuf))) return rc;
-    uint32_t* d_blk = (uint32_t*)cbuf;
-    uint32_t* d_grp = d_blk + cblocks;
-    uint32_t admitted = 0;
-    if (cblocks) {
-        pg::filter_block_count_kernel<<<cblocks, 256, 0, ctx->stream>>>(f, t->rows, d_blk);
-        pg::filter_group_scan_kernel<<<cgroups, 1024, 0, ctx->stream>>>(d_blk, cblocks, d_grp);
-        pg::filter_total_scan_kernel<<<1, 1024, 0, ctx->stream>>>(d_grp, cgroups);
-        PG_HIP(hipGetLastError());
-        PG_HIP(hipMemcpyAsync(&admitted, d_grp + cgroups, 4, hipMemcpyDeviceToHost, ctx->stream));
-        PG_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    uint32_t *d_blk, *d_grp, cblocks, admitted;
+    if ((rc = pg::filter_count_locked(ctx, f, t->rows, &d_blk, &d_grp, &cblocks, &admitted))) return rc;
     f.admitted = admitted;
     const uint32_t step = metric == 1 ? 128u : (uint32_t)pg::kMaxQueries;
     if (admitted == 0) {
@@ -3458,7 +3480,7 @@ int pg_recall_topk_where(pg_ctx* ctx, const pg_table* t, const pg_features* fs, 
                                             out_count ? out_count + q0 : nullptr, nullptr, false, metric == 1, nullptr, true)))
                 return rc;
         }
-        pg::compact_map_rows_kernel<<<(uint32_t)(((size_t)nq * k + 255) / 256), 256, 0, ctx->stream>>>(d_rows, (uint64_t)nq * k, d_ids, t->row_offset);
+        pg::compact_map_rows_kernel<<<(uint32_t)(((size_t)nq * k + 255) / 256), 256, 0, ctx->stream>>>(d_rows, (uint64_t)nq * k, d_ids, t->row_offset, admitted);
         PG_HIP(hipGetLastError());
         ct.d = nullptr;
         ct.d_nx = nullptr;
@@ -3476,6 +3498,63 @@ int pg_recall_topk_where(pg_ctx* ctx, const pg_table* t, const pg_features* fs, 
     return PG_OK;
 }
 
+// A filtered VIEW of a table: the rows `column OP value` admits, in row order, copied into a table of their own whose recalls
+// answer with the source's row ids.  What a Hologres recall with a WhereClause whose constant is fixed when the recall is built
+// (hologres_vector_recall.go:56-61: "${time}" is substituted in the constructor) searches: build the view once per table
+// generation and every recall flavour — pg_recall_topk[_l2][_dev], a coalescer's pg_coalescer_recall[_l2] — serves it at the speed
+// of an unfiltered table of that size (own shadows, statistics and threshold model).  A snapshot: later changes of the source or
+// the column do not reach it.  Ties break by source row, as in pg_recall_topk_where.  Destroyed with pg_table_destroy.
+int pg_table_view_create(pg_ctx* ctx, const pg_table* t, const pg_features* fs, int column, int op, long long value, pg_table** out_view) {
+    PG_REQUIRE(ctx && t && fs && out_view, "pg_table_view_create: NULL argument");
+    PG_REQUIRE(!t->d_row_map, "pg_table_view_create: the source is a view itself");
+    PG_REQUIRE(column >= 0 && (size_t)column < fs->cols.size(), "pg_table_view_create: column %d out of range", column);
+    PG_REQUIRE(op >= 0 && op <= 5, "pg_table_view_create: op %d unknown (0 >, 1 >=, 2 <, 3 <=, 4 ==, 5 !=)", op);
+    PG_REQUIRE(fs->rows >= t->rows, "pg_table_view_create: the feature store holds %llu rows, the table %llu", (unsigned long long)fs->rows,
+               (unsigned long long)t->rows);
+    const pg_features::Column& c = fs->cols[(size_t)column];
+    if ((c.dtype != PG_F_I32 && c.dtype != PG_F_I64) || !c.d) {
+        pg::set_error("pg_table_view_create: column \"%s\" must be an int32 / int64 column with values", c.name.c_str());
+        return PG_ERR_UNSUPPORTED;
+    }
+    pg::RowFilter f;
+    f.col = c.d;
+    f.dtype = c.dtype;
+    f.op = op;
+    f.val = value;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableRead tr(t->rw);
+    PG_HIP(hipSetDevice(ctx->device));
+    int rc;
+    uint32_t *d_blk, *d_grp, cblocks, admitted;
+    if ((rc = pg::filter_count_locked(ctx, f, t->rows, &d_blk, &d_grp, &cblocks, &admitted))) return rc;
+    if (admitted == 0) {
+        pg::set_error("pg_table_view_create: no row passes the filter");
+        return PG_ERR_INVALID;
+    }
+    pg_table* v = new pg_table();
+    v->rows = admitted;
+    v->dim = t->dim;
+    v->row_offset = 0;
+    v->map_offset = t->row_offset;
+    hipError_t e = hipMalloc((void**)&v->d, ((size_t)admitted + 64) * t->dim * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&v->d_row_map, ((size_t)admitted + 64) * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        pg::set_error("pg_table_view_create: hipMalloc(%.1f GB) failed: %s", (double)admitted * t->dim * 4 / 1e9, hipGetErrorString(e));
+        if (v->d) (void)hipFree(v->d);
+        delete v;
+        return PG_ERR_NOMEM;
+    }
+    pg::filter_scatter_kernel<<<cblocks, 256, 0, ctx->stream>>>(f, t->rows, d_blk, d_grp, v->d_row_map);
+    const uint64_t quads = (uint64_t)admitted * (t->dim / 4);
+    pg::compact_gather_kernel<<<(uint32_t)((quads + 255) / 256), 256, 0, ctx->stream>>>(t->d, v->d_row_map, admitted, t->dim, v->d);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipMemsetAsync(v->d + (size_t)admitted * t->dim, 0, (size_t)64 * t->dim * sizeof(float), ctx->stream));
+    PG_HIP(hipMemsetAsync(v->d_row_map + admitted, 0, 64 * sizeof(uint32_t), ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    *out_view = v;
+    return PG_OK;
+}
+
 // I2IVectorRecall (service/recall/item_2_item_vector_racall.go:51-152): the trigger item's own embedding
 // (dao.VectorString(item_id)) is the query of the same inner-product top-K; the trigger is not excluded (the
 // reference's SQL does not exclude it either).
@@ -3483,6 +3562,7 @@ int pg_i2i_recall(pg_ctx* ctx, const pg_table* trigger_table, const uint32_t* tr
                   const pg_table* t, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
     PG_REQUIRE(ctx && trigger_table && t && trigger_rows && out_rows && out_scores, "pg_i2i_recall: NULL argument");
     PG_REQUIRE(trigger_table->dim == t->dim, "pg_i2i_recall: trigger table dim %u != searched table dim %u", trigger_table->dim, t->dim);
+    PG_REQUIRE(!trigger_table->d_row_map, "pg_i2i_recall: the trigger table is a filtered view (trigger rows are rows of the source)");
     PG_REQUIRE(n >= 1 && n <= (uint32_t)pg::kMaxQueries && (t->dim <= 128 || n <= 32), "pg_i2i_recall: %u trigger items per call unsupported", n);
     if (k < 1 || k > 16384) {
         pg::set_error("pg_i2i_recall: k=%u unsupported (1..16384)", k);

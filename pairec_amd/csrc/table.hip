@@ -128,6 +128,7 @@ int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
     if (t->d_pred) PG_HIP(hipFree(t->d_pred));
     if (t->d_nx) PG_HIP(hipFree(t->d_nx));
     if (t->d_nxmin) PG_HIP(hipFree(t->d_nxmin));
+    if (t->d_row_map) PG_HIP(hipFree(t->d_row_map));
     delete t;
     return PG_OK;
 }
@@ -215,6 +216,8 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     PG_HIP(hipDeviceSynchronize());
     std::swap(a->d, b->d);
     std::swap(a->row_offset, b->row_offset);
+    std::swap(a->d_row_map, b->d_row_map);
+    std::swap(a->map_offset, b->map_offset);
     std::swap(a->stats_valid, b->stats_valid);
     std::swap(a->all_finite, b->all_finite);
     std::swap(a->max_norm, b->max_norm);

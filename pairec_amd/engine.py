@@ -202,6 +202,20 @@ class Table:
                                                        _ptr(q[s:e]), e - s, k, _ptr(r_), _ptr(s_), _ptr(c_)))
         return rows, scores, counts
 
+    def view(self, feats: "Features", column: str, op: str, value: int) -> "Table":
+        """The rows `column OP value` admits, as a table of their own whose recalls answer with THIS table's row ids
+        (pg_table_view_create): the WhereClause of a Hologres recall whose constant is fixed when the recall is built."""
+        ops = {">": 0, ">=": 1, "<": 2, "<=": 3, "==": 4, "!=": 5}
+        col = self.ctx.L.pg_features_column_index(feats.h, column.encode())
+        h = C.c_void_p()
+        _lib.check(self.ctx.L.pg_table_view_create(self.ctx.h, self.h, feats.h, col, ops[op], int(value), C.byref(h)))
+        v = Table.__new__(Table)
+        v.ctx, v.dim, v.row_offset, v.h = self.ctx, self.dim, 0, h
+        rows = C.c_uint64()
+        _lib.check(self.ctx.L.pg_table_info(h, C.byref(rows), None, None))
+        v.rows = rows.value
+        return v
+
     def i2i_recall(self, trigger_rows, k: int, trigger_table: Optional["Table"] = None):
         """I2IVectorRecall: rows of `trigger_table` (default: this table) are the queries."""
         tr = np.ascontiguousarray(trigger_rows, dtype=np.uint32)

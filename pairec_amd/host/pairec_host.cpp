@@ -830,12 +830,21 @@ struct GpuHologresVectorRecall : recall::Recall {
         std::vector<float> dist(k);
         uint32_t cnt = 0;
         if (conf.WhereOp >= 0) {
-            // the filter's column is looked up per request: feature columns may be (re)loaded after the engine is built
-            const int col = e->feats ? pg_features_column_index(e->feats, conf.WhereColumn.c_str()) : -1;
-            if (col < 0) return ret;                        // the SQL would fail on an unknown column: logged, empty (:170-176)
-            if (pg_recall_topk_where(e->ctx, e->table, e->feats, col, conf.WhereOp, conf.WhereValue, l2 ? 1 : 0, vec.data(), 1, k, rows.data(),
-                                     dist.data(), &cnt) != PG_OK)
-                return ret;
+            // the admitted rows as a view of the table, built by the first request of a table generation; concurrent requests
+            // share its passes through the view's own coalescer
+            const Engine::FilterView* fv = e->ViewFor(conf, k);
+            if (!fv || fv->empty) return ret;               // unknown column: the SQL would fail (logged, empty :170-176); nothing admitted
+            int rc;
+            if (fv->co)
+                rc = l2 ? pg_coalescer_recall_l2(fv->co, vec.data(), rows.data(), dist.data(), &cnt)
+                        : pg_coalescer_recall(fv->co, vec.data(), rows.data(), dist.data(), &cnt);
+            else if (fv->view)
+                rc = l2 ? pg_recall_topk_l2(e->ctx, fv->view, vec.data(), 1, k, rows.data(), dist.data(), &cnt)
+                        : pg_recall_topk(e->ctx, fv->view, vec.data(), 1, k, rows.data(), dist.data(), &cnt);
+            else                                            // the view could not be built (memory): filter per call
+                rc = pg_recall_topk_where(e->ctx, e->table, e->feats, pg_features_column_index(e->feats, conf.WhereColumn.c_str()), conf.WhereOp,
+                                          conf.WhereValue, l2 ? 1 : 0, vec.data(), 1, k, rows.data(), dist.data(), &cnt);
+            if (rc != PG_OK) return ret;
         } else if (e->coalesce) {                           // concurrent requests share the exact pass
             std::string cerr;
             pg_coalescer* co = e->SceneCoalescer(k, &cerr);
@@ -1257,6 +1266,7 @@ Engine::~Engine() {
         }
         for (auto& kv : co_scene) pg_coalescer_destroy(kv.second);
         for (auto& kv : co_online) pg_coalescer_destroy(kv.second);
+        DropViewsLocked();
         if (model) pg_model_destroy(ctx, model);
         for (auto& kv : named_models) pg_model_destroy(ctx, kv.second);
         if (fm2t) pg_model_destroy(ctx, fm2t);
@@ -1360,6 +1370,45 @@ void Engine::DropCoalescers() {
     co_scene.clear();
     for (auto& kv : co_online) pg_coalescer_destroy(kv.second);
     co_online.clear();
+    DropViewsLocked();
+}
+
+void Engine::DropViewsLocked() {
+    for (auto& kv : co_views) {
+        if (kv.second.co) pg_coalescer_destroy(kv.second.co);
+        if (kv.second.view) pg_table_destroy(ctx, kv.second.view);
+    }
+    co_views.clear();
+}
+
+// The view of a filtered Hologres recall for the table's current generation.  The constant of the clause was fixed when the
+// recall was built (hologres_vector_recall.go:56-61), so the admitted set only changes with the table (ingest.cpp: a commit is
+// exclusive against every request, so no request sees two generations) or with the column (ph_engine_set_feature_column drops
+// the views).  nullptr: no feature column of that name (the SQL would fail).
+const Engine::FilterView* Engine::ViewFor(const recconf::RecallConfig& conf, uint32_t k) {
+    std::lock_guard<std::mutex> g(co_mu);
+    const int col = feats ? pg_features_column_index(feats, conf.WhereColumn.c_str()) : -1;
+    if (col < 0) return nullptr;
+    FilterView& fv = co_views[conf.Name];
+    const uint64_t gen = generation.load();
+    if (fv.generation == gen) return &fv;
+    if (fv.co) pg_coalescer_destroy(fv.co);
+    if (fv.view) pg_table_destroy(ctx, fv.view);
+    fv = FilterView();
+    fv.generation = gen;
+    const int rc = pg_table_view_create(ctx, table, feats, col, conf.WhereOp, conf.WhereValue, &fv.view);
+    if (rc == PG_ERR_INVALID) { fv.empty = true; return &fv; }           // no row passes: every answer is empty
+    if (rc != PG_OK) { fv.failed = true; fv.view = nullptr; return &fv; }
+    if (coalesce) {
+        pg_scene_config sc;
+        memset(&sc, 0, sizeof sc);
+        sc.base.k = k;
+        sc.base.max_wait_us = coalesce_wait_us;
+        sc.base.depth = coalesce_depth;
+        sc.base.timeout_us = coalesce_timeout_us;
+        if (pg_coalescer_create_scene(ctx, fv.view, &sc, &fv.co) != PG_OK) fv.co = nullptr;    // direct calls on the view then
+    }
+    return &fv;
 }
 
 pg_coalescer* Engine::PageCoalescer(const recconf::RecallConfig& conf, std::string* err) {

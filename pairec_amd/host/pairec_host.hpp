@@ -418,6 +418,17 @@ public:
     std::vector<std::string> fm2t_columns;              // the FM model's item field columns (the "fm2t" algorithm's configuration)
     uint32_t fm2t_d_user = 0, fm2t_nuf = 0;
     std::map<std::string, std::pair<pg_coalescer*, pg_expr*>> co_page;   // page recalls: name → (coalescer, compiled RankScore)
+    // Hologres recalls with a WhereClause: the admitted rows as a filtered view of the table (pg_table_view_create), built by the
+    // first request of a table generation, with a coalescer of its own when Coalesce is on
+    struct FilterView {
+        pg_table* view = nullptr;
+        pg_coalescer* co = nullptr;
+        uint64_t generation = ~0ull;
+        bool empty = false, failed = false;      // no row passes / the view could not be built (the per-call form serves)
+    };
+    std::map<std::string, FilterView> co_views;         // by recall name
+    const FilterView* ViewFor(const recconf::RecallConfig& conf, uint32_t k);
+    void DropViewsLocked();
     pg_coalescer* SceneCoalescer(uint32_t k, std::string* err);
     pg_coalescer* OnlineCoalescer(uint32_t k, std::string* err);
     void DropCoalescers();

@@ -569,6 +569,65 @@ def test_recall_with_a_where_clause_matches_the_oracle_on_the_admitted_rows(ctx)
     t.destroy()
 
 
+def test_filtered_view_recalls_report_the_source_rows(ctx):
+    """pg_table_view_create: the rows a WhereClause admits (constant fixed when the recall is built, hologres_vector_recall.go:
+    56-61) as a table of their own.  Every recall flavour over the view — inner product and squared Euclidean, 1 to 200
+    queries (4-bit pass, screened pass, hit records), the coalescer's per-request calls from 96 threads — answers with the
+    SOURCE table's row ids, exactly the oracle's top-K over the admitted rows (ties by source row).  Views serve recalls only."""
+    import threading
+    rng = np.random.default_rng(5)
+    n, d, k = 600_000, 128, 400
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d) * rng.uniform(0.8, 1.25, (n, 1)).astype(np.float32)
+    tab[1000:1040] = tab[2000:2040]                                       # duplicates: ties by source row
+    off = 1 << 20
+    t = pa.Table(ctx, n, d, row_offset=off)
+    t.upload(tab)
+    feats = pa.Features(ctx, n)
+    cat = rng.integers(0, 10, n).astype(np.int32)
+    cat[1000:1040] = 3
+    cat[2000:2040] = 3
+    feats.set_column("cat", pa.F_I32, cat)
+    feats.set_column("stamp", pa.F_I64, np.arange(n, dtype=np.int64) + (1 << 41))
+    for col, op, value, mask in (("cat", "==", 3, cat == 3), ("stamp", ">=", (1 << 41) + n - 300, np.arange(n) >= n - 300),
+                                 ("cat", "!=", 0, cat != 0)):
+        idx = np.nonzero(mask)[0]
+        v = t.view(feats, col, op, value)
+        assert v.rows == idx.size
+        m = min(k, idx.size)
+        for nq, l2 in ((1, False), (3, True), (40, False), (130, True), (200, False)):
+            q = (o.synth_rows(o.SEED_QUERY, 17 * nq, nq, d) * np.float32(1.05)).astype(np.float32)
+            rows, sc, cnt = (v.recall_topk_l2 if l2 else v.recall_topk)(q, k)
+            sel = sorted(set([0, nq // 2, nq - 1]))
+            orow, osc = (o.recall_topk_l2 if l2 else o.recall_topk)(tab[idx], q[sel], k)
+            assert cnt.tolist() == [m] * nq
+            assert np.array_equal(rows[sel][:, :m], (idx[orow[:, :m].astype(np.int64)] + off).astype(np.uint64)), (col, nq, l2)
+            assert np.array_equal(bits(sc[sel][:, :m]), bits(osc[:, :m])), (col, nq, l2)
+            assert np.all(rows[:, m:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+        if col == "cat" and op == "==":
+            # the same answers as the per-call form, and through a coalescer over the view
+            q = o.synth_rows(o.SEED_QUERY, 900, 96, d)
+            wr, ws, _ = t.recall_topk_where(feats, col, op, value, q, k)
+            vr, vs, _ = v.recall_topk(q, k)
+            assert np.array_equal(wr, vr) and np.array_equal(bits(ws), bits(vs))
+            co = pa.Coalescer(ctx, v, k, algos=[], max_wait_us=2000)
+            got = [None] * 96
+            th = [threading.Thread(target=lambda i=i: got.__setitem__(i, co.recall_l2(q[i]) if i % 2 else co.recall(q[i]))) for i in range(96)]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            lr, ls, _ = v.recall_topk_l2(q, k)
+            for i in range(96):
+                want = (lr[i], ls[i]) if i % 2 else (vr[i], vs[i])
+                assert np.array_equal(got[i][0], want[0]) and np.array_equal(bits(got[i][1]), bits(want[1])), i
+            with pytest.raises(pa._lib.PgError):
+                co.i2i_recall(5)                                         # trigger rows are rows of the source
+            co.destroy()
+        v.destroy()
+    with pytest.raises(pa._lib.PgError):
+        t.view(feats, "cat", ">", 100)                                    # nothing passes
+    feats.destroy()
+    t.destroy()
+
+
 def test_recall_follows_table_updates(ctx):
     """The screen streams a quantised shadow (int8 here) of the table that is built lazily; uploads, synthetic fills and
     hot swaps must invalidate / carry it — every recall answers for the rows the table holds now."""

@@ -601,6 +601,25 @@ def test_hologres_vector_recalls_with_a_where_clause(H):
     assert 0 < int((cat >= 49).sum()) < 150
     check("s_holo_rare", cat >= 49, True)
     assert json.loads(H.ph_recommend(h, b"u3", 150, b"s_holo_nocol"))["items"] == []
+    # the filter's view follows the column: category 7 moves to other items
+    cat2 = np.roll(cat, 1234)
+    assert H.ph_engine_set_feature_column(h, b"cat_id", cat2.ctypes.data, n) == 0, H.ph_last_error()
+    check("s_holo_cat", cat2 == 7, False)
+    H.ph_engine_destroy(h)
+    # Coalesce on: the view has a coalescer of its own; 48 requests from 16 threads per filtered recall
+    g["Coalesce"] = {"MaxWaitUs": 2000}
+    h, _, user = _engine(H, cfg)
+    assert H.ph_engine_set_feature_column(h, b"create_time", create_time.ctypes.data, n) == 0, H.ph_last_error()
+    assert H.ph_engine_set_feature_column(h, b"cat_id", cat.ctypes.data, n) == 0, H.ph_last_error()
+    H.ph_set_user_vector(h, b"u3", ("{" + ",".join(repr(float(v)) for v in user) + "}").encode())
+    H.ph_recommend_concurrent.restype = C.c_char_p
+    H.ph_recommend_concurrent.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    for scene, mask, l2 in (("s_holo_cat", cat == 7, False), ("s_holo_v2_recent", age < 86400, True)):
+        pages = json.loads(H.ph_recommend_concurrent(h, json.dumps(["u3"] * 48).encode(), 150, scene.encode(), 16))
+        idx = np.nonzero(mask)[0]
+        orow, osc = (o.recall_topk_l2 if l2 else o.recall_topk)(tab[idx], user[None], 150)
+        want = {"item_%d" % idx[int(r)]: float(sc) for r, sc in zip(orow[0], osc[0])}
+        assert len(pages) == 48 and all({x["item_id"]: x["score"] for x in p["items"]} == want for p in pages), scene
     H.ph_engine_destroy(h)
 
 
