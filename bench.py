@@ -502,7 +502,7 @@ def rank_shapes_leg(pa, o, ctx, table, R, K):
             pmc = json.load(f)
     except (OSError, ValueError):
         pass
-    kernels = {(512, 256): "pg::dnn3_ws_kernel", (1024, 512): "pg::mlp_kernel<1, 1024, 512, ...>"}
+    kernels = {(512, 256): "pg::dnn3_ws_kernel", (1024, 512): "pg::dnn3_ls_kernel"}
     out = []
     for h1, h2 in RANK_SHAPES:
         w = o.Dnn3Weights(d_user=128, d_item=128, h1=h1, h2=h2, seed=o.SEED_WEIGHTS ^ (h1 + h2))
