@@ -608,6 +608,70 @@ def l2_recall_leg(pa, o, ctx, rows, K):
     return out
 
 
+def where_recall_leg(pa, o, ctx, rows, K):
+    """Hologres vector recalls with a WhereClause (hologres_vector_recall.go:23,56-61): `create_time >= constant` over an int32
+    item column on the benchmark's table shape, inner product, host buffers in and out — the per-call filter
+    (pg_recall_topk_where) and a filtered view (pg_table_view_create) at three selectivities, a slice checked against the
+    oracle run on the admitted rows alone."""
+    d = 128
+    t = pa.Table(ctx, rows, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    feats = pa.Features(ctx, rows)
+    rng = np.random.default_rng(23)
+    col = rng.integers(0, 1_000_000, rows).astype(np.int32)
+    feats.set_column("create_time", pa.F_I32, col)
+    out = {"workload": "inner-product top-%d of the rows of a %d x %d fp32 table that `create_time >= c` admits (exact)" % (K, rows, d)}
+
+    def best_ms(f):
+        f()
+        f()
+        b = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            f()
+            b = min(b, time.perf_counter() - t0)
+        return b * 1e3
+    for frac in (0.5, 0.1, 0.01):
+        c = int(1_000_000 * (1 - frac))
+        res = {}
+        for nq in (1, 128):
+            q = o.synth_rows(o.SEED_QUERY, 0, nq, d)
+            res["per_call_ms_%d_queries" % nq] = best_ms(lambda: t.recall_topk_where(feats, "create_time", ">=", c, q, K))
+        t0 = time.perf_counter()
+        v = t.view(feats, "create_time", ">=", c)
+        res["view_build_ms"] = (time.perf_counter() - t0) * 1e3
+        res["view_rows"] = v.rows
+        for nq in (1, 128):
+            q = o.synth_rows(o.SEED_QUERY, 0, nq, d)
+            for _ in range(4):
+                v.recall_topk(q, K)                        # shadows, statistics, threshold model of the view
+            res["view_ms_%d_queries" % nq] = best_ms(lambda: v.recall_topk(q, K))
+        res["view_requests_per_s_at_128"] = 128 / (res["view_ms_128_queries"] * 1e-3)
+        if frac == 0.01:
+            q = o.synth_rows(o.SEED_QUERY, 500, 3, d)
+            idx = np.nonzero(col >= c)[0]
+            full_head = t.download(0, min(rows, 4_000_000))
+            keep = idx[idx < full_head.shape[0]]
+            orow, osc = o.recall_topk(full_head[keep], q, 50)
+            # the same filter restricted to the head of the table: a second column that also excludes the tail
+            col2 = col.copy()
+            col2[full_head.shape[0]:] = -1
+            feats.set_column("create_time_head", pa.F_I32, col2)
+            r1, s1, _ = t.recall_topk_where(feats, "create_time_head", ">=", c, q, 50)
+            v2 = t.view(feats, "create_time_head", ">=", c)
+            r2, s2, _ = v2.recall_topk(q, 50)
+            v2.destroy()
+            want = keep[orow.astype(np.int64)].astype(np.uint64)
+            out["slice_matches_oracle"] = bool(np.array_equal(r1, want) and np.array_equal(r2, want) and
+                                               np.array_equal(s1.view(np.uint32), osc.view(np.uint32)) and
+                                               np.array_equal(s2.view(np.uint32), osc.view(np.uint32)))
+        v.destroy()
+        out["admitted_%g" % frac] = res
+    feats.destroy()
+    t.destroy()
+    return out
+
+
 def cfg4_leg(pa, o, ctx, R, K):
     """BASELINE.json configs[3]: FM (8 + 8 fields, k = 16) + two-tower (128 → 256 → 64) rank of R x K candidates,
     field tables of 1M rows each.  HBM-gather bound: 544 algorithmic bytes per item."""
@@ -1013,6 +1077,7 @@ def main():
         out["other_configs"] = {"cfg1": cfg1_leg(pa, o, ctx), "cfg4": cfg4_leg(pa, o, ctx, R, K),
                                 "cfg5_one_shard": cfg5_leg(pa, o, R, K, prec)}
         out["l2_recall"] = l2_recall_leg(pa, o, ctx, args.rows, K)
+        out["where_recall"] = where_recall_leg(pa, o, ctx, args.rows, K)
 
     if rank == 0 and extras and not args.no_live_traffic and not os.environ.get("PG_BENCH_CHILD"):
         # roofline.traffic, live: the same scan stage under rocprofv3 --pmc in two child runs (the tables of this process are
