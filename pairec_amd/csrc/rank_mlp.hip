@@ -183,6 +183,12 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
     constexpr bool PRE = PREC == 1 && OCC >= 2;        // preloaded B fragments (bf16, several workgroups per CU)
     bf16x8 b1f[PRE ? KG1 : 1][PRE ? L1NB : 1];
     bf16x8 b2f[PRE ? KGC : 1][PRE ? L2NB : 1];
+#ifdef PG_MLP_PROFILE
+    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_readcyclecounter();
+#define MLP_MARK(i) { const uint64_t tn = __builtin_readcyclecounter(); prof[i] += tn - tp; tp = tn; }
+#else
+#define MLP_MARK(i)
+#endif
 
     // ---------------- gather prologue: 32 lanes x 16 B per item, 8 items per pass ------------
     {
@@ -349,7 +355,9 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             }
         }
     }
+    MLP_MARK(0)
     __syncthreads();
+    MLP_MARK(1)
 
     const int mrow0 = wm * MB * 32;
     f32x16 acc2[MB][L2NB];
@@ -402,6 +410,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             gemm_tile<PREC, MB, L1NB, kDIN, true>(acc1, XT, mrow0, reinterpret_cast<const char*>(a.w1p),
                                                   frag1(chunk), lane);
         }
+        MLP_MARK(2)
         // relu → P() → H1 chunk tile (A operand of layer 2): one packed store per 4 columns
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
@@ -416,7 +425,9 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                     store_h_quad<PREC, CH>(H1T, row, col, v0 > 0.0f ? v0 : 0.0f, v1 > 0.0f ? v1 : 0.0f,
                                            v2 > 0.0f ? v2 : 0.0f, v3 > 0.0f ? v3 : 0.0f);
                 }
+        MLP_MARK(3)
         __syncthreads();
+        MLP_MARK(4)
         // ---- layer 2 partial: acc2 += H1chunk · W2[chunk*CH .. +CH, :]
         if constexpr (PRE) {
             gemm_tile_pre<MB, L2NB, CH>(acc2, H1T, mrow0, b2f, lane);
@@ -426,7 +437,9 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             gemm_tile<PREC, MB, L2NB, CH, true>(acc2, H1T, mrow0, reinterpret_cast<const char*>(a.w2p),
                                                 frag2(chunk), lane);
         }
+        MLP_MARK(5)
         if (NH1 == 1 || chunk + 1 == NCHUNK) __syncthreads();
+        MLP_MARK(6)
     }
 
     // ---- layer-2 activation → H2 tile (fp32; rows padded by one 16-B quad: an odd number of quads per
@@ -502,6 +515,15 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
         }
         if (tid < BM && (uint32_t)tid < cnt) a.out[item0 + tid] = 1.0f / (1.0f + expf(-(ph[0] + ph[1])));
     }
+#ifdef PG_MLP_PROFILE
+    if constexpr (MODEL == 3 && PREC == 1) {           // (field_emb is unused by this instance: the launcher points it at a buffer)
+        MLP_MARK(7)
+        if (lane == 0 && blockIdx.x >= 5000 && blockIdx.x < 5016) {
+            uint64_t* o = (uint64_t*)(a.field_emb) + ((blockIdx.x - 5000) * 4 + wave) * 8;
+            for (int i = 0; i < 8; ++i) o[i] = prof[i];
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -832,6 +854,25 @@ static int launch_fm2t_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
         if constexpr (PREC == 1) {
             constexpr size_t lds = mlp_lds_bytes(1, TO, 128, 1, kFmBM);
             if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, TH, TO, false, 2, 2, 3, 128, 1, 2, FK, kFmBM>, lds))) return rc;
+#ifdef PG_MLP_PROFILE
+            // developer aid (make MLP_EXTRA=-DPG_MLP_PROFILE): per-phase cycle counts of 16 mid-grid workgroups, printed once
+            static uint64_t* dbg = nullptr;
+            if (!dbg) (void)hipMalloc(&dbg, 16 * 4 * 8 * 8);
+            MlpArgs b = a;
+            b.field_emb = reinterpret_cast<const float* const*>(dbg);
+            mlp_kernel<1, TH, TO, false, 2, 2, 3, 128, 1, 2, FK, kFmBM><<<grid, 256, lds, ctx->stream>>>(b);
+            uint64_t hcyc[16 * 4 * 8];
+            (void)hipMemcpy(hcyc, dbg, sizeof hcyc, hipMemcpyDeviceToHost);
+            static int calls = 0;
+            if (++calls == 5) {
+                double av[8] = {0};
+                for (int w = 0; w < 64; ++w)
+                    for (int i = 0; i < 8; ++i) av[i] += (double)hcyc[w * 8 + i] / 64.0;
+                fprintf(stderr, "mlp model 3, mean cycles per wave and tile: gather+fm %.0f | barrier %.0f | L1 mfma %.0f | relu+store %.0f | barrier %.0f | L2 mfma %.0f | barrier %.0f | head %.0f\n",
+                        av[0], av[1], av[2], av[3], av[4], av[5], av[6], av[7]);
+            }
+            return PG_OK;
+#endif
             mlp_kernel<1, TH, TO, false, 2, 2, 3, 128, 1, 2, FK, kFmBM><<<grid, 256, lds, ctx->stream>>>(a);
         } else {
             constexpr size_t lds = mlp_lds_bytes(0, TO, 128, 1);
