@@ -2761,6 +2761,11 @@ struct PlanRun {                     // the launches of one plan (helper of reca
     bool susp_clean = true;          // recall_init_kernel left the suspect counters at zero: the plan's first screened launch skips its memset
     bool no_i8 = false;              // the plan launches no int8 / bf16 screen (thresholds predicted, full pass on the 4-bit shadow):
                                      // its integer-unit thresholds are not needed
+    bool exact_chunks = false;       // every chunk on the exact scan: the safe plan of a FILTERED recall.  Its thresholds stay open until K
+                                     // admitted rows were seen — under a selective filter, for many chunks — and a screened chunk with open
+                                     // thresholds makes every row a suspect of every query: the hit-record regions are sized for the bounded
+                                     // chunk spread evenly over the waves, the waves' shares are not even.  The exact scan stages admitted
+                                     // rows only, at most the chunk's rows per query.
 
     explicit PlanRun(RecallJob* job) : j(job), ctx(job->ctx), t(job->t), rs(job->rs) {}
 
@@ -2775,7 +2780,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
         }
         PG_HIP(hipEventRecord(pool[2 * n_ev], ctx->stream));
         const uint32_t nq = j->nq;
-        if (j->screen && !thr_is_open) {
+        if (j->screen && !thr_is_open && !exact_chunks) {
             ScreenArgs sa;
             sa.tab16 = t->shadow_is_i8 ? (const void*)t->d8 : (const void*)t->d16;
             sa.blk_norm2 = t->dnorm2;
@@ -3062,7 +3067,8 @@ int recall_job_enqueue(RecallJob* j) {
     } else {
         // measured: growth 4 is best for the exact scan, 2 for the screened scan whose re-scoring
         // gathers 512 B per staged candidate
-        const double growth = kn.chunk_growth > 1.0 ? kn.chunk_growth : (j->screen ? 2.0 : 4.0);
+        r.exact_chunks = plan == kSafe && j->filter.col;
+        const double growth = kn.chunk_growth > 1.0 ? kn.chunk_growth : (j->screen && !r.exact_chunks ? 2.0 : 4.0);
         if ((rc = r.grow_scan(j->nblocks, 1, j->k, growth, plan == kSafe))) return rc;
     }
     PG_HIP(hipEventRecord((*j->events)[1], ctx->stream));

@@ -56,7 +56,12 @@ while time.time() < t_end:
         compact_off = rng.random() < 0.25
         if compact_off:
             ctx.set_option("where_compact_max_rows", 0)
-        rows, sc, cnt = t.recall_topk_where(feats, "c64" if use64 else "c32", op, value, q, k, l2=l2)
+        try:
+            rows, sc, cnt = t.recall_topk_where(feats, "c64" if use64 else "c32", op, value, q, k, l2=l2)
+        except Exception:
+            print("FAILED CASE:", dict(n=n, d=d, prof=int(prof), off=off, card=card, use64=use64, op=op, value=value, admitted=int(idx.size), k=k, nq=nq, l2=l2,
+                                        compact_off=compact_off), flush=True)
+            raise
         if compact_off:
             ctx.set_option("where_compact_max_rows", 8 << 20)
         m = min(k, idx.size)

@@ -561,6 +561,10 @@ def test_recall_with_a_where_clause_matches_the_oracle_on_the_admitted_rows(ctx)
     check("create_time", ts32, "<", 10_000, 3, False)
     check("create_time", ts32, "<=", 300, 5, False)
     check("create_time", ts32, ">=", 990_000, 130, True)
+    # a handful of admitted rows, 256 queries: thresholds stay open through every chunk of the last-resort plan (it must not
+    # put such chunks on the screened scan: every row would be a suspect of every query)
+    check("create_time", ts32, "==", int(ts32[12345]), 256, False)
+    check("create_time", ts32, "==", int(ts32[777]), 200, True)
     ctx.set_option("where_compact_max_rows", 8 << 20)
     with pytest.raises(pa._lib.PgError):
         feats.set_column("price", pa.F_F32, np.zeros(n, np.float32))
