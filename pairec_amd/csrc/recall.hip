@@ -2812,10 +2812,19 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             sa.l2_b = j->l2 ? rs.thr_ref : nullptr;    // (no refinement step under this metric: its buffer carries B_q)
             const uint32_t rec_waves = (uint32_t)ctx->num_cus * 8u;
             if (records) {
-                // a region per wave: four times the share of 256 x K suspects a wave expects, never below the 2 048 records the
-                // safe plan's bounded chunks can leave in one region (kCandSlack / 2 rows over >= 2 048 waves: 4 blocks x 8 x 64)
+                // a region per wave: four times the share of 256 x K suspects a wave expects, never below the records the safe
+                // plan's bounded chunks can leave in one region
                 uint32_t cap_w = (uint32_t)(((uint64_t)kMaxQueries * j->k * 4 / rec_waves + 255) / 256 * 256);
-                const uint32_t floor_w = (kCandSlack / 2 / kPieceRows + rec_waves - 1) / rec_waves * 512;
+                // (the safe plan's chunk — kCandSlack / 2 rows — with EVERY row a suspect of every query, e.g. a table in ascending
+                //  score order: 8 x 64 records per block, and the blocks of a SIMD's pair of waves split as screen_kernel splits
+                //  them — the larger share decides.  Sized for an even split, the early wave's fifth block went to the spill pool,
+                //  which at a small K is small: "overflow in safe mode" on such a table at K = 10, 256 queries.)
+                const uint32_t pairs = (uint32_t)ctx->num_cus * 4u;
+                const uint32_t pb = (kCandSlack / 2 / kPieceRows + pairs - 1) / pairs;
+                const uint32_t es = sa.early_share > 512 ? sa.early_share : 1024 - sa.early_share;
+                uint32_t eb = (uint32_t)(((uint64_t)pb * es + 512) >> 10) + 1;
+                if (eb > pb) eb = pb;
+                const uint32_t floor_w = eb * 512;
                 if (cap_w < floor_w) cap_w = floor_w;
                 // + a spill pool for tables whose best rows sit together: room for all of 256 x 2 K suspects
                 const uint32_t pool_cap = (uint32_t)(((uint64_t)kMaxQueries * j->k * 2 + kRecPoolSlice - 1) / kRecPoolSlice * kRecPoolSlice);

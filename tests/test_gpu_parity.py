@@ -573,6 +573,28 @@ def test_recall_with_a_where_clause_matches_the_oracle_on_the_admitted_rows(ctx)
     t.destroy()
 
 
+def test_recall_hit_records_on_a_table_in_ascending_score_order(ctx):
+    """The last-resort plan's case — every later row beats every earlier one, for every query — at more than 128 queries
+    (hit records) and a small K (a small spill pool): each bounded chunk makes every row a suspect of every query, and the
+    per-wave record regions must hold that for the uneven split of a SIMD's blocks between its two waves."""
+    rng = np.random.default_rng(3)
+    d = 128
+    for n, k, nq in ((1_200_000, 10, 256), (1_000_000, 1, 200), (1_100_000, 300, 129)):
+        v = rng.standard_normal(d).astype(np.float32)
+        v /= np.linalg.norm(v)
+        scale = np.linspace(0.2, 1.0, n, dtype=np.float32)[:, None]
+        tab = (v[None, :] * scale + 0.002 * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+        q = (v[None, :] + 0.05 * rng.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+        t = pa.Table(ctx, n, d)
+        t.upload(tab)
+        rows, sc, cnt = t.recall_topk(q, k)
+        sel = [0, nq // 2, nq - 1]
+        orow, osc = o.recall_topk(tab, q[sel], k)
+        assert np.array_equal(rows[sel], orow) and np.array_equal(bits(sc[sel]), bits(osc)), (n, k, nq)
+        assert cnt.tolist() == [k] * nq
+        t.destroy()
+
+
 def test_filtered_view_recalls_report_the_source_rows(ctx):
     """pg_table_view_create: the rows a WhereClause admits (constant fixed when the recall is built, hologres_vector_recall.go:
     56-61) as a table of their own.  Every recall flavour over the view — inner product and squared Euclidean, 1 to 200
