@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
                                                       const uint32_t* __restrict__ susp,
                                                       const uint32_t* __restrict__ susp_cnt, uint32_t cap,
                                                       uint32_t* __restrict__ cnt, uint64_t* __restrict__ cand,
-                                                      uint32_t* __restrict__ overflow, uint32_t scap,
+                                                      uint32_t* __restrict__ overflow, uint32_t scap, uint32_t n_rows,
                                                       const float* __restrict__ nx = nullptr, const float* __restrict__ nqv = nullptr,
                                                       RowFilter filter = RowFilter()) {
     // (scap: capacity and stride of the suspect lists; cap: of the candidate lists)
@@ -1153,9 +1153,13 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     // The gathers run one unit (a 256-B half of 64 rows) ahead of the arithmetic: while a wave walks one half-row
     // tile, the loads of the next half — or of the next chunk's first half — are in flight (one exposed HBM round
     // trip per chunk and phase before).
+    // (a list that overflowed has holes — the decode kernel reserves a run of slots and writes none of it when the run crosses
+    //  the capacity — whose stale contents may be rows of an earlier, larger table: the plan is discarded, but the gather must
+    //  stay inside this table.  Found as a memory fault by scripts/soak_adversarial.py: zero queries, every row a tie.)
     auto row_of = [&](uint32_t t0) -> uint32_t {
         const uint32_t e = t0 + threadIdx.x;
-        return e < n ? susp[(uint64_t)q * scap + e] : 0u;
+        const uint32_t r = e < n ? susp[(uint64_t)q * scap + e] : 0u;
+        return r < n_rows ? r : 0u;
     };
     constexpr int NPH = DIM / 64;
     const uint32_t step = gridDim.x * 256u;
@@ -2865,13 +2869,13 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             const dim3 rg(i4 ? screen4_rescore_blocks() : kRescoreBlocksPerQuery, nq);
             if (j->l2)
                 rescore_kernel<128, true><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap, rs.cnt,
-                                                                       rs.cand[cur], rs.overflow, scap, t->d_nx, rs.pred_ms, j->filter);
+                                                                       rs.cand[cur], rs.overflow, scap, j->rows, t->d_nx, rs.pred_ms, j->filter);
             else if (t->dim == 64)
                 rescore_kernel<64><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap,
-                                                                rs.cnt, rs.cand[cur], rs.overflow, scap, nullptr, nullptr, j->filter);
+                                                                rs.cnt, rs.cand[cur], rs.overflow, scap, j->rows, nullptr, nullptr, j->filter);
             else
                 rescore_kernel<128><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap,
-                                                                 rs.cnt, rs.cand[cur], rs.overflow, scap, nullptr, nullptr, j->filter);
+                                                                 rs.cnt, rs.cand[cur], rs.overflow, scap, j->rows, nullptr, nullptr, j->filter);
             PG_HIP(hipGetLastError());
         } else {
             // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
