@@ -1,0 +1,124 @@
+"""Soak: DPPSort / SSDSort on the device against the oracle over random candidate sets — sizes 2..1500, dims 64 / 128, clustered
+embeddings, exact duplicates among the candidates, relevance with ties / negative values / a wide range, every option switch,
+random topn / window / alpha / gamma.  Pick sequences must be identical.
+Usage: soak_rerank.py [seconds] [seed]"""
+import os, sys, time
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import oracle as o
+import pairec_amd as pa
+
+def dpp_gap_at(L, picks_before, window, cand_a, cand_b):
+    """Relative gap between the marginal gains d2 of two candidates at the pick where two sequences part (numpy restatement
+    of DPPWithWindow's state at that pick: the picks of the windows before it are masked, the picks of its own window
+    conditioned on).  ~1e-16 x the gains' scale = the argmax there is decided by rounding noise."""
+    n = L.shape[0]
+    done = (len(picks_before) // window) * window
+    existed, own = picks_before[:done], picks_before[done:]
+    d2 = np.diag(L).astype(np.float64).copy()
+    scale = float(np.abs(d2).max())
+    c = []
+    for j in own:
+        dj = np.sqrt(d2[j])
+        e = (L[j] - sum((ci[j] * ci for ci in c), np.zeros(n))) / dj
+        c.append(e)
+        d2 = d2 - e * e
+    return abs(d2[cand_a] - d2[cand_b]) / max(scale, 1e-300)
+
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ctx = pa.Context(0)
+t_end = time.time() + seconds
+cases = bad = skipped = noise = 0
+while time.time() < t_end:
+    d = int(rng.choice([64, 128]))
+    n_tab = int(rng.choice([2000, 20000]))
+    nc = int(rng.choice([1, 3, 12, 200]))
+    centers = rng.standard_normal((nc, d)).astype(np.float32)
+    tab = (centers[rng.integers(0, nc, n_tab)] + np.float32(rng.choice([0.02, 0.2, 1.0])) * rng.standard_normal((n_tab, d))).astype(np.float32)
+    t = pa.Table(ctx, n_tab, d)
+    t.upload(tab)
+    for _ in range(12):
+        n = int(rng.choice([2, 5, 17, 100, 500, 1500]))
+        cand = rng.choice(n_tab, n, replace=n > n_tab // 2).astype(np.uint32)
+        dups = bool(n >= 5 and rng.random() < 0.4)            # exact duplicates among the candidates
+        if dups:
+            cand[rng.integers(0, n, n // 4)] = cand[0]
+        dups = dups or len(set(cand.tolist())) < n
+        rk = rng.integers(0, 4)
+        rel = rng.random(n) if rk == 0 else (np.round(rng.random(n), 1) if rk == 1 else (rng.standard_normal(n) if rk == 2 else rng.random(n) * 5))
+        rel = np.sort(rel)[::-1].copy()
+        topn = int(rng.choice([1, 10, 37, 100, n, n + 5]))
+        window = int(rng.choice([1, 2, 5, 10, 30]))
+        desc = dict(d=d, n=n, topn=topn, window=window, dups=dups, rel_max=float(np.abs(rel).max()))
+        try:
+            if rng.random() < 0.5:
+                alpha = float(rng.choice([0.05, 0.5, 1.0, 2.0]))
+                norm, pos, mode = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(0, 3))
+                hk = rng.standard_normal((n, int(rng.choice([8, 48])))) if rng.random() < 0.3 else None
+                has_table = hk is None or rng.random() < 0.5
+                desc.update(kind="dpp", alpha=alpha, norm=norm, pos=pos, mode=mode, hook=hk is not None, table=has_table)
+                rs, ok = o.dpp_relevance(rel, mode)
+                if not ok:
+                    skipped += 1
+                    continue
+                F = o.dpp_features(tab[cand] if has_table else None, hk, norm, pos)
+                with np.errstate(all="ignore"):
+                    L = o.dpp_kernel_matrix_f(F, rs, alpha)
+                    want = o.dpp_with_window(L, topn, window)
+                if not np.all(np.isfinite(L)):
+                    skipped += 1
+                    continue
+                got, used = pa.dpp_ex(ctx, t if has_table else None, cand, rel, alpha, topn, window, norm, pos, mode, hk)
+                ok2 = np.array_equal(got, want) and np.array_equal(used.view(np.uint64), rs.view(np.uint64))
+            else:
+                gamma = float(rng.choice([0.1, 0.25, 0.5, 1.0]))
+                norm, pos, mode, star = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(0, 3)), bool(rng.integers(0, 2))
+                desc.update(kind="ssd", gamma=gamma, norm=norm, pos=pos, mode=mode, star=star)
+                emb = o.ssd_embeddings(tab[cand], norm, pos)
+                qual, ok = o.ssd_quality(rel, mode)
+                if not ok:
+                    skipped += 1
+                    continue
+                with np.errstate(all="ignore"):
+                    want = o.ssd_window(emb, qual, gamma, topn, window, star)
+                got, gq = pa.ssd(ctx, t, cand, rel, gamma, topn, window, norm, pos, mode, star)
+                ok2 = np.array_equal(got, want) and np.array_equal(gq, qual)
+        except Exception as exn:
+            print("FAILED CASE", desc, repr(exn), flush=True)
+            bad += 1
+            cases += 1
+            continue
+        cases += 1
+        if not ok2 and len(set(int(x) for x in want)) < len(want):
+            # the oracle's own sequence repeats an item: SSD's volume (the product of every pick's residual norm, never divided
+            # again) has overflowed to inf — un-normalised embeddings, hundreds of picks — and items with a zero residual score
+            # inf x 0 = NaN; the reference's MaxIdx then lands on an already selected item.  Nothing to compare in that regime.
+            skipped += 1
+            continue
+        if not ok2:
+            m_ = min(len(got), len(want))
+            first = int(np.argmax(got[:m_] != want[:m_])) if m_ and np.any(got[:m_] != want[:m_]) else -1
+            gap = None
+            if desc["kind"] == "dpp" and first >= 0 and len(got) == len(want):
+                with np.errstate(all="ignore"):
+                    gap = dpp_gap_at(L, [int(x) for x in want[:first]], window if topn > window else max(topn, 1), int(got[first]), int(want[first]))
+            if gap is not None and gap < 1e-9:
+                # exp(alpha r) comes from the device's libm here and from glibc in the oracle (<= 1 ulp apart, as Go's own Exp is
+                # from both): where two candidates' gains agree to rounding noise — exact duplicates, more picks in a window than
+                # the kernel's rank — the argmax may fall either way.  Counted, not failed.
+                noise += 1
+            else:
+                bad += 1
+                print("MISMATCH", desc, "lens", len(got), len(want), "first difference at", first, "relative d2 gap", gap, flush=True)
+                if os.environ.get("SOAK_DUMP"):
+                    outd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+                    os.makedirs(outd, exist_ok=True)
+                    np.savez(os.path.join(outd, "rerank_fail_%d.npz" % bad), emb32=tab[cand], rel=rel, got=got, want=want, desc=repr(desc))
+    t.destroy()
+print(f"soak_rerank: {cases} calls, {bad} bad, {noise} parted at a pick decided by rounding noise (relative gain gap < 1e-9), {skipped} skipped "
+      f"(degenerate relevance / non-finite kernel / the oracle's own sequence repeats items)", flush=True)
+sys.exit(1 if bad else 0)
