@@ -41,6 +41,8 @@ while time.time() < t_end:
     elif kind == "duplicate_runs":
         base = rng.standard_normal((max(n // 5000, 4), d)).astype(np.float32) * np.float32(0.1)
         tab = np.repeat(base, 5000, axis=0)[:n].copy()
+        if tab.shape[0] < n:
+            tab = np.concatenate([tab, 0.1 * noise[: n - tab.shape[0]]])
     elif kind == "all_equal":
         tab = np.repeat(v[None] * np.float32(0.7), n, axis=0)
     elif kind == "zero_rows":
