@@ -20,7 +20,12 @@ while time.time() < t_end:
     n = int(rng.choice([3000, 50_000, 400_000, 1_500_000, 3_000_000]))
     d = int(rng.choice([64, 128, 128]))
     tab = o.synth_rows(o.SEED_TABLE, int(rng.integers(0, 1 << 30)), n, d)
-    prof = rng.integers(0, 3)
+    prof = rng.integers(0, 5)
+    if prof >= 3:                                       # score order ascending / descending in the row index (for queries near v)
+        v_ = rng.standard_normal(d).astype(np.float32)
+        v_ /= np.linalg.norm(v_)
+        ramp = np.linspace(0.2, 1.0, n, dtype=np.float32)[:, None]
+        tab = (v_[None] * (ramp if prof == 3 else ramp[::-1]) + 0.002 * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
     if prof == 1:
         tab = (tab * rng.uniform(0.6, 1.5, (n, 1)).astype(np.float32)).astype(np.float32)
     elif prof == 2:
@@ -35,6 +40,9 @@ while time.time() < t_end:
     card = int(rng.choice([2, 10, 100, 10_000, 1_000_000]))
     col32 = rng.integers(0, card, n).astype(np.int32)
     col64 = (rng.integers(0, card, n).astype(np.int64) - (1 << 40))
+    if rng.random() < 0.4:                              # a column that grows with the row (create_time of a table in insertion order):
+        col32 = (np.arange(n) // max(n // card, 1)).astype(np.int32)          # filters admit contiguous row ranges
+        col64 = col32.astype(np.int64) - (1 << 40)
     feats.set_column("c32", pa.F_I32, col32)
     feats.set_column("c64", pa.F_I64, col64)
     n_tables += 1
@@ -51,6 +59,8 @@ while time.time() < t_end:
             nq = min(nq, 200)
         l2 = bool(rng.integers(0, 2))
         q = (o.synth_rows(o.SEED_QUERY, int(rng.integers(0, 1 << 20)), nq, d) * np.float32(rng.uniform(0.5, 2.0))).astype(np.float32)
+        if prof >= 3 and rng.random() < 0.7:
+            q = (v_[None] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
         if rng.random() < 0.3 and idx.size:
             q[0] = tab[idx[0]]                                     # a query equal to an admitted row
         compact_off = rng.random() < 0.25
