@@ -23,7 +23,7 @@ cases = bad = 0
 while time.time() < t_end:
     kind = str(rng.choice(KINDS))
     d = int(rng.choice([64, 128, 128, 128, 192, 256]))
-    n = int(rng.choice([40_000, 300_000, 1_200_000, 2_500_000]))
+    n = int(rng.choice([1, 5, 31, 33, 100, 2_000, 40_000, 300_000, 1_200_000, 2_500_000]))
     v = rng.standard_normal(d).astype(np.float32)
     v /= np.linalg.norm(v)
     noise = rng.standard_normal((n, d)).astype(np.float32)
@@ -34,12 +34,12 @@ while time.time() < t_end:
         tab = v[None] * ramp[::-1] + 0.002 * noise
     elif kind in ("best_at_head", "best_in_middle", "best_at_tail"):
         tab = 0.1 * noise
-        m = min(int(rng.integers(100, 30_000)), n // 4)
-        a = 0 if kind == "best_at_head" else (n // 2 if kind == "best_in_middle" else n - m)
+        m = max(min(int(rng.integers(100, 30_000)), n // 4), 1)
+        a = 0 if kind == "best_at_head" else (max(n // 2 - m, 0) if kind == "best_in_middle" else n - m)
         tab[a:a + m] += v[None] * rng.uniform(0.8, 1.2, (m, 1)).astype(np.float32)
     elif kind == "duplicate_runs":
         base = rng.standard_normal((max(n // 5000, 4), d)).astype(np.float32)
-        tab = np.repeat(base, 5000, axis=0)[:n].copy()
+        tab = np.repeat(base, max(min(5000, n // 4), 1), axis=0)[:n].copy()
         if tab.shape[0] < n:
             tab = np.concatenate([tab, noise[: n - tab.shape[0]]])
     elif kind == "all_equal":
@@ -48,7 +48,7 @@ while time.time() < t_end:
         tab = noise * (rng.random((n, 1)) < 0.3).astype(np.float32)
     elif kind == "huge_rows":
         tab = 0.3 * noise
-        hi = rng.integers(0, n, 50)
+        hi = rng.integers(0, n, min(50, n))
         tab[hi] *= np.float32(300.0)
     elif kind == "tiny_values":
         tab = noise * np.float32(1e-6)
