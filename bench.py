@@ -158,16 +158,16 @@ def measure_traffic_live(args, R):
 
 def scan_kernel_name(R, dim, elem_bytes):
     """The kernel recall.hip dispatches for the full-table pass at this batch size (dispatch_screen):
-    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH>."""
+    screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH, L2> (L2 = 0: inner product)."""
     if elem_bytes == 0:
         return "pg::scan_kernel<%d,1>" % dim
     if elem_bytes == 1:
         if R > 128:
-            return "pg::screen_kernel<128,4,8,1,0,true,2>"
+            return "pg::screen_kernel<128,4,8,1,0,true,2,0>"
         nqb = 4 if R > 64 else (2 if R > 32 else 1)
-        return "pg::screen_kernel<128,%d,8,1,0,true,1>" % nqb
+        return "pg::screen_kernel<128,%d,8,1,0,true,1,0>" % nqb
     nqb, waves = (8, 4) if R > 128 else ((4, 8) if R > 64 else ((2, 8) if R > 32 else (1, 8)))
-    return "pg::screen_kernel<%d,%d,%d,1,0,false,1>" % (dim, nqb, waves)
+    return "pg::screen_kernel<%d,%d,%d,1,0,false,1,0>" % (dim, nqb, waves)
 
 
 def device_info():

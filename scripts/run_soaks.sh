@@ -1,0 +1,13 @@
+#!/bin/bash
+# Every randomised / adversarial soak, S seconds each (default 60), on the GPU box:
+#   gpurun --timeout 1500 -- 'bash scripts/run_soaks.sh 60'
+# Exit status 1 if any of them reports a mismatch.  DESIGN.md 3 lists what each one covers.
+S=${1:-60}
+cd "$(dirname "$0")/.."
+rc=0
+for s in soak_adversarial soak_where soak_pipeline_adversarial soak_group soak_scene soak_coalescer soak_records soak_l2 soak_rank soak_fm2t soak_rerank; do
+  echo "== $s ($S s)"
+  timeout $((S * 4 + 300)) python3 scripts/$s.py "$S" 2>&1 | grep -a "MISMATCH\|FAILED\|^soak\|^rounds\|fault\|Traceback" | tail -4 || true
+  [ "${PIPESTATUS[0]}" = "0" ] || rc=1
+done
+exit $rc
