@@ -15,9 +15,11 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctx = pa.Context(0)
-bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+def bits(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return np.where(np.isnan(a), np.uint32(0x7FC00000), a.view(np.uint32))       # (a NaN's sign / payload is not part of the answer)
 KINDS = ("ascending", "descending", "best_at_head", "best_in_middle", "best_at_tail", "duplicate_runs", "all_equal", "zero_rows",
-         "huge_rows", "tiny_values", "direction_plus_noise", "two_clusters")
+         "huge_rows", "tiny_values", "direction_plus_noise", "two_clusters", "nonfinite_rows")
 t_end = time.time() + seconds
 cases = bad = 0
 while time.time() < t_end:
@@ -50,6 +52,10 @@ while time.time() < t_end:
         tab = 0.3 * noise
         hi = rng.integers(0, n, min(50, n))
         tab[hi] *= np.float32(300.0)
+    elif kind == "nonfinite_rows":                          # a few NaN / +-inf values in the table (such tables ride the exact scan)
+        tab = 0.3 * noise
+        for val in (np.nan, np.inf, -np.inf):
+            tab[rng.integers(0, n, 3), rng.integers(0, d, 3)] = val
     elif kind == "tiny_values":
         tab = noise * np.float32(1e-6)
     elif kind == "direction_plus_noise":
@@ -73,7 +79,9 @@ while time.time() < t_end:
         qk = rng.integers(0, 3)
         q = (v[None] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32) if qk == 0 else \
             (rng.standard_normal((nq, d)).astype(np.float32) if qk == 1 else tab[rng.integers(0, n, nq)].copy())
-        desc = dict(kind=kind, n=n, d=d, nq=nq, k=k, l2=bool(l2), qk=int(qk))
+        if rng.random() < 0.15:                               # non-finite or enormous query components
+            q[rng.integers(0, nq), rng.integers(0, d)] = rng.choice([np.nan, np.inf, -np.inf, 3e38, 1e-40])
+        desc = dict(kind=kind, n=n, d=d, nq=nq, k=k, l2=bool(l2), qk=int(qk), q_finite=bool(np.all(np.isfinite(q))))
         if os.environ.get('SOAK_TRACE'):
             print('case', desc, flush=True)
         try:
