@@ -260,6 +260,52 @@ struct ExprDev {
     uint32_t n;
 };
 
+// math.Pow as `^` sees it (utils/ast/ast.go:246; Go stdlib math/pow.go, go 1.24 per the reference's go.mod).  Go does not call a
+// libm pow: Pow(x, 1) = x and Pow(x, +-0.5) = Sqrt(x), 1 / Sqrt(x) are exact special cases, and the INTEGER part of the exponent
+// is applied by repeated squaring of Frexp(x)'s mantissa with the binary exponent carried on the side — so 400^4 is exactly
+// 25 600 000 000 where pow() is an ulp off (and that ulp decides whether the power is an integer-valued exponent of the next
+// `^`, or what an integer `%` of it leaves: found by scripts/soak_expr.py).  Integer-valued exponents therefore take Go's loop
+// here, bit for bit (the oracle restates the same loop); fractional ones stay on pow(), within 2 ulp of Go's Exp(yf Log(x)) form.
+__device__ __forceinline__ double go_pow(double x, double y) {
+    if (y == 1.0) return x;
+    const bool xfin = x == x && fabs(x) != __builtin_inf();
+    if (y == 0.5 && xfin && x != 0.0) return sqrt(x);
+    if (y == -0.5 && xfin && x != 0.0) return 1.0 / sqrt(x);
+    const double ay = fabs(y);
+    if (xfin && x != 0.0 && x != 1.0 && y != 0.0 && ay < 9223372036854775808.0 && ay == trunc(ay)) {
+        double a1 = 1.0;
+        long long ae = 0;
+        int xe_i;
+        double x1 = frexp(x, &xe_i);
+        long long xe = xe_i;
+        for (long long i = (long long)ay; i != 0; i >>= 1) {
+            if (xe < -(1ll << 12) || (1ll << 12) < xe) {
+                // overflow / underflow of the result: catch the exponent, stop
+                ae += xe;
+                break;
+            }
+            if (i & 1) {
+                a1 *= x1;
+                ae += xe;
+            }
+            x1 *= x1;
+            xe <<= 1;
+            if (x1 < 0.5) {
+                x1 += x1;
+                xe--;
+            }
+        }
+        if (y < 0.0) {
+            a1 = 1.0 / a1;
+            ae = -ae;
+        }
+        if (ae > 4096) ae = 4096;                     // ldexp's int argument: far beyond the format either way
+        if (ae < -4096) ae = -4096;
+        return ldexp(a1, (int)ae);
+    }
+    return pow(x, y);
+}
+
 __global__ void expr_eval_kernel(ExprDev e, const double* __restrict__ vars, uint32_t n_items,
                                  double* __restrict__ out, uint32_t* __restrict__ err, uint32_t items_per_flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,7 +339,7 @@ __global__ void expr_eval_kernel(ExprDev e, const double* __restrict__ vars, uin
                     else v = (double)(li % ri);
                     break;
                 }
-                case OP_POW: v = pow(l, r); break;
+                case OP_POW: v = go_pow(l, r); break;
                 case OP_FNZ: v = (l != 0.0) ? l : r; break;
             }
             st[sp++] = v;
