@@ -1010,6 +1010,14 @@ def test_expr_matches_oracle_on_5000_items(ctx):
     for s, want1 in (("-5", -5.0), ("2*1e-5", 0.0), ("2^3^2", 64.0), ("7%3", 1.0), ("0#4*2", 8.0)):
         q = pa.Expr(s)
         assert q.eval(ctx, np.zeros((0, 3)))[0] == want1
+    # `^` with an integer-valued exponent is math.Pow's repeated-squaring loop (math/pow.go), not a libm pow: exact where the
+    # products are, Go's own value where they are not; an integer power stays an integer exponent of the next `^`
+    for s, want1 in (("4e2^4e0", 25600000000.0), ("4e2^4e0%1000", 0.0), ("10^308", 1.0000000000000006e308), ("10^309", np.inf),
+                     ("(0-238.9)^(4e2^4e0-8e3)", np.inf), ("(0-238.9)^(4e2^4e0-7999)", -np.inf), ("(0-2)^3", -8.0),
+                     ("1.5^(0-3)", 1.0 / (1.5 * 1.5 * 1.5)), ("7.25^1", 7.25), ("9^0.5", 3.0), ("16^(0-0.5)", 0.25)):
+        q = pa.Expr(s)
+        got1 = q.eval(ctx, np.zeros((0, 3)))[0]
+        assert got1 == want1 and got1 == o.expr_eval(o.expr_parse(s), lambda name: None), s
         q.free()
     e.free()
     z.free()

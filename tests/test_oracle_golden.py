@@ -525,3 +525,16 @@ def test_dnn3_blocked_form_equals_the_rowwise_form():
         b = o.dnn3_forward(w, prec, u, items, threads=-4)
         assert np.array_equal(np.asarray(a).view(np.uint64 if a.dtype == np.float64 else np.uint32),
                               np.asarray(b).view(np.uint64 if b.dtype == np.float64 else np.uint32))
+
+
+def test_expr_pow_follows_gos_integer_power_loop():
+    """math.Pow (math/pow.go) applies the integer part of an exponent by repeated squaring of Frexp(x)'s mantissa with the
+    binary exponent beside it: exact where the products are, and its own value where they are not — the restatement must not
+    fall back on a libm pow for integer-valued exponents."""
+    assert o.go_pow(400.0, 4.0) == 25600000000.0
+    assert o.go_pow(10.0, 308.0) == 1.0000000000000006e308          # (the loop's result; a correctly rounded pow gives 1e308)
+    assert o.go_pow(10.0, 309.0) == float("inf") and o.go_pow(10.0, -330.0) == 0.0
+    assert o.go_pow(-2.0, 3.0) == -8.0 and o.go_pow(-2.0, 4.0) == 16.0
+    assert o.go_pow(-238.9, 25599992000.0) == float("inf") and o.go_pow(-238.9, 25599992001.0) == float("-inf")
+    assert o.go_pow(7.25, 1.0) == 7.25 and o.go_pow(1.5, -3.0) == 1.0 / (1.5 * 1.5 * 1.5)
+    assert o.expr_eval(o.expr_parse("4e2^4e0%1000"), lambda name: None) == 0.0
