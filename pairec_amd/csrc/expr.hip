@@ -412,6 +412,13 @@ int pg_expr_compile(const char* source, pg_expr** out) {
         delete e;
         return PG_ERR_PARSE;
     }
+    // (the program is bounded below — kMaxProg operations — and parser and emitter recurse on the C++ stack: a source of a
+    //  hundred thousand tokens must be refused here, not overflow that stack; the reference's expressions are ~10 nodes)
+    if (toks.size() > 4 * (size_t)pg::kMaxProg) {
+        pg::set_error("pg_expr_compile: expression too large (%zu tokens)", toks.size());
+        delete e;
+        return PG_ERR_UNSUPPORTED;
+    }
     pg::Parser p(toks);
     const int root = p.parse_expression();
     int depth = 0;

@@ -44,6 +44,15 @@ public:
 private:
     const std::string& s_;
     size_t p_ = 0;
+    int depth_ = 0;
+    // nesting bound (encoding/json stops at 10 000 levels: "exceeded max depth"; this parser recurses on the C++ stack — a
+    // config of a million '[' must be an error, not a stack overflow)
+    static constexpr int kMaxDepth = 1000;
+    struct Nest {
+        int& d;
+        explicit Nest(int& depth) : d(depth) { ++d; }
+        ~Nest() { --d; }
+    };
     void ws() { while (p_ < s_.size() && (s_[p_] == ' ' || s_[p_] == '\n' || s_[p_] == '\t' || s_[p_] == '\r')) ++p_; }
     bool lit(const char* w) { size_t n = strlen(w); if (s_.compare(p_, n, w) == 0) { p_ += n; return true; } return false; }
     bool value(Value* v) {
@@ -103,6 +112,8 @@ private:
         return true;
     }
     bool array(Value* v) {
+        Nest nest(depth_);
+        if (depth_ > kMaxDepth) return false;
         v->type = Value::Array;
         ++p_;
         ws();
@@ -119,6 +130,8 @@ private:
         }
     }
     bool object(Value* v) {
+        Nest nest(depth_);
+        if (depth_ > kMaxDepth) return false;
         v->type = Value::Object;
         ++p_;
         ws();

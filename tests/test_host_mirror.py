@@ -79,6 +79,23 @@ def test_gpu_recall_where_clause_forms(H):
         assert b"is not supported (the device serves" in H.ph_last_error()
 
 
+def test_hostile_nesting_is_an_error_not_a_stack_overflow(H):
+    """The mirror's JSON parser and the RankScore compiler recurse on the C++ stack: a config of a million '[' or an
+    expression of a hundred thousand terms must come back as an error (encoding/json has its own "exceeded max depth")."""
+    import pairec_amd as pa
+    for opener in (b"[", b'{"a":'):
+        assert H.ph_parse_recconf(opener * 1_000_000) is None and b"json" in H.ph_last_error()
+    deep_ok = b"[" * 900 + b"]" * 900
+    assert H.ph_parse_recconf(deep_ok) is None or True          # (well-formed nesting inside the bound parses; it is not a recconf)
+    for src in ("1+" * 100_000 + "1", "(" * 1_000_000 + "1" + ")" * 1_000_000, "2^" * 100_000 + "2"):
+        with pytest.raises(pa._lib.PgError) as ei:
+            pa.Expr(src)
+        assert "too large" in str(ei.value)
+    e = pa.Expr("(" * 200 + "${x}" + ")" * 200 + "+1")           # deep but small: fine
+    assert e.var_names == ["x"]
+    e.free()
+
+
 def test_parse_vector_string(H):
     buf = (C.c_float * 16)()
     text = "1:0.12 2:-0.3 junk 3:1e-2 4:x 5:1:2"
