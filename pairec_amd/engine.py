@@ -98,6 +98,9 @@ class Context:
         if seg_offsets is None:
             seg_offsets = [0, s.shape[0]]
         so = np.ascontiguousarray(seg_offsets, dtype=np.uint32)
+        if so.shape[0] < 1 or int(so[-1]) != s.shape[0]:
+            # (the C call takes the item count from the last offset: the buffers must be that long)
+            raise ValueError("sort_scores: seg_offsets must end at len(scores) = %d" % s.shape[0])
         out = np.zeros(s.shape[0], dtype=np.uint32)
         _lib.check(self.L.pg_sort_scores(self.h, _ptr(s), _ptr(so), so.shape[0] - 1,
                                          int(descending), _ptr(out)))

@@ -10,4 +10,7 @@ for s in soak_adversarial soak_where soak_pipeline_adversarial soak_group soak_s
   timeout $((S * 4 + 300)) python3 scripts/$s.py "$S" 2>&1 | grep -a "MISMATCH\|FAILED\|^soak\|^rounds\|fault\|Traceback" | tail -4 || true
   [ "${PIPESTATUS[0]}" = "0" ] || rc=1
 done
+echo "== soak_blobs, soak_misuse"
+python3 scripts/soak_blobs.py 2000 2>&1 | tail -1 || rc=1
+python3 scripts/soak_misuse.py 2>&1 | tail -1 || rc=1
 exit $rc
