@@ -603,11 +603,12 @@ def test_hologres_vector_recalls_with_a_where_clause(H):
     assert H.ph_engine_set_feature_column(h, b"cat_id", cat.ctypes.data, n) == 0, H.ph_last_error()
     H.ph_set_user_vector(h, b"u3", ("{" + ",".join(repr(float(v)) for v in user) + "}").encode())
 
-    def check(scene, mask, l2, k=150):
+    def check(scene, mask, l2, k=150, tab_=None):
+        tab_ = tab if tab_ is None else tab_
         out = json.loads(H.ph_recommend(h, b"u3", k, scene.encode()))["items"]
         idx = np.nonzero(mask)[0]
         f = o.recall_topk_l2 if l2 else o.recall_topk
-        orow, osc = f(tab[idx], user[None], k)
+        orow, osc = f(tab_[idx], user[None], k)
         m = min(k, idx.size)
         want = {"item_%d" % idx[int(r)]: float(sc) for r, sc in zip(orow[0][:m], osc[0][:m])}
         assert len(out) == m and {x["item_id"]: x["score"] for x in out} == want, scene
@@ -622,6 +623,17 @@ def test_hologres_vector_recalls_with_a_where_clause(H):
     cat2 = np.roll(cat, 1234)
     assert H.ph_engine_set_feature_column(h, b"cat_id", cat2.ctypes.data, n) == 0, H.ph_last_error()
     check("s_holo_cat", cat2 == 7, False)
+    # ... and the table: a new generation of rows (same ids) is ingested; the first request afterwards rebuilds the view
+    H.ph_engine_ingest_begin.argtypes = [C.c_void_p]
+    H.ph_engine_ingest_chunk.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint64]
+    H.ph_engine_ingest_commit.argtypes = [C.c_void_p]
+    tab2 = (tab * rng.uniform(0.6, 1.4, (n, 1)).astype(np.float32)).astype(np.float32)
+    assert H.ph_engine_ingest_begin(h) == 0
+    ids = b"".join(b"item_%d\0" % i for i in range(n))
+    assert H.ph_engine_ingest_chunk(h, ids, len(ids), tab2.ctypes.data, n) == 0
+    assert H.ph_engine_ingest_commit(h) == 0
+    check("s_holo_cat", cat2 == 7, False, tab_=tab2)
+    check("s_holo_v2_recent", age < 86400, True, tab_=tab2)
     H.ph_engine_destroy(h)
     # Coalesce on: the view has a coalescer of its own; 48 requests from 16 threads per filtered recall
     g["Coalesce"] = {"MaxWaitUs": 2000}
