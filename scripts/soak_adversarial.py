@@ -15,6 +15,11 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctx = pa.Context(0)
+if os.environ.get("SOAK_SMALL_TABLE_PLANS"):
+    # the plans that only big tables take by default — the 4-bit screen of small batches, the threshold model, the refinement —
+    # on these mid-size structured tables
+    for opt, val in (("i4_min_rows", 1024), ("predict_min_rows", 0), ("refine_min_rows", 1024)):
+        ctx.set_option(opt, val)
 def bits(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return np.where(np.isnan(a), np.uint32(0x7FC00000), a.view(np.uint32))       # (a NaN's sign / payload is not part of the answer)
