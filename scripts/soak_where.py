@@ -12,6 +12,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctx = pa.Context(0)
+if os.environ.get("SOAK_SMALL_TABLE_PLANS"):            # the 4-bit screen, the threshold model and the refinement on these tables and views
+    for opt, val in (("i4_min_rows", 1024), ("predict_min_rows", 0), ("refine_min_rows", 1024)):
+        ctx.set_option(opt, val)
 OPS = {">": np.greater, ">=": np.greater_equal, "<": np.less, "<=": np.less_equal, "==": np.equal, "!=": np.not_equal}
 bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 t_end = time.time() + budget
