@@ -66,7 +66,9 @@ int pg_synchronize(pg_ctx* ctx);
  * once a table has seen >= 1024 queries of one K (plan 0) "no_predict", "predict_sigmas" (default 4.5),
  * "predict_min_rows" (default 2^22), and for the 256-query screen "screen_early_share" (default 604: the share
  * x 1024 of a SIMD's blocks its older wave takes; 512 = even), "screen_early_share_narrow" (the <= 128-query kernels, default
- * 512); value is parsed as a number. */
+ * 512); for the squared-Euclidean recall "l2_exact", "l2_max_slack" (default 1.0); for pg_recall_topk_where the compact route's
+ * limits "where_compact_max_rows" (default 2^23; half of it for batches of <= 4 queries) and "where_compact_min_ratio"
+ * (default 8: at most an eighth of the table); value is parsed as a number. */
 int pg_set_option(pg_ctx* ctx, const char* name, const char* value);
 int pg_device_malloc(pg_ctx* ctx, size_t bytes, void** out);
 int pg_device_free(pg_ctx* ctx, void* p);
