@@ -138,6 +138,9 @@ struct pg_table {
     double pred_n = 0.0, pred_sum = 0.0, pred_sum2 = 0.0, pred_min = 0.0, pred_total = 0.0;   // host copy as of the last verified batch
     uint32_t pred_backoff = 0;    // batches that stay on the pilot plan after a prediction failed verification
     uint32_t pred_failures = 0;
+    // screened plans that ended in an overflowing suspect / record / candidate list (rows crowded within the screen's error of
+    // every query's K-th score: DESIGN.md 4.1): after two in a row the table's recalls start on the exact scan for a while
+    uint32_t screen_overflow_streak = 0, screen_backoff = 0;
 };
 
 // rank model weights resident in HBM (rank_mlp.hip loads them)

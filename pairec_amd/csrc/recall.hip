@@ -2668,6 +2668,14 @@ int recall_job_prepare(RecallJob* j) {
         if ((rc = ensure_table_stats(ctx, t))) return rc;
         if (!t->stats_valid || !t->all_finite) screen = false;      // no shadow (dim, memory) or non-finite rows
     }
+    if (screen && t->screen_backoff) {                 // this table's screened plans kept overflowing: exact scan for now
+        std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
+        pg_table* tm = const_cast<pg_table*>(t);
+        if (tm->screen_backoff) {
+            tm->screen_backoff--;
+            screen = false;
+        }
+    }
     // squared Euclidean: the int8 screen with per-block cutoffs for up to 128 queries (dim 128, int8 shadow); else the exact scan
     if (j->l2 && !(screen && t->dim == 128 && t->shadow_is_i8 && j->nq <= 128 && !kn.l2_exact)) screen = false;
     // rows of (nearly) one norm: one cutoff per 32-row block; beyond: the per-row test (three VALU instructions per bound instead of half a one)
@@ -3191,6 +3199,26 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
             tm->pred_backoff = 64u << (tm->pred_failures < 6 ? tm->pred_failures : 6);
             PG_HIP(hipMemsetAsync(tm->d_pred + 128 + 128 * 128, 0, 24, ctx->stream));
             tm->pred_n = tm->pred_sum = tm->pred_sum2 = 0.0;
+        }
+    }
+    if (j->screen) {
+        // A screened plan that OVERFLOWED (not: a threshold a few queries' lists fell short of) says the rows crowd within the
+        // screen's error of the K-th scores — nearly collinear rows and queries along them: 1 % of 40 M rows within the int8
+        // margin of every query's threshold — and the chunked fallback plans would screen the same crowd chunk by chunk (256
+        // queries, 40 M such rows: 180 ms shuffled, 790 ms in ascending order, where the exact scan takes 30).  The job's
+        // remaining plans run on the exact scan; two such batches in a row and the table's next 64 start there.
+        pg_table* tm = const_cast<pg_table*>(j->t);
+        std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
+        if (j->h_status[0] != 0) {
+            j->screen = j->screen4 = j->l2_per_row = false;
+            j->pred_observe = false;
+            // (... starting over at the pilot plan: on the exact scan the sample's threshold is as good as anywhere, while the
+            //  growing-chunk plans meet a table in ascending order with a flood of candidates per chunk)
+            for (int p = 0; p < j->n_plans; ++p)
+                if (j->plans[p] == kPilot && p < j->next_plan) j->next_plan = p;
+            if (++tm->screen_overflow_streak >= 2) tm->screen_backoff = 64;
+        } else if (ok) {
+            tm->screen_overflow_streak = 0;
         }
     }
     if (!ok) ctx->stats.recall_rescans++;

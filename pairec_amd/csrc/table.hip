@@ -158,6 +158,7 @@ int pg_table_fill_synthetic(pg_ctx* ctx, pg_table* t, uint64_t seed, int normali
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(ctx->stream));
     t->stats_valid = false;
+    t->screen_overflow_streak = t->screen_backoff = 0;
     t->nx_valid = false;
     return PG_OK;
 }
@@ -173,6 +174,7 @@ int pg_table_fill_gaussian(pg_ctx* ctx, pg_table* t, uint64_t seed, float sigma)
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(ctx->stream));
     t->stats_valid = false;
+    t->screen_overflow_streak = t->screen_backoff = 0;
     t->nx_valid = false;
     return PG_OK;
 }
@@ -190,6 +192,7 @@ int pg_table_upload(pg_ctx* ctx, pg_table* t, uint64_t row0, uint64_t nrows, con
                           hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
     t->stats_valid = false;
+    t->screen_overflow_streak = t->screen_backoff = 0;
     t->nx_valid = false;
     return PG_OK;
 }
@@ -250,6 +253,8 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->pred_total, b->pred_total);
     std::swap(a->pred_backoff, b->pred_backoff);
     std::swap(a->pred_failures, b->pred_failures);
+    std::swap(a->screen_overflow_streak, b->screen_overflow_streak);
+    std::swap(a->screen_backoff, b->screen_backoff);
     return PG_OK;
 }
 
