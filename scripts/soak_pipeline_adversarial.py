@@ -18,13 +18,13 @@ w = o.Dnn3Weights()
 model = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
 ex = pa.Expr("${gpu_dnn}*(1+${current_score})^0.1")
 bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
-KINDS = ("ascending", "descending", "best_at_head", "best_at_tail", "duplicate_runs", "all_equal", "zero_rows", "huge_rows", "plain")
+KINDS = ("ascending", "descending", "best_at_head", "best_at_tail", "duplicate_runs", "all_equal", "zero_rows", "huge_rows", "plain", "crowded")
 d = 128
 t_end = time.time() + seconds
 cases = bad = 0
 while time.time() < t_end:
     kind = str(rng.choice(KINDS))
-    n = int(rng.choice([60_000, 700_000, 2_000_000]))
+    n = int(rng.choice([60_000, 700_000, 2_000_000])) if kind != "crowded" else 3_000_000
     v = rng.standard_normal(d).astype(np.float32)
     v /= np.linalg.norm(v)
     noise = rng.standard_normal((n, d)).astype(np.float32)
@@ -33,6 +33,8 @@ while time.time() < t_end:
         tab = v[None] * ramp + 0.002 * noise
     elif kind == "descending":
         tab = v[None] * ramp[::-1] + 0.002 * noise
+    elif kind == "crowded":                                   # nearly collinear rows in random order: the screened lists overflow
+        tab = v[None] * rng.uniform(0.2, 1.0, (n, 1)).astype(np.float32) + 0.002 * noise
     elif kind in ("best_at_head", "best_at_tail"):
         tab = 0.1 * noise
         m = min(int(rng.integers(100, 30_000)), n // 4)
