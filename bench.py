@@ -10,12 +10,20 @@ deep and alternating between two library contexts (two HIP streams with their ow
 and tail of one batch run under the other's scan / rank kernels (each batch is verified when it is ended).
 
   python bench.py --gpus N --steps K --warmup W
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL), two modes:
+N > 1, one rank per GPU over RCCL: under torch.distributed.run (WORLD_SIZE set) this process IS a rank; started plainly
+(`python bench.py --gpus N`), it starts its N ranks itself through torch.distributed.run before anything touches the GPU, and
+exits non-zero when the box has fewer than N GPUs (PG_BENCH_SHARE_GPU=1: developer mode, all ranks on cuda:0 over gloo with
+host-staged exchanges; the line then says n_gpus 1, ranks N).  Two one-process-per-GPU modes:
   --mode replica (default): the 51.2 GB table fits one GPU, so it is replicated and the *requests*
       are sharded — every rank runs its own batches, no data-path collective, weak scaling.
   --mode shard: cfg-5 style — every rank holds --rows rows of one N x --rows table (contiguous row
       ranges), all_gather of the per-shard top-K lists + all_reduce of the score slab per step, DPP on the merged
       top-500 (pairec_amd/dist.py); value counts each request once.
+and two ONE-process modes over N devices, no torch — what a cgo host calls (csrc/group.hip):
+  --mode group: cfg-5 in one process: pg_group_* over N devices (peer stores + HIP events instead of collectives), two steps
+      in flight, DPPSort on the merged top-500, host buffers in and out.
+  --mode router: cfg-2/3 replicas in one process: one coalescer per device behind pg_router_*, 768 x N host threads with one
+      request outstanding each; the timed region is exactly steps x 256 x N requests.
 
 At N = 1 the same JSON line also carries (each a bounded, separately timed leg after the headline region):
   "concurrent_callers"  the same table / model / k served through the request coalescer to --callers host threads
@@ -62,12 +70,14 @@ def parse_args():
     ap.add_argument("--calibrate", type=int, default=10,
                     help="untimed batches served before the warm-up steps, like the shadow build: the table's threshold "
                          "model (DESIGN.md 4.1, plan 0) starts predicting once it has observed 1024 verified queries of one K")
-    ap.add_argument("--rows", type=int, default=100_000_000)
+    ap.add_argument("--rows", type=int, default=None,
+                    help="table rows PER GPU: default 100M (replica / router: the whole table on every GPU), 125M for shard / "
+                         "group (configs[4]: 1 B rows over 8 GPUs)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=5000)
     ap.add_argument("--batch", type=int, default=256, help="requests per step (<= 256 = one table pass)")
     ap.add_argument("--prec", choices=["bf16", "f32"], default="bf16")
-    ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
+    ap.add_argument("--mode", choices=["replica", "shard", "group", "router"], default="replica")
     ap.add_argument("--table-dist", choices=["uniform", "gaussian"], default="uniform",
                     help="headline table: SURVEY.md 8d's normalised uniform rows, or N(0,1) rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,7 +92,38 @@ def parse_args():
     ap.add_argument("--page", type=int, default=100, help="entries each concurrent caller asks for (ctx.Size)")
     ap.add_argument("--latency-reqs", type=int, default=500,
                     help="single-request latency samples at N=1 (the first 10 %% are discarded as warm-up, SURVEY.md 8d)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.rows is None:
+        args.rows = 125_000_000 if args.mode in ("shard", "group") else 100_000_000
+    return args
+
+
+def free_port():
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    p_ = so.getsockname()[1]
+    so.close()
+    return p_
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run, the driver's own
+    command line) from this process, which has not touched the GPU and never will — torch.cuda.device_count() does not
+    initialise it — and exit with their code.  Fewer GPUs than ranks is an error, not a quiet one-rank run."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    share = os.environ.get("PG_BENCH_SHARE_GPU") == "1"
+    if have < args.gpus and not share:
+        sys.stderr.write("bench.py: --gpus %d but this box has %d GPU(s); refusing to run fewer ranks than asked for "
+                         "(PG_BENCH_SHARE_GPU=1 runs the %d ranks on cuda:0 as a developer check, never a measurement)\n"
+                         % (args.gpus, have, args.gpus))
+        raise SystemExit(2)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def profile_numbers(R):
@@ -852,15 +893,175 @@ def cfg5_leg(pa, o, R, K, prec):
     return out
 
 
+class _TableView:
+    """(what roofline_block reads off a table: the shard-group owns the real object)"""
+
+    def __init__(self, L, ctx_h, table_h):
+        self.L, self.ctx_h, self.h = L, ctx_h, table_h
+
+    def screen_info(self):
+        from pairec_amd import _lib
+        eb, sc, rs = C.c_int(), C.c_float(), C.c_float()
+        _lib.check(self.L.pg_table_screen_info(self.ctx_h, self.h, C.byref(eb), C.byref(sc), C.byref(rs)))
+        return eb.value, sc.value, rs.value
+
+
+def inprocess_main(args, R, K):
+    """--mode group / router: ONE process over N devices through the C ABI alone (no torch, no collectives library) — the
+    boundary a cgo host uses.  group = configs[4] (row-range shards, peer stores, DPPSort); router = replicas of the
+    configs[1]+[2] table behind per-request calls.  Same contract as the other modes: W untimed steps, exactly K timed ones,
+    one JSON line."""
+    import pairec_amd as pa
+    from pairec_amd import _lib
+    from oracle import oracle as o       # synthetic-data spec + cpu_baseline leg only
+    L = _lib.load()
+    have = C.c_int()
+    _lib.check(L.pg_device_count(C.byref(have)))
+    N = args.gpus
+    share = os.environ.get("PG_BENCH_SHARE_GPU") == "1"
+    if have.value < N and not share:
+        sys.stderr.write("bench.py: --gpus %d --mode %s but this process sees %d GPU(s); refusing to run on fewer devices than "
+                         "asked for (PG_BENCH_SHARE_GPU=1: logical shards / replicas on cuda:0, a developer check)\n"
+                         % (N, args.mode, have.value))
+        raise SystemExit(2)
+    devices = list(range(N)) if have.value >= N else [0] * N
+    physical = len(set(devices))
+    w = o.Dnn3Weights()
+    prec = pa.PREC_BF16 if args.prec == "bf16" else pa.PREC_F32
+    blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+    expr = pa.Expr(RANK_EXPR)
+    total_steps = args.warmup + args.steps
+    out_extra = {}
+    if args.mode == "group":
+        g = pa.ShardGroup(devices)
+        g.table_create(args.rows * N, args.dim)
+        g.table_fill_synthetic(o.SEED_TABLE)
+        g.model_load(pa.MODEL_DNN3, prec, blob)
+        qs = [make_queries(o, s_, R, args.dim) for s_ in range(total_steps + 1)]
+        dpp_c = DPP_CANDIDATES
+        for s_ in range(max(args.warmup, 1)):                       # (the first step builds shadows and both lanes' scratch)
+            g.recommend(expr, "gpu_dnn", qs[s_ % len(qs)], K, args.page, dpp_candidates=dpp_c, dpp_alpha=DPP_ALPHA,
+                        dpp_window=DPP_WINDOW)
+        g.recommend(expr, "gpu_dnn", qs[0], K, args.page, dpp_candidates=dpp_c)
+        # per-shard scan stage of an un-overlapped step (HIP events on each shard's launch stream)
+        scan = []
+        for sh in range(N):
+            ms, nbytes = C.c_double(), C.c_uint64()
+            _lib.check(L.pg_last_scan_kernel_ms(C.c_void_p(L.pg_group_ctx(g.h, sh)), C.byref(ms), C.byref(nbytes)))
+            scan.append(ms.value)
+        import gc
+        gc.collect()
+        gc.disable()
+        t0 = time.perf_counter()
+        tk = g.recommend_begin(expr, "gpu_dnn", qs[args.warmup], K, args.page, dpp_candidates=dpp_c, dpp_alpha=DPP_ALPHA,
+                               dpp_window=DPP_WINDOW)
+        for s_ in range(args.steps):
+            nxt = g.recommend_begin(expr, "gpu_dnn", qs[args.warmup + s_ + 1], K, args.page, dpp_candidates=dpp_c,
+                                    dpp_alpha=DPP_ALPHA, dpp_window=DPP_WINDOW) if s_ + 1 < args.steps else None
+            page = g.recommend_end(tk)
+            tk = nxt
+        elapsed = time.perf_counter() - t0
+        gc.enable()
+        assert int(page[4].min()) == args.page
+        scan_avg_ms = float(max(scan))
+        tv = _TableView(L, C.c_void_p(L.pg_group_ctx(g.h, 0)), C.c_void_p(L.pg_group_table(g.h, 0)))
+        rf = roofline_block(tv, R, args, args.rows, scan_avg_ms, None)
+        rf["per_shard_scan_ms"] = scan
+        g.destroy()
+        workload = ("configs[4]: %d x %d fp32 table in %d row-range shards (%d rows each), %d requests x top-%d -> merge -> "
+                    "owner-computes DNN3 rank (%s) -> fuse -> sort -> DPPSort(%d candidates, page %d, window %d); one process, "
+                    "pg_group_recommend_begin / _end, two steps in flight, host buffers in and out"
+                    % (args.rows * N, args.dim, N, args.rows, R, K, args.prec, dpp_c, args.page, DPP_WINDOW))
+        parallelism = "table row-range shards x%d in one process: peer stores + HIP events, no collective library" % N
+        value = R * K * args.steps / elapsed
+    else:
+        ctxs, tables, models, cos = [], [], [], []
+        for dv in devices:
+            cx = pa.Context(dv, None)
+            tb = pa.Table(cx, args.rows, args.dim)
+            tb.fill_synthetic(o.SEED_TABLE)
+            tb.screen_info()
+            md = pa.RankModel(cx, pa.MODEL_DNN3, prec, blob)
+            ctxs.append(cx)
+            tables.append(tb)
+            models.append(md)
+            cos.append(pa.Coalescer(cx, tb, K, md, expr, "gpu_dnn", max_top_n=args.page, depth=3))
+        router = pa.Router(cos)
+        users = np.ascontiguousarray(o.synth_rows(o.SEED_QUERY, 0, 1000, args.dim))
+        spec = LoadgenSpec(mode=0, user_vecs=users.ctypes.data, n_users=1000, dim=args.dim, k=K, top_n=args.page)
+        callers = max(args.callers, 1) * N
+        hl = host_lib()
+        hl.ph_loadgen_run_target.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(LoadgenSpec), C.c_uint32, C.c_uint32,
+                                             C.c_double, C.c_uint64, C.POINTER(LoadgenResult)]
+
+        def run(n_req):
+            res = LoadgenResult()
+            rc = hl.ph_loadgen_run_target(None, router.h, C.byref(spec), callers, 0, 600.0, n_req, C.byref(res))
+            if rc or res.errors:
+                raise RuntimeError("load generator failed (rc %d, %d errors)" % (rc, res.errors))
+            return res
+        run((args.calibrate + max(args.warmup, 1)) * R * N)           # threshold models of every replica + warm-up, untimed
+        res = run(args.steps * R * N)
+        elapsed = res.seconds
+        served = router.served().tolist()
+        # the scan stage alone on replica 0, one caller-made batch at a time (per-kernel duration without overlap)
+        d_qs = [ctxs[0].to_device(make_queries(o, s_, R, args.dim)) for s_ in range(4)]
+        import copy
+        a1 = copy.copy(args)
+        a1.warmup, a1.steps = 1, 8
+        router.destroy()
+        for c_ in cos:
+            c_.destroy()
+        _, _, scan_ms = run_headline(pa, ctxs[0], tables[0], models[0], expr, d_qs, a1, R, K, ctxs[0].synchronize)
+        rf = roofline_block(tables[0], R, args, args.rows, float(np.mean(scan_ms)), None, ctxs[0].last_scan_kernel()[1])
+        out_extra = {"callers": callers, "requests": int(res.requests), "p50_ms": res.p50_ms, "p99_ms": res.p99_ms,
+                     "served_per_replica": served}
+        for m_ in models:
+            m_.destroy()
+        for t_ in tables:
+            t_.destroy()
+        workload = ("configs[1]+[2] behind per-request calls: %d replicas of the %d x %d table, one coalescer per device behind "
+                    "pg_router_recommend; %d host threads with one request (top-%d -> DNN3 %s -> fuse -> sort -> page of %d) "
+                    "outstanding each; timed region = exactly steps x %d x %d requests"
+                    % (N, args.rows, args.dim, callers, K, args.prec, args.page, R, N))
+        parallelism = "request-parallel x%d in one process (least-outstanding router), table replicated per GPU, no exchange" % N
+        value = res.requests * K / elapsed
+    out = {
+        "metric": "ranked items/sec, 5k-cand DNN rank (recall top-5000 -> DNN3 -> fuse -> sort%s)"
+                  % (" -> DPPSort" if args.mode == "group" else ""),
+        "value": value, "unit": "ranked items/s", "n_gpus": physical, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.prec, "data": "synthetic", "mode": args.mode,
+        "config": {"workload": workload, "requests_per_step": R * (N if args.mode == "router" else 1),
+                   "candidates_per_request": K, "table_rows_per_gpu": args.rows, "dim": args.dim, "parallelism": parallelism},
+        "roofline": rf, "cpu_baseline": None, "device": device_info(),
+    }
+    out.update(out_extra)
+    if physical != N:
+        out["ranks"] = N
+        out["dev_mode"] = "PG_BENCH_SHARE_GPU=1: %d logical %s on ONE device — a correctness run of the N > 1 code, not a measurement" \
+                          % (N, "shards" if args.mode == "group" else "replicas")
+    if N == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(o, args, R, K)
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     R, K = args.batch, args.k
     assert 1 <= R <= 256
+    if args.mode in ("group", "router"):
+        # one process drives all N devices; under a launcher only rank 0 works (the others leave before touching a GPU)
+        if rank == 0:
+            inprocess_main(args, R, K)
+        return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)                            # does not return
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import pairec_amd as pa
     from oracle import oracle as o       # synthetic-data spec + cpu_baseline leg only
@@ -883,7 +1084,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     shard = world > 1 and args.mode == "shard"
-    from pairec_amd.dist import shard_range, sharded_step, shard_context, GpuShardEngine
+    from pairec_amd.dist import shard_range, sharded_step, shard_context, GpuShardEngine, HostStagedCollectives
+    # the exchanges of the sharded step: RCCL on device tensors; host-staged gloo when the ranks share cuda:0 (dev mode)
+    coll = HostStagedCollectives(dist, torch) if share_gpu else dist
     if shard:
         # one dedicated torch stream shared by the library's kernels and the step's torch ops / RCCL collectives
         ctx, tstream = shard_context(torch, pa, local_rank)
@@ -958,12 +1161,12 @@ def main():
         # cfg 5: recall + rank + sort.dpp_sort — DPP candidates = top 500 by score, alpha 1, page (ctx.Size) 100, window 10
         dpp = {"candidates": 500, "alpha": 1.0, "window": 10}
         for s in range(args.warmup):
-            sharded_step(eng, dist, torch, t_qs[s], R, K, args.page, dpp)
+            sharded_step(eng, coll, torch, t_qs[s], R, K, args.page, dpp)
         sync()
         scan_ms = []
         t0 = time.perf_counter()
         for s in range(args.warmup, total_steps):
-            sharded_step(eng, dist, torch, t_qs[s], R, K, args.page, dpp)
+            sharded_step(eng, coll, torch, t_qs[s], R, K, args.page, dpp)
             scan_ms.append(ctx.last_scan_kernel()[0])
         sync()
         elapsed = time.perf_counter() - t0
@@ -982,8 +1185,8 @@ def main():
     rank_items = R * K / (world if shard else 1)
     out = {
         "metric": "ranked items/sec, 5k-cand DNN rank (recall top-5000 of 100M x 128 -> DNN3 -> fuse -> sort)",
-        "value": value, "unit": "ranked items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "value": value, "unit": "ranked items/s", "n_gpus": 1 if share_gpu else world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "mode": args.mode if world > 1 else "single",
         "scaling": "weak",
         "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
         "config": {"workload": "configs[1]+[2]: recall 5k of %dx%d fp32 table in HBM -> 3-layer DNN rank "
@@ -1008,6 +1211,10 @@ def main():
         if args.prec == "bf16" and st.last_rank_ms > 0 else None,
     }
 
+    if share_gpu:
+        out["ranks"] = world
+        out["dev_mode"] = ("PG_BENCH_SHARE_GPU=1: %d ranks on ONE device, gloo with host-staged exchanges — a correctness run "
+                           "of the N > 1 code, not a measurement" % world)
     solo = world == 1
     if solo and args.latency_reqs > 0:
         # p50 single-request latency (R=1), same pipeline, inputs resident, one batch at a time

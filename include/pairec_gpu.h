@@ -55,6 +55,9 @@ const char* pg_version(void);
  * torch.distributed's collectives are ordered on) or NULL to create a private one.  The null stream (handle 0,
  * torch's default stream) cannot be adopted — NULL always means "private": a host that mixes its own device work
  * with library calls creates a stream of its own and passes it here (pairec_amd/dist.py shard_context). */
+/* gfx950 devices this process can see (what a host sizes pg_group_create / its replica list with; the reference has no
+ * counterpart — its FAISS / EAS endpoints are URLs in recconf, algorithm/eas/model.go:38-60). */
+int pg_device_count(int* out);
 int pg_init(int device, void* stream, pg_ctx** out);
 int pg_shutdown(pg_ctx* ctx);
 int pg_synchronize(pg_ctx* ctx);

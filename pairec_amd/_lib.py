@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpairec_gpu.so")
 
 # every symbol include/pairec_gpu.h declares (tests/test_abi.py checks the two stay in sync)
 EXPORTS = [
-    "pg_last_error", "pg_version", "pg_init", "pg_shutdown", "pg_synchronize", "pg_device_malloc",
+    "pg_last_error", "pg_version", "pg_device_count", "pg_init", "pg_shutdown", "pg_synchronize", "pg_device_malloc",
     "pg_device_free", "pg_memcpy_h2d", "pg_memcpy_d2h", "pg_table_create", "pg_table_destroy",
     "pg_table_fill_synthetic", "pg_table_upload", "pg_table_download", "pg_table_swap",
     "pg_table_info", "pg_table_gather", "pg_recall_topk", "pg_recall_topk_dev", "pg_recall_topk_l2", "pg_recall_topk_l2_dev", "pg_recall_topk_where", "pg_table_view_create",
@@ -101,6 +101,7 @@ def load():
     L.pg_last_error.restype = C.c_char_p
     L.pg_version.restype = C.c_char_p
     sig = {
+        "pg_device_count": [P(i32)],
         "pg_init": [i32, vp, P(vp)],
         "pg_shutdown": [vp],
         "pg_synchronize": [vp],

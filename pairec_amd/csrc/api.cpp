@@ -81,6 +81,14 @@ extern "C" {
 const char* pg_last_error(void) { return pg::g_err.c_str(); }
 const char* pg_version(void) { return "pairec_gpu 0.2 (gfx950)"; }
 
+int pg_device_count(int* out) {
+    PG_REQUIRE(out != nullptr, "pg_device_count: out is NULL");
+    int n = 0;
+    PG_HIP(hipGetDeviceCount(&n));
+    *out = n;
+    return PG_OK;
+}
+
 int pg_init(int device, void* stream, pg_ctx** out) {
     PG_REQUIRE(out != nullptr, "pg_init: out is NULL");
     int n = 0;

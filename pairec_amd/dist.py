@@ -54,6 +54,46 @@ def shard_context(torch, pa, device: int):
     return ctx, stream
 
 
+class HostStagedCollectives:
+    """torch.distributed's three collectives of the step with the payload staged through host memory — the DEV / TEST
+    transport for several ranks that share ONE device (RCCL refuses two ranks on a device, and gloo has no
+    all_gather / reduce_scatter for device tensors).  The kernels, buffers, ownership bookkeeping and the order of
+    the exchanges are the product's; only the wire differs.  Never used when every rank has its own GPU.
+
+    Every call runs on the caller's current stream: `.cpu()` waits for what the stream has queued, the copy back is
+    queued behind it."""
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+
+    def get_world_size(self):
+        return self.dist.get_world_size()
+
+    def get_rank(self):
+        return self.dist.get_rank()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def all_gather_into_tensor(self, out, inp):
+        h_out = self.torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(h_out, inp.cpu())
+        out.copy_(h_out)
+
+    def all_reduce(self, t):
+        h = t.cpu()
+        self.dist.all_reduce(h)
+        t.copy_(h)
+
+    def reduce_scatter_tensor(self, out, inp):
+        # (sum of disjoint owners' rows and +0.0 elsewhere: exact whatever the reduction order)
+        h = inp.cpu()
+        self.dist.all_reduce(h)
+        n = out.shape[0]
+        r = self.dist.get_rank()
+        out.copy_(h[r * n:(r + 1) * n])
+
+
 def sharded_step(engine, dist, torch, queries, nq: int, k: int, page: int = 0, dpp=None):
     """One request batch (see _sharded_step), with every torch op of the step on the engine's stream."""
     guard = getattr(engine, "stream_guard", None)

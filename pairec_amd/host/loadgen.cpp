@@ -46,10 +46,13 @@ typedef struct {
     const pg_dpp_options* dpp;    // mode 3
 } ph_loadgen_spec;
 
-// Every caller issues `warmup` unmeasured requests, waits at a barrier, then loops until `seconds` have elapsed.
-int ph_loadgen_run_ex(pg_coalescer* c, const ph_loadgen_spec* sp, uint32_t callers, uint32_t warmup, double seconds,
-                      ph_loadgen_result* out) {
-    if (!c || !sp || !out || callers == 0) return -1;
+// Every caller issues `warmup` unmeasured requests, waits at a barrier, then loops until `seconds` have elapsed — or, with
+// max_requests > 0, until the callers together have STARTED that many requests (a fixed amount of work: bench.py's router
+// mode times exactly steps x 256 x replicas requests).  `r` != NULL sends modes 0 / 1 through the replica router instead of `c`.
+int ph_loadgen_run_target(pg_coalescer* c, pg_router* r, const ph_loadgen_spec* sp, uint32_t callers, uint32_t warmup,
+                          double seconds, uint64_t max_requests, ph_loadgen_result* out) {
+    if ((!c && !r) || !sp || !out || callers == 0) return -1;
+    if (r && sp->mode != 0 && sp->mode != 1) return -1;
     const int mode = sp->mode;
     const float* user_vecs = sp->user_vecs;
     const uint32_t n_users = sp->n_users, dim = sp->dim, k = sp->k, top_n = sp->top_n;
@@ -58,6 +61,7 @@ int ph_loadgen_run_ex(pg_coalescer* c, const ph_loadgen_spec* sp, uint32_t calle
     using Clock = std::chrono::steady_clock;
     std::atomic<uint32_t> ready{0};
     std::atomic<bool> go{false}, stop{false};
+    std::atomic<uint64_t> started{0};
     std::vector<std::vector<float>> lat(callers);
     std::vector<uint64_t> sums(callers, 0), errs(callers, 0);
     std::vector<std::thread> th;
@@ -79,8 +83,13 @@ int ph_loadgen_run_ex(pg_coalescer* c, const ph_loadgen_spec* sp, uint32_t calle
                 const uint32_t off = sp->pool_size > sp->rank_items ? (uint32_t)((rng >> 33) % (sp->pool_size - sp->rank_items)) : 0u;
                 int rc;
                 switch (mode) {
-                    case 0: rc = pg_coalescer_recommend(c, v, top_n, rows.data(), rec.data(), rnk.data(), fus.data(), &cnt); break;
-                    case 1: rc = pg_coalescer_recall(c, v, rows.data(), rec.data(), &cnt); break;
+                    case 0:
+                        rc = r ? pg_router_recommend(r, v, top_n, rows.data(), rec.data(), rnk.data(), fus.data(), &cnt)
+                               : pg_coalescer_recommend(c, v, top_n, rows.data(), rec.data(), rnk.data(), fus.data(), &cnt);
+                        break;
+                    case 1:
+                        rc = r ? pg_router_recall(r, v, rows.data(), rec.data(), &cnt) : pg_coalescer_recall(c, v, rows.data(), rec.data(), &cnt);
+                        break;
                     case 2:
                         rc = pg_coalescer_rank_fm2t(c, v, sp->user_field_ids + (size_t)u_now * sp->n_user_fields, sp->cand_pool + off, sp->rank_items,
                                                     rec.data());
@@ -109,6 +118,7 @@ int ph_loadgen_run_ex(pg_coalescer* c, const ph_loadgen_spec* sp, uint32_t calle
             while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
             lat[t].reserve(4096);
             while (!stop.load(std::memory_order_relaxed)) {
+                if (max_requests && started.fetch_add(1, std::memory_order_relaxed) >= max_requests) break;
                 const auto t0 = Clock::now();
                 one();
                 lat[t].push_back(std::chrono::duration<float, std::milli>(Clock::now() - t0).count());
@@ -118,8 +128,16 @@ int ph_loadgen_run_ex(pg_coalescer* c, const ph_loadgen_spec* sp, uint32_t calle
     while (ready.load() < callers) std::this_thread::yield();
     const auto t0 = Clock::now();
     go.store(true, std::memory_order_release);
-    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
-    stop.store(true);
+    if (max_requests) {
+        // fixed work: the callers stop by themselves; `seconds` is only a bound against a stuck device
+        const auto deadline = t0 + std::chrono::duration<double>(seconds > 0 ? seconds : 600.0);
+        while (started.load(std::memory_order_relaxed) < max_requests && Clock::now() < deadline)
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        if (started.load() < max_requests) stop.store(true);
+    } else {
+        std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+        stop.store(true);
+    }
     for (auto& x : th) x.join();
     const double el = std::chrono::duration<double>(Clock::now() - t0).count();
     std::vector<float> all;
@@ -146,6 +164,11 @@ int ph_loadgen_run_ex(pg_coalescer* c, const ph_loadgen_spec* sp, uint32_t calle
         out->mean_ms = s / all.size();
     }
     return 0;
+}
+
+int ph_loadgen_run_ex(pg_coalescer* c, const ph_loadgen_spec* sp, uint32_t callers, uint32_t warmup, double seconds,
+                      ph_loadgen_result* out) {
+    return ph_loadgen_run_target(c, nullptr, sp, callers, warmup, seconds, 0, out);
 }
 
 // the two original modes (0 recommend, 1 recall)
