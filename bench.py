@@ -571,6 +571,44 @@ def rank_shapes_leg(pa, o, ctx, table, R, K):
     return out
 
 
+def multi_output_leg(pa, o, ctx, table, R, K):
+    """A two-output model (probs_ctr / probs_cvr on one trunk, PG_MODEL_DNN3_MULTI) against the one-output model of the
+    same trunk: the rank stage alone, bf16, R x K random candidate rows.  The reference's fixtures are such models
+    (easyrec_response.go:35-70); one gather + one trunk per item whatever the number of outputs."""
+    n = table.rows
+    rng = np.random.default_rng(5)
+    nI = R * K
+    cand = rng.integers(0, n, nI).astype(np.uint32)
+    offs = (np.arange(R + 1) * K).astype(np.uint32)
+    us = o.synth_rows(o.SEED_QUERY, 0, R, 128)
+    d_u, d_c, d_o = ctx.to_device(us), ctx.to_device(cand), ctx.to_device(offs)
+    d_out = ctx.malloc(nI * 4 * 8)
+    out = {}
+    w1 = o.Dnn3Weights()
+    models = {1: pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16, pa.pack_dnn3(w1.w1, w1.b1, w1.w2, w1.b2, w1.w3, w1.b3, 128))}
+    for n_out in (2, 4, 8):
+        w = o.Dnn3MultiWeights(n_out)
+        models[n_out] = pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, pa.PREC_BF16, pa.pack_dnn3_multi(w.w1, w.b1, w.w2, w.b2, w.w3m, w.b3m, 128))
+    for n_out, m in models.items():
+        best = 1e9
+        for _ in range(3):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                m.rank_dnn3_dev(table, d_u, d_c, d_o, R, nI, d_out)
+            ctx.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 10)
+        out["outputs_%d_ms" % n_out] = best * 1e3
+        m.destroy()
+    for n_out in (2, 4, 8):
+        out["outputs_%d_vs_1" % n_out] = out["outputs_%d_ms" % n_out] / out["outputs_1_ms"]
+    out["note"] = ("rank stage alone, 256-512-256-n_out bf16, %d x %d candidates; k separate one-output models would cost k x outputs_1_ms"
+                   % (R, K))
+    for p_ in (d_u, d_c, d_o, d_out):
+        ctx.free(p_)
+    return out
+
+
 def cfg1_leg(pa, o, ctx):
     """BASELINE.json configs[0]: 1M x 64 in-memory vector table, dot-product top-200, sort.item_score (ascending) —
     the reference's CPU-runnable case.  CPU row = the oracle (scan + heap top-K + sort) on all host cores; the GPU
@@ -1248,6 +1286,7 @@ def main():
             c_.synchronize()
         shapes = rank_shapes_leg(pa, o, ctx, table, R, K)
         out["rank_shapes"] = shapes
+        out["multi_output_rank"] = multi_output_leg(pa, o, ctx, table, R, K)
         bs = [e for e in shapes if e["shape"] == "256-512-256-1"][0]
         in_pipe = out["rank_roofline"]
         out["rank_roofline"] = {"bound": "mfma", "kernel": bs["kernel"], "achieved": bs["achieved"], "peak": bs["peak"],

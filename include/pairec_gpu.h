@@ -40,12 +40,13 @@ typedef enum {
     PG_ERR_UNSUPPORTED = -4, /* shape outside what the kernels are built for */
     PG_ERR_ARITH = -5,       /* expression: division by zero / modulo by zero (reference panics) */
     PG_ERR_PARSE = -6,       /* expression: lexer "symbol error" (utils/ast/parse.go:125-133) */
+    PG_ERR_EMPTY = -8,       /* pg_table_view_create: no row passes the filter (a result, not a misconfiguration) */
     PG_ERR_TIMEOUT = -7      /* the call's deadline passed (algorithm/eas/client.go:53-58: 100 ms default per predict); the
                                 work it belonged to still completes for the other callers of its batch */
 } pg_status;
 
 typedef enum { PG_PREC_F32 = 0, PG_PREC_BF16 = 1 } pg_prec;
-typedef enum { PG_MODEL_DNN3 = 1, PG_MODEL_FM_TWOTOWER = 2 } pg_model_kind;
+typedef enum { PG_MODEL_DNN3 = 1, PG_MODEL_FM_TWOTOWER = 2, PG_MODEL_DNN3_MULTI = 3 } pg_model_kind;
 
 const char* pg_last_error(void);
 const char* pg_version(void);
@@ -160,6 +161,16 @@ int pg_rows_to_local_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows,
  *   score = sigmoid( w3 · relu( W2ᵀ relu( W1ᵀ [user ‖ item_row] + b1 ) + b2 ) + b3 )
  *   shapes: d_user 1..4096; d_item 64 or 128 (= the table's dim); (h1, h2) in {128-128, 256-128, 256-256, 512-256,
  *   1024-512}; the benchmark shape [128+128]-512-256 in bf16 runs on the weights-stationary kernel
+ * PG_MODEL_DNN3_MULTI blob — a multi-output model: n_out heads on ONE shared trunk, the shape of the reference's own fixtures
+ * (EasyrecResponse.multiValModule, algorithm/eas/easyrec_response.go:35-70: probs_ctr / probs_cvr of one PAI-EAS model;
+ * RankService writes them as "<algo>_<output>", service/rank/rank_service.go:315-319):
+ *   u32 d_user, d_item, h1, h2, n_out (1..8);  w1; b1; w2; b2 as above; w3[h2][n_out]; b3[n_out]
+ *   score_o = sigmoid( w3[:, o] · h2 + b3[o] ) — every head has exactly the arithmetic of a PG_MODEL_DNN3 with that column
+ *   (in PG_PREC_F32, bit for bit); ONE gather and ONE trunk per item whatever n_out.  pg_model_load stores it as a
+ *   PG_MODEL_DNN3 with pg_model_num_outputs() = n_out: pg_rank_dnn3[_dev] then write n_out planes, out_scores[o * n_items + i]
+ *   (n_items = req_offsets[n_req], resp. the n_items argument), and pg_coalescer_rank_dnn3 n_out planes of its n candidates.
+ * Exported weights: every matrix is plain row-major [in][out] fp32 exactly as a Dense layer's kernel is saved;
+ * tools/pack_model.py builds either blob from an .npz of such arrays.
  * PG_MODEL_FM_TWOTOWER blob:
  *   u32 n_user_fields, n_item_fields, k, d_user, t_h1, t_out, vocab; f32 fm_b;
  *   uw1[d_user][t_h1]; ub1; uw2[t_h1][t_out]; ub2; iw1[nif*k][t_h1]; ib1; iw2[t_h1][t_out]; ib2;
@@ -172,6 +183,8 @@ int pg_rows_to_local_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_rows,
 int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blob, size_t len,
                   pg_model** out);
 int pg_model_destroy(pg_ctx* ctx, pg_model* m);
+/* outputs per item: 1, or n_out of a PG_MODEL_DNN3_MULTI */
+int pg_model_num_outputs(const pg_model* m, uint32_t* out);
 
 /* DNN3: R requests; request r has user vector user_vecs[r][d_user] and candidates
  * cand_rows[req_offsets[r] .. req_offsets[r+1]) (local row indices into `t`).  out_scores is fp32
@@ -314,7 +327,7 @@ int pg_recall_topk_where(pg_ctx* ctx, const pg_table* t, const pg_features* fs, 
  * serves it at the speed of an unfiltered table of that size (its own shadows, statistics and threshold model; requests of many
  * callers share a pass).  A snapshot: later changes of the source or the column do not reach it.  Views serve recall calls only: the
  * recommend calls, and a view as i2i TRIGGER table, are refused (PG_ERR_UNSUPPORTED / PG_ERR_INVALID); rank / DPP / SSD calls take the
- * source table and the recalled ids.  PG_ERR_INVALID when no row passes.  Destroyed with pg_table_destroy. */
+ * source table and the recalled ids.  PG_ERR_EMPTY when no row passes (PG_ERR_INVALID is a bad column / operator / feature store).  Destroyed with pg_table_destroy. */
 int pg_table_view_create(pg_ctx* ctx, const pg_table* t, const pg_features* fs, int column, int op, long long value, pg_table** out_view);
 /* FM + two-tower rank straight from candidate rows: the model's item field ids are the integer columns
  * item_field_cols[n_item_fields] of `fs` (out-of-vocabulary ids are clamped as in pg_rank_fm2t_dev) */
@@ -502,6 +515,11 @@ typedef struct {
     const pg_features* features;
     const int32_t* item_field_cols;
     const pg_item_rows* item_rows;   /* optional: the materialised records of (model, features, columns) — preferred when set */
+    /* a multi-output model (PG_MODEL_DNN3_MULTI): the names of its pg_model_num_outputs() outputs; RankScore then reads
+     * "<name>_<output>" per output (rank_service.go:315-319), pg_coalescer_recommend_ex returns one rank plane per output
+     * (in list order, an algorithm's outputs adjacent), pg_coalescer_rank / _rank_dnn3 write out_scores[o * n + i].
+     * NULL for single-output models; NULL for a multi-output one names its outputs "0", "1", … */
+    const char* const* output_names;
 } pg_rank_algo;
 typedef struct {
     pg_coalescer_config base;

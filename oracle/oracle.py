@@ -206,6 +206,32 @@ def dnn3_forward(w: Dnn3Weights, prec: int, user_vec: np.ndarray, item_rows: np.
     return out
 
 
+class Dnn3MultiWeights(Dnn3Weights):
+    """A multi-output model: n_out heads (probs_ctr, probs_cvr, ...) on ONE shared trunk — the shape of the reference's
+    own fixtures (algorithm/eas/easyrec_response.go:35-70, utils/ast/ast_test.go:90-129: ppnet_probs_ctr / _cvr).
+    w3 [h2][n_out], b3 [n_out]; head o is the DNN3 whose last layer is (w3[:, o], b3[o])."""
+
+    def __init__(self, n_out=2, d_user=128, d_item=128, h1=512, h2=256, seed=SEED_WEIGHTS):
+        super().__init__(d_user, d_item, h1, h2, seed)
+        self.n_out = n_out
+        cols = [self.w3] + [synth_uniform(seed ^ (0x305 + 16 * o), h2, 1.0 / math.sqrt(h2)) for o in range(1, n_out)]
+        self.w3m = np.ascontiguousarray(np.stack(cols, axis=1))                       # [h2][n_out]
+        self.b3m = np.array([self.b3] + [float(synth_uniform(seed ^ (0x306 + 16 * o), 1, 1.0 / math.sqrt(h2))[0])
+                                         for o in range(1, n_out)], dtype=np.float32)
+
+    def head(self, o: int) -> Dnn3Weights:
+        h = Dnn3Weights.__new__(Dnn3Weights)
+        h.__dict__.update({k_: v for k_, v in self.__dict__.items() if k_ not in ("w3m", "b3m", "n_out")})
+        h.w3 = np.ascontiguousarray(self.w3m[:, o])
+        h.b3 = float(self.b3m[o])
+        return h
+
+
+def dnn3_multi_forward(w: Dnn3MultiWeights, prec: int, user_vec: np.ndarray, item_rows: np.ndarray, threads: int = 0) -> np.ndarray:
+    """scores [n_out][n_items]: every head through the single-output specification (orc_dnn3_forward) with its own column."""
+    return np.stack([dnn3_forward(w.head(o), prec, user_vec, item_rows, threads) for o in range(w.n_out)])
+
+
 class _Fm2t(C.Structure):
     _fields_ = [("n_user_fields", C.c_uint32), ("n_item_fields", C.c_uint32), ("k", C.c_uint32),
                 ("d_user", C.c_uint32), ("t_h1", C.c_uint32), ("t_out", C.c_uint32),

@@ -17,7 +17,7 @@ EXPORTS = [
     "pg_device_free", "pg_memcpy_h2d", "pg_memcpy_d2h", "pg_table_create", "pg_table_destroy",
     "pg_table_fill_synthetic", "pg_table_upload", "pg_table_download", "pg_table_swap",
     "pg_table_info", "pg_table_gather", "pg_recall_topk", "pg_recall_topk_dev", "pg_recall_topk_l2", "pg_recall_topk_l2_dev", "pg_recall_topk_where", "pg_table_view_create",
-    "pg_topk_merge_dev", "pg_model_load", "pg_model_destroy", "pg_rank_dnn3", "pg_rank_dnn3_dev",
+    "pg_topk_merge_dev", "pg_model_load", "pg_model_destroy", "pg_model_num_outputs", "pg_rank_dnn3", "pg_rank_dnn3_dev",
     "pg_rank_fm2t", "pg_rank_fm2t_dev", "pg_expr_compile", "pg_expr_free", "pg_expr_num_vars",
     "pg_expr_var_name", "pg_expr_eval", "pg_expr_eval_dev", "pg_sort_scores", "pg_sort_scores_dev",
     "pg_dpp", "pg_stats", "pg_last_scan_kernel_ms", "pg_rows_to_local_dev", "pg_widen_f32_dev",
@@ -67,7 +67,8 @@ class PgCoalescerConfig(C.Structure):
 
 class PgRankAlgo(C.Structure):
     _fields_ = [("model", C.c_void_p), ("name", C.c_char_p), ("features", C.c_void_p),
-                ("item_field_cols", C.POINTER(C.c_int32)), ("item_rows", C.c_void_p)]
+                ("item_field_cols", C.POINTER(C.c_int32)), ("item_rows", C.c_void_p),
+                ("output_names", C.POINTER(C.c_char_p))]
 
 
 class PgSceneConfig(C.Structure):
@@ -102,6 +103,7 @@ def load():
     L.pg_version.restype = C.c_char_p
     sig = {
         "pg_device_count": [P(i32)],
+        "pg_model_num_outputs": [vp, P(u32)],
         "pg_init": [i32, vp, P(vp)],
         "pg_shutdown": [vp],
         "pg_synchronize": [vp],

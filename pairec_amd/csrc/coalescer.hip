@@ -198,6 +198,10 @@ struct pg_coalescer {
     pg::RankAlgoRef algos[pg::kMaxAlgos];
     std::string algo_names[pg::kMaxAlgos];
     int n_algos = 0;
+    int plane0[pg::kMaxAlgos] = {0, 1, 2, 3};  // first score plane of algorithm a (a multi-output DNN3 takes one per head)
+    int n_planes = 0;
+    uint32_t max_heads = 1;                // most outputs of any one algorithm (a rank-flavour batch writes that many planes)
+    std::vector<std::string> plane_names;
     const pg_expr* e = nullptr;
     std::vector<int> var_src;
     pg::RerankStage rerank;
@@ -243,7 +247,7 @@ int flavour_of(int queue) {
     return (queue == kQRecall || queue == kQRecallL2) ? kRecall : (queue == kQRecommend ? kRecommend : (queue == kQDpp ? kDpp : kRank));
 }
 
-size_t page_bytes(const pg_coalescer* c) { return (size_t)c->max_batch * c->max_top_n * page_entry_bytes(std::max(c->n_algos, 1)); }
+size_t page_bytes(const pg_coalescer* c) { return (size_t)c->max_batch * c->max_top_n * page_entry_bytes(std::max(c->n_planes, 1)); }
 
 void fail_req(Req* r, int rc, const char* msg) {
     r->rc = rc;
@@ -292,14 +296,14 @@ int alloc_slot(pg_coalescer* c, Slot* s) {
         PG_HIP(hipHostMalloc((void**)&s->h_off, ((size_t)c->max_rank_reqs + 1) * 4));
         PG_HIP(hipMalloc((void**)&s->d_cand, (size_t)c->rank_item_cap * 4));
         PG_HIP(hipMalloc((void**)&s->d_off, ((size_t)c->max_rank_reqs + 1) * 4));
-        out_bytes = std::max(out_bytes, (size_t)c->rank_item_cap * 4);
+        out_bytes = std::max(out_bytes, (size_t)c->rank_item_cap * 4 * c->max_heads);    // (a multi-output model: a plane per head)
     }
     if (c->e) out_bytes = std::max(out_bytes, page_bytes(c) + nb * 8);
     PG_HIP(hipHostMalloc((void**)&s->h_out, out_bytes));
     PG_HIP(hipMalloc((void**)&s->d_rows, nb * k * 8));
     PG_HIP(hipMalloc((void**)&s->d_recall, nb * k * 4));
     PG_HIP(hipMalloc((void**)&s->d_count, nb * 4));
-    if (rank) PG_HIP(hipMalloc((void**)&s->d_rank, (size_t)c->n_algos * c->rank_stride * 4));
+    if (rank) PG_HIP(hipMalloc((void**)&s->d_rank, (size_t)std::max(c->n_planes, (int)c->max_heads) * c->rank_stride * 4));
     if (c->e) {
         PG_HIP(hipMalloc((void**)&s->d_fused, nb * k * 8));
         PG_HIP(hipMalloc((void**)&s->d_order, nb * k * 4));
@@ -364,13 +368,17 @@ int slot_copy_out(pg_coalescer* c, Slot* s) {
         const uint32_t top = s->n_items;
         int rc;
         if ((rc = page_launch(st, s->d_order, c->rerank.kind ? s->d_pick : nullptr, s->d_pick_cnt, s->d_rows, s->d_recall, s->d_rank,
-                              c->rank_stride, c->n_algos, s->d_fused, nq, c->k, top, s->d_page)))
+                              c->rank_stride, c->n_planes, s->d_fused, nq, c->k, top, s->d_page)))
             return rc;
     }
     PG_HIP(hipEventRecord(s->computed, st));
     PG_HIP(hipStreamWaitEvent(c->copy_stream, s->computed, 0));
     if (fl == kRank) {
-        PG_HIP(hipMemcpyAsync(s->h_out, s->d_rank, (size_t)s->n_items * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        // head o of a multi-output model: plane o of the batch, [n_items] each, back to back in the image
+        const uint32_t heads = c->algos[s->queue - kQRank0].m->n_out;
+        for (uint32_t o = 0; o < heads; ++o)
+            PG_HIP(hipMemcpyAsync(s->h_out + (size_t)o * s->n_items * 4, s->d_rank + (size_t)o * c->rank_stride, (size_t)s->n_items * 4,
+                                  hipMemcpyDeviceToHost, c->copy_stream));
     } else if (fl == kRecall) {
         const size_t nk = (size_t)nq * c->k;
         PG_HIP(hipMemcpyAsync(s->h_out, s->d_rows, nk * 8, hipMemcpyDeviceToHost, c->copy_stream));
@@ -381,7 +389,7 @@ int slot_copy_out(pg_coalescer* c, Slot* s) {
         PG_HIP(hipMemcpyAsync(s->h_dout + c->dpp_item_cap, s->d_dout + c->dpp_item_cap, (size_t)nq * 4, hipMemcpyDeviceToHost, c->copy_stream));
     } else {
         const size_t np = (size_t)nq * s->n_items;
-        PG_HIP(hipMemcpyAsync(s->h_out, s->d_page, np * page_entry_bytes(c->n_algos), hipMemcpyDeviceToHost, c->copy_stream));
+        PG_HIP(hipMemcpyAsync(s->h_out, s->d_page, np * page_entry_bytes(c->n_planes), hipMemcpyDeviceToHost, c->copy_stream));
         PG_HIP(hipMemcpyAsync(s->h_out + page_bytes(c), s->d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, c->copy_stream));
         if (c->rerank.kind)
             PG_HIP(hipMemcpyAsync(s->h_out + page_bytes(c) + (size_t)c->max_batch * 4, s->d_pick_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost,
@@ -398,10 +406,11 @@ int enqueue_recall_batch(pg_coalescer* c, Slot* s, bool first) {
     const uint32_t nq = s->n_req;
     int rc;
     std::lock_guard<std::mutex> g(ctx->mu);
-    TableRead tr(c->t->rw);
-    TableRead tr2;
-    if (c->trigger_table != c->t) tr2 = TableRead(c->trigger_table->rw);
+    TableRead2 tr(c->t, c->trigger_table);
     RecallJob& j = s->run->job;
+    // a swap / upload between this batch's first pass and its re-plan: the job's statistics and plans are the old version's —
+    // the whole batch starts over on the new rows (one version per batch)
+    if (!first && j.table_gen != c->t->generation.load(std::memory_order_relaxed)) first = true;
     if (first) {
         bool any_trigger = false, any_online = false;
         for (uint32_t q = 0; q < nq; ++q) {
@@ -447,7 +456,7 @@ int enqueue_rank_batch(pg_coalescer* c, Slot* s) {
     std::lock_guard<std::mutex> g(ctx->mu);
     TableRead tr(c->t->rw);
     if (al.m->kind != PG_MODEL_DNN3) PG_HIP(hipMemcpyAsync(s->d_ufid, s->h_ufid, (size_t)nq * al.m->nuf * 4, hipMemcpyHostToDevice, st));
-    return rank_algo_locked(ctx, al, c->t, s->d_vec, s->d_ufid, s->d_cand, s->d_off, nq, s->n_items, s->d_rank);
+    return rank_algo_locked(ctx, al, c->t, s->d_vec, s->d_ufid, s->d_cand, s->d_off, nq, s->n_items, s->d_rank, c->rank_stride);
 }
 
 int enqueue_dpp_batch(pg_coalescer* c, Slot* s) {
@@ -509,6 +518,8 @@ int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
     call.t = c->t;
     for (int a = 0; a < c->n_algos; ++a) call.algos[a] = c->algos[a];
     call.n_algos = c->n_algos;
+    for (int a = 0; a < c->n_algos; ++a) call.plane0[a] = c->plane0[a];
+    call.n_planes = c->n_planes;
     call.e = c->e;
     call.var_src = c->var_src.data();
     call.nv = (int)c->var_src.size();
@@ -990,7 +1001,35 @@ int pg_coalescer_create_scene(pg_ctx* ctx, const pg_table* t, const pg_scene_con
     c->trigger_table = trig;
     c->query_model = sc->query_model;
     c->n_algos = (int)sc->n_algos;
-    const char* names[pg::kMaxAlgos] = {nullptr, nullptr, nullptr, nullptr};
+    // score planes and their RankScore names: "<algo>" or, per output of a multi-output model, "<algo>_<output>"
+    // (rank_service.go:315-319)
+    const char* names[pg::kMaxPlanes] = {nullptr};
+    for (int a = 0; a < c->n_algos; ++a) {
+        const uint32_t heads = sc->algos[a].model->n_out;
+        c->plane0[a] = c->n_planes;
+        if (heads > 1) {
+            if (c->n_planes + (int)heads > pg::kMaxPlanes) {
+                pg::set_error("pg_coalescer_create: the scene's models have more than %d outputs together", pg::kMaxPlanes);
+                delete c;
+                return PG_ERR_INVALID;
+            }
+            for (uint32_t o = 0; o < heads; ++o) {
+                // (no names given: "<algo>_0", "<algo>_1", … — enough for a scene that only ranks)
+                const char* on = sc->algos[a].output_names ? sc->algos[a].output_names[o] : nullptr;
+                if (sc->algos[a].output_names && (!on || !on[0])) {
+                    pg::set_error("pg_coalescer_create: \"%s\": output %u has no name", sc->algos[a].name, o);
+                    delete c;
+                    return PG_ERR_INVALID;
+                }
+                c->plane_names.push_back(std::string(sc->algos[a].name) + "_" + (on ? std::string(on) : std::to_string(o)));
+            }
+        } else {
+            c->plane_names.push_back(sc->algos[a].name);
+        }
+        c->n_planes += (int)heads;
+        c->max_heads = std::max(c->max_heads, heads);
+    }
+    for (int p_ = 0; p_ < c->n_planes; ++p_) names[p_] = c->plane_names[(size_t)p_].c_str();
     for (int a = 0; a < c->n_algos; ++a) {
         c->algos[a].m = sc->algos[a].model;
         c->algos[a].fs = sc->algos[a].features;
@@ -998,11 +1037,10 @@ int pg_coalescer_create_scene(pg_ctx* ctx, const pg_table* t, const pg_scene_con
         if (sc->algos[a].item_field_cols)
             for (uint32_t f = 0; f < sc->algos[a].model->nif && f < 16; ++f) c->algos[a].item_field_cols[f] = sc->algos[a].item_field_cols[f];
         c->algo_names[a] = sc->algos[a].name;
-        names[a] = c->algo_names[a].c_str();
     }
     c->e = sc->rank_score;
     int rc;
-    if (c->e && (rc = pg::recommend_bind_vars(c->e, names, c->n_algos, &c->var_src, "pg_coalescer_create"))) {
+    if (c->e && (rc = pg::recommend_bind_vars(c->e, names, c->n_planes, &c->var_src, "pg_coalescer_create"))) {
         delete c;
         return rc;
     }
@@ -1208,7 +1246,9 @@ int pg_coalescer_rank(pg_coalescer* c, uint32_t algo, const float* user_vec, con
     r->n = n;
     int rc;
     if ((rc = pg::submit_and_wait(c, r))) return rc;
-    if (r->rc == PG_OK) memcpy(out_scores, r->slot->h_out + (size_t)r->item0 * 4, (size_t)n * 4);
+    if (r->rc == PG_OK)                                  // head o: out_scores[o * n ..), from plane o of the batch image
+        for (uint32_t o = 0; o < m->n_out; ++o)
+            memcpy(out_scores + (size_t)o * n, r->slot->h_out + ((size_t)o * r->slot->n_items + r->item0) * 4, (size_t)n * 4);
     return pg::finish_call(c, r);
 }
 
@@ -1297,7 +1337,7 @@ int pg_coalescer_recommend_ex(pg_coalescer* c, const float* user_vec, const int3
                               uint64_t* out_rows, float* out_recall_scores, float* out_rank_scores, double* out_fused,
                               uint32_t* out_count) {
     PG_REQUIRE(c, "pg_coalescer_recommend_ex: NULL argument");
-    return coalescer_recommend_common(c, user_vec, user_field_ids, top_n, out_rows, out_recall_scores, out_rank_scores, c->n_algos, out_fused,
+    return coalescer_recommend_common(c, user_vec, user_field_ids, top_n, out_rows, out_recall_scores, out_rank_scores, c->n_planes, out_fused,
                                       out_count);
 }
 

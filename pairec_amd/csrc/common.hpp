@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -91,6 +92,9 @@ struct pg_table {
     // DPP gather: one enqueue) therefore sees ONE table version even when a second context (a coalescer's sibling)
     // enqueues while the table is being swapped.  Lock order: ctx->mu, then the table.
     mutable std::shared_mutex rw;
+    // bumped by every exclusive section (upload, fill, swap): a recall job remembers the value it was prepared against, and a
+    // re-plan or a patch that finds another one restarts the whole batch on the new rows instead of mixing generations
+    mutable std::atomic<uint64_t> generation{0};
     float* d = nullptr;          // [rows][dim] fp32 row-major
     uint64_t rows = 0;
     uint32_t dim = 0;
@@ -150,6 +154,8 @@ struct pg_model {
     uint32_t d_user = 0, d_item = 0, h1 = 0, h2 = 0;           // DNN3
     uint32_t nuf = 0, nif = 0, k = 0, th = 0, to = 0, vocab = 0;  // two-tower
     float b3 = 0.f, fm_b = 0.f;
+    uint32_t n_out = 1;     // DNN3: heads on the shared trunk (PG_MODEL_DNN3_MULTI; kind is stored as PG_MODEL_DNN3)
+    float* b3v = nullptr;   // device [n_out] head biases (b3 = b3v[0])
     // device buffers
     float* w1u = nullptr;   // [d_user][h1] (DNN3) / uw1 (two-tower), operand-rounded fp32
     float* b1 = nullptr;    // b1 / ub1
@@ -159,7 +165,7 @@ struct pg_model {
     void* w2p = nullptr;    // packed layer 2
     float* c1_shared = nullptr;   // two-tower: ib1
     float* b2 = nullptr;
-    float* w3 = nullptr;    // DNN3 head
+    float* w3 = nullptr;    // DNN3 head(s): [n_out][h2]
     float* fields = nullptr;          // two-tower: all field tables, one allocation
     const float** d_field_emb = nullptr;
     const float** d_field_lin = nullptr;
@@ -212,13 +218,27 @@ struct pg_ctx {
 namespace pg {
 
 typedef std::shared_lock<std::shared_mutex> TableRead;
+// shared access to two tables (a recall whose queries are rows of a trigger table): taken in ADDRESS order, the order
+// TableWrite(a, b) uses — a reader holding t and waiting for the trigger table against a swap of the two would deadlock
+struct TableRead2 {
+    TableRead a, b;
+    TableRead2(const pg_table* x, const pg_table* y) {
+        if (y && y < x) std::swap(x, y);
+        a = TableRead(x->rw);
+        if (y && y != x) b = TableRead(y->rw);
+    }
+};
 // exclusive access to one or two tables (address order) with nothing in flight on the device
 struct TableWrite {
     std::unique_lock<std::shared_mutex> a, b;
     TableWrite(const pg_table* x, const pg_table* y = nullptr) {
         if (y && y < x) std::swap(x, y);
         a = std::unique_lock<std::shared_mutex>(x->rw);
-        if (y && y != x) b = std::unique_lock<std::shared_mutex>(y->rw);
+        x->generation.fetch_add(1, std::memory_order_relaxed);
+        if (y && y != x) {
+            b = std::unique_lock<std::shared_mutex>(y->rw);
+            y->generation.fetch_add(1, std::memory_order_relaxed);
+        }
     }
 };
 
@@ -304,6 +324,7 @@ struct RecallJob {
     // after a failed check of the pilot plan without overflow: the queries that ended short of K candidates (their
     // sample threshold was too high).  A handful can be re-run one by one instead of re-running the whole batch.
     std::vector<uint32_t> failed;
+    uint64_t table_gen = 0;                 // t->generation when the job was prepared (the statistics, shadow and plans are that version's)
 };
 constexpr size_t kMaxPatchQueries = 8;
 // All four: caller holds ctx->mu.  prepare may synchronise once (a table's statistics / shadow on first use).
@@ -338,9 +359,10 @@ int topk_merge_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores
                       uint32_t* d_out_count);
 
 // ---- stage launchers shared with pipeline.hip (caller holds ctx->mu; nothing synchronises) -------------------
+// head o of a multi-head model writes d_out + o * out_stride (out_stride = 0: n_items)
 int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float* d_user,
                          const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items,
-                         float* d_out);
+                         float* d_out, size_t out_stride = 0);
 int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_user, uint32_t n_req, float* d_out);
 int rank_fm2t_irows_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_item_rows* ir, const float* d_user, const int32_t* d_ufids,
                                const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items, float* d_out);

@@ -374,7 +374,7 @@ int step_enqueue(pg_group* g, pg_group_ticket* tk, uint32_t attempt) {
         PG_HIP(hipMemcpyAsync(l.d_q, tk->users.data(), (size_t)nq * g->dim * 4, hipMemcpyHostToDevice, l.ctx->stream));
         std::lock_guard<std::mutex> cg(l.ctx->mu);
         RecallJob& j = l.run->job;
-        const bool retry_next_plan = attempt > 0 && l.plan_failed;
+        const bool retry_next_plan = attempt > 0 && l.plan_failed && j.table_gen == s.tab->generation.load(std::memory_order_relaxed);
         if (!retry_next_plan) {
             j = RecallJob();
             j.ctx = l.ctx;
@@ -742,6 +742,7 @@ int pg_group_recommend_begin(pg_group* g, const pg_expr* e, const char* rank_var
     const pg_model* m0 = g->sh[0].model;
     PG_REQUIRE(m0->kind == PG_MODEL_DNN3 && m0->d_item == g->dim && m0->d_user == g->dim,
                "pg_group_recommend: the model must be DNN3 with d_user = d_item = the table's dim");
+    PG_REQUIRE(m0->n_out == 1, "pg_group_recommend: multi-output models are served by a scene coalescer on one GPU (pg_coalescer_create_scene)");
     const uint32_t C = plan->dpp_candidates ? std::min(k, std::max(top_n, plan->dpp_candidates)) : 0u;
     PG_REQUIRE(C <= 8192, "pg_group_recommend: %u DPP candidates (at most 8192)", C);
     pg_group_ticket* tk = new pg_group_ticket();
@@ -809,7 +810,10 @@ int pg_group_recommend_end(pg_group* g, pg_group_ticket* tk, uint64_t* out_rows,
             all_ok = all_ok && ok;
         }
         if (rc || all_ok) break;
-        if (attempt >= 3) {
+        // a shard's job runs out of plans by itself (recall_job_enqueue: "overflow in safe mode"); with the threshold model's
+        // plan in front and one restart on the exact scan after a screened overflow, a valid sequence takes up to
+        // 2 x (plans) enqueues — the bound here only stops a loop that makes no progress
+        if (attempt >= 12) {
             pg::set_error("pg_group_recommend: recall plans kept failing (internal error)");
             rc = PG_ERR_DEVICE;
             break;

@@ -143,7 +143,7 @@ int post_fuse_sort_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint
     }
     if ((rc = expr_eval_enqueue_locked(ctx, c.e, ps.d_vars, n, c.d_fused + o, ps.d_err, c.k))) return rc;
     if (c.pads) {
-        mask_pads_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_rows + o, n, c.d_rank + o, c.rank_stride, c.n_algos, c.d_fused + o);
+        mask_pads_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_rows + o, n, c.d_rank + o, c.rank_stride, c.planes(), c.d_fused + o);
         PG_HIP(hipGetLastError());
     }
     return sort_dev_locked(ctx, c.d_fused + o, ps.d_off, nq, n, c.k, 1, c.d_order + o);
@@ -184,10 +184,10 @@ static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q
     // RankAlgoList: every algorithm scores every candidate (rank_service.go:259-289 fans them out as goroutines)
     for (int a = 0; a < c.n_algos; ++a) {
         const RankAlgoRef& al = c.algos[a];
-        float* out = c.d_rank + (size_t)a * c.rank_stride + o;
+        float* out = c.d_rank + (size_t)c.plane0[a] * c.rank_stride + o;
         const float* users = c.d_queries + (size_t)q0 * c.t->dim;
         if ((rc = rank_algo_locked(ctx, al, c.t, users, c.d_ufids ? c.d_ufids + (size_t)q0 * c.ufid_stride : nullptr, ps.d_local, ps.d_off, nq, n,
-                                   out)))
+                                   out, c.rank_stride)))
             return rc;
     }
     if ((rc = post_fuse_sort_locked(ctx, c, q0, nq, ps))) return rc;
@@ -204,8 +204,8 @@ static int recommend_post_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q
 }
 
 int rank_algo_locked(pg_ctx* ctx, const RankAlgoRef& al, const pg_table* t, const float* d_user, const int32_t* d_ufids,
-                     const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items, float* d_out) {
-    if (al.m->kind == PG_MODEL_DNN3) return rank_dnn3_dev_locked(ctx, al.m, t, d_user, d_cand, d_off, n_req, n_items, d_out);
+                     const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items, float* d_out, size_t out_stride) {
+    if (al.m->kind == PG_MODEL_DNN3) return rank_dnn3_dev_locked(ctx, al.m, t, d_user, d_cand, d_off, n_req, n_items, d_out, out_stride);
     if (al.irows) return rank_fm2t_irows_dev_locked(ctx, al.m, al.irows, d_user, d_ufids, d_cand, d_off, n_req, n_items, d_out);
     return rank_fm2t_rows_dev_locked(ctx, al.m, al.fs, al.item_field_cols, d_user, d_ufids, d_cand, d_off, n_req, n_items, d_out);
 }
@@ -221,6 +221,8 @@ int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool firs
     PostScratch ps;
     if ((rc = post_scratch(ctx, c, c.nq, &ps))) return rc;
     r->patched = false;
+    // a swap / upload between this batch's first pass and its re-plan: start over on the new rows (one version per batch)
+    if (!first && r->job.table_gen != c.t->generation.load(std::memory_order_relaxed)) first = true;
     if (first) {
         RecallJob& j = r->job;
         j = RecallJob();
@@ -249,7 +251,10 @@ int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok, const RecommendCall* c) 
     int rc;
     if ((rc = recall_job_check(&r->job, ok))) return rc;
     RecallJob& j = r->job;
-    if (!*ok && !j.failed.empty() && j.failed.size() <= kMaxPatchQueries && j.nq > 1) {
+    // (patching single requests in place is only sound on the version the rest of the batch came from; after a swap the
+    // caller's re-enqueue restarts the whole batch)
+    if (!*ok && !j.failed.empty() && j.failed.size() <= kMaxPatchQueries && j.nq > 1 &&
+        j.table_gen == j.t->generation.load(std::memory_order_relaxed)) {
         // The pilot's threshold was too high for a few requests only (a 1e-4 event per request at the default margin):
         // re-run those requests — recall from the growing-chunk plan, then the stages behind it — synchronously and in
         // place, instead of the whole batch.  The nested recalls use the context's own status block.
@@ -295,6 +300,7 @@ int pg_recommend_dnn3_begin(pg_ctx* ctx, const pg_table* t, const pg_model* m, c
     PG_REQUIRE(nq > 0 && nq <= (uint32_t)pg::kMaxQueries && k > 0 && k <= 16384, "pg_recommend_dnn3: bad nq / k");
     PG_REQUIRE(m->kind == PG_MODEL_DNN3 && t->dim == m->d_item && m->d_user == t->dim,
                "pg_recommend_dnn3: the model must be DNN3 with d_user = d_item = the table's dim");
+    PG_REQUIRE(m->n_out == 1, "pg_recommend_dnn3: a multi-output model needs its output names: serve it through a scene (pg_coalescer_create_scene)");
     pg_ticket* tk = new pg_ticket();
     int rc;
     if ((rc = pg::recommend_bind_vars(e, &rank_var, 1, &tk->var_src, "pg_recommend_dnn3"))) {

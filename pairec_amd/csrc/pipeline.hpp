@@ -32,8 +32,11 @@ struct RankAlgoRef {
     const pg_item_rows* irows = nullptr;   // FM + two-tower: the materialised item records (preferred over fs / columns)
 };
 // rank the candidates of n_req requests with one algorithm of the list (caller holds ctx->mu)
+// (a multi-output DNN3 writes one plane per head: head o at d_out + o * out_stride; out_stride = 0: n_items)
 int rank_algo_locked(pg_ctx* ctx, const RankAlgoRef& al, const pg_table* t, const float* d_user, const int32_t* d_ufids,
-                     const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items, float* d_out);
+                     const uint32_t* d_cand, const uint32_t* d_off, uint32_t n_req, uint32_t n_items, float* d_out,
+                     size_t out_stride = 0);
+constexpr int kMaxPlanes = 12;         // score planes of a scene: one per single-output algorithm, n_out per multi-output one
 // The diversity re-rank behind the sort (SortNames: [.., DPPSort], sort/dpp_sort.go:271-351): the first `candidates`
 // entries of every sorted list are the DPP candidates, the page is DPPWithWindow's pick sequence among them.
 struct RerankStage {
@@ -43,8 +46,9 @@ struct RerankStage {
 };
 
 // VectorRecall → rank with every algorithm of the list → RankScore fusion → ItemRankScore sort → (DPPSort) for nq
-// requests of k candidates each; every pointer is a device pointer, layouts as pg_recommend_dnn3_dev.  var_src[i] = a:
-// variable i of `e` is algorithm a's score (its name in RankAlgoList), -1: Item.Score (the recall score).
+// requests of k candidates each; every pointer is a device pointer, layouts as pg_recommend_dnn3_dev.  var_src[i] = p:
+// variable i of `e` is score plane p (an algorithm's name in RankAlgoList, or "<algo>_<output>" of a multi-output one,
+// rank_service.go:315-319), -1: Item.Score (the recall score).
 struct RecommendCall {
     const pg_table* t = nullptr;
     RankAlgoRef algos[kMaxAlgos];
@@ -58,8 +62,13 @@ struct RecommendCall {
     uint32_t nq = 0, k = 0;
     uint64_t* d_rows = nullptr;
     float* d_recall = nullptr;
-    float* d_rank = nullptr;           // n_algos planes of rank_stride floats, each [nq][k]
+    float* d_rank = nullptr;           // planes() planes of rank_stride floats, each [nq][k]
     size_t rank_stride = 0;
+    // score planes: algorithm a writes planes plane0[a] .. plane0[a] + (its model's outputs) - 1; n_planes = 0 means
+    // one plane per algorithm in list order (no multi-output model in the list)
+    int plane0[kMaxAlgos] = {0, 1, 2, 3};
+    int n_planes = 0;
+    int planes() const { return n_planes ? n_planes : n_algos; }
     double* d_fused = nullptr;
     uint32_t* d_order = nullptr;
     uint32_t* d_count = nullptr;       // optional

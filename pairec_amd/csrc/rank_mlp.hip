@@ -477,6 +477,26 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
         const float o = __shfl_xor(p, 1);
         const float z = half ? (o + p) : (p + o);
         if (half == 0 && (tid >> 1) < BM && (uint32_t)row < cnt) a.out[item0 + row] = 1.0f / (1.0f + expf(-z));
+        if constexpr (MODEL == 1) {
+            // the other heads of a multi-output model (easyrec_response.go:35-70): the same two half chains over the same
+            // H2 tile, w3 row `hd` straight from global memory (every thread reads the same addresses)
+            for (uint32_t hd = 1; hd < a.n_out; ++hd) {
+                const float4* wg = reinterpret_cast<const float4*>(a.w3 + (size_t)hd * H2 + half * (H2 / 2));
+                float ph_ = half ? 0.0f : a.b3v[hd];
+#pragma unroll 4
+                for (int m = 0; m < H2 / 8; ++m) {
+                    const float4 x = hr[m], y = wg[m];
+                    ph_ = __fmaf_rn(x.x, y.x, ph_);
+                    ph_ = __fmaf_rn(x.y, y.y, ph_);
+                    ph_ = __fmaf_rn(x.z, y.z, ph_);
+                    ph_ = __fmaf_rn(x.w, y.w, ph_);
+                }
+                const float oh = __shfl_xor(ph_, 1);
+                const float zh = half ? (oh + ph_) : (ph_ + oh);
+                if (half == 0 && (tid >> 1) < BM && (uint32_t)row < cnt)
+                    a.out[(size_t)hd * a.out_stride + item0 + row] = 1.0f / (1.0f + expf(-zh));
+            }
+        }
     } else {
         // pass e carries columns [e*HH, (e+1)*HH) = half chain e; thread `row` (tid < 128) runs both
         float ph[2] = {0.0f, 0.0f};
@@ -511,6 +531,25 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                     p = __fmaf_rn(x.w, y.w, p);
                 }
                 ph[e] = p;
+                if constexpr (MODEL == 1) {
+                    // the other heads: half chain e of head `hd`; pass 0 parks it in the output slot, pass 1 finishes it
+                    for (uint32_t hd = 1; hd < a.n_out; ++hd) {
+                        const float4* wg = reinterpret_cast<const float4*>(a.w3 + (size_t)hd * H2 + e * HH);
+                        float q = e ? 0.0f : a.b3v[hd];
+#pragma unroll 4
+                        for (int m = 0; m < HH / 4; ++m) {
+                            const float4 x = hr[m], y = wg[m];
+                            q = __fmaf_rn(x.x, y.x, q);
+                            q = __fmaf_rn(x.y, y.y, q);
+                            q = __fmaf_rn(x.z, y.z, q);
+                            q = __fmaf_rn(x.w, y.w, q);
+                        }
+                        if ((uint32_t)tid < cnt) {
+                            float* dst = a.out + (size_t)hd * a.out_stride + item0 + tid;
+                            *dst = e == 0 ? q : 1.0f / (1.0f + expf(-(*dst + q)));
+                        }
+                    }
+                }
             }
         }
         if (tid < BM && (uint32_t)tid < cnt) a.out[item0 + tid] = 1.0f / (1.0f + expf(-(ph[0] + ph[1])));
@@ -930,7 +969,7 @@ static int dispatch_fm2t_mlp(pg_ctx* ctx, const pg_model* m, const MlpArgs& a, u
 
 int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
                                 const float* d_user, const uint32_t* d_cand, const uint32_t* d_off,
-                                uint32_t n_req, uint32_t n_items, float* d_out) {
+                                uint32_t n_req, uint32_t n_items, float* d_out, size_t out_stride) {
     if (n_items == 0 || n_req == 0) return PG_OK;
     const uint32_t max_tiles = n_items / kWsItems + n_req;      // sized for the smaller (64-item) tiles
     RankScratch rs;
@@ -967,6 +1006,16 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     a.w1p = m->w1p;
     a.w2p = m->w2p;
     a.out = d_out;
+    a.n_out = m->n_out;
+    a.out_stride = out_stride ? out_stride : (size_t)n_items;
+    a.b3v = m->b3v;
+    a.head_part = nullptr;
+    if (ws && m->n_out > 1) {
+        // the weights-stationary kernel's partials of heads 1..: a block per workgroup (its LDS is full)
+        void* hp;
+        if ((rc = scratch_reserve(ctx, 11, (size_t)ctx->num_cus * (kMaxHeads - 1) * 4 * kWsItems * 4, &hp))) return rc;
+        a.head_part = (float*)hp;
+    }
     if (ws) {
         // bf16: weights-stationary persistent kernel over 64-item tiles
         if ((rc = launch_dnn3_ws(ctx, a))) return rc;
@@ -1156,25 +1205,36 @@ int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blo
         delete m;
         return code;
     };
-    if (kind == PG_MODEL_DNN3) {
-        if (len < 16) { pg::set_error("pg_model_load: blob too short"); return fail(PG_ERR_INVALID); }
-        uint32_t hdr[4];
-        memcpy(hdr, p, 16);
-        m->d_user = hdr[0]; m->d_item = hdr[1]; m->h1 = hdr[2]; m->h2 = hdr[3];
+    if (kind == PG_MODEL_DNN3 || kind == PG_MODEL_DNN3_MULTI) {
+        const bool multi = kind == PG_MODEL_DNN3_MULTI;
+        const size_t hb = multi ? 20 : 16;
+        m->kind = PG_MODEL_DNN3;                 // every rank entry point takes it; n_out says how many planes it writes
+        if (len < hb) { pg::set_error("pg_model_load: blob too short"); return fail(PG_ERR_INVALID); }
+        uint32_t hdr[5] = {0, 0, 0, 0, 1};
+        memcpy(hdr, p, hb);
+        m->d_user = hdr[0]; m->d_item = hdr[1]; m->h1 = hdr[2]; m->h2 = hdr[3]; m->n_out = hdr[4];
+        if (m->n_out == 0 || m->n_out > (uint32_t)pg::kMaxHeads) {
+            pg::set_error("pg_model_load: a multi-output DNN3 has 1..%d outputs, the blob says %u", pg::kMaxHeads, m->n_out);
+            return fail(PG_ERR_UNSUPPORTED);
+        }
         if ((m->d_item != 128 && m->d_item != 64) || !pg::dnn3_shape_ok(m->h1, m->h2) || m->d_user == 0 || m->d_user > 4096) {
             pg::set_error("pg_model_load: DNN3 shape [%u+%u]->%u->%u->1 unsupported (d_item 64 or 128; hidden widths "
                           "128-128, 256-128, 256-256, 512-256, 1024-512)", m->d_user, m->d_item, m->h1, m->h2);
             return fail(PG_ERR_UNSUPPORTED);
         }
         const size_t din = (size_t)m->d_user + m->d_item;
-        const size_t need = 16 + (din * m->h1 + m->h1 + (size_t)m->h1 * m->h2 + m->h2 + m->h2 + 1) * 4;
+        const size_t need = hb + (din * m->h1 + m->h1 + (size_t)m->h1 * m->h2 + m->h2 + ((size_t)m->h2 + 1) * m->n_out) * 4;
         if (len != need) { pg::set_error("pg_model_load: DNN3 blob is %zu bytes, expected %zu", len, need); return fail(PG_ERR_INVALID); }
-        const float* w1 = (const float*)(p + 16);
+        const float* w1 = (const float*)(p + hb);
         const float* b1 = w1 + din * m->h1;
         const float* w2 = b1 + m->h1;
         const float* b2 = w2 + (size_t)m->h1 * m->h2;
-        const float* w3 = b2 + m->h2;
-        m->b3 = w3[m->h2];
+        const float* w3 = b2 + m->h2;                      // [h2][n_out] as exported ([in][out]); kept head-major on the device
+        const float* b3 = w3 + (size_t)m->h2 * m->n_out;
+        m->b3 = b3[0];
+        std::vector<float> w3t((size_t)m->n_out * m->h2);
+        for (uint32_t o = 0; o < m->n_out; ++o)
+            for (uint32_t j = 0; j < m->h2; ++j) w3t[(size_t)o * m->h2 + j] = w3[(size_t)j * m->n_out + o];
         auto w1u = pg::rounded(w1, (size_t)m->d_user * m->h1, m->prec);
         // the kernel's layer 1 is 128 deep: a 64-wide item row is padded with zero columns, W1 with zero rows
         std::vector<float> w1i((size_t)pg::kDIN * m->h1, 0.0f);
@@ -1186,7 +1246,8 @@ int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blo
         if ((rc = pg::upload(ctx, m, w1p.data(), w1p.size(), &m->w1p))) return fail(rc);
         if ((rc = pg::upload(ctx, m, w2p.data(), w2p.size(), &m->w2p))) return fail(rc);
         if ((rc = pg::upload(ctx, m, b2, m->h2 * 4, (void**)&m->b2))) return fail(rc);
-        if ((rc = pg::upload(ctx, m, w3, m->h2 * 4, (void**)&m->w3))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, w3t.data(), w3t.size() * 4, (void**)&m->w3))) return fail(rc);
+        if ((rc = pg::upload(ctx, m, b3, m->n_out * 4, (void**)&m->b3v))) return fail(rc);
     } else if (kind == PG_MODEL_FM_TWOTOWER) {
         if (len < 32) { pg::set_error("pg_model_load: blob too short"); return fail(PG_ERR_INVALID); }
         uint32_t hdr[7];
@@ -1244,6 +1305,12 @@ int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blo
     return PG_OK;
 }
 
+int pg_model_num_outputs(const pg_model* m, uint32_t* out) {
+    PG_REQUIRE(m && out, "pg_model_num_outputs: NULL argument");
+    *out = m->n_out;
+    return PG_OK;
+}
+
 int pg_model_destroy(pg_ctx* ctx, pg_model* m) {
     PG_REQUIRE(ctx, "pg_model_destroy: ctx is NULL");
     if (!m) return PG_OK;
@@ -1290,7 +1357,7 @@ int pg_rank_dnn3(pg_ctx* ctx, const pg_model* m, const pg_table* t, const float*
     void* buf;
     int rc;
     const size_t ub = (size_t)n_req * m->d_user * 4, cb = (size_t)n_items * 4, ob = (size_t)(n_req + 1) * 4;
-    const size_t sb = (size_t)n_items * 4;
+    const size_t sb = (size_t)n_items * 4 * m->n_out;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     if ((rc = pg::scratch_reserve(ctx, 5, al(ub) + al(cb) + al(ob) + al(sb), &buf))) return rc;
     char* b = (char*)buf;

@@ -40,6 +40,7 @@ constexpr int kBM = 128;       // items per workgroup tile
 constexpr int kDIN = 128;      // gathered input width
 constexpr int kFmMaxK = 32;        // largest FM embedding width (item fields x width = kDIN)
 constexpr int kFmUserStride = 1 + 2 * kFmMaxK;   // per-request FM prefix: lin, s[<=32] at +1, q[<=32] at +33
+constexpr int kMaxHeads = 8;           // outputs of a multi-head DNN3
 constexpr int kItemRowFloats = 160;    // a materialised item record: 128 embedding floats + <= 16 linear weights, padded to 5 x 128 B
 
 // the item-field columns of a feature store, by value (kernel argument of the item-record builder)
@@ -78,6 +79,12 @@ struct MlpArgs {
     uint32_t w3_stride;
     float b3;
     const float* b2;
+    // DNN3 with several heads on the shared trunk: w3 is [n_out][h2], b3v [n_out] (b3 = b3v[0]); head o's scores go to
+    // out + o * out_stride; head_part: global scratch for the weights-stationary kernel's partials of heads 1..
+    uint32_t n_out;
+    size_t out_stride;
+    const float* b3v;
+    float* head_part;
     // pre-packed weights
     const void* w1p;
     const void* w2p;

@@ -19,9 +19,11 @@ namespace pg {
 // Arithmetic and k order of layers 1 and 2 are mlp_kernel<1, H1, H2, …>'s; the head sums a lane's H2/8 columns, then the
 // item's 8 partials in slot order, as dnn3_ws_kernel does (a fixed order inside the bf16 mode's 1e-5).
 // ---------------------------------------------------------------------------------------------
+// (n_out heads on the shared trunk: w3 rows and head partials per head, then the heads' biases)
 template <int H1, int H2, bool W1L>
-constexpr size_t rs_lds_bytes() {
-    return (size_t)kWsItems * (kDIN + H1) * 2 + (size_t)(H1 + 2 * H2 + 8 * kWsItems) * 4 + (W1L ? (size_t)kDIN * H1 * 2 : 0);
+constexpr size_t rs_lds_bytes(uint32_t n_out) {
+    return (size_t)kWsItems * (kDIN + H1) * 2 + (size_t)(H1 + H2 + n_out * (H2 + 8 * kWsItems) + kMaxHeads) * 4 +
+           (W1L ? (size_t)kDIN * H1 * 2 : 0);
 }
 
 // make WS_EXTRA=-DPG_RS_PROFILE: per-phase cycle counts of the first workgroups (developer aid)
@@ -46,9 +48,11 @@ __global__ __launch_bounds__(256 * MSPLIT, WPC) void dnn3_rs_kernel(MlpArgs a) {
     char* const H1T = smem + XT_B;
     float* const c1s = reinterpret_cast<float*>(smem + XT_B + (size_t)kWsItems * H1 * 2);
     float* const b2s = c1s + H1;
-    float* const w3s = b2s + H2;
-    float* const hps = w3s + H2;                                          // head partials [8 slots][64 items]
-    char* const W1S = reinterpret_cast<char*>(hps + 8 * kWsItems);        // W1L: layer 1's fragments, shared by the waves of a column slice
+    const uint32_t n_out = a.n_out;                                       // heads on the shared trunk (1: the plain DNN3)
+    float* const w3s = b2s + H2;                                          // [n_out][H2]
+    float* const hps = w3s + n_out * H2;                                  // head partials [n_out][8 slots][64 items]
+    float* const b3s = hps + n_out * 8 * kWsItems;                        // [kMaxHeads]
+    char* const W1S = reinterpret_cast<char*>(b3s + kMaxHeads);           // W1L: layer 1's fragments, shared by the waves of a column slice
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,9 +83,10 @@ __global__ __launch_bounds__(256 * MSPLIT, WPC) void dnn3_rs_kernel(MlpArgs a) {
             w2r[nb][ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(a.w2p) +
                                                            (size_t)((wave * NB2 + nb) * KS2 + ks) * 1024 + lane * 16);
     if (tid < H2) {
-        w3s[tid] = a.w3[tid];
+        for (uint32_t o = 0; o < n_out; ++o) w3s[o * H2 + tid] = a.w3[o * H2 + tid];
         b2s[tid] = a.b2[tid];
     }
+    if (tid < (int)n_out) b3s[tid] = a.b3v[tid];
 
     // gather role: 4 adjacent lanes per item, lane l of them takes quads 4j + l (64 contiguous bytes per instruction)
     const int g_item = tid / GL, g_l = tid % GL;
@@ -233,17 +238,37 @@ __global__ __launch_bounds__(256 * MSPLIT, WPC) void dnn3_rs_kernel(MlpArgs a) {
                     }
                 hps[(wave * 2 + h) * kWsItems + (mbase + m0 + mb) * 32 + i32] = p;
             }
+            // the other heads of a multi-output model: the same chain with their own w3 row
+            for (uint32_t o = 1; o < n_out; ++o) {
+#pragma unroll
+                for (int mb = 0; mb < MBG; ++mb) {
+                    float p = 0.0f;
+#pragma unroll
+                    for (int nb = 0; nb < NB2; ++nb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 wv = *reinterpret_cast<const float4*>(w3s + o * H2 + (wave * NB2 + nb) * 32 + 8 * g + 4 * h);
+                            p = __fmaf_rn(fmaxf(acc[mb][nb][4 * g + 0], 0.0f), wv.x, p);
+                            p = __fmaf_rn(fmaxf(acc[mb][nb][4 * g + 1], 0.0f), wv.y, p);
+                            p = __fmaf_rn(fmaxf(acc[mb][nb][4 * g + 2], 0.0f), wv.z, p);
+                            p = __fmaf_rn(fmaxf(acc[mb][nb][4 * g + 3], 0.0f), wv.w, p);
+                        }
+                    hps[(o * 8 + wave * 2 + h) * kWsItems + (mbase + m0 + mb) * 32 + i32] = p;
+                }
+            }
         }
         RS_MARK(4)
         __syncthreads();                                   // partials visible; everyone is done with X and H1
         RS_MARK(5)
 
-        // ---- scores: z = (((b3 + p0) + p1) + …) + p7, 16 items per wave
-        if (lane < FPW && fin_item < cur.cnt) {
-            float z = a.b3;
+        // ---- scores: z = (((b3 + p0) + p1) + …) + p7, 16 items per wave; lane group g = lane / FPW takes heads g, g + 64 / FPW, …
+        if (fin_item < cur.cnt) {
+            for (uint32_t o = (uint32_t)lane / FPW; o < n_out; o += 64 / FPW) {
+                float z = b3s[o];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) z += hps[s * kWsItems + fin_item];
-            a.out[cur.item0 + fin_item] = 1.0f / (1.0f + expf(-z));
+                for (int s = 0; s < 8; ++s) z += hps[(o * 8 + s) * kWsItems + fin_item];
+                a.out[(size_t)o * a.out_stride + cur.item0 + fin_item] = 1.0f / (1.0f + expf(-z));
+            }
         }
         cur = nxt;
         nxt = nn;
@@ -263,7 +288,7 @@ __global__ __launch_bounds__(256 * MSPLIT, WPC) void dnn3_rs_kernel(MlpArgs a) {
 // under the other's MFMAs); the wider shapes take 304 / 352 and run one
 template <int H1, int H2, int WPC, int MBG, int MSPLIT, bool W1L>
 static int launch_rs(pg_ctx* ctx, const MlpArgs& a) {
-    constexpr size_t lds = rs_lds_bytes<H1, H2, W1L>();
+    const size_t lds = rs_lds_bytes<H1, H2, W1L>(a.n_out);
     int rc;
     if ((rc = ensure_dyn_lds(ctx, (const void*)dnn3_rs_kernel<H1, H2, WPC, MBG, MSPLIT, W1L>, lds))) return rc;
 #ifdef PG_RS_PROFILE
@@ -319,8 +344,8 @@ __device__ __forceinline__ void ls_store_h_quad(char* tile, int row, int col, fl
     *reinterpret_cast<uint2*>(tile + row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + (col & 7) * 2) = p;
 }
 template <int H1, int H2>
-constexpr size_t ls_lds_bytes() {
-    return (size_t)kLsItems * kDIN * 2 + 2 * (size_t)kLsItems * 64 * 2 + (size_t)(H1 + 2 * H2 + 16 * kLsItems) * 4;
+constexpr size_t ls_lds_bytes(uint32_t n_out) {
+    return (size_t)kLsItems * kDIN * 2 + 2 * (size_t)kLsItems * 64 * 2 + (size_t)(H1 + H2 + n_out * (H2 + 16 * kLsItems) + kMaxHeads) * 4;
 }
 
 template <int H1, int H2>
@@ -333,8 +358,10 @@ __global__ __launch_bounds__(512, 1) void dnn3_ls_kernel(MlpArgs a) {
     char* const H1C = smem + XT_B;
     float* const c1s = reinterpret_cast<float*>(smem + XT_B + 2 * H1C_B);
     float* const b2s = c1s + H1;
-    float* const w3s = b2s + H2;
-    float* const hps = w3s + H2;                           // head partials [16 slots][128 items]
+    const uint32_t n_out = a.n_out;                        // heads on the shared trunk (1: the plain DNN3)
+    float* const w3s = b2s + H2;                           // [n_out][H2]
+    float* const hps = w3s + n_out * H2;                   // head partials [n_out][16 slots][128 items]
+    float* const b3s = hps + n_out * 16 * kLsItems;        // [kMaxHeads]
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_tiles = *a.n_tiles;
@@ -342,9 +369,10 @@ __global__ __launch_bounds__(512, 1) void dnn3_ls_kernel(MlpArgs a) {
     const uint32_t t_end = (uint32_t)(((uint64_t)n_tiles * (blockIdx.x + 1)) / gridDim.x);
     if (t_begin >= t_end) return;
     for (int i = tid; i < H2; i += 512) {
-        w3s[i] = a.w3[i];
+        for (uint32_t o = 0; o < n_out; ++o) w3s[o * H2 + i] = a.w3[o * H2 + i];
         b2s[i] = a.b2[i];
     }
+    if (tid < (int)n_out) b3s[tid] = a.b3v[tid];
     const char* const w1base = reinterpret_cast<const char*>(a.w1p);
     const char* const w2base = reinterpret_cast<const char*>(a.w2p) + (size_t)(wave * 2) * KS2 * 1024;
     const int mb1 = wave & 3, nb1 = wave >> 2;
@@ -520,12 +548,32 @@ __global__ __launch_bounds__(512, 1) void dnn3_ls_kernel(MlpArgs a) {
                 }
             hps[(wave * 2 + h) * M + mb * 32 + i32] = p;
         }
-        __syncthreads();
-        if (tid_o < (uint32_t)M && tid_o < cnt) {
-            float z = a.b3;
+        for (uint32_t o = 1; o < n_out; ++o) {             // the other heads of a multi-output model
 #pragma unroll
-            for (int s = 0; s < 16; ++s) z += hps[s * M + tid_o];
-            a.out[item0 + tid_o] = 1.0f / (1.0f + expf(-z));
+            for (int mb = 0; mb < 4; ++mb) {
+                float p = 0.0f;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 wv = *reinterpret_cast<const float4*>(w3s + o * H2 + (wave * 2 + nb) * 32 + 8 * g + 4 * h);
+                        p = __fmaf_rn(fmaxf(acc2[mb][nb][4 * g + 0], 0.0f), wv.x, p);
+                        p = __fmaf_rn(fmaxf(acc2[mb][nb][4 * g + 1], 0.0f), wv.y, p);
+                        p = __fmaf_rn(fmaxf(acc2[mb][nb][4 * g + 2], 0.0f), wv.z, p);
+                        p = __fmaf_rn(fmaxf(acc2[mb][nb][4 * g + 3], 0.0f), wv.w, p);
+                    }
+                hps[(o * 16 + wave * 2 + h) * M + mb * 32 + i32] = p;
+            }
+        }
+        __syncthreads();
+        // 512 threads, 128 items: thread group tid / 128 takes heads g, g + 4
+        if ((tid_o & (M - 1)) < cnt) {
+            for (uint32_t o = tid_o / M; o < n_out; o += 512 / M) {
+                float z = b3s[o];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) z += hps[(o * 16 + s) * M + (tid_o & (M - 1))];
+                a.out[(size_t)o * a.out_stride + item0 + (tid_o & (M - 1))] = 1.0f / (1.0f + expf(-z));
+            }
         }
         RS_MARK(5)
     }
@@ -539,7 +587,7 @@ __global__ __launch_bounds__(512, 1) void dnn3_ls_kernel(MlpArgs a) {
 
 template <int H1, int H2>
 static int launch_ls(pg_ctx* ctx, const MlpArgs& a) {
-    constexpr size_t lds = ls_lds_bytes<H1, H2>();
+    const size_t lds = ls_lds_bytes<H1, H2>(a.n_out);
     int rc;
     if ((rc = ensure_dyn_lds(ctx, (const void*)dnn3_ls_kernel<H1, H2>, lds))) return rc;
 #ifdef PG_RS_PROFILE

@@ -40,6 +40,13 @@ struct WsTile {
     uint32_t req, item0, cnt;
 };
 
+// MULTI: a model with several heads on the shared trunk (n_out <= kMaxHeads outputs, EasyrecResponse.multiValModule,
+// algorithm/eas/easyrec_response.go:35-70).  Head 0 is the code above, bit for bit.  The other heads run the same
+// relu → dot over the lane's 32 columns with their own w3 row (from L1 / L2: the LDS is full), and their 4 partials per
+// item (one per wave) go through a per-workgroup block of GLOBAL scratch instead of LDS (the workgroup's own L1 keeps it coherent across
+// the barrier); they are finished under the next tile's block A like head 0's — by the lanes that idle there: lane group
+// g = lane / 16 finishes heads g and g + 4 of the wave's 16 items, so the sigmoids of up to four heads cost one.
+template <bool MULTI>
 __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
     constexpr int H1 = 512, H2 = 256, KS1 = kDIN / 16, KS2 = H1 / 16;      // 8 / 32 k-steps
     constexpr int XT_B = kWsItems * kDIN * 2;                             // 16 KiB
@@ -141,11 +148,63 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) fin_p[s] = hps[s * kWsItems + fin_item];
     };
+    // (MULTI) this workgroup's partials of heads 1..: [head - 1][4 waves][64 items] — a wave's two column halves are
+    // added in the wave (lanes i and i + 32) before they are stored, so a head's score is b3 + s0 + s1 + s2 + s3
+    float* const gp = MULTI ? a.head_part + (size_t)blockIdx.x * ((kMaxHeads - 1) * 4 * kWsItems) : nullptr;
+    const uint32_t n_out = MULTI ? a.n_out : 1u;
+    // (MULTI) lane group g = lane / 16 finishes heads g and g + 4 of the wave's 16 items
+    float fin_q[4], fin_b = 0.0f;
+    auto finalize_read_multi = [&]() {
+        if constexpr (MULTI) {
+            // (per-lane values from an opaque thread id: carried across the tile loop they are spilled)
+            uint32_t l_ = threadIdx.x;
+            asm volatile("" : "+v"(l_));
+            const uint32_t grp = (l_ >> 4) & 3, item = (l_ >> 6) * (kWsItems / 4) + (l_ & 15);
+            if (grp >= 1 && grp < n_out && fin.cnt) {
+                fin_b = a.b3v[grp];
+                const float* const src = a.head_part + (size_t)blockIdx.x * ((kMaxHeads - 1) * 4 * kWsItems) +
+                                         (grp - 1) * 4 * kWsItems + item;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fin_q[s] = src[s * kWsItems];
+            }
+        }
+    };
     auto finalize_write = [&]() {
         float z = a.b3;
 #pragma unroll
         for (int s = 0; s < 8; ++s) z += fin_p[s];
         if (lane < kWsItems / 4 && fin_item < fin.cnt) a.out[fin.item0 + fin_item] = 1.0f / (1.0f + expf(-z));
+    };
+    // (MULTI) the previous tile's other heads: read before the barrier behind layer 1 (every wave's reads are complete
+    // there, this tile's head phase may then rewrite the block), finished behind layer 2, whose MFMAs cover the loads
+    auto finalize_write_multi = [&]() {
+        if constexpr (MULTI) {
+            uint32_t l_ = threadIdx.x;
+            asm volatile("" : "+v"(l_));
+            const uint32_t grp = (l_ >> 4) & 3, item = (l_ >> 6) * (kWsItems / 4) + (l_ & 15);
+            if (grp >= 1 && grp < n_out && item < fin.cnt) {
+                float zo = fin_b;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) zo += fin_q[s];
+                a.out[(size_t)grp * a.out_stride + fin.item0 + item] = 1.0f / (1.0f + expf(-zo));
+            }
+        }
+    };
+    // heads 4..7 (rare): read and finished in one go, the latency shows
+    auto finalize_high_heads = [&]() {
+        if constexpr (MULTI) {
+            uint32_t l_ = threadIdx.x;
+            asm volatile("" : "+v"(l_));
+            const uint32_t o = ((l_ >> 4) & 3) + 4, item = (l_ >> 6) * (kWsItems / 4) + (l_ & 15);
+            if (o < n_out && item < fin.cnt) {
+                float zo = a.b3v[o];
+                const float* const src = a.head_part + (size_t)blockIdx.x * ((kMaxHeads - 1) * 4 * kWsItems) +
+                                         (o - 1) * 4 * kWsItems + item;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) zo += src[s * kWsItems];
+                a.out[(size_t)o * a.out_stride + fin.item0 + item] = 1.0f / (1.0f + expf(-zo));
+            }
+        }
     };
 
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
@@ -247,6 +306,8 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
             for (int q = 0; q < 16; ++q) store_h(accB, wave * 128 + 64, q >> 3, (q >> 2) & 1, q & 3);
         }
         WS_MARK(2)
+        finalize_read_multi();
+        if (MULTI && n_out > 4) finalize_high_heads();
         __syncthreads();
         WS_MARK(3)
 
@@ -302,6 +363,7 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
             }
             WS_MFMA_DONE4(acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]);
         }
+        finalize_write_multi();
         WS_MARK(4)
 
         // next tile's streamed fragments (this tile's were last read by block B)
@@ -338,6 +400,32 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
                     }
                 hps[(wave * 2 + ((tid_o >> 5) & 1)) * kWsItems + mb * 32 + (tid_o & 31)] = p;
             }
+            if constexpr (MULTI) {
+                // the other heads: same chain over the same columns, w3 row o from global memory (every tile reads the
+                // same 1 KB per head: L1-resident), partials to the workgroup's global block
+                for (uint32_t o = 1; o < n_out; ++o) {
+                    const float* const w3o = a.w3 + (size_t)o * H2 + wave * 64 + 4 * h;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) wv[nb][g] = *reinterpret_cast<const float4*>(w3o + nb * 32 + 8 * g);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        float p = 0.0f;
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                p = __fmaf_rn(ws_relu(acc2[mb][nb][4 * g + 0]), wv[nb][g].x, p);
+                                p = __fmaf_rn(ws_relu(acc2[mb][nb][4 * g + 1]), wv[nb][g].y, p);
+                                p = __fmaf_rn(ws_relu(acc2[mb][nb][4 * g + 2]), wv[nb][g].z, p);
+                                p = __fmaf_rn(ws_relu(acc2[mb][nb][4 * g + 3]), wv[nb][g].w, p);
+                            }
+                        p += __shfl_xor(p, 32);
+                        if (((tid_o >> 5) & 1) == 0) gp[((o - 1) * 4 + wave) * kWsItems + mb * 32 + (tid_o & 31)] = p;
+                    }
+                }
+            }
         }
         WS_MARK(5)
         __syncthreads();                                   // partials visible; also: everyone is done with H1
@@ -349,6 +437,9 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
     }
     finalize_read();
     finalize_write();
+    finalize_read_multi();
+    finalize_write_multi();
+    if (MULTI && n_out > 4) finalize_high_heads();
 #ifdef PG_WS_PROFILE
     if (lane == 0 && blockIdx.x < 4) {
         uint64_t* o = (uint64_t*)(a.field_emb) + (blockIdx.x * 4 + wave) * 8;
@@ -360,13 +451,18 @@ __global__ __launch_bounds__(256, 1) void dnn3_ws_kernel(MlpArgs a) {
 int launch_dnn3_ws(pg_ctx* ctx, const MlpArgs& a) {
     constexpr size_t lds = ws_lds_bytes();
     int rc;
-    if ((rc = ensure_dyn_lds(ctx, (const void*)dnn3_ws_kernel, lds))) return rc;
+    if (a.n_out > 1) {
+        if ((rc = ensure_dyn_lds(ctx, (const void*)dnn3_ws_kernel<true>, lds))) return rc;
+        dnn3_ws_kernel<true><<<ctx->num_cus, 256, lds, ctx->stream>>>(a);
+        return PG_OK;
+    }
+    if ((rc = ensure_dyn_lds(ctx, (const void*)dnn3_ws_kernel<false>, lds))) return rc;
 #ifdef PG_WS_PROFILE
     static uint64_t* dbg = nullptr;
     if (!dbg) hipMalloc(&dbg, 4 * 4 * 8 * 8);
     MlpArgs b = a;
     b.field_emb = reinterpret_cast<const float* const*>(dbg);
-    dnn3_ws_kernel<<<ctx->num_cus, 256, lds, ctx->stream>>>(b);
+    dnn3_ws_kernel<false><<<ctx->num_cus, 256, lds, ctx->stream>>>(b);
     uint64_t hcyc[128];
     hipMemcpy(hcyc, dbg, sizeof hcyc, hipMemcpyDeviceToHost);
     static int calls = 0;
@@ -377,7 +473,7 @@ int launch_dnn3_ws(pg_ctx* ctx, const MlpArgs& a) {
             fprintf(stderr, "\n");
         }
 #else
-    dnn3_ws_kernel<<<ctx->num_cus, 256, lds, ctx->stream>>>(a);
+    dnn3_ws_kernel<false><<<ctx->num_cus, 256, lds, ctx->stream>>>(a);
 #endif
     return PG_OK;
 }

@@ -2630,6 +2630,7 @@ int recall_job_prepare(RecallJob* j) {
         }
         if ((rc = ensure_table_nx(ctx, t))) return rc;
     }
+    j->table_gen = t->generation.load(std::memory_order_relaxed);
     j->rows_qualified = (uint32_t)t->rows;
     if (j->filter.col && j->filter.admitted >= 0) {
         j->rows_qualified = (uint32_t)j->filter.admitted;
@@ -3576,7 +3577,7 @@ int pg_table_view_create(pg_ctx* ctx, const pg_table* t, const pg_features* fs, 
     if ((rc = pg::filter_count_locked(ctx, f, t->rows, &d_blk, &d_grp, &cblocks, &admitted))) return rc;
     if (admitted == 0) {
         pg::set_error("pg_table_view_create: no row passes the filter");
-        return PG_ERR_INVALID;
+        return PG_ERR_EMPTY;
     }
     pg_table* v = new pg_table();
     v->rows = admitted;
@@ -3619,9 +3620,7 @@ int pg_i2i_recall(pg_ctx* ctx, const pg_table* trigger_table, const uint32_t* tr
         PG_REQUIRE(trigger_rows[i] < trigger_table->rows, "pg_i2i_recall: trigger row %u outside table of %llu rows", trigger_rows[i],
                    (unsigned long long)trigger_table->rows);
     std::lock_guard<std::mutex> g(ctx->mu);
-    pg::TableRead tr(t->rw);
-    pg::TableRead tr2;
-    if (trigger_table != t) tr2 = pg::TableRead(trigger_table->rw);
+    pg::TableRead2 tr(t, trigger_table);
     void* buf;
     int rc;
     const size_t qb = (size_t)n * t->dim * 4, rb = (size_t)n * k * 8, sb = (size_t)n * k * 4;

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 
 PREC_F32, PREC_BF16 = 0, 1
-MODEL_DNN3, MODEL_FM_TWOTOWER = 1, 2
+MODEL_DNN3, MODEL_FM_TWOTOWER, MODEL_DNN3_MULTI = 1, 2, 3
 MAX_QUERIES = 256         # per table pass (32 when dim > 128)
 
 
@@ -249,6 +249,20 @@ def pack_dnn3(w1, b1, w2, b2, w3, b3, d_user: int) -> bytes:
             np.ascontiguousarray(w3, dtype=np.float32).tobytes() + struct.pack("<f", float(b3)))
 
 
+def pack_dnn3_multi(w1, b1, w2, b2, w3, b3, d_user: int) -> bytes:
+    """PG_MODEL_DNN3_MULTI blob (include/pairec_gpu.h): w3 [h2][n_out], b3 [n_out] — n_out heads on one trunk."""
+    w1 = np.ascontiguousarray(w1, dtype=np.float32)
+    w2 = np.ascontiguousarray(w2, dtype=np.float32)
+    w3 = np.ascontiguousarray(w3, dtype=np.float32)
+    b3 = np.ascontiguousarray(b3, dtype=np.float32).reshape(-1)
+    din, h1 = w1.shape
+    h2 = w2.shape[1]
+    assert w3.shape == (h2, b3.shape[0])
+    return (struct.pack("<5I", d_user, din - d_user, h1, h2, b3.shape[0]) + w1.tobytes() +
+            np.ascontiguousarray(b1, dtype=np.float32).tobytes() + w2.tobytes() +
+            np.ascontiguousarray(b2, dtype=np.float32).tobytes() + w3.tobytes() + b3.tobytes())
+
+
 def pack_fm2t(w) -> bytes:
     """w: object with the attributes of oracle.Fm2tWeights (duck-typed; no oracle import here)."""
     parts = [struct.pack("<7If", w.nuf, w.nif, w.k, w.d_user, w.t_h1, w.t_out, w.vocab, w.fm_b)]
@@ -270,6 +284,9 @@ class RankModel:
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
         _lib.check(ctx.L.pg_model_load(ctx.h, kind, prec, buf, len(blob), C.byref(h)))
         self.h = h
+        n = C.c_uint32()
+        _lib.check(ctx.L.pg_model_num_outputs(h, C.byref(n)))
+        self.n_out = n.value
 
     def destroy(self):
         if self.h:
@@ -278,13 +295,14 @@ class RankModel:
 
     def rank_dnn3(self, table: Table, user_vecs: np.ndarray, cand_rows: np.ndarray,
                   req_offsets: Sequence[int]) -> np.ndarray:
+        """scores [n_items]; a multi-output model: [n_out][n_items] (one plane per head)."""
         u = np.ascontiguousarray(user_vecs, dtype=np.float32)
         c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
         ro = np.ascontiguousarray(req_offsets, dtype=np.uint32)
-        out = np.empty(c.shape[0], dtype=np.float32)
+        out = np.empty((self.n_out, c.shape[0]), dtype=np.float32)
         _lib.check(self.ctx.L.pg_rank_dnn3(self.ctx.h, self.h, table.h, _ptr(u), _ptr(c), _ptr(ro),
                                            ro.shape[0] - 1, _ptr(out)))
-        return out
+        return out[0] if self.n_out == 1 else out
 
     def rank_dnn3_dev(self, table: Table, d_user_vecs: int, d_cand_rows: int, d_req_offsets: int,
                       n_req: int, n_items: int, d_out: int):
@@ -460,6 +478,9 @@ class Coalescer:
         scene = algos is not None or dpp is not None or query_model is not None or trigger_table is not None \
             or max_rerank_items or max_hook_dim
         self.n_algos = 1 if model else 0
+        self.n_planes = getattr(model, "n_out", 1) if model else 0
+        self.algo_outputs = [self.n_planes] if model else []
+        self.dnn_heads = self.n_planes or 1
         if not scene:
             _lib.check(ctx.L.pg_coalescer_create(ctx.h, table.h, model.h if model else None, expr.h if expr else None,
                                                  rank_var.encode() if rank_var else None, C.byref(cfg), C.byref(h)))
@@ -474,7 +495,11 @@ class Coalescer:
                 self._keep.append(nm)
                 arr[i].model = m.h
                 arr[i].name = nm
-                if len(a) == 3:                       # (name, model, ItemRows)
+                if len(a) == 3 and isinstance(a[2], (list, tuple)):     # (name, multi-output model, output names)
+                    onames = (C.c_char_p * len(a[2]))(*[str(x).encode() for x in a[2]])
+                    self._keep.append(onames)
+                    arr[i].output_names = onames
+                elif len(a) == 3:                     # (name, model, ItemRows)
                     arr[i].item_rows = a[2].h
                 elif len(a) > 3:                      # (name, model, Features, item field column names)
                     feats, cols = a[2], a[3]
@@ -499,6 +524,9 @@ class Coalescer:
             sc.max_rerank_items = max_rerank_items
             sc.max_hook_dim = max_hook_dim
             self.n_algos = len(algos)
+            self.n_planes = sum(getattr(a[1], "n_out", 1) for a in algos)
+            self.algo_outputs = [getattr(a[1], "n_out", 1) for a in algos]
+            self.dnn_heads = next((a[1].n_out for a in algos if a[1].kind in (MODEL_DNN3, MODEL_DNN3_MULTI)), 1)
             _lib.check(ctx.L.pg_coalescer_create_scene(ctx.h, table.h, C.byref(sc), C.byref(h)))
         self.h = h
 
@@ -537,18 +565,20 @@ class Coalescer:
     def rank_dnn3(self, user_vec: np.ndarray, cand_rows: np.ndarray) -> np.ndarray:
         u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(-1)
         c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
-        out = np.empty(c.shape[0], dtype=np.float32)
+        heads = getattr(self, "dnn_heads", 1)
+        out = np.empty((heads, c.shape[0]), dtype=np.float32)
         _lib.check(self.ctx.L.pg_coalescer_rank_dnn3(self.h, _ptr(u), _ptr(c), c.shape[0], _ptr(out)))
-        return out
+        return out[0] if heads == 1 else out
 
     def rank(self, algo: int, user_vec: np.ndarray, cand_rows: np.ndarray, user_field_ids=None) -> np.ndarray:
         u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(-1)
         c = np.ascontiguousarray(cand_rows, dtype=np.uint32)
         uf = None if user_field_ids is None else np.ascontiguousarray(user_field_ids, dtype=np.int32)
-        out = np.empty(c.shape[0], dtype=np.float32)
+        heads = self.algo_outputs[algo]
+        out = np.empty((heads, c.shape[0]), dtype=np.float32)
         _lib.check(self.ctx.L.pg_coalescer_rank(self.h, algo, _ptr(u), _ptr(uf) if uf is not None else None, _ptr(c),
                                                 c.shape[0], _ptr(out)))
-        return out
+        return out[0] if heads == 1 else out
 
     def rank_fm2t(self, user_vec: np.ndarray, user_field_ids, cand_rows: np.ndarray) -> np.ndarray:
         u = np.ascontiguousarray(user_vec, dtype=np.float32).reshape(-1)
@@ -567,12 +597,12 @@ class Coalescer:
         rec = np.empty(top_n, dtype=np.float32)
         fus = np.empty(top_n, dtype=np.float64)
         cnt = C.c_uint32()
-        if user_field_ids is None and self.n_algos <= 1:
+        if user_field_ids is None and self.n_planes <= 1:
             rnk = np.empty(top_n, dtype=np.float32)
             _lib.check(self.ctx.L.pg_coalescer_recommend(self.h, _ptr(u), top_n, _ptr(rows), _ptr(rec), _ptr(rnk),
                                                          _ptr(fus), C.byref(cnt)))
         else:
-            rnk = np.empty((self.n_algos, top_n), dtype=np.float32)
+            rnk = np.empty((self.n_planes, top_n), dtype=np.float32)
             uf = None if user_field_ids is None else np.ascontiguousarray(user_field_ids, dtype=np.int32)
             _lib.check(self.ctx.L.pg_coalescer_recommend_ex(self.h, _ptr(u), _ptr(uf) if uf is not None else None, top_n,
                                                             _ptr(rows), _ptr(rec), _ptr(rnk), _ptr(fus), C.byref(cnt)))
@@ -622,6 +652,7 @@ class GroupCoalescer(Coalescer):
                  max_wait_us: int = 0, depth: int = 0, timeout_us: int = 0):
         self.L = group.L
         self.group, self.k, self.n_algos = group, k, 1
+        self.n_planes, self.algo_outputs, self.dnn_heads = 1, [1], 1
         self.max_top_n = max_top_n or k
         plan = _lib.PgGroupPlan(k, dpp_candidates, dpp_alpha, dpp_window, int(dpp_normalize_emb))
         cfg = _lib.PgCoalescerConfig(k, max_batch, max_wait_us, depth, max_top_n, 0, timeout_us)

@@ -132,6 +132,26 @@ bool Engine::IngestBegin(std::string* err) {
     staging_dict.reset(new IdDict());
     staging_dict->Reserve(table_rows, table_rows * 16);
     staging_filled = 0;
+    if (staging_feats) { pg_features_destroy(ctx, staging_feats); staging_feats = nullptr; }    // an abandoned load's columns
+    return true;
+}
+
+// One int32 item feature column of the generation being loaded (between IngestBegin and IngestCommit), keyed by the NEW
+// rows.  The commit changes the columns over together with rows and ids; a generation that replaces a table with
+// feature columns must bring its own (IngestCommit refuses otherwise: the old columns describe the old rows).
+bool Engine::IngestFeatureColumn(const std::string& name, const int32_t* values, uint64_t n, std::string* err) {
+    std::lock_guard<std::mutex> g(ingest_mu);
+    if (!staging || !staging_dict) { if (err) *err = "ingest: no load in progress (IngestBegin first)"; return false; }
+    if (n != table_rows || !values) { if (err) *err = "ingest: a feature column has one value per table row"; return false; }
+    if (!staging_feats && pg_features_create(ctx, table_rows, &staging_feats) != PG_OK) {
+        if (err) *err = std::string("pg_features_create (staging): ") + pg_last_error();
+        staging_feats = nullptr;
+        return false;
+    }
+    if (pg_features_set_column(ctx, staging_feats, name.c_str(), PG_F_I32, values, 0.0) != PG_OK) {
+        if (err) *err = std::string("pg_features_set_column: ") + pg_last_error();
+        return false;
+    }
     return true;
 }
 
@@ -139,19 +159,26 @@ bool Engine::IngestChunk(const char* ids, size_t ids_bytes, const float* rows, u
     std::lock_guard<std::mutex> g(ingest_mu);
     if (!staging || !staging_dict) { if (err) *err = "ingest: no load in progress (IngestBegin first)"; return false; }
     if (staging_filled + n > table_rows) { if (err) *err = "ingest: more rows than the table holds"; return false; }
-    // n NUL-terminated ids back to back
+    // n NUL-terminated ids back to back — exactly n: an id with a NUL inside would shift every later id by a row
     const char* p = ids;
     const char* end = ids + ids_bytes;
     for (uint64_t i = 0; i < n; ++i) {
         const char* z = (const char*)memchr(p, 0, (size_t)(end - p));
         if (!z) { if (err) *err = "ingest: fewer ids than rows in the chunk"; return false; }
-        staging_dict->Append(p, (size_t)(z - p));
         p = z + 1;
     }
+    if (p != end) { if (err) *err = "ingest: the chunk's id buffer holds more than one id per row (an id with a NUL byte inside?)"; return false; }
     // the rows go straight into the staging table; the live table keeps serving (its lock is not touched)
     if (pg_table_upload(ctx, staging, staging_filled, n, rows) != PG_OK) {
         if (err) *err = std::string("pg_table_upload: ") + pg_last_error();
         return false;
+    }
+    // the dictionary follows the rows only once they are in place (a failed upload leaves both where they were)
+    p = ids;
+    for (uint64_t i = 0; i < n; ++i) {
+        const char* z = (const char*)memchr(p, 0, (size_t)(end - p));
+        staging_dict->Append(p, (size_t)(z - p));
+        p = z + 1;
     }
     staging_filled += n;
     return true;
@@ -162,6 +189,11 @@ bool Engine::IngestCommit(std::string* err) {
     if (!staging || !staging_dict) { if (err) *err = "ingest: no load in progress"; return false; }
     if (staging_filled != table_rows) {
         if (err) *err = "ingest: " + std::to_string(staging_filled) + " of " + std::to_string(table_rows) + " rows loaded (a partition is replaced whole)";
+        return false;
+    }
+    if (feats && pg_features_num_columns(feats) > 0 && !staging_feats) {
+        if (err) *err = "ingest: the engine serves row-keyed feature columns (a WhereClause column / FM item fields); the new generation "
+                        "must bring its own (ph_engine_ingest_feature_column between begin and commit) — the old ones describe the old rows";
         return false;
     }
     if (!staging_dict->BuildIndex(err)) return false;
@@ -177,8 +209,15 @@ bool Engine::IngestCommit(std::string* err) {
             return false;
         }
         std::atomic_store(&dict, std::shared_ptr<const IdDict>(staging_dict.release()));
+        if (staging_feats) {
+            // rows, ids and columns change over together; whatever was built over the old columns (the scene coalescer's FM
+            // algorithm, filtered views) goes with them — nothing is in flight inside this section
+            DropCoalescers();
+            std::swap(feats, staging_feats);
+        }
         generation++;
     }
+    if (staging_feats) { pg_features_destroy(ctx, staging_feats); staging_feats = nullptr; }   // the previous generation's columns
     staging_filled = 0;                         // `staging` now holds the previous generation's rows: the next load overwrites them
     return true;
 }
@@ -221,6 +260,7 @@ bool Engine::IngestFile(const std::string& path, std::string* err) {
             rows.resize(o + dim);
             in.read((char*)&rows[o], (std::streamsize)dim * 4);
             if (!in) { if (err) *err = "ingest: " + path + ": truncated at row " + std::to_string(r); return false; }
+            if (id.find('\0') != std::string::npos) { if (err) *err = "ingest: " + path + ": the id of row " + std::to_string(r) + " contains a NUL byte"; return false; }
             ids.append(id);
             ids.push_back('\0');
             if (++in_chunk == chunk && !flush()) return false;
@@ -247,7 +287,8 @@ bool Engine::IngestFile(const std::string& path, std::string* err) {
                 ++got;
                 p = e;
             }
-            if (got != dim) { if (err) *err = "ingest: " + path + ":" + std::to_string(lineno) + ": " + std::to_string(got) + " values, the table has dim " + std::to_string(dim); return false; }
+            while (*p == ',' || *p == ' ' || *p == '}' || *p == '\r') ++p;
+            if (got != dim || *p) { if (err) *err = "ingest: " + path + ":" + std::to_string(lineno) + ": " + (got != dim ? std::to_string(got) : "more than " + std::to_string(dim)) + " values, the table has dim " + std::to_string(dim); return false; }
             ids.append(line, 0, tab);
             ids.push_back('\0');
             if (++in_chunk == chunk && !flush()) return false;
@@ -273,6 +314,10 @@ int ph_engine_ingest_chunk(void* h, const char* ids, size_t ids_bytes, const flo
     auto* e = (pairec::Engine*)h;
     return e && ids && rows && e->IngestChunk(ids, ids_bytes, rows, n, &g_ph_err_ingest) ? 0 : -1;
 }
+int ph_engine_ingest_feature_column(void* h, const char* name, const int32_t* values, uint64_t n) {
+    auto* e = (pairec::Engine*)h;
+    return e && name && e->IngestFeatureColumn(name, values, n, &g_ph_err_ingest) ? 0 : -1;
+}
 int ph_engine_ingest_commit(void* h) {
     auto* e = (pairec::Engine*)h;
     return e && e->IngestCommit(&g_ph_err_ingest) ? 0 : -1;
@@ -295,6 +340,7 @@ int ph_engine_set_ids(void* h, const char* ids, size_t ids_bytes, uint64_t n) {
         d->Append(p, (size_t)(z - p));
         p = z + 1;
     }
+    if (p != end) { g_ph_err_ingest = "set_ids: the buffer holds more than one id per row (an id with a NUL byte inside?)"; return -1; }
     if (!d->BuildIndex(&g_ph_err_ingest)) return -1;
     pairec::VersionLock::Write w(e->version);
     std::atomic_store(&e->dict, std::shared_ptr<const pairec::IdDict>(d.release()));

@@ -598,6 +598,29 @@ struct GpuDnnAlgorithm : algorithm::IAlgorithm {
         // multi-output model (EasyrecResponse.multiValModule, easyrec_response.go:35-70): GetModuleType() = true and a score
         // per output name; RankService writes them as "<algo>_<output>" (rank_service.go:315-319)
         out->responses.assign(n, algorithm::AlgoResponse());
+        auto mh = e->named_models.find(name);
+        if (mh != e->named_models.end()) {
+            // the model as exported: ONE trunk, one head per output (PG_MODEL_DNN3_MULTI) — one gather, one launch
+            uint32_t heads = 0;
+            pg_model_num_outputs(mh->second, &heads);
+            if (heads != outputs.size()) {
+                if (err) *err = "dnn: model of " + name + " has " + std::to_string(heads) + " outputs, the algorithm names " +
+                                std::to_string(outputs.size());
+                return false;
+            }
+            std::vector<float> planes((size_t)heads * n);
+            const uint32_t off[2] = {0, n};
+            if (req.UserVector.empty()) { if (err) *err = "dnn: no user vector"; return false; }
+            if (pg_rank_dnn3(e->ctx, mh->second, e->table, req.UserVector.data(), rows.data(), off, 1, planes.data()) != PG_OK) {
+                if (err) *err = pg_err("pg_rank_dnn3");
+                return false;
+            }
+            for (uint32_t i = 0; i < n; ++i) {
+                out->responses[i].multiValModule = true;
+                for (uint32_t o = 0; o < heads; ++o) out->responses[i].scoreArr[outputs[o]] = (double)planes[(size_t)o * n + i];
+            }
+            return true;
+        }
         for (const auto& o : outputs) {
             auto it = e->named_models.find(name + "/" + o);
             if (!Score(it == e->named_models.end() ? nullptr : it->second, req, rows, &scores, err)) return false;
@@ -1028,7 +1051,8 @@ struct GpuDPPSort : sort::ISort {                        // sort/dpp_sort.go:108
         std::vector<uint32_t> idx((size_t)std::max(size, 1));
         uint32_t cnt = 0;
         int rc;
-        pg_coalescer* co = e->coalesce ? e->SceneCoalescer(0, err) : nullptr;
+        std::string cerr;                               // (a failed coalescer falls back to the direct call: not this call's error)
+        pg_coalescer* co = e->coalesce ? e->SceneCoalescer(0, &cerr) : nullptr;
         // SortService.Sort runs once per request, requests overlap (sort/sort.go:65-125): equal-shaped DPP calls share a launch
         if (co && n <= 1024) rc = pg_coalescer_dpp(co, rows.data(), rel.data(), n, &o, nullptr, idx.data(), &cnt, used.data());
         else rc = pg_dpp_ex(e->ctx, e->table, rows.data(), rel.data(), n, &o, nullptr, idx.data(), &cnt, used.data());
@@ -1143,8 +1167,9 @@ struct GpuSSDSort : sort::ISort {                        // sort/ssd_sort.go:110
         // SortService.Sort runs once per request, requests overlap (sort/sort.go:65-125): equal-shaped SSD calls of concurrent
         // requests share one launch (every request its own workgroups and barrier); other shapes take the direct call
         int src = PG_ERR_UNSUPPORTED;
+        std::string cerr;                               // (a failed coalescer falls back to the direct call: not this call's error)
         if (e->coalesce && n <= 1024)
-            if (pg_coalescer* co = e->SceneCoalescer(0, err))
+            if (pg_coalescer* co = e->SceneCoalescer(0, &cerr))
                 src = pg_coalescer_ssd(co, rows.data(), rel.data(), n, gamma, (uint32_t)std::max(size, 0), (uint32_t)std::max(windowSize, 0),
                                        conf.NormalizeEmb ? 1 : 0, conf.EnsurePositiveSim ? 1 : 0, (doNorm == 1 || doNorm == 2) ? doNorm : 0,
                                        conf.UseSSDStar ? 1 : 0, idx.data(), &cnt, quality.data());
@@ -1271,6 +1296,7 @@ Engine::~Engine() {
         for (auto& kv : named_models) pg_model_destroy(ctx, kv.second);
         if (fm2t) pg_model_destroy(ctx, fm2t);
         if (feats) pg_features_destroy(ctx, feats);
+        if (staging_feats) pg_features_destroy(ctx, staging_feats);
         if (item_emb) pg_table_destroy(ctx, item_emb);
         if (staging) pg_table_destroy(ctx, staging);
         if (table) pg_table_destroy(ctx, table);
@@ -1397,7 +1423,9 @@ const Engine::FilterView* Engine::ViewFor(const recconf::RecallConfig& conf, uin
     fv = FilterView();
     fv.generation = gen;
     const int rc = pg_table_view_create(ctx, table, feats, col, conf.WhereOp, conf.WhereValue, &fv.view);
-    if (rc == PG_ERR_INVALID) { fv.empty = true; return &fv; }           // no row passes: every answer is empty
+    if (rc == PG_ERR_EMPTY) { fv.empty = true; return &fv; }             // no row passes: every answer is empty
+    // (PG_ERR_INVALID is a misconfiguration — a feature store shorter than the table, a bad operator: the per-call path below
+    // reports it on every request instead of serving empty pages for the whole generation)
     if (rc != PG_OK) { fv.failed = true; fv.view = nullptr; return &fv; }
     if (coalesce) {
         pg_scene_config sc;
@@ -1451,6 +1479,16 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
         if (o.kind == recall::LoadOutcome::kPanic) { if (err) *err = "panic: " + o.message; return nullptr; }
         if (o.kind == recall::LoadOutcome::kUnavailable) { if (err) *err = o.message; return nullptr; }
     }
+    // RankConf.ASTType = "antlr" selects another expression language in the reference (GetExpASTWithType /
+    // ExprASTResultWithType, utils/ast/ast.go:338-389: the valuate evaluator with AntlrFunctions — maxIndex, maxValue, …).
+    // This engine evaluates the default grammar only; evaluating an "antlr" RankScore with it would silently change scores.
+    for (const auto& kv : e->config.RankConf)
+        if (kv.second.ASTType == "antlr") {
+            if (err) *err = "RankConf[" + kv.first + "].ASTType \"antlr\": the antlr expression evaluator (utils/ast/ast.go:338-389, "
+                            "GetExpASTByAntlr / ExprASTResultByAntlr) is not implemented by the GPU engine; leave ASTType empty to use "
+                            "the default AST or keep this scene's RankScore on the CPU path";
+            return nullptr;
+        }
     for (const auto& sc : e->config.SortConfs) {
         // RegisterSortWithConfig (sort/sort.go:162-200): DPPSort / SSDSort open their Hologres datasource first
         // (NewDPPSort, dpp_sort.go:60-64; NewSSDSort, ssd_sort.go:52-56) and panic without it; an unknown SortType
@@ -1750,6 +1788,7 @@ void ph_engine_destroy(void* h) { delete (Engine*)h; }
 int ph_engine_load_dnn3(void* h, int prec, const char* blob, size_t len) {
     Engine* e = (Engine*)h;
     if (!e || !blob) return -1;
+    VersionLock::Write w(e->version);                  // no request is inside the coalescers / holds the model this replaces
     e->DropCoalescers();                               // they hold the old model
     if (e->model) { pg_model_destroy(e->ctx, e->model); e->model = nullptr; }
     const int rc = pg_model_load(e->ctx, PG_MODEL_DNN3, (pg_prec)prec, blob, len, &e->model);
@@ -1757,10 +1796,26 @@ int ph_engine_load_dnn3(void* h, int prec, const char* blob, size_t len) {
     return rc;
 }
 
+// the multi-output model of rank algorithm `algo` (blob format PG_MODEL_DNN3_MULTI: n_out heads on one trunk); its
+// outputs are named by the algorithm's "Outputs" list, in order
+int ph_engine_load_dnn3_multi(void* h, const char* algo, int prec, const char* blob, size_t len) {
+    Engine* e = (Engine*)h;
+    if (!e || !blob || !algo) return -1;
+    VersionLock::Write w(e->version);                  // no request in flight holds the model this replaces
+    pg_model* m = nullptr;
+    const int rc = pg_model_load(e->ctx, PG_MODEL_DNN3_MULTI, (pg_prec)prec, blob, len, &m);
+    if (rc != PG_OK) { g_ph_err = pg_last_error(); return rc; }
+    auto it = e->named_models.find(algo);
+    if (it != e->named_models.end()) pg_model_destroy(e->ctx, it->second);
+    e->named_models[algo] = m;
+    return 0;
+}
+
 // one DNN3 model per output of a multi-output rank algorithm: key "<algo>/<output>"
 int ph_engine_load_dnn3_named(void* h, const char* key, int prec, const char* blob, size_t len) {
     Engine* e = (Engine*)h;
     if (!e || !blob || !key) return -1;
+    VersionLock::Write w(e->version);
     pg_model* m = nullptr;
     const int rc = pg_model_load(e->ctx, PG_MODEL_DNN3, (pg_prec)prec, blob, len, &m);
     if (rc != PG_OK) { g_ph_err = pg_last_error(); return rc; }
@@ -1774,6 +1829,7 @@ int ph_engine_load_dnn3_named(void* h, const char* key, int prec, const char* bl
 int ph_engine_load_fm2t(void* h, int prec, const char* blob, size_t len) {
     Engine* e = (Engine*)h;
     if (!e || !blob) return -1;
+    VersionLock::Write w(e->version);
     e->DropCoalescers();                               // they hold the old model
     if (e->fm2t) { pg_model_destroy(e->ctx, e->fm2t); e->fm2t = nullptr; }
     const int rc = pg_model_load(e->ctx, PG_MODEL_FM_TWOTOWER, (pg_prec)prec, blob, len, &e->fm2t);
@@ -1791,6 +1847,10 @@ int ph_engine_load_fm2t(void* h, int prec, const char* blob, size_t len) {
 int ph_engine_set_feature_column(void* h, const char* name, const int32_t* values, uint64_t n) {
     Engine* e = (Engine*)h;
     if (!e || !name || !values || n != e->table_rows) { g_ph_err = "feature column: bad argument (one value per table row)"; return -1; }
+    // exclusive against every request (they hold the version lock shared from their first plug-in call to their last label
+    // lookup): the coalescers and views dropped here are not in use, and no request sees the column half-way.  A column
+    // that belongs to a NEW generation of the table goes through ph_engine_ingest_feature_column instead.
+    VersionLock::Write w(e->version);
     e->DropCoalescers();
     if (!e->feats && pg_features_create(e->ctx, e->table_rows, &e->feats) != PG_OK) { g_ph_err = pg_last_error(); return -1; }
     const int rc = pg_features_set_column(e->ctx, e->feats, name, PG_F_I32, values, 0.0);

@@ -448,6 +448,10 @@ public:
     pg_table* staging = nullptr;
     std::unique_ptr<IdDict> staging_dict;
     uint64_t staging_filled = 0;
+    // the row-keyed feature columns (WhereClause column, FM item fields) of the generation being loaded: they change over
+    // with the rows and the ids, inside the same exclusive section
+    pg_features* staging_feats = nullptr;
+    bool IngestFeatureColumn(const std::string& name, const int32_t* values, uint64_t n, std::string* err);
     bool IngestBegin(std::string* err);
     bool IngestChunk(const char* ids, size_t ids_bytes, const float* rows, uint64_t n, std::string* err);
     bool IngestCommit(std::string* err);

@@ -1,0 +1,151 @@
+"""GPU parity tests of the multi-output DNN3 (PG_MODEL_DNN3_MULTI): n_out heads on ONE shared trunk, one gather and one
+launch whatever n_out — the shape of the reference's own fixtures (EasyrecResponse.multiValModule,
+algorithm/eas/easyrec_response.go:35-70; the "<algo>_<output>" write-back of service/rank/rank_service.go:315-319; the
+RankScore of utils/ast/ast_test.go:90-129 over ppnet_probs_ctr / ppnet_probs_cvr).
+
+Bar: every head within the precision mode's tolerance of the oracle's single-output specification run with that head's
+column (fp32 2e-7, bf16 1e-5); in fp32 — and for head 0 in bf16 — BIT-identical to the single-output model on the device
+(same kernels, same summation order); the scene's page from ONE launch equal to the oracle pipeline's."""
+import numpy as np
+import pytest
+
+import pairec_amd as pa
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(128, 128), (256, 128), (256, 256), (512, 256), (1024, 512)]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def _pack(w):
+    return pa.pack_dnn3_multi(w.w1, w.b1, w.w2, w.b2, w.w3m, w.b3m, w.d_user)
+
+
+def _pack_head(w, hd):
+    h = w.head(hd)
+    return pa.pack_dnn3(h.w1, h.b1, h.w2, h.b2, h.w3, h.b3, h.d_user)
+
+
+@pytest.mark.parametrize("h1,h2", SHAPES)
+@pytest.mark.parametrize("prec,tol", [(0, 2e-7), (1, 1e-5)])
+def test_multihead_matches_oracle_and_single_head_models(ctx, h1, h2, prec, tol):
+    n, d = 40_000, 128
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    rng = np.random.default_rng(h1 + h2 + prec)
+    sizes = [5000, 1, 0, 333, 128, 129, 64, 65]                         # ragged, empty, tile-boundary requests
+    users = o.synth_rows(o.SEED_QUERY, 3, len(sizes), 128)
+    cands = [rng.integers(0, n, s_).astype(np.uint32) for s_ in sizes]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    for n_out in (2, 3, 8) if (h1, h2) == (512, 256) else (2, 5):
+        w = o.Dnn3MultiWeights(n_out, 128, 128, h1, h2, seed=o.SEED_WEIGHTS ^ (h1 * 3 + n_out))
+        m = pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, prec, _pack(w))
+        assert m.n_out == n_out
+        got = m.rank_dnn3(t, users, np.concatenate(cands), off)
+        assert got.shape == (n_out, int(off[-1]))
+        ref = np.concatenate([o.dnn3_multi_forward(w, prec, users[r], tab[cands[r]]) for r in range(len(sizes))], axis=1)
+        assert np.max(np.abs(got.astype(np.float64) - ref)) <= tol, (h1, h2, prec, n_out)
+        for hd in (0, n_out - 1):
+            single = pa.RankModel(ctx, pa.MODEL_DNN3, prec, _pack_head(w, hd))
+            one = single.rank_dnn3(t, users, np.concatenate(cands), off)
+            single.destroy()
+            if prec == 0 or hd == 0 or (h1, h2) != (512, 256):
+                # the same arithmetic in the same order as the single-output model (the weights-stationary bf16 kernel
+                # adds a wave's two column halves first for heads 1..: inside 1e-5)
+                assert np.array_equal(bits(got[hd]), bits(one)), (h1, h2, prec, n_out, hd)
+            else:
+                assert np.max(np.abs(got[hd] - one)) <= 2e-6
+        m.destroy()
+    t.destroy()
+
+
+def test_multihead_dim64_table_and_bad_blobs(ctx):
+    """d_item = 64 (the generic kernel's zero-padded layer 1), and the loader's refusals."""
+    n = 20_000
+    t = pa.Table(ctx, n, 64)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, 64)
+    w = o.Dnn3MultiWeights(3, 96, 64, 256, 128, seed=77)
+    rng = np.random.default_rng(9)
+    users = rng.standard_normal((3, 96)).astype(np.float32)
+    users /= np.linalg.norm(users, axis=1, keepdims=True)           # (the bf16 mode's 1e-5 is stated for normalised inputs)
+    sizes = [700, 0, 131]
+    cands = [rng.integers(0, n, s_).astype(np.uint32) for s_ in sizes]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    for prec, tol in ((0, 2e-7), (1, 1e-5)):
+        m = pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, prec, _pack(w))
+        got = m.rank_dnn3(t, users, np.concatenate(cands), off)
+        ref = np.concatenate([o.dnn3_multi_forward(w, prec, users[r], tab[cands[r]]) for r in range(3)], axis=1)
+        assert np.max(np.abs(got.astype(np.float64) - ref)) <= tol
+        m.destroy()
+    blob = _pack(w)
+    with pytest.raises(pa._lib.PgError):
+        pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, 0, blob[:-4])                     # one bias short
+    with pytest.raises(pa._lib.PgError):
+        pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, 0, blob[:16] + (9).to_bytes(4, "little") + blob[20:])   # 9 outputs
+    with pytest.raises(pa._lib.PgError):
+        pa.RankModel(ctx, pa.MODEL_DNN3, 0, blob)                                 # the single-output kind has another header
+    t.destroy()
+
+
+# the reference fixture's RankScore (utils/ast/ast_test.go:90-129) with the recall score where it reads ${log_price}
+RANK_SCORE = "(${ppnet_probs_ctr}+2*${ppnet_probs_cvr})*(1+${current_score})^0.1"
+
+
+def test_scene_with_two_output_model_one_launch(ctx):
+    """A scene whose RankAlgoList names ONE two-output algorithm "ppnet" (outputs probs_ctr, probs_cvr): per-request
+    rank calls return both planes; the coalesced recommend evaluates the fixture's expression over both outputs from a
+    single rank launch per batch and returns the oracle pipeline's page (fp32: ids exact)."""
+    import threading
+    n, d, k, top_n, callers = 90_000, 128, 300, 30, 64
+    t = pa.Table(ctx, n, d)
+    t.fill_synthetic(o.SEED_TABLE)
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    w = o.Dnn3MultiWeights(2)
+    m = pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, pa.PREC_F32, _pack(w))
+    ex = pa.Expr(RANK_SCORE)
+    co = pa.Coalescer(ctx, t, k, expr=ex, algos=[("ppnet", m, ["probs_ctr", "probs_cvr"])], max_top_n=top_n, max_rank_items=k)
+    q = o.synth_rows(o.SEED_QUERY, 11, callers, d)
+    # per-request rank (IAlgorithm.Run): both planes
+    rng = np.random.default_rng(3)
+    cand = rng.integers(0, n, 200).astype(np.uint32)
+    got = co.rank(0, q[0], cand)
+    ref = o.dnn3_multi_forward(w, 0, q[0], tab[cand])
+    assert got.shape == (2, 200) and np.max(np.abs(got.astype(np.float64) - ref)) <= 2e-7
+    st0 = ctx.stats().rank_calls
+    out = [None] * callers
+    errs = []
+
+    def call(i):
+        try:
+            out[i] = co.recommend(q[i], top_n)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=call, args=(i,)) for i in range(callers)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs[0]
+    stats = co.stats()
+    orow, osc = o.recall_topk(tab, q, k)
+    for i in range(0, callers, 7):
+        rk = o.dnn3_multi_forward(w, 0, q[i], tab[orow[i].astype(np.int64)])
+        fused = (o.widen_f32(rk[0]) + 2 * o.widen_f32(rk[1])) * (1 + o.widen_f32(osc[i])) ** 0.1
+        order = o.sort_scores(fused, True)[:top_n]
+        rows, rec, rnk, fus, cnt = out[i]
+        assert cnt == top_n and np.array_equal(rows, orow[i][order]), i
+        assert rnk.shape == (2, top_n)
+        assert np.max(np.abs(rnk.astype(np.float64) - rk[:, order])) <= 2e-7 and np.max(np.abs(fus - fused[order])) <= 1e-6
+    # one rank launch per recommend batch (not one per output): launches on both contexts <= batches
+    assert stats.batches[2] >= 1
+    co.destroy()
+    # an expression naming an output the model does not have is refused at creation
+    with pytest.raises(pa._lib.PgError):
+        pa.Coalescer(ctx, t, k, expr=pa.Expr("${ppnet_probs_xyz}"), algos=[("ppnet", m, ["probs_ctr", "probs_cvr"])], max_top_n=top_n)
+    assert ctx.stats().rank_calls >= st0
+    m.destroy()
+    t.destroy()
