@@ -229,8 +229,8 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         c.WhereClause = !r.s("WhereClause").empty() ? r.s("WhereClause") : r.at("HologresVectorConf").s("WhereClause");
         c.TimeInterval = (int)(r.n("TimeInterval") != 0 ? r.n("TimeInterval") : r.at("HologresVectorConf").n("TimeInterval"));
         if (!c.WhereClause.empty()) {
-            if (c.Kind != "hologres" && c.Kind != "hologres_v2") {
-                if (err) *err = "pairec_gpu.Recalls: " + c.Name + ": WhereClause is not supported by Kind \"" + c.Kind + "\" (Kinds hologres, hologres_v2 take one)";
+            if (c.Kind != "hologres" && c.Kind != "hologres_v2" && c.Kind != "online_hologres") {
+                if (err) *err = "pairec_gpu.Recalls: " + c.Name + ": WhereClause is not supported by Kind \"" + c.Kind + "\" (Kinds hologres, hologres_v2, online_hologres take one)";
                 return false;
             }
             if (!recall::ParseWhereClause(c.WhereClause, c.TimeInterval, &c.WhereColumn, &c.WhereOp, &c.WhereValue)) {
@@ -955,6 +955,79 @@ struct GpuOnlineVectorRecall : recall::Recall {
     }
 };
 
+// recall.Recall with the body of OnlineHologresVectorRecall.GetCandidateItems (online_hologres_vector_recall.go:105-237, result
+// cache omitted): the user's features → the vector model's USER TOWER on the device (the reference asks a PAI-EAS model for
+// EasyrecUserEmbResponse.GetUserEmb, :120-131, and keeps it in userVectorCache, :109-112,133) → the RecallCount rows of the
+// Hologres vector table with the largest inner product (`pm_approx_inner_product_distance(...) ORDER BY distance desc`, :27),
+// restricted by HologresVectorConf.WhereClause (:59-63) — Item.Score = distance, RetrieveId = the recall's name (:208-210).
+// The vector table is the engine's item-embedding table (UserDefineConfs.pairec_gpu.OnlineVector), the clause's column an
+// int32 feature column keyed by its rows.  One embedding per user (the reference splits GetUserEmb on "|" for multi-interest
+// models and gives every part RecallCount / parts rows, :188-196).
+struct GpuOnlineHologresVectorRecall : recall::Recall {
+    Engine* e;
+    recconf::RecallConfig conf;
+    struct CachedEmb { std::vector<float> v; std::chrono::steady_clock::time_point used; };
+    std::mutex mu;
+    std::map<std::string, CachedEmb> userVectorCache;              // cache.WithMaximumSize(10000), expire-after-access cacheTime + 10 s (:74-77)
+    GpuOnlineHologresVectorRecall(Engine* eng, recconf::RecallConfig c) : e(eng), conf(std::move(c)) {}
+    bool UserEmbedding(const std::string& uid, const std::vector<float>& uv, std::vector<float>* emb) {
+        const auto now = std::chrono::steady_clock::now();
+        const auto ttl = std::chrono::seconds(std::max(conf.CacheTime, 0) + 10);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = userVectorCache.find(conf.CachePrefix + uid);
+            if (it != userVectorCache.end() && now - it->second.used <= ttl) {
+                it->second.used = now;
+                *emb = it->second.v;
+                return true;
+            }
+        }
+        emb->assign(e->dim_item_emb(), 0.0f);
+        if (pg_fm2t_user_embedding(e->ctx, e->fm2t, uv.data(), 1, emb->data()) != PG_OK) return false;     // logged, empty (:123-125)
+        std::lock_guard<std::mutex> g(mu);
+        if (userVectorCache.size() >= 10000) userVectorCache.erase(userVectorCache.begin());
+        userVectorCache[conf.CachePrefix + uid] = CachedEmb{*emb, now};
+        return true;
+    }
+    std::vector<module::ItemPtr> GetCandidateItems(module::User* user, context::RecommendContext*) override {
+        std::vector<module::ItemPtr> ret;
+        std::string value, err;
+        if (!e->fm2t || !e->item_emb) return ret;                                                  // no model / vector table: logged, empty
+        if (!e->user_vectors.VectorString(user->Id, &value, &err)) return ret;
+        const std::vector<float> uv = recall::ParseVectorString(value);
+        const uint32_t k = (uint32_t)std::max(conf.RecallCount, 0);
+        if (k == 0 || uv.size() != e->fm2t_d_user) return ret;
+        std::vector<uint64_t> rows(k);
+        std::vector<float> dist(k);
+        uint32_t cnt = 0;
+        int rc;
+        if (conf.WhereOp >= 0) {
+            std::vector<float> emb;
+            if (!UserEmbedding(user->Id, uv, &emb)) return ret;
+            const Engine::FilterView* fv = e->ViewFor(conf, k, e->item_emb);
+            if (!fv || fv->empty) return ret;                   // unknown column: the SQL would fail (logged, empty); nothing admitted
+            if (fv->co) rc = pg_coalescer_recall(fv->co, emb.data(), rows.data(), dist.data(), &cnt);
+            else if (fv->view) rc = pg_recall_topk(e->ctx, fv->view, emb.data(), 1, k, rows.data(), dist.data(), &cnt);
+            else rc = pg_recall_topk_where(e->ctx, e->item_emb, e->feats, pg_features_column_index(e->feats, conf.WhereColumn.c_str()), conf.WhereOp,
+                                           conf.WhereValue, 0, emb.data(), 1, k, rows.data(), dist.data(), &cnt);
+        } else if (e->coalesce) {                               // tower + search of concurrent requests in one pass
+            pg_coalescer* co = e->OnlineCoalescer(k, &err);
+            if (!co) return ret;
+            rc = pg_coalescer_online_recall(co, uv.data(), rows.data(), dist.data(), &cnt);
+        } else {
+            rc = pg_online_vector_recall(e->ctx, e->fm2t, e->item_emb, uv.data(), 1, k, rows.data(), dist.data(), &cnt);
+        }
+        if (rc != PG_OK) return ret;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            auto item = std::make_shared<module::Item>(e->IdOfRow(rows[i]));
+            item->RetrieveId = conf.Name;
+            item->Score = (double)dist[i];
+            ret.push_back(item);
+        }
+        return ret;
+    }
+};
+
 // MockRecall (service/recall/mock_recall.go:27-41): recallCount random ids with random scores
 struct MockRecall : recall::Recall {
     recconf::RecallConfig conf;
@@ -1411,7 +1484,8 @@ void Engine::DropViewsLocked() {
 // recall was built (hologres_vector_recall.go:56-61), so the admitted set only changes with the table (ingest.cpp: a commit is
 // exclusive against every request, so no request sees two generations) or with the column (ph_engine_set_feature_column drops
 // the views).  nullptr: no feature column of that name (the SQL would fail).
-const Engine::FilterView* Engine::ViewFor(const recconf::RecallConfig& conf, uint32_t k) {
+const Engine::FilterView* Engine::ViewFor(const recconf::RecallConfig& conf, uint32_t k, const pg_table* base) {
+    if (!base) base = table;
     std::lock_guard<std::mutex> g(co_mu);
     const int col = feats ? pg_features_column_index(feats, conf.WhereColumn.c_str()) : -1;
     if (col < 0) return nullptr;
@@ -1422,7 +1496,7 @@ const Engine::FilterView* Engine::ViewFor(const recconf::RecallConfig& conf, uin
     if (fv.view) pg_table_destroy(ctx, fv.view);
     fv = FilterView();
     fv.generation = gen;
-    const int rc = pg_table_view_create(ctx, table, feats, col, conf.WhereOp, conf.WhereValue, &fv.view);
+    const int rc = pg_table_view_create(ctx, base, feats, col, conf.WhereOp, conf.WhereValue, &fv.view);
     if (rc == PG_ERR_EMPTY) { fv.empty = true; return &fv; }             // no row passes: every answer is empty
     // (PG_ERR_INVALID is a misconfiguration — a feature store shorter than the table, a bad operator: the per-call path below
     // reports it on every request instead of serving empty pages for the whole generation)
@@ -1532,6 +1606,7 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
     const json::Value& ov = g.at("OnlineVector");          // the vector model's item side: item-tower outputs as a table
     if (ov.type == json::Value::Object) {
         e->item_emb_rows = (uint64_t)ov.n("Rows", (long long)e->table_rows);
+        e->item_emb_dim = (uint32_t)ov.n("Dim", 64);
         if (pg_table_create(e->ctx, e->item_emb_rows, (uint32_t)ov.n("Dim", 64), 0, &e->item_emb) != PG_OK ||
             pg_table_fill_synthetic(e->ctx, e->item_emb, (uint64_t)ov.n("SyntheticSeed", 0x5EED0077), 1) != PG_OK) {
             if (err) *err = pg_err("online vector item table");
@@ -1583,6 +1658,7 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
         else if (r.Kind == "i2i") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuI2IVectorRecall>(e.get(), r));
         else if (r.Kind == "hologres_v2") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuHologresVectorRecall>(e.get(), r, true));
         else if (r.Kind == "hologres") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuHologresVectorRecall>(e.get(), r, false));
+        else if (r.Kind == "online_hologres") e->recalls.RegisterRecall(r.Name, std::make_shared<GpuOnlineHologresVectorRecall>(e.get(), r));
         else if (r.Kind == "page") {
             if (r.RankScore.empty() || r.RankVar.empty() || r.RecallCount <= 0) {
                 if (err) *err = "pairec_gpu.Recalls: Kind \"page\" needs RecallCount, RankScore and RankVar";

@@ -427,7 +427,9 @@ public:
         bool empty = false, failed = false;      // no row passes / the view could not be built (the per-call form serves)
     };
     std::map<std::string, FilterView> co_views;         // by recall name
-    const FilterView* ViewFor(const recconf::RecallConfig& conf, uint32_t k);
+    const FilterView* ViewFor(const recconf::RecallConfig& conf, uint32_t k, const pg_table* base = nullptr);   // base: the searched table (default: `table`)
+    uint32_t item_emb_dim = 0;
+    uint32_t dim_item_emb() const { return item_emb_dim; }
     void DropViewsLocked();
     pg_coalescer* SceneCoalescer(uint32_t k, std::string* err);
     pg_coalescer* OnlineCoalescer(uint32_t k, std::string* err);

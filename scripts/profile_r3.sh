@@ -6,12 +6,12 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_r3
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/callers" -o t -- python3 "$REPO/scripts/dev_callers.py" > "$OUT/callers.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5" -o t -- python3 "$REPO/scripts/dev_cfg5.py" > "$OUT/cfg5.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg4" -o t -- python3 "$REPO/scripts/dev_cfg4c.py" > "$OUT/cfg4.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/callers" -o t -- python3 "$REPO/scripts/dev/callers.py" > "$OUT/callers.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5" -o t -- python3 "$REPO/scripts/dev/cfg5.py" > "$OUT/cfg5.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg4" -o t -- python3 "$REPO/scripts/dev/cfg4c.py" > "$OUT/cfg4.log" 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --output-format csv -d "$OUT/cfg4_pmc_$name" -o pmc -- python3 "$REPO/scripts/dev_cfg4c.py" 20000000 > "$OUT/cfg4_pmc_$name.log" 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d "$OUT/cfg4_pmc_$name" -o pmc -- python3 "$REPO/scripts/dev/cfg4c.py" 20000000 > "$OUT/cfg4_pmc_$name.log" 2>&1
 done
 python3 - "$OUT" <<'PY'
 import sys, os, csv, glob, collections

@@ -631,8 +631,13 @@ def test_hologres_vector_recalls_with_a_where_clause(H):
     assert H.ph_engine_ingest_begin(h) == 0
     ids = b"".join(b"item_%d\0" % i for i in range(n))
     assert H.ph_engine_ingest_chunk(h, ids, len(ids), tab2.ctypes.data, n) == 0
+    # the generation brings its row-keyed columns along (they change over with the rows, inside the commit): category 7 moves again
+    H.ph_engine_ingest_feature_column.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+    cat3 = np.roll(cat, 4321)
+    assert H.ph_engine_ingest_feature_column(h, b"cat_id", cat3.ctypes.data, n) == 0
+    assert H.ph_engine_ingest_feature_column(h, b"create_time", create_time.ctypes.data, n) == 0
     assert H.ph_engine_ingest_commit(h) == 0
-    check("s_holo_cat", cat2 == 7, False, tab_=tab2)
+    check("s_holo_cat", cat3 == 7, False, tab_=tab2)
     check("s_holo_v2_recent", age < 86400, True, tab_=tab2)
     H.ph_engine_destroy(h)
     # Coalesce on: the view has a coalescer of its own; 48 requests from 16 threads per filtered recall
@@ -869,3 +874,152 @@ def test_http_harness_end_to_end():
     assert post({"size": 5})["code"] == 400
     srv.shutdown()
     h.close()
+
+
+def test_asttype_antlr_is_refused_at_load(H):
+    """RankConf.ASTType = "antlr" selects the valuate evaluator in the reference (GetExpASTWithType / ExprASTResultWithType,
+    utils/ast/ast.go:338-389; functions such as maxIndex, ast_test.go:267+).  The engine evaluates the default grammar only:
+    such a scene is an error at load — before any GPU work — never a silent evaluation by the other grammar.  Any other
+    ASTType value means the default AST in the reference too."""
+    import copy
+    cfg = copy.deepcopy(CONFIG)
+    cfg["RankConf"]["home_feed"]["ASTType"] = "antlr"
+    assert not H.ph_engine_create(json.dumps(cfg).encode())
+    msg = H.ph_last_error()
+    assert b'ASTType "antlr"' in msg and b"RankConf[home_feed]" in msg and b"utils/ast/ast.go:338-389" in msg
+
+
+@pytest.mark.gpu
+def test_multi_output_algorithm_on_one_shared_trunk(H):
+    """The same scene served by ONE two-output model (PG_MODEL_DNN3_MULTI, the trunk shared as in the exported PAI-EAS model
+    of easyrec_response.go:35-70): one pg_rank_dnn3 per batch writes both "<algo>_<output>" scores; an output list that
+    does not match the model is an error of the algorithm (the batch keeps its scores, rank_service.go:274-276)."""
+    import copy
+    import pairec_amd as pa
+    H.ph_engine_load_dnn3_multi.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+    cfg = copy.deepcopy(CONFIG)
+    cfg["UserDefineConfs"]["pairec_gpu"]["Algorithms"][1] = {"Name": "ppnet", "Kind": "dnn3", "Outputs": ["probs_ctr", "probs_cvr"]}
+    expr = "(${ppnet_probs_ctr}+2*${ppnet_probs_cvr})*(1+${current_score})^0.1"
+    cfg["RankConf"]["home_feed"] = {"RankAlgoList": ["ppnet"], "RankScore": expr, "BatchCount": 100}
+    h, _, user = _engine(H, cfg)
+    w = o.Dnn3MultiWeights(2, seed=o.SEED_WEIGHTS ^ 0x33)
+    blob = pa.pack_dnn3_multi(w.w1, w.b1, w.w2, w.b2, w.w3m, w.b3m, 128)
+    assert H.ph_engine_load_dnn3_multi(h, b"ppnet", pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+    out = json.loads(H.ph_recommend(h, b"u1", 40, b"home_feed"))["items"]
+    tab = o.synth_rows(o.SEED_TABLE, 0, 20000, 128)
+    rows, scores = o.recall_topk(tab, user[None], 300)
+    ref = o.dnn3_multi_forward(w, 0, user, tab[rows[0].astype(np.int64)])
+    fused = (o.widen_f32(ref[0]) + 2 * o.widen_f32(ref[1])) * (1 + o.widen_f32(scores[0])) ** 0.1
+    assert [x["item_id"] for x in out] == ["item_%d" % rows[0][i] for i in o.sort_scores(fused, True)[:40]]
+    pos = {"item_%d" % r: i for i, r in enumerate(rows[0])}
+    for x in out:
+        i = pos[x["item_id"]]
+        a, b = x["algo_scores"]["ppnet_probs_ctr"], x["algo_scores"]["ppnet_probs_cvr"]
+        assert abs(a - ref[0][i]) <= 2e-7 and abs(b - ref[1][i]) <= 2e-7 and "ppnet" not in x["algo_scores"]
+        assert abs(x["score"] - (a + 2 * b) * (1 + float(scores[0][i])) ** 0.1) <= 1e-12
+    # three heads behind a two-output algorithm: the algorithm errs, the items keep no ppnet scores (RankScore then reads 0)
+    w3 = o.Dnn3MultiWeights(3)
+    blob = pa.pack_dnn3_multi(w3.w1, w3.b1, w3.w2, w3.b2, w3.w3m, w3.b3m, 128)
+    assert H.ph_engine_load_dnn3_multi(h, b"ppnet", pa.PREC_F32, blob, len(blob)) == 0
+    out = json.loads(H.ph_recommend(h, b"u1", 10, b"home_feed"))["items"]
+    assert all("ppnet_probs_ctr" not in x["algo_scores"] for x in out)
+    H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
+def test_online_hologres_vector_recall(H):
+    """OnlineHologresVectorRecall (service/recall/online_hologres_vector_recall.go:105-237): the user's features → the vector
+    model's user embedding → the RecallCount rows of the Hologres vector table with the largest inner product, restricted by
+    HologresVectorConf.WhereClause; Item.Score = distance, RetrieveId = the recall's name.  Kind "online_hologres": the user
+    tower runs on the device, the vector table is the engine's item-embedding table, the clause a feature column."""
+    import copy
+    import pairec_amd as pa
+    H.ph_engine_load_fm2t.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    H.ph_engine_set_feature_column.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+    n = 20000
+    for coalesce in (False, True):
+        cfg = copy.deepcopy(CONFIG)
+        g = cfg["UserDefineConfs"]["pairec_gpu"]
+        g["OnlineVector"] = {"Rows": n, "Dim": 64, "SyntheticSeed": o.SEED_TABLE ^ 0x77}
+        if coalesce:
+            g["Coalesce"] = {"MaxWaitUs": 200}
+        g["Recalls"] += [{"Name": "oh_all", "Kind": "online_hologres", "RecallCount": 90},
+                         {"Name": "oh_cat", "Kind": "online_hologres", "RecallCount": 90,
+                          "HologresVectorConf": {"WhereClause": "cat_id = 3"}},
+                         {"Name": "oh_nocol", "Kind": "online_hologres", "RecallCount": 90, "WhereClause": "missing > 1"}]
+        for name in ("oh_all", "oh_cat", "oh_nocol"):
+            cfg["SceneConfs"]["s_" + name] = {"default": {"RecallNames": [name]}}
+        h, _, user = _engine(H, cfg)
+        fw = o.Fm2tWeights(vocab=500)
+        blob = pa.pack_fm2t(fw)
+        assert H.ph_engine_load_fm2t(h, pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+        rng = np.random.default_rng(12)
+        cat = rng.integers(0, 8, n).astype(np.int32)
+        assert H.ph_engine_set_feature_column(h, b"cat_id", cat.ctypes.data, n) == 0, H.ph_last_error()
+        emb = o.synth_rows(o.SEED_TABLE ^ 0x77, 0, n, 64)
+        ue = o.fm2t_user_embedding(fw, 0, user)
+        # unfiltered: the whole vector table
+        out = json.loads(H.ph_recommend(h, b"u1", 90, b"s_oh_all"))["items"]
+        orow, osc = o.recall_topk(emb, ue[None], 90)
+        assert [x["item_id"] for x in out] == ["item_%d" % r for r in orow[0]]
+        assert [x["score"] for x in out] == [float(s_) for s_ in osc[0]] and {x["retrieve_id"] for x in out} == {"oh_all"}
+        # WHERE cat_id = 3: the oracle on the admitted rows alone; asked twice (the second answer comes from the user-embedding cache)
+        keep = np.nonzero(cat == 3)[0]
+        frow, fsc = o.recall_topk(emb[keep], ue[None], 90)
+        for _ in range(2):
+            out = json.loads(H.ph_recommend(h, b"u1", 90, b"s_oh_cat"))["items"]
+            assert [x["item_id"] for x in out] == ["item_%d" % keep[r] for r in frow[0]]
+            assert [x["score"] for x in out] == [float(s_) for s_ in fsc[0]] and {x["retrieve_id"] for x in out} == {"oh_cat"}
+        # an unknown column: the reference's SQL fails — logged, empty list
+        assert json.loads(H.ph_recommend(h, b"u1", 90, b"s_oh_nocol"))["items"] == []
+        H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
+def test_feature_columns_change_over_with_the_table_generation(H):
+    """A new generation of the table brings its own row-keyed feature columns (ph_engine_ingest_feature_column between begin
+    and commit): rows, ids and columns change over in ONE exclusive section, so a `WhereClause` never reads the previous
+    generation's column against the new rows; a generation that brings none while the engine serves columns is refused."""
+    import copy
+    H.ph_engine_set_feature_column.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+    H.ph_engine_ingest_begin.argtypes = [C.c_void_p]
+    H.ph_engine_ingest_chunk.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint64]
+    H.ph_engine_ingest_feature_column.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+    H.ph_engine_ingest_commit.argtypes = [C.c_void_p]
+    H.ph_ingest_last_error.restype = C.c_char_p
+    n = 20000
+    cfg = copy.deepcopy(CONFIG)
+    g = cfg["UserDefineConfs"]["pairec_gpu"]
+    g["Coalesce"] = {"MaxWaitUs": 200}
+    g["Recalls"].append({"Name": "holo_cat", "Kind": "hologres", "RecallCount": 60, "WhereClause": "cat_id = 2"})
+    cfg["SceneConfs"]["s_cat"] = {"default": {"RecallNames": ["holo_cat"]}}
+    h, _, user = _engine(H, cfg)
+    rng = np.random.default_rng(21)
+    tab_a = o.synth_rows(o.SEED_TABLE, 0, n, 128)
+    cat_a = rng.integers(0, 5, n).astype(np.int32)
+    assert H.ph_engine_set_feature_column(h, b"cat_id", cat_a.ctypes.data, n) == 0
+
+    def page():
+        return json.loads(H.ph_recommend(h, b"u1", 60, b"s_cat"))["items"]
+
+    def want(tab, cat, prefix):
+        keep = np.nonzero(cat == 2)[0]
+        r, s_ = o.recall_topk(tab[keep], user[None], 60)
+        return sorted("%s%d" % (prefix, keep[i]) for i in r[0])
+    assert sorted(x["item_id"] for x in page()) == want(tab_a, cat_a, "item_")
+    # generation B: other rows, other ids, another column
+    tab_b = o.synth_rows(o.SEED_TABLE ^ 0x5, 0, n, 128)
+    cat_b = rng.integers(0, 5, n).astype(np.int32)
+    ids_b = b"".join(b"b%d\0" % i for i in range(n))
+    assert H.ph_engine_ingest_begin(h) == 0
+    assert H.ph_engine_ingest_chunk(h, ids_b, len(ids_b), tab_b.ctypes.data, n) == 0
+    assert H.ph_engine_ingest_commit(h) != 0 and b"must bring its own" in H.ph_ingest_last_error()      # no column staged
+    assert sorted(x["item_id"] for x in page()) == want(tab_a, cat_a, "item_")                           # still generation A, whole
+    assert H.ph_engine_ingest_feature_column(h, b"cat_id", cat_b.ctypes.data, n) == 0, H.ph_ingest_last_error()
+    assert H.ph_engine_ingest_commit(h) == 0, H.ph_ingest_last_error()
+    assert sorted(x["item_id"] for x in page()) == want(tab_b, cat_b, "b")
+    # an id buffer with a NUL inside an id is refused (it would shift every later id by a row)
+    assert H.ph_engine_ingest_begin(h) == 0
+    bad = b"x\0y\0" + b"".join(b"c%d\0" % i for i in range(n - 1))
+    assert H.ph_engine_ingest_chunk(h, bad, len(bad), tab_b.ctypes.data, n) != 0 and b"more than one id per row" in H.ph_ingest_last_error()
+    H.ph_engine_destroy(h)
