@@ -131,8 +131,15 @@ constexpr int kDppTile = 64, kDppKc = 16;
 // contiguous bytes per row and instruction).  Every element is its own k-ascending fma chain, as the specification
 // wants it; S is symmetric bit for bit (a product commutes), L is not — L_ij = (r_i S_ij) r_j and L_ji = (r_j S_ij) r_i
 // are both formed from the one S_ij.
-__global__ __launch_bounds__(64) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
-                                                               uint32_t n, uint32_t d1, uint32_t nt, double* __restrict__ L) {
+// Round 4 — where the "missing 70 %" was (profiles/r4_dpp_pmc_summary.txt): with `__launch_bounds__(64)` alone the compiler
+// took 496 registers (256 + 240 AGPRs as spill space), i.e. ONE wave per SIMD, and every chunk's panel loads were issued
+// and awaited at the top of the chunk: a wave lived 127 K cycles for 33 K cycles of fma — 38 K of them waiting for the
+// global loads (SQ_WAIT_ANY), most of the rest LDS-read latency with no second wave to cover it.  Now two waves per SIMD
+// (`__launch_bounds__(64, 2)`: <= 256 registers) and the next chunk's 32 values per lane are requested BEFORE the current
+// chunk's 1 024 fma (va / vb are dead during the fma block: the prefetch costs no register).  (Tried: chunks of 8
+// columns double-buffered in LDS — 0.70 ms against 0.52: a row's 64-B segments fetch every 128-B line twice.)
+__global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
+                                                                  uint32_t n, uint32_t d1, uint32_t nt, double* __restrict__ L) {
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) double sa[kDppKc][kDppTile + 2];      // [k][row], rows padded to a 16-B multiple
     __shared__ __attribute__((aligned(16))) double sb[kDppKc][kDppTile + 2];
@@ -153,16 +160,25 @@ __global__ __launch_bounds__(64) void dpp_kernel_matrix_kernel(const double* __r
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
-    for (uint32_t k0 = 0; k0 < d1; k0 += kDppKc) {
-        const uint32_t kc = d1 - k0 < (uint32_t)kDppKc ? d1 - k0 : (uint32_t)kDppKc;
-        double va[16], vb[16];
+    double va[16], vb[16];
+    // (unconditional loads from clamped addresses — 32-bit byte offsets on the request's base —: rows past n only feed
+    // accumulators that are never written, columns past d1 are never multiplied; predicated loads compiled into 32
+    // branches per chunk and spilled their addresses)
+    const char* const Fb = reinterpret_cast<const char*>(Fq);
+    auto load_panels = [&](uint32_t k0) {
+        const uint32_t kcol = (k0 + kk < d1 ? k0 + kk : d1 - 1) * 8u;
+        const uint32_t rowb = d1 * 8u;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const uint32_t row = (uint32_t)it * 4 + rr;
-            const uint32_t ri = i0 + row, rj = j0 + row;
-            va[it] = (ri < n && kk < kc) ? Fq[(size_t)ri * d1 + k0 + kk] : 0.0;
-            vb[it] = (rj < n && kk < kc) ? Fq[(size_t)rj * d1 + k0 + kk] : 0.0;
+            const uint32_t ri = i0 + row < n ? i0 + row : n - 1, rj = j0 + row < n ? j0 + row : n - 1;
+            va[it] = *reinterpret_cast<const double*>(Fb + (ri * rowb + kcol));
+            vb[it] = *reinterpret_cast<const double*>(Fb + (rj * rowb + kcol));
         }
+    };
+    load_panels(0);
+    for (uint32_t k0 = 0; k0 < d1; k0 += kDppKc) {
+        const uint32_t kc = d1 - k0 < (uint32_t)kDppKc ? d1 - k0 : (uint32_t)kDppKc;
         __syncthreads();                                       // the previous step's readers are done
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -170,6 +186,7 @@ __global__ __launch_bounds__(64) void dpp_kernel_matrix_kernel(const double* __r
             sb[kk][it * 4 + rr] = vb[it];
         }
         __syncthreads();
+        if (k0 + kDppKc < d1) load_panels(k0 + kDppKc);        // in flight under this chunk's fma
         for (uint32_t k = 0; k < kc; ++k) {
             f64x2 av[4], bv[4];
 #pragma unroll

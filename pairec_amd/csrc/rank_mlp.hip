@@ -841,6 +841,7 @@ struct RankScratch {
     uint32_t *tile_req, *tile_item0, *tile_cnt, *n_tiles, *req_tile0;
     float* c1;       // [n_req][h1]  (DNN3) or uo [n_req][to] (two-tower)
     float* fm_user;  // [n_req][kFmUserStride]
+    float* sink;     // [1024] write-only
 };
 
 static int rank_scratch(pg_ctx* ctx, uint32_t n_req, uint32_t max_tiles, uint32_t per_req_floats,
@@ -848,7 +849,7 @@ static int rank_scratch(pg_ctx* ctx, uint32_t n_req, uint32_t max_tiles, uint32_
     void* p;
     int rc;
     const size_t ints = (size_t)3 * max_tiles + 64 + n_req;
-    const size_t bytes = ints * 4 + ((size_t)n_req * per_req_floats + (size_t)n_req * kFmUserStride) * 4 + 256;
+    const size_t bytes = ints * 4 + ((size_t)n_req * per_req_floats + (size_t)n_req * kFmUserStride) * 4 + 256 + 8192;
     if ((rc = scratch_reserve(ctx, 6, bytes, &p))) return rc;
     uint32_t* u = (uint32_t*)p;
     rs->tile_req = u;
@@ -858,6 +859,7 @@ static int rank_scratch(pg_ctx* ctx, uint32_t n_req, uint32_t max_tiles, uint32_
     rs->req_tile0 = rs->n_tiles + 64;
     rs->c1 = (float*)(rs->req_tile0 + n_req);
     rs->fm_user = rs->c1 + (size_t)n_req * per_req_floats;
+    rs->sink = rs->fm_user + (size_t)n_req * kFmUserStride + 16;     // 1 024 floats nobody reads (rank_ir.hip's always-issued stores)
     return PG_OK;
 }
 
@@ -1039,7 +1041,9 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
                                 uint32_t n_req, uint32_t n_items, float* d_out, const pg_item_rows* ir = nullptr,
                                 const uint32_t* d_cand = nullptr) {
     if (n_items == 0 || n_req == 0) return PG_OK;
-    const uint32_t bm = m->prec ? (uint32_t)kFmBM : (uint32_t)kBM;
+    // the benchmark's shape over item records: the stationary-weights kernel (rank_ir.hip), 64-item tiles
+    const bool irs = ir && !ctx->knobs.rank_no_ws && fm2t_irs_shape(m->th, m->to, m->k, m->nif, m->prec);
+    const uint32_t bm = irs ? (uint32_t)kIrsItems : (m->prec ? (uint32_t)kFmBM : (uint32_t)kBM);
     const uint32_t max_tiles = n_items / bm + n_req;
     RankScratch rs;
     int rc;
@@ -1075,7 +1079,12 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     a.w1p = m->w1p;
     a.w2p = m->w2p;
     a.out = d_out;
-    if ((rc = dispatch_fm2t_mlp(ctx, m, a, max_tiles))) return rc;
+    a.sink = rs.sink;
+    if (irs) {
+        if ((rc = launch_fm2t_irs(ctx, a))) return rc;
+    } else if ((rc = dispatch_fm2t_mlp(ctx, m, a, max_tiles))) {
+        return rc;
+    }
     PG_HIP(hipGetLastError());
     PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->rank_timing_pending = true;

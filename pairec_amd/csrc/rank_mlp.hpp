@@ -89,6 +89,7 @@ struct MlpArgs {
     const void* w1p;
     const void* w2p;
     float* out;
+    float* sink;                     // >= 1024 floats nobody reads (fm2t_irs_kernel's always-issued stores)
 };
 
 template <int PREC>
@@ -149,5 +150,11 @@ int launch_dnn3_rs(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
 // ... and the eight-wave streamed-weights kernel for 1024-512; 128-item tiles
 bool dnn3_ls_shape(uint32_t h1, uint32_t h2);
 int launch_dnn3_ls(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
+
+// rank_ir.hip: FM + two-tower over materialised item records for the benchmark's shape (towers 256-64, 8 fields x 16, bf16):
+// weights stationary in registers, records two tiles ahead; 64-item tiles
+constexpr int kIrsItems = 64;
+bool fm2t_irs_shape(uint32_t th, uint32_t to, uint32_t k, uint32_t nif, int prec);
+int launch_fm2t_irs(pg_ctx* ctx, const MlpArgs& a);
 
 }  // namespace pg

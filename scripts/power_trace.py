@@ -65,12 +65,26 @@ def sample_smi():
         return {"power_w": None, "sclk_mhz": None, "mclk_mhz": None, "temp_c": None}
 
 
+def tool_snapshot():
+    """What the vendor tools say right now (gpu_metrics: current / average socket power, current gfx clocks per XCD) —
+    slower to call than sysfs (~1 s), so only every few seconds, from a side thread."""
+    out = {}
+    for name, cmd in (("amd_smi", ["amd-smi", "metric", "--power", "--clock", "--json"]),
+                      ("rocm_smi", ["rocm-smi", "--showpower", "--showclocks", "--json"])):
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=20)
+            out[name] = json.loads(r.stdout) if r.stdout.strip().startswith(("{", "[")) else r.stdout[-1500:]
+        except Exception as e:                          # noqa: BLE001
+            out[name] = "unavailable: %s" % e
+    return out
+
+
 def pct(v, p):
     v = sorted(x for x in v if x is not None)
     return v[min(len(v) - 1, int(p * len(v)))] if v else None
 
 
-def run_phase(name, bench_args, hw, period, settle, out_rows):
+def run_phase(name, bench_args, hw, period, settle, out_rows, snap_after=None):
     env = dict(os.environ)
     proc = None
     if bench_args is not None:
@@ -78,6 +92,23 @@ def run_phase(name, bench_args, hw, period, settle, out_rows):
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
     t0 = time.time()
     samples = []
+    snaps = []
+    stop = [False]
+
+    def snapper():
+        time.sleep(snap_after)
+        while not stop[0]:
+            sn = tool_snapshot()
+            sn["t"] = time.time() - t0
+            snaps.append(sn)
+            for _ in range(10):
+                if stop[0]:
+                    break
+                time.sleep(0.1)
+    import threading
+    th = threading.Thread(target=snapper, daemon=True)
+    if proc is not None and snap_after is not None:
+        th.start()
     while True:
         s_ = sample_sysfs(hw) if hw else sample_smi()
         s_["t"] = time.time() - t0
@@ -89,6 +120,7 @@ def run_phase(name, bench_args, hw, period, settle, out_rows):
         elif proc.poll() is not None:
             break
         time.sleep(period)
+    stop[0] = True
     line = None
     if proc is not None:
         out = proc.stdout.read()
@@ -101,6 +133,23 @@ def run_phase(name, bench_args, hw, period, settle, out_rows):
     res = {"samples": len(keep), "power_w": {k: pct([x["power_w"] for x in keep], q) for k, q in (("p10", .1), ("median", .5), ("p90", .9))},
            "sclk_mhz": {k: pct([x["sclk_mhz"] for x in keep], q) for k, q in (("p10", .1), ("median", .5), ("p90", .9))},
            "temp_c": pct([x["temp_c"] for x in keep], .5)}
+    if snaps:
+        # amd-smi's gpu_metrics view is the one that tracks the load (on this box the hwmon files above sit at their idle
+        # values whatever runs): socket power and the eight XCDs' gfx clocks per snapshot
+        pw, clk = [], []
+        for sn in snaps:
+            try:
+                g0 = sn["amd_smi"]["gpu_data"][0] if isinstance(sn["amd_smi"], dict) else sn["amd_smi"][0]
+                pw.append(float(g0["power"]["socket_power"]["value"]))
+                cl = [float(v["clk"]["value"]) for k, v in g0["clock"].items() if k.startswith("gfx_") and isinstance(v.get("clk"), dict)]
+                if cl:
+                    clk.append(sum(cl) / len(cl))
+            except Exception:                           # noqa: BLE001
+                pass
+        keep_n = max(1, int(len(pw) * 0.6))
+        res["amd_smi"] = {"snapshots": len(pw), "socket_power_w": pw, "mean_gfx_clk_mhz": clk,
+                          "socket_power_w_median_late": pct(pw[-keep_n:], .5), "mean_gfx_clk_mhz_median_late": pct(clk[-keep_n:], .5)}
+        res["last_tool_snapshot"] = snaps[-1]
     if line:
         res["bench"] = {"value": line["value"], "ms_per_step": line["ms_per_step"], "dtype": line["dtype"],
                         "requests_per_step": line["config"]["requests_per_step"],
@@ -111,8 +160,9 @@ def run_phase(name, bench_args, hw, period, settle, out_rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r4_power"))
-    ap.add_argument("--period", type=float, default=0.02)
-    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--period", type=float, default=0.1)
+    ap.add_argument("--steps", type=int, default=10000, help="timed steps of the 256-request phase (~4.2 ms each): the SMU's "
+                    "telemetry is a slow moving average, a phase has to run for tens of seconds before it settles")
     ap.add_argument("--rows", type=int, default=100_000_000)
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -121,13 +171,13 @@ def main():
             "--no-rank-shapes", "--no-f32-leg", "--no-live-traffic"]
     rows = []
     summary = {"_how": "scripts/power_trace.py: hwmon sysfs (%s) sampled every %.0f ms while a child bench.py runs its timed region; "
-                       "per phase the last 40 %% of the samples (the timed region)" % (hw or "rocm-smi --json fallback", a.period * 1e3),
+                       "per phase the last 40 %% of the samples (the timed region); tool_snapshots = amd-smi / rocm-smi read every ~5 s from a side thread" % (hw or "rocm-smi --json fallback", a.period * 1e3),
                "power_cap_w": (read_int(os.path.join(hw, "power1_cap")) or 0) / 1e6 if hw else None,
                "power_cap_max_w": (read_int(os.path.join(hw, "power1_cap_max")) or 0) / 1e6 if hw else None}
     summary["idle"] = run_phase("idle", None, hw, a.period, 1.0, rows)
-    summary["headline_256_requests_bf16"] = run_phase("r256", base + ["--steps", str(a.steps)], hw, a.period, 0.4, rows)
-    summary["headline_64_requests_bf16"] = run_phase("r64", base + ["--steps", str(a.steps * 3 // 2), "--batch", "64"], hw, a.period, 0.4, rows)
-    summary["headline_256_requests_f32_rank"] = run_phase("r256f32", base + ["--steps", str(a.steps // 3), "--prec", "f32"], hw, a.period, 0.4, rows)
+    summary["headline_256_requests_bf16"] = run_phase("r256", base + ["--steps", str(a.steps)], hw, a.period, 0.4, rows, snap_after=12.0)
+    summary["headline_64_requests_bf16"] = run_phase("r64", base + ["--steps", str(a.steps * 3 // 2), "--batch", "64"], hw, a.period, 0.4, rows, snap_after=12.0)
+    summary["headline_256_requests_f32_rank"] = run_phase("r256f32", base + ["--steps", str(a.steps // 3), "--prec", "f32"], hw, a.period, 0.4, rows, snap_after=12.0)
     with open(os.path.join(a.out, "power_trace.json"), "w") as f:
         json.dump(summary, f, indent=1)
     with open(os.path.join(a.out, "power_trace_samples.csv"), "w") as f:
