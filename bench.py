@@ -198,6 +198,47 @@ def measure_traffic_live(args, R):
     return int(total), detail
 
 
+def measure_kernel_traffic(script_args, kernel_substr, tail=8):
+    """HBM bytes per launch of one kernel, measured now: two child runs of a small driver script under `rocprofv3 --pmc`
+    (FETCH_SIZE, WRITE_SIZE — one counter per run, no trace domains, the program directly behind `--`); FETCH_SIZE (KB) x 1024
+    x 2 per the gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE (KB) x 1024; mean over the kernel's last `tail`
+    dispatches.  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ):
+        return None, "this run is itself being profiled: no nested rocprofv3"
+    total, detail = 0.0, {}
+    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+        d = tempfile.mkdtemp(prefix="pg_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", "python3"] + script_args
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited with %d" % (counter, r.returncode)
+            v = []
+            for p_ in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(p_)):
+                    if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
+                        v.append((int(row.get("Dispatch_Id", 0)), float(row.get("Counter_Value", 0) or 0)))
+            if not v:
+                return None, "no %s rows for %s" % (counter, kernel_substr)
+            v.sort()
+            t_ = [x[1] for x in v[-tail:]]
+            b = sum(t_) / len(t_) * scale
+            detail["%s_bytes" % counter.lower()] = int(b)
+            total += b
+        except Exception as e:                      # noqa: BLE001 — the measurement is optional
+            return None, "%s: %s" % (type(e).__name__, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(total), detail
+
+
 def scan_kernel_name(R, dim, elem_bytes):
     """The kernel recall.hip dispatches for the full-table pass at this batch size (dispatch_screen):
     screen_kernel<DIM, NQB, WAVES, SPLIT, VAR, I8, QH, L2> (L2 = 0: inner product)."""
@@ -402,6 +443,34 @@ def run_headline(pa, ctx, table, model, expr, qs_dev, args, R, K, sync, extra_ct
     elapsed = time.perf_counter() - t0
     gc.enable()
     return pipe, elapsed, pipe.scan_ms
+
+
+def headline_spot_check(o, pipe, table, w, prec, queries_of_last_step, K):
+    """One request of the LAST timed batch against the oracle (the checker, outside the timed region): the recall scores of
+    the returned rows bit for bit (the oracle's dot products of the rows gathered from the table), the model scores within
+    the precision mode's tolerance, the fused scores to 1e-12 relative and the ItemRankScore order = the oracle's sort of
+    the device's own fused scores."""
+    b = pipe.bufs[(pipe.issued - 1) % pipe.depth]
+    ctx = pipe.ctx
+    rows, rec, rnk = np.zeros(K, np.uint64), np.zeros(K, np.float32), np.zeros(K, np.float32)
+    fus, order = np.zeros(K, np.float64), np.zeros(K, np.uint32)
+    for a_, p_ in ((rows, b[0]), (rec, b[1]), (rnk, b[2]), (fus, b[3]), (order, b[4])):
+        ctx.d2h(a_, p_)
+    q0 = queries_of_last_step[0]
+    emb = table.gather(rows.astype(np.uint32))
+    want_rec = o.dot_scores(emb, q0[None])[0]
+    want_rnk = o.dnn3_forward(w, 1 if prec == "bf16" else 0, q0, emb)
+    want_fus = o.widen_f32(rnk) * (1 + o.widen_f32(rec)) ** 0.1
+    tol = 1e-5 if prec == "bf16" else 2e-7
+    res = {"request": "request 0 of the last timed batch, %d candidates" % K,
+           "recall_scores_bit_exact": bool(np.array_equal(rec.view(np.uint32), want_rec.view(np.uint32))),
+           "recall_sorted": bool(np.all(np.diff(rec.astype(np.float64)) <= 0)),
+           "rank_max_abs_err": float(np.max(np.abs(rnk.astype(np.float64) - want_rnk))), "rank_tolerance": tol,
+           "fused_max_rel_err": float(np.max(np.abs(fus - want_fus) / np.maximum(np.abs(want_fus), 1e-300))),
+           "order_equals_oracle_sort": bool(np.array_equal(order, o.sort_scores(fus, True)))}
+    res["ok"] = bool(res["recall_scores_bit_exact"] and res["recall_sorted"] and res["rank_max_abs_err"] <= tol and
+                     res["fused_max_rel_err"] <= 1e-12 and res["order_equals_oracle_sort"])
+    return res
 
 
 class LoadgenResult(C.Structure):
@@ -879,9 +948,12 @@ def cfg4_leg(pa, o, ctx, R, K):
         "per_field_path": {"device_ms_per_step": per_field_ms, "value": n / (per_field_ms * 1e-3),
                            "note": "pg_rank_fm2t_dev: 8 ids + 8 scattered 64-B embedding rows per item (1056 B of HBM traffic)"},
         "concurrent_callers": callers,
-        "roofline": {"bound": "hbm", "kernel": "pg::mlp_kernel<1,256,64,false,2,2,3,...> (FM + item tower over materialised item records)",
+        "roofline": {"bound": "hbm", "kernel": "pg::fm2t_irs_kernel (FM + item tower over materialised item records: LDS-DMA three tiles "
+                                                "ahead, weights stationary in registers, producer / consumer waves)",
                      "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                      "bytes_per_item": FM2T_BYTES_PER_ITEM, "traffic": None,
+                     "ms_basis": "device_ms_per_step = HIP events around the whole rank stage (tile table + user tower / FM prefix "
+                                 "kernel + the rank kernel); the rank kernel alone is kernel_ms_from_profile",
                      # the materialised record is five 128-B lines (544 B used)
                      "hbm_bytes_per_item_moved": 640,
                      "frac_on_bytes_moved": n * 640 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -1221,6 +1293,7 @@ def main():
         predicted0 = sum(c_.stats().recall_predicted for c_ in [ctx] + extra_ctxs)
         rescans0 = sum(c_.stats().recall_rescans for c_ in [ctx] + extra_ctxs)
         pipe, elapsed, scan_ms = run_headline(pa, ctx, table, model, expr, d_qs, args, R, K, sync, extra_ctxs)
+        spot = headline_spot_check(o, pipe, table, w, args.prec, qs[(total_steps - 1) % len(qs)], K) if rank == 0 else None
         predicted_batches = sum(c_.stats().recall_predicted for c_ in [ctx] + extra_ctxs) - predicted0
         rescans = sum(c_.stats().recall_rescans for c_ in [ctx] + extra_ctxs) - rescans0
         if extra_ctxs:
@@ -1286,6 +1359,7 @@ def main():
                                    if world > 1 else "1 GPU")},
         "roofline": roofline_block(table, R, args, end - begin, scan_avg_ms, measured_gbs, ctx.last_scan_kernel()[1]),
         "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},
+        "oracle_spot_check": None if shard else spot,
         "rank_roofline": {"bound": "mfma", "kernel": "pg::dnn3_ws_kernel",
                           "achieved": rank_items * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
                           "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -1387,6 +1461,14 @@ def main():
         out["roofline"]["traffic_detail"] = detail
         if tb:
             out["roofline"]["traffic_over_streamed_bytes"] = tb / out["roofline"]["bytes_per_pass"]
+        # ... and cfg 4's rank kernel: HBM bytes per launch of 1.28 M items (scripts/dev/cfg4_prof.py under rocprofv3 --pmc)
+        c4 = out.get("other_configs", {}).get("cfg4")
+        if c4:
+            tb4, det4 = measure_kernel_traffic([os.path.join(ROOT, "scripts", "dev", "cfg4_prof.py"), "random"], "fm2t_irs_kernel")
+            c4["roofline"]["traffic"] = tb4
+            c4["roofline"]["traffic_detail"] = det4
+            if tb4:
+                c4["roofline"]["traffic_bytes_per_item"] = tb4 / (R * K)
     if rank == 0:
         out["device"] = device_info()
         if solo and not args.no_cpu_baseline:

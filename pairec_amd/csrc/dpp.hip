@@ -131,14 +131,15 @@ constexpr int kDppTile = 64, kDppKc = 16;
 // contiguous bytes per row and instruction).  Every element is its own k-ascending fma chain, as the specification
 // wants it; S is symmetric bit for bit (a product commutes), L is not — L_ij = (r_i S_ij) r_j and L_ji = (r_j S_ij) r_i
 // are both formed from the one S_ij.
-// Round 4 — where the "missing 70 %" was (profiles/r4_dpp_pmc_summary.txt): with `__launch_bounds__(64)` alone the compiler
-// took 496 registers (256 + 240 AGPRs as spill space), i.e. ONE wave per SIMD, and every chunk's panel loads were issued
-// and awaited at the top of the chunk: a wave lived 127 K cycles for 33 K cycles of fma — 38 K of them waiting for the
-// global loads (SQ_WAIT_ANY), most of the rest LDS-read latency with no second wave to cover it.  Now two waves per SIMD
-// (`__launch_bounds__(64, 2)`: <= 256 registers) and the next chunk's 32 values per lane are requested BEFORE the current
-// chunk's 1 024 fma (va / vb are dead during the fma block: the prefetch costs no register).  (Tried: chunks of 8
-// columns double-buffered in LDS — 0.70 ms against 0.52: a row's 64-B segments fetch every 128-B line twice.)
-__global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
+// Round 4 (profiles/r4_dpp_pmc_summary.txt): with `__launch_bounds__(64)` the compiler takes 496 registers, i.e. ONE wave
+// per SIMD, and the old kernel issued and awaited every chunk's panel loads at the top of the chunk: a wave lived 127 K cycles
+// for 33 K cycles of fma, 38 K of them waiting for those loads (SQ_WAIT_ANY).  Now the next chunk's 32 values per lane are
+// requested BEFORE the current chunk's 1 024 fma (va / vb are dead during the fma block) from clamped, unconditional
+// addresses (predicated loads compiled into 32 branches per chunk): 521 -> 456 us per 256 x 500 x 129.  Tried and dropped:
+// two waves per SIMD (`__launch_bounds__(64, 2)`: 256 registers, spills in the loop — 700 us); 8-column chunks
+// double-buffered in LDS (700 us: a row's 64-B segments fetch every 128-B line twice); the operands of step k + 1 read
+// before the fma of step k (466 us: no gain — VALU 38 % and LDS 25 % busy, the wave is latency-bound with nobody to cover).
+__global__ __launch_bounds__(64) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
                                                                   uint32_t n, uint32_t d1, uint32_t nt, double* __restrict__ L) {
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) double sa[kDppKc][kDppTile + 2];      // [k][row], rows padded to a 16-B multiple

@@ -1337,7 +1337,10 @@ def test_full_size_pipeline_properties(ctx):
         generator), every row whose key beats the K-th returned key is in the answer;
     (d) batching invariance: a query alone / in a batch of 128 / in the batch of 256 gets the same answer;
     (e) rank + fusion + sort over all 1.28 M candidates: a sample of scores within tolerance of the
-        oracle, the per-request order equal to the oracle's sort of the device's own scores."""
+        oracle, the per-request order equal to the oracle's sort of the device's own scores;
+    (f) the plan `bench.py` times: once the table's threshold model has observed 1 024 verified queries it predicts the
+        first thresholds (plan 0) — four more batches train it, then the SAME 256 queries on predicted thresholds return
+        the pilot plan's answer bit for bit, and a fresh batch passes the exactness and completeness checks."""
     n, d, k, R = 100_000_000, 128, 5000, 256
     t = pa.Table(ctx, n, d)
     t.fill_synthetic(o.SEED_TABLE)
@@ -1400,6 +1403,29 @@ def test_full_size_pipeline_properties(ctx):
     sorted_scores = np.take_along_axis(fs, order.reshape(R, k).astype(np.int64), axis=1)
     assert np.all(np.diff(sorted_scores, axis=1) <= 0)
     m.destroy()
+    # (f) plan 0 at full size
+    p0 = ctx.stats().recall_predicted
+    for b in range(5):
+        t.recall_topk(o.synth_rows(o.SEED_QUERY, 1000 + 256 * b, R, d), k)      # other users: 1 280 more verified queries
+    rows2, scores2, cnt2 = t.recall_topk(q, k)
+    assert ctx.stats().recall_predicted > p0, "the threshold model never predicted: plan 0 was not exercised"
+    assert np.array_equal(rows2, rows) and np.array_equal(bits(scores2), bits(scores)) and cnt2.tolist() == [k] * R
+    qn = o.synth_rows(o.SEED_QUERY, 5000, R, d)
+    p1 = ctx.stats().recall_predicted
+    rows3, scores3, cnt3 = t.recall_topk(qn, k)
+    assert ctx.stats().recall_predicted > p1 and cnt3.tolist() == [k] * R
+    for r in (0, 200):
+        want = o.dot_scores(t.gather(rows3[r].astype(np.uint32)), qn[r:r + 1])[0]
+        assert np.array_equal(bits(scores3[r]), bits(want))
+    lo = int(rng.integers(0, n - 1_000_000))
+    sl = o.synth_rows(o.SEED_TABLE, lo, 1_000_000, d)
+    qs = [1, 100, 255]
+    sc = o.dot_scores(sl, qn[qs])
+    for j, r in enumerate(qs):
+        kth_s, kth_row = scores3[r, -1], int(rows3[r, -1])
+        s = sc[j]
+        better = np.nonzero((s > kth_s) | ((s == kth_s) & (np.arange(lo, lo + len(s)) < kth_row)))[0] + lo
+        assert np.all(np.isin(better, rows3[r])), (lo, r)
     t.destroy()
 
 
