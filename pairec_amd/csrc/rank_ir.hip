@@ -49,7 +49,8 @@ constexpr size_t kIrRaw = 4 * kIrWaveRaw;                       // 36 KiB per ra
 constexpr size_t kIrXT = (size_t)kIrsItems * kDIN * 2;          // 16 KiB
 constexpr size_t kIrH1 = (size_t)kIrsItems * kIrTH * 2;         // 32 KiB
 constexpr size_t kIrH2 = (size_t)kIrsItems * kIrHS * 4;         // 17 KiB per H2 tile
-constexpr size_t ir_lds_bytes() { return 2 * kIrRaw + 2 * kIrXT + kIrH1 + kIrH2 + (size_t)kIrSlots * kIrSlotF * 4 + kIrTO * 4; }
+constexpr size_t kIrMeta = 4 * 2 * 64 * 4 + 16;                   // per producer wave two slots of 64 dwords: rows + next descriptor; head flags
+constexpr size_t ir_lds_bytes() { return 2 * kIrRaw + 2 * kIrXT + kIrH1 + kIrH2 + (size_t)kIrSlots * kIrSlotF * 4 + kIrTO * 4 + kIrMeta; }
 static_assert(ir_lds_bytes() <= 160 * 1024, "fm2t_irs_kernel: LDS budget");
 
 struct IrTile {
@@ -96,11 +97,18 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
     float* const H2T = reinterpret_cast<float*>(H1T + kIrH1);               // H2 tile
     float* const ring = H2T + kIrsItems * kIrHS;                            // [slot]: b3s[64] | w3s[64] | fus[48]
     float* const b2s = ring + kIrSlots * kIrSlotF;                          // ib2[64]
+    const uint32_t* const meta = reinterpret_cast<const uint32_t*>(b2s + kIrTO);   // [producer][2][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS byte address of smem
     const uint32_t lds_ring = lds0 + (uint32_t)(2 * kIrRaw + 2 * kIrXT + kIrH1 + kIrH2);
+    const uint32_t lds_meta = lds_ring + (uint32_t)(kIrSlots * kIrSlotF * 4 + kIrTO * 4);
+    // [2]: the trips whose H2 tile waves 6 / 7 have read (explicitly an LDS pointer: a volatile generic one compiles to flat
+    // accesses, each behind a vmcnt(0))
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    lds_vu32* const hflag = reinterpret_cast<lds_vu32*>((__attribute__((address_space(3))) char*)smem + (2 * kIrRaw + 2 * kIrXT + kIrH1 + kIrH2 +
+                                                        kIrSlots * kIrSlotF * 4 + kIrTO * 4 + 4 * 2 * 64 * 4));
     const uint32_t n_tiles = *a.n_tiles;
     const uint32_t t_begin = (uint32_t)(((uint64_t)n_tiles * blockIdx.x) / gridDim.x);
     const uint32_t t_end = (uint32_t)(((uint64_t)n_tiles * (blockIdx.x + 1)) / gridDim.x);
@@ -133,6 +141,7 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
     }
     asm volatile("" : "+v"(c1v[0]), "+v"(c1v[1]));
     if (tid < kIrTO) b2s[tid] = a.b2[tid];
+    if (tid < 2) hflag[tid] = 0;
     // (the loads above are ordinary ones: their wait belongs here, not at their first use inside the loop, where the
     // compiler would repeat a vmcnt(0) on every trip)
 #pragma unroll
@@ -140,12 +149,14 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks) asm volatile("" : "+v"(w2r[ks]));
 
-    // ---- scalar side (producers): tile descriptors and the wave's sixteen candidate rows of a tile (the tables were written by
-    // earlier launches; through the CONSTANT address space they come by scalar loads, which the vector-memory counter does
-    // not see)
+    // ---- tile descriptors and candidate rows (producers).  In the loop they arrive like everything else — by LDS-DMA, a
+    // tile before they are needed, counted in the same queue: ONE `global_load_lds_dword` per wave and tile brings the wave's
+    // candidate rows of tile T (every lane its own record's row; the four lanes of a record fetch the same dword) and, in
+    // lanes 1..3, tile T + 1's descriptor, into the wave's meta slot.  (Scalar loads here cost the producers two dependent
+    // round trips per tile with nothing to overlap them: 1 200 of a tile's 6 400 cycles.)  Only the prologue reads the
+    // tables through the scalar cache.
     typedef const __attribute__((address_space(4))) uint32_t* cu32p;
     const cu32p k_req = (cu32p)(uintptr_t)a.tile_req, k_item0 = (cu32p)(uintptr_t)a.tile_item0, k_cnt = (cu32p)(uintptr_t)a.tile_cnt;
-    const cu32p k_cand = (cu32p)(uintptr_t)a.cand_rows;
     const int pw = wave & 3;                                // producer index of waves 4..7
     auto desc = [&](uint32_t t) {
         const uint32_t tc = t < t_end ? t : t_end - 1;      // (past the range: a valid entry, cnt forced to 0)
@@ -153,61 +164,49 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
         if (t >= t_end) d.cnt = 0;
         return d;
     };
-    struct Rows {                                           // (named scalars: an array here becomes an indexed stack object,
-        uint32_t r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;   // i.e. a scratch load per tile)
+    // index into cand_rows of this lane's record of tile d (a request's last tile: clamped to its last candidate)
+    auto cand_index = [&](const IrTile& d, uint32_t l_) {
+        const uint32_t it = (uint32_t)pw * 16 + (l_ >> 2), last = d.cnt ? d.cnt - 1 : 0u;
+        return d.item0 + (it < last ? it : last);
     };
-    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-    auto load_rows = [&](const IrTile& d) {
-        if ((uint32_t)pw * 16 + 16 <= d.cnt) {              // the usual case: sixteen consecutive candidates, ONE scalar load
-            const u32x16 v = *reinterpret_cast<const __attribute__((address_space(4))) u32x16*>(k_cand + d.item0 + (uint32_t)pw * 16);
-            return Rows{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
-        }
-        const uint32_t last = d.cnt ? d.cnt - 1 : 0u;       // a request's last tile: indices clamped one by one
-        auto one = [&](uint32_t i) {
-            const uint32_t it = (uint32_t)pw * 16 + i;
-            return (uint32_t)k_cand[d.item0 + (it < last ? it : last)];  // (no arithmetic on the value here: its first use is the wait)
-        };
-        return Rows{one(0), one(1), one(2), one(3), one(4), one(5), one(6), one(7), one(8), one(9), one(10), one(11), one(12), one(13),
-                    one(14), one(15)};
+    // the meta DMA: rows of tile d (lanes 0, 4.., and their duplicates), descriptor of tile `tn` (lanes 1..3) -> meta slot
+    auto meta_issue = [&](uint32_t tn, const IrTile& d, uint32_t slot) {
+        uint32_t l_ = (uint32_t)lane;
+        asm volatile("" : "+v"(l_));
+        const uint32_t tc = tn < t_end ? tn : t_end - 1;
+        const uint32_t* p = a.cand_rows + cand_index(d, l_);
+        p = l_ == 1 ? a.tile_req + tc : p;
+        p = l_ == 2 ? a.tile_item0 + tc : p;
+        p = l_ == 3 ? a.tile_cnt + tc : p;
+        ir_dma4(p, lds_meta + (uint32_t)((pw * 2 + slot) * 64 * 4));
     };
     // ---- the DMAs of one tile into raw slot `sl` (records) and ring slot `rs` (wave 4: FM prefix, wave 5: tower output)
-    auto issue = [&](const IrTile& d, const Rows& w, uint32_t sl, uint32_t rs) {
+    auto issue = [&](uint32_t req, uint32_t rowA, uint32_t rowB, uint32_t rowC, uint32_t sl, uint32_t rs) {
         uint32_t l_ = (uint32_t)lane;
         asm volatile("" : "+v"(l_));                        // (per-lane values re-derived per tile: carried across the loop they are spilled)
         if (wave == 4) {
             // fus[L]: L < 16 the prefix's s, < 32 its q, 32 its linear part (lanes up to 47 land in the slot's padding)
             const uint32_t fi = l_ < 16 ? 1 + l_ : (l_ < 32 ? 1 + kFmMaxK + (l_ - 16) : 0u);
-            if (l_ < 48) ir_dma4(a.fm_user + (size_t)d.req * kFmUserStride + fi, lds_ring + (rs * kIrSlotF + kIrsItems + kIrTO) * 4);
+            if (l_ < 48) ir_dma4(a.fm_user + (size_t)req * kFmUserStride + fi, lds_ring + (rs * kIrSlotF + kIrsItems + kIrTO) * 4);
         } else if (wave == 5) {
-            ir_dma4(a.w3 + (size_t)d.req * a.w3_stride + l_, lds_ring + (rs * kIrSlotF + kIrsItems) * 4);
+            ir_dma4(a.w3 + (size_t)req * a.w3_stride + l_, lds_ring + (rs * kIrSlotF + kIrsItems) * 4);
         }
-        // this lane's record: row w.r<lane / 4> — the sixteen scalars go to lanes 0, 4, .., 60 of a register and every lane
-        // fetches its group leader's (a select chain here is rewritten by the compiler into an indexed stack object)
-        int rv = 0;
-        asm volatile("v_writelane_b32 %0, %1, 0" : "+v"(rv) : "s"(w.r0));
-        asm volatile("v_writelane_b32 %0, %1, 4" : "+v"(rv) : "s"(w.r1));
-        asm volatile("v_writelane_b32 %0, %1, 8" : "+v"(rv) : "s"(w.r2));
-        asm volatile("v_writelane_b32 %0, %1, 12" : "+v"(rv) : "s"(w.r3));
-        asm volatile("v_writelane_b32 %0, %1, 16" : "+v"(rv) : "s"(w.r4));
-        asm volatile("v_writelane_b32 %0, %1, 20" : "+v"(rv) : "s"(w.r5));
-        asm volatile("v_writelane_b32 %0, %1, 24" : "+v"(rv) : "s"(w.r6));
-        asm volatile("v_writelane_b32 %0, %1, 28" : "+v"(rv) : "s"(w.r7));
-        asm volatile("v_writelane_b32 %0, %1, 32" : "+v"(rv) : "s"(w.r8));
-        asm volatile("v_writelane_b32 %0, %1, 36" : "+v"(rv) : "s"(w.r9));
-        asm volatile("v_writelane_b32 %0, %1, 40" : "+v"(rv) : "s"(w.r10));
-        asm volatile("v_writelane_b32 %0, %1, 44" : "+v"(rv) : "s"(w.r11));
-        asm volatile("v_writelane_b32 %0, %1, 48" : "+v"(rv) : "s"(w.r12));
-        asm volatile("v_writelane_b32 %0, %1, 52" : "+v"(rv) : "s"(w.r13));
-        asm volatile("v_writelane_b32 %0, %1, 56" : "+v"(rv) : "s"(w.r14));
-        asm volatile("v_writelane_b32 %0, %1, 60" : "+v"(rv) : "s"(w.r15));
-        const uint32_t j = l_ & 3;
-        uint32_t row = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l_ & ~3u) * 4), rv);
-        row = row < a.irow_count ? row : a.irow_count;                      // (outside the store: the defaults' record)
-        const char* const rec = reinterpret_cast<const char*>(a.irows) + (size_t)row * (kItemRowFloats * 4) + j * 16;
+        // Records go out as whole 128-B lines: EIGHT adjacent lanes per record and instruction (an instruction touches 8 lines
+        // instead of 16 half lines — the address path's cost is per line: 0.260 -> 0.219 ms), two passes of eight records x
+        // the four lines of embeddings; the fifth line's two quads of linear weights with four lanes per record, sixteen
+        // records at once.  The wave's raw share is then: piece 4 p + i = line i of records 8 p .. 8 p + 7 (record g at
+        // g * 128), piece 8 the linear quads (record r at r * 64)
+        auto clampr = [&](uint32_t r) { return r < a.irow_count ? r : a.irow_count; };   // (outside the store: the defaults' record)
+        const uint32_t jj = l_ & 7;
+        const char* const recA = reinterpret_cast<const char*>(a.irows) + (size_t)clampr(rowA) * (kItemRowFloats * 4) + jj * 16;
+        const char* const recB = reinterpret_cast<const char*>(a.irows) + (size_t)clampr(rowB) * (kItemRowFloats * 4) + jj * 16;
         const uint32_t dst = lds0 + sl * (uint32_t)kIrRaw + (uint32_t)pw * (uint32_t)kIrWaveRaw;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) ir_dma16(rec + f * 64, dst + f * 1024);
-        if (j < 2) ir_dma16(rec + kDIN * 4, dst + 8 * 1024);
+        for (int i = 0; i < 4; ++i) ir_dma16(recA + i * 128, dst + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ir_dma16(recB + i * 128, dst + (4 + i) * 1024);
+        const uint32_t j = l_ & 3;
+        if (j < 2) ir_dma16(reinterpret_cast<const char*>(a.irows) + (size_t)clampr(rowC) * (kItemRowFloats * 4) + kDIN * 4 + j * 16, dst + 8 * 1024);
     };
     // ---- raw slot `sl` (this thread's own pieces) -> X tile and FM terms of the tile; the ring slot holds its request's FM prefix
     auto convert = [&](uint32_t sl, uint32_t rs, char* XT) {
@@ -215,11 +214,13 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
         asm volatile("" : "+v"(t_));
         const int j = t_ & 3;
         const int r = (int)((t_ - 256) >> 2);
-        const char* const wraw = RAW0 + sl * kIrRaw + (size_t)pw * kIrWaveRaw + (t_ & 63) * 16;
+        const char* const wbase = RAW0 + sl * kIrRaw + (size_t)pw * kIrWaveRaw;
+        const uint32_t rw = (t_ & 63) >> 2;                  // record within the wave: its lines were fetched in pass rw / 8, group rw % 8
+        const char* const wraw = wbase + (rw >> 3) * 4096 + (rw & 7) * 128 + j * 16;
         float4 e[8];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) e[f] = *reinterpret_cast<const float4*>(wraw + f * 1024);
-        const float4 lq = *reinterpret_cast<const float4*>(wraw + 8 * 1024);            // (lanes 0 / 1 of the record)
+        for (int f = 0; f < 8; ++f) e[f] = *reinterpret_cast<const float4*>(wraw + (f >> 1) * 1024 + (f & 1) * 64);
+        const float4 lq = *reinterpret_cast<const float4*>(wbase + 8 * 1024 + (t_ & 63) * 16);   // (lanes 0 / 1 of the record)
         const float* fu = ring + rs * kIrSlotF + kIrsItems + kIrTO;
         // the eight chains of this lane (s and q of four columns), two columns per instruction (v_pk_add_f32 / v_pk_fma_f32:
         // the same IEEE operations per element, in the same order)
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
     };
     // ---- the head of a tile whose H2 tile / FM terms / tower output are in LDS (waves 6, 7: two threads per item).  The
     // store is issued by every lane for every tile: items past the tile's count (and the odd lanes) write to the sink
-    auto head = [&](const IrTile& d, uint32_t rs) {
+    auto head = [&](const IrTile& d, uint32_t rs, uint32_t signal) {
         uint32_t t_ = (uint32_t)tid;
         asm volatile("" : "+v"(t_));
         const uint32_t u = t_ - 384;
@@ -269,6 +270,11 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
             x[m] = hr[m];
             y[m] = wr[m];
         }
+        // the H2 tile may be overwritten once these reads have executed: the LDS serves a wave's accesses in order, so a
+        // flag written behind them says so (the consumers check it before layer 2's stores, see the loop)
+        asm volatile("" ::: "memory");
+        if (signal && (t_ & 63) == 0) hflag[(t_ >> 6) - 6] = signal;
+        asm volatile("" ::: "memory");
         float p = half ? 0.0f : ring[rs * kIrSlotF + row];
 #pragma unroll
         for (int m = 0; m < kIrTO / 8; ++m) {
@@ -285,31 +291,36 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
     auto ring_add = [](uint32_t s, uint32_t k) { const uint32_t x = s + k; return x >= (uint32_t)kIrSlots ? x - kIrSlots : x; };
 
     // ---- prologue (producers).  Tile t_begin synchronously through raw slot t_begin & 1; then tiles + 1 and + 2 in flight
-    // with the event sequence the loop's counted waits assume: [DMAs of + 1] [waves 6 / 7: one store] [DMAs of + 2].  No
-    // scalar state is carried across iterations (a copied descriptor is a wait for its load): every iteration re-reads the
-    // descriptors it needs from the (cached) tile table, early enough
+    // with the event sequence the loop's counted waits assume: [DMAs of + 1] [waves 6 / 7: one store] [meta] [DMAs of + 2].
+    // The descriptors of tiles t - 1 .. t + 3 travel through the loop as wave-uniform values (dA .. d3), shifted per trip
     uint32_t s6 = t_begin % kIrSlots;                       // ring slot of tile t
-    IrTile d3{0, 0, 0};                                     // (producers) the tile whose DMAs go out in the coming second half, and
-    Rows w3{};                                              // its rows
+    IrTile dA{0, 0, 0}, dB{0, 0, 0}, dC{0, 0, 0}, dD{0, 0, 0}, d3{0, 0, 0};
+    uint32_t r0[3] = {0, 0, 0}, r1[3] = {0, 0, 0}, r2[3] = {0, 0, 0};
     if (wave >= 4) {
-        const IrTile d0 = desc(t_begin);
-        const Rows w0 = load_rows(d0);
-        issue(d0, w0, t_begin & 1, s6);
+        dB = desc(t_begin);
+        dC = desc(t_begin + 1);
+        dD = desc(t_begin + 2);
+        d3 = desc(t_begin + 3);
+        dA = dB;
+        dA.cnt = 0;                                         // (first trip's head: nothing to finish, all lanes to the sink)
+        uint32_t l_ = (uint32_t)lane;
+        asm volatile("" : "+v"(l_));
+        // (lane l's three records of a tile: l / 8 and 8 + l / 8 for the line passes, l / 4 for the linear quads)
+        const uint32_t la = (l_ >> 3) * 4, lb = 32 + (l_ >> 3) * 4;
+        r0[0] = a.cand_rows[cand_index(dB, la)]; r0[1] = a.cand_rows[cand_index(dB, lb)]; r0[2] = a.cand_rows[cand_index(dB, l_)];
+        r1[0] = a.cand_rows[cand_index(dC, la)]; r1[1] = a.cand_rows[cand_index(dC, lb)]; r1[2] = a.cand_rows[cand_index(dC, l_)];
+        r2[0] = a.cand_rows[cand_index(dD, la)]; r2[1] = a.cand_rows[cand_index(dD, lb)]; r2[2] = a.cand_rows[cand_index(dD, l_)];
+        issue(dB.req, r0[0], r0[1], r0[2], t_begin & 1, s6);
         ir_wait_vm<0>();
     }
     ir_barrier();                                           // the FM prefix (wave 4's DMA)
     if (wave >= 4) {
         convert(t_begin & 1, s6, XT0 + (t_begin & 1) * kIrXT);
-        const IrTile d1 = desc(t_begin + 1);
-        const Rows w1 = load_rows(d1);
-        issue(d1, w1, (t_begin + 1) & 1, ring_add(s6, 1));
+        issue(dC.req, r1[0], r1[1], r1[2], (t_begin + 1) & 1, ring_add(s6, 1));
         if (wave >= 6) a.sink[128 + (tid - 384)] = 0.0f;
-        const IrTile d2 = desc(t_begin + 2);
-        const Rows w2 = load_rows(d2);
-        issue(d2, w2, t_begin & 1, ring_add(s6, 2));
-        if (wave == 4) ir_wait_vm<19>();                    // tile t_begin + 1's FM prefix, before the first barrier A
-        d3 = desc(t_begin + 3);
-        w3 = load_rows(d3);
+        meta_issue(t_begin + 4, d3, (t_begin + 1) & 1);     // rows of tile + 3, descriptor of tile + 4: read in the first trip
+        issue(dD.req, r2[0], r2[1], r2[2], t_begin & 1, ring_add(s6, 2));
+        if (wave == 4) ir_wait_vm<20>();                    // tile t_begin + 1's FM prefix, before the first barrier A
     }
 
 #ifdef PG_IR_PROFILE
@@ -362,20 +373,15 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
             IR_MARK(1)
         } else {
             // ---- producers, first half: this wave's share of tile t + 1's records (DMA'd three tiles ago) -> the other X tile
-            // and the FM terms — ten events stand behind those DMAs in the wave's queue (tile t + 2's issue group, and for
-            // waves 6 / 7 one store in front of it) —, then waves 6 / 7 finish tile t - 1 (first trip: count 0, all to the sink)
-            ir_wait_vm<10>();
+            // and the FM terms — eleven events stand behind those DMAs in the wave's queue (waves 6 / 7: the head's store, the
+            // meta DMA, tile t + 2's nine record DMAs; waves 4 / 5: the meta DMA and ten DMAs)
+            ir_wait_vm<11>();
             IR_MARK(4)
             convert((t + 1) & 1, ring_add(s6, 1), XT0 + ((t + 1) & 1) * kIrXT);
             IR_MARK(5)
-            if (wave >= 6) {
-                IrTile dp = desc(t > t_begin ? t - 1 : t_begin);
-                if (t == t_begin) dp.cnt = 0;
-                head(dp, s6 == 0 ? kIrSlots - 1 : s6 - 1);
-            }
             IR_MARK(1)
         }
-        ir_barrier();                                       // B: H1 complete; H2 (tile t - 1) consumed
+        ir_barrier();                                       // B: H1 complete
         IR_MARK(2)
         if (wave < 4) {
             // ---- consumers: layer 2 of tile t, output block (mb2, nb2) -> fp32 H2 tile
@@ -388,12 +394,23 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
             const int row = mb2 * 32 + i32;
             const char* const h1r = H1T + row * (kIrTH * 2);
             bf16x8 af[4];                                   // three steps ahead: this chain's MFMAs are dependent, its reads are not
+            uint32_t hf0 = 0, hf1 = 0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const bf16x8*>(h1r + (((i * 2 + h) ^ sw) << 4));
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
                 if (ks + 3 < KS2) af[(ks + 3) & 3] = *reinterpret_cast<const bf16x8*>(h1r + ((((ks + 3) * 2 + h) ^ sw) << 4));
+                if (ks == KS2 - 4) {                       // (behind the last fragment read: the answer is there when the MFMAs end)
+                    hf0 = hflag[0];
+                    hf1 = hflag[1];
+                }
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2r[ks], af[ks & 3], acc2, 0, 0, 0);
+            }
+            // tile t - 1's head (waves 6 / 7, at the start of this same half) reads the H2 tile these stores overwrite: it has
+            // signalled long before layer 2's MFMAs end — checked, not assumed
+            while (hf0 < t - t_begin + 1 || hf1 < t - t_begin + 1) {
+                hf0 = hflag[0];
+                hf1 = hflag[1];
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -401,18 +418,30 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
                     make_float4(acc2[4 * g + 0], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3]);
             IR_MARK(3)
         } else {
-            // ---- producers, second half: the raw slot just converted goes out again for tile t + 3 (its reads were this
-            // thread's own and have returned: the conversion consumed them)
+            // ---- producers, second half.  Waves 6 / 7 first finish tile t - 1 (head: its H2 tile is overwritten by this
+            // half's layer 2 — at its end, behind the flag the head sets; first trip: count 0, all lanes to the sink).  Then the
+            // meta slot written a trip ago (nine events or more behind it: tile t + 2's issue group) gives this lane's rows of
+            // tile t + 3 and tile t + 4's descriptor; the next meta DMA goes out, then tile t + 3's records into the raw slot
+            // just converted (its reads were this wave's own and have returned: the conversion consumed them)
+            ir_wait_vm<9>();
             IR_MARK(3)
-            issue(d3, w3, (t + 1) & 1, ring_add(s6, 3));
+            if (wave >= 6) head(dA, s6 == 0 ? kIrSlots - 1 : s6 - 1, t - t_begin + 1);
+            IR_MARK(1)
+            uint32_t l_ = (uint32_t)lane;
+            asm volatile("" : "+v"(l_));
+            const uint32_t* const mb = meta + (pw * 2 + ((t + 1) & 1)) * 64;
+            const uint32_t rowA = mb[(l_ >> 3) * 4], rowB = mb[32 + (l_ >> 3) * 4], rowC = mb[l_ & ~3u];
+            IrTile d4{(uint32_t)__builtin_amdgcn_readfirstlane((int)mb[1]), (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[2]),
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[3])};
+            if (t + 4 >= t_end) d4.cnt = 0;
+            meta_issue(t + 5, d4, t & 1);
+            issue(d3.req, rowA, rowB, rowC, (t + 1) & 1, ring_add(s6, 3));
             IR_MARK(6)
-            // wave 4: the FM prefix of tile t + 2 (DMA'd two tiles ago) must have landed before barrier A, behind which every
-            // producer reads it.  Behind it in this wave's queue: the 9 record DMAs of its own issue group and the 10 just issued
-            if (wave == 4) ir_wait_vm<19>();
-            // the next trip's descriptor and rows (tile t + 4): two dependent scalar round trips, taken here where the
-            // producers have slack, so that nothing scalar is pending in their first half
-            d3 = desc(t + 4);
-            w3 = load_rows(d3);
+            // wave 4: the FM prefix of tile t + 2 (DMA'd a trip ago) must have landed before barrier A, behind which every
+            // producer reads it.  Behind it in this wave's queue: the 9 record DMAs of its own issue group, this trip's meta DMA
+            // and the 10 just issued
+            if (wave == 4) ir_wait_vm<20>();
+            dA = dB; dB = dC; dC = dD; dD = d3; d3 = d4;
         }
         s6 = ring_add(s6, 1);
     }
@@ -424,7 +453,7 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
 #endif
     // the head of the last tile (its H2 tile was written in the last phase 2)
     ir_barrier();
-    if (wave >= 6) head(desc(t_end - 1), s6 == 0 ? kIrSlots - 1 : s6 - 1);
+    if (wave >= 6) head(dA, s6 == 0 ? kIrSlots - 1 : s6 - 1, 0);
     ir_wait_vm<0>();                                        // (DMAs of tiles past the range are still landing in this workgroup's LDS)
 }
 

@@ -717,6 +717,35 @@ __global__ void dnn3_user_partial_kernel(const float* __restrict__ user, uint32_
     c1[(size_t)r * h1 + j] = acc;
 }
 
+// the FM prefix of a request (user fields first in the specification's sums), one workgroup beside the tower's
+__device__ __forceinline__ void fm2t_user_prefix(uint32_t r, uint32_t tid, const float* const* __restrict__ field_emb,
+                                                 const float* const* __restrict__ field_lin,
+                                                 const int32_t* __restrict__ user_field_ids, uint32_t vocab, float fm_b,
+                                                 float* __restrict__ fm_user, uint32_t nuf, uint32_t fk) {
+    if (!user_field_ids) return;
+    if (tid < fk) {
+        float s = 0.0f, q = 0.0f;
+        for (uint32_t f = 0; f < nuf; ++f) {
+            int32_t id = user_field_ids[(size_t)r * nuf + f];
+            id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
+            const float v = field_emb[f][(size_t)id * fk + tid];
+            s = s + v;
+            q = __fmaf_rn(v, v, q);
+        }
+        fm_user[(size_t)r * kFmUserStride + 1 + tid] = s;
+        fm_user[(size_t)r * kFmUserStride + 1 + kFmMaxK + tid] = q;
+    }
+    if (tid == 64) {
+        float lin = fm_b;
+        for (uint32_t f = 0; f < nuf; ++f) {
+            int32_t id = user_field_ids[(size_t)r * nuf + f];
+            id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
+            lin = lin + field_lin[f][id];
+        }
+        fm_user[(size_t)r * kFmUserStride] = lin;
+    }
+}
+
 // two-tower request side: user tower output uo[r][t_out] and the user prefix of the FM sums.
 __global__ __launch_bounds__(256) void fm2t_user_kernel(
     const float* __restrict__ user, uint32_t du, const float* __restrict__ uw1,
@@ -728,28 +757,7 @@ __global__ __launch_bounds__(256) void fm2t_user_kernel(
     __shared__ float us[4096];
     const uint32_t r = blockIdx.x, tid = threadIdx.x;
     if (blockIdx.y == 1) {                       // the FM prefix of the request, beside the tower (its own workgroup)
-        if (!user_field_ids) return;
-        if (tid < fk) {
-            float s = 0.0f, q = 0.0f;
-            for (uint32_t f = 0; f < nuf; ++f) {
-                int32_t id = user_field_ids[(size_t)r * nuf + f];
-                id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
-                const float v = field_emb[f][(size_t)id * fk + tid];
-                s = s + v;
-                q = __fmaf_rn(v, v, q);
-            }
-            fm_user[(size_t)r * kFmUserStride + 1 + tid] = s;
-            fm_user[(size_t)r * kFmUserStride + 1 + kFmMaxK + tid] = q;
-        }
-        if (tid == 64) {
-            float lin = fm_b;
-            for (uint32_t f = 0; f < nuf; ++f) {
-                int32_t id = user_field_ids[(size_t)r * nuf + f];
-                id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
-                lin = lin + field_lin[f][id];
-            }
-            fm_user[(size_t)r * kFmUserStride] = lin;
-        }
+        fm2t_user_prefix(r, tid, field_emb, field_lin, user_field_ids, vocab, fm_b, fm_user, nuf, fk);
         return;
     }
     for (uint32_t k = tid; k < du; k += blockDim.x) us[k] = round_prec(user[(size_t)r * du + k], prec);
@@ -782,6 +790,76 @@ __global__ __launch_bounds__(256) void fm2t_user_kernel(
         for (; j < th; ++j) acc = __fmaf_rn(u1[j], uw2[(size_t)j * to + o], acc);
         uo[(size_t)r * to + o] = acc;
     }
+}
+
+// The same tower when its shape allows every weight a thread needs to sit in its registers (user width DU, hidden width
+// <= 256, 256 / t_out threads per output each owning SUB = t_hidden * t_out / 256 consecutive terms of the output's chain):
+// ALL weight loads of both layers are issued before the first fmaf — one memory round trip for the request instead of
+// du / 8 + t_hidden / 8 dependent ones (the generic kernel's layer 2 keeps only t_out threads busy: 32 round trips at
+// 256 -> 64).  The chains themselves are unchanged (k ascending; an output's chain passes from part to part through LDS),
+// so the results are the generic kernel's bit for bit.
+template <int DU, int SUB>
+__global__ __launch_bounds__(256) void fm2t_user_fast_kernel(
+    const float* __restrict__ user, const float* __restrict__ uw1, const float* __restrict__ ub1,
+    const float* __restrict__ uw2, const float* __restrict__ ub2, uint32_t th, uint32_t to, int prec,
+    const float* const* __restrict__ field_emb, const float* const* __restrict__ field_lin,
+    const int32_t* __restrict__ user_field_ids, uint32_t vocab, float fm_b, float* __restrict__ uo,
+    float* __restrict__ fm_user, uint32_t nuf, uint32_t fk) {
+    __shared__ float us[DU];
+    __shared__ float u1[256];
+    __shared__ float carry[256];
+    const uint32_t r = blockIdx.x, tid = threadIdx.x;
+    if (blockIdx.y == 1) {
+        fm2t_user_prefix(r, tid, field_emb, field_lin, user_field_ids, vocab, fm_b, fm_user, nuf, fk);
+        return;
+    }
+    const uint32_t parts = 256u / to, o = tid % to, part = tid / to;
+    const bool l1 = tid < th;
+    float w1v[DU], w2v[SUB];
+    const float* w1c = uw1 + (l1 ? tid : 0u);
+#pragma unroll
+    for (int k = 0; k < DU; ++k) w1v[k] = w1c[(size_t)k * th];
+    const float* w2c = uw2 + (size_t)(part * SUB) * to + o;
+#pragma unroll
+    for (int i = 0; i < SUB; ++i) w2v[i] = w2c[(size_t)i * to];
+    float acc = ub1[l1 ? tid : 0u];
+    float acc2 = ub2[o];
+    if (tid < DU) us[tid] = round_prec(user[(size_t)r * DU + tid], prec);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DU; ++k) acc = __fmaf_rn(us[k], w1v[k], acc);
+    if (l1) u1[tid] = round_prec(acc > 0.0f ? acc : 0.0f, prec);
+    __syncthreads();
+    for (uint32_t p = 0; p < parts; ++p) {
+        if (part == p) {
+            if (p) acc2 = carry[o];
+#pragma unroll
+            for (int i = 0; i < SUB; ++i) acc2 = __fmaf_rn(u1[p * SUB + i], w2v[i], acc2);
+            if (p + 1 == parts) uo[(size_t)r * to + o] = acc2;
+            else carry[o] = acc2;
+        }
+        __syncthreads();
+    }
+}
+
+// launches the request side of FM + two-tower: the register-resident form where the shape allows it
+static void launch_fm2t_user(pg_ctx* ctx, const pg_model* m, const float* d_user, const int32_t* d_ufids, uint32_t n_req,
+                             bool with_prefix, float* uo, float* fm_user) {
+    const dim3 grid(n_req, with_prefix ? 2 : 1);
+    const float* const* fe = with_prefix ? m->d_field_emb : nullptr;
+    const float* const* fl = with_prefix ? m->d_field_lin : nullptr;
+    const uint32_t sub = (m->to && 256u % m->to == 0) ? m->th * m->to / 256u : 0;
+    const bool fits = m->d_user == 128 && m->th <= 256 && m->to <= 256 && sub * (256u / (m->to ? m->to : 1)) == m->th &&
+                      !ctx->knobs.rank_no_ws;
+    if (fits && sub == 64)
+        fm2t_user_fast_kernel<128, 64><<<grid, 256, 0, ctx->stream>>>(d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to, m->prec,
+                                                                     fe, fl, d_ufids, m->vocab, m->fm_b, uo, fm_user, m->nuf, m->k);
+    else if (fits && sub == 32)
+        fm2t_user_fast_kernel<128, 32><<<grid, 256, 0, ctx->stream>>>(d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to, m->prec,
+                                                                     fe, fl, d_ufids, m->vocab, m->fm_b, uo, fm_user, m->nuf, m->k);
+    else
+        fm2t_user_kernel<<<grid, 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to, m->prec, fe,
+                                                        fl, d_ufids, m->vocab, m->fm_b, uo, fm_user, m->nuf, m->k);
 }
 
 }  // namespace pg
@@ -1052,9 +1130,7 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     if ((rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, bm, rs.tile_req, rs.tile_item0, rs.tile_cnt, rs.n_tiles,
                                  rs.req_tile0)))
         return rc;
-    fm2t_user_kernel<<<dim3(n_req, 2), 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th,
-                                                     m->to, m->prec, m->d_field_emb, m->d_field_lin, d_ufids,
-                                                     m->vocab, m->fm_b, rs.c1, rs.fm_user, m->nuf, m->k);
+    launch_fm2t_user(ctx, m, d_user, d_ufids, n_req, true, rs.c1, rs.fm_user);
     MlpArgs a{};
     a.tile_req = rs.tile_req;
     a.tile_item0 = rs.tile_item0;
@@ -1179,8 +1255,7 @@ int rank_fm2t_rows_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_features*
 // user-tower output uo[r][t_out] only: the "user embedding" an EasyRec / TorchRec vector model serves
 int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_user, uint32_t n_req, float* d_out) {
     if (n_req == 0) return PG_OK;
-    fm2t_user_kernel<<<n_req, 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to,
-                                                     m->prec, nullptr, nullptr, nullptr, m->vocab, m->fm_b, d_out, nullptr, m->nuf, m->k);
+    launch_fm2t_user(ctx, m, d_user, nullptr, n_req, false, d_out, nullptr);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
