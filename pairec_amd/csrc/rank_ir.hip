@@ -49,7 +49,7 @@ constexpr size_t kIrRaw = 4 * kIrWaveRaw;                       // 36 KiB per ra
 constexpr size_t kIrXT = (size_t)kIrsItems * kDIN * 2;          // 16 KiB
 constexpr size_t kIrH1 = (size_t)kIrsItems * kIrTH * 2;         // 32 KiB
 constexpr size_t kIrH2 = (size_t)kIrsItems * kIrHS * 4;         // 17 KiB per H2 tile
-constexpr size_t kIrMeta = 4 * 2 * 64 * 4 + 16;                   // per producer wave two slots of 64 dwords: rows + next descriptor; head flags
+constexpr size_t kIrMeta = 4 * 2 * 64 * 4;                        // per producer wave two slots of 64 dwords: rows + next descriptor
 constexpr size_t ir_lds_bytes() { return 2 * kIrRaw + 2 * kIrXT + kIrH1 + kIrH2 + (size_t)kIrSlots * kIrSlotF * 4 + kIrTO * 4 + kIrMeta; }
 static_assert(ir_lds_bytes() <= 160 * 1024, "fm2t_irs_kernel: LDS budget");
 
@@ -104,11 +104,6 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS byte address of smem
     const uint32_t lds_ring = lds0 + (uint32_t)(2 * kIrRaw + 2 * kIrXT + kIrH1 + kIrH2);
     const uint32_t lds_meta = lds_ring + (uint32_t)(kIrSlots * kIrSlotF * 4 + kIrTO * 4);
-    // [2]: the trips whose H2 tile waves 6 / 7 have read (explicitly an LDS pointer: a volatile generic one compiles to flat
-    // accesses, each behind a vmcnt(0))
-    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
-    lds_vu32* const hflag = reinterpret_cast<lds_vu32*>((__attribute__((address_space(3))) char*)smem + (2 * kIrRaw + 2 * kIrXT + kIrH1 + kIrH2 +
-                                                        kIrSlots * kIrSlotF * 4 + kIrTO * 4 + 4 * 2 * 64 * 4));
     const uint32_t n_tiles = *a.n_tiles;
     const uint32_t t_begin = (uint32_t)(((uint64_t)n_tiles * blockIdx.x) / gridDim.x);
     const uint32_t t_end = (uint32_t)(((uint64_t)n_tiles * (blockIdx.x + 1)) / gridDim.x);
@@ -141,7 +136,6 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
     }
     asm volatile("" : "+v"(c1v[0]), "+v"(c1v[1]));
     if (tid < kIrTO) b2s[tid] = a.b2[tid];
-    if (tid < 2) hflag[tid] = 0;
     // (the loads above are ordinary ones: their wait belongs here, not at their first use inside the loop, where the
     // compiler would repeat a vmcnt(0) on every trip)
 #pragma unroll
@@ -222,27 +216,27 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
         for (int f = 0; f < 8; ++f) e[f] = *reinterpret_cast<const float4*>(wraw + (f >> 1) * 1024 + (f & 1) * 64);
         const float4 lq = *reinterpret_cast<const float4*>(wbase + 8 * 1024 + (t_ & 63) * 16);   // (lanes 0 / 1 of the record)
         const float* fu = ring + rs * kIrSlotF + kIrsItems + kIrTO;
-        // the eight chains of this lane (s and q of four columns), two columns per instruction (v_pk_add_f32 / v_pk_fma_f32:
-        // the same IEEE operations per element, in the same order)
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 sa, sb, qa, qb;
+        // the eight chains of this lane (s and q of four columns) as plain v_add_f32 / v_fma_f32: beside another wave's MFMAs
+        // on the SIMD a packed fp32 instruction costs more than the two it replaces (asm: the compiler would pack them again)
+        float sc[4], qc[4];
         {
             const float4 s4 = *reinterpret_cast<const float4*>(fu + 4 * j);
             const float4 q4 = *reinterpret_cast<const float4*>(fu + 16 + 4 * j);
-            sa = f32x2{s4.x, s4.y}; sb = f32x2{s4.z, s4.w};
-            qa = f32x2{q4.x, q4.y}; qb = f32x2{q4.z, q4.w};
+            sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+            qc[0] = q4.x; qc[1] = q4.y; qc[2] = q4.z; qc[3] = q4.w;
         }
 #pragma unroll
         for (int f = 0; f < 8; ++f) {                       // user prefix first, fields ascending
-            const f32x2 xa = {e[f].x, e[f].y}, xb = {e[f].z, e[f].w};
-            sa = sa + xa; qa = __builtin_elementwise_fma(xa, xa, qa);
-            sb = sb + xb; qb = __builtin_elementwise_fma(xb, xb, qb);
+            const float xv[4] = {e[f].x, e[f].y, e[f].z, e[f].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                asm("v_add_f32 %0, %1, %0" : "+v"(sc[c]) : "v"(xv[c]));
+                asm("v_fma_f32 %0, %1, %1, %0" : "+v"(qc[c]) : "v"(xv[c]));
+            }
         }
         float s_[4];
-        s_[0] = __fmaf_rn(sa.x, sa.x, -qa.x);
-        s_[1] = __fmaf_rn(sa.y, sa.y, -qa.y);
-        s_[2] = __fmaf_rn(sb.x, sb.x, -qb.x);
-        s_[3] = __fmaf_rn(sb.y, sb.y, -qb.y);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_[c] = __fmaf_rn(sc[c], sc[c], -qc[c]);
         float cross = (s_[0] + s_[1]) + (s_[2] + s_[3]);    // tree levels 1, 2 (columns of one quad)
         cross = cross + ir_lane_xor1(cross);                // level 3: quads 2m, 2m + 1
         cross = cross + ir_lane_xor2(cross);                // level 4
@@ -257,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
     };
     // ---- the head of a tile whose H2 tile / FM terms / tower output are in LDS (waves 6, 7: two threads per item).  The
     // store is issued by every lane for every tile: items past the tile's count (and the odd lanes) write to the sink
-    auto head = [&](const IrTile& d, uint32_t rs, uint32_t signal) {
+    auto head = [&](const IrTile& d, uint32_t rs) {
         uint32_t t_ = (uint32_t)tid;
         asm volatile("" : "+v"(t_));
         const uint32_t u = t_ - 384;
@@ -270,11 +264,6 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
             x[m] = hr[m];
             y[m] = wr[m];
         }
-        // the H2 tile may be overwritten once these reads have executed: the LDS serves a wave's accesses in order, so a
-        // flag written behind them says so (the consumers check it before layer 2's stores, see the loop)
-        asm volatile("" ::: "memory");
-        if (signal && (t_ & 63) == 0) hflag[(t_ >> 6) - 6] = signal;
-        asm volatile("" ::: "memory");
         float p = half ? 0.0f : ring[rs * kIrSlotF + row];
 #pragma unroll
         for (int m = 0; m < kIrTO / 8; ++m) {
@@ -374,14 +363,16 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
         } else {
             // ---- producers, first half: this wave's share of tile t + 1's records (DMA'd three tiles ago) -> the other X tile
             // and the FM terms — eleven events stand behind those DMAs in the wave's queue (waves 6 / 7: the head's store, the
-            // meta DMA, tile t + 2's nine record DMAs; waves 4 / 5: the meta DMA and ten DMAs)
+            // meta DMA, tile t + 2's nine record DMAs; waves 4 / 5: the meta DMA and ten DMAs) —, then waves 6 / 7 finish tile
+            // t - 1 (head; first trip: count 0, all lanes to the sink)
             ir_wait_vm<11>();
             IR_MARK(4)
             convert((t + 1) & 1, ring_add(s6, 1), XT0 + ((t + 1) & 1) * kIrXT);
             IR_MARK(5)
+            if (wave >= 6) head(dA, s6 == 0 ? kIrSlots - 1 : s6 - 1);
             IR_MARK(1)
         }
-        ir_barrier();                                       // B: H1 complete
+        ir_barrier();                                       // B: H1 complete; H2 (tile t - 1) consumed
         IR_MARK(2)
         if (wave < 4) {
             // ---- consumers: layer 2 of tile t, output block (mb2, nb2) -> fp32 H2 tile
@@ -394,23 +385,12 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
             const int row = mb2 * 32 + i32;
             const char* const h1r = H1T + row * (kIrTH * 2);
             bf16x8 af[4];                                   // three steps ahead: this chain's MFMAs are dependent, its reads are not
-            uint32_t hf0 = 0, hf1 = 0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const bf16x8*>(h1r + (((i * 2 + h) ^ sw) << 4));
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
                 if (ks + 3 < KS2) af[(ks + 3) & 3] = *reinterpret_cast<const bf16x8*>(h1r + ((((ks + 3) * 2 + h) ^ sw) << 4));
-                if (ks == KS2 - 4) {                       // (behind the last fragment read: the answer is there when the MFMAs end)
-                    hf0 = hflag[0];
-                    hf1 = hflag[1];
-                }
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2r[ks], af[ks & 3], acc2, 0, 0, 0);
-            }
-            // tile t - 1's head (waves 6 / 7, at the start of this same half) reads the H2 tile these stores overwrite: it has
-            // signalled long before layer 2's MFMAs end — checked, not assumed
-            while (hf0 < t - t_begin + 1 || hf1 < t - t_begin + 1) {
-                hf0 = hflag[0];
-                hf1 = hflag[1];
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -418,15 +398,12 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
                     make_float4(acc2[4 * g + 0], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3]);
             IR_MARK(3)
         } else {
-            // ---- producers, second half.  Waves 6 / 7 first finish tile t - 1 (head: its H2 tile is overwritten by this
-            // half's layer 2 — at its end, behind the flag the head sets; first trip: count 0, all lanes to the sink).  Then the
-            // meta slot written a trip ago (nine events or more behind it: tile t + 2's issue group) gives this lane's rows of
-            // tile t + 3 and tile t + 4's descriptor; the next meta DMA goes out, then tile t + 3's records into the raw slot
-            // just converted (its reads were this wave's own and have returned: the conversion consumed them)
-            ir_wait_vm<9>();
+            // ---- producers, second half.  The meta slot written a trip ago (ten events behind it: tile t + 2's issue group
+            // and, for waves 6 / 7, this trip's store) gives this lane's rows of tile t + 3 and tile t + 4's descriptor; the next
+            // meta DMA goes out, then tile t + 3's records into the raw slot just converted (its reads were this wave's own and
+            // have returned: the conversion consumed them)
+            ir_wait_vm<10>();
             IR_MARK(3)
-            if (wave >= 6) head(dA, s6 == 0 ? kIrSlots - 1 : s6 - 1, t - t_begin + 1);
-            IR_MARK(1)
             uint32_t l_ = (uint32_t)lane;
             asm volatile("" : "+v"(l_));
             const uint32_t* const mb = meta + (pw * 2 + ((t + 1) & 1)) * 64;
@@ -453,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
 #endif
     // the head of the last tile (its H2 tile was written in the last phase 2)
     ir_barrier();
-    if (wave >= 6) head(dA, s6 == 0 ? kIrSlots - 1 : s6 - 1, 0);
+    if (wave >= 6) head(dA, s6 == 0 ? kIrSlots - 1 : s6 - 1);
     ir_wait_vm<0>();                                        // (DMAs of tiles past the range are still landing in this workgroup's LDS)
 }
 
