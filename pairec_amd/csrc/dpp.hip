@@ -139,7 +139,7 @@ constexpr int kDppTile = 64, kDppKc = 16;
 // two waves per SIMD (`__launch_bounds__(64, 2)`: 256 registers, spills in the loop — 700 us); 8-column chunks
 // double-buffered in LDS (700 us: a row's 64-B segments fetch every 128-B line twice); the operands of step k + 1 read
 // before the fma of step k (466 us: no gain — VALU 38 % and LDS 25 % busy, the wave is latency-bound with nobody to cover).
-__global__ __launch_bounds__(64) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
+__global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
                                                                   uint32_t n, uint32_t d1, uint32_t nt, double* __restrict__ L) {
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) double sa[kDppKc][kDppTile + 2];      // [k][row], rows padded to a 16-B multiple
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(64) void dpp_kernel_matrix_kernel(const double* __r
             vb[it] = *reinterpret_cast<const double*>(Fb + (rj * rowb + kcol));
         }
     };
-    load_panels(0);
     for (uint32_t k0 = 0; k0 < d1; k0 += kDppKc) {
+        load_panels(k0);
         const uint32_t kc = d1 - k0 < (uint32_t)kDppKc ? d1 - k0 : (uint32_t)kDppKc;
         __syncthreads();                                       // the previous step's readers are done
 #pragma unroll
@@ -187,7 +187,6 @@ __global__ __launch_bounds__(64) void dpp_kernel_matrix_kernel(const double* __r
             sb[kk][it * 4 + rr] = vb[it];
         }
         __syncthreads();
-        if (k0 + kDppKc < d1) load_panels(k0 + kDppKc);        // in flight under this chunk's fma
         for (uint32_t k = 0; k < kc; ++k) {
             f64x2 av[4], bv[4];
 #pragma unroll
@@ -219,29 +218,37 @@ __global__ __launch_bounds__(64) void dpp_kernel_matrix_kernel(const double* __r
         const uint32_t i = i0 + 2 * ty + (b & 1) + 16 * (b >> 1);
         riv[b] = i < n ? rq[i] : 0.0;
     }
-    for (int mirror = 0; mirror < (ti != tj ? 2 : 1); ++mirror)
-        for (int half = 0; half < 2; ++half) {
-            __syncthreads();                                    // the panels' / the previous half's readers are done
-            // this lane's elements whose OUTPUT row falls into rows [32 half, 32 half + 32) of the (mirrored) tile
+    // (mirror and half as compile-time values: with runtime ones the compiler keeps the accumulators in scratch and forms
+    // every product in every pass)
+    auto pass = [&](auto mirror_c, auto half_c) {
+        constexpr int mirror = decltype(mirror_c)::value, half = decltype(half_c)::value;
+        __syncthreads();                                    // the panels' / the previous half's readers are done
+        // this lane's elements whose OUTPUT row falls into rows [32 half, 32 half + 32) of the (mirrored) tile
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < 8; ++a)
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const int row_t = 2 * (int)ty + (a & 1) + 16 * (a >> 1);        // row of the tile
-                    const int col_t = 2 * (int)tx + (b & 1) + 16 * (b >> 1);
-                    const int orow = mirror ? col_t : row_t, ocol = mirror ? row_t : col_t;
-                    if ((orow >> 5) != half) continue;
-                    const double v = mirror ? __dmul_rn(__dmul_rn(rjv[b], acc[a][b]), riv[a])
-                                            : __dmul_rn(__dmul_rn(riv[a], acc[a][b]), rjv[b]);
-                    stage[(orow & 31) * 65 + ocol] = v;
-                }
-            __syncthreads();
-            const uint32_t r0 = (mirror ? j0 : i0) + 32 * half, c0 = mirror ? i0 : j0;
-            for (int rr2 = 0; rr2 < 32; ++rr2) {
-                const uint32_t gi = r0 + rr2, gj = c0 + lane;
-                if (gi < n && gj < n) L[((size_t)q * n + gi) * n + gj] = stage[rr2 * 65 + lane];
+            for (int b = 0; b < 8; ++b) {
+                const int row_t = 2 * (int)ty + (a & 1) + 16 * (a >> 1);        // row of the tile
+                const int col_t = 2 * (int)tx + (b & 1) + 16 * (b >> 1);
+                const int orow = mirror ? col_t : row_t, ocol = mirror ? row_t : col_t;
+                if (((mirror ? b : a) >> 2) != half) continue;                  // (orow >> 5: 2 t + (x & 1) < 16)
+                const double v = mirror ? __dmul_rn(__dmul_rn(rjv[b], acc[a][b]), riv[a])
+                                        : __dmul_rn(__dmul_rn(riv[a], acc[a][b]), rjv[b]);
+                stage[(orow & 31) * 65 + ocol] = v;
             }
+        __syncthreads();
+        const uint32_t r0 = (mirror ? j0 : i0) + 32 * half, c0 = mirror ? i0 : j0;
+        for (int rr2 = 0; rr2 < 32; ++rr2) {
+            const uint32_t gi = r0 + rr2, gj = c0 + lane;
+            if (gi < n && gj < n) L[((size_t)q * n + gi) * n + gj] = stage[rr2 * 65 + lane];
         }
+    };
+    pass(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+    pass(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
+    if (ti != tj) {
+        pass(std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
+        pass(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+    }
 }
 
 // floats.MaxIdx: first maximum, NaN skipped; all-NaN → index 0.  Block-wide, result in *s_idx.
