@@ -131,19 +131,26 @@ constexpr int kDppTile = 64, kDppKc = 16;
 // contiguous bytes per row and instruction).  Every element is its own k-ascending fma chain, as the specification
 // wants it; S is symmetric bit for bit (a product commutes), L is not — L_ij = (r_i S_ij) r_j and L_ji = (r_j S_ij) r_i
 // are both formed from the one S_ij.
-// Round 4 (profiles/r4_dpp_pmc_summary.txt): with `__launch_bounds__(64)` the compiler takes 496 registers, i.e. ONE wave
-// per SIMD, and the old kernel issued and awaited every chunk's panel loads at the top of the chunk: a wave lived 127 K cycles
-// for 33 K cycles of fma, 38 K of them waiting for those loads (SQ_WAIT_ANY).  Now the next chunk's 32 values per lane are
-// requested BEFORE the current chunk's 1 024 fma (va / vb are dead during the fma block) from clamped, unconditional
-// addresses (predicated loads compiled into 32 branches per chunk): 521 -> 456 us per 256 x 500 x 129.  Tried and dropped:
-// two waves per SIMD (`__launch_bounds__(64, 2)`: 256 registers, spills in the loop — 700 us); 8-column chunks
-// double-buffered in LDS (700 us: a row's 64-B segments fetch every 128-B line twice); the operands of step k + 1 read
-// before the fma of step k (466 us: no gain — VALU 38 % and LDS 25 % busy, the wave is latency-bound with nobody to cover).
+// Round 4 (profiles/r4_dpp_pmc_summary.txt, scripts/micro/fma64_rate.hip).  What the chip gives: v_fmac_f64 from 64
+// independent accumulators runs at 4.7 cycles per wave-instruction and SIMD with two waves per SIMD (6.2 with one) at the
+// 1.8 GHz it sustains under that load — 25 T fma/s, not the nominal 39: this kernel's 4.66 G fma cannot take less than
+// 0.19 ms.  Where it stood: one wave per SIMD (496 registers), every chunk's panel loads awaited at the top of the chunk,
+// VALU 38 % busy — 521 us.  Steps: next chunk's loads requested before the fma block (456 us); then TWO waves per SIMD —
+// possible once the epilogue's passes were compile-time code (with `mirror` / `half` as loop variables the compiler kept
+// the 64 accumulators in scratch and formed all 256 products in each of the four passes: 241 spilled dwords under a
+// 256-register budget) and the panel loads moved back inside the chunk (their 64 registers are dead during the fma
+// block; the other wave covers the wait): 365 us; panel loads without per-load arithmetic and a 17-wide last chunk
+// instead of a ninth staging round for one column: 356 us = VALU 50 % busy at 2.1 GHz, 0.53 of what the chip gives.
+// Tried and dropped: 8-column chunks double-buffered in LDS (700 us: a row's 64-B segments fetch every 128-B line twice);
+// the operands of step k + 1 read before the fma of step k (no gain).
 __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
                                                                   uint32_t n, uint32_t d1, uint32_t nt, double* __restrict__ L) {
     typedef double f64x2 __attribute__((ext_vector_type(2)));
-    __shared__ __attribute__((aligned(16))) double sa[kDppKc][kDppTile + 2];      // [k][row], rows padded to a 16-B multiple
-    __shared__ __attribute__((aligned(16))) double sb[kDppKc][kDppTile + 2];
+    // the two panels [k][row], rows padded to a 16-B multiple (+ 1 column: the 17-wide tail); ONE array: the output staging
+    // below runs over both
+    __shared__ __attribute__((aligned(16))) double panels[2][kDppKc + 1][kDppTile + 2];
+    auto& sa = panels[0];
+    auto& sb = panels[1];
     const uint32_t q = blockIdx.z;
     // tile pair p → (ti, tj), ti <= tj: row ti holds nt - ti pairs
     uint32_t ti = 0, p = blockIdx.x;
@@ -162,29 +169,45 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* 
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
     double va[16], vb[16];
-    // (unconditional loads from clamped addresses — 32-bit byte offsets on the request's base —: rows past n only feed
-    // accumulators that are never written, columns past d1 are never multiplied; predicated loads compiled into 32
-    // branches per chunk and spilled their addresses)
+    // Panel loads with NO per-load arithmetic: a lane's byte offset (row rr, column k0 + kk) is one register advanced per
+    // chunk, the sixteen row groups are wave-uniform bases (scalar registers).  Rows past n and columns past d1 are read
+    // — F carries 64 rows of slack behind the last request (dpp_run_locked) — but only feed accumulators that are never
+    // written / k-steps that are never taken.  (Clamped addresses cost 130 VALU instructions per chunk beside its 1 024 fma.)
     const char* const Fb = reinterpret_cast<const char*>(Fq);
-    auto load_panels = [&](uint32_t k0) {
-        const uint32_t kcol = (k0 + kk < d1 ? k0 + kk : d1 - 1) * 8u;
-        const uint32_t rowb = d1 * 8u;
+    const uint32_t rowb = d1 * 8u;
+    uint32_t voff = rr * rowb + kk * 8u;
+    auto load_panels = [&]() {
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const uint32_t row = (uint32_t)it * 4 + rr;
-            const uint32_t ri = i0 + row < n ? i0 + row : n - 1, rj = j0 + row < n ? j0 + row : n - 1;
-            va[it] = *reinterpret_cast<const double*>(Fb + (ri * rowb + kcol));
-            vb[it] = *reinterpret_cast<const double*>(Fb + (rj * rowb + kcol));
+            const char* const ba = Fb + (size_t)(i0 + (uint32_t)it * 4) * rowb;      // (uniform)
+            const char* const bb = Fb + (size_t)(j0 + (uint32_t)it * 4) * rowb;
+            va[it] = *reinterpret_cast<const double*>(ba + voff);
+            vb[it] = *reinterpret_cast<const double*>(bb + voff);
         }
+        voff += kDppKc * 8u;
     };
+    // a width of 16 m + 1 (the embedding's 128 columns + the constant one) ends with a chunk of 17 instead of a ninth
+    // staging round for a single column
+    const bool tail17 = d1 > (uint32_t)kDppKc && d1 % kDppKc == 1;
     for (uint32_t k0 = 0; k0 < d1; k0 += kDppKc) {
-        load_panels(k0);
-        const uint32_t kc = d1 - k0 < (uint32_t)kDppKc ? d1 - k0 : (uint32_t)kDppKc;
+        uint32_t kc = d1 - k0 < (uint32_t)kDppKc ? d1 - k0 : (uint32_t)kDppKc;
+        const bool last17 = tail17 && k0 + kDppKc + 1 == d1;
+        load_panels();
+        double xa = 0.0, xb = 0.0;
+        if (last17) {                                          // column k0 + 16 of rows `lane` of both panels
+            xa = *reinterpret_cast<const double*>(Fb + (size_t)(i0 + lane) * rowb + (size_t)(k0 + kDppKc) * 8u);
+            xb = *reinterpret_cast<const double*>(Fb + (size_t)(j0 + lane) * rowb + (size_t)(k0 + kDppKc) * 8u);
+        }
         __syncthreads();                                       // the previous step's readers are done
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             sa[kk][it * 4 + rr] = va[it];
             sb[kk][it * 4 + rr] = vb[it];
+        }
+        if (last17) {
+            sa[kDppKc][lane] = xa;
+            sb[kDppKc][lane] = xb;
+            kc = kDppKc + 1;
         }
         __syncthreads();
         for (uint32_t k = 0; k < kc; ++k) {
@@ -203,13 +226,14 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* 
                     acc[2 * a + 1][2 * b + 1] = fma(av[a].y, bv[b].y, acc[2 * a + 1][2 * b + 1]);
                 }
         }
+        if (last17) break;
     }
     // L tile and (off the diagonal) its mirror, written as whole 512-B rows: the patches go through LDS — half a tile
     // (32 rows) at a time, in the panels' space — so that a store instruction covers one contiguous row of 64 doubles
     // (patch-wise stores are 16-B runs scattered over eight rows: 512 MB of them per 256-request batch)
     const double* rq = r + (size_t)q * n;
-    double* const stage = &sa[0][0];                            // 32 x 65 doubles fit the two panels (2 x 16 x 66)
-    static_assert(32 * 65 <= 2 * kDppKc * (kDppTile + 2), "the output staging aliases the panels");
+    double* const stage = &panels[0][0][0];                     // 32 x 65 doubles fit the two panels (2 x 17 x 66)
+    static_assert(32 * 65 <= 2 * (kDppKc + 1) * (kDppTile + 2), "the output staging aliases the panels");
     double rjv[8], riv[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -514,7 +538,8 @@ int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, cons
     if (window == 0) window = 10;                        // NewDPPSort default (dpp_sort.go:89-91)
     const uint32_t d1 = hook_dim + (has_table ? d : 0u) + 1;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t bF = al((size_t)R * n * d1 * 8), bR = al((size_t)R * n * 8), bL = al((size_t)R * n * n * 8);
+    // (F: 64 rows of slack behind the last request — the kernel matrix's panel loads are not clamped)
+    const size_t bF = al(((size_t)R * n + kDppTile) * d1 * 8), bR = al((size_t)R * n * 8), bL = al((size_t)R * n * n * 8);
     const size_t bD2 = al((size_t)R * n * 8), bC = al((size_t)R * std::min(window, n) * n * 8);
     void* buf;
     int rc;
