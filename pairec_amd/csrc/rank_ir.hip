@@ -191,7 +191,10 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
         // records at once.  The wave's raw share is then: piece 4 p + i = line i of records 8 p .. 8 p + 7 (record g at
         // g * 128), piece 8 the linear quads (record r at r * 64)
         auto clampr = [&](uint32_t r) { return r < a.irow_count ? r : a.irow_count; };   // (outside the store: the defaults' record)
-        const uint32_t jj = l_ & 7;
+        // (the two 64-B halves of a line change places for records 2, 3, 6, 7 of a pass — on the SOURCE side, the LDS image of
+        // a DMA is lane-linear —: the conversion's 16-lane read groups hold records {0, 3, 5, 6} / {1, 2, 4, 7}, whose
+        // quads would otherwise share banks two by two)
+        const uint32_t jj = (l_ & 7) ^ ((l_ >> 2) & 4);
         const char* const recA = reinterpret_cast<const char*>(a.irows) + (size_t)clampr(rowA) * (kItemRowFloats * 4) + jj * 16;
         const char* const recB = reinterpret_cast<const char*>(a.irows) + (size_t)clampr(rowB) * (kItemRowFloats * 4) + jj * 16;
         const uint32_t dst = lds0 + sl * (uint32_t)kIrRaw + (uint32_t)pw * (uint32_t)kIrWaveRaw;
@@ -211,9 +214,11 @@ __global__ __launch_bounds__(512, 1) void fm2t_irs_kernel(MlpArgs a) {
         const char* const wbase = RAW0 + sl * kIrRaw + (size_t)pw * kIrWaveRaw;
         const uint32_t rw = (t_ & 63) >> 2;                  // record within the wave: its lines were fetched in pass rw / 8, group rw % 8
         const char* const wraw = wbase + (rw >> 3) * 4096 + (rw & 7) * 128 + j * 16;
+        const char* const weven = wraw + ((rw >> 1) & 1) * 64;          // even fields' half of the record's lines (see issue)
+        const char* const wodd = wraw + (((rw >> 1) & 1) ^ 1) * 64;
         float4 e[8];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) e[f] = *reinterpret_cast<const float4*>(wraw + (f >> 1) * 1024 + (f & 1) * 64);
+        for (int f = 0; f < 8; ++f) e[f] = *reinterpret_cast<const float4*>(((f & 1) ? wodd : weven) + (f >> 1) * 1024);
         const float4 lq = *reinterpret_cast<const float4*>(wbase + 8 * 1024 + (t_ & 63) * 16);   // (lanes 0 / 1 of the record)
         const float* fu = ring + rs * kIrSlotF + kIrsItems + kIrTO;
         // the eight chains of this lane (s and q of four columns) as plain v_add_f32 / v_fma_f32: beside another wave's MFMAs
