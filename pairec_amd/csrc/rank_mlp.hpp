@@ -156,5 +156,8 @@ int launch_dnn3_ls(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
 constexpr int kIrsItems = 64;
 bool fm2t_irs_shape(uint32_t th, uint32_t to, uint32_t k, uint32_t nif, int prec);
 int launch_fm2t_irs(pg_ctx* ctx, const MlpArgs& a);
+// the same shape with every wave a whole pipeline over 32-item tiles (rank_is.hip)
+constexpr int kIswItems = 32;
+int launch_fm2t_isw(pg_ctx* ctx, const MlpArgs& a);
 
 }  // namespace pg

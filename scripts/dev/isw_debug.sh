@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.."
+touch pairec_amd/csrc/rank_is.hip
+make -C pairec_amd/csrc WS_EXTRA=-DPG_ISW_DEBUG -j8 > /dev/null 2>&1
+for m in 1 2 3 4 5 6 7 0; do python scripts/dev/isw_debug.py $m 2>&1 | tail -3; done
