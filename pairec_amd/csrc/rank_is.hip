@@ -33,7 +33,8 @@ namespace pg {
 constexpr int kIsTH = 256, kIsTO = 64;
 constexpr size_t kIsW1 = (size_t)kDIN * kIsTH * 2;            // 64 KiB of layer-1 fragments [n-block][k-step][lane]
 constexpr size_t kIsW2 = (size_t)kIsTH * kIsTO * 2;           // 32 KiB of layer-2 fragments
-constexpr size_t is_lds_bytes() { return kIsW1 + kIsW2 + kIsTH * 4 + kIsTO * 4; }
+constexpr int kIsRq = 132;                                    // floats of a wave's request cache: s[32] | q[32] | lin | pad | tower output [64] at 68
+constexpr size_t is_lds_bytes(int waves) { return kIsW1 + kIsW2 + kIsTH * 4 + kIsTO * 4 + (size_t)waves * kIsRq * 4; }
 
 __device__ __forceinline__ float is_lane_xor1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(64 * kIsWaves, 1) void fm2t_isw_kernel(MlpArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const rq = b2s + kIsTO + wave * kIsRq;             // this wave's request cache (filled when its tile's request changes)
     // ---- the towers -> LDS, once
     {
         const uint4* const g1 = reinterpret_cast<const uint4*>(a.w1p);
@@ -146,16 +148,24 @@ __global__ __launch_bounds__(64 * kIsWaves, 1) void fm2t_isw_kernel(MlpArgs a) {
         load_rows(d1, rows1);
         if (t < t_end) issue_gather(rows0);
     }
+    uint32_t cached_req = 0xFFFFFFFFu;
     for (; t < t_end; t += kIsWaves) {
         uint32_t l_ = (uint32_t)lane;
         asm volatile("" : "+v"(l_));                           // (per-lane indices re-derived per tile: hoisted, they are spilled)
         const uint32_t req = d0.req, item0 = d0.item0, cnt = d0.cnt;
         const uint32_t gj = l_ & 3;
-        // the request's FM prefix: s / q of this lane's four columns, the linear part
-        const float* const fu = a.fm_user + (size_t)req * kFmUserStride;
-        const float4 s4 = *reinterpret_cast<const float4*>(fu + 1 + 4 * gj);
-        const float4 q4 = *reinterpret_cast<const float4*>(fu + 1 + kFmMaxK + 4 * gj);
-        const float linu = fu[0];
+        // the request's FM prefix and user-tower output: through the wave's LDS cache (a request is ~150 tiles long; read
+        // from global per tile, these eleven loads were the exposed latencies of the trip)
+        if (req != cached_req) {
+            const float* const fu = a.fm_user + (size_t)req * kFmUserStride;
+            rq[l_] = fu[1 + l_];                               // s[0..31] | q[0..31]
+            if (l_ == 0) rq[64] = fu[0];
+            rq[68 + l_] = a.w3[(size_t)req * a.w3_stride + l_];
+            cached_req = req;
+        }
+        const float4 s4 = *reinterpret_cast<const float4*>(rq + 4 * gj);
+        const float4 q4 = *reinterpret_cast<const float4*>(rq + kFmMaxK + 4 * gj);
+        const float linu = rq[64];
 
         // ---- FM terms and the packed quads (fm2t_irs_kernel's conversion, per pass)
         uint32_t qp[2][8][2];
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(64 * kIsWaves, 1) void fm2t_isw_kernel(MlpArgs a) {
         }
         // ---- head: chain 0 over output columns 0..31 (from the FM term), chain 1 over 32..63 (from 0), both ascending; a
         // lane half owns columns 8 g + 4 h + 0..3 of a block, so the chains change halves every four columns
-        const float* const w3 = a.w3 + (size_t)req * a.w3_stride;
+        const float* const w3 = rq + 68;
         float c0 = fm_term, c1 = 0.0f;                          // (meaningful in the half whose turn it is)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(64 * kIsWaves, 1) void fm2t_isw_kernel(MlpArgs a) {
 bool fm2t_isw_shape(uint32_t th, uint32_t to, uint32_t k, uint32_t nif, int prec) { return prec == 1 && th == 256 && to == 64 && k == 16 && nif == 8; }
 
 int launch_fm2t_isw(pg_ctx* ctx, const MlpArgs& a) {
-    constexpr size_t lds = is_lds_bytes();
+    constexpr size_t lds = is_lds_bytes(kIsWaves);
     int rc;
     if ((rc = ensure_dyn_lds(ctx, (const void*)fm2t_isw_kernel, lds))) return rc;
 #ifdef PG_ISW_DEBUG
