@@ -948,8 +948,8 @@ def cfg4_leg(pa, o, ctx, R, K):
         "per_field_path": {"device_ms_per_step": per_field_ms, "value": n / (per_field_ms * 1e-3),
                            "note": "pg_rank_fm2t_dev: 8 ids + 8 scattered 64-B embedding rows per item (1056 B of HBM traffic)"},
         "concurrent_callers": callers,
-        "roofline": {"bound": "hbm", "kernel": "pg::fm2t_irs_kernel (FM + item tower over materialised item records: LDS-DMA three tiles "
-                                                "ahead, weights stationary in registers, producer / consumer waves)",
+        "roofline": {"bound": "hbm", "kernel": "pg::fm2t_isw_kernel (FM + item tower over materialised item records: every wave a whole "
+                                                "pipeline over 32-item tiles, towers in LDS, X / H1 in registers, records one tile ahead)",
                      "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                      "bytes_per_item": FM2T_BYTES_PER_ITEM, "traffic": None,
                      "ms_basis": "device_ms_per_step = HIP events around the whole rank stage (tile table + user tower / FM prefix "
@@ -1464,7 +1464,7 @@ def main():
         # ... and cfg 4's rank kernel: HBM bytes per launch of 1.28 M items (scripts/dev/cfg4_prof.py under rocprofv3 --pmc)
         c4 = out.get("other_configs", {}).get("cfg4")
         if c4:
-            tb4, det4 = measure_kernel_traffic([os.path.join(ROOT, "scripts", "dev", "cfg4_prof.py"), "random"], "fm2t_irs_kernel")
+            tb4, det4 = measure_kernel_traffic([os.path.join(ROOT, "scripts", "dev", "cfg4_prof.py"), "random"], "fm2t_isw_kernel")
             c4["roofline"]["traffic"] = tb4
             c4["roofline"]["traffic_detail"] = det4
             if tb4:

@@ -74,7 +74,7 @@ __device__ __forceinline__ float is_to_lower(float v) {
 }
 
 #ifndef PG_ISW_WAVES
-#define PG_ISW_WAVES 12
+#define PG_ISW_WAVES 8
 #endif
 constexpr int kIsWaves = PG_ISW_WAVES;                         // per CU (one workgroup)
 
@@ -226,6 +226,20 @@ __global__ __launch_bounds__(64 * kIsWaves, 1) void fm2t_isw_kernel(MlpArgs a) {
         if (t + kIsWaves < t_end) issue_gather(rows1);
         load_rows(d2, rows1);                                  // (tile t + 2 W's rows: requested behind the gather that used the old ones)
 
+#ifdef PG_ISW_GATHER_ONLY
+        {                                                      // (developer experiment: the gather + FM + permutes alone)
+            float v = fm_term;
+#pragma unroll
+            for (int f = 0; f < 8; ++f)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v += (float)xb[f][i];
+            if (bh == 1 && bi < cnt) a.out[item0 + bi] = v;
+            d0 = d1;
+            d1 = d2;
+            d2 = d3;
+            continue;
+        }
+#endif
         // ---- the towers: per hidden block 8 + 4 MFMAs
         f32x16 acc2[2];
 #pragma unroll

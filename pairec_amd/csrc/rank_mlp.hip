@@ -1121,7 +1121,7 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     if (n_items == 0 || n_req == 0) return PG_OK;
     // the benchmark's shape over item records: the stationary-weights kernel (rank_ir.hip), 64-item tiles
     const bool irs = ir && !ctx->knobs.rank_no_ws && fm2t_irs_shape(m->th, m->to, m->k, m->nif, m->prec);
-    const bool isw = irs && ctx->knobs.fm2t_isw;
+    const bool isw = irs && !ctx->knobs.fm2t_irs;
     const uint32_t bm = isw ? (uint32_t)kIswItems : irs ? (uint32_t)kIrsItems : (m->prec ? (uint32_t)kFmBM : (uint32_t)kBM);
     const uint32_t max_tiles = n_items / bm + n_req;
     RankScratch rs;

@@ -29,3 +29,9 @@ for _ in range(12):
     _lib.check(ctx.L.pg_rank_fm2t_irows_dev(ctx.h, m.h, ir.h, d_u, d_uf, d_c, d_off, R, n, d_out))
 ctx.synchronize()
 print("device ms", ctx.stats().last_rank_ms)
+if len(sys.argv) > 2 and sys.argv[2] == "sync":          # one call at a time, as bench.py's cfg-4 leg times it
+    ms = []
+    for _ in range(20):
+        _lib.check(ctx.L.pg_rank_fm2t_irows_dev(ctx.h, m.h, ir.h, d_u, d_uf, d_c, d_off, R, n, d_out))
+        ms.append(ctx.stats().last_rank_ms)
+    print("device ms, one call at a time: mean %.4f min %.4f max %.4f" % (np.mean(ms), np.min(ms), np.max(ms)))

@@ -3,7 +3,6 @@ import os, sys, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-os.environ["PG_FM2T_ISW"] = "1"
 os.environ["PG_ISW_DEBUG_MODE"] = str(mode)
 import pairec_amd as pa
 from pairec_amd import _lib

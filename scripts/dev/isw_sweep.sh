@@ -1,7 +1,6 @@
 #!/bin/bash
 # developer experiment: waves per CU of fm2t_isw_kernel
 cd "$(dirname "$0")/../.."
-export PG_FM2T_ISW=1
 for w in 8; do
   touch pairec_amd/csrc/rank_is.hip
   make -C pairec_amd/csrc WS_EXTRA=-DPG_ISW_WAVES=$w -j8 > /dev/null 2>&1

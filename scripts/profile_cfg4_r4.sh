@@ -29,7 +29,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         by = collections.defaultdict(list)
         for r in csv.DictReader(open(p)):
             kn = r.get("Kernel_Name", "?")
-            if "fm2t_irs" in kn or "mlp_kernel" in kn:
+            if "fm2t_isw" in kn or "fm2t_irs" in kn or "mlp_kernel" in kn:
                 by[(kn[:60], r.get("Counter_Name", "?"))].append(float(r.get("Counter_Value", 0) or 0))
         lines.append("== %s (mean per dispatch)" % os.path.basename(d))
         for (kn, cn), v in sorted(by.items()):
