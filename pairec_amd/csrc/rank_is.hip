@@ -27,8 +27,17 @@ namespace pg {
 //   * per hidden block: 8 layer-1 MFMAs (one chain, k ascending, from the bias) and 4 layer-2 MFMAs (two output blocks,
 //     k-steps 2 nb, 2 nb + 1) — the accumulation orders of both layers are fm2t_irs_kernel's, hence mlp_kernel's, hence
 //     the per-field path's: scores are bit-identical (test_fm2t_materialised_item_records_are_bit_identical).
-// Eight waves per CU (two per SIMD, 256 registers each) run out of phase by themselves: one's gather latency and VALU
-// phases lie under the others' MFMAs.
+// Eight waves per CU (two per SIMD, 246 registers) run out of phase by themselves: one's gather latency and VALU phases
+// lie under the others' MFMAs.  The records of a wave's NEXT tile are requested before its towers run (72 registers in
+// flight under the MFMAs), its candidate rows a trip earlier, its descriptor a trip before that; the request's FM prefix
+// and user-tower output sit in a wave-private LDS cache refilled when the request changes (~150 tiles).
+// Measured (256 x 5 000 random candidates of a 20 M-item catalogue, one MI355X): rank stage 0.226-0.230 ms against
+// fm2t_irs_kernel's 0.246-0.262 on the same box, 0.227 in bench.py's leg (0.241); with every candidate = row 0 0.15 ms
+// (0.19).  The gather + FM sums alone (-DPG_ISW_GATHER_ONLY) take 0.171 ms = 5.3 TB/s of record lines: the towers' LDS
+// and MFMA traffic costs the memory side a quarter of that (waves wait 55 % of their lifetime for their records, all
+// 2 048 of them with 18 KB in flight).  Tried: twelve waves (168 registers: 99 spilled dwords with the prefetch, 0.28 ms
+// without it), whole-line fetches with eight lanes per record (probe: -2 % on the gather alone, nothing under the towers —
+// unlike fm2t_irs_kernel's LDS-DMAs, where it gave 16 %), non-temporal loads (nothing).
 // ---------------------------------------------------------------------------------------------
 constexpr int kIsTH = 256, kIsTO = 64;
 constexpr size_t kIsW1 = (size_t)kDIN * kIsTH * 2;            // 64 KiB of layer-1 fragments [n-block][k-step][lane]
