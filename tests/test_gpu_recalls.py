@@ -182,3 +182,41 @@ def test_fm2t_materialised_item_records_are_bit_identical(ctx, nuf, nif, k, th, 
         ir.destroy()
         m.destroy()
     feats.destroy()
+
+
+@pytest.mark.gpu
+def test_fm2t_item_record_kernels_agree_bit_for_bit_on_ragged_batches(ctx):
+    """The benchmark's shape (8 x 16 item fields, towers 256 / 64, bf16) has two kernels over the item records:
+    fm2t_isw_kernel (rank_is.hip, the default: every wave a whole pipeline over 32-item tiles, X and H1 in registers) and
+    fm2t_irs_kernel (rank_ir.hip, option fm2t_irs: producer / consumer waves over 64-item tiles).  Both run the
+    specification's chains and the same MFMA sequences: equal to each other and to the per-field path bit for bit — on
+    requests of 0, 1, 31, 32, 33, 64, 65 and thousands of candidates, fewer tiles than waves, candidates outside the store."""
+    vocab, n_items = 5000, 50_000
+    fw = o.Fm2tWeights(vocab=vocab)
+    rng = np.random.default_rng(321)
+    ids = rng.integers(0, vocab, (n_items, 8)).astype(np.int32)
+    feats = pa.Features(ctx, n_items)
+    cols = ["c%d" % f for f in range(8)]
+    for f, c in enumerate(cols):
+        feats.set_column(c, pa.F_I32, np.ascontiguousarray(ids[:, f]), default=3 + f)
+    m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, pa.PREC_BF16, pa.pack_fm2t(fw))
+    ir = pa.ItemRows(m, feats, cols)
+    for sizes in ([5], [0, 1, 31, 32, 33, 64, 65, 0, 700], [4000, 1, 2500], [32] * 40):
+        R = len(sizes)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+        n = int(off[-1])
+        users = o.synth_rows(o.SEED_QUERY, 3, R, 128)
+        ufids = rng.integers(0, vocab, (R, 8)).astype(np.int32)
+        cand = rng.integers(0, n_items, n).astype(np.uint32)
+        cand[0] = n_items + 1                                   # the defaults' record
+        want = m.rank_fm2t_rows(feats, cols, users, ufids, cand, off)
+        got = {}
+        for irs in (0, 1):
+            ctx.set_option("fm2t_irs", irs)
+            got[irs] = ir.rank(users, ufids, cand, off)
+        ctx.set_option("fm2t_irs", 0)
+        assert np.array_equal(bits(got[0]), bits(want)), sizes
+        assert np.array_equal(bits(got[1]), bits(want)), sizes
+    ir.destroy()
+    m.destroy()
+    feats.destroy()
