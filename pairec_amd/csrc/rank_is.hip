@@ -98,18 +98,6 @@ __global__ __launch_bounds__(64 * kIsWaves, 1) void fm2t_isw_kernel(MlpArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const rq = b2s + kIsTO + wave * kIsRq;             // this wave's request cache (filled when its tile's request changes)
-    // ---- the towers -> LDS, once
-    {
-        const uint4* const g1 = reinterpret_cast<const uint4*>(a.w1p);
-        const uint4* const g2 = reinterpret_cast<const uint4*>(a.w2p);
-        uint4* const s1 = reinterpret_cast<uint4*>(W1S);
-        uint4* const s2 = reinterpret_cast<uint4*>(W2S);
-        for (uint32_t i = tid; i < kIsW1 / 16; i += 64 * kIsWaves) s1[i] = g1[i];
-        for (uint32_t i = tid; i < kIsW2 / 16; i += 64 * kIsWaves) s2[i] = g2[i];
-        if (tid < kIsTH) c1s[tid] = a.c1[tid];
-        if (tid < kIsTO) b2s[tid] = a.b2[tid];
-    }
-    __syncthreads();
     const uint32_t n_tiles = *a.n_tiles;
     const uint32_t t_begin = (uint32_t)(((uint64_t)n_tiles * blockIdx.x) / gridDim.x);
     const uint32_t t_end = (uint32_t)(((uint64_t)n_tiles * (blockIdx.x + 1)) / gridDim.x);
@@ -157,6 +145,18 @@ __global__ __launch_bounds__(64 * kIsWaves, 1) void fm2t_isw_kernel(MlpArgs a) {
         load_rows(d1, rows1);
         if (t < t_end) issue_gather(rows0);
     }
+    // ---- the towers -> LDS, once — behind the first tile's record loads, which fly meanwhile
+    {
+        const uint4* const g1 = reinterpret_cast<const uint4*>(a.w1p);
+        const uint4* const g2 = reinterpret_cast<const uint4*>(a.w2p);
+        uint4* const s1 = reinterpret_cast<uint4*>(W1S);
+        uint4* const s2 = reinterpret_cast<uint4*>(W2S);
+        for (uint32_t i = tid; i < kIsW1 / 16; i += 64 * kIsWaves) s1[i] = g1[i];
+        for (uint32_t i = tid; i < kIsW2 / 16; i += 64 * kIsWaves) s2[i] = g2[i];
+        if (tid < kIsTH) c1s[tid] = a.c1[tid];
+        if (tid < kIsTO) b2s[tid] = a.b2[tid];
+    }
+    __syncthreads();
     uint32_t cached_req = 0xFFFFFFFFu;
     for (; t < t_end; t += kIsWaves) {
         uint32_t l_ = (uint32_t)lane;

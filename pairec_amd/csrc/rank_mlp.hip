@@ -626,8 +626,8 @@ __global__ __launch_bounds__(1024) void build_tiles_kernel(
 // prefix for itself in LDS — a few loads per thread — and then writes ITS 256 tiles; workgroup 0 also publishes the
 // prefix and the tile count.  One workgroup walking 20 000 tiles took 70-90 us of a 0.6 ms rank stage (r3 profile);
 // this takes one short launch.  The grid covers the host's upper bound n_items / tile_items + n_req.
-__global__ __launch_bounds__(256) void build_tiles_wide_kernel(
-    const uint32_t* __restrict__ req_offsets, uint32_t n_req, uint32_t* __restrict__ tile_req,
+__device__ __forceinline__ void build_tiles_wide_body(
+    uint32_t block, const uint32_t* __restrict__ req_offsets, uint32_t n_req, uint32_t* __restrict__ tile_req,
     uint32_t* __restrict__ tile_item0, uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ n_tiles,
     uint32_t* __restrict__ req_tile0, uint32_t tile_items) {
     __shared__ uint32_t chunk_sum[256];
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void build_tiles_wide_kernel(
         __syncthreads();
     }
     uint32_t acc = chunk_sum[tid] - sum;
-    const bool publish = blockIdx.x == 0;
+    const bool publish = block == 0;
     for (uint32_t r = r0; r < r1; ++r) {
         pre[r] = acc;
         if (publish) req_tile0[r] = acc;
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void build_tiles_wide_kernel(
     const uint32_t total = chunk_sum[255];
     if (publish && tid == 0) *n_tiles = total;
     __syncthreads();
-    const uint32_t t = blockIdx.x * 256 + tid;
+    const uint32_t t = block * 256 + tid;
     if (t >= total) return;
     uint32_t lo = 0, hi = n_req - 1;                       // the LAST request whose first tile is <= t (see above)
     while (lo < hi) {
@@ -669,6 +669,21 @@ __global__ __launch_bounds__(256) void build_tiles_wide_kernel(
     tile_item0[t] = i;
     tile_cnt[t] = (e - i < tile_items) ? e - i : tile_items;
 }
+__global__ __launch_bounds__(256) void build_tiles_wide_kernel(
+    const uint32_t* __restrict__ req_offsets, uint32_t n_req, uint32_t* __restrict__ tile_req,
+    uint32_t* __restrict__ tile_item0, uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ n_tiles,
+    uint32_t* __restrict__ req_tile0, uint32_t tile_items) {
+    build_tiles_wide_body(blockIdx.x, req_offsets, n_req, tile_req, tile_item0, tile_cnt, n_tiles, req_tile0, tile_items);
+}
+// the tile table as a third plane of the two-tower request-side launch (fm2t_user_fast_kernel, blockIdx.y == 2): the
+// two are independent, and a launch boundary costs as much as the table does
+struct TileTableArgs {
+    const uint32_t* req_offsets;
+    uint32_t n_req;
+    uint32_t *tile_req, *tile_item0, *tile_cnt, *n_tiles, *req_tile0;
+    uint32_t tile_items;
+    uint32_t blocks;                                       // 0: no table in this launch
+};
 
 static int build_tiles_launch(pg_ctx* ctx, const uint32_t* d_off, uint32_t n_req, uint32_t max_tiles, uint32_t tile_items,
                               uint32_t* tile_req, uint32_t* tile_item0, uint32_t* tile_cnt, uint32_t* n_tiles,
@@ -804,11 +819,17 @@ __global__ __launch_bounds__(256) void fm2t_user_fast_kernel(
     const float* __restrict__ uw2, const float* __restrict__ ub2, uint32_t th, uint32_t to, int prec,
     const float* const* __restrict__ field_emb, const float* const* __restrict__ field_lin,
     const int32_t* __restrict__ user_field_ids, uint32_t vocab, float fm_b, float* __restrict__ uo,
-    float* __restrict__ fm_user, uint32_t nuf, uint32_t fk) {
+    float* __restrict__ fm_user, uint32_t nuf, uint32_t fk, uint32_t n_req, TileTableArgs tt) {
     __shared__ float us[DU];
     __shared__ float u1[256];
     __shared__ float carry[256];
     const uint32_t r = blockIdx.x, tid = threadIdx.x;
+    if (blockIdx.y == 2) {
+        if (r < tt.blocks)
+            build_tiles_wide_body(r, tt.req_offsets, tt.n_req, tt.tile_req, tt.tile_item0, tt.tile_cnt, tt.n_tiles, tt.req_tile0, tt.tile_items);
+        return;
+    }
+    if (r >= n_req) return;
     if (blockIdx.y == 1) {
         fm2t_user_prefix(r, tid, field_emb, field_lin, user_field_ids, vocab, fm_b, fm_user, nuf, fk);
         return;
@@ -842,24 +863,33 @@ __global__ __launch_bounds__(256) void fm2t_user_fast_kernel(
     }
 }
 
-// launches the request side of FM + two-tower: the register-resident form where the shape allows it
+// launches the request side of FM + two-tower: the register-resident form where the shape allows it.  `tt` (optional): a
+// tile table to build in the same launch; *tiles_built says whether that happened (else the caller launches the table)
 static void launch_fm2t_user(pg_ctx* ctx, const pg_model* m, const float* d_user, const int32_t* d_ufids, uint32_t n_req,
-                             bool with_prefix, float* uo, float* fm_user) {
-    const dim3 grid(n_req, with_prefix ? 2 : 1);
+                             bool with_prefix, float* uo, float* fm_user, const TileTableArgs* tt = nullptr, bool* tiles_built = nullptr) {
+    if (tiles_built) *tiles_built = false;
     const float* const* fe = with_prefix ? m->d_field_emb : nullptr;
     const float* const* fl = with_prefix ? m->d_field_lin : nullptr;
     const uint32_t sub = (m->to && 256u % m->to == 0) ? m->th * m->to / 256u : 0;
     const bool fits = m->d_user == 128 && m->th <= 256 && m->to <= 256 && sub * (256u / (m->to ? m->to : 1)) == m->th &&
                       !ctx->knobs.rank_no_ws;
-    if (fits && sub == 64)
-        fm2t_user_fast_kernel<128, 64><<<grid, 256, 0, ctx->stream>>>(d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to, m->prec,
-                                                                     fe, fl, d_ufids, m->vocab, m->fm_b, uo, fm_user, m->nuf, m->k);
-    else if (fits && sub == 32)
-        fm2t_user_fast_kernel<128, 32><<<grid, 256, 0, ctx->stream>>>(d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to, m->prec,
-                                                                     fe, fl, d_ufids, m->vocab, m->fm_b, uo, fm_user, m->nuf, m->k);
-    else
-        fm2t_user_kernel<<<grid, 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to, m->prec, fe,
-                                                        fl, d_ufids, m->vocab, m->fm_b, uo, fm_user, m->nuf, m->k);
+    if (fits && (sub == 64 || sub == 32)) {
+        TileTableArgs t{};
+        if (tt && with_prefix && tt->blocks && tt->n_req <= kTilesLdsReqs) {
+            t = *tt;
+            if (tiles_built) *tiles_built = true;
+        }
+        const dim3 grid(std::max(n_req, t.blocks), t.blocks ? 3 : (with_prefix ? 2 : 1));
+        if (sub == 64)
+            fm2t_user_fast_kernel<128, 64><<<grid, 256, 0, ctx->stream>>>(d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to, m->prec, fe, fl,
+                                                                         d_ufids, m->vocab, m->fm_b, uo, fm_user, m->nuf, m->k, n_req, t);
+        else
+            fm2t_user_fast_kernel<128, 32><<<grid, 256, 0, ctx->stream>>>(d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to, m->prec, fe, fl,
+                                                                         d_ufids, m->vocab, m->fm_b, uo, fm_user, m->nuf, m->k, n_req, t);
+    } else {
+        fm2t_user_kernel<<<dim3(n_req, with_prefix ? 2 : 1), 256, 0, ctx->stream>>>(d_user, m->d_user, m->w1u, m->b1, m->uw2, m->ub2, m->th, m->to,
+                                                                                    m->prec, fe, fl, d_ufids, m->vocab, m->fm_b, uo, fm_user, m->nuf, m->k);
+    }
 }
 
 }  // namespace pg
@@ -1128,10 +1158,13 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     int rc;
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->to, &rs))) return rc;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    if ((rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, bm, rs.tile_req, rs.tile_item0, rs.tile_cnt, rs.n_tiles,
-                                 rs.req_tile0)))
+    // the request side and the tile table: one launch where the register-resident user kernel serves the shape
+    const TileTableArgs tt{d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt, rs.n_tiles, rs.req_tile0, bm, (max_tiles + 255) / 256};
+    bool tiles_built = false;
+    launch_fm2t_user(ctx, m, d_user, d_ufids, n_req, true, rs.c1, rs.fm_user, &tt, &tiles_built);
+    if (!tiles_built && (rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, bm, rs.tile_req, rs.tile_item0, rs.tile_cnt, rs.n_tiles,
+                                                 rs.req_tile0)))
         return rc;
-    launch_fm2t_user(ctx, m, d_user, d_ufids, n_req, true, rs.c1, rs.fm_user);
     MlpArgs a{};
     a.tile_req = rs.tile_req;
     a.tile_item0 = rs.tile_item0;
