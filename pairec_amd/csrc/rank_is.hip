@@ -32,7 +32,7 @@ namespace pg {
 // flight under the MFMAs), its candidate rows a trip earlier, its descriptor a trip before that; the request's FM prefix
 // and user-tower output sit in a wave-private LDS cache refilled when the request changes (~150 tiles).
 // Measured (256 x 5 000 random candidates of a 20 M-item catalogue, one MI355X): rank stage 0.226-0.230 ms against
-// fm2t_irs_kernel's 0.246-0.262 on the same box, 0.227 in bench.py's leg (0.241); with every candidate = row 0 0.15 ms
+// fm2t_irs_kernel's 0.246-0.262 on the same box, 0.219-0.227 in bench.py's leg (0.241); with every candidate = row 0 0.15 ms
 // (0.19).  The gather + FM sums alone (-DPG_ISW_GATHER_ONLY) take 0.171 ms = 5.3 TB/s of record lines: the towers' LDS
 // and MFMA traffic costs the memory side a quarter of that (waves wait 55 % of their lifetime for their records, all
 // 2 048 of them with 18 KB in flight).  Tried: twelve waves (168 registers: 99 spilled dwords with the prefetch, 0.28 ms
@@ -268,15 +268,27 @@ __global__ __launch_bounds__(64 * kIsWaves, 1) void fm2t_isw_kernel(MlpArgs a) {
             }
             bf16x8 wf[KS1];
 #pragma unroll
+#ifdef PG_ISW_NO_LDSW                                           // (developer experiment: the towers without their LDS traffic — wrong results)
+            for (int ks = 0; ks < KS1; ++ks) wf[ks] = xb[(ks + nb) & 7];
+#else
             for (int ks = 0; ks < KS1; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(W1S + (size_t)(nb * KS1 + ks) * 1024 + l_ * 16);
+#endif
             bf16x8 w2f[2][2];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int nb2 = 0; nb2 < 2; ++nb2)
+#ifdef PG_ISW_NO_LDSW
+                    w2f[u][nb2] = xb[(u * 2 + nb2 + nb) & 7];
+#else
                     w2f[u][nb2] = *reinterpret_cast<const bf16x8*>(W2S + (size_t)(nb2 * KS2 + 2 * nb + u) * 1024 + l_ * 16);
+#endif
 #pragma unroll
+#ifdef PG_ISW_NO_MFMA                                           // (developer experiment: the LDS traffic without the MFMAs — wrong results)
+            for (int ks = 0; ks < KS1; ++ks) acc[ks] += (float)wf[ks][0] * (float)xb[ks][1];
+#else
             for (int ks = 0; ks < KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xb[ks], acc, 0, 0, 0);
+#endif
             // relu -> bf16 -> the two k-steps' B fragments of layer 2
             uint32_t pk[4][2];
 #pragma unroll
@@ -291,7 +303,11 @@ __global__ __launch_bounds__(64 * kIsWaves, 1) void fm2t_isw_kernel(MlpArgs a) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const bf16x8 hb = __builtin_bit_cast(bf16x8, u32x4{pk[2 * u][0], pk[2 * u][1], pk[2 * u + 1][0], pk[2 * u + 1][1]});
 #pragma unroll
+#ifdef PG_ISW_NO_MFMA
+                for (int nb2 = 0; nb2 < 2; ++nb2) acc2[nb2][u] += (float)w2f[u][nb2][0] * (float)hb[1];
+#else
                 for (int nb2 = 0; nb2 < 2; ++nb2) acc2[nb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[u][nb2], hb, acc2[nb2], 0, 0, 0);
+#endif
             }
         }
         // ---- head: chain 0 over output columns 0..31 (from the FM term), chain 1 over 32..63 (from 0), both ascending; a
