@@ -106,7 +106,8 @@ while time.time() < t_end:
             if desc["kind"] == "dpp" and first >= 0 and len(got) == len(want):
                 with np.errstate(all="ignore"):
                     gap = dpp_gap_at(L, [int(x) for x in want[:first]], window if topn > window else max(topn, 1), int(got[first]), int(want[first]))
-            if gap is not None and gap < 1e-9:
+            if gap is not None and (gap < 1e-9 or gap != gap):      # (NaN: a pick of the window itself had a non-positive gain — an exact
+                # duplicate of an earlier pick: sqrt of -1e-17 vs +1e-17 —, every gain behind it is NaN in the restatement too)
                 # exp(alpha r) comes from the device's libm here and from glibc in the oracle (<= 1 ulp apart, as Go's own Exp is
                 # from both): where two candidates' gains agree to rounding noise — exact duplicates, more picks in a window than
                 # the kernel's rank — the argmax may fall either way.  Counted, not failed.
