@@ -35,15 +35,22 @@ struct BitonicLds {
 
 // P: power of two, 512 <= P <= 8192; threads t < P/8 are active (whole waves), every thread of the
 // 1024-thread workgroup must call (barriers).  WITH_IDX = false ignores ix (keys are unique).
+// n_real: elements at positions >= n_real are padding — all equal and not below any real key.  In phase kk elements stay
+// inside their aligned block of kk, so a block that starts at or behind n_real holds padding only and has nothing to
+// sort: a wave whose 512 elements lie in such blocks skips the phase's compare-exchanges (not its barriers).  5 000 of
+// 8 192: six of sixteen waves idle through the 55 stages up to kk = 1024, four through the 11 of kk = 2048 — the network is
+// VALU-bound, four waves per SIMD.
 template <bool WITH_IDX>
 __device__ __forceinline__ void bitonic_sort_reg(uint64_t (&k)[kBitonicE], uint32_t (&ix)[kBitonicE], uint32_t P,
-                                                 BitonicLds& lds) {
+                                                 BitonicLds& lds, uint32_t n_real = 0xFFFFFFFFu) {
     const uint32_t t = threadIdx.x;
-    const bool act = t < P / kBitonicE;
+    const bool act_all = t < P / kBitonicE;
+    const uint32_t wbase = (t & ~63u) * kBitonicE;        // this wave's first element
     auto lt = [](uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
         return WITH_IDX ? (ka < kb || (ka == kb && ia < ib)) : (ka < kb);
     };
     for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+        const bool act = act_all && (kk >= 64u * kBitonicE ? (wbase & ~(kk - 1)) : wbase) < n_real;    // (wave-uniform)
         // ---- partners in other threads (j >= 8, so kk >= 16): direction is per thread
         const bool dir = (t & (kk / kBitonicE)) == 0;     // this thread's sub-sequence ascends
         for (uint32_t j = kk >> 1; j >= (uint32_t)kBitonicE; j >>= 1) {

@@ -1740,7 +1740,7 @@ __global__ __launch_bounds__(1024) void final_kernel_reg(const uint64_t* __restr
         k[u] = (i < n) ? ~in[i] : ~0ull;               // descending = ascending on the complement; pad last
         ix[u] = 0;
     }
-    bitonic_sort_reg<false>(k, ix, P, lds);
+    bitonic_sort_reg<false>(k, ix, P, lds, n);
 #pragma unroll
     for (int u = 0; u < kBitonicE; ++u) {
         const uint32_t i = t * kBitonicE + u;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(1024) void sort_kernel_reg(const double* __restrict
             ix[u] = 0xFFFFFFFFu;
         }
     }
-    bitonic_sort_reg<true>(k, ix, P, lds);
+    bitonic_sort_reg<true>(k, ix, P, lds, n);
     if (act) {
 #pragma unroll
         for (int u = 0; u < kBitonicE; ++u) {
