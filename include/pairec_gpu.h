@@ -45,7 +45,13 @@ typedef enum {
                                 work it belonged to still completes for the other callers of its batch */
 } pg_status;
 
-typedef enum { PG_PREC_F32 = 0, PG_PREC_BF16 = 1 } pg_prec;
+/* Precision of a rank model's two matrix layers.  The reference hands model outputs on as fp32 widened to f64
+ * (algorithm/eas/easyrec_response.go:479-483, eas/tf_response.go:55-59).
+ *   PG_PREC_F32    fp32 MFMA, bit-defined (a k-ordered fmaf chain): the specification.
+ *   PG_PREC_BF16   operands rounded to bf16, fp32 accumulation: fastest; scores within ~4e-5 of the fp32 path.
+ *   PG_PREC_BF16X3 "split bf16": every operand as hi + lo bf16, three products per term into the fp32 accumulator, nothing
+ *                  else rounded: scores within 1e-5 of PG_PREC_F32 (observed ~1e-6) at the bf16 matrix pipe's speed / 3. */
+typedef enum { PG_PREC_F32 = 0, PG_PREC_BF16 = 1, PG_PREC_BF16X3 = 2 } pg_prec;
 typedef enum { PG_MODEL_DNN3 = 1, PG_MODEL_FM_TWOTOWER = 2, PG_MODEL_DNN3_MULTI = 3 } pg_model_kind;
 
 const char* pg_last_error(void);

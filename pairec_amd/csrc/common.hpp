@@ -164,6 +164,8 @@ struct pg_model {
     float* ub2 = nullptr;
     void* w1p = nullptr;    // packed item-side layer 1
     void* w2p = nullptr;    // packed layer 2
+    void* w1p_lo = nullptr; // PG_PREC_BF16X3: the lo fragments (inside the w1p / w2p allocations)
+    void* w2p_lo = nullptr;
     float* c1_shared = nullptr;   // two-tower: ib1
     float* b2 = nullptr;
     float* w3 = nullptr;    // DNN3 head(s): [n_out][h2]

@@ -14,6 +14,10 @@
 //   two-tower : x = concat of 8 item-field embeddings, c1 = ib1, w3 = user-tower output, bias3=y_fm
 // PG_PREC_BF16: operands bf16, fp32 accumulate on v_mfma_f32_32x32x16_bf16.
 // PG_PREC_F32 : v_mfma_f32_32x32x2_f32, which is a k-ordered fmaf chain → bit-reproducible.
+// PG_PREC_BF16X3: the fp32 specification on the bf16 matrix pipe — activations and weights as hi + lo bf16 pairs,
+//               three products (lo·hi, hi·lo, hi·hi) into the fp32 accumulator; scores within 1e-5 of the fp32 path
+//               (observed ~1e-6), no operand rounding anywhere else.  Model outputs are fp32 widened to f64 in the
+//               reference (algorithm/eas/easyrec_response.go:479-483, eas/tf_response.go:55-59).
 //
 // Tiling: workgroup = 4 waves = 128 items; layer 1 is produced in chunks of 128 hidden columns
 // that go through LDS (as the A operand of layer 2) and are consumed immediately, so h1 never
@@ -32,14 +36,40 @@ namespace pg {
 // TR = true swaps the MFMA operands: the accumulator block then holds C^T — lane ↔ item row, register r ↔
 // column (r&3) + 8(r>>2) + 4h of the n-block — so a lane owns 4 consecutive columns of one item, which
 // packs into one LDS store (the products and the k order are unchanged, so the bits are too).
+// PREC 2 (split bf16): `tile` is the hi tile, the lo tile lies tile_lo bytes on; wpk_lo = the lo fragments.
 template <int PREC, int MB, int NB, int K, bool TR, typename FragOff>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[MB][NB], const char* tile, int mrow0,
-                                          const char* wpk, FragOff frag, int lane) {
+                                          const char* wpk, FragOff frag, int lane, int tile_lo = 0,
+                                          const char* wpk_lo = nullptr) {
     constexpr int ES = PREC ? 2 : 4;
     constexpr int ROWB = K * ES;
     constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
     const int i32 = lane & 31, h = lane >> 5;
-    if constexpr (PREC == 1) {
+    if constexpr (PREC == 2) {
+        static_assert(TR, "split bf16: transposed accumulators only");
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks) {
+            bf16x8 bh[NB], bl[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bh[nb] = *reinterpret_cast<const bf16x8*>(wpk + frag(nb, ks) + lane * 16);
+                bl[nb] = *reinterpret_cast<const bf16x8*>(wpk_lo + frag(nb, ks) + lane * 16);
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int row = mrow0 + mb * 32 + i32;
+                const char* const ap = tile + row * ROWB + ((((ks * 2 + h) ^ (row & SW))) << 4);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + tile_lo);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {      // the two corrections first, the leading product last
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nb], ah, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nb], al, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nb], ah, acc[mb][nb], 0, 0, 0);
+                }
+            }
+        }
+    } else if constexpr (PREC == 1) {
 #pragma unroll
         for (int ks = 0; ks < K / 16; ++ks) {
             bf16x8 bf[NB];
@@ -120,8 +150,8 @@ __device__ __forceinline__ void gemm_tile_pre(f32x16 (&acc)[MB][NB], const char*
 // LDS of one workgroup: X tile + H1 chunk tile, aliased after the GEMMs by the fp32 H2 tile of one
 // epilogue pass (H2 / EP columns, padded rows); then w3 and the per-item head bias.
 constexpr size_t mlp_lds_bytes(int prec, int h2, int ch, int ep, int bm = kBM) {
-    const size_t es = prec ? 2 : 4;
-    const size_t nh1 = (prec && (size_t)bm * (kDIN + 2 * ch) * es <= 72 * 1024) ? 2 : 1;   // as NH1 in mlp_kernel
+    const size_t es = prec == 1 ? 2 : 4;               // (split bf16: a hi and a lo tile of 2 B per element)
+    const size_t nh1 = (prec == 1 && (size_t)bm * (kDIN + 2 * ch) * es <= 72 * 1024) ? 2 : 1;   // as NH1 in mlp_kernel
     const size_t tiles = (size_t)bm * (kDIN + nh1 * ch) * es;
     const size_t h2t = (size_t)bm * (h2 / ep + 4) * 4;
     return (tiles > h2t ? tiles : h2t) + (size_t)h2 * 4 + (size_t)bm * 4;
@@ -140,14 +170,17 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
     constexpr int L1NB = CH / 32 / WN;
     constexpr int L2NB = H2 / 32 / WN;
     constexpr int ES = PREC ? 2 : 4;
-    constexpr int TILE_B = BM * kDIN * ES;
-    constexpr int H1_B = BM * CH * ES;
+    constexpr int PL = PREC == 2 ? 2 : 1;              // operand tiles per matrix (split bf16: hi, then lo)
+    constexpr int X_LO = BM * kDIN * ES;               // offset of the lo tile (PREC 2)
+    constexpr int H_LO = BM * CH * ES;
+    constexpr int TILE_B = BM * kDIN * ES * PL;
+    constexpr int H1_B = BM * CH * ES * PL;
     constexpr int NCHUNK = H1 / CH;
     constexpr int KG1 = PREC ? kDIN / 16 : kDIN / 8;   // k-groups (fragments) of the 128-deep layer-1 GEMM
     constexpr int KGC = PREC ? CH / 16 : CH / 8;       // k-groups of one CH-deep layer-2 partial GEMM
     constexpr int HH = H2 / EP;                        // head columns per epilogue pass
     // H1 chunk tiles: double-buffered where two workgroups still fit a CU's 160 KB
-    constexpr int NH1 = (PREC && TILE_B + 2 * H1_B <= 72 * 1024) ? 2 : 1;
+    constexpr int NH1 = (PREC == 1 && TILE_B + 2 * H1_B <= 72 * 1024) ? 2 : 1;
     constexpr size_t REGION = (size_t)(TILE_B + NH1 * H1_B) > (size_t)BM * (HH + 4) * 4
                                   ? (size_t)(TILE_B + NH1 * H1_B) : (size_t)BM * (HH + 4) * 4;
     static_assert(L1NB >= 1 && L2NB >= 1 && MB >= 1, "bad wave layout");
@@ -207,7 +240,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int p = 0; p < NP; ++p) store_x_quad<PREC>(XT, p * 8 + (tid >> 5), c, v[p]);
+            for (int p = 0; p < NP; ++p) store_x_quad<PREC>(XT, p * 8 + (tid >> 5), c, v[p], X_LO);
         } else if constexpr (MODEL == 3) {
             // two-tower from MATERIALISED item records (pg_fm2t_item_rows_build): the item's field embeddings and linear
             // weights are one contiguous 544-B record found from the candidate row alone — no ids → rows second hop, five
@@ -265,7 +298,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                     s_[4 * j + 1] = s_[4 * j + 1] + x.y; q_[4 * j + 1] = __fmaf_rn(x.y, x.y, q_[4 * j + 1]);
                     s_[4 * j + 2] = s_[4 * j + 2] + x.z; q_[4 * j + 2] = __fmaf_rn(x.z, x.z, q_[4 * j + 2]);
                     s_[4 * j + 3] = s_[4 * j + 3] + x.w; q_[4 * j + 3] = __fmaf_rn(x.w, x.w, q_[4 * j + 3]);
-                    store_x_quad<PREC>(XT, (int)r, f * QPF + 2 * j + kh, x);
+                    store_x_quad<PREC>(XT, (int)r, f * QPF + 2 * j + kh, x, X_LO);
                 }
 #pragma unroll
             for (int k = 0; k < HK; ++k) s_[k] = __fmaf_rn(s_[k], s_[k], -q_[k]);
@@ -342,7 +375,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                         s_[4 * j + 1] = s_[4 * j + 1] + x.y; q_[4 * j + 1] = __fmaf_rn(x.y, x.y, q_[4 * j + 1]);
                         s_[4 * j + 2] = s_[4 * j + 2] + x.z; q_[4 * j + 2] = __fmaf_rn(x.z, x.z, q_[4 * j + 2]);
                         s_[4 * j + 3] = s_[4 * j + 3] + x.w; q_[4 * j + 3] = __fmaf_rn(x.w, x.w, q_[4 * j + 3]);
-                        store_x_quad<PREC>(XT, (int)r, f * QPF + j, x);
+                        store_x_quad<PREC>(XT, (int)r, f * QPF + j, x, X_LO);
                     }
                 }
 #pragma unroll
@@ -408,7 +441,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
             load_bfrags<L2NB, KGC>(b2f, reinterpret_cast<const char*>(a.w2p), frag2(chunk), lane);
         } else {
             gemm_tile<PREC, MB, L1NB, kDIN, true>(acc1, XT, mrow0, reinterpret_cast<const char*>(a.w1p),
-                                                  frag1(chunk), lane);
+                                                  frag1(chunk), lane, X_LO, reinterpret_cast<const char*>(a.w1p_lo));
         }
         MLP_MARK(2)
         // relu → P() → H1 chunk tile (A operand of layer 2): one packed store per 4 columns
@@ -423,7 +456,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                     const float v0 = acc1[mb][nb][4 * g + 0], v1 = acc1[mb][nb][4 * g + 1];
                     const float v2 = acc1[mb][nb][4 * g + 2], v3 = acc1[mb][nb][4 * g + 3];
                     store_h_quad<PREC, CH>(H1T, row, col, v0 > 0.0f ? v0 : 0.0f, v1 > 0.0f ? v1 : 0.0f,
-                                           v2 > 0.0f ? v2 : 0.0f, v3 > 0.0f ? v3 : 0.0f);
+                                           v2 > 0.0f ? v2 : 0.0f, v3 > 0.0f ? v3 : 0.0f, H_LO);
                 }
         MLP_MARK(3)
         __syncthreads();
@@ -435,7 +468,7 @@ __global__ __launch_bounds__(256, OCC) void mlp_kernel(MlpArgs a) {
                 load_bfrags<L1NB, KG1>(b1f, reinterpret_cast<const char*>(a.w1p), frag1(chunk + 1), lane);
         } else {
             gemm_tile<PREC, MB, L2NB, CH, true>(acc2, H1T, mrow0, reinterpret_cast<const char*>(a.w2p),
-                                                frag2(chunk), lane);
+                                                frag2(chunk), lane, H_LO, reinterpret_cast<const char*>(a.w2p_lo));
         }
         MLP_MARK(5)
         if (NH1 == 1 || chunk + 1 == NCHUNK) __syncthreads();
@@ -902,9 +935,11 @@ namespace pg {
 // Pack W[K][N] (row-major, k major) into MFMA B-fragment order, 1 KiB per (n-block, k-group).
 //   bf16: fragment (nbg, ks): lane (j,hk) holds W[ks*16 + 8*hk + e][nbg*32 + j], e = 0..7
 //   f32 : fragment (nbg, g8): lane (j,h)  holds W[g8*8 + 2*st + h][nbg*32 + j], st = 0..3
+//   split bf16 (prec 2): the bf16 layout twice — every hi fragment, then every lo fragment (lo = RNE(w - hi))
 static std::vector<uint8_t> pack_weights(const float* w, uint32_t K, uint32_t N, int prec) {
     const uint32_t kg = prec ? K / 16 : K / 8;
-    std::vector<uint8_t> out((size_t)(N / 32) * kg * 1024);
+    const size_t plane = (size_t)(N / 32) * kg * 1024;
+    std::vector<uint8_t> out(plane * (prec == 2 ? 2 : 1));
     for (uint32_t nbg = 0; nbg < N / 32; ++nbg)
         for (uint32_t g = 0; g < kg; ++g) {
             uint8_t* frag = out.data() + ((size_t)nbg * kg + g) * 1024;
@@ -912,8 +947,12 @@ static std::vector<uint8_t> pack_weights(const float* w, uint32_t K, uint32_t N,
                 const uint32_t j = lane & 31, hh = lane >> 5;
                 if (prec) {
                     uint16_t* d = reinterpret_cast<uint16_t*>(frag + lane * 16);
-                    for (uint32_t e = 0; e < 8; ++e)
-                        d[e] = f32_to_bf16_rne(w[(size_t)(g * 16 + 8 * hh + e) * N + nbg * 32 + j]);
+                    uint16_t* dl = reinterpret_cast<uint16_t*>(frag + plane + lane * 16);
+                    for (uint32_t e = 0; e < 8; ++e) {
+                        const float v = w[(size_t)(g * 16 + 8 * hh + e) * N + nbg * 32 + j];
+                        d[e] = f32_to_bf16_rne(v);
+                        if (prec == 2) dl[e] = f32_to_bf16_rne(v - bf16_to_f32(d[e]));
+                    }
                 } else {
                     float* d = reinterpret_cast<float*>(frag + lane * 16);
                     for (uint32_t st = 0; st < 4; ++st)
@@ -983,6 +1022,12 @@ static int launch_dnn3_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
         constexpr size_t lds = mlp_lds_bytes(1, H2, 64, 2);
         if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, H1, H2, true, 2, 2, 1, 64, 2, OCC>, lds))) return rc;
         mlp_kernel<1, H1, H2, true, 2, 2, 1, 64, 2, OCC><<<grid, 256, lds, ctx->stream>>>(a);
+    } else if constexpr (PREC == 2) {
+        // split bf16, the general form (the benchmark's shape has a kernel of its own, rank_x3.hip): the bf16 tiling with
+        // a hi and a lo operand tile, one workgroup per CU's worth of registers
+        constexpr size_t lds = mlp_lds_bytes(2, H2, 64, 2);
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<2, H1, H2, true, 2, 2, 1, 64, 2, 1>, lds))) return rc;
+        mlp_kernel<2, H1, H2, true, 2, 2, 1, 64, 2, 1><<<grid, 256, lds, ctx->stream>>>(a);
     } else {
         constexpr int EP = H2 > 256 ? 2 : 1;
         constexpr size_t lds = mlp_lds_bytes(0, H2, 128, EP);
@@ -1023,6 +1068,10 @@ static int launch_fm2t_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
             return PG_OK;
 #endif
             mlp_kernel<1, TH, TO, false, 2, 2, 3, 128, 1, 2, FK, kFmBM><<<grid, 256, lds, ctx->stream>>>(a);
+        } else if constexpr (PREC == 2) {
+            constexpr size_t lds = mlp_lds_bytes(2, TO, 128, 1, kFmBM);
+            if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<2, TH, TO, false, 2, 2, 3, 128, 1, 1, FK, kFmBM>, lds))) return rc;
+            mlp_kernel<2, TH, TO, false, 2, 2, 3, 128, 1, 1, FK, kFmBM><<<grid, 256, lds, ctx->stream>>>(a);
         } else {
             constexpr size_t lds = mlp_lds_bytes(0, TO, 128, 1);
             if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, TH, TO, false, 2, 2, 3, 128, 1, 1, FK>, lds))) return rc;
@@ -1036,6 +1085,10 @@ static int launch_fm2t_mlp(pg_ctx* ctx, const MlpArgs& a, uint32_t grid) {
         constexpr size_t lds = mlp_lds_bytes(1, TO, 128, 1, kFmBM);
         if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<1, TH, TO, false, 2, 2, 2, 128, 1, 2, FK, kFmBM>, lds))) return rc;
         mlp_kernel<1, TH, TO, false, 2, 2, 2, 128, 1, 2, FK, kFmBM><<<grid, 256, lds, ctx->stream>>>(a);
+    } else if constexpr (PREC == 2) {
+        constexpr size_t lds = mlp_lds_bytes(2, TO, 128, 1, kFmBM);
+        if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<2, TH, TO, false, 2, 2, 2, 128, 1, 1, FK, kFmBM>, lds))) return rc;
+        mlp_kernel<2, TH, TO, false, 2, 2, 2, 128, 1, 1, FK, kFmBM><<<grid, 256, lds, ctx->stream>>>(a);
     } else {
         constexpr size_t lds = mlp_lds_bytes(0, TO, 128, 1);
         if ((rc = ensure_dyn_lds(ctx, (const void*)mlp_kernel<0, TH, TO, false, 2, 2, 2, 128, 1, 1, FK>, lds))) return rc;
@@ -1061,7 +1114,9 @@ static bool fm2t_shape_ok(uint32_t th, uint32_t to, uint32_t k) {
 }
 static int dispatch_dnn3_mlp(pg_ctx* ctx, const pg_model* m, const MlpArgs& a, uint32_t grid) {
 #define X(A, B)                                                                                          \
-    if (m->h1 == A && m->h2 == B) return m->prec ? launch_dnn3_mlp<1, A, B>(ctx, a, grid) : launch_dnn3_mlp<0, A, B>(ctx, a, grid);
+    if (m->h1 == A && m->h2 == B)                                                                        \
+        return m->prec == 2 ? launch_dnn3_mlp<2, A, B>(ctx, a, grid)                                      \
+                            : (m->prec ? launch_dnn3_mlp<1, A, B>(ctx, a, grid) : launch_dnn3_mlp<0, A, B>(ctx, a, grid));
     PG_DNN3_SHAPES(X)
 #undef X
     set_error("rank: DNN3 shape ->%u->%u has no kernel", m->h1, m->h2);
@@ -1070,7 +1125,8 @@ static int dispatch_dnn3_mlp(pg_ctx* ctx, const pg_model* m, const MlpArgs& a, u
 static int dispatch_fm2t_mlp(pg_ctx* ctx, const pg_model* m, const MlpArgs& a, uint32_t grid) {
 #define X(A, B, C)                                                                                       \
     if (m->th == A && m->to == B && m->k == C)                                                           \
-        return m->prec ? launch_fm2t_mlp<1, A, B, C>(ctx, a, grid) : launch_fm2t_mlp<0, A, B, C>(ctx, a, grid);
+        return m->prec == 2 ? launch_fm2t_mlp<2, A, B, C>(ctx, a, grid)                                   \
+                            : (m->prec ? launch_fm2t_mlp<1, A, B, C>(ctx, a, grid) : launch_fm2t_mlp<0, A, B, C>(ctx, a, grid));
     PG_FM2T_SHAPES(X)
 #undef X
     set_error("rank: two-tower shape ->%u->%u, k=%u has no kernel", m->th, m->to, m->k);
@@ -1087,10 +1143,12 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->h1, &rs))) return rc;
     const bool no_ws = ctx->knobs.rank_no_ws;        // A/B switch: the streaming kernel
     // the weights-stationary kernel is built for the benchmark's shape: [d_user + 128] -> 512 -> 256 -> 1 in bf16
-    const bool ws = m->prec && !no_ws && m->h1 == 512 && m->h2 == 256 && t->dim == 128;
+    const bool ws = m->prec == 1 && !no_ws && m->h1 == 512 && m->h2 == 256 && t->dim == 128;
     // the small shapes, gather-bound: the whole model in registers (rank_rs.hip)
-    const bool rs_k = m->prec && !no_ws && t->dim == 128 && dnn3_rs_shape(m->h1, m->h2);
-    const bool ls_k = m->prec && !no_ws && t->dim == 128 && dnn3_ls_shape(m->h1, m->h2);
+    const bool rs_k = m->prec == 1 && !no_ws && t->dim == 128 && dnn3_rs_shape(m->h1, m->h2);
+    const bool ls_k = m->prec == 1 && !no_ws && t->dim == 128 && dnn3_ls_shape(m->h1, m->h2);
+    // split bf16: the two-role kernel (rank_x3.hip), 128-item tiles; 1024-512 and 64-wide tables take the general form
+    const bool x3_k = m->prec == 2 && !no_ws && t->dim == 128 && dnn3_x3_shape(m->h1, m->h2);
     const uint32_t grid128 = n_items / kBM + n_req;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     if ((rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, ws || rs_k ? (uint32_t)kWsItems : (uint32_t)kBM, rs.tile_req, rs.tile_item0,
@@ -1115,6 +1173,8 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     a.b2 = m->b2;
     a.w1p = m->w1p;
     a.w2p = m->w2p;
+    a.w1p_lo = m->w1p_lo;
+    a.w2p_lo = m->w2p_lo;
     a.out = d_out;
     a.n_out = m->n_out;
     a.out_stride = out_stride ? out_stride : (size_t)n_items;
@@ -1133,6 +1193,8 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
         if ((rc = launch_dnn3_rs(ctx, m->h1, m->h2, a))) return rc;
     } else if (ls_k) {
         if ((rc = launch_dnn3_ls(ctx, m->h1, m->h2, a))) return rc;
+    } else if (x3_k) {
+        if ((rc = launch_dnn3_x3(ctx, m->h1, m->h2, a))) return rc;
     } else if ((rc = dispatch_dnn3_mlp(ctx, m, a, grid128))) {
         return rc;
     }
@@ -1188,6 +1250,8 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     a.b2 = m->b2;
     a.w1p = m->w1p;
     a.w2p = m->w2p;
+    a.w1p_lo = m->w1p_lo;
+    a.w2p_lo = m->w2p_lo;
     a.out = d_out;
     a.sink = rs.sink;
     if (isw) {
@@ -1312,7 +1376,7 @@ extern "C" {
 int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blob, size_t len,
                   pg_model** out) {
     PG_REQUIRE(ctx && blob && out, "pg_model_load: NULL argument");
-    PG_REQUIRE(prec == PG_PREC_F32 || prec == PG_PREC_BF16, "pg_model_load: bad precision %d", (int)prec);
+    PG_REQUIRE(prec == PG_PREC_F32 || prec == PG_PREC_BF16 || prec == PG_PREC_BF16X3, "pg_model_load: bad precision %d", (int)prec);
     std::lock_guard<std::mutex> g(ctx->mu);
     PG_HIP(hipSetDevice(ctx->device));
     const uint8_t* p = (const uint8_t*)blob;
@@ -1365,6 +1429,10 @@ int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blo
         if ((rc = pg::upload(ctx, m, b1, m->h1 * 4, (void**)&m->b1))) return fail(rc);
         if ((rc = pg::upload(ctx, m, w1p.data(), w1p.size(), &m->w1p))) return fail(rc);
         if ((rc = pg::upload(ctx, m, w2p.data(), w2p.size(), &m->w2p))) return fail(rc);
+        if (m->prec == 2) {                          // split bf16: the lo fragments follow the hi fragments
+            m->w1p_lo = (char*)m->w1p + w1p.size() / 2;
+            m->w2p_lo = (char*)m->w2p + w2p.size() / 2;
+        }
         if ((rc = pg::upload(ctx, m, b2, m->h2 * 4, (void**)&m->b2))) return fail(rc);
         if ((rc = pg::upload(ctx, m, w3t.data(), w3t.size() * 4, (void**)&m->w3))) return fail(rc);
         if ((rc = pg::upload(ctx, m, b3, m->n_out * 4, (void**)&m->b3v))) return fail(rc);
@@ -1408,6 +1476,10 @@ int pg_model_load(pg_ctx* ctx, pg_model_kind kind, pg_prec prec, const void* blo
         if ((rc = pg::upload(ctx, m, iw1p.data(), iw1p.size(), &m->w1p))) return fail(rc);
         if ((rc = pg::upload(ctx, m, ib1, m->th * 4, (void**)&m->c1_shared))) return fail(rc);
         if ((rc = pg::upload(ctx, m, iw2p.data(), iw2p.size(), &m->w2p))) return fail(rc);
+        if (m->prec == 2) {
+            m->w1p_lo = (char*)m->w1p + iw1p.size() / 2;
+            m->w2p_lo = (char*)m->w2p + iw2p.size() / 2;
+        }
         if ((rc = pg::upload(ctx, m, ib2, m->to * 4, (void**)&m->b2))) return fail(rc);
         if ((rc = pg::upload(ctx, m, fields, field_fl * 4, (void**)&m->fields))) return fail(rc);
         std::vector<const float*> pe(nf), pl(nf);

@@ -32,8 +32,23 @@ __host__ __device__ __forceinline__ float bf16_to_f32(uint16_t v) {
     return f;
 #endif
 }
+// operand rounding of a precision mode: 0 = fp32, 1 = bf16 (RNE), 2 = split bf16 (x = hi + lo, three MFMA products:
+// nothing is rounded on the scalar side — the mode's specification is the fp32 one)
 __host__ __device__ __forceinline__ float round_prec(float x, int prec) {
-    return prec ? bf16_to_f32(f32_to_bf16_rne(x)) : x;
+    return prec == 1 ? bf16_to_f32(f32_to_bf16_rne(x)) : x;
+}
+
+// PG_PREC_BF16X3: a pair of fp32 values as two packed bf16 pairs, hi = RNE(x), lo = RNE(x - hi) — x - hi is exact in
+// fp32, so |x - hi - lo| <= 2^-17 |x|; with the weights split the same way, hi*hi + hi*lo + lo*hi leaves a relative
+// error of ~2^-16 per product (the dropped lo*lo term), at fp32 accumulation.  A non-finite or > bf16-max value makes
+// hi infinite and lo NaN: such inputs score NaN in this mode.
+__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));            // v_cvt_pk_bf16_f32 (RNE)
+    const f32x2_ r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_));
 }
 
 constexpr int kBM = 128;       // items per workgroup tile
@@ -85,16 +100,26 @@ struct MlpArgs {
     size_t out_stride;
     const float* b3v;
     float* head_part;
-    // pre-packed weights
+    // pre-packed weights (PG_PREC_BF16X3: the hi fragments; the lo fragments follow at w1p_lo / w2p_lo)
     const void* w1p;
     const void* w2p;
+    const void* w1p_lo;
+    const void* w2p_lo;
     float* out;
     float* sink;                     // >= 1024 floats nobody reads (fm2t_irs_kernel's always-issued stores)
 };
 
+// (PREC 2: the hi tile has the bf16 layout, the lo tile follows it `lo_off` bytes on)
 template <int PREC>
-__device__ __forceinline__ void store_x_quad(char* tile, int row, int c, float4 v) {
-    if constexpr (PREC == 1) {
+__device__ __forceinline__ void store_x_quad(char* tile, int row, int c, float4 v, int lo_off = 0) {
+    if constexpr (PREC == 2) {
+        uint2 ph, pl;
+        split_bf16x2(v.x, v.y, ph.x, pl.x);
+        split_bf16x2(v.z, v.w, ph.y, pl.y);
+        char* const d = tile + row * 256 + ((((c >> 1) ^ (row & 15))) << 4) + (c & 1) * 8;
+        *reinterpret_cast<uint2*>(d) = ph;
+        *reinterpret_cast<uint2*>(d + lo_off) = pl;
+    } else if constexpr (PREC == 1) {
         // 4 bf16 = 8 B at element 4c: 16-B quad index c/2, XOR-swizzled by row
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -124,11 +149,18 @@ __device__ __forceinline__ void store_h_elem(char* tile, int row, int col, float
 
 // 4 consecutive columns col..col+3 (col % 4 == 0) of one row, after relu and operand rounding
 template <int PREC, int K>
-__device__ __forceinline__ void store_h_quad(char* tile, int row, int col, float v0, float v1, float v2, float v3) {
+__device__ __forceinline__ void store_h_quad(char* tile, int row, int col, float v0, float v1, float v2, float v3, int lo_off = 0) {
     constexpr int ES = PREC ? 2 : 4;
     constexpr int ROWB = K * ES;
     constexpr int SW = (ROWB / 16 < 16 ? ROWB / 16 : 16) - 1;
-    if constexpr (PREC == 1) {
+    if constexpr (PREC == 2) {
+        uint2 ph, pl;
+        split_bf16x2(v0, v1, ph.x, pl.x);
+        split_bf16x2(v2, v3, ph.y, pl.y);
+        char* const d = tile + row * ROWB + ((((col >> 3) ^ (row & SW))) << 4) + (col & 7) * 2;
+        *reinterpret_cast<uint2*>(d) = ph;
+        *reinterpret_cast<uint2*>(d + lo_off) = pl;
+    } else if constexpr (PREC == 1) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         const f32x2 lo = {v0, v1}, hi = {v2, v3};
@@ -150,6 +182,10 @@ int launch_dnn3_rs(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
 // ... and the eight-wave streamed-weights kernel for 1024-512; 128-item tiles
 bool dnn3_ls_shape(uint32_t h1, uint32_t h2);
 int launch_dnn3_ls(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
+
+// rank_x3.hip: DNN3 in PG_PREC_BF16X3 (split bf16) — 128-item tiles, layer-1 and layer-2 waves sharing each SIMD
+bool dnn3_x3_shape(uint32_t h1, uint32_t h2);
+int launch_dnn3_x3(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
 
 // rank_ir.hip: FM + two-tower over materialised item records for the benchmark's shape (towers 256-64, 8 fields x 16, bf16):
 // weights stationary in registers, records two tiles ahead; 64-item tiles

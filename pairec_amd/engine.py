@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 MODEL_DNN3, MODEL_FM_TWOTOWER, MODEL_DNN3_MULTI = 1, 2, 3
 MAX_QUERIES = 256         # per table pass (32 when dim > 128)
 
