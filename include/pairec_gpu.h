@@ -223,6 +223,16 @@ int pg_fm2t_user_embedding_dev(pg_ctx* ctx, const pg_model* m, const float* d_us
 int pg_expr_compile(const char* source, pg_expr** out);
 int pg_expr_free(pg_expr* e);
 int pg_expr_num_vars(const pg_expr* e);
+/* RankConfig.ScoreRewrite (recconf/recconf.go:743; service/rank/rank_service.go:296-306,343-353): a map source → expression.
+ * Per item the reference evaluates EVERY source's expression over the item as the algorithms left it, collects the results
+ * in a map, writes them back with Item.AddAlgoScores (overwriting / adding algorithm scores named `source`) and only then
+ * evaluates RankScore.  Attach the scene's rewrites to its compiled RankScore; every pipeline that fuses scores with that
+ * expression (pg_recommend_*, the scene / group coalescers, pg_group_*) then evaluates them first, on the device, in f64:
+ * a RankScore variable naming a source reads the rewritten score, a rewrite's own variables read the un-rewritten ones
+ * (the scene's "<algo>" / "<algo>_<output>" planes and current_score).  exprs[i] == NULL: the source's expression did not
+ * compile — the reference logs it and scores 0 (rank_service.go:299-303,349-351).  The expressions are copied.
+ * pg_expr_eval[_dev] evaluate the bare expression over caller-made variables and know nothing of rewrites.  n = 0 removes. */
+int pg_expr_set_score_rewrites(pg_expr* rank_score, uint32_t n, const char* const* sources, const pg_expr* const* exprs);
 const char* pg_expr_var_name(const pg_expr* e, int i);
 int pg_expr_eval(pg_ctx* ctx, const pg_expr* e, const double* vars, uint32_t n_items,
                  double* out_scores);

@@ -702,20 +702,42 @@ def to_float(v, default: float) -> float:
     return default
 
 
-def fuse_scores(expr: str, items: List[OracleItem], ctx_params: Optional[Dict[str, float]] = None):
+def fuse_scores(expr: str, items: List[OracleItem], ctx_params: Optional[Dict[str, float]] = None,
+                score_rewrite: Optional[Dict[str, str]] = None):
     """rank_service.go:339-363: item.Score = ExprASTResult(ast, AstParameterData{ctx,item});
-    AB params win when non-zero (service/rank/ast_parameter_data.go:30-40)."""
-    ast = expr_parse(expr)
-    if ast is None:
+    AB params win when non-zero (service/rank/ast_parameter_data.go:30-40).
+    score_rewrite = RankConfig.ScoreRewrite (rank_service.go:296-306,343-353): per item every source's expression is
+    evaluated over the item as it stands, the results collected in a map, then written back with AddAlgoScores
+    (module/item.go:177-188) before RankScore; a source whose expression does not parse scores 0 (:299-303,349-351).
+    An empty RankScore skips both (:339)."""
+    if expr == "":
         return
+    try:
+        ast = expr_parse(expr)
+    except Exception:                                          # noqa: BLE001 — the reference logs and leaves exprAst nil (:291-294)
+        ast = None
     ctx_params = ctx_params or {}
+    rewrite_asts = {}
+    for source, src_expr in (score_rewrite or {}).items():
+        try:
+            rewrite_asts[source] = expr_parse(src_expr)
+        except Exception:                                      # noqa: BLE001 — logged, `continue` (:299-303)
+            pass
     for it in items:
         def lookup(name, it=it):
             v = ctx_params.get(name, 0.0)
             if v != 0:
                 return v
             return it.float_expr_data(name)
-        it.score = expr_eval(ast, lookup)
+        if score_rewrite:
+            scores = {}
+            for source in score_rewrite:
+                a = rewrite_asts.get(source)
+                scores[source] = expr_eval(a, lookup) if a is not None else 0.0
+            for name, s in scores.items():                     # AddAlgoScores
+                it.algo_scores[name] = float(s)
+        if ast is not None:
+            it.score = expr_eval(ast, lookup)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -522,7 +522,7 @@ int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
     call.n_planes = c->n_planes;
     call.e = c->e;
     call.var_src = c->var_src.data();
-    call.nv = (int)c->var_src.size();
+    call.nv = pg_expr_num_vars(c->e);
     call.d_queries = s->d_vec;
     call.d_ufids = s->d_ufid;
     call.ufid_stride = c->ufid_stride;
@@ -1007,12 +1007,14 @@ int pg_coalescer_create_scene(pg_ctx* ctx, const pg_table* t, const pg_scene_con
     for (int a = 0; a < c->n_algos; ++a) {
         const uint32_t heads = sc->algos[a].model->n_out;
         c->plane0[a] = c->n_planes;
+        // (for EVERY algorithm, before its names are pushed: a single-output one behind models that already fill the
+        // planes would write past names[] below — ADVICE r4)
+        if (c->n_planes + (int)heads > pg::kMaxPlanes) {
+            pg::set_error("pg_coalescer_create: the scene's models have more than %d outputs together", pg::kMaxPlanes);
+            delete c;
+            return PG_ERR_INVALID;
+        }
         if (heads > 1) {
-            if (c->n_planes + (int)heads > pg::kMaxPlanes) {
-                pg::set_error("pg_coalescer_create: the scene's models have more than %d outputs together", pg::kMaxPlanes);
-                delete c;
-                return PG_ERR_INVALID;
-            }
             for (uint32_t o = 0; o < heads; ++o) {
                 // (no names given: "<algo>_0", "<algo>_1", … — enough for a scene that only ranks)
                 const char* on = sc->algos[a].output_names ? sc->algos[a].output_names[o] : nullptr;

@@ -202,7 +202,15 @@ struct pg_ctx {
     bool own_stream = false;
     int num_cus = 256;
     std::mutex mu;               // serialises calls on this context
-    pg::Scratch scratch[14];     // named scratch slots (see users; 8 = the recommend pipeline's intermediates, 10 = its re-rank stage)
+    // named scratch slots (transient: a slot's contents are valid until the next reserve of the same slot on this context;
+    // users that share a slot are stages that never overlap on the context's one stream):
+    //   0 table upload staging / fm2t rows' gathered field ids     1 table / features host staging
+    //   2, 3 recall.hip candidate lists and thresholds             4 small status words (expr, misc, recall, recall_i4)
+    //   5 host-buffer entry points' staging (rank, recall, sort, dpp, ssd, expr)
+    //   6 rank tile table + request partials   7 sort / dpp / ssd work areas   8 recommend pipeline intermediates (post_scratch)
+    //   9 group.hip   10 re-rank stage (DPP candidates)   11 recall.hip: the screened pass's record regions
+    //   12, 13 recall.hip   14 rank_mlp.hip: head partials of the weights-stationary multi-head kernel   15 free
+    pg::Scratch scratch[16];
     std::mutex pool_mu;          // guards pipe_free
     std::vector<pg::PipeRun*> pipe_free;     // per-batch status blocks / events of the device-resident pipelines
     std::map<const void*, size_t> dyn_lds;   // kernels whose dynamic-LDS limit was raised on this device
@@ -377,6 +385,14 @@ int rank_fm2t_rows_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_features*
 int expr_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32_t n_items, double* d_out,
                              uint32_t* d_err, uint32_t items_per_flag);
 void set_expr_arith_error(const pg_expr* e);
+// RankConfig.ScoreRewrite attached to a RankScore expression (pg_expr_set_score_rewrites; expr.hip)
+constexpr int kMaxRewrites = 8;
+int expr_num_rewrites(const pg_expr* e);
+const char* expr_rewrite_source(const pg_expr* e, int r);
+int expr_rewrite_num_vars(const pg_expr* e, int r);
+const char* expr_rewrite_var_name(const pg_expr* e, int r, int i);
+int expr_rewrite_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, int r, const double* d_vars, uint32_t n_items, double* d_out,
+                                     uint32_t* d_err, uint32_t items_per_flag);
 int table_gather_locked(pg_ctx* ctx, const pg_table* t, const uint32_t* d_rows, uint32_t n, float* d_out);
 int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, const double* d_rel, uint32_t R, uint32_t n,
                    uint32_t d, uint32_t hook_dim, double alpha, uint32_t topn, uint32_t window, int normalize,

@@ -38,6 +38,15 @@ struct pg_expr {
     std::vector<std::string> vars;
     int max_depth = 0;
     bool empty = false;       // "" → no expression (GetExpAST returns nil)
+    // RankConfig.ScoreRewrite of the scene this RankScore belongs to (pg_expr_set_score_rewrites): evaluated by the
+    // recommend pipelines' fusion stage before the RankScore itself (pipeline.hip: post_fuse_sort_locked)
+    struct Rewrite {
+        std::string source;
+        bool failed = false;  // the source's expression did not compile in the reference: the score is 0 (rank_service.go:349-351)
+        std::vector<pg::Instr> prog;
+        std::vector<std::string> vars;
+    };
+    std::vector<Rewrite> rewrites;
 };
 
 namespace pg {
@@ -365,6 +374,26 @@ int expr_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars
     return PG_OK;
 }
 
+// the fusion stage's view of a RankScore's rewrites (pipeline.hip)
+int expr_num_rewrites(const pg_expr* e) { return e ? (int)e->rewrites.size() : 0; }
+const char* expr_rewrite_source(const pg_expr* e, int r) { return e->rewrites[(size_t)r].source.c_str(); }
+int expr_rewrite_num_vars(const pg_expr* e, int r) { return (int)e->rewrites[(size_t)r].vars.size(); }
+const char* expr_rewrite_var_name(const pg_expr* e, int r, int i) { return e->rewrites[(size_t)r].vars[(size_t)i].c_str(); }
+int expr_rewrite_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, int r, const double* d_vars, uint32_t n_items, double* d_out,
+                                     uint32_t* d_err, uint32_t items_per_flag) {
+    const pg_expr::Rewrite& rw = e->rewrites[(size_t)r];
+    if (rw.failed || rw.prog.empty()) {
+        PG_HIP(hipMemsetAsync(d_out, 0, (size_t)n_items * 8, ctx->stream));
+        return PG_OK;
+    }
+    ExprDev dev;
+    dev.n = (uint32_t)rw.prog.size();
+    for (size_t i = 0; i < rw.prog.size(); ++i) dev.prog[i] = rw.prog[i];
+    expr_eval_kernel<<<(n_items + 255) / 256, 256, 0, ctx->stream>>>(dev, d_vars, n_items, d_out, d_err, items_per_flag);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 void set_expr_arith_error(const pg_expr* e) {
     set_error("pg_expr_eval: violation of arithmetic specification: a division by zero in '%s' "
               "(the reference panics in ExprASTResult, utils/ast/ast.go:243-249)", e->source.c_str());
@@ -442,6 +471,30 @@ int pg_expr_free(pg_expr* e) {
 }
 
 int pg_expr_num_vars(const pg_expr* e) { return e ? (int)e->vars.size() : 0; }
+
+int pg_expr_set_score_rewrites(pg_expr* rank_score, uint32_t n, const char* const* sources, const pg_expr* const* exprs) {
+    PG_REQUIRE(rank_score && (n == 0 || (sources && exprs)), "pg_expr_set_score_rewrites: NULL argument");
+    PG_REQUIRE(n <= (uint32_t)pg::kMaxRewrites, "pg_expr_set_score_rewrites: %u rewrites (at most %d)", n, pg::kMaxRewrites);
+    PG_REQUIRE(n == 0 || !rank_score->empty, "pg_expr_set_score_rewrites: the reference rewrites scores only in front of a RankScore "
+               "(service/rank/rank_service.go:339-353); this one is empty");
+    std::vector<pg_expr::Rewrite> rw(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        PG_REQUIRE(sources[i] && sources[i][0], "pg_expr_set_score_rewrites: rewrite %u has no source name", i);
+        for (uint32_t j = 0; j < i; ++j)
+            PG_REQUIRE(rw[j].source != sources[i], "pg_expr_set_score_rewrites: source \"%s\" twice (ScoreRewrite is a map)", sources[i]);
+        rw[i].source = sources[i];
+        if (!exprs[i]) {
+            rw[i].failed = true;
+            continue;
+        }
+        PG_REQUIRE(exprs[i]->rewrites.empty(), "pg_expr_set_score_rewrites: \"%s\": a rewrite expression cannot carry rewrites itself", sources[i]);
+        if (exprs[i]->empty) continue;                  // GetExpAST(""): a nil tree evaluates to 0
+        rw[i].prog = exprs[i]->prog;
+        rw[i].vars = exprs[i]->vars;
+    }
+    rank_score->rewrites.swap(rw);
+    return PG_OK;
+}
 
 const char* pg_expr_var_name(const pg_expr* e, int i) {
     if (!e || i < 0 || i >= (int)e->vars.size()) return "";

@@ -336,7 +336,7 @@ void tail_call(const pg_group* g, const Shard& s, const Lane& l, const pg_group_
     c->algos[0].m = s.model;
     c->e = tk->e;
     c->var_src = tk->src.data();
-    c->nv = (int)tk->src.size();
+    c->nv = pg_expr_num_vars(tk->e);
     c->nq = nqs;
     c->k = tk->k;
     c->d_rows = l.t_rows;

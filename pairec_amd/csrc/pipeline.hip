@@ -18,15 +18,17 @@ namespace pg {
 // vars[v][i] = (double) (src[v] >= 0 ? rank plane src[v] : recall)[i] — the float32 → float64 widening every response
 // decoder of the reference performs (algorithm/eas/easyrec_response.go:479-483), for all variables of the expression
 struct VarSrc { int8_t src[32]; };
+// (src >= 0: score plane; -1: Item.Score; <= -2: the f64 result of score rewrite -2 - src, rw [n_rewrites][n])
 __global__ void bind_vars_kernel(const float* __restrict__ recall, const float* __restrict__ rank, size_t rank_stride,
-                                 uint32_t n, uint32_t nv, VarSrc vs, double* __restrict__ vars, uint32_t* __restrict__ err) {
+                                 uint32_t n, uint32_t nv, VarSrc vs, double* __restrict__ vars, uint32_t* __restrict__ err,
+                                 const double* __restrict__ rw, int zero_err) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (uint32_t)kMaxQueries) err[i] = 0;             // the RankScore flags of the evaluation behind this launch
+    if (zero_err && i < (uint32_t)kMaxQueries) err[i] = 0; // the RankScore flags of the evaluations behind this launch
     if (i >= n) return;
     const double a = (double)recall[i];
     for (uint32_t v = 0; v < nv; ++v) {
         const int sa = vs.src[v];
-        vars[(size_t)v * n + i] = sa >= 0 ? (double)rank[(size_t)sa * rank_stride + i] : a;
+        vars[(size_t)v * n + i] = sa >= 0 ? (double)rank[(size_t)sa * rank_stride + i] : (sa == -1 ? a : rw[(size_t)(-2 - sa) * n + i]);
     }
 }
 
@@ -78,25 +80,52 @@ void pipe_pool_destroy(pg_ctx* ctx) {
     ctx->pipe_free.clear();
 }
 
+// var_src: the RankScore's variables first, then those of every score rewrite in order (RecommendCall::nv counts the
+// RankScore's only).  A RankScore variable that names a rewrite's source reads the rewritten score (AddAlgoScores overwrites
+// the algorithm's, module/item.go:177-188); a rewrite's own variables read the scores as the algorithms left them — the
+// reference fills a map from the un-rewritten item first (rank_service.go:343-353).
 int recommend_bind_vars(const pg_expr* e, const char* const* names, int n_algos, std::vector<int>* var_src, const char* who) {
-    const int nv = pg_expr_num_vars(e);
-    if (nv > 32) {
-        set_error("%s: RankScore has %d variables (at most 32)", who, nv);
+    const int nv = pg_expr_num_vars(e), n_rw = expr_num_rewrites(e);
+    int worst = nv;
+    for (int r = 0; r < n_rw; ++r) worst = std::max(worst, expr_rewrite_num_vars(e, r));
+    if (worst > 32) {
+        set_error("%s: RankScore (or one of its score rewrites) has %d variables (at most 32)", who, worst);
         return PG_ERR_UNSUPPORTED;
     }
-    var_src->assign((size_t)nv, -1);
-    for (int i = 0; i < nv; ++i) {
-        const char* name = pg_expr_var_name(e, i);
+    var_src->clear();
+    auto plane_of = [&](const char* name) {
         int found = -2;
         for (int a = 0; a < n_algos; ++a)
             if (names[a] && !strcmp(name, names[a])) found = a;
         if (found == -2 && !strcmp(name, "current_score")) found = -1;
-        if (found == -2) {
-            set_error("%s: RankScore variable \"%s\" is neither a rank algorithm of the scene nor current_score", who, name);
+        return found;                                     // -2: unknown
+    };
+    for (int i = 0; i < nv; ++i) {
+        const char* name = pg_expr_var_name(e, i);
+        int found = -2;
+        bool rewritten = false;                           // (-2 - r is also the "unknown" mark for r = 0)
+        for (int r = 0; r < n_rw; ++r)
+            if (!strcmp(name, expr_rewrite_source(e, r))) {
+                found = -2 - r;
+                rewritten = true;
+            }
+        if (!rewritten && (found = plane_of(name)) == -2) {
+            set_error("%s: RankScore variable \"%s\" is neither a rank algorithm of the scene, a ScoreRewrite source nor current_score", who, name);
             return PG_ERR_INVALID;
         }
-        (*var_src)[(size_t)i] = found;
+        var_src->push_back(found);
     }
+    for (int r = 0; r < n_rw; ++r)
+        for (int i = 0; i < expr_rewrite_num_vars(e, r); ++i) {
+            const char* name = expr_rewrite_var_name(e, r, i);
+            const int found = plane_of(name);
+            if (found == -2) {
+                set_error("%s: ScoreRewrite[\"%s\"] variable \"%s\" is neither a rank algorithm of the scene nor current_score", who,
+                          expr_rewrite_source(e, r), name);
+                return PG_ERR_INVALID;
+            }
+            var_src->push_back(found);
+        }
     return PG_OK;
 }
 
@@ -106,7 +135,11 @@ int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostScratch* 
     int rc;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t b_local = al((size_t)n * 4), b_off = al((size_t)(nq + 1) * 4), b_err = al((size_t)kMaxQueries * 4);
-    const size_t b_vars = al((size_t)std::max(c.nv, 1) * n * 8);
+    // variables of the widest expression + one f64 result per score rewrite
+    int wide = std::max(c.nv, 1);
+    const int n_rw = expr_num_rewrites(c.e);
+    for (int r = 0; r < n_rw; ++r) wide = std::max(wide, expr_rewrite_num_vars(c.e, r));
+    const size_t b_vars = al((size_t)(wide + n_rw) * n * 8);
     if ((rc = scratch_reserve(ctx, 8, b_local + b_off + b_err + b_vars, &buf))) return rc;
     ps->d_local = (uint32_t*)buf;
     ps->d_off = (uint32_t*)((char*)buf + b_local);
@@ -133,12 +166,32 @@ int post_fuse_sort_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint
     hipStream_t st = ctx->stream;
     int rc;
     VarSrc vs;
+    // RankConfig.ScoreRewrite (rank_service.go:343-353): every source's expression over the scores as the algorithms left
+    // them, all of them before any is written back; results stay f64 (AddAlgoScores) behind the variables
+    const int n_rw = expr_num_rewrites(c.e);
+    int wide = std::max(c.nv, 1);
+    for (int r = 0; r < n_rw; ++r) wide = std::max(wide, expr_rewrite_num_vars(c.e, r));
+    double* const d_rw = ps.d_vars + (size_t)wide * n;
+    const uint32_t bind_grid = (std::max(n, (uint32_t)kMaxQueries) + 255) / 256;
+    bool zeroed = false;
+    for (int r = 0, at = c.nv; r < n_rw; ++r) {
+        const int nvr = expr_rewrite_num_vars(c.e, r);
+        for (int i = 0; i < 32; ++i) vs.src[i] = i < nvr ? (int8_t)c.var_src[at + i] : (int8_t)-1;
+        at += nvr;
+        if (nvr > 0 || !zeroed) {
+            bind_vars_kernel<<<bind_grid, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n, (uint32_t)nvr, vs, ps.d_vars, ps.d_err,
+                                                        nullptr, zeroed ? 0 : 1);
+            PG_HIP(hipGetLastError());
+            zeroed = true;
+        }
+        if ((rc = expr_rewrite_eval_enqueue_locked(ctx, c.e, r, ps.d_vars, n, d_rw + (size_t)r * n, ps.d_err, c.k))) return rc;
+    }
     for (int i = 0; i < 32; ++i) vs.src[i] = i < c.nv ? (int8_t)c.var_src[i] : (int8_t)-1;
     if (c.nv > 0) {
-        bind_vars_kernel<<<(std::max(n, (uint32_t)kMaxQueries) + 255) / 256, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n,
-                                                                                        (uint32_t)c.nv, vs, ps.d_vars, ps.d_err);
+        bind_vars_kernel<<<bind_grid, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n, (uint32_t)c.nv, vs, ps.d_vars, ps.d_err,
+                                                    d_rw, zeroed ? 0 : 1);
         PG_HIP(hipGetLastError());
-    } else {
+    } else if (!zeroed) {
         PG_HIP(hipMemsetAsync(ps.d_err, 0, (size_t)kMaxQueries * 4, st));
     }
     if ((rc = expr_eval_enqueue_locked(ctx, c.e, ps.d_vars, n, c.d_fused + o, ps.d_err, c.k))) return rc;
@@ -308,7 +361,7 @@ int pg_recommend_dnn3_begin(pg_ctx* ctx, const pg_table* t, const pg_model* m, c
         return rc;
     }
     pg::RecommendCall& c = tk->call;
-    c.t = t; c.algos[0].m = m; c.n_algos = 1; c.e = e; c.var_src = tk->var_src.data(); c.nv = (int)tk->var_src.size();
+    c.t = t; c.algos[0].m = m; c.n_algos = 1; c.e = e; c.var_src = tk->var_src.data(); c.nv = pg_expr_num_vars(e);
     c.d_queries = d_queries; c.nq = nq; c.k = k;
     c.d_rows = d_out_rows; c.d_recall = d_out_recall_scores; c.d_rank = d_out_rank_scores; c.rank_stride = (size_t)nq * k;
     c.d_fused = d_out_fused; c.d_order = d_out_order; c.d_count = d_out_count;

@@ -1183,7 +1183,7 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     if (ws && m->n_out > 1) {
         // the weights-stationary kernel's partials of heads 1..: a block per workgroup (its LDS is full)
         void* hp;
-        if ((rc = scratch_reserve(ctx, 11, (size_t)ctx->num_cus * (kMaxHeads - 1) * 4 * kWsItems * 4, &hp))) return rc;
+        if ((rc = scratch_reserve(ctx, 14, (size_t)ctx->num_cus * (kMaxHeads - 1) * 4 * kWsItems * 4, &hp))) return rc;
         a.head_part = (float*)hp;
     }
     if (ws) {

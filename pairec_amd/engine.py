@@ -425,6 +425,25 @@ class Expr:
             self.L.pg_expr_free(self.h)
             self.h = None
 
+    def set_score_rewrites(self, rewrites: dict):
+        """RankConfig.ScoreRewrite {source: expression} of the scene this RankScore belongs to (pg_expr_set_score_rewrites).
+        An expression that does not compile is passed as NULL — the reference scores such a source 0."""
+        names = list(rewrites.keys())
+        exprs = []
+        for nm in names:
+            try:
+                exprs.append(Expr(rewrites[nm]))
+            except _lib.PgError:
+                exprs.append(None)
+        arr_n = (C.c_char_p * max(len(names), 1))(*[nm.encode("utf-8") for nm in names])
+        arr_e = (C.c_void_p * max(len(names), 1))(*[(x.h if x is not None else None) for x in exprs])
+        try:
+            _lib.check(self.L.pg_expr_set_score_rewrites(self.h, len(names), arr_n, arr_e))
+        finally:
+            for x in exprs:
+                if x is not None:
+                    x.free()
+
     def eval(self, ctx: Context, vars_: np.ndarray) -> np.ndarray:
         """vars_: [n_vars][n_items] fp64 in var_names order → fused scores [n_items] fp64."""
         v = np.ascontiguousarray(vars_, dtype=np.float64).reshape(len(self.var_names), -1) \

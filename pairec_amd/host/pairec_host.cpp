@@ -164,6 +164,7 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         c.RankAlgoList = str_list(kv.second.at("RankAlgoList"));
         c.RankScore = kv.second.s("RankScore"); c.Processor = kv.second.s("Processor");
         c.ASTType = kv.second.s("ASTType"); c.BatchCount = (int)kv.second.n("BatchCount");
+        for (const auto& rw : kv.second.at("ScoreRewrite").obj) c.ScoreRewrite[rw.first] = rw.second.str;
         out->RankConf[kv.first] = c;
     }
     for (const auto& kv : root.at("SortNames").obj) out->SortNames[kv.first] = str_list(kv.second);
@@ -223,6 +224,7 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         c.CacheAdapter = r.s("CacheAdapter"); c.CacheConfig = r.s("CacheConfig");
         c.RecallCount = (int)r.n("RecallCount"); c.CacheTime = (int)r.n("CacheTime");
         c.RankScore = r.s("RankScore"); c.RankVar = r.s("RankVar");
+        for (const auto& rw : r.at("ScoreRewrite").obj) c.ScoreRewrite[rw.first] = rw.second.str;
         // HologresVectorConf.WhereClause / TimeInterval (recconf.go:492-497) restrict the SQL's candidates.  The device serves
         // the form `column OP integer` over an int32 item column keyed by row, "${time}" standing for now - TimeInterval as in
         // hologres_vector_recall.go:56-61; anything else is refused here rather than answered over other candidates.
@@ -1331,24 +1333,50 @@ bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, co
         }
     }
     if (!conf.RankScore.empty()) {                                           // :339-363
+        const uint32_t n = (uint32_t)items.size();
+        // one expression over every item: variables from the AB parameters first, then the item (ast_parameter_data.go:30-40)
+        auto eval = [&](pg_expr* ex, std::vector<double>* out) -> bool {
+            const int nv = pg_expr_num_vars(ex);
+            std::vector<double> vars((size_t)nv * n, 0.0);
+            out->assign(n, 0.0);
+            for (int v = 0; v < nv; ++v) {
+                const std::string name = pg_expr_var_name(ex, v);
+                auto ab = ctx->ExperimentParams.find(name);
+                for (uint32_t i = 0; i < n; ++i) {
+                    double x = 0.0;
+                    if (ab != ctx->ExperimentParams.end() && ab->second != 0.0) x = ab->second;
+                    else items[i]->FloatExprData(name, &x);
+                    vars[(size_t)v * n + i] = x;
+                }
+            }
+            return !n || pg_expr_eval(e->ctx, ex, nv ? vars.data() : nullptr, n, out->data()) == PG_OK;
+        };
         pg_expr* ex = nullptr;
         if (pg_expr_compile(conf.RankScore.c_str(), &ex) != PG_OK) { if (err) *err = pg_err("pg_expr_compile"); return false; }
-        const int nv = pg_expr_num_vars(ex);
-        const uint32_t n = (uint32_t)items.size();
-        std::vector<double> vars((size_t)nv * n, 0.0), out(n);
-        for (int v = 0; v < nv; ++v) {
-            const std::string name = pg_expr_var_name(ex, v);
-            auto ab = ctx->ExperimentParams.find(name);                     // ast_parameter_data.go:30-40
+        // ScoreRewrite (:296-306,343-353): every source's expression over the item as the algorithms left it, into a map
+        // first, then written back (AddAlgoScores); a source whose expression does not compile scores 0
+        if (!conf.ScoreRewrite.empty()) {
+            std::vector<std::pair<std::string, std::vector<double>>> rewritten;
+            for (const auto& rw : conf.ScoreRewrite) {
+                std::vector<double> vals(n, 0.0);
+                pg_expr* rex = nullptr;
+                if (pg_expr_compile(rw.second.c_str(), &rex) == PG_OK) {
+                    const bool ok = eval(rex, &vals);
+                    pg_expr_free(rex);
+                    if (!ok) { pg_expr_free(ex); if (err) *err = pg_err(("pg_expr_eval (ScoreRewrite[" + rw.first + "])").c_str()); return false; }
+                }
+                rewritten.emplace_back(rw.first, std::move(vals));
+            }
             for (uint32_t i = 0; i < n; ++i) {
-                double x = 0.0;
-                if (ab != ctx->ExperimentParams.end() && ab->second != 0.0) x = ab->second;
-                else items[i]->FloatExprData(name, &x);
-                vars[(size_t)v * n + i] = x;
+                std::map<std::string, double> scores;
+                for (const auto& rw : rewritten) scores[rw.first] = rw.second[i];
+                items[i]->AddAlgoScores(scores);
             }
         }
-        const int rcode = n ? pg_expr_eval(e->ctx, ex, nv ? vars.data() : nullptr, n, out.data()) : PG_OK;
+        std::vector<double> out;
+        const bool ok = eval(ex, &out);
         pg_expr_free(ex);
-        if (rcode != PG_OK) { if (err) *err = pg_err("pg_expr_eval"); return false; }
+        if (!ok) { if (err) *err = pg_err("pg_expr_eval"); return false; }
         for (uint32_t i = 0; i < n; ++i) items[i]->Score = out[i];
     }
     return true;
@@ -1525,6 +1553,25 @@ pg_coalescer* Engine::PageCoalescer(const recconf::RecallConfig& conf, std::stri
     if (pg_expr_compile(conf.RankScore.c_str(), &ex) != PG_OK) {
         if (err) *err = std::string("pg_expr_compile: ") + pg_last_error();
         return nullptr;
+    }
+    if (!conf.ScoreRewrite.empty()) {
+        // the scene's ScoreRewrite rides on the RankScore: the device evaluates every source from the un-rewritten scores
+        // in front of it (a source that does not compile scores 0, as in rank_service.go:299-303,349-351)
+        std::vector<const char*> src;
+        std::vector<pg_expr*> rex;
+        for (const auto& rw : conf.ScoreRewrite) {
+            pg_expr* r = nullptr;
+            if (pg_expr_compile(rw.second.c_str(), &r) != PG_OK) r = nullptr;
+            src.push_back(rw.first.c_str());
+            rex.push_back(r);
+        }
+        const int rc = pg_expr_set_score_rewrites(ex, (uint32_t)src.size(), src.data(), rex.data());
+        for (pg_expr* r : rex) pg_expr_free(r);
+        if (rc != PG_OK) {
+            if (err) *err = std::string("pg_expr_set_score_rewrites: ") + pg_last_error();
+            pg_expr_free(ex);
+            return nullptr;
+        }
     }
     pg_coalescer_config cfg;
     memset(&cfg, 0, sizeof cfg);
@@ -2319,7 +2366,16 @@ const char* ph_parse_recconf(const char* text) {
     for (const auto& kv : c.RankConf) {
         o += ",\"rank_" + kv.first + "\":{\"batch\":" + std::to_string(kv.second.BatchCount) + ",\"score\":";
         json::Escape(kv.second.RankScore, &o);
-        o += ",\"algos\":" + std::to_string(kv.second.RankAlgoList.size()) + "}";
+        o += ",\"algos\":" + std::to_string(kv.second.RankAlgoList.size()) + ",\"score_rewrite\":{";
+        bool first = true;
+        for (const auto& rw : kv.second.ScoreRewrite) {
+            if (!first) o += ",";
+            first = false;
+            json::Escape(rw.first, &o);
+            o += ":";
+            json::Escape(rw.second, &o);
+        }
+        o += "}}";
     }
     o += "}";
     return o.c_str();

@@ -45,6 +45,7 @@ struct Item {
 
     explicit Item(ItemId id = "") : Id(std::move(id)) {}
     void AddAlgoScore(const std::string& name, double score) { algoScores[name] = score; }   // item.go:168-176
+    void AddAlgoScores(const std::map<std::string, double>& scores) { for (const auto& kv : scores) algoScores[kv.first] = kv.second; }   // item.go:177-188
     void AddProperty(const std::string& k, json::Value v) { Properties[k] = std::move(v); }
     // Item.FloatExprData (item.go:189-212): "current_score" has the recall_score side effect
     bool FloatExprData(const std::string& name, double* out);
@@ -103,11 +104,13 @@ struct RecallConfig {
     long long WhereValue = 0;
     int TimeInterval = 0;
     std::string RankScore, RankVar;         // Kind "page": the RankScore expression and the name the model's score has in it
+    std::map<std::string, std::string> ScoreRewrite;     // Kind "page": RankConfig.ScoreRewrite of the scene it finishes (evaluated on the device)
 };
 struct RankConfig {
     std::vector<std::string> RankAlgoList;
     std::string RankScore, Processor, ASTType;
     int BatchCount = 0;
+    std::map<std::string, std::string> ScoreRewrite;     // recconf.go:743: algo-score name → expression (rank_service.go:296-306,343-353)
 };
 struct DPPSortConfig {
     std::string Name;

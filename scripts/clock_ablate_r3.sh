@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 5: such a build is libpairec_gpu_dev.so — export PG_LIB_VARIANT=dev for the runs below)
 # developer aid: sustained shader clock of the 256-query screen's ablation variants (needs a build with
 # SCAN_EXTRA=-DPG_SCAN_VARIANTS): GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the largest screen_kernel dispatches
 REPO=$(cd "$(dirname "$0")/.." && pwd)

@@ -6,5 +6,6 @@ set -e
 cd "$(dirname "$0")/.."
 touch pairec_amd/csrc/rank_ir.hip
 make -C pairec_amd/csrc WS_EXTRA=-DPG_IR_PROFILE -j8 > /dev/null
-python scripts/dev/cfg4_prof.py random 2>&1 | grep -v "^$" | tail -14
-python scripts/dev/cfg4_prof.py row0 2>&1 | grep -v "^$" | tail -14
+# (the instrumented build is libpairec_gpu_dev.so, selected by PG_LIB_VARIANT=dev: the product library is not replaced)
+PG_LIB_VARIANT=dev PG_FM2T_IRS=1 python scripts/dev/cfg4_prof.py random 2>&1 | grep -v "^$" | tail -14
+PG_LIB_VARIANT=dev PG_FM2T_IRS=1 python scripts/dev/cfg4_prof.py row0 2>&1 | grep -v "^$" | tail -14

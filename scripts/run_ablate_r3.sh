@@ -1,4 +1,5 @@
 # developer ablation timings of the 256-query screen (needs a build with SCAN_EXTRA=-DPG_SCAN_VARIANTS); results are wrong by design
+# (round 5: such a build is libpairec_gpu_dev.so — export PG_LIB_VARIANT=dev for the runs below)
 # VAR: 0 product, 4 test but never the hit path, 1 no screen test, 2 no MFMA and no test (stream only); full pass = launch 2 of the
 # pilot plan without the refinement step (includes decode + re-scoring of whatever was staged)
 for v in ${VARS:-0 4 1 2}; do

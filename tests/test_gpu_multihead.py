@@ -146,6 +146,19 @@ def test_scene_with_two_output_model_one_launch(ctx):
     # an expression naming an output the model does not have is refused at creation
     with pytest.raises(pa._lib.PgError):
         pa.Coalescer(ctx, t, k, expr=pa.Expr("${ppnet_probs_xyz}"), algos=[("ppnet", m, ["probs_ctr", "probs_cvr"])], max_top_n=top_n)
+    # a scene's models write at most 12 score planes together: 8 + 4 outputs fill them, a single-output algorithm behind
+    # them must be refused (the bound was only checked for multi-output models — 13 names on a 12-entry array)
+    w8, w4, w1 = o.Dnn3MultiWeights(8), o.Dnn3MultiWeights(4), o.Dnn3Weights()
+    m8 = pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, pa.PREC_F32, _pack(w8))
+    m4 = pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, pa.PREC_F32, _pack(w4))
+    m1 = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w1.w1, w1.b1, w1.w2, w1.b2, w1.w3, w1.b3, 128))
+    full = pa.Coalescer(ctx, t, k, algos=[("a", m8), ("b", m4)], max_top_n=top_n)        # 12 planes: allowed
+    full.destroy()
+    with pytest.raises(pa._lib.PgError) as ei:
+        pa.Coalescer(ctx, t, k, algos=[("a", m8), ("b", m4), ("c", m1)], max_top_n=top_n)
+    assert ei.value.code == -1 and "outputs together" in str(ei.value)
+    for mm in (m8, m4, m1):
+        mm.destroy()
     assert ctx.stats().rank_calls >= st0
     m.destroy()
     t.destroy()

@@ -119,7 +119,7 @@ def test_unique_filter_matches_reference_semantics(H):
 def test_recconf_subset(H):
     got = json.loads(H.ph_parse_recconf(json.dumps(CONFIG).encode()))
     assert got["recalls"] == 0 and got["gpu_recall0"] == {"name": "gpu_vector_recall", "count": 300, "algo": "gpu_faiss"}
-    assert got["rank_home_feed"] == {"batch": 100, "score": RANK_SCORE, "algos": 1}
+    assert got["rank_home_feed"] == {"batch": 100, "score": RANK_SCORE, "algos": 1, "score_rewrite": {}}
     assert H.ph_parse_recconf(b"{not json") is None and b"json" in H.ph_last_error()
 
 
