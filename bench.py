@@ -83,6 +83,8 @@ def parse_args():
                     help="headline table: SURVEY.md 8d's normalised uniform rows, or N(0,1) rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only (profiling runs)")
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="N > 1: skip the parity preflight of the sharded step on the run's own wire (it runs before anything is timed)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs behind roofline.traffic")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the PG_PREC_F32 headline and the bf16-vs-f32 figures")
@@ -109,13 +111,38 @@ def free_port():
     return p_
 
 
+def count_gpus():
+    """GPUs of this box WITHOUT initialising the HIP runtime in this process: the KFD topology in sysfs (a node with SIMDs is
+    a GPU); where that is unreadable, a short-lived child asks torch.  (torch.cuda.device_count() may fall back to
+    hipGetDeviceCount, which does initialise the runtime — ADVICE r4.)"""
+    import glob
+    import subprocess
+    n, seen = 0, False
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(prop):
+                f = line.split()
+                if len(f) == 2 and f[0] == "simd_count":
+                    seen = True
+                    n += int(f[1]) > 0
+        except OSError:
+            pass
+    if seen:
+        return n
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run, the driver's own
-    command line) from this process, which has not touched the GPU and never will — torch.cuda.device_count() does not
-    initialise it — and exit with their code.  Fewer GPUs than ranks is an error, not a quiet one-rank run."""
+    command line) and exit with their code.  This process never initialises the GPU (count_gpus reads sysfs or asks a
+    child); the ranks are always fresh children, never an exec of this process.  Fewer GPUs than ranks is an error, not a
+    quiet one-rank run."""
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
+    have = count_gpus()
     share = os.environ.get("PG_BENCH_SHARE_GPU") == "1"
     if have < args.gpus and not share:
         sys.stderr.write("bench.py: --gpus %d but this box has %d GPU(s); refusing to run fewer ranks than asked for "
@@ -1066,6 +1093,224 @@ class _TableView:
         return eb.value, sc.value, rs.value
 
 
+def _checksums(torch, tensors):
+    """one wrapping 64-bit position-weighted sum per tensor (bit patterns, not values), on the tensors' device"""
+    out = []
+    for t in tensors:
+        x = t.contiguous()
+        x = x.view(torch.int64) if x.element_size() == 8 else x.view(torch.int32).to(torch.int64)
+        x = x.reshape(-1)
+        out.append((x * torch.arange(1, x.numel() + 1, device=x.device, dtype=torch.int64)).sum())
+    return torch.stack(out)
+
+
+def ranks_agree(torch, coll, world, tensors):
+    """Every rank of the sharded step must hold the same rows / fused scores / order / page: their checksums, all-gathered
+    on the step's own wire (RCCL, or the host-staged gloo of the dev mode), compared on every rank."""
+    mine = _checksums(torch, tensors)
+    if world == 1:
+        return True
+    g = torch.empty(world * mine.numel(), dtype=torch.int64, device=mine.device)
+    coll.all_gather_into_tensor(g, mine)
+    return bool((g.view(world, -1) == mine[None, :]).all().item())
+
+
+def oracle_step_pages(o, tab, w, q, k, top_n, dpp_c, alpha, window):
+    """The sharded step on ONE table through the oracle (the checker): recall → DNN3 (fp32) → RankScore → ItemRankScore →
+    DPPSort.doSort; → per request the page's global rows."""
+    rows, rec = o.recall_topk(tab, q, k)
+    pages = []
+    for r in range(q.shape[0]):
+        rk = o.dnn3_forward(w, 0, q[r], tab[rows[r].astype(np.int64)])
+        fused = o.widen_f32(rk) * (1 + o.widen_f32(rec[r])) ** 0.1
+        order = o.sort_scores(fused, True)
+        c = min(k, max(top_n, dpp_c))
+        head = order[:c]
+        emb = o.l2_normalize_f64(tab[rows[r][head].astype(np.int64)].astype(np.float64))
+        page = head[o.dpp_with_window(o.dpp_kernel_matrix(emb, fused[head], alpha), top_n, window)]
+        pages.append(rows[r][page])
+    return pages
+
+
+def preflight_ranks(pa, o, torch, dist, coll, rank, world, device, share_gpu):
+    """Before anything is timed on N > 1 ranks: the sharded step of configs[4] — recall on every rank's row range, the
+    all-gather merge, owner-computes rank, the all-reduced score slab, DPP over reduce-scattered rows — on a SMALL table over
+    the run's own wire (RCCL with one rank per GPU; host-staged gloo when the ranks share cuda:0), against the single-table
+    oracle ON EVERY RANK, and the ranks against each other.  The first run on real peer devices validates itself
+    (VERDICT r4 #3; service/recall.go:126-150 is the fan-in this replaces).  → (dict, ok) — identical on every rank."""
+    from pairec_amd.dist import GpuShardEngine, shard_context, shard_range, sharded_step
+    n, d, k, R, top_n, dpp_c = 80_003, 128, 300, 7, 25, 90
+    res = {"backend": "gloo (host-staged: ranks share one device)" if share_gpu else "nccl", "ranks": world,
+           "workload": "sharded step on a %d x %d table, %d requests, k %d, DPP %d -> page %d; f32 rank model" % (n, d, R, k, dpp_c, top_n)}
+    err = ""
+    agree = True
+    try:
+        b, e = shard_range(n, world, rank)
+        ctx, _stream = shard_context(torch, pa, device)
+        t = pa.Table(ctx, e - b, d, row_offset=b)
+        tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+        if rank % 2 == 0:
+            t.fill_synthetic(o.SEED_TABLE)
+        else:
+            t.upload(tab[b:e])
+        w = o.Dnn3Weights()
+        m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+        ex = pa.Expr(RANK_EXPR)
+        eng = GpuShardEngine(torch, ctx, t, m, ex, k, R)
+        for step, (user0, nq) in enumerate(((77, R), (500, R - 2))):
+            q = o.synth_rows(o.SEED_QUERY, user0, nq, d)
+            tq = torch.from_numpy(q).to(torch.device("cuda", device))
+            torch.cuda.synchronize()
+            rows, fused, order, page = sharded_step(eng, coll if world > 1 else None, torch, tq, nq, k, top_n,
+                                                    {"candidates": dpp_c, "alpha": 1.0, "window": 10})
+            torch.cuda.synchronize()
+            with torch.cuda.stream(eng.stream):
+                agree = ranks_agree(torch, coll, world, (rows, fused, order, page)) and agree
+            rows_n = rows.cpu().numpy().astype(np.uint64)
+            page_n = page.cpu().numpy().astype(np.int64)
+            want = oracle_step_pages(o, tab, w, q, k, top_n, dpp_c, 1.0, 10)
+            for r in range(nq):
+                if not np.array_equal(rows_n[r][page_n[r]], want[r]):
+                    err = err or "rank %d step %d request %d: the page differs from the oracle's" % (rank, step, r)
+        del eng
+        ex.free()
+        m.destroy()
+        t.destroy()
+        ctx.close()
+    except Exception as ex_:                                    # noqa: BLE001 — reported, then the run stops
+        err = err or "rank %d: %s: %s" % (rank, type(ex_).__name__, ex_)
+    if not agree:
+        err = err or "rank %d: rows / fused / order / page differ between ranks" % rank
+    # every rank learns whether ANY rank failed (one int per rank over the control channel)
+    bad = torch.tensor([1 if err else 0], dtype=torch.int32, device="cpu" if share_gpu else torch.device("cuda", device))
+    if world > 1:
+        dist.all_reduce(bad)
+    res["pages_equal_oracle_on_every_rank"] = int(bad.item()) == 0
+    res["ranks_agree"] = agree
+    res["ok"] = int(bad.item()) == 0
+    if err:
+        res["error_on_this_rank"] = err
+        print("[bench] preflight: %s" % err, file=sys.stderr, flush=True)
+    return res, res["ok"]
+
+
+def preflight_group(pa, o, devices):
+    """The same step through pg_group_* (one process, peer stores + HIP events between the devices — what a cgo host
+    calls) on a small table, against the single-table oracle.  → dict with "ok"."""
+    n, d, k, R, top_n, dpp_c = 90_001, 128, 400, 7, 40, 120
+    res = {"devices": devices, "workload": "pg_group_recommend on a %d x %d table in %d row-range shards, %d requests, k %d, "
+                                           "DPP %d -> page %d" % (n, d, len(devices), R, k, dpp_c, top_n)}
+    try:
+        tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+        w = o.Dnn3Weights()
+        g = pa.ShardGroup(devices)
+        g.table_create(n, d)
+        g.table_fill_synthetic(o.SEED_TABLE)
+        g.model_load(pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+        ex = pa.Expr(RANK_EXPR)
+        q = o.synth_rows(o.SEED_QUERY, 21, R, d)
+        rows, rec, rnk, fus, cnt = g.recommend(ex, "gpu_dnn", q, k, top_n, dpp_candidates=dpp_c, dpp_alpha=1.0, dpp_window=10)
+        want = oracle_step_pages(o, tab, w, q, k, top_n, dpp_c, 1.0, 10)
+        ok = all(int(cnt[r]) == top_n and np.array_equal(rows[r], want[r]) for r in range(R))
+        g.destroy()
+        ex.free()
+        res["ok"] = bool(ok)
+        if not ok:
+            res["error"] = "a page differs from the oracle's"
+    except Exception as ex_:                                    # noqa: BLE001
+        res["ok"] = False
+        res["error"] = "%s: %s" % (type(ex_).__name__, ex_)
+    if not res["ok"]:
+        print("[bench] group preflight: %s" % res.get("error"), file=sys.stderr, flush=True)
+    return res
+
+
+def shard_sub_leg(pa, o, torch, dist, coll, rank, world, device, args, R, K, prec, blob):
+    """configs[4] as a sub-object of the default N > 1 line: the table in row-range shards (args_rows_shard rows per rank),
+    the sharded step with DPPSort over RCCL, W untimed + K timed steps, max over ranks; every rank's results checked against
+    each other on the wire.  (The headline of that line is the replica mode; `--mode shard` makes this the headline.)"""
+    from pairec_amd.dist import GpuShardEngine, shard_context, shard_range, sharded_step
+    rows = 125_000_000 if args.rows == 100_000_000 else args.rows
+    begin, end = shard_range(rows * world, world, rank)
+    ctx, _stream = shard_context(torch, pa, device)
+    table = pa.Table(ctx, end - begin, args.dim, row_offset=begin)
+    table.fill_synthetic(o.SEED_TABLE)
+    table.screen_info()
+    model = pa.RankModel(ctx, pa.MODEL_DNN3, prec, blob)
+    expr = pa.Expr(RANK_EXPR)
+    eng = GpuShardEngine(torch, ctx, table, model, expr, K, R)
+    dev = torch.device("cuda", device)
+    total = args.warmup + args.steps
+    t_qs = [torch.from_numpy(make_queries(o, 7000 + s_, R, args.dim)).to(dev) for s_ in range(total)]
+    torch.cuda.synchronize()
+    dpp = {"candidates": DPP_CANDIDATES, "alpha": DPP_ALPHA, "window": DPP_WINDOW}
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize()
+    for s_ in range(max(args.warmup, 1)):
+        sharded_step(eng, coll, torch, t_qs[s_ % total], R, K, args.page, dpp)
+    sync()
+    t0 = time.perf_counter()
+    for s_ in range(args.warmup, total):
+        res = sharded_step(eng, coll, torch, t_qs[s_], R, K, args.page, dpp)
+    sync()
+    elapsed = time.perf_counter() - t0
+    with torch.cuda.stream(eng.stream):
+        agree = ranks_agree(torch, coll, world, res)
+        fused_sorted = bool((torch.gather(res[1], 1, res[2].long()).diff(dim=1) <= 0).all().item())
+    tdev = torch.device("cpu") if coll is not dist else dev
+    t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    out = {"value": R * K * args.steps / elapsed, "unit": "ranked items/s", "ms_per_step": elapsed / args.steps * 1e3,
+           "scaling": "weak", "ranks_agree": agree, "lists_sorted": fused_sorted, "ok": bool(agree and fused_sorted),
+           "config": {"workload": "configs[4]: %d x %d fp32 table in %d row-range shards (%d rows each), %d requests x top-%d -> "
+                                  "all_gather merge -> owner-computes DNN3 rank (%s) -> all_reduce scores -> fuse -> sort -> "
+                                  "DPPSort(%d candidates, page %d, window %d, reduce_scatter rows + all_gather picks)"
+                                  % (rows * world, args.dim, world, rows, R, K, args.prec, DPP_CANDIDATES, args.page, DPP_WINDOW),
+                      "parallelism": "one process per GPU, RCCL" if coll is dist else "ranks share one device (dev mode)"}}
+    del eng
+    expr.free()
+    model.destroy()
+    table.destroy()
+    ctx.close()
+    return out
+
+
+def group_sub_leg(pa, o, devices, args, R, K, prec, blob):
+    """configs[4] through pg_group_* (one process, N devices, peer stores) as a sub-object of the default N > 1 line;
+    run by rank 0 while the other ranks wait."""
+    rows = 125_000_000 if args.rows == 100_000_000 else args.rows
+    N = len(devices)
+    g = pa.ShardGroup(devices)
+    g.table_create(rows * N, args.dim)
+    g.table_fill_synthetic(o.SEED_TABLE)
+    g.model_load(pa.MODEL_DNN3, prec, blob)
+    expr = pa.Expr(RANK_EXPR)
+    qs = [make_queries(o, 9000 + s_, R, args.dim) for s_ in range(args.warmup + args.steps + 1)]
+    kw = dict(dpp_candidates=DPP_CANDIDATES, dpp_alpha=DPP_ALPHA, dpp_window=DPP_WINDOW)
+    for s_ in range(max(args.warmup, 1)):
+        g.recommend(expr, "gpu_dnn", qs[s_], K, args.page, **kw)
+    t0 = time.perf_counter()
+    tk = g.recommend_begin(expr, "gpu_dnn", qs[args.warmup], K, args.page, **kw)
+    for s_ in range(args.steps):
+        nxt = g.recommend_begin(expr, "gpu_dnn", qs[args.warmup + s_ + 1], K, args.page, **kw) if s_ + 1 < args.steps else None
+        page = g.recommend_end(tk)
+        tk = nxt
+    elapsed = time.perf_counter() - t0
+    ok = int(page[4].min()) == args.page and bool(np.all(np.isfinite(page[3])))
+    g.destroy()
+    expr.free()
+    return {"value": R * K * args.steps / elapsed, "unit": "ranked items/s", "ms_per_step": elapsed / args.steps * 1e3,
+            "scaling": "weak", "ok": bool(ok),
+            "config": {"workload": "configs[4]: %d x %d fp32 table in %d row-range shards, %d requests x top-%d -> merge -> "
+                                   "owner-computes DNN3 rank (%s) -> fuse -> sort -> DPPSort(%d candidates, page %d); one process, "
+                                   "pg_group_recommend_begin / _end, two steps in flight"
+                                   % (rows * N, args.dim, N, R, K, args.prec, DPP_CANDIDATES, args.page),
+                       "parallelism": "row-range shards x%d in one process: peer stores + HIP events, no collective library" % N}}
+
+
 def inprocess_main(args, R, K):
     """--mode group / router: ONE process over N devices through the C ABI alone (no torch, no collectives library) — the
     boundary a cgo host uses.  group = configs[4] (row-range shards, peer stores, DPPSort); router = replicas of the
@@ -1086,6 +1331,14 @@ def inprocess_main(args, R, K):
         raise SystemExit(2)
     devices = list(range(N)) if have.value >= N else [0] * N
     physical = len(set(devices))
+    pf = None
+    if N > 1 and not args.no_preflight:
+        # before anything is timed: the group step on a small table over these devices against the oracle
+        pf = preflight_group(pa, o, devices)
+        if not pf["ok"]:
+            print(json.dumps({"metric": "ranked items/sec, 5k-cand DNN rank", "value": None, "unit": "ranked items/s", "n_gpus": physical,
+                              "mode": args.mode, "preflight": pf, "error": "the N > 1 parity preflight failed: nothing was timed"}))
+            raise SystemExit(3)
     w = o.Dnn3Weights()
     prec = {"bf16": pa.PREC_BF16, "bf16x3": pa.PREC_BF16X3}.get(args.prec, pa.PREC_F32)
     blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
@@ -1197,6 +1450,7 @@ def inprocess_main(args, R, K):
         "roofline": rf, "cpu_baseline": None, "device": device_info(),
     }
     out.update(out_extra)
+    out["preflight"] = pf
     if physical != N:
         out["ranks"] = N
         out["dev_mode"] = "PG_BENCH_SHARE_GPU=1: %d logical %s on ONE device — a correctness run of the N > 1 code, not a measurement" \
@@ -1247,6 +1501,26 @@ def main():
     from pairec_amd.dist import shard_range, sharded_step, shard_context, GpuShardEngine, HostStagedCollectives
     # the exchanges of the sharded step: RCCL on device tensors; host-staged gloo when the ranks share cuda:0 (dev mode)
     coll = HostStagedCollectives(dist, torch) if share_gpu else dist
+    preflight = None
+    if world > 1 and not args.no_preflight:
+        # the first thing N > 1 ranks do: prove the sharded step on this wire against the oracle (and pg_group_* over the
+        # same devices), on every rank; a failure stops the run before a number exists
+        preflight, pf_ok = preflight_ranks(pa, o, torch, dist, coll, rank, world, local_rank, share_gpu)
+        flag = torch.zeros(1, dtype=torch.int32, device="cpu" if share_gpu else torch.device("cuda", local_rank))
+        if pf_ok and rank == 0:
+            preflight["group"] = preflight_group(pa, o, [0] * world if share_gpu else list(range(world)))
+            flag += 0 if preflight["group"]["ok"] else 1
+        dist.all_reduce(flag)
+        pf_ok = pf_ok and int(flag.item()) == 0
+        preflight["ok"] = pf_ok
+        if not pf_ok:
+            if rank == 0:
+                print(json.dumps({"metric": "ranked items/sec, 5k-cand DNN rank", "value": None, "unit": "ranked items/s",
+                                  "n_gpus": 1 if share_gpu else world, "preflight": preflight,
+                                  "error": "the N > 1 parity preflight failed: nothing was timed"}))
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
     if shard:
         # one dedicated torch stream shared by the library's kernels and the step's torch ops / RCCL collectives
         ctx, tstream = shard_context(torch, pa, local_rank)
@@ -1327,10 +1601,15 @@ def main():
         scan_ms = []
         t0 = time.perf_counter()
         for s in range(args.warmup, total_steps):
-            sharded_step(eng, coll, torch, t_qs[s], R, K, args.page, dpp)
+            last = sharded_step(eng, coll, torch, t_qs[s], R, K, args.page, dpp)
             scan_ms.append(ctx.last_scan_kernel()[0])
         sync()
         elapsed = time.perf_counter() - t0
+        # the last timed step's results: identical on every rank (checksums over the wire), every list in ItemRankScore order
+        with torch.cuda.stream(eng.stream):
+            shard_sanity = {"ranks_agree": ranks_agree(torch, coll, world, last),
+                            "lists_sorted": bool((torch.gather(last[1], 1, last[2].long()).diff(dim=1) <= 0).all().item())}
+        shard_sanity["ok"] = shard_sanity["ranks_agree"] and shard_sanity["lists_sorted"]
     if os.environ.get("PG_BENCH_STEPTIMES"):          # developer aid
         print("scan ms:", " ".join("%.2f" % x for x in scan_ms), "| rescans", ctx.stats().recall_rescans, file=sys.stderr)
     st = ctx.stats()
@@ -1350,9 +1629,13 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "mode": args.mode if world > 1 else "single",
         "scaling": "weak",
         "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
-        "config": {"workload": "configs[1]+[2]: recall 5k of %dx%d fp32 table in HBM -> 3-layer DNN rank "
-                               "(256-512-256-1, %s MFMA) -> RankScore fusion (fp64) -> ItemRankScore sort"
-                               % (args.rows, args.dim, args.prec),
+        "config": {"workload": ("configs[4]: %d x %d fp32 table in %d row-range shards (%d rows each), %d requests x top-%d -> all_gather "
+                                "merge -> owner-computes DNN3 rank (%s) -> all_reduce scores -> fuse -> sort -> DPPSort(500 candidates, "
+                                "page %d, window 10)" % (args.rows * world, args.dim, world, args.rows, R, K, args.prec, args.page))
+                               if shard else
+                               ("configs[1]+[2]: recall 5k of %dx%d fp32 table in HBM -> 3-layer DNN rank "
+                                "(256-512-256-1, %s MFMA) -> RankScore fusion (fp64) -> ItemRankScore sort"
+                                % (args.rows, args.dim, args.prec)),
                    "requests_per_step": R, "candidates_per_request": K, "table_rows": args.rows,
                    "dim": args.dim, "table_dist": args.table_dist, "batches_in_flight": 2 if not shard else 1,
                    "contexts": args.contexts,
@@ -1365,7 +1648,8 @@ def main():
                                    if world > 1 else "1 GPU")},
         "roofline": roofline_block(table, R, args, end - begin, scan_avg_ms, measured_gbs, ctx.last_scan_kernel()[1]),
         "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},
-        "oracle_spot_check": None if shard else spot,
+        "oracle_spot_check": shard_sanity if shard else spot,
+        "preflight": preflight,
         "rank_roofline": {"bound": "mfma", "kernel": "pg::dnn3_ws_kernel",
                           "achieved": rank_items * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
                           "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -1496,6 +1780,25 @@ def main():
             c4["roofline"]["traffic_detail"] = det4
             if tb4:
                 c4["roofline"]["traffic_bytes_per_item"] = tb4 / (R * K)
+    if world > 1 and not shard and not args.no_extras:
+        # the default N > 1 line carries both §8(e) forms of configs[4] beside the replica headline: the sharded step over
+        # RCCL (every rank) and pg_group_* in one process (rank 0, the others wait) — one driver command, both curves
+        for c_ in extra_ctxs:
+            c_.close()
+        model.destroy()
+        table.destroy()
+        blob5 = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+        try:
+            out["shard"] = shard_sub_leg(pa, o, torch, dist, coll, rank, world, 0 if share_gpu else local_rank, args, R, K, prec, blob5)
+        except Exception as ex_:                                # noqa: BLE001
+            out["shard"] = {"ok": False, "error": "%s: %s" % (type(ex_).__name__, ex_)}
+        dist.barrier()
+        if rank == 0:
+            try:
+                out["group"] = group_sub_leg(pa, o, [0] * world if share_gpu else list(range(world)), args, R, K, prec, blob5)
+            except Exception as ex_:                            # noqa: BLE001
+                out["group"] = {"ok": False, "error": "%s: %s" % (type(ex_).__name__, ex_)}
+        dist.barrier()
     failed = False
     if rank == 0:
         out["device"] = device_info()

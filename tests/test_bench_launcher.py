@@ -36,3 +36,46 @@ def test_inprocess_modes_fail_loudly_without_devices():
     for mode in ("group", "router"):
         r = _run(["--gpus", "2", "--mode", mode, "--steps", "1"])
         assert r.returncode != 0 and '"n_gpus"' not in r.stdout
+
+
+def test_launcher_counts_gpus_without_initialising_them():
+    """launch_ranks' parent must stay GPU-free (it starts the ranks as children): count_gpus reads the KFD topology or asks
+    a short-lived child — it never calls into torch.cuda in this process."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+    before = torch.cuda.is_initialized()
+    n = bench.count_gpus()
+    assert n == torch.cuda.device_count() or n >= 0
+    assert torch.cuda.is_initialized() == before
+
+
+def test_preflight_flag_and_modes_parse():
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "8", "--no-preflight", "--mode", "shard", "--prec", "bf16x3"]
+        a = bench.parse_args()
+        assert a.no_preflight and a.rows == 125_000_000 and a.prec == "bf16x3"
+        sys.argv = ["bench.py", "--gpus", "8"]
+        a = bench.parse_args()
+        assert not a.no_preflight and a.mode == "replica" and a.rows == 100_000_000
+    finally:
+        sys.argv = old
+
+
+def test_oracle_step_pages_is_the_single_table_pipeline():
+    """The preflight's checker: recall -> DNN3 -> RankScore -> sort -> DPP pick sequence on a small table; the page is a
+    DPP re-ordering of the head of the sorted list."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import numpy as np
+    from oracle import oracle as o
+    tab = o.synth_rows(o.SEED_TABLE, 0, 3000, 128)
+    q = o.synth_rows(o.SEED_QUERY, 1, 2, 128)
+    w = o.Dnn3Weights()
+    pages = bench.oracle_step_pages(o, tab, w, q, 100, 10, 30, 1.0, 5)
+    rows, rec = o.recall_topk(tab, q, 100)
+    for r in range(2):
+        assert len(pages[r]) == 10 and len(set(pages[r].tolist())) == 10 and set(pages[r].tolist()) <= set(rows[r].tolist())

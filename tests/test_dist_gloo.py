@@ -131,6 +131,28 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _agree_worker(rank, world, port, q, corrupt):
+    """bench.py's cross-rank check (every rank must hold identical rows / fused / order / page) over gloo: true when the
+    ranks agree, false on EVERY rank when one of them differs in a single bit of one tensor."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        import bench
+        g = torch.Generator().manual_seed(5)
+        rows = torch.randint(0, 1 << 40, (5, 64), generator=g, dtype=torch.int64)
+        fused = torch.rand((5, 64), generator=g, dtype=torch.float64)
+        order = torch.argsort(fused, dim=1, descending=True).to(torch.int32)
+        page = order[:, :8].contiguous()
+        if corrupt and rank == 1:
+            fused = fused.clone()
+            fused.view(torch.int64)[3, 17] ^= 1                      # one ulp of one score on one rank
+        q.put((rank, bench.ranks_agree(torch, dist, world, (rows, fused, order, page))))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -151,6 +173,22 @@ def _run(world):
         p.join(60)
         assert p.exitcode == 0
     return res
+
+
+@pytest.mark.timeout(300)
+def test_ranks_agree_check_of_the_bench_preflight():
+    ctx = mp.get_context("spawn")
+    for corrupt in (False, True):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q, corrupt)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=180) for _ in range(2))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        assert res == ({0: False, 1: False} if corrupt else {0: True, 1: True})
 
 
 def test_shard_ranges_cover_table():
