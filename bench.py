@@ -1641,6 +1641,9 @@ def main():
                    "contexts": args.contexts,
                    "calibration_batches": 0 if shard else args.calibrate,
                    "timed_batches_on_predicted_thresholds": None if shard else int(predicted_batches),
+                   # the claim "the timed region runs on plan 0" as a checked figure: warm-up + timed batches of the region
+                   "batches_in_timed_region_incl_warmup": None if shard else int(args.warmup + args.steps),
+                   "all_batches_on_predicted_thresholds": None if shard else bool(predicted_batches >= args.warmup + args.steps),
                    "batches_re_run_after_a_failed_plan": None if shard else int(rescans),
                    "parallelism": ("table row-range shards x%d (%d rows total), all_gather top-K merge + all_reduce scores + DPP top-500"
                                    % (world, args.rows * world)) if shard else

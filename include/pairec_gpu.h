@@ -223,6 +223,16 @@ int pg_fm2t_user_embedding_dev(pg_ctx* ctx, const pg_model* m, const float* d_us
 int pg_expr_compile(const char* source, pg_expr** out);
 int pg_expr_free(pg_expr* e);
 int pg_expr_num_vars(const pg_expr* e);
+/* GetExpASTWithType (utils/ast/ast.go:338-343): ast_type NULL, "" or anything but "antlr" = pg_expr_compile.  "antlr" selects the
+ * reference's second evaluator (go-antlr-valuate v0.0.4, un-vendored); the engine serves the SUBSET its tests pin
+ * (utils/ast/ast_test.go:30-56,90-167,213-300): + - * / ^ (^ = math.Pow, above * /, above + -), parentheses, unary minus,
+ * numbers, ${name}, maxIndex(${list}) / maxValue(${list}) (antlr_functions.go:34-66) — `/` is float division (no panic).
+ * Everything else returns PG_ERR_UNSUPPORTED naming the construct.  A list function becomes a variable called
+ * "maxIndex(name)" / "maxValue(name)" (pg_expr_var_name) that the caller fills per item from the list property.
+ * ExprASTResultByAntlr's error rule — an item that lacks ANY variable of the expression scores 0 (ast.go:374-383) — is the
+ * caller's to apply (pg_expr_is_antlr tells it to). */
+int pg_expr_compile_typed(const char* source, const char* ast_type, pg_expr** out);
+int pg_expr_is_antlr(const pg_expr* e);
 /* RankConfig.ScoreRewrite (recconf/recconf.go:743; service/rank/rank_service.go:296-306,343-353): a map source → expression.
  * Per item the reference evaluates EVERY source's expression over the item as the algorithms left it, collects the results
  * in a map, writes them back with Item.AddAlgoScores (overwriting / adding algorithm scores named `source`) and only then

@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import re
 import subprocess
 from typing import Dict, List, Optional, Sequence
 
@@ -656,6 +657,169 @@ def go_pow(x: float, y: float) -> float:
         if x == 0 and y < 0:
             return math.copysign(math.inf, x) if float(y).is_integer() and int(y) % 2 == 1 else math.inf
         return math.nan
+
+
+# ---------------------------------------------------------------------------------------------
+# ASTType "antlr" (utils/ast/ast.go:275-389): the expression goes to go-antlr-valuate v0.0.4 — NOT vendored, its grammar is
+# known here only through the reference's own tests (utils/ast/ast_test.go:30-56,90-167,213-300) and the functions pairec
+# registers (utils/ast/antlr_functions.go:34-91).  Restated: the subset those pin — + - * / ^ with ^ = math.Pow binding
+# tighter than * /, those tighter than + -; parentheses; unary minus; numbers; ${name}; maxIndex(${v}) / maxValue(${v}) —
+# and ExprASTResultByAntlr's error rule: a variable the data map lacks (or a non-numeric one) fails Evaluate → 0.
+# "parity unpinned" beyond those vectors: `/` is taken as Go's float64 division, a chained a^b^c is refused.
+# ---------------------------------------------------------------------------------------------
+class AntlrUnsupported(Exception):
+    pass
+
+
+def antlr_parse(src: str):
+    """GetExpASTByAntlr for the pinned subset: '' → None; anything outside the subset raises AntlrUnsupported."""
+    if src == "":
+        return None
+    pos = [0]
+
+    def ws():
+        while pos[0] < len(src) and src[pos[0]] in " \t\n\r":
+            pos[0] += 1
+
+    def param():
+        if src[pos[0]:pos[0] + 2] != "${":
+            raise AntlrUnsupported("expected ${name}")
+        close = src.find("}", pos[0] + 2)
+        if close < 0 or close == pos[0] + 2:
+            raise AntlrUnsupported("unterminated ${")
+        name = src[pos[0] + 2:close]
+        pos[0] = close + 1
+        return name
+
+    def primary():
+        ws()
+        if pos[0] >= len(src):
+            raise AntlrUnsupported("unexpected end")
+        c = src[pos[0]]
+        if c == "(":
+            pos[0] += 1
+            e = expr()
+            ws()
+            if pos[0] >= len(src) or src[pos[0]] != ")":
+                raise AntlrUnsupported("missing )")
+            pos[0] += 1
+            return e
+        if c == "-":
+            pos[0] += 1
+            return ("neg", power())
+        if c == "$":
+            return ("param", param())
+        if c.isdigit() or c == ".":
+            m = re.match(r"(\d+\.?\d*|\.\d+)([eE][+-]?\d+)?", src[pos[0]:])
+            if not m:
+                raise AntlrUnsupported("malformed number")
+            pos[0] += m.end()
+            return ("num", float(m.group(0)))
+        if c.isalpha() or c == "_":
+            m = re.match(r"[A-Za-z_][A-Za-z0-9_]*", src[pos[0]:])
+            fn = m.group(0)
+            if fn not in ("maxIndex", "maxValue"):
+                raise AntlrUnsupported("function %s" % fn)
+            pos[0] += m.end()
+            ws()
+            if pos[0] >= len(src) or src[pos[0]] != "(":
+                raise AntlrUnsupported("%s(" % fn)
+            pos[0] += 1
+            ws()
+            name = param()
+            ws()
+            if pos[0] >= len(src) or src[pos[0]] != ")":
+                raise AntlrUnsupported("%s: one ${list} argument" % fn)
+            pos[0] += 1
+            return (fn, name)
+        raise AntlrUnsupported("'%s'" % c)
+
+    def power():
+        b = primary()
+        ws()
+        if pos[0] < len(src) and src[pos[0]] == "^":
+            pos[0] += 1
+            b = ("bin", "^", b, primary())
+            ws()
+            if pos[0] < len(src) and src[pos[0]] == "^":
+                raise AntlrUnsupported("chained ^")
+        return b
+
+    def term():
+        l = power()
+        while True:
+            ws()
+            if pos[0] >= len(src) or src[pos[0]] not in "*/":
+                return l
+            if src[pos[0]:pos[0] + 2] == "**":
+                raise AntlrUnsupported("**")
+            op = src[pos[0]]
+            pos[0] += 1
+            l = ("bin", op, l, power())
+
+    def expr():
+        l = term()
+        while True:
+            ws()
+            if pos[0] >= len(src) or src[pos[0]] not in "+-":
+                return l
+            op = src[pos[0]]
+            pos[0] += 1
+            l = ("bin", op, l, term())
+
+    e = expr()
+    ws()
+    if pos[0] != len(src):
+        raise AntlrUnsupported("'%s'" % src[pos[0]])
+    return e
+
+
+def antlr_result(ast, data: Dict[str, object]) -> float:
+    """ExprASTResultByAntlr (ast.go:374-389) over the item's ExprData map: an evaluation error → 0."""
+    class _Fail(Exception):
+        pass
+
+    def num(v):
+        if isinstance(v, bool) or not isinstance(v, (int, float, np.integer, np.floating)):
+            raise _Fail()
+        return float(v)
+
+    def ev(a):
+        k = a[0]
+        if k == "num":
+            return a[1]
+        if k == "param":
+            if a[1] not in data:
+                raise _Fail()
+            return num(data[a[1]])
+        if k == "neg":
+            return -ev(a[1])
+        if k in ("maxIndex", "maxValue"):
+            if a[1] not in data or not isinstance(data[a[1]], (list, tuple, np.ndarray)) or len(data[a[1]]) == 0:
+                raise _Fail()
+            vals = [to_float(x, 0.0) for x in data[a[1]]]
+            best = 0
+            for i in range(1, len(vals)):                      # findMax (antlr_functions.go:72-91): first maximum
+                if vals[i] > vals[best]:
+                    best = i
+            return float(best) if k == "maxIndex" else vals[best]
+        l, r = ev(a[2]), ev(a[3])
+        if a[1] == "+":
+            return l + r
+        if a[1] == "-":
+            return l - r
+        if a[1] == "*":
+            return l * r
+        if a[1] == "/":
+            return float(np.float64(l) / np.float64(r)) if r != 0 else float(np.divide(np.float64(l), np.float64(r)))
+        return go_pow(l, r)
+    if ast is None:
+        return 0.0
+    try:
+        with np.errstate(all="ignore"):
+            return ev(ast)
+    except _Fail:
+        return 0.0
 
 
 class OracleItem:

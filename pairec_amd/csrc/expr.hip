@@ -10,7 +10,11 @@
 //   the token (parseNumber, ast.go:108-124) and the recorded error is ignored by GetExpAST — so
 //   "-5" is 0-5 and "2*1e-5" is 2*0;  `#` = first non-zero, `^` = math.Pow, `%` = int(l) % int(r);
 //   `/` by zero and `%` by zero panic in the reference → PG_ERR_ARITH here.
-// The antlr evaluator (ASTType "antlr", go-antlr-valuate, not vendored) is out of scope.
+// ASTType "antlr" (GetExpASTByAntlr / ExprASTResultByAntlr, ast.go:275-389) hands the source to go-antlr-valuate v0.0.4, which
+// is not vendored.  pg_expr_compile_typed(…, "antlr") serves the SUBSET of that language the reference's own tests pin
+// (ast_test.go:30-56,90-167,213-300): + - * / ^ with ^ = math.Pow above * / above + -, parentheses, unary minus, numbers,
+// ${name}, and the registered functions maxIndex(${v}) / maxValue(${v}) over a list property (antlr_functions.go:34-66) —
+// compiled to the same device program; anything else is refused BY NAME (PG_ERR_UNSUPPORTED), never evaluated differently.
 #include "common.hpp"
 
 #include <cmath>
@@ -19,7 +23,9 @@
 
 namespace pg {
 
-enum OpCode : uint32_t { OP_CONST = 0, OP_VAR, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD, OP_POW, OP_FNZ };
+enum OpCode : uint32_t { OP_CONST = 0, OP_VAR, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD, OP_POW, OP_FNZ,
+                         OP_DIVF,   // antlr subset: float division as Go's `/` on float64 (no panic: ±Inf / NaN)
+                         OP_NEG };  // antlr subset: unary minus
 
 struct Instr {
     uint32_t op;
@@ -38,6 +44,7 @@ struct pg_expr {
     std::vector<std::string> vars;
     int max_depth = 0;
     bool empty = false;       // "" → no expression (GetExpAST returns nil)
+    bool antlr = false;       // compiled by pg_expr_compile_typed(…, "antlr"): the evaluation-error rule of ExprASTResultByAntlr applies on the host
     // RankConfig.ScoreRewrite of the scene this RankScore belongs to (pg_expr_set_score_rewrites): evaluated by the
     // recommend pipelines' fusion stage before the RankScore itself (pipeline.hip: post_fuse_sort_locked)
     struct Rewrite {
@@ -329,10 +336,15 @@ __global__ void expr_eval_kernel(ExprDev e, const double* __restrict__ vars, uin
         } else if (in.op == OP_VAR) {
             st[sp++] = vars[(size_t)in.arg * n_items + i];
         } else {
+            if (in.op == OP_NEG) {
+                st[sp - 1] = -st[sp - 1];
+                continue;
+            }
             const double r = st[--sp];
             const double l = st[--sp];
             double v = 0.0;
             switch (in.op) {
+                case OP_DIVF: v = l / r; break;
                 case OP_ADD: v = l + r; break;
                 case OP_SUB: v = l - r; break;
                 case OP_MUL: v = l * r; break;
@@ -464,6 +476,187 @@ int pg_expr_compile(const char* source, pg_expr** out) {
     *out = e;
     return PG_OK;
 }
+
+// ---- the antlr subset (see the file header) -------------------------------------------------------------------------
+namespace pg {
+namespace {
+struct AntlrParser {
+    const std::string& s;
+    size_t i = 0;
+    pg_expr* e;
+    int depth = 0, max_depth = 0, nest = 0;
+    std::string err;
+    AntlrParser(const std::string& src, pg_expr* out) : s(src), e(out) {}
+    void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r')) ++i; }
+    bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
+    void push(uint32_t op, uint32_t arg, double val) {
+        e->prog.push_back({op, arg, val});
+        if (op == OP_CONST || op == OP_VAR) max_depth = std::max(max_depth, ++depth);
+        else if (op != OP_NEG) --depth;
+    }
+    uint32_t var(const std::string& name) {
+        uint32_t idx = 0;
+        for (; idx < e->vars.size(); ++idx)
+            if (e->vars[idx] == name) break;
+        if (idx == e->vars.size()) e->vars.push_back(name);
+        return idx;
+    }
+    bool param(std::string* name) {                  // ${name}
+        if (s.compare(i, 2, "${") != 0) return fail("expected ${name}");
+        const size_t close = s.find('}', i + 2);
+        if (close == std::string::npos || close == i + 2) return fail("unterminated or empty ${…}");
+        *name = s.substr(i + 2, close - i - 2);
+        i = close + 1;
+        return true;
+    }
+    bool primary() {
+        ws();
+        if (i >= s.size()) return fail("unexpected end of the expression");
+        if (++nest > 64) return fail("nesting deeper than 64");
+        bool ok = primary_inner();
+        --nest;
+        return ok;
+    }
+    bool primary_inner() {
+        const char c = s[i];
+        if (c == '(') {
+            ++i;
+            if (!expr()) return false;
+            ws();
+            if (i >= s.size() || s[i] != ')') return fail("missing ')'");
+            ++i;
+            return true;
+        }
+        if (c == '-') {
+            ++i;
+            if (!unary_operand()) return false;
+            push(OP_NEG, 0, 0.0);
+            return true;
+        }
+        if (c == '$') {
+            std::string name;
+            if (!param(&name)) return false;
+            push(OP_VAR, var(name), 0.0);
+            return true;
+        }
+        if ((c >= '0' && c <= '9') || c == '.') {
+            char* end = nullptr;
+            const double v = strtod(s.c_str() + i, &end);
+            const size_t used = (size_t)(end - (s.c_str() + i));
+            if (used == 0) return fail("malformed number");
+            // (strtod also reads hex floats, "inf" and "nan": not numbers of the subset)
+            for (size_t j = i; j < i + used; ++j) {
+                const char d = s[j];
+                if (!((d >= '0' && d <= '9') || d == '.' || d == 'e' || d == 'E' || ((d == '+' || d == '-') && j > i &&
+                      (s[j - 1] == 'e' || s[j - 1] == 'E'))))
+                    return fail("malformed number");
+            }
+            i += used;
+            push(OP_CONST, 0, v);
+            return true;
+        }
+        if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_') {
+            size_t j = i;
+            while (j < s.size() && ((s[j] >= 'a' && s[j] <= 'z') || (s[j] >= 'A' && s[j] <= 'Z') || (s[j] >= '0' && s[j] <= '9') || s[j] == '_')) ++j;
+            const std::string fn = s.substr(i, j - i);
+            if (fn != "maxIndex" && fn != "maxValue")
+                return fail("\"" + fn + "\" is not in the served subset (functions: maxIndex, maxValue over a ${list} property)");
+            i = j;
+            ws();
+            if (i >= s.size() || s[i] != '(') return fail(fn + ": expected '('");
+            ++i;
+            ws();
+            std::string name;
+            if (!param(&name)) return fail(fn + ": the argument must be one ${list} property");
+            ws();
+            if (i >= s.size() || s[i] != ')') return fail(fn + ": the argument must be one ${list} property");
+            ++i;
+            // a derived variable: the host resolves "maxIndex(name)" / "maxValue(name)" from the item's list property
+            push(OP_VAR, var(fn + "(" + name + ")"), 0.0);
+            return true;
+        }
+        return fail(std::string("'") + c + "' is not in the served subset");
+    }
+    bool unary_operand() { return power(); }         // -a^b = -(a^b)
+    bool power() {
+        if (!primary()) return false;
+        ws();
+        if (i < s.size() && s[i] == '^') {
+            ++i;
+            if (!primary()) return false;
+            push(OP_POW, 0, 0.0);
+            ws();
+            if (i < s.size() && s[i] == '^') return fail("a ^ b ^ c: the associativity of the reference's antlr grammar is not pinned by its tests; parenthesise");
+        }
+        return true;
+    }
+    bool term() {
+        if (!power()) return false;
+        for (;;) {
+            ws();
+            if (i >= s.size() || (s[i] != '*' && s[i] != '/')) return true;
+            if (s.compare(i, 2, "**") == 0) return fail("'**' is not in the served subset");
+            const char op = s[i++];
+            if (!power()) return false;
+            push(op == '*' ? OP_MUL : OP_DIVF, 0, 0.0);
+        }
+    }
+    bool expr() {
+        if (!term()) return false;
+        for (;;) {
+            ws();
+            if (i >= s.size() || (s[i] != '+' && s[i] != '-')) return true;
+            const char op = s[i++];
+            if (!term()) return false;
+            push(op == '+' ? OP_ADD : OP_SUB, 0, 0.0);
+        }
+    }
+};
+}  // namespace
+}  // namespace pg
+
+int pg_expr_compile_typed(const char* source, const char* ast_type, pg_expr** out) {
+    // GetExpASTWithType (ast.go:338-343): exactly "antlr" selects the other evaluator, anything else the default one
+    if (!ast_type || strcmp(ast_type, "antlr") != 0) return pg_expr_compile(source, out);
+    PG_REQUIRE(source && out, "pg_expr_compile_typed: NULL argument");
+    pg_expr* e = new pg_expr();
+    e->source = source;
+    e->antlr = true;
+    if (e->source.empty()) {                                 // GetExpASTByAntlr(""): nil
+        e->empty = true;
+        *out = e;
+        return PG_OK;
+    }
+    if (e->source.size() > 16384) {
+        pg::set_error("pg_expr_compile_typed: expression too large (%zu bytes)", e->source.size());
+        delete e;
+        return PG_ERR_UNSUPPORTED;
+    }
+    pg::AntlrParser p(e->source, e);
+    bool ok = p.expr();
+    if (ok) {
+        p.ws();
+        if (p.i != e->source.size()) ok = p.fail(std::string("'") + e->source[p.i] + "' is not in the served subset");
+    }
+    if (!ok) {
+        pg::set_error("pg_expr_compile_typed: ASTType \"antlr\": %s at byte %zu of '%s' — the engine serves the subset of the "
+                      "go-antlr-valuate language the reference's tests pin (+ - * / ^, parentheses, ${name}, maxIndex / maxValue; "
+                      "utils/ast/ast_test.go:30-56,90-167,213-300) and refuses the rest rather than evaluate it differently",
+                      p.err.c_str(), p.i, source);
+        delete e;
+        return PG_ERR_UNSUPPORTED;
+    }
+    if (e->prog.size() > (size_t)pg::kMaxProg || p.max_depth > pg::kMaxStack) {
+        pg::set_error("pg_expr_compile_typed: expression too large (%zu operations, depth %d)", e->prog.size(), p.max_depth);
+        delete e;
+        return PG_ERR_UNSUPPORTED;
+    }
+    e->max_depth = p.max_depth;
+    *out = e;
+    return PG_OK;
+}
+
+int pg_expr_is_antlr(const pg_expr* e) { return e && e->antlr ? 1 : 0; }
 
 int pg_expr_free(pg_expr* e) {
     delete e;

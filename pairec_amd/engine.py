@@ -412,10 +412,14 @@ def rank_fm2t_rows_host(model: "RankModel", feats: "Features", item_field_names,
 class Expr:
     """Compiled RankConfig.RankScore expression (utils/ast replacement)."""
 
-    def __init__(self, source: str):
+    def __init__(self, source: str, ast_type: str = ""):
+        """ast_type "antlr": the subset of the reference's second evaluator (pg_expr_compile_typed)."""
         self.L = _lib.load()
         h = C.c_void_p()
-        _lib.check(self.L.pg_expr_compile(source.encode("utf-8"), C.byref(h)))
+        if ast_type:
+            _lib.check(self.L.pg_expr_compile_typed(source.encode("utf-8"), ast_type.encode("utf-8"), C.byref(h)))
+        else:
+            _lib.check(self.L.pg_expr_compile(source.encode("utf-8"), C.byref(h)))
         self.h = h
         n = self.L.pg_expr_num_vars(h)
         self.var_names = [self.L.pg_expr_var_name(h, i).decode("utf-8") for i in range(n)]

@@ -1337,22 +1337,66 @@ bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, co
         // one expression over every item: variables from the AB parameters first, then the item (ast_parameter_data.go:30-40)
         auto eval = [&](pg_expr* ex, std::vector<double>* out) -> bool {
             const int nv = pg_expr_num_vars(ex);
+            const bool antlr = pg_expr_is_antlr(ex) != 0;
             std::vector<double> vars((size_t)nv * n, 0.0);
+            std::vector<char> failed(antlr ? n : 0, 0);
             out->assign(n, 0.0);
             for (int v = 0; v < nv; ++v) {
                 const std::string name = pg_expr_var_name(ex, v);
                 auto ab = ctx->ExperimentParams.find(name);
+                if (!antlr) {
+                    for (uint32_t i = 0; i < n; ++i) {
+                        double x = 0.0;
+                        if (ab != ctx->ExperimentParams.end() && ab->second != 0.0) x = ab->second;
+                        else items[i]->FloatExprData(name, &x);
+                        vars[(size_t)v * n + i] = x;
+                    }
+                    continue;
+                }
+                // ASTType "antlr": the data is AstParameterData.ExprData() — the experiment's parameters overlaid by the item's
+                // algorithm scores and properties (ast_parameter_data.go:17-28, item.go:213-227; no "current_score" there); a
+                // variable the map lacks, or one that is not a number, fails the evaluation: the item scores 0 (ast.go:374-383).
+                // maxIndex(${p}) / maxValue(${p}) (antlr_functions.go:34-66,72-91) read the list property p.
+                const bool fidx = name.rfind("maxIndex(", 0) == 0, fval = name.rfind("maxValue(", 0) == 0;
+                const std::string inner = (fidx || fval) ? name.substr(9, name.size() - 10) : name;
                 for (uint32_t i = 0; i < n; ++i) {
                     double x = 0.0;
-                    if (ab != ctx->ExperimentParams.end() && ab->second != 0.0) x = ab->second;
-                    else items[i]->FloatExprData(name, &x);
+                    bool ok = false;
+                    const module::Item& it = *items[i];
+                    auto a = it.algoScores.find(inner);
+                    auto p = it.Properties.find(inner);
+                    if (fidx || fval) {
+                        if (p != it.Properties.end() && p->second.type == json::Value::Array && !p->second.arr.empty()) {
+                            size_t best = 0;
+                            double bv = ToFloat(p->second.arr[0], 0.0);
+                            for (size_t j = 1; j < p->second.arr.size(); ++j) {
+                                const double cv = ToFloat(p->second.arr[j], 0.0);
+                                if (cv > bv) { bv = cv; best = j; }
+                            }
+                            x = fidx ? (double)best : bv;
+                            ok = true;
+                        }
+                    } else if (p != it.Properties.end()) {                  // (the item's properties are written last: they win)
+                        ok = p->second.type == json::Value::Number;
+                        x = p->second.num;
+                    } else if (a != it.algoScores.end()) {
+                        x = a->second;
+                        ok = true;
+                    } else if (ab != ctx->ExperimentParams.end()) {
+                        x = ab->second;
+                        ok = true;
+                    }
+                    if (!ok) failed[i] = 1;
                     vars[(size_t)v * n + i] = x;
                 }
             }
-            return !n || pg_expr_eval(e->ctx, ex, nv ? vars.data() : nullptr, n, out->data()) == PG_OK;
+            if (n && pg_expr_eval(e->ctx, ex, nv ? vars.data() : nullptr, n, out->data()) != PG_OK) return false;
+            for (uint32_t i = 0; antlr && i < n; ++i)
+                if (failed[i]) (*out)[i] = 0.0;
+            return true;
         };
         pg_expr* ex = nullptr;
-        if (pg_expr_compile(conf.RankScore.c_str(), &ex) != PG_OK) { if (err) *err = pg_err("pg_expr_compile"); return false; }
+        if (pg_expr_compile_typed(conf.RankScore.c_str(), conf.ASTType.c_str(), &ex) != PG_OK) { if (err) *err = pg_err("pg_expr_compile"); return false; }
         // ScoreRewrite (:296-306,343-353): every source's expression over the item as the algorithms left it, into a map
         // first, then written back (AddAlgoScores); a source whose expression does not compile scores 0
         if (!conf.ScoreRewrite.empty()) {
@@ -1360,7 +1404,7 @@ bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, co
             for (const auto& rw : conf.ScoreRewrite) {
                 std::vector<double> vals(n, 0.0);
                 pg_expr* rex = nullptr;
-                if (pg_expr_compile(rw.second.c_str(), &rex) == PG_OK) {
+                if (pg_expr_compile_typed(rw.second.c_str(), conf.ASTType.c_str(), &rex) == PG_OK) {
                     const bool ok = eval(rex, &vals);
                     pg_expr_free(rex);
                     if (!ok) { pg_expr_free(ex); if (err) *err = pg_err(("pg_expr_eval (ScoreRewrite[" + rw.first + "])").c_str()); return false; }
@@ -1603,12 +1647,21 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
     // RankConf.ASTType = "antlr" selects another expression language in the reference (GetExpASTWithType /
     // ExprASTResultWithType, utils/ast/ast.go:338-389: the valuate evaluator with AntlrFunctions — maxIndex, maxValue, …).
     // This engine evaluates the default grammar only; evaluating an "antlr" RankScore with it would silently change scores.
+    // Round 5: the subset of that language the reference's tests pin is compiled to the device program
+    // (pg_expr_compile_typed); a RankScore or ScoreRewrite expression outside it still stops the load, named.
     for (const auto& kv : e->config.RankConf)
         if (kv.second.ASTType == "antlr") {
-            if (err) *err = "RankConf[" + kv.first + "].ASTType \"antlr\": the antlr expression evaluator (utils/ast/ast.go:338-389, "
-                            "GetExpASTByAntlr / ExprASTResultByAntlr) is not implemented by the GPU engine; leave ASTType empty to use "
-                            "the default AST or keep this scene's RankScore on the CPU path";
-            return nullptr;
+            std::vector<std::pair<std::string, std::string>> exprs;
+            exprs.emplace_back("RankScore", kv.second.RankScore);
+            for (const auto& rw : kv.second.ScoreRewrite) exprs.emplace_back("ScoreRewrite[" + rw.first + "]", rw.second);
+            for (const auto& ex : exprs) {
+                pg_expr* probe = nullptr;
+                if (pg_expr_compile_typed(ex.second.c_str(), "antlr", &probe) != PG_OK) {
+                    if (err) *err = "RankConf[" + kv.first + "]." + ex.first + " with ASTType \"antlr\": " + pg_last_error();
+                    return nullptr;
+                }
+                pg_expr_free(probe);
+            }
         }
     for (const auto& sc : e->config.SortConfs) {
         // RegisterSortWithConfig (sort/sort.go:162-200): DPPSort / SSDSort open their Hologres datasource first

@@ -197,3 +197,41 @@ def test_bf16_mode_against_f32_mode_bounds(ctx):
     for m in (m16, m32):
         m.destroy()
     t.destroy()
+
+
+def test_extra_heads_cost_a_fraction_of_a_model(ctx):
+    """What DESIGN.md / README claim for heads on a shared trunk, bounded: at 256 x 5 000 candidates the
+    rank stage of a 2-output model costs at most 1.12 x the one-output model's (k separate models cost k x), 4 outputs at
+    most 1.3 x, 8 at most 1.6 x — best of several alternating runs, device time around the stage."""
+    import time
+    n, R, K = 4_000_000, 256, 5000
+    t = pa.Table(ctx, n, 128)
+    t.fill_synthetic(o.SEED_TABLE)
+    rng = np.random.default_rng(5)
+    nI = R * K
+    d_u = ctx.to_device(o.synth_rows(o.SEED_QUERY, 0, R, 128))
+    d_c = ctx.to_device(rng.integers(0, n, nI).astype(np.uint32))
+    d_o = ctx.to_device((np.arange(R + 1) * K).astype(np.uint32))
+    d_out = ctx.malloc(nI * 4 * 8)
+    w1 = o.Dnn3Weights()
+    models = {1: pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16, pa.pack_dnn3(w1.w1, w1.b1, w1.w2, w1.b2, w1.w3, w1.b3, 128))}
+    for n_out in (2, 4, 8):
+        w = o.Dnn3MultiWeights(n_out)
+        models[n_out] = pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, pa.PREC_BF16, _pack(w))
+    best = {k_: 1e9 for k_ in models}
+    for _ in range(5):                                   # alternating: clock and power state drift hits every model alike
+        for n_out, m in models.items():
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(8):
+                m.rank_dnn3_dev(t, d_u, d_c, d_o, R, nI, d_out)
+            ctx.synchronize()
+            best[n_out] = min(best[n_out], (time.perf_counter() - t0) / 8)
+    ratios = {k_: best[k_] / best[1] for k_ in (2, 4, 8)}
+    print("rank stage ms by outputs:", {k_: round(v * 1e3, 4) for k_, v in best.items()}, "ratios", ratios)
+    assert ratios[2] <= 1.12 and ratios[4] <= 1.3 and ratios[8] <= 1.6, ratios
+    for m in models.values():
+        m.destroy()
+    for p_ in (d_u, d_c, d_o, d_out):
+        ctx.free(p_)
+    t.destroy()

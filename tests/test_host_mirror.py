@@ -876,17 +876,22 @@ def test_http_harness_end_to_end():
     h.close()
 
 
-def test_asttype_antlr_is_refused_at_load(H):
+def test_asttype_antlr_outside_the_served_subset_is_refused_at_load(H):
     """RankConf.ASTType = "antlr" selects the valuate evaluator in the reference (GetExpASTWithType / ExprASTResultWithType,
-    utils/ast/ast.go:338-389; functions such as maxIndex, ast_test.go:267+).  The engine evaluates the default grammar only:
-    such a scene is an error at load — before any GPU work — never a silent evaluation by the other grammar.  Any other
-    ASTType value means the default AST in the reference too."""
+    utils/ast/ast.go:338-389).  The engine serves the subset of that language the reference's tests pin
+    (tests/test_expr_antlr.py); a scene whose RankScore or ScoreRewrite uses anything else is an error at load — before any
+    GPU work — never a silent evaluation by another grammar."""
     import copy
     cfg = copy.deepcopy(CONFIG)
     cfg["RankConf"]["home_feed"]["ASTType"] = "antlr"
+    cfg["RankConf"]["home_feed"]["RankScore"] = "${gpu_dnn} > 0.5 ? 1 : 0"
     assert not H.ph_engine_create(json.dumps(cfg).encode())
     msg = H.ph_last_error()
-    assert b'ASTType "antlr"' in msg and b"RankConf[home_feed]" in msg and b"utils/ast/ast.go:338-389" in msg
+    assert b'ASTType "antlr"' in msg and b"RankConf[home_feed].RankScore" in msg and b"utils/ast/ast_test.go" in msg
+    cfg["RankConf"]["home_feed"]["RankScore"] = "${gpu_dnn}*2"
+    cfg["RankConf"]["home_feed"]["ScoreRewrite"] = {"gpu_dnn": "exp(${gpu_dnn})"}
+    assert not H.ph_engine_create(json.dumps(cfg).encode())
+    assert b"ScoreRewrite[gpu_dnn]" in H.ph_last_error() and b'"exp"' in H.ph_last_error()
 
 
 @pytest.mark.gpu
