@@ -17,6 +17,13 @@
 //   One barrier per chunk.  The two waves of a SIMD run different code between the same barriers, so one's LDS reads, global
 //   loads and conversions sit under the other's MFMAs without any hand-made interleaving — and the matrix pipe sees
 //   48 + 96 MFMAs per SIMD and interval whichever wave issues them.
+// Where it stands (round 5, PG_X3_PROFILE-style cycle stamps and ablation builds on the dev library): the matrix pipe is 61 %
+// busy at the 1.95 GHz the chip holds under this kernel.  An interval is 6.3-6.7 K cycles for 4.6 K of MFMA issue per SIMD;
+// the layer-1 wave is its critical path (48 MFMAs + conversion: 2.9 K cycles with the pipe to itself, 5.4-6.8 K beside the
+// layer-2 wave's 96 MFMAs).  Tried and dropped, all bit-identical, none faster than 1.18-1.20 ms: the conversion of chunk
+// c under the MFMAs of chunk c + 1 (second accumulator set, layer-2 waves two intervals behind; as a block per k-step, and
+// cut into pieces between the individual MFMAs), weight fragments re-requested per k-step, weight fragments two k-steps
+// ahead in the layer-2 waves, priority to the layer-2 waves (-3 %).
 // Weights (768 KB at 512-256: every matrix as hi and lo fragments) do not fit the CU: they stream from L2 once per tile,
 // global → registers, each fragment a k-step (layer 2) or a chunk (layer 1) ahead of its use.  A layer-2 fragment feeds
 // four item blocks (hi fragments twice): 6 / 3 MFMAs per 1-KiB load.  LDS: X hi / lo 64 KB + two H1 chunks hi / lo 64 KB +
@@ -42,11 +49,13 @@ constexpr size_t x3_lds_bytes(uint32_t n_out) {
 
 // relu → split → 4 consecutive columns of one row of an H1 chunk tile (128-B rows, quads keyed by (row >> 1) & 7: see
 // ls_store_h_quad in rank_rs.hip); the lo tile lies LO bytes on
+__device__ __forceinline__ float x3_relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
+
 template <int LO>
 __device__ __forceinline__ void x3_store_h_quad(char* tile, int row, int col, float v0, float v1, float v2, float v3) {
     uint2 ph, pl;
-    split_bf16x2(fmaxf(v0, 0.0f), fmaxf(v1, 0.0f), ph.x, pl.x);
-    split_bf16x2(fmaxf(v2, 0.0f), fmaxf(v3, 0.0f), ph.y, pl.y);
+    split_bf16x2(x3_relu(v0), x3_relu(v1), ph.x, pl.x);
+    split_bf16x2(x3_relu(v2), x3_relu(v3), ph.y, pl.y);
     char* const d = tile + row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + (col & 7) * 2;
     *reinterpret_cast<uint2*>(d) = ph;
     *reinterpret_cast<uint2*>(d + LO) = pl;
@@ -81,6 +90,9 @@ __global__ __launch_bounds__(512, 1) void dnn3_x3_kernel(MlpArgs a) {
 
     if (wave < 4) {
         // =========================================== layer-1 waves ===========================================
+        // the layer-1 wave's MFMAs first: its relu / split / store then runs under the other wave's MFMAs (+1 %; the other
+        // way round costs 3 %)
+        asm volatile("s_setprio 2");
         const int mp = wave & 1, nb1 = wave >> 1;
         const char* const w1h_base = reinterpret_cast<const char*>(a.w1p);
         const char* const w1l_base = reinterpret_cast<const char*>(a.w1p_lo);

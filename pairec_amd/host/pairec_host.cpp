@@ -1731,8 +1731,24 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
         else { if (err) *err = "pairec_gpu.Sorts: unknown SortType " + sc.SortType; return nullptr; }
     }
     // algorithms by name (the shim's start hook does the same with algorithm.RegisterAlgorithm)
+    bool first_dnn = true, first_fm = true;
     for (const auto& a : g.at("Algorithms").arr) {
         const std::string name = a.s("Name"), kind = a.s("Kind");
+        if (a.has("Precision")) {
+            // the rank model's matrix layers: "f32" (bit-defined), "bf16" (fastest), "bf16x3" (split bf16: the fp32 scores of
+            // the reference's model servers — eas/easyrec_response.go:479-483 — at matrix-pipe speed)
+            const std::string pr = a.s("Precision");
+            const int pv = pr == "f32" ? PG_PREC_F32 : pr == "bf16" ? PG_PREC_BF16 : pr == "bf16x3" ? PG_PREC_BF16X3 : -1;
+            if (pv < 0) {
+                if (err) *err = "pairec_gpu.Algorithms: " + name + ": Precision \"" + pr + "\" (f32, bf16 or bf16x3)";
+                return nullptr;
+            }
+            e->algo_precision[name] = pv;
+            if (kind == "dnn3" && first_dnn) e->default_dnn_precision = pv;
+            if (kind == "fm2t" && first_fm) e->default_fm2t_precision = pv;
+        }
+        first_dnn = first_dnn && kind != "dnn3";
+        first_fm = first_fm && kind != "fm2t";
         if (kind == "faiss") e->algorithms.RegisterAlgorithm(name, std::make_shared<GpuFaissAlgorithm>(e.get()));
         else if (kind == "dnn3") {
             std::vector<std::string> outs;
@@ -1967,6 +1983,7 @@ int ph_engine_load_dnn3(void* h, int prec, const char* blob, size_t len) {
     VersionLock::Write w(e->version);                  // no request is inside the coalescers / holds the model this replaces
     e->DropCoalescers();                               // they hold the old model
     if (e->model) { pg_model_destroy(e->ctx, e->model); e->model = nullptr; }
+    if (prec < 0) prec = e->default_dnn_precision;     // pairec_gpu.Algorithms[].Precision of the scene's DNN
     const int rc = pg_model_load(e->ctx, PG_MODEL_DNN3, (pg_prec)prec, blob, len, &e->model);
     if (rc != PG_OK) g_ph_err = pg_last_error();
     return rc;
@@ -1979,6 +1996,7 @@ int ph_engine_load_dnn3_multi(void* h, const char* algo, int prec, const char* b
     if (!e || !blob || !algo) return -1;
     VersionLock::Write w(e->version);                  // no request in flight holds the model this replaces
     pg_model* m = nullptr;
+    if (prec < 0) prec = e->PrecisionOf(algo, e->default_dnn_precision);
     const int rc = pg_model_load(e->ctx, PG_MODEL_DNN3_MULTI, (pg_prec)prec, blob, len, &m);
     if (rc != PG_OK) { g_ph_err = pg_last_error(); return rc; }
     auto it = e->named_models.find(algo);
@@ -1993,6 +2011,7 @@ int ph_engine_load_dnn3_named(void* h, const char* key, int prec, const char* bl
     if (!e || !blob || !key) return -1;
     VersionLock::Write w(e->version);
     pg_model* m = nullptr;
+    if (prec < 0) prec = e->PrecisionOf(std::string(key).substr(0, std::string(key).find('/')), e->default_dnn_precision);
     const int rc = pg_model_load(e->ctx, PG_MODEL_DNN3, (pg_prec)prec, blob, len, &m);
     if (rc != PG_OK) { g_ph_err = pg_last_error(); return rc; }
     auto it = e->named_models.find(key);
@@ -2008,6 +2027,7 @@ int ph_engine_load_fm2t(void* h, int prec, const char* blob, size_t len) {
     VersionLock::Write w(e->version);
     e->DropCoalescers();                               // they hold the old model
     if (e->fm2t) { pg_model_destroy(e->ctx, e->fm2t); e->fm2t = nullptr; }
+    if (prec < 0) prec = e->default_fm2t_precision;
     const int rc = pg_model_load(e->ctx, PG_MODEL_FM_TWOTOWER, (pg_prec)prec, blob, len, &e->fm2t);
     if (rc != PG_OK) g_ph_err = pg_last_error();
     else if (len >= 16) {

@@ -405,6 +405,13 @@ public:
     pg_table* table = nullptr;
     pg_model* model = nullptr;
     std::map<std::string, pg_model*> named_models;      // multi-output rank algorithms: "<algo>/<output>" → DNN3 model
+    // pairec_gpu.Algorithms[].Precision ("f32" | "bf16" | "bf16x3", default bf16): what a loader passing prec < 0 gets
+    std::map<std::string, int> algo_precision;
+    int default_dnn_precision = PG_PREC_BF16, default_fm2t_precision = PG_PREC_BF16;
+    int PrecisionOf(const std::string& algo, int fallback) const {
+        auto it = algo_precision.find(algo);
+        return it == algo_precision.end() ? fallback : it->second;
+    }
     pg_features* feats = nullptr;                       // item "context features" as device columns (EasyRec request flavour)
     std::map<std::string, std::vector<int32_t>> user_fields;   // uid → dictionary-encoded user categorical features
     pg_model* fm2t = nullptr;                           // FM + two-tower model: rank algorithm "fm2t", and the vector model of the online recall

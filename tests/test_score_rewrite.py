@@ -118,6 +118,10 @@ def test_mirror_rank_service_applies_score_rewrite(H):
     expr_src = "${gpu_dnn}*(1+${boost})^0.1"
     cfg["RankConf"]["home_feed"]["RankScore"] = expr_src
     cfg["RankConf"]["home_feed"]["ScoreRewrite"] = REWRITES
+    cfg["UserDefineConfs"]["pairec_gpu"]["Algorithms"][1]["Precision"] = "bf16x3"
+    bad = copy.deepcopy(cfg)
+    bad["UserDefineConfs"]["pairec_gpu"]["Algorithms"][1]["Precision"] = "fp8"
+    assert not H.ph_engine_create(json.dumps(bad).encode()) and b"Precision" in H.ph_last_error()
     parsed = json.loads(H.ph_parse_recconf(json.dumps(cfg).encode()))
     assert parsed["rank_home_feed"]["score_rewrite"] == REWRITES
     h = H.ph_engine_create(json.dumps(cfg).encode())
@@ -129,7 +133,8 @@ def test_mirror_rank_service_applies_score_rewrite(H):
     vec = " ".join("%d:%s" % (i + 1, repr(float(v))) for i, v in enumerate(user))
     H.ph_set_user_vector(h, b"u1", vec.encode())
     blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
-    assert H.ph_engine_load_dnn3(h, pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+    # (prec -1: the algorithm's configured "Precision" — here bf16x3, whose scores are the fp32 path's to ~1e-7)
+    assert H.ph_engine_load_dnn3(h, -1, blob, len(blob)) == 0, H.ph_last_error()
     out = json.loads(H.ph_recommend(h, b"u1", 50, b"home_feed"))
     rows, scores = o.recall_topk(tab, user[None], 300)
     items = [o.OracleItem("item_%d" % r, float(s), "gpu_vector_recall") for r, s in zip(rows[0], scores[0])]
@@ -142,7 +147,7 @@ def test_mirror_rank_service_applies_score_rewrite(H):
     for g in out["items"]:
         w_ = by_id[g["item_id"]]
         assert abs(g["score"] - w_.score) <= 1e-6
-        assert abs(g["algo_scores"]["gpu_dnn"] - w_.algo_scores["gpu_dnn"]) <= 2e-7       # the REWRITTEN score (x 0.5)
+        assert abs(g["algo_scores"]["gpu_dnn"] - w_.algo_scores["gpu_dnn"]) <= 1e-6       # the REWRITTEN score (x 0.5 + …)
         assert abs(g["algo_scores"]["boost"] - w_.algo_scores["boost"]) <= 1e-6
     assert all(a["score"] >= b["score"] for a, b in zip(out["items"], out["items"][1:]))
     H.ph_engine_destroy(h)
