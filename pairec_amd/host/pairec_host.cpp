@@ -337,6 +337,75 @@ std::vector<AlgoResponse> WidenF32(const float* scores, size_t n) {
     for (size_t i = 0; i < n; ++i) ret.emplace_back((double)scores[i]);
     return ret;
 }
+std::vector<AlgoResponse> TfResponse(const std::vector<std::pair<std::string, OutputArray>>& outputs) {
+    std::vector<AlgoResponse> ret;                          // tf_response.go:56-61: the first output only (`break`)
+    if (!outputs.empty())
+        for (float v : outputs[0].second.float_val) ret.emplace_back((double)v);
+    return ret;
+}
+std::vector<AlgoResponse> TfMutValResponse(const std::vector<std::pair<std::string, OutputArray>>& outputs) {
+    std::vector<AlgoResponse> ret;                          // tf_response.go:35-47
+    for (const auto& kv : outputs)
+        for (size_t i = 0; i < kv.second.float_val.size(); ++i) {
+            if (i >= ret.size()) { ret.emplace_back(); ret.back().multiValModule = true; }
+            ret[i].scoreArr[kv.first] = (double)kv.second.float_val[i];
+        }
+    return ret;
+}
+bool TorchrecMutValResponse(size_t n_items, const std::vector<std::pair<std::string, OutputArray>>& outputs,
+                            std::vector<AlgoResponse>* out, std::string* err) {
+    out->assign(n_items, AlgoResponse());                   // easyrec_response.go:474-491
+    for (auto& r : *out) r.multiValModule = true;
+    for (const auto& kv : outputs) {
+        if (kv.second.size() < n_items) {                   // (the reference indexes FloatVal[i] and panics)
+            if (err) *err = "output " + kv.first + " holds fewer values than items";
+            out->clear();
+            return false;
+        }
+        for (size_t i = 0; i < n_items; ++i) (*out)[i].scoreArr[kv.first] = kv.second.at(i);
+    }
+    return true;
+}
+bool TorchrecMutClassificationResponse(size_t n_items, const std::vector<std::pair<std::string, OutputArray>>& outputs,
+                                       std::vector<AlgoResponse>* out, std::string* err) {
+    out->assign(n_items, AlgoResponse());                   // easyrec_response.go:543-565
+    for (const auto& kv : outputs) {
+        const size_t dims = kv.second.shape.size();
+        if (dims != 1 && dims != 2) continue;               // other ranks leave the output out of the map
+        const size_t width = dims == 2 ? (size_t)kv.second.shape[1] : 1;
+        if (kv.second.float_val.size() < n_items * width) {
+            if (err) *err = "output " + kv.first + " holds fewer values than items";
+            out->clear();
+            return false;
+        }
+        for (size_t i = 0; i < n_items; ++i) {
+            std::vector<double>& dst = (*out)[i].mulClassifyArr[kv.first];
+            for (size_t c = 0; c < width; ++c) dst.push_back((double)kv.second.float_val[i * width + c]);
+        }
+    }
+    return true;
+}
+bool TorchrecEmbeddingItemsResponse(const std::vector<std::string>& item_ids, const OutputArray* scores,
+                                    std::vector<EmbeddingInfo>* out, std::string* err) {
+    out->clear();                                           // easyrec_response.go:707-731
+    for (size_t i = 0; i < item_ids.size(); ++i) {
+        EmbeddingInfo info;
+        info.ItemId = item_ids[i];
+        if (scores) {
+            if (i >= scores->size()) {
+                if (err) *err = "match_item_scores holds fewer values than item_ids";
+                out->clear();
+                return false;
+            }
+            info.Score = scores->at(i);
+        }
+        out->push_back(info);
+    }
+    return true;
+}
+double PssmartScore(double score, const std::string& lable, const std::string& label) {
+    return (lable == "0" || label == "0") ? 1 - score : score;       // pmml_response.go:24-31
+}
 }  // namespace decode
 }  // namespace algorithm
 
@@ -2196,6 +2265,50 @@ const char* ph_decode_response(const char* spec_json) {
         std::vector<std::vector<double>> o2;
         for (const auto& row : sp.at("tf_rows").arr) { o2.emplace_back(); for (const auto& x : row.arr) o2.back().push_back(x.num); }
         ret = algorithm::decode::TFServingResponse(o2);
+    } else if (fn == "tfResponseFunc" || fn == "tfMutValResponseFunc" || fn == "torchrecMutValResponseFunc" ||
+               fn == "torchrecMutValResponseFuncDebug" || fn == "torchrecMutClassificationResponseFunc" ||
+               fn == "torchrecMutClassificationResponseFuncDebug" || fn == "torchrecEmbeddingItemsResponseFunc") {
+        // "outputs_list": [{"name":…, "dtype": "float"|"double", "values": […], "shape": […]}] in the message's order
+        std::vector<std::pair<std::string, algorithm::decode::OutputArray>> outsl;
+        for (const auto& ov : sp.at("outputs_list").arr) {
+            algorithm::decode::OutputArray oa;
+            oa.is_double = ov.s("dtype") == "double";
+            for (const auto& x : ov.at("values").arr) { if (oa.is_double) oa.double_val.push_back(x.num); else oa.float_val.push_back((float)x.num); }
+            for (const auto& x : ov.at("shape").arr) oa.shape.push_back((long long)x.num);
+            outsl.emplace_back(ov.s("name"), std::move(oa));
+        }
+        bool ok = true;
+        if (fn == "tfResponseFunc") ret = algorithm::decode::TfResponse(outsl);
+        else if (fn == "tfMutValResponseFunc") ret = algorithm::decode::TfMutValResponse(outsl);
+        else if (fn.rfind("torchrecMutVal", 0) == 0) ok = algorithm::decode::TorchrecMutValResponse(ids.size(), outsl, &ret, &err);
+        else if (fn.rfind("torchrecMutClassification", 0) == 0) ok = algorithm::decode::TorchrecMutClassificationResponse(ids.size(), outsl, &ret, &err);
+        else {
+            const algorithm::decode::OutputArray* sc = nullptr;
+            for (const auto& kv : outsl) if (kv.first == "match_item_scores") sc = &kv.second;
+            std::vector<algorithm::EmbeddingInfo> items;
+            ok = algorithm::decode::TorchrecEmbeddingItemsResponse(ids, sc, &items, &err);
+            std::string o = "[";
+            for (size_t i = 0; ok && i < items.size(); ++i) {
+                if (i) o += ",";
+                o += "{\"item_id\":";
+                json::Escape(items[i].ItemId, &o);
+                char buf[64];
+                snprintf(buf, sizeof buf, ",\"score\":%.17g}", items[i].Score);
+                o += buf;
+            }
+            o += "]";
+            if (!ok) { g_ph_err = err; return nullptr; }
+            g_ph_out = o;
+            return g_ph_out.c_str();
+        }
+        if (!ok) { g_ph_err = err; return nullptr; }
+    } else if (fn == "easyrecResponseFuncDebug") {
+        ret = algorithm::decode::EasyrecResponse(ids, results);                    // (:237-268: the same scores + the debug strings)
+    } else if (fn == "easyrecMutValResponseFuncDebug") {
+        if (!algorithm::decode::EasyrecMutValResponse(ids, outs, results, &ret, &err)) { g_ph_err = err; return nullptr; }
+    } else if (fn == "pssmartResponseFunc") {
+        for (const auto& v : sp.at("predictions").arr)
+            ret.emplace_back(algorithm::decode::PssmartScore(v.d("score"), v.s("lable"), v.s("label")));
     } else if (fn == "widenF32") {
         std::vector<float> f;
         for (const auto& x : sp.at("float_val").arr) f.push_back((float)x.num);

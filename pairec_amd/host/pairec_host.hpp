@@ -205,6 +205,30 @@ double AlinkFMScore(double prediction_result, double prediction_score);
 std::vector<AlgoResponse> TFServingResponse(const std::vector<std::vector<double>>& outputs);
 // tfResponseFunc / torchrecMutValResponseFunc's float32 → float64 widening (eas/tf_response.go:55-59)
 std::vector<AlgoResponse> WidenF32(const float* scores, size_t n);
+// one model output tensor as the PAI-EAS protobufs carry it: float32 or float64 values, row-major, with its shape
+struct OutputArray {
+    bool is_double = false;
+    std::vector<float> float_val;
+    std::vector<double> double_val;
+    std::vector<long long> shape;
+    double at(size_t i) const { return is_double ? double_val[i] : (double)float_val[i]; }
+    size_t size() const { return is_double ? double_val.size() : float_val.size(); }
+};
+// tfResponseFunc (eas/tf_response.go:50-62): the FIRST output's float32 values, one score per item
+std::vector<AlgoResponse> TfResponse(const std::vector<std::pair<std::string, OutputArray>>& outputs);
+// tfMutValResponseFunc (eas/tf_response.go:29-48): item i's map {output name: FloatVal[i]} over every output
+std::vector<AlgoResponse> TfMutValResponse(const std::vector<std::pair<std::string, OutputArray>>& outputs);
+// torchrecMutValResponseFunc[Debug] (eas/easyrec_response.go:468-535): per item {output: FloatVal[i] | DoubleVal[i]}
+bool TorchrecMutValResponse(size_t n_items, const std::vector<std::pair<std::string, OutputArray>>& outputs,
+                            std::vector<AlgoResponse>* out, std::string* err);
+// torchrecMutClassificationResponseFunc[Debug] (:537-626): shape [N] → one value, [N, C] → C values per item (float32)
+bool TorchrecMutClassificationResponse(size_t n_items, const std::vector<std::pair<std::string, OutputArray>>& outputs,
+                                       std::vector<AlgoResponse>* out, std::string* err);
+// torchrecEmbeddingItemsResponseFunc (:700-734): item_ids[i] with match_item_scores[i] (float32 or float64)
+bool TorchrecEmbeddingItemsResponse(const std::vector<std::string>& item_ids, const OutputArray* match_item_scores,
+                                    std::vector<EmbeddingInfo>* out, std::string* err);
+// pssmartResponse.GetScore (eas/pmml_response.go:10-32): label "0" (either spelling of the key) → 1 - score
+double PssmartScore(double score, const std::string& lable, const std::string& label);
 }  // namespace decode
 struct AlgoData {
     enum Kind { kVector, kRank, kEmbedding } kind = kVector;

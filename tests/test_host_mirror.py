@@ -220,6 +220,38 @@ def test_response_decoders_reference_fixtures(H):
     assert [x["score"] for x in r] == [0.1, 0.2, 0.3]
     r = dec({"func": "widenF32", "float_val": [0.8612537, 1e-7]})
     assert [x["score"] for x in r] == o.widen_f32(np.array([0.8612537, 1e-7], dtype=np.float32)).tolist()
+    # round 5: the tf / torchrec / pssmart families (algorithm/eas/client.go:60-108 names them; the decoders' arithmetic is
+    # float32 → float64 widening plus indexing).  outputs_list keeps the message's order: tfResponseFunc reads the FIRST output.
+    fv = [0.8612537, 0.25, 1e-7]
+    wide = o.widen_f32(np.array(fv, dtype=np.float32)).tolist()
+    outs = [{"name": "probs_ctr", "dtype": "float", "values": fv, "shape": [3]},
+            {"name": "probs_cvr", "dtype": "double", "values": [0.5, 0.125, 0.75], "shape": [3]}]
+    r = dec({"func": "tfResponseFunc", "outputs_list": outs})                              # eas/tf_response.go:50-62
+    assert [x["score"] for x in r] == wide and not any(x["module_type"] for x in r)
+    r = dec({"func": "tfMutValResponseFunc", "outputs_list": [outs[0], {"name": "y", "dtype": "float", "values": [0.5, 0.5, 0.5], "shape": [3]}]})
+    assert all(x["module_type"] for x in r) and [x["score_map"]["probs_ctr"] for x in r] == wide and r[2]["score_map"]["y"] == 0.5
+    for fn in ("torchrecMutValResponseFunc", "torchrecMutValResponseFuncDebug"):            # eas/easyrec_response.go:468-535
+        r = dec({"func": fn, "item_ids": ["a", "b", "c"], "outputs_list": outs})
+        assert [x["score_map"]["probs_ctr"] for x in r] == wide                             # DT_FLOAT widened
+        assert [x["score_map"]["probs_cvr"] for x in r] == [0.5, 0.125, 0.75] and all(x["module_type"] for x in r)   # DT_DOUBLE as is
+    assert dec({"func": "torchrecMutValResponseFunc", "item_ids": ["a", "b", "c", "d"], "outputs_list": outs}) is None
+    cls = [{"name": "p1", "dtype": "float", "values": [0.7, 0.3], "shape": [2]},
+           {"name": "p6", "dtype": "float", "values": [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.11, 0.22, 0.33, 0.44, 0.55, 0.66], "shape": [2, 6]}]
+    for fn in ("torchrecMutClassificationResponseFunc", "torchrecMutClassificationResponseFuncDebug"):     # :537-626
+        r = dec({"func": fn, "item_ids": ["item_1", "item_2"], "outputs_list": cls})
+        assert r[1]["classify"]["p1"] == [f32(0.3)] and r[1]["classify"]["p6"] == [f32(v) for v in (0.11, 0.22, 0.33, 0.44, 0.55, 0.66)]
+        assert not r[0]["module_type"]
+    r = dec({"func": "torchrecEmbeddingItemsResponseFunc", "item_ids": ["i9", "i3"],                     # :700-734
+             "outputs_list": [{"name": "match_item_scores", "dtype": "float", "values": [0.8612537, 0.25], "shape": [1, 2]}]})
+    assert r == [{"item_id": "i9", "score": wide[0]}, {"item_id": "i3", "score": 0.25}]
+    r = dec({"func": "easyrecResponseFuncDebug", "item_ids": ["a", "missing"], "results": {"a": [0.25]}})
+    assert [x["score"] for x in r] == [0.25, 0.0]
+    r = dec({"func": "easyrecMutValResponseFuncDebug", "item_ids": ["a"], "outputs": ["x", "y"], "results": {"a": [0.5, 0.25]}})
+    assert r[0]["score_map"] == {"x": 0.5, "y": 0.25}
+    r = dec({"func": "pssmartResponseFunc", "predictions": [{"score": 0.8, "lable": "0"}, {"score": 0.8, "label": "0"},   # pmml_response.go:10-32
+                                                            {"score": 0.8, "lable": "1", "label": "1"}, {"score": 0.8}]})
+    assert [x["score"] for x in r] == [1 - 0.8, 1 - 0.8, 0.8, 0.8]
+    assert dec({"func": "lincubResponseFunc"}) is None and b"unknown decoder" in H.ph_last_error()
 
 
 @pytest.mark.gpu
