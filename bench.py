@@ -1502,16 +1502,20 @@ def main():
     # the exchanges of the sharded step: RCCL on device tensors; host-staged gloo when the ranks share cuda:0 (dev mode)
     coll = HostStagedCollectives(dist, torch) if share_gpu else dist
     preflight = None
+    group_ok = True
     if world > 1 and not args.no_preflight:
         # the first thing N > 1 ranks do: prove the sharded step on this wire against the oracle (and pg_group_* over the
         # same devices), on every rank; a failure stops the run before a number exists
         preflight, pf_ok = preflight_ranks(pa, o, torch, dist, coll, rank, world, local_rank, share_gpu)
+        # pg_group_* over the same devices (rank 0; the others wait).  The modes of THIS process — replica, shard — do not go
+        # through pg_group: a failure there is reported, costs the line its `group` sub-object, and does not stop the run
+        # (it is fatal in --mode group / router, whose data path it is).
         flag = torch.zeros(1, dtype=torch.int32, device="cpu" if share_gpu else torch.device("cuda", local_rank))
         if pf_ok and rank == 0:
             preflight["group"] = preflight_group(pa, o, [0] * world if share_gpu else list(range(world)))
             flag += 0 if preflight["group"]["ok"] else 1
         dist.all_reduce(flag)
-        pf_ok = pf_ok and int(flag.item()) == 0
+        group_ok = pf_ok and int(flag.item()) == 0
         preflight["ok"] = pf_ok
         if not pf_ok:
             if rank == 0:
@@ -1796,7 +1800,7 @@ def main():
         except Exception as ex_:                                # noqa: BLE001
             out["shard"] = {"ok": False, "error": "%s: %s" % (type(ex_).__name__, ex_)}
         dist.barrier()
-        if rank == 0:
+        if rank == 0 and (preflight is None or group_ok):
             try:
                 out["group"] = group_sub_leg(pa, o, [0] * world if share_gpu else list(range(world)), args, R, K, prec, blob5)
             except Exception as ex_:                            # noqa: BLE001
