@@ -10,7 +10,8 @@ ctx = pa.Context(0)
 R, K, vocab, n_cat = 256, 5000, 1_000_000, 20_000_000
 n = R * K
 fw = o.Fm2tWeights(vocab=vocab)
-m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, pa.PREC_BF16, pa.pack_fm2t(fw))
+PREC = {"bf16": pa.PREC_BF16, "bf16x3": pa.PREC_BF16X3, "f32": pa.PREC_F32}[os.environ.get("CFG4_PREC", "bf16")]
+m = pa.RankModel(ctx, pa.MODEL_FM_TWOTOWER, PREC, pa.pack_fm2t(fw))
 rng = np.random.default_rng(5)
 users = o.synth_rows(o.SEED_QUERY, 0, R, 128)
 ufids = rng.integers(0, vocab, (R, 8)).astype(np.int32)
