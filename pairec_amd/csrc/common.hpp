@@ -73,6 +73,7 @@ struct Knobs {
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
     uint32_t rank_sort_max = 8;    // PG_RANK_SORT_MAX: up to this many lists per call are sorted by counting ranks (0 = never)
     bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
+    bool rank_t3 = false;          // PG_RANK_T3: the benchmark's bf16 DNN3 on the three-waves-per-SIMD kernel (rank_t3.hip) instead of rank_ws.hip (A/B)
     bool fm2t_irs = false;         // PG_FM2T_IRS: cfg 4's item-record rank on the producer / consumer kernel (rank_ir.hip) instead of rank_is.hip (A/B)
     bool no_predict = false;       // PG_NO_PREDICT: never replace the pilot sample by the learned threshold model
     double predict_sigmas = 4.5;   // PG_PREDICT_SIGMAS: margin of the predicted threshold, in standard deviations of the observed quantile
