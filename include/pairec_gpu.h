@@ -254,6 +254,16 @@ int pg_expr_eval_dev(pg_ctx* ctx, const pg_expr* e, const double* d_vars, uint32
  * tfserving/response.go:51-64; recall: vector_recall.go:98). */
 int pg_widen_f32_dev(pg_ctx* ctx, const float* d_in, uint32_t n, double* d_out);
 
+/* The fusion step of RankService.Rank (service/rank/rank_service.go:339-363) alone, for a host that runs the stages itself
+ * (pairec_amd/dist.py's sharded step between its collectives): n items, n_planes model-score planes d_rank[p * rank_stride + i]
+ * (float32, widened as the decoders do) named plane_names[p] ("<algo>" or "<algo>_<output>"), d_recall[i] = Item.Score
+ * ("current_score").  RankConfig.ScoreRewrite attached to `rank_score` (pg_expr_set_score_rewrites) is evaluated first, from
+ * the un-rewritten planes (rank_service.go:343-353).  d_fused[i] = the RankScore, f64.  A division by zero anywhere is
+ * PG_ERR_ARITH (the call synchronises to learn it); a variable that names neither a plane, a rewrite source nor
+ * current_score PG_ERR_INVALID. */
+int pg_fuse_scores_dev(pg_ctx* ctx, const pg_expr* rank_score, const char* const* plane_names, uint32_t n_planes,
+                       const float* d_rank, size_t rank_stride, const float* d_recall, uint32_t n, double* d_fused);
+
 /* ---- sort -----------------------------------------------------------------------------------
  * Replaces ItemRankScoreSort (descending, sort/item_rank_score.go:26-32) and ItemScoreSort
  * (ascending, sort/item_score.go:36-41): out_order[i] = index of the i-th item.  Segmented:

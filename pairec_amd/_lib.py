@@ -20,7 +20,7 @@ EXPORTS = [
     "pg_table_fill_synthetic", "pg_table_upload", "pg_table_download", "pg_table_swap",
     "pg_table_info", "pg_table_gather", "pg_recall_topk", "pg_recall_topk_dev", "pg_recall_topk_l2", "pg_recall_topk_l2_dev", "pg_recall_topk_where", "pg_table_view_create",
     "pg_topk_merge_dev", "pg_model_load", "pg_model_destroy", "pg_model_num_outputs", "pg_rank_dnn3", "pg_rank_dnn3_dev",
-    "pg_rank_fm2t", "pg_rank_fm2t_dev", "pg_expr_compile", "pg_expr_free", "pg_expr_num_vars", "pg_expr_set_score_rewrites", "pg_expr_compile_typed", "pg_expr_is_antlr",
+    "pg_rank_fm2t", "pg_rank_fm2t_dev", "pg_expr_compile", "pg_expr_free", "pg_expr_num_vars", "pg_expr_set_score_rewrites", "pg_expr_compile_typed", "pg_expr_is_antlr", "pg_fuse_scores_dev",
     "pg_expr_var_name", "pg_expr_eval", "pg_expr_eval_dev", "pg_sort_scores", "pg_sort_scores_dev",
     "pg_dpp", "pg_stats", "pg_last_scan_kernel_ms", "pg_rows_to_local_dev", "pg_widen_f32_dev",
     "pg_hbm_read_probe", "pg_table_screen_info", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
@@ -140,6 +140,7 @@ def load():
         "pg_expr_set_score_rewrites": [vp, u32, vp, vp],
         "pg_expr_compile_typed": [C.c_char_p, C.c_char_p, P(vp)],
         "pg_expr_is_antlr": [vp],
+        "pg_fuse_scores_dev": [vp, vp, vp, u32, vp, sz, vp, u32, vp],
         "pg_expr_eval": [vp, vp, vp, u32, vp],
         "pg_expr_eval_dev": [vp, vp, vp, u32, vp],
         "pg_sort_scores": [vp, vp, vp, u32, i32, vp],

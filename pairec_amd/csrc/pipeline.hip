@@ -158,6 +158,42 @@ int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostScratch* 
     return PG_OK;
 }
 
+// The fusion itself: ScoreRewrite sources first, then RankScore, over n items whose planes lie rank_stride apart; d_vars holds
+// (widest expression's variables + number of rewrites) x n doubles; d_err kMaxQueries flags (one per items_per_flag items)
+int fuse_scores_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const int* var_src, int nv, const float* d_recall, const float* d_rank,
+                               size_t rank_stride, uint32_t n, uint32_t items_per_flag, double* d_vars, uint32_t* d_err, double* d_fused) {
+    hipStream_t st = ctx->stream;
+    int rc;
+    VarSrc vs;
+    // RankConfig.ScoreRewrite (rank_service.go:343-353): every source's expression over the scores as the algorithms left
+    // them, all of them before any is written back; results stay f64 (AddAlgoScores) behind the variables
+    const int n_rw = expr_num_rewrites(e);
+    int wide = std::max(nv, 1);
+    for (int r = 0; r < n_rw; ++r) wide = std::max(wide, expr_rewrite_num_vars(e, r));
+    double* const d_rw = d_vars + (size_t)wide * n;
+    const uint32_t bind_grid = (std::max(n, (uint32_t)kMaxQueries) + 255) / 256;
+    bool zeroed = false;
+    for (int r = 0, at = nv; r < n_rw; ++r) {
+        const int nvr = expr_rewrite_num_vars(e, r);
+        for (int i = 0; i < 32; ++i) vs.src[i] = i < nvr ? (int8_t)var_src[at + i] : (int8_t)-1;
+        at += nvr;
+        if (nvr > 0 || !zeroed) {
+            bind_vars_kernel<<<bind_grid, 256, 0, st>>>(d_recall, d_rank, rank_stride, n, (uint32_t)nvr, vs, d_vars, d_err, nullptr, zeroed ? 0 : 1);
+            PG_HIP(hipGetLastError());
+            zeroed = true;
+        }
+        if ((rc = expr_rewrite_eval_enqueue_locked(ctx, e, r, d_vars, n, d_rw + (size_t)r * n, d_err, items_per_flag))) return rc;
+    }
+    for (int i = 0; i < 32; ++i) vs.src[i] = i < nv ? (int8_t)var_src[i] : (int8_t)-1;
+    if (nv > 0) {
+        bind_vars_kernel<<<bind_grid, 256, 0, st>>>(d_recall, d_rank, rank_stride, n, (uint32_t)nv, vs, d_vars, d_err, d_rw, zeroed ? 0 : 1);
+        PG_HIP(hipGetLastError());
+    } else if (!zeroed) {
+        PG_HIP(hipMemsetAsync(d_err, 0, (size_t)kMaxQueries * 4, st));
+    }
+    return expr_eval_enqueue_locked(ctx, e, d_vars, n, d_fused, d_err, items_per_flag);
+}
+
 // RankScore fusion over the algorithms' score planes + ItemRankScore sort for requests [q0, q0 + nq) of the call
 // (rank_service.go:339-363, sort/item_rank_score.go:26-32); ps.d_off must hold the uniform offsets
 int post_fuse_sort_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps) {
@@ -165,36 +201,9 @@ int post_fuse_sort_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint
     const size_t o = (size_t)q0 * c.k;
     hipStream_t st = ctx->stream;
     int rc;
-    VarSrc vs;
-    // RankConfig.ScoreRewrite (rank_service.go:343-353): every source's expression over the scores as the algorithms left
-    // them, all of them before any is written back; results stay f64 (AddAlgoScores) behind the variables
-    const int n_rw = expr_num_rewrites(c.e);
-    int wide = std::max(c.nv, 1);
-    for (int r = 0; r < n_rw; ++r) wide = std::max(wide, expr_rewrite_num_vars(c.e, r));
-    double* const d_rw = ps.d_vars + (size_t)wide * n;
-    const uint32_t bind_grid = (std::max(n, (uint32_t)kMaxQueries) + 255) / 256;
-    bool zeroed = false;
-    for (int r = 0, at = c.nv; r < n_rw; ++r) {
-        const int nvr = expr_rewrite_num_vars(c.e, r);
-        for (int i = 0; i < 32; ++i) vs.src[i] = i < nvr ? (int8_t)c.var_src[at + i] : (int8_t)-1;
-        at += nvr;
-        if (nvr > 0 || !zeroed) {
-            bind_vars_kernel<<<bind_grid, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n, (uint32_t)nvr, vs, ps.d_vars, ps.d_err,
-                                                        nullptr, zeroed ? 0 : 1);
-            PG_HIP(hipGetLastError());
-            zeroed = true;
-        }
-        if ((rc = expr_rewrite_eval_enqueue_locked(ctx, c.e, r, ps.d_vars, n, d_rw + (size_t)r * n, ps.d_err, c.k))) return rc;
-    }
-    for (int i = 0; i < 32; ++i) vs.src[i] = i < c.nv ? (int8_t)c.var_src[i] : (int8_t)-1;
-    if (c.nv > 0) {
-        bind_vars_kernel<<<bind_grid, 256, 0, st>>>(c.d_recall + o, c.d_rank + o, c.rank_stride, n, (uint32_t)c.nv, vs, ps.d_vars, ps.d_err,
-                                                    d_rw, zeroed ? 0 : 1);
-        PG_HIP(hipGetLastError());
-    } else if (!zeroed) {
-        PG_HIP(hipMemsetAsync(ps.d_err, 0, (size_t)kMaxQueries * 4, st));
-    }
-    if ((rc = expr_eval_enqueue_locked(ctx, c.e, ps.d_vars, n, c.d_fused + o, ps.d_err, c.k))) return rc;
+    if ((rc = fuse_scores_enqueue_locked(ctx, c.e, c.var_src, c.nv, c.d_recall + o, c.d_rank + o, c.rank_stride, n, c.k, ps.d_vars, ps.d_err,
+                                         c.d_fused + o)))
+        return rc;
     if (c.pads) {
         mask_pads_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.d_rows + o, n, c.d_rank + o, c.rank_stride, c.planes(), c.d_fused + o);
         PG_HIP(hipGetLastError());
@@ -399,6 +408,34 @@ int pg_recommend_end(pg_ctx* ctx, pg_ticket* tk, double* scan_ms) {
     pg::pipe_run_release(ctx, tk->run);
     delete tk;
     return rc;
+}
+
+int pg_fuse_scores_dev(pg_ctx* ctx, const pg_expr* e, const char* const* plane_names, uint32_t n_planes, const float* d_rank,
+                       size_t rank_stride, const float* d_recall, uint32_t n, double* d_fused) {
+    PG_REQUIRE(ctx && e && (n_planes == 0 || (plane_names && d_rank)) && d_recall && d_fused, "pg_fuse_scores_dev: NULL argument");
+    PG_REQUIRE(n_planes <= (uint32_t)pg::kMaxPlanes, "pg_fuse_scores_dev: %u planes (at most %d)", n_planes, pg::kMaxPlanes);
+    if (n == 0) return PG_OK;
+    std::vector<int> var_src;
+    int rc;
+    if ((rc = pg::recommend_bind_vars(e, plane_names, (int)n_planes, &var_src, "pg_fuse_scores_dev"))) return rc;
+    const int nv = pg_expr_num_vars(e), n_rw = pg::expr_num_rewrites(e);
+    int wide = std::max(nv, 1);
+    for (int r = 0; r < n_rw; ++r) wide = std::max(wide, pg::expr_rewrite_num_vars(e, r));
+    std::lock_guard<std::mutex> g(ctx->mu);
+    void* buf;
+    const size_t b_vars = (((size_t)(wide + n_rw) * n * 8) + 255) & ~(size_t)255;
+    if ((rc = pg::scratch_reserve(ctx, 15, b_vars + (size_t)pg::kMaxQueries * 4, &buf))) return rc;
+    double* const d_vars = (double*)buf;
+    uint32_t* const d_err = (uint32_t*)((char*)buf + b_vars);
+    if ((rc = pg::fuse_scores_enqueue_locked(ctx, e, var_src.data(), nv, d_recall, d_rank, rank_stride, n, 0u, d_vars, d_err, d_fused))) return rc;
+    // (items_per_flag = 0: one flag for the call; read through the context's pinned status words)
+    PG_HIP(hipMemcpyAsync(ctx->h_status + 321, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_status[321] != 0) {
+        pg::set_expr_arith_error(e);
+        return PG_ERR_ARITH;
+    }
+    return PG_OK;
 }
 
 int pg_recommend_end_timed(pg_ctx* ctx, pg_ticket* tk, uint32_t timeout_us, double* scan_ms) {

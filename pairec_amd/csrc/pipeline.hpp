@@ -102,6 +102,8 @@ struct PostScratch {
 };
 int post_scratch(pg_ctx* ctx, const RecommendCall& c, uint32_t nq, PostScratch* ps);
 int post_fuse_sort_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps);
+int fuse_scores_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const int* var_src, int nv, const float* d_recall, const float* d_rank,
+                               size_t rank_stride, uint32_t n, uint32_t items_per_flag, double* d_vars, uint32_t* d_err, double* d_fused);
 int rerank_select_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps);
 int rerank_run_locked(pg_ctx* ctx, const RecommendCall& c, uint32_t q0, uint32_t nq, const PostScratch& ps);
 

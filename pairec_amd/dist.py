@@ -198,7 +198,8 @@ class GpuShardEngine:
         self.order = torch.empty(n, dtype=i32, device=dev)
         self.seg = torch.arange(0, n + 1, k_max, dtype=i32, device=dev)
         self.c_rows = self.c_rel = self.c_emb = self.picks = self.pick_cnt = None
-        assert expr.var_names == ["gpu_dnn", "current_score"]       # column order of the vars slab below
+        # (the fusion is pg_fuse_scores_dev: the RankScore's variables bind to the plane "gpu_dnn" and current_score, and a
+        #  RankConfig.ScoreRewrite attached to the expression is evaluated in front of it, as in every other pipeline)
         torch.cuda.synchronize(dev)                                 # (arange above ran on torch's default stream)
 
     def _check(self, rc):
@@ -242,12 +243,10 @@ class GpuShardEngine:
     def fuse_sort(self, rank_scores, recall_scores, nq, k):
         n = nq * k
         L, h = self.ctx.L, self.ctx.h
-        v = self.vars[:, :n] if n == self.vars.shape[1] else self.torch.empty((2, n), dtype=self.torch.float64,
-                                                                            device=self.dev)
-        self._check(L.pg_widen_f32_dev(h, rank_scores.contiguous().data_ptr(), n, v[0].data_ptr()))
-        self._check(L.pg_widen_f32_dev(h, recall_scores.contiguous().data_ptr(), n, v[1].data_ptr()))
         fused, order = self.fused[:n], self.order[:n]
-        self._check(L.pg_expr_eval_dev(h, self.expr.h, v.data_ptr(), n, fused.data_ptr()))
+        names = (C.c_char_p * 1)(b"gpu_dnn")
+        self._check(L.pg_fuse_scores_dev(h, self.expr.h, names, 1, rank_scores.contiguous().data_ptr(), n,
+                                         recall_scores.contiguous().data_ptr(), n, fused.data_ptr()))
         seg = self.seg[:nq + 1] if k == self.k_max else \
             self.torch.arange(0, n + 1, k, dtype=self.torch.int32, device=self.dev)
         self._check(L.pg_sort_scores_dev(h, fused.data_ptr(), seg.data_ptr(), nq, n, k, 1, order.data_ptr()))

@@ -81,6 +81,23 @@ def test_device_fusion_with_two_rewrites_matches_the_oracle(ctx):
     assert ei.value.code == -5
     ex2.free()
 
+    # pg_fuse_scores_dev: the fusion alone (what pairec_amd/dist.py calls between its collectives), same answers
+    import ctypes as C
+    n_it = int(rnk[0].size)
+    d_rank, d_rec, d_out = ctx.to_device(rnk[0]), ctx.to_device(rec[0]), ctx.malloc(n_it * 8)
+    names = (C.c_char_p * 1)(b"gpu_dnn")
+    pa._lib.check(ctx.L.pg_fuse_scores_dev(ctx.h, ex.h, names, 1, d_rank, n_it, d_rec, n_it, d_out))
+    alone = np.zeros(n_it, np.float64)
+    ctx.d2h(alone, d_out)
+    assert np.array_equal(alone.view(np.uint64), fus[0].view(np.uint64))
+    ex2 = pa.Expr("1/(${gpu_dnn}-${gpu_dnn})")
+    with pytest.raises(pa._lib.PgError) as ei:
+        pa._lib.check(ctx.L.pg_fuse_scores_dev(ctx.h, ex2.h, names, 1, d_rank, n_it, d_rec, n_it, d_out))
+    assert ei.value.code == -5
+    ex2.free()
+    for p_ in (d_rank, d_rec, d_out):
+        ctx.free(p_)
+
     # the scene coalescer: two algorithms, a rewrite over both feeding RankScore; single-request calls
     w2 = o.Dnn3Weights(h1=256, h2=128, seed=o.SEED_WEIGHTS ^ 0x51)
     m2 = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w2.w1, w2.b1, w2.w2, w2.b2, w2.w3, w2.b3, 128))
