@@ -6,7 +6,7 @@ S=${1:-60}
 SEED=${2:-1}
 cd "$(dirname "$0")/.."
 rc=0
-for s in soak_adversarial soak_where soak_pipeline_adversarial soak_group soak_scene soak_coalescer soak_records soak_l2 soak_rank soak_fm2t soak_rerank soak_expr; do
+for s in soak_adversarial soak_where soak_pipeline_adversarial soak_group soak_scene soak_coalescer soak_records soak_l2 soak_rank soak_fm2t soak_rerank soak_expr soak_antlr_rewrite; do
   echo "== $s ($S s)"
   timeout $((S * 4 + 300)) python3 scripts/$s.py "$S" "$SEED" 2>&1 | grep -a "MISMATCH\|FAILED\|^soak\|^rounds\|fault\|Traceback" | tail -4 || true
   [ "${PIPESTATUS[0]}" = "0" ] || rc=1
