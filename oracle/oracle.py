@@ -955,7 +955,9 @@ def recall_cache_string(items: List[OracleItem], recall_name: str) -> str:
 
 
 def go_fmt_float(x: float) -> str:
-    """fmt %v for float64 = strconv 'g' with shortest repr, exponent for exp < -4 || exp >= 21."""
+    """fmt %v for float64 = strconv 'g', precision -1: the shortest digits that round-trip, in exponent form for
+    exp < -4 || exp >= 6 (strconv/ftoa.go, case 'g': "if precision was the shortest possible, use precision 6 for this decision" —
+    the familiar `map[id:1.2345678e+07]` of a JSON number printed with %v; 21 is encoding/json's threshold, not fmt's)."""
     if x != x:
         return "NaN"
     if math.isinf(x):
@@ -982,7 +984,7 @@ def go_fmt_float(x: float) -> str:
         dexp = exp + (len(ip) - 1)
     digits = digits.rstrip("0") or "0"
     sign = "-" if x < 0 else ""
-    if dexp < -4 or dexp >= 21:
+    if dexp < -4 or dexp >= 6:
         mant = digits[0] + ("." + digits[1:] if len(digits) > 1 else "")
         return "%s%se%s%02d" % (sign, mant, "+" if dexp >= 0 else "-", abs(dexp))
     if dexp >= 0:

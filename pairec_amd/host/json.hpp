@@ -16,6 +16,7 @@ struct Value {
     bool b = false;
     double num = 0.0;
     bool is_int = false;
+    bool is_u64 = false;           // an integer that is a Go uint64 (utils "hash"): `i` holds its bit pattern
     long long i = 0;
     std::string str;
     std::vector<Value> arr;

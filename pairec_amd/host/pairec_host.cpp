@@ -86,7 +86,7 @@ std::string GoFmtFloat(double x) {
         if (m[i] >= '0' && m[i] <= '9') digits.push_back(m[i]);
     while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
     const std::string sign = x < 0 ? "-" : "";
-    if (dexp < -4 || dexp >= 21) {
+    if (dexp < -4 || dexp >= 6) {               // strconv 'g', shortest: the %e form from exponent 6 on
         std::string out = sign + digits.substr(0, 1);
         if (digits.size() > 1) out += "." + digits.substr(1);
         char e[16];
@@ -168,6 +168,28 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         out->RankConf[kv.first] = c;
     }
     for (const auto& kv : root.at("SortNames").obj) out->SortNames[kv.first] = str_list(kv.second);
+    auto parse_scene_features = [&](const json::Value& scenes, std::map<std::string, SceneFeatureConfig>* dst) {
+        for (const auto& sc : scenes.obj) {                        // recconf.go:52-53,169-176,256-265
+            SceneFeatureConfig sf;
+            sf.AsynLoadFeature = sc.second.at("AsynLoadFeature").type == json::Value::Bool && sc.second.at("AsynLoadFeature").b;
+            for (const auto& lc : sc.second.at("FeatureLoadConfs").arr) {
+                FeatureLoadConfig l;
+                l.DaoAdapterType = lc.at("FeatureDaoConf").s("AdapterType");
+                for (const auto& f : lc.at("Features").arr) {
+                    FeatureConfig c;
+                    c.FeatureType = f.s("FeatureType"); c.FeatureName = f.s("FeatureName"); c.FeatureSource = f.s("FeatureSource");
+                    c.FeatureValue = f.s("FeatureValue"); c.FeatureStore = f.s("FeatureStore"); c.Normalizer = f.s("Normalizer");
+                    c.Expression = f.s("Expression");
+                    c.RemoveFeatureSource = f.at("RemoveFeatureSource").type == json::Value::Bool && f.at("RemoveFeatureSource").b;
+                    l.Features.push_back(std::move(c));
+                }
+                sf.FeatureLoadConfs.push_back(std::move(l));
+            }
+            (*dst)[sc.first] = std::move(sf);
+        }
+    };
+    parse_scene_features(root.at("FeatureConfs"), &out->FeatureConfs);
+    parse_scene_features(root.at("UserFeatureConfs"), &out->UserFeatureConfs);
     for (const auto& sc : root.at("SceneConfs").obj)
         for (const auto& cat : sc.second.obj)
             out->SceneRecallNames[sc.first][cat.first] = str_list(cat.second.at("RecallNames"));
@@ -1732,6 +1754,26 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
                 pg_expr_free(probe);
             }
         }
+    // FeatureService.LoadFeatureConf (feature_service.go:33-58) / UserFeatureService: one Feature per FeatureLoadConfig.  An unknown
+    // FeatureType is the reference's panic (op.go:32); an expression normalizer outside the stated subset stops the load, named.
+    {
+        auto build = [&](const std::map<std::string, recconf::SceneFeatureConfig>& src, const char* key,
+                         std::map<std::string, std::vector<std::shared_ptr<feature::Feature>>>* dst) {
+            for (const auto& sc : src)
+                for (const auto& lc : sc.second.FeatureLoadConfs) {
+                    auto f = std::make_shared<feature::Feature>();
+                    std::string ferr;
+                    if (!f->LoadWithConfig(lc.Features, &ferr)) {
+                        if (err) *err = std::string(key) + "[" + sc.first + "]: " + ferr;
+                        return false;
+                    }
+                    (*dst)[sc.first].push_back(std::move(f));
+                }
+            return true;
+        };
+        if (!build(e->config.FeatureConfs, "FeatureConfs", &e->sceneFeatures)) return nullptr;
+        if (!build(e->config.UserFeatureConfs, "UserFeatureConfs", &e->sceneUserFeatures)) return nullptr;
+    }
     for (const auto& sc : e->config.SortConfs) {
         // RegisterSortWithConfig (sort/sort.go:162-200): DPPSort / SSDSort open their Hologres datasource first
         // (NewDPPSort, dpp_sort.go:60-64; NewSSDSort, ssd_sort.go:52-56) and panic without it; an unknown SortType
@@ -1872,6 +1914,16 @@ bool Engine::Recommend(const std::string& uid, int size, const std::string& scen
     // separate argument for them): "item_id" is what I2IVectorRecall reads with context.GetParameter
     for (const auto& kv : experiment_params.at("_param").obj) ctx.Param[kv.first] = kv.second;
     ctx.ExperimentParamsJson = experiment_params;
+    // the request's user features ("features" of POST /api/recommend → User.Properties, web/recommend_controller.go) ride under
+    // "_user_features"; UserFeatureService.LoadUserFeatures (user_recommend.go:64) transforms them before the recalls
+    for (const auto& kv : experiment_params.at("_user_features").obj) user.Properties[kv.first] = kv.second;
+    {
+        auto uf = sceneUserFeatures.find(scene);
+        if (uf != sceneUserFeatures.end()) {
+            std::vector<module::ItemPtr> none;
+            for (const auto& f : uf->second) f->LoadFeatures(&user, none, &ctx);
+        }
+    }
     // RecallService.GetItems (service/recall.go:53-153): scene → category → recall names, concatenated
     std::vector<module::ItemPtr> items;
     auto sc = config.SceneRecallNames.find(scene);
@@ -1892,6 +1944,13 @@ bool Engine::Recommend(const std::string& uid, int size, const std::string& scen
                 items.insert(items.end(), got.begin(), got.end());
             }
     items = filter::UniqueFilter(items);
+    {   // FeatureService.LoadFeatures (user_recommend.go:129; feature_service.go:77-131): "features.scene.name" of the experiment first
+        std::string fscene = ctx.HasExperiment() ? ctx.ExperimentParamsJson.s("features.scene.name") : "";
+        if (fscene.empty()) fscene = scene;
+        auto sf = sceneFeatures.find(fscene);
+        if (sf != sceneFeatures.end())
+            for (const auto& f : sf->second) f->LoadFeatures(&user, items, &ctx);
+    }
     if (!rank::Rank(this, &user, items, &ctx, err)) return false;
     // SortService.Sort (sort/sort.go:65-125): SortNames[scene] else the default ItemRankScore
     std::vector<std::string> names;
@@ -2408,6 +2467,111 @@ const char* ph_easyrec_generator(const char* spec_json) {
     return o.c_str();
 }
 
+// ---- service/feature drivers -------------------------------------------------------------------------------------
+static void dyn_json(const json::Value& v, std::string* o) {        // floats keep a '.', so a reader can tell float64 10 from int 10
+    switch (v.type) {
+        case json::Value::String: json::Escape(v.str, o); break;
+        case json::Value::Bool: *o += v.b ? "true" : "false"; break;
+        case json::Value::Number:
+            if (v.is_u64) *o += std::to_string((unsigned long long)v.i);
+            else if (v.is_int) *o += std::to_string(v.i);
+            else if (v.num != v.num || std::isinf(v.num)) *o += "null";
+            else {
+                std::string t = json::NumToString(v.num);
+                if (t.find_first_of(".eEn") == std::string::npos) t += ".0";
+                *o += t;
+            }
+            break;
+        case json::Value::Array:
+            *o += "[";
+            for (size_t i = 0; i < v.arr.size(); ++i) { if (i) *o += ","; dyn_json(v.arr[i], o); }
+            *o += "]";
+            break;
+        case json::Value::Object: {
+            *o += "{";
+            bool first = true;
+            for (const auto& kv : v.obj) { if (!first) *o += ","; first = false; json::Escape(kv.first, o); *o += ":"; dyn_json(kv.second, o); }
+            *o += "}";
+            break;
+        }
+        default: *o += "null";
+    }
+}
+static const char* go_type_of(const json::Value& v) {
+    switch (v.type) {
+        case json::Value::String: return "string";
+        case json::Value::Bool: return "bool";
+        case json::Value::Number: return v.is_u64 ? "uint64" : (v.is_int ? "int" : "float64");
+        case json::Value::Array: return "slice";
+        case json::Value::Object: return "map";
+        default: return "nil";
+    }
+}
+// NewNormalizer(name, expression).Apply(value): {"name":..,"expression":..,"value":..,"clock_ms":n?} →
+// {"kind": Go type of the normalizer | null, "result": .., "type": Go type of the result}; an expression outside the subset → NULL + error
+const char* ph_normalizer_apply(const char* spec_json) {
+    json::Value root;
+    std::string err;
+    const std::string text = spec_json ? spec_json : "";
+    if (!json::Parser(text).Parse(&root, &err)) { g_ph_err = err; return nullptr; }
+    feature::SetClockForTest(root.n("clock_ms", 0));
+    auto nz = feature::NewNormalizer(root.s("name"), root.s("expression"), &err);
+    if (!nz && !err.empty()) { g_ph_err = err; return nullptr; }
+    std::string& o = g_ph_out;
+    if (!nz) { o = "{\"kind\":null}"; return o.c_str(); }
+    const json::Value r = nz->Apply(root.at("value"));
+    o = std::string("{\"kind\":\"") + nz->Kind() + "\",\"type\":\"" + go_type_of(r) + "\",\"result\":";
+    dyn_json(r, &o);
+    o += "}";
+    return o.c_str();
+}
+// Feature.LoadFeatures: {"features":[FeatureConfig…], "user":{"id":..,"properties":{..}}|null,
+// "items":[{"id":..,"retrieve_id":..,"properties":{..}}], "context_features":{..}?, "clock_ms":n?} → {"user":{..}|null,"items":[{..}]}
+const char* ph_feature_load(const char* spec_json) {
+    json::Value root;
+    std::string err;
+    const std::string text = spec_json ? spec_json : "";
+    if (!json::Parser(text).Parse(&root, &err)) { g_ph_err = err; return nullptr; }
+    feature::SetClockForTest(root.n("clock_ms", 0));
+    std::vector<feature::FeatureConfig> confs;
+    for (const auto& f : root.at("features").arr) {
+        feature::FeatureConfig c;
+        c.FeatureType = f.s("FeatureType"); c.FeatureName = f.s("FeatureName"); c.FeatureSource = f.s("FeatureSource");
+        c.FeatureValue = f.s("FeatureValue"); c.FeatureStore = f.s("FeatureStore"); c.Normalizer = f.s("Normalizer");
+        c.Expression = f.s("Expression");
+        c.RemoveFeatureSource = f.at("RemoveFeatureSource").type == json::Value::Bool && f.at("RemoveFeatureSource").b;
+        confs.push_back(std::move(c));
+    }
+    feature::Feature feat;
+    if (!feat.LoadWithConfig(confs, &err)) { g_ph_err = err; return nullptr; }
+    std::unique_ptr<module::User> user;
+    if (root.at("user").type == json::Value::Object) {
+        user.reset(new module::User(root.at("user").s("id")));
+        user->Properties = root.at("user").at("properties").obj;
+    }
+    std::vector<module::ItemPtr> items;
+    for (const auto& it : root.at("items").arr) {
+        auto item = std::make_shared<module::Item>(it.s("id"));
+        item->RetrieveId = it.s("retrieve_id");
+        item->Properties = it.at("properties").obj;
+        items.push_back(item);
+    }
+    context::RecommendContext ctx;
+    if (root.at("context_features").type == json::Value::Object) ctx.Param["features"] = root.at("context_features");
+    feat.LoadFeatures(user.get(), items, &ctx);
+    std::string& o = g_ph_out;
+    o = "{\"user\":";
+    if (user) { json::Value u; u.type = json::Value::Object; u.obj = user->Properties; dyn_json(u, &o); } else o += "null";
+    o += ",\"items\":[";
+    for (size_t i = 0; i < items.size(); ++i) {
+        if (i) o += ",";
+        json::Value p; p.type = json::Value::Object; p.obj = items[i]->Properties;
+        dyn_json(p, &o);
+    }
+    o += "]}";
+    return o.c_str();
+}
+
 // cache adapters + clone hooks, self-checked in C++ (bit i set = check i passed)
 int ph_cache_clone_semantics(void) {
     int ok = 0;
@@ -2540,6 +2704,14 @@ const char* ph_parse_recconf(const char* text) {
     o = "{\"recalls\":" + std::to_string(c.RecallConfs.size()) + ",\"gpu_recalls\":" + std::to_string(c.GpuRecalls.size()) +
         ",\"gpu_sorts\":" + std::to_string(c.GpuSorts.size()) + ",\"algos\":" + std::to_string(c.AlgoConfs.size()) +
         ",\"rank_scenes\":" + std::to_string(c.RankConf.size()) + ",\"dpp\":" + std::to_string(c.DPPConf.size());
+    auto count_features = [](const std::map<std::string, recconf::SceneFeatureConfig>& m) {
+        size_t n = 0;
+        for (const auto& sc : m) for (const auto& lc : sc.second.FeatureLoadConfs) n += lc.Features.size();
+        return n;
+    };
+    if (!c.FeatureConfs.empty() || !c.UserFeatureConfs.empty())
+        o += ",\"feature_transforms\":" + std::to_string(count_features(c.FeatureConfs)) + ",\"user_feature_transforms\":" +
+             std::to_string(count_features(c.UserFeatureConfs));
     auto echo = [&](const char* key, const recconf::RecallConfig& r) {
         o += std::string(",\"") + key + "\":{\"name\":";
         json::Escape(r.Name, &o);

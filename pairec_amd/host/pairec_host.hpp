@@ -137,7 +137,14 @@ struct SortConfig {                        // recconf.go:820-838: Name, SortType
     DPPSortConfig DPPConf;
     SSDSortConfig SSDConf;
 };
+struct FeatureConfig {                      // recconf.go:256-265
+    std::string FeatureType, FeatureName, FeatureSource, FeatureValue, FeatureStore, Normalizer, Expression;
+    bool RemoveFeatureSource = false;
+};
+struct FeatureLoadConfig { std::vector<FeatureConfig> Features; std::string DaoAdapterType; };   // recconf.go:173-176 (the DAO fetch is storage: out of scope)
+struct SceneFeatureConfig { std::vector<FeatureLoadConfig> FeatureLoadConfs; bool AsynLoadFeature = false; };   // recconf.go:169-172
 struct RecommendConfig {
+    std::map<std::string, SceneFeatureConfig> UserFeatureConfs, FeatureConfs;   // by scene (recconf.go:52-53)
     std::vector<AlgoConfig> AlgoConfs;
     std::vector<RecallConfig> RecallConfs;
     std::map<std::string, RankConfig> RankConf;                               // by scene
@@ -298,7 +305,7 @@ bool ParseCacheString(const std::string& line, const std::string& recall_name, c
 }  // namespace recall
 
 // fmt.Sprintf("%v", float64): strconv 'g' with the shortest round-trip digits, exponent form for
-// exp < -4 || exp >= 21
+// exp < -4 || exp >= 6
 std::string GoFmtFloat(double x);
 
 // ---- cache (persist/cache/cache.go:13-41) ---------------------------------------------------------
@@ -407,6 +414,7 @@ private:
 };
 
 // ---- the engine: GPU-backed plugins wired under the registries -------------------------------------
+namespace feature { class Feature; }
 class Engine {
 public:
     ~Engine();
@@ -424,6 +432,9 @@ public:
     recall::Registry recalls;
     sort::Registry sorts;
     recconf::RecommendConfig config;
+    // FeatureService / UserFeatureService (service/feature/feature_service.go:77-131, user_feature_service.go): the transforms of
+    // FeatureConfs[scene] run between the filter and the rank call, those of UserFeatureConfs[scene] before the recalls
+    std::map<std::string, std::vector<std::shared_ptr<feature::Feature>>> sceneFeatures, sceneUserFeatures;
 
     pg_ctx* ctx = nullptr;
     pg_table* table = nullptr;
@@ -522,5 +533,42 @@ private:
 bool Rank(Engine* e, module::User* user, std::vector<module::ItemPtr>& items, context::RecommendContext* ctx,
           std::string* err);
 }
+
+// ---- service/feature: normalizers + feature transforms ---------------------------------
+// NewNormalizer (service/feature/normalizer.go:19-41) and the FeatureOp family (op.go:17-33, new_feature_op.go,
+// delete_feature_op.go, batch_raw_feature_op.go) behind Feature.LoadFeatures (feature.go:17-41): host glue upstream of the
+// rank call, mirrored so that a scene's FeatureLoadConfig reads the same here.  The two expression normalizers evaluate a
+// stated SUBSET of their third-party languages (Knetic/govaluate v3.0.1-0.20171022003610 for "expression", expr-lang/expr
+// v1.17.6 for "expr" — both go.mod dependencies absent from the reference tree): what is outside it is refused by name when the
+// normalizer is built, never approximated.  feature.cpp states the subset.
+namespace feature {
+struct Normalizer {
+    virtual ~Normalizer() = default;
+    virtual json::Value Apply(const json::Value& value) = 0;     // Normalizer.Apply (normalizer.go:15-17)
+    virtual const char* Kind() const = 0;                        // the Go type a caller switches on (new_feature_op.go:18-45)
+};
+// nullptr for a name the reference does not know (its NewNormalizer returns a nil interface) — and, with *err set, for an
+// expression outside the subset
+std::shared_ptr<Normalizer> NewNormalizer(const std::string& name, const std::string& expression, std::string* err);
+// utils.GovaluateFunctions (utils/govaluate_functions.go:20-330) by name: the functions both expression languages share
+bool CallFunction(const std::string& name, const std::vector<json::Value>& args, json::Value* out, std::string* err);
+bool HasFunction(const std::string& name);
+// the clock the time normalizers and timestamp() read: 0 = the system's (tests pin it)
+void SetClockForTest(long long unix_millis);
+
+using FeatureConfig = recconf::FeatureConfig;
+class Feature {                             // feature.go:10-41 without the FeatureDao fetch (storage is out of scope)
+public:
+    bool LoadWithConfig(const std::vector<FeatureConfig>& features, std::string* err);
+    void LoadFeatures(module::User* user, std::vector<module::ItemPtr>& items, context::RecommendContext* ctx);
+private:
+    struct Trans { FeatureConfig conf; std::string source; std::shared_ptr<Normalizer> normalizer; };
+    std::vector<Trans> trans_;
+};
+// Item.StringProperty (module/item.go:101-122: a float64 prints as its truncated integer) and User.StringProperty
+// (module/user.go:168-189: a float64 prints with strconv 'f', -1)
+std::string ItemStringProperty(const module::Item& it, const std::string& key);
+std::string UserStringProperty(const module::User& u, const std::string& key);
+}  // namespace feature
 
 }  // namespace pairec

@@ -296,6 +296,56 @@ def test_config_driven_pipeline_matches_oracle(H):
 
 
 @pytest.mark.gpu
+def test_scene_feature_transforms_feed_the_rank_score(H):
+    """FeatureConfs / UserFeatureConfs (recconf.go:52-53) through the request: UserFeatureService before the recalls
+    (user_recommend.go:64), FeatureService between the filter and the rank call (:129), and a transformed item property as a
+    RankScore variable (Item.FloatExprData falls back to Properties, item.go:189-212)."""
+    import copy
+    import pairec_amd as pa
+    _bind_row2(H)
+    cfg = copy.deepcopy(CONFIG)
+    score = RANK_SCORE + " + ${boost} + ${wk}"
+    cfg["RankConf"]["home_feed"]["RankScore"] = score
+    cfg["UserFeatureConfs"] = {"home_feed": {"FeatureLoadConfs": [{"Features": [
+        {"FeatureType": "new_feature", "FeatureStore": "user", "FeatureName": "vip2", "Normalizer": "expression", "Expression": "vip * 2"}]}]}}
+    cfg["FeatureConfs"] = {"home_feed": {"FeatureLoadConfs": [{"FeatureDaoConf": {"AdapterType": "hologres"}, "Features": [
+        {"FeatureType": "new_feature", "FeatureStore": "item", "FeatureName": "boost", "Normalizer": "expr",
+         "Expression": "item.recall_name == 'gpu_vector_recall' ? user.vip2 * 0.25 : 100"},
+        {"FeatureType": "new_feature", "FeatureStore": "item", "FeatureName": "wk", "Normalizer": "expression", "Expression": "1 / 8"},
+        {"FeatureType": "raw_feature", "FeatureStore": "item", "FeatureName": "u_vip", "FeatureSource": "user:vip2"}]}]}}
+    echo = json.loads(H.ph_parse_recconf(json.dumps(cfg).encode()))
+    assert echo["feature_transforms"] == 3 and echo["user_feature_transforms"] == 1
+    h = H.ph_engine_create(json.dumps(cfg).encode())
+    assert h, H.ph_last_error()
+    n, d = 20000, 128
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    w = o.Dnn3Weights()
+    user = o.synth_rows(o.SEED_QUERY, 9, 1, d)[0]
+    H.ph_set_user_vector(h, b"u1", " ".join("%d:%s" % (i + 1, repr(float(v))) for i, v in enumerate(user)).encode())
+    blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+    assert H.ph_engine_load_dnn3(h, pa.PREC_F32, blob, len(blob)) == 0, H.ph_last_error()
+    r = H.ph_recommend_ab(h, b"u1", 40, b"home_feed", json.dumps({"_user_features": {"vip": 3}}).encode())
+    assert r, H.ph_last_error()
+    out = json.loads(r)
+    rows, scores = o.recall_topk(tab, user[None], 300)
+    items = [o.OracleItem("item_%d" % r_, float(s), "gpu_vector_recall") for r_, s in zip(rows[0], scores[0])]
+    dnn = o.dnn3_forward(w, 0, user, tab[rows[0].astype(np.int64)])
+    for it, s in zip(items, dnn):
+        it.add_algo_score("gpu_dnn", float(np.float32(s)))
+        it.properties = {"boost": 1.5, "wk": 0.125}                                 # vip 3 → vip2 6.0 → 6 * 0.25
+    o.fuse_scores(score, items)
+    order = o.sort_scores([it.score for it in items], True)[:40]
+    for g, i in zip(out["items"], order):
+        assert abs(g["score"] - items[i].score) <= 1e-6
+    assert len(out["items"]) == 40 and min(x["score"] for x in out["items"]) > 1.6
+    H.ph_engine_destroy(h)
+    # a transform outside the subset stops the load, named by scene
+    cfg["FeatureConfs"]["home_feed"]["FeatureLoadConfs"][0]["Features"][0]["Expression"] = "item.tags | len()"
+    assert not H.ph_engine_create(json.dumps(cfg).encode())
+    assert b"FeatureConfs[home_feed]" in H.ph_last_error() and b"'|'" in H.ph_last_error()
+
+
+@pytest.mark.gpu
 def test_config_driven_ssd_sort_matches_oracle(H):
     """pairec_gpu.Sorts → GpuSSDSort registered by name (the reference's own SSDSort in SortConfs needs a Hologres
     datasource) with SSDSortConfig's fields (ssd_sort.go:110-343): the page is the oracle's SSD pick sequence over
@@ -375,6 +425,11 @@ def test_go_percent_v_float_format(H):
     for v in vals:
         assert H.ph_go_fmt_float(float(v)).decode() == o.go_fmt_float(float(v)), v
     assert H.ph_go_fmt_float(float("nan")) == b"NaN"
+    # strconv 'g' with the shortest digits switches to the exponent form at exponent 6 (`fmt.Println(float64(12345678))` is
+    # 1.2345678e+07) and below -4
+    for v, want in [(100000.0, "100000"), (999999.5, "999999.5"), (1e6, "1e+06"), (12345678.0, "1.2345678e+07"),
+                    (1700000000.0, "1.7e+09"), (0.0001, "0.0001"), (0.00001234, "1.234e-05"), (-2500000.0, "-2.5e+06")]:
+        assert H.ph_go_fmt_float(v).decode() == o.go_fmt_float(v) == want
 
 
 def test_recall_cache_line_format_and_parse(H):
