@@ -215,6 +215,7 @@ bool RecommendConfig::Parse(const std::string& text, RecommendConfig* out, std::
         SortConfig c;
         c.Name = sc.s("Name"); c.SortType = sc.s("SortType");
         c.SortByField = sc.s("SortByField");
+        c.SortOrder = sc.s("SortOrder");
         c.SwitchThreshold = sc.d("SwitchThreshold");
         if (c.SortType == "DPPSort") {
             c.DPPConf = parse_dpp(sc.at("DPPConf"), c.Name);
@@ -1286,6 +1287,36 @@ struct GpuAlgoScoreSort : sort::ISort {
     }
 };
 
+// CustomFieldSort (sort/custom_field_sort.go:21-73): by Item.FloatExprData(SortByField) — an algo score, else a property, "current_score"
+// = Item.Score — falling back to the item's own Score where the field is missing; "asc" or (default, and for anything else) "desc".
+// The order is the device sort's (ties by position, where Go's sort.Slice leaves them unspecified).
+struct GpuCustomFieldSort : sort::ISort {
+    Engine* e;
+    std::string sortByField, sortOrder;
+    GpuCustomFieldSort(Engine* eng, const recconf::SortConfig& c) : e(eng), sortByField(c.SortByField.empty() ? "current_score" : c.SortByField) {
+        sortOrder = c.SortOrder;
+        std::transform(sortOrder.begin(), sortOrder.end(), sortOrder.begin(), ::tolower);
+        if (sortOrder != "asc" && sortOrder != "desc") sortOrder = "desc";
+    }
+    bool Sort(sort::SortData* d, std::string* err) override {
+        const uint32_t n = (uint32_t)d->Data.size();
+        if (n == 0) return true;
+        std::vector<double> key(n);
+        for (uint32_t i = 0; i < n; ++i)
+            if (!d->Data[i]->FloatExprData(sortByField, &key[i])) key[i] = d->Data[i]->Score;
+        const uint32_t seg[2] = {0, n};
+        std::vector<uint32_t> order(n);
+        if (pg_sort_scores(e->ctx, key.data(), seg, 1, sortOrder == "asc" ? 0 : 1, order.data()) != PG_OK) {
+            if (err) *err = pg_err("pg_sort_scores");
+            return false;
+        }
+        std::vector<module::ItemPtr> out(n);
+        for (uint32_t i = 0; i < n; ++i) out[i] = d->Data[order[i]];
+        d->Data.swap(out);
+        return true;
+    }
+};
+
 struct GpuSSDSort : sort::ISort {                        // sort/ssd_sort.go:110-343 (embedding table = item table)
     Engine* e;
     recconf::SSDSortConfig conf;
@@ -1828,15 +1859,18 @@ Engine* Engine::Create(const std::string& config_json, std::string* err) {
     e->sorts.RegisterSort("ItemRankScore", std::make_shared<GpuItemRankScoreSort>(e.get()), nullptr);
     e->sorts.RegisterSort("ItemScore", std::make_shared<GpuItemScoreSort>(e.get()), nullptr);
     for (const auto& d : e->config.DPPConf) e->sorts.RegisterSort(d.Name, std::make_shared<GpuDPPSort>(e.get(), d), nullptr);
-    // SortConfs (validated above): AlgoScoreSort is host logic over a GPU sort; the other rule-based sorts are outside
-    // this engine's scope and are skipped
-    for (const auto& sc : e->config.SortConfs)
+    // SortConfs (validated above): AlgoScoreSort and CustomFieldSort are host logic over a GPU sort; the other rule-based sorts
+    // are outside this engine's scope and are skipped
+    for (const auto& sc : e->config.SortConfs) {
         if (sc.SortType == "AlgoScoreSort") e->sorts.RegisterSortWithConfig(sc.Name, std::make_shared<GpuAlgoScoreSort>(e.get(), sc));
+        else if (sc.SortType == "CustomFieldSort") e->sorts.RegisterSortWithConfig(sc.Name, std::make_shared<GpuCustomFieldSort>(e.get(), sc));
+    }
     // the GPU sorts of a pairec process: registered by name in the start hook (sort.RegisterSort — first registration wins)
     for (const auto& sc : e->config.GpuSorts) {
         if (sc.SortType == "DPPSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuDPPSort>(e.get(), sc.DPPConf), nullptr);
         else if (sc.SortType == "SSDSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuSSDSort>(e.get(), sc.SSDConf), nullptr);
         else if (sc.SortType == "AlgoScoreSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuAlgoScoreSort>(e.get(), sc), nullptr);
+        else if (sc.SortType == "CustomFieldSort") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuCustomFieldSort>(e.get(), sc), nullptr);
         else if (sc.SortType == "ItemRankScore") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuItemRankScoreSort>(e.get()), nullptr);
         else if (sc.SortType == "ItemScore") e->sorts.RegisterSort(sc.Name, std::make_shared<GpuItemScoreSort>(e.get()), nullptr);
         else { if (err) *err = "pairec_gpu.Sorts: unknown SortType " + sc.SortType; return nullptr; }
@@ -2217,6 +2251,34 @@ static const char* items_to_json(const std::vector<module::ItemPtr>& items) {
         o += "}}";
     }
     o += "]}";
+    return o.c_str();
+}
+
+// one registered sort over caller-made items: [{"id":..,"score":x,"properties":{..},"algo_scores":{..}}] → ["id", …] in the sorted order
+const char* ph_engine_sort(void* h, const char* sort_name, const char* items_json, int size) {
+    Engine* e = (Engine*)h;
+    json::Value root;
+    std::string err;
+    const std::string text = items_json ? items_json : "";
+    if (!json::Parser(text).Parse(&root, &err)) { g_ph_err = err; return nullptr; }
+    auto s = e->sorts.Get(sort_name ? sort_name : "");
+    if (!s) { g_ph_err = std::string("Sort:not find, name:") + (sort_name ? sort_name : ""); return nullptr; }
+    sort::SortData sd;
+    context::RecommendContext ctx;
+    ctx.Size = size;
+    sd.Context = &ctx;
+    for (const auto& it : root.arr) {
+        auto item = std::make_shared<module::Item>(it.s("id"));
+        item->Score = it.d("score");
+        item->Properties = it.at("properties").obj;
+        for (const auto& kv : it.at("algo_scores").obj) item->AddAlgoScore(kv.first, kv.second.num);
+        sd.Data.push_back(item);
+    }
+    if (!s->Sort(&sd, &err)) { g_ph_err = err; return nullptr; }
+    std::string& o = g_ph_out;
+    o = "[";
+    for (size_t i = 0; i < sd.Data.size(); ++i) { if (i) o += ","; json::Escape(sd.Data[i]->Id, &o); }
+    o += "]";
     return o.c_str();
 }
 

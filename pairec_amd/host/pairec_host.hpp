@@ -131,7 +131,8 @@ struct SSDSortConfig {                     // recconf.go:980-1000 (the fields th
 };
 struct SortConfig {                        // recconf.go:820-838: Name, SortType, nested DPPConf / SSDConf
     std::string Name, SortType;
-    std::string SortByField;               // AlgoScoreSort (sort/algo_score_sort.go:17-27)
+    std::string SortByField;               // AlgoScoreSort (sort/algo_score_sort.go:17-27), CustomFieldSort (custom_field_sort.go:21-38)
+    std::string SortOrder;                 // CustomFieldSort: "asc" | "desc" (anything else is "desc")
     double SwitchThreshold = 0.0;
     std::string HologresName;              // DPPConf / SSDConf .DaoConf.HologresName: what NewDPPSort / NewSSDSort open first
     DPPSortConfig DPPConf;

@@ -346,6 +346,40 @@ def test_scene_feature_transforms_feed_the_rank_score(H):
 
 
 @pytest.mark.gpu
+def test_custom_field_sort_reference_known_answers(H):
+    """CustomFieldSort (sort/custom_field_sort.go:21-73) registered from SortConfs and from pairec_gpu.Sorts: the orders
+    custom_field_sort_test.go expects, a missing field falling back to the item's own Score (:52-62), and a random case against
+    numpy's stable order."""
+    import copy
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")))["sort_custom_field"]
+    H.ph_engine_sort.restype = C.c_char_p
+    H.ph_engine_sort.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    cfg = copy.deepcopy(CONFIG)
+    cfg["SortConfs"] = [dict(Name="cf%d" % i, SortType="CustomFieldSort", **g["custom_field"]) for i, g in enumerate(gold)]
+    cfg["UserDefineConfs"]["pairec_gpu"]["Sorts"] = [{"Name": "by_ctr_asc", "SortType": "CustomFieldSort", "SortByField": "ctr", "SortOrder": "asc"}]
+    h = H.ph_engine_create(json.dumps(cfg).encode())
+    assert h, H.ph_last_error()
+    for i, g in enumerate(gold):
+        items = [{"id": it["id"], "score": it.get("score", 0.0), "properties": {k: v for k, v in it.items() if k not in ("id", "score")}}
+                 for it in g["items"]]
+        got = json.loads(H.ph_engine_sort(h, b"cf%d" % i, json.dumps(items).encode(), 10))
+        assert got == g["expect_ids"], g["ref"]
+    # an algo score wins over a property of the same name (item.go:198-203); items without the field sort by their Score
+    items = [{"id": "a", "score": 0.5, "algo_scores": {"ctr": 0.9}, "properties": {"ctr": 0.0}},
+             {"id": "b", "score": 0.7, "properties": {"ctr": 0.2}},
+             {"id": "c", "score": 0.6},
+             {"id": "d", "score": 0.1, "properties": {"ctr": "0.65"}}]
+    assert json.loads(H.ph_engine_sort(h, b"by_ctr_asc", json.dumps(items).encode(), 10)) == ["b", "c", "d", "a"]
+    rng = np.random.default_rng(5)
+    v = np.round(rng.random(3000), 2)                                                  # many ties
+    items = [{"id": "i%d" % i, "score": 0.0, "properties": {"ctr": float(x)}} for i, x in enumerate(v)]
+    got = json.loads(H.ph_engine_sort(h, b"by_ctr_asc", json.dumps(items).encode(), 10))
+    assert got == ["i%d" % i for i in np.argsort(v, kind="stable")]
+    assert H.ph_engine_sort(h, b"nope", b"[]", 10) is None and b"Sort:not find" in H.ph_last_error()
+    H.ph_engine_destroy(h)
+
+
+@pytest.mark.gpu
 def test_config_driven_ssd_sort_matches_oracle(H):
     """pairec_gpu.Sorts → GpuSSDSort registered by name (the reference's own SSDSort in SortConfs needs a Hologres
     datasource) with SSDSortConfig's fields (ssd_sort.go:110-343): the page is the oracle's SSD pick sequence over
