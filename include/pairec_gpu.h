@@ -498,6 +498,10 @@ int pg_gather_owned_rows_dev(pg_ctx* ctx, const pg_table* t, const uint64_t* d_g
 int pg_dpp_batch_dev(pg_ctx* ctx, const float* d_emb, const double* d_rel, uint32_t n_req, uint32_t n, uint32_t dim,
                      double alpha, uint32_t topn, uint32_t window, int normalize_emb, uint32_t* d_out_idx,
                      uint32_t* d_out_count);
+/* DPPSort.KernelMatrix alone (sort/dpp_sort.go:372-475, table path): d_out_L [n_req][n][n] = diag(r) F F^T diag(r) in fp64 for the
+ * same inputs as pg_dpp_batch_dev — what its greedy part consumes, exposed so that the matrix can be checked bit for bit */
+int pg_dpp_kernel_matrix_dev(pg_ctx* ctx, const float* d_emb, const double* d_rel, uint32_t n_req, uint32_t n, uint32_t dim,
+                             double alpha, int normalize_emb, double* d_out_L);
 
 /* ---- request coalescer --------------------------------------------------------------------------
  * The reference calls its plug-ins once per request from many goroutines at once: one IAlgorithm.Run per recall

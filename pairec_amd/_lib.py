@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PG_LIB_VARIANT=dev selects libpairec_gpu_dev.so: what `make WS_EXTRA=… / SCAN_EXTRA=… / MLP_EXTRA=…` builds (profile marks,
 # ablations) — the product library is never one of those (pairec_amd/csrc/Makefile)
 LIB_PATH = os.path.join(_HERE, "libpairec_gpu_dev.so" if os.environ.get("PG_LIB_VARIANT") == "dev" else "libpairec_gpu.so")
+if os.environ.get("PG_LIB_PATH"):                  # developer A/B runs: an explicitly named build
+    LIB_PATH = os.environ["PG_LIB_PATH"]
 
 # every symbol include/pairec_gpu.h declares (tests/test_abi.py checks the two stay in sync)
 EXPORTS = [
@@ -35,7 +37,7 @@ EXPORTS = [
     "pg_fm2t_item_rows_build", "pg_fm2t_item_rows_update", "pg_fm2t_item_rows_destroy", "pg_rank_fm2t_irows_dev",
     "pg_rank_fm2t_irows",
     "pg_topk_merge_lists_dev", "pg_owned_compact_dev", "pg_scatter_f32_dev", "pg_dpp_candidates_dev",
-    "pg_gather_owned_rows_dev", "pg_dpp_batch_dev",
+    "pg_gather_owned_rows_dev", "pg_dpp_batch_dev", "pg_dpp_kernel_matrix_dev",
     "pg_group_create", "pg_group_destroy", "pg_group_size", "pg_group_ctx", "pg_group_table", "pg_group_table_create",
     "pg_group_table_fill_synthetic", "pg_group_table_upload", "pg_group_model_load", "pg_group_recommend",
     "pg_group_recommend_begin", "pg_group_recommend_end", "pg_group_info", "pg_coalescer_create_group",
@@ -194,6 +196,7 @@ def load():
         "pg_dpp_candidates_dev": [vp, vp, vp, vp, u32, u32, u32, vp, vp],
         "pg_gather_owned_rows_dev": [vp, vp, vp, u32, vp],
         "pg_dpp_batch_dev": [vp, vp, vp, u32, u32, u32, C.c_double, u32, u32, i32, vp, vp],
+        "pg_dpp_kernel_matrix_dev": [vp, vp, vp, u32, u32, u32, C.c_double, i32, vp],
         "pg_group_create": [P(C.c_int), u32, P(vp)],
         "pg_group_destroy": [vp],
         "pg_group_table_create": [vp, u64, u32],

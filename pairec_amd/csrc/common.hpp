@@ -73,6 +73,7 @@ struct Knobs {
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
     uint32_t rank_sort_max = 8;    // PG_RANK_SORT_MAX: up to this many lists per call are sorted by counting ranks (0 = never)
     bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
+    bool dpp_valu = false;         // PG_DPP_VALU: the DPP kernel matrix on the fp64 vector pipe (round-4 kernel) instead of the fp64 matrix pipe (A/B; same bits)
     bool rank_t3 = false;          // PG_RANK_T3: the benchmark's bf16 DNN3 on the three-waves-per-SIMD kernel (rank_t3.hip) instead of rank_ws.hip (A/B)
     bool fm2t_irs = false;         // PG_FM2T_IRS: cfg 4's item-record rank on the producer / consumer kernel (rank_ir.hip) instead of rank_is.hip (A/B)
     bool no_predict = false;       // PG_NO_PREDICT: never replace the pilot sample by the learned threshold model
@@ -397,7 +398,7 @@ int expr_rewrite_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, int r, const
 int table_gather_locked(pg_ctx* ctx, const pg_table* t, const uint32_t* d_rows, uint32_t n, float* d_out);
 int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, const double* d_rel, uint32_t R, uint32_t n,
                    uint32_t d, uint32_t hook_dim, double alpha, uint32_t topn, uint32_t window, int normalize,
-                   int ensure_pos, int has_table, uint32_t* d_out, uint32_t* d_out_count);
+                   int ensure_pos, int has_table, uint32_t* d_out, uint32_t* d_out_count, double* d_L_out = nullptr);
 int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg, uint32_t n_items,
                     uint32_t max_seg, int desc, uint32_t* d_out);
 

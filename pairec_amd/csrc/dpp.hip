@@ -19,6 +19,9 @@
 #include <type_traits>
 #include <vector>
 
+#ifndef DPP_ABL
+#define DPP_ABL 0
+#endif
 namespace pg {
 
 // Feature rows, one thread per candidate of one request (blockIdx.y = request), following KernelMatrix
@@ -123,6 +126,21 @@ __global__ __launch_bounds__(64) void dpp_prepare_table_kernel(DppPrep a) {
 // k-ascending fma chain (the staging only changes where the operands come from), so the bits are those of the
 // one-thread-per-element version — which read every F row n times from L2: 66 GB for 256 requests x 500 candidates
 // (cfg 5's batch), 30 ms; tiled it is ~1 ms.
+// Which (request, tile pair) a workgroup of the kernel matrix takes.  The dispatcher places workgroup b on XCD b % 8, and every
+// XCD has its own L2: with the tile pairs of a request dealt over the grid's x and the requests over z, the nt (nt + 1) / 2 tiles
+// that share a request's F rows ran on all eight XCDs, and each fetched its two 64-row panels from the fabric again —
+// FETCH_SIZE 1.75 GB per 256-request batch (profiles/r4_dpp_v2_pmc_summary.txt) for 132 MB of F, and 0.29 ms of the kernel's
+// 0.35 with the arithmetic removed (round 5 ablation, DPP_ABL).  Here XCD x serves requests x, x + 8, …, all tile pairs of one
+// request on consecutive workgroups of that XCD: a request's F (516 KB at 500 x 129) is fetched once and stays in the 4 MB L2
+// while its tiles run.  (Placement is a speed assumption only: any other assignment of workgroups to XCDs computes the same.)
+__device__ __forceinline__ bool dpp_tile_of_block(uint32_t nt, uint32_t R, uint32_t* q, uint32_t* p) {
+    const uint32_t pairs = nt * (nt + 1) / 2, b = blockIdx.x;
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    *q = xcd + 8u * (slot / pairs);
+    *p = slot % pairs;
+    return *q < R;
+}
+
 constexpr int kDppTile = 64, kDppKc = 16;
 // One WAVE per 64 x 64 tile of S = F F^T, upper triangle only (blockIdx.x walks the tile pairs ti <= tj): lane (ty, tx)
 // of an 8 x 8 grid owns the 8 x 8 patch rows {2ty, 2ty + 1} + 16a, columns {2tx, 2tx + 1} + 16b — 64 accumulators per
@@ -144,16 +162,18 @@ constexpr int kDppTile = 64, kDppKc = 16;
 // Tried and dropped: 8-column chunks double-buffered in LDS (700 us: a row's 64-B segments fetch every 128-B line twice);
 // the operands of step k + 1 read before the fma of step k (no gain).
 __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
-                                                                  uint32_t n, uint32_t d1, uint32_t nt, double* __restrict__ L) {
+                                                                  uint32_t n, uint32_t d1, uint32_t nt, uint32_t R, uint32_t ld, double* __restrict__ L) {
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     // the two panels [k][row], rows padded to a 16-B multiple (+ 1 column: the 17-wide tail); ONE array: the output staging
     // below runs over both
     __shared__ __attribute__((aligned(16))) double panels[2][kDppKc + 1][kDppTile + 2];
     auto& sa = panels[0];
     auto& sb = panels[1];
-    const uint32_t q = blockIdx.z;
+    // (request, tile pair) of this workgroup: see dpp_tile_of_block
+    uint32_t q, p;
+    if (!dpp_tile_of_block(nt, R, &q, &p)) return;
     // tile pair p → (ti, tj), ti <= tj: row ti holds nt - ti pairs
-    uint32_t ti = 0, p = blockIdx.x;
+    uint32_t ti = 0;
     while (p >= nt - ti) {
         p -= nt - ti;
         ++ti;
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* 
         const uint32_t r0 = (mirror ? j0 : i0) + 32 * half, c0 = mirror ? i0 : j0;
         for (int rr2 = 0; rr2 < 32; ++rr2) {
             const uint32_t gi = r0 + rr2, gj = c0 + lane;
-            if (gi < n && gj < n) L[((size_t)q * n + gi) * n + gj] = stage[rr2 * 65 + lane];
+            if (gi < n && gj < n) __builtin_nontemporal_store(stage[rr2 * 65 + lane], &L[((size_t)q * n + gi) * ld + gj]);   // (streams out: see the matrix-pipe kernel)
         }
     };
     pass(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
@@ -273,6 +293,179 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* 
         pass(std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
         pass(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
     }
+}
+
+// Round 5: the same tile on the fp64 matrix pipe.  v_mfma_f64_16x16x4_f64 accumulates D = C + a_0 b_0 + … + a_3 b_3 as the
+// k-ascending fma chain the specification is (scripts/micro/mfma_f64.hip, profiles/r5_mfma_f64_microbench.txt: 256 of 256
+// outputs over K = 128 with exponents spread over 2^±20 bit-equal to the chain; 125 / 46 / 65 of 256 to the other candidate
+// orders), so S_ij keeps its bits (tests/test_gpu_parity.py::test_dpp_kernel_matrix_bits_on_both_pipes: this kernel, the vector
+// kernel and the oracle agree bit for bit) — and an instruction retires 1 024 fma for TWO 8-byte operand reads per lane where the
+// vector form needs 8 reads of 16 B per 64.  The instruction takes 64 cycles (16 fma per clock and SIMD = 38 T fma/s measured:
+// the chip's fp64 matrix peak IS its vector peak — the instructions execute on the SIMD's fp64 vector units), 33 k-steps x 16
+// blocks per tile = 0.136 ms of pipe time per 256 x 500 x 129 batch.  A wave owns the 64 x 64 tile as 4 x 4 blocks of 16 x 16:
+// block (a, b), register g, lane l = row 16a + (l >> 4) + 4g, column 16b + (l & 15).  The panels are staged as before, the next
+// chunk's requested before this chunk's instructions; a width that is not a multiple of four ends with zero operands written
+// into the panel (fma(0, 0, acc) = acc: the chain starts at +0 and cannot reach -0).  Epilogue as before: L_ij = (r_i S_ij) r_j
+// and its mirror, as whole rows through LDS.
+// Measured (profiles/r5_dpp_mfma_summary.txt): 0.343 ms as first built — exactly the vector kernel's time: neither pipe was the
+// bound.  FETCH_SIZE 1.75 GB for 132 MB of F: dpp_tile_of_block (one request's tiles on one XCD) → 135 MB, 0.304 ms; L's 512 MB as
+// non-temporal stores: 0.277 ms (matrix pipe 49 % busy).  What is left is the pairing of two waves per SIMD on one fp64 unit: with
+// the matrix instructions removed the kernel takes 0.144 ms, with them 0.277 = the sum, not the maximum — a wave's staging and
+// epilogue (≈ 1 700 vector instructions per tile) advance at about one instruction per partner matrix instruction (64 cycles),
+// s_setprio does not change that, and one wave per SIMD (0.37 ms) leaves every load latency exposed.  Not done: a single wave
+// per SIMD that issues its LDS / global traffic between its own matrix instructions (hand-placed, as csrc/recall.hip does).
+__global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_mfma_kernel(const double* __restrict__ F, const double* __restrict__ r,
+                                                                       uint32_t n, uint32_t d1, uint32_t nt, uint32_t R, uint32_t ld, double* __restrict__ L
+#ifdef DPP_PROFILE
+                                                                       , unsigned long long* prof
+#endif
+                                                                       ) {
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) double panels[2][kDppKc + 1][kDppTile + 2];
+    auto& sa = panels[0];
+    auto& sb = panels[1];
+    uint32_t q, p;
+    if (!dpp_tile_of_block(nt, R, &q, &p)) return;
+#ifdef DPP_PROFILE
+    // phases: 0 prologue (first panels requested), 1 waiting for a chunk's panels + their LDS writes, 2 requesting the next panels,
+    // 3 the chunk's matrix instructions (operand reads included), 4 epilogue
+    uint64_t ph[5] = {0, 0, 0, 0, 0}, tp = __builtin_readcyclecounter();
+#define DPP_MARK(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const uint64_t tn = __builtin_readcyclecounter(); ph[i] += tn - tp; tp = tn; }
+#else
+#define DPP_MARK(i)
+#endif
+    uint32_t ti = 0;
+    while (p >= nt - ti) {
+        p -= nt - ti;
+        ++ti;
+    }
+    const uint32_t tj = ti + p;
+    const uint32_t i0 = ti * kDppTile, j0 = tj * kDppTile;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t kk = lane & 15, rr = lane >> 4;             // staging: column kk of rows rr + 4 it; operands: row kk, k-slot rr
+    const double* Fq = F + (size_t)q * n * d1;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+#define DPP_ACCS "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]), \
+                 "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3])
+    asm volatile("s_nop 3" : DPP_ACCS);                         // the zeros are VALU writes
+    // One wave per workgroup: LDS accesses of a wave execute in program order, so the panels need no barrier — and must not have
+    // __syncthreads(), whose s_waitcnt vmcnt(0) would make every chunk wait for the NEXT chunk's panel loads, which are requested
+    // before the chunk's instructions so that they land under them (and, in the epilogue, for the previous pass's stores).
+    double va[16], vb[16];
+    const char* const Fb = reinterpret_cast<const char*>(Fq);
+    const uint32_t rowb = d1 * 8u;
+    uint32_t voff = rr * rowb + kk * 8u;
+    auto load_panels = [&]() {                                  // (unclamped: see dpp_kernel_matrix_kernel)
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            va[it] = *reinterpret_cast<const double*>(Fb + (size_t)(i0 + (uint32_t)it * 4) * rowb + voff);
+            vb[it] = *reinterpret_cast<const double*>(Fb + (size_t)(j0 + (uint32_t)it * 4) * rowb + voff);
+        }
+        voff += kDppKc * 8u;
+    };
+    // (inline asm with the accumulator as "+v": the builtin let the allocator place a k-step's results in fresh registers — 271
+    // spilled dwords under the two-waves budget.  Wait states by hand: operands fresh from LDS → s_nop 3; the accumulators are
+    // read by nothing but their own next instruction until the s_nops behind the loop.)  No selects: fp64 matrix instructions
+    // execute on the SIMD's fp64 vector units, and beside a partner wave that issues them back to back every OTHER vector
+    // instruction of a wave gets one slot per 64 cycles, whatever its priority (round 5 profile build: 150 cycles per panel load,
+    // 90 K cycles for the epilogue's ~1 000 instructions) — k-slots past the width read zeros that were written into the panels.
+    auto step = [&](uint32_t kr) {                              // one instruction per block: k-slot kr of this lane
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            av[a] = sa[kr][16 * a + kk];
+            bv[a] = sb[kr][16 * a + kk];
+        }
+        asm volatile("s_nop 3" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[a][b]) : "v"(av[a]), "v"(bv[b]));
+    };
+    load_panels();
+    DPP_MARK(0)
+    for (uint32_t k0 = 0; k0 < d1; k0 += kDppKc) {              // (the 129th column is a ninth chunk of one: its staging hides like the others')
+        const uint32_t kc = d1 - k0 < (uint32_t)kDppKc ? d1 - k0 : (uint32_t)kDppKc;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            sa[kk][it * 4 + rr] = va[it];
+            sb[kk][it * 4 + rr] = vb[it];
+        }
+        for (uint32_t z = kc; z < ((kc + 3u) & ~3u); ++z) {     // a width that is not a multiple of four: zeros behind it
+            sa[z][lane] = 0.0;
+            sb[z][lane] = 0.0;
+        }
+        DPP_MARK(1)
+        if (k0 + kDppKc < d1) load_panels();                    // the next chunk's, under this chunk's instructions
+        DPP_MARK(2)
+#if DPP_ABL == 2
+        if (d1 == 12345u)
+#endif
+#pragma unroll 1
+        for (uint32_t s4 = 0; 4 * s4 < kc; ++s4) step(4 * s4 + rr);   // (one code path: the accumulators stay where they are)
+        asm volatile("" ::: "memory");
+        DPP_MARK(3)
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : DPP_ACCS);   // a 16-pass instruction's results, before anything else reads them
+#undef DPP_ACCS
+    const double* rq = r + (size_t)q * n;
+    double* const stage = &panels[0][0][0];                     // 32 x 65 doubles fit the two panels (2 x 17 x 66)
+    static_assert(32 * 65 <= 2 * (kDppKc + 1) * (kDppTile + 2), "the output staging aliases the panels");
+    double rjv[4], riv[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t j = j0 + 16 * b + kk;
+        rjv[b] = j < n ? rq[j] : 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t i = i0 + 16 * b + rr + 4 * g;
+            riv[b][g] = i < n ? rq[i] : 0.0;
+        }
+    }
+    auto pass = [&](auto mirror_c, auto half_c) {
+        constexpr int mirror = decltype(mirror_c)::value, half = decltype(half_c)::value;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (((mirror ? b : a) >> 1) != half) continue;                  // output rows [32 half, 32 half + 32)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row_t = 16 * a + (int)rr + 4 * g, col_t = 16 * b + (int)kk;
+                    const int orow = mirror ? col_t : row_t, ocol = mirror ? row_t : col_t;
+                    const double v = mirror ? __dmul_rn(__dmul_rn(rjv[b], acc[a][b][g]), riv[a][g])
+                                            : __dmul_rn(__dmul_rn(riv[a][g], acc[a][b][g]), rjv[b]);
+                    stage[(orow & 31) * 65 + ocol] = v;
+                }
+            }
+        const uint32_t r0 = (mirror ? j0 : i0) + 32 * half, c0 = mirror ? i0 : j0;
+        for (int rr2 = 0; rr2 < 32; ++rr2) {
+            const uint32_t gi = r0 + rr2, gj = c0 + lane;
+#if DPP_ABL == 1
+            if (gi < n && gj < n && stage[rr2 * 65 + lane] == 1.2345e300) L[((size_t)q * n + gi) * ld + gj] = stage[rr2 * 65 + lane];
+#else
+            // (non-temporal: 2 MB of L per request stream out once; as ordinary stores they pass through the L2 the tiles' F rows live in)
+            if (gi < n && gj < n) __builtin_nontemporal_store(stage[rr2 * 65 + lane], &L[((size_t)q * n + gi) * ld + gj]);
+#endif
+        }
+    };
+    pass(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+    pass(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
+    if (ti != tj) {
+        pass(std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
+        pass(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+    }
+#ifdef DPP_PROFILE
+    DPP_MARK(4)
+    if (lane == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(&prof[i], (unsigned long long)ph[i]);
+#endif
+#undef DPP_MARK
 }
 
 // floats.MaxIdx: first maximum, NaN skipped; all-NaN → index 0.  Block-wide, result in *s_idx.
@@ -309,13 +502,13 @@ __device__ __forceinline__ void block_argmax(const double* __restrict__ v, uint3
 // DPPWithWindow + DPP (dpp_sort.go:477-551), one workgroup.
 //   d2: [n], c: [window][n] scratch in global memory (L2-resident), Y: output indices.
 //   One workgroup per request (blockIdx.x): L, d2, c, out are that request's slices.
-__global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restrict__ L_all, uint32_t N,
+__global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restrict__ L_all, uint32_t N, uint32_t ld,
                                                           uint32_t topn_total, uint32_t window,
                                                           double* __restrict__ d2_all, double* __restrict__ c_all,
                                                           uint32_t* __restrict__ out_all, uint32_t* __restrict__ out_count) {
     const uint32_t req = blockIdx.x;
     const uint32_t wrows = window < N ? window : N;
-    const double* __restrict__ L = L_all + (size_t)req * N * N;
+    const double* __restrict__ L = L_all + (size_t)req * N * ld;          // rows of ld doubles (dpp_run_locked)
     double* __restrict__ d2 = d2_all + (size_t)req * N;
     double* __restrict__ c = c_all + (size_t)req * wrows * N;
     uint32_t* __restrict__ out = out_all + (size_t)req * topn_total;
@@ -340,7 +533,7 @@ __global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restri
         for (uint32_t i = tid; i < N; i += blockDim.x) {
             bool ex = false;
             for (uint32_t e = 0; e < existed; ++e) ex |= (out[e] == i);
-            d2[i] = ex ? nan : L[(size_t)i * N + i];
+            d2[i] = ex ? nan : L[(size_t)i * ld + i];
         }
         __syncthreads();
         block_argmax(d2, N, s_val, s_idx, &s_j);
@@ -357,7 +550,7 @@ __global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restri
             const uint32_t k = ny - 1;
             const double inv = 1.0 / dj;
             for (uint32_t n = tid; n < N; n += blockDim.x) {
-                double lj = L[(size_t)j * N + n];
+                double lj = L[(size_t)j * ld + n];
                 if (k > 0) {
                     double ss = 0.0;
                     for (uint32_t i = 0; i < k; ++i)
@@ -412,14 +605,14 @@ __device__ __forceinline__ void dpp_static_for(F&& f) {
 }
 
 template <int EPL, int WMAX>
-__global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __restrict__ L_all, uint32_t N,
+__global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __restrict__ L_all, uint32_t N, uint32_t ld,
                                                              uint32_t topn_total, uint32_t window,
                                                              uint32_t* __restrict__ out_all, uint32_t* __restrict__ out_count) {
     extern __shared__ double c_lds[];                   // [min(window, WMAX)][EPL * 64]
     constexpr uint32_t NS = EPL * 64;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     const uint32_t req = blockIdx.x, lane = threadIdx.x;
-    const double* __restrict__ L = L_all + (size_t)req * N * N;
+    const double* __restrict__ L = L_all + (size_t)req * N * ld;          // rows of ld doubles (dpp_run_locked)
     uint32_t* __restrict__ out = out_all + (size_t)req * topn_total;
     const double epsilon = 1e-10;
     const double nan = __longlong_as_double(0x7FF8000000000000ll);
@@ -458,7 +651,7 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
             const uint32_t n = (uint32_t)s * 64u + lane;
-            d2[s] = (n < N && !sel[s]) ? L[(size_t)n * N + n] : nan;       // already selected (and the padding): NaN
+            d2[s] = (n < N && !sel[s]) ? L[(size_t)n * ld + n] : nan;       // already selected (and the padding): NaN
         }
         uint32_t j;
         double dj;
@@ -479,7 +672,7 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 const uint32_t n = (uint32_t)s * 64u + lane;
-                lv[s] = n < N ? L[(size_t)j * N + n] : 0.0;
+                lv[s] = n < N ? L[(size_t)j * ld + n] : 0.0;
             }
             double cj[WMAX];
 #pragma unroll
@@ -533,13 +726,17 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
 // Caller holds ctx->mu; nothing synchronises.
 int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, const double* d_rel, uint32_t R, uint32_t n,
                    uint32_t d, uint32_t hook_dim, double alpha, uint32_t topn, uint32_t window, int normalize,
-                   int ensure_pos, int has_table, uint32_t* d_out, uint32_t* d_out_count) {
-    if (R == 0 || n == 0 || topn == 0) return PG_OK;
+                   int ensure_pos, int has_table, uint32_t* d_out, uint32_t* d_out_count, double* d_L_out) {
+    if (R == 0 || n == 0 || (topn == 0 && !d_L_out)) return PG_OK;
     if (window == 0) window = 10;                        // NewDPPSort default (dpp_sort.go:89-91)
     const uint32_t d1 = hook_dim + (has_table ? d : 0u) + 1;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // L's rows are padded to whole 128-byte lines: a tile's 512-byte row segments then cover four lines each — with rows of n = 500
+    // doubles every segment began and ended inside a line that a workgroup of another XCD completes, and the 512 MB of a
+    // 256-request batch left the chip as partial-line writes at 1.46 TB/s (0.35 ms whatever the arithmetic pipe did)
+    const uint32_t ld = (n + 15u) & ~15u;
     // (F: 64 rows of slack behind the last request — the kernel matrix's panel loads are not clamped)
-    const size_t bF = al(((size_t)R * n + kDppTile) * d1 * 8), bR = al((size_t)R * n * 8), bL = al((size_t)R * n * n * 8);
+    const size_t bF = al(((size_t)R * n + kDppTile) * d1 * 8), bR = al((size_t)R * n * 8), bL = al((size_t)R * n * ld * 8);
     const size_t bD2 = al((size_t)R * n * 8), bC = al((size_t)R * std::min(window, n) * n * 8);
     void* buf;
     int rc;
@@ -559,18 +756,43 @@ int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, cons
     else if (has_table && hook_dim == 0 && d == 64) dpp_prepare_table_kernel<64><<<dim3((n + 63) / 64, R), 64, 0, ctx->stream>>>(a);
     else dpp_prepare_kernel<<<dim3((n + 63) / 64, R), 64, 0, ctx->stream>>>(a);
     const uint32_t nt = (n + kDppTile - 1) / kDppTile;
-    dpp_kernel_matrix_kernel<<<dim3(nt * (nt + 1) / 2, 1, R), 64, 0, ctx->stream>>>(F, Rr, n, d1, nt, L);
+    const uint32_t km_blocks = nt * (nt + 1) / 2 * ((R + 7u) / 8u) * 8u;       // (dpp_tile_of_block)
+    if (ctx->knobs.dpp_valu) dpp_kernel_matrix_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, Rr, n, d1, nt, R, ld, L);
+#ifdef DPP_PROFILE
+    else {
+        static unsigned long long* prof = nullptr;
+        if (!prof) hipMalloc(&prof, 5 * 8);
+        hipMemsetAsync(prof, 0, 5 * 8, ctx->stream);
+        dpp_kernel_matrix_mfma_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, Rr, n, d1, nt, R, ld, L, prof);
+        unsigned long long h[5];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpy(h, prof, sizeof h, hipMemcpyDeviceToHost);
+        static int calls = 0;
+        if (++calls == 5) {
+            const double tiles = (double)(nt * (nt + 1) / 2) * R;
+            fprintf(stderr, "dpp kernel matrix, s_memtime ticks per tile: prologue %.0f, panel wait + LDS writes %.0f, panel requests %.0f, matrix instructions %.0f, epilogue %.0f\n",
+                    h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles);
+        }
+    }
+#else
+    else dpp_kernel_matrix_mfma_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, Rr, n, d1, nt, R, ld, L);
+#endif
+    if (d_L_out) {                                              // KernelMatrix alone (pg_dpp_kernel_matrix_dev)
+        PG_HIP(hipGetLastError());
+        PG_HIP(hipMemcpy2DAsync(d_L_out, (size_t)n * 8, L, (size_t)ld * 8, (size_t)n * 8, (size_t)R * n, hipMemcpyDeviceToDevice, ctx->stream));
+        return PG_OK;
+    }
     const uint32_t wrows = window < n ? window : n;
     if (n <= 512 && window <= 16) {
         const size_t lds = (size_t)wrows * 512 * 8;
         if ((rc = ensure_dyn_lds(ctx, (const void*)dpp_greedy_wave_kernel<8, 16>, lds))) return rc;
-        dpp_greedy_wave_kernel<8, 16><<<R, 64, lds, ctx->stream>>>(L, n, topn, window, d_out, d_out_count);
+        dpp_greedy_wave_kernel<8, 16><<<R, 64, lds, ctx->stream>>>(L, n, ld, topn, window, d_out, d_out_count);
     } else if (n <= 1024 && window <= 10) {
         const size_t lds = (size_t)wrows * 1024 * 8;
         if ((rc = ensure_dyn_lds(ctx, (const void*)dpp_greedy_wave_kernel<16, 10>, lds))) return rc;
-        dpp_greedy_wave_kernel<16, 10><<<R, 64, lds, ctx->stream>>>(L, n, topn, window, d_out, d_out_count);
+        dpp_greedy_wave_kernel<16, 10><<<R, 64, lds, ctx->stream>>>(L, n, ld, topn, window, d_out, d_out_count);
     } else {
-        dpp_greedy_kernel<<<R, 1024, 0, ctx->stream>>>(L, n, topn, window, D2, Cm, d_out, d_out_count);
+        dpp_greedy_kernel<<<R, 1024, 0, ctx->stream>>>(L, n, ld, topn, window, D2, Cm, d_out, d_out_count);
     }
     PG_HIP(hipGetLastError());
     return PG_OK;

@@ -562,6 +562,14 @@ int pg_dpp_batch_dev(pg_ctx* ctx, const float* d_emb, const double* d_rel, uint3
     return pg::dpp_run_locked(ctx, d_emb, nullptr, d_rel, n_req, n, dim, 0, alpha, topn, window, normalize_emb, 1, 1, d_out_idx, d_out_count);
 }
 
+int pg_dpp_kernel_matrix_dev(pg_ctx* ctx, const float* d_emb, const double* d_rel, uint32_t n_req, uint32_t n, uint32_t dim,
+                             double alpha, int normalize_emb, double* d_out_L) {
+    PG_REQUIRE(ctx && d_emb && d_rel && d_out_L, "pg_dpp_kernel_matrix_dev: NULL argument");
+    PG_REQUIRE(n <= 8192 && dim <= 4096 && n_req <= 65535, "pg_dpp_kernel_matrix_dev: %u requests x %u candidates x %u dims unsupported", n_req, n, dim);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return pg::dpp_run_locked(ctx, d_emb, nullptr, d_rel, n_req, n, dim, 0, alpha, 0, 0, normalize_emb, 1, 1, nullptr, nullptr, d_out_L);
+}
+
 int pg_topk_merge_lists_dev(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
                             uint32_t per_list, int list_major, uint32_t k, uint64_t* d_out_rows, float* d_out_scores) {
     PG_REQUIRE(ctx && d_rows && d_scores && d_out_rows && d_out_scores, "pg_topk_merge_lists_dev: NULL argument");

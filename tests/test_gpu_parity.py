@@ -1139,6 +1139,44 @@ def test_dpp_matches_oracle(ctx):
     t.destroy()
 
 
+def test_dpp_kernel_matrix_bits_on_both_pipes(ctx):
+    """DPPSort.KernelMatrix alone (pg_dpp_kernel_matrix_dev): the fp64 MATRIX pipe (v_mfma_f64_16x16x4_f64, the default since round
+    5) and the vector-pipe kernel (knob dpp_valu) give the same bits of L = diag(r) F F^T diag(r), and with alpha = 0 (r = 1
+    exactly on host and device; exp() is the one operation whose last bit the two may round differently) those are the bits of the
+    oracle's k-ascending fma chains — over sizes around the 64-row tiles, widths that are and are not 16 m + 1, rows whose
+    exponents spread over 2^±12 (where any other summation order shows), a zero row and signed zeros."""
+    from pairec_amd import _lib
+    rng = np.random.default_rng(21)
+    cases = [(3, 500, 128, True), (2, 64, 128, True), (2, 65, 64, True), (1, 1, 128, True), (2, 129, 16, False), (1, 200, 20, False),
+             (2, 63, 3, True), (1, 333, 130, False), (1, 512, 128, True), (1, 100, 15, False), (1, 70, 33, True)]
+    for R, n, d, norm in cases:
+        emb = rng.standard_normal((R, n, d)).astype(np.float32)
+        emb *= np.exp2(rng.integers(-12, 13, (R, n, d))).astype(np.float32)          # products of very different magnitudes
+        if n > 4:
+            emb[0, 2, : d // 2] = -0.0
+            if not norm:
+                emb[0, 3] = 0.0                                                      # an all-zero row: S = 0, the chain never leaves +0
+        rel = np.sort(rng.random((R, n)), axis=1)[:, ::-1].copy()
+        d_e, d_r, d_L = ctx.to_device(emb), ctx.to_device(rel), ctx.malloc(R * n * n * 8)
+        for alpha in (0.0, 0.7):
+            got = {}
+            for valu in (0, 1):
+                ctx.set_option("dpp_valu", valu)
+                L = np.zeros((R, n, n))
+                _lib.check(ctx.L.pg_dpp_kernel_matrix_dev(ctx.h, d_e, d_r, R, n, d, alpha, int(norm), d_L))
+                ctx.d2h(L, d_L)
+                got[valu] = L
+            ctx.set_option("dpp_valu", 0)
+            assert np.array_equal(got[0].view(np.uint64), got[1].view(np.uint64)), (R, n, d, norm, alpha)
+            want = np.stack([o.dpp_kernel_matrix_f(o.dpp_features(emb[q], None, norm, True), rel[q], alpha) for q in range(R)])
+            if alpha == 0.0:
+                assert np.array_equal(got[0].view(np.uint64), want.view(np.uint64)), (R, n, d, norm, float(np.max(np.abs(got[0] - want))))
+            else:
+                assert np.allclose(got[0], want, rtol=1e-15, atol=0.0), (R, n, d, norm)
+        for p in (d_e, d_r, d_L):
+            ctx.free(p)
+
+
 def test_dpp_options_match_oracle(ctx):
     """DPPSort.KernelMatrix's switches (dpp_sort.go:382-447): dpp_norm_relevance_score 1 / 2, hook embeddings
     prepended to the table embedding, hook-only rows with and without EnsurePositiveSim, un-normalised rows —
