@@ -1210,11 +1210,10 @@ struct WeekNormalizer : Normalizer {
     const char* Kind() const override { return "CreateWeekNormalizer"; }
 };
 struct RandomNormalizer : Normalizer {                              // rand.Intn(100) (:86-97): any value of [0, 100)
-    uint64_t state;
+    std::atomic<uint64_t> state;                                    // (requests run concurrently; math/rand's source is locked)
     RandomNormalizer() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); state = (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
     V Apply(const V&) override {
-        state += 0x9E3779B97F4A7C15ull;
-        uint64_t z = state;
+        uint64_t z = state.fetch_add(0x9E3779B97F4A7C15ull) + 0x9E3779B97F4A7C15ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         z ^= z >> 31;
