@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void dpp_prepare_table_kernel(DppPrep a) {
     a.r[item] = exp(a.alpha * a.rel[item]);
 }
 
-// L = diag(r) (F F^T) diag(r) for one request per blockIdx.z: a 64 x 64 tile of L per workgroup, the two 64-row
+// S = F F^T (round 5: the scaling L = diag(r) S diag(r) is applied where the greedy kernels read) for one request: a 64 x 64 tile per workgroup, the two 64-row
 // panels of F staged through LDS 16 columns at a time, every thread a 4 x 4 patch.  Each S_ij is still its own
 // k-ascending fma chain (the staging only changes where the operands come from), so the bits are those of the
 // one-thread-per-element version — which read every F row n times from L2: 66 GB for 256 requests x 500 candidates
@@ -161,8 +161,8 @@ constexpr int kDppTile = 64, kDppKc = 16;
 // instead of a ninth staging round for one column: 356 us = VALU 50 % busy at 2.1 GHz, 0.53 of what the chip gives.
 // Tried and dropped: 8-column chunks double-buffered in LDS (700 us: a row's 64-B segments fetch every 128-B line twice);
 // the operands of step k + 1 read before the fma of step k (no gain).
-__global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* __restrict__ F, const double* __restrict__ r,
-                                                                  uint32_t n, uint32_t d1, uint32_t nt, uint32_t R, uint32_t ld, double* __restrict__ L) {
+__global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* __restrict__ F,
+                                                                  uint32_t n, uint32_t d1, uint32_t nt, uint32_t R, uint32_t ld, double* __restrict__ S) {
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     // the two panels [k][row], rows padded to a 16-B multiple (+ 1 column: the 17-wide tail); ONE array: the output staging
     // below runs over both
@@ -248,20 +248,11 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* 
         }
         if (last17) break;
     }
-    // L tile and (off the diagonal) its mirror, written as whole 512-B rows: the patches go through LDS — half a tile
+    // The S tile and (off the diagonal) its mirror — its transpose; round 5: the r-scaling moved to the greedy kernels — written as whole 512-B rows: the patches go through LDS — half a tile
     // (32 rows) at a time, in the panels' space — so that a store instruction covers one contiguous row of 64 doubles
     // (patch-wise stores are 16-B runs scattered over eight rows: 512 MB of them per 256-request batch)
-    const double* rq = r + (size_t)q * n;
     double* const stage = &panels[0][0][0];                     // 32 x 65 doubles fit the two panels (2 x 17 x 66)
     static_assert(32 * 65 <= 2 * (kDppKc + 1) * (kDppTile + 2), "the output staging aliases the panels");
-    double rjv[8], riv[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const uint32_t j = j0 + 2 * tx + (b & 1) + 16 * (b >> 1);
-        rjv[b] = j < n ? rq[j] : 0.0;
-        const uint32_t i = i0 + 2 * ty + (b & 1) + 16 * (b >> 1);
-        riv[b] = i < n ? rq[i] : 0.0;
-    }
     // (mirror and half as compile-time values: with runtime ones the compiler keeps the accumulators in scratch and forms
     // every product in every pass)
     auto pass = [&](auto mirror_c, auto half_c) {
@@ -276,16 +267,15 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* 
                 const int col_t = 2 * (int)tx + (b & 1) + 16 * (b >> 1);
                 const int orow = mirror ? col_t : row_t, ocol = mirror ? row_t : col_t;
                 if (((mirror ? b : a) >> 2) != half) continue;                  // (orow >> 5: 2 t + (x & 1) < 16)
-                const double v = mirror ? __dmul_rn(__dmul_rn(rjv[b], acc[a][b]), riv[a])
-                                        : __dmul_rn(__dmul_rn(riv[a], acc[a][b]), rjv[b]);
-                stage[(orow & 31) * 65 + ocol] = v;
+                stage[(orow & 31) * 65 + ocol] = acc[a][b];
             }
         __syncthreads();
         const uint32_t r0 = (mirror ? j0 : i0) + 32 * half, c0 = mirror ? i0 : j0;
-        for (int rr2 = 0; rr2 < 32; ++rr2) {
-            const uint32_t gi = r0 + rr2, gj = c0 + lane;
-            if (gi < n && gj < n) __builtin_nontemporal_store(stage[rr2 * 65 + lane], &L[((size_t)q * n + gi) * ld + gj]);   // (streams out: see the matrix-pipe kernel)
-        }
+        const uint32_t rows = r0 < n ? (n - r0 < 32u ? n - r0 : 32u) : 0u;      // (uniform; the column test once per pass)
+        double* const rowp = S + ((size_t)q * n + r0) * ld + c0;                 // (uniform: stores with a scalar base)
+        if (c0 + lane < n)
+            for (uint32_t rr2 = 0; rr2 < rows; ++rr2)
+                __builtin_nontemporal_store(stage[rr2 * 65 + lane], rowp + (size_t)rr2 * ld + lane);   // (streams out: see the matrix-pipe kernel)
     };
     pass(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
     pass(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
@@ -305,17 +295,18 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* 
 // blocks per tile = 0.136 ms of pipe time per 256 x 500 x 129 batch.  A wave owns the 64 x 64 tile as 4 x 4 blocks of 16 x 16:
 // block (a, b), register g, lane l = row 16a + (l >> 4) + 4g, column 16b + (l & 15).  The panels are staged as before, the next
 // chunk's requested before this chunk's instructions; a width that is not a multiple of four ends with zero operands written
-// into the panel (fma(0, 0, acc) = acc: the chain starts at +0 and cannot reach -0).  Epilogue as before: L_ij = (r_i S_ij) r_j
-// and its mirror, as whole rows through LDS.
+// into the panel (fma(0, 0, acc) = acc: the chain starts at +0 and cannot reach -0).  Epilogue: the tile of S and its mirror (its
+// transpose: S is symmetric bit for bit) as whole rows through LDS; L_ij = (r_i S_ij) r_j is formed by the greedy kernels for the
+// diagonal and the rows they pick — a fifth of the matrix — which took 1 024 multiplications per tile out of this epilogue.
 // Measured (profiles/r5_dpp_mfma_summary.txt): 0.343 ms as first built — exactly the vector kernel's time: neither pipe was the
 // bound.  FETCH_SIZE 1.75 GB for 132 MB of F: dpp_tile_of_block (one request's tiles on one XCD) → 135 MB, 0.304 ms; L's 512 MB as
-// non-temporal stores: 0.277 ms (matrix pipe 49 % busy).  What is left is the pairing of two waves per SIMD on one fp64 unit: with
+// non-temporal stores: 0.277 ms (matrix pipe 49 % busy); S instead of L, the stores' tests hoisted: 0.262 ms.  What is left is the pairing of two waves per SIMD on one fp64 unit: with
 // the matrix instructions removed the kernel takes 0.144 ms, with them 0.277 = the sum, not the maximum — a wave's staging and
 // epilogue (≈ 1 700 vector instructions per tile) advance at about one instruction per partner matrix instruction (64 cycles),
 // s_setprio does not change that, and one wave per SIMD (0.37 ms) leaves every load latency exposed.  Not done: a single wave
 // per SIMD that issues its LDS / global traffic between its own matrix instructions (hand-placed, as csrc/recall.hip does).
-__global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_mfma_kernel(const double* __restrict__ F, const double* __restrict__ r,
-                                                                       uint32_t n, uint32_t d1, uint32_t nt, uint32_t R, uint32_t ld, double* __restrict__ L
+__global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_mfma_kernel(const double* __restrict__ F,
+                                                                       uint32_t n, uint32_t d1, uint32_t nt, uint32_t R, uint32_t ld, double* __restrict__ S
 #ifdef DPP_PROFILE
                                                                        , unsigned long long* prof
 #endif
@@ -413,20 +404,8 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_mfma_kernel(const dou
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : DPP_ACCS);   // a 16-pass instruction's results, before anything else reads them
 #undef DPP_ACCS
-    const double* rq = r + (size_t)q * n;
     double* const stage = &panels[0][0][0];                     // 32 x 65 doubles fit the two panels (2 x 17 x 66)
     static_assert(32 * 65 <= 2 * (kDppKc + 1) * (kDppTile + 2), "the output staging aliases the panels");
-    double rjv[4], riv[4][4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const uint32_t j = j0 + 16 * b + kk;
-        rjv[b] = j < n ? rq[j] : 0.0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint32_t i = i0 + 16 * b + rr + 4 * g;
-            riv[b][g] = i < n ? rq[i] : 0.0;
-        }
-    }
     auto pass = [&](auto mirror_c, auto half_c) {
         constexpr int mirror = decltype(mirror_c)::value, half = decltype(half_c)::value;
 #pragma unroll
@@ -438,21 +417,20 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_mfma_kernel(const dou
                 for (int g = 0; g < 4; ++g) {
                     const int row_t = 16 * a + (int)rr + 4 * g, col_t = 16 * b + (int)kk;
                     const int orow = mirror ? col_t : row_t, ocol = mirror ? row_t : col_t;
-                    const double v = mirror ? __dmul_rn(__dmul_rn(rjv[b], acc[a][b][g]), riv[a][g])
-                                            : __dmul_rn(__dmul_rn(riv[a][g], acc[a][b][g]), rjv[b]);
-                    stage[(orow & 31) * 65 + ocol] = v;
+                    stage[(orow & 31) * 65 + ocol] = acc[a][b][g];
                 }
             }
         const uint32_t r0 = (mirror ? j0 : i0) + 32 * half, c0 = mirror ? i0 : j0;
-        for (int rr2 = 0; rr2 < 32; ++rr2) {
-            const uint32_t gi = r0 + rr2, gj = c0 + lane;
+        const uint32_t rows = r0 < n ? (n - r0 < 32u ? n - r0 : 32u) : 0u;      // (uniform; the column test once per pass)
+        double* const rowp = S + ((size_t)q * n + r0) * ld + c0;                 // (uniform: stores with a scalar base)
 #if DPP_ABL == 1
-            if (gi < n && gj < n && stage[rr2 * 65 + lane] == 1.2345e300) L[((size_t)q * n + gi) * ld + gj] = stage[rr2 * 65 + lane];
+        if (c0 + lane < n && stage[lane] == 1.2345e300)
 #else
-            // (non-temporal: 2 MB of L per request stream out once; as ordinary stores they pass through the L2 the tiles' F rows live in)
-            if (gi < n && gj < n) __builtin_nontemporal_store(stage[rr2 * 65 + lane], &L[((size_t)q * n + gi) * ld + gj]);
+        if (c0 + lane < n)
 #endif
-        }
+            for (uint32_t rr2 = 0; rr2 < rows; ++rr2)
+                // (non-temporal: 2 MB per request stream out once; as ordinary stores they pass through the L2 the tiles' F rows live in)
+                __builtin_nontemporal_store(stage[rr2 * 65 + lane], rowp + (size_t)rr2 * ld + lane);
     };
     pass(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
     pass(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
@@ -466,6 +444,15 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_mfma_kernel(const dou
         for (int i = 0; i < 5; ++i) atomicAdd(&prof[i], (unsigned long long)ph[i]);
 #endif
 #undef DPP_MARK
+}
+
+// L_ij = (r_i S_ij) r_j for the whole matrix (pg_dpp_kernel_matrix_dev; the greedy kernels form the elements they read themselves)
+__global__ void dpp_scale_kernel(const double* __restrict__ S, const double* __restrict__ r, uint32_t n, uint32_t ld,
+                                 double* __restrict__ L) {
+    const uint32_t j = blockIdx.x * 64u + threadIdx.x, i = blockIdx.y, q = blockIdx.z;
+    if (j >= n) return;
+    const double* rq = r + (size_t)q * n;
+    L[((size_t)q * n + i) * n + j] = __dmul_rn(__dmul_rn(rq[i], S[((size_t)q * n + i) * ld + j]), rq[j]);
 }
 
 // floats.MaxIdx: first maximum, NaN skipped; all-NaN → index 0.  Block-wide, result in *s_idx.
@@ -502,13 +489,16 @@ __device__ __forceinline__ void block_argmax(const double* __restrict__ v, uint3
 // DPPWithWindow + DPP (dpp_sort.go:477-551), one workgroup.
 //   d2: [n], c: [window][n] scratch in global memory (L2-resident), Y: output indices.
 //   One workgroup per request (blockIdx.x): L, d2, c, out are that request's slices.
-__global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restrict__ L_all, uint32_t N, uint32_t ld,
+__global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restrict__ S_all, const double* __restrict__ r_all, uint32_t N, uint32_t ld,
                                                           uint32_t topn_total, uint32_t window,
                                                           double* __restrict__ d2_all, double* __restrict__ c_all,
                                                           uint32_t* __restrict__ out_all, uint32_t* __restrict__ out_count) {
     const uint32_t req = blockIdx.x;
     const uint32_t wrows = window < N ? window : N;
-    const double* __restrict__ L = L_all + (size_t)req * N * ld;          // rows of ld doubles (dpp_run_locked)
+    const double* __restrict__ S = S_all + (size_t)req * N * ld;          // rows of ld doubles (dpp_run_locked)
+    const double* __restrict__ r = r_all + (size_t)req * N;
+    // L_ij = (r_i S_ij) r_j (dpp_sort.go:463-472), formed where an element is read: the kernel matrix stores S
+    auto L_at = [&](uint32_t i, uint32_t j) { return __dmul_rn(__dmul_rn(r[i], S[(size_t)i * ld + j]), r[j]); };
     double* __restrict__ d2 = d2_all + (size_t)req * N;
     double* __restrict__ c = c_all + (size_t)req * wrows * N;
     uint32_t* __restrict__ out = out_all + (size_t)req * topn_total;
@@ -533,7 +523,7 @@ __global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restri
         for (uint32_t i = tid; i < N; i += blockDim.x) {
             bool ex = false;
             for (uint32_t e = 0; e < existed; ++e) ex |= (out[e] == i);
-            d2[i] = ex ? nan : L[(size_t)i * ld + i];
+            d2[i] = ex ? nan : L_at(i, i);
         }
         __syncthreads();
         block_argmax(d2, N, s_val, s_idx, &s_j);
@@ -550,7 +540,7 @@ __global__ __launch_bounds__(1024) void dpp_greedy_kernel(const double* __restri
             const uint32_t k = ny - 1;
             const double inv = 1.0 / dj;
             for (uint32_t n = tid; n < N; n += blockDim.x) {
-                double lj = L[(size_t)j * ld + n];
+                double lj = L_at(j, n);
                 if (k > 0) {
                     double ss = 0.0;
                     for (uint32_t i = 0; i < k; ++i)
@@ -605,17 +595,26 @@ __device__ __forceinline__ void dpp_static_for(F&& f) {
 }
 
 template <int EPL, int WMAX>
-__global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __restrict__ L_all, uint32_t N, uint32_t ld,
+__global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __restrict__ S_all, const double* __restrict__ r_all, uint32_t N, uint32_t ld,
                                                              uint32_t topn_total, uint32_t window,
                                                              uint32_t* __restrict__ out_all, uint32_t* __restrict__ out_count) {
     extern __shared__ double c_lds[];                   // [min(window, WMAX)][EPL * 64]
     constexpr uint32_t NS = EPL * 64;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     const uint32_t req = blockIdx.x, lane = threadIdx.x;
-    const double* __restrict__ L = L_all + (size_t)req * N * ld;          // rows of ld doubles (dpp_run_locked)
+    const double* __restrict__ S = S_all + (size_t)req * N * ld;          // rows of ld doubles (dpp_run_locked)
+    const double* __restrict__ r = r_all + (size_t)req * N;
     uint32_t* __restrict__ out = out_all + (size_t)req * topn_total;
     const double epsilon = 1e-10;
     const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    // L_ij = (r_i S_ij) r_j (dpp_sort.go:463-472), formed where an element is read — the diagonal and the picked rows, a fifth of
+    // the matrix: the kernel matrix stores S, and its epilogue lost the 4 multiplications per element pair
+    double rn[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const uint32_t n = (uint32_t)s * 64u + lane;
+        rn[s] = n < N ? r[n] : 0.0;
+    }
     double c[EPL][WMAX];
     double d2[EPL];
     bool sel[EPL];
@@ -648,10 +647,19 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
         uint32_t topn = (topn_total <= window) ? topn_total : (call < n_calls ? window : rem);
         if (topn > N) topn = N;
         if (topn == 0) continue;
+        {
+            double sv[EPL];                                     // (every load first, unconditionally: a select per element made the
+#pragma unroll                                                  //  compiler branch around each load and wait for them one by one)
+            for (int s = 0; s < EPL; ++s) {
+                const uint32_t n = (uint32_t)s * 64u + lane, nc = n < N ? n : 0u;
+                sv[s] = S[(size_t)nc * ld + nc];
+            }
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) {
-            const uint32_t n = (uint32_t)s * 64u + lane;
-            d2[s] = (n < N && !sel[s]) ? L[(size_t)n * ld + n] : nan;       // already selected (and the padding): NaN
+            for (int s = 0; s < EPL; ++s) {
+                const uint32_t n = (uint32_t)s * 64u + lane;
+                const double l = __dmul_rn(__dmul_rn(rn[s], sv[s]), rn[s]);
+                d2[s] = (n < N && !sel[s]) ? l : nan;           // already selected (and the padding): NaN
+            }
         }
         uint32_t j;
         double dj;
@@ -669,10 +677,20 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
             if (dj < epsilon) { broke = true; stop = true; return; }
             const double inv = 1.0 / sqrt(dj);
             double lv[EPL];
+            double rsel = rn[0];                                 // r[j] from the lane that holds it (j is wave-uniform): no load in the pick's chain
+#pragma unroll
+            for (int s = 1; s < EPL; ++s) rsel = (j >> 6) == (uint32_t)s ? rn[s] : rsel;
+            const double rj = __shfl(rsel, (int)(j & 63u), 64);
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) {                      // (the row's loads first, all of them: see above)
+                const uint32_t n = (uint32_t)s * 64u + lane;
+                lv[s] = S[(size_t)j * ld + (n < N ? n : 0u)];
+            }
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 const uint32_t n = (uint32_t)s * 64u + lane;
-                lv[s] = n < N ? L[(size_t)j * ld + n] : 0.0;
+                const double l = __dmul_rn(__dmul_rn(rj, lv[s]), rn[s]);
+                lv[s] = n < N ? l : 0.0;
             }
             double cj[WMAX];
 #pragma unroll
@@ -757,13 +775,13 @@ int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, cons
     else dpp_prepare_kernel<<<dim3((n + 63) / 64, R), 64, 0, ctx->stream>>>(a);
     const uint32_t nt = (n + kDppTile - 1) / kDppTile;
     const uint32_t km_blocks = nt * (nt + 1) / 2 * ((R + 7u) / 8u) * 8u;       // (dpp_tile_of_block)
-    if (ctx->knobs.dpp_valu) dpp_kernel_matrix_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, Rr, n, d1, nt, R, ld, L);
+    if (ctx->knobs.dpp_valu) dpp_kernel_matrix_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, n, d1, nt, R, ld, L);
 #ifdef DPP_PROFILE
     else {
         static unsigned long long* prof = nullptr;
         if (!prof) hipMalloc(&prof, 5 * 8);
         hipMemsetAsync(prof, 0, 5 * 8, ctx->stream);
-        dpp_kernel_matrix_mfma_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, Rr, n, d1, nt, R, ld, L, prof);
+        dpp_kernel_matrix_mfma_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, n, d1, nt, R, ld, L, prof);
         unsigned long long h[5];
         hipStreamSynchronize(ctx->stream);
         hipMemcpy(h, prof, sizeof h, hipMemcpyDeviceToHost);
@@ -775,24 +793,24 @@ int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, cons
         }
     }
 #else
-    else dpp_kernel_matrix_mfma_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, Rr, n, d1, nt, R, ld, L);
+    else dpp_kernel_matrix_mfma_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, n, d1, nt, R, ld, L);
 #endif
     if (d_L_out) {                                              // KernelMatrix alone (pg_dpp_kernel_matrix_dev)
         PG_HIP(hipGetLastError());
-        PG_HIP(hipMemcpy2DAsync(d_L_out, (size_t)n * 8, L, (size_t)ld * 8, (size_t)n * 8, (size_t)R * n, hipMemcpyDeviceToDevice, ctx->stream));
+        dpp_scale_kernel<<<dim3((n + 63) / 64, n, R), 64, 0, ctx->stream>>>(L, Rr, n, ld, d_L_out);
         return PG_OK;
     }
     const uint32_t wrows = window < n ? window : n;
     if (n <= 512 && window <= 16) {
         const size_t lds = (size_t)wrows * 512 * 8;
         if ((rc = ensure_dyn_lds(ctx, (const void*)dpp_greedy_wave_kernel<8, 16>, lds))) return rc;
-        dpp_greedy_wave_kernel<8, 16><<<R, 64, lds, ctx->stream>>>(L, n, ld, topn, window, d_out, d_out_count);
+        dpp_greedy_wave_kernel<8, 16><<<R, 64, lds, ctx->stream>>>(L, Rr, n, ld, topn, window, d_out, d_out_count);
     } else if (n <= 1024 && window <= 10) {
         const size_t lds = (size_t)wrows * 1024 * 8;
         if ((rc = ensure_dyn_lds(ctx, (const void*)dpp_greedy_wave_kernel<16, 10>, lds))) return rc;
-        dpp_greedy_wave_kernel<16, 10><<<R, 64, lds, ctx->stream>>>(L, n, ld, topn, window, d_out, d_out_count);
+        dpp_greedy_wave_kernel<16, 10><<<R, 64, lds, ctx->stream>>>(L, Rr, n, ld, topn, window, d_out, d_out_count);
     } else {
-        dpp_greedy_kernel<<<R, 1024, 0, ctx->stream>>>(L, n, ld, topn, window, D2, Cm, d_out, d_out_count);
+        dpp_greedy_kernel<<<R, 1024, 0, ctx->stream>>>(L, Rr, n, ld, topn, window, D2, Cm, d_out, d_out_count);
     }
     PG_HIP(hipGetLastError());
     return PG_OK;

@@ -42,7 +42,7 @@ while time.time() < t_end:
     t = pa.Table(ctx, n_tab, d)
     t.upload(tab)
     for _ in range(12):
-        n = int(rng.choice([2, 5, 17, 100, 500, 1500]))
+        n = int(rng.choice([2, 5, 17, 100, 500, 800, 1500]))
         cand = rng.choice(n_tab, n, replace=n > n_tab // 2).astype(np.uint32)
         dups = bool(n >= 5 and rng.random() < 0.4)            # exact duplicates among the candidates
         if dups:

@@ -1136,6 +1136,12 @@ def test_dpp_matches_oracle(ctx):
         got = pa.dpp(ctx, t, cand, rel, 1.0, topn, window, True)
         assert np.array_equal(got, want), (topn, window)
     assert not np.array_equal(pa.dpp(ctx, t, cand, rel, 1.0, 100, 10, True), np.arange(100))
+    # the other greedy kernels: 512 < n <= 1024 (sixteen elements per lane), and beyond it / wider windows (one workgroup)
+    for n2, topn, window in ((800, 60, 10), (1024, 30, 7), (1100, 40, 10), (600, 40, 20)):
+        cand2 = rng.choice(n_tab, n2, replace=False).astype(np.uint32)
+        rel2 = np.sort(rng.random(n2))[::-1].copy()
+        L2 = o.dpp_kernel_matrix(o.l2_normalize_f64(tab[cand2].astype(np.float64)), rel2, 1.0)
+        assert np.array_equal(pa.dpp(ctx, t, cand2, rel2, 1.0, topn, window, True), o.dpp_with_window(L2, topn, window)), (n2, topn, window)
     t.destroy()
 
 
