@@ -93,8 +93,7 @@ template <int D>
 __global__ __launch_bounds__(64) void dpp_prepare_table_kernel(DppPrep a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t q = blockIdx.y;
-    if (i >= a.n) return;
-    const size_t item = (size_t)q * a.n + i;
+    const size_t item = (size_t)q * a.n + (i < a.n ? i : a.n - 1);          // (lanes past the request's rows compute its last row again: every lane takes part in the LDS exchange below)
     const float4* x4 = reinterpret_cast<const float4*>(a.emb32 + item * D);
     double v[D];
 #pragma unroll
@@ -114,11 +113,28 @@ __global__ __launch_bounds__(64) void dpp_prepare_table_kernel(DppPrep a) {
         for (int k = 0; k < D; ++k) v[k] = inv * v[k];
     }
     const double isq2 = 0.70710678118654757;
-    double* f = a.F + item * (D + 1);
+    // F rows leave as whole 128-byte runs: the wave's 64 rows x 16 columns go through LDS, and a store instruction then covers
+    // four rows x 16 columns (one lane per row wrote 8 bytes into 64 different lines per instruction: 129 x 64 line accesses per
+    // wave — the kernel's 0.09 ms for 256 x 500 rows).  A wave is a workgroup: LDS operations execute in program order.
+    __shared__ double tile[64][17];
+    const uint32_t lane = threadIdx.x, kk = lane & 15, rr = lane >> 4;
+    const size_t row0 = (size_t)q * a.n + (size_t)blockIdx.x * 64;           // the wave's first row (of this request)
+    const uint32_t rows = a.n - blockIdx.x * 64 < 64u ? a.n - blockIdx.x * 64 : 64u;
+    double* const Fw = a.F + row0 * (D + 1);
 #pragma unroll
-    for (int k = 0; k < D; ++k) f[k] = isq2 * v[k];
-    f[D] = isq2 * 1.0;
-    a.r[item] = exp(a.alpha * a.rel[item]);
+    for (int c = 0; c < D / 16; ++c) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tile[lane][k] = isq2 * v[16 * c + k];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const uint32_t row = (uint32_t)it * 4 + rr;
+            if (row < rows) Fw[(size_t)row * (D + 1) + 16 * c + kk] = tile[row][kk];
+        }
+    }
+    if (i < a.n) {
+        a.F[item * (D + 1) + D] = isq2 * 1.0;
+        a.r[item] = exp(a.alpha * a.rel[item]);
+    }
 }
 
 // S = F F^T (round 5: the scaling L = diag(r) S diag(r) is applied where the greedy kernels read) for one request: a 64 x 64 tile per workgroup, the two 64-row
