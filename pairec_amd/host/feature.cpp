@@ -69,6 +69,12 @@ static std::string go_format_f(double x) {
     return sign + "0." + std::string((size_t)(-dexp - 1), '0') + digits;
 }
 
+// Go's int(float64) on amd64 (cvttsd2si): truncation; NaN and values outside int64 give the "integer indefinite" 0x8000000000000000
+static long long f2i(double d) {
+    if (!(d > -9223372036854775808.0 && d < 9223372036854775808.0)) return (long long)0x8000000000000000ull;
+    return (long long)d;
+}
+
 // utils.ToString (utils/type.go:120-141)
 static std::string to_string(const V& v, const std::string& def) {
     if (v.type == V::String) return v.str;
@@ -80,7 +86,7 @@ static std::string to_string(const V& v, const std::string& def) {
 }
 // utils.ToInt (utils/type.go:11-42)
 static long long to_int(const V& v, long long def) {
-    if (v.type == V::Number) return v.is_int ? v.i : (long long)v.num;
+    if (v.type == V::Number) return v.is_int ? v.i : f2i(v.num);
     if (v.type == V::String) {
         char* e = nullptr;
         const long long r = strtoll(v.str.c_str(), &e, 10);
@@ -1016,7 +1022,7 @@ struct Eval {
                 }
                 if (!is_num(v)) return fail("Value '" + sprint_v(v) + "' cannot be used with the numeric prefix '" + n->op + "', it is not a number");
                 if (n->op == "+") { *out = v; return true; }
-                *out = (d == Dialect::ExprLang && v.is_int) ? Int(-v.i) : Float(-v.num);
+                *out = (d == Dialect::ExprLang && v.is_int) ? Int((long long)(0ull - (unsigned long long)v.i)) : Float(-v.num);
                 return true;
             }
             case Node::Ternary: {
@@ -1042,7 +1048,7 @@ struct Eval {
         if (a.size() != 1) return fail("invalid number of arguments for " + name + " (expected 1, got " + std::to_string(a.size()) + ")");
         const V& x = a[0];
         if (name == "int") {
-            if (is_num(x)) { *out = Int(x.is_int ? x.i : (long long)x.num); return true; }
+            if (is_num(x)) { *out = Int(x.is_int ? x.i : f2i(x.num)); return true; }
             if (is_str(x)) {
                 char* e = nullptr;
                 const long long r = strtoll(x.str.c_str(), &e, 10);
@@ -1072,7 +1078,7 @@ struct Eval {
         }
         if (name == "abs") {
             if (!is_num(x)) return fail("invalid argument for abs");
-            *out = x.is_int ? Int(x.i < 0 ? -x.i : x.i) : Float(std::fabs(x.num));
+            *out = x.is_int ? Int(x.i < 0 ? (long long)(0ull - (unsigned long long)x.i) : x.i) : Float(std::fabs(x.num));
             return true;
         }
         return fail("unknown function '" + name + "'");
@@ -1267,7 +1273,7 @@ std::string ItemStringProperty(const module::Item& it, const std::string& key) {
     if (p == it.Properties.end()) return "";
     const V& v = p->second;
     if (v.type == V::String) return v.str;
-    if (v.type == V::Number && !v.is_u64) return std::to_string(v.is_int ? v.i : (long long)v.num);   // float64: strconv.Itoa(int(value))
+    if (v.type == V::Number && !v.is_u64) return std::to_string(v.is_int ? v.i : f2i(v.num));   // float64: strconv.Itoa(int(value))
     return "";
 }
 std::string UserStringProperty(const module::User& u, const std::string& key) {           // user.go:168-189
