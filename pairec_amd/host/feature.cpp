@@ -406,6 +406,7 @@ bool CallFunction(const std::string& name, const std::vector<V>& a, V* out, std:
         if (n < 2) return fail("args must have lat and lng params");
         const long long level = n > 2 ? to_int(a[2], 15) : 15;
         if (level < 0 || level > 30) return fail("level must be 0..30");
+        if (!std::isfinite(f(0)) || !std::isfinite(f(1))) return fail("lat / lng must be finite");
         *out = Int((long long)s2_cell_id(f(0), f(1), (int)level));
         return true;
     }
