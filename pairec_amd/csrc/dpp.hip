@@ -13,6 +13,7 @@
 // the greedy update uses separate multiply and add, sequential over earlier picks, exactly as
 // gonum's Dgemm-by-axpy does on amd64, and is bit-identical to oracle/oracle.c given the same L.
 #include "pipeline.hpp"
+#include "bitonic_reg.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -636,26 +637,47 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
     bool sel[EPL];
 #pragma unroll
     for (int s = 0; s < EPL; ++s) sel[s] = false;
-    // floats.MaxIdx over d2: first maximum, NaN skipped, nothing left → index 0; returns d2[j] as well
+    // floats.MaxIdx over d2: first maximum, NaN skipped, nothing left → index 0; returns d2[j] as well.  The reduction is in every
+    // pick's dependent chain (round 5 profile build: 1 750 of a pick's 5 500 cycles as a butterfly over (value, index) pairs), so
+    // it is split: the wave's maximum VALUE (v_max_f64 passes over NaN) through six lane exchanges, then the first index that
+    // holds it from one ballot per element slot — scalar work.  Both results are made wave-uniform registers: the window's
+    // `stop` / `broke` tests then compile to scalar branches instead of exec-mask bookkeeping around every unrolled pick.
     auto argmax = [&](uint32_t& j, double& dj) {
-        double best = 0.0;
-        uint32_t bi = kNone;
+        double m = d2[0];
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) {
-            const double x = d2[s];
-            if (x == x && (bi == kNone || x > best)) { best = x; bi = (uint32_t)s * 64u + lane; }
-        }
+        for (int s = 1; s < EPL; ++s) m = fmax(m, d2[s]);
+        dpp_static_for<0, 6>([&](auto sc) {
+            constexpr int off = 1 << decltype(sc)::value;
+            const uint64_t bb = (uint64_t)__double_as_longlong(m);
+            const uint32_t lo = lane_xor<off>((uint32_t)bb), hi = lane_xor<off>((uint32_t)(bb >> 32));
+            m = fmax(m, __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)));
+        });
+        auto uniform = [](double x) {
+            const uint64_t b = (uint64_t)__double_as_longlong(x);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+            return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        };
+        m = uniform(m);
+        uint32_t found = kNone;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double ov = __shfl_xor(best, off, 64);
-            const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
-            if (oi != kNone && (bi == kNone || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+        for (int s = EPL - 1; s >= 0; --s) {                    // (descending: the lowest slot that holds the maximum is assigned last)
+            const uint64_t b = __builtin_amdgcn_ballot_w64(d2[s] == m);
+            if (b) found = (uint32_t)s * 64u + (uint32_t)__builtin_ctzll(b);
         }
-        const double first = __shfl(d2[0], 0, 64);
-        j = bi == kNone ? 0u : bi;
-        dj = bi == kNone ? first : best;
+        if (found == kNone) {                                   // nothing but NaN
+            j = 0u;
+            dj = uniform(d2[0]);                                // (lane 0's: element 0)
+        } else {
+            j = found;
+            dj = m;
+        }
     };
     uint32_t done = 0;
+#ifdef DPP_PROFILE
+    uint64_t prof_wait = 0, prof_picks = 0, prof_arg = 0, prof_upd = 0;
+    const uint64_t prof_t0 = __builtin_readcyclecounter();
+    uint64_t prof_mark = prof_t0;
+#endif
     uint32_t n_calls, rem;
     if (topn_total <= window) { n_calls = 1; rem = 0; }
     else { n_calls = topn_total / window; rem = topn_total % window; }
@@ -702,6 +724,14 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
                 const uint32_t n = (uint32_t)s * 64u + lane;
                 lv[s] = S[(size_t)j * ld + (n < N ? n : 0u)];
             }
+#ifdef DPP_PROFILE
+            {                                                    // cycles from the row's requests to its arrival
+                const uint64_t t0 = __builtin_readcyclecounter();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                prof_wait += __builtin_readcyclecounter() - t0;
+                ++prof_picks;
+            }
+#endif
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 const uint32_t n = (uint32_t)s * 64u + lane;
@@ -727,7 +757,16 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
                 if ((uint32_t)s * 64u + lane == j) d2[s] = nan;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: orders the LDS column copy for the later picks
+#ifdef DPP_PROFILE
+            const uint64_t ta0 = __builtin_readcyclecounter();
+            prof_upd += ta0 - prof_mark;
+#endif
             argmax(j, dj);
+#ifdef DPP_PROFILE
+            asm volatile("" : "+v"(dj));
+            prof_mark = __builtin_readcyclecounter();
+            prof_arg += prof_mark - ta0;
+#endif
             if (lane == 0) out[done + ny] = j;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) sel[s] = sel[s] || ((uint32_t)s * 64u + lane == j);
@@ -752,6 +791,12 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
         done += ny;
     }
     if (lane == 0) out_count[req] = done;
+#ifdef DPP_PROFILE
+    if (lane == 0 && req == 3)
+        printf("dpp greedy (request 3): %llu picks, %llu ticks in all, %llu waiting for the picked rows, %llu in the argmax, %llu from one argmax to the next (row wait included)\n",
+               (unsigned long long)prof_picks, (unsigned long long)(__builtin_readcyclecounter() - prof_t0), (unsigned long long)prof_wait,
+               (unsigned long long)prof_arg, (unsigned long long)prof_upd);
+#endif
 }
 
 // DPP for R independent requests of n candidates each, device-resident: d_emb32 [R][n][d] fp32 (NULL on the

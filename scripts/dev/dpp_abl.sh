@@ -1,4 +1,7 @@
+#!/bin/bash
+# developer aid: kernel times of the DPP stage with an ablation build (make -C pairec_amd/csrc DPP_EXTRA=-DDPP_ABL=n → libpairec_gpu_dev.so):
+# 1 no stores of S, 2 no matrix instructions, 4 the greedy kernel reads a row that does not depend on its pick (wrong results by design)
 cd /tmp && export TMPDIR=/tmp
-for v in abl1 abl2; do
-  PG_LIB_PATH=$GRAFT_REPO_ROOT/pairec_amd/libpairec_gpu_$v.so rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/dpp_$v -o t -- python3 $GRAFT_REPO_ROOT/scripts/dev/dpp_batch.py > /dev/null 2>&1
-done
+R=$GRAFT_REPO_ROOT
+PG_LIB_VARIANT=dev rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/dpp_abl -o t -- python3 $R/scripts/dev/dpp_batch.py > $R/gpurun_out/dpp_abl.log 2>&1
+grep -a "dpp_" $R/gpurun_out/dpp_abl/t_kernel_stats.csv | cut -d, -f1-4 | cut -c1-140
