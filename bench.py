@@ -625,7 +625,7 @@ RANK_SHAPES = ((128, 128), (256, 128), (256, 256), (512, 256), (1024, 512))
 def rank_shapes_leg(pa, o, ctx, table, R, K):
     """The DNN3 rank stage ALONE (tile table + request partial + MLP kernel), bf16, per hidden shape: R requests x K
     random candidate rows of the resident table, nothing else on the device — the kernel's own duration, which the
-    pipelined headline loop cannot show (there a rank kernel shares the CUs with the other context's scan).  FLOP are
+    pipelined headline loop cannot show (there a rank kernel runs right behind a scan, at the clock the power cap leaves).  FLOP are
     SURVEY.md 8(d)'s 2*(256*h1 + h1*h2 + h2) per item; mfma_busy comes from the committed PMC pass when there is one."""
     n = table.rows
     rng = np.random.default_rng(5)
@@ -1710,8 +1710,9 @@ def main():
                                             "%d x %d random candidate rows of the resident table" % (R, K),
                                 "mfma_busy_from_profile": bs["mfma_busy_from_profile"],
                                 "in_pipeline": {"ms": st.last_rank_ms, "frac": in_pipe["frac"] if in_pipe else None,
-                                                "note": "HIP events around the stage inside the headline loop, where it "
-                                                        "shares the CUs with the other context's scan kernel"}}
+                                                "note": "HIP events around the stage inside the headline loop, i.e. right behind the scan: the "
+                                                        "clock the power cap leaves (--contexts 1 gives the same time, so it is not the "
+                                                        "other context's scan kernel beside it)"}}
 
     if solo and args.prec == "bf16" and not args.no_f32_leg:
         # the headline again at PG_PREC_F32 — the mode that meets north_star's 1e-5 unconditionally — and what separates the modes
