@@ -150,12 +150,28 @@ __global__ __launch_bounds__(64) void dpp_prepare_table_kernel(DppPrep a) {
 // 0.35 with the arithmetic removed (round 5 ablation, DPP_ABL).  Here XCD x serves requests x, x + 8, …, all tile pairs of one
 // request on consecutive workgroups of that XCD: a request's F (516 KB at 500 x 129) is fetched once and stays in the 4 MB L2
 // while its tiles run.  (Placement is a speed assumption only: any other assignment of workgroups to XCDs computes the same.)
+// Requests beyond the last full round of eight (and a batch of fewer than eight — one request of pg_dpp) are not left to one XCD
+// each with the others idle: XCD x takes request x mod rem of that round and every ways-th tile pair of it, ways = the number of
+// XCDs that share the request.
 __device__ __forceinline__ bool dpp_tile_of_block(uint32_t nt, uint32_t R, uint32_t* q, uint32_t* p) {
     const uint32_t pairs = nt * (nt + 1) / 2, b = blockIdx.x;
     const uint32_t xcd = b & 7u, slot = b >> 3;
-    *q = xcd + 8u * (slot / pairs);
-    *p = slot % pairs;
-    return *q < R;
+    const uint32_t full = R >> 3, rem = R & 7u, slots_full = full * pairs;
+    if (slot < slots_full) {
+        *q = xcd + 8u * (slot / pairs);
+        *p = slot % pairs;
+        return true;
+    }
+    if (rem == 0) return false;
+    const uint32_t qq = xcd % rem, part = xcd / rem, ways = (8u - qq + rem - 1u) / rem;
+    *q = 8u * full + qq;
+    *p = part + ways * (slot - slots_full);
+    return *p < pairs;
+}
+__host__ inline uint32_t dpp_km_blocks(uint32_t nt, uint32_t R) {
+    const uint32_t pairs = nt * (nt + 1) / 2, full = R >> 3, rem = R & 7u;
+    const uint32_t slots = full * pairs + (rem ? (pairs + 8u / rem - 1u) / (8u / rem) : 0u);     // (the request with the fewest XCDs: floor(8 / rem))
+    return slots * 8u;
 }
 
 constexpr int kDppTile = 64, kDppKc = 16;
@@ -835,7 +851,7 @@ int dpp_run_locked(pg_ctx* ctx, const float* d_emb32, const double* d_hook, cons
     else if (has_table && hook_dim == 0 && d == 64) dpp_prepare_table_kernel<64><<<dim3((n + 63) / 64, R), 64, 0, ctx->stream>>>(a);
     else dpp_prepare_kernel<<<dim3((n + 63) / 64, R), 64, 0, ctx->stream>>>(a);
     const uint32_t nt = (n + kDppTile - 1) / kDppTile;
-    const uint32_t km_blocks = nt * (nt + 1) / 2 * ((R + 7u) / 8u) * 8u;       // (dpp_tile_of_block)
+    const uint32_t km_blocks = dpp_km_blocks(nt, R);                            // (dpp_tile_of_block)
     if (ctx->knobs.dpp_valu) dpp_kernel_matrix_kernel<<<km_blocks, 64, 0, ctx->stream>>>(F, n, d1, nt, R, ld, L);
 #ifdef DPP_PROFILE
     else {

@@ -1154,7 +1154,8 @@ def test_dpp_kernel_matrix_bits_on_both_pipes(ctx):
     from pairec_amd import _lib
     rng = np.random.default_rng(21)
     cases = [(3, 500, 128, True), (2, 64, 128, True), (2, 65, 64, True), (1, 1, 128, True), (2, 129, 16, False), (1, 200, 20, False),
-             (2, 63, 3, True), (1, 333, 130, False), (1, 512, 128, True), (1, 100, 15, False), (1, 70, 33, True)]
+             (2, 63, 3, True), (1, 333, 130, False), (1, 512, 128, True), (1, 100, 15, False), (1, 70, 33, True),
+             (9, 70, 16, True), (17, 130, 8, False), (8, 65, 4, True)]        # full rounds of eight requests + a partial one (the XCD placement)
     for R, n, d, norm in cases:
         emb = rng.standard_normal((R, n, d)).astype(np.float32)
         emb *= np.exp2(rng.integers(-12, 13, (R, n, d))).astype(np.float32)          # products of very different magnitudes
