@@ -345,6 +345,14 @@ int pg_features_gather_f32_dev(pg_ctx* ctx, const pg_features* fs, const int32_t
                                const float* scale, const float* bias, const uint32_t* d_rows, uint32_t n,
                                float* d_out);
 
+/* d_out[i] = the expression with every variable bound to the feature column of that name at d_rows[i] (the column default for a row
+ * outside the store), evaluated in fp64 on the device — the numeric `expression` normalizer of a new_feature over item features
+ * (service/feature/new_feature_op.go:54-115 with an ExpressionNormalizer, normalizer.go:112-138; service/feature/feature.go:73-78 walks
+ * the items one by one) for a candidate batch, without boxing a map per item.  `e`: pg_expr_compile (pairec's default grammar, `${col}`)
+ * or pg_expr_compile_typed(…, "antlr") for the arithmetic subset; at most 16 variables, each of which must be a column (PG_ERR_INVALID
+ * names the first that is not); PG_ERR_ARITH as pg_expr_eval_dev. */
+int pg_features_eval_dev(pg_ctx* ctx, const pg_features* fs, const pg_expr* e, const uint32_t* d_rows, uint32_t n, double* d_out);
+
 /* A Hologres vector recall with its WhereClause (HologresVectorConf.WhereClause, recconf.go:492-497; hologres_vector_recall.go:
  * 23,49-62 and _v2.go:23,56-61: "FROM table WHERE … ORDER BY distance LIMIT n"), in the shape the device serves: `column OP
  * constant` over an int32 / int64 feature column keyed by item row ("create_time > ${time}" with the constant substituted by the

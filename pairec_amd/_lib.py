@@ -37,7 +37,7 @@ EXPORTS = [
     "pg_fm2t_item_rows_build", "pg_fm2t_item_rows_update", "pg_fm2t_item_rows_destroy", "pg_rank_fm2t_irows_dev",
     "pg_rank_fm2t_irows",
     "pg_topk_merge_lists_dev", "pg_owned_compact_dev", "pg_scatter_f32_dev", "pg_dpp_candidates_dev",
-    "pg_gather_owned_rows_dev", "pg_dpp_batch_dev", "pg_dpp_kernel_matrix_dev",
+    "pg_gather_owned_rows_dev", "pg_dpp_batch_dev", "pg_dpp_kernel_matrix_dev", "pg_features_eval_dev",
     "pg_group_create", "pg_group_destroy", "pg_group_size", "pg_group_ctx", "pg_group_table", "pg_group_table_create",
     "pg_group_table_fill_synthetic", "pg_group_table_upload", "pg_group_model_load", "pg_group_recommend",
     "pg_group_recommend_begin", "pg_group_recommend_end", "pg_group_info", "pg_coalescer_create_group",
@@ -197,6 +197,7 @@ def load():
         "pg_gather_owned_rows_dev": [vp, vp, vp, u32, vp],
         "pg_dpp_batch_dev": [vp, vp, vp, u32, u32, u32, C.c_double, u32, u32, i32, vp, vp],
         "pg_dpp_kernel_matrix_dev": [vp, vp, vp, u32, u32, u32, C.c_double, i32, vp],
+        "pg_features_eval_dev": [vp, vp, vp, vp, u32, vp],
         "pg_group_create": [P(C.c_int), u32, P(vp)],
         "pg_group_destroy": [vp],
         "pg_group_table_create": [vp, u64, u32],

@@ -212,7 +212,8 @@ struct pg_ctx {
     //   6 rank tile table + request partials   7 sort / dpp / ssd work areas   8 recommend pipeline intermediates (post_scratch)
     //   9 group.hip   10 re-rank stage (DPP candidates)   11 recall.hip: the screened pass's record regions
     //   12, 13 recall.hip   14 rank_mlp.hip: head partials of the weights-stationary multi-head kernel   15 pg_fuse_scores_dev
-    pg::Scratch scratch[16];
+    //   16 pg_features_eval_dev: the bound variables
+    pg::Scratch scratch[17];
     std::mutex pool_mu;          // guards pipe_free
     std::vector<pg::PipeRun*> pipe_free;     // per-batch status blocks / events of the device-resident pipelines
     std::map<const void*, size_t> dyn_lds;   // kernels whose dynamic-LDS limit was raised on this device

@@ -428,9 +428,71 @@ static int expr_eval_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars,
     return PG_OK;
 }
 
+// ---- an expression over feature columns (pg_features_eval_dev) ----------------------------------------------------
+// vars[v][i] = column v at rows[i] as fp64 (the evaluator's layout: one plane per variable; the column default for a row outside the store); up to 16 columns as kernel
+// arguments: nothing is staged, nothing synchronises before the evaluation
+struct ExprCol {
+    const void* base;
+    int32_t dtype;
+    int32_t pad;
+    double def;
+};
+struct ExprCols16 { ExprCol c[16]; };
+__global__ void features_bind_f64_kernel(ExprCols16 cols, uint32_t nv, uint64_t rows, const uint32_t* __restrict__ cand, uint32_t n,
+                                         double* __restrict__ vars) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nv) return;
+    const uint32_t v = t / n, i = t % n;
+    const ExprCol c = cols.c[v];
+    const uint32_t row = cand[i];
+    double x = c.def;
+    if (row < rows) {
+        switch (c.dtype) {
+            case PG_F_I32: x = (double)((const int32_t*)c.base)[row]; break;
+            case PG_F_I64: x = (double)((const int64_t*)c.base)[row]; break;
+            case PG_F_F32: x = (double)((const float*)c.base)[row]; break;
+            default: x = ((const double*)c.base)[row];
+        }
+    }
+    vars[t] = x;
+}
+
 }  // namespace pg
 
 extern "C" {
+
+int pg_features_eval_dev(pg_ctx* ctx, const pg_features* fs, const pg_expr* e, const uint32_t* d_rows, uint32_t n, double* d_out) {
+    PG_REQUIRE(ctx && fs && e && d_out, "pg_features_eval_dev: NULL argument");
+    if (n == 0) return PG_OK;
+    PG_REQUIRE(d_rows, "pg_features_eval_dev: NULL argument");
+    const size_t nv = e->vars.size();
+    PG_REQUIRE(nv <= 16, "pg_features_eval_dev: %zu variables (at most 16 columns per expression)", nv);
+    PG_REQUIRE((uint64_t)n * (nv ? nv : 1) < 0xFFFFFFFFull, "pg_features_eval_dev: n x variables too large");
+    pg::ExprCols16 h;
+    memset(&h, 0, sizeof h);
+    for (size_t v = 0; v < nv; ++v) {
+        const pg_features::Column* col = nullptr;
+        for (const auto& c : fs->cols)
+            if (c.name == e->vars[v]) { col = &c; break; }
+        if (!col) {
+            pg::set_error("pg_features_eval_dev: variable \"%s\" of `%s` is not a column of the feature store", e->vars[v].c_str(), e->source.c_str());
+            return PG_ERR_INVALID;
+        }
+        h.c[v] = pg::ExprCol{col->d, col->dtype, 0, col->def};
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    double* d_vars = nullptr;
+    if (nv) {
+        void* buf;
+        int rc;
+        if ((rc = pg::scratch_reserve(ctx, 16, (size_t)n * nv * 8, &buf))) return rc;
+        d_vars = (double*)buf;
+        const uint32_t total = n * (uint32_t)nv;
+        pg::features_bind_f64_kernel<<<(total + 255) / 256, 256, 0, ctx->stream>>>(h, (uint32_t)nv, fs->rows, d_rows, n, d_vars);
+        PG_HIP(hipGetLastError());
+    }
+    return pg::expr_eval_locked(ctx, e, d_vars, n, d_out);
+}
 
 int pg_expr_compile(const char* source, pg_expr** out) {
     PG_REQUIRE(source && out, "pg_expr_compile: NULL argument");

@@ -885,6 +885,21 @@ class Features:
         idx = np.asarray([self.index(n) if isinstance(n, str) else int(n) for n in names], dtype=np.int32)
         return idx
 
+    def eval_expr(self, expr: "Expr", rows: np.ndarray) -> np.ndarray:
+        """The expression with its variables bound to the columns of their names at `rows`, fp64 (pg_features_eval_dev):
+        a numeric `expression` normalizer over item features for a candidate batch."""
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        d_r = self.ctx.to_device(r)
+        d_o = self.ctx.malloc(max(r.shape[0] * 8, 16))
+        try:
+            _lib.check(self.ctx.L.pg_features_eval_dev(self.ctx.h, self.h, expr.h, d_r, r.shape[0], d_o))
+            out = np.zeros(r.shape[0], dtype=np.float64)
+            self.ctx.d2h(out, d_o)
+        finally:
+            self.ctx.free(d_r)
+            self.ctx.free(d_o)
+        return out
+
     def gather_i32(self, names, rows: np.ndarray) -> np.ndarray:
         idx = self._cols(names)
         r = np.ascontiguousarray(rows, dtype=np.uint32)

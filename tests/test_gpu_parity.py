@@ -1261,6 +1261,54 @@ def test_ssd_matches_oracle(ctx):
 # ---------------------------------------------------------------------------------------------
 # typed feature columns on the device
 # ---------------------------------------------------------------------------------------------
+def test_expression_over_feature_columns_matches_oracle(ctx):
+    """pg_features_eval_dev: an expression whose variables are feature columns, per candidate row in fp64 — the numeric
+    `expression` normalizer of a new_feature over item features (service/feature/new_feature_op.go:54-115) for a batch — against
+    the oracle's ExprASTResult (default grammar) and antlr_result (the antlr subset), incl. rows outside the store (column
+    defaults), every column type, a constant expression, an unknown column and a division by zero."""
+    rng = np.random.default_rng(33)
+    n = 4000
+    fs = pa.Features(ctx, n)
+    cols = {"clicks": (pa.F_I32, rng.integers(0, 10_000, n).astype(np.int32), 0.0),
+            "shows": (pa.F_I64, rng.integers(1, 2**40, n).astype(np.int64), 1.0),
+            "price": (pa.F_F32, (rng.random(n) * 100).astype(np.float32), 9.5),
+            "ctr": (pa.F_F64, rng.random(n), 0.25)}
+    for name, (dt, v, d) in cols.items():
+        fs.set_column(name, dt, v, default=d)
+    rows = np.concatenate([rng.integers(0, n, 500), [0xFFFFFFFF, n, n - 1, 0]]).astype(np.uint32)
+
+    def column(name, i):
+        dt, v, d = cols[name]
+        return float(v[rows[i]]) if rows[i] < n else d
+    for src in ["(${clicks} + 1) / (${shows} + 2) * ${price}^0.5", "(${clicks} + 1) / (${shows} + 2) * ${price}", "${ctr} * 100 - ${price} # 3",
+                "${price} % 7 + ${clicks}", "2.5", "${ctr}"]:
+        e = pa.Expr(src)
+        got = fs.eval_expr(e, rows)
+        ast = o.expr_parse(src)
+        want = np.array([o.expr_eval(ast, lambda nm, i=i: column(nm, i)) for i in range(len(rows))])
+        if "^" in src:
+            assert np.allclose(got, want, rtol=4e-16, atol=0.0), src          # pow: the device's last ulp (DESIGN 5.3)
+        else:
+            assert np.array_equal(got, want), src
+        e.free()
+    src = "(${clicks} + 2*${ctr}) * ${price}^0.1 - ${shows} / 3"
+    e = pa.Expr(src, "antlr")
+    got = fs.eval_expr(e, rows)
+    tree = o.antlr_parse(src)
+    want = np.array([o.antlr_result(tree, {nm: column(nm, i) for nm in cols}) for i in range(len(rows))])
+    assert np.allclose(got, want, rtol=1e-15, atol=0.0), "antlr"
+    e.free()
+    e = pa.Expr("${clicks} + ${nope}")
+    with pytest.raises(RuntimeError, match="nope.*not a column"):
+        fs.eval_expr(e, rows)
+    e.free()
+    e = pa.Expr("${price} / (${clicks} - ${clicks})")
+    with pytest.raises(RuntimeError):
+        fs.eval_expr(e, rows)
+    e.free()
+    fs.destroy()
+
+
 def test_feature_columns_gather_and_defaults(ctx):
     """pg_features_*: typed columns keyed by item row; an item without the feature (row past the store)
     reads the column default — the device form of feature.defaultValue (algo_data.go:154-171).  Integer
