@@ -729,17 +729,22 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
             if (stop) return;
             if (ny >= topn) { stop = true; return; }
             if (dj < epsilon) { broke = true; stop = true; return; }
-            const double inv = 1.0 / sqrt(dj);
             double lv[EPL];
-            double rsel = rn[0];                                 // r[j] from the lane that holds it (j is wave-uniform): no load in the pick's chain
-#pragma unroll
-            for (int s = 1; s < EPL; ++s) rsel = (j >> 6) == (uint32_t)s ? rn[s] : rsel;
-            const double rj = __shfl(rsel, (int)(j & 63u), 64);
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {                      // (the row's loads first, all of them: see above)
                 const uint32_t n = (uint32_t)s * 64u + lane;
                 lv[s] = S[(size_t)j * ld + (n < N ? n : 0u)];
             }
+            double cj[WMAX];
+#pragma unroll
+            for (int i = 0; i < k; ++i) cj[i] = c_lds[(uint32_t)i * NS + j];
+            __builtin_amdgcn_sched_barrier(0);                   // … and the earlier picks' column entries: requested before the
+                                                                 // square root and the division below, whose ~40 dependent fp64 operations they land under
+            const double inv = 1.0 / sqrt(dj);
+            double rsel = rn[0];                                 // r[j] from the lane that holds it (j is wave-uniform): no load in the pick's chain
+#pragma unroll
+            for (int s = 1; s < EPL; ++s) rsel = (j >> 6) == (uint32_t)s ? rn[s] : rsel;
+            const double rj = __shfl(rsel, (int)(j & 63u), 64);
 #ifdef DPP_PROFILE
             {                                                    // cycles from the row's requests to its arrival
                 const uint64_t t0 = __builtin_readcyclecounter();
@@ -754,9 +759,6 @@ __global__ __launch_bounds__(64) void dpp_greedy_wave_kernel(const double* __res
                 const double l = __dmul_rn(__dmul_rn(rj, lv[s]), rn[s]);
                 lv[s] = n < N ? l : 0.0;
             }
-            double cj[WMAX];
-#pragma unroll
-            for (int i = 0; i < k; ++i) cj[i] = c_lds[(uint32_t)i * NS + j];
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 double lj = lv[s];
