@@ -28,6 +28,30 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
     else return (uint32_t)__shfl_xor((int)v, M, 64);
 }
 
+// the wave's maximum of x with NaN passed over (v_max_f64), as a wave-uniform value (scalar registers): six lane exchanges —
+// the VALUE half of a "first maximum, NaN skipped" argmax (floats.MaxIdx); the index then comes from a ballot of x == max
+template <int K0, int K1, class F>
+__device__ __forceinline__ void lane_static_for(F&& f) {
+    if constexpr (K0 < K1) {
+        f(std::integral_constant<int, K0>{});
+        lane_static_for<K0 + 1, K1>(f);
+    }
+}
+__device__ __forceinline__ double uniform_f64(double x) {
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_max_f64(double m) {
+    lane_static_for<0, 6>([&](auto sc) {
+        constexpr int off = 1 << decltype(sc)::value;
+        const uint64_t bb = (uint64_t)__double_as_longlong(m);
+        const uint32_t lo = lane_xor<off>((uint32_t)bb), hi = lane_xor<off>((uint32_t)(bb >> 32));
+        m = fmax(m, __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)));
+    });
+    return uniform_f64(m);
+}
+
 struct BitonicLds {
     uint64_t xk[kBitonicE][1024];
     uint32_t xi[kBitonicE][1024];

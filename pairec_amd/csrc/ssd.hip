@@ -17,6 +17,7 @@
 // add/subtract (ScaleVec, then floats.Sub/Add); quality = r + (volume·l2).  Bit-identical to
 // oracle/oracle.c:orc_ssd_window.
 #include "pipeline.hpp"
+#include "bitonic_reg.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -391,13 +392,13 @@ __global__ __launch_bounds__(64) void ssd_kernel_grid(const double* __restrict__
         const uint32_t par = t & 1;
         const bool pop = t > W && t < T;
         // ---- publish: this workgroup's best (with its vector), the item leaving the window
-        double bq = q;
-        uint32_t bi = (valid && q == q) ? j : kNone;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double oq = __shfl_xor(bq, off, 64);
-            const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
-            if (oi != kNone && (bi == kNone || oq > bq || (oq == bq && oi < bi))) { bq = oq; bi = oi; }
+        // (argmax as in dpp_greedy_wave_kernel: the wave's maximum value through six lane exchanges, the first lane that holds it
+        // from a ballot — instead of a butterfly over (value, index) pairs; the results are wave-uniform)
+        double bq = wave_max_f64(valid ? q : nan);
+        uint32_t bi = kNone;
+        if (bq == bq) {
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(valid && q == bq);
+            bi = wg * 64u + (uint32_t)__builtin_ctzll(bal);
         }
         if (lane == 0) { mail->part_q[par][wg] = bq; mail->part_i[par][wg] = bi; }
         // (nothing pickable anywhere → pick 0, as floats.MaxIdx does: workgroup 0 then publishes candidate 0)
@@ -420,18 +421,29 @@ __global__ __launch_bounds__(64) void ssd_kernel_grid(const double* __restrict__
         }
         ssd_grid_barrier(&mail->counter, G, phase);
         // ---- every workgroup reduces the G partial results identically
-        double gq = nan;
-        uint32_t gi = kNone;
-        for (uint32_t w = lane; w < G; w += 64) {       // G <= 128: at most 2 per lane, ascending
-            const double oq = ld_dev(&mail->part_q[par][w]);
-            const uint32_t oi = ld_dev(&mail->part_i[par][w]);
-            if (oi != kNone && (gi == kNone || oq > gq || (oq == gq && oi < gi))) { gq = oq; gi = oi; }
-        }
+        // G <= 128 partial results, two slots per lane (workgroups `lane` and `lane + 64`; a workgroup's candidates precede the next
+        // one's, so the lowest slot-then-lane that holds the maximum is the first maximum)
+        double pq[2];
+        uint32_t pi[2];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double oq = __shfl_xor(gq, off, 64);
-            const uint32_t oi = (uint32_t)__shfl_xor((int)gi, off, 64);
-            if (oi != kNone && (gi == kNone || oq > gq || (oq == gq && oi < gi))) { gq = oq; gi = oi; }
+        for (int sl = 0; sl < 2; ++sl) {
+            const uint32_t w = lane + 64u * (uint32_t)sl;
+            pq[sl] = nan;
+            pi[sl] = kNone;
+            if (w < G) {
+                pq[sl] = ld_dev(&mail->part_q[par][w]);
+                pi[sl] = ld_dev(&mail->part_i[par][w]);
+            }
+            if (pi[sl] == kNone) pq[sl] = nan;
+        }
+        const double gq = wave_max_f64(fmax(pq[0], pq[1]));
+        uint32_t gi = kNone;
+        if (gq == gq) {
+#pragma unroll
+            for (int sl = 1; sl >= 0; --sl) {
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(pq[sl] == gq);
+                if (bal) gi = (uint32_t)__builtin_amdgcn_readlane((int)pi[sl], (int)__builtin_ctzll(bal));
+            }
         }
         const uint32_t idx = gi == kNone ? 0u : gi;      // pick number t
         const uint32_t wwg = idx >> 6;
