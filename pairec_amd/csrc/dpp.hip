@@ -333,7 +333,8 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_kernel(const double* 
 // diagonal and the rows they pick — a fifth of the matrix — which took 1 024 multiplications per tile out of this epilogue.
 // Measured (profiles/r5_dpp_mfma_summary.txt): 0.343 ms as first built — exactly the vector kernel's time: neither pipe was the
 // bound.  FETCH_SIZE 1.75 GB for 132 MB of F: dpp_tile_of_block (one request's tiles on one XCD) → 135 MB, 0.304 ms; L's 512 MB as
-// non-temporal stores: 0.277 ms (matrix pipe 49 % busy); S instead of L, the stores' tests hoisted: 0.262 ms.  What is left is the pairing of two waves per SIMD on one fp64 unit: with
+// non-temporal stores: 0.277 ms (matrix pipe 49 % busy); S instead of L, the stores' tests hoisted: 0.262 ms; panels staged with 16-byte
+// loads (eight lanes per row, half the load instructions): −5 % (0.258 against 0.274 on one box).  What is left is the pairing of two waves per SIMD on one fp64 unit: with
 // the matrix instructions removed the kernel takes 0.144 ms, with them 0.277 = the sum, not the maximum — a wave's staging and
 // epilogue (≈ 1 700 vector instructions per tile) advance at about one instruction per partner matrix instruction (64 cycles),
 // s_setprio does not change that, and one wave per SIMD (0.37 ms) leaves every load latency exposed.  Not done: a single wave
@@ -379,15 +380,18 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_mfma_kernel(const dou
     // One wave per workgroup: LDS accesses of a wave execute in program order, so the panels need no barrier — and must not have
     // __syncthreads(), whose s_waitcnt vmcnt(0) would make every chunk wait for the NEXT chunk's panel loads, which are requested
     // before the chunk's instructions so that they land under them (and, in the epilogue, for the previous pass's stores).
-    double va[16], vb[16];
+    // staging: 16 bytes per lane — columns 2 kq, 2 kq + 1 of rows r8 + 8 it (eight lanes per row: its chunk's 128 bytes)
+    typedef double f64x2 __attribute__((ext_vector_type(2), aligned(8)));
+    f64x2 va[8], vb[8];
     const char* const Fb = reinterpret_cast<const char*>(Fq);
     const uint32_t rowb = d1 * 8u;
-    uint32_t voff = rr * rowb + kk * 8u;
+    const uint32_t kq = lane & 7, r8 = lane >> 3;
+    uint32_t voff = r8 * rowb + kq * 16u;
     auto load_panels = [&]() {                                  // (unclamped: see dpp_kernel_matrix_kernel)
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            va[it] = *reinterpret_cast<const double*>(Fb + (size_t)(i0 + (uint32_t)it * 4) * rowb + voff);
-            vb[it] = *reinterpret_cast<const double*>(Fb + (size_t)(j0 + (uint32_t)it * 4) * rowb + voff);
+        for (int it = 0; it < 8; ++it) {
+            va[it] = *reinterpret_cast<const f64x2*>(Fb + (size_t)(i0 + (uint32_t)it * 8) * rowb + voff);
+            vb[it] = *reinterpret_cast<const f64x2*>(Fb + (size_t)(j0 + (uint32_t)it * 8) * rowb + voff);
         }
         voff += kDppKc * 8u;
     };
@@ -416,9 +420,11 @@ __global__ __launch_bounds__(64, 2) void dpp_kernel_matrix_mfma_kernel(const dou
     for (uint32_t k0 = 0; k0 < d1; k0 += kDppKc) {              // (the 129th column is a ninth chunk of one: its staging hides like the others')
         const uint32_t kc = d1 - k0 < (uint32_t)kDppKc ? d1 - k0 : (uint32_t)kDppKc;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            sa[kk][it * 4 + rr] = va[it];
-            sb[kk][it * 4 + rr] = vb[it];
+        for (int it = 0; it < 8; ++it) {
+            sa[2 * kq][it * 8 + r8] = va[it].x;
+            sa[2 * kq + 1][it * 8 + r8] = va[it].y;
+            sb[2 * kq][it * 8 + r8] = vb[it].x;
+            sb[2 * kq + 1][it * 8 + r8] = vb[it].y;
         }
         for (uint32_t z = kc; z < ((kc + 3u) & ~3u); ++z) {     // a width that is not a multiple of four: zeros behind it
             sa[z][lane] = 0.0;
