@@ -615,6 +615,41 @@ def expr_eval(ast, lookup) -> float:
     return 0.0
 
 
+def pow_last_ulp_explains(evaluate, device_value) -> bool:
+    """The device's pow() is within 2 ulp of libm's; where a power feeds something discontinuous — an integer `%`,
+    the exponent of a negative base (an integer or not: a number or NaN; even or odd: its sign) — that ulp changes the value, not its
+    last digit.  True iff `evaluate()` (an oracle evaluation) reproduces `device_value` (NaN matching NaN) with the results of its
+    first three go_pow calls moved by -2 … +2 ulps each, independently: the difference is the pow tolerance, not an evaluator's."""
+    import itertools
+    global go_pow
+    orig = go_pow
+    d = float(device_value)
+    try:
+        for shifts in itertools.product((0, -1, 1, -2, 2), repeat=3):
+            if shifts == (0, 0, 0):
+                continue
+            calls = [0]
+
+            def nudged(x, y):
+                r = orig(x, y)
+                k = shifts[calls[0]] if calls[0] < 3 else 0
+                calls[0] += 1
+                if k and math.isfinite(r) and r != 0.0:
+                    for _ in range(abs(k)):
+                        r = math.nextafter(r, math.inf if k > 0 else -math.inf)
+                return r
+            go_pow = nudged
+            try:
+                w = float(evaluate())
+            except Exception:
+                continue
+            if (math.isnan(w) and math.isnan(d)) or w == d or (math.isfinite(w) and abs(w - d) <= 1e-10 * max(abs(w), 1e-300)):
+                return True
+    finally:
+        go_pow = orig
+    return False
+
+
 def go_pow(x: float, y: float) -> float:
     """math.Pow (Go stdlib `math/pow.go`, go 1.24 per reference go.mod:3).  Go applies the INTEGER part of the exponent by
     repeated squaring of Frexp(x)'s mantissa with the binary exponent carried on the side (exact where the products are, e.g.

@@ -71,7 +71,7 @@ def values(n):
 
 
 t_end = time.time() + seconds
-n_str = n_acc = n_eval = n_rw = bad = 0
+n_str = n_acc = n_eval = n_rw = bad = n_pow = 0
 tab = w = t = m = None
 if use_gpu:
     nrow = 20000
@@ -134,6 +134,9 @@ while time.time() < t_end:
             tol = 1e-10 if "^" in src else 4e-15
             okv = (math.isnan(gi) and math.isnan(want)) or gi == want or (math.isfinite(want) and abs(gi - want) <= tol * max(abs(want), 1e-300))
             n_eval += 1
+            if not okv and "^" in src and o.pow_last_ulp_explains(lambda: o.antlr_result(ast, dd), gi):
+                n_pow += 1                               # (a power inside an exponent of a negative base, …: oracle.pow_last_ulp_explains)
+                continue
             if not okv:
                 bad += 1
                 print("VALUE MISMATCH", repr(src), dd, "device", gi, "oracle", want, flush=True)
@@ -166,5 +169,6 @@ while time.time() < t_end:
                     print("REWRITE MISMATCH", rank_src, rew, "device", fus[r_][i], "oracle", it.score, flush=True)
                     break
         ex.free()
-print(f"soak_antlr_rewrite: {n_str} strings, {n_acc} accepted by both sides, {n_eval} device values, {n_rw} rewritten fused scores, {bad} bad", flush=True)
+print(f"soak_antlr_rewrite: {n_str} strings, {n_acc} accepted by both sides, {n_eval} device values, {n_rw} rewritten fused scores, {bad} bad "
+      f"({n_pow} values differ by what pow's last ulp does to a discontinuous use of it)", flush=True)
 sys.exit(1 if bad else 0)
