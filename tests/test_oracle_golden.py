@@ -538,3 +538,20 @@ def test_expr_pow_follows_gos_integer_power_loop():
     assert o.go_pow(-238.9, 25599992000.0) == float("inf") and o.go_pow(-238.9, 25599992001.0) == float("-inf")
     assert o.go_pow(7.25, 1.0) == 7.25 and o.go_pow(1.5, -3.0) == 1.0 / (1.5 * 1.5 * 1.5)
     assert o.expr_eval(o.expr_parse("4e2^4e0%1000"), lambda name: None) == 0.0
+
+
+def test_pow_last_ulp_classifier():
+    """oracle.pow_last_ulp_explains (the soaks' classifier): a power inside the exponent of a negative base — the inner pow's last ulp
+    decides whether the outer exponent is an integer, i.e. a number or NaN — is explained; an arbitrary wrong value is not."""
+    src = "(${ctr})*(2.50*0 - 3e1)^(3.864*${ctr} ^ 9.650 * 886^${current_score}#${cvr} # ${a_b}+396)"
+    vals = {"ctr": 0.49297272577611595, "current_score": 5.956023815646717, "cvr": 23.186559967770872, "a_b": 1280679.6164711325}
+    ast = o.expr_parse(src)
+    ev = lambda: o.expr_eval(ast, lambda nm: vals.get(nm))
+    assert math.isnan(ev())
+    assert o.pow_last_ulp_explains(ev, float("inf")) and not o.pow_last_ulp_explains(ev, 1.0)
+    src = "maxIndex(${probs})*0 + (maxValue(${probs}))^(213+592^4.723*141) / (-9.876 * 369)-474"
+    data = {"probs": [-0.29112667712280665, -1.0701016109674397, -0.8296780524853117]}
+    tree = o.antlr_parse(src)
+    ev = lambda: o.antlr_result(tree, data)
+    assert ev() == -474.0 and o.pow_last_ulp_explains(ev, float("nan")) and not o.pow_last_ulp_explains(ev, 5.0)
+    assert o.go_pow(2.0, 10.0) == 1024.0                                             # (the hook is restored)
