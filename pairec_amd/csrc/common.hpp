@@ -68,6 +68,9 @@ struct Knobs {
     bool no_refine = false;        // PG_NO_REFINE: the pilot plan's full pass keeps the sample's threshold throughout
     uint32_t refine_min_rows = 1u << 24;   // PG_REFINE_MIN_ROWS: smallest table whose full pass is split for the refinement
     bool no_screen_i4 = false;     // PG_NO_SCREEN_I4: small batches stay on the int8 screen
+    bool no_screen_i4m = false;    // PG_NO_SCREEN_I4M: batches of 5..64 queries stay on the int8 screen
+    uint32_t i4m_max_queries = 64; // PG_I4M_MAX_QUERIES: largest batch the 4-bit matrix-pipe screen serves (<= kI4mMaxQueries)
+    double i4m_max_lambda = 2.2;   // PG_I4M_MAX_LAMBDA: largest pg_table::lam4 it is used for
     uint32_t i4_min_rows = 1u << 22; // PG_I4_MIN_ROWS: smallest table the 4-bit screen is built for
     double i4_max_lambda = 1.7;    // PG_I4_MAX_LAMBDA: largest pg_table::lam4 the 4-bit screen is used for
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
@@ -274,6 +277,11 @@ struct RecallScratch {
     float* thr_ref;          // [kMaxQueries] the thresholds the pilot plan's refinement step raised (verified after the pass)
     uint32_t* q4;            // 4-bit screen: [4][32] int8 queries + [4][4] constants (recall_i4.hip)
     float* pred_ms;          // [kMaxQueries][2] the threshold model's mean and sigma of every query's scores
+    // mid-batch screen (recall_i4m.hip): the int8 queries in plain order + the 4-bit bound's constants; the suspects that
+    // passed its int8 stage, [kI4mMaxQueries][cap]
+    uint32_t* q4m;
+    uint32_t* susp2;
+    uint32_t* susp2_cnt;     // [kI4mMaxQueries]
 };
 // A predicate over an integer feature column that restricts a recall's candidates (HologresVectorConf.WhereClause of the
 // reference, hologres_vector_recall.go:49-62, in the one shape the device serves: `column OP constant`).  Rows that fail it
@@ -322,6 +330,7 @@ struct RecallJob {
     uint32_t rows = 0, nblocks = 0;
     bool screen = false;
     bool screen4 = false;                   // the pilot plan's full pass streams the 4-bit shadow (nq <= kI4MaxQueries)
+    bool screen4m = false;                  // ... through the matrix pipe, suspects thinned on the int8 shadow (kI4MaxQueries < nq <= kI4mMaxQueries)
     int plans[4] = {0, 0, 0, 0};
     bool predict = false;                   // plans[0] takes its first thresholds from the table's threshold model
     bool pred_observe = false;              // the table has a model: this job contributes its observed quantiles
@@ -365,6 +374,12 @@ int screen4_prep_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs)
 int screen4_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t row_begin, uint32_t row_end,
                    uint32_t cap4, const float* l2_nqv = nullptr);
 uint32_t screen4_rescore_blocks();
+// recall_i4m.hip (caller holds ctx->mu): the same shadow through the int8 matrix pipe for 5 .. kI4mMaxQueries queries
+constexpr uint32_t kI4mMaxQueries = 64;
+constexpr uint32_t kQ4mWords = kI4mMaxQueries * 32 + kI4mMaxQueries * 4 + 4;
+int screen4m_prep_launch(pg_ctx* ctx, const RecallScratch& rs, uint32_t nq);
+int screen4m_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t row_begin, uint32_t row_end,
+                    uint32_t cap1);
 int topk_merge_strided_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
                               uint32_t per_list, size_t row_ls, size_t row_qs, size_t sc_ls, size_t sc_qs, uint32_t k,
                               uint64_t* d_out_rows, float* d_out_scores, uint32_t* d_out_count);

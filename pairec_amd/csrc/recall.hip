@@ -2109,7 +2109,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     void* small;
     int rc;
     const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
-    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 40 + 2048;
+    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 40 + 2048 + (size_t)kQ4mWords * 4 + 256 + 64;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
     rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
@@ -2123,11 +2123,14 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     rs->q4 = (uint32_t*)(rs->qscale + kMaxQueries);      // 4 x 128 B + 4 x 16 B
     rs->thr_ref = (float*)(rs->q4 + 160);                // [kMaxQueries]
     rs->pred_ms = rs->thr_ref + kMaxQueries;             // [kMaxQueries][2]
+    rs->susp2_cnt = (uint32_t*)(rs->pred_ms + 2 * kMaxQueries);                       // [kI4mMaxQueries]
+    rs->q4m = (uint32_t*)(((uintptr_t)(rs->susp2_cnt + kI4mMaxQueries) + 63) & ~(uintptr_t)63);   // (16-byte fragment loads)
     void* c;
-    if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4), &c))) return rc;
+    if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4) + (size_t)kI4mMaxQueries * cap * 4, &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
     rs->cand[1] = rs->cand[0] + (size_t)kMaxQueries * cap;
     rs->susp = (uint32_t*)(rs->cand[1] + (size_t)kMaxQueries * cap);
+    rs->susp2 = rs->susp + (size_t)kMaxQueries * cap;
     rs->cap = cap;
     return PG_OK;
 }
@@ -2682,7 +2685,7 @@ int recall_job_prepare(RecallJob* j) {
     // rows of (nearly) one norm: one cutoff per 32-row block; beyond: the per-row test (three VALU instructions per bound instead of half a one)
     j->l2_per_row = j->l2 && screen && t->l2_slack > kn.l2_max_slack;
     j->screen = screen;
-    j->screen4 = false;
+    j->screen4 = j->screen4m = false;
     j->n_plans = 0;
     j->stride = 1;
     j->sample_blocks = 0;
@@ -2723,6 +2726,12 @@ int recall_job_prepare(RecallJob* j) {
         // queries; Gaussian rows, lambda 1.3: 1.46 / 1.59 / 1.78 / 2.02 — every query re-scores its own suspects)
         static const double kLamScale[kI4MaxQueries] = {1.0, 1.0, 0.88, 0.7};
         j->screen4 = t->i4_ok && (double)t->lam4 <= kn.i4_max_lambda * kLamScale[j->nq - 1];
+    }
+    // 5 .. 64 queries: the same shadow through the matrix pipe, suspects thinned on the int8 shadow (recall_i4m.hip); inner product only
+    if (screen && !j->l2 && t->dim == 128 && t->shadow_is_i8 && j->nq > kI4MaxQueries && j->nq <= kI4mMaxQueries &&
+        j->nq <= kn.i4m_max_queries && j->plans[0] == kPilot && !kn.no_screen_i4m && rows >= kn.i4_min_rows) {
+        if ((rc = ensure_table_i4(ctx, t))) return rc;
+        j->screen4m = t->i4_ok && (double)t->lam4 <= kn.i4m_max_lambda;
     }
     // the threshold model: observe with every pilot-plan batch of a big int8-screened table; predict once the observed
     // quantile is tight (plan 0)
@@ -2857,12 +2866,17 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             // the full pass of a small batch streams the 4-bit shadow; its few suspect lists share the whole buffer
             // (whole 64-row groups: a range starts on an even block and ends on one or at the table's end)
             const bool i4 = j->screen4 && allow_i4 && st == 1 && (rb & 1) == 0 && (((rb + cb) & 1) == 0 || rb + cb == j->nblocks);
+            const bool i4m = j->screen4m && allow_i4 && st == 1 && (rb & 1) == 0 && (((rb + cb) & 1) == 0 || rb + cb == j->nblocks);
             const uint32_t scap = i4 ? rs.cap * (uint32_t)(kMaxQueries / kI4MaxQueries) : rs.cap;
             const uint64_t r_begin = (uint64_t)rb * kPieceRows;
             const uint64_t r_end = (uint64_t)(rb + cb) * kPieceRows < j->rows ? (uint64_t)(rb + cb) * kPieceRows : j->rows;
             if (i4) {
                 if ((rc2 = screen4_launch(ctx, t, rs, nq, (uint32_t)r_begin, (uint32_t)r_end, scap, j->l2 ? rs.pred_ms : nullptr))) return rc2;
                 j->scan_bytes += (r_end - r_begin) * (j->l2 ? 72 : 68);      // (squared Euclidean: + the row's |x|^2)
+            } else if (i4m) {
+                // stage-1 suspects share the whole buffer ([nq][4 cap]); what passes the int8 stage lands in susp2 ([nq][cap])
+                if ((rc2 = screen4m_launch(ctx, t, rs, nq, (uint32_t)r_begin, (uint32_t)r_end, rs.cap * (uint32_t)(kMaxQueries / kI4mMaxQueries)))) return rc2;
+                j->scan_bytes += (r_end - r_begin) * 68;
             } else {
                 if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) return rc2;
                 if (records) {
@@ -2882,6 +2896,9 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             else if (t->dim == 64)
                 rescore_kernel<64><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap,
                                                                 rs.cnt, rs.cand[cur], rs.overflow, scap, j->rows, nullptr, nullptr, j->filter);
+            else if (i4m)
+                rescore_kernel<128><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp2, rs.susp2_cnt, rs.cap,
+                                                                 rs.cnt, rs.cand[cur], rs.overflow, rs.cap, j->rows, nullptr, nullptr, j->filter);
             else
                 rescore_kernel<128><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap,
                                                                  rs.cnt, rs.cand[cur], rs.overflow, scap, j->rows, nullptr, nullptr, j->filter);
@@ -3010,6 +3027,7 @@ int recall_job_enqueue(RecallJob* j) {
             PG_HIP(hipGetLastError());
         }
         if (j->screen4 && (rc = screen4_prep_launch(ctx, t, rs))) return rc;
+        if (j->screen4m && (rc = screen4m_prep_launch(ctx, rs, j->nq))) return rc;
     }
     const bool observe = j->pred_observe && (plan == kPilot || plan == kPredict);
     if (observe || plan == kPredict) {
@@ -3069,7 +3087,7 @@ int recall_job_enqueue(RecallJob* j) {
         // threshold can exceed the true K-th score — which is CHECKED after the pass (refine_verify_kernel: the K-th
         // best score that came out must reach the raised threshold), and such a query is re-run like one whose sample
         // threshold was too high.  Randomly ordered rows fail with the sample's own probability (six sigma).
-        const uint32_t nb_q = j->nblocks / 4;
+        const uint32_t nb_q = (j->nblocks / 4) & ~1u;      // (even: the 4-bit screens walk whole 64-row pieces)
         const double m2 = (double)j->k * 0.25;
         const uint32_t k2 = (uint32_t)ceil(m2 + kn.pilot_sigmas * sqrt(m2) + 8.0);
         // (not behind a predicted threshold: that one already sits tighter than what a quarter of the table can certify —
@@ -3211,7 +3229,7 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
         pg_table* tm = const_cast<pg_table*>(j->t);
         std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
         if (j->h_status[0] != 0) {
-            j->screen = j->screen4 = j->l2_per_row = false;
+            j->screen = j->screen4 = j->screen4m = j->l2_per_row = false;
             j->pred_observe = false;
             // (... starting over at the pilot plan: on the exact scan the sample's threshold is as good as anywhere, while the
             //  growing-chunk plans meet a table in ascending order with a flood of candidates per chunk)

@@ -230,8 +230,10 @@ __global__ __launch_bounds__(256) void table_quant4_kernel(const float* __restri
             amax = fmaxf(amax, __shfl_xor(amax, off, 64));
             ss += __shfl_xor(ss, off, 64);
         }
-        const float s = bf16_up(amax / 7.0f);              // the stored scale IS the scale of the nibbles
-        const float inv = amax > 0.0f ? 1.0f / s : 0.0f;
+        // the stored scale IS the scale of the nibbles; never below 1e-30 (an all-zero row's nibbles mean zero under any scale, a
+        // row of values below 7e-30 rounds to them and its residual says so): recall_i4m.hip divides by it
+        const float s = bf16_up(fmaxf(amax / 7.0f, 1e-30f));
+        const float inv = 1.0f / s;
         float rs = 0.0f;
         uint32_t word = 0;
 #pragma unroll
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void table_quant4_kernel(const float* __restri
             const float R = bf16_up(sqrtf(rs) * 1.001f + 1e-30f);
             out_scale[g / G] = (__float_as_uint(s) >> 16) | (__float_as_uint(R) & 0xffff0000u);
             if (ss > 0.0f) lam += R / sqrtf(ss);
-            rho_mx = fmaxf(rho_mx, s > 0.0f ? rs / (s * s * (float)DIM) : 0.0f);
+            rho_mx = fmaxf(rho_mx, s > 1e-18f ? rs / (s * s * (float)DIM) : 0.0f);
             r_mx = fmaxf(r_mx, R);
         }
     }
