@@ -26,7 +26,9 @@ static void knobs_from_env(Knobs* k) {
     k->i4_min_rows = (uint32_t)num("PG_I4_MIN_ROWS", (double)(1u << 22));
     k->no_screen_i4m = flag("PG_NO_SCREEN_I4M");
     k->i4m_max_queries = (uint32_t)num("PG_I4M_MAX_QUERIES", 64);
+    k->i4m_min_queries = (uint32_t)num("PG_I4M_MIN_QUERIES", 3);
     k->i4m_max_lambda = num("PG_I4M_MAX_LAMBDA", 2.2);
+    k->i4m_max_pairs = num("PG_I4M_MAX_PAIRS", 8.0e6);
     k->rank_no_ws = flag("PG_RANK_NO_WS");
     k->rank_sort_max = (uint32_t)num("PG_RANK_SORT_MAX", 8);
     k->sort_lds = flag("PG_SORT_LDS");
@@ -163,7 +165,9 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "i4_min_rows") k.i4_min_rows = (uint32_t)v;
     else if (n == "no_screen_i4m") k.no_screen_i4m = b;
     else if (n == "i4m_max_queries") k.i4m_max_queries = (uint32_t)v;
+    else if (n == "i4m_min_queries") k.i4m_min_queries = (uint32_t)v;
     else if (n == "i4m_max_lambda") k.i4m_max_lambda = v;
+    else if (n == "i4m_max_pairs") k.i4m_max_pairs = v;
     else if (n == "rank_no_ws") k.rank_no_ws = b;
     else if (n == "rank_sort_max") k.rank_sort_max = (uint32_t)v;
     else if (n == "sort_lds") k.sort_lds = b;

@@ -69,8 +69,10 @@ struct Knobs {
     uint32_t refine_min_rows = 1u << 24;   // PG_REFINE_MIN_ROWS: smallest table whose full pass is split for the refinement
     bool no_screen_i4 = false;     // PG_NO_SCREEN_I4: small batches stay on the int8 screen
     bool no_screen_i4m = false;    // PG_NO_SCREEN_I4M: batches of 5..64 queries stay on the int8 screen
+    uint32_t i4m_min_queries = 3;  // PG_I4M_MIN_QUERIES: smallest batch it serves (below: recall_i4.hip's vector-ALU screen, exact re-scoring of all its suspects)
     uint32_t i4m_max_queries = 64; // PG_I4M_MAX_QUERIES: largest batch the 4-bit matrix-pipe screen serves (<= kI4mMaxQueries)
     double i4m_max_lambda = 2.2;   // PG_I4M_MAX_LAMBDA: largest pg_table::lam4 it is used for
+    double i4m_max_pairs = 8.0e6;  // PG_I4M_MAX_PAIRS: ... and the most (row, query) pairs per pass its 4-bit stage may be expected to pass on
     uint32_t i4_min_rows = 1u << 22; // PG_I4_MIN_ROWS: smallest table the 4-bit screen is built for
     double i4_max_lambda = 1.7;    // PG_I4_MAX_LAMBDA: largest pg_table::lam4 the 4-bit screen is used for
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
@@ -137,6 +139,7 @@ struct pg_table {
     float rho4 = 0.0f;           // max over rows of ||x - x^|| / (s_row sqrt(dim)) (diagnostic)
     float rmax4 = 0.0f;          // max over rows of ||x - x^|| (upper bound)
     float lam4 = 0.0f;           // mean residual term in units of the score spread (decides whether the shadow pays)
+    float i4m_pairs = 0.0f;      // recall_i4m.hip: running average of the (row, query) pairs its 4-bit stage lets through, per query
     uint32_t prefix_failures = 0; // batches whose refined thresholds failed verification for most queries (ordered rows): two → no refinement
     // Threshold predictor (recall.hip, DESIGN.md 4.1, plan 0): a Gaussian model of a query's scores over the rows — mean
     // vector and covariance from a row sample, built with the statistics — and the quantile z = (K-th best score −

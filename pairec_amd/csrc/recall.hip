@@ -2123,8 +2123,8 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     rs->q4 = (uint32_t*)(rs->qscale + kMaxQueries);      // 4 x 128 B + 4 x 16 B
     rs->thr_ref = (float*)(rs->q4 + 160);                // [kMaxQueries]
     rs->pred_ms = rs->thr_ref + kMaxQueries;             // [kMaxQueries][2]
-    rs->susp2_cnt = (uint32_t*)(rs->pred_ms + 2 * kMaxQueries);                       // [kI4mMaxQueries]
-    rs->q4m = (uint32_t*)(((uintptr_t)(rs->susp2_cnt + kI4mMaxQueries) + 63) & ~(uintptr_t)63);   // (16-byte fragment loads)
+    rs->susp2_cnt = (uint32_t*)(rs->pred_ms + 2 * kMaxQueries);                       // [kI4mMaxQueries] + one statistics word
+    rs->q4m = (uint32_t*)(((uintptr_t)(rs->susp2_cnt + kI4mMaxQueries + 1) + 63) & ~(uintptr_t)63);   // (16-byte fragment loads)
     void* c;
     if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4) + (size_t)kI4mMaxQueries * cap * 4, &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
@@ -2178,6 +2178,7 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
     if (t->stats_valid || t->shadow_failed) return PG_OK;
     t->i4_ok = t->i4_failed = false;                  // the 4-bit shadow (recall_i4.hip) follows the rows too
+    t->i4m_pairs = 0.0f;
     t->pred_model = false;                            // ... and the threshold model
     t->prefix_failures = 0;
     if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
@@ -2270,7 +2271,8 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     return PG_OK;
 }
 
-constexpr uint32_t kPredStatsAt = 600;        // words [600, 608) of a job's status block: the table's observation sums
+constexpr uint32_t kPredStatsAt = 600;        // words [600, 610) of a job's status block: the table's observation sums
+constexpr uint32_t kI4mStatAt = 612;          // ... the (row, query) pairs the 4-bit stage of a mid-batch pass let through
 
 // the threshold model of a table (dim 128): mean and covariance of a row sample, built once per generation of the rows
 static int ensure_pred_model(pg_ctx* ctx, const pg_table* tc) {
@@ -2728,10 +2730,13 @@ int recall_job_prepare(RecallJob* j) {
         j->screen4 = t->i4_ok && (double)t->lam4 <= kn.i4_max_lambda * kLamScale[j->nq - 1];
     }
     // 5 .. 64 queries: the same shadow through the matrix pipe, suspects thinned on the int8 shadow (recall_i4m.hip); inner product only
-    if (screen && !j->l2 && t->dim == 128 && t->shadow_is_i8 && j->nq > kI4MaxQueries && j->nq <= kI4mMaxQueries &&
+    if (screen && !j->l2 && t->dim == 128 && t->shadow_is_i8 && j->nq >= kn.i4m_min_queries && j->nq <= kI4mMaxQueries &&
         j->nq <= kn.i4m_max_queries && j->plans[0] == kPilot && !kn.no_screen_i4m && rows >= kn.i4_min_rows) {
         if ((rc = ensure_table_i4(ctx, t))) return rc;
-        j->screen4m = t->i4_ok && (double)t->lam4 <= kn.i4m_max_lambda;
+        // every pair the 4-bit stage lets through is one random 128-B read (~14 G/s measured): beyond i4m_max_pairs of them per pass
+        // the int8 shadow's wider stream is the shorter pass.  The count per query is the table's own running average.
+        j->screen4m = t->i4_ok && (double)t->lam4 <= kn.i4m_max_lambda && (double)t->i4m_pairs * j->nq <= kn.i4m_max_pairs;
+        if (j->screen4m) j->screen4 = false;
     }
     // the threshold model: observe with every pilot-plan batch of a big int8-screened table; predict once the observed
     // quantile is tight (plan 0)
@@ -3142,6 +3147,8 @@ int recall_job_enqueue(RecallJob* j) {
         PG_HIP(hipGetLastError());
         PG_HIP(hipMemcpyAsync(j->h_status + kPredStatsAt, stats, 40, hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (j->screen4m)
+        PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt, rs.susp2_cnt + kI4mMaxQueries, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (j->d_out_count)
         PG_HIP(hipMemcpyAsync(j->d_out_count, j->d_count, 4 * j->nq, hipMemcpyDeviceToDevice, ctx->stream));
     PG_HIP(hipMemcpyAsync(j->h_status, rs.overflow, 4 * (1 + (size_t)j->nq), hipMemcpyDeviceToHost, ctx->stream));     // [overflow | counts]
@@ -3239,6 +3246,14 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
         } else if (ok) {
             tm->screen_overflow_streak = 0;
         }
+    }
+    if (j->screen4m && ok && (plan == kPilot || plan == kPredict)) {
+        // what the 4-bit stage lets through per query decides up to which batch size it beats the int8 shadow (recall_job_prepare)
+        pg_table* tm = const_cast<pg_table*>(j->t);
+        std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
+        const float per_q = (float)j->h_status[kI4mStatAt] / (float)j->nq;
+        tm->i4m_pairs = tm->i4m_pairs > 0.0f ? 0.75f * tm->i4m_pairs + 0.25f * per_q : per_q;
+        if (ctx->knobs.debug_scan) fprintf(stderr, "[pg] plan %d 4-bit stage: %.0f pairs per query (running %.0f)\n", plan, per_q, tm->i4m_pairs);
     }
     if (!ok) ctx->stats.recall_rescans++;
     if (ok && plan == kPredict) ctx->stats.recall_predicted++;

@@ -106,7 +106,7 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-// NQB query blocks of 32 (1: 5..32 queries, 2: 33..64)
+// NQB query blocks of 32 (1: up to 32 queries, 2: 33..64)
 template <int NQB>
 __global__ __launch_bounds__(64 * kMWaves, 2) void screen4m_kernel(Screen4mArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -372,23 +372,56 @@ __global__ __launch_bounds__(256) void screen4m_prep_kernel(const float* __restr
     }
 }
 
-// Stage 2: the stage-1 suspects of every query against the int8 shadow — eight lanes gather a suspect's 128-B row, four
-// v_dot4_i32_i8 each, three lane exchanges; survivors (I8 >= the int8 screen's integer threshold) are compacted into the list
-// rescore_kernel reads.  grid (blocks, nq), 256 threads.
+// Stage 2: the stage-1 suspects of every query against the int8 shadow.  A wave walks chunks of 64 suspects of one query:
+// eight lanes gather a suspect's 128-B row (sixteen bytes each: one full line per suspect), four v_dot4_i32_i8 per lane, and the
+// eight rows' eight partial sums of a lane group are reduced ACROSS the group in seven exchanges (a transposing butterfly: lane
+// 8 g + i ends with the total of the group's row i — its own suspect).  Survivors (I8 >= the int8 screen's integer threshold)
+// are compacted into the list rescore_kernel reads.  The gathers of the next chunk are in flight under the arithmetic of this
+// one and the suspect rows are read two chunks ahead: random 128-B lines reach 6.4 TB/s on this part when enough of them are
+// requested (scripts/micro/gather128.hip), a wave that waits for one chunk at a time gets 1.8.  grid (blocks, nq), 256 threads.
 constexpr int kS2Stage = 448;            // staged survivors per wave (flushed above 384)
+__device__ __forceinline__ void rs8_gather(i32x4 (&v)[8], const int8_t* __restrict__ d8, uint32_t row, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r_i = (uint32_t)__shfl((int)row, (lane & 56) + i, 64);
+        v[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(d8 + (size_t)r_i * 128) + (lane & 7));
+    }
+}
+__device__ __forceinline__ int rs8_reduce(const i32x4 (&v)[8], const i32x4& qd, int lane) {
+    int p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int acc = __builtin_amdgcn_sdot4(v[i].x, qd.x, 0, false);
+        acc = __builtin_amdgcn_sdot4(v[i].y, qd.y, acc, false);
+        acc = __builtin_amdgcn_sdot4(v[i].z, qd.z, acc, false);
+        p[i] = __builtin_amdgcn_sdot4(v[i].w, qd.w, acc, false);
+    }
+    // lane bit 2 keeps rows 4..7 (else 0..3) and hands the other half to its partner; then bit 1, then bit 0
+    const bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    int s4[4], s2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s4[i] = (b2 ? p[i + 4] : p[i]) + __shfl_xor(b2 ? p[i] : p[i + 4], 4, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) s2[i] = (b1 ? s4[i + 2] : s4[i]) + __shfl_xor(b1 ? s4[i] : s4[i + 2], 2, 64);
+    return (b0 ? s2[1] : s2[0]) + __shfl_xor(b0 ? s2[0] : s2[1], 1, 64);
+}
 __global__ __launch_bounds__(256) void rescreen8_kernel(const int8_t* __restrict__ d8, const uint32_t* __restrict__ q4m,
                                                         const float* __restrict__ thr_screen, const uint32_t* __restrict__ susp,
                                                         const uint32_t* __restrict__ susp_cnt, uint32_t scap, uint32_t n_rows,
                                                         uint32_t* __restrict__ susp2, uint32_t* __restrict__ susp2_cnt, uint32_t cap2,
-                                                        uint32_t* __restrict__ overflow) {
+                                                        uint32_t* __restrict__ overflow, uint32_t* __restrict__ stat) {
     __shared__ uint32_t stage[4][kS2Stage];
     const uint32_t q = blockIdx.y;
     const uint32_t n_raw = susp_cnt[q];
     const uint32_t n = n_raw < scap ? n_raw : scap;
     if (n_raw > scap && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 1u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(stat, n);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int T = __float_as_int(thr_screen[q]);
     const i32x4 qd = *reinterpret_cast<const i32x4*>(q4m + (size_t)q * 32 + (lane & 7) * 4);
+    const uint32_t nchunks = (n + 63) / 64, cstep = gridDim.x * 4;
+    uint32_t c = blockIdx.x * 4 + (uint32_t)w;
+    if (c >= nchunks) return;
     uint32_t cnt = 0;
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -405,31 +438,14 @@ __global__ __launch_bounds__(256) void rescreen8_kernel(const int8_t* __restrict
         __builtin_amdgcn_wave_barrier();
         cnt = 0;
     };
-    const uint32_t step = gridDim.x * 256u;
-    for (uint32_t t0 = blockIdx.x * 256u + (uint32_t)w * 64u; t0 < n; t0 += step) {
-        const uint32_t e = t0 + lane;
-        // (a list that overflowed has holes whose stale contents may be rows of an earlier, larger table: stay inside this one)
-        uint32_t row = e < n ? susp[(uint64_t)q * scap + e] : 0u;
-        row = row < n_rows ? row : 0u;
-        i32x4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t r_i = (uint32_t)__shfl((int)row, (lane & 56) + i, 64);
-            v[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(d8 + (size_t)r_i * 128) + (lane & 7));
-        }
-        int mine = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int acc = __builtin_amdgcn_sdot4(v[i].x, qd.x, 0, false);
-            acc = __builtin_amdgcn_sdot4(v[i].y, qd.y, acc, false);
-            acc = __builtin_amdgcn_sdot4(v[i].z, qd.z, acc, false);
-            acc = __builtin_amdgcn_sdot4(v[i].w, qd.w, acc, false);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            if ((lane & 7) == i) mine = acc;
-        }
-        const bool keep = e < n && mine >= T;
+    // (a list that overflowed has holes whose stale contents may be rows of an earlier, larger table: stay inside this one)
+    auto rows_of = [&](uint32_t ch) -> uint32_t {
+        const uint32_t e = ch * 64 + lane;
+        const uint32_t r = (ch < nchunks && e < n) ? susp[(uint64_t)q * scap + e] : 0u;
+        return r < n_rows ? r : 0u;
+    };
+    auto emit = [&](uint32_t ch, uint32_t row, int mine) {
+        const bool keep = ch * 64 + lane < n && mine >= T;
         const uint64_t bm = __builtin_amdgcn_ballot_w64(keep);
         if (bm) {
             const uint32_t k = (uint32_t)__popcll(bm);
@@ -438,6 +454,26 @@ __global__ __launch_bounds__(256) void rescreen8_kernel(const int8_t* __restrict
             cnt += k;
             if (cnt > (uint32_t)(kS2Stage - 64)) flush();
         }
+    };
+    i32x4 va[8], vb[8];
+    uint32_t rowA = rows_of(c), rowB = rows_of(c + cstep);
+    rs8_gather(va, d8, rowA, lane);
+    for (;;) {
+        // chunk c's rows are in flight in va; rowB holds the rows of chunk c + cstep
+        const bool hasB = c + cstep < nchunks;
+        if (hasB) rs8_gather(vb, d8, rowB, lane);
+        const uint32_t rowC = rows_of(c + 2 * cstep);
+        emit(c, rowA, rs8_reduce(va, qd, lane));
+        if (!hasB) break;
+        c += cstep;
+        const bool hasC = c + cstep < nchunks;
+        if (hasC) rs8_gather(va, d8, rowC, lane);
+        const uint32_t rowD = rows_of(c + 2 * cstep);
+        emit(c, rowB, rs8_reduce(vb, qd, lane));
+        if (!hasC) break;
+        c += cstep;
+        rowA = rowC;
+        rowB = rowD;
     }
     if (cnt) flush();
 }
@@ -472,7 +508,8 @@ int screen4m_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uin
     if (grid > (npieces + kMWaves - 1) / kMWaves) grid = (npieces + kMWaves - 1) / kMWaves;
     if (grid == 0) grid = 1;
     int rc;
-    PG_HIP(hipMemsetAsync(rs.susp2_cnt, 0, sizeof(uint32_t) * kI4mMaxQueries, ctx->stream));
+    PG_HIP(hipMemsetAsync(rs.susp2_cnt, 0, sizeof(uint32_t) * (kI4mMaxQueries + 1), ctx->stream));
+    uint32_t* const stat = rs.susp2_cnt + kI4mMaxQueries;      // (zeroed with the counters; copied out with the job's status words)
     if (nq <= 32) {
         if ((rc = ensure_dyn_lds(ctx, (const void*)screen4m_kernel<1>, kMLds))) return rc;
         screen4m_kernel<1><<<grid, 64 * kMWaves, kMLds, ctx->stream>>>(a);
@@ -481,8 +518,10 @@ int screen4m_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uin
         screen4m_kernel<2><<<grid, 64 * kMWaves, kMLds, ctx->stream>>>(a);
     }
     PG_HIP(hipGetLastError());
-    rescreen8_kernel<<<dim3(256, nq), 256, 0, ctx->stream>>>(t->d8, rs.q4m, rs.thr_screen, rs.susp, rs.susp_cnt, cap1, (uint32_t)t->rows,
-                                                             rs.susp2, rs.susp2_cnt, rs.cap, rs.overflow);
+    // ~ the resident waves of the chip over all queries (a wave then walks a few dozen chunks of a typical list)
+    const uint32_t s2_blocks = nq >= 8 ? 2048u / nq : 256u;
+    rescreen8_kernel<<<dim3(s2_blocks, nq), 256, 0, ctx->stream>>>(t->d8, rs.q4m, rs.thr_screen, rs.susp, rs.susp_cnt, cap1, (uint32_t)t->rows,
+                                                             rs.susp2, rs.susp2_cnt, rs.cap, rs.overflow, stat);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }

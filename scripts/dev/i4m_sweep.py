@@ -20,9 +20,9 @@ for i in range(12):
     t.recall_topk_dev(d_q + (i % 8) * 256 * 128 * 4, 256, K, d_rows, d_sc)
 if os.environ.get("PG_SWEEP_DEBUG"):
     ctx.set_option("debug_scan", "1")
-for mode in ("i4m", "int8"):
+for mode in os.environ.get("PG_SWEEP_MODES", "i4m,int8").split(","):
     ctx.set_option("no_screen_i4m", "0" if mode == "i4m" else "1")
-    for R in (1, 4, 5, 8, 16, 32, 48, 64, 128, 256):
+    for R in [int(x) for x in os.environ.get("PG_SWEEP_R", "1,2,4,8,16,32,48,64,128,256").split(",")]:
         ms, by = [], 0
         for it in range(6):
             off = ((it * 7 + R) % 15) * 256 * 128 * 4

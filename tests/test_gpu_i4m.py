@@ -18,11 +18,12 @@ def bits(a):
 @pytest.fixture
 def small_table_opts(ctx):
     """the 4-bit screens on tables far below their production size limit, a quarter of the rows as the pilot sample"""
-    for name, v in (("i4_min_rows", "0"), ("pilot_fraction", "0.25"), ("i4m_max_lambda", "1000"), ("i4_max_lambda", "3")):
+    for name, v in (("i4_min_rows", "0"), ("pilot_fraction", "0.25"), ("i4m_max_lambda", "1000"), ("i4_max_lambda", "3"),
+                    ("i4m_max_pairs", "1e12")):
         ctx.set_option(name, v)
     yield ctx
     for name, v in (("i4_min_rows", str(1 << 22)), ("pilot_fraction", "0"), ("i4m_max_lambda", "2.2"), ("i4_max_lambda", "1.7"),
-                    ("no_screen_i4m", "0"), ("i4m_max_queries", "64")):
+                    ("no_screen_i4m", "0"), ("i4m_max_queries", "64"), ("i4m_max_pairs", "8e6")):
         ctx.set_option(name, v)
 
 
@@ -37,7 +38,7 @@ def check(ctx, t, tab, q, k, expect_narrow=True):
         assert (nbytes < tab.shape[0] * 128) == expect_narrow, (nbytes, tab.shape[0] * 128, expect_narrow)
 
 
-@pytest.mark.parametrize("nq", [5, 8, 16, 31, 32, 33, 48, 64])
+@pytest.mark.parametrize("nq", [2, 3, 5, 8, 16, 31, 32, 33, 48, 64])
 def test_mid_batch_uniform_rows(small_table_opts, nq):
     """the benchmark's row distribution (uniform, normalised), every batch size class incl. both ends of each query block"""
     ctx = small_table_opts
