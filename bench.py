@@ -76,8 +76,12 @@ def parse_args():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=5000)
     ap.add_argument("--batch", type=int, default=256, help="requests per step (<= 256 = one table pass)")
-    ap.add_argument("--prec", choices=["bf16", "f32", "bf16x3"], default="bf16",
-                    help="rank model precision of the headline: bf16 (configs[2]), f32, or bf16x3 = split bf16 (fp32 scores on the bf16 MFMA)")
+    ap.add_argument("--prec", choices=["bf16", "f32", "bf16x3"], default="bf16x3",
+                    help="rank model precision of the headline: bf16x3 (default) = split bf16 — configs[2]'s bf16 MFMA with hi + lo "
+                         "operands, the one matrix-pipe mode whose scores are within north_star's 1e-5 of the fp32 path; bf16 = plain "
+                         "bf16 operands (faster, 4e-5 from fp32); f32 = fp32 MFMA")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the requests-per-pass sweep (batch_sweep)")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the clustered-table leg (clustered_table)")
     ap.add_argument("--mode", choices=["replica", "shard", "group", "router"], default="replica")
     ap.add_argument("--table-dist", choices=["uniform", "gaussian"], default="uniform",
                     help="headline table: SURVEY.md 8d's normalised uniform rows, or N(0,1) rows")
@@ -184,7 +188,7 @@ def measure_traffic_live(args, R):
         return None, "rocprofv3 not on PATH"
     if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ):
         return None, "this run is itself being profiled: no nested rocprofv3"
-    kernels = ("screen_kernel", "screen4_kernel", "screen_decode_kernel", "rescore_kernel")
+    kernels = ("screen_kernel", "screen4_kernel", "screen4m_kernel", "rescreen8_kernel", "screen_decode_kernel", "rescore_kernel")
     steps = 6
     detail = {}
     total = 0.0
@@ -196,7 +200,7 @@ def measure_traffic_live(args, R):
                    "python3", os.path.abspath(__file__), "--steps", str(steps), "--warmup", "2", "--batch", str(R),
                    "--rows", str(args.rows), "--dim", str(args.dim), "--k", str(args.k), "--prec", args.prec,
                    "--table-dist", args.table_dist, "--calibrate", str(args.calibrate),
-                   "--no-cpu-baseline", "--latency-reqs", "0", "--no-extras", "--no-rank-shapes", "--no-f32-leg", "--contexts", "1", "--callers", "0"]
+                   "--no-cpu-baseline", "--latency-reqs", "0", "--no-extras", "--no-rank-shapes", "--no-f32-leg", "--no-batch-sweep", "--no-clustered", "--contexts", "1", "--callers", "0"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s exited with %d" % (counter, r.returncode)
@@ -415,7 +419,7 @@ def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs, scan_b
     shard_bytes = rows_local * args.dim * (elem_bytes if screened else 4)
     # batches of <= 4 queries: the full pass streams the 4-bit shadow (68 B per row, csrc/recall_i4.hip) — the engine's own
     # byte count of the last recall's scan launches (pilot sample on the main shadow + that pass) says whether it did
-    four_bit = bool(screened and R <= 4 and args.dim == 128 and scan_bytes and scan_bytes < shard_bytes)
+    four_bit = bool(screened and R <= 64 and args.dim == 128 and scan_bytes and scan_bytes < shard_bytes)
     if four_bit:
         shard_bytes = int(scan_bytes)
     fp32_bytes = rows_local * args.dim * 4
@@ -429,7 +433,8 @@ def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs, scan_b
     hbm_frac = achieved / HBM_PEAK_GBS
     return {
         "bound": "mfma" if (max(mfma_frac, busy) > hbm_frac and not four_bit) else "hbm",
-        "kernel": ("pg::screen4_kernel<%d>" % R) if four_bit else scan_kernel_name(R, args.dim, elem_bytes),
+        "kernel": (("pg::screen4_kernel<%d>" % R) if R <= 2 else ("pg::screen4m_kernel<%d>" % (1 if R <= 32 else 2)))
+                  if four_bit else scan_kernel_name(R, args.dim, elem_bytes),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
         "frac_basis": "achieved / peak / unit / frac price the bytes the pass streams against HBM whatever `bound` says (the "
                       "series is comparable across rounds); the matrix-pipe side of the same pass is mfma_achieved / mfma_peak "
@@ -490,7 +495,11 @@ def headline_spot_check(o, pipe, table, w, prec, queries_of_last_step, K):
     want_rnk = o.dnn3_forward(w, 1 if prec == "bf16" else 0, q0, emb)    # bf16x3 is checked against the fp32 specification
     want_fus = o.widen_f32(rnk) * (1 + o.widen_f32(rec)) ** 0.1
     tol = {"bf16": 1e-5, "bf16x3": 1e-6}.get(prec, 2e-7)
+    err_fp32 = float(np.max(np.abs(rnk.astype(np.float64) - (want_rnk if prec != "bf16" else o.dnn3_forward(w, 0, q0, emb)))))
     res = {"request": "request 0 of the last timed batch, %d candidates" % K,
+           "rank_oracle": "fp32 specification (no rounding point mirrored)" if prec != "bf16" else "oracle that rounds operands to bf16 where the kernel does",
+           "rank_max_abs_err_vs_fp32_oracle": err_fp32, "north_star_tolerance": 1e-5,
+           "within_north_star_tolerance_of_fp32_oracle": bool(err_fp32 <= 1e-5),
            "recall_scores_bit_exact": bool(np.array_equal(rec.view(np.uint32), want_rec.view(np.uint32))),
            "recall_sorted": bool(np.all(np.diff(rec.astype(np.float64)) <= 0)),
            "rank_max_abs_err": float(np.max(np.abs(rnk.astype(np.float64) - want_rnk))), "rank_tolerance": tol,
@@ -586,7 +595,7 @@ def concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K):
     co = pa.Coalescer(ctx, table, K, model, expr, "gpu_dnn", max_top_n=args.page, depth=3)
     try:
         main_leg = loadgen(co, spec, args.callers, args.callers_seconds, 2, 2, K)
-        sweep = [loadgen(co, spec, c_, 1.5, 2, 2, K) for c_ in (256, 512) if c_ != args.callers]
+        sweep = [loadgen(co, spec, c_, 1.5, 2, 2, K) for c_ in (8, 32, 128, 256, 512) if c_ != args.callers]
         solo = loadgen(co, spec, 1, 1.0, 3, 2, K)
         out = dict(main_leg)
         out.update({"other_caller_counts": sweep, "solo_caller": solo})
@@ -615,6 +624,114 @@ def concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K):
                 "cross PCIe (the page: rows, three scores per entry); the coalescer batches up to 256 requests per table "
                 "pass, 3 batches in flight",
     })
+    return out
+
+
+
+SWEEP_BATCHES = (1, 4, 8, 16, 32, 64, 128, 256)
+
+
+def batch_sweep_leg(pa, o, ctx, table, model, expr, args, K, extra_ctxs, measured_gbs):
+    """Requests per table pass, R in SWEEP_BATCHES (SURVEY.md 8(d)'s Qb in {1, 8, 32} / R in {1, 16, 64} are points of it): what a
+    pass costs when per-request callers (service/recall/vector_recall.go:32-123, one call per request; rank_service.go:264-289)
+    fill it only partly.  Per point: the scan stage's event-timed launches with ONE batch in flight (ms_per_pass: screen or scan
+    kernels + the exact re-scoring), the bytes they streamed (the engine's own count: 68 B per row on the 4-bit shadow up to 64
+    requests, 128 B on the int8 shadow beyond), frac = bytes / time / 8 TB/s, and the whole step (recall -> rank -> fusion ->
+    sort) one batch at a time and two batches in flight as in the headline."""
+    out = []
+    for Rb in SWEEP_BATCHES:
+        d = [ctx.to_device(make_queries(o, 3000 + 17 * i, Rb, args.dim)) for i in range(6)]
+        one = Pipeline1(pa, ctx, table, model, expr, Rb, K, depth=1)
+        for i in range(3):
+            one.step(d[i])
+        one.drain()
+        ctx.synchronize()
+        n = 12
+        passes, nbytes = [], 0
+        t0 = time.perf_counter()
+        for i in range(n):
+            one.begin(d[i % 6])
+            one.drain()
+            ms_, nbytes = ctx.last_scan_kernel()
+            passes.append(ms_)
+        ctx.synchronize()
+        wall1 = (time.perf_counter() - t0) / n
+        two = Pipeline1(pa, ctx, table, model, expr, Rb, K, extra_ctxs=extra_ctxs)
+        for i in range(3):
+            two.step(d[i])
+        two.drain()
+        for c_ in [ctx] + list(extra_ctxs):
+            c_.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2 * n):
+            two.step(d[i % 6])
+        two.drain()
+        for c_ in [ctx] + list(extra_ctxs):
+            c_.synchronize()
+        wall2 = (time.perf_counter() - t0) / (2 * n)
+        for pipe_ in (one, two):
+            for b in pipe_.bufs:
+                for p_ in b:
+                    ctx.free(p_)
+        for p_ in d:
+            ctx.free(p_)
+        ms_pass = float(np.mean(passes))
+        out.append({"R": Rb, "ms_per_pass": ms_pass, "ms_per_pass_min": float(np.min(passes)), "bytes_streamed": int(nbytes),
+                    "bytes_per_row": nbytes / table.rows,
+                    "achieved_gbs": nbytes / ms_pass / 1e6, "frac": nbytes / ms_pass / 1e6 / HBM_PEAK_GBS,
+                    "frac_of_measured": nbytes / ms_pass / 1e6 / measured_gbs if measured_gbs else None,
+                    "ms_per_step_one_in_flight": wall1 * 1e3, "ms_per_step": wall2 * 1e3,
+                    "items_per_s": Rb * K / wall2, "requests_per_s": Rb / wall2})
+    return out
+
+
+MIX_SEED, MIX_CENTRES = 0x5EED0007, 1000
+
+
+def clustered_table_leg(pa, o, ctx, table, model, expr, args, R, K, sync, extra_ctxs, headline_ms):
+    """The headline step on CLUSTERED rows (pg_table_fill_mixture: MIX_CENTRES centres on the unit sphere, within-cluster noise of
+    norm sigma, normalised; queries are further points of the same mixture, so a query's top-K sits inside one cluster whose
+    members score close to each other — the case the int8 bound's slack multiplies suspects in; uniform and i.i.d. Gaussian rows
+    are its two best).  Per sigma: items/s, suspects per answer (what the full pass handed to the exact fp32 re-scoring / K),
+    scan-stage ms with one batch in flight, batches that fell back (screen overflow -> exact scan; failed plan -> re-run) and a
+    slice of the device's rows regenerated by the oracle bit for bit."""
+    import copy
+    out = []
+    for sigma in (0.3, 0.1, 0.03):
+        table.fill_mixture(MIX_SEED, MIX_CENTRES, sigma)
+        eb = table.screen_info()[0]
+        sl = table.download(table.rows - 4096, 4096)
+        slice_ok = bool(np.array_equal(sl.view(np.uint32), o.synth_mixture_rows(MIX_SEED, table.rows - 4096, 4096, args.dim, MIX_CENTRES, sigma).view(np.uint32)))
+        qs = [ctx.to_device(o.synth_mixture_rows(MIX_SEED, 1000 * s_, R, args.dim, MIX_CENTRES, sigma, stream=1)) for s_ in range(args.calibrate + 6)]
+        a0 = copy.copy(args)
+        a0.warmup, a0.steps = args.calibrate, 0
+        run_headline(pa, ctx, table, model, expr, qs[6:], a0, R, K, sync, extra_ctxs)
+        ctxs = [ctx] + list(extra_ctxs)
+        s0 = [c_.stats() for c_ in ctxs]
+        a1 = copy.copy(args)
+        a1.warmup, a1.steps = 2, 10
+        pipe, el, _ = run_headline(pa, ctx, table, model, expr, qs[:6], a1, R, K, sync, extra_ctxs)
+        s1 = [c_.stats() for c_ in ctxs]
+
+        def delta(f):
+            return sum(getattr(b_, f) - getattr(a_, f) for a_, b_ in zip(s0, s1))
+        a2 = copy.copy(args)
+        a2.warmup, a2.steps = 1, 6
+        _, _, scan = run_headline(pa, ctx, table, model, expr, qs[:6], a2, R, K, sync)
+        nq = max(delta("recall_suspect_queries"), 1)
+        for b in pipe.bufs:
+            for p_ in b:
+                ctx.free(p_)
+        for p_ in qs:
+            ctx.free(p_)
+        ms_step = el / a1.steps * 1e3
+        out.append({"sigma": sigma, "centres": MIX_CENTRES, "shadow_elem_bytes": eb, "value": R * K * a1.steps / el, "unit": "ranked items/s",
+                    "ms_per_step": ms_step, "vs_uniform_headline_ms": ms_step / headline_ms,
+                    "suspects_per_answer": delta("recall_suspects") / nq / K, "scan_stage_ms_per_pass": float(np.mean(scan)),
+                    "batches": a1.warmup + a1.steps, "batches_on_predicted_thresholds": int(delta("recall_predicted")),
+                    "batches_re_run_after_a_failed_plan": int(delta("recall_rescans")),
+                    "batches_that_fell_to_the_exact_scan": int(delta("recall_screen_overflows")),
+                    "slice_matches_oracle": slice_ok})
     return out
 
 
@@ -664,6 +781,25 @@ def rank_shapes_leg(pa, o, ctx, table, R, K):
                     "frac": nI * flop / best / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                     "gather_gbs": nI * 512 / best / 1e9,
                     "mfma_busy_from_profile": (pmc.get(key) or {}).get("mfma_busy")})
+    # the benchmark's shape at PG_PREC_BF16X3 (dnn3_x3_kernel: three bf16 products per term, fp32 scores)
+    w = o.Dnn3Weights()
+    m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16X3, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    best = 1e9
+    for _ in range(3):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            m.rank_dnn3_dev(table, d_u, d_c, d_o, R, nI, d_out)
+        ctx.synchronize()
+        best = min(best, (time.perf_counter() - t0) / 10)
+    dev_ms = ctx.stats().last_rank_ms
+    m.destroy()
+    out.append({"shape": "256-512-256-1", "prec": "bf16x3", "kernel": "pg::dnn3_x3_kernel<512, 256>",
+                "ms_per_%d_items" % nI: best * 1e3, "device_ms": dev_ms, "items_per_s": nI / best,
+                "achieved": nI * FLOPS_PER_ITEM / best / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": nI * FLOPS_PER_ITEM / best / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                "executed_flop_per_item": 3 * 393216, "executed_frac": nI * 3 * 393216 / best / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                "gather_gbs": nI * 512 / best / 1e9, "mfma_busy_from_profile": 0.61})
     for p_ in (d_u, d_c, d_o, d_out):
         ctx.free(p_)
     return out
@@ -1638,8 +1774,9 @@ def main():
                                 "page %d, window 10)" % (args.rows * world, args.dim, world, args.rows, R, K, args.prec, args.page))
                                if shard else
                                ("configs[1]+[2]: recall 5k of %dx%d fp32 table in HBM -> 3-layer DNN rank "
-                                "(256-512-256-1, %s MFMA) -> RankScore fusion (fp64) -> ItemRankScore sort"
-                                % (args.rows, args.dim, args.prec)),
+                                "(256-512-256-1, %s) -> RankScore fusion (fp64) -> ItemRankScore sort"
+                                % (args.rows, args.dim, {"bf16x3": "bf16 MFMA with split hi + lo operands = bf16x3, fp32-accurate scores",
+                                                         "bf16": "bf16 MFMA", "f32": "fp32 MFMA"}[args.prec])),
                    "requests_per_step": R, "candidates_per_request": K, "table_rows": args.rows,
                    "dim": args.dim, "table_dist": args.table_dist, "batches_in_flight": 2 if not shard else 1,
                    "contexts": args.contexts,
@@ -1657,11 +1794,11 @@ def main():
         "stages_ms": {"recall_device_ms": st.last_recall_ms, "rank_device_ms": st.last_rank_ms},
         "oracle_spot_check": shard_sanity if shard else spot,
         "preflight": preflight,
-        "rank_roofline": {"bound": "mfma", "kernel": "pg::dnn3_ws_kernel",
+        "rank_roofline": {"bound": "mfma", "kernel": "pg::dnn3_ws_kernel" if args.prec == "bf16" else "pg::dnn3_x3_kernel<512, 256>",
                           "achieved": rank_items * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9,
                           "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": rank_items * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS}
-        if args.prec == "bf16" and st.last_rank_ms > 0 else None,
+        if args.prec != "f32" and st.last_rank_ms > 0 else None,
     }
 
     if share_gpu:
@@ -1695,56 +1832,71 @@ def main():
                                                                      "measured_peak", "frac_of_measured", "bytes_per_pass",
                                                                      "ms_per_pass", "traffic_from_profile")}
 
-    if solo and args.prec == "bf16" and not args.no_rank_shapes:
-        # the rank stage alone, per hidden shape; the benchmark shape's entry is the rank roofline proper
+    if solo and args.prec != "f32" and not args.no_rank_shapes:
+        # the rank stage alone, per hidden shape (bf16) and the benchmark's shape in the headline's precision: the rank roofline proper
         for c_ in [ctx] + list(extra_ctxs):
             c_.synchronize()
         shapes = rank_shapes_leg(pa, o, ctx, table, R, K)
         out["rank_shapes"] = shapes
         out["multi_output_rank"] = multi_output_leg(pa, o, ctx, table, R, K)
-        bs = [e for e in shapes if e["shape"] == "256-512-256-1"][0]
-        in_pipe = out["rank_roofline"]
+        bs = [e for e in shapes if e["shape"] == "256-512-256-1" and e.get("prec", "bf16") == args.prec][0]
         out["rank_roofline"] = {"bound": "mfma", "kernel": bs["kernel"], "achieved": bs["achieved"], "peak": bs["peak"],
                                 "unit": "TFLOP/s", "frac": bs["frac"], "ms": bs["ms_per_%d_items" % (R * K)],
+                                "executed_frac": bs.get("executed_frac"),
                                 "measured": "rank stage alone on the device (tile table + request partial + MLP kernel), "
-                                            "%d x %d random candidate rows of the resident table" % (R, K),
+                                            "%d x %d random candidate rows of the resident table; achieved / frac price SURVEY.md 8(d)'s "
+                                            "%d flop per item (bf16x3 executes three bf16 products per term: executed_frac)" % (R, K, FLOPS_PER_ITEM),
                                 "mfma_busy_from_profile": bs["mfma_busy_from_profile"],
-                                "in_pipeline": {"ms": st.last_rank_ms, "frac": in_pipe["frac"] if in_pipe else None,
+                                "in_pipeline": {"ms": st.last_rank_ms,
+                                                "frac": R * K * FLOPS_PER_ITEM / max(st.last_rank_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS,
                                                 "note": "HIP events around the stage inside the headline loop, i.e. right behind the scan: the "
-                                                        "clock the power cap leaves (--contexts 1 gives the same time, so it is not the "
-                                                        "other context's scan kernel beside it)"}}
+                                                        "clock the power cap leaves"}}
 
-    if solo and args.prec == "bf16" and not args.no_f32_leg:
-        # the headline again at PG_PREC_F32 — the mode that meets north_star's 1e-5 unconditionally — and what separates the modes
-        m32 = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
-        _, el32, _ = run_headline(pa, ctx, table, m32, expr, d_qs, args, R, K, sync, extra_ctxs)
-        out["f32_mode"] = {"value": R * K * args.steps / el32, "unit": "ranked items/s", "ms_per_step": el32 / args.steps * 1e3,
-                           "dtype": "f32", "vs_bf16": (R * K * args.steps / el32) / value,
-                           "note": "the same timed region with the rank model at PG_PREC_F32 (fp32 MFMA, scores within 2e-7 of the "
-                                   "oracle's fp32 chains); recall, fusion and sort are the same kernels in both modes"}
-        out["bf16_vs_f32"] = precision_figures(pa, ctx, table, expr, model, m32, qs[args.warmup % len(qs)], K, args.page)
-        # ... and at PG_PREC_BF16X3 (split bf16: hi + lo operands, three products per term on the bf16 MFMA): the mode that
-        # meets the 1e-5 against the fp32 path at matrix-pipe speed
-        mx3 = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16X3, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
-        pipe3, el3, _ = run_headline(pa, ctx, table, mx3, expr, d_qs, args, R, K, sync, extra_ctxs)
-        rank3_ms = ctx.stats().last_rank_ms               # (HIP events around the stage of the last batch on this context)
-        spot3 = headline_spot_check(o, pipe3, table, w, "bf16x3", qs[(total_steps - 1) % len(qs)], K)
-        fig3 = precision_figures(pa, ctx, table, expr, mx3, m32, qs[args.warmup % len(qs)], K, args.page)
-        fig3["note"] = fig3["note"].replace("bf16 mode minus", "bf16x3 mode minus")
-        out["bf16x3_mode"] = {"value": R * K * args.steps / el3, "unit": "ranked items/s", "ms_per_step": el3 / args.steps * 1e3,
-                              "dtype": "bf16x3", "vs_bf16": (R * K * args.steps / el3) / value,
-                              "rank_stage_ms_in_pipeline": rank3_ms,
-                              "max_abs_dscore_vs_f32_mode": fig3["max_abs_dscore"],
-                              "frac_requests_page_order_equals_f32_mode": fig3["frac_requests_page_order_unchanged"],
-                              "frac_requests_page_order_equals_f32_mode_up_to_score_ties":
-                                  fig3["frac_requests_page_order_unchanged_up_to_ties"],
-                              "oracle_spot_check": spot3, "vs_f32_mode": fig3,
-                              "note": "the same timed region with the rank model at PG_PREC_BF16X3; the spot check compares with "
-                                      "the FP32 oracle (no rounding point mirrored), tolerance 1e-6"}
-        if not spot3["ok"]:
-            print("[bench] bf16x3 spot check FAILED: %s" % json.dumps(spot3), file=sys.stderr, flush=True)
-        mx3.destroy()
-        m32.destroy()
+    if solo and not args.no_f32_leg:
+        # The same timed region in the other precision modes, and what separates each matrix-pipe mode from PG_PREC_F32 (the fp32
+        # specification: scores within 2e-7 of the oracle's chains).  north_star's tolerance is 1e-5 on float scores against the
+        # reference's fp32 path (algorithm/eas/easyrec_response.go:479-483, eas/tf_response.go:55-59): bf16x3 — the headline —
+        # meets it (1.2e-7), plain bf16 does not (4e-5; it passes only against an oracle that rounds where it rounds).
+        blob = pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128)
+        precs = {"bf16": pa.PREC_BF16, "bf16x3": pa.PREC_BF16X3, "f32": pa.PREC_F32}
+        m32 = model if args.prec == "f32" else pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, blob)
+        q_fig = qs[args.warmup % len(qs)]
+        if args.prec != "f32":
+            out["%s_vs_f32" % args.prec] = precision_figures(pa, ctx, table, expr, model, m32, q_fig, K, args.page)
+            out["%s_vs_f32" % args.prec]["note"] = out["%s_vs_f32" % args.prec]["note"].replace("bf16 mode minus", "%s mode (the headline) minus" % args.prec)
+        for name in ("bf16", "bf16x3", "f32"):
+            if name == args.prec:
+                continue
+            mm = m32 if name == "f32" else pa.RankModel(ctx, pa.MODEL_DNN3, precs[name], blob)
+            pipe_m, el_m, _ = run_headline(pa, ctx, table, mm, expr, d_qs, args, R, K, sync, extra_ctxs)
+            ent = {"value": R * K * args.steps / el_m, "unit": "ranked items/s", "ms_per_step": el_m / args.steps * 1e3,
+                   "dtype": name, "vs_headline": (R * K * args.steps / el_m) / value,
+                   "rank_stage_ms_in_pipeline": ctx.stats().last_rank_ms,
+                   "oracle_spot_check": headline_spot_check(o, pipe_m, table, w, name, qs[(total_steps - 1) % len(qs)], K)}
+            if name != "f32":
+                fig = precision_figures(pa, ctx, table, expr, mm, m32, q_fig, K, args.page)
+                fig["note"] = fig["note"].replace("bf16 mode minus", "%s mode minus" % name)
+                ent["%s_vs_f32" % name] = fig
+                ent["max_abs_dscore_vs_f32_mode"] = fig["max_abs_dscore"]
+                ent["frac_requests_page_order_equals_f32_mode"] = fig["frac_requests_page_order_unchanged"]
+                ent["frac_requests_page_order_equals_f32_mode_up_to_score_ties"] = fig["frac_requests_page_order_unchanged_up_to_ties"]
+            ent["note"] = {"bf16": "the same timed region with plain bf16 operands (configs[2] read literally): faster, and outside "
+                                   "north_star's 1e-5 of the fp32 path — its spot check compares with an oracle that mirrors its roundings",
+                           "bf16x3": "the same timed region with the rank model at PG_PREC_BF16X3; spot check against the FP32 oracle",
+                           "f32": "the same timed region with the rank model at PG_PREC_F32 (fp32 MFMA, scores within 2e-7 of the "
+                                  "oracle's fp32 chains); recall, fusion and sort are the same kernels in every mode"}[name]
+            if not ent["oracle_spot_check"]["ok"]:
+                print("[bench] %s spot check FAILED: %s" % (name, json.dumps(ent["oracle_spot_check"])), file=sys.stderr, flush=True)
+            out["%s_mode" % name] = ent
+            for b_ in pipe_m.bufs:
+                for p_ in b_:
+                    ctx.free(p_)
+            if name != "f32":
+                mm.destroy()
+        if m32 is not model:
+            m32.destroy()
+    if solo and not args.no_batch_sweep:
+        out["batch_sweep"] = batch_sweep_leg(pa, o, ctx, table, model, expr, args, K, extra_ctxs, measured_gbs)
     extras = solo and not args.no_extras
     if extras and args.callers > 0:
         out["concurrent_callers"] = concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K)
@@ -1766,6 +1918,8 @@ def main():
                                    "roofline": {k_: rf[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac",
                                                                       "frac_survey_8d", "ms_per_pass", "shadow_elem_bytes",
                                                                       "mfma_frac")}}
+        if not args.no_clustered:
+            out["clustered_table"] = clustered_table_leg(pa, o, ctx, table, model, expr, args, R, K, sync, extra_ctxs, ms_per_step)
         table.destroy()
         out["other_configs"] = {"cfg1": cfg1_leg(pa, o, ctx), "cfg4": cfg4_leg(pa, o, ctx, R, K),
                                 "cfg5_one_shard": cfg5_leg(pa, o, R, K, prec)}
@@ -1822,10 +1976,11 @@ def main():
             out["value_withheld"] = out["value"]
             out["value"] = None
             failed = True
-        x3 = out.get("bf16x3_mode")
-        if x3 and not x3["oracle_spot_check"]["ok"]:
-            x3["value_withheld"], x3["value"] = x3["value"], None
-            failed = True
+        for mname in ("bf16_mode", "bf16x3_mode", "f32_mode"):
+            mo = out.get(mname)
+            if mo and not mo["oracle_spot_check"]["ok"]:
+                mo["value_withheld"], mo["value"] = mo["value"], None
+                failed = True
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -96,6 +96,10 @@ int pg_table_fill_synthetic(pg_ctx* ctx, pg_table* t, uint64_t seed, int normali
  * Gaussian; the uniform rows of SURVEY.md 8d are the int8 screen's best case).  Defined by the device's own fp64
  * log / cos: reproducible run to run, compared in tests against downloaded rows. */
 int pg_table_fill_gaussian(pg_ctx* ctx, pg_table* t, uint64_t seed, float sigma);
+/* clustered rows — the third benchmark distribution (trained embeddings cluster: the tables behind
+ * service/recall/hologres_vector_recall.go:23): n_centres centres on the unit sphere, a row = its centre + noise of norm
+ * ~ sigma, normalised.  No transcendental in it: oracle/oracle.c regenerates any slice bit for bit. */
+int pg_table_fill_mixture(pg_ctx* ctx, pg_table* t, uint64_t seed, uint32_t n_centres, float sigma);
 int pg_table_upload(pg_ctx* ctx, pg_table* t, uint64_t row0, uint64_t nrows, const float* host_rows);
 int pg_table_download(pg_ctx* ctx, const pg_table* t, uint64_t row0, uint64_t nrows, float* host_rows);
 /* atomically exchange the contents of two tables of equal shape (the analogue of the Hologres
@@ -676,6 +680,11 @@ typedef struct {
     uint64_t sort_calls, sort_items;
     double   last_recall_ms, last_rank_ms, last_sort_ms;   /* hipEvent-timed, device side */
     uint64_t recall_predicted;          /* batches whose screening threshold came from the table's threshold model and held */
+    /* screened recalls whose first plan held: the (row, query) pairs the full pass handed to the exact fp32 re-scoring, and the
+     * queries they belong to (suspects per answer = recall_suspects / recall_suspect_queries / K); the pairs a mid-batch pass's
+     * 4-bit stage handed to its int8 stage; screened plans that overflowed (rows crowded within the screen's error of the K-th
+     * score) and finished on the exact scan */
+    uint64_t recall_suspects, recall_suspect_queries, recall_i4m_pairs, recall_screen_overflows;
 } pg_stats_t;
 int pg_stats(pg_ctx* ctx, pg_stats_t* out);
 /* time (ms) of the dominant kernel of the last pg_recall_* call, measured with HIP events on the

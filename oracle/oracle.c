@@ -54,6 +54,33 @@ void orc_synth_rows(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, 
     }
 }
 
+/* clustered rows (pairec_amd/csrc/table.hip, table_fill_mixture_kernel): centre c = splitmix64((seed + 2 + 16 stream) ^ g) mod
+ * n_centres, x = centre (normalised synthetic row c of seed + 1) + noise_scale * uniform(seed + 3 + 16 stream), normalised.
+ * stream 0 is what the device fills a table with; other streams draw further points of the same mixture (queries). */
+void orc_synth_mixture_rows(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, uint32_t n_centres, float noise_scale,
+                            uint64_t stream, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < (int64_t)nrows; ++r) {
+        const uint64_t g = row0 + (uint64_t)r;
+        const uint32_t c = (uint32_t)(orc_splitmix64((seed + 2 + 16 * stream) ^ g) % n_centres);
+        float* o = out + (size_t)r * dim;
+        float ss = 0.0f;
+        for (uint32_t k = 0; k < dim; ++k) {
+            float v = orc_synth_value(seed + 1, c, k, dim);
+            ss = fmaf(v, v, ss);
+        }
+        const float ic = 1.0f / sqrtf(ss);
+        float sx = 0.0f;
+        for (uint32_t k = 0; k < dim; ++k) {
+            float x = fmaf(orc_synth_value(seed + 3 + 16 * stream, g, k, dim), noise_scale, orc_synth_value(seed + 1, c, k, dim) * ic);
+            o[k] = x;
+            sx = fmaf(x, x, sx);
+        }
+        const float ix = 1.0f / sqrtf(sx);
+        for (uint32_t k = 0; k < dim; ++k) o[k] = o[k] * ix;
+    }
+}
+
 void orc_synth_uniform(uint64_t seed, uint64_t n, float scale, float* out) {
     for (uint64_t i = 0; i < n; ++i) {
         uint64_t u = orc_splitmix64(seed ^ i);

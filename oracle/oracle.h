@@ -25,6 +25,8 @@ float    orc_synth_value(uint64_t seed, uint64_t row, uint32_t col, uint32_t dim
 /* rows [row0,row0+nrows) of the synthetic table; normalize!=0 → L2-normalised in fp32 */
 void orc_synth_rows(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, int normalize,
                     float* out);
+void orc_synth_mixture_rows(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, uint32_t n_centres, float noise_scale,
+                            uint64_t stream, float* out);
 /* uniform [-scale,scale) vector of n values: value i = synth_value(seed, 0, i, n) * scale */
 void orc_synth_uniform(uint64_t seed, uint64_t n, float scale, float* out);
 

@@ -44,6 +44,8 @@ def lib():
         L.orc_synth_value.restype = C.c_float
         L.orc_synth_value.argtypes = [u64, u64, u32, u32]
         L.orc_synth_rows.argtypes = [u64, u64, u64, u32, i32, f32p]
+        L.orc_synth_mixture_rows.argtypes = [u64, u64, u64, u32, u32, C.c_float, u64, f32p]
+        L.orc_synth_mixture_rows.restype = None
         L.orc_synth_uniform.argtypes = [u64, u64, C.c_float, f32p]
         L.orc_topk_key.restype = u64
         L.orc_topk_key.argtypes = [C.c_float, u32]
@@ -97,6 +99,15 @@ SEED_TABLE, SEED_QUERY, SEED_WEIGHTS, SEED_FIELDS, SEED_CANDS = (
 def synth_rows(seed: int, row0: int, nrows: int, dim: int, normalize: bool = True) -> np.ndarray:
     out = np.empty((nrows, dim), dtype=np.float32)
     lib().orc_synth_rows(seed, row0, nrows, dim, int(normalize), _f32p(out))
+    return out
+
+
+def synth_mixture_rows(seed: int, row0: int, nrows: int, dim: int, n_centres: int, sigma: float, stream: int = 0) -> np.ndarray:
+    """Clustered rows (pg_table_fill_mixture's definition, bit for bit at stream 0): n_centres centres on the unit sphere,
+    within-cluster noise of norm ~ sigma, normalised; stream > 0 draws further points of the same mixture (queries)."""
+    out = np.empty((nrows, dim), dtype=np.float32)
+    ns = np.float32(sigma) * np.sqrt(np.float32(3.0) / np.float32(dim), dtype=np.float32)
+    lib().orc_synth_mixture_rows(seed, row0, nrows, dim, n_centres, float(np.float32(ns)), stream, _f32p(out))
     return out
 
 

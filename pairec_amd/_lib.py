@@ -28,7 +28,7 @@ EXPORTS = [
     "pg_hbm_read_probe", "pg_table_screen_info", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
     "pg_features_column_index", "pg_features_num_columns", "pg_features_gather_i32_dev",
     "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev", "pg_rank_fm2t_rows", "pg_recommend_dnn3_dev", "pg_set_option",
-    "pg_table_fill_gaussian", "pg_dpp_ex", "pg_i2i_recall", "pg_online_vector_recall", "pg_fm2t_user_embedding",
+    "pg_table_fill_gaussian", "pg_table_fill_mixture", "pg_dpp_ex", "pg_i2i_recall", "pg_online_vector_recall", "pg_fm2t_user_embedding",
     "pg_fm2t_user_embedding_dev", "pg_recommend_dnn3_begin", "pg_recommend_end",
     "pg_coalescer_create", "pg_coalescer_destroy", "pg_coalescer_recall", "pg_coalescer_rank_dnn3",
     "pg_coalescer_recommend", "pg_coalescer_stats", "pg_coalescer_create_scene", "pg_coalescer_i2i_recall", "pg_coalescer_recall_l2",
@@ -50,7 +50,9 @@ class PgStats(C.Structure):
                 ("recall_rescans", C.c_uint64), ("rank_calls", C.c_uint64),
                 ("rank_items", C.c_uint64), ("sort_calls", C.c_uint64), ("sort_items", C.c_uint64),
                 ("last_recall_ms", C.c_double), ("last_rank_ms", C.c_double),
-                ("last_sort_ms", C.c_double), ("recall_predicted", C.c_uint64)]
+                ("last_sort_ms", C.c_double), ("recall_predicted", C.c_uint64),
+                ("recall_suspects", C.c_uint64), ("recall_suspect_queries", C.c_uint64), ("recall_i4m_pairs", C.c_uint64),
+                ("recall_screen_overflows", C.c_uint64)]
 
 
 class PgDppOptions(C.Structure):
@@ -162,6 +164,7 @@ def load():
         "pg_recommend_dnn3_dev": [vp, vp, vp, vp, C.c_char_p, vp, u32, u32, vp, vp, vp, vp, vp, vp],
         "pg_set_option": [vp, C.c_char_p, C.c_char_p],
         "pg_table_fill_gaussian": [vp, vp, u64, C.c_float],
+        "pg_table_fill_mixture": [vp, vp, u64, C.c_uint32, C.c_float],
         "pg_i2i_recall": [vp, vp, vp, u32, vp, u32, vp, vp, vp],
         "pg_online_vector_recall": [vp, vp, vp, vp, u32, u32, vp, vp, vp],
         "pg_fm2t_user_embedding": [vp, vp, vp, u32, vp],

@@ -28,7 +28,7 @@ static void knobs_from_env(Knobs* k) {
     k->i4m_max_queries = (uint32_t)num("PG_I4M_MAX_QUERIES", 64);
     k->i4m_min_queries = (uint32_t)num("PG_I4M_MIN_QUERIES", 3);
     k->i4m_max_lambda = num("PG_I4M_MAX_LAMBDA", 2.2);
-    k->i4m_max_pairs = num("PG_I4M_MAX_PAIRS", 8.0e6);
+    k->i4m_max_pairs = num("PG_I4M_MAX_PAIRS", 2.4e7);
     k->rank_no_ws = flag("PG_RANK_NO_WS");
     k->rank_sort_max = (uint32_t)num("PG_RANK_SORT_MAX", 8);
     k->sort_lds = flag("PG_SORT_LDS");

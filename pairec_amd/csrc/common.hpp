@@ -72,7 +72,7 @@ struct Knobs {
     uint32_t i4m_min_queries = 3;  // PG_I4M_MIN_QUERIES: smallest batch it serves (below: recall_i4.hip's vector-ALU screen, exact re-scoring of all its suspects)
     uint32_t i4m_max_queries = 64; // PG_I4M_MAX_QUERIES: largest batch the 4-bit matrix-pipe screen serves (<= kI4mMaxQueries)
     double i4m_max_lambda = 2.2;   // PG_I4M_MAX_LAMBDA: largest pg_table::lam4 it is used for
-    double i4m_max_pairs = 8.0e6;  // PG_I4M_MAX_PAIRS: ... and the most (row, query) pairs per pass its 4-bit stage may be expected to pass on
+    double i4m_max_pairs = 2.4e7;  // PG_I4M_MAX_PAIRS: ... and the most (row, query) pairs per pass its 4-bit stage may be expected to pass on
     uint32_t i4_min_rows = 1u << 22; // PG_I4_MIN_ROWS: smallest table the 4-bit screen is built for
     double i4_max_lambda = 1.7;    // PG_I4_MAX_LAMBDA: largest pg_table::lam4 the 4-bit screen is used for
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
@@ -339,6 +339,7 @@ struct RecallJob {
     bool pred_observe = false;              // the table has a model: this job contributes its observed quantiles
     bool observed = false;                  // ... and the enqueued plan did
     double z_lo = 0.0;
+    bool susp_stat = false;                 // the enqueued plan reports its suspect counts with the status words
     bool refined = false;                   // the enqueued pilot plan raised its thresholds after the first quarter
     int n_plans = 0, next_plan = 0, enqueued_plan = -1;
     uint32_t stride = 1, sample_blocks = 0, k_pilot = 0, perm_mul = 1;

@@ -1823,6 +1823,17 @@ __global__ __launch_bounds__(256) void final_rank_kernel(const uint64_t* __restr
 }
 
 // after a refined pilot plan: thr = score of the K-th best candidate kept (select_kernel), thr_ref = the raised threshold
+// statistics: the suspects the plan's last screened launch handed to the exact re-scoring, summed over the queries
+__global__ void susp_sum_kernel(const uint32_t* __restrict__ cnt, uint32_t nq, uint32_t* __restrict__ out) {
+    uint32_t v = threadIdx.x < nq ? cnt[threadIdx.x] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __shared__ uint32_t s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = s[0] + s[1] + s[2] + s[3];
+}
+
 __global__ void refine_verify_kernel(const float* __restrict__ thr, const float* __restrict__ thr_ref,
                                      uint32_t* __restrict__ count, uint32_t nq) {
     const uint32_t q = threadIdx.x;
@@ -2123,8 +2134,8 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     rs->q4 = (uint32_t*)(rs->qscale + kMaxQueries);      // 4 x 128 B + 4 x 16 B
     rs->thr_ref = (float*)(rs->q4 + 160);                // [kMaxQueries]
     rs->pred_ms = rs->thr_ref + kMaxQueries;             // [kMaxQueries][2]
-    rs->susp2_cnt = (uint32_t*)(rs->pred_ms + 2 * kMaxQueries);                       // [kI4mMaxQueries] + one statistics word
-    rs->q4m = (uint32_t*)(((uintptr_t)(rs->susp2_cnt + kI4mMaxQueries + 1) + 63) & ~(uintptr_t)63);   // (16-byte fragment loads)
+    rs->susp2_cnt = (uint32_t*)(rs->pred_ms + 2 * kMaxQueries);                       // [kI4mMaxQueries] + two statistics words
+    rs->q4m = (uint32_t*)(((uintptr_t)(rs->susp2_cnt + kI4mMaxQueries + 2) + 63) & ~(uintptr_t)63);   // (16-byte fragment loads)
     void* c;
     if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4) + (size_t)kI4mMaxQueries * cap * 4, &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
@@ -2733,9 +2744,11 @@ int recall_job_prepare(RecallJob* j) {
     if (screen && !j->l2 && t->dim == 128 && t->shadow_is_i8 && j->nq >= kn.i4m_min_queries && j->nq <= kI4mMaxQueries &&
         j->nq <= kn.i4m_max_queries && j->plans[0] == kPilot && !kn.no_screen_i4m && rows >= kn.i4_min_rows) {
         if ((rc = ensure_table_i4(ctx, t))) return rc;
-        // every pair the 4-bit stage lets through is one random 128-B read (~14 G/s measured): beyond i4m_max_pairs of them per pass
+        // every pair the 4-bit stage lets through is one random 128-B read (~35 G/s in rescreen8_kernel): beyond i4m_max_pairs of them per pass
         // the int8 shadow's wider stream is the shorter pass.  The count per query is the table's own running average.
-        j->screen4m = t->i4_ok && (double)t->lam4 <= kn.i4m_max_lambda && (double)t->i4m_pairs * j->nq <= kn.i4m_max_pairs;
+        // (two query blocks: the 4-bit stage is vector-ALU-bound, 1.7 instead of 1.2 ms per 100 M rows — the budget shrinks with the gain)
+        j->screen4m = t->i4_ok && (double)t->lam4 <= kn.i4m_max_lambda &&
+                      (double)t->i4m_pairs * j->nq <= kn.i4m_max_pairs * (j->nq > 32 ? 0.45 : 1.0);
         if (j->screen4m) j->screen4 = false;
     }
     // the threshold model: observe with every pilot-plan batch of a big int8-screened table; predict once the observed
@@ -2788,6 +2801,8 @@ struct PlanRun {                     // the launches of one plan (helper of reca
     bool susp_clean = true;          // recall_init_kernel left the suspect counters at zero: the plan's first screened launch skips its memset
     bool no_i8 = false;              // the plan launches no int8 / bf16 screen (thresholds predicted, full pass on the 4-bit shadow):
                                      // its integer-unit thresholds are not needed
+    bool last_full_screened = false; // the plan's last scan launch was a screened one ...
+    bool last_was_i4m = false;       // ... of the mid-batch kind (its survivors are counted in susp2_cnt)
     bool exact_chunks = false;       // every chunk on the exact scan: the safe plan of a FILTERED recall.  Its thresholds stay open until K
                                      // admitted rows were seen — under a selective filter, for many chunks — and a screened chunk with open
                                      // thresholds makes every row a suspect of every query: the hit-record regions are sized for the bounded
@@ -2868,6 +2883,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             }
             if (!susp_clean) PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
             susp_clean = false;
+            last_full_screened = true;
             // the full pass of a small batch streams the 4-bit shadow; its few suspect lists share the whole buffer
             // (whole 64-row groups: a range starts on an even block and ends on one or at the table's end)
             const bool i4 = j->screen4 && allow_i4 && st == 1 && (rb & 1) == 0 && (((rb + cb) & 1) == 0 || rb + cb == j->nblocks);
@@ -2882,7 +2898,9 @@ struct PlanRun {                     // the launches of one plan (helper of reca
                 // stage-1 suspects share the whole buffer ([nq][4 cap]); what passes the int8 stage lands in susp2 ([nq][cap])
                 if ((rc2 = screen4m_launch(ctx, t, rs, nq, (uint32_t)r_begin, (uint32_t)r_end, rs.cap * (uint32_t)(kMaxQueries / kI4mMaxQueries)))) return rc2;
                 j->scan_bytes += (r_end - r_begin) * 68;
+                last_was_i4m = true;
             } else {
+                last_was_i4m = false;
                 if ((rc2 = dispatch_screen(ctx, t->dim, t->shadow_is_i8, sa))) return rc2;
                 if (records) {
                     screen_decode_kernel<<<rec_waves / 8 + sa.rec_pool_cap / kRecPoolSlice, 1024, 0, ctx->stream>>>(
@@ -2909,6 +2927,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
                                                                  rs.cnt, rs.cand[cur], rs.overflow, scap, j->rows, nullptr, nullptr, j->filter);
             PG_HIP(hipGetLastError());
         } else {
+            last_full_screened = false;
             // exact scan (the first chunk of a screened recall too: its threshold is still -inf,
             // every row is a candidate and there is nothing to screen) in groups of <= 64 queries,
             // one launch; blockIdx.y walks the groups
@@ -3147,8 +3166,16 @@ int recall_job_enqueue(RecallJob* j) {
         PG_HIP(hipGetLastError());
         PG_HIP(hipMemcpyAsync(j->h_status + kPredStatsAt, stats, 40, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (j->screen4m)
-        PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt, rs.susp2_cnt + kI4mMaxQueries, 4, hipMemcpyDeviceToHost, ctx->stream));
+    j->susp_stat = j->screen && (plan == kPilot || plan == kPredict) && r.last_full_screened;
+    if (j->susp_stat) {
+        // [kI4mStatAt] the pairs a mid-batch pass's 4-bit stage let through (zero otherwise), [+ 1] the suspects that reached the
+        // exact re-scoring in the full pass's last launch
+        uint32_t* const st = rs.susp2_cnt + kI4mMaxQueries;
+        if (!r.last_was_i4m) PG_HIP(hipMemsetAsync(st, 0, 4, ctx->stream));
+        susp_sum_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(r.last_was_i4m ? rs.susp2_cnt : rs.susp_cnt, j->nq, st + 1);
+        PG_HIP(hipGetLastError());
+        PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt, st, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (j->d_out_count)
         PG_HIP(hipMemcpyAsync(j->d_out_count, j->d_count, 4 * j->nq, hipMemcpyDeviceToDevice, ctx->stream));
     PG_HIP(hipMemcpyAsync(j->h_status, rs.overflow, 4 * (1 + (size_t)j->nq), hipMemcpyDeviceToHost, ctx->stream));     // [overflow | counts]
@@ -3236,6 +3263,7 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
         pg_table* tm = const_cast<pg_table*>(j->t);
         std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
         if (j->h_status[0] != 0) {
+            ctx->stats.recall_screen_overflows++;
             j->screen = j->screen4 = j->screen4m = j->l2_per_row = false;
             j->pred_observe = false;
             // (... starting over at the pilot plan: on the exact scan the sample's threshold is as good as anywhere, while the
@@ -3247,7 +3275,12 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
             tm->screen_overflow_streak = 0;
         }
     }
-    if (j->screen4m && ok && (plan == kPilot || plan == kPredict)) {
+    if (j->susp_stat && ok) {
+        ctx->stats.recall_suspects += j->h_status[kI4mStatAt + 1];
+        ctx->stats.recall_suspect_queries += j->nq;
+        ctx->stats.recall_i4m_pairs += j->h_status[kI4mStatAt];
+    }
+    if (j->screen4m && j->susp_stat && ok) {
         // what the 4-bit stage lets through per query decides up to which batch size it beats the int8 shadow (recall_job_prepare)
         pg_table* tm = const_cast<pg_table*>(j->t);
         std::lock_guard<std::mutex> build_guard(g_stats_build_mu);

@@ -46,6 +46,53 @@ __global__ __launch_bounds__(256) void table_fill_synth_kernel(float* __restrict
     }
 }
 
+// Clustered rows (the third benchmark distribution: trained embeddings cluster, service/recall/hologres_vector_recall.go:23 runs
+// against such tables): row g belongs to centre c = splitmix64((seed + 2) ^ g) mod n_centres; the centre is SURVEY.md 8d's
+// normalised synthetic row c of seed + 1; x = centre + noise_scale * u, u uniform in [-1, 1) from seed + 3 (noise_scale =
+// sigma sqrt(3 / dim): the noise vector's norm is ~ sigma, the centre's is 1); the row is then normalised like the synthetic
+// ones.  No transcendental: oracle/oracle.c (orc_synth_mixture_rows) regenerates any slice bit for bit.
+template <int DIM>
+__global__ __launch_bounds__(256) void table_fill_mixture_kernel(float* __restrict__ out, uint64_t rows, uint64_t row_offset,
+                                                                uint64_t seed, uint32_t n_centres, float noise_scale) {
+    __shared__ float inv_c[256], inv_x[256];
+    __shared__ uint32_t cen[256];
+    const uint64_t r0 = (uint64_t)blockIdx.x * 256;
+    const uint64_t r = r0 + threadIdx.x;
+    if (r < rows) {
+        const uint64_t g = row_offset + r;
+        const uint32_t c = (uint32_t)(splitmix64((seed + 2) ^ g) % n_centres);
+        float ss = 0.0f;
+        for (int k = 0; k < DIM; ++k) {
+            const float v = synth_value(seed + 1, c, k, DIM);
+            ss = __fmaf_rn(v, v, ss);
+        }
+        const float ic = 1.0f / sqrtf(ss);
+        float sx = 0.0f;
+        for (int k = 0; k < DIM; ++k) {
+            const float x = __fmaf_rn(synth_value(seed + 3, g, k, DIM), noise_scale, synth_value(seed + 1, c, k, DIM) * ic);
+            sx = __fmaf_rn(x, x, sx);
+        }
+        cen[threadIdx.x] = c;
+        inv_c[threadIdx.x] = ic;
+        inv_x[threadIdx.x] = 1.0f / sqrtf(sx);
+    }
+    __syncthreads();
+    constexpr int QPR = DIM / 4, RPI = 256 / QPR;
+    const int q = threadIdx.x % QPR;
+    for (int rr = threadIdx.x / QPR; rr < 256; rr += RPI) {
+        const uint64_t row = r0 + rr;
+        if (row >= rows) break;
+        const uint64_t g = row_offset + row;
+        const uint32_t c = cen[rr];
+        const float ic = inv_c[rr], ix = inv_x[rr];
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = __fmaf_rn(synth_value(seed + 3, g, 4 * q + e, DIM), noise_scale, synth_value(seed + 1, c, 4 * q + e, DIM) * ic) * ix;
+        *reinterpret_cast<float4*>(out + row * DIM + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // Gaussian rows for the second benchmark distribution (real embeddings look Gaussian, not uniform): Box-Muller on
 // one splitmix64 draw per element, z = sqrt(-2 ln u1) cos(2 pi u2) with u1 from the draw's upper 53 bits (tails to
 // 8.5 sigma) evaluated in fp64, value = (float)(z * scale).  Device-defined: tests compare against the rows they
@@ -171,6 +218,24 @@ int pg_table_fill_gaussian(pg_ctx* ctx, pg_table* t, uint64_t seed, float sigma)
     const uint64_t n = t->rows * (uint64_t)t->dim;
     pg::table_fill_gauss_kernel<<<(uint32_t)ctx->num_cus * 16, 256, 0, ctx->stream>>>(t->d, n, t->row_offset * (uint64_t)t->dim, seed,
                                                                                      (double)sigma);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    t->stats_valid = false;
+    t->screen_overflow_streak = t->screen_backoff = 0;
+    t->nx_valid = false;
+    return PG_OK;
+}
+
+int pg_table_fill_mixture(pg_ctx* ctx, pg_table* t, uint64_t seed, uint32_t n_centres, float sigma) {
+    PG_REQUIRE(ctx && t, "pg_table_fill_mixture: NULL argument");
+    PG_REQUIRE(n_centres >= 1 && sigma >= 0.0f && sigma < 1e30f, "pg_table_fill_mixture: n_centres >= 1, sigma >= 0 and finite");
+    PG_REQUIRE(t->dim == 64 || t->dim == 128, "pg_table_fill_mixture: dim=%u unsupported (64 or 128)", t->dim);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    pg::TableWrite w(t);
+    const uint32_t blocks = (uint32_t)((t->rows + 255) / 256);
+    const float ns = sigma * sqrtf(3.0f / (float)t->dim);
+    if (t->dim == 64) pg::table_fill_mixture_kernel<64><<<blocks, 256, 0, ctx->stream>>>(t->d, t->rows, t->row_offset, seed, n_centres, ns);
+    else pg::table_fill_mixture_kernel<128><<<blocks, 256, 0, ctx->stream>>>(t->d, t->rows, t->row_offset, seed, n_centres, ns);
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(ctx->stream));
     t->stats_valid = false;

@@ -140,6 +140,10 @@ class Table:
     def fill_gaussian(self, seed: int, sigma: float = 1.0):
         _lib.check(self.ctx.L.pg_table_fill_gaussian(self.ctx.h, self.h, seed, float(sigma)))
 
+    def fill_mixture(self, seed: int, n_centres: int, sigma: float):
+        """clustered rows: n_centres centres on the unit sphere, within-cluster noise of norm ~ sigma, normalised"""
+        _lib.check(self.ctx.L.pg_table_fill_mixture(self.ctx.h, self.h, seed, int(n_centres), float(sigma)))
+
     def upload(self, rows: np.ndarray, row0: int = 0):
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         assert rows.ndim == 2 and rows.shape[1] == self.dim

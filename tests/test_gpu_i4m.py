@@ -23,7 +23,7 @@ def small_table_opts(ctx):
         ctx.set_option(name, v)
     yield ctx
     for name, v in (("i4_min_rows", str(1 << 22)), ("pilot_fraction", "0"), ("i4m_max_lambda", "2.2"), ("i4_max_lambda", "1.7"),
-                    ("no_screen_i4m", "0"), ("i4m_max_queries", "64"), ("i4m_max_pairs", "8e6")):
+                    ("no_screen_i4m", "0"), ("i4m_max_queries", "64"), ("i4m_max_pairs", "2.4e7")):
         ctx.set_option(name, v)
 
 
