@@ -685,6 +685,7 @@ typedef struct {
      * 4-bit stage handed to its int8 stage; screened plans that overflowed (rows crowded within the screen's error of the K-th
      * score) and finished on the exact scan */
     uint64_t recall_suspects, recall_suspect_queries, recall_i4m_pairs, recall_screen_overflows;
+    uint64_t recall_record_growths;     /* batches re-run with larger hit-record areas (the table keeps them) */
 } pg_stats_t;
 int pg_stats(pg_ctx* ctx, pg_stats_t* out);
 /* time (ms) of the dominant kernel of the last pg_recall_* call, measured with HIP events on the

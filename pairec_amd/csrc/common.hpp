@@ -140,6 +140,7 @@ struct pg_table {
     float rmax4 = 0.0f;          // max over rows of ||x - x^|| (upper bound)
     float lam4 = 0.0f;           // mean residual term in units of the score spread (decides whether the shadow pays)
     float i4m_pairs = 0.0f;      // recall_i4m.hip: running average of the (row, query) pairs its 4-bit stage lets through, per query
+    uint32_t rec_scale = 0;      // recall.hip: the 256-query pass's hit-record areas, x their default size (0 = 1; doubled when a batch overflows them)
     uint32_t prefix_failures = 0; // batches whose refined thresholds failed verification for most queries (ordered rows): two → no refinement
     // Threshold predictor (recall.hip, DESIGN.md 4.1, plan 0): a Gaussian model of a query's scores over the rows — mean
     // vector and covariance from a row sample, built with the statistics — and the quantile z = (K-th best score −

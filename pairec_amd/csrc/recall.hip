@@ -456,6 +456,7 @@ struct ScreenArgs {
 // without the LDS stage, were measured: 4.35 vs 3.1 ms per pass — with stores in flight in every second block the
 // counted waits over-wait all the time and the ring runs one piece deep.)
 constexpr uint32_t kRecBytes = 80;
+constexpr uint32_t kRecOvfWord = 1 + kMaxQueries + 1;       // rs.overflow[kRecOvfWord]: the overflow was one of the hit-record areas (they can grow: pg_table::rec_scale)
 // make SCAN_EXTRA=-DPG_SCREEN_PROFILE: per-phase cycle counts of the query-halves loop, printed by launch_screen (developer aid)
 #ifdef PG_SCREEN_PROFILE
 #define SP_MARK(i) { const uint64_t tn = __builtin_readcyclecounter(); sp[i] += tn - sp_t; sp_t = tn; }
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void screen_kernel(ScreenArg
                 if (lane == 0) g = atomicAdd(&a.rec_cnt[a.rec_waves], rec_st);
                 g = __builtin_amdgcn_readfirstlane(g);
                 if (g + rec_st > a.rec_pool_cap) {
-                    if (lane == 0) *a.overflow = 1u;
+                    if (lane == 0) { *a.overflow = 1u; a.overflow[kRecOvfWord] = 1u; }
                 } else {
                     char* const dst = a.rec_pool + (size_t)g * kRecBytes;
                     for (uint32_t o = lane * 16; o < rec_st * kRecBytes; o += 1024)
@@ -1850,7 +1851,7 @@ __global__ void recall_init_kernel(const float* __restrict__ queries, uint32_t n
         cnt[i] = 0;
         cnt[kMaxQueries + i] = 0;                          // susp_cnt (RecallScratch: right behind cnt)
     }
-    if (i == 0) *overflow = 0;
+    if (i == 0) { *overflow = 0; overflow[kRecOvfWord] = 0; }
 }
 
 // squared-Euclidean recall: |x|^2 of every row and |q|^2 of every query as k-ascending fmaf chains (the specification's), and
@@ -2190,6 +2191,7 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     if (t->stats_valid || t->shadow_failed) return PG_OK;
     t->i4_ok = t->i4_failed = false;                  // the 4-bit shadow (recall_i4.hip) follows the rows too
     t->i4m_pairs = 0.0f;
+    t->rec_scale = 0;
     t->pred_model = false;                            // ... and the threshold model
     t->prefix_failures = 0;
     if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
@@ -2420,6 +2422,7 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
 // batch are queued behind its recall without the GPU ever waiting for the host.
 // ---------------------------------------------------------------------------------------------
 enum RecallPlan { kPilot = 0, kGrow = 1, kSafe = 2, kPredict = 3 };
+constexpr uint32_t kMaxRecScale = 16;         // hit-record areas up to 16 x their default size (80 B x 123 M records = 9.8 GB per context at K = 5 000)
 
 static inline uint64_t rs_cap_bound(uint32_t k) { return (uint64_t)k + kCandSlack; }
 
@@ -2856,7 +2859,8 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             if (records) {
                 // a region per wave: four times the share of 256 x K suspects a wave expects, never below the records the safe
                 // plan's bounded chunks can leave in one region
-                uint32_t cap_w = (uint32_t)(((uint64_t)kMaxQueries * j->k * 4 / rec_waves + 255) / 256 * 256);
+                const uint64_t rsc = t->rec_scale ? t->rec_scale : 1;     // (tables whose batches overflowed these areas got larger ones)
+                uint32_t cap_w = (uint32_t)(((uint64_t)kMaxQueries * j->k * 4 * rsc / rec_waves + 255) / 256 * 256);
                 // (the safe plan's chunk — kCandSlack / 2 rows — with EVERY row a suspect of every query, e.g. a table in ascending
                 //  score order: 8 x 64 records per block, and the blocks of a SIMD's pair of waves split as screen_kernel splits
                 //  them — the larger share decides.  Sized for an even split, the early wave's fifth block went to the spill pool,
@@ -2869,7 +2873,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
                 const uint32_t floor_w = eb * 512;
                 if (cap_w < floor_w) cap_w = floor_w;
                 // + a spill pool for tables whose best rows sit together: room for all of 256 x 2 K suspects
-                const uint32_t pool_cap = (uint32_t)(((uint64_t)kMaxQueries * j->k * 2 + kRecPoolSlice - 1) / kRecPoolSlice * kRecPoolSlice);
+                const uint32_t pool_cap = (uint32_t)(((uint64_t)kMaxQueries * j->k * 2 * rsc + kRecPoolSlice - 1) / kRecPoolSlice * kRecPoolSlice);
                 const size_t head = ((size_t)(rec_waves + 1) * 4 + 255) & ~(size_t)255;
                 void* p;
                 if ((rc2 = scratch_reserve(ctx, 11, head + ((size_t)rec_waves * cap_w + pool_cap) * kRecBytes, &p))) return rc2;
@@ -3166,6 +3170,7 @@ int recall_job_enqueue(RecallJob* j) {
         PG_HIP(hipGetLastError());
         PG_HIP(hipMemcpyAsync(j->h_status + kPredStatsAt, stats, 40, hipMemcpyDeviceToHost, ctx->stream));
     }
+    PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt + 2, rs.overflow + kRecOvfWord, 4, hipMemcpyDeviceToHost, ctx->stream));
     j->susp_stat = j->screen && (plan == kPilot || plan == kPredict) && r.last_full_screened;
     if (j->susp_stat) {
         // [kI4mStatAt] the pairs a mid-batch pass's 4-bit stage let through (zero otherwise), [+ 1] the suspects that reached the
@@ -3262,7 +3267,15 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
         // remaining plans run on the exact scan; two such batches in a row and the table's next 64 start there.
         pg_table* tm = const_cast<pg_table*>(j->t);
         std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
-        if (j->h_status[0] != 0) {
+        if (j->h_status[0] != 0 && j->h_status[kI4mStatAt + 2] != 0 && tm->rec_scale < kMaxRecScale) {
+            // the hit-record areas of the 256-query pass were too small for this table (clustered rows: a query's whole cluster sits
+            // within the screen's error of its K-th score — tens of suspects per answer where uniform rows have two): they grow, and
+            // the same plan runs again; the table keeps the larger areas
+            tm->rec_scale = tm->rec_scale ? tm->rec_scale * 2 : 2;
+            ctx->stats.recall_record_growths++;
+            if (j->next_plan > 0) j->next_plan--;
+            if (ctx->knobs.debug_scan) fprintf(stderr, "[pg] plan %d overflowed its hit-record areas: scale -> %u, again\n", plan, tm->rec_scale);
+        } else if (j->h_status[0] != 0) {
             ctx->stats.recall_screen_overflows++;
             j->screen = j->screen4 = j->screen4m = j->l2_per_row = false;
             j->pred_observe = false;

@@ -304,6 +304,7 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->rmax4, b->rmax4);
     std::swap(a->lam4, b->lam4);
     std::swap(a->i4m_pairs, b->i4m_pairs);
+    std::swap(a->rec_scale, b->rec_scale);
     std::swap(a->prefix_failures, b->prefix_failures);
     std::swap(a->d_pred, b->d_pred);
     std::swap(a->d_nx, b->d_nx);
