@@ -81,6 +81,8 @@ struct Knobs {
     bool dpp_valu = false;         // PG_DPP_VALU: the DPP kernel matrix on the fp64 vector pipe (round-4 kernel) instead of the fp64 matrix pipe (A/B; same bits)
     bool rank_t3 = false;          // PG_RANK_T3: the benchmark's bf16 DNN3 on the three-waves-per-SIMD kernel (rank_t3.hip) instead of rank_ws.hip (A/B)
     bool fm2t_irs = false;         // PG_FM2T_IRS: cfg 4's item-record rank on the producer / consumer kernel (rank_ir.hip) instead of rank_is.hip (A/B)
+    uint32_t max_rec_scale = 16;   // PG_MAX_REC_SCALE: the 256-query pass's hit-record areas grow up to this many times their default size with a table
+                                   // whose batches overflow them (16: 80 B x 123 M records = 9.8 GB per context at K = 5 000); 1 = never (exact scan instead)
     bool no_predict = false;       // PG_NO_PREDICT: never replace the pilot sample by the learned threshold model
     double predict_sigmas = 4.5;   // PG_PREDICT_SIGMAS: margin of the predicted threshold, in standard deviations of the observed quantile
     uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way

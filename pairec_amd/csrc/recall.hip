@@ -2422,7 +2422,6 @@ static int dispatch_screen(pg_ctx* ctx, uint32_t dim, bool i8, const ScreenArgs&
 // batch are queued behind its recall without the GPU ever waiting for the host.
 // ---------------------------------------------------------------------------------------------
 enum RecallPlan { kPilot = 0, kGrow = 1, kSafe = 2, kPredict = 3 };
-constexpr uint32_t kMaxRecScale = 16;         // hit-record areas up to 16 x their default size (80 B x 123 M records = 9.8 GB per context at K = 5 000)
 
 static inline uint64_t rs_cap_bound(uint32_t k) { return (uint64_t)k + kCandSlack; }
 
@@ -3267,7 +3266,7 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
         // remaining plans run on the exact scan; two such batches in a row and the table's next 64 start there.
         pg_table* tm = const_cast<pg_table*>(j->t);
         std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
-        if (j->h_status[0] != 0 && j->h_status[kI4mStatAt + 2] != 0 && tm->rec_scale < kMaxRecScale) {
+        if (j->h_status[0] != 0 && j->h_status[kI4mStatAt + 2] != 0 && (tm->rec_scale ? tm->rec_scale : 1) < ctx->knobs.max_rec_scale) {
             // the hit-record areas of the 256-query pass were too small for this table (clustered rows: a query's whole cluster sits
             // within the screen's error of its K-th score — tens of suspects per answer where uniform rows have two): they grow, and
             // the same plan runs again; the table keeps the larger areas

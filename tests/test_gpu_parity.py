@@ -864,8 +864,10 @@ def test_recall_all_ties_falls_through_every_plan(ctx):
 
 def test_recall_rows_crowded_within_the_screens_error_move_to_the_exact_scan(ctx):
     """Rows nearly collinear, queries along them: a per cent of the table lies within the int8 margin of every query's K-th
-    score, the screened plan's lists overflow.  The job finishes on the exact scan (not chunk by chunk through the same crowd),
-    and after two such batches the table's recalls start there; an upload resets that.  Answers exact throughout."""
+    score, the screened plan's hit-record areas overflow.  Round 6: the areas grow with such a table (pg_table::rec_scale) and the
+    screened pass holds from then on; with the growth switched off (max_rec_scale 1, the round-3 behaviour) the job finishes on
+    the exact scan (not chunk by chunk through the same crowd), and after two such batches the table's recalls start there; an
+    upload resets either.  Answers exact throughout."""
     rng = np.random.default_rng(3)
     n, d, k, nq = 3_000_000, 128, 2000, 256
     v = rng.standard_normal(d).astype(np.float32)
@@ -875,17 +877,32 @@ def test_recall_rows_crowded_within_the_screens_error_move_to_the_exact_scan(ctx
     t.upload(tab)
     q = (v[None] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
     orow, osc = o.recall_topk(tab, q[:2], k)
-    plans = []
-    for _ in range(4):
+
+    def four_batches():
+        plans, grown, fell = [], [], []
+        for _ in range(4):
+            s0 = ctx.stats()
+            rows, sc, cnt = t.recall_topk(q, k)
+            s1 = ctx.stats()
+            plans.append(s1.recall_rescans - s0.recall_rescans)
+            grown.append(s1.recall_record_growths - s0.recall_record_growths)
+            fell.append(s1.recall_screen_overflows - s0.recall_screen_overflows)
+            assert np.array_equal(rows[:2], orow) and np.array_equal(bits(sc[:2]), bits(osc)) and cnt.tolist() == [k] * nq
+        return plans, grown, fell
+    ctx.set_option("max_rec_scale", 1)
+    try:
+        plans, grown, fell = four_batches()
+        assert plans[0] >= 1 and plans[1] >= 1 and plans[2] == 0 and plans[3] == 0 and sum(grown) == 0 and fell[0] >= 1, (plans, grown, fell)
+        t.upload(tab[:1000], 0)                                         # new contents: the screen gets its chance again
         before = ctx.stats().recall_rescans
-        rows, sc, cnt = t.recall_topk(q, k)
-        plans.append(ctx.stats().recall_rescans - before)
-        assert np.array_equal(rows[:2], orow) and np.array_equal(bits(sc[:2]), bits(osc)) and cnt.tolist() == [k] * nq
-    assert plans[0] >= 1 and plans[1] >= 1 and plans[2] == 0 and plans[3] == 0, plans
-    t.upload(tab[:1000], 0)                                             # new contents: the screen gets its chance again
-    before = ctx.stats().recall_rescans
-    t.recall_topk(q, k)
-    assert ctx.stats().recall_rescans > before
+        t.recall_topk(q, k)
+        assert ctx.stats().recall_rescans > before
+    finally:
+        ctx.set_option("max_rec_scale", 16)
+    t.upload(tab[:1000], 0)
+    plans, grown, fell = four_batches()
+    assert grown[0] >= 1 and sum(grown[1:]) == 0 and sum(fell) == 0 and plans[1:] == [0, 0, 0], (plans, grown, fell)
+    assert ctx.last_scan_kernel()[1] <= n * 128 * 1.2                   # ... and the pass streams the int8 shadow, not the fp32 rows
     t.destroy()
 
 
