@@ -36,6 +36,7 @@ static void knobs_from_env(Knobs* k) {
     k->rank_t3 = flag("PG_RANK_T3");
     k->dpp_valu = flag("PG_DPP_VALU");
     k->max_rec_scale = (uint32_t)num("PG_MAX_REC_SCALE", 16);
+    k->coalescer_rejoin = !flag("PG_COALESCER_NO_REJOIN");
     k->no_predict = flag("PG_NO_PREDICT");
     k->predict_sigmas = num("PG_PREDICT_SIGMAS", 4.5);
     k->predict_min_rows = (uint32_t)num("PG_PREDICT_MIN_ROWS", (double)(1u << 22));
@@ -176,6 +177,7 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "rank_t3") k.rank_t3 = b;
     else if (n == "dpp_valu") k.dpp_valu = b;
     else if (n == "max_rec_scale") k.max_rec_scale = v >= 1 ? (uint32_t)v : 1u;
+    else if (n == "coalescer_rejoin") k.coalescer_rejoin = b;
     else if (n == "no_predict") k.no_predict = b;
     else if (n == "predict_sigmas") k.predict_sigmas = v;
     else if (n == "predict_min_rows") k.predict_min_rows = (uint32_t)v;

@@ -83,6 +83,7 @@ struct Knobs {
     bool fm2t_irs = false;         // PG_FM2T_IRS: cfg 4's item-record rank on the producer / consumer kernel (rank_ir.hip) instead of rank_is.hip (A/B)
     uint32_t max_rec_scale = 16;   // PG_MAX_REC_SCALE: the 256-query pass's hit-record areas grow up to this many times their default size with a table
                                    // whose batches overflow them (16: 80 B x 123 M records = 9.8 GB per context at K = 5 000); 1 = never (exact scan instead)
+    bool coalescer_rejoin = true;  // PG_COALESCER_NO_REJOIN clears it: after a completion a waiting partial batch is held for the callers just answered
     bool no_predict = false;       // PG_NO_PREDICT: never replace the pilot sample by the learned threshold model
     double predict_sigmas = 4.5;   // PG_PREDICT_SIGMAS: margin of the predicted threshold, in standard deviations of the observed quantile
     uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way
