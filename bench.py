@@ -1401,6 +1401,9 @@ def shard_sub_leg(pa, o, torch, dist, coll, rank, world, device, args, R, K, pre
     elapsed = float(t.item())
     out = {"value": R * K * args.steps / elapsed, "unit": "ranked items/s", "ms_per_step": elapsed / args.steps * 1e3,
            "scaling": "weak", "ranks_agree": agree, "lists_sorted": fused_sorted, "ok": bool(agree and fused_sorted),
+           # the first exchange carries the best K/G + 6 sqrt(K/G) + 8 entries per request (pairec_amd/dist.py); a shard whose
+           # last sent entry lands inside the merged top-K makes the step repeat it with the full lists
+           "exchange": dict(getattr(eng, "exchange_stats", None) or {}, unpruned_bytes_per_shard=R * K * 12),
            "config": {"workload": "configs[4]: %d x %d fp32 table in %d row-range shards (%d rows each), %d requests x top-%d -> "
                                   "all_gather merge -> owner-computes DNN3 rank (%s) -> all_reduce scores -> fuse -> sort -> "
                                   "DPPSort(%d candidates, page %d, window %d, reduce_scatter rows + all_gather picks)"
@@ -1750,6 +1753,7 @@ def main():
             shard_sanity = {"ranks_agree": ranks_agree(torch, coll, world, last),
                             "lists_sorted": bool((torch.gather(last[1], 1, last[2].long()).diff(dim=1) <= 0).all().item())}
         shard_sanity["ok"] = shard_sanity["ranks_agree"] and shard_sanity["lists_sorted"]
+        shard_sanity["exchange"] = dict(getattr(eng, "exchange_stats", None) or {}, unpruned_bytes_per_shard=R * K * 12)
     if os.environ.get("PG_BENCH_STEPTIMES"):          # developer aid
         print("scan ms:", " ".join("%.2f" % x for x in scan_ms), "| rescans", ctx.stats().recall_rescans, file=sys.stderr)
     st = ctx.stats()

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import oracle as o                       # noqa: E402
-from pairec_amd.dist import shard_range, sharded_step  # noqa: E402
+from pairec_amd.dist import shard_range, sharded_step, exchange_width  # noqa: E402
 
 N_ROWS, DIM, K, NQ = 6001, 64, 300, 5
 
@@ -116,17 +116,29 @@ class CpuEngine:
 PAGE, DPP = 20, {"candidates": 60, "alpha": 1.0, "window": 10}
 
 
-def _worker(rank, world, port, q):
+def _table(case):
+    """random: rows spread over the shards at random (no shard's share of an answer comes near its exchange width);
+    head_shard: the first shard's rows are three times as long, so every answer sits in it entirely; ties: every row is the
+    same vector — every score ties, the order is the row order, and the answer is the first K rows of the first shard."""
+    tab = o.synth_rows(o.SEED_TABLE, 0, N_ROWS, DIM)
+    if case == "head_shard":
+        tab[:N_ROWS // 4] *= np.float32(3.0)
+    elif case == "ties":
+        tab[:] = tab[0]
+    return tab
+
+
+def _worker(rank, world, port, q, case="random", prune=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        tab = o.synth_rows(o.SEED_TABLE, 0, N_ROWS, DIM)
+        tab = _table(case)
         b, e = shard_range(N_ROWS, world, rank)
         eng = CpuEngine(tab[b:e], b, o.Dnn3Weights())
         queries = torch.from_numpy(o.synth_rows(o.SEED_QUERY, 0, NQ, DIM))
-        rows, fused, order, page = sharded_step(eng, dist if world > 1 else None, torch, queries, NQ, K, PAGE, DPP)
-        q.put((rank, rows.numpy(), fused.numpy(), order.numpy(), page.numpy()))
+        rows, fused, order, page = sharded_step(eng, dist if world > 1 else None, torch, queries, NQ, K, PAGE, DPP, prune=prune)
+        q.put((rank, rows.numpy(), fused.numpy(), order.numpy(), page.numpy(), getattr(eng, "exchange_stats", None)))
     finally:
         dist.destroy_process_group()
 
@@ -161,11 +173,11 @@ def _free_port():
     return p
 
 
-def _run(world):
+def _run(world, case="random", prune=True):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, case, prune)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda x: x[0])
@@ -204,7 +216,8 @@ def test_sharded_step_world2_equals_single():
     single = _run(1)[0]
     two = _run(2)
     # every rank ends with the same answer, and it is the single-shard answer
-    for rank, rows, fused, order, page in two:
+    for rank, rows, fused, order, page, st in two:
+        assert st["round2_steps"] == 0 and st["merge_entries_per_request"] == 2 * exchange_width(K, 2) < 2 * K
         assert np.array_equal(rows, single[1]), rank
         assert np.array_equal(fused.view(np.uint64), single[2].view(np.uint64)), rank
         assert np.array_equal(order, single[3]), rank
@@ -219,3 +232,34 @@ def test_sharded_step_world2_equals_single():
         pg_ = single[4][qi].tolist()
         assert len(set(pg_)) == PAGE and set(pg_) <= set(head)
     assert any(single[4][qi].tolist() != single[3][qi][:PAGE].tolist() for qi in range(NQ))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,case", [(2, "head_shard"), (4, "head_shard"), (2, "ties"), (4, "random")])
+def test_pruned_exchange_is_exact_against_adversarial_shards(world, case):
+    """The first exchange carries the best K/G + 6 sqrt(K/G) + 8 entries per request and shard (dist.exchange_width).  A shard
+    that holds the whole answer — longer rows, or every score tied so that the lowest row ids win — makes every rank repeat the
+    exchange with the full lists (counted); rows spread at random never do.  Either way every rank ends with the single-table
+    answer, bit for bit, the same as with the pruning off."""
+    single = _run(1, case)[0]
+    for prune in (True, False):
+        res = _run(world, case, prune)
+        for rank, rows, fused, order, page, st in res:
+            assert np.array_equal(rows, single[1]), (rank, prune)
+            assert np.array_equal(fused.view(np.uint64), single[2].view(np.uint64)), (rank, prune)
+            assert np.array_equal(order, single[3]) and np.array_equal(page, single[4]), (rank, prune)
+            assert st["steps"] == 1
+            if not prune:
+                assert st["round2_steps"] == 0 and st["merge_entries_per_request"] == world * K
+            elif case == "random":
+                assert st["round2_steps"] == 0 and st["merge_entries_per_request"] == world * exchange_width(K, world)
+            else:
+                assert st["round2_steps"] == 1 and st["round2_shards"] >= 1, st
+    tab = _table(case)
+    g_rows, _ = o.recall_topk(tab, o.synth_rows(o.SEED_QUERY, 0, NQ, DIM), K)
+    assert np.array_equal(single[1].astype(np.uint64), g_rows)
+
+
+def test_exchange_width():
+    assert exchange_width(5000, 8) == 783 and exchange_width(5000, 1) == 5000 and exchange_width(10, 2) == 10
+    assert 256 * exchange_width(5000, 8) * 12 <= 2.6e6          # bytes per shard and 256-request step (15.4 MB unpruned)
