@@ -132,6 +132,12 @@ def count_gpus():
         except OSError:
             pass
     if seen:
+        # (the topology ignores HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES, which the ranks honour: cap by
+        # the shortest of the lists that are set — ADVICE r5)
+        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v is not None:
+                n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
         return n
     r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
     try:
@@ -1268,7 +1274,7 @@ def oracle_step_pages(o, tab, w, q, k, top_n, dpp_c, alpha, window):
     return pages
 
 
-def preflight_ranks(pa, o, torch, dist, coll, rank, world, device, share_gpu):
+def preflight_ranks(pa, o, torch, dist, coll, rank, world, device, share_gpu, ctl=None):
     """Before anything is timed on N > 1 ranks: the sharded step of configs[4] — recall on every rank's row range, the
     all-gather merge, owner-computes rank, the all-reduced score slab, DPP over reduce-scattered rows — on a SMALL table over
     the run's own wire (RCCL with one rank per GPU; host-staged gloo when the ranks share cuda:0), against the single-table
@@ -1280,6 +1286,9 @@ def preflight_ranks(pa, o, torch, dist, coll, rank, world, device, share_gpu):
            "workload": "sharded step on a %d x %d table, %d requests, k %d, DPP %d -> page %d; f32 rank model" % (n, d, R, k, dpp_c, top_n)}
     err = ""
     agree = True
+    eng = None
+    # phase 1, local: table, model, engine.  A rank that fails here must not leave its peers inside the collectives of phase 2
+    # (they would sit there until the watchdog fires): every rank reports over the CPU control channel first
     try:
         b, e = shard_range(n, world, rank)
         ctx, _stream = shard_context(torch, pa, device)
@@ -1293,6 +1302,20 @@ def preflight_ranks(pa, o, torch, dist, coll, rank, world, device, share_gpu):
         m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
         ex = pa.Expr(RANK_EXPR)
         eng = GpuShardEngine(torch, ctx, t, m, ex, k, R)
+    except Exception as ex_:                                    # noqa: BLE001 — reported, then the run stops
+        err = "rank %d (setup): %s: %s" % (rank, type(ex_).__name__, ex_)
+    setup_bad = torch.tensor([1 if err else 0], dtype=torch.int32)
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.all_reduce(setup_bad, group=ctl)
+    if int(setup_bad.item()) != 0:
+        res.update({"pages_equal_oracle_on_every_rank": False, "ranks_agree": False, "ok": False,
+                    "error": "the set-up of the preflight failed on %d rank(s): its collective phase was skipped" % int(setup_bad.item())})
+        if err:
+            res["error_on_this_rank"] = err
+            print("[bench] preflight: %s" % err, file=sys.stderr, flush=True)
+        return res, False
+    try:
         for step, (user0, nq) in enumerate(((77, R), (500, R - 2))):
             q = o.synth_rows(o.SEED_QUERY, user0, nq, d)
             tq = torch.from_numpy(q).to(torch.device("cuda", device))
@@ -1318,9 +1341,10 @@ def preflight_ranks(pa, o, torch, dist, coll, rank, world, device, share_gpu):
     if not agree:
         err = err or "rank %d: rows / fused / order / page differ between ranks" % rank
     # every rank learns whether ANY rank failed (one int per rank over the control channel)
-    bad = torch.tensor([1 if err else 0], dtype=torch.int32, device="cpu" if share_gpu else torch.device("cuda", device))
+    bad = torch.tensor([1 if err else 0], dtype=torch.int32)
     if world > 1:
-        dist.all_reduce(bad)
+        torch.cuda.synchronize()
+        dist.all_reduce(bad, group=ctl)                         # (CPU control channel: no collective kernel on the devices)
     res["pages_equal_oracle_on_every_rank"] = int(bad.item()) == 0
     res["ranks_agree"] = agree
     res["ok"] = int(bad.item()) == 0
@@ -1635,6 +1659,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # The control channel: flags and the waits around legs that ONE rank runs over all devices (pg_group_*) go over gloo on
+        # the CPU.  An RCCL barrier is an all-reduce kernel that spins on every waiting rank's GPU — beside the persistent
+        # one-workgroup-per-CU kernels of the leg being timed.
+        ctl = None if share_gpu else dist.new_group(backend="gloo")
+
+        def cpu_barrier():
+            torch.cuda.synchronize()
+            dist.barrier(group=ctl)
 
     shard = world > 1 and args.mode == "shard"
     from pairec_amd.dist import shard_range, sharded_step, shard_context, GpuShardEngine, HostStagedCollectives
@@ -1645,15 +1677,16 @@ def main():
     if world > 1 and not args.no_preflight:
         # the first thing N > 1 ranks do: prove the sharded step on this wire against the oracle (and pg_group_* over the
         # same devices), on every rank; a failure stops the run before a number exists
-        preflight, pf_ok = preflight_ranks(pa, o, torch, dist, coll, rank, world, local_rank, share_gpu)
+        preflight, pf_ok = preflight_ranks(pa, o, torch, dist, coll, rank, world, local_rank, share_gpu, ctl)
         # pg_group_* over the same devices (rank 0; the others wait).  The modes of THIS process — replica, shard — do not go
         # through pg_group: a failure there is reported, costs the line its `group` sub-object, and does not stop the run
         # (it is fatal in --mode group / router, whose data path it is).
-        flag = torch.zeros(1, dtype=torch.int32, device="cpu" if share_gpu else torch.device("cuda", local_rank))
+        flag = torch.zeros(1, dtype=torch.int32)
         if pf_ok and rank == 0:
             preflight["group"] = preflight_group(pa, o, [0] * world if share_gpu else list(range(world)))
             flag += 0 if preflight["group"]["ok"] else 1
-        dist.all_reduce(flag)
+        torch.cuda.synchronize()
+        dist.all_reduce(flag, group=ctl)                      # (the other ranks wait on the CPU while rank 0 drives their devices)
         group_ok = pf_ok and int(flag.item()) == 0
         preflight["ok"] = pf_ok
         if not pf_ok:
@@ -1661,7 +1694,7 @@ def main():
                 print(json.dumps({"metric": "ranked items/sec, 5k-cand DNN rank", "value": None, "unit": "ranked items/s",
                                   "n_gpus": 1 if share_gpu else world, "preflight": preflight,
                                   "error": "the N > 1 parity preflight failed: nothing was timed"}))
-            dist.barrier()
+            cpu_barrier()
             dist.destroy_process_group()
             raise SystemExit(3)
     if shard:
@@ -1958,13 +1991,13 @@ def main():
             out["shard"] = shard_sub_leg(pa, o, torch, dist, coll, rank, world, 0 if share_gpu else local_rank, args, R, K, prec, blob5)
         except Exception as ex_:                                # noqa: BLE001
             out["shard"] = {"ok": False, "error": "%s: %s" % (type(ex_).__name__, ex_)}
-        dist.barrier()
+        cpu_barrier()                                         # (ranks 1.. wait on the CPU: nothing of theirs runs beside the group leg)
         if rank == 0 and (preflight is None or group_ok):
             try:
                 out["group"] = group_sub_leg(pa, o, [0] * world if share_gpu else list(range(world)), args, R, K, prec, blob5)
             except Exception as ex_:                            # noqa: BLE001
                 out["group"] = {"ok": False, "error": "%s: %s" % (type(ex_).__name__, ex_)}
-        dist.barrier()
+        cpu_barrier()
     failed = False
     if rank == 0:
         out["device"] = device_info()

@@ -245,7 +245,10 @@ int pg_expr_is_antlr(const pg_expr* e);
  * a RankScore variable naming a source reads the rewritten score, a rewrite's own variables read the un-rewritten ones
  * (the scene's "<algo>" / "<algo>_<output>" planes and current_score).  exprs[i] == NULL: the source's expression did not
  * compile — the reference logs it and scores 0 (rank_service.go:299-303,349-351).  The expressions are copied.
- * pg_expr_eval[_dev] evaluate the bare expression over caller-made variables and know nothing of rewrites.  n = 0 removes. */
+ * pg_expr_eval[_dev] evaluate the bare expression over caller-made variables and know nothing of rewrites.  n = 0 removes.
+ * ATTACH BEFORE CREATING ANY PIPELINE FROM THE EXPRESSION: a coalescer (for its lifetime) and a batch begun and not yet ended
+ * hold variable bindings sized for the rewrites present when they were made — while there is such a holder the call fails
+ * with PG_ERR_INVALID and changes nothing. */
 int pg_expr_set_score_rewrites(pg_expr* rank_score, uint32_t n, const char* const* sources, const pg_expr* const* exprs);
 const char* pg_expr_var_name(const pg_expr* e, int i);
 int pg_expr_eval(pg_ctx* ctx, const pg_expr* e, const double* vars, uint32_t n_items,

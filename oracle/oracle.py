@@ -751,8 +751,14 @@ def antlr_parse(src: str):
             pos[0] += 1
             return e
         if c == "-":
+            # (prefix minus against ^: the reference's tests never combine them and govaluate-style grammars bind the prefix
+            #  tighter than the exponent (-2^2 = 4) — refused rather than evaluated on an assumption; write -(a^b) or (-a)^b)
             pos[0] += 1
-            return ("neg", power())
+            operand = primary()
+            ws()
+            if pos[0] < len(src) and src[pos[0]] == "^":
+                raise AntlrUnsupported("-a^b: parenthesise")
+            return ("neg", operand)
         if c == "$":
             return ("param", param())
         if c.isdigit() or c == ".":

@@ -33,7 +33,6 @@ static void knobs_from_env(Knobs* k) {
     k->rank_sort_max = (uint32_t)num("PG_RANK_SORT_MAX", 8);
     k->sort_lds = flag("PG_SORT_LDS");
     k->fm2t_irs = flag("PG_FM2T_IRS");
-    k->rank_t3 = flag("PG_RANK_T3");
     k->dpp_valu = flag("PG_DPP_VALU");
     k->max_rec_scale = (uint32_t)num("PG_MAX_REC_SCALE", 16);
     k->coalescer_rejoin = !flag("PG_COALESCER_NO_REJOIN");
@@ -174,7 +173,6 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "rank_sort_max") k.rank_sort_max = (uint32_t)v;
     else if (n == "sort_lds") k.sort_lds = b;
     else if (n == "fm2t_irs") k.fm2t_irs = b;
-    else if (n == "rank_t3") k.rank_t3 = b;
     else if (n == "dpp_valu") k.dpp_valu = b;
     else if (n == "max_rec_scale") k.max_rec_scale = v >= 1 ? (uint32_t)v : 1u;
     else if (n == "coalescer_rejoin") k.coalescer_rejoin = b;

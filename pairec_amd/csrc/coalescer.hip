@@ -203,6 +203,7 @@ struct pg_coalescer {
     uint32_t max_heads = 1;                // most outputs of any one algorithm (a rank-flavour batch writes that many planes)
     std::vector<std::string> plane_names;
     const pg_expr* e = nullptr;
+    pg::ExprHold e_hold;             // (pg_expr_set_score_rewrites refuses while a coalescer holds the expression's bindings)
     std::vector<int> var_src;
     pg::RerankStage rerank;
     pg_group* group = nullptr;       // a coalescer over a shard group (pg_coalescer_create_group): recommend only
@@ -1076,6 +1077,7 @@ int pg_coalescer_create_scene(pg_ctx* ctx, const pg_table* t, const pg_scene_con
         c->algo_names[a] = sc->algos[a].name;
     }
     c->e = sc->rank_score;
+    c->e_hold.take(c->e);
     int rc;
     if (c->e && (rc = pg::recommend_bind_vars(c->e, names, c->n_planes, &c->var_src, "pg_coalescer_create"))) {
         delete c;
@@ -1524,6 +1526,7 @@ int pg_coalescer_create_group(pg_group* g, const pg_expr* e, const char* rank_va
     c->grank_var = rank_var;
     c->ctx = pg_group_ctx(g, 0);
     c->e = e;
+    c->e_hold.take(e);
     c->k = plan->k;
     c->max_batch = cfg->max_batch ? cfg->max_batch : (uint32_t)pg::kMaxQueries;
     c->max_wait_us = cfg->max_wait_us ? cfg->max_wait_us : 100;

@@ -79,7 +79,6 @@ struct Knobs {
     uint32_t rank_sort_max = 8;    // PG_RANK_SORT_MAX: up to this many lists per call are sorted by counting ranks (0 = never)
     bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
     bool dpp_valu = false;         // PG_DPP_VALU: the DPP kernel matrix on the fp64 vector pipe (round-4 kernel) instead of the fp64 matrix pipe (A/B; same bits)
-    bool rank_t3 = false;          // PG_RANK_T3: the benchmark's bf16 DNN3 on the three-waves-per-SIMD kernel (rank_t3.hip) instead of rank_ws.hip (A/B)
     bool fm2t_irs = false;         // PG_FM2T_IRS: cfg 4's item-record rank on the producer / consumer kernel (rank_ir.hip) instead of rank_is.hip (A/B)
     uint32_t max_rec_scale = 16;   // PG_MAX_REC_SCALE: the 256-query pass's hit-record areas grow up to this many times their default size with a table
                                    // whose batches overflow them (16: 80 B x 123 M records = 9.8 GB per context at K = 5 000); 1 = never (exact scan instead)
@@ -413,6 +412,23 @@ int expr_eval_enqueue_locked(pg_ctx* ctx, const pg_expr* e, const double* d_vars
 void set_expr_arith_error(const pg_expr* e);
 // RankConfig.ScoreRewrite attached to a RankScore expression (pg_expr_set_score_rewrites; expr.hip)
 constexpr int kMaxRewrites = 8;
+// Holders of a compiled RankScore: everything that keeps a variable binding made from it (recommend_bind_vars: coalescers for their
+// lifetime, tickets until they are ended, pg_fuse_scores_dev for the call).  pg_expr_set_score_rewrites refuses while there is
+// one — the bindings are sized for the rewrites attached at that moment.
+void expr_hold(const pg_expr* e);
+void expr_release(const pg_expr* e);
+struct ExprHold {
+    const pg_expr* e = nullptr;
+    ExprHold() = default;
+    ExprHold(const ExprHold&) = delete;
+    ExprHold& operator=(const ExprHold&) = delete;
+    void take(const pg_expr* x) {
+        if (e) expr_release(e);
+        e = x;
+        if (e) expr_hold(e);
+    }
+    ~ExprHold() { if (e) expr_release(e); }
+};
 int expr_num_rewrites(const pg_expr* e);
 const char* expr_rewrite_source(const pg_expr* e, int r);
 int expr_rewrite_num_vars(const pg_expr* e, int r);

@@ -12,7 +12,7 @@
 //   `/` by zero and `%` by zero panic in the reference → PG_ERR_ARITH here.
 // ASTType "antlr" (GetExpASTByAntlr / ExprASTResultByAntlr, ast.go:275-389) hands the source to go-antlr-valuate v0.0.4, which
 // is not vendored.  pg_expr_compile_typed(…, "antlr") serves the SUBSET of that language the reference's own tests pin
-// (ast_test.go:30-56,90-167,213-300): + - * / ^ with ^ = math.Pow above * / above + -, parentheses, unary minus, numbers,
+// (ast_test.go:30-56,90-167,213-300): + - * / ^ with ^ = math.Pow above * / above + -, parentheses, unary minus (not against ^), numbers,
 // ${name}, and the registered functions maxIndex(${v}) / maxValue(${v}) over a list property (antlr_functions.go:34-66) —
 // compiled to the same device program; anything else is refused BY NAME (PG_ERR_UNSUPPORTED), never evaluated differently.
 #include "common.hpp"
@@ -54,6 +54,7 @@ struct pg_expr {
         std::vector<std::string> vars;
     };
     std::vector<Rewrite> rewrites;
+    mutable std::atomic<int> holders{0};     // bindings made from this expression that are still alive (pg::ExprHold)
 };
 
 namespace pg {
@@ -590,8 +591,13 @@ struct AntlrParser {
             return true;
         }
         if (c == '-') {
+            // prefix minus against ^: never combined in the reference's tests, and govaluate-style grammars bind the prefix tighter
+            // than the exponent (-2^2 = 4) — refused rather than evaluated on an assumption: -(a^b) or (-a)^b
             ++i;
-            if (!unary_operand()) return false;
+            if (!primary()) return false;
+            ws();
+            if (i < s.size() && s[i] == '^')
+                return fail("-a ^ b: the precedence of a prefix minus against ^ in the reference's antlr grammar is not pinned by its tests; parenthesise");
             push(OP_NEG, 0, 0.0);
             return true;
         }
@@ -639,7 +645,6 @@ struct AntlrParser {
         }
         return fail(std::string("'") + c + "' is not in the served subset");
     }
-    bool unary_operand() { return power(); }         // -a^b = -(a^b)
     bool power() {
         if (!primary()) return false;
         ws();
@@ -726,10 +731,21 @@ int pg_expr_free(pg_expr* e) {
 }
 
 int pg_expr_num_vars(const pg_expr* e) { return e ? (int)e->vars.size() : 0; }
+}  // extern "C"
+namespace pg {
+void expr_hold(const pg_expr* e) { e->holders.fetch_add(1, std::memory_order_acq_rel); }
+void expr_release(const pg_expr* e) { e->holders.fetch_sub(1, std::memory_order_acq_rel); }
+}  // namespace pg
+extern "C" {
 
 int pg_expr_set_score_rewrites(pg_expr* rank_score, uint32_t n, const char* const* sources, const pg_expr* const* exprs) {
     PG_REQUIRE(rank_score && (n == 0 || (sources && exprs)), "pg_expr_set_score_rewrites: NULL argument");
     PG_REQUIRE(n <= (uint32_t)pg::kMaxRewrites, "pg_expr_set_score_rewrites: %u rewrites (at most %d)", n, pg::kMaxRewrites);
+    if (rank_score->holders.load(std::memory_order_acquire) != 0) {
+        pg::set_error("pg_expr_set_score_rewrites: the expression is bound by a live pipeline (a coalescer, or a batch that has not been "
+                      "ended): attach the rewrites before creating any pipeline from it");
+        return PG_ERR_INVALID;
+    }
     PG_REQUIRE(n == 0 || !rank_score->empty, "pg_expr_set_score_rewrites: the reference rewrites scores only in front of a RankScore "
                "(service/rank/rank_service.go:339-353); this one is empty");
     std::vector<pg_expr::Rewrite> rw(n);

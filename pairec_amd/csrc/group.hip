@@ -201,6 +201,7 @@ struct pg_group_ticket {
     int lane = 0;
     uint32_t nq = 0, k = 0, C = 0, top_n = 0;
     const pg_expr* e = nullptr;
+    pg::ExprHold e_hold;
     std::vector<int> src;
     pg_group_plan plan{};
     std::vector<float> users;        // the step's inputs (a failed plan re-enqueues the step)
@@ -754,6 +755,7 @@ int pg_group_recommend_begin(pg_group* g, const pg_expr* e, const char* rank_var
     const uint32_t C = plan->dpp_candidates ? std::min(k, std::max(top_n, plan->dpp_candidates)) : 0u;
     PG_REQUIRE(C <= 8192, "pg_group_recommend: %u DPP candidates (at most 8192)", C);
     pg_group_ticket* tk = new pg_group_ticket();
+    tk->e_hold.take(e);
     int rc;
     if ((rc = pg::recommend_bind_vars(e, &rank_var, 1, &tk->src, "pg_group_recommend"))) {
         delete tk;

@@ -347,6 +347,7 @@ int recommend_verify(pg_ctx* ctx, PipeRun* r, bool* ok, const RecommendCall* c) 
 struct pg_ticket {
     pg::RecommendCall call;
     std::vector<int> var_src;
+    pg::ExprHold e_hold;
     pg::PipeRun* run = nullptr;
 };
 
@@ -364,6 +365,7 @@ int pg_recommend_dnn3_begin(pg_ctx* ctx, const pg_table* t, const pg_model* m, c
                "pg_recommend_dnn3: the model must be DNN3 with d_user = d_item = the table's dim");
     PG_REQUIRE(m->n_out == 1, "pg_recommend_dnn3: a multi-output model needs its output names: serve it through a scene (pg_coalescer_create_scene)");
     pg_ticket* tk = new pg_ticket();
+    tk->e_hold.take(e);
     int rc;
     if ((rc = pg::recommend_bind_vars(e, &rank_var, 1, &tk->var_src, "pg_recommend_dnn3"))) {
         delete tk;
@@ -416,6 +418,8 @@ int pg_fuse_scores_dev(pg_ctx* ctx, const pg_expr* e, const char* const* plane_n
     PG_REQUIRE(n_planes <= (uint32_t)pg::kMaxPlanes, "pg_fuse_scores_dev: %u planes (at most %d)", n_planes, pg::kMaxPlanes);
     if (n == 0) return PG_OK;
     std::vector<int> var_src;
+    pg::ExprHold hold;
+    hold.take(e);
     int rc;
     if ((rc = pg::recommend_bind_vars(e, plane_names, (int)n_planes, &var_src, "pg_fuse_scores_dev"))) return rc;
     const int nv = pg_expr_num_vars(e), n_rw = pg::expr_num_rewrites(e);

@@ -1137,14 +1137,13 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
                                 const float* d_user, const uint32_t* d_cand, const uint32_t* d_off,
                                 uint32_t n_req, uint32_t n_items, float* d_out, size_t out_stride) {
     if (n_items == 0 || n_req == 0) return PG_OK;
-    const uint32_t max_tiles = n_items / kT3Items + n_req;      // sized for the smallest (32-item) tiles
+    const uint32_t max_tiles = n_items / 32 + n_req;            // sized for the smallest (32-item) tiles
     RankScratch rs;
     int rc;
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->h1, &rs))) return rc;
     const bool no_ws = ctx->knobs.rank_no_ws;        // A/B switch: the streaming kernel
     // the weights-stationary kernel is built for the benchmark's shape: [d_user + 128] -> 512 -> 256 -> 1 in bf16
     const bool ws = m->prec == 1 && !no_ws && m->h1 == 512 && m->h2 == 256 && t->dim == 128;
-    const bool t3 = ws && ctx->knobs.rank_t3 && m->n_out <= 4;   // the same shape on twelve waves (rank_t3.hip; its LDS holds <= 4 heads)
     // the small shapes, gather-bound: the whole model in registers (rank_rs.hip)
     const bool rs_k = m->prec == 1 && !no_ws && t->dim == 128 && dnn3_rs_shape(m->h1, m->h2);
     const bool ls_k = m->prec == 1 && !no_ws && t->dim == 128 && dnn3_ls_shape(m->h1, m->h2);
@@ -1152,7 +1151,7 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     const bool x3_k = m->prec == 2 && !no_ws && t->dim == 128 && dnn3_x3_shape(m->h1, m->h2);
     const uint32_t grid128 = n_items / kBM + n_req;
     PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    if ((rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, t3 ? (uint32_t)kT3Items : (ws || rs_k ? (uint32_t)kWsItems : (uint32_t)kBM), rs.tile_req, rs.tile_item0,
+    if ((rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, ws || rs_k ? (uint32_t)kWsItems : (uint32_t)kBM, rs.tile_req, rs.tile_item0,
                                  rs.tile_cnt, rs.n_tiles, rs.req_tile0)))
         return rc;
     dnn3_user_partial_kernel<<<dim3(n_req, (m->h1 + 255) / 256), 256, 0, ctx->stream>>>(
@@ -1187,9 +1186,7 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
         if ((rc = scratch_reserve(ctx, 14, (size_t)ctx->num_cus * (kMaxHeads - 1) * 4 * kWsItems * 4, &hp))) return rc;
         a.head_part = (float*)hp;
     }
-    if (t3) {
-        if ((rc = launch_dnn3_t3(ctx, a))) return rc;
-    } else if (ws) {
+    if (ws) {
         // bf16: weights-stationary persistent kernel over 64-item tiles
         if ((rc = launch_dnn3_ws(ctx, a))) return rc;
     } else if (rs_k) {

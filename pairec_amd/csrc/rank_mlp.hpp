@@ -183,9 +183,6 @@ int launch_dnn3_rs(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
 bool dnn3_ls_shape(uint32_t h1, uint32_t h2);
 int launch_dnn3_ls(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);
 
-// rank_t3.hip: the benchmark's bf16 DNN3 with the weights in the registers of twelve waves; 32-item tiles
-constexpr int kT3Items = 32;
-int launch_dnn3_t3(pg_ctx* ctx, const MlpArgs& a);
 // rank_x3.hip: DNN3 in PG_PREC_BF16X3 (split bf16) — 128-item tiles, layer-1 and layer-2 waves sharing each SIMD
 bool dnn3_x3_shape(uint32_t h1, uint32_t h2);
 int launch_dnn3_x3(pg_ctx* ctx, uint32_t h1, uint32_t h2, const MlpArgs& a);

@@ -2256,6 +2256,7 @@ static const char* items_to_json(const std::vector<module::ItemPtr>& items) {
 
 // one registered sort over caller-made items: [{"id":..,"score":x,"properties":{..},"algo_scores":{..}}] → ["id", …] in the sorted order
 const char* ph_engine_sort(void* h, const char* sort_name, const char* items_json, int size) {
+    if (!h) { g_ph_err = "ph_engine_sort: NULL engine"; return nullptr; }
     Engine* e = (Engine*)h;
     json::Value root;
     std::string err;

@@ -37,9 +37,11 @@ def test_oracle_antlr_subset_against_the_reference_vectors(golden):
     assert o.antlr_result(o.antlr_parse(""), {}) == 0.0
     # precedence and the float division of the subset
     assert o.antlr_result(o.antlr_parse("2+3*2^3/4-1"), {}) == 2 + 3 * 8 / 4 - 1
-    assert o.antlr_result(o.antlr_parse("-${a}^2"), {"a": 3.0}) == -9.0
+    assert o.antlr_result(o.antlr_parse("-(${a}^2)"), {"a": 3.0}) == -9.0
+    assert o.antlr_result(o.antlr_parse("(-${a})^2"), {"a": 3.0}) == 9.0
+    assert o.antlr_result(o.antlr_parse("2*-3"), {}) == -6.0 and o.antlr_result(o.antlr_parse("2^-1"), {}) == 0.5
     assert o.antlr_result(o.antlr_parse("1/${z}"), {"z": 0.0}) == math.inf
-    for bad in ("${a} % 2", "log(${a})", "${a} > 1", "2 ** 3", "${a}^2^3", "'x'", "${a} ? 1 : 2", "hash(${a})"):
+    for bad in ("-${a}^2", "${a} % 2", "log(${a})", "${a} > 1", "2 ** 3", "${a}^2^3", "'x'", "${a} ? 1 : 2", "hash(${a})"):
         with pytest.raises(o.AntlrUnsupported):
             o.antlr_parse(bad)
 
@@ -84,7 +86,7 @@ def test_antlr_subset_on_the_device(ctx, golden):
         e.free()
     # random expressions of the subset against the oracle's restatement, 2 000 items
     rng = np.random.default_rng(8)
-    src = "(${a}+2*${b})*${c}^0.1 - ${a}/(${b}-${b}) * 0 + -${c}^2/3"
+    src = "(${a}+2*${b})*${c}^0.1 - ${a}/(${b}-${b}) * 0 + -(${c}^2)/3"
     e = pa.Expr(src, "antlr")
     v = rng.uniform(0.01, 2.0, (3, 2000))
     got = e.eval(ctx, v)                                        # x/0 is ±Inf here (no arithmetic error), Inf * 0 = NaN

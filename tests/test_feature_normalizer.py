@@ -18,7 +18,8 @@ GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_known_ans
 
 @pytest.fixture(scope="module")
 def H():
-    L = C.CDLL(os.path.join(ROOT, "pairec_amd", "libpairec_host.so"))
+    # (PH_HOST_LIB: scripts/host_asan.sh / host_tsan.sh point the same tests at the sanitizer builds of the library)
+    L = C.CDLL(os.environ.get("PH_HOST_LIB") or os.path.join(ROOT, "pairec_amd", "libpairec_host.so"))
     L.ph_last_error.restype = C.c_char_p
     L.ph_normalizer_apply.restype = C.c_char_p
     L.ph_normalizer_apply.argtypes = [C.c_char_p]

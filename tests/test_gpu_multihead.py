@@ -235,34 +235,3 @@ def test_extra_heads_cost_a_fraction_of_a_model(ctx):
     for p_ in (d_u, d_c, d_o, d_out):
         ctx.free(p_)
     t.destroy()
-
-
-def test_three_waves_per_simd_kernel_matches_the_default_one(ctx):
-    """dnn3_t3_kernel (csrc/rank_t3.hip, pg_set_option("rank_t3"): twelve waves per CU, the model's fragments in their
-    registers, 32-item tiles) is an alternative to dnn3_ws_kernel for the benchmark's shape: same oracle tolerance on
-    ragged / empty / tile-boundary requests, 1 and 4 heads; 8 heads do not fit its LDS and stay on the default kernel."""
-    n = 50_000
-    t = pa.Table(ctx, n, 128)
-    t.fill_synthetic(o.SEED_TABLE)
-    tab = o.synth_rows(o.SEED_TABLE, 0, n, 128)
-    rng = np.random.default_rng(9)
-    sizes = [5000, 1, 0, 333, 32, 33, 31, 64, 65, 127, 257]
-    users = o.synth_rows(o.SEED_QUERY, 3, len(sizes), 128)
-    cands = [rng.integers(0, n, s_).astype(np.uint32) for s_ in sizes]
-    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
-    for n_out in (1, 4, 8):
-        w = o.Dnn3MultiWeights(n_out)
-        m = pa.RankModel(ctx, pa.MODEL_DNN3_MULTI, pa.PREC_BF16, _pack(w))
-        ref = np.concatenate([o.dnn3_multi_forward(w, 1, users[r], tab[cands[r]]) for r in range(len(sizes))], axis=1)
-        base = m.rank_dnn3(t, users, np.concatenate(cands), off)
-        ctx.set_option("rank_t3", 1)
-        try:
-            got = m.rank_dnn3(t, users, np.concatenate(cands), off)
-        finally:
-            ctx.set_option("rank_t3", 0)
-        got, base = got.reshape(n_out, -1), base.reshape(n_out, -1)
-        assert np.max(np.abs(got.astype(np.float64) - ref)) <= 1e-5 and np.max(np.abs(got - base)) <= 4e-6
-        if n_out == 8:
-            assert np.array_equal(bits(got), bits(base))               # (the knob does not apply: the default kernel ran)
-        m.destroy()
-    t.destroy()

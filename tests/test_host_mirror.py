@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def H():
-    L = C.CDLL(os.path.join(ROOT, "pairec_amd", "libpairec_host.so"))
+    # (PH_HOST_LIB: scripts/host_asan.sh / host_tsan.sh point the same tests at the sanitizer builds of the library)
+    L = C.CDLL(os.environ.get("PH_HOST_LIB") or os.path.join(ROOT, "pairec_amd", "libpairec_host.so"))
     L.ph_last_error.restype = C.c_char_p
     L.ph_engine_create.restype = C.c_void_p
     L.ph_engine_create.argtypes = [C.c_char_p]

@@ -106,6 +106,10 @@ def test_device_fusion_with_two_rewrites_matches_the_oracle(ctx):
     ex3 = pa.Expr(src2)
     ex3.set_score_rewrites(rw2)
     co = pa.Coalescer(ctx, t, k, expr=ex3, algos=[("a", m), ("b", m2)], max_top_n=50, max_wait_us=200)
+    # the coalescer holds bindings sized for these rewrites: changing them now is refused, and nothing changes
+    with pytest.raises(pa._lib.PgError) as ei:
+        ex3.set_score_rewrites({"mix": "${a}"})
+    assert ei.value.code == -1
     tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
     for r in range(R):
         g_rows, g_rec, g_rnk, g_fus, cnt = co.recommend(q[r], 50)
