@@ -486,6 +486,11 @@ int pg_group_recommend_begin(pg_group* g, const pg_expr* e, const char* rank_var
                              const float* user_vecs, uint32_t nq, uint32_t top_n, pg_group_ticket** out);
 int pg_group_recommend_end(pg_group* g, pg_group_ticket* ticket, uint64_t* out_rows, float* out_recall_scores,
                            float* out_rank_scores, double* out_fused, uint32_t* out_count);
+/* The first exchange of the sharded step (the reference's only fan-in is service/recall.go:126-150): every shard
+ * sends the best ceil(k/G + 6 sqrt(k/G) + 8) entries of every request's list; a step in which some shard's last sent entry lies
+ * inside a merged top-k is repeated with the whole lists.  out4 = {steps served, steps that had to be repeated, bytes one shard
+ * sent to each peer in the last step, entries per request and shard in it}. */
+int pg_group_exchange_stats(pg_group* g, uint64_t* out4);
 
 /* The shard-side steps of the same flow as device-level calls, for a one-process-per-GPU host that runs the two
  * exchanges itself (pairec_amd/dist.py over torch.distributed / RCCL).  Everything is fixed-size and stays on the

@@ -28,7 +28,7 @@ EXPORTS = [
     "pg_hbm_read_probe", "pg_table_screen_info", "pg_ssd", "pg_features_create", "pg_features_destroy", "pg_features_set_column",
     "pg_features_column_index", "pg_features_num_columns", "pg_features_gather_i32_dev",
     "pg_features_gather_f32_dev", "pg_rank_fm2t_rows_dev", "pg_rank_fm2t_rows", "pg_recommend_dnn3_dev", "pg_set_option",
-    "pg_table_fill_gaussian", "pg_table_fill_mixture", "pg_dpp_ex", "pg_i2i_recall", "pg_online_vector_recall", "pg_fm2t_user_embedding",
+    "pg_table_fill_gaussian", "pg_table_fill_mixture", "pg_group_exchange_stats", "pg_dpp_ex", "pg_i2i_recall", "pg_online_vector_recall", "pg_fm2t_user_embedding",
     "pg_fm2t_user_embedding_dev", "pg_recommend_dnn3_begin", "pg_recommend_end",
     "pg_coalescer_create", "pg_coalescer_destroy", "pg_coalescer_recall", "pg_coalescer_rank_dnn3",
     "pg_coalescer_recommend", "pg_coalescer_stats", "pg_coalescer_create_scene", "pg_coalescer_i2i_recall", "pg_coalescer_recall_l2",
@@ -211,6 +211,7 @@ def load():
         "pg_group_recommend_begin": [vp, vp, C.c_char_p, P(PgGroupPlan), vp, u32, u32, P(vp)],
         "pg_group_recommend_end": [vp, vp, vp, vp, vp, vp, vp],
         "pg_group_info": [vp, P(u64), P(u32)],
+        "pg_group_exchange_stats": [vp, P(u64)],
         "pg_coalescer_create_group": [vp, vp, C.c_char_p, P(PgGroupPlan), P(PgCoalescerConfig), P(vp)],
         "pg_router_create": [P(vp), u32, P(vp)],
         "pg_router_destroy": [vp],

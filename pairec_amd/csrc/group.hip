@@ -8,8 +8,13 @@
 // connected — one hop), ordered by HIP events; on logical shards of one device the same stores are local.
 //
 //   every shard g      local exact top-k of its row range                                   (recall job, no host sync)
-//   all-gather         shard g copies its packed [nq][k] (rows | scores) block — ONE copy per peer — into slot g of
-//                      every shard's gather buffer
+//   all-gather         shard g copies the HEADS of its lists — the best m = ceil(k/G + 6 sqrt(k/G) + 8) entries of every request,
+//                      packed (rows | scores), ONE copy per peer — into slot g of every shard's gather buffer (G = 8, k = 5 000:
+//                      783 entries, 2.4 MB per shard and 256-request step instead of 15.4).  Exact: an entry a shard did not send
+//                      ranks behind that shard's m-th, so nothing unsent can belong to the merged top-k unless some shard's m-th
+//                      entry lies strictly inside it — which every shard checks after its merge (tail_needed_kernel); the flag
+//                      travels with the step's status words and _end repeats the step with the full lists (counted:
+//                      pg_group_exchange_stats; two such steps in a row and the next 64 exchange full lists at once)
 //   every shard h      identical deterministic merge → global top-k; compacts the candidates it OWNS, ranks them
 //                      (DNN3, embedding rows are local), stores the scores into the slab of the request's TAIL shard
 //   tail shard s       owns the requests q = s (mod G): RankScore fusion → ItemRankScore sort → DPP candidates = first
@@ -42,6 +47,8 @@ struct Lane {
     // sized for (nq_cap, k_cap)
     float* d_q = nullptr;
     char* d_own = nullptr;           // this shard's packed block: rows u64 [nq][k] | scores f32 [nq][k]
+    char* d_head = nullptr;          // the heads of its lists, packed the same way: rows u64 [nq][m] | scores f32 [nq][m]
+    uint32_t* d_tail = nullptr;      // != 0: some shard's last sent entry lies inside a merged top-k (the exchange was too narrow)
     char* g_blk = nullptr;           // G packed blocks, slot i written by shard i
     uint64_t* m_rows = nullptr;      // merged [nq][k]
     float* m_sc = nullptr;
@@ -66,7 +73,7 @@ struct Lane {
     uint32_t* pick_cnt = nullptr;    // [256]
     char* d_page = nullptr;
     char* h_page = nullptr;          // pinned
-    uint32_t* h_flags = nullptr;     // pinned: [0,256) RankScore flags, [256,512) counts, [512,768) DPP pick counts
+    uint32_t* h_flags = nullptr;     // pinned: [0,256) RankScore flags, [256,512) counts, [512,768) DPP pick counts, [768] the d_tail flag
     // the peers' buffers of the same lane (device arrays of G pointers)
     float** slab_tab = nullptr;
     uint64_t** crows_tab = nullptr;
@@ -147,6 +154,41 @@ __global__ __launch_bounds__(1024) void owned_fill_kernel(const uint64_t* __rest
     }
 }
 
+// the first m entries of every request's list, packed: rows [nq][m] | scores [nq][m] (scores at byte offset sc_off)
+__global__ void pack_heads_kernel(const uint64_t* __restrict__ rows, const float* __restrict__ scores, uint32_t nq, uint32_t k, uint32_t m,
+                                  uint64_t* __restrict__ h_rows, float* __restrict__ h_scores) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * m) return;
+    const uint32_t q = i / m, j = i % m;
+    h_rows[i] = rows[(size_t)q * k + j];
+    h_scores[i] = scores[(size_t)q * k + j];
+}
+// after the merge of G lists of m entries: does some list's LAST entry rank strictly inside its request's merged top-k?  Then an
+// entry that shard did not send could too.  Order = the recall's (score descending by IEEE totalOrder with NaN last, row
+// ascending); a request whose merged list is short of k takes every full list as suspect.  One thread per (list, request).
+__device__ __forceinline__ uint32_t tail_ord(float f) {
+    const uint32_t b = __float_as_uint(f);
+    if (f != f) return 0u;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ void tail_needed_kernel(const char* __restrict__ g_blk, size_t slot_bytes, size_t sc_off, uint32_t G, uint32_t nq, uint32_t m,
+                                   const uint64_t* __restrict__ m_rows, const float* __restrict__ m_sc, const uint32_t* __restrict__ m_cnt,
+                                   uint32_t k, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * nq) return;
+    const uint32_t g = i / nq, q = i % nq;
+    const uint64_t r_m = reinterpret_cast<const uint64_t*>(g_blk + (size_t)g * slot_bytes)[(size_t)q * m + m - 1];
+    if (r_m == ~0ull) return;                                  // the list ended before its m-th entry: nothing was left unsent
+    const float s_m = reinterpret_cast<const float*>(g_blk + (size_t)g * slot_bytes + sc_off)[(size_t)q * m + m - 1];
+    bool need = m_cnt[q] < k;
+    if (!need) {
+        const uint64_t r_k = m_rows[(size_t)q * k + k - 1];
+        const uint32_t a = tail_ord(s_m), b = tail_ord(m_sc[(size_t)q * k + k - 1]);
+        need = a > b || (a == b && r_m < r_k);
+    }
+    if (need) atomicOr(flag, 1u);
+}
+
 // slab[slot[i]] = score[i] for the owned candidates (slab may live on the lead's device: peer store)
 __global__ void scatter_scores_kernel(const float* __restrict__ score, const uint32_t* __restrict__ slot,
                                       const uint32_t* __restrict__ total, uint32_t cap, float* __restrict__ slab) {
@@ -205,6 +247,8 @@ struct pg_group_ticket {
     std::vector<int> src;
     pg_group_plan plan{};
     std::vector<float> users;        // the step's inputs (a failed plan re-enqueues the step)
+    bool full_exchange = false;      // exchange the whole lists (the heads were too narrow for this batch, or the group is backing off)
+    uint32_t m = 0;                  // entries per request and shard the enqueued attempt exchanged
 };
 
 struct pg_group {
@@ -216,6 +260,9 @@ struct pg_group {
     std::mutex mu;                 // enqueueing / collecting a step, table and model changes
     bool lane_busy[pg::kLanes] = {false, false};
     int next_lane = 0;
+    // the first exchange (under mu): steps served, steps repeated with the full lists, the bytes a shard sent last time
+    uint64_t ex_steps = 0, ex_round2 = 0, ex_last_bytes = 0, ex_last_entries = 0;
+    uint32_t ex_streak = 0, ex_backoff = 0;
 };
 
 namespace pg {
@@ -233,14 +280,14 @@ size_t blk_bytes(size_t n) { return blk_rows_bytes(n) + ((n * 4 + 255) & ~(size_
 void free_lane_buffers(Lane& l) {
     if (!l.ctx) return;
     hipSetDevice(l.ctx->device);
-    for (void* p : {(void*)l.d_q, (void*)l.d_own, (void*)l.g_blk, (void*)l.m_rows, (void*)l.m_sc, (void*)l.m_cnt, (void*)l.d_local,
+    for (void* p : {(void*)l.d_q, (void*)l.d_own, (void*)l.d_head, (void*)l.d_tail, (void*)l.g_blk, (void*)l.m_rows, (void*)l.m_sc, (void*)l.m_cnt, (void*)l.d_local,
                     (void*)l.d_slot, (void*)l.d_off, (void*)l.d_rank, (void*)l.t_rows, (void*)l.t_recall, (void*)l.t_slab, (void*)l.t_fused,
                     (void*)l.t_order, (void*)l.t_count, (void*)l.t_err, (void*)l.c_rows, (void*)l.c_rel, (void*)l.c_emb, (void*)l.c_bail,
                     (void*)l.pick, (void*)l.pick_cnt, (void*)l.d_page, (void*)l.slab_tab, (void*)l.crows_tab, (void*)l.cemb_tab})
         if (p) hipFree(p);
     if (l.h_page) hipHostFree(l.h_page);
     if (l.h_flags) hipHostFree(l.h_flags);
-    l.d_q = nullptr; l.d_own = nullptr; l.g_blk = nullptr; l.m_rows = nullptr; l.m_sc = nullptr; l.m_cnt = nullptr; l.d_local = nullptr;
+    l.d_q = nullptr; l.d_own = nullptr; l.d_head = nullptr; l.d_tail = nullptr; l.g_blk = nullptr; l.m_rows = nullptr; l.m_sc = nullptr; l.m_cnt = nullptr; l.d_local = nullptr;
     l.d_slot = nullptr; l.d_off = nullptr; l.d_rank = nullptr; l.t_rows = nullptr; l.t_recall = nullptr; l.t_slab = nullptr;
     l.t_fused = nullptr; l.t_order = nullptr; l.t_count = nullptr; l.t_err = nullptr; l.c_rows = nullptr; l.c_rel = nullptr;
     l.c_emb = nullptr; l.c_bail = nullptr; l.pick = nullptr; l.pick_cnt = nullptr; l.d_page = nullptr; l.h_page = nullptr;
@@ -281,6 +328,8 @@ int ensure_step_buffers(pg_group* g, uint32_t nq, uint32_t k, uint32_t C, uint32
             PG_HIP(hipMalloc((void**)&l.d_q, (size_t)nq * g->dim * 4));
             PG_HIP(hipMalloc((void**)&l.d_own, blk_bytes(n)));
             PG_HIP(hipMalloc((void**)&l.g_blk, blk_bytes(n) * G));
+            PG_HIP(hipMalloc((void**)&l.d_head, blk_bytes(n)));
+            PG_HIP(hipMalloc((void**)&l.d_tail, 256));
             PG_HIP(hipMalloc((void**)&l.m_rows, n * 8));
             PG_HIP(hipMalloc((void**)&l.m_sc, n * 4));
             PG_HIP(hipMalloc((void**)&l.m_cnt, 256 * 4));
@@ -303,7 +352,7 @@ int ensure_step_buffers(pg_group* g, uint32_t nq, uint32_t k, uint32_t C, uint32
             PG_HIP(hipMalloc((void**)&l.pick_cnt, 256 * 4));
             PG_HIP(hipMalloc((void**)&l.d_page, page));
             PG_HIP(hipHostMalloc((void**)&l.h_page, page));
-            PG_HIP(hipHostMalloc((void**)&l.h_flags, 768 * 4));
+            PG_HIP(hipHostMalloc((void**)&l.h_flags, 772 * 4));
             PG_HIP(hipMalloc((void**)&l.slab_tab, (size_t)G * sizeof(void*)));
             PG_HIP(hipMalloc((void**)&l.crows_tab, (size_t)G * sizeof(void*)));
             PG_HIP(hipMalloc((void**)&l.cemb_tab, (size_t)G * sizeof(void*)));
@@ -391,17 +440,34 @@ int step_enqueue(pg_group* g, pg_group_ticket* tk, uint32_t attempt) {
         }
         if ((rc = recall_job_enqueue(&j))) return rc;
     }
-    // ---- 2. all-gather: shard i stores its packed block into slot i of every shard (one copy per peer); every tail
-    //         shard clears its slab (padding slots have no owner) ------------------------------------------------------
+    // ---- 2. all-gather: shard i stores the heads of its lists (or, for a repeated / backed-off step, the whole lists) into slot i
+    //         of every shard — one copy per peer; every tail shard clears its slab (padding slots have no owner) ------------
+    uint32_t m = k;
+    if (!tk->full_exchange && G > 1) {
+        const double per = (double)k / G;
+        const uint32_t w = (uint32_t)ceil(per + 6.0 * sqrt(per) + 8.0);
+        if (w < k) m = w;
+    }
+    tk->m = m;
+    const size_t nm = (size_t)nq * m;
+    const size_t hb = blk_bytes(nm), hrb = blk_rows_bytes(nm);      // bytes of one packed block of heads, of its rows part
     for (uint32_t i = 0; i < G; ++i) {
         Lane& l = g->sh[i].lane[L];
         PG_HIP(hipSetDevice(l.ctx->device));
         hipStream_t st = l.ctx->stream;
+        const char* src = l.d_own;
+        if (m < k) {
+            pack_heads_kernel<<<(uint32_t)((nm + 255) / 256), 256, 0, st>>>((const uint64_t*)l.d_own, (const float*)(l.d_own + rb), nq, k, m,
+                                                                            (uint64_t*)l.d_head, (float*)(l.d_head + hrb));
+            PG_HIP(hipGetLastError());
+            src = l.d_head;
+        }
         for (uint32_t h = 0; h < G; ++h)
-            PG_HIP(hipMemcpyAsync(g->sh[h].lane[L].g_blk + (size_t)i * bb, l.d_own, bb, hipMemcpyDeviceToDevice, st));
+            PG_HIP(hipMemcpyAsync(g->sh[h].lane[L].g_blk + (size_t)i * bb, src, m < k ? hb : bb, hipMemcpyDeviceToDevice, st));
         PG_HIP(hipEventRecord(l.ev_lists, st));
         const uint32_t nqs = i < nq ? (nq - i + G - 1) / G : 0u;
         if (nqs) PG_HIP(hipMemsetAsync(l.t_slab, 0, (size_t)nqs * k * 4, st));
+        PG_HIP(hipMemsetAsync(l.d_tail, 0, 4, st));
         PG_HIP(hipEventRecord(l.ev_ready, st));
     }
     // ---- 3. every shard: merge, rank what it owns, store the scores into the tail shards' slabs --------------------
@@ -414,9 +480,14 @@ int step_enqueue(pg_group* g, pg_group_ticket* tk, uint32_t attempt) {
             if (i != h) PG_HIP(hipStreamWaitEvent(st, g->sh[i].lane[L].ev_lists, 0));
         {
             std::lock_guard<std::mutex> cg(l.ctx->mu);
-            if ((rc = topk_merge_strided_locked(l.ctx, (const uint64_t*)l.g_blk, (const float*)(l.g_blk + rb), nq, G, k, bb / 8, k, bb / 4, k, k,
-                                                l.m_rows, l.m_sc, l.m_cnt)))
+            // (slot stride bb whatever was sent; inside a slot the block is packed for m entries per request)
+            if ((rc = topk_merge_strided_locked(l.ctx, (const uint64_t*)l.g_blk, (const float*)(l.g_blk + (m < k ? hrb : rb)), nq, G, m, bb / 8, m,
+                                                bb / 4, m, k, l.m_rows, l.m_sc, l.m_cnt)))
                 return rc;
+            if (m < k) {
+                tail_needed_kernel<<<(G * nq + 255) / 256, 256, 0, st>>>(l.g_blk, bb, hrb, G, nq, m, l.m_rows, l.m_sc, l.m_cnt, k, l.d_tail);
+                PG_HIP(hipGetLastError());
+            }
             uint32_t* d_cnt = l.d_off + nq + 1;
             owned_count_kernel<<<nq, 256, 0, st>>>(l.m_rows, k, s.tab->row_offset, s.tab->rows, d_cnt);
             owned_scan_kernel<<<1, 256, 0, st>>>(d_cnt, nq, l.d_off);
@@ -502,6 +573,7 @@ int step_enqueue(pg_group* g, pg_group_ticket* tk, uint32_t attempt) {
             PG_HIP(hipMemcpyAsync(l.h_flags + 256, l.t_count, (size_t)nqs * 4, hipMemcpyDeviceToHost, st));
             if (C) PG_HIP(hipMemcpyAsync(l.h_flags + 512, l.pick_cnt, (size_t)nqs * 4, hipMemcpyDeviceToHost, st));
         }
+        PG_HIP(hipMemcpyAsync(l.h_flags + 768, l.d_tail, 4, hipMemcpyDeviceToHost, st));
         PG_HIP(hipEventRecord(l.ev_done, st));
     }
     return PG_OK;
@@ -776,6 +848,11 @@ int pg_group_recommend_begin(pg_group* g, const pg_expr* e, const char* rank_var
         return PG_ERR_INVALID;
     }
     tk->lane = L;
+    if (g->ex_backoff) {                              // (the heads kept proving too narrow: whole lists for now)
+        g->ex_backoff--;
+        tk->full_exchange = true;
+        if (!g->ex_backoff) g->ex_streak = 0;
+    }
     for (auto& s : g->sh) s.lane[L].plan_failed = false;
     if ((rc = pg::step_enqueue(g, tk, 0))) {
         for (auto& s : g->sh) {                       // leave nothing half-enqueued behind
@@ -818,6 +895,30 @@ int pg_group_recommend_end(pg_group* g, pg_group_ticket* tk, uint64_t* out_rows,
             l.plan_failed = !ok;                              // remembered for the retry: this shard moves to its next plan
             if (ok) pg::recall_job_finish(&l.run->job);
             all_ok = all_ok && ok;
+        }
+        // ... and of the first exchange: a shard's last sent entry inside a merged top-k means its unsent tail could matter —
+        // the step runs again with the whole lists (every shard computed the flag from the same bytes)
+        bool narrow = false;
+        if (!rc && all_ok && !tk->full_exchange) {
+            for (uint32_t i = 0; i < G; ++i) narrow = narrow || g->sh[i].lane[L].h_flags[768] != 0;
+        }
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            if (!rc && all_ok) {
+                if (narrow) {
+                    g->ex_round2++;
+                    if (++g->ex_streak >= 2) g->ex_backoff = 64;     // (rows in score order, one shard holding the answers: full lists at once for a while)
+                } else {
+                    g->ex_steps++;
+                    g->ex_last_entries = tk->m;
+                    g->ex_last_bytes = (uint64_t)nq * tk->m * 12;
+                    if (!tk->full_exchange) g->ex_streak = 0;
+                }
+            }
+        }
+        if (narrow) {
+            tk->full_exchange = true;
+            all_ok = false;
         }
         if (rc || all_ok) break;
         // a shard's job runs out of plans by itself (recall_job_enqueue: "overflow in safe mode"); with the threshold model's
@@ -862,6 +963,16 @@ int pg_group_recommend_end(pg_group* g, pg_group_ticket* tk, uint64_t* out_rows,
     }
     delete tk;
     return rc;
+}
+
+int pg_group_exchange_stats(pg_group* g, uint64_t* out4) {
+    PG_REQUIRE(g && out4, "pg_group_exchange_stats: NULL argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    out4[0] = g->ex_steps;
+    out4[1] = g->ex_round2;
+    out4[2] = g->ex_last_bytes;
+    out4[3] = g->ex_last_entries;
+    return PG_OK;
 }
 
 int pg_group_recommend(pg_group* g, const pg_expr* e, const char* rank_var, const pg_group_plan* plan,

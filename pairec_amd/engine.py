@@ -797,6 +797,12 @@ class ShardGroup:
                                                    C.byref(tk)))
         return (tk, u.shape[0], top_n)
 
+    def exchange_stats(self) -> dict:
+        """the first exchange: steps served, steps repeated with the whole lists, bytes per shard and peer and entries per request in the last step"""
+        a = (C.c_uint64 * 4)()
+        _lib.check(self.L.pg_group_exchange_stats(self.h, a))
+        return {"steps": int(a[0]), "round2_steps": int(a[1]), "exchange1_bytes_per_shard": int(a[2]), "entries_per_request_and_shard": int(a[3])}
+
     def recommend_end(self, ticket):
         tk, nq, top_n = ticket
         rows = np.empty((nq, top_n), dtype=np.uint64)

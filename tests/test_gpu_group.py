@@ -237,3 +237,38 @@ def test_dist_engine_ranks_sharing_one_gpu_match_oracle(world, prec):
                         os.path.join(root, "tests", "dist_engine_check.py")], capture_output=True, text=True, timeout=900,
                        env=env)
     assert r.returncode == 0 and "dist engine OK (world %d)" % world in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("case", ["random", "head_shard", "ties"])
+def test_group_pruned_exchange_is_exact_against_adversarial_shards(case):
+    """pg_group_* sends the heads of the lists in its first exchange (ceil(k/G + 6 sqrt(k/G) + 8) entries per request and shard)
+    and repeats a step with the whole lists when some shard's last sent entry lies inside a merged top-k.  Rows spread at random
+    never need that; a shard that holds every answer (longer rows; or every score tied, so that the lowest row ids win) always
+    does — counted, then backed off — and the pages equal the single-table oracle's either way."""
+    shards, n, d, k, R, top_n = 4, 120_000, 128, 400, 9, 30
+    tab = o.synth_rows(o.SEED_TABLE, 0, n, d)
+    if case == "head_shard":
+        tab[:n // 4] *= np.float32(3.0)
+    elif case == "ties":
+        tab[:] = tab[0]
+    w = o.Dnn3Weights()
+    g = pa.ShardGroup([0] * shards)
+    g.table_create(n, d)
+    g.table_upload(tab, 0)
+    g.model_load(pa.MODEL_DNN3, pa.PREC_F32, pa.pack_dnn3(w.w1, w.b1, w.w2, w.b2, w.w3, w.b3, 128))
+    ex = pa.Expr(EXPR)
+    m = int(np.ceil(k / shards + 6 * np.sqrt(k / shards) + 8))
+    for step in range(4):
+        q = o.synth_rows(o.SEED_QUERY, 21 + step, R, d)
+        rows, rec, rnk, fus, cnt = g.recommend(ex, "gpu_dnn", q, k, top_n, dpp_candidates=0)
+        want = oracle_pipeline(tab, w, pa.PREC_F32, q, k, top_n, 0, 1.0, 10)
+        for r in range(R):
+            assert cnt[r] == top_n and np.array_equal(rows[r], want[r][0]) and np.array_equal(bits(rec[r]), bits(want[r][1])), (case, step, r)
+        st = g.exchange_stats()
+        if case == "random":
+            assert st["round2_steps"] == 0 and st["entries_per_request_and_shard"] == m < k
+            assert st["exchange1_bytes_per_shard"] == R * m * 12
+        else:
+            # steps 0 and 1 are repeated with the whole lists; after two in a row the group exchanges whole lists at once
+            assert st["round2_steps"] == min(step + 1, 2) and st["entries_per_request_and_shard"] == k, (case, step, st)
+    g.destroy()
