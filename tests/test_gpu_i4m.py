@@ -185,3 +185,31 @@ def test_mid_batch_matches_single_requests(small_table_opts):
         r, s, _ = t.recall_topk(q[i:i + 1], k)
         assert np.array_equal(r[0], rows[i]) and np.array_equal(bits(s[0]), bits(scores[i]))
     t.destroy()
+
+
+@pytest.mark.parametrize("sigma,nq", [(0.3, 256), (0.1, 256), (0.03, 130), (0.1, 24), (0.03, 3)])
+def test_clustered_rows_are_exact(ctx, sigma, nq):
+    """pg_table_fill_mixture: 20 centres on the sphere, 2 M rows = 100 K per cluster, queries drawn from the same mixture — a
+    query's top-K sits inside one cluster whose members score within the screens' error of each other (9-20 suspects per
+    answer at 256 queries; the hit-record areas grow with the table instead of the pass falling to the exact scan).  The fill is
+    the oracle's bit for bit, and ids / order / score bits of every batch size class equal the oracle's."""
+    n, d, k, C_, seed = 2_000_000, 128, 5000, 20, 0x5EED0007
+    t = pa.Table(ctx, n, d)
+    t.fill_mixture(seed, C_, sigma)
+    tab = o.synth_mixture_rows(seed, 0, n, d, C_, sigma)
+    assert np.array_equal(bits(t.download(n - 70_000, 70_000)), bits(tab[n - 70_000:]))
+    q = o.synth_mixture_rows(seed, 555, nq, d, C_, sigma, stream=1)
+    ctx.set_option("i4_min_rows", "0")
+    try:
+        for rep in range(2):                               # (the second batch runs with the areas the first one grew)
+            s0 = ctx.stats()
+            rows, scores, cnt = t.recall_topk(q, k)
+            s1 = ctx.stats()
+            if rep == 0:
+                orow, osc = o.recall_topk(tab, q, k)
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc)) and cnt.tolist() == [k] * nq
+        assert s1.recall_screen_overflows == s0.recall_screen_overflows        # the steady state stays on the screened pass
+        assert ctx.last_scan_kernel()[1] <= n * 128 * 1.3
+    finally:
+        ctx.set_option("i4_min_rows", str(1 << 22))
+    t.destroy()
