@@ -518,8 +518,13 @@ int screen4m_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uin
         screen4m_kernel<2><<<grid, 64 * kMWaves, kMLds, ctx->stream>>>(a);
     }
     PG_HIP(hipGetLastError());
-    // ~ the resident waves of the chip over all queries (a wave then walks a few dozen chunks of a typical list)
-    const uint32_t s2_blocks = nq >= 8 ? 2048u / nq : 256u;
+    // a wave should walk ~10 chunks of 64 suspects (its gathers run a chunk ahead: a wave with two or three chunks spends its time
+    // on the first round trip — 8 queries: 104 us with 256 blocks per query, the 4-bit stage's pass-through known from earlier
+    // batches puts it at a quarter of that); never more than the chip holds at once
+    const double pairs = t->i4m_pairs > 0.0f ? (double)t->i4m_pairs : 170000.0;
+    uint32_t s2_blocks = (uint32_t)(pairs / 64.0 / 10.0 / 4.0) + 1;
+    if (s2_blocks > 2048u / nq) s2_blocks = 2048u / nq;
+    if (s2_blocks < 8) s2_blocks = 8;
     rescreen8_kernel<<<dim3(s2_blocks, nq), 256, 0, ctx->stream>>>(t->d8, rs.q4m, rs.thr_screen, rs.susp, rs.susp_cnt, cap1, (uint32_t)t->rows,
                                                              rs.susp2, rs.susp2_cnt, rs.cap, rs.overflow, stat);
     PG_HIP(hipGetLastError());
