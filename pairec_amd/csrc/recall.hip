@@ -2748,9 +2748,9 @@ int recall_job_prepare(RecallJob* j) {
         if ((rc = ensure_table_i4(ctx, t))) return rc;
         // every pair the 4-bit stage lets through is one random 128-B read (~35 G/s in rescreen8_kernel): beyond i4m_max_pairs of them per pass
         // the int8 shadow's wider stream is the shorter pass.  The count per query is the table's own running average.
-        // (two query blocks: the 4-bit stage is vector-ALU-bound, 1.7 instead of 1.2 ms per 100 M rows — the budget shrinks with the gain)
+        // (two query blocks: the 4-bit stage is vector-ALU-bound, 1.5 instead of 1.2 ms per 100 M rows — the budget shrinks with the gain)
         j->screen4m = t->i4_ok && (double)t->lam4 <= kn.i4m_max_lambda &&
-                      (double)t->i4m_pairs * j->nq <= kn.i4m_max_pairs * (j->nq > 32 ? 0.45 : 1.0);
+                      (double)t->i4m_pairs * j->nq <= kn.i4m_max_pairs * (j->nq > 32 ? 0.7 : 1.0);
         if (j->screen4m) j->screen4 = false;
     }
     // the threshold model: observe with every pilot-plan batch of a big int8-screened table; predict once the observed

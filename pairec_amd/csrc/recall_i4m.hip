@@ -278,10 +278,12 @@ __global__ __launch_bounds__(64 * kMWaves, 2) void screen4m_kernel(Screen4mArgs 
                 for (int r2 = 0; r2 < 8; ++r2) {
                     const f32x2 t = __builtin_elementwise_fma(nm2, beta[c][r2], mg2);
                     const f32x2 t2 = __builtin_elementwise_fma(tau[c][r2], u2, t);
-                    const bool h0 = !(__int_as_float(acc[c][2 * r2]) < t2.x);
-                    const bool h1 = !(__int_as_float(acc[c][2 * r2 + 1]) < t2.y);
-                    m32 = (m32 << 1) | (h0 ? 1u : 0u);
-                    m32 = (m32 << 1) | (h1 ? 1u : 0u);
+                    // m32 = 2 m32 + hit: the compare's lane mask (compiler-visible: it pads the MFMA -> VALU hazard of the accumulators)
+                    // shifted in as the carry of an add — one instruction instead of a select and a shift-or
+                    const uint64_t k0 = __builtin_amdgcn_fcmpf(__int_as_float(acc[c][2 * r2]), t2.x, 11);          // 11: unordered or >=
+                    asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(m32) : "s"(k0) : "vcc");
+                    const uint64_t k1 = __builtin_amdgcn_fcmpf(__int_as_float(acc[c][2 * r2 + 1]), t2.y, 11);
+                    asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(m32) : "s"(k1) : "vcc");
                 }
             if (row >= a.row_end) m32 = 0;
             // stage the hits, one per lane per round (ballot + prefix count)
