@@ -698,7 +698,8 @@ def clustered_table_leg(pa, o, ctx, table, model, expr, args, R, K, sync, extra_
     """The headline step on CLUSTERED rows (pg_table_fill_mixture: MIX_CENTRES centres on the unit sphere, within-cluster noise of
     norm sigma, normalised; queries are further points of the same mixture, so a query's top-K sits inside one cluster whose
     members score close to each other — the case the int8 bound's slack multiplies suspects in; uniform and i.i.d. Gaussian rows
-    are its two best).  Per sigma: items/s, suspects per answer (what the full pass handed to the exact fp32 re-scoring / K),
+    are its two best).  Per sigma: items/s, suspects per answer (what the int8 screen let through / K) and how many of them reached
+    the exact fp32 re-scoring after the two-digit refinement stage such tables switch on (csrc/recall_r2.hip),
     scan-stage ms with one batch in flight, batches that fell back (screen overflow -> exact scan; failed plan -> re-run) and a
     slice of the device's rows regenerated by the oracle bit for bit."""
     import copy
@@ -733,7 +734,9 @@ def clustered_table_leg(pa, o, ctx, table, model, expr, args, R, K, sync, extra_
         ms_step = el / a1.steps * 1e3
         out.append({"sigma": sigma, "centres": MIX_CENTRES, "shadow_elem_bytes": eb, "value": R * K * a1.steps / el, "unit": "ranked items/s",
                     "ms_per_step": ms_step, "vs_uniform_headline_ms": ms_step / headline_ms,
-                    "suspects_per_answer": delta("recall_suspects") / nq / K, "scan_stage_ms_per_pass": float(np.mean(scan)),
+                    "suspects_per_answer": delta("recall_suspects") / nq / K,
+                    "rescored_per_answer": delta("recall_rescored") / nq / K,
+                    "scan_stage_ms_per_pass": float(np.mean(scan)),
                     "batches": a1.warmup + a1.steps, "batches_on_predicted_thresholds": int(delta("recall_predicted")),
                     "batches_re_run_after_a_failed_plan": int(delta("recall_rescans")),
                     "batches_that_fell_to_the_exact_scan": int(delta("recall_screen_overflows")),

@@ -694,6 +694,8 @@ typedef struct {
      * score) and finished on the exact scan */
     uint64_t recall_suspects, recall_suspect_queries, recall_i4m_pairs, recall_screen_overflows;
     uint64_t recall_record_growths;     /* batches re-run with larger hit-record areas (the table keeps them) */
+    uint64_t recall_rescored;           /* of recall_suspects, the pairs that reached the exact fp32 re-scoring (fewer where a table's
+                                           crowded rows switched the two-digit refinement stage on, csrc/recall_r2.hip) */
 } pg_stats_t;
 int pg_stats(pg_ctx* ctx, pg_stats_t* out);
 /* time (ms) of the dominant kernel of the last pg_recall_* call, measured with HIP events on the

@@ -35,9 +35,12 @@ static void knobs_from_env(Knobs* k) {
     k->fm2t_irs = flag("PG_FM2T_IRS");
     k->dpp_valu = flag("PG_DPP_VALU");
     k->max_rec_scale = (uint32_t)num("PG_MAX_REC_SCALE", 16);
+    k->no_r2 = flag("PG_NO_R2");
+    k->r2_min_factor = num("PG_R2_MIN_FACTOR", 3.0);
     k->coalescer_rejoin = !flag("PG_COALESCER_NO_REJOIN");
     k->no_predict = flag("PG_NO_PREDICT");
     k->predict_sigmas = num("PG_PREDICT_SIGMAS", 4.5);
+    k->predict_max_factor = num("PG_PREDICT_MAX_FACTOR", 4.0);
     k->predict_min_rows = (uint32_t)num("PG_PREDICT_MIN_ROWS", (double)(1u << 22));
     k->screen_early_share = (uint32_t)num("PG_SCREEN_EARLY_SHARE", 604);
     k->l2_exact = flag("PG_L2_EXACT");
@@ -174,10 +177,13 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "sort_lds") k.sort_lds = b;
     else if (n == "fm2t_irs") k.fm2t_irs = b;
     else if (n == "dpp_valu") k.dpp_valu = b;
+    else if (n == "no_r2") k.no_r2 = b;
+    else if (n == "r2_min_factor") k.r2_min_factor = v;
     else if (n == "max_rec_scale") k.max_rec_scale = v >= 1 ? (uint32_t)v : 1u;
     else if (n == "coalescer_rejoin") k.coalescer_rejoin = b;
     else if (n == "no_predict") k.no_predict = b;
     else if (n == "predict_sigmas") k.predict_sigmas = v;
+    else if (n == "predict_max_factor") k.predict_max_factor = v;
     else if (n == "predict_min_rows") k.predict_min_rows = (uint32_t)v;
     else if (n == "screen_early_share") k.screen_early_share = (uint32_t)v;
     else if (n == "l2_exact") k.l2_exact = b;

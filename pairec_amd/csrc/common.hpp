@@ -80,10 +80,13 @@ struct Knobs {
     bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
     bool dpp_valu = false;         // PG_DPP_VALU: the DPP kernel matrix on the fp64 vector pipe (round-4 kernel) instead of the fp64 matrix pipe (A/B; same bits)
     bool fm2t_irs = false;         // PG_FM2T_IRS: cfg 4's item-record rank on the producer / consumer kernel (rank_ir.hip) instead of rank_is.hip (A/B)
+    bool no_r2 = false;            // PG_NO_R2: never refine the int8 screen's suspects on the residual shadow
+    double r2_min_factor = 3.0;    // PG_R2_MIN_FACTOR: ... refine once a table's passes average more than this many suspects per answer (x K)
     uint32_t max_rec_scale = 16;   // PG_MAX_REC_SCALE: the 256-query pass's hit-record areas grow up to this many times their default size with a table
                                    // whose batches overflow them (16: 80 B x 123 M records = 9.8 GB per context at K = 5 000); 1 = never (exact scan instead)
     bool coalescer_rejoin = true;  // PG_COALESCER_NO_REJOIN clears it: after a completion a waiting partial batch is held for the callers just answered
     bool no_predict = false;       // PG_NO_PREDICT: never replace the pilot sample by the learned threshold model
+    double predict_max_factor = 4.0;   // PG_PREDICT_MAX_FACTOR: a table whose predicted thresholds let more than this many suspects per answer through goes back to the pilot plan
     double predict_sigmas = 4.5;   // PG_PREDICT_SIGMAS: margin of the predicted threshold, in standard deviations of the observed quantile
     uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way
     uint32_t screen_early_share_narrow = 512;   // PG_SCREEN_EARLY_SHARE_NARROW: the same for the 8-wave kernels of <= 128 queries
@@ -142,6 +145,12 @@ struct pg_table {
     float rmax4 = 0.0f;          // max over rows of ||x - x^|| (upper bound)
     float lam4 = 0.0f;           // mean residual term in units of the score spread (decides whether the shadow pays)
     float i4m_pairs = 0.0f;      // recall_i4m.hip: running average of the (row, query) pairs its 4-bit stage lets through, per query
+    // recall_r2.hip: the int8 RESIDUAL shadow (x = s8 X8 + s8r Xr + e2) that the refinement stage of crowded tables gathers beside
+    // the int8 shadow; built the first time the table shows more than Knobs::r2_min_factor screen suspects per answer
+    int8_t* d8r = nullptr;
+    float s8r = 0.0f, resid2 = 0.0f;   // its scale (s8 / 254), the measured upper bound of ||e2||
+    bool r2_ok = false, r2_failed = false;
+    float wide_susp = 0.0f;      // running average of the int8 screen's suspects per query (passes without a 4-bit stage)
     uint32_t rec_scale = 0;      // recall.hip: the 256-query pass's hit-record areas, x their default size (0 = 1; doubled when a batch overflows them)
     uint32_t prefix_failures = 0; // batches whose refined thresholds failed verification for most queries (ordered rows): two → no refinement
     // Threshold predictor (recall.hip, DESIGN.md 4.1, plan 0): a Gaussian model of a query's scores over the rows — mean
@@ -288,6 +297,10 @@ struct RecallScratch {
     uint32_t* q4m;
     uint32_t* susp2;
     uint32_t* susp2_cnt;     // [kI4mMaxQueries]
+    // refinement stage of crowded tables (recall_r2.hip): the queries in sixteen bits + constants; its survivors' counts
+    // (their lists share susp2, which holds kMaxQueries lists)
+    uint32_t* q16;
+    uint32_t* susp2w_cnt;    // [kMaxQueries]
 };
 // A predicate over an integer feature column that restricts a recall's candidates (HologresVectorConf.WhereClause of the
 // reference, hologres_vector_recall.go:49-62, in the one shape the device serves: `column OP constant`).  Rows that fail it
@@ -336,6 +349,7 @@ struct RecallJob {
     uint32_t rows = 0, nblocks = 0;
     bool screen = false;
     bool screen4 = false;                   // the pilot plan's full pass streams the 4-bit shadow (nq <= kI4MaxQueries)
+    bool stage2 = false;                    // the int8 screen's suspects pass the two-digit refinement (recall_r2.hip) before the exact re-scoring
     bool screen4m = false;                  // ... through the matrix pipe, suspects thinned on the int8 shadow (kI4MaxQueries < nq <= kI4mMaxQueries)
     int plans[4] = {0, 0, 0, 0};
     bool predict = false;                   // plans[0] takes its first thresholds from the table's threshold model
@@ -343,6 +357,7 @@ struct RecallJob {
     bool observed = false;                  // ... and the enqueued plan did
     double z_lo = 0.0;
     bool susp_stat = false;                 // the enqueued plan reports its suspect counts with the status words
+    bool stat_wide = false;                 // ... and they are the int8 screen's own (no 4-bit stage in front)
     bool refined = false;                   // the enqueued pilot plan raised its thresholds after the first quarter
     int n_plans = 0, next_plan = 0, enqueued_plan = -1;
     uint32_t stride = 1, sample_blocks = 0, k_pilot = 0, perm_mul = 1;
@@ -385,6 +400,10 @@ uint32_t screen4_rescore_blocks();
 constexpr uint32_t kI4mMaxQueries = 64;
 constexpr uint32_t kQ4mWords = kI4mMaxQueries * 32 + kI4mMaxQueries * 4 + 4;
 int screen4m_prep_launch(pg_ctx* ctx, const RecallScratch& rs, uint32_t nq);
+// recall_r2.hip (caller holds ctx->mu)
+int ensure_table_r2(pg_ctx* ctx, const pg_table* tc);
+int rescreen16_prep_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq);
+int rescreen16_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq);
 int screen4m_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t row_begin, uint32_t row_end,
                     uint32_t cap1);
 int topk_merge_strided_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,

@@ -2121,7 +2121,8 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     void* small;
     int rc;
     const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
-    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 40 + 2048 + (size_t)kQ4mWords * 4 + 256 + 64;
+    const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 40 + 2048 + (size_t)kQ4mWords * 4 + 256 + 64 +
+                               (size_t)kMaxQueries * (2 * 128 + 16 + 4) + 128;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
     rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
@@ -2137,8 +2138,10 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     rs->pred_ms = rs->thr_ref + kMaxQueries;             // [kMaxQueries][2]
     rs->susp2_cnt = (uint32_t*)(rs->pred_ms + 2 * kMaxQueries);                       // [kI4mMaxQueries] + two statistics words
     rs->q4m = (uint32_t*)(((uintptr_t)(rs->susp2_cnt + kI4mMaxQueries + 2) + 63) & ~(uintptr_t)63);   // (16-byte fragment loads)
+    rs->q16 = (uint32_t*)(((uintptr_t)(rs->q4m + kQ4mWords) + 63) & ~(uintptr_t)63);              // [256][32] Qh | [256][32] Ql | [256][4]
+    rs->susp2w_cnt = rs->q16 + (size_t)kMaxQueries * (2 * 32 + 4);
     void* c;
-    if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4) + (size_t)kI4mMaxQueries * cap * 4, &c))) return rc;
+    if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4) + (size_t)kMaxQueries * cap * 4, &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
     rs->cand[1] = rs->cand[0] + (size_t)kMaxQueries * cap;
     rs->susp = (uint32_t*)(rs->cand[1] + (size_t)kMaxQueries * cap);
@@ -2192,6 +2195,8 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     t->i4_ok = t->i4_failed = false;                  // the 4-bit shadow (recall_i4.hip) follows the rows too
     t->i4m_pairs = 0.0f;
     t->rec_scale = 0;
+    t->r2_ok = t->r2_failed = false;                  // ... and the residual shadow (recall_r2.hip)
+    t->wide_susp = 0.0f;
     t->pred_model = false;                            // ... and the threshold model
     t->prefix_failures = 0;
     if (t->dim != 64 && t->dim != 128) { t->shadow_failed = true; return PG_OK; }
@@ -2753,6 +2758,14 @@ int recall_job_prepare(RecallJob* j) {
                       (double)t->i4m_pairs * j->nq <= kn.i4m_max_pairs * (j->nq > 32 ? 0.7 : 1.0);
         if (j->screen4m) j->screen4 = false;
     }
+    // crowded rows (clustered embeddings: many suspects per answer): the int8 screen's suspects pass a two-digit refinement on the
+    // residual shadow before the exact re-scoring (recall_r2.hip); passes with a 4-bit stage have their own int8 stage
+    j->stage2 = false;
+    if (screen && !j->l2 && t->dim == 128 && t->shadow_is_i8 && !j->screen4m && !j->screen4 && !kn.no_r2 &&
+        (double)t->wide_susp > kn.r2_min_factor * (double)j->k) {
+        if ((rc = ensure_table_r2(ctx, t))) return rc;
+        j->stage2 = t->r2_ok;
+    }
     // the threshold model: observe with every pilot-plan batch of a big int8-screened table; predict once the observed
     // quantile is tight (plan 0)
     j->predict = j->pred_observe = false;
@@ -2805,6 +2818,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
                                      // its integer-unit thresholds are not needed
     bool last_full_screened = false; // the plan's last scan launch was a screened one ...
     bool last_was_i4m = false;       // ... of the mid-batch kind (its survivors are counted in susp2_cnt)
+    bool last_was_r2 = false;        // ... followed by the refinement stage (its survivors are counted in susp2w_cnt)
     bool exact_chunks = false;       // every chunk on the exact scan: the safe plan of a FILTERED recall.  Its thresholds stay open until K
                                      // admitted rows were seen — under a selective filter, for many chunks — and a screened chunk with open
                                      // thresholds makes every row a suspect of every query: the hit-record regions are sized for the bounded
@@ -2887,6 +2901,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             if (!susp_clean) PG_HIP(hipMemsetAsync(rs.susp_cnt, 0, sizeof(uint32_t) * kMaxQueries, ctx->stream));
             susp_clean = false;
             last_full_screened = true;
+            last_was_r2 = false;
             // the full pass of a small batch streams the 4-bit shadow; its few suspect lists share the whole buffer
             // (whole 64-row groups: a range starts on an even block and ends on one or at the table's end)
             const bool i4 = j->screen4 && allow_i4 && st == 1 && (rb & 1) == 0 && (((rb + cb) & 1) == 0 || rb + cb == j->nblocks);
@@ -2916,7 +2931,14 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             j->scanned_rows += (uint64_t)cb * kPieceRows;
             // exact re-scoring of the launch's suspects → candidate keys (grid.x strides over each list)
             const dim3 rg(i4 ? screen4_rescore_blocks() : kRescoreBlocksPerQuery, nq);
-            if (j->l2)
+            const bool r2 = j->stage2 && t->shadow_is_i8 && !i4 && !i4m && !j->l2 && t->dim == 128;
+            if (r2) {
+                // crowded rows: the suspects once more with two more digits (recall_r2.hip); what is left goes to the exact re-scoring
+                if ((rc2 = rescreen16_launch(ctx, t, rs, nq))) return rc2;
+                last_was_r2 = true;
+                rescore_kernel<128><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp2, rs.susp2w_cnt, rs.cap,
+                                                                 rs.cnt, rs.cand[cur], rs.overflow, rs.cap, j->rows, nullptr, nullptr, j->filter);
+            } else if (j->l2)
                 rescore_kernel<128, true><<<rg, 256, 0, ctx->stream>>>(t->d, rs.qpad, rs.thr, rs.susp, rs.susp_cnt, rs.cap, rs.cnt,
                                                                        rs.cand[cur], rs.overflow, scap, j->rows, t->d_nx, rs.pred_ms, j->filter);
             else if (t->dim == 64)
@@ -3055,6 +3077,7 @@ int recall_job_enqueue(RecallJob* j) {
         }
         if (j->screen4 && (rc = screen4_prep_launch(ctx, t, rs))) return rc;
         if (j->screen4m && (rc = screen4m_prep_launch(ctx, rs, j->nq))) return rc;
+        if (j->stage2 && (rc = rescreen16_prep_launch(ctx, t, rs, j->nq))) return rc;
     }
     const bool observe = j->pred_observe && (plan == kPilot || plan == kPredict);
     if (observe || plan == kPredict) {
@@ -3179,6 +3202,11 @@ int recall_job_enqueue(RecallJob* j) {
         susp_sum_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(r.last_was_i4m ? rs.susp2_cnt : rs.susp_cnt, j->nq, st + 1);
         PG_HIP(hipGetLastError());
         PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt, st, 8, hipMemcpyDeviceToHost, ctx->stream));
+        // [+ 3] what reached the exact re-scoring: the same, or the survivors of the refinement stage
+        if (r.last_was_r2) susp_sum_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.susp2w_cnt, j->nq, rs.susp2w_cnt + kMaxQueries);
+        PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt + 3, r.last_was_r2 ? rs.susp2w_cnt + kMaxQueries : st + 1, 4, hipMemcpyDeviceToHost,
+                              ctx->stream));
+        j->stat_wide = !r.last_was_i4m;
     }
     if (j->d_out_count)
         PG_HIP(hipMemcpyAsync(j->d_out_count, j->d_count, 4 * j->nq, hipMemcpyDeviceToDevice, ctx->stream));
@@ -3287,7 +3315,29 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
             tm->screen_overflow_streak = 0;
         }
     }
+    if (j->susp_stat && ok && j->stat_wide) {
+        // (the int8 screen's suspects per query: decides whether the table's passes get the refinement stage)
+        pg_table* tm = const_cast<pg_table*>(j->t);
+        std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
+        const float per_q = (float)j->h_status[kI4mStatAt + 1] / (float)j->nq;
+        tm->wide_susp = tm->wide_susp > 0.0f ? 0.75f * tm->wide_susp + 0.25f * per_q : per_q;
+    }
+    if (plan == kPredict && ok && j->susp_stat && j->stat_wide &&
+        (double)j->h_status[kI4mStatAt + 1] > ctx->knobs.predict_max_factor * (double)j->k * j->nq) {
+        // The predicted thresholds held but let far more than K rows per query through: on clustered rows the model's margin —
+        // a few per cent of the distance between a query's mean score and its K-th best — is many times the spread of the
+        // scores inside the query's cluster, every member of which then is a true candidate (20 per answer where the sample's
+        // threshold leaves 7-15 suspects, of which the refinement stage keeps one).  Such a table goes back to the pilot plan;
+        // the model gets another try after an exponentially growing number of batches.
+        pg_table* tm = const_cast<pg_table*>(j->t);
+        std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
+        tm->pred_failures++;
+        tm->pred_backoff = 64u << (tm->pred_failures < 6 ? tm->pred_failures : 6);
+        if (ctx->knobs.debug_scan) fprintf(stderr, "[pg] plan %d held with %.1f suspects per answer: pilot plan for the next %u batches\n", plan,
+                                           (double)j->h_status[kI4mStatAt + 1] / j->nq / j->k, tm->pred_backoff);
+    }
     if (j->susp_stat && ok) {
+        ctx->stats.recall_rescored += j->h_status[kI4mStatAt + 3];
         ctx->stats.recall_suspects += j->h_status[kI4mStatAt + 1];
         ctx->stats.recall_suspect_queries += j->nq;
         ctx->stats.recall_i4m_pairs += j->h_status[kI4mStatAt];

@@ -169,6 +169,7 @@ int pg_table_destroy(pg_ctx* ctx, pg_table* t) {
     if (t->d) PG_HIP(hipFree(t->d));
     if (t->d16) PG_HIP(hipFree(t->d16));
     if (t->d8) PG_HIP(hipFree(t->d8));
+    if (t->d8r) PG_HIP(hipFree(t->d8r));
     if (t->d4) PG_HIP(hipFree(t->d4));
     if (t->d4s) PG_HIP(hipFree(t->d4s));
     if (t->dnorm2) PG_HIP(hipFree(t->dnorm2));
@@ -305,6 +306,12 @@ int pg_table_swap(pg_ctx* ctx, pg_table* a, pg_table* b) {
     std::swap(a->lam4, b->lam4);
     std::swap(a->i4m_pairs, b->i4m_pairs);
     std::swap(a->rec_scale, b->rec_scale);
+    std::swap(a->d8r, b->d8r);
+    std::swap(a->s8r, b->s8r);
+    std::swap(a->resid2, b->resid2);
+    std::swap(a->r2_ok, b->r2_ok);
+    std::swap(a->r2_failed, b->r2_failed);
+    std::swap(a->wide_susp, b->wide_susp);
     std::swap(a->prefix_failures, b->prefix_failures);
     std::swap(a->d_pred, b->d_pred);
     std::swap(a->d_nx, b->d_nx);

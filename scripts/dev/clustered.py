@@ -29,8 +29,9 @@ for it in range(reps):
     wall = (time.perf_counter() - t0) * 1e3
     s1 = ctx.stats()
     ms, by = ctx.last_scan_kernel()
-    print("it %d: wall %.2f ms scan %.2f ms bytes %.2f GB | suspects/answer %.2f rescans %d overflows %d predicted %d" % (
-        it, wall, ms, by / 1e9, (s1.recall_suspects - s0.recall_suspects) / max(s1.recall_suspect_queries - s0.recall_suspect_queries, 1) / K,
+    nqd = max(s1.recall_suspect_queries - s0.recall_suspect_queries, 1)
+    print("it %d: wall %.2f ms scan %.2f ms bytes %.2f GB | suspects/answer %.2f rescored/answer %.2f rescans %d overflows %d predicted %d" % (
+        it, wall, ms, by / 1e9, (s1.recall_suspects - s0.recall_suspects) / nqd / K, (s1.recall_rescored - s0.recall_rescored) / nqd / K,
         s1.recall_rescans - s0.recall_rescans, s1.recall_screen_overflows - s0.recall_screen_overflows, s1.recall_predicted - s0.recall_predicted), flush=True)
     ctx.free(d_q)
 if os.environ.get("PG_CHECK"):

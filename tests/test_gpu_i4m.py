@@ -210,6 +210,75 @@ def test_clustered_rows_are_exact(ctx, sigma, nq):
             assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc)) and cnt.tolist() == [k] * nq
         assert s1.recall_screen_overflows == s0.recall_screen_overflows        # the steady state stays on the screened pass
         assert ctx.last_scan_kernel()[1] <= n * 128 * 1.3
+        if nq > 64:
+            # crowded rows switch the refinement stage on (csrc/recall_r2.hip): the third batch re-scores a fraction of the
+            # int8 screen's suspects — and still answers with the oracle's bits
+            s0 = ctx.stats()
+            rows, scores, cnt = t.recall_topk(q, k)
+            s1 = ctx.stats()
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+            susp, resc = s1.recall_suspects - s0.recall_suspects, s1.recall_rescored - s0.recall_rescored
+            assert susp > 3 * k * nq and resc < susp / 2, (susp, resc)
+            ctx.set_option("no_r2", 1)
+            s0 = ctx.stats()
+            rows, scores, cnt = t.recall_topk(q, k)
+            s1 = ctx.stats()
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+            assert s1.recall_rescored - s0.recall_rescored == s1.recall_suspects - s0.recall_suspects
     finally:
         ctx.set_option("i4_min_rows", str(1 << 22))
+        ctx.set_option("no_r2", 0)
+    t.destroy()
+
+
+def test_refinement_stage_on_hostile_data(ctx):
+    """The two-digit refinement (int8 + int8 residual shadow, 16-bit queries: csrc/recall_r2.hip) forced on for every
+    int8-screened pass (r2_min_factor 0) over the data built against the int8 bound: an outlier that coarsens the table's
+    scale, tiny rows, zero rows, winners that differ by less than a quantisation step, exact duplicates, zero / one-hot /
+    tiny / huge / non-finite queries, negative best scores — ids, order and score bits stay the oracle's."""
+    rng = np.random.default_rng(77)
+    n, d, k, nq = 150_000, 128, 600, 100
+    tab = rng.standard_normal((n, d)).astype(np.float32) * 0.05
+    tab[1234, 17] = 0.5
+    tab[2000:2600] *= 1e-6
+    tab[3000:3100] = 0.0
+    near = (rng.standard_normal(d) * 0.05).astype(np.float32)
+    tab[5000:5400] = near * (1.0 + 1e-6 * np.arange(400, dtype=np.float32)[:, None])
+    tab[7000:7050] = tab[6000:6050]
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[0] = 0.0
+    q[1] = 0.0
+    q[1, 17] = 1.0
+    q[2] = near
+    q[3] = -near
+    q[4] *= np.float32(1e-20)
+    q[5] *= np.float32(1e15)
+    q[6:30:3] *= -1.0
+    t = pa.Table(ctx, n, d)
+    t.upload(tab)
+    assert t.screen_info()[0] == 1
+    ctx.set_option("r2_min_factor", -1)
+    try:
+        for lo, hi in ((0, 100), (7, 80), (0, 3)):
+            s0 = ctx.stats()
+            rows, scores, _ = t.recall_topk(q[lo:hi], k)
+            s1 = ctx.stats()
+            orow, osc = o.recall_topk(tab, q[lo:hi], k)
+            assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc)), (lo, hi)
+            if lo == 7:
+                assert 0 < s1.recall_rescored - s0.recall_rescored <= s1.recall_suspects - s0.recall_suspects
+        bad = q[10:90].copy()
+        bad[3, 5] = np.inf
+        bad[7, 9] = np.nan
+        rows, scores, _ = t.recall_topk(bad, k)
+        orow, osc = o.recall_topk(tab, bad, k)
+        assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+        # the residual shadow follows an upload
+        tab[40_000:90_000] = rng.standard_normal((50_000, d)).astype(np.float32) * 0.2
+        t.upload(tab[40_000:90_000], row0=40_000)
+        rows, scores, _ = t.recall_topk(q[7:99], k)
+        orow, osc = o.recall_topk(tab, q[7:99], k)
+        assert np.array_equal(rows, orow) and np.array_equal(bits(scores), bits(osc))
+    finally:
+        ctx.set_option("r2_min_factor", 3)
     t.destroy()
