@@ -86,7 +86,7 @@ struct Knobs {
                                    // whose batches overflow them (16: 80 B x 123 M records = 9.8 GB per context at K = 5 000); 1 = never (exact scan instead)
     bool coalescer_rejoin = true;  // PG_COALESCER_NO_REJOIN clears it: after a completion a waiting partial batch is held for the callers just answered
     bool no_predict = false;       // PG_NO_PREDICT: never replace the pilot sample by the learned threshold model
-    double predict_max_factor = 4.0;   // PG_PREDICT_MAX_FACTOR: a table whose predicted thresholds let more than this many suspects per answer through goes back to the pilot plan
+    double predict_max_factor = 4.0;   // PG_PREDICT_MAX_FACTOR: a table whose predicted thresholds admit more than this many candidates per answer goes back to the pilot plan
     double predict_sigmas = 4.5;   // PG_PREDICT_SIGMAS: margin of the predicted threshold, in standard deviations of the observed quantile
     uint32_t predict_min_rows = 1u << 22;   // PG_PREDICT_MIN_ROWS: smaller tables are launch-bound either way
     uint32_t screen_early_share_narrow = 512;   // PG_SCREEN_EARLY_SHARE_NARROW: the same for the 8-wave kernels of <= 128 queries

@@ -2122,7 +2122,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     int rc;
     const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
     const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 40 + 2048 + (size_t)kQ4mWords * 4 + 256 + 64 +
-                               (size_t)kMaxQueries * (2 * 128 + 16 + 4) + 128;
+                               (size_t)kMaxQueries * (2 * 128 + 16 + 4) + 192;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
     rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
@@ -3153,6 +3153,10 @@ int recall_job_enqueue(RecallJob* j) {
         } else if ((rc = r.scan_range(0, j->nblocks, 1, false, true))) {
             return rc;
         }
+        // (statistics: the candidates the full pass collected, before the select keeps K of each list — a predicted threshold that
+        //  admits many times K is no use to the table, recall_job_check)
+        susp_sum_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.cnt, j->nq, rs.susp2w_cnt + kMaxQueries + 1);
+        PG_HIP(hipGetLastError());
         if ((rc = r.refresh(j->k))) return rc;
     } else {
         // measured: growth 4 is best for the exact scan, 2 for the screened scan whose re-scoring
@@ -3206,6 +3210,7 @@ int recall_job_enqueue(RecallJob* j) {
         if (r.last_was_r2) susp_sum_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.susp2w_cnt, j->nq, rs.susp2w_cnt + kMaxQueries);
         PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt + 3, r.last_was_r2 ? rs.susp2w_cnt + kMaxQueries : st + 1, 4, hipMemcpyDeviceToHost,
                               ctx->stream));
+        PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt + 4, rs.susp2w_cnt + kMaxQueries + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
         j->stat_wide = !r.last_was_i4m;
     }
     if (j->d_out_count)
@@ -3322,19 +3327,20 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
         const float per_q = (float)j->h_status[kI4mStatAt + 1] / (float)j->nq;
         tm->wide_susp = tm->wide_susp > 0.0f ? 0.75f * tm->wide_susp + 0.25f * per_q : per_q;
     }
-    if (plan == kPredict && ok && j->susp_stat && j->stat_wide &&
-        (double)j->h_status[kI4mStatAt + 1] > ctx->knobs.predict_max_factor * (double)j->k * j->nq) {
-        // The predicted thresholds held but let far more than K rows per query through: on clustered rows the model's margin —
-        // a few per cent of the distance between a query's mean score and its K-th best — is many times the spread of the
-        // scores inside the query's cluster, every member of which then is a true candidate (20 per answer where the sample's
-        // threshold leaves 7-15 suspects, of which the refinement stage keeps one).  Such a table goes back to the pilot plan;
-        // the model gets another try after an exponentially growing number of batches.
+    if (plan == kPredict && ok && j->susp_stat &&
+        (double)j->h_status[kI4mStatAt + 4] > ctx->knobs.predict_max_factor * (double)j->k * j->nq) {
+        // The predicted thresholds held but admitted far more than K rows per query as CANDIDATES (exact score >= threshold): on
+        // clustered rows the model's margin — a few per cent of the distance between a query's mean score and its K-th best — is
+        // many times the spread of the scores inside the query's cluster, every member of which then is a true candidate (20 per
+        // answer; the refinement stage cannot reject what really reaches the threshold, while the sample's threshold leaves 7-15
+        // suspects of which it keeps one).  Such a table goes back to the pilot plan; the model gets another try after an
+        // exponentially growing number of batches.
         pg_table* tm = const_cast<pg_table*>(j->t);
         std::lock_guard<std::mutex> build_guard(g_stats_build_mu);
         tm->pred_failures++;
         tm->pred_backoff = 64u << (tm->pred_failures < 6 ? tm->pred_failures : 6);
-        if (ctx->knobs.debug_scan) fprintf(stderr, "[pg] plan %d held with %.1f suspects per answer: pilot plan for the next %u batches\n", plan,
-                                           (double)j->h_status[kI4mStatAt + 1] / j->nq / j->k, tm->pred_backoff);
+        if (ctx->knobs.debug_scan) fprintf(stderr, "[pg] plan %d held with %.1f candidates per answer: pilot plan for the next %u batches\n", plan,
+                                           (double)j->h_status[kI4mStatAt + 4] / j->nq / j->k, tm->pred_backoff);
     }
     if (j->susp_stat && ok) {
         ctx->stats.recall_rescored += j->h_status[kI4mStatAt + 3];
