@@ -18,13 +18,13 @@ ctx = pa.Context(0)
 if os.environ.get("SOAK_SMALL_TABLE_PLANS"):
     # the plans that only big tables take by default — the 4-bit screen of small batches, the threshold model, the refinement —
     # on these mid-size structured tables
-    for opt, val in (("i4_min_rows", 1024), ("predict_min_rows", 0), ("refine_min_rows", 1024)):
+    for opt, val in (("i4_min_rows", 1024), ("predict_min_rows", 0), ("refine_min_rows", 1024), ("i4m_max_pairs", 1e12), ("i4m_max_lambda", 1e6)):
         ctx.set_option(opt, val)
 def bits(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return np.where(np.isnan(a), np.uint32(0x7FC00000), a.view(np.uint32))       # (a NaN's sign / payload is not part of the answer)
 KINDS = ("ascending", "descending", "best_at_head", "best_in_middle", "best_at_tail", "duplicate_runs", "all_equal", "zero_rows",
-         "huge_rows", "tiny_values", "direction_plus_noise", "two_clusters", "nonfinite_rows")
+         "huge_rows", "tiny_values", "direction_plus_noise", "two_clusters", "nonfinite_rows", "mixture")
 t_end = time.time() + seconds
 cases = bad = 0
 while time.time() < t_end:
@@ -63,6 +63,11 @@ while time.time() < t_end:
             tab[rng.integers(0, n, 3), rng.integers(0, d, 3)] = val
     elif kind == "tiny_values":
         tab = noise * np.float32(1e-6)
+    elif kind == "mixture":                                 # clustered rows: a few centres, tight clusters, normalised
+        cen = rng.standard_normal((int(rng.choice([2, 8, 40])), d)).astype(np.float32)
+        cen /= np.linalg.norm(cen, axis=1, keepdims=True)
+        tab = cen[rng.integers(0, cen.shape[0], n)] + np.float32(rng.choice([0.3, 0.1, 0.03])) / np.float32(np.sqrt(d)) * noise
+        tab /= np.linalg.norm(tab, axis=1, keepdims=True)
     elif kind == "direction_plus_noise":
         tab = v[None] * np.float32(0.9) + 0.05 * noise
     else:
@@ -75,7 +80,9 @@ while time.time() < t_end:
     t.upload(tab)
     for _ in range(5):
         l2 = d in (64, 128) and rng.random() < 0.35
-        nq = int(rng.choice([1, 2, 4, 7, 32, 64, 65, 128, 129, 200, 256]))
+        nq = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 32, 33, 48, 64, 65, 128, 129, 200, 256]))
+        # (round 6: the refinement stage of crowded tables — int8 residual shadow, 16-bit queries — forced on for half the batches)
+        ctx.set_option("r2_min_factor", -1 if rng.random() < 0.5 else 3)
         if d > 128:
             nq = min(nq, 32)
         if l2:

@@ -20,6 +20,7 @@ SHAPES = ((128, 128), (256, 128), (256, 256), (512, 256), (1024, 512))
 t_end = time.time() + seconds
 cases = bad = 0
 worst = {0: 0.0, 1: 0.0, 2: 0.0}
+bf16_cases = bf16_over = 0
 while time.time() < t_end:
     d_item = int(rng.choice([64, 128]))
     n = int(rng.choice([300, 50_000, 400_000]))
@@ -75,7 +76,15 @@ while time.time() < t_end:
         worst[prec] = max(worst[prec], err)
         cases += 1
         big = kind == 2 or uscale > 1.0                        # rows or users beyond unit norm
-        tol = 2e-7 if prec == 0 else ((1e-4 if big else 1.5e-5) if prec == 1 else (2e-6 if big else 1e-6))
+        # fp32: the specification itself.  bf16x3: north_star's tolerance against the FP32 oracle, nothing mirrored (1e-5; a case
+        # beyond the 2e-6 regression bar is printed without failing).  Plain bf16 is only held to a looser bar against an oracle that
+        # rounds where it rounds — how often it leaves 1e-5 even there is COUNTED and reported at the end.
+        tol = 2e-7 if prec == 0 else ((1e-4 if big else 1.5e-5) if prec == 1 else 1e-5)
+        if prec == 1:
+            bf16_cases += 1
+            bf16_over += err > 1e-5
+        if prec == 2 and err > 2e-6:
+            print("NOTE bf16x3 beyond its 2e-6 regression bar (inside north_star's 1e-5)", desc, "max abs err", err, flush=True)
         if not (err <= tol) or not np.all(np.isfinite(got)):
             bad += 1
             print("MISMATCH", desc, "max abs err", err, flush=True)
@@ -102,5 +111,7 @@ while time.time() < t_end:
             bad += 1
             print("MISMATCH sort", dict(S=S, total=int(off[-1]), descending=desc_), flush=True)
     t.destroy()
-print(f"soak_rank: {cases} cases, {bad} bad; worst |error|: fp32 mode {worst[0]:.2e}, bf16 mode {worst[1]:.2e}, bf16x3 mode {worst[2]:.2e}", flush=True)
+print(f"soak_rank: {cases} cases, {bad} bad; worst |error|: fp32 mode {worst[0]:.2e}, bf16 mode {worst[1]:.2e}, bf16x3 mode {worst[2]:.2e} "
+      f"(bf16x3 fails at north_star's 1e-5 against the fp32 oracle); plain bf16 exceeded 1e-5 against its MIRRORING oracle in "
+      f"{bf16_over} of {bf16_cases} cases", flush=True)
 sys.exit(1 if bad else 0)
