@@ -555,3 +555,23 @@ def test_pow_last_ulp_classifier():
     ev = lambda: o.antlr_result(tree, data)
     assert ev() == -474.0 and o.pow_last_ulp_explains(ev, float("nan")) and not o.pow_last_ulp_explains(ev, 5.0)
     assert o.go_pow(2.0, 10.0) == 1024.0                                             # (the hook is restored)
+
+
+def test_mixture_rows_are_clustered_normalised_and_reproducible():
+    """o.synth_mixture_rows (oracle.c: orc_synth_mixture_rows; the device's pg_table_fill_mixture regenerates it bit for bit — GPU
+    test tests/test_gpu_i4m.py): rows of norm 1, any slice equals the same rows of a larger draw, a row's nearest centre is its own,
+    and queries (stream 1) are new points of the SAME centres."""
+    seed, C_, sigma, d = 0x5EED0007, 50, 0.1, 128
+    a = o.synth_mixture_rows(seed, 0, 6000, d, C_, sigma)
+    b = o.synth_mixture_rows(seed, 1234, 100, d, C_, sigma)
+    assert np.array_equal(a[1234:1334].view(np.uint32), b.view(np.uint32))
+    assert np.max(np.abs(np.linalg.norm(a.astype(np.float64), axis=1) - 1.0)) < 2e-7
+    cen = o.synth_rows(seed + 1, 0, C_, d)                       # the centres: SURVEY 8d's normalised rows of seed + 1
+    sim = a.astype(np.float64) @ cen.astype(np.float64).T
+    own = sim.max(axis=1)
+    assert np.all(own > 0.98) and np.all(np.sort(sim, axis=1)[:, -2] < 0.6)      # cos to the own centre ~ 1 / sqrt(1 + sigma^2)
+    q = o.synth_mixture_rows(seed, 0, 200, d, C_, sigma, stream=1)
+    assert not np.array_equal(q[:200], a[:200])
+    assert np.all((q.astype(np.float64) @ cen.astype(np.float64).T).max(axis=1) > 0.98)
+    counts = np.bincount(sim.argmax(axis=1), minlength=C_)
+    assert counts.min() > 60 and counts.max() < 200                               # 6 000 rows over 50 centres
