@@ -565,7 +565,7 @@ def test_mixture_rows_are_clustered_normalised_and_reproducible():
     a = o.synth_mixture_rows(seed, 0, 6000, d, C_, sigma)
     b = o.synth_mixture_rows(seed, 1234, 100, d, C_, sigma)
     assert np.array_equal(a[1234:1334].view(np.uint32), b.view(np.uint32))
-    assert np.max(np.abs(np.linalg.norm(a.astype(np.float64), axis=1) - 1.0)) < 2e-7
+    assert np.max(np.abs(np.linalg.norm(a.astype(np.float64), axis=1) - 1.0)) < 1e-6     # (fp32 normalisation)
     cen = o.synth_rows(seed + 1, 0, C_, d)                       # the centres: SURVEY 8d's normalised rows of seed + 1
     sim = a.astype(np.float64) @ cen.astype(np.float64).T
     own = sim.max(axis=1)
