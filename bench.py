@@ -1466,10 +1466,11 @@ def group_sub_leg(pa, o, devices, args, R, K, prec, blob):
         tk = nxt
     elapsed = time.perf_counter() - t0
     ok = int(page[4].min()) == args.page and bool(np.all(np.isfinite(page[3])))
+    exch = dict(g.exchange_stats(), unpruned_bytes_per_shard=R * K * 12)
     g.destroy()
     expr.free()
     return {"value": R * K * args.steps / elapsed, "unit": "ranked items/s", "ms_per_step": elapsed / args.steps * 1e3,
-            "scaling": "weak", "ok": bool(ok),
+            "scaling": "weak", "ok": bool(ok), "exchange": exch,
             "config": {"workload": "configs[4]: %d x %d fp32 table in %d row-range shards, %d requests x top-%d -> merge -> "
                                    "owner-computes DNN3 rank (%s) -> fuse -> sort -> DPPSort(%d candidates, page %d); one process, "
                                    "pg_group_recommend_begin / _end, two steps in flight"
