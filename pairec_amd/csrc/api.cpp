@@ -38,6 +38,7 @@ static void knobs_from_env(Knobs* k) {
     k->no_r2 = flag("PG_NO_R2");
     k->r2_min_factor = num("PG_R2_MIN_FACTOR", 3.0);
     k->coalescer_rejoin = !flag("PG_COALESCER_NO_REJOIN");
+    k->coalescer_rejoin_us_per_caller = num("PG_COALESCER_REJOIN_US", 2.0);
     k->no_predict = flag("PG_NO_PREDICT");
     k->predict_sigmas = num("PG_PREDICT_SIGMAS", 4.5);
     k->predict_max_factor = num("PG_PREDICT_MAX_FACTOR", 4.0);
@@ -181,6 +182,7 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "r2_min_factor") k.r2_min_factor = v;
     else if (n == "max_rec_scale") k.max_rec_scale = v >= 1 ? (uint32_t)v : 1u;
     else if (n == "coalescer_rejoin") k.coalescer_rejoin = b;
+    else if (n == "coalescer_rejoin_us_per_caller") k.coalescer_rejoin_us_per_caller = v;
     else if (n == "no_predict") k.no_predict = b;
     else if (n == "predict_sigmas") k.predict_sigmas = v;
     else if (n == "predict_max_factor") k.predict_max_factor = v;

@@ -839,14 +839,14 @@ void completer_main(pg_coalescer* c) {
         const double ms = std::chrono::duration<double, std::milli>(Clock::now() - s->enqueued).count();
         lk.lock();
         c->inflight.pop_front();
-        if (!c->group && s->queue < kQRank0 && s->queue != kQDpp && s->n_req && s->n_req < c->max_batch && c->inflight.empty() &&
+        if (!c->group && s->queue < kQRank0 && s->queue != kQDpp && s->n_req && c->inflight.empty() &&
             c->ctx->knobs.coalescer_rejoin) {
             const int f = s->queue;
             const bool on = c->rejoin_score[f] >= 0.5 || (++c->rejoin_probe[f] & 15u) == 0;
             if (on) {
                 c->rejoin_n[f] = s->n_req;
                 c->rejoin_target[f] = c->queue[f].size() + s->n_req;
-                c->rejoin_until[f] = Clock::now() + std::chrono::microseconds(50 + 2 * (int)s->n_req);
+                c->rejoin_until[f] = Clock::now() + std::chrono::microseconds(50 + (int)(c->ctx->knobs.coalescer_rejoin_us_per_caller * s->n_req));
             }
         }
         c->stats.device_ms[(fl == kDpp && s->key.ssd) ? (int)kSsd : fl] += ms;

@@ -84,6 +84,7 @@ struct Knobs {
     double r2_min_factor = 3.0;    // PG_R2_MIN_FACTOR: ... refine once a table's passes average more than this many suspects per answer (x K)
     uint32_t max_rec_scale = 16;   // PG_MAX_REC_SCALE: the 256-query pass's hit-record areas grow up to this many times their default size with a table
                                    // whose batches overflow them (16: 80 B x 123 M records = 9.8 GB per context at K = 5 000); 1 = never (exact scan instead)
+    double coalescer_rejoin_us_per_caller = 2.0;   // PG_COALESCER_REJOIN_US: the hold lasts at most 50 + this x n microseconds for a batch of n
     bool coalescer_rejoin = true;  // PG_COALESCER_NO_REJOIN clears it: after a completion a waiting partial batch is held for the callers just answered
     bool no_predict = false;       // PG_NO_PREDICT: never replace the pilot sample by the learned threshold model
     double predict_max_factor = 4.0;   // PG_PREDICT_MAX_FACTOR: a table whose predicted thresholds admit more than this many candidates per answer goes back to the pilot plan

@@ -16,11 +16,11 @@ m = pa.RankModel(ctx, pa.MODEL_DNN3, pa.PREC_BF16X3, pa.pack_dnn3(w.w1, w.b1, w.
 ex = pa.Expr(bench.RANK_EXPR)
 users = np.ascontiguousarray(o.synth_rows(o.SEED_QUERY, 0, 1000, 128))
 spec = bench.LoadgenSpec(mode=0, user_vecs=users.ctypes.data, n_users=1000, dim=128, k=5000, top_n=100)
-for rejoin in (1, 0):
+for rejoin in [int(x) for x in os.environ.get("PG_CS_REJOIN", "1,0").split(",")]:
     ctx.set_option("coalescer_rejoin", rejoin)
     co = pa.Coalescer(ctx, t, 5000, m, ex, "gpu_dnn", max_top_n=100, depth=3)
     bench.loadgen(co, spec, 768, 3.0, 2, 2, 5000)          # (trains the table's threshold model)
-    for callers in (1, 4, 8, 16, 32, 64, 128, 256, 768):
+    for callers in [int(x) for x in os.environ.get("PG_CS_CALLERS", "1,4,8,16,32,64,128,256,768").split(",")]:
         r = bench.loadgen(co, spec, callers, 1.5, 2, 2, 5000)
         print("rejoin %d callers %4d: p50 %.2f ms p99 %.2f  avg batch %.1f  %.1f M items/s" % (rejoin, callers, r["p50_ms"], r["p99_ms"], r["avg_batch"], r["value"] / 1e6), flush=True)
     co.destroy()
