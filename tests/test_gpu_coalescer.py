@@ -322,3 +322,46 @@ def test_concurrent_callers_throughput_is_10x_solo(ctx, world):
     print("solo %.0f req/s (p50 %.2f ms), 256 callers %.0f req/s (p50 %.2f ms, p99 %.2f ms)" %
           (rs, solo.p50_ms, rm, many.p50_ms, many.p99_ms))
     assert rm >= 10 * rs
+
+
+@pytest.mark.parametrize("callers", [5, 24, 48])
+def test_coalesced_mid_batches_ride_the_4bit_paths_and_equal_solo_calls(ctx, world, callers):
+    """Round 6: a handful to a few dozen concurrent callers make passes of 3-64 requests — the 4-bit shadow through the matrix
+    pipe + its int8 stage (csrc/recall_i4m.hip; forced on for this small table), behind the rejoin hold of the coalescer.  Every
+    caller's page equals the same request alone, bit for bit, and the recall flavour equals pg_recall_topk; the callers, closed
+    loops, end up in ONE batch per round."""
+    t, m, ex = world
+    k, top_n, rounds = 500, 50, 4
+    for name, v in (("i4_min_rows", "0"), ("i4m_max_pairs", "1e12"), ("i4m_max_lambda", "1000")):
+        ctx.set_option(name, v)
+    try:
+        q = o.synth_rows(o.SEED_QUERY, 300, callers * rounds, 128)
+        ref = {}
+        for i in range(0, callers * rounds, 7):
+            rows, rec, rnk, fus, order, cnt = pa.recommend_dnn3(ctx, t, m, ex, "gpu_dnn", q[i:i + 1], k)
+            p = order[0][:top_n]
+            ref[i] = (rows[0][p], rec[0][p], rnk[0][p], fus[0][p])
+        r_rows, r_sc, _ = t.recall_topk(q[:callers], k)
+        co = pa.Coalescer(ctx, t, k, m, ex, "gpu_dnn", max_top_n=top_n, max_wait_us=2000)
+        got = [None] * (callers * rounds)
+        rec_got = [None] * callers
+
+        def call(i):
+            for r in range(rounds):
+                got[i + r * callers] = co.recommend(q[i + r * callers], top_n)
+            rec_got[i] = co.recall(q[i])
+        run_threads(callers, call)
+        st = co.stats()
+        co.destroy()
+        for i, (rows, rec, rnk, fus) in ref.items():
+            g = got[i]
+            assert g[4] == top_n and np.array_equal(g[0], rows), "request %d: page differs from the solo call" % i
+            assert np.array_equal(bits(g[1]), bits(rec)) and np.array_equal(bits(g[2]), bits(rnk)) and np.array_equal(bits(g[3]), bits(fus))
+        for i in range(callers):
+            assert np.array_equal(rec_got[i][0], r_rows[i]) and np.array_equal(bits(rec_got[i][1]), bits(r_sc[i]))
+        assert st.requests[2] == callers * rounds
+        assert st.batches[2] <= rounds + 3, "the closed loops did not merge into one batch per round: %d batches" % st.batches[2]
+        assert ctx.last_scan_kernel()[1] < t.rows * 128
+    finally:
+        for name, v in (("i4_min_rows", str(1 << 22)), ("i4m_max_pairs", "2.4e7"), ("i4m_max_lambda", "2.2")):
+            ctx.set_option(name, v)
