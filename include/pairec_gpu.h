@@ -696,6 +696,8 @@ typedef struct {
     uint64_t recall_record_growths;     /* batches re-run with larger hit-record areas (the table keeps them) */
     uint64_t recall_rescored;           /* of recall_suspects, the pairs that reached the exact fp32 re-scoring (fewer where a table's
                                            crowded rows switched the two-digit refinement stage on, csrc/recall_r2.hip) */
+    uint64_t sort_split_calls;          /* score sorts and top-K final orders that took the split sort (few lists of 1025 … 8192
+                                           items: runs sorted wave by wave over the chip, csrc/split_sort.hpp) */
 } pg_stats_t;
 int pg_stats(pg_ctx* ctx, pg_stats_t* out);
 /* time (ms) of the dominant kernel of the last pg_recall_* call, measured with HIP events on the

@@ -53,7 +53,7 @@ class PgStats(C.Structure):
                 ("last_sort_ms", C.c_double), ("recall_predicted", C.c_uint64),
                 ("recall_suspects", C.c_uint64), ("recall_suspect_queries", C.c_uint64), ("recall_i4m_pairs", C.c_uint64),
                 ("recall_screen_overflows", C.c_uint64), ("recall_record_growths", C.c_uint64),
-                ("recall_rescored", C.c_uint64)]
+                ("recall_rescored", C.c_uint64), ("sort_split_calls", C.c_uint64)]
 
 
 class PgDppOptions(C.Structure):

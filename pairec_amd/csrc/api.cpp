@@ -31,6 +31,7 @@ static void knobs_from_env(Knobs* k) {
     k->i4m_max_pairs = num("PG_I4M_MAX_PAIRS", 2.4e7);
     k->rank_no_ws = flag("PG_RANK_NO_WS");
     k->rank_sort_max = (uint32_t)num("PG_RANK_SORT_MAX", 8);
+    k->split_sort_max = (uint32_t)num("PG_SPLIT_SORT_MAX", 128);
     k->sort_lds = flag("PG_SORT_LDS");
     k->fm2t_irs = flag("PG_FM2T_IRS");
     k->dpp_valu = flag("PG_DPP_VALU");
@@ -175,6 +176,7 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "i4m_max_pairs") k.i4m_max_pairs = v;
     else if (n == "rank_no_ws") k.rank_no_ws = b;
     else if (n == "rank_sort_max") k.rank_sort_max = (uint32_t)v;
+    else if (n == "split_sort_max") k.split_sort_max = (uint32_t)v;
     else if (n == "sort_lds") k.sort_lds = b;
     else if (n == "fm2t_irs") k.fm2t_irs = b;
     else if (n == "dpp_valu") k.dpp_valu = b;

@@ -64,7 +64,8 @@ struct BitonicLds {
 // sort: a wave whose 512 elements lie in such blocks skips the phase's compare-exchanges (not its barriers).  5 000 of
 // 8 192: six of sixteen waves idle through the 55 stages up to kk = 1024, four through the 11 of kk = 2048 — the network is
 // VALU-bound, four waves per SIMD.
-template <bool WITH_IDX>
+// WAVE_ONLY: P = 512 in a one-wave workgroup — the branch that crosses waves is not compiled, `lds` is never touched.
+template <bool WITH_IDX, bool WAVE_ONLY = false>
 __device__ __forceinline__ void bitonic_sort_reg(uint64_t (&k)[kBitonicE], uint32_t (&ix)[kBitonicE], uint32_t P,
                                                  BitonicLds& lds, uint32_t n_real = 0xFFFFFFFFu) {
     const uint32_t t = threadIdx.x;
@@ -80,7 +81,7 @@ __device__ __forceinline__ void bitonic_sort_reg(uint64_t (&k)[kBitonicE], uint3
         for (uint32_t j = kk >> 1; j >= (uint32_t)kBitonicE; j >>= 1) {
             const uint32_t m = j / kBitonicE;             // partner thread = t ^ m
             const bool keep_min = ((t & m) == 0) == dir;
-            if (m >= 64) {
+            if (!WAVE_ONLY && m >= 64) {
                 if (act) {
 #pragma unroll
                     for (int u = 0; u < kBitonicE; ++u) {

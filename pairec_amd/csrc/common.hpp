@@ -76,6 +76,7 @@ struct Knobs {
     uint32_t i4_min_rows = 1u << 22; // PG_I4_MIN_ROWS: smallest table the 4-bit screen is built for
     double i4_max_lambda = 1.7;    // PG_I4_MAX_LAMBDA: largest pg_table::lam4 the 4-bit screen is used for
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
+    uint32_t split_sort_max = 128; // PG_SPLIT_SORT_MAX: up to this many lists (of 1025 … 8192 items) per call are sorted run by run over the chip (split_sort.hpp; 0 = never)
     uint32_t rank_sort_max = 8;    // PG_RANK_SORT_MAX: up to this many lists per call are sorted by counting ranks (0 = never)
     bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
     bool dpp_valu = false;         // PG_DPP_VALU: the DPP kernel matrix on the fp64 vector pipe (round-4 kernel) instead of the fp64 matrix pipe (A/B; same bits)
@@ -302,7 +303,10 @@ struct RecallScratch {
     // (their lists share susp2, which holds kMaxQueries lists)
     uint32_t* q16;
     uint32_t* susp2w_cnt;    // [kMaxQueries]
+    uint32_t* status;        // [kRecallStatusWords] a job's status words, packed by one kernel for ONE copy to the host
+    uint32_t* cnt_seen;      // [kMaxQueries] the candidates each query had collected when the last select kept K of them
 };
+constexpr uint32_t kRecallStatusWords = 640;
 // A predicate over an integer feature column that restricts a recall's candidates (HologresVectorConf.WhereClause of the
 // reference, hologres_vector_recall.go:49-62, in the one shape the device serves: `column OP constant`).  Rows that fail it
 // never become candidates — it is applied where candidates are made (exact re-scoring, the exact scan's hit path), so every
@@ -386,7 +390,7 @@ int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, ui
 int recall_patch_failed_locked(RecallJob* j, uint32_t* counts);
 int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs);
 int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
-                  uint32_t cap, uint32_t k, int thr_only = 0);
+                  uint32_t cap, uint32_t k, int thr_only = 0, uint32_t* cnt_seen = nullptr);
 int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap, uint32_t nq, uint32_t k,
                  uint64_t row_offset, uint64_t* d_out_rows, float* d_out_scores, uint32_t* d_out_count);
 int ensure_table_stats(pg_ctx* ctx, const pg_table* tc);
@@ -406,7 +410,7 @@ int ensure_table_r2(pg_ctx* ctx, const pg_table* tc);
 int rescreen16_prep_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq);
 int rescreen16_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq);
 int screen4m_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t row_begin, uint32_t row_end,
-                    uint32_t cap1);
+                    uint32_t cap1, bool susp2_clean = false);
 int topk_merge_strided_locked(pg_ctx* ctx, const uint64_t* d_rows, const float* d_scores, uint32_t nq, uint32_t nlists,
                               uint32_t per_list, size_t row_ls, size_t row_qs, size_t sc_ls, size_t sc_qs, uint32_t k,
                               uint64_t* d_out_rows, float* d_out_scores, uint32_t* d_out_count);

@@ -27,6 +27,7 @@
 //   final_kernel     per query: bitonic sort of the K survivors in LDS, decode to (row, score).
 #include "common.hpp"
 #include "bitonic_reg.hpp"
+#include "split_sort.hpp"
 
 #include <type_traits>
 
@@ -1566,7 +1567,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const uint64_t* __restrict
                                                       uint64_t* __restrict__ cand_out,
                                                       uint32_t* __restrict__ cnt,
                                                       float* __restrict__ thr, uint32_t cap,
-                                                      uint32_t K, int thr_only) {
+                                                      uint32_t K, int thr_only, uint32_t* __restrict__ cnt_seen) {
     // thr_only: the lists stay as they are (cand_out is not written, cnt unchanged); the query's threshold rises to the
     // score of its K-th largest candidate so far — when it has that many (the refinement step of the pilot plan)
     extern __shared__ __attribute__((aligned(16))) char sel_smem[];
@@ -1578,6 +1579,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const uint64_t* __restrict
     const uint64_t* in = cand_in + (uint64_t)q * cap;
     uint64_t* out = cand_out + (uint64_t)q * cap;
     uint32_t M = cnt[q];
+    if (threadIdx.x == 0 && cnt_seen) cnt_seen[q] = M;      // (statistics: the candidates collected before K of them are kept)
     if (M > cap) M = cap;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) { s_min = ~0ull; s_max = 0ull; }
@@ -2052,11 +2054,11 @@ __global__ void pred_update_kernel(const float* __restrict__ thr, const float* _
 }
 
 int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
-                         uint32_t cap, uint32_t k, int thr_only) {
+                         uint32_t cap, uint32_t k, int thr_only, uint32_t* cnt_seen) {
     constexpr size_t lds = (size_t)kSelLdsKeys * 8;
     int rc_attr;
     if ((rc_attr = ensure_dyn_lds(ctx, (const void*)select_kernel, lds))) return rc_attr;
-    select_kernel<<<nq, 1024, lds, ctx->stream>>>(in, out, cnt, thr, cap, k, thr_only);
+    select_kernel<<<nq, 1024, lds, ctx->stream>>>(in, out, cnt, thr, cap, k, thr_only, cnt_seen);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
@@ -2122,7 +2124,7 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     int rc;
     const size_t qb16_bytes = (size_t)kScreenMaxNQB * (dim / 16) * 64 * 16;
     const size_t small_bytes = (size_t)kMaxQueries * dim * 4 + qb16_bytes + (size_t)kMaxQueries * 40 + 2048 + (size_t)kQ4mWords * 4 + 256 + 64 +
-                               (size_t)kMaxQueries * (2 * 128 + 16 + 4) + 192;
+                               (size_t)kMaxQueries * (2 * 128 + 16 + 4) + 192 + (size_t)(kRecallStatusWords + kMaxQueries) * 4 + 64;
     if ((rc = scratch_reserve(ctx, 2, small_bytes, &small))) return rc;
     rs->qpad = (float*)small;
     rs->qb16 = (uint4*)((char*)small + (size_t)kMaxQueries * dim * 4);
@@ -2140,6 +2142,8 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     rs->q4m = (uint32_t*)(((uintptr_t)(rs->susp2_cnt + kI4mMaxQueries + 2) + 63) & ~(uintptr_t)63);   // (16-byte fragment loads)
     rs->q16 = (uint32_t*)(((uintptr_t)(rs->q4m + kQ4mWords) + 63) & ~(uintptr_t)63);              // [256][32] Qh | [256][32] Ql | [256][4]
     rs->susp2w_cnt = rs->q16 + (size_t)kMaxQueries * (2 * 32 + 4);
+    rs->status = (uint32_t*)(((uintptr_t)(rs->susp2w_cnt + kMaxQueries + 2) + 63) & ~(uintptr_t)63);
+    rs->cnt_seen = rs->status + kRecallStatusWords;
     void* c;
     if ((rc = scratch_reserve(ctx, 3, (size_t)kMaxQueries * cap * (2 * 8 + 4) + (size_t)kMaxQueries * cap * 4, &c))) return rc;
     rs->cand[0] = (uint64_t*)c;
@@ -2150,9 +2154,37 @@ int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs) {
     return PG_OK;
 }
 
+// final as a split sort (split_sort.hpp): descending by candidate key = ascending on the complement, keys distinct
+struct FinalSortPolicy {
+    static constexpr bool kWithIdx = false;
+    const uint64_t* cand;
+    const uint32_t* cnt;
+    uint32_t cap, K;
+    uint64_t row_offset;
+    uint64_t* out_rows;
+    float* out_scores;
+    uint32_t* out_count;
+    __device__ uint32_t count(uint32_t q) const { const uint32_t n = cnt[q]; return n < K ? n : K; }
+    __device__ uint64_t key(uint32_t q, uint32_t i) const { return ~cand[(uint64_t)q * cap + i]; }
+    __device__ void store(uint32_t q, uint32_t rank, uint64_t k, uint32_t) const {
+        out_rows[(uint64_t)q * K + rank] = row_offset + key_row(~k);
+        out_scores[(uint64_t)q * K + rank] = key_score(~k);
+    }
+    // positions past the candidates (fewer than K rows in the table); t = this thread among nt of the list's workgroups
+    __device__ void tail(uint32_t q, uint32_t n, uint32_t t, uint32_t nt) const {
+        for (uint32_t i = n + t; i < K; i += nt) {
+            out_rows[(uint64_t)q * K + i] = ~0ull;
+            out_scores[(uint64_t)q * K + i] = -__builtin_inff();
+        }
+        if (t == 0 && out_count) out_count[q] = n;
+    }
+};
+
 int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap,
                         uint32_t nq, uint32_t k, uint64_t row_offset, uint64_t* d_out_rows,
                         float* d_out_scores, uint32_t* d_out_count) {
+    if (split_sort_applies(ctx, nq, k))
+        return split_sort_launch(ctx, FinalSortPolicy{cand, cnt, cap, k, row_offset, d_out_rows, d_out_scores, d_out_count}, nq, k);
     if (k <= kRankSortMaxItems && nq <= ctx->knobs.rank_sort_max && !ctx->knobs.sort_lds) {
         const size_t lds = (size_t)((k + 31u) & ~31u) * 8;
         int rc_attr;
@@ -2289,8 +2321,42 @@ int ensure_table_stats(pg_ctx* ctx, const pg_table* tc) {
     return PG_OK;
 }
 
-constexpr uint32_t kPredStatsAt = 600;        // words [600, 610) of a job's status block: the table's observation sums
-constexpr uint32_t kI4mStatAt = 612;          // ... the (row, query) pairs the 4-bit stage of a mid-batch pass let through
+// a job's status block, packed on the device by status_pack_kernel and copied to the host in ONE piece: [0] overflow flag,
+// [1 + q] valid count of query q, then
+constexpr uint32_t kPredStatsAt = 260;        // words [260, 270): the table's observation sums (five doubles)
+constexpr uint32_t kI4mStatAt = 272;          // [272] the (row, query) pairs the 4-bit stage of a mid-batch pass let through,
+                                              // [+1] suspects of the full pass's last launch, [+2] a hit-record area overflowed,
+                                              // [+3] pairs that reached the exact re-scoring, [+4] candidates the pass collected
+constexpr uint32_t kStatusCopyWords = kI4mStatAt + 5;
+static_assert(kStatusCopyWords <= 300 && kStatusCopyWords <= kRecallStatusWords, "the status block ends in front of the words other calls keep in ctx->h_status");
+
+// (launched <<<1, kMaxQueries>>>; null pointers = words that stay zero)
+__global__ void status_pack_kernel(const uint32_t* __restrict__ overflow, uint32_t nq, uint32_t rec_ovf_word,
+                                   const uint32_t* __restrict__ pred_stats, const uint32_t* __restrict__ pairs_word,
+                                   const uint32_t* __restrict__ susp, const uint32_t* __restrict__ rescored,
+                                   const uint32_t* __restrict__ cand_seen, uint32_t* __restrict__ out) {
+    const uint32_t t = threadIdx.x;
+    uint32_t v1 = (susp && t < nq) ? susp[t] : 0u, v3 = (rescored && t < nq) ? rescored[t] : 0u, v4 = (cand_seen && t < nq) ? cand_seen[t] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v1 += __shfl_xor(v1, off, 64);
+        v3 += __shfl_xor(v3, off, 64);
+        v4 += __shfl_xor(v4, off, 64);
+    }
+    __shared__ uint32_t s[3][4];
+    if ((t & 63) == 0) { s[0][t >> 6] = v1; s[1][t >> 6] = v3; s[2][t >> 6] = v4; }
+    out[1 + t] = t < nq ? overflow[1 + t] : 0u;
+    if (t < 10) out[kPredStatsAt + t] = pred_stats ? pred_stats[t] : 0u;
+    __syncthreads();
+    if (t == 0) {
+        out[0] = overflow[0];
+        out[kI4mStatAt] = pairs_word ? *pairs_word : 0u;
+        out[kI4mStatAt + 1] = s[0][0] + s[0][1] + s[0][2] + s[0][3];
+        out[kI4mStatAt + 2] = overflow[rec_ovf_word];
+        out[kI4mStatAt + 3] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+        out[kI4mStatAt + 4] = s[2][0] + s[2][1] + s[2][2] + s[2][3];
+    }
+}
 
 // the threshold model of a table (dim 128): mean and covariance of a row sample, built once per generation of the rows
 static int ensure_pred_model(pg_ctx* ctx, const pg_table* tc) {
@@ -2813,6 +2879,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
     RecallScratch& rs;
     uint32_t n_ev = 0;
     int cur = 0;
+    bool susp2_clean = false;        // screen4m_prep_kernel left the mid-batch pass's second counters at zero (same)
     bool susp_clean = true;          // recall_init_kernel left the suspect counters at zero: the plan's first screened launch skips its memset
     bool no_i8 = false;              // the plan launches no int8 / bf16 screen (thresholds predicted, full pass on the 4-bit shadow):
                                      // its integer-unit thresholds are not needed
@@ -2914,7 +2981,8 @@ struct PlanRun {                     // the launches of one plan (helper of reca
                 j->scan_bytes += (r_end - r_begin) * (j->l2 ? 72 : 68);      // (squared Euclidean: + the row's |x|^2)
             } else if (i4m) {
                 // stage-1 suspects share the whole buffer ([nq][4 cap]); what passes the int8 stage lands in susp2 ([nq][cap])
-                if ((rc2 = screen4m_launch(ctx, t, rs, nq, (uint32_t)r_begin, (uint32_t)r_end, rs.cap * (uint32_t)(kMaxQueries / kI4mMaxQueries)))) return rc2;
+                if ((rc2 = screen4m_launch(ctx, t, rs, nq, (uint32_t)r_begin, (uint32_t)r_end, rs.cap * (uint32_t)(kMaxQueries / kI4mMaxQueries), susp2_clean))) return rc2;
+                susp2_clean = false;
                 j->scan_bytes += (r_end - r_begin) * 68;
                 last_was_i4m = true;
             } else {
@@ -2986,10 +3054,11 @@ struct PlanRun {                     // the launches of one plan (helper of reca
         return PG_OK;
     }
     // keep the best `kk` candidates per query, refresh the thresholds, swap the ping-pong lists
-    int refresh(uint32_t kk) {
+    // last: no launch screens against these thresholds any more (the screen's integer cutoffs are not derived)
+    int refresh(uint32_t kk, bool last = false) {
         int rc2;
-        if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk, 0))) return rc2;
-        if (j->screen && !no_i8) {
+        if ((rc2 = launch_select(ctx, j->nq, rs.cand[cur], rs.cand[cur ^ 1], rs.cnt, rs.thr, rs.cap, kk, 0, rs.cnt_seen))) return rc2;
+        if (j->screen && !no_i8 && !(last && !j->l2)) {
             if (j->l2) screen_thr8_l2_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, rs.pred_ms, t->s8, t->max_norm,
                                                                                 rs.thr_screen, rs.thr_ref, j->l2_per_row ? 1 : 0);
             else if (t->shadow_is_i8) screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
@@ -3076,7 +3145,10 @@ int recall_job_enqueue(RecallJob* j) {
             PG_HIP(hipGetLastError());
         }
         if (j->screen4 && (rc = screen4_prep_launch(ctx, t, rs))) return rc;
-        if (j->screen4m && (rc = screen4m_prep_launch(ctx, rs, j->nq))) return rc;
+        if (j->screen4m) {
+            if ((rc = screen4m_prep_launch(ctx, rs, j->nq))) return rc;
+            r.susp2_clean = true;
+        }
         if (j->stage2 && (rc = rescreen16_prep_launch(ctx, t, rs, j->nq))) return rc;
     }
     const bool observe = j->pred_observe && (plan == kPilot || plan == kPredict);
@@ -3155,9 +3227,8 @@ int recall_job_enqueue(RecallJob* j) {
         }
         // (statistics: the candidates the full pass collected, before the select keeps K of each list — a predicted threshold that
         //  admits many times K is no use to the table, recall_job_check)
-        susp_sum_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.cnt, j->nq, rs.susp2w_cnt + kMaxQueries + 1);
-        PG_HIP(hipGetLastError());
-        if ((rc = r.refresh(j->k))) return rc;
+        // (select_kernel notes them in rs.cnt_seen)
+        if ((rc = r.refresh(j->k, true))) return rc;
     } else {
         // measured: growth 4 is best for the exact scan, 2 for the screened scan whose re-scoring
         // gathers 512 B per staged candidate
@@ -3194,28 +3265,24 @@ int recall_job_enqueue(RecallJob* j) {
         double* stats = reinterpret_cast<double*>(t->d_pred + 128 + 128 * 128);
         pred_update_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.pred_ms, j->d_count, j->nq, j->k < j->rows ? j->k : j->rows, stats);
         PG_HIP(hipGetLastError());
-        PG_HIP(hipMemcpyAsync(j->h_status + kPredStatsAt, stats, 40, hipMemcpyDeviceToHost, ctx->stream));
     }
-    PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt + 2, rs.overflow + kRecOvfWord, 4, hipMemcpyDeviceToHost, ctx->stream));
     j->susp_stat = j->screen && (plan == kPilot || plan == kPredict) && r.last_full_screened;
-    if (j->susp_stat) {
-        // [kI4mStatAt] the pairs a mid-batch pass's 4-bit stage let through (zero otherwise), [+ 1] the suspects that reached the
-        // exact re-scoring in the full pass's last launch
-        uint32_t* const st = rs.susp2_cnt + kI4mMaxQueries;
-        if (!r.last_was_i4m) PG_HIP(hipMemsetAsync(st, 0, 4, ctx->stream));
-        susp_sum_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(r.last_was_i4m ? rs.susp2_cnt : rs.susp_cnt, j->nq, st + 1);
+    j->stat_wide = j->susp_stat && !r.last_was_i4m;
+    {
+        // the status words in one block, one copy (they were six copies and two sums of their own: ~40 us of a small batch's step):
+        // [kI4mStatAt] the pairs a mid-batch pass's 4-bit stage let through (zero otherwise), [+ 1] the suspects its int8 stage / the
+        // int8 screen handed on in the full pass's last launch, [+ 3] what reached the exact re-scoring: the same, or the survivors
+        // of the refinement stage, [+ 4] the candidates the pass collected (select_kernel notes them before it keeps K)
+        const uint32_t* const susp = j->susp_stat ? (r.last_was_i4m ? rs.susp2_cnt : rs.susp_cnt) : nullptr;
+        status_pack_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(
+            rs.overflow, j->nq, kRecOvfWord, observe ? reinterpret_cast<const uint32_t*>(t->d_pred + 128 + 128 * 128) : nullptr,
+            j->susp_stat && r.last_was_i4m ? rs.susp2_cnt + kI4mMaxQueries : nullptr, susp, j->susp_stat && r.last_was_r2 ? rs.susp2w_cnt : susp,
+            j->susp_stat ? rs.cnt_seen : nullptr, rs.status);
         PG_HIP(hipGetLastError());
-        PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt, st, 8, hipMemcpyDeviceToHost, ctx->stream));
-        // [+ 3] what reached the exact re-scoring: the same, or the survivors of the refinement stage
-        if (r.last_was_r2) susp_sum_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.susp2w_cnt, j->nq, rs.susp2w_cnt + kMaxQueries);
-        PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt + 3, r.last_was_r2 ? rs.susp2w_cnt + kMaxQueries : st + 1, 4, hipMemcpyDeviceToHost,
-                              ctx->stream));
-        PG_HIP(hipMemcpyAsync(j->h_status + kI4mStatAt + 4, rs.susp2w_cnt + kMaxQueries + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-        j->stat_wide = !r.last_was_i4m;
     }
     if (j->d_out_count)
         PG_HIP(hipMemcpyAsync(j->d_out_count, j->d_count, 4 * j->nq, hipMemcpyDeviceToDevice, ctx->stream));
-    PG_HIP(hipMemcpyAsync(j->h_status, rs.overflow, 4 * (1 + (size_t)j->nq), hipMemcpyDeviceToHost, ctx->stream));     // [overflow | counts]
+    PG_HIP(hipMemcpyAsync(j->h_status, rs.status, 4 * (size_t)kStatusCopyWords, hipMemcpyDeviceToHost, ctx->stream));
     j->n_ev = r.n_ev;
     j->refined = refined;
     j->enqueued_plan = plan;

@@ -317,9 +317,11 @@ __global__ __launch_bounds__(64 * kMWaves, 2) void screen4m_kernel(Screen4mArgs 
 
 // per call: the int8 queries (screen_prep8_kernel's quantisation: the same Q and s_q the int8 stage's thresholds mean) in
 // plain order, the bound's per-query constants and kappa.  One workgroup, four threads per query.
-__global__ __launch_bounds__(256) void screen4m_prep_kernel(const float* __restrict__ qpad, uint32_t nq, uint32_t* __restrict__ q4m) {
+__global__ __launch_bounds__(256) void screen4m_prep_kernel(const float* __restrict__ qpad, uint32_t nq, uint32_t* __restrict__ q4m,
+                                                            uint32_t* __restrict__ susp2_cnt) {
     __shared__ float s_ratio[64];
     const uint32_t tid = threadIdx.x, qi = tid >> 2, part = tid & 3;
+    if (tid <= kI4mMaxQueries) susp2_cnt[tid] = 0u;         // the int8 stage's counters + its statistics word, for the job's first launch
     const float* q = qpad + (size_t)qi * 128 + part * 32;
     float mx = 0.0f;
     int bad = 0;
@@ -489,15 +491,16 @@ __global__ __launch_bounds__(256) void rescreen8_kernel(const int8_t* __restrict
 }  // namespace
 
 int screen4m_prep_launch(pg_ctx* ctx, const RecallScratch& rs, uint32_t nq) {
-    screen4m_prep_kernel<<<1, 256, 0, ctx->stream>>>(rs.qpad, nq, rs.q4m);
+    screen4m_prep_kernel<<<1, 256, 0, ctx->stream>>>(rs.qpad, nq, rs.q4m, rs.susp2_cnt);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
 
 // stage 1 over rows [row_begin, row_end) (row_begin a multiple of 64) into rs.susp as [nq][cap1], then stage 2 into
-// rs.susp2 as [nq][rs.cap]; rs.susp_cnt must be zero on entry, rs.susp2_cnt is zeroed here
+// rs.susp2 as [nq][rs.cap]; rs.susp_cnt must be zero on entry, rs.susp2_cnt is zeroed here unless the caller says it still is
+// (the job's first launch: screen4m_prep_kernel left it so)
 int screen4m_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uint32_t nq, uint32_t row_begin, uint32_t row_end,
-                    uint32_t cap1) {
+                    uint32_t cap1, bool susp2_clean) {
     Screen4mArgs a;
     a.d4 = reinterpret_cast<const char*>(t->d4);
     a.d4s = t->d4s;
@@ -516,7 +519,7 @@ int screen4m_launch(pg_ctx* ctx, const pg_table* t, const RecallScratch& rs, uin
     if (grid > (npieces + kMWaves - 1) / kMWaves) grid = (npieces + kMWaves - 1) / kMWaves;
     if (grid == 0) grid = 1;
     int rc;
-    PG_HIP(hipMemsetAsync(rs.susp2_cnt, 0, sizeof(uint32_t) * (kI4mMaxQueries + 1), ctx->stream));
+    if (!susp2_clean) PG_HIP(hipMemsetAsync(rs.susp2_cnt, 0, sizeof(uint32_t) * (kI4mMaxQueries + 1), ctx->stream));
     uint32_t* const stat = rs.susp2_cnt + kI4mMaxQueries;      // (zeroed with the counters; copied out with the job's status words)
     if (nq <= 32) {
         if ((rc = ensure_dyn_lds(ctx, (const void*)screen4m_kernel<1>, kMLds))) return rc;

@@ -8,6 +8,7 @@
 // for segments up to 8192 items, in a global scratch slab beyond that.
 #include "common.hpp"
 #include "bitonic_reg.hpp"
+#include "split_sort.hpp"
 
 namespace pg {
 
@@ -179,6 +180,23 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const double* __restrict
     }
 }
 
+// the score sort as a split sort (split_sort.hpp): keys as in sort_kernel_reg, ties by input position
+struct ScoreSortPolicy {
+    static constexpr bool kWithIdx = true;
+    const double* scores;
+    const uint32_t* seg;
+    int desc;
+    uint32_t* out;
+    __device__ uint32_t count(uint32_t s) const { return seg[s + 1] - seg[s]; }
+    __device__ uint64_t key(uint32_t s, uint32_t i) const {
+        const double sc = scores[seg[s] + i];
+        const uint64_t key = (sc != sc) ? (desc ? 0ull : ~0ull) : f64_ordered_bits(sc);   // NaN sorts last
+        return desc ? ~key : key;
+    }
+    __device__ void store(uint32_t s, uint32_t rank, uint64_t, uint32_t idx) const { out[seg[s] + rank] = idx; }
+    __device__ void tail(uint32_t, uint32_t, uint32_t, uint32_t) const {}
+};
+
 int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, uint32_t n_seg,
                            uint32_t n_items, uint32_t max_seg, int desc, uint32_t* d_out) {
     if (n_seg == 0 || n_items == 0) return PG_OK;
@@ -197,7 +215,10 @@ int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, 
         g_keys = (uint64_t*)p;
         g_idx = (uint32_t*)(g_keys + (size_t)n_seg * stride);
     }
-    if (max_seg <= kRankSortMaxItems && n_seg <= ctx->knobs.rank_sort_max && !ctx->knobs.sort_lds) {
+    if (split_sort_applies(ctx, n_seg, max_seg)) {
+        int rc;
+        if ((rc = split_sort_launch(ctx, ScoreSortPolicy{d_scores, d_seg, desc, d_out}, n_seg, max_seg))) return rc;
+    } else if (max_seg <= kRankSortMaxItems && n_seg <= ctx->knobs.rank_sort_max && !ctx->knobs.sort_lds) {
         const size_t rl = (size_t)((max_seg + 31u) & ~31u) * 8;
         if (n_seg <= 2) {
             if ((rc_attr = ensure_dyn_lds(ctx, (const void*)sort_rank_kernel<16>, rl))) return rc_attr;

@@ -1094,44 +1094,103 @@ def test_sort_matches_oracle_segmented(ctx):
             assert np.array_equal(got[a:b], o.sort_scores(s[a:b], desc)), (desc, i)
 
 
-def test_sort_register_network_segments_up_to_8192(ctx):
-    """All segments <= 8192: the register-resident bitonic network (shuffle / LDS exchanges) — ties by
-    index, NaN last, -0 == +0, heavy duplicates, every power-of-two boundary."""
-    rng = np.random.default_rng(17)
-    sizes = [8192, 0, 1, 2, 3, 511, 512, 513, 5000, 4096, 4097, 64, 65, 1000, 8191]
-    segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+def _sort_corner_scores(rng, segs, equal_segment=None):
     s = rng.random(int(segs[-1]))
     s[::7] = np.round(s[::7], 1)                             # heavy ties
     s[3::501] = np.nan
     s[10::997] = -0.0
     s[11::997] = 0.0
-    s[segs[8]:segs[9]] = 0.25                                # one segment of 5000 identical scores
+    if equal_segment is not None:
+        s[segs[equal_segment]:segs[equal_segment + 1]] = 0.25   # one segment of identical scores
+    return s
+
+
+def _check_sort(ctx, s, segs, sizes, tag):
     for desc in (True, False):
         got = ctx.sort_scores(s, segs, descending=desc)
         for i in range(len(sizes)):
             a, b = int(segs[i]), int(segs[i + 1])
-            assert np.array_equal(got[a:b], o.sort_scores(s[a:b], desc)), (desc, i, sizes[i])
+            assert np.array_equal(got[a:b], o.sort_scores(s[a:b], desc)), (tag, desc, i, sizes[i])
+
+
+def test_sort_register_network_segments_up_to_8192(ctx):
+    """All segments <= 8192: the register-resident bitonic network (shuffle / LDS exchanges) — ties by
+    index, NaN last, -0 == +0, heavy duplicates, every power-of-two boundary.  (The split sort would take a call of
+    this size: switched off here, it has the test below.)"""
+    rng = np.random.default_rng(17)
+    sizes = [8192, 0, 1, 2, 3, 511, 512, 513, 5000, 4096, 4097, 64, 65, 1000, 8191]
+    segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    s = _sort_corner_scores(rng, segs, 8)
+    ctx.set_option("split_sort_max", 0)
+    try:
+        _check_sort(ctx, s, segs, sizes, "network")
+    finally:
+        ctx.set_option("split_sort_max", 128)
 
 
 def test_sort_few_segments_rank_by_counting(ctx):
-    """Up to 8 segments of <= 16384 items take the counting kernel (64 items per workgroup, spread over the chip — the
-    single-request path): same order as the network — ties by index, NaN last, -0 == +0, an all-equal segment, the
-    chunk boundaries of the four-way split."""
+    """Up to 8 segments of <= 16384 items take the counting kernel (64 items per workgroup, spread over the chip) when the
+    split sort does not (lists beyond 8192 items, or the split sort switched off): same order as the network — ties by index,
+    NaN last, -0 == +0, an all-equal segment, the chunk boundaries of the four-way split."""
     rng = np.random.default_rng(19)
-    for sizes in ([8192, 0, 1, 5000, 513, 63, 4097, 2], [5000], [7], [8191, 8185], [16384, 9000, 8193], [12345]):
+    ctx.set_option("split_sort_max", 0)
+    try:
+        for sizes in ([8192, 0, 1, 5000, 513, 63, 4097, 2], [5000], [7], [8191, 8185], [16384, 9000, 8193], [12345]):
+            segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+            s = _sort_corner_scores(rng, segs, 3 if len(sizes) > 3 else None)
+            _check_sort(ctx, s, segs, sizes, "counting")
+    finally:
+        ctx.set_option("split_sort_max", 128)
+
+
+def test_sort_split_over_the_chip(ctx):
+    """1 … 128 lists of 1025 … 8192 items: every 512-slot piece sorted by one wave, final positions by binary searches in the
+    list's other runs (csrc/split_sort.hpp) — the same total order as the network: ties by input position across and inside
+    runs (a list of identical scores, ties that straddle run boundaries), NaN last, -0 == +0, ragged lists beside full ones."""
+    rng = np.random.default_rng(23)
+    cases = ([5000], [8192], [1025, 0, 1, 511, 512, 513], [8192, 5000, 1536, 1537, 2, 4097, 8191, 1024],
+             [5000] * 32, [3000 + 37 * i for i in range(100)], [8192] * 3 + [1] * 125)
+    for sizes in cases:
         segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
-        s = rng.random(int(segs[-1]))
-        s[::7] = np.round(s[::7], 1)
-        s[3::501] = np.nan
-        s[10::997] = -0.0
-        s[11::997] = 0.0
-        if len(sizes) > 3:
-            s[segs[3]:segs[4]] = 0.25
-        for desc in (True, False):
-            got = ctx.sort_scores(s, segs, descending=desc)
-            for i in range(len(sizes)):
-                a, b = int(segs[i]), int(segs[i + 1])
-                assert np.array_equal(got[a:b], o.sort_scores(s[a:b], desc)), (desc, i, sizes[i])
+        s = _sort_corner_scores(rng, segs, 1 if len(sizes) > 1 else None)
+        if len(sizes) == 1:
+            s[500:530] = 0.5                                   # equal scores across the first run boundary
+            s[1000:2100] = np.nan                              # NaN items across two boundaries
+        _check_sort(ctx, s, segs, sizes, "split")
+    before = ctx.stats().sort_split_calls
+    ctx.sort_scores(rng.random(5000), descending=True)
+    assert ctx.stats().sort_split_calls == before + 1
+
+
+def test_recall_final_order_split_equals_network_and_oracle(ctx):
+    """The top-K's final order (descending score, then row) through the split sort (1 … 128 queries, K > 1024) equals the
+    one-workgroup network's and the oracle's; a table with fewer rows than K fills the tail (~0 rows, -inf scores, count)."""
+    rng = np.random.default_rng(29)
+    for rows, k in ((120_000, 5000), (3000, 5000), (9000, 8192), (50_000, 1025)):
+        tab = rng.uniform(-1, 1, (rows, 128)).astype(np.float32)
+        h = (rows // 2) // 3 * 3
+        tab[0:h:3] = tab[1:h:3]                                    # equal rows = equal scores: ties by row
+        t = pa.Table(ctx, rows, 128)
+        t.upload(tab)
+        for nq in (1, 8, 33, 128):
+            q = rng.uniform(-1, 1, (nq, 128)).astype(np.float32)
+            before = ctx.stats().sort_split_calls
+            r1, s1, c1 = t.recall_topk(q, k)
+            assert ctx.stats().sort_split_calls > before
+            ctx.set_option("split_sort_max", 0)
+            try:
+                r0, s0, c0 = t.recall_topk(q, k)
+            finally:
+                ctx.set_option("split_sort_max", 128)
+            assert np.array_equal(r0, r1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(c0, c1)
+            for i in (0, nq - 1):
+                er, es = o.recall_topk(tab, q[i : i + 1], k)
+                er, es = er[0], es[0]
+                n = min(k, rows)
+                assert c1[i] == n
+                assert np.array_equal(r1[i, :n], er[:n]) and np.array_equal(s1[i, :n].view(np.uint32), es[:n].view(np.uint32))
+                assert np.all(r1[i, n:] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(np.isneginf(s1[i, n:]))
+        del t
 
 
 # ---------------------------------------------------------------------------------------------
