@@ -171,6 +171,15 @@ def profile_numbers(R):
     (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md §HBM, + WRITE_SIZE) and the MFMA pipe's busy
     fraction.  NOT measured in this run — hence the field name traffic_from_profile."""
     try:
+        # round 6: the 1 … 64-request passes (4-bit shadow through the matrix pipe) have summaries of their own (scripts/profile_r6.sh)
+        p6 = os.path.join(ROOT, "profiles", "r6_sweep_%d_summary.json" % R)
+        if os.path.exists(p6):
+            with open(p6) as f:
+                pm = json.load(f).get("pmc", {})
+            tot = sum(v.get("fetch_bytes", 0) + v.get("write_bytes", 0) for v in pm.values())
+            busy = max([v.get("mfma_busy_frac", 0.0) for v in pm.values()] or [0.0])
+            if tot > 0:
+                return {"hbm_bytes_per_pass": int(tot), "mfma_busy_frac": round(busy, 4), "source": os.path.relpath(p6, ROOT)}
         with open(PROFILE_JSON) as f:
             d = json.load(f)
         e = d.get(str(R), {})
@@ -423,7 +432,7 @@ def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs, scan_b
     elem_bytes = table.screen_info()[0]
     screened = elem_bytes != 0
     shard_bytes = rows_local * args.dim * (elem_bytes if screened else 4)
-    # batches of <= 4 queries: the full pass streams the 4-bit shadow (68 B per row, csrc/recall_i4.hip) — the engine's own
+    # batches of <= 64 queries: the full pass streams the 4-bit shadow (68 B per row, csrc/recall_i4m.hip) — the engine's own
     # byte count of the last recall's scan launches (pilot sample on the main shadow + that pass) says whether it did
     four_bit = bool(screened and R <= 64 and args.dim == 128 and scan_bytes and scan_bytes < shard_bytes)
     if four_bit:
@@ -439,7 +448,7 @@ def roofline_block(table, R, args, rows_local, scan_avg_ms, measured_gbs, scan_b
     hbm_frac = achieved / HBM_PEAK_GBS
     return {
         "bound": "mfma" if (max(mfma_frac, busy) > hbm_frac and not four_bit) else "hbm",
-        "kernel": (("pg::screen4_kernel<%d>" % R) if R <= 2 else ("pg::screen4m_kernel<%d>" % (1 if R <= 32 else 2)))
+        "kernel": ("pg::screen4m_kernel<%d> (+ rescreen8_kernel, rescore_kernel)" % (1 if R <= 32 else 2))
                   if four_bit else scan_kernel_name(R, args.dim, elem_bytes),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
         "frac_basis": "achieved / peak / unit / frac price the bytes the pass streams against HBM whatever `bound` says (the "

@@ -26,12 +26,13 @@ static void knobs_from_env(Knobs* k) {
     k->i4_min_rows = (uint32_t)num("PG_I4_MIN_ROWS", (double)(1u << 22));
     k->no_screen_i4m = flag("PG_NO_SCREEN_I4M");
     k->i4m_max_queries = (uint32_t)num("PG_I4M_MAX_QUERIES", 64);
-    k->i4m_min_queries = (uint32_t)num("PG_I4M_MIN_QUERIES", 3);
+    k->i4m_min_queries = (uint32_t)num("PG_I4M_MIN_QUERIES", 1);
     k->i4m_max_lambda = num("PG_I4M_MAX_LAMBDA", 2.2);
     k->i4m_max_pairs = num("PG_I4M_MAX_PAIRS", 2.4e7);
     k->rank_no_ws = flag("PG_RANK_NO_WS");
-    k->rank_sort_max = (uint32_t)num("PG_RANK_SORT_MAX", 8);
-    k->split_sort_max = (uint32_t)num("PG_SPLIT_SORT_MAX", 128);
+    k->rank_sort_max = (uint32_t)num("PG_RANK_SORT_MAX", 32);
+    k->rank_sort_work = num("PG_RANK_SORT_WORK", 7e7);
+    k->split_sort_max = (uint32_t)num("PG_SPLIT_SORT_MAX", 96);
     k->sort_lds = flag("PG_SORT_LDS");
     k->fm2t_irs = flag("PG_FM2T_IRS");
     k->dpp_valu = flag("PG_DPP_VALU");
@@ -177,6 +178,7 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "rank_no_ws") k.rank_no_ws = b;
     else if (n == "rank_sort_max") k.rank_sort_max = (uint32_t)v;
     else if (n == "split_sort_max") k.split_sort_max = (uint32_t)v;
+    else if (n == "rank_sort_work") k.rank_sort_work = v;
     else if (n == "sort_lds") k.sort_lds = b;
     else if (n == "fm2t_irs") k.fm2t_irs = b;
     else if (n == "dpp_valu") k.dpp_valu = b;

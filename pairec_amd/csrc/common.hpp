@@ -69,15 +69,16 @@ struct Knobs {
     uint32_t refine_min_rows = 1u << 24;   // PG_REFINE_MIN_ROWS: smallest table whose full pass is split for the refinement
     bool no_screen_i4 = false;     // PG_NO_SCREEN_I4: small batches stay on the int8 screen
     bool no_screen_i4m = false;    // PG_NO_SCREEN_I4M: batches of 5..64 queries stay on the int8 screen
-    uint32_t i4m_min_queries = 3;  // PG_I4M_MIN_QUERIES: smallest batch it serves (below: recall_i4.hip's vector-ALU screen, exact re-scoring of all its suspects)
+    uint32_t i4m_min_queries = 1;  // PG_I4M_MIN_QUERIES: smallest batch it serves (below, and for squared-Euclidean recalls and tables without an int8 shadow: recall_i4.hip's vector-ALU screen, exact re-scoring of all its suspects; one query: 1.08 against 1.17 ms per 100 M rows)
     uint32_t i4m_max_queries = 64; // PG_I4M_MAX_QUERIES: largest batch the 4-bit matrix-pipe screen serves (<= kI4mMaxQueries)
     double i4m_max_lambda = 2.2;   // PG_I4M_MAX_LAMBDA: largest pg_table::lam4 it is used for
     double i4m_max_pairs = 2.4e7;  // PG_I4M_MAX_PAIRS: ... and the most (row, query) pairs per pass its 4-bit stage may be expected to pass on
     uint32_t i4_min_rows = 1u << 22; // PG_I4_MIN_ROWS: smallest table the 4-bit screen is built for
     double i4_max_lambda = 1.7;    // PG_I4_MAX_LAMBDA: largest pg_table::lam4 the 4-bit screen is used for
     bool rank_no_ws = false;       // PG_RANK_NO_WS: streaming DNN3 kernel instead of the weights-stationary one
-    uint32_t split_sort_max = 128; // PG_SPLIT_SORT_MAX: up to this many lists (of 1025 … 8192 items) per call are sorted run by run over the chip (split_sort.hpp; 0 = never)
-    uint32_t rank_sort_max = 8;    // PG_RANK_SORT_MAX: up to this many lists per call are sorted by counting ranks (0 = never)
+    uint32_t split_sort_max = 96;  // PG_SPLIT_SORT_MAX: up to this many lists (of 1025 … 8192 items, ~450 K items in all) per call are sorted run by run over the chip (split_sort.hpp; 0 = never)
+    uint32_t rank_sort_max = 32;   // PG_RANK_SORT_MAX: up to this many lists per call are sorted by counting ranks (0 = never) ...
+    double rank_sort_work = 7e7;   // PG_RANK_SORT_WORK: ... while lists x items^2 stays under this (lists of <= 8192 items; the top-K's final order, one compare per key, takes 1.5 x)
     bool sort_lds = false;         // PG_SORT_LDS: LDS bitonic sort instead of the register-resident one
     bool dpp_valu = false;         // PG_DPP_VALU: the DPP kernel matrix on the fp64 vector pipe (round-4 kernel) instead of the fp64 matrix pipe (A/B; same bits)
     bool fm2t_irs = false;         // PG_FM2T_IRS: cfg 4's item-record rank on the producer / consumer kernel (rank_ir.hip) instead of rank_is.hip (A/B)

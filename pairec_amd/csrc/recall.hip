@@ -2183,9 +2183,9 @@ struct FinalSortPolicy {
 int final_launch(pg_ctx* ctx, const uint64_t* cand, const uint32_t* cnt, uint32_t cap,
                         uint32_t nq, uint32_t k, uint64_t row_offset, uint64_t* d_out_rows,
                         float* d_out_scores, uint32_t* d_out_count) {
-    if (split_sort_applies(ctx, nq, k))
+    if (!rank_sort_applies(ctx, nq, k, 1.5) && split_sort_applies(ctx, nq, k))
         return split_sort_launch(ctx, FinalSortPolicy{cand, cnt, cap, k, row_offset, d_out_rows, d_out_scores, d_out_count}, nq, k);
-    if (k <= kRankSortMaxItems && nq <= ctx->knobs.rank_sort_max && !ctx->knobs.sort_lds) {
+    if (rank_sort_applies(ctx, nq, k, 1.5)) {
         const size_t lds = (size_t)((k + 31u) & ~31u) * 8;
         int rc_attr;
         if (nq <= 2) {
@@ -2813,7 +2813,9 @@ int recall_job_prepare(RecallJob* j) {
         static const double kLamScale[kI4MaxQueries] = {1.0, 1.0, 0.88, 0.7};
         j->screen4 = t->i4_ok && (double)t->lam4 <= kn.i4_max_lambda * kLamScale[j->nq - 1];
     }
-    // 5 .. 64 queries: the same shadow through the matrix pipe, suspects thinned on the int8 shadow (recall_i4m.hip); inner product only
+    // 1 .. 64 queries, inner product, int8 main shadow: the same 4-bit shadow through the matrix pipe, suspects thinned on the int8
+    // shadow (recall_i4m.hip) — also for one or two queries (1.08 against the vector screen's 1.17 ms per 100 M rows: its int8 stage
+    // re-scores a twentieth of the suspects)
     if (screen && !j->l2 && t->dim == 128 && t->shadow_is_i8 && j->nq >= kn.i4m_min_queries && j->nq <= kI4mMaxQueries &&
         j->nq <= kn.i4m_max_queries && j->plans[0] == kPilot && !kn.no_screen_i4m && rows >= kn.i4_min_rows) {
         if ((rc = ensure_table_i4(ctx, t))) return rc;

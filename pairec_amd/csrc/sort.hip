@@ -215,10 +215,7 @@ int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, 
         g_keys = (uint64_t*)p;
         g_idx = (uint32_t*)(g_keys + (size_t)n_seg * stride);
     }
-    if (split_sort_applies(ctx, n_seg, max_seg)) {
-        int rc;
-        if ((rc = split_sort_launch(ctx, ScoreSortPolicy{d_scores, d_seg, desc, d_out}, n_seg, max_seg))) return rc;
-    } else if (max_seg <= kRankSortMaxItems && n_seg <= ctx->knobs.rank_sort_max && !ctx->knobs.sort_lds) {
+    if (rank_sort_applies(ctx, n_seg, max_seg)) {
         const size_t rl = (size_t)((max_seg + 31u) & ~31u) * 8;
         if (n_seg <= 2) {
             if ((rc_attr = ensure_dyn_lds(ctx, (const void*)sort_rank_kernel<16>, rl))) return rc_attr;
@@ -227,6 +224,9 @@ int sort_dev_locked(pg_ctx* ctx, const double* d_scores, const uint32_t* d_seg, 
             if ((rc_attr = ensure_dyn_lds(ctx, (const void*)sort_rank_kernel<64>, rl))) return rc_attr;
             sort_rank_kernel<64><<<dim3((max_seg + 63) / 64, n_seg), 256, rl, ctx->stream>>>(d_scores, d_seg, desc, d_out);
         }
+    } else if (split_sort_applies(ctx, n_seg, max_seg)) {
+        int rc;
+        if ((rc = split_sort_launch(ctx, ScoreSortPolicy{d_scores, d_seg, desc, d_out}, n_seg, max_seg))) return rc;
     } else if (max_seg <= kSortLdsMax && !ctx->knobs.sort_lds)
         sort_kernel_reg<<<n_seg, 1024, 0, ctx->stream>>>(d_scores, d_seg, desc, d_out);
     else

@@ -153,9 +153,19 @@ int split_sort_launch(pg_ctx* ctx, const Policy& pol, uint32_t n_lists, uint32_t
     return PG_OK;
 }
 
-// a call takes this path when it carries few enough lists of a size worth splitting
+// Which sort a call takes (event-timed on MI355X, lists of 5 000: scripts/dev/sort_sweep.py): counting ranks is n^2 per list
+// but one short launch — 18-21 us for one or two lists, 46 at four; the split sort 35 us up to 16 lists, 44 at 32, 62 at 96;
+// the one-workgroup network 61-68 whatever the count (31 at 1 500 items, 70 at 8 192).  So: counting while lists x n^2 stays
+// under rank_sort_work, else the split sort while the call holds at most ~450 K items in at most split_sort_max lists, else
+// the network.  Lists beyond 8 192 items have neither alternative: counting up to kRankSortMaxSegments lists as before.
+inline bool rank_sort_applies(const pg_ctx* ctx, uint32_t n_lists, uint32_t max_items, double work_scale = 1.0) {
+    if (ctx->knobs.sort_lds || max_items > kRankSortMaxItems || n_lists > ctx->knobs.rank_sort_max) return false;
+    if (max_items > kSplitMaxItems) return n_lists <= kRankSortMaxSegments;
+    return (double)n_lists * max_items * max_items <= ctx->knobs.rank_sort_work * work_scale;
+}
 inline bool split_sort_applies(const pg_ctx* ctx, uint32_t n_lists, uint32_t max_items) {
-    return max_items > 2 * kSplitRun && max_items <= kSplitMaxItems && n_lists <= ctx->knobs.split_sort_max && !ctx->knobs.sort_lds;
+    return max_items > 2 * kSplitRun && max_items <= kSplitMaxItems && n_lists <= ctx->knobs.split_sort_max &&
+           (uint64_t)n_lists * max_items <= 450000u && !ctx->knobs.sort_lds;
 }
 
 }  // namespace pg

@@ -1,4 +1,4 @@
-"""The mid-batch recall (csrc/recall_i4m.hip): passes of 5 … 64 queries stream the 4-bit shadow through the int8 matrix
+"""The mid-batch recall (csrc/recall_i4m.hip): passes of 1 … 64 queries stream the 4-bit shadow through the int8 matrix
 pipe, thin the suspects on the int8 shadow, re-score exactly.  Results must stay bit-identical to the oracle's
 (`o.recall_topk`: the reference's VectorRecall → FaissModel.Run top-K, service/recall/vector_recall.go:32-123) whatever
 the screens let through, on data built against the bounds, and the pass must really have read the narrow shadow."""
@@ -38,7 +38,7 @@ def check(ctx, t, tab, q, k, expect_narrow=True):
         assert (nbytes < tab.shape[0] * 128) == expect_narrow, (nbytes, tab.shape[0] * 128, expect_narrow)
 
 
-@pytest.mark.parametrize("nq", [2, 3, 5, 8, 16, 31, 32, 33, 48, 64])
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8, 16, 31, 32, 33, 48, 64])
 def test_mid_batch_uniform_rows(small_table_opts, nq):
     """the benchmark's row distribution (uniform, normalised), every batch size class incl. both ends of each query block"""
     ctx = small_table_opts
@@ -82,7 +82,7 @@ def test_mid_batch_hostile_data(small_table_opts):
     t = pa.Table(ctx, n, d)
     t.upload(tab)
     assert t.screen_info()[0] == 1
-    for lo, hi in ((0, 5), (0, 9), (2, 40), (0, 64), (9, 14), (20, 53)):
+    for lo, hi in ((0, 5), (0, 9), (2, 40), (0, 64), (9, 14), (20, 53), (2, 3), (3, 4), (6, 8), (7, 8)):
         # (a zero query makes every row a suspect: its plan overflows by design and the next plan answers on the wide shadow)
         check(ctx, t, tab, qs[lo:hi], k, expect_narrow=None if lo < 2 else True)
     bad = qs[10:20].copy()

@@ -254,8 +254,9 @@ def test_recall_small_batch_4bit_screen_is_exact(ctx):
     qs[6] *= np.float32(1e-20)
     qs[7] *= np.float32(1e15)
     # (i4_max_lambda: Gaussian rows sit at lambda 1.3, above the default limit for 4 queries — lifted here so that
-    # every batch size exercises the narrow shadow)
-    for name, v in (("i4_min_rows", "0"), ("pilot_fraction", "0.25"), ("i4_max_lambda", "3")):
+    # every batch size exercises the narrow shadow; the matrix-pipe screen that serves such batches by default is switched off:
+    # this is the vector screen's test — squared-Euclidean recalls and tables on a bf16 main shadow have no other)
+    for name, v in (("i4_min_rows", "0"), ("pilot_fraction", "0.25"), ("i4_max_lambda", "3"), ("no_screen_i4m", "1")):
         ctx.set_option(name, v)
     try:
         t = pa.Table(ctx, n, d)
@@ -318,6 +319,7 @@ def test_recall_small_batch_4bit_screen_is_exact(ctx):
         ctx.set_option("i4_min_rows", str(1 << 22))
         ctx.set_option("pilot_fraction", "0")
         ctx.set_option("i4_max_lambda", "1.7")
+        ctx.set_option("no_screen_i4m", "0")
 
 
 def test_recall_heavy_tailed_table_stays_fast(ctx):
@@ -1122,34 +1124,38 @@ def test_sort_register_network_segments_up_to_8192(ctx):
     segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
     s = _sort_corner_scores(rng, segs, 8)
     ctx.set_option("split_sort_max", 0)
+    ctx.set_option("rank_sort_max", 0)
     try:
         _check_sort(ctx, s, segs, sizes, "network")
     finally:
-        ctx.set_option("split_sort_max", 128)
+        ctx.set_option("split_sort_max", 96)
+        ctx.set_option("rank_sort_max", 32)
 
 
 def test_sort_few_segments_rank_by_counting(ctx):
-    """Up to 8 segments of <= 16384 items take the counting kernel (64 items per workgroup, spread over the chip) when the
-    split sort does not (lists beyond 8192 items, or the split sort switched off): same order as the network — ties by index,
+    """A few short lists (lists x items^2 under the knob rank_sort_work — lifted here — or up to 8 lists beyond 8192 items)
+    take the counting kernel (64 items per workgroup, spread over the chip): same order as the network — ties by index,
     NaN last, -0 == +0, an all-equal segment, the chunk boundaries of the four-way split."""
     rng = np.random.default_rng(19)
-    ctx.set_option("split_sort_max", 0)
+    ctx.set_option("rank_sort_work", 1e18)
     try:
         for sizes in ([8192, 0, 1, 5000, 513, 63, 4097, 2], [5000], [7], [8191, 8185], [16384, 9000, 8193], [12345]):
             segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
             s = _sort_corner_scores(rng, segs, 3 if len(sizes) > 3 else None)
             _check_sort(ctx, s, segs, sizes, "counting")
     finally:
-        ctx.set_option("split_sort_max", 128)
+        ctx.set_option("rank_sort_work", 7e7)
 
 
 def test_sort_split_over_the_chip(ctx):
-    """1 … 128 lists of 1025 … 8192 items: every 512-slot piece sorted by one wave, final positions by binary searches in the
+    """Up to 96 lists of 1025 … 8192 items (more work than the counting kernel takes, switched off here so that the single lists
+    come this way too): every 512-slot piece sorted by one wave, final positions by binary searches in the
     list's other runs (csrc/split_sort.hpp) — the same total order as the network: ties by input position across and inside
     runs (a list of identical scores, ties that straddle run boundaries), NaN last, -0 == +0, ragged lists beside full ones."""
     rng = np.random.default_rng(23)
     cases = ([5000], [8192], [1025, 0, 1, 511, 512, 513], [8192, 5000, 1536, 1537, 2, 4097, 8191, 1024],
-             [5000] * 32, [3000 + 37 * i for i in range(100)], [8192] * 3 + [1] * 125)
+             [5000] * 32, [3000 + 17 * i for i in range(96)], [8192] * 3 + [1] * 50)
+    ctx.set_option("rank_sort_max", 0)
     for sizes in cases:
         segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
         s = _sort_corner_scores(rng, segs, 1 if len(sizes) > 1 else None)
@@ -1160,11 +1166,16 @@ def test_sort_split_over_the_chip(ctx):
     before = ctx.stats().sort_split_calls
     ctx.sort_scores(rng.random(5000), descending=True)
     assert ctx.stats().sort_split_calls == before + 1
+    ctx.set_option("rank_sort_max", 32)
+    ctx.sort_scores(rng.random(5000), descending=True)          # one list of 5 000: counting is the shorter launch
+    assert ctx.stats().sort_split_calls == before + 1
+    ctx.sort_scores(rng.random(8 * 5000), np.arange(9, dtype=np.uint32) * 5000, descending=True)
+    assert ctx.stats().sort_split_calls == before + 2
 
 
 def test_recall_final_order_split_equals_network_and_oracle(ctx):
-    """The top-K's final order (descending score, then row) through the split sort (1 … 128 queries, K > 1024) equals the
-    one-workgroup network's and the oracle's; a table with fewer rows than K fills the tail (~0 rows, -inf scores, count)."""
+    """The top-K's final order (descending score, then row) through the split sort (up to ~450 K items in up to 96 lists, K > 1024) equals the
+    one-workgroup network's (the counting kernel's where the call is small) and the oracle's; a table with fewer rows than K fills the tail (~0 rows, -inf scores, count)."""
     rng = np.random.default_rng(29)
     for rows, k in ((120_000, 5000), (3000, 5000), (9000, 8192), (50_000, 1025)):
         tab = rng.uniform(-1, 1, (rows, 128)).astype(np.float32)
@@ -1172,16 +1183,20 @@ def test_recall_final_order_split_equals_network_and_oracle(ctx):
         tab[0:h:3] = tab[1:h:3]                                    # equal rows = equal scores: ties by row
         t = pa.Table(ctx, rows, 128)
         t.upload(tab)
-        for nq in (1, 8, 33, 128):
+        for nq in (1, 8, 33, 54):
             q = rng.uniform(-1, 1, (nq, 128)).astype(np.float32)
+            rd, sd, cd = t.recall_topk(q, k)                       # defaults: counting for a small call, else the split sort
             before = ctx.stats().sort_split_calls
-            r1, s1, c1 = t.recall_topk(q, k)
-            assert ctx.stats().sort_split_calls > before
-            ctx.set_option("split_sort_max", 0)
+            ctx.set_option("rank_sort_max", 0)
             try:
+                r1, s1, c1 = t.recall_topk(q, k)
+                assert ctx.stats().sort_split_calls > before
+                ctx.set_option("split_sort_max", 0)
                 r0, s0, c0 = t.recall_topk(q, k)
             finally:
-                ctx.set_option("split_sort_max", 128)
+                ctx.set_option("split_sort_max", 96)
+                ctx.set_option("rank_sort_max", 32)
+            assert np.array_equal(rd, r1) and np.array_equal(sd.view(np.uint32), s1.view(np.uint32)) and np.array_equal(cd, c1)
             assert np.array_equal(r0, r1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(c0, c1)
             for i in (0, nq - 1):
                 er, es = o.recall_topk(tab, q[i : i + 1], k)
