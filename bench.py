@@ -319,6 +319,58 @@ def device_info():
         return None
 
 
+def smi_sample():
+    """One reading of rocm-smi: package power (W), shader clock (MHz), the power cap (W).  None when the tool is missing."""
+    import subprocess, re
+    try:
+        txt = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True,
+                             timeout=20).stdout
+        pw = re.search(r"GPU\[0\].*?Current Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
+        ck = re.search(r"GPU\[0\].*?sclk clock level: \S+ \(([0-9.]+)Mhz\)", txt)
+        cap = re.search(r"GPU\[0\].*?Max Graphics Package Power \(W\): ([0-9.]+)", txt)
+        if not pw or not ck:
+            return None
+        return {"package_w": float(pw.group(1)), "sclk_mhz": float(ck.group(1)), "cap_w": float(cap.group(1)) if cap else None}
+    except Exception:
+        return None
+
+
+def power_leg(step_fn, drain_fn, seconds=3.0, sync_each=False):
+    """What the package draws and clocks at while `step_fn` runs back to back for `seconds`: rocm-smi sampled from a thread (the
+    tool is a child process per reading, ~0.3 s each; the first reading is dropped — the loop may still be ramping).  The two
+    kernels that dominate the headline step run AT the package power limit with the shader clock pulled below its 2.4 GHz
+    maximum — which is why their matrix-pipe busy fraction x clock, not the busy fraction alone, is what schedules can move."""
+    import threading
+    stop, readings = threading.Event(), []
+
+    def sampler():
+        while not stop.is_set():
+            r_ = smi_sample()
+            if r_ is None:
+                return
+            readings.append(r_)
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    n = 0
+    th.start()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(16):
+            step_fn()
+        n += 16
+        if sync_each:                                  # (asynchronous calls: do not run ahead of the clock)
+            drain_fn()
+    drain_fn()
+    el = time.perf_counter() - t0
+    stop.set()
+    th.join(timeout=30)
+    rd = readings[1:-1] if len(readings) > 3 else readings
+    if not rd:
+        return None
+    return {"seconds": el, "steps": n, "ms_per_step": el / n * 1e3, "readings": len(rd),
+            "package_w": float(np.median([r_["package_w"] for r_ in rd])), "sclk_mhz": float(np.median([r_["sclk_mhz"] for r_ in rd])),
+            "cap_w": rd[0]["cap_w"]}
+
+
 def make_queries(o, step, R, dim):
     # 1000 distinct users cycle through the run (SURVEY.md §8d)
     return o.synth_rows(o.SEED_QUERY, (step * R) % 1000, R, dim)
@@ -1948,6 +2000,37 @@ def main():
     if solo and not args.no_batch_sweep:
         out["batch_sweep"] = batch_sweep_leg(pa, o, ctx, table, model, expr, args, K, extra_ctxs, measured_gbs)
     extras = solo and not args.no_extras
+    if extras:
+        # power and clock under load: the headline loop, the recall pass alone, the rank stage alone (a few seconds each)
+        pw = {}
+        pp = Pipeline1(pa, ctx, table, model, expr, R, K, extra_ctxs=extra_ctxs)
+        it = [0]
+
+        def hstep():
+            pp.step(d_qs[it[0] % len(d_qs)])
+            it[0] += 1
+        pw["headline_loop"] = power_leg(hstep, pp.drain)
+        d_rows_, d_sc_ = pp.bufs[0][0], pp.bufs[0][1]
+
+        def rstep():
+            table.recall_topk_dev(d_qs[it[0] % len(d_qs)], R, K, d_rows_, d_sc_)
+            it[0] += 1
+        pw["recall_pass_alone"] = power_leg(rstep, ctx.synchronize)
+        rng_ = np.random.default_rng(5)
+        cand_ = ctx.to_device(rng_.integers(0, table.rows, R * K).astype(np.uint32))
+        offs_ = ctx.to_device((np.arange(R + 1) * K).astype(np.uint32))
+        pw["rank_stage_alone"] = power_leg(lambda: model.rank_dnn3_dev(table, d_qs[0], cand_, offs_, R, R * K, pp.bufs[0][2]), ctx.synchronize, sync_each=True)
+        ctx.free(cand_)
+        ctx.free(offs_)
+        for c_ in [ctx] + list(extra_ctxs):
+            c_.synchronize()
+        for b_ in pp.bufs:
+            for p_ in b_:
+                ctx.free(p_)
+        if any(pw.values()):
+            pw["note"] = ("rocm-smi sampled from a thread while the named loop runs back to back for ~3 s (median reading): package power "
+                          "against its cap and the shader clock the firmware leaves (maximum 2400 MHz)")
+            out["power"] = pw
     if extras and args.callers > 0:
         out["concurrent_callers"] = concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K)
     if extras:

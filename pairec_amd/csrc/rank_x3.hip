@@ -24,6 +24,11 @@
 // c under the MFMAs of chunk c + 1 (second accumulator set, layer-2 waves two intervals behind; as a block per k-step, and
 // cut into pieces between the individual MFMAs), weight fragments re-requested per k-step, weight fragments two k-steps
 // ahead in the layer-2 waves, priority to the layer-2 waves (-3 %).
+// Round 6 (same box, `scripts/dev/x3_time.py`, builds with `make WS_EXTRA=-DPG_X3_ABL=n`): 1.205 ms; X stored UNSPLIT (ablation 1 = the
+// most a pre-split hi / lo shadow of the table rows could save): 1.23; H1 stored with NO relu / split at all (ablation 3): 1.19; X
+// fragments two k-steps ahead: 1.205.  The conversions are not what the kernel waits for, and neither is the matrix pipe's schedule:
+// rocm-smi beside a loop of this kernel reads 1 377-1 381 W of the 1 400 W package limit at 2.04-2.09 GHz of 2.4 (`scripts/dev/
+// power_probe.sh`, bench.py's `power` object) — the kernel runs at the power limit, a busier pipe gets a lower clock.
 // Weights (768 KB at 512-256: every matrix as hi and lo fragments) do not fit the CU: they stream from L2 once per tile,
 // global → registers, each fragment a k-step (layer 2) or a chunk (layer 1) ahead of its use.  A layer-2 fragment feeds
 // four item blocks (hi fragments twice): 6 / 3 MFMAs per 1-KiB load.  LDS: X hi / lo 64 KB + two H1 chunks hi / lo 64 KB +
@@ -54,12 +59,24 @@ __device__ __forceinline__ float x3_relu(float v) { return __builtin_amdgcn_fmed
 template <int LO>
 __device__ __forceinline__ void x3_store_h_quad(char* tile, int row, int col, float v0, float v1, float v2, float v3) {
     uint2 ph, pl;
+#if defined(PG_X3_ABL) && PG_X3_ABL == 3          // ablation (wrong results): H1 stored without relu / split — the conversion's whole cost
+    ph.x = __float_as_uint(v0); pl.x = __float_as_uint(v1); ph.y = __float_as_uint(v2); pl.y = __float_as_uint(v3);
+#else
     split_bf16x2(x3_relu(v0), x3_relu(v1), ph.x, pl.x);
     split_bf16x2(x3_relu(v2), x3_relu(v3), ph.y, pl.y);
+#endif
     char* const d = tile + row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + (col & 7) * 2;
     *reinterpret_cast<uint2*>(d) = ph;
     *reinterpret_cast<uint2*>(d + LO) = pl;
 }
+
+#if defined(PG_X3_ABL) && PG_X3_ABL == 1
+__device__ __forceinline__ void store_x_quad_raw(char* tile, int row, int c, float4 v, int lo_off) {
+    char* const d = tile + row * 256 + ((((c >> 1) ^ (row & 15))) << 4) + (c & 1) * 8;
+    *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+    *reinterpret_cast<uint2*>(d + lo_off) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+}
+#endif
 
 template <int H1, int H2>
 __global__ __launch_bounds__(512, 1) void dnn3_x3_kernel(MlpArgs a) {
@@ -130,7 +147,13 @@ __global__ __launch_bounds__(512, 1) void dnn3_x3_kernel(MlpArgs a) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) store_x_quad<2>(XH, p * 64 + (t_ >> 2), 4 * j + (t_ & 3), xq[p][j], X_B);
+                for (int j = 0; j < 8; ++j) {
+#if defined(PG_X3_ABL) && PG_X3_ABL == 1      // ablation (wrong results): X stored unsplit — what a pre-split shadow of the rows could save at most
+                    store_x_quad_raw(XH, p * 64 + (t_ >> 2), 4 * j + (t_ & 3), xq[p][j], X_B);
+#else
+                    store_x_quad<2>(XH, p * 64 + (t_ >> 2), 4 * j + (t_ & 3), xq[p][j], X_B);
+#endif
+                }
             if (d.req != c1_req) {
                 c1_req = d.req;
                 for (int i = t_; i < H1; i += 256) c1s[i] = a.c1[(size_t)d.req * a.c1_stride + i];

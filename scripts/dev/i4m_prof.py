@@ -9,6 +9,7 @@ from oracle import oracle as o
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
 gauss = len(sys.argv) > 3 and sys.argv[3] == "gauss"
+loop = len(sys.argv) > 3 and sys.argv[3] == "loop"          # (scripts/dev/power_probe.sh: ~8 s of back-to-back passes)
 ctx = pa.Context(0)
 t = pa.Table(ctx, rows, 128)
 if gauss:
@@ -24,7 +25,8 @@ for i in range(12):
     t.recall_topk_dev(d_q + (i % 8) * 256 * 128 * 4, 256, K, d_rows, d_sc)
 if os.environ.get("PG_SWEEP_DEBUG"):
     ctx.set_option("debug_scan", "1")
-for it in range(10):
+for it in range(2500 if loop else 10):
     t.recall_topk_dev(d_q + ((it * 7 + 3) % 15) * 256 * 128 * 4, R, K, d_rows, d_sc)
-    ctx.synchronize()
-    print(ctx.last_scan_kernel())
+    if not loop or it % 500 == 0:
+        ctx.synchronize()
+        print(ctx.last_scan_kernel())
