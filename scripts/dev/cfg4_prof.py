@@ -36,3 +36,12 @@ if len(sys.argv) > 2 and sys.argv[2] == "sync":          # one call at a time, a
         _lib.check(ctx.L.pg_rank_fm2t_irows_dev(ctx.h, m.h, ir.h, d_u, d_uf, d_c, d_off, R, n, d_out))
         ms.append(ctx.stats().last_rank_ms)
     print("device ms, one call at a time: mean %.4f min %.4f max %.4f" % (np.mean(ms), np.min(ms), np.max(ms)))
+if len(sys.argv) > 2 and sys.argv[2] == "loop":          # ~6 s of back-to-back calls (scripts/dev/power_probe.sh samples rocm-smi beside it)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < 9.0:
+        for _ in range(64):
+            _lib.check(ctx.L.pg_rank_fm2t_irows_dev(ctx.h, m.h, ir.h, d_u, d_uf, d_c, d_off, R, n, d_out))
+        ctx.synchronize()
+        k += 64
+    print("loop: %.4f ms per call" % ((time.perf_counter() - t0) / k * 1e3))

@@ -25,7 +25,11 @@ for i in range(12):
     t.recall_topk_dev(d_q + (i % 8) * 256 * 128 * 4, 256, K, d_rows, d_sc)
 if os.environ.get("PG_SWEEP_DEBUG"):
     ctx.set_option("debug_scan", "1")
-for it in range(2500 if loop else 10):
+import time
+t_loop = time.perf_counter()
+for it in range(1_000_000 if loop else 10):
+    if loop and time.perf_counter() - t_loop > 10.0:
+        break
     t.recall_topk_dev(d_q + ((it * 7 + 3) % 15) * 256 * 128 * 4, R, K, d_rows, d_sc)
     if not loop or it % 500 == 0:
         ctx.synchronize()

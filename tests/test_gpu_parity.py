@@ -1173,6 +1173,27 @@ def test_sort_split_over_the_chip(ctx):
     assert ctx.stats().sort_split_calls == before + 2
 
 
+def test_sort_random_calls_take_every_path(ctx):
+    """Random calls — 1 … 200 lists of random sizes up to 9 000, tie densities from none to all-equal, NaN / signed zeros / infinities
+    sprinkled in, both directions: whatever path the call's size selects (counting, split, one-workgroup network, the global-memory
+    network beyond 8 192 items), the order is the oracle's."""
+    rng = np.random.default_rng(31)
+    for case in range(24):
+        nseg = int(rng.choice([1, 2, 3, 7, 20, 60, 97, 200]))
+        top = int(rng.choice([40, 600, 1500, 5000, 8192, 9000]))
+        sizes = rng.integers(0, top + 1, nseg).tolist()
+        sizes[int(rng.integers(0, nseg))] = top
+        segs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+        n = int(segs[-1])
+        levels = int(rng.choice([1, 3, 50, 10**9]))
+        s = rng.random(n) if levels == 10**9 else rng.integers(0, levels, n).astype(np.float64) / levels
+        s[rng.random(n) < 0.002] = np.nan
+        s[rng.random(n) < 0.002] = -0.0
+        s[rng.random(n) < 0.002] = np.inf
+        s[rng.random(n) < 0.002] = -np.inf
+        _check_sort(ctx, s, segs, sizes, "random %d" % case)
+
+
 def test_recall_final_order_split_equals_network_and_oracle(ctx):
     """The top-K's final order (descending score, then row) through the split sort (up to ~450 K items in up to 96 lists, K > 1024) equals the
     one-workgroup network's (the counting kernel's where the call is small) and the oracle's; a table with fewer rows than K fills the tail (~0 rows, -inf scores, count)."""
