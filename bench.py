@@ -87,6 +87,7 @@ def parse_args():
                     help="headline table: SURVEY.md 8d's normalised uniform rows, or N(0,1) rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only (profiling runs)")
+    ap.add_argument("--no-power", action="store_true", help="skip the power / clock readings (rocm-smi sampled beside three short loops)")
     ap.add_argument("--no-preflight", action="store_true",
                     help="N > 1: skip the parity preflight of the sharded step on the run's own wire (it runs before anything is timed)")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -2000,7 +2001,9 @@ def main():
     if solo and not args.no_batch_sweep:
         out["batch_sweep"] = batch_sweep_leg(pa, o, ctx, table, model, expr, args, K, extra_ctxs, measured_gbs)
     extras = solo and not args.no_extras
-    if extras:
+    if extras and args.callers > 0:
+        out["concurrent_callers"] = concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K)
+    if extras and not args.no_power:
         # power and clock under load: the headline loop, the recall pass alone, the rank stage alone (a few seconds each)
         pw = {}
         pp = Pipeline1(pa, ctx, table, model, expr, R, K, extra_ctxs=extra_ctxs)
@@ -2031,8 +2034,6 @@ def main():
             pw["note"] = ("rocm-smi sampled from a thread while the named loop runs back to back for ~3 s (median reading): package power "
                           "against its cap and the shader clock the firmware leaves (maximum 2400 MHz)")
             out["power"] = pw
-    if extras and args.callers > 0:
-        out["concurrent_callers"] = concurrent_callers_leg(pa, o, ctx, table, model, expr, args, K)
     if extras:
         # the same headline measurement on the other table distribution (uniform rows are the int8 screen's best case)
         other = "gaussian" if args.table_dist == "uniform" else "uniform"
