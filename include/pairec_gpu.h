@@ -78,7 +78,12 @@ int pg_synchronize(pg_ctx* ctx);
  * x 1024 of a SIMD's blocks its older wave takes; 512 = even), "screen_early_share_narrow" (the <= 128-query kernels, default
  * 512); for the squared-Euclidean recall "l2_exact", "l2_max_slack" (default 1.0); for pg_recall_topk_where the compact route's
  * limits "where_compact_max_rows" (default 2^23; half of it for batches of <= 4 queries) and "where_compact_min_ratio"
- * (default 8: at most an eighth of the table); value is parsed as a number. */
+ * (default 8: at most an eighth of the table); round 6: for the 1 … 64-query passes on the 4-bit shadow through the matrix pipe
+ * (csrc/recall_i4m.hip) "no_screen_i4m", "i4m_min_queries" (default 1), "i4m_max_queries" (64), "i4m_max_lambda", "i4m_max_pairs";
+ * for crowded tables "max_rec_scale", "no_r2", "r2_min_factor", "predict_max_factor"; for the coalescer "coalescer_rejoin",
+ * "coalescer_rejoin_us_per_caller"; and which sort a call with few lists takes (csrc/split_sort.hpp): "rank_sort_max" (default 32
+ * lists) with "rank_sort_work" (lists x items^2 <= 7e7: counting ranks), "split_sort_max" (default 96 lists of 1025 … 8192 items:
+ * runs sorted wave by wave over the chip; 0 = never).  value is parsed as a number. */
 int pg_set_option(pg_ctx* ctx, const char* name, const char* value);
 int pg_device_malloc(pg_ctx* ctx, size_t bytes, void** out);
 int pg_device_free(pg_ctx* ctx, void* p);
