@@ -1826,17 +1826,6 @@ __global__ __launch_bounds__(256) void final_rank_kernel(const uint64_t* __restr
 }
 
 // after a refined pilot plan: thr = score of the K-th best candidate kept (select_kernel), thr_ref = the raised threshold
-// statistics: the suspects the plan's last screened launch handed to the exact re-scoring, summed over the queries
-__global__ void susp_sum_kernel(const uint32_t* __restrict__ cnt, uint32_t nq, uint32_t* __restrict__ out) {
-    uint32_t v = threadIdx.x < nq ? cnt[threadIdx.x] : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    __shared__ uint32_t s[4];
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) *out = s[0] + s[1] + s[2] + s[3];
-}
-
 __global__ void refine_verify_kernel(const float* __restrict__ thr, const float* __restrict__ thr_ref,
                                      uint32_t* __restrict__ count, uint32_t nq) {
     const uint32_t q = threadIdx.x;
