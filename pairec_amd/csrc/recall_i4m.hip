@@ -1,4 +1,4 @@
-// recall_i4m.hip — the mid-batch screen: the full table pass of a recall with 5 … kI4mMaxQueries queries streams the
+// recall_i4m.hip — the small- and mid-batch screen: the full table pass of a recall with 1 … kI4mMaxQueries queries streams the
 // 4-bit shadow of the rows (recall_i4.hip: 68 B per row instead of the int8 shadow's 128) through the int8 matrix
 // pipe, then thins its suspects on the int8 shadow before the exact re-scoring.  Such a pass is HBM-bound on the
 // shadow it streams (MFMA busy 0.36 at 128 queries on the int8 shadow), so the bytes are the cost.  Reference path:
