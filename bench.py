@@ -320,18 +320,23 @@ def device_info():
         return None
 
 
+def parse_smi(txt):
+    """package power (W), shader clock (MHz) and the power cap (W) of GPU 0 out of `rocm-smi --showpower --showclocks --showmaxpower`."""
+    import re
+    pw = re.search(r"GPU\[0\].*?Current Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
+    ck = re.search(r"GPU\[0\].*?sclk clock level: \S+ \(([0-9.]+)Mhz\)", txt)
+    cap = re.search(r"GPU\[0\].*?Max Graphics Package Power \(W\): ([0-9.]+)", txt)
+    if not pw or not ck:
+        return None
+    return {"package_w": float(pw.group(1)), "sclk_mhz": float(ck.group(1)), "cap_w": float(cap.group(1)) if cap else None}
+
+
 def smi_sample():
-    """One reading of rocm-smi: package power (W), shader clock (MHz), the power cap (W).  None when the tool is missing."""
-    import subprocess, re
+    """One reading of rocm-smi (a child process).  None when the tool is missing or prints something else."""
+    import subprocess
     try:
-        txt = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True,
-                             timeout=20).stdout
-        pw = re.search(r"GPU\[0\].*?Current Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
-        ck = re.search(r"GPU\[0\].*?sclk clock level: \S+ \(([0-9.]+)Mhz\)", txt)
-        cap = re.search(r"GPU\[0\].*?Max Graphics Package Power \(W\): ([0-9.]+)", txt)
-        if not pw or not ck:
-            return None
-        return {"package_w": float(pw.group(1)), "sclk_mhz": float(ck.group(1)), "cap_w": float(cap.group(1)) if cap else None}
+        return parse_smi(subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True,
+                                        text=True, timeout=20).stdout)
     except Exception:
         return None
 

@@ -91,3 +91,24 @@ def test_oracle_step_pages_is_the_single_table_pipeline():
     rows, rec = o.recall_topk(tab, q, 100)
     for r in range(2):
         assert len(pages[r]) == 10 and len(set(pages[r].tolist())) == 10 and set(pages[r].tolist()) <= set(rows[r].tolist())
+
+
+def test_power_readings_parse_rocm_smi_text():
+    """bench.py's `power` object reads GPU 0's package power, shader clock and cap out of rocm-smi's text (transcribed from an MI355X
+    box); anything else — the tool missing, another layout — yields None and the object is left out of the line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    txt = ("\n============================ ROCm System Management Interface ============================\n"
+           "================================ Current clock frequencies ================================\n"
+           "GPU[0]\t\t: fclk clock level: 0: (1250Mhz)\nGPU[0]\t\t: mclk clock level: 0: (2000Mhz)\n"
+           "GPU[0]\t\t: sclk clock level: 1: (1535Mhz)\nGPU[0]\t\t: socclk clock level: 0: (28Mhz)\n"
+           "=================================== Power Consumption ====================================\n"
+           "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1402.0\n"
+           "================================== Max Graphics Package Power ==================================\n"
+           "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\n"
+           "================================== End of ROCm SMI Log ===================================\n")
+    assert bench.parse_smi(txt) == {"package_w": 1402.0, "sclk_mhz": 1535.0, "cap_w": 1400.0}
+    idle = txt.replace("sclk clock level: 1: (1535Mhz)", "sclk clock level: S: (95Mhz)").replace("1402.0", "247.0")
+    assert bench.parse_smi(idle) == {"package_w": 247.0, "sclk_mhz": 95.0, "cap_w": 1400.0}
+    assert bench.parse_smi(txt.replace("GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\n", ""))["cap_w"] is None
+    assert bench.parse_smi("rocm-smi: command not found") is None and bench.parse_smi("") is None
