@@ -539,7 +539,11 @@ int pg_dpp_kernel_matrix_dev(pg_ctx* ctx, const float* d_emb, const double* d_re
  * for the whole batch on the context's stream, and hands every caller its slice.  Up to `depth` batches are in
  * flight, so the next batch is queued behind the running one.  Results are bit-identical to the same request
  * issued alone through pg_recall_topk / pg_rank_dnn3 / pg_recommend_dnn3_dev (scores do not depend on what else
- * shares a pass).  cgo note: the calling goroutine's OS thread is parked in a futex wait, not spinning. */
+ * shares a pass).  cgo note: the calling goroutine's OS thread is parked in a futex wait, not spinning.
+ * A coalesced batch records none of its context's stage timers (pg_stats' last_recall_ms / last_rank_ms, pg_last_scan_kernel_ms
+ * keep what the last direct call left; the byte count is kept up): each HIP event record is ~6 us of idle queue, 40-60 us of a
+ * small batch's 1.3-1.8 ms.  PG_COALESCER_TIMERS=1 in the environment records them as direct calls do; pg_coalescer_stats'
+ * device_ms (enqueue -> completion) is there either way. */
 typedef struct pg_coalescer pg_coalescer;
 typedef struct {
     uint32_t k;               /* recall depth (RecallConfig.RecallCount), fixed per coalescer: 1..16384            */

@@ -189,6 +189,7 @@ __global__ void stall_kernel(uint64_t ticks) {
 
 struct pg_coalescer {
     pg_ctx* ctx = nullptr;
+    bool timers = false;             // PG_COALESCER_TIMERS=1: the batches record the contexts' stage timers (pg_stats' last_*_ms) — ~50 us per small batch
     pg_ctx* sibling = nullptr;       // a second context on the same device (own stream and scratch): the slots alternate
                                      // between the two, so the latency-bound head and tail of one batch (pilot, selects,
                                      // fusion, sort) run under the other batch's scan / rank kernels
@@ -419,6 +420,7 @@ int enqueue_recall_batch(pg_coalescer* c, Slot* s, bool first) {
     const uint32_t nq = s->n_req;
     int rc;
     std::lock_guard<std::mutex> g(ctx->mu);
+    TimersScope quiet(ctx, c->timers);             // (nobody reads the stage timers of a coalesced batch: no event records)
     TableRead2 tr(c->t, c->trigger_table);
     RecallJob& j = s->run->job;
     // a swap / upload between this batch's first pass and its re-plan: the job's statistics and plans are the old version's —
@@ -467,6 +469,7 @@ int enqueue_rank_batch(pg_coalescer* c, Slot* s) {
     PG_HIP(hipMemcpyAsync(s->d_cand, s->h_cand, (size_t)s->n_items * 4, hipMemcpyHostToDevice, st));
     PG_HIP(hipMemcpyAsync(s->d_off, s->h_off, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, st));
     std::lock_guard<std::mutex> g(ctx->mu);
+    TimersScope quiet(ctx, c->timers);             // (nobody reads the stage timers of a coalesced batch: no event records)
     TableRead tr(c->t->rw);
     if (al.m->kind != PG_MODEL_DNN3) PG_HIP(hipMemcpyAsync(s->d_ufid, s->h_ufid, (size_t)nq * al.m->nuf * 4, hipMemcpyHostToDevice, st));
     return rank_algo_locked(ctx, al, c->t, s->d_vec, s->d_ufid, s->d_cand, s->d_off, nq, s->n_items, s->d_rank, c->rank_stride);
@@ -482,6 +485,7 @@ int enqueue_dpp_batch(pg_coalescer* c, Slot* s) {
     if (key.has_table) PG_HIP(hipMemcpyAsync(s->d_dcand, s->h_dcand, items * 4, hipMemcpyHostToDevice, st));
     if (key.hook_dim) PG_HIP(hipMemcpyAsync(s->d_dhook, s->h_dhook, items * key.hook_dim * 8, hipMemcpyHostToDevice, st));
     std::lock_guard<std::mutex> g(ctx->mu);
+    TimersScope quiet(ctx, c->timers);             // (nobody reads the stage timers of a coalesced batch: no event records)
     TableRead tr(c->t->rw);
     int rc;
     if (key.ssd)
@@ -553,6 +557,7 @@ int slot_enqueue(pg_coalescer* c, Slot* s, bool first) {
     call.top_n = top;
     call.d_pick = s->d_pick;
     call.d_pick_cnt = s->d_pick_cnt;
+    call.timers = c->timers;
     if ((rc = recommend_enqueue(ctx, call, s->run, first))) return rc;
     return slot_copy_out(c, s);
 }
@@ -1111,6 +1116,7 @@ int pg_coalescer_create_scene(pg_ctx* ctx, const pg_table* t, const pg_scene_con
         pg::destroy_partial(c);
         return PG_ERR_DEVICE;
     }
+    { const char* tv = getenv("PG_COALESCER_TIMERS"); c->timers = tv && atoi(tv) != 0; }
     if (c->depth >= 2 && pg_init(ctx->device, nullptr, &c->sibling) != PG_OK) c->sibling = nullptr;   // (optional: one stream works too)
     if (c->sibling) {
         // the sibling serves every other batch: it must plan exactly as the caller's context does

@@ -248,6 +248,7 @@ struct pg_ctx {
     uint64_t last_scan_bytes = 0;
     // pinned host staging for small status words
     uint32_t* h_status = nullptr;
+    bool timers_off = false;            // (under mu) the call being enqueued records no stage-timer events: TimersScope
 };
 
 namespace pg {
@@ -363,6 +364,7 @@ struct RecallJob {
     bool observed = false;                  // ... and the enqueued plan did
     double z_lo = 0.0;
     bool susp_stat = false;                 // the enqueued plan reports its suspect counts with the status words
+    bool timers = true;                     // this enqueue recorded its stage-timer events (false: a coalescer batch — recall_job_check reads none)
     bool stat_wide = false;                 // ... and they are the int8 screen's own (no 4-bit stage in front)
     bool refined = false;                   // the enqueued pilot plan raised its thresholds after the first quarter
     int n_plans = 0, next_plan = 0, enqueued_plan = -1;
@@ -389,6 +391,15 @@ int recall_dev_locked(pg_ctx* ctx, const pg_table* t, const float* d_queries, ui
 // re-run the failed queries of `j` (at most kMaxPatchQueries) one by one, synchronously, writing into their slices of
 // the job's outputs and their valid counts into counts[q]; caller holds ctx->mu
 int recall_patch_failed_locked(RecallJob* j, uint32_t* counts);
+// Stage timers (HIP events around the recall plan, its scan launches and the rank stage: pg_stats' last_*_ms, pg_last_scan_kernel_ms)
+// cost ~6 us of idle queue per record — 40-60 us of a 1.3-1.8 ms small-batch step.  A caller that reads none of them (the coalescer:
+// its statistics are enqueue -> completion times) switches them off for the calls it enqueues; caller holds ctx->mu.
+struct TimersScope {
+    pg_ctx* ctx;
+    bool prev;
+    TimersScope(pg_ctx* c, bool timers) : ctx(c), prev(c->timers_off) { c->timers_off = !timers; }
+    ~TimersScope() { ctx->timers_off = prev; }
+};
 int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs);
 int launch_select(pg_ctx* ctx, uint32_t nq, const uint64_t* in, uint64_t* out, uint32_t* cnt, float* thr,
                   uint32_t cap, uint32_t k, int thr_only = 0, uint32_t* cnt_seen = nullptr);

@@ -278,6 +278,7 @@ int recommend_enqueue(pg_ctx* ctx, const RecommendCall& c, PipeRun* r, bool firs
         return PG_ERR_UNSUPPORTED;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
+    TimersScope quiet(ctx, c.timers);
     TableRead tr(c.t->rw);               // recall, rank and the DPP gather of one batch read one version of the table
     int rc;
     PostScratch ps;

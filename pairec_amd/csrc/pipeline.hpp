@@ -50,6 +50,7 @@ struct RerankStage {
 // variable i of `e` is score plane p (an algorithm's name in RankAlgoList, or "<algo>_<output>" of a multi-output one,
 // rank_service.go:315-319), -1: Item.Score (the recall score).
 struct RecommendCall {
+    bool timers = true;                // stage-timer events around the recall plan, its scan launches and the rank stage (TimersScope)
     const pg_table* t = nullptr;
     RankAlgoRef algos[kMaxAlgos];
     int n_algos = 0;

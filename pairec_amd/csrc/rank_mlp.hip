@@ -1150,7 +1150,7 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
     // split bf16: the two-role kernel (rank_x3.hip), 128-item tiles; 1024-512 and 64-wide tables take the general form
     const bool x3_k = m->prec == 2 && !no_ws && t->dim == 128 && dnn3_x3_shape(m->h1, m->h2);
     const uint32_t grid128 = n_items / kBM + n_req;
-    PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (!ctx->timers_off) PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     if ((rc = build_tiles_launch(ctx, d_off, n_req, max_tiles, ws || rs_k ? (uint32_t)kWsItems : (uint32_t)kBM, rs.tile_req, rs.tile_item0,
                                  rs.tile_cnt, rs.n_tiles, rs.req_tile0)))
         return rc;
@@ -1199,8 +1199,10 @@ int rank_dnn3_dev_locked(pg_ctx* ctx, const pg_model* m, const pg_table* t,
         return rc;
     }
     PG_HIP(hipGetLastError());
-    PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
-    ctx->rank_timing_pending = true;
+    if (!ctx->timers_off) {
+        PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->rank_timing_pending = true;
+    }
     ctx->stats.rank_calls++;
     ctx->stats.rank_items += n_items;
     return PG_OK;
@@ -1219,7 +1221,7 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
     RankScratch rs;
     int rc;
     if ((rc = rank_scratch(ctx, n_req, max_tiles, m->to, &rs))) return rc;
-    PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (!ctx->timers_off) PG_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     // the request side and the tile table: one launch where the register-resident user kernel serves the shape
     const TileTableArgs tt{d_off, n_req, rs.tile_req, rs.tile_item0, rs.tile_cnt, rs.n_tiles, rs.req_tile0, bm, (max_tiles + 255) / 256};
     bool tiles_built = false;
@@ -1262,8 +1264,10 @@ static int rank_fm2t_dev_locked(pg_ctx* ctx, const pg_model* m, const float* d_u
         return rc;
     }
     PG_HIP(hipGetLastError());
-    PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
-    ctx->rank_timing_pending = true;
+    if (!ctx->timers_off) {
+        PG_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->rank_timing_pending = true;
+    }
     ctx->stats.rank_calls++;
     ctx->stats.rank_items += n_items;
     return PG_OK;

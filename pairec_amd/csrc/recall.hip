@@ -2894,7 +2894,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             PG_HIP(hipEventCreate(&e));
             pool.push_back(e);
         }
-        PG_HIP(hipEventRecord(pool[2 * n_ev], ctx->stream));
+        if (j->timers) PG_HIP(hipEventRecord(pool[2 * n_ev], ctx->stream));
         const uint32_t nq = j->nq;
         if (j->screen && !thr_is_open && !exact_chunks) {
             ScreenArgs sa;
@@ -3040,7 +3040,7 @@ struct PlanRun {                     // the launches of one plan (helper of reca
             j->scan_bytes += (uint64_t)cb * kPieceRows * t->dim * 4;
             j->scanned_rows += (uint64_t)cb * kPieceRows;
         }
-        PG_HIP(hipEventRecord(pool[2 * n_ev + 1], ctx->stream));
+        if (j->timers) PG_HIP(hipEventRecord(pool[2 * n_ev + 1], ctx->stream));
         ++n_ev;
         return PG_OK;
     }
@@ -3157,7 +3157,8 @@ int recall_job_enqueue(RecallJob* j) {
     bool refined = false;
     // events 0/1 of the pool bracket the whole plan; PlanRun's launches use the pairs after them
     r.n_ev = 1;
-    PG_HIP(hipEventRecord((*j->events)[0], ctx->stream));
+    j->timers = !ctx->timers_off;
+    if (j->timers) PG_HIP(hipEventRecord((*j->events)[0], ctx->stream));
     if (plan == kPredict && !r.no_i8) {
         // no sample: the first thresholds are the model's (pred_query_kernel above), here in the int8 screen's units
         screen_thr8_kernel<<<1, kMaxQueries, 0, ctx->stream>>>(rs.thr, rs.eps, rs.qscale, t->s8, rs.thr_screen);
@@ -3227,7 +3228,7 @@ int recall_job_enqueue(RecallJob* j) {
         const double growth = kn.chunk_growth > 1.0 ? kn.chunk_growth : (j->screen && !r.exact_chunks ? 2.0 : 4.0);
         if ((rc = r.grow_scan(j->nblocks, 1, j->k, growth, plan == kSafe))) return rc;
     }
-    PG_HIP(hipEventRecord((*j->events)[1], ctx->stream));
+    if (j->timers) PG_HIP(hipEventRecord((*j->events)[1], ctx->stream));
     if ((rc = final_launch(ctx, rs.cand[r.cur], rs.cnt, rs.cap, j->nq, j->k, t->row_offset, j->d_out_rows,
                            j->d_out_scores, j->d_count)))
         return rc;
@@ -3286,9 +3287,9 @@ int recall_job_check(RecallJob* j, bool* ok_out) {
     pg_ctx* ctx = j->ctx;
     const int plan = j->enqueued_plan;
     float ms = 0.f;
-    PG_HIP(hipEventElapsedTime(&ms, (*j->events)[0], (*j->events)[1]));
+    if (j->timers) PG_HIP(hipEventElapsedTime(&ms, (*j->events)[0], (*j->events)[1]));
     j->total_ms += ms;
-    for (uint32_t i = 1; i < j->n_ev; ++i) {
+    for (uint32_t i = 1; j->timers && i < j->n_ev; ++i) {
         PG_HIP(hipEventElapsedTime(&ms, (*j->events)[2 * i], (*j->events)[2 * i + 1]));
         j->scan_ms += ms;
         if (ctx->knobs.debug_scan) fprintf(stderr, "[pg] plan %d scan launch %u: %.3f ms\n", plan, i - 1, ms);
@@ -3427,8 +3428,10 @@ void recall_job_finish(RecallJob* j) {
     pg_ctx* ctx = j->ctx;
     ctx->stats.recall_calls++;
     ctx->stats.recall_rows_scanned += j->scanned_rows;
-    ctx->stats.last_recall_ms = j->total_ms;
-    ctx->last_scan_ms = j->scan_ms;
+    if (j->timers) {                                   // (a batch without stage timers leaves the last direct call's figures)
+        ctx->stats.last_recall_ms = j->total_ms;
+        ctx->last_scan_ms = j->scan_ms;
+    }
     ctx->last_scan_launches = j->scan_launches;
     ctx->last_scan_bytes = j->scan_bytes;              // bytes the scan launches streamed (fp32 rows, int8 / bf16 / 4-bit shadow)
 }

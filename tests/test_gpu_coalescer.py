@@ -365,3 +365,32 @@ def test_coalesced_mid_batches_ride_the_4bit_paths_and_equal_solo_calls(ctx, wor
     finally:
         for name, v in (("i4_min_rows", str(1 << 22)), ("i4m_max_pairs", "2.4e7"), ("i4m_max_lambda", "2.2")):
             ctx.set_option(name, v)
+
+
+def test_coalesced_batches_record_no_stage_timers_unless_asked(ctx, world):
+    """A coalesced batch records none of its context's stage-timer events (each costs ~6 us of idle queue): pg_stats' last_recall_ms /
+    last_rank_ms keep what the last DIRECT call left, the pages are the same; PG_COALESCER_TIMERS=1 at creation records them again."""
+    import os
+    t, m, ex = world
+    k, top_n = 300, 20
+    q = o.synth_rows(o.SEED_QUERY, 900, 4, 128)
+    rows, rec, rnk, fus, order, cnt = pa.recommend_dnn3(ctx, t, m, ex, "gpu_dnn", q[0:1], k)
+    ref = rows[0][order[0][:top_n]]
+    s0 = ctx.stats()
+    assert s0.last_recall_ms > 0 and s0.last_rank_ms > 0
+    for env, timers in ((None, False), ("1", True)):
+        if env is None:
+            os.environ.pop("PG_COALESCER_TIMERS", None)
+        else:
+            os.environ["PG_COALESCER_TIMERS"] = env
+        try:
+            co = pa.Coalescer(ctx, t, k, m, ex, "gpu_dnn", max_top_n=top_n, max_wait_us=200, depth=1)
+        finally:
+            os.environ.pop("PG_COALESCER_TIMERS", None)
+        for i in range(3):
+            g = co.recommend(q[0], top_n)
+            assert np.array_equal(g[0], ref)
+        co.destroy()
+        s1 = ctx.stats()
+        unchanged = s1.last_recall_ms == s0.last_recall_ms and s1.last_rank_ms == s0.last_rank_ms
+        assert unchanged == (not timers), (timers, s0.last_recall_ms, s1.last_recall_ms, s0.last_rank_ms, s1.last_rank_ms)
