@@ -83,7 +83,9 @@ int pg_synchronize(pg_ctx* ctx);
  * for crowded tables "max_rec_scale", "no_r2", "r2_min_factor", "predict_max_factor"; for the coalescer "coalescer_rejoin",
  * "coalescer_rejoin_us_per_caller"; and which sort a call with few lists takes (csrc/split_sort.hpp): "rank_sort_max" (default 32
  * lists) with "rank_sort_work" (lists x items^2 <= 7e7: counting ranks), "split_sort_max" (default 96 lists of 1025 … 8192 items:
- * runs sorted wave by wave over the chip; 0 = never).  value is parsed as a number. */
+ * runs sorted wave by wave over the chip; 0 = never); "stage_timers" (default 1; 0: this context's direct calls record no HIP events
+ * around the recall plan, its scan launches and the rank stage — pg_stats' last_*_ms and pg_last_scan_kernel_ms stop moving, a
+ * small batch's step gets 40-60 us shorter; a coalescer's batches never record them, see there).  value is parsed as a number. */
 int pg_set_option(pg_ctx* ctx, const char* name, const char* value);
 int pg_device_malloc(pg_ctx* ctx, size_t bytes, void** out);
 int pg_device_free(pg_ctx* ctx, void* p);

@@ -180,6 +180,7 @@ int pg_set_option(pg_ctx* ctx, const char* name, const char* value) {
     else if (n == "split_sort_max") k.split_sort_max = (uint32_t)v;
     else if (n == "rank_sort_work") k.rank_sort_work = v;
     else if (n == "sort_lds") k.sort_lds = b;
+    else if (n == "stage_timers") ctx->timers_off = !b;      // (not a Knobs member: a coalescer's sibling context copies the knobs, its batches decide for themselves)
     else if (n == "fm2t_irs") k.fm2t_irs = b;
     else if (n == "dpp_valu") k.dpp_valu = b;
     else if (n == "no_r2") k.no_r2 = b;

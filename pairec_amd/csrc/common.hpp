@@ -397,7 +397,7 @@ int recall_patch_failed_locked(RecallJob* j, uint32_t* counts);
 struct TimersScope {
     pg_ctx* ctx;
     bool prev;
-    TimersScope(pg_ctx* c, bool timers) : ctx(c), prev(c->timers_off) { c->timers_off = !timers; }
+    TimersScope(pg_ctx* c, bool timers) : ctx(c), prev(c->timers_off) { c->timers_off = prev || !timers; }      // (only ever off: pg_set_option "stage_timers" 0 stays in force)
     ~TimersScope() { ctx->timers_off = prev; }
 };
 int recall_scratch(pg_ctx* ctx, uint32_t dim, uint32_t k, RecallScratch* rs);

@@ -1366,6 +1366,7 @@ int fm2t_user_embedding_locked(pg_ctx* ctx, const pg_model* m, const float* d_us
 
 static int finish_rank_timing(pg_ctx* ctx) {
     PG_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ctx->rank_timing_pending) return PG_OK;       // (stage timers off: nothing was recorded, last_rank_ms stays)
     float ms = 0.f;
     PG_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
     ctx->stats.last_rank_ms = ms;

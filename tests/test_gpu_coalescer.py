@@ -394,3 +394,17 @@ def test_coalesced_batches_record_no_stage_timers_unless_asked(ctx, world):
         s1 = ctx.stats()
         unchanged = s1.last_recall_ms == s0.last_recall_ms and s1.last_rank_ms == s0.last_rank_ms
         assert unchanged == (not timers), (timers, s0.last_recall_ms, s1.last_recall_ms, s0.last_rank_ms, s1.last_rank_ms)
+        s0 = s1
+    # direct calls go without them on request (pg_set_option "stage_timers"): same results, the figures stop moving
+    ctx.set_option("stage_timers", 0)
+    try:
+        rows2, rec2, rnk2, fus2, order2, cnt2 = pa.recommend_dnn3(ctx, t, m, ex, "gpu_dnn", q[0:1], k)
+        r_rows, r_sc, _ = t.recall_topk(q[1:3], k)
+        s2 = ctx.stats()
+        assert np.array_equal(rows2, rows) and np.array_equal(order2, order) and np.array_equal(bits(fus2), bits(fus))
+        assert s2.last_recall_ms == s0.last_recall_ms and s2.last_rank_ms == s0.last_rank_ms
+    finally:
+        ctx.set_option("stage_timers", 1)
+    pa.recommend_dnn3(ctx, t, m, ex, "gpu_dnn", q[0:1], k)
+    s3 = ctx.stats()
+    assert s3.last_recall_ms > 0 and (s3.last_recall_ms != s0.last_recall_ms or s3.last_rank_ms != s0.last_rank_ms)
